@@ -1,0 +1,134 @@
+"""Pins the CPU oracle (oracle/ic_oracle.py) to the reference: known-answer values from the reference's own
+tests, and golden vectors recorded by running the reference (tests/golden/make_golden.py). CPU only."""
+import numpy as np
+import pytest
+
+from oracle import ic_oracle as O
+
+
+# ---- known answers held by the reference's tests/test_distributions.py -------------------------------------
+def test_kat_normal():  # :1190, :1223
+    assert np.allclose(O.normal_log_prob(0.0, 0.0, 1.0), -0.918939, atol=1e-5)
+    assert np.allclose(O.normal_log_prob(np.array([0., 2.]), np.array([0., 2.]), np.array([1., 3.])),
+                       [-0.918939, -2.01755], atol=1e-5)
+
+
+def test_kat_truncated_normal():  # :1326, :1363, :1439
+    assert np.allclose(O.truncated_normal_log_prob(2.0, 2.0, 3.0, -4.0, 4.0), -1.69563, atol=1e-4)
+    lp = O.truncated_normal_log_prob(np.array([0., 2.]), np.array([0., 2.]), np.array([1., 3.]),
+                                     np.array([-1., -4.]), np.array([1., 4.]))
+    assert np.allclose(lp, [-0.537223, -1.69563], atol=1e-4)
+    # clamp_mean_between_low_high=True case: means [0,2] clamp to [0.5,1]
+    lp = O.truncated_normal_log_prob(np.array([0.75, -3.]), np.array([0.5, 1.]), np.array([1., 3.]),
+                                     np.array([0.5, -4.]), np.array([1., 1.]))
+    assert np.allclose(lp, [0.702875, -2.11283], atol=1e-4)
+    assert np.isneginf(O.truncated_normal_log_prob(5.0, 2.0, 3.0, -4.0, 4.0))
+
+
+def test_kat_categorical():  # :1474, :1503
+    assert np.allclose(O.categorical_log_prob(0, np.array([0.1, 0.2, 0.7])), -2.30259, atol=1e-5)
+    lp = O.categorical_log_prob([0, 1], np.array([[0.1, 0.2, 0.7], [0.2, 0.5, 0.3]]))
+    assert np.allclose(lp, [-2.30259, -0.693147], atol=1e-5)
+
+
+def test_kat_mixture():  # :2101, :2137
+    v = np.array([0.7, 8.1])
+    mu = np.array([[0., 2., 3.], [1., 5., 10.]])
+    sd = np.array([[.1, .1, .1], [1., 1., 1.]])
+    pr = np.array([[0.7, 0.2, 0.1], [0.1, 0.2, 0.7]])
+    lp = O.mixture_log_prob(O.normal_log_prob(v[:, None], mu, sd), pr)
+    assert np.allclose(lp, [-23.473, -3.06649], atol=1e-3)
+
+
+def test_kat_uniform():  # :1565
+    assert O.uniform_log_prob(0.5, 0.0, 1.0) == 0.0
+
+
+# ---- architecture pins ------------------------------------------------------------
+def test_param_counts(golden):
+    case, meta, params, batch, loss, isr = golden
+    assert sum(v.size for v in params.values()) == meta['num_params']
+    if case == 'gum':
+        assert meta['num_params'] == 85215   # H=64 GUM (1 address), measured in the survey
+
+
+# ---- golden vectors recorded from the reference -------------------------------------------------
+def _run(golden, dtype=np.float64, want_grads=True):
+    case, meta, params, batch, loss, isr = golden
+    net = O.Net(params, meta['obs_names'], K=meta['mixture_components'], dtype=dtype)
+    out = O.loss_and_grads(net, batch, meta['addresses'], meta['dist_names'], want_grads=want_grads)
+    return out
+
+
+def test_sub_batching_matches_reference(golden):
+    case, meta, params, batch, loss, isr = golden
+    subs, _ = O.split_sub_batches(batch['trace_len'], batch['addr_idx'])
+    assert [list(map(int, s)) for s in subs] == meta['sub_batches']
+
+
+def test_loss_forward_matches_reference(golden):
+    case, meta, params, batch, loss, isr = golden
+    out = _run(golden, want_grads=False)
+    assert abs(out['loss'] - float(loss['loss'])) <= 2e-6 * abs(float(loss['loss']))
+    for i in range(len(out['lstm_in'])):
+        np.testing.assert_allclose(out['lstm_in'][i], loss['lstm_in_%d' % i], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out['lstm_out'][i], loss['lstm_out_%d' % i], rtol=1e-5, atol=2e-6)
+    for k, (si, t) in enumerate(meta['lp_index']):
+        np.testing.assert_allclose(out['lp'][k], loss['lp_%d_%d' % (si, t)], rtol=2e-5, atol=2e-5)
+
+
+def test_loss_forward_fp32_mode(golden):
+    case, meta, params, batch, loss, isr = golden
+    out = _run(golden, dtype=np.float32, want_grads=False)
+    assert abs(out['loss'] - float(loss['loss'])) <= 2e-5 * abs(float(loss['loss']))
+
+
+def test_gradients_match_reference(golden):
+    case, meta, params, batch, loss, isr = golden
+    out = _run(golden)
+    worst = 0.0
+    for i, n in enumerate(meta['param_names']):
+        ref = loss['g%d' % i]
+        got = out['grads'][n]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(got - ref).max() / scale
+        worst = max(worst, err)
+        assert err < 5e-4, (n, err)
+        if not meta['has_grad'][i]:
+            assert np.all(got == 0), n
+    assert worst < 5e-4
+
+
+def test_is_log_weights_match_reference(golden):
+    case, meta, params, batch, loss, isr = golden
+    net = O.Net(params, meta['obs_names'], K=meta['mixture_components'])
+    # IS addresses index into meta['is_addresses']; dist type from the training-batch table
+    addr_to_dist = dict(zip(meta['addresses'], meta['dist_names']))
+    addresses = meta['is_addresses']
+    dist_names = [addr_to_dist[a] for a in addresses]
+    p_lp, q_lp, qparams, lw = O.is_rescore(net, isr['observe'], isr['trace_len'], isr['addr'], isr['value'],
+                                           isr['prior'], addresses, dist_names)
+    np.testing.assert_allclose(p_lp, isr['prior_lp'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(q_lp, isr['prop_lp'], rtol=1e-4, atol=1e-4)
+    # trace log weight = sum_t (log p - log q) + sum_obs log lik  (trace.py:123-125)
+    np.testing.assert_allclose(lw + isr['obs_lw'], isr['lw'], rtol=1e-4, atol=1e-4)
+    # proposal parameters of the first particle
+    r0 = qparams[0]
+    if len(r0) == 3:
+        got = np.concatenate([r0[0][0], r0[1][0], r0[2][0]])
+        np.testing.assert_allclose(got, isr['prop_params'][0], rtol=2e-4, atol=1e-5)
+
+
+def test_ess_formula():
+    lw = np.array([0.0, 0.0, 0.0, 0.0])
+    assert abs(O.effective_sample_size(lw) - 4.0) < 1e-12
+    assert abs(O.effective_sample_size(np.array([0.0, -1e9])) - 1.0) < 1e-12
+
+
+def test_neg_inf_rescue():
+    """-inf log_prob rows are replaced by log(1e-8) (inference_network_lstm.py:207-213) and carry no gradient."""
+    y = np.zeros((2, 30))
+    prior = np.array([[-1., 1.], [-1., 1.]])
+    lp, dy, _ = O.head_truncated_normal_mixture(y, prior, np.array([0.3, 1.5]), 10)
+    assert np.isfinite(lp[0]) and np.isneginf(lp[1])
+    assert np.all(np.isfinite(dy[0])) and np.all(dy[1, :20] == 0)
