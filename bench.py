@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            # IC training traces/s (BASELINE.json configs[1])
+  python bench.py --workload is ...                        # IS posterior particles/s (configs[3])
+
+A "step" of the default workload is one pass of the hot path over one minibatch of 1024 synthetic
+GaussianUnknownMean traces already resident in HBM: zero_grad -> InferenceNetworkLSTM._loss -> backward ->
+[flat-gradient all-reduce over RCCL when N > 1] -> Adam (pyprob/nn/inference_network.py:486-496) with LSTM
+hidden 512, 1 643 583 parameters, fp32. For N > 1 the driver launches one process per GPU
+(torch.distributed.run); per-GPU work is fixed (weak scaling), value = whole-job traces/s.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fp32 MFMA GEMM, forward X*W_ih^T launch) timed live with HIP events on the
+                 stream it runs on, priced against the fp32-matrix peak (157.3 TFLOP/s)
+  cpu_baseline : the numpy oracle port of the same step (forward + backward + Adam) timed on this host's cores on a
+                 bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def make_engine(lstm_dim, device, seed):
+    from pyprob_amd.engine import ICEngine
+    from pyprob_amd.spec import NetSpec
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=lstm_dim, proposal_mixture_components=10)
+    spec.add_address('16__forward__mu__Normal__1', 'Normal')
+    return ICEngine(spec, device=device, seed=seed)
+
+
+def synth_gum_dataset(n, device, seed):
+    """Packed offline dataset of GaussianUnknownMean prior traces in HBM (columnar, pre-shuffled):
+    mu ~ N(1, sqrt 5); y0, y1 ~ N(mu, sqrt 2)   (reference tests/test_inference.py:97-109)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    mu = 1.0 + (5.0 ** 0.5) * torch.randn(n, generator=g, device=device)
+    obs = mu[:, None] + (2.0 ** 0.5) * torch.randn(n, 2, generator=g, device=device)
+    prior = torch.tensor([1.0, 5.0 ** 0.5], device=device).repeat(n, 1).contiguous()
+    return obs.contiguous(), mu.contiguous(), prior
+
+
+def cpu_baseline_train(lstm_dim, batch, budget_s=12.0):
+    """Oracle port of one training step (numpy fp32: _loss forward, manual backward, Adam), timed on host cores."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from helpers import synthetic_gum_arrays
+    from oracle import ic_oracle as O
+    from pyprob_amd.spec import NetSpec
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=lstm_dim)
+    spec.add_address('mu', 'Normal')
+    rng = np.random.default_rng(0)
+    P = {n: spec.init_tensor(n, rng) for n in spec.tensors}
+    M = {n: np.zeros_like(v) for n, v in P.items()}
+    V = {n: np.zeros_like(v) for n, v in P.items()}
+    steps, t0 = 0, time.time()
+    while True:
+        arrays = synthetic_gum_arrays(batch, seed=steps)
+        net = O.Net(P, ['obs0', 'obs1'], K=10, dtype=np.float32)
+        out = O.loss_and_grads(net, arrays, ['mu'], ['Normal'])
+        for n in P:
+            O.adam_step(P[n], out['grads'][n].astype(np.float32), M[n], V[n], steps + 1, 1e-3)
+        steps += 1
+        if steps >= 3 and time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return dict(value=steps * batch / dt, unit='traces/s', cores=os.cpu_count(), kind='port',
+                sample='%d steps of %d GUM traces, H=%d: oracle/ic_oracle.py loss_and_grads + adam_step (numpy fp32, '
+                       'BLAS threads = all cores)' % (steps, batch, lstm_dim))
+
+
+def cpu_baseline_is(n=20000):
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from oracle import ic_oracle as O
+    from pyprob_amd.spec import NetSpec
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
+    spec.add_address('mu', 'Normal')
+    rng = np.random.default_rng(0)
+    P = {k: spec.init_tensor(k, rng) for k in spec.tensors}
+    net = O.Net(P, ['obs0', 'obs1'], K=10, dtype=np.float32)
+    vals = rng.normal(7, 1, n).astype(np.float32)
+    prior = np.tile(np.array([[1.0, 5 ** 0.5]], np.float32), (n, 1))
+    t0 = time.time()
+    m = 0
+    while time.time() - t0 < 10.0:
+        k = min(500, n - m)
+        if k <= 0:
+            break
+        O.is_rescore(net, [8.0, 9.0], np.ones(k, np.int32), np.zeros(k, np.int32), vals[m:m + k], prior[m:m + k], ['mu'],
+                     ['Normal'])
+        m += k
+    dt = time.time() - t0
+    return dict(value=m / dt, unit='particles/s', cores=1, kind='port',
+                sample='%d particles re-scored one at a time (oracle is_rescore, per-particle batch-1 network like the '
+                       'reference)' % m)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='train', choices=['train', 'is'])
+    ap.add_argument('--lstm-dim', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=1024)
+    ap.add_argument('--dataset', type=int, default=1000000, help='offline traces resident in HBM (per job)')
+    ap.add_argument('--particles', type=int, default=1000000, help='IS particles per job')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', device_id=device)
+
+    from pyprob_amd import lib as L
+    from pyprob_amd.packed import PackedBatch
+    lib = L.load()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng = make_engine(args.lstm_dim, device, seed=123)
+    eng.world_size = world
+    if world > 1:
+        eng.broadcast_params()
+    out = {}
+    K, W = args.steps, args.warmup
+
+    if args.workload == 'train':
+        B = args.batch
+        per_rank = max(args.dataset // world, B * 8)
+        obs, mu, prior = synth_gum_dataset(per_rank, device, seed=1000 + rank)
+        nb = per_rank // B
+        cache = {}
+        batches = [PackedBatch.from_device_columns(obs[i * B:(i + 1) * B], mu[i * B:(i + 1) * B],
+                                                   prior[i * B:(i + 1) * B], 0, 1, cache) for i in range(min(nb, K + W))]
+        lr = 1e-3 * (world ** 0.5)          # inference_network.py:448
+        for i in range(W):
+            eng.train_step(batches[i % len(batches)], lr)
+        lib.pp_prof_arm(0, K)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            eng.train_step(batches[(W + i) % len(batches)], lr)
+        barrier()
+        dt = time.perf_counter() - t0
+        ms = np.zeros(K, np.float32)
+        fl = np.zeros(K, np.float64)
+        cnt = C.c_int32(0)
+        lib.pp_prof_collect(ms.ctypes.data, K, C.byref(cnt), fl.ctypes.data)
+        lib.pp_prof_arm(0, 0)
+        final_loss = float(eng.loss_buf[0].item())
+        units = B * K
+        metric, unit = 'ic_train_traces_per_sec', 'traces/s'
+        if cnt.value > 0:
+            avg_ms = float(ms[:cnt.value].mean())
+            ach = float(fl[0]) / (avg_ms * 1e-3) / 1e12
+            out['roofline'] = dict(bound='mfma', achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+                                   frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
+                                   kernel='gemm_f32_kernel<64,64,32,32,NT,vec4> (forward X*W_ih^T, %dx%dx%d)'
+                                          % (B, 4 * args.lstm_dim, eng.spec.lstm_in),
+                                   avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=int(cnt.value),
+                                   flops_per_launch=float(fl[0]))
+        config = dict(workload='GaussianUnknownMean IC training, offline traces resident in HBM, LSTM hidden=%d, '
+                               'batch=%d per GPU' % (args.lstm_dim, B),
+                      traces_in_hbm=per_rank * world, params=eng.spec.num_parameters(), global_batch=B * world,
+                      parallelism='dp%d' % world, optimizer='Adam lr=1e-3*sqrt(world)', final_loss=round(final_loss, 4))
+    else:
+        from pyprob_amd.is_engine import ISRunner, gum_posterior
+        n = args.particles // world
+        run = ISRunner(eng)
+        for i in range(W):
+            gum_posterior(eng, n, seed=rank, offset=rank * n, runner=run)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            st = gum_posterior(eng, n, seed=7 + i, offset=rank * n, runner=run)
+        barrier()
+        dt = time.perf_counter() - t0
+        units = n * K
+        metric, unit = 'is_posterior_particles_per_sec', 'particles/s'
+        # HBM roofline of the sampling/scoring chain: algorithmic bytes per particle = value 4 + log q 4 written,
+        # then 4 log-weight passes reading 4-8 B and read-modify-writing lw (8 B): 8 + 4*12 + stats 8 = 64 B
+        bytes_per_particle = 64.0
+        ach = units * bytes_per_particle / dt / 1e9
+        out['roofline'] = dict(bound='hbm', achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+                               frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                               kernel='is_mixture_kernel + logweight_kernel x3 + axpy + is_stats (whole posterior call, '
+                                      'wall-clock; per-kernel event timing not armed for this workload)')
+        config = dict(workload='GaussianUnknownMean posterior_results IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, '
+                               'LSTM hidden=%d, %d particles per posterior call per GPU' % (args.lstm_dim, n),
+                      particles_per_call=n * world, parallelism='particles sharded x%d' % world,
+                      ess=round(st['ess'], 1), posterior_mean=round(st['mean'], 4))
+
+    # max over ranks
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = units * world / dt
+    if rank == 0:
+        line = dict(metric=metric, value=round(value, 1), unit=unit, n_gpus=world, steps=K, warmup=W,
+                    ms_per_step=round(dt / K * 1e3, 4), higher_is_better=True, scaling='weak', vs_baseline=None,
+                    dtype='f32', data='synthetic', config=config)
+        line.update(out)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline_train(args.lstm_dim, args.batch) if args.workload == 'train' \
+                else cpu_baseline_is()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

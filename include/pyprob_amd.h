@@ -1,0 +1,272 @@
+/*
+ * pyprob_amd.h -- C ABI of libpyprob_amd.so: the MI355X (gfx950) inference-compilation engine for pyprob.
+ *
+ * This is the drop-in boundary (SURVEY.md §8b seam B3). pyprob itself is 100% Python and has no FFI for this
+ * path, so every entry point below cites the reference *Python* code it replaces (paths relative to the pyprob
+ * v1.5.0 tree). The reference-side binding a maintainer would add is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs; no torch/HIP types. `stream` is a hipStream_t passed as void*.
+ *   - every pointer marked "dev" is device (HBM) memory owned by the caller (the host uses the PyTorch-ROCm
+ *     caching allocator as plumbing); the library never allocates or frees device memory and never
+ *     synchronises the stream unless the function says so.
+ *   - all arithmetic is fp32 (reference: util._dtype = torch.float, pyprob/util.py:29). GEMMs use the exact
+ *     fp32 MFMA (v_mfma_f32_32x32x2_f32), everything else fp32 VALU.
+ *   - return value: 0 on success, a hipError_t (>0) from a failed launch, or a PP_E* code (<0). No C++
+ *     exceptions cross this ABI. pp_last_error() returns a static, thread-local description.
+ *   - threading: call from one host thread per stream (pyprob's trace runtime is single-threaded,
+ *     pyprob/state.py:13-27).
+ *
+ * Packed trace batch ("step-major ragged"): the B traces of a minibatch are sorted by controlled length,
+ * longest first; row r = row_off[t] + b holds time step t of trace b (b < n_active[t]). Sub-batches of the
+ * reference (pyprob/nn/dataset.py:21-37: traces with an identical address sequence) are runs of traces in this
+ * order; because nn.LSTM weights are shared and h0=c0=0 for every trace, running all sub-batches through one
+ * step-major pass is arithmetically the per-sub-batch loop of InferenceNetworkLSTM._loss
+ * (pyprob/nn/inference_network_lstm.py:138-219).
+ */
+#ifndef PYPROB_AMD_H
+#define PYPROB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_ABI_VERSION 1
+#define PP_MAX_OBS 8
+
+/* error codes (negative; positive values are hipError_t) */
+#define PP_EINVAL   (-1)   /* bad argument (shape, alignment, null pointer) */
+#define PP_ENOSPACE (-2)   /* workspace too small */
+#define PP_ENODEV   (-3)   /* no gfx950 device / kernels not loadable */
+
+/* proposal head kinds (pyprob/nn/inference_network_lstm.py:52-66) */
+#define PP_HEAD_NORMAL_MIXTURE       0  /* ProposalNormalNormalMixture: prior Normal(mean, stddev) */
+#define PP_HEAD_TRUNCNORMAL_MIXTURE  1  /* ProposalUniformTruncatedNormalMixture: prior Uniform(low, high) */
+#define PP_HEAD_CATEGORICAL          2  /* ProposalCategoricalCategorical: prior Categorical(C) */
+
+int         pp_abi_version(void);
+const char* pp_last_error(void);
+/* number of visible HIP devices whose arch is gfx950; 0 if none (never throws) */
+int         pp_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Network description. Offsets are in floats into one flat fp32 parameter buffer (and the identically laid
+ * out gradient / Adam-moment buffers). Tensor shapes are the reference's.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct pp_addr {
+    int32_t kind;        /* PP_HEAD_* */
+    int32_t n_out;       /* head output width: 3K (mixtures) or C (categorical) */
+    int32_t hid;         /* head hidden width int((H+n_out)/2), embedding_feedforward.py:26 */
+    int32_t smp_in;      /* sample-embedding input width: 1, or C (one-hot) for categorical */
+    int32_t dtype_id;    /* index of the distribution-type embedding this address uses */
+    int32_t _pad;
+    int64_t addr_emb;    /* [addr_dim]            _layers_address_embedding.<addr> */
+    int64_t dtype_emb;   /* [dtype_dim]           _layers_distribution_type_embedding.<DistName> */
+    int64_t smp_w;       /* [smp_dim, smp_in]     _layers_sample_embedding.<addr>._layers.0.weight */
+    int64_t smp_b;       /* [smp_dim] */
+    int64_t w1, b1;      /* [hid, H], [hid]       _layers_proposal.<addr>._ff._layers.0 */
+    int64_t w2, b2;      /* [n_out, hid], [n_out] _layers_proposal.<addr>._ff._layers.1 */
+} pp_addr;
+
+typedef struct pp_net {
+    int32_t n_obs;                    /* observables with a FEEDFORWARD depth-2 embedding (inference_network.py:110-118) */
+    int32_t obs_in[PP_MAX_OBS];       /* flattened input width of observable o */
+    int32_t obs_hid[PP_MAX_OBS];      /* int((in+out)/2) */
+    int32_t obs_out[PP_MAX_OBS];      /* embedding dim of observable o */
+    int64_t obs_w0[PP_MAX_OBS], obs_b0[PP_MAX_OBS], obs_w1[PP_MAX_OBS], obs_b1[PP_MAX_OBS];
+    int32_t e_obs;                    /* sum of obs_out */
+    int32_t smp_dim, addr_dim, dtype_dim;
+    int64_t fin_w0, fin_b0, fin_w1, fin_b1;   /* _layers_observe_embedding_final (e_obs -> e_obs -> e_obs) */
+    int32_t lstm_in;                  /* I = e_obs + smp_dim + 2*(addr_dim+dtype_dim), inference_network_lstm.py:30 */
+    int32_t lstm_dim;                 /* H */
+    int64_t w_ih, w_hh, b_ih, b_hh;   /* _layers_lstm.{weight_ih,weight_hh,bias_ih,bias_hh}_l0 */
+    int32_t n_addr;
+    int32_t n_dtype;
+    const pp_addr* addrs;             /* host array [n_addr] */
+    const int64_t* addr_table;        /* dev  [n_addr, PP_ADDR_TABLE_COLS] same records for per-row dispatch */
+    int64_t n_params;                 /* floats in the flat buffer (incl. padding) */
+} pp_net;
+
+/* columns of the device address table */
+#define PP_ADDR_TABLE_COLS 8
+#define PP_AT_KIND 0
+#define PP_AT_SMP_IN 1
+#define PP_AT_ADDR_EMB 2
+#define PP_AT_DTYPE_EMB 3
+#define PP_AT_SMP_W 4
+#define PP_AT_SMP_B 5
+#define PP_AT_N_OUT 6
+#define PP_AT_RESERVED 7
+
+typedef struct pp_batch {
+    int32_t n_traces;            /* B  (Batch.size, pyprob/nn/dataset.py:24) */
+    int32_t n_rows;              /* R = sum of controlled trace lengths */
+    int32_t t_max;               /* longest controlled trace */
+    int32_t obs_width;           /* sum of obs_in */
+    const int32_t* n_active;     /* host [t_max]   traces with length > t */
+    const int32_t* row_off;      /* host [t_max+1] prefix sum of n_active */
+    const int32_t* grp_off;      /* host [n_addr+1] rows grouped by address: group a = grp_rows[grp_off[a]:grp_off[a+1]] */
+    const float*   obs;          /* dev [B, obs_width] observed values, trace order = packed order */
+    const float*   value;        /* dev [R] sampled value of every controlled variable (category index as float) */
+    const float*   prior;        /* dev [R, 2] (mean, stddev) | (low, high) | unused */
+    const int32_t* addr;         /* dev [R] address id of the row */
+    const int32_t* prev_row;     /* dev [R] row of the previous time step of the same trace, -1 at t = 0 */
+    const int32_t* grp_rows;     /* dev [R] row ids sorted by address id */
+    const int32_t* trace;        /* dev [R] trace index b of the row */
+    const int32_t* row_off_dev;  /* dev [t_max+1] copy of row_off */
+    const int32_t* nxt_off;      /* host [n_addr+1] rows grouped by the address of their PREVIOUS variable */
+    const int32_t* nxt_rows;     /* dev [R - B] row ids (t >= 1) sorted by previous address id */
+} pp_batch;
+
+/* ------------------------------------------------------------------------------------------------------
+ * Whole-path entry points
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch HBM pp_ic_loss needs for a batch of at most n_traces traces / n_rows rows. */
+size_t pp_ic_workspace_bytes(const pp_net* net, int32_t n_traces, int32_t n_rows);
+
+#define PP_LOSS_BACKWARD   1   /* also write dLoss/dparams into `grads` */
+#define PP_LOSS_ZERO_GRADS 2   /* zero `grads` (n_params floats) first: optimizer.zero_grad(), inference_network.py:486 */
+#define PP_LOSS_KEEP_LP    4   /* write the per-row proposal log_prob (row order) to lp_out */
+
+/*
+ * InferenceNetworkLSTM._loss(batch) (+ loss.backward()):  pyprob/nn/inference_network_lstm.py:136-220,
+ * pyprob/nn/inference_network.py:487,493. Computes
+ *     loss = -(1/B) * sum_rows log q(value | lstm state)          (written to loss_out[0], dev)
+ * with -inf log-probs replaced by log(1e-8) (:207-213); status_out[0] (dev int32) is set non-zero if the loss
+ * is still non-finite (the reference then skips the batch, :216-217). With PP_LOSS_BACKWARD, `grads` receives
+ * the gradient of every parameter in the layout of `params` (tensors that do not participate stay zero).
+ */
+int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params /*dev*/, float* grads /*dev or NULL*/,
+               void* workspace /*dev*/, size_t workspace_bytes, float* loss_out /*dev [1]*/,
+               int32_t* status_out /*dev [1]*/, float* lp_out /*dev [R] or NULL*/, int32_t flags, void* stream);
+
+/*
+ * torch.optim.Adam.step() over the flat buffer (pyprob/nn/inference_network.py:348,496), per-tensor skipping
+ * of parameters whose grad is None (tensors that did not take part in the loss) and per-tensor step counts.
+ *   chunk_tensor  dev [n_params/1024]  tensor id owning each 1024-float chunk (tensors are padded to 1024)
+ *   active        dev [n_tensors]      float >0 -> tensor has a gradient this step (DP: all-reduced presence map,
+ *                                      pyprob/nn/inference_network.py:300-315)
+ *   tensor_step   dev [n_tensors]      int32 Adam step count per tensor, incremented here when active
+ *   grad_scale    1/world_size for data-parallel averaging (:324-325), else 1
+ */
+int pp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
+                 const int32_t* chunk_tensor, const float* active, int32_t* tensor_step,
+                 float* corr /*dev [2*n_tensors] scratch*/, int32_t n_tensors,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Importance sampling with the inference network, lock-step over N particles
+ * (pyprob/state.py:203-219, pyprob/nn/inference_network_lstm.py:82-134, pyprob/trace.py:123-125)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch for pp_is_step with n particles. */
+size_t pp_is_workspace_bytes(const pp_net* net, int32_t n);
+
+/*
+ * InferenceNetwork._infer_init(observe): observe embedding of the single observation, batch 1
+ * (pyprob/nn/inference_network.py:141-148). obs: dev [obs_width]; e_out: dev [e_obs].
+ */
+int pp_is_init(const pp_net* net, const float* params, const float* obs, float* e_out, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/*
+ * One controlled `pyprob.sample` statement for n particles at once: _infer_step (LSTM step with carried
+ * (h, c)) -> proposal head -> value ~ q -> log q(value).
+ *   addr_id / prev_addr_id   address of this / the previous controlled variable (-1: first variable of the trace)
+ *   e_obs_vec  dev [e_obs]   output of pp_is_init (shared by all particles)
+ *   prev_value dev [n]       values sampled at the previous statement (ignored when prev_addr_id < 0)
+ *   prior      dev [n,2] or [2] (prior_stride 0 = same prior parameters for every particle)
+ *   h, c       dev [n, H]    LSTM state, updated in place (zeroed internally when prev_addr_id < 0)
+ *   value_in   dev [n] or NULL: if given, score these values instead of sampling (re-scoring / parity tests)
+ *   value_out  dev [n]       sampled (or copied) values
+ *   logq_out   dev [n]       proposal log_prob of value (Mixture.log_prob / Categorical.log_prob)
+ *   seed, offset             Philox4x32-10 counter-based RNG: particle i uses counter (offset + i)
+ * When every particle shares the LSTM input (first statement of the trace: no previous value) the network is
+ * evaluated once for one row and the head output is broadcast -- same arithmetic, N-fold less work.
+ */
+int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+               const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride,
+               float* h, float* c, const float* value_in, float* value_out, float* logq_out,
+               uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream);
+
+/* log p(value) for Normal / Uniform / Categorical priors and likelihood terms, accumulated into the
+ * per-particle log-weight:  lw[i] += sign * log_prob(dist(params_i); x_i)
+ * (state.py:211-217: +prior, -proposal; state.py:147-149: +likelihood_importance * likelihood).
+ *   kind: 0 Normal(p0=mean,p1=stddev), 1 Uniform(p0=low,p1=high)
+ *   p0/p1/x strides: 0 broadcasts a single value, 1 reads per particle. lp_out optional (dev [n]). */
+int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,
+                            const float* x, int32_t x_stride, float scale, float* lw /*dev [n]*/, float* lp_out,
+                            int32_t n, void* stream);
+
+/* lw[i] += scale * term[i] (e.g. -log q). */
+int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream);
+
+/* Wavefront-reduced importance statistics over n particles (pyprob/distributions/empirical.py:298-309,
+ * 451-466, 758-766): out (dev, double[6]) = { max lw, sum w, sum w^2, sum w*x, sum w*x^2, count finite } with
+ * w = exp(lw - max lw). ESS = (sum w)^2 / sum w^2. Two passes; `scratch` dev >= 64 doubles. */
+int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Individual kernels (used by the whole-path entry points; exported for unit parity tests and profiling)
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct pp_gemm_args {
+    const float* A; int64_t lda; const int32_t* a_idx;  /* A(m,k) = a_kmajor ? A[ix(k)*lda + m] : A[ix(m)*lda + k] */
+    const float* B; int64_t ldb; const int32_t* b_idx;  /* B(n,k) = b_kmajor ? B[ix(k)*ldb + n] : B[ix(n)*ldb + k] */
+    float*       C; int64_t ldc; const int32_t* c_idx;  /* C[ix(m)*ldc + n] */
+    int32_t M, N, K;
+    int32_t a_kmajor, b_kmajor;
+    const float* bias;   /* [N] or NULL, added to every row */
+    const float* bias2;  /* [N] or NULL */
+    const float* mask; int64_t ldmask;  /* optional: result = mask[ix_c(m)*ldmask + n] > 0 ? result : 0 (ReLU backward) */
+    int32_t relu;        /* result = max(result, 0) */
+    int32_t accumulate;  /* C += result instead of C = result */
+} pp_gemm_args;
+
+/* C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ) on the fp32 matrix cores (nn.Linear / nn.LSTM GEMMs and their
+ * gradients: embedding_feedforward.py:40, inference_network_lstm.py:188). *_idx are optional dev row-index
+ * (gather/scatter) arrays: the "address-dispatch gather" of the proposal heads. */
+int pp_gemm_f32(const pp_gemm_args* args, void* stream);
+
+/* out[c] += sum_i X[ix(i)*ldx + c] for c < n_cols (bias and embedding-table gradients). out2 optional. */
+int pp_colsum_f32(const float* X, int64_t ldx, const int32_t* row_idx, int32_t n_rows, int32_t n_cols,
+                  float* out, float* out2, void* stream);
+
+/* LSTM input rows  x = [E | s_{t-1} | d_{t-1} | a_{t-1} | d_t | a_t]  (inference_network_lstm.py:146-181).
+ * E: dev [B, e_obs] (trace b of row r = r - row_off[t]; given as trace_of_row dev [R]). X: dev [R, ldx]. */
+int pp_lstm_input_gather(const pp_net* net, const float* params, const float* E, const int32_t* trace_of_row,
+                         const float* value, const int32_t* addr, const int32_t* prev_row, int32_t n_rows,
+                         float* X, int64_t ldx, void* stream);
+
+/* Pointwise LSTM cell, gate order i,f,g,o (torch.nn.LSTM). G: [n,4H] pre-activations in, activated gates out. */
+int pp_lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int32_t n, int32_t H, void* stream);
+/* Backward of the cell for one time step. G: gates in, dG (pre-activation grads) out. dc_carry: dev [n,H];
+ * rows < n_next hold dL/dc_t from step t+1 on entry; on exit rows < n hold dL/dc_{t-1}. */
+int pp_lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry,
+                     int32_t n, int32_t n_next, int32_t H, void* stream);
+
+/* Proposal transforms + Mixture/Categorical log_prob + its gradient w.r.t. the head output y
+ * (proposal_normal_normal_mixture.py:20-35, proposal_uniform_truncated_normal_mixture.py:20-36,
+ *  proposal_categorical_categorical.py:16-20, distributions/mixture.py:14-16,42-44,
+ *  distributions/truncated_normal.py:25-30,40-54).
+ *   y  dev [n, ldy]  head outputs, compact group order; rows dev [n] -> row id (value/prior/lp_out index) or NULL
+ *   dy dev [n, ldy]  (NULL: forward only) receives grad_scale * d lp / d y  (0 for rows whose lp is -inf)
+ *   loss_acc dev [1] += -sum lp (after the -inf -> log(1e-8) rescue); nonfinite dev [1] set if any lp is NaN/+inf */
+int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* rows, const float* value,
+                    const float* prior, int32_t n, int32_t n_out, float grad_scale, float* lp_out, float* dy,
+                    float* loss_acc, int32_t* nonfinite, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * In-stream kernel timing for bench.py's roofline leg: when armed, pp_ic_loss records a hipEvent pair
+ * around the kernel class `which` (0: forward input GEMM X*W_ih^T) on its stream, once per call.
+ * ---------------------------------------------------------------------------------------------------- */
+int pp_prof_arm(int32_t which, int32_t max_samples);          /* allocate event pairs; 0 disarms */
+int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_out); /* syncs the events */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYPROB_AMD_H */

@@ -1,0 +1,447 @@
+// Host-side orchestration behind the C ABI: InferenceNetworkLSTM._loss (+ backward) as a chain of HIP kernels over
+// the step-major packed trace batch. No allocation, no host synchronisation: every launch goes to the caller's stream.
+#include "common.hpp"
+
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace pp {
+
+// kernels.hip / gemm_f32.hip
+const char* last_error();
+int gemm_f32(const pp_gemm_args* a, hipStream_t st);
+int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
+               hipStream_t st);
+int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
+                      const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
+                      int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st);
+int sample_embed_bwd(const pp_net* net, const float* params, const float* value, const int32_t* addr,
+                     const int32_t* prev_row, int row_begin, int n_rows, const float* dX, int64_t ldx, float* grads,
+                     hipStream_t st);
+int obs_grad(const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max, int n_traces, int e_obs,
+             const float* E, int64_t lde, float* dE, int64_t ldde, hipStream_t st);
+int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st);
+int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
+                  int H, hipStream_t st);
+int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
+                 int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
+                 hipStream_t st);
+int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out,
+                  hipStream_t st);
+int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
+              const float* active, int32_t* tensor_step, float* corr, int n_tensors, float lr, float beta1, float beta2,
+              float eps, float wd, float gscale, hipStream_t st);
+
+static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+// ---- in-stream kernel timing (bench.py roofline leg) ---------------------------------------------------
+struct Prof {
+    int which = -1;
+    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<double> flops;
+    int used = 0;
+};
+static Prof g_prof;
+
+static void prof_begin(int which, hipStream_t st) {
+    if (g_prof.which == which && g_prof.used < (int)g_prof.ev0.size()) (void)hipEventRecord(g_prof.ev0[g_prof.used], st);
+}
+static void prof_end(int which, double flops, hipStream_t st) {
+    if (g_prof.which == which && g_prof.used < (int)g_prof.ev0.size()) {
+        (void)hipEventRecord(g_prof.ev1[g_prof.used], st);
+        g_prof.flops[g_prof.used] = flops;
+        g_prof.used++;
+    }
+}
+
+// ---- workspace carving ------------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* p, size_t c) : base(static_cast<char*>(p)), cap(c) {}
+    template <typename T>
+    T* take(int64_t count) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+        return p;
+    }
+};
+
+struct Workspace {
+    // forward activations
+    float* obs_h[PP_MAX_OBS];  // [B, round4(obs_hid)]
+    float* cat;                // [B, e4] concatenated per-observable embeddings
+    float* f1;                 // [B, e4] hidden layer of the final observe embedding
+    float* E;                  // [B, e4] observe embedding
+    float* X;                  // [R, i4] LSTM input rows
+    float* G;                  // [R, 4H] gate pre-activations -> gates -> dG
+    float* C;                  // [R, H]
+    float* Hs;                 // [R, H]
+    float* A1;                 // [R, hid4] head hidden activations, group-compact row order
+    float* Y;                  // [R, out4] head outputs
+    float* DY;                 // [R, out4]
+    // backward
+    float* dZ1;                // [R, hid4]
+    float* dH;                 // [R, H]
+    float* dC;                 // [B, H]
+    float* dX;                 // [R, i4]
+    float* dE;                 // [B, e4]
+    float* dF1;                // [B, e4]
+    float* dCat;               // [B, e4]
+    float* dObsH;              // [B, maxhid4]
+    float* loss_acc;           // [1]
+    int32_t* flag;             // [1]
+    int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
+    size_t bytes;
+};
+
+static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspace& w) {
+    Carver c(p, cap);
+    const int H = net->lstm_dim;
+    w.e4 = round4(net->e_obs);
+    w.i4 = round4(net->lstm_in);
+    int64_t hid = 1, out = 1;
+    for (int a = 0; a < net->n_addr; ++a) {
+        hid = std::max<int64_t>(hid, net->addrs[a].hid);
+        out = std::max<int64_t>(out, net->addrs[a].n_out);
+    }
+    w.hid4 = round4(hid);
+    w.out4 = round4(out);
+    w.maxohid4 = 4;
+    for (int o = 0; o < net->n_obs; ++o) {
+        w.ohid4[o] = round4(net->obs_hid[o]);
+        w.maxohid4 = std::max(w.maxohid4, w.ohid4[o]);
+        w.obs_h[o] = c.take<float>((int64_t)B * w.ohid4[o]);
+    }
+    w.cat = c.take<float>((int64_t)B * w.e4);
+    w.f1 = c.take<float>((int64_t)B * w.e4);
+    w.E = c.take<float>((int64_t)B * w.e4);
+    w.X = c.take<float>((int64_t)R * w.i4);
+    w.G = c.take<float>((int64_t)R * 4 * H);
+    w.C = c.take<float>((int64_t)R * H);
+    w.Hs = c.take<float>((int64_t)R * H);
+    w.A1 = c.take<float>((int64_t)R * w.hid4);
+    w.Y = c.take<float>((int64_t)R * w.out4);
+    w.DY = c.take<float>((int64_t)R * w.out4);
+    w.dZ1 = c.take<float>((int64_t)R * w.hid4);
+    w.dH = c.take<float>((int64_t)R * H);
+    w.dC = c.take<float>((int64_t)B * H);
+    w.dX = c.take<float>((int64_t)R * w.i4);
+    w.dE = c.take<float>((int64_t)B * w.e4);
+    w.dF1 = c.take<float>((int64_t)B * w.e4);
+    w.dCat = c.take<float>((int64_t)B * w.e4);
+    w.dObsH = c.take<float>((int64_t)B * w.maxohid4);
+    w.loss_acc = c.take<float>(64);
+    w.flag = c.take<int32_t>(64);
+    w.bytes = c.off + 256;
+}
+
+static int check_net(const pp_net* net) {
+    PP_CHECK_ARG(net, "null pp_net");
+    PP_CHECK_ARG(net->n_obs >= 1 && net->n_obs <= PP_MAX_OBS, "pp_net: n_obs=%d out of range", net->n_obs);
+    PP_CHECK_ARG(net->lstm_dim > 0 && net->lstm_in > 0 && net->e_obs > 0, "pp_net: bad dimensions");
+    PP_CHECK_ARG(net->lstm_in == net->e_obs + net->smp_dim + 2 * (net->addr_dim + net->dtype_dim),
+                 "pp_net: lstm_in != e_obs + smp_dim + 2*(addr_dim+dtype_dim)");
+    PP_CHECK_ARG(net->n_addr == 0 || net->addrs, "pp_net: addrs is null");
+    return 0;
+}
+
+// y = act(x W^T + b): x [n, in] (ldx), W [out, in], y [n, out] (ldy)
+static int linear_fwd(const float* x, int64_t ldx, const int32_t* x_idx, const float* W, const float* b, float* y,
+                      int64_t ldy, int n, int in, int out, bool relu, const float* bias2, hipStream_t st) {
+    pp_gemm_args g{};
+    g.A = x; g.lda = ldx; g.a_idx = x_idx;
+    g.B = W; g.ldb = in;
+    g.C = y; g.ldc = ldy;
+    g.M = n; g.N = out; g.K = in;
+    g.bias = b; g.bias2 = bias2; g.relu = relu ? 1 : 0;
+    return gemm_f32(&g, st);
+}
+
+// dW[out, in] += dz^T x ; db[out] += colsum(dz); dz [n, out] (lddz), x [n, in] (ldx, optional k-gather x_idx)
+static int linear_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, const int32_t* x_idx, float* dW,
+                        float* db, float* db2, int n, int in, int out, hipStream_t st) {
+    pp_gemm_args g{};
+    g.A = dz; g.lda = lddz; g.a_kmajor = 1;
+    g.B = x; g.ldb = ldx; g.b_kmajor = 1; g.b_idx = x_idx;
+    g.C = dW; g.ldc = in;
+    g.M = out; g.N = in; g.K = n;
+    g.accumulate = 1;
+    PP_TRY(gemm_f32(&g, st));
+    if (db) PP_TRY(colsum_f32(dz, lddz, nullptr, n, out, db, db2, st));
+    return 0;
+}
+
+// dx[n, in] (lddx, optional scatter idx) = (dz W) (* relu mask); W [out, in]
+static int linear_dgrad(const float* dz, int64_t lddz, const float* W, float* dx, int64_t lddx, const int32_t* dx_idx,
+                        const float* mask, int64_t ldmask, int n, int in, int out, bool accumulate, hipStream_t st) {
+    pp_gemm_args g{};
+    g.A = dz; g.lda = lddz;
+    g.B = W; g.ldb = in; g.b_kmajor = 1;
+    g.C = dx; g.ldc = lddx; g.c_idx = dx_idx;
+    g.M = n; g.N = in; g.K = out;
+    g.mask = mask; g.ldmask = ldmask;
+    g.accumulate = accumulate ? 1 : 0;
+    return gemm_f32(&g, st);
+}
+
+static int observe_embedding_fwd(const pp_net* net, const float* P, const float* obs, int64_t ldobs, int B, Workspace& w,
+                                 hipStream_t st) {
+    int ci = 0, co = 0;
+    for (int o = 0; o < net->n_obs; ++o) {
+        PP_TRY(linear_fwd(obs + ci, ldobs, nullptr, P + net->obs_w0[o], P + net->obs_b0[o], w.obs_h[o], w.ohid4[o], B,
+                          net->obs_in[o], net->obs_hid[o], true, nullptr, st));
+        PP_TRY(linear_fwd(w.obs_h[o], w.ohid4[o], nullptr, P + net->obs_w1[o], P + net->obs_b1[o], w.cat + co, w.e4, B,
+                          net->obs_hid[o], net->obs_out[o], true, nullptr, st));
+        ci += net->obs_in[o];
+        co += net->obs_out[o];
+    }
+    PP_TRY(linear_fwd(w.cat, w.e4, nullptr, P + net->fin_w0, P + net->fin_b0, w.f1, w.e4, B, net->e_obs, net->e_obs, true,
+                      nullptr, st));
+    PP_TRY(linear_fwd(w.f1, w.e4, nullptr, P + net->fin_w1, P + net->fin_b1, w.E, w.e4, B, net->e_obs, net->e_obs, true,
+                      nullptr, st));
+    return 0;
+}
+
+int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads, void* ws,
+            size_t ws_bytes, float* loss_out, int32_t* status_out, float* lp_out, int flags, hipStream_t st) {
+    PP_TRY(check_net(net));
+    PP_CHECK_ARG(bt && P && ws && loss_out, "pp_ic_loss: null pointer");
+    PP_CHECK_ARG(bt->n_traces > 0 && bt->n_rows >= bt->n_traces && bt->t_max >= 1, "pp_ic_loss: empty batch");
+    PP_CHECK_ARG(bt->n_active && bt->row_off && bt->grp_off && bt->obs && bt->value && bt->prior && bt->addr &&
+                     bt->prev_row && bt->grp_rows && bt->trace && bt->row_off_dev && bt->nxt_off && bt->nxt_rows,
+                 "pp_ic_loss: incomplete pp_batch");
+    const bool bwd = flags & PP_LOSS_BACKWARD;
+    PP_CHECK_ARG(!bwd || grads, "pp_ic_loss: PP_LOSS_BACKWARD needs a gradient buffer");
+    const int B = bt->n_traces, R = bt->n_rows, T = bt->t_max, H = net->lstm_dim, I = net->lstm_in;
+    Workspace w;
+    carve(net, B, R, ws, ws_bytes, w);
+    if (w.bytes > ws_bytes) {
+        set_error("pp_ic_loss: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
+        return PP_ENOSPACE;
+    }
+    (void)hipMemsetAsync(w.loss_acc, 0, 256, st);
+    (void)hipMemsetAsync(w.flag, 0, 256, st);
+    if (bwd && (flags & PP_LOSS_ZERO_GRADS)) (void)hipMemsetAsync(grads, 0, (size_t)net->n_params * sizeof(float), st);
+
+    // ---------------- forward ----------------
+    PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
+    PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st));
+    prof_begin(0, st);
+    PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st));
+    prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
+    for (int t = 0; t < T; ++t) {
+        const int n = bt->n_active[t], r0 = bt->row_off[t];
+        float* Gt = w.G + (int64_t)r0 * 4 * H;
+        const float* c_prev = nullptr;
+        if (t > 0) {
+            const int rp = bt->row_off[t - 1];
+            pp_gemm_args g{};
+            g.A = w.Hs + (int64_t)rp * H; g.lda = H;
+            g.B = P + net->w_hh; g.ldb = H;
+            g.C = Gt; g.ldc = 4 * H;
+            g.M = n; g.N = 4 * H; g.K = H;
+            g.accumulate = 1;
+            PP_TRY(gemm_f32(&g, st));
+            c_prev = w.C + (int64_t)rp * H;
+        }
+        PP_TRY(lstm_cell_fwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.Hs + (int64_t)r0 * H, n, H, st));
+    }
+    const float gscale = -1.0f / (float)B;
+    for (int a = 0; a < net->n_addr; ++a) {
+        const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
+        if (n <= 0) continue;
+        const pp_addr& ad = net->addrs[a];
+        float* A1 = w.A1 + (int64_t)g0 * w.hid4;
+        float* Y = w.Y + (int64_t)g0 * w.out4;
+        PP_TRY(linear_fwd(w.Hs, H, bt->grp_rows + g0, P + ad.w1, P + ad.b1, A1, w.hid4, n, H, ad.hid, true, nullptr, st));
+        PP_TRY(linear_fwd(A1, w.hid4, nullptr, P + ad.w2, P + ad.b2, Y, w.out4, n, ad.hid, ad.n_out, false, nullptr, st));
+        PP_TRY(head_logprob(ad.kind, Y, w.out4, bt->grp_rows + g0, bt->value, bt->prior, n, ad.n_out, gscale,
+                            (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr, bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr,
+                            w.loss_acc, w.flag, st));
+    }
+    PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
+    if (!bwd) return 0;
+
+    // ---------------- backward ----------------
+    for (int a = 0; a < net->n_addr; ++a) {
+        const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
+        if (n <= 0) continue;
+        const pp_addr& ad = net->addrs[a];
+        const float* A1 = w.A1 + (int64_t)g0 * w.hid4;
+        const float* DY = w.DY + (int64_t)g0 * w.out4;
+        float* dZ1 = w.dZ1 + (int64_t)g0 * w.hid4;
+        PP_TRY(linear_wgrad(DY, w.out4, A1, w.hid4, nullptr, grads + ad.w2, grads + ad.b2, nullptr, n, ad.hid, ad.n_out, st));
+        PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st));
+        PP_TRY(linear_wgrad(dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, grads + ad.b1, nullptr, n, H, ad.hid, st));
+        PP_TRY(linear_dgrad(dZ1, w.hid4, P + ad.w1, w.dH, H, bt->grp_rows + g0, nullptr, 0, n, H, ad.hid, false, st));
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        const int n = bt->n_active[t], r0 = bt->row_off[t];
+        const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
+        float* Gt = w.G + (int64_t)r0 * 4 * H;
+        const float* c_prev = t > 0 ? w.C + (int64_t)bt->row_off[t - 1] * H : nullptr;
+        PP_TRY(lstm_cell_bwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.dH + (int64_t)r0 * H, w.dC, n, n_next, H, st));
+        if (t > 0)  // dh_{t-1} += dG_t W_hh
+            PP_TRY(linear_dgrad(Gt, 4 * H, P + net->w_hh, w.dH + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0, n,
+                                H, 4 * H, true, st));
+    }
+    // LSTM parameter gradients
+    PP_TRY(linear_wgrad(w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, grads + net->b_ih, grads + net->b_hh, R, I,
+                        4 * H, st));
+    if (T > 1) {
+        const int r1 = bt->row_off[1];
+        PP_TRY(linear_wgrad(w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, nullptr, nullptr,
+                            R - r1, H, 4 * H, st));
+    }
+    // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding
+    PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, false, st));
+    const int c1 = net->e_obs, c2 = c1 + net->smp_dim, c3 = c2 + net->dtype_dim, c4 = c3 + net->addr_dim,
+              c5 = c4 + net->dtype_dim;
+    for (int a = 0; a < net->n_addr; ++a) {
+        const pp_addr& ad = net->addrs[a];
+        const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
+        if (n > 0) {  // rows where `a` is the current address
+            PP_TRY(colsum_f32(w.dX + c4, w.i4, bt->grp_rows + g0, n, net->dtype_dim, grads + ad.dtype_emb, nullptr, st));
+            PP_TRY(colsum_f32(w.dX + c5, w.i4, bt->grp_rows + g0, n, net->addr_dim, grads + ad.addr_emb, nullptr, st));
+        }
+        const int q0 = bt->nxt_off[a], m = bt->nxt_off[a + 1] - q0;
+        if (m > 0) {  // rows whose previous variable has address `a`
+            PP_TRY(colsum_f32(w.dX + c2, w.i4, bt->nxt_rows + q0, m, net->dtype_dim, grads + ad.dtype_emb, nullptr, st));
+            PP_TRY(colsum_f32(w.dX + c3, w.i4, bt->nxt_rows + q0, m, net->addr_dim, grads + ad.addr_emb, nullptr, st));
+        }
+    }
+    if (T > 1)
+        PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
+    // observe embedding backward (dE already carries the ReLU mask of the last layer)
+    PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));
+    const int e = net->e_obs;
+    PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
+    PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st));
+    PP_TRY(linear_wgrad(w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, grads + net->fin_b0, nullptr, B, e, e, st));
+    PP_TRY(linear_dgrad(w.dF1, w.e4, P + net->fin_w0, w.dCat, w.e4, nullptr, w.cat, w.e4, B, e, e, false, st));
+    int ci = 0, co = 0;
+    for (int o = 0; o < net->n_obs; ++o) {
+        const int in = net->obs_in[o], hid = net->obs_hid[o], out = net->obs_out[o];
+        PP_TRY(linear_wgrad(w.dCat + co, w.e4, w.obs_h[o], w.ohid4[o], nullptr, grads + net->obs_w1[o],
+                            grads + net->obs_b1[o], nullptr, B, hid, out, st));
+        PP_TRY(linear_dgrad(w.dCat + co, w.e4, P + net->obs_w1[o], w.dObsH, w.ohid4[o], nullptr, w.obs_h[o], w.ohid4[o], B,
+                            hid, out, false, st));
+        PP_TRY(linear_wgrad(w.dObsH, w.ohid4[o], bt->obs + ci, bt->obs_width, nullptr, grads + net->obs_w0[o],
+                            grads + net->obs_b0[o], nullptr, B, in, hid, st));
+        ci += in;
+        co += out;
+    }
+    return 0;
+}
+
+}  // namespace pp
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int pp_abi_version(void) { return PP_ABI_VERSION; }
+const char* pp_last_error(void) { return pp::last_error(); }
+
+int pp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+size_t pp_ic_workspace_bytes(const pp_net* net, int32_t n_traces, int32_t n_rows) {
+    if (!net || pp::check_net(net) != 0) return 0;
+    pp::Workspace w;
+    pp::carve(net, n_traces, n_rows, nullptr, 0, w);
+    return w.bytes;
+}
+
+int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params, float* grads, void* workspace,
+               size_t workspace_bytes, float* loss_out, int32_t* status_out, float* lp_out, int32_t flags, void* stream) {
+    return pp::ic_loss(net, batch, params, grads, workspace, workspace_bytes, loss_out, status_out, lp_out, flags,
+                       pp::as_stream(stream));
+}
+
+int pp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
+                 const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, float* corr, int32_t n_tensors,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    return pp::adam_step(params, grads, exp_avg, exp_avg_sq, n_params, chunk_tensor, active, tensor_step, corr, n_tensors,
+                         lr, beta1, beta2, eps, weight_decay, grad_scale, pp::as_stream(stream));
+}
+
+int pp_colsum_f32(const float* X, int64_t ldx, const int32_t* row_idx, int32_t n_rows, int32_t n_cols, float* out,
+                  float* out2, void* stream) {
+    return pp::colsum_f32(X, ldx, row_idx, n_rows, n_cols, out, out2, pp::as_stream(stream));
+}
+
+int pp_lstm_input_gather(const pp_net* net, const float* params, const float* E, const int32_t* trace_of_row,
+                         const float* value, const int32_t* addr, const int32_t* prev_row, int32_t n_rows, float* X,
+                         int64_t ldx, void* stream) {
+    if (!net) return PP_EINVAL;
+    return pp::lstm_input_gather(net, params, E, pp::round4(net->e_obs), trace_of_row, value, addr, prev_row, -1, -1, n_rows,
+                                 X, ldx, pp::as_stream(stream));
+}
+
+int pp_lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int32_t n, int32_t H, void* stream) {
+    return pp::lstm_cell_fwd(G, c_prev, c, h, n, H, pp::as_stream(stream));
+}
+
+int pp_lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int32_t n,
+                     int32_t n_next, int32_t H, void* stream) {
+    return pp::lstm_cell_bwd(G, c_prev, c, dh, dc_carry, n, n_next, H, pp::as_stream(stream));
+}
+
+int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
+                    int32_t n, int32_t n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc,
+                    int32_t* nonfinite, void* stream) {
+    return pp::head_logprob(kind, y, ldy, rows, value, prior, n, n_out, grad_scale, lp_out, dy, loss_acc, nonfinite,
+                            pp::as_stream(stream));
+}
+
+int pp_prof_arm(int32_t which, int32_t max_samples) {
+    for (auto e : pp::g_prof.ev0) (void)hipEventDestroy(e);
+    for (auto e : pp::g_prof.ev1) (void)hipEventDestroy(e);
+    pp::g_prof.ev0.clear();
+    pp::g_prof.ev1.clear();
+    pp::g_prof.flops.clear();
+    pp::g_prof.used = 0;
+    pp::g_prof.which = -1;
+    if (max_samples <= 0) return 0;
+    pp::g_prof.ev0.resize(max_samples);
+    pp::g_prof.ev1.resize(max_samples);
+    pp::g_prof.flops.assign(max_samples, 0.0);
+    for (int i = 0; i < max_samples; ++i) {
+        if (hipEventCreate(&pp::g_prof.ev0[i]) != hipSuccess || hipEventCreate(&pp::g_prof.ev1[i]) != hipSuccess) {
+            pp::set_error("pp_prof_arm: hipEventCreate failed");
+            return PP_ENODEV;
+        }
+    }
+    pp::g_prof.which = which;
+    return 0;
+}
+
+int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_out) {
+    int n = std::min<int>(pp::g_prof.used, cap);
+    for (int i = 0; i < n; ++i) {
+        (void)hipEventSynchronize(pp::g_prof.ev1[i]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, pp::g_prof.ev0[i], pp::g_prof.ev1[i]);
+        ms_out[i] = ms;
+        if (flops_out) flops_out[i] = pp::g_prof.flops[i];
+    }
+    if (n_out) *n_out = n;
+    pp::g_prof.used = 0;
+    return 0;
+}
+
+}  // extern "C"

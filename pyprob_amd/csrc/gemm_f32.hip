@@ -1,0 +1,263 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-exact fmaf chain).
+//
+//   C[ix_c(m), n] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// Replaces every nn.Linear / nn.LSTM matmul of the reference's hot path and their autograd gradients
+// (pyprob/nn/embedding_feedforward.py:40, pyprob/nn/inference_network_lstm.py:188).
+// Both operands may be "k-contiguous" (row-major [rows][K]) or "k-major" ([K][rows]) so that forward (NT),
+// data-gradient (NN) and weight-gradient (TN) products all run on one kernel, and either may carry a row
+// gather (the address-dispatch gather of the per-address proposal heads / ragged time steps).
+//
+// Tiling (wave64, 4 waves / 256 threads per workgroup):
+//   * workgroup tile BM x BN, K staged through LDS in slabs of BK = 32
+//   * k-contiguous operands sit in LDS as [row][BK+4]: one ds_read_b128 per lane feeds four MFMAs
+//     (lane l reads row l&31, k = 8*s + 4*(l>>5) .. +3); row stride 36 floats = 9 sixteen-byte slots (odd) so the
+//     16-lane groups of ds_read_b128 hit 16 distinct slots -> conflict free.
+//   * k-major operands sit in LDS as [k][rows+4]: four ds_read_b32 per lane (consecutive rows -> conflict free).
+//   * the summation index may be visited in any order, so MFMA step j of sub-slab s uses k = 8s + j from
+//     lanes 0-31 and k = 8s + 4 + j from lanes 32-63 for BOTH operands.
+//   * global->register prefetch of slab i+1 overlaps the MFMAs of slab i (two barriers per slab).
+#include "common.hpp"
+
+namespace pp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int KPAD = 4;
+
+struct GemmParams {
+    const float* A; int64_t lda; const int32_t* a_idx;
+    const float* B; int64_t ldb; const int32_t* b_idx;
+    float* C; int64_t ldc; const int32_t* c_idx;
+    int M, N, K;
+    const float* bias; const float* bias2;
+    const float* mask; int64_t ldmask;
+    int relu, accumulate;
+};
+
+// ---- global -> register staging of one [ROWS x BK] operand slab ------------------------------------------
+// KM = false: element (row, k) at P[ix(row0+row)*ld + k0+k]; KM = true: at P[ix(k0+k)*ld + row0+row].
+template <int ROWS, bool KM, int VEC>
+struct Stager {
+    static constexpr int PER_THREAD = ROWS * BK / 256;  // floats per thread
+    static constexpr int NV = PER_THREAD / VEC;         // vector slots per thread
+    float r[PER_THREAD];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, const int32_t* __restrict__ idx,
+                                         int row0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int s = tid + 256 * p;
+            int row, k;
+            if (!KM) {
+                row = s / (BK / VEC);
+                k = (s % (BK / VEC)) * VEC;
+            } else {
+                k = s / (ROWS / VEC);
+                row = (s % (ROWS / VEC)) * VEC;
+            }
+            const int grow = row0 + row, gk = k0 + k;
+            if (!KM) {
+                if (grow < nrows && gk < K) {
+                    const int64_t rr = idx ? (int64_t)idx[grow] : (int64_t)grow;
+                    const float* src = P + rr * ld + gk;
+                    if (VEC == 4 && gk + 3 < K) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = (gk + e < K) ? src[e] : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) r[p * VEC + e] = 0.0f;
+                }
+            } else {
+                if (gk < K && grow < nrows) {
+                    const int64_t kk = idx ? (int64_t)idx[gk] : (int64_t)gk;
+                    const float* src = P + kk * ld + grow;
+                    if (VEC == 4 && grow + 3 < nrows) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = (grow + e < nrows) ? src[e] : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) r[p * VEC + e] = 0.0f;
+                }
+            }
+        }
+    }
+
+    // LDS image: !KM -> [ROWS][BK+KPAD], KM -> [BK][ROWS+KPAD]
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int s = tid + 256 * p;
+            int off;
+            if (!KM) {
+                const int row = s / (BK / VEC), k = (s % (BK / VEC)) * VEC;
+                off = row * (BK + KPAD) + k;
+            } else {
+                const int k = s / (ROWS / VEC), row = (s % (ROWS / VEC)) * VEC;
+                off = k * (ROWS + KPAD) + row;
+            }
+            if (VEC == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r[p * VEC + e];
+                *reinterpret_cast<f32x4*>(S + off) = v;
+            } else {
+                S[off] = r[p];
+            }
+        }
+    }
+};
+
+// fragment of one 32-row MFMA operand for sub-slab s (8 k values): out[j] = element (row, 8s + 4h + j)
+template <int ROWS, bool KM>
+__device__ __forceinline__ void read_frag(const float* __restrict__ S, int row, int s, int h, float out[4]) {
+    if (!KM) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(S + row * (BK + KPAD) + s * 8 + h * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = S[(s * 8 + h * 4 + j) * (ROWS + KPAD) + row];
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * (BK + KPAD)];
+    float* As = smem;
+    float* Bs = smem + BM * (BK + KPAD);
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    Stager<BM, A_KM, VEC> sa;
+    Stager<BN, B_KM, VEC> sb;
+    const int nslab = (p.K + BK - 1) / BK;
+    sa.load(p.A, p.lda, p.a_idx, m0, p.M, 0, p.K, tid);
+    sb.load(p.B, p.ldb, p.b_idx, n0, p.N, 0, p.K, tid);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+
+    for (int slab = 0; slab < nslab; ++slab) {
+        const bool more = slab + 1 < nslab;
+        if (more) {
+            sa.load(p.A, p.lda, p.a_idx, m0, p.M, (slab + 1) * BK, p.K, tid);
+            sb.load(p.B, p.ldb, p.b_idx, n0, p.N, (slab + 1) * BK, p.K, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            float a[TM][4], b[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) read_frag<BM, A_KM>(As, wm * WM + i * 32 + l31, s, h, a[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) read_frag<BN, B_KM>(Bs, wn * WN + j * 32 + l31, s, h, b[j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            sa.store(As, tid);
+            sb.store(Bs, tid);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wn * WN + j * 32 + l31;
+            if (gn >= p.N) continue;
+            float bsum = 0.0f;
+            if (p.bias) bsum += p.bias[gn];
+            if (p.bias2) bsum += p.bias2[gn];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gm >= p.M) continue;
+                const int64_t cm = p.c_idx ? (int64_t)p.c_idx[gm] : (int64_t)gm;
+                float v = acc[i][j][r] + bsum;
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (p.mask) v = (p.mask[cm * p.ldmask + gn] > 0.0f) ? v : 0.0f;
+                float* dst = p.C + cm * p.ldc + gn;
+                if (p.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int VEC>
+static int launch_layout(const GemmParams& p, bool akm, bool bkm, hipStream_t st) {
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM));
+    dim3 block(256);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC>), grid, block, 0, st, p);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC>), grid, block, 0, st, p);
+    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, VEC>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC>), grid, block, 0, st, p);
+    PP_LAUNCH_CHECK("pp_gemm_f32");
+    return 0;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
+    PP_CHECK_ARG(a && a->A && a->B && a->C, "pp_gemm_f32: null operand");
+    PP_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0, "pp_gemm_f32: negative dimension");
+    if (a->M == 0 || a->N == 0) return 0;
+    GemmParams p;
+    p.A = a->A; p.lda = a->lda; p.a_idx = a->a_idx;
+    p.B = a->B; p.ldb = a->ldb; p.b_idx = a->b_idx;
+    p.C = a->C; p.ldc = a->ldc; p.c_idx = a->c_idx;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.bias = a->bias; p.bias2 = a->bias2; p.mask = a->mask; p.ldmask = a->ldmask;
+    p.relu = a->relu; p.accumulate = a->accumulate;
+    const bool vec = (a->lda % 4 == 0) && (a->ldb % 4 == 0) && aligned16(a->A) && aligned16(a->B);
+    // Tile choice: the hot-path GEMMs are small (<= a few thousand rows); 64x64 tiles give >= 2 workgroups per CU
+    // on the 1024x2048x212 input GEMM. Very tall problems (batched IS) use 128x128 tiles.
+    const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
+    const bool big = tiles64 >= 4096 && a->N >= 128;
+    if (big) {
+        return vec ? launch_layout<128, 128, 64, 64, 4>(p, a->a_kmajor, a->b_kmajor, st)
+                   : launch_layout<128, 128, 64, 64, 1>(p, a->a_kmajor, a->b_kmajor, st);
+    }
+    return vec ? launch_layout<64, 64, 32, 32, 4>(p, a->a_kmajor, a->b_kmajor, st)
+               : launch_layout<64, 64, 32, 32, 1>(p, a->a_kmajor, a->b_kmajor, st);
+}
+
+}  // namespace pp
+
+extern "C" int pp_gemm_f32(const pp_gemm_args* args, void* stream) { return pp::gemm_f32(args, pp::as_stream(stream)); }

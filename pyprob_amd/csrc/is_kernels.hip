@@ -1,0 +1,459 @@
+// Importance sampling with the inference network, lock-step over N particles (pyprob/state.py:203-219,
+// pyprob/nn/inference_network_lstm.py:82-134, pyprob/trace.py:123-125, pyprob/model.py:59-71): device-side proposal
+// sampling (Philox4x32-10), proposal / prior / likelihood log-probs, per-particle log-weight accumulation and the
+// wavefront-reduced importance statistics (ESS, weighted mean / variance).
+#include "common.hpp"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace pp {
+
+int gemm_f32(const pp_gemm_args* a, hipStream_t st);
+int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
+                      const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
+                      int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st);
+int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st);
+
+static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+constexpr int MAXK = 16;
+constexpr float kFp32Eps = 1.1920928955078125e-07f;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kSqrt2 = 1.41421356237309504880f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+
+__device__ __forceinline__ float std_cdf(float x) { return 0.5f * (1.0f + erff(x * kInvSqrt2)); }
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter = particle index, key = seed ----------------------------
+struct Philox {
+    uint32_t c[4], k[2];
+    __device__ __forceinline__ Philox(uint64_t seed, uint64_t ctr, uint32_t stream) {
+        c[0] = (uint32_t)ctr; c[1] = (uint32_t)(ctr >> 32); c[2] = stream; c[3] = 0;
+        k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
+    }
+    __device__ __forceinline__ void next(uint32_t out[4]) {
+        uint32_t x0 = c[0], x1 = c[1], x2 = c[2], x3 = c[3], k0 = k[0], k1 = k[1];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
+            const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+        c[3]++;  // next block of four for this particle
+    }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// KIND 0: Normal mixture around a Normal prior; KIND 1: TruncatedNormal mixture inside a Uniform prior.
+template <int KIND>
+__global__ __launch_bounds__(256) void is_mixture_kernel(const float* __restrict__ Y, int64_t ldy, int y_shared,
+                                                         const float* __restrict__ prior, int prior_stride, int n,
+                                                         int K, const float* __restrict__ value_in,
+                                                         float* __restrict__ value_out, float* __restrict__ logq_out,
+                                                         uint64_t seed, uint64_t offset) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* y = Y + (y_shared ? 0 : (int64_t)i * ldy);
+    const float pa = prior[(int64_t)i * 2 * prior_stride], pb = prior[(int64_t)i * 2 * prior_stride + 1];
+    float mu[MAXK], sd[MAXK], p[MAXK];
+    float zmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) zmax = fmaxf(zmax, y[2 * K + k]);
+    float zs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            p[k] = expf(y[2 * K + k] - zmax);
+            zs += p[k];
+        }
+    float ps = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            p[k] = p[k] / zs;
+            ps += p[k];
+        }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            p[k] = p[k] / ps;
+            if (KIND == 0) {
+                mu[k] = pa + y[k] * pb;
+                sd[k] = expf(y[K + k]) * pb;
+            } else {
+                const float rng = pb - pa;
+                mu[k] = pa + sigmoidf_(y[k]) * rng;
+                sd[k] = rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
+            }
+        }
+    float v;
+    if (value_in) {
+        v = value_in[i];
+    } else {
+        Philox rng(seed, offset + (uint64_t)i, 0x1C);
+        v = NAN;
+        for (int attempt = 0; attempt < 64; ++attempt) {
+            uint32_t r[4];
+            rng.next(r);
+            const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
+            // component index ~ Categorical(p)   (Mixture.sample, distributions/mixture.py:47-63)
+            float cum = 0.0f, mk = mu[0], sk = sd[0];
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (k < K) {
+                    cum += p[k];
+                    if (!found) {
+                        mk = mu[k];
+                        sk = sd[k];
+                        if (u0 < cum) found = true;
+                    }
+                }
+            if (KIND == 0) {
+                v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);   // Box-Muller
+                break;
+            } else {
+                // inverse-CDF draw inside [low, high) with rejection (distributions/truncated_normal.py:94-112)
+                const float ca = std_cdf((pa - mk) / sk), cb = std_cdf((pb - mk) / sk);
+                const float uu = ca + u1 * (cb - ca);
+                v = mk + sk * kSqrt2 * erfinvf(2.0f * uu - 1.0f);
+                if (isfinite(v) && v >= pa && v < pb) break;
+                v = NAN;
+            }
+        }
+    }
+    // log q(v)   (Mixture.log_prob, distributions/mixture.py:42-44)
+    float a[MAXK], amax = -INFINITY;
+    const bool inside = (KIND == 0) || (v >= pa && v <= pb);
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            const float lpk = logf(fminf(fmaxf(p[k], kFp32Eps), 1.0f - kFp32Eps));
+            const float t = (v - mu[k]) / sd[k];
+            float comp;
+            if (KIND == 0) {
+                comp = -0.5f * t * t - logf(sd[k]) - kHalfLog2Pi;
+            } else {
+                const float Z = std_cdf((pb - mu[k]) / sd[k]) - std_cdf((pa - mu[k]) / sd[k]);
+                comp = (inside ? 0.0f : -INFINITY) + (-0.5f * t * t - kHalfLog2Pi) - logf(sd[k] * Z);
+            }
+            a[k] = lpk + comp;
+            amax = fmaxf(amax, a[k]);
+        }
+    float lp = amax;
+    if (amax > -INFINITY) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) s += expf(a[k] - amax);
+        lp = amax + logf(s);
+    }
+    value_out[i] = v;
+    logq_out[i] = lp;
+}
+
+__global__ __launch_bounds__(256) void is_categorical_kernel(const float* __restrict__ Y, int64_t ldy, int y_shared,
+                                                             int n, int C, const float* __restrict__ value_in,
+                                                             float* __restrict__ value_out,
+                                                             float* __restrict__ logq_out, uint64_t seed,
+                                                             uint64_t offset) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* y = Y + (y_shared ? 0 : (int64_t)i * ldy);
+    float zmax = -INFINITY;
+    for (int k = 0; k < C; ++k) zmax = fmaxf(zmax, y[k]);
+    float zs = 0.0f;
+    for (int k = 0; k < C; ++k) zs += expf(y[k] - zmax);
+    float S = 0.0f;
+    for (int k = 0; k < C; ++k) S += expf(y[k] - zmax) / zs + 1e-8f;
+    int vi;
+    if (value_in) {
+        vi = (int)value_in[i];
+        vi = vi < 0 ? 0 : (vi >= C ? C - 1 : vi);
+    } else {
+        Philox rng(seed, offset + (uint64_t)i, 0x1C);
+        uint32_t r[4];
+        rng.next(r);
+        const float u0 = u01(r[0]);
+        float cum = 0.0f;
+        vi = C - 1;
+        for (int k = 0; k < C; ++k) {
+            cum += (expf(y[k] - zmax) / zs + 1e-8f) / S;
+            if (u0 < cum) {
+                vi = k;
+                break;
+            }
+        }
+    }
+    const float pv = (expf(y[vi] - zmax) / zs + 1e-8f) / S;
+    value_out[i] = (float)vi;
+    logq_out[i] = logf(fminf(fmaxf(pv, kFp32Eps), 1.0f - kFp32Eps));
+}
+
+// h[i,:] = hs[0,:], c[i,:] = cs[0,:]
+__global__ __launch_bounds__(256) void broadcast_state_kernel(const float* __restrict__ hs, const float* __restrict__ cs,
+                                                              float* __restrict__ h, float* __restrict__ c, int n, int H) {
+    const int64_t total = (int64_t)n * H;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % H);
+        h[e] = hs[j];
+        c[e] = cs[j];
+    }
+}
+
+struct IsWorkspace {
+    float *X, *G, *A1, *Y, *hs, *cs;
+    float *obs_h, *cat, *f1;
+    int64_t i4, hid4, out4, e4, maxohid4;
+    size_t bytes;
+};
+
+static void is_carve(const pp_net* net, int n, void* p, IsWorkspace& w) {
+    char* base = static_cast<char*>(p);
+    size_t off = 0;
+    auto take = [&](int64_t count) {
+        off = (off + 255) & ~size_t(255);
+        float* q = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += (size_t)std::max<int64_t>(count, 1) * sizeof(float);
+        return q;
+    };
+    const int H = net->lstm_dim;
+    w.i4 = round4(net->lstm_in);
+    w.e4 = round4(net->e_obs);
+    int64_t hid = 1, out = 1;
+    for (int a = 0; a < net->n_addr; ++a) {
+        hid = std::max<int64_t>(hid, net->addrs[a].hid);
+        out = std::max<int64_t>(out, net->addrs[a].n_out);
+    }
+    w.hid4 = round4(hid);
+    w.out4 = round4(out);
+    w.maxohid4 = 4;
+    for (int o = 0; o < net->n_obs; ++o) w.maxohid4 = std::max<int64_t>(w.maxohid4, round4(net->obs_hid[o]));
+    w.X = take((int64_t)n * w.i4);
+    w.G = take((int64_t)n * 4 * H);
+    w.A1 = take((int64_t)n * w.hid4);
+    w.Y = take((int64_t)n * w.out4);
+    w.hs = take(H);
+    w.cs = take(H);
+    w.obs_h = take(w.maxohid4);
+    w.cat = take(w.e4);
+    w.f1 = take(w.e4);
+    w.bytes = off + 256;
+}
+
+static int lin(const float* x, int64_t ldx, const float* W, const float* b, const float* b2, float* y, int64_t ldy, int n,
+               int in, int out, bool relu, bool accumulate, hipStream_t st) {
+    pp_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.lda = ldx;
+    g.B = W; g.ldb = in;
+    g.C = y; g.ldc = ldy;
+    g.M = n; g.N = out; g.K = in;
+    g.bias = b; g.bias2 = b2; g.relu = relu; g.accumulate = accumulate;
+    return gemm_f32(&g, st);
+}
+
+int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, void* ws, size_t ws_bytes,
+            hipStream_t st) {
+    PP_CHECK_ARG(net && P && obs && e_out && ws, "pp_is_init: null pointer");
+    IsWorkspace w;
+    is_carve(net, 1, ws, w);
+    if (w.bytes > ws_bytes) {
+        set_error("pp_is_init: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
+        return PP_ENOSPACE;
+    }
+    int ci = 0, co = 0, width = 0;
+    for (int o = 0; o < net->n_obs; ++o) width += net->obs_in[o];
+    for (int o = 0; o < net->n_obs; ++o) {
+        PP_TRY(lin(obs + ci, width, P + net->obs_w0[o], P + net->obs_b0[o], nullptr, w.obs_h, w.maxohid4, 1, net->obs_in[o],
+                   net->obs_hid[o], true, false, st));
+        PP_TRY(lin(w.obs_h, w.maxohid4, P + net->obs_w1[o], P + net->obs_b1[o], nullptr, w.cat + co, w.e4, 1, net->obs_hid[o],
+                   net->obs_out[o], true, false, st));
+        ci += net->obs_in[o];
+        co += net->obs_out[o];
+    }
+    PP_TRY(lin(w.cat, w.e4, P + net->fin_w0, P + net->fin_b0, nullptr, w.f1, w.e4, 1, net->e_obs, net->e_obs, true, false, st));
+    PP_TRY(lin(w.f1, w.e4, P + net->fin_w1, P + net->fin_b1, nullptr, e_out, w.e4, 1, net->e_obs, net->e_obs, true, false, st));
+    return 0;
+}
+
+int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
+            const float* prev_value, const float* prior, int prior_stride, float* h, float* c, const float* value_in,
+            float* value_out, float* logq_out, uint64_t seed, uint64_t offset, void* ws, size_t ws_bytes,
+            hipStream_t st) {
+    PP_CHECK_ARG(net && P && e_obs_vec && h && c && value_out && logq_out && ws, "pp_is_step: null pointer");
+    PP_CHECK_ARG(addr_id >= 0 && addr_id < net->n_addr && prev_addr_id < net->n_addr, "pp_is_step: address id out of range");
+    PP_CHECK_ARG(prev_addr_id < 0 || prev_value, "pp_is_step: prev_value is required after the first statement");
+    if (n <= 0) return 0;
+    const pp_addr& ad = net->addrs[addr_id];
+    PP_CHECK_ARG(ad.kind == PP_HEAD_CATEGORICAL || prior, "pp_is_step: prior parameters required");
+    const bool shared = prev_addr_id < 0;  // identical LSTM input and zero state for every particle
+    const int m = shared ? 1 : n;
+    const int H = net->lstm_dim, I = net->lstm_in;
+    IsWorkspace w;
+    is_carve(net, m, ws, w);
+    if (w.bytes > ws_bytes) {
+        set_error("pp_is_step: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
+        return PP_ENOSPACE;
+    }
+    PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
+                             w.i4, st));
+    PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, P + net->b_hh, w.G, 4 * H, m, I, 4 * H, false, false, st));
+    const float* hcur;
+    if (shared) {
+        PP_TRY(lstm_cell_fwd(w.G, nullptr, w.cs, w.hs, 1, H, st));
+        const int64_t total = (int64_t)n * H;
+        const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+        hipLaunchKernelGGL(broadcast_state_kernel, dim3(blocks), dim3(256), 0, st, w.hs, w.cs, h, c, n, H);
+        PP_LAUNCH_CHECK("broadcast_state");
+        hcur = w.hs;
+    } else {
+        PP_TRY(lin(h, H, P + net->w_hh, nullptr, nullptr, w.G, 4 * H, n, H, 4 * H, false, true, st));
+        PP_TRY(lstm_cell_fwd(w.G, c, c, h, n, H, st));
+        hcur = h;
+    }
+    PP_TRY(lin(hcur, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
+    PP_TRY(lin(w.A1, w.hid4, P + ad.w2, P + ad.b2, nullptr, w.Y, w.out4, m, ad.hid, ad.n_out, false, false, st));
+    dim3 grid(cdiv(n, 256)), block(256);
+    if (ad.kind == PP_HEAD_CATEGORICAL) {
+        hipLaunchKernelGGL(is_categorical_kernel, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, n, ad.n_out, value_in,
+                           value_out, logq_out, seed, offset);
+    } else {
+        PP_CHECK_ARG(ad.n_out % 3 == 0 && ad.n_out / 3 <= MAXK, "pp_is_step: at most %d mixture components", MAXK);
+        if (ad.kind == PP_HEAD_NORMAL_MIXTURE)
+            hipLaunchKernelGGL(is_mixture_kernel<0>, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, prior, prior_stride,
+                               n, ad.n_out / 3, value_in, value_out, logq_out, seed, offset);
+        else
+            hipLaunchKernelGGL(is_mixture_kernel<1>, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, prior, prior_stride,
+                               n, ad.n_out / 3, value_in, value_out, logq_out, seed, offset);
+    }
+    PP_LAUNCH_CHECK("pp_is_step(sample)");
+    return 0;
+}
+
+// lw[i] += scale * log_prob(dist(p0_i, p1_i); x_i)
+__global__ __launch_bounds__(256) void logweight_kernel(int kind, const float* __restrict__ p0, int s0,
+                                                        const float* __restrict__ p1, int s1,
+                                                        const float* __restrict__ x, int sx, float scale,
+                                                        float* __restrict__ lw, float* __restrict__ lp_out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = p0[(int64_t)i * s0], b = p1[(int64_t)i * s1], v = x[(int64_t)i * sx];
+    float lp;
+    if (kind == 0) {  // Normal(mean a, stddev b)
+        const float t = v - a;
+        lp = -(t * t) / (2.0f * b * b) - logf(b) - kHalfLog2Pi;
+    } else {  // Uniform(low a, high b): support [low, high)
+        lp = (v >= a && v < b) ? -logf(b - a) : -INFINITY;
+    }
+    if (lp_out) lp_out[i] = lp;
+    if (lw) lw[i] += scale * lp;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float scale, const float* __restrict__ t, float* __restrict__ lw, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) lw[i] += scale * t[i];
+}
+
+// Importance statistics in double: one workgroup of 1024 lanes, two passes (max, then sums), wavefront reductions.
+__global__ __launch_bounds__(1024) void is_stats_kernel(const float* __restrict__ lw, const float* __restrict__ x, int n,
+                                                        double* __restrict__ out) {
+    __shared__ double sh[16][5];
+    __shared__ float shmax[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+        const float l = lw[i];
+        if (isfinite(l)) m = fmaxf(m, l);
+    }
+    m = wave_max(m);
+    if (lane == 0) shmax[wave] = m;
+    __syncthreads();
+    float gmax = shmax[0];
+    for (int k = 1; k < 16; ++k) gmax = fmaxf(gmax, shmax[k]);
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int i = tid; i < n; i += 1024) {
+        const float l = lw[i];
+        if (!isfinite(l)) continue;   // Model._traces discards particles with non-finite weight (model.py:65-68)
+        const double wgt = exp((double)l - (double)gmax);
+        const double xv = x ? (double)x[i] : 0.0;
+        s[0] += wgt; s[1] += wgt * wgt; s[2] += wgt * xv; s[3] += wgt * xv * xv; s[4] += 1.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double r = wave_sum(s[q]);
+        if (lane == 0) sh[wave][q] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < 16; ++k)
+            for (int q = 0; q < 5; ++q) t[q] += sh[k][q];
+        out[0] = (double)gmax;
+        for (int q = 0; q < 5; ++q) out[1 + q] = t[q];
+    }
+}
+
+}  // namespace pp
+
+extern "C" {
+
+size_t pp_is_workspace_bytes(const pp_net* net, int32_t n) {
+    if (!net) return 0;
+    pp::IsWorkspace w;
+    pp::is_carve(net, n, nullptr, w);
+    return w.bytes;
+}
+
+int pp_is_init(const pp_net* net, const float* params, const float* obs, float* e_out, void* workspace,
+               size_t workspace_bytes, void* stream) {
+    return pp::is_init(net, params, obs, e_out, workspace, workspace_bytes, pp::as_stream(stream));
+}
+
+int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+               const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride, float* h,
+               float* c, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
+               void* workspace, size_t workspace_bytes, void* stream) {
+    return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, value_in,
+                       value_out, logq_out, seed, offset, workspace, workspace_bytes, pp::as_stream(stream));
+}
+
+int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,
+                            const float* x, int32_t x_stride, float scale, float* lw, float* lp_out, int32_t n,
+                            void* stream) {
+    if (!(p0 && p1 && x) || (kind != 0 && kind != 1)) {
+        pp::set_error("pp_logweight_accumulate: bad argument");
+        return PP_EINVAL;
+    }
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pp::logweight_kernel, dim3(pp::cdiv(n, 256)), dim3(256), 0, pp::as_stream(stream), kind, p0,
+                       p0_stride, p1, p1_stride, x, x_stride, scale, lw, lp_out, n);
+    PP_LAUNCH_CHECK("pp_logweight_accumulate");
+    return 0;
+}
+
+int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream) {
+    if (!(term && lw)) return PP_EINVAL;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pp::axpy_kernel, dim3(pp::cdiv(n, 256)), dim3(256), 0, pp::as_stream(stream), scale, term, lw, n);
+    PP_LAUNCH_CHECK("pp_axpy");
+    return 0;
+}
+
+int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream) {
+    (void)scratch;
+    if (!(lw && out) || n <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(pp::is_stats_kernel, dim3(1), dim3(1024), 0, pp::as_stream(stream), lw, x, n, out);
+    PP_LAUNCH_CHECK("pp_is_stats");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,630 @@
+// HBM-bound kernels of the inference-compilation path: ragged LSTM-input gather (address dispatch), LSTM cell,
+// proposal transforms + mixture log-prob with a wavefront-reduced loss accumulator, column reductions for bias /
+// embedding-table gradients, flat Adam. All fp32, gfx950 wave64.
+#include "common.hpp"
+
+#include <math.h>
+#include <stdarg.h>
+
+#include <algorithm>
+
+namespace pp {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------------------
+// out[c] += sum_i X[ix(i)*ldx + c]
+// 256 threads = 64 columns x 4 row lanes; each workgroup reduces ROWS_PER_BLOCK rows, one atomic per column.
+// ------------------------------------------------------------------------------------------------------
+constexpr int COLSUM_ROWS = 256;
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx,
+                                                     const int32_t* __restrict__ idx, int n_rows, int n_cols,
+                                                     float* __restrict__ out, float* __restrict__ out2) {
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x;
+    const int cl = tid & 63, rl = tid >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * COLSUM_ROWS;
+    const int r1 = min(n_rows, r0 + COLSUM_ROWS);
+    float acc = 0.0f;
+    if (col < n_cols) {
+        for (int i = r0 + rl; i < r1; i += 4) {
+            const int64_t r = idx ? (int64_t)idx[i] : (int64_t)i;
+            acc += X[r * ldx + col];
+        }
+    }
+    part[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && col < n_cols) {
+        const float s = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+        atomicAdd(out + col, s);
+        if (out2) atomicAdd(out2 + col, s);
+    }
+}
+
+int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
+               hipStream_t st) {
+    PP_CHECK_ARG(X && out, "pp_colsum_f32: null pointer");
+    if (n_rows <= 0 || n_cols <= 0) return 0;
+    dim3 grid(cdiv(n_cols, 64), cdiv(n_rows, COLSUM_ROWS));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, X, ldx, idx, n_rows, n_cols, out, out2);
+    PP_LAUNCH_CHECK("pp_colsum_f32");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LSTM input rows: x = [E | s_prev | d_prev | a_prev | d_cur | a_cur]   (inference_network_lstm.py:146-181)
+// One thread per output element; consecutive lanes write consecutive columns (coalesced row writes); the
+// embedding rows are looked up through the per-address offset table (address dispatch).
+// ------------------------------------------------------------------------------------------------------
+struct GatherDims {
+    int e_obs, smp, dtype, addr, I;
+};
+
+__device__ __forceinline__ float sample_embed_elem(const float* __restrict__ params, const int64_t* __restrict__ at,
+                                                   int a, int j, float v) {
+    const int smp_in = (int)at[a * PP_ADDR_TABLE_COLS + PP_AT_SMP_IN];
+    const float* w = params + at[a * PP_ADDR_TABLE_COLS + PP_AT_SMP_W];
+    const float* b = params + at[a * PP_ADDR_TABLE_COLS + PP_AT_SMP_B];
+    float s;
+    if (smp_in == 1) {
+        s = w[j] * v + b[j];
+    } else {
+        int c = (int)v;
+        c = c < 0 ? 0 : (c >= smp_in ? smp_in - 1 : c);
+        s = w[j * smp_in + c] + b[j];
+    }
+    return fmaxf(s, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void lstm_input_gather_kernel(
+    GatherDims d, const float* __restrict__ params, const int64_t* __restrict__ at, const float* __restrict__ E,
+    int64_t e_stride, const int32_t* __restrict__ trace, const float* __restrict__ value,
+    const int32_t* __restrict__ addr, const int32_t* __restrict__ prev_row, int32_t fixed_addr,
+    int32_t fixed_prev_addr, int n_rows, float* __restrict__ X, int64_t ldx) {
+    const int64_t total = (int64_t)n_rows * d.I;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / d.I);
+        const int c = (int)(e - (int64_t)r * d.I);
+        float out;
+        const int c1 = d.e_obs, c2 = c1 + d.smp, c3 = c2 + d.dtype, c4 = c3 + d.addr, c5 = c4 + d.dtype;
+        if (c < c1) {
+            const int64_t b = trace ? (int64_t)trace[r] : (int64_t)r;
+            out = E[b * e_stride + c];
+        } else if (c < c4) {
+            // previous-variable part
+            int ap;
+            float v = 0.0f;
+            if (prev_row) {
+                const int pr = prev_row[r];
+                ap = pr < 0 ? -1 : addr[pr];
+                if (pr >= 0) v = value[pr];
+            } else {  // lock-step IS: every row has the same previous address, value[r] is the previous value
+                ap = fixed_prev_addr;
+                if (ap >= 0) v = value[r];
+            }
+            if (ap < 0) {
+                out = 0.0f;
+            } else if (c < c2) {
+                out = sample_embed_elem(params, at, ap, c - c1, v);
+            } else if (c < c3) {
+                out = params[at[ap * PP_ADDR_TABLE_COLS + PP_AT_DTYPE_EMB] + (c - c2)];
+            } else {
+                out = params[at[ap * PP_ADDR_TABLE_COLS + PP_AT_ADDR_EMB] + (c - c3)];
+            }
+        } else {
+            const int a = addr ? addr[r] : fixed_addr;
+            if (c < c5) out = params[at[a * PP_ADDR_TABLE_COLS + PP_AT_DTYPE_EMB] + (c - c4)];
+            else out = params[at[a * PP_ADDR_TABLE_COLS + PP_AT_ADDR_EMB] + (c - c5)];
+        }
+        X[(int64_t)r * ldx + c] = out;
+    }
+}
+
+int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
+                      const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
+                      int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st) {
+    PP_CHECK_ARG(net && params && E && X && net->addr_table, "pp_lstm_input_gather: null pointer");
+    if (n_rows <= 0) return 0;
+    GatherDims d{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+    PP_CHECK_ARG(d.I == d.e_obs + d.smp + 2 * (d.dtype + d.addr), "pp_lstm_input_gather: lstm_in mismatch");
+    const int64_t total = (int64_t)n_rows * d.I;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(lstm_input_gather_kernel, dim3(blocks), dim3(256), 0, st, d, params, net->addr_table, E, e_stride,
+                       trace, value, addr, prev_row, fixed_addr, fixed_prev_addr, n_rows, X, ldx);
+    PP_LAUNCH_CHECK("pp_lstm_input_gather");
+    return 0;
+}
+
+// Gradient of the sample-embedding layers (one Linear + ReLU per address) from dX[:, e_obs : e_obs+smp].
+// lane -> row; when a wave's rows share the previous address (the common case in step-major order) the
+// contributions are wave-reduced and one lane issues the atomics.
+__global__ __launch_bounds__(256) void sample_embed_bwd_kernel(GatherDims d, const float* __restrict__ params,
+                                                               const int64_t* __restrict__ at,
+                                                               const float* __restrict__ value,
+                                                               const int32_t* __restrict__ addr,
+                                                               const int32_t* __restrict__ prev_row, int row_begin,
+                                                               int n_rows, const float* __restrict__ dX, int64_t ldx,
+                                                               float* __restrict__ grads) {
+    const int r = row_begin + blockIdx.x * 256 + threadIdx.x;
+    const bool live = r < n_rows;
+    int ap = -1;
+    float v = 0.0f;
+    if (live) {
+        const int pr = prev_row[r];
+        if (pr >= 0) {
+            ap = addr[pr];
+            v = value[pr];
+        }
+    }
+    const int ap0 = __builtin_amdgcn_readfirstlane(ap);
+    const bool uniform = __all(ap == ap0);
+    if (uniform && ap0 < 0) return;
+    for (int j = 0; j < d.smp; ++j) {
+        float ds = 0.0f;
+        int smp_in = 1, cat = 0;
+        if (ap >= 0) {
+            smp_in = (int)at[ap * PP_ADDR_TABLE_COLS + PP_AT_SMP_IN];
+            const float s = sample_embed_elem(params, at, ap, j, v);
+            ds = s > 0.0f ? dX[(int64_t)r * ldx + d.e_obs + j] : 0.0f;
+            if (smp_in > 1) {
+                cat = (int)v;
+                cat = cat < 0 ? 0 : (cat >= smp_in ? smp_in - 1 : cat);
+            }
+        }
+        const int smp_in0 = __builtin_amdgcn_readfirstlane(smp_in);
+        if (uniform && smp_in0 == 1) {
+            const float sw = wave_sum(ds * v), sb = wave_sum(ds);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(grads + at[ap0 * PP_ADDR_TABLE_COLS + PP_AT_SMP_W] + j, sw);
+                atomicAdd(grads + at[ap0 * PP_ADDR_TABLE_COLS + PP_AT_SMP_B] + j, sb);
+            }
+        } else if (ap >= 0 && ds != 0.0f) {
+            float* gw = grads + at[ap * PP_ADDR_TABLE_COLS + PP_AT_SMP_W];
+            float* gb = grads + at[ap * PP_ADDR_TABLE_COLS + PP_AT_SMP_B];
+            if (smp_in == 1) atomicAdd(gw + j, ds * v);
+            else atomicAdd(gw + j * smp_in + cat, ds);
+            atomicAdd(gb + j, ds);
+        }
+    }
+}
+
+int sample_embed_bwd(const pp_net* net, const float* params, const float* value, const int32_t* addr,
+                     const int32_t* prev_row, int row_begin, int n_rows, const float* dX, int64_t ldx, float* grads,
+                     hipStream_t st) {
+    if (n_rows - row_begin <= 0) return 0;
+    GatherDims d{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+    hipLaunchKernelGGL(sample_embed_bwd_kernel, dim3(cdiv(n_rows - row_begin, 256)), dim3(256), 0, st, d, params,
+                       net->addr_table, value, addr, prev_row, row_begin, n_rows, dX, ldx, grads);
+    PP_LAUNCH_CHECK("sample_embed_bwd");
+    return 0;
+}
+
+// dE[b, c] = (E[b,c] > 0) * sum_t dX[row_off[t] + b, c]: gradient into the observe embedding output, with the
+// ReLU mask of the final embedding layer applied (deterministic: no atomics).
+__global__ __launch_bounds__(256) void obs_grad_kernel(const float* __restrict__ dX, int64_t ldx,
+                                                       const int32_t* __restrict__ row_off, int t_max, int n_traces,
+                                                       int e_obs, const float* __restrict__ E, int64_t lde,
+                                                       float* __restrict__ dE, int64_t ldde) {
+    const int64_t total = (int64_t)n_traces * e_obs;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int b = (int)(e / e_obs), c = (int)(e - (int64_t)b * e_obs);
+        float acc = 0.0f;
+        for (int t = 0; t < t_max; ++t) {
+            const int r0 = row_off[t], n = row_off[t + 1] - r0;
+            if (b >= n) break;
+            acc += dX[(int64_t)(r0 + b) * ldx + c];
+        }
+        dE[(int64_t)b * ldde + c] = E[(int64_t)b * lde + c] > 0.0f ? acc : 0.0f;
+    }
+}
+
+int obs_grad(const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max, int n_traces, int e_obs,
+             const float* E, int64_t lde, float* dE, int64_t ldde, hipStream_t st) {
+    const int64_t total = (int64_t)n_traces * e_obs;
+    if (total <= 0) return 0;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(obs_grad_kernel, dim3(blocks), dim3(256), 0, st, dX, ldx, row_off_dev, t_max, n_traces, e_obs, E,
+                       lde, dE, ldde);
+    PP_LAUNCH_CHECK("obs_grad");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LSTM cell (torch.nn.LSTM gate order i, f, g, o)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ G, const float* __restrict__ c_prev,
+                                                            float* __restrict__ c, float* __restrict__ h, int n,
+                                                            int H) {
+    const int64_t total = (int64_t)n * H;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / H), j = (int)(e - (int64_t)r * H);
+        float* g = G + (int64_t)r * 4 * H;
+        const float gi = sigmoidf_(g[j]);
+        const float gf = sigmoidf_(g[H + j]);
+        const float gg = tanhf(g[2 * H + j]);
+        const float go = sigmoidf_(g[3 * H + j]);
+        const float cp = c_prev ? c_prev[e] : 0.0f;
+        const float cn = gf * cp + gi * gg;
+        g[j] = gi;
+        g[H + j] = gf;
+        g[2 * H + j] = gg;
+        g[3 * H + j] = go;
+        c[e] = cn;
+        h[e] = go * tanhf(cn);
+    }
+}
+
+int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st) {
+    PP_CHECK_ARG(G && c && h && H > 0, "pp_lstm_cell_fwd: bad argument");
+    if (n <= 0) return 0;
+    const int64_t total = (int64_t)n * H;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(blocks), dim3(256), 0, st, G, c_prev, c, h, n, H);
+    PP_LAUNCH_CHECK("pp_lstm_cell_fwd");
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ G, const float* __restrict__ c_prev,
+                                                            const float* __restrict__ c,
+                                                            const float* __restrict__ dh,
+                                                            float* __restrict__ dc_carry, int n, int n_next, int H) {
+    const int64_t total = (int64_t)n * H;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / H), j = (int)(e - (int64_t)r * H);
+        float* g = G + (int64_t)r * 4 * H;
+        const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+        const float tc = tanhf(c[e]);
+        const float dhv = dh[e];
+        const float dc = (r < n_next ? dc_carry[e] : 0.0f) + dhv * go * (1.0f - tc * tc);
+        const float cp = c_prev ? c_prev[e] : 0.0f;
+        g[j] = dc * gg * gi * (1.0f - gi);
+        g[H + j] = dc * cp * gf * (1.0f - gf);
+        g[2 * H + j] = dc * gi * (1.0f - gg * gg);
+        g[3 * H + j] = dhv * tc * go * (1.0f - go);
+        dc_carry[e] = dc * gf;
+    }
+}
+
+int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
+                  int H, hipStream_t st) {
+    PP_CHECK_ARG(G && c && dh && dc_carry && H > 0 && n_next <= n, "pp_lstm_cell_bwd: bad argument");
+    if (n <= 0) return 0;
+    const int64_t total = (int64_t)n * H;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks), dim3(256), 0, st, G, c_prev, c, dh, dc_carry, n, n_next, H);
+    PP_LAUNCH_CHECK("pp_lstm_cell_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Proposal heads: transforms + log_prob + d log_prob / d y, one row per lane, loss reduced per wavefront.
+// ------------------------------------------------------------------------------------------------------
+constexpr int MAXK = 16;
+constexpr float kFp32Eps = 1.1920928955078125e-07f;   // torch.finfo(float32).eps (util.clamp_probs)
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+constexpr float kLogEps = -18.420680743952367f;        // log(1e-8), pyprob/util.py:35
+
+__device__ __forceinline__ float std_cdf(float x) { return 0.5f * (1.0f + erff(x * kInvSqrt2)); }
+__device__ __forceinline__ float std_pdf(float x) { return kInvSqrt2Pi * expf(-0.5f * x * x); }
+
+struct MixtureParams {
+    float mu[MAXK], sd[MAXK], pi[MAXK], p[MAXK];
+    float pisum;
+};
+
+// kind 0: Normal components around a Normal prior; kind 1: TruncatedNormal components inside a Uniform prior.
+template <int KIND>
+__device__ __forceinline__ void mixture_params(const float* __restrict__ y, int K, float pa, float pb,
+                                               MixtureParams& m, float sm[MAXK], float ss[MAXK]) {
+    float zmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) zmax = fmaxf(zmax, y[2 * K + k]);
+    float zs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            m.pi[k] = expf(y[2 * K + k] - zmax);
+            zs += m.pi[k];
+        }
+    float ps = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            m.pi[k] = m.pi[k] / zs;
+            ps += m.pi[k];
+        }
+    m.pisum = ps;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            m.p[k] = m.pi[k] / ps;
+            if (KIND == 0) {
+                m.mu[k] = pa + y[k] * pb;
+                m.sd[k] = expf(y[K + k]) * pb;
+            } else {
+                const float rng = pb - pa;
+                sm[k] = sigmoidf_(y[k]);
+                ss[k] = sigmoidf_(y[K + k]);
+                m.mu[k] = pa + sm[k] * rng;
+                m.sd[k] = rng / 1000.0f + ss[k] * rng * 10.0f;
+            }
+        }
+}
+
+// log q(v) and responsibilities; returns lp (may be -inf for TruncatedNormal outside [low, high])
+template <int KIND>
+__device__ __forceinline__ float mixture_logprob(const MixtureParams& m, int K, float v, float low, float high,
+                                                 float a[MAXK]) {
+    float amax = -INFINITY;
+    const bool inside = (KIND == 0) || (v >= low && v <= high);
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            const float lpk = logf(fminf(fmaxf(m.p[k], kFp32Eps), 1.0f - kFp32Eps));
+            const float t = (v - m.mu[k]) / m.sd[k];
+            float comp;
+            if (KIND == 0) {
+                comp = -0.5f * t * t - logf(m.sd[k]) - kHalfLog2Pi;
+            } else {
+                const float alpha = (low - m.mu[k]) / m.sd[k], beta = (high - m.mu[k]) / m.sd[k];
+                const float Z = std_cdf(beta) - std_cdf(alpha);
+                comp = (inside ? 0.0f : -INFINITY) + (-0.5f * t * t - kHalfLog2Pi) - logf(m.sd[k] * Z);
+            }
+            a[k] = lpk + comp;
+            amax = fmaxf(amax, a[k]);
+        }
+    if (!(amax > -INFINITY)) return amax;  // -inf (or NaN)
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) s += expf(a[k] - amax);
+    return amax + logf(s);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void head_mixture_kernel(const float* __restrict__ Y, int64_t ldy,
+                                                           const int32_t* __restrict__ rows,
+                                                           const float* __restrict__ value,
+                                                           const float* __restrict__ prior, int n, int K,
+                                                           float grad_scale, float* __restrict__ lp_out,
+                                                           float* __restrict__ DY, float* __restrict__ loss_acc,
+                                                           int32_t* __restrict__ nonfinite) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float contrib = 0.0f;
+    bool bad = false;
+    if (i < n) {
+        const int r = rows ? rows[i] : i;
+        const float* y = Y + (int64_t)i * ldy;
+        const float v = value[r], pa = prior[2 * r], pb = prior[2 * r + 1];
+        MixtureParams m;
+        float sm[MAXK], ss[MAXK], a[MAXK];
+        mixture_params<KIND>(y, K, pa, pb, m, sm, ss);
+        float lp = mixture_logprob<KIND>(m, K, v, pa, pb, a);
+        if (lp_out) lp_out[r] = lp;
+        const bool rescued = (lp == -INFINITY);
+        bad = !rescued && !isfinite(lp);
+        contrib = rescued ? -kLogEps : -lp;
+        if (DY) {
+            float* dy = DY + (int64_t)i * ldy;
+            if (rescued || bad) {
+                for (int k = 0; k < 3 * K; ++k) dy[k] = 0.0f;
+            } else {
+                // responsibilities and the softmax/normalisation chain (see oracle/ic_oracle.py head_*_mixture)
+                float resp[MAXK], dp[MAXK];
+                float dpp = 0.0f;
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k)
+                    if (k < K) {
+                        resp[k] = expf(a[k] - lp);
+                        const bool in = (m.p[k] >= kFp32Eps) && (m.p[k] <= 1.0f - kFp32Eps);
+                        dp[k] = in ? resp[k] / m.p[k] : 0.0f;
+                        dpp += dp[k] * m.p[k];
+                    }
+                float dpipi = 0.0f;
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k)
+                    if (k < K) {
+                        dp[k] = (dp[k] - dpp) / m.pisum;  // d lp / d pi_k
+                        dpipi += dp[k] * m.pi[k];
+                    }
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k)
+                    if (k < K) {
+                        const float t = (v - m.mu[k]) / m.sd[k];
+                        float dmu, dsd;
+                        if (KIND == 0) {
+                            dmu = resp[k] * t / m.sd[k];
+                            dsd = resp[k] * (t * t - 1.0f) / m.sd[k];
+                            dy[k] = grad_scale * dmu * pb;
+                            dy[K + k] = grad_scale * dsd * m.sd[k];
+                        } else {
+                            const float rng = pb - pa;
+                            const float alpha = (pa - m.mu[k]) / m.sd[k], beta = (pb - m.mu[k]) / m.sd[k];
+                            const float Z = std_cdf(beta) - std_cdf(alpha);
+                            const float fa = std_pdf(alpha), fb = std_pdf(beta);
+                            dmu = resp[k] * (t / m.sd[k] - (fa - fb) / (m.sd[k] * Z));
+                            dsd = resp[k] * ((t * t - 1.0f) / m.sd[k] - (alpha * fa - beta * fb) / (m.sd[k] * Z));
+                            dy[k] = grad_scale * dmu * rng * sm[k] * (1.0f - sm[k]);
+                            dy[K + k] = grad_scale * dsd * rng * 10.0f * ss[k] * (1.0f - ss[k]);
+                        }
+                        dy[2 * K + k] = grad_scale * m.pi[k] * (dp[k] - dpipi);
+                    }
+            }
+        }
+    }
+    // wavefront-reduced loss accumulator: one atomic per wave
+    const float ws = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0 && loss_acc && ws != 0.0f) atomicAdd(loss_acc, ws);
+    if (bad && nonfinite) atomicOr(nonfinite, 1);
+}
+
+// Categorical head: probs = softmax(y) + 1e-8, renormalised and clamped by torch.distributions.Categorical.
+__global__ __launch_bounds__(256) void head_categorical_kernel(const float* __restrict__ Y, int64_t ldy,
+                                                               const int32_t* __restrict__ rows,
+                                                               const float* __restrict__ value, int n, int C,
+                                                               float grad_scale, float* __restrict__ lp_out,
+                                                               float* __restrict__ DY, float* __restrict__ loss_acc,
+                                                               int32_t* __restrict__ nonfinite) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float contrib = 0.0f;
+    bool bad = false;
+    if (i < n) {
+        const int r = rows ? rows[i] : i;
+        const float* y = Y + (int64_t)i * ldy;
+        int vi = (int)value[r];
+        vi = vi < 0 ? 0 : (vi >= C ? C - 1 : vi);
+        float zmax = -INFINITY;
+        for (int k = 0; k < C; ++k) zmax = fmaxf(zmax, y[k]);
+        float zs = 0.0f;
+        for (int k = 0; k < C; ++k) zs += expf(y[k] - zmax);
+        float S = 0.0f, pisum = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const float pik = expf(y[k] - zmax) / zs;
+            S += pik + 1e-8f;
+            pisum += pik;
+        }
+        const float piv = expf(y[vi] - zmax) / zs;
+        const float pv = (piv + 1e-8f) / S;
+        const float lp = logf(fminf(fmaxf(pv, kFp32Eps), 1.0f - kFp32Eps));
+        if (lp_out) lp_out[r] = lp;
+        bad = !isfinite(lp);
+        contrib = -lp;
+        if (DY) {
+            float* dy = DY + (int64_t)i * ldy;
+            const bool in = (pv >= kFp32Eps) && (pv <= 1.0f - kFp32Eps);
+            const float dpv = in ? 1.0f / pv : 0.0f;      // d lp / d p_v
+            const float dpp = dpv * pv;                   // sum_k dp_k p_k
+            // dq_k = (dp_k - dpp) / S ; sum_k dq_k pi_k = (dpv*piv - dpp*pisum) / S
+            const float dqpi = (dpv * piv - dpp * pisum) / S;
+            for (int k = 0; k < C; ++k) {
+                const float pik = expf(y[k] - zmax) / zs;
+                const float dq = ((k == vi ? dpv : 0.0f) - dpp) / S;
+                dy[k] = bad ? 0.0f : grad_scale * pik * (dq - dqpi);
+            }
+        }
+    }
+    const float ws = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0 && loss_acc && ws != 0.0f) atomicAdd(loss_acc, ws);
+    if (bad && nonfinite) atomicOr(nonfinite, 1);
+}
+
+int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
+                 int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
+                 hipStream_t st) {
+    PP_CHECK_ARG(y && value, "pp_head_logprob: null pointer");
+    if (n <= 0) return 0;
+    dim3 grid(cdiv(n, 256)), block(256);
+    if (kind == PP_HEAD_CATEGORICAL) {
+        hipLaunchKernelGGL(head_categorical_kernel, grid, block, 0, st, y, ldy, rows, value, n, n_out, grad_scale,
+                           lp_out, dy, loss_acc, nonfinite);
+    } else {
+        PP_CHECK_ARG(prior, "pp_head_logprob: mixture heads need prior parameters");
+        PP_CHECK_ARG(n_out % 3 == 0 && n_out / 3 <= MAXK && n_out > 0,
+                     "pp_head_logprob: mixture heads support 1..%d components (got n_out=%d)", MAXK, n_out);
+        if (kind == PP_HEAD_NORMAL_MIXTURE)
+            hipLaunchKernelGGL(head_mixture_kernel<0>, grid, block, 0, st, y, ldy, rows, value, prior, n, n_out / 3,
+                               grad_scale, lp_out, dy, loss_acc, nonfinite);
+        else if (kind == PP_HEAD_TRUNCNORMAL_MIXTURE)
+            hipLaunchKernelGGL(head_mixture_kernel<1>, grid, block, 0, st, y, ldy, rows, value, prior, n, n_out / 3,
+                               grad_scale, lp_out, dy, loss_acc, nonfinite);
+        else
+            PP_CHECK_ARG(false, "pp_head_logprob: unknown head kind %d", kind);
+    }
+    PP_LAUNCH_CHECK("pp_head_logprob");
+    return 0;
+}
+
+// loss = acc / B, status = non-finite flag
+__global__ void loss_finalize_kernel(const float* __restrict__ acc, const int32_t* __restrict__ flag, float inv_b,
+                                     float* __restrict__ loss_out, int32_t* __restrict__ status_out) {
+    const float l = acc[0] * inv_b;
+    loss_out[0] = l;
+    if (status_out) status_out[0] = (flag[0] != 0 || !isfinite(l)) ? 1 : 0;
+}
+
+int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, acc, flag, 1.0f / (float)n_traces, loss_out,
+                       status_out);
+    PP_LAUNCH_CHECK("loss_finalize");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Adam over the flat parameter buffer. Tensors are padded to 1024-float chunks; a chunk -> tensor map gives each
+// workgroup its tensor's presence flag and bias corrections (per-tensor step counts, as torch.optim.Adam keeps).
+// ------------------------------------------------------------------------------------------------------
+__global__ void adam_prepare_kernel(const float* __restrict__ active, int32_t* __restrict__ tensor_step,
+                                    float* __restrict__ corr, int n_tensors, float lr, float beta1, float beta2) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tensors) return;
+    if (active[t] > 0.0f) {
+        const int step = tensor_step[t] + 1;
+        tensor_step[t] = step;
+        const double bc1 = 1.0 - pow((double)beta1, (double)step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step);
+        corr[2 * t] = (float)((double)lr / bc1);
+        corr[2 * t + 1] = (float)(1.0 / sqrt(bc2));
+    } else {
+        corr[2 * t] = 0.0f;
+        corr[2 * t + 1] = 0.0f;
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, const float* __restrict__ Gr,
+                                                   float* __restrict__ M, float* __restrict__ V,
+                                                   const int32_t* __restrict__ chunk_tensor,
+                                                   const float* __restrict__ active, const float* __restrict__ corr,
+                                                   float beta1, float beta2, float eps, float wd, float gscale) {
+    const int t = chunk_tensor[blockIdx.x];
+    if (t < 0 || !(active[t] > 0.0f)) return;
+    const float step_size = corr[2 * t], inv_sqrt_bc2 = corr[2 * t + 1];
+    const int64_t o = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    f32x4 p = *reinterpret_cast<f32x4*>(P + o);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gr + o);
+    f32x4 m = *reinterpret_cast<f32x4*>(M + o);
+    f32x4 v = *reinterpret_cast<f32x4*>(V + o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float g = g0[e] * gscale;
+        if (wd != 0.0f) g += wd * p[e];
+        m[e] = beta1 * m[e] + (1.0f - beta1) * g;
+        v[e] = beta2 * v[e] + (1.0f - beta2) * g * g;
+        const float denom = sqrtf(v[e]) * inv_sqrt_bc2 + eps;
+        p[e] -= step_size * (m[e] / denom);
+    }
+    *reinterpret_cast<f32x4*>(P + o) = p;
+    *reinterpret_cast<f32x4*>(M + o) = m;
+    *reinterpret_cast<f32x4*>(V + o) = v;
+}
+
+int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
+              const float* active, int32_t* tensor_step, float* corr, int n_tensors, float lr, float beta1, float beta2,
+              float eps, float wd, float gscale, hipStream_t st) {
+    PP_CHECK_ARG(params && grads && m && v && chunk_tensor && active && tensor_step && corr, "pp_adam_step: null pointer");
+    PP_CHECK_ARG(n_params % 1024 == 0, "pp_adam_step: n_params must be a multiple of 1024 (padded tensors)");
+    if (n_tensors <= 0 || n_params == 0) return 0;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(cdiv(n_tensors, 256)), dim3(256), 0, st, active, tensor_step, corr,
+                       n_tensors, lr, beta1, beta2);
+    PP_LAUNCH_CHECK("pp_adam_step(prepare)");
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(n_params / 1024)), dim3(256), 0, st, params, grads, m, v,
+                       chunk_tensor, active, corr, beta1, beta2, eps, wd, gscale);
+    PP_LAUNCH_CHECK("pp_adam_step");
+    return 0;
+}
+
+}  // namespace pp

@@ -1,0 +1,170 @@
+"""ICEngine: device-resident state of one LSTM inference network and the calls into libpyprob_amd.so.
+
+Owns (as PyTorch-ROCm tensors -- plumbing for HBM allocation and streams only): the flat parameter buffer, the
+identically laid out gradient and Adam-moment buffers, the per-tensor step/presence arrays and the kernel workspace.
+Every compute step is a C-ABI call (include/pyprob_amd.h); nothing here falls back to torch ops or to the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .spec import NetSpec
+
+
+class ICEngine:
+    def __init__(self, spec: NetSpec, device='cuda:0', seed=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.HipLibraryError('pyprob_amd needs a ROCm device (torch.cuda.is_available() is False); there is '
+                                    'no CPU fallback.')
+        self.spec = spec
+        self.device = torch.device(device)
+        self.rng = np.random.default_rng(seed)
+        self.params = torch.zeros(0, dtype=torch.float32, device=self.device)
+        self.workspace = None
+        self.ws_bytes = 0
+        self.ws_shape = (0, 0)
+        self.loss_buf = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.status_buf = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.world_size = 1
+        self._resize(initialise=list(spec.tensors.keys()))
+
+    # ---- buffers -----------------------------------------------------------------------------------------
+    def _resize(self, initialise):
+        """(Re)allocate the flat buffers for the current spec, keep existing values, initialise new tensors, and
+        reset the optimizer state (the reference rebuilds Adam when layers change, inference_network.py:481-483)."""
+        spec = self.spec
+        n = spec.n_params
+        new = torch.zeros(n + 1024, dtype=torch.float32, device=self.device)[:n]
+        old_n = self.params.numel()
+        if old_n:
+            new[:old_n].copy_(self.params)   # tensors are only ever appended
+        host = {}
+        for name in initialise:
+            host[name] = spec.init_tensor(name, self.rng)
+        self.params = new
+        for name, arr in host.items():
+            self.set_tensor(name, arr)
+        # grads carry a tail: [n_tensors presence flags | loss] so that DP needs ONE all-reduce
+        self.grads_full = torch.zeros(n + spec.n_tensors + 1, dtype=torch.float32, device=self.device)
+        self.grads = self.grads_full[:n]
+        self.active = self.grads_full[n:n + spec.n_tensors]
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.tensor_step = torch.zeros(spec.n_tensors, dtype=torch.int32, device=self.device)
+        self.corr = torch.zeros(2 * spec.n_tensors, dtype=torch.float32, device=self.device)
+        self.chunk_tensor = torch.from_numpy(spec.chunk_tensor_map()).to(self.device)
+        self.addr_table = torch.from_numpy(spec.address_table()).to(self.device)
+        self.net = spec.c_struct(self.addr_table.data_ptr())
+        self._active_cache = {}
+        self.ws_shape = (0, 0)
+
+    def add_addresses(self, items):
+        """items: iterable of (address, dist_name, num_categories). Returns True if layers were created."""
+        created = []
+        for address, dist_name, ncat in items:
+            created += self.spec.add_address(address, dist_name, ncat)
+        if created:
+            self._resize(initialise=created)
+        return bool(created)
+
+    def _ensure_workspace(self, n_traces, n_rows):
+        if n_traces <= self.ws_shape[0] and n_rows <= self.ws_shape[1]:
+            return
+        bt, br = max(n_traces, self.ws_shape[0]), max(n_rows, self.ws_shape[1])
+        need = self.lib.pp_ic_workspace_bytes(C.byref(self.net), bt, br)
+        if need == 0:
+            raise RuntimeError('pp_ic_workspace_bytes failed: %s' % self.lib.pp_last_error().decode())
+        self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.ws_bytes = need
+        self.ws_shape = (bt, br)
+
+    # ---- tensor access (reference state_dict names) ------------------------------------------------------------
+    def tensor(self, name, buf=None):
+        off, shape = self.spec.tensors[name]
+        buf = self.params if buf is None else buf
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def set_tensor(self, name, array):
+        t = torch.as_tensor(np.asarray(array, np.float32)).to(self.device)
+        self.tensor(name).copy_(t.view(self.spec.tensors[name][1]))
+
+    def state_dict(self):
+        return {name: self.tensor(name).detach().cpu().clone() for name in self.spec.tensors}
+
+    def load_state_dict(self, sd):
+        for name in self.spec.tensors:
+            self.set_tensor(name, sd[name].detach().cpu().numpy() if hasattr(sd[name], 'detach') else sd[name])
+
+    def grad_dict(self):
+        return {name: self.tensor(name, self.grads).detach().cpu().numpy().copy() for name in self.spec.tensors}
+
+    # ---- the hot path ----------------------------------------------------------------------------------------
+    def loss(self, batch, backward=False, keep_lp=False, zero_grads=True):
+        """InferenceNetworkLSTM._loss(batch) (+ backward). Returns the device loss scalar (1-element view); the
+        non-finite status stays on the device in self.status_buf[0] (no host sync here)."""
+        if batch.c is None:
+            batch.to(self.device)
+        self._ensure_workspace(batch.n_traces, batch.n_rows)
+        flags = 0
+        if backward:
+            flags |= L.PP_LOSS_BACKWARD
+            if zero_grads:
+                flags |= L.PP_LOSS_ZERO_GRADS
+        lp = None
+        if keep_lp:
+            flags |= L.PP_LOSS_KEEP_LP
+            lp = torch.empty(batch.n_rows, dtype=torch.float32, device=self.device)
+        rc = self.lib.pp_ic_loss(C.byref(self.net), C.byref(batch.c), self.params.data_ptr(),
+                                 self.grads.data_ptr() if backward else None, self.workspace.data_ptr(), self.ws_bytes,
+                                 self.loss_buf.data_ptr(), self.status_buf.data_ptr(), L.ptr(lp), flags, L.stream_ptr())
+        L.check(rc, 'pp_ic_loss')
+        if backward:
+            self._set_active(batch)
+        return (self.loss_buf[:1], lp) if keep_lp else self.loss_buf[:1]
+
+    def _set_active(self, batch):
+        key = (tuple(batch.cur_counts > 0), tuple(batch.prev_counts > 0))
+        act = self._active_cache.get(key)
+        if act is None:
+            act = torch.from_numpy(self.spec.active_mask(batch.cur_counts, batch.prev_counts)).to(self.device)
+            self._active_cache[key] = act
+        self.active.copy_(act)
+        self.grads_full[-1:].copy_(self.loss_buf[:1])
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+        """optimizer.step() for optim.Adam (inference_network.py:348,496); grads are divided by world_size first
+        when data-parallel (inference_network.py:324-325)."""
+        rc = self.lib.pp_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                   self.exp_avg_sq.data_ptr(), self.spec.n_params, self.chunk_tensor.data_ptr(),
+                                   self.active.data_ptr(), self.tensor_step.data_ptr(), self.corr.data_ptr(),
+                                   self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
+                                   L.stream_ptr())
+        L.check(rc, 'pp_adam_step')
+
+    def train_step(self, batch, lr, weight_decay=0.0):
+        """zero_grad -> loss -> backward -> [all-reduce] -> Adam (inference_network.py:486-496). No host sync."""
+        loss = self.loss(batch, backward=True)
+        if self.world_size > 1:
+            self.allreduce_grads()
+        self.adam_step(lr, weight_decay=weight_decay)
+        return loss
+
+    # ---- data parallel ------------------------------------------------------------------------------------
+    def allreduce_grads(self):
+        """ONE RCCL all-reduce (SUM) over [flat grads | presence map | loss]
+        (replaces the per-tensor loop of _distributed_sync_grad, inference_network.py:296-333)."""
+        import torch.distributed as dist
+        dist.all_reduce(self.grads_full)
+
+    def broadcast_params(self):
+        """_distributed_sync_parameters (inference_network.py:290-294) as one broadcast of the flat buffer."""
+        import torch.distributed as dist
+        dist.broadcast(self.params, 0)
+
+    def reset_optimizer(self):
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.tensor_step.zero_()

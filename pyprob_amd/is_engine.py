@@ -1,0 +1,121 @@
+"""Lock-step importance sampling with the inference network: N particles advance through the model's controlled
+`sample` statements together.
+
+The reference runs one particle at a time (pyprob/model.py:59) and, inside it, one batch-1 `_infer_step` per
+`pyprob.sample` (pyprob/state.py:203-219, pyprob/nn/inference_network_lstm.py:82-134). Here every statement is one
+C-ABI call for all particles of this rank: LSTM step + proposal head + device-side sampling + log q, followed by
+fused prior/likelihood log-prob kernels that accumulate the per-particle log-weight
+(log w = sum_t [log p(v_t) - log q(v_t)] + sum_j log p(y_j | .), pyprob/trace.py:123-125).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+class ISRunner:
+    def __init__(self, engine):
+        self.eng = engine
+        self.lib = engine.lib
+        self.dev = engine.device
+        self.e_obs = torch.zeros(engine.spec.e_obs + 8, dtype=torch.float32, device=self.dev)
+        self.ws = None
+        self.ws_bytes = 0
+        self.n = 0
+        self.offset = 0
+        self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
+
+    def _ensure_ws(self, n):
+        need = self.lib.pp_is_workspace_bytes(C.byref(self.eng.net), n)
+        if need > self.ws_bytes:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.ws_bytes = need
+
+    def init(self, observe):
+        """InferenceNetwork._infer_init(observe) (inference_network.py:141-148): embed the observation once."""
+        obs = torch.as_tensor(np.asarray(observe, np.float32).reshape(-1)).to(self.dev)
+        if obs.numel() != self.eng.spec.obs_width:
+            raise ValueError('observe has %d values, the network expects %d' % (obs.numel(), self.eng.spec.obs_width))
+        self._ensure_ws(1)
+        L.check(self.lib.pp_is_init(C.byref(self.eng.net), self.eng.params.data_ptr(), obs.data_ptr(),
+                                    self.e_obs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, L.stream_ptr()), 'pp_is_init')
+
+    def begin(self, n, offset=0):
+        """Start n traces in lock step (state._begin_trace, state.py:339-345): LSTM state is reset by the first step."""
+        H = self.eng.spec.lstm_dim
+        if n != self.n:
+            self.h = torch.empty(n, H, dtype=torch.float32, device=self.dev)
+            self.c = torch.empty(n, H, dtype=torch.float32, device=self.dev)
+            self.n = n
+        self.prev_value = None
+        self.offset = int(offset)
+        self._ensure_ws(n)
+
+    def step(self, addr_id, prev_addr_id, prior, value_in=None, seed=0):
+        """One controlled sample statement for all particles. prior: device tensor [1,2] (shared) or [n,2].
+        Returns (values [n], log q [n]) as device tensors."""
+        n = self.n
+        value = torch.empty(n, dtype=torch.float32, device=self.dev)
+        logq = torch.empty(n, dtype=torch.float32, device=self.dev)
+        stride = 0 if (prior is None or prior.shape[0] == 1) else 1
+        rc = self.lib.pp_is_step(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id),
+                                 -1 if prev_addr_id is None else int(prev_addr_id), n, self.e_obs.data_ptr(),
+                                 L.ptr(self.prev_value), L.ptr(prior), stride, self.h.data_ptr(), self.c.data_ptr(),
+                                 L.ptr(value_in), value.data_ptr(), logq.data_ptr(), int(seed), self.offset,
+                                 self.ws.data_ptr(), self.ws_bytes, L.stream_ptr())
+        L.check(rc, 'pp_is_step')
+        self.prev_value = value
+        return value, logq
+
+    # ---- log-weight terms ---------------------------------------------------------------------------------
+    def accumulate(self, lw, kind, p0, p1, x, scale=1.0):
+        """lw += scale * log_prob(dist(p0, p1); x); p0/p1/x are device tensors of 1 (broadcast) or n elements."""
+        n = lw.numel()
+
+        def s(t):
+            return 0 if t.numel() == 1 else 1
+        rc = self.lib.pp_logweight_accumulate(int(kind), p0.data_ptr(), s(p0), p1.data_ptr(), s(p1), x.data_ptr(), s(x),
+                                              float(scale), lw.data_ptr(), None, n, L.stream_ptr())
+        L.check(rc, 'pp_logweight_accumulate')
+
+    def axpy(self, lw, scale, term):
+        L.check(self.lib.pp_axpy(float(scale), term.data_ptr(), lw.data_ptr(), lw.numel(), L.stream_ptr()), 'pp_axpy')
+
+    def stats(self, lw, x=None):
+        """Importance statistics (Empirical.finalize / expectation / effective_sample_size,
+        pyprob/distributions/empirical.py:298-309, 451-466, 758-766) reduced on the device in float64."""
+        rc = self.lib.pp_is_stats(lw.data_ptr(), L.ptr(x), lw.numel(), self._stats.data_ptr(), None, L.stream_ptr())
+        L.check(rc, 'pp_is_stats')
+        m, sw, sw2, swx, swx2, cnt = self._stats[:6].cpu().numpy().tolist()
+        mean = swx / sw if sw > 0 else float('nan')
+        var = swx2 / sw - mean * mean if sw > 0 else float('nan')
+        return dict(max_lw=m, sum_w=sw, sum_w2=sw2, sum_wx=swx, sum_wx2=swx2, count=cnt,
+                    ess=(sw * sw / sw2) if sw2 > 0 else 0.0, mean=mean, var=var,
+                    log_evidence=m + np.log(sw / max(cnt, 1)) if sw > 0 else float('-inf'))
+
+
+def gum_posterior(engine, num_particles, obs=(8.0, 9.0), prior_mean=1.0, prior_stddev=5.0 ** 0.5,
+                  likelihood_stddev=2.0 ** 0.5, seed=0, offset=0, runner=None, return_particles=False):
+    """posterior_results(N, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe={'obs0':.., 'obs1':..}) for the
+    GaussianUnknownMean program (reference tests/test_inference.py:97-109), executed lock-step:
+        mu = sample(Normal(m0, s0)); observe(Normal(mu, s), obs0); observe(Normal(mu, s), obs1); return mu
+    log w = log N(mu; m0, s0) - log q(mu | y) + log N(y0; mu, s) + log N(y1; mu, s)   (SURVEY.md §8a)."""
+    run = runner or ISRunner(engine)
+    dev = engine.device
+    run.init(obs)
+    run.begin(num_particles, offset=offset)
+    prior = torch.tensor([[prior_mean, prior_stddev]], dtype=torch.float32, device=dev)
+    mu, logq = run.step(0, None, prior, seed=seed)
+    lw = torch.zeros(num_particles, dtype=torch.float32, device=dev)
+    run.accumulate(lw, 0, prior[0, 0:1], prior[0, 1:2], mu)            # + log p(mu)        state.py:211
+    run.axpy(lw, -1.0, logq)                                           # - log q(mu)        state.py:212,217
+    s = torch.tensor([likelihood_stddev], dtype=torch.float32, device=dev)
+    for y in obs:                                                      # + log p(y_j | mu)  state.py:147-149
+        run.accumulate(lw, 0, mu, s, torch.tensor([float(y)], dtype=torch.float32, device=dev))
+    st = run.stats(lw, mu)
+    st['std'] = float(np.sqrt(max(st['var'], 0.0)))
+    if return_particles:
+        st['values'], st['log_weights'] = mu, lw
+    return st

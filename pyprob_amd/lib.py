@@ -1,0 +1,120 @@
+"""ctypes binding of libpyprob_amd.so (include/pyprob_amd.h). There is NO fallback: if the HIP library is missing or
+cannot be loaded, importing the compute path raises -- the product never routes through a CPU implementation."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
+
+PP_ABI_VERSION = 1
+PP_MAX_OBS = 8
+PP_ADDR_TABLE_COLS = 8
+PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL = 0, 1, 2
+PP_LOSS_BACKWARD, PP_LOSS_ZERO_GRADS, PP_LOSS_KEEP_LP = 1, 2, 4
+
+i32, i64, f32p, i32p, vp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p
+
+
+class pp_addr(C.Structure):
+    _fields_ = [('kind', i32), ('n_out', i32), ('hid', i32), ('smp_in', i32), ('dtype_id', i32), ('_pad', i32),
+                ('addr_emb', i64), ('dtype_emb', i64), ('smp_w', i64), ('smp_b', i64),
+                ('w1', i64), ('b1', i64), ('w2', i64), ('b2', i64)]
+
+
+class pp_net(C.Structure):
+    _fields_ = [('n_obs', i32),
+                ('obs_in', i32 * PP_MAX_OBS), ('obs_hid', i32 * PP_MAX_OBS), ('obs_out', i32 * PP_MAX_OBS),
+                ('obs_w0', i64 * PP_MAX_OBS), ('obs_b0', i64 * PP_MAX_OBS), ('obs_w1', i64 * PP_MAX_OBS),
+                ('obs_b1', i64 * PP_MAX_OBS),
+                ('e_obs', i32), ('smp_dim', i32), ('addr_dim', i32), ('dtype_dim', i32),
+                ('fin_w0', i64), ('fin_b0', i64), ('fin_w1', i64), ('fin_b1', i64),
+                ('lstm_in', i32), ('lstm_dim', i32),
+                ('w_ih', i64), ('w_hh', i64), ('b_ih', i64), ('b_hh', i64),
+                ('n_addr', i32), ('n_dtype', i32),
+                ('addrs', C.POINTER(pp_addr)), ('addr_table', vp), ('n_params', i64)]
+
+
+class pp_batch(C.Structure):
+    _fields_ = [('n_traces', i32), ('n_rows', i32), ('t_max', i32), ('obs_width', i32),
+                ('n_active', C.POINTER(i32)), ('row_off', C.POINTER(i32)), ('grp_off', C.POINTER(i32)),
+                ('obs', vp), ('value', vp), ('prior', vp), ('addr', vp), ('prev_row', vp), ('grp_rows', vp),
+                ('trace', vp), ('row_off_dev', vp), ('nxt_off', C.POINTER(i32)), ('nxt_rows', vp)]
+
+
+class pp_gemm_args(C.Structure):
+    _fields_ = [('A', vp), ('lda', i64), ('a_idx', vp),
+                ('B', vp), ('ldb', i64), ('b_idx', vp),
+                ('C', vp), ('ldc', i64), ('c_idx', vp),
+                ('M', i32), ('N', i32), ('K', i32), ('a_kmajor', i32), ('b_kmajor', i32),
+                ('bias', vp), ('bias2', vp), ('mask', vp), ('ldmask', i64), ('relu', i32), ('accumulate', i32)]
+
+
+# name -> (restype, argtypes); every symbol include/pyprob_amd.h declares
+PROTOTYPES = {
+    'pp_abi_version': (C.c_int, []),
+    'pp_last_error': (C.c_char_p, []),
+    'pp_device_count': (C.c_int, []),
+    'pp_ic_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32, i32]),
+    'pp_ic_loss': (C.c_int, [C.POINTER(pp_net), C.POINTER(pp_batch), vp, vp, vp, C.c_size_t, vp, vp, vp, i32, vp]),
+    'pp_adam_step': (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_float, vp]),
+    'pp_is_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32]),
+    'pp_is_init': (C.c_int, [C.POINTER(pp_net), vp, vp, vp, vp, C.c_size_t, vp]),
+    'pp_is_step': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, C.c_uint64,
+                             C.c_uint64, vp, C.c_size_t, vp]),
+    'pp_logweight_accumulate': (C.c_int, [i32, vp, i32, vp, i32, vp, i32, C.c_float, vp, vp, i32, vp]),
+    'pp_axpy': (C.c_int, [C.c_float, vp, vp, i32, vp]),
+    'pp_is_stats': (C.c_int, [vp, vp, i32, vp, vp, vp]),
+    'pp_gemm_f32': (C.c_int, [C.POINTER(pp_gemm_args), vp]),
+    'pp_colsum_f32': (C.c_int, [vp, i64, vp, i32, i32, vp, vp, vp]),
+    'pp_lstm_input_gather': (C.c_int, [C.POINTER(pp_net), vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]),
+    'pp_lstm_cell_fwd': (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
+    'pp_lstm_cell_bwd': (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    'pp_head_logprob': (C.c_int, [i32, vp, i64, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]),
+    'pp_prof_arm': (C.c_int, [i32, i32]),
+    'pp_prof_collect': (C.c_int, [vp, i32, vp, vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the C-ABI library (building is __graft_entry__.build()'s / pyprob_amd.build.build()'s job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError('%s not found: build it with `python -m pyprob_amd.build` (hipcc, gfx950). '
+                              'pyprob_amd has no CPU fallback.' % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pp_abi_version() != PP_ABI_VERSION:
+        raise HipLibraryError('ABI version mismatch: library %d, binding %d' % (lib.pp_abi_version(), PP_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().pp_last_error()
+        raise RuntimeError('libpyprob_amd %s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,309 @@
+"""GPU parity of the whole hot path (InferenceNetworkLSTM._loss + backward, Adam, importance sampling) through the
+C ABI, against (a) the golden vectors recorded from the reference and (b) the numpy oracle at benchmark sizes, plus
+size-independent properties. Tolerance: north_star asks 1e-4 relative on log-weights; most checks are tighter."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import (engine_from_golden, packed_from_golden, rel_err, spec_from_golden, synthetic_gum_arrays,
+                     synthetic_gumm_arrays)
+from oracle import ic_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _unpack_lp(pb, lp_rows, batch):
+    """per-row log_prob (packed row order) -> trace-major order of the golden arrays"""
+    out = np.empty(pb.n_rows, np.float64)
+    out[pb.src_row] = lp_rows
+    return out
+
+
+def test_golden_loss_logprob_and_gradients(golden):
+    case, meta, params, batch, loss, isr = golden
+    eng = engine_from_golden(meta, params)
+    pb = packed_from_golden(meta, batch, eng.spec).to(eng.device)
+    l, lp = eng.loss(pb, backward=True, keep_lp=True)
+    torch.cuda.synchronize()
+    assert int(eng.status_buf[0].item()) == 0
+    ref_loss = float(loss['loss'])
+    assert abs(float(l.item()) - ref_loss) <= 1e-5 * abs(ref_loss), (float(l.item()), ref_loss)
+    # per-row log_prob against the reference's Mixture/Categorical.log_prob outputs
+    lp_tm = _unpack_lp(pb, lp.cpu().numpy(), batch)
+    off = np.concatenate([[0], np.cumsum(batch['trace_len'])])
+    for k, (si, t) in enumerate(meta['lp_index']):
+        rows = off[np.array(meta['sub_batches'][si])] + t
+        np.testing.assert_allclose(lp_tm[rows], loss['lp_%d_%d' % (si, t)], rtol=1e-4, atol=1e-4)
+    # every parameter gradient against loss.backward() of the reference
+    g = eng.grad_dict()
+    worst = ('', 0.0)
+    for i, n in enumerate(meta['param_names']):
+        ref = loss['g%d' % i]
+        err = np.abs(g[n] - ref).max() / max(np.abs(ref).max(), 1e-6)
+        if err > worst[1]:
+            worst = (n, err)
+        if not meta['has_grad'][i]:
+            assert np.all(g[n] == 0), n
+    assert worst[1] < 1e-3, worst
+    # presence map = which tensors had grad != None in the reference
+    act = eng.active.cpu().numpy()
+    names = list(eng.spec.tensors.keys())
+    ref_has = dict(zip(meta['param_names'], meta['has_grad']))
+    assert [bool(a) for a in act] == [bool(ref_has[n]) for n in names]
+
+
+def _oracle_run(spec, params, arrays, addresses, dist_names, want_grads=True):
+    net = O.Net(params, [o[0] for o in spec.obs], K=spec.K)
+    return O.loss_and_grads(net, arrays, addresses, dist_names, want_grads=want_grads)
+
+
+def _fresh_engine(lstm_dim, addresses, dist, seed=0):
+    from pyprob_amd.engine import ICEngine
+    from pyprob_amd.spec import NetSpec
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=lstm_dim)
+    for a in addresses:
+        spec.add_address(a, dist)
+    return ICEngine(spec, seed=seed)
+
+
+def _packed(arrays, spec):
+    from pyprob_amd.packed import PackedBatch
+    return PackedBatch.from_ragged(arrays['trace_len'], arrays['addr_idx'], arrays['values'], arrays['prior'],
+                                   arrays['obs'], len(spec.addresses))
+
+
+@pytest.mark.parametrize('H', [512])
+def test_benchmark_size_gum_against_oracle(H):
+    """config 2 shape: GUM, batch 1024, LSTM hidden 512 (1 643 583 parameters)."""
+    eng = _fresh_engine(H, ['mu'], 'Normal')
+    assert eng.spec.num_parameters() == 1643583
+    arrays = synthetic_gum_arrays(1024, seed=3)
+    pb = _packed(arrays, eng.spec).to(eng.device)
+    l, lp = eng.loss(pb, backward=True, keep_lp=True)
+    torch.cuda.synchronize()
+    params = {k: v.numpy() for k, v in eng.state_dict().items()}
+    out = _oracle_run(eng.spec, params, arrays, ['mu'], ['Normal'])
+    assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
+    lp_tm = _unpack_lp(pb, lp.cpu().numpy(), arrays)
+    np.testing.assert_allclose(lp_tm, out['lp'][0], rtol=1e-4, atol=1e-4)
+    g = eng.grad_dict()
+    for n in eng.spec.tensors:
+        assert rel_err(g[n], out['grads'][n]) < 2e-3 or np.abs(out['grads'][n]).max() < 1e-7, n
+
+
+def test_benchmark_size_gumm_ragged_against_oracle():
+    """config 3 shape: GUMM (variable-length traces, one head per address), batch 1024, hidden 512."""
+    arrays, addresses = synthetic_gumm_arrays(1024, seed=4, max_iter=6)
+    eng = _fresh_engine(512, addresses, 'Uniform')
+    pb = _packed(arrays, eng.spec).to(eng.device)
+    l, lp = eng.loss(pb, backward=True, keep_lp=True)
+    torch.cuda.synchronize()
+    params = {k: v.numpy() for k, v in eng.state_dict().items()}
+    out = _oracle_run(eng.spec, params, arrays, addresses, ['Uniform'] * len(addresses))
+    assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
+    g = eng.grad_dict()
+    bad = []
+    for n in eng.spec.tensors:
+        scale = np.abs(out['grads'][n]).max()
+        if scale > 1e-7 and rel_err(g[n], out['grads'][n]) > 3e-3:
+            bad.append((n, rel_err(g[n], out['grads'][n])))
+    assert not bad, bad[:5]
+
+
+def test_loss_is_permutation_invariant_and_additive():
+    """Size-independent properties: the loss does not depend on trace order, and the loss of a union of two
+    batches is the size-weighted mean of their losses."""
+    arrays, addresses = synthetic_gumm_arrays(600, seed=11, max_iter=5)
+    eng = _fresh_engine(64, addresses, 'Uniform', seed=5)
+    off = np.concatenate([[0], np.cumsum(arrays['trace_len'])])
+
+    def subset(idx):
+        rows = np.concatenate([np.arange(off[b], off[b + 1]) for b in idx])
+        return dict(trace_len=arrays['trace_len'][idx], addr_idx=arrays['addr_idx'][rows], values=arrays['values'][rows],
+                    prior=arrays['prior'][rows], obs=arrays['obs'][idx])
+
+    full = float(eng.loss(_packed(arrays, eng.spec).to(eng.device)).item())
+    perm = np.random.default_rng(0).permutation(600)
+    shuffled = float(eng.loss(_packed(subset(perm), eng.spec).to(eng.device)).item())
+    assert abs(full - shuffled) <= 2e-6 * abs(full)
+    a, b = perm[:250], perm[250:]
+    la = float(eng.loss(_packed(subset(a), eng.spec).to(eng.device)).item())
+    lb = float(eng.loss(_packed(subset(b), eng.spec).to(eng.device)).item())
+    assert abs(full - (250 * la + 350 * lb) / 600) <= 3e-6 * abs(full)
+
+
+def test_adam_matches_torch_semantics():
+    """Several optimizer steps against the oracle's Adam, including tensors without gradient (skipped, step count
+    not advanced) -- torch.optim.Adam as the reference configures it (inference_network.py:348)."""
+    meta, params, batch, loss, isr = load_golden('gumm')
+    eng = engine_from_golden(meta, params)
+    pb = packed_from_golden(meta, batch, eng.spec).to(eng.device)
+    P = {k: v.astype(np.float64).copy() for k, v in params.items()}
+    M = {k: np.zeros_like(v) for k, v in P.items()}
+    V = {k: np.zeros_like(v) for k, v in P.items()}
+    names = list(eng.spec.tensors.keys())
+    for step in range(1, 4):
+        eng.train_step(pb, lr=1e-3)
+        torch.cuda.synchronize()
+        net = O.Net(P, meta['obs_names'], K=10)
+        out = O.loss_and_grads(net, batch, meta['addresses'], meta['dist_names'])
+        act = eng.spec.active_mask(pb.cur_counts, pb.prev_counts)
+        for i, n in enumerate(names):
+            if act[i]:
+                O.adam_step(P[n], out['grads'][n], M[n], V[n], step, 1e-3)
+    sd = eng.state_dict()
+    worst = max(rel_err(sd[n].numpy(), P[n]) for n in names)
+    assert worst < 2e-4, worst
+    steps = eng.tensor_step.cpu().numpy()
+    act = eng.spec.active_mask(pb.cur_counts, pb.prev_counts)
+    assert np.all(steps[act > 0] == 3) and np.all(steps[act == 0] == 0)
+    # untouched tensors are bit-identical
+    for i, n in enumerate(names):
+        if not act[i]:
+            np.testing.assert_array_equal(sd[n].numpy(), params[n])
+
+
+def test_training_reduces_loss_on_gum():
+    eng = _fresh_engine(64, ['mu'], 'Normal', seed=1)
+    arrays = synthetic_gum_arrays(2048, seed=8)
+    pb = _packed(arrays, eng.spec).to(eng.device)
+    first = float(eng.loss(pb).item())
+    for _ in range(150):
+        eng.train_step(pb, lr=1e-3)
+    last = float(eng.loss(pb).item())
+    assert np.isfinite(last) and last < first - 0.3, (first, last)
+
+
+def test_polymorph_growth_keeps_existing_parameters():
+    eng = _fresh_engine(64, ['a0'], 'Uniform', seed=2)
+    before = eng.state_dict()
+    assert eng.add_addresses([('a1', 'Uniform', None), ('c', 'Categorical', 5)])
+    assert not eng.add_addresses([('a1', 'Uniform', None)])
+    after = eng.state_dict()
+    for n in before:
+        np.testing.assert_array_equal(before[n].numpy(), after[n].numpy())
+    assert eng.spec.num_parameters() > sum(v.numel() for v in before.values())
+    assert int(eng.tensor_step.sum().item()) == 0
+
+
+# ---- importance sampling ------------------------------------------------------------------------------------
+def _is_runner(eng):
+    from pyprob_amd.is_engine import ISRunner
+    return ISRunner(eng)
+
+
+def test_is_rescoring_matches_reference_records(golden):
+    """Re-score the reference-sampled particles: proposal log_prob, prior log_prob and the per-trace
+    log-importance-weight of state.py:211-217 / trace.py:123-125, within 1e-4 relative."""
+    case, meta, params, batch, loss, isr = golden
+    eng = engine_from_golden(meta, params)
+    run = _is_runner(eng)
+    run.init(isr['observe'])
+    addresses = meta['is_addresses']
+    off = np.concatenate([[0], np.cumsum(isr['trace_len'])])
+    lw_all = np.zeros(len(isr['trace_len']))
+    q_all = np.zeros(len(isr['value']))
+    for b in range(len(isr['trace_len'])):
+        run.begin(1)
+        prev = None
+        for t in range(int(isr['trace_len'][b])):
+            r = off[b] + t
+            a = eng.spec.address_id[addresses[isr['addr'][r]]]
+            info = eng.spec.addresses[a]
+            v = torch.tensor([isr['value'][r]], dtype=torch.float32, device=eng.device)
+            pr = torch.tensor(isr['prior'][r, :2].reshape(1, 2), dtype=torch.float32, device=eng.device)
+            _, logq = run.step(a, prev, pr, value_in=v)
+            q_all[r] = float(logq.item())
+            prev = a
+        lw_all[b] = 0.0
+    np.testing.assert_allclose(q_all, isr['prop_lp'], rtol=1e-4, atol=1e-4)
+    # trace log weight: sum_t (log p - log q) + observed likelihood terms (taken from the record)
+    lw = np.array([np.sum(isr['prior_lp'][off[b]:off[b + 1]] - q_all[off[b]:off[b + 1]]) for b in range(len(off) - 1)])
+    np.testing.assert_allclose(lw + isr['obs_lw'], isr['lw'], rtol=1e-4, atol=1e-4)
+
+
+def test_is_first_statement_is_shared_and_batched_matches_single():
+    """The first sample statement has identical LSTM input for every particle: the batched call (network evaluated
+    once) must equal N independent batch-1 calls."""
+    meta, params, batch, loss, isr = load_golden('gumm')
+    eng = engine_from_golden(meta, params)
+    run = _is_runner(eng)
+    run.init(isr['observe'])
+    a0 = eng.spec.address_id[meta['is_addresses'][0]]
+    a1 = eng.spec.address_id[meta['is_addresses'][1]]
+    n = 1000
+    vals = torch.linspace(-0.99, 0.99, n, device=eng.device)
+    prior = torch.tensor([[-1.0, 1.0]], device=eng.device)
+    run.begin(n)
+    _, q0 = run.step(a0, None, prior, value_in=vals)
+    _, q1 = run.step(a1, a0, prior, value_in=vals.flip(0))
+    q0, q1 = q0.cpu().numpy().copy(), q1.cpu().numpy().copy()
+    for i in (0, 17, 999):
+        run.begin(1)
+        _, s0 = run.step(a0, None, prior, value_in=vals[i:i + 1])
+        _, s1 = run.step(a1, a0, prior, value_in=vals.flip(0)[i:i + 1])
+        assert abs(float(s0.item()) - q0[i]) < 1e-5 and abs(float(s1.item()) - q1[i]) < 2e-5
+
+
+def test_is_sampling_distribution_and_weights():
+    """Device-side sampling: draws follow the proposal (moments of a Normal mixture), truncated draws stay inside
+    the support, self-normalised weights with q = proposal and target = proposal are all equal (ESS = N)."""
+    meta, params, batch, loss, isr = load_golden('gum')
+    eng = engine_from_golden(meta, params)
+    run = _is_runner(eng)
+    run.init(isr['observe'])
+    n = 200000
+    prior = torch.tensor([[1.0, 5.0 ** 0.5]], device=eng.device)
+    run.begin(n)
+    v, logq = run.step(0, None, prior, seed=1234)
+    mu, sd, p = [np.asarray(x, np.float64) for x in np.split(isr['prop_params'][0], 3)]
+    mean_ref = float((p * mu).sum())
+    var_ref = float((p * (sd ** 2 + mu ** 2)).sum() - mean_ref ** 2)
+    vs = v.cpu().numpy().astype(np.float64)
+    assert abs(vs.mean() - mean_ref) < 5 * np.sqrt(var_ref / n) + 1e-3
+    assert abs(vs.var() - var_ref) / var_ref < 0.03
+    # log q of the sampled values equals an independent evaluation of the mixture density
+    comp = O.normal_log_prob(vs[:2000, None], mu[None], sd[None])
+    np.testing.assert_allclose(logq.cpu().numpy()[:2000], O.mixture_log_prob(comp, np.tile(p, (2000, 1))), rtol=1e-4, atol=1e-4)
+    stats = run.stats(logq - logq, v)
+    assert abs(stats['ess'] - n) < 1e-6 * n
+    # determinism: same seed and offset -> same particles
+    run.begin(n)
+    v_again, _ = run.step(0, None, prior, seed=1234)
+    assert torch.equal(v, v_again)
+
+
+def test_is_truncated_sampling_stays_in_support():
+    meta, params, batch, loss, isr = load_golden('gumm')
+    eng = engine_from_golden(meta, params)
+    run = _is_runner(eng)
+    run.init(isr['observe'])
+    a0 = eng.spec.address_id[meta['is_addresses'][0]]
+    n = 100000
+    prior = torch.tensor([[-1.0, 1.0]], device=eng.device)
+    run.begin(n)
+    v, logq = run.step(a0, None, prior, seed=99)
+    vs = v.cpu().numpy()
+    assert np.all(np.isfinite(vs)) and vs.min() >= -1.0 and vs.max() < 1.0
+    assert np.all(np.isfinite(logq.cpu().numpy()))
+    # importance-weighted normalising constant of q over its support is 1: E_q[ 1/(2 q(v)) * 1 ] with uniform target
+    w = np.exp(-np.log(2.0) - logq.cpu().numpy().astype(np.float64))
+    assert abs(w.mean() - 1.0) < 0.05
+
+
+def test_gum_posterior_statistics_after_training():
+    """End to end on the analytically solvable GUM model (reference tests/test_inference.py:173-202 thresholds):
+    train on prior traces, run IS with the network for obs (8, 9): posterior mean 7.25, std sqrt(1/1.2)."""
+    from pyprob_amd.is_engine import gum_posterior
+    eng = _fresh_engine(64, ['mu'], 'Normal', seed=3)
+    rng = np.random.default_rng(0)
+    for it in range(600):
+        arrays = synthetic_gum_arrays(256, seed=int(rng.integers(1 << 30)))
+        eng.train_step(_packed(arrays, eng.spec).to(eng.device), lr=1e-3)
+    res = gum_posterior(eng, 50000, obs=(8.0, 9.0), seed=5)
+    assert abs(res['mean'] - 7.25) < 0.75
+    assert abs(res['std'] - np.sqrt(1 / 1.2)) < 0.75
+    assert res['ess'] > 0.15 * 50000
