@@ -136,8 +136,8 @@ def test_loss_is_permutation_invariant_and_additive():
 
 
 def test_adam_matches_torch_semantics():
-    """Several optimizer steps against the oracle's Adam, including tensors without gradient (skipped, step count
-    not advanced) -- torch.optim.Adam as the reference configures it (inference_network.py:348)."""
+    """Optimizer steps against the oracle's Adam fed with the SAME gradients, including tensors without gradient
+    (skipped, step count not advanced) -- torch.optim.Adam as the reference configures it (inference_network.py:348)."""
     meta, params, batch, loss, isr = load_golden('gumm')
     eng = engine_from_golden(meta, params)
     pb = packed_from_golden(meta, batch, eng.spec).to(eng.device)
@@ -145,25 +145,45 @@ def test_adam_matches_torch_semantics():
     M = {k: np.zeros_like(v) for k, v in P.items()}
     V = {k: np.zeros_like(v) for k, v in P.items()}
     names = list(eng.spec.tensors.keys())
-    for step in range(1, 4):
-        eng.train_step(pb, lr=1e-3)
+    act = eng.spec.active_mask(pb.cur_counts, pb.prev_counts)
+    for step in range(1, 5):
+        eng.loss(pb, backward=True)
+        g = eng.grad_dict()
+        eng.adam_step(1e-3, weight_decay=1e-5 if step == 4 else 0.0)
         torch.cuda.synchronize()
-        net = O.Net(P, meta['obs_names'], K=10)
-        out = O.loss_and_grads(net, batch, meta['addresses'], meta['dist_names'])
-        act = eng.spec.active_mask(pb.cur_counts, pb.prev_counts)
+        for i, n in enumerate(names):
+            if act[i]:
+                O.adam_step(P[n], g[n].astype(np.float64), M[n], V[n], step, 1e-3, weight_decay=1e-5 if step == 4 else 0.0)
+        sd = eng.state_dict()
+        worst = max(rel_err(sd[n].numpy(), P[n]) for n in names)
+        assert worst < 2e-6, (step, worst)
+    steps = eng.tensor_step.cpu().numpy()
+    assert np.all(steps[act > 0] == 4) and np.all(steps[act == 0] == 0)
+    for i, n in enumerate(names):       # untouched tensors are bit-identical
+        if not act[i]:
+            np.testing.assert_array_equal(sd[n].numpy(), params[n])
+
+
+def test_train_steps_track_the_oracle():
+    """Three full train steps (loss -> backward -> Adam) against the oracle doing the same in float64: the loss
+    trajectory agrees; parameters agree up to Adam's sign-sensitivity for near-zero gradients."""
+    meta, params, batch, loss, isr = load_golden('gum')
+    eng = engine_from_golden(meta, params)
+    pb = packed_from_golden(meta, batch, eng.spec).to(eng.device)
+    P = {k: v.astype(np.float64).copy() for k, v in params.items()}
+    M = {k: np.zeros_like(v) for k, v in P.items()}
+    V = {k: np.zeros_like(v) for k, v in P.items()}
+    act = eng.spec.active_mask(pb.cur_counts, pb.prev_counts)
+    names = list(eng.spec.tensors.keys())
+    for step in range(1, 4):
+        l = float(eng.train_step(pb, lr=1e-3).item())
+        out = O.loss_and_grads(O.Net(P, meta['obs_names'], K=10), batch, meta['addresses'], meta['dist_names'])
+        assert abs(l - out['loss']) < 1e-4 * abs(out['loss']), (step, l, out['loss'])
         for i, n in enumerate(names):
             if act[i]:
                 O.adam_step(P[n], out['grads'][n], M[n], V[n], step, 1e-3)
     sd = eng.state_dict()
-    worst = max(rel_err(sd[n].numpy(), P[n]) for n in names)
-    assert worst < 2e-4, worst
-    steps = eng.tensor_step.cpu().numpy()
-    act = eng.spec.active_mask(pb.cur_counts, pb.prev_counts)
-    assert np.all(steps[act > 0] == 3) and np.all(steps[act == 0] == 0)
-    # untouched tensors are bit-identical
-    for i, n in enumerate(names):
-        if not act[i]:
-            np.testing.assert_array_equal(sd[n].numpy(), params[n])
+    assert max(rel_err(sd[n].numpy(), P[n]) for n in names) < 5e-3
 
 
 def test_training_reduces_loss_on_gum():
