@@ -224,6 +224,10 @@ typedef struct pp_gemm_args {
     const float* mask; int64_t ldmask;  /* optional: result = mask[ix_c(m)*ldmask + n] > 0 ? result : 0 (ReLU backward) */
     int32_t relu;        /* result = max(result, 0) */
     int32_t accumulate;  /* C += result instead of C = result */
+    float*       colsum; /* optional [N]: colsum[n] += sum_m result[m,n] (after relu/mask): fused bias gradient */
+    int32_t split_k;     /* 0: one workgroup per tile walks all of K (bit-reproducible); 1: the library may spread K over
+                            several workgroups and combine with float atomics (used for the gradient products) */
+    int32_t _pad;
 } pp_gemm_args;
 
 /* C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ) on the fp32 matrix cores (nn.Linear / nn.LSTM GEMMs and their

@@ -24,7 +24,7 @@ int obs_grad(const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max
              const float* E, int64_t lde, float* dE, int64_t ldde, hipStream_t st);
 int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st);
 int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
-                  int H, hipStream_t st);
+                  int H, float* db, float* db2, hipStream_t st);
 int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
                  int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
                  hipStream_t st);
@@ -134,8 +134,8 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.dF1 = c.take<float>((int64_t)B * w.e4);
     w.dCat = c.take<float>((int64_t)B * w.e4);
     w.dObsH = c.take<float>((int64_t)B * w.maxohid4);
-    w.loss_acc = c.take<float>(64);
-    w.flag = c.take<int32_t>(64);
+    w.loss_acc = c.take<float>(128);   // one 512-byte region: [loss accumulator | non-finite flag], zeroed by one memset
+    w.flag = reinterpret_cast<int32_t*>(w.loss_acc ? w.loss_acc + 64 : nullptr);
     w.bytes = c.off + 256;
 }
 
@@ -170,6 +170,7 @@ static int linear_wgrad(const float* dz, int64_t lddz, const float* x, int64_t l
     g.C = dW; g.ldc = in;
     g.M = out; g.N = in; g.K = n;
     g.accumulate = 1;
+    g.split_k = 1;
     PP_TRY(gemm_f32(&g, st));
     if (db) PP_TRY(colsum_f32(dz, lddz, nullptr, n, out, db, db2, st));
     return 0;
@@ -177,7 +178,8 @@ static int linear_wgrad(const float* dz, int64_t lddz, const float* x, int64_t l
 
 // dx[n, in] (lddx, optional scatter idx) = (dz W) (* relu mask); W [out, in]
 static int linear_dgrad(const float* dz, int64_t lddz, const float* W, float* dx, int64_t lddx, const int32_t* dx_idx,
-                        const float* mask, int64_t ldmask, int n, int in, int out, bool accumulate, hipStream_t st) {
+                        const float* mask, int64_t ldmask, int n, int in, int out, bool accumulate, hipStream_t st,
+                        float* colsum = nullptr) {
     pp_gemm_args g{};
     g.A = dz; g.lda = lddz;
     g.B = W; g.ldb = in; g.b_kmajor = 1;
@@ -185,6 +187,8 @@ static int linear_dgrad(const float* dz, int64_t lddz, const float* W, float* dx
     g.M = n; g.N = in; g.K = out;
     g.mask = mask; g.ldmask = ldmask;
     g.accumulate = accumulate ? 1 : 0;
+    g.colsum = colsum;
+    g.split_k = 1;
     return gemm_f32(&g, st);
 }
 
@@ -223,8 +227,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         set_error("pp_ic_loss: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
         return PP_ENOSPACE;
     }
-    (void)hipMemsetAsync(w.loss_acc, 0, 256, st);
-    (void)hipMemsetAsync(w.flag, 0, 256, st);
+    (void)hipMemsetAsync(w.loss_acc, 0, 512, st);
     if (bwd && (flags & PP_LOSS_ZERO_GRADS)) (void)hipMemsetAsync(grads, 0, (size_t)net->n_params * sizeof(float), st);
 
     // ---------------- forward ----------------
@@ -275,8 +278,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const float* DY = w.DY + (int64_t)g0 * w.out4;
         float* dZ1 = w.dZ1 + (int64_t)g0 * w.hid4;
         PP_TRY(linear_wgrad(DY, w.out4, A1, w.hid4, nullptr, grads + ad.w2, grads + ad.b2, nullptr, n, ad.hid, ad.n_out, st));
-        PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st));
-        PP_TRY(linear_wgrad(dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, grads + ad.b1, nullptr, n, H, ad.hid, st));
+        PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st,
+                            grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
+        PP_TRY(linear_wgrad(dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, nullptr, nullptr, n, H, ad.hid, st));
         PP_TRY(linear_dgrad(dZ1, w.hid4, P + ad.w1, w.dH, H, bt->grp_rows + g0, nullptr, 0, n, H, ad.hid, false, st));
     }
     for (int t = T - 1; t >= 0; --t) {
@@ -284,14 +288,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
         float* Gt = w.G + (int64_t)r0 * 4 * H;
         const float* c_prev = t > 0 ? w.C + (int64_t)bt->row_off[t - 1] * H : nullptr;
-        PP_TRY(lstm_cell_bwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.dH + (int64_t)r0 * H, w.dC, n, n_next, H, st));
+        PP_TRY(lstm_cell_bwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.dH + (int64_t)r0 * H, w.dC, n, n_next, H,
+                             grads + net->b_ih, grads + net->b_hh, st));   // bias gradients fused
         if (t > 0)  // dh_{t-1} += dG_t W_hh
             PP_TRY(linear_dgrad(Gt, 4 * H, P + net->w_hh, w.dH + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0, n,
                                 H, 4 * H, true, st));
     }
     // LSTM parameter gradients
-    PP_TRY(linear_wgrad(w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, grads + net->b_ih, grads + net->b_hh, R, I,
-                        4 * H, st));
+    PP_TRY(linear_wgrad(w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, nullptr, nullptr, R, I, 4 * H, st));
     if (T > 1) {
         const int r1 = bt->row_off[1];
         PP_TRY(linear_wgrad(w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, nullptr, nullptr,
@@ -320,8 +324,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
-    PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st));
-    PP_TRY(linear_wgrad(w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, grads + net->fin_b0, nullptr, B, e, e, st));
+    PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st,
+                        grads + net->fin_b0));
+    PP_TRY(linear_wgrad(w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, nullptr, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dF1, w.e4, P + net->fin_w0, w.dCat, w.e4, nullptr, w.cat, w.e4, B, e, e, false, st));
     int ci = 0, co = 0;
     for (int o = 0; o < net->n_obs; ++o) {
@@ -329,9 +334,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(linear_wgrad(w.dCat + co, w.e4, w.obs_h[o], w.ohid4[o], nullptr, grads + net->obs_w1[o],
                             grads + net->obs_b1[o], nullptr, B, hid, out, st));
         PP_TRY(linear_dgrad(w.dCat + co, w.e4, P + net->obs_w1[o], w.dObsH, w.ohid4[o], nullptr, w.obs_h[o], w.ohid4[o], B,
-                            hid, out, false, st));
-        PP_TRY(linear_wgrad(w.dObsH, w.ohid4[o], bt->obs + ci, bt->obs_width, nullptr, grads + net->obs_w0[o],
-                            grads + net->obs_b0[o], nullptr, B, in, hid, st));
+                            hid, out, false, st, grads + net->obs_b0[o]));
+        PP_TRY(linear_wgrad(w.dObsH, w.ohid4[o], bt->obs + ci, bt->obs_width, nullptr, grads + net->obs_w0[o], nullptr,
+                            nullptr, B, in, hid, st));
         ci += in;
         co += out;
     }
@@ -398,7 +403,7 @@ int pp_lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int32_t 
 
 int pp_lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int32_t n,
                      int32_t n_next, int32_t H, void* stream) {
-    return pp::lstm_cell_bwd(G, c_prev, c, dh, dc_carry, n, n_next, H, pp::as_stream(stream));
+    return pp::lstm_cell_bwd(G, c_prev, c, dh, dc_carry, n, n_next, H, nullptr, nullptr, pp::as_stream(stream));
 }
 
 int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,

@@ -19,6 +19,8 @@
 //   * global->register prefetch of slab i+1 overlaps the MFMAs of slab i (two barriers per slab).
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace pp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,6 +36,7 @@ struct GemmParams {
     int M, N, K;
     const float* bias; const float* bias2;
     const float* mask; int64_t ldmask;
+    float* colsum;   // optional: colsum[n] += sum_m result[m, n] (bias gradients fused into the producing GEMM)
     int relu, accumulate;
 };
 
@@ -156,21 +159,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    Stager<BM, A_KM, VEC> sa;
-    Stager<BN, B_KM, VEC> sb;
-    const int nslab = (p.K + BK - 1) / BK;
-    sa.load(p.A, p.lda, p.a_idx, m0, p.M, 0, p.K, tid);
-    sb.load(p.B, p.ldb, p.b_idx, n0, p.N, 0, p.K, tid);
-    sa.store(As, tid);
-    sb.store(Bs, tid);
-    __syncthreads();
+    // split-K: blockIdx.z owns a contiguous range of K slabs and adds its partial tile with float atomics
+    const int nslab_total = (p.K + BK - 1) / BK;
+    const int per = (nslab_total + gridDim.z - 1) / gridDim.z;
+    const int s_begin = blockIdx.z * per;
+    const int nslab = min(nslab_total, s_begin + per) - s_begin;
+    if (nslab <= 0) return;
+    const bool split = gridDim.z > 1;
 
-    for (int slab = 0; slab < nslab; ++slab) {
-        const bool more = slab + 1 < nslab;
-        if (more) {
-            sa.load(p.A, p.lda, p.a_idx, m0, p.M, (slab + 1) * BK, p.K, tid);
-            sb.load(p.B, p.ldb, p.b_idx, n0, p.N, (slab + 1) * BK, p.K, tid);
-        }
+    // two register sets: the loads of slab i+2 are issued before the MFMAs of slab i and consumed after the MFMAs
+    // of slab i+1, so ~2 slabs of matrix work cover one HBM/L2 round trip.
+    Stager<BM, A_KM, VEC> sa0, sa1;
+    Stager<BN, B_KM, VEC> sb0, sb1;
+    auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
             float a[TM][4], b[TN][4];
@@ -186,43 +187,83 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        if (more) {
-            sa.store(As, tid);
-            sb.store(Bs, tid);
-            __syncthreads();
+    };
+    sa0.load(p.A, p.lda, p.a_idx, m0, p.M, s_begin * BK, p.K, tid);
+    sb0.load(p.B, p.ldb, p.b_idx, n0, p.N, s_begin * BK, p.K, tid);
+    if (nslab > 1) {
+        sa1.load(p.A, p.lda, p.a_idx, m0, p.M, (s_begin + 1) * BK, p.K, tid);
+        sb1.load(p.B, p.ldb, p.b_idx, n0, p.N, (s_begin + 1) * BK, p.K, tid);
+    }
+    sa0.store(As, tid);
+    sb0.store(Bs, tid);
+    __syncthreads();
+    for (int i = 0; i < nslab; i += 2) {
+        // LDS holds slab i, set 1 holds slab i+1 (in flight), set 0 is free
+        if (i + 2 < nslab) {
+            sa0.load(p.A, p.lda, p.a_idx, m0, p.M, (s_begin + i + 2) * BK, p.K, tid);
+            sb0.load(p.B, p.ldb, p.b_idx, n0, p.N, (s_begin + i + 2) * BK, p.K, tid);
         }
+        compute();
+        if (i + 1 >= nslab) break;
+        __syncthreads();
+        sa1.store(As, tid);
+        sb1.store(Bs, tid);
+        __syncthreads();
+        // LDS holds slab i+1, set 0 holds slab i+2 (in flight), set 1 is free
+        if (i + 3 < nslab) {
+            sa1.load(p.A, p.lda, p.a_idx, m0, p.M, (s_begin + i + 3) * BK, p.K, tid);
+            sb1.load(p.B, p.ldb, p.b_idx, n0, p.N, (s_begin + i + 3) * BK, p.K, tid);
+        }
+        compute();
+        if (i + 2 >= nslab) break;
+        __syncthreads();
+        sa0.store(As, tid);
+        sb0.store(Bs, tid);
+        __syncthreads();
     }
 
     // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool lead = blockIdx.z == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int gn = n0 + wn * WN + j * 32 + l31;
-            if (gn >= p.N) continue;
+            const bool ncol = gn < p.N;
             float bsum = 0.0f;
-            if (p.bias) bsum += p.bias[gn];
-            if (p.bias2) bsum += p.bias2[gn];
+            if (ncol && lead) {
+                if (p.bias) bsum += p.bias[gn];
+                if (p.bias2) bsum += p.bias2[gn];
+            }
+            float csum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (gm >= p.M) continue;
+                if (!ncol || gm >= p.M) continue;
                 const int64_t cm = p.c_idx ? (int64_t)p.c_idx[gm] : (int64_t)gm;
                 float v = acc[i][j][r] + bsum;
-                if (p.relu) v = fmaxf(v, 0.0f);
-                if (p.mask) v = (p.mask[cm * p.ldmask + gn] > 0.0f) ? v : 0.0f;
                 float* dst = p.C + cm * p.ldc + gn;
-                if (p.accumulate) v += *dst;
-                *dst = v;
+                if (split) {
+                    atomicAdd(dst, v);
+                } else {
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (p.mask) v = (p.mask[cm * p.ldmask + gn] > 0.0f) ? v : 0.0f;
+                    csum += v;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+            if (p.colsum && !split) {   // wave-uniform condition
+                csum += __shfl_xor(csum, 32, 64);
+                if (h == 0 && ncol) atomicAdd(p.colsum + gn, csum);
             }
         }
     }
 }
 
 template <int BM, int BN, int WM, int WN, int VEC>
-static int launch_layout(const GemmParams& p, bool akm, bool bkm, hipStream_t st) {
-    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM));
+static int launch_layout(const GemmParams& p, bool akm, bool bkm, int splits, hipStream_t st) {
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), splits);
     dim3 block(256);
     if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC>), grid, block, 0, st, p);
     else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC>), grid, block, 0, st, p);
@@ -245,17 +286,36 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.bias = a->bias; p.bias2 = a->bias2; p.mask = a->mask; p.ldmask = a->ldmask;
     p.relu = a->relu; p.accumulate = a->accumulate;
+    p.colsum = a->colsum;
     const bool vec = (a->lda % 4 == 0) && (a->ldb % 4 == 0) && aligned16(a->A) && aligned16(a->B);
     // Tile choice: the hot-path GEMMs are small (<= a few thousand rows); 64x64 tiles give >= 2 workgroups per CU
     // on the 1024x2048x212 input GEMM. Very tall problems (batched IS) use 128x128 tiles.
     const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
     const bool big = tiles64 >= 4096 && a->N >= 128;
-    if (big) {
-        return vec ? launch_layout<128, 128, 64, 64, 4>(p, a->a_kmajor, a->b_kmajor, st)
-                   : launch_layout<128, 128, 64, 64, 1>(p, a->a_kmajor, a->b_kmajor, st);
+    // Split-K: the weight-gradient products have K = rows of the batch and only a handful of output tiles; one
+    // workgroup per tile would walk dozens of slabs serially while most CUs idle. Spread the slabs over
+    // ~2 workgroups per CU and combine with float atomics (the gradient buffers are zero-initialised accumulators).
+    // Only for linear epilogues into a dense or pre-zeroed destination.
+    int splits = 1;
+    const int nslab = cdiv(a->K, BK);
+    const bool linear = !a->relu && !a->mask && !a->colsum;
+    if (a->split_k && !big && linear && nslab >= 4 && tiles64 < 384 && (a->accumulate || !a->c_idx)) {
+        splits = (int)std::min<int64_t>(std::min<int64_t>((512 + tiles64 - 1) / tiles64, nslab / 2), 32);
+        if (splits < 1) splits = 1;
     }
-    return vec ? launch_layout<64, 64, 32, 32, 4>(p, a->a_kmajor, a->b_kmajor, st)
-               : launch_layout<64, 64, 32, 32, 1>(p, a->a_kmajor, a->b_kmajor, st);
+    if (splits > 1 && !a->accumulate) {   // partial tiles are added atomically: start from zero
+        hipError_t e = hipMemset2DAsync(a->C, (size_t)a->ldc * sizeof(float), 0, (size_t)a->N * sizeof(float), a->M, st);
+        if (e != hipSuccess) {
+            set_error("pp_gemm_f32: hipMemset2DAsync failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    if (big) {
+        return vec ? launch_layout<128, 128, 64, 64, 4>(p, a->a_kmajor, a->b_kmajor, 1, st)
+                   : launch_layout<128, 128, 64, 64, 1>(p, a->a_kmajor, a->b_kmajor, 1, st);
+    }
+    return vec ? launch_layout<64, 64, 32, 32, 4>(p, a->a_kmajor, a->b_kmajor, splits, st)
+               : launch_layout<64, 64, 32, 32, 1>(p, a->a_kmajor, a->b_kmajor, splits, st);
 }
 
 }  // namespace pp

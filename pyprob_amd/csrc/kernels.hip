@@ -23,7 +23,7 @@ const char* last_error() { return g_err; }
 // out[c] += sum_i X[ix(i)*ldx + c]
 // 256 threads = 64 columns x 4 row lanes; each workgroup reduces ROWS_PER_BLOCK rows, one atomic per column.
 // ------------------------------------------------------------------------------------------------------
-constexpr int COLSUM_ROWS = 256;
+constexpr int COLSUM_ROWS = 64;
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx,
                                                      const int32_t* __restrict__ idx, int n_rows, int n_cols,
@@ -33,13 +33,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     const int cl = tid & 63, rl = tid >> 6;
     const int col = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * COLSUM_ROWS;
-    const int r1 = min(n_rows, r0 + COLSUM_ROWS);
     float acc = 0.0f;
     if (col < n_cols) {
-        for (int i = r0 + rl; i < r1; i += 4) {
-            const int64_t r = idx ? (int64_t)idx[i] : (int64_t)i;
-            acc += X[r * ldx + col];
+        // 16 rows per lane, all loads issued before the adds (independent addresses: latency overlaps)
+        float v[COLSUM_ROWS / 4];
+#pragma unroll
+        for (int q = 0; q < COLSUM_ROWS / 4; ++q) {
+            const int i = r0 + rl + 4 * q;
+            v[q] = 0.0f;
+            if (i < n_rows) {
+                const int64_t r = idx ? (int64_t)idx[i] : (int64_t)i;
+                v[q] = X[r * ldx + col];
+            }
         }
+#pragma unroll
+        for (int q = 0; q < COLSUM_ROWS / 4; ++q) acc += v[q];
     }
     part[rl][cl] = acc;
     __syncthreads();
@@ -241,13 +249,20 @@ int obs_grad(const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max
 // ------------------------------------------------------------------------------------------------------
 // LSTM cell (torch.nn.LSTM gate order i, f, g, o)
 // ------------------------------------------------------------------------------------------------------
+constexpr int CELL_ROWS = 8;    // rows per workgroup; 256 threads = 64 hidden units x 4 row lanes
+
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ G, const float* __restrict__ c_prev,
                                                             float* __restrict__ c, float* __restrict__ h, int n,
                                                             int H) {
-    const int64_t total = (int64_t)n * H;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int r = (int)(e / H), j = (int)(e - (int64_t)r * H);
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    if (j >= H) return;
+#pragma unroll
+    for (int q = 0; q < CELL_ROWS / 4; ++q) {
+        const int r = blockIdx.y * CELL_ROWS + rl + 4 * q;
+        if (r >= n) break;
         float* g = G + (int64_t)r * 4 * H;
+        const int64_t e = (int64_t)r * H + j;
         const float gi = sigmoidf_(g[j]);
         const float gf = sigmoidf_(g[H + j]);
         const float gg = tanhf(g[2 * H + j]);
@@ -266,9 +281,7 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ 
 int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st) {
     PP_CHECK_ARG(G && c && h && H > 0, "pp_lstm_cell_fwd: bad argument");
     if (n <= 0) return 0;
-    const int64_t total = (int64_t)n * H;
-    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(blocks), dim3(256), 0, st, G, c_prev, c, h, n, H);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(H, 64), cdiv(n, CELL_ROWS)), dim3(256), 0, st, G, c_prev, c, h, n, H);
     PP_LAUNCH_CHECK("pp_lstm_cell_fwd");
     return 0;
 }
@@ -276,31 +289,51 @@ int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int 
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ G, const float* __restrict__ c_prev,
                                                             const float* __restrict__ c,
                                                             const float* __restrict__ dh,
-                                                            float* __restrict__ dc_carry, int n, int n_next, int H) {
-    const int64_t total = (int64_t)n * H;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int r = (int)(e / H), j = (int)(e - (int64_t)r * H);
-        float* g = G + (int64_t)r * 4 * H;
-        const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
-        const float tc = tanhf(c[e]);
-        const float dhv = dh[e];
-        const float dc = (r < n_next ? dc_carry[e] : 0.0f) + dhv * go * (1.0f - tc * tc);
-        const float cp = c_prev ? c_prev[e] : 0.0f;
-        g[j] = dc * gg * gi * (1.0f - gi);
-        g[H + j] = dc * cp * gf * (1.0f - gf);
-        g[2 * H + j] = dc * gi * (1.0f - gg * gg);
-        g[3 * H + j] = dhv * tc * go * (1.0f - go);
-        dc_carry[e] = dc * gf;
+                                                            float* __restrict__ dc_carry, int n, int n_next, int H,
+                                                            float* __restrict__ db, float* __restrict__ db2) {
+    __shared__ float part[4][4][64];
+    const int jl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < H) {
+#pragma unroll
+        for (int q = 0; q < CELL_ROWS / 4; ++q) {
+            const int r = blockIdx.y * CELL_ROWS + rl + 4 * q;
+            if (r >= n) break;
+            float* g = G + (int64_t)r * 4 * H;
+            const int64_t e = (int64_t)r * H + j;
+            const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+            const float tc = tanhf(c[e]);
+            const float dhv = dh[e];
+            const float dc = (r < n_next ? dc_carry[e] : 0.0f) + dhv * go * (1.0f - tc * tc);
+            const float cp = c_prev ? c_prev[e] : 0.0f;
+            const float d0 = dc * gg * gi * (1.0f - gi);
+            const float d1 = dc * cp * gf * (1.0f - gf);
+            const float d2 = dc * gi * (1.0f - gg * gg);
+            const float d3 = dhv * tc * go * (1.0f - go);
+            g[j] = d0; g[H + j] = d1; g[2 * H + j] = d2; g[3 * H + j] = d3;
+            dc_carry[e] = dc * gf;
+            s0 += d0; s1 += d1; s2 += d2; s3 += d3;
+        }
+    }
+    if (!db) return;
+    // fused bias gradient: db[gate*H + j] += sum over this workgroup's rows
+    part[rl][0][jl] = s0; part[rl][1][jl] = s1; part[rl][2][jl] = s2; part[rl][3][jl] = s3;
+    __syncthreads();
+    if (j < H) {
+        const int gate = rl;
+        const float t = part[0][gate][jl] + part[1][gate][jl] + part[2][gate][jl] + part[3][gate][jl];
+        atomicAdd(db + gate * H + j, t);
+        if (db2) atomicAdd(db2 + gate * H + j, t);
     }
 }
 
 int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
-                  int H, hipStream_t st) {
+                  int H, float* db, float* db2, hipStream_t st) {
     PP_CHECK_ARG(G && c && dh && dc_carry && H > 0 && n_next <= n, "pp_lstm_cell_bwd: bad argument");
     if (n <= 0) return 0;
-    const int64_t total = (int64_t)n * H;
-    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks), dim3(256), 0, st, G, c_prev, c, dh, dc_carry, n, n_next, H);
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(H, 64), cdiv(n, CELL_ROWS)), dim3(256), 0, st, G, c_prev, c, dh,
+                       dc_carry, n, n_next, H, db, db2);
     PP_LAUNCH_CHECK("pp_lstm_cell_bwd");
     return 0;
 }
@@ -394,14 +427,14 @@ __device__ __forceinline__ float mixture_logprob(const MixtureParams& m, int K, 
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void head_mixture_kernel(const float* __restrict__ Y, int64_t ldy,
+__global__ __launch_bounds__(64) void head_mixture_kernel(const float* __restrict__ Y, int64_t ldy,
                                                            const int32_t* __restrict__ rows,
                                                            const float* __restrict__ value,
                                                            const float* __restrict__ prior, int n, int K,
                                                            float grad_scale, float* __restrict__ lp_out,
                                                            float* __restrict__ DY, float* __restrict__ loss_acc,
                                                            int32_t* __restrict__ nonfinite) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;
     float contrib = 0.0f;
     bool bad = false;
     if (i < n) {
@@ -471,13 +504,13 @@ __global__ __launch_bounds__(256) void head_mixture_kernel(const float* __restri
 }
 
 // Categorical head: probs = softmax(y) + 1e-8, renormalised and clamped by torch.distributions.Categorical.
-__global__ __launch_bounds__(256) void head_categorical_kernel(const float* __restrict__ Y, int64_t ldy,
+__global__ __launch_bounds__(64) void head_categorical_kernel(const float* __restrict__ Y, int64_t ldy,
                                                                const int32_t* __restrict__ rows,
                                                                const float* __restrict__ value, int n, int C,
                                                                float grad_scale, float* __restrict__ lp_out,
                                                                float* __restrict__ DY, float* __restrict__ loss_acc,
                                                                int32_t* __restrict__ nonfinite) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;
     float contrib = 0.0f;
     bool bad = false;
     if (i < n) {
@@ -525,7 +558,7 @@ int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, con
                  hipStream_t st) {
     PP_CHECK_ARG(y && value, "pp_head_logprob: null pointer");
     if (n <= 0) return 0;
-    dim3 grid(cdiv(n, 256)), block(256);
+    dim3 grid(cdiv(n, 64)), block(64);   // one wavefront per workgroup: spread the transcendental-heavy rows over CUs
     if (kind == PP_HEAD_CATEGORICAL) {
         hipLaunchKernelGGL(head_categorical_kernel, grid, block, 0, st, y, ldy, rows, value, n, n_out, grad_scale,
                            lp_out, dy, loss_acc, nonfinite);

@@ -26,7 +26,6 @@ class ICEngine:
         self.workspace = None
         self.ws_bytes = 0
         self.ws_shape = (0, 0)
-        self.loss_buf = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.status_buf = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.world_size = 1
         self._resize(initialise=list(spec.tensors.keys()))
@@ -51,6 +50,7 @@ class ICEngine:
         self.grads_full = torch.zeros(n + spec.n_tensors + 1, dtype=torch.float32, device=self.device)
         self.grads = self.grads_full[:n]
         self.active = self.grads_full[n:n + spec.n_tensors]
+        self.loss_buf = self.grads_full[n + spec.n_tensors:]     # the loss kernel writes straight into the tail
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.tensor_step = torch.zeros(spec.n_tensors, dtype=torch.int32, device=self.device)
@@ -59,6 +59,7 @@ class ICEngine:
         self.addr_table = torch.from_numpy(spec.address_table()).to(self.device)
         self.net = spec.c_struct(self.addr_table.data_ptr())
         self._active_cache = {}
+        self._active_key = None
         self.ws_shape = (0, 0)
 
     def add_addresses(self, items):
@@ -127,12 +128,14 @@ class ICEngine:
 
     def _set_active(self, batch):
         key = (tuple(batch.cur_counts > 0), tuple(batch.prev_counts > 0))
+        if key == self._active_key and self.world_size == 1:
+            return          # presence map already in place (it is only overwritten by the DP all-reduce)
         act = self._active_cache.get(key)
         if act is None:
             act = torch.from_numpy(self.spec.active_mask(batch.cur_counts, batch.prev_counts)).to(self.device)
             self._active_cache[key] = act
         self.active.copy_(act)
-        self.grads_full[-1:].copy_(self.loss_buf[:1])
+        self._active_key = key
 
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
         """optimizer.step() for optim.Adam (inference_network.py:348,496); grads are divided by world_size first

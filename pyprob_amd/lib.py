@@ -46,7 +46,8 @@ class pp_gemm_args(C.Structure):
                 ('B', vp), ('ldb', i64), ('b_idx', vp),
                 ('C', vp), ('ldc', i64), ('c_idx', vp),
                 ('M', i32), ('N', i32), ('K', i32), ('a_kmajor', i32), ('b_kmajor', i32),
-                ('bias', vp), ('bias2', vp), ('mask', vp), ('ldmask', i64), ('relu', i32), ('accumulate', i32)]
+                ('bias', vp), ('bias2', vp), ('mask', vp), ('ldmask', i64), ('relu', i32), ('accumulate', i32),
+                ('colsum', vp), ('split_k', i32), ('_pad', i32)]
 
 
 # name -> (restype, argtypes); every symbol include/pyprob_amd.h declares

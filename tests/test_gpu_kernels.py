@@ -26,7 +26,7 @@ def dev(a, device, dtype=None):
 
 
 def run_gemm(env, A, B, M, N, K, akm, bkm, a_idx=None, b_idx=None, c_idx=None, bias=None, bias2=None, mask=None,
-             relu=False, acc_init=None, c_rows=None, lda=None, ldb=None):
+             relu=False, acc_init=None, c_rows=None, lda=None, ldb=None, split_k=0):
     L, lib, device = env
     dA, dB = dev(A, device), dev(B, device)
     crow = M if c_rows is None else c_rows
@@ -53,6 +53,7 @@ def run_gemm(env, A, B, M, N, K, akm, bkm, a_idx=None, b_idx=None, c_idx=None, b
         g.mask, g.ldmask = t.data_ptr(), mask.shape[1]
     g.M, g.N, g.K, g.a_kmajor, g.b_kmajor = M, N, K, int(akm), int(bkm)
     g.relu, g.accumulate = int(relu), int(acc_init is not None)
+    g.split_k = int(split_k)
     L.check(lib.pp_gemm_f32(C.byref(g), L.stream_ptr()), 'pp_gemm_f32')
     torch.cuda.synchronize()
     return dC.cpu().numpy()
@@ -127,6 +128,43 @@ def test_gemm_gather_scatter_epilogue(env):
     got = run_gemm(env, A, B, M, N, K, False, False, mask=mask)
     ref = np.where(mask > 0, ref_gemm(A, B, M, N, K, False, False, None, None), 0)
     np.testing.assert_allclose(got[:, :N], ref, rtol=2e-6, atol=2e-6)
+
+
+def test_gemm_split_k_and_fused_colsum(env):
+    """Deep-K / few-tile products take the split-K path (float atomics); masked dgrad products can emit the column
+    sums (bias gradient) from the epilogue."""
+    L, lib, device = env
+    rng = np.random.default_rng(21)
+    for (M, N, K, akm, bkm) in [(64, 64, 1024, True, True), (2048, 212, 1024, True, True), (1024, 212, 2048, False, True),
+                                (271, 512, 1000, True, True)]:
+        a_rows, a_cols = (K, M) if akm else (M, K)
+        b_rows, b_cols = (K, N) if bkm else (N, K)
+        A = rng.uniform(-1, 1, (a_rows, ((a_cols + 3) // 4) * 4)).astype(np.float32)
+        B = rng.uniform(-1, 1, (b_rows, ((b_cols + 3) // 4) * 4)).astype(np.float32)
+        ref = ref_gemm(A, B, M, N, K, akm, bkm, None, None)
+        got = run_gemm(env, A, B, M, N, K, akm, bkm, split_k=1)[:, :N]           # fresh destination (memset inside)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-6, (M, N, K)
+        init = rng.uniform(-1, 1, (M, N + 3)).astype(np.float32)
+        got = run_gemm(env, A, B, M, N, K, akm, bkm, acc_init=init, split_k=1)[:, :N]   # accumulate onto existing values
+        again = run_gemm(env, A, B, M, N, K, akm, bkm)[:, :N]                    # split_k=0 is bit-reproducible
+        assert np.array_equal(again, run_gemm(env, A, B, M, N, K, akm, bkm)[:, :N])
+        assert np.abs(got - (ref + init[:, :N])).max() / np.abs(ref).max() < 3e-6, (M, N, K)
+    # fused colsum with mask
+    M, N, K = 1000, 271, 30
+    A = rng.uniform(-1, 1, (M, 32)).astype(np.float32)
+    B = rng.uniform(-1, 1, (K, 272)).astype(np.float32)
+    mask = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    dA, dB, dM = dev(A, device), dev(B, device), dev(mask, device)
+    dC = torch.zeros(M, N + 1, device=device)
+    cs = torch.ones(N, device=device)
+    g = L.pp_gemm_args()
+    g.A, g.lda, g.B, g.ldb, g.b_kmajor = dA.data_ptr(), 32, dB.data_ptr(), 272, 1
+    g.C, g.ldc, g.M, g.N, g.K = dC.data_ptr(), N + 1, M, N, K
+    g.mask, g.ldmask, g.colsum = dM.data_ptr(), N, cs.data_ptr()
+    L.check(lib.pp_gemm_f32(C.byref(g), L.stream_ptr()))
+    ref = np.where(mask > 0, A[:, :K].astype(np.float64) @ B[:, :N].astype(np.float64), 0)
+    np.testing.assert_allclose(dC.cpu().numpy()[:, :N], ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), 1 + ref.sum(0), rtol=1e-4, atol=1e-3)
 
 
 def test_gemm_large_tile_path(env):

@@ -32,7 +32,7 @@ def test_struct_sizes_match_header_layout():
     import ctypes as C
     from pyprob_amd import lib as L
     assert C.sizeof(L.pp_addr) == 6 * 4 + 8 * 8
-    assert C.sizeof(L.pp_gemm_args) == 9 * 8 + 5 * 4 + 4 + 4 * 8 + 2 * 4  # incl. padding after b_kmajor
+    assert C.sizeof(L.pp_gemm_args) == 9 * 8 + 5 * 4 + 4 + 4 * 8 + 2 * 4 + 8 + 8  # incl. padding after b_kmajor
     assert C.sizeof(L.pp_batch) % 8 == 0
 
 
