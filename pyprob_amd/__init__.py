@@ -2,3 +2,15 @@
 API. Hand-written HIP (gfx950) behind a C ABI (include/pyprob_amd.h); PyTorch-ROCm is used for HBM allocation,
 streams and torch.distributed only."""
 __version__ = '0.1.0'
+
+
+def __getattr__(name):
+    """Lazy pyprob-style top level: pyprob_amd.sample / observe / Model / InferenceEngine ... (importing the package
+    must not require torch or a GPU)."""
+    if name in ('sample', 'observe', 'TraceMode', 'InferenceEngine'):
+        from . import state
+        return getattr(state, name)
+    if name == 'Model':
+        from .model import Model
+        return Model
+    raise AttributeError(name)

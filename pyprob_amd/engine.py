@@ -159,8 +159,8 @@ class ICEngine:
     def allreduce_grads(self):
         """ONE RCCL all-reduce (SUM) over [flat grads | presence map | loss]
         (replaces the per-tensor loop of _distributed_sync_grad, inference_network.py:296-333)."""
-        import torch.distributed as dist
-        dist.all_reduce(self.grads_full)
+        from .parallel import allreduce_flat_
+        allreduce_flat_(self.grads_full)
 
     def broadcast_params(self):
         """_distributed_sync_parameters (inference_network.py:290-294) as one broadcast of the flat buffer."""

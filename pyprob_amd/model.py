@@ -1,0 +1,124 @@
+"""Model facade for the hot path (mirror of pyprob/model.py:24-215): prior, posterior_results with importance
+sampling (with or without the inference network), learn_inference_network, save/load_inference_network."""
+import time
+
+import torch
+
+from . import state
+from .distributions import Empirical
+from .nn import InferenceNetworkLSTM, OnlineDataset
+from .state import InferenceEngine, TraceMode
+
+
+def trace_result(trace):
+    return trace.result
+
+
+class Model:
+    def __init__(self, name='Unnamed PyProb model'):
+        self.name = name
+        self._inference_network = None
+
+    def forward(self):
+        raise RuntimeError('Model instances must provide a forward method.')
+
+    def _trace_generator(self, trace_mode=TraceMode.PRIOR, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING,
+                         inference_network=None, observe=None, likelihood_importance=1., *args, **kwargs):
+        """pyprob/model.py:39-45"""
+        state._init_traces(func=self.forward, trace_mode=trace_mode, inference_engine=inference_engine,
+                           inference_network=inference_network, observe=observe, likelihood_importance=likelihood_importance)
+        while True:
+            state._begin_trace()
+            result = self.forward(*args, **kwargs)
+            yield state._end_trace(result)
+
+    def _traces(self, num_traces=10, trace_mode=TraceMode.PRIOR, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING,
+                inference_network=None, map_func=None, observe=None, likelihood_importance=1., *args, **kwargs):
+        """pyprob/model.py:47-88: one particle per forward() run; non-finite weights are discarded."""
+        gen = self._trace_generator(trace_mode=trace_mode, inference_engine=inference_engine,
+                                    inference_network=inference_network, observe=observe,
+                                    likelihood_importance=likelihood_importance, *args, **kwargs)
+        traces = Empirical()
+        map_func = map_func or (lambda t: t)
+        for _ in range(num_traces):
+            trace = next(gen)
+            lw = 1. if trace_mode == TraceMode.PRIOR else trace.log_importance_weight
+            if lw != lw or lw in (float('inf'), float('-inf')):
+                continue
+            traces.add(map_func(trace), lw)
+        return traces.finalize()
+
+    def _traces_lockstep(self, num_traces, observe, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
+        """All particles of this rank advance through forward() together (straight-line programs)."""
+        net = self._inference_network
+        runner = net._is
+        ls = state.LockStepState(runner, num_traces, seed, offset)
+        state._init_traces(func=self.forward, trace_mode=TraceMode.POSTERIOR,
+                           inference_engine=InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
+                           inference_network=net, observe=observe, likelihood_importance=likelihood_importance, lock_step=ls)
+        runner.begin(num_traces, offset=offset)
+        state._begin_trace()
+        try:
+            result = self.forward(*args, **kwargs)
+        finally:
+            state._lock_step = None
+            state._current_trace = None
+        emp = Empirical(values=result, log_weights=ls.lw)
+        emp.finalize()
+        emp.device_stats = runner.stats(ls.lw, result if torch.is_tensor(result) else None)
+        return emp
+
+    def prior_results(self, num_traces=10, *args, **kwargs):
+        return self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=trace_result, *args, **kwargs)
+
+    def posterior_results(self, num_traces=10, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING, observe=None,
+                          lock_step=False, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
+        """pyprob/model.py:106-117,180-181 for the IS engines. lock_step=True runs all particles together on the
+        device (programs without data-dependent Python control flow)."""
+        if inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK:
+            if self._inference_network is None:
+                raise RuntimeError('Cannot run inference engine IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK because no '
+                                   'inference network for this model is available. Use learn_inference_network or '
+                                   'load_inference_network first.')
+            if lock_step:
+                post = self._traces_lockstep(num_traces, observe, seed=seed, offset=offset,
+                                             likelihood_importance=likelihood_importance, *args, **kwargs)
+            else:
+                post = self._traces(num_traces, TraceMode.POSTERIOR, inference_engine, self._inference_network,
+                                    trace_result, observe, likelihood_importance, *args, **kwargs)
+            post.rename('Posterior, IC, traces: {:,}, ESS: {:,.2f}'.format(post.length, post.effective_sample_size))
+        else:
+            post = self._traces(num_traces, TraceMode.POSTERIOR, inference_engine, None, trace_result, observe,
+                                likelihood_importance, *args, **kwargs)
+            post.rename('Posterior, IS, traces: {:,}, ESS: {:,.2f}'.format(post.length, post.effective_sample_size))
+        return post
+
+    def learn_inference_network(self, num_traces, observe_embeddings={}, batch_size=64, lstm_dim=512, lstm_depth=1,
+                                proposal_mixture_components=10, learning_rate_init=0.001, learning_rate_end=1e-6,
+                                learning_rate_scheduler_type=None, weight_decay=0., distributed_backend=None,
+                                device='cuda:0', seed=None, dataset=None, log_file_name=None):
+        """pyprob/model.py:186-215 with inference_network=InferenceNetwork.LSTM."""
+        if dataset is None:
+            dataset = OnlineDataset(model=self)
+        if self._inference_network is None:
+            print('Creating new inference network...')
+            self._inference_network = InferenceNetworkLSTM(model=self, observe_embeddings=observe_embeddings,
+                                                           lstm_dim=lstm_dim, lstm_depth=lstm_depth,
+                                                           proposal_mixture_components=proposal_mixture_components,
+                                                           device=device, seed=seed)
+        else:
+            print('Continuing to train existing inference network...')
+        self._inference_network.optimize(num_traces=num_traces, dataset=dataset, batch_size=batch_size,
+                                         learning_rate_init=learning_rate_init, learning_rate_end=learning_rate_end,
+                                         learning_rate_scheduler_type=learning_rate_scheduler_type,
+                                         weight_decay=weight_decay, distributed_backend=distributed_backend,
+                                         log_file_name=log_file_name)
+
+    def save_inference_network(self, file_name):
+        if self._inference_network is None:
+            raise RuntimeError('The model has no trained inference network.')
+        self._inference_network._save(file_name)
+
+    def load_inference_network(self, file_name, device='cuda:0'):
+        self._inference_network = InferenceNetworkLSTM._load(file_name, device=device)
+        self._inference_network._model = self

@@ -1,0 +1,378 @@
+"""Host-side mirror of pyprob.nn for the hot path: Batch, OnlineDataset, InferenceNetworkLSTM.
+
+Same names, argument meaning and error behaviour as the reference (pyprob/nn/dataset.py:21-62,
+pyprob/nn/inference_network.py:25-599, pyprob/nn/inference_network_lstm.py:11-220); the arithmetic is the HIP
+engine's (`ICEngine`, one C-ABI call per loss / optimizer step / IS statement).
+"""
+import math
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .engine import ICEngine
+from .is_engine import ISRunner
+from .packed import PackedBatch, pack_traces
+from .spec import NetSpec
+
+
+class Batch:
+    """pyprob/nn/dataset.py:21-47: a minibatch of traces, sub-batched by address sequence."""
+
+    def __init__(self, traces):
+        self.traces = traces
+        self.size = len(traces)
+        sub_batches = {}
+        total = 0
+        for trace in traces:
+            tl = trace.length_controlled
+            if tl == 0:
+                raise ValueError('Trace of length zero.')
+            total += tl
+            h = ''.join([v.address for v in trace.variables_controlled])
+            sub_batches.setdefault(h, []).append(trace)
+        self.sub_batches = list(sub_batches.values())
+        self.mean_length_controlled = total / self.size
+
+    def __len__(self):
+        return len(self.traces)
+
+    def __getitem__(self, key):
+        return self.traces[key]
+
+
+class OnlineDataset:
+    """pyprob/nn/dataset.py:50-62: every item runs the model once in PRIOR_FOR_INFERENCE_NETWORK mode."""
+
+    def __init__(self, model, length=None):
+        self._model = model
+        self._length = int(1e6) if length is None else length
+
+    def __len__(self):
+        return self._length
+
+    def __getitem__(self, idx):
+        from .state import TraceMode
+        return next(self._model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK))
+
+
+class ProposalSample:
+    """What `_infer_step` returns: the proposal of one controlled variable, already sampled and scored on the device
+    (reference: a Mixture/Categorical object with .sample() and .log_prob(value, sum=True))."""
+
+    def __init__(self, value, log_q):
+        self._value, self._log_q = value, log_q
+
+    def sample(self):
+        return self._value
+
+    def log_prob(self, value, sum=False):
+        # state.sample scores exactly the value it just drew (state.py:208-212)
+        return self._log_q[0] if sum else self._log_q
+
+
+class InferenceNetworkLSTM:
+    # observe_embeddings example: {'obs1': {'dim': 32}}   (FEEDFORWARD, depth 2)
+    def __init__(self, model=None, observe_embeddings={}, lstm_dim=512, lstm_depth=1, sample_embedding_dim=4,
+                 address_embedding_dim=64, distribution_type_embedding_dim=8, proposal_mixture_components=10,
+                 device='cuda:0', seed=None):
+        if lstm_depth != 1:
+            raise ValueError('pyprob_amd implements lstm_depth=1 (the reference default)')
+        self._model = model
+        self._observe_embeddings = observe_embeddings
+        self._lstm_dim = lstm_dim
+        self._sample_embedding_dim = sample_embedding_dim
+        self._address_embedding_dim = address_embedding_dim
+        self._distribution_type_embedding_dim = distribution_type_embedding_dim
+        self._proposal_mixture_components = proposal_mixture_components
+        self._device = device
+        self._seed = seed
+        self._engine = None
+        self._is = None
+        self._layers_initialized = False
+        self._layers_pre_generated = False
+        self._optimizer_ready = False
+        self._learning_rate_init = None
+        self._learning_rate_end = None
+        self._learning_rate_scheduler_type = None
+        self._weight_decay = None
+        self._total_train_seconds = 0
+        self._total_train_traces = 0
+        self._total_train_traces_end = None
+        self._total_train_iterations = 0
+        self._loss_init = None
+        self._loss_min = float('inf')
+        self._loss_max = None
+        self._loss_previous = float('inf')
+        self._history_train_loss = []
+        self._history_train_loss_trace = []
+        self._history_num_params = []
+        self._history_num_params_trace = []
+        self._distributed_world_size = 1
+        self._infer_prev_addr_id = None
+
+    # ---- layer creation ------------------------------------------------------------------------------------
+    def _init_layers_observe_embedding(self, observe_embeddings, example_trace):
+        """inference_network.py:80-130 for FEEDFORWARD embeddings: input width from the example trace."""
+        if len(observe_embeddings) == 0:
+            raise ValueError('At least one observe embedding is needed to initialize inference network.')
+        if isinstance(observe_embeddings, set):
+            observe_embeddings = {o: {} for o in observe_embeddings}
+        obs = {}
+        for name, value in observe_embeddings.items():
+            v = dict(value)
+            variable = example_trace.named_variables[name]
+            v['input_dim'] = int(np.prod(v['reshape'])) if 'reshape' in v else int(torch.as_tensor(variable.value).numel())
+            if 'dim' not in v:
+                print('Observable {}: embedding dim not specified, using the default 256.'.format(name))
+            obs[name] = v
+        self._obs_spec = obs
+        self._obs_names = list(obs.keys())
+
+    def _init_layers(self):
+        spec = NetSpec(self._obs_spec, lstm_dim=self._lstm_dim, sample_embedding_dim=self._sample_embedding_dim,
+                       address_embedding_dim=self._address_embedding_dim,
+                       distribution_type_embedding_dim=self._distribution_type_embedding_dim,
+                       proposal_mixture_components=self._proposal_mixture_components)
+        self._engine = ICEngine(spec, device=self._device, seed=self._seed)
+        self._is = ISRunner(self._engine)
+
+    def _polymorph(self, batch):
+        """inference_network_lstm.py:34-80: new address => new embeddings + proposal head + sample embedding."""
+        items = []
+        spec = self._engine.spec
+        seen = set()
+        for sub_batch in batch.sub_batches:
+            for variable in sub_batch[0].variables_controlled:
+                a = variable.address
+                if a not in spec.address_id and a not in seen:
+                    d = variable.distribution
+                    ncat = d.num_categories if d.name == 'Categorical' else None
+                    items.append((a, d.name, ncat))
+                    seen.add(a)
+                    print('New layers, address: {}, distribution: {}'.format(a[:60], d.name))
+        layers_changed = self._engine.add_addresses(items) if items else False
+        if layers_changed:
+            n = spec.num_parameters()
+            print('Total addresses: {:,}, distribution types: {:,}, parameters: {:,}'.format(
+                len(spec.addresses), len(spec.dtypes), n))
+            self._history_num_params.append(n)
+            self._history_num_params_trace.append(self._total_train_traces)
+        return layers_changed
+
+    # ---- training loss --------------------------------------------------------------------------------------
+    def _pack(self, batch):
+        if isinstance(batch, PackedBatch):
+            return batch
+        spec = self._engine.spec
+        for sub_batch in batch.sub_batches:
+            for v in sub_batch[0].variables_controlled:
+                if v.address not in spec.address_id:
+                    print('Address unknown by inference network: {}'.format(v.address))
+                    return None
+        return pack_traces(batch.traces, spec, self._obs_names)
+
+    def _loss(self, batch, backward=False):
+        """`_loss(batch)` -> (success, loss) like inference_network_lstm.py:136-220. `loss` is a 1-element device tensor
+        (already divided by batch.size); with backward=True the gradients are left in the engine's flat buffer."""
+        pb = self._pack(batch)
+        if pb is None:
+            return False, 0
+        for info_id, n in enumerate(pb.cur_counts):
+            if n > 0:
+                self._engine.spec.addresses[info_id].total_train_iterations += 1      # :198
+        loss = self._engine.loss(pb, backward=backward)
+        return True, loss
+
+    # ---- importance sampling ---------------------------------------------------------------------------------
+    def _infer_init(self, observe=None):
+        """inference_network.py:141-148"""
+        self._infer_observe = observe
+        vals = []
+        for name in self._obs_names:
+            vals.extend(torch.as_tensor(observe[name], dtype=torch.float32).reshape(-1).tolist())
+        self._is.init(vals)
+        self._infer_prev_addr_id = None
+
+    def _prior_tensor(self, distribution, n=1):
+        if distribution.name == 'Normal':
+            p = torch.stack([distribution.mean.reshape(-1), distribution.stddev.reshape(-1)], 1)
+        elif distribution.name == 'Uniform':
+            p = torch.stack([distribution.low.reshape(-1), distribution.high.reshape(-1)], 1)
+        else:
+            return None
+        return p.to(self._engine.device, torch.float32).contiguous()
+
+    def _infer_step(self, variable, prev_variable=None, proposal_min_train_iterations=None):
+        """inference_network_lstm.py:82-134 for one particle: returns the prior when the address is unknown or the
+        proposal is not trained enough, else the (sampled, scored) proposal."""
+        spec = self._engine.spec
+        address = variable.address
+        distribution = variable.distribution
+        if address not in spec.address_id or (prev_variable is not None and prev_variable.address not in spec.address_id):
+            warnings.warn('Using prior. No proposal for address: {}'.format(address))
+            return distribution
+        a = spec.address_id[address]
+        if proposal_min_train_iterations is not None and \
+                spec.addresses[a].total_train_iterations < proposal_min_train_iterations:
+            warnings.warn('Using prior. Proposal not sufficiently trained for address: {}'.format(address))
+            return distribution
+        if prev_variable is None:
+            self._is.begin(1)
+            prev = None
+        else:
+            prev = spec.address_id[prev_variable.address]
+            self._is.prev_value = torch.as_tensor(prev_variable.value, dtype=torch.float32).reshape(1).to(self._engine.device)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # follows torch's global seed (pyprob.seed)
+        value, logq = self._is.step(a, prev, self._prior_tensor(distribution), seed=seed)
+        return ProposalSample(value.cpu(), logq.cpu())
+
+    def _infer_step_lockstep(self, address, distribution, ls):
+        spec = self._engine.spec
+        if address not in spec.address_id:
+            raise RuntimeError('lock-step importance sampling: no proposal for address {}'.format(address))
+        a = spec.address_id[address]
+        prior = self._prior_tensor(distribution)
+        value, logq = ls.runner.step(a, ls.prev_addr_id, prior, seed=ls.seed + 7919 * ls.statement)
+        ls.prev_addr_id = a
+        ls.statement += 1
+        return value, logq, a
+
+    def _accumulate_prior(self, ls, distribution, value):
+        dev = self._engine.device
+        if distribution.name == 'Normal':
+            ls.runner.accumulate(ls.lw, 0, distribution.mean.reshape(-1).to(dev), distribution.stddev.reshape(-1).to(dev), value)
+        elif distribution.name == 'Uniform':
+            ls.runner.accumulate(ls.lw, 1, distribution.low.reshape(-1).to(dev), distribution.high.reshape(-1).to(dev), value)
+        else:
+            lp = distribution.log_prob(value.cpu()).to(dev, torch.float32).contiguous()
+            ls.runner.axpy(ls.lw, 1.0, lp)
+
+    # ---- optimisation ---------------------------------------------------------------------------------------
+    def _learning_rate(self):
+        """POLY1 / POLY2 decay driven by the trace count (inference_network.py:357-379, :568)."""
+        t = self._learning_rate_scheduler_type
+        if t in (None, 'NONE'):
+            return self._learning_rate_init
+        power = 1.0 if t == 'POLY1' else 2.0
+        frac = max(0.0, 1.0 - self._total_train_traces / self._total_train_traces_end)
+        return (self._learning_rate_init - self._learning_rate_end) * (frac ** power) + self._learning_rate_end
+
+    def optimize(self, num_traces, dataset, batch_size=64, learning_rate_init=0.0001, learning_rate_end=1e-6,
+                 learning_rate_scheduler_type=None, weight_decay=1e-5, num_traces_end=1e9, distributed_backend=None,
+                 distributed_params_sync_every_iter=10000, stop_with_bad_loss=False, log_file_name=None, verbose=True):
+        """The training loop of inference_network.py:381-599 for Optimizer.ADAM: per minibatch _polymorph ->
+        zero_grad -> _loss -> backward -> [all-reduce, divide by world] -> Adam step, traces/s bookkeeping."""
+        if not self._layers_initialized:
+            self._init_layers_observe_embedding(self._observe_embeddings, example_trace=dataset[0])
+            self._init_layers()
+            self._layers_initialized = True
+        world, rank = 1, 0
+        if distributed_backend is not None:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group(backend=distributed_backend)
+            world, rank = dist.get_world_size(), dist.get_rank()
+        self._distributed_world_size = world
+        self._engine.world_size = world
+        if self._learning_rate_init is None:
+            self._learning_rate_init = learning_rate_init * math.sqrt(world)            # :448
+        if self._learning_rate_end is None:
+            self._learning_rate_end = learning_rate_end
+        if self._learning_rate_scheduler_type is None:
+            self._learning_rate_scheduler_type = learning_rate_scheduler_type
+        if self._weight_decay is None:
+            self._weight_decay = weight_decay
+        if self._total_train_traces_end is None:
+            self._total_train_traces_end = num_traces_end
+        prev_seconds = self._total_train_seconds
+        time_start = time.time()
+        trace = 0
+        log_file = open(log_file_name, 'w', buffering=1) if (rank == 0 and log_file_name) else None
+        if log_file:
+            log_file.write('time, iteration, trace, loss, learning_rate, mean_trace_length_controlled, sub_mini_batches, '
+                           'traces_per_second\n')
+        stop = False
+        last = time_start
+        i_item = 0
+        while not stop:
+            traces = [dataset[i_item + k] for k in range(batch_size)]
+            i_item += batch_size
+            batch = Batch(traces)
+            if world > 1 and self._total_train_iterations % distributed_params_sync_every_iter == 0:
+                self._engine.broadcast_params()                                       # :473-474
+            layers_changed = False if self._layers_pre_generated else self._polymorph(batch)
+            if layers_changed:
+                self._engine.reset_optimizer()                                        # :481-483
+            success, loss = self._loss(batch, backward=True)
+            if success and int(self._engine.status_buf[0].item()) != 0:
+                success = False
+            if not success:
+                print('Cannot compute loss, skipping batch. Loss: {}'.format(loss))
+                if stop_with_bad_loss:
+                    return
+                continue
+            if world > 1:
+                self._engine.allreduce_grads()                                        # :494-495
+            self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay)
+            loss = float(loss.item()) / (world if world > 1 else 1)                  # tail is the all-reduced SUM
+            now = time.time()
+            if self._loss_init is None:
+                self._loss_init = self._loss_max = loss
+            self._loss_min = min(self._loss_min, loss)
+            self._loss_max = max(self._loss_max, loss)
+            self._loss_previous = loss
+            self._total_train_iterations += 1
+            trace += batch.size * world
+            self._total_train_traces += batch.size * world
+            self._total_train_seconds = prev_seconds + (now - time_start)
+            self._history_train_loss.append(loss)
+            self._history_train_loss_trace.append(self._total_train_traces)
+            tps = batch.size * world / max(now - last, 1e-9)
+            last = now
+            if log_file:
+                log_file.write('{}, {}, {}, {}, {}, {}, {}, {}\n'.format(self._total_train_seconds, self._total_train_iterations,
+                               self._total_train_traces, loss, self._learning_rate(), batch.mean_length_controlled,
+                               len(batch.sub_batches), tps))
+            if trace >= num_traces:
+                stop = True
+        if verbose and rank == 0:
+            print('Stop condition reached. num_traces: {}  loss {:+.3e}  traces/s {:,.0f}'.format(
+                num_traces, self._loss_previous, self._total_train_traces / max(self._total_train_seconds, 1e-9)))
+        if log_file:
+            log_file.close()
+
+    # ---- checkpoint (state_dict interchange with the reference's tensor names) ---------------------------------
+    def state_dict(self):
+        return self._engine.state_dict()
+
+    def _save(self, file_name):
+        spec = self._engine.spec
+        torch.save(dict(state_dict=self.state_dict(), obs_spec=self._obs_spec, lstm_dim=self._lstm_dim,
+                        K=self._proposal_mixture_components,
+                        addresses=[(a.address, a.dist_name, a.num_categories, a.total_train_iterations) for a in spec.addresses],
+                        total_train_traces=self._total_train_traces, total_train_iterations=self._total_train_iterations,
+                        exp_avg=self._engine.exp_avg.cpu(), exp_avg_sq=self._engine.exp_avg_sq.cpu(),
+                        tensor_step=self._engine.tensor_step.cpu()), file_name)
+
+    @staticmethod
+    def _load(file_name, device='cuda:0'):
+        d = torch.load(file_name, weights_only=False)
+        net = InferenceNetworkLSTM(observe_embeddings=d['obs_spec'], lstm_dim=d['lstm_dim'],
+                                   proposal_mixture_components=d['K'], device=device)
+        net._obs_spec = d['obs_spec']
+        net._obs_names = list(d['obs_spec'].keys())
+        net._init_layers()
+        net._layers_initialized = True
+        net._engine.add_addresses([(a, dn, nc) for a, dn, nc, _ in d['addresses']])
+        for info, (_, _, _, it) in zip(net._engine.spec.addresses, d['addresses']):
+            info.total_train_iterations = it
+        net._engine.load_state_dict(d['state_dict'])
+        net._engine.exp_avg.copy_(d['exp_avg'])
+        net._engine.exp_avg_sq.copy_(d['exp_avg_sq'])
+        net._engine.tensor_step.copy_(d['tensor_step'])
+        net._total_train_traces = d['total_train_traces']
+        net._total_train_iterations = d['total_train_iterations']
+        return net

@@ -1,0 +1,92 @@
+"""Data-parallel pieces of the hot path: one process per GPU, torch.distributed (backend "nccl" is
+RCCL on ROCm; "gloo" in the CPU tests).
+
+  * training: ONE all-reduce(SUM) per step over the flat buffer [gradients | presence map | loss] instead of the
+    reference's per-tensor loop (pyprob/nn/inference_network.py:296-333), then every rank divides by world size;
+  * minibatch partition: the bucketed sampler of pyprob/nn/dataset.py:328-400 (all ranks walk the same bucket at the
+    same time, each rank takes a disjoint stride of its minibatches);
+  * importance sampling: particles are independent -> contiguous shards per rank with disjoint Philox counters, no
+    collective on the data path (pyprob/model.py:339-406 shards the same way over processes).
+"""
+import math
+
+import numpy as np
+
+
+def allreduce_flat_(buf):
+    """all-reduce(SUM) of the flat [grads | presence | loss] buffer, in place."""
+    import torch.distributed as dist
+    dist.all_reduce(buf)
+    return buf
+
+
+def finish_reduce(buf, n_params, n_tensors, world_size):
+    """After the all-reduce: averaged gradients (inference_network.py:324-325), merged presence map (:300-315: a tensor
+    is updated if ANY rank produced a gradient) and mean loss (:327-333). Returns views (grads, active, loss)."""
+    grads = buf[:n_params]
+    grads /= float(world_size)
+    active = buf[n_params:n_params + n_tensors]
+    loss = buf[n_params + n_tensors:] / float(world_size)
+    return grads, active, loss
+
+
+def shard_range(n, rank, world):
+    """Contiguous particle shard of this rank: (offset, count), counts differ by at most one."""
+    base, rem = divmod(n, world)
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+class DistributedTraceBatchSampler:
+    """Mirror of pyprob/nn/dataset.py:328-400 over a list of sorted trace indices."""
+
+    def __init__(self, sorted_indices, batch_size, rank, world_size, num_buckets=None, shuffle_batches=True,
+                 shuffle_buckets=True):
+        self._world_size, self._rank = world_size, rank
+        idx = list(sorted_indices)
+        num_batches_to_drop = math.floor(len(idx) / batch_size) % world_size
+        num_traces_to_drop = num_batches_to_drop * batch_size
+        rng = np.random.RandomState(0)             # every rank drops the same traces
+        if num_traces_to_drop:
+            drop = set(rng.choice(len(idx), num_traces_to_drop, replace=False).tolist())
+            idx = [v for i, v in enumerate(idx) if i not in drop]
+        self._batches = [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
+        if self._batches and len(self._batches[-1]) < batch_size:
+            del self._batches[-1]
+        if not self._batches:
+            raise RuntimeError('dataset too small for batch_size:{} and world_size:{}'.format(batch_size, world_size))
+        if num_buckets is None:
+            num_buckets = len(self._batches) / world_size
+        self._num_buckets = num_buckets
+        self._bucket_size = math.ceil(len(self._batches) / num_buckets)
+        if self._bucket_size < world_size:
+            raise RuntimeError('batch_size:{} and num_buckets:{} imply a bucket_size:{} smaller than world_size:{}'.format(
+                batch_size, num_buckets, self._bucket_size, world_size))
+        self._buckets = [self._batches[i:i + self._bucket_size] for i in range(0, len(self._batches), self._bucket_size)]
+        if len(self._buckets[-1]) < self._bucket_size:
+            if len(self._buckets) < 2:
+                raise RuntimeError('dataset too small for given batch_size:{} and num_buckets:{}'.format(batch_size, num_buckets))
+            self._buckets[-2].extend(self._buckets[-1])
+            del self._buckets[-1]
+        self._shuffle_batches, self._shuffle_buckets = shuffle_batches, shuffle_buckets
+        self._epoch = 0
+        self._current_bucket_id = 0
+
+    def __iter__(self):
+        self._epoch += 1
+        bucket_ids = list(range(len(self._buckets)))
+        if self._shuffle_buckets:
+            np.random.RandomState(self._epoch).shuffle(bucket_ids)   # same order on every rank
+        for bucket_id in bucket_ids:
+            bucket = self._buckets[bucket_id]
+            self._current_bucket_id = bucket_id
+            num_batches = math.floor(len(bucket) / self._world_size)
+            batches = bucket[self._rank:len(bucket):self._world_size][:num_batches]
+            if self._shuffle_batches:
+                np.random.shuffle(batches)
+            for batch in batches:
+                yield batch
+
+    def __len__(self):
+        return len(self._batches)

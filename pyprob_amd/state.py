@@ -1,0 +1,208 @@
+"""The probabilistic-program interpreter for the engines on the hot path (mirror of pyprob/state.py).
+
+Module-global trace state, `sample` / `observe`, address extraction from the call site, two execution modes:
+
+  * per-trace mode  -- one particle / one prior trace per run of `forward()`, as pyprob does (state.py:158-293,
+                       118-155); the IC branch (state.py:203-219) calls `InferenceNetworkLSTM._infer_step`, which
+                       is one `pp_is_step` C call (LSTM step + head + sample + log q) with n = 1;
+  * lock-step mode  -- N particles run `forward()` ONCE with N-wide device tensors as values (straight-line
+                       programs such as GaussianUnknownMean): every `sample` is one `pp_is_step` for all particles,
+                       every `observe` one fused log-prob/accumulate kernel. Programs with data-dependent Python
+                       control flow must use per-trace mode.
+
+MCMC engines, prior inflation, `tag`/`factor` and the address dictionary are out of scope.
+"""
+import enum
+import sys
+import time
+
+import torch
+
+from .distributions import Normal, Uniform
+from .trace import Trace, Variable
+
+
+class TraceMode(enum.Enum):
+    PRIOR = 1
+    POSTERIOR = 2
+    PRIOR_FOR_INFERENCE_NETWORK = 3
+
+
+class InferenceEngine(enum.Enum):
+    IMPORTANCE_SAMPLING = 0
+    IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK = 1
+
+
+_trace_mode = TraceMode.PRIOR
+_inference_engine = InferenceEngine.IMPORTANCE_SAMPLING
+_likelihood_importance = 1.
+_current_trace = None
+_current_trace_root_function_name = None
+_current_trace_inference_network = None
+_current_trace_previous_variable = None
+_current_trace_observed_variables = {}
+_current_trace_execution_start = None
+_lock_step = None      # LockStepState when N particles advance together
+
+
+def _make_address(distribution, address):
+    if address is None:
+        base = _extract_address_from_caller() + '__' + distribution._address_suffix
+    else:
+        base = address + '__' + distribution._address_suffix
+    instance = _current_trace.last_instance(base) + 1
+    return base, base + '__' + str(instance), instance
+
+
+def _extract_address_from_caller():
+    # one extra frame because of _make_address
+    frame = sys._getframe(3)
+    ip = frame.f_lasti
+    names = []
+    while frame is not None:
+        n = frame.f_code.co_name
+        names.append(n)
+        if n == _current_trace_root_function_name:
+            break
+        frame = frame.f_back
+    return '{}__{}'.format(ip, '__'.join(reversed(names)))
+
+
+class LockStepState:
+    """Per-call state of lock-step importance sampling: particle count, log-weight accumulator, IS runner."""
+
+    def __init__(self, runner, n, seed, offset):
+        self.runner = runner
+        self.n = n
+        self.seed = seed
+        self.offset = offset
+        self.statement = 0
+        self.prev_addr_id = None
+        self.lw = torch.zeros(n, dtype=torch.float32, device=runner.dev)
+
+
+def observe(distribution, value=None, name=None, address=None):
+    """state.observe, pyprob/state.py:118-155."""
+    if _current_trace is None:
+        return None
+    base, addr, instance = _make_address(distribution, address)
+    if name in _current_trace_observed_variables:
+        value = _current_trace_observed_variables[name]
+    elif value is not None:
+        value = torch.as_tensor(value, dtype=torch.float32)
+    elif _trace_mode == TraceMode.PRIOR_FOR_INFERENCE_NETWORK and distribution is not None:
+        value = distribution.sample()
+    else:
+        value = None
+    if _lock_step is not None and value is not None:
+        ls = _lock_step
+        dev = ls.runner.dev
+        v = torch.as_tensor(value, dtype=torch.float32).reshape(-1).to(dev)
+        if isinstance(distribution, Normal):
+            ls.runner.accumulate(ls.lw, 0, distribution.mean.reshape(-1).to(dev), distribution.stddev.reshape(-1).to(dev), v,
+                                 scale=_likelihood_importance)
+        elif isinstance(distribution, Uniform):
+            ls.runner.accumulate(ls.lw, 1, distribution.low.reshape(-1).to(dev), distribution.high.reshape(-1).to(dev), v,
+                                 scale=_likelihood_importance)
+        else:
+            raise RuntimeError('lock-step importance sampling supports Normal and Uniform likelihoods; got {}'.format(
+                distribution.name))
+        variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                            log_prob=None, log_importance_weight=None, observed=True, name=name)
+        _current_trace.add(variable)
+        return value
+    if value is None:
+        observed, log_prob, lw = False, None, None
+    else:
+        observed = True
+        log_prob = _likelihood_importance * distribution.log_prob(value, sum=True)
+        lw = float(log_prob)                                   # state.py:147-149
+    variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                        log_prob=log_prob, log_importance_weight=lw, observed=observed, name=name)
+    _current_trace.add(variable)
+    return variable.value
+
+
+def sample(distribution, name=None, address=None, control=True):
+    """state.sample, pyprob/state.py:158-293 (PRIOR / IS / IS-with-inference-network branches)."""
+    global _current_trace_previous_variable
+    if _current_trace is None:
+        return distribution.sample()
+    base, addr, instance = _make_address(distribution, address)
+    if name in _current_trace_observed_variables:
+        value = _current_trace_observed_variables[name]
+        log_prob = _likelihood_importance * distribution.log_prob(value, sum=True)
+        variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                            log_prob=log_prob, log_importance_weight=float(log_prob), observed=True, name=name)
+        _current_trace.add(variable)
+        return variable.value
+
+    ic = (_trace_mode == TraceMode.POSTERIOR and
+          _inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK and control)
+    if _lock_step is not None:
+        if not ic:
+            raise RuntimeError('lock-step mode runs controlled samples with the inference network only')
+        ls = _lock_step
+        net = _current_trace_inference_network
+        value, logq, addr_id = net._infer_step_lockstep(addr, distribution, ls)
+        net._accumulate_prior(ls, distribution, value)             # + log p(value)   state.py:211
+        ls.runner.axpy(ls.lw, -1.0, logq)                          # - log q(value)   state.py:212,217
+        variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                            log_prob=None, control=True, name=name)
+        _current_trace.add(variable)
+        return value
+
+    log_importance_weight = None
+    if ic:
+        variable = Variable(distribution=distribution, value=None, address_base=base, address=addr, instance=instance,
+                            log_prob=0., control=control, name=name)
+        proposal = _current_trace_inference_network._infer_step(variable, prev_variable=_current_trace_previous_variable)
+        value = proposal.sample()
+        if value.dim() > 0:
+            value = value[0]
+        log_prob = distribution.log_prob(value, sum=True)
+        proposal_log_prob = proposal.log_prob(value, sum=True)
+        log_importance_weight = float(log_prob) - float(proposal_log_prob)          # state.py:217
+        variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                            log_prob=log_prob, log_importance_weight=log_importance_weight, control=control, name=name)
+        _current_trace_previous_variable = variable
+    else:
+        value = distribution.sample()
+        log_prob = distribution.log_prob(value, sum=True)
+        variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                            log_prob=log_prob, log_importance_weight=None, control=control, name=name)
+    _current_trace.add(variable)
+    return variable.value
+
+
+def _init_traces(func, trace_mode=TraceMode.PRIOR, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING,
+                 inference_network=None, observe=None, likelihood_importance=1., lock_step=None):
+    """state._init_traces, pyprob/state.py:296-336."""
+    global _trace_mode, _inference_engine, _likelihood_importance, _current_trace_root_function_name
+    global _current_trace_inference_network, _current_trace_observed_variables, _lock_step
+    _trace_mode = trace_mode
+    _inference_engine = inference_engine
+    _likelihood_importance = likelihood_importance
+    _current_trace_root_function_name = func.__code__.co_name
+    _current_trace_observed_variables = {} if observe is None else observe
+    _current_trace_inference_network = inference_network
+    _lock_step = lock_step
+    if inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK:
+        if inference_network is None:
+            raise ValueError('Expecting an inference network')
+        inference_network._infer_init(_current_trace_observed_variables)
+
+
+def _begin_trace():
+    global _current_trace, _current_trace_previous_variable, _current_trace_execution_start
+    _current_trace_execution_start = time.time()
+    _current_trace = Trace()
+    _current_trace_previous_variable = None
+
+
+def _end_trace(result):
+    global _current_trace
+    trace = _current_trace
+    _current_trace = None
+    trace.end(result, time.time() - _current_trace_execution_start)
+    return trace

@@ -1,0 +1,58 @@
+"""The reference's test programs written against the pyprob_amd host API (same source as
+reference tests/test_inference.py:97-109 and :252-275 with `pyprob` -> `pyprob_amd`)."""
+import math
+
+import torch
+
+import pyprob_amd as pyprob
+from pyprob_amd.distributions import Normal, Uniform, Categorical
+from pyprob_amd.model import Model
+
+
+class GaussianWithUnknownMean(Model):
+    def __init__(self, prior_mean=1, prior_stddev=math.sqrt(5), likelihood_stddev=math.sqrt(2)):
+        self.prior_mean = prior_mean
+        self.prior_stddev = prior_stddev
+        self.likelihood_stddev = likelihood_stddev
+        super().__init__('Gaussian with unknown mean')
+
+    def forward(self):
+        mu = pyprob.sample(Normal(self.prior_mean, self.prior_stddev))
+        likelihood = Normal(mu, self.likelihood_stddev)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+class GaussianWithUnknownMeanMarsaglia(Model):
+    def __init__(self, prior_mean=1, prior_stddev=math.sqrt(5), likelihood_stddev=math.sqrt(2)):
+        self.prior_mean = prior_mean
+        self.prior_stddev = prior_stddev
+        self.likelihood_stddev = likelihood_stddev
+        super().__init__('Gaussian with unknown mean (Marsaglia)')
+
+    def marsaglia(self, mean, stddev):
+        uniform = Uniform(-1, 1)
+        s = 1
+        while float(s) >= 1:
+            x = pyprob.sample(uniform)
+            y = pyprob.sample(uniform)
+            s = x * x + y * y
+        return mean + stddev * (x * torch.sqrt(-2 * torch.log(s) / s))
+
+    def forward(self):
+        mu = self.marsaglia(self.prior_mean, self.prior_stddev)
+        likelihood = Normal(mu, self.likelihood_stddev)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+class CategoricalThenNormal(Model):
+    def forward(self):
+        c = pyprob.sample(Categorical([0.2, 0.3, 0.5]))
+        mu = pyprob.sample(Normal(c.float() * 2.0 - 1.0, 1.5))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu

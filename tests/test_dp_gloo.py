@@ -1,0 +1,115 @@
+"""world_size-2 data-parallel protocol on CPU (gloo): one all-reduce over [flat grads | presence | loss] reproduces
+the reference's per-tensor gradient sync (pyprob/nn/inference_network.py:296-333); bucketed sampler; particle shards.
+The gradients come from the oracle (test infrastructure) -- no GPU needed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, load_golden
+from helpers import spec_from_golden, synthetic_gumm_arrays
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import ic_oracle as O
+    from pyprob_amd.parallel import allreduce_flat_, finish_reduce
+    meta, params, batch, loss, isr = load_golden('gumm')
+    spec = spec_from_golden(meta, params)
+    # rank-local minibatch: traces [rank::world] of the golden batch
+    B = len(batch['trace_len'])
+    off = np.concatenate([[0], np.cumsum(batch['trace_len'])])
+    idx = np.arange(rank, B - (B % world), world)
+    rows = np.concatenate([np.arange(off[b], off[b + 1]) for b in idx])
+    local = dict(trace_len=batch['trace_len'][idx], addr_idx=batch['addr_idx'][rows], values=batch['values'][rows],
+                 prior=batch['prior'][rows], obs=batch['obs'][idx])
+    net = O.Net(params, meta['obs_names'], K=10)
+    o = O.loss_and_grads(net, local, meta['addresses'], meta['dist_names'])
+    # flat buffer [grads | presence | loss] in the product's layout
+    buf = torch.zeros(spec.n_params + spec.n_tensors + 1, dtype=torch.float64)
+    names = list(spec.tensors.keys())
+    for n in names:
+        o_, shape = spec.tensors[n]
+        buf[o_:o_ + int(np.prod(shape))] = torch.from_numpy(o['grads'][n].reshape(-1))
+    ids = np.array([spec.address_id[meta['addresses'][i]] for i in local['addr_idx']])
+    cur = np.bincount(ids, minlength=len(spec.addresses))
+    lens = local['trace_len']
+    loff = np.concatenate([[0], np.cumsum(lens)])
+    not_last = np.ones(len(ids), bool)
+    not_last[loff[1:] - 1] = False
+    prev = np.bincount(ids[not_last], minlength=len(spec.addresses))
+    buf[spec.n_params:spec.n_params + spec.n_tensors] = torch.from_numpy(spec.active_mask(cur, prev).astype(np.float64))
+    buf[-1] = o['loss']
+    allreduce_flat_(buf)
+    grads, active, l = finish_reduce(buf, spec.n_params, spec.n_tensors, world)
+    if rank == 0:
+        torch.save(dict(grads=grads.clone(), active=active.clone(), loss=l.clone(), idx=idx), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_equals_global_batch_gradient(tmp_path):
+    world, port = 2, 29500 + os.getpid() % 2000
+    out = str(tmp_path / 'dp.pt')
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r = torch.load(out, weights_only=False)
+    from oracle import ic_oracle as O
+    meta, params, batch, loss, isr = load_golden('gumm')
+    spec = spec_from_golden(meta, params)
+    B = len(batch['trace_len'])
+    keep = np.arange(B - (B % world))
+    off = np.concatenate([[0], np.cumsum(batch['trace_len'])])
+    rows = np.concatenate([np.arange(off[b], off[b + 1]) for b in keep])
+    glob = dict(trace_len=batch['trace_len'][keep], addr_idx=batch['addr_idx'][rows], values=batch['values'][rows],
+                prior=batch['prior'][rows], obs=batch['obs'][keep])
+    o = O.loss_and_grads(O.Net(params, meta['obs_names'], K=10), glob, meta['addresses'], meta['dist_names'])
+    # mean of the per-rank mean losses == global mean loss (equal per-rank batch sizes); same for gradients
+    assert abs(float(r['loss']) - o['loss']) < 1e-9
+    for n, (o_, shape) in spec.tensors.items():
+        g = r['grads'][o_:o_ + int(np.prod(shape))].numpy().reshape(shape)
+        np.testing.assert_allclose(g, o['grads'][n], rtol=1e-9, atol=1e-12)
+    # merged presence: a tensor is active if any rank touched it
+    ids = np.array([spec.address_id[meta['addresses'][i]] for i in glob['addr_idx']])
+    assert np.all((r['active'].numpy() > 0) >= (spec.active_mask(np.bincount(ids, minlength=len(spec.addresses)),
+                                                                 np.zeros(len(spec.addresses))) > 0))
+
+
+def test_distributed_sampler_partitions_batches():
+    from pyprob_amd.parallel import DistributedTraceBatchSampler
+    idx = list(range(1000))
+    world = 4
+    per_rank = []
+    for rank in range(world):
+        s = DistributedTraceBatchSampler(idx, batch_size=16, rank=rank, world_size=world, num_buckets=5,
+                                         shuffle_batches=False)
+        per_rank.append([tuple(b) for b in s])
+    n = {len(p) for p in per_rank}
+    assert len(n) == 1                                        # same number of iterations on every rank
+    flat = [b for p in per_rank for b in p]
+    assert len(set(flat)) == len(flat)                        # disjoint minibatches
+    assert all(len(b) == 16 for b in flat)
+    # all ranks walk buckets in the same order: the k-th batch of every rank comes from the same bucket
+    s0 = DistributedTraceBatchSampler(idx, 16, 0, world, num_buckets=5, shuffle_batches=False)
+    bucket_of = {tuple(b): i for i, bk in enumerate(s0._buckets) for b in bk}
+    for k in range(len(per_rank[0])):
+        assert len({bucket_of[p[k]] for p in per_rank}) == 1
+    with pytest.raises(RuntimeError):
+        DistributedTraceBatchSampler(list(range(64)), 16, 0, 8, num_buckets=4)
+
+
+def test_particle_shards_cover_the_range():
+    from pyprob_amd.parallel import shard_range
+    for n in (1000000, 1000003, 7):
+        for world in (1, 2, 8):
+            shards = [shard_range(n, r, world) for r in range(world)]
+            assert shards[0][0] == 0 and sum(c for _, c in shards) == n
+            for (o0, c0), (o1, _) in zip(shards, shards[1:]):
+                assert o0 + c0 == o1

@@ -1,0 +1,102 @@
+"""CPU tests of the host-side mirror of the trace runtime (pyprob_amd/{state,trace,model,nn,distributions}.py):
+trace structure, addresses, sub-batching, packing, IS with prior proposals. No GPU."""
+import numpy as np
+import pytest
+import torch
+
+from models import GaussianWithUnknownMean, GaussianWithUnknownMeanMarsaglia, CategoricalThenNormal
+from oracle import ic_oracle as O
+from pyprob_amd.nn import Batch
+from pyprob_amd.packed import pack_traces
+from pyprob_amd.spec import NetSpec
+from pyprob_amd.state import InferenceEngine, TraceMode
+
+
+def _prior_traces(model, n):
+    gen = model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK)
+    return [next(gen) for _ in range(n)]
+
+
+def test_gum_trace_structure():
+    torch.manual_seed(1)
+    traces = _prior_traces(GaussianWithUnknownMean(), 20)
+    for t in traces:
+        assert t.length_controlled == 1 and len(t.variables_observed) == 2        # reference tests/test_trace.py counts
+        assert set(t.named_variables) == {'obs0', 'obs1'}
+        v = t.variables_controlled[0]
+        assert v.address.endswith('__Normal__1') and '__forward__' in v.address
+        assert v.distribution.name == 'Normal'
+    assert len({t.variables_controlled[0].address for t in traces}) == 1
+    a0 = traces[0].named_variables['obs0'].address
+    a1 = traces[0].named_variables['obs1'].address
+    assert a0 != a1
+
+
+def test_gumm_trace_lengths_and_instances():
+    torch.manual_seed(2)
+    traces = _prior_traces(GaussianWithUnknownMeanMarsaglia(), 400)
+    lens = np.array([t.length_controlled for t in traces])
+    assert lens.min() == 2 and np.all(lens % 2 == 0)
+    assert abs(lens.mean() - 2.546) < 0.25        # reference tests/test_model.py:80: 2.563
+    long = [t for t in traces if t.length_controlled >= 4][0]
+    addrs = [v.address for v in long.variables_controlled]
+    assert addrs[0].endswith('__Uniform__1') and addrs[2].endswith('__Uniform__2')
+    assert addrs[0].rsplit('__', 1)[0] == addrs[2].rsplit('__', 1)[0]          # same call site, next instance
+    assert addrs[0] != addrs[1]
+
+
+def test_batch_sub_batching_and_packing_agree_with_oracle():
+    torch.manual_seed(3)
+    traces = _prior_traces(GaussianWithUnknownMeanMarsaglia(), 64)
+    batch = Batch(traces)
+    assert batch.size == 64 and abs(batch.mean_length_controlled - np.mean([t.length_controlled for t in traces])) < 1e-12
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=64)
+    for t in traces:
+        for v in t.variables_controlled:
+            spec.add_address(v.address, v.distribution.name)
+    pb = pack_traces(traces, spec, ['obs0', 'obs1'])
+    # the same grouping the reference's Batch makes (oracle.split_sub_batches restates dataset.py:21-37)
+    ids = [spec.address_id[v.address] for t in traces for v in t.variables_controlled]
+    subs, _ = O.split_sub_batches([t.length_controlled for t in traces], np.array(ids))
+    assert sorted(map(len, subs)) == sorted(map(len, batch.sub_batches))
+    assert pb.n_rows == sum(t.length_controlled for t in traces)
+    vals = np.array([float(v.value) for t in traces for v in t.variables_controlled], np.float32)
+    np.testing.assert_array_equal(pb.value, vals[pb.src_row])
+    np.testing.assert_allclose(pb.prior[:, 0], -1.0)
+    np.testing.assert_allclose(pb.prior[:, 1], 1.0)
+    obs = np.array([[float(t.named_variables[n].value) for n in ('obs0', 'obs1')] for t in traces], np.float32)
+    np.testing.assert_array_equal(pb.obs, obs[pb.order])
+    with pytest.raises(ValueError):
+        Batch([type('T', (), {'length_controlled': 0, 'variables_controlled': []})()])
+
+
+def test_importance_sampling_with_prior_proposals_gum():
+    """IMPORTANCE_SAMPLING engine (no network) on the host: posterior mean 7.25, std sqrt(1/1.2) for obs (8, 9)
+    (reference tests/test_inference.py:118-145 thresholds)."""
+    torch.manual_seed(4)
+    model = GaussianWithUnknownMean()
+    post = model.posterior_results(4000, InferenceEngine.IMPORTANCE_SAMPLING, observe={'obs0': 8, 'obs1': 9})
+    assert abs(post.mean - 7.25) < 0.75
+    assert abs(post.stddev - np.sqrt(1 / 1.2)) < 0.75
+    assert 1 < post.effective_sample_size < 4000
+    # log weight of one trace = sum of the two likelihood terms (state.py:147-149, trace.py:123-125)
+    gen = model._trace_generator(trace_mode=TraceMode.POSTERIOR, observe={'obs0': 8, 'obs1': 9})
+    t = next(gen)
+    mu = float(t.result)
+    ref = O.normal_log_prob(8.0, mu, np.sqrt(2)) + O.normal_log_prob(9.0, mu, np.sqrt(2))
+    assert abs(t.log_importance_weight - ref) < 1e-4
+
+
+def test_posterior_with_network_requires_network():
+    model = GaussianWithUnknownMean()
+    with pytest.raises(RuntimeError):
+        model.posterior_results(10, InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe={'obs0': 8, 'obs1': 9})
+
+
+def test_categorical_program_traces():
+    torch.manual_seed(5)
+    traces = _prior_traces(CategoricalThenNormal(), 10)
+    for t in traces:
+        names = [v.distribution.name for v in t.variables_controlled]
+        assert names == ['Categorical', 'Normal']
+        assert t.variables_controlled[0].distribution.num_categories == 3
