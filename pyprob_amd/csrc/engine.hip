@@ -34,6 +34,13 @@ int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_p
               const float* active, int32_t* tensor_step, float* corr, int n_tensors, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t st);
 
+// obs_embed.hip
+bool obs_fused_supported(const pp_net* net);
+int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
+                        float* cat, float* f1, float* E, hipStream_t st);
+int obs_embed_bwd_fused(const pp_net* net, const float* P, float* grads, const float* obs, int n_traces,
+                        float* const* obs_h, const float* cat, const float* f1, const float* dE, hipStream_t st);
+
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
 // ---- in-stream kernel timing (bench.py roofline leg) ---------------------------------------------------
@@ -194,6 +201,8 @@ static int linear_dgrad(const float* dz, int64_t lddz, const float* W, float* dx
 
 static int observe_embedding_fwd(const pp_net* net, const float* P, const float* obs, int64_t ldobs, int B, Workspace& w,
                                  hipStream_t st) {
+    if (obs_fused_supported(net))   // small embeddings: one fused launch (obs_embed.hip)
+        return obs_embed_fwd_fused(net, P, obs, B, w.obs_h, w.cat, w.f1, w.E, st);
     int ci = 0, co = 0;
     for (int o = 0; o < net->n_obs; ++o) {
         PP_TRY(linear_fwd(obs + ci, ldobs, nullptr, P + net->obs_w0[o], P + net->obs_b0[o], w.obs_h[o], w.ohid4[o], B,
@@ -322,6 +331,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
     // observe embedding backward (dE already carries the ReLU mask of the last layer)
     PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));
+    if (obs_fused_supported(net)) {
+        PP_TRY(obs_embed_bwd_fused(net, P, grads, bt->obs, B, w.obs_h, w.cat, w.f1, w.dE, st));
+        return 0;
+    }
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st,

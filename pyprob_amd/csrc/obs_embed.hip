@@ -1,0 +1,340 @@
+// Fused observe-embedding kernels (InferenceNetwork._embed_observe, pyprob/nn/inference_network.py:132-139, built
+// at :80-130: per observable FF(in -> hid -> out, ReLU, ReLU); concat; FF(e -> e -> e, ReLU, ReLU)) for SMALL
+// embeddings (e_obs <= 64, sum of hidden widths <= 64, inputs <= 8 wide): the whole stack is a few thousand MACs per
+// trace, so six GEMM launches forward and ~18 launches backward were pure launch/latency cost. Here one wavefront walks
+// a trace through all layers with the weights resident in LDS: lane j owns output unit j, inputs are broadcast
+// with v_readlane, weight rows are read conflict-free (row stride cols+1). The backward kernel keeps each lane's
+// weight-gradient rows in registers across its traces, combines the four waves with LDS float atomics and flushes one
+// atomic per parameter per workgroup. Larger embeddings take the generic GEMM path (engine.hip).
+#include "common.hpp"
+
+#include <stdlib.h>
+
+#include <algorithm>
+
+namespace pp {
+
+constexpr int OBS_EMAX = 64;    // lanes
+constexpr int OBS_HIDMAX = 32;  // per-observable hidden width kept in registers
+constexpr int OBS_INMAX = 8;
+
+struct ObsLayer {
+    int64_t w_off, b_off;  // offsets into the flat parameter / gradient buffers
+    int rows, cols;        // weight [rows, cols]
+    int lds_w, lds_b;      // offsets (floats) into the LDS image; weight rows have stride cols + 1
+};
+
+struct ObsFusedArgs {
+    int n_obs, e_obs, width;
+    int in[PP_MAX_OBS], hid[PP_MAX_OBS], out[PP_MAX_OBS];
+    int hoff[PP_MAX_OBS];  // first lane of observable o's hidden units
+    ObsLayer l0[PP_MAX_OBS], l1[PP_MAX_OBS], f0, f1;
+    int lds_total;
+    int64_t ohid_ld[PP_MAX_OBS], e_ld;
+    float* obs_h[PP_MAX_OBS];   // [B, ohid_ld] hidden activations of observable o (saved for backward)
+};
+
+// broadcast lane `idx` (wave-uniform index) of x: v_readlane_b32, no LDS round trip (a runtime-indexed __shfl lowers to
+// ds_bpermute_b32 and serialises on lgkmcnt)
+__device__ __forceinline__ float bcast(float x, int idx) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), idx));
+}
+
+__device__ __forceinline__ void obs_stage_layer(const ObsLayer& L, const float* __restrict__ P, float* lds, int tid) {
+    const int n = L.rows * L.cols;
+    for (int i = tid; i < n; i += 256) {   // flat index: every lane busy even for the 1-column layers
+        const int r = i / L.cols, c = i - r * L.cols;
+        lds[L.lds_w + r * (L.cols + 1) + c] = P[L.w_off + i];
+    }
+    for (int i = tid; i < L.rows; i += 256) lds[L.lds_b + i] = P[L.b_off + i];
+}
+
+__device__ __forceinline__ void obs_stage_all(const ObsFusedArgs& a, const float* __restrict__ P, float* lds, int tid) {
+    for (int o = 0; o < a.n_obs; ++o) {
+        obs_stage_layer(a.l0[o], P, lds, tid);
+        obs_stage_layer(a.l1[o], P, lds, tid);
+    }
+    obs_stage_layer(a.f0, P, lds, tid);
+    obs_stage_layer(a.f1, P, lds, tid);
+}
+
+// y_lane = relu(b[lane] + sum_k W[lane][k] * x_k), x_k held by lane k (+ x_lane0) of the wave
+__device__ __forceinline__ float obs_dense(const float* lds, const ObsLayer& L, int row, bool act, float x, int x_lane0) {
+    const float* w = lds + L.lds_w + (act ? row : 0) * (L.cols + 1);
+    // four independent partial sums, eight LDS reads in flight: the loop is latency-bound otherwise
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int k = 0;
+    for (; k + 8 <= L.cols; k += 8) {
+        float wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wv[q] = w[k + q];
+        s0 += wv[0] * bcast(x, x_lane0 + k) + wv[4] * bcast(x, x_lane0 + k + 4);
+        s1 += wv[1] * bcast(x, x_lane0 + k + 1) + wv[5] * bcast(x, x_lane0 + k + 5);
+        s2 += wv[2] * bcast(x, x_lane0 + k + 2) + wv[6] * bcast(x, x_lane0 + k + 6);
+        s3 += wv[3] * bcast(x, x_lane0 + k + 3) + wv[7] * bcast(x, x_lane0 + k + 7);
+    }
+    for (; k < L.cols; ++k) s0 += w[k] * bcast(x, x_lane0 + k);
+    const float s = (s0 + s1) + (s2 + s3);
+    return act ? fmaxf(s + lds[L.lds_b + row], 0.0f) : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a, const float* __restrict__ P,
+                                                            const float* __restrict__ obs, int n_traces,
+                                                            int traces_per_wave, float* __restrict__ cat,
+                                                            float* __restrict__ f1, float* __restrict__ E) {
+    __shared__ float lds[10240];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    obs_stage_all(a, P, lds, tid);
+    __syncthreads();
+    const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
+    for (int t = 0; t < traces_per_wave; ++t) {
+        const int b = b0 + t;
+        if (b >= n_traces) break;   // wave-uniform
+        float h = 0.0f, c = 0.0f;
+        int ci = 0, co = 0;
+        for (int o = 0; o < a.n_obs; ++o) {
+            const int jh = lane - a.hoff[o];
+            const bool acth = jh >= 0 && jh < a.hid[o];
+            if (acth) {   // layer 0 reads the raw observation directly (no cross-lane traffic)
+                const float* w = lds + a.l0[o].lds_w + jh * (a.in[o] + 1);
+                float s = lds[a.l0[o].lds_b + jh];
+                for (int i = 0; i < a.in[o]; ++i) s += w[i] * obs[(int64_t)b * a.width + ci + i];
+                h = fmaxf(s, 0.0f);
+                a.obs_h[o][(int64_t)b * a.ohid_ld[o] + jh] = h;
+            }
+            ci += a.in[o];
+        }
+        for (int o = 0; o < a.n_obs; ++o) {
+            const int jc = lane - co;
+            const bool actc = jc >= 0 && jc < a.out[o];
+            const float v = obs_dense(lds, a.l1[o], jc, actc, h, a.hoff[o]);
+            if (actc) c = v;
+            co += a.out[o];
+        }
+        const bool acte = lane < a.e_obs;
+        if (acte) cat[(int64_t)b * a.e_ld + lane] = c;
+        const float y1 = obs_dense(lds, a.f0, lane, acte, c, 0);
+        if (acte) f1[(int64_t)b * a.e_ld + lane] = y1;
+        const float y2 = obs_dense(lds, a.f1, lane, acte, y1, 0);
+        if (acte) E[(int64_t)b * a.e_ld + lane] = y2;
+    }
+}
+
+// dx_lane = sum_j dz_j * W[j][lane] (lane < cols), dz_j held by lane z_lane0 + j
+__device__ __forceinline__ float obs_dense_t(const float* lds, const ObsLayer& L, int col, bool act, float dz, int z_lane0) {
+    const float* w = lds + L.lds_w + (act ? col : 0);
+    const int ld = L.cols + 1;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int j = 0;
+    for (; j + 8 <= L.rows; j += 8) {
+        float wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wv[q] = w[(j + q) * ld];
+        s0 += wv[0] * bcast(dz, z_lane0 + j) + wv[4] * bcast(dz, z_lane0 + j + 4);
+        s1 += wv[1] * bcast(dz, z_lane0 + j + 1) + wv[5] * bcast(dz, z_lane0 + j + 5);
+        s2 += wv[2] * bcast(dz, z_lane0 + j + 2) + wv[6] * bcast(dz, z_lane0 + j + 6);
+        s3 += wv[3] * bcast(dz, z_lane0 + j + 3) + wv[7] * bcast(dz, z_lane0 + j + 7);
+    }
+    for (; j < L.rows; ++j) s0 += w[j * ld] * bcast(dz, z_lane0 + j);
+    return act ? (s0 + s1) + (s2 + s3) : 0.0f;
+}
+
+// LDS gradient image with FIXED strides (independent of the layer sizes) so that the register rows are written with
+// static indices: [gF1: 64 x 65][gF0: 64 x 65][gW1: 64 x 33][gW0: 64 x 9][biases: 4 x 64]
+constexpr int G_F1 = 0, G_F0 = 64 * 65, G_W1 = 2 * 64 * 65, G_W0 = G_W1 + 64 * 33, G_B = G_W0 + 64 * 9;
+constexpr int G_TOTAL = G_B + 4 * 64;   // 11264 floats
+
+__device__ __forceinline__ void obs_flush_weight(const ObsLayer& L, const float* g, int g_ld, int g_row0,
+                                                 float* __restrict__ grads, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < L.rows; r += 4)
+        for (int c = lane; c < L.cols; c += 64) atomicAdd(grads + L.w_off + (int64_t)r * L.cols + c, g[(g_row0 + r) * g_ld + c]);
+}
+
+__global__ __launch_bounds__(256) void obs_embed_bwd_kernel(const ObsFusedArgs a, const float* __restrict__ P,
+                                                            float* __restrict__ grads, const float* __restrict__ obs,
+                                                            int n_traces, int traces_per_wave,
+                                                            const float* __restrict__ cat, const float* __restrict__ f1,
+                                                            const float* __restrict__ dE) {
+    __shared__ float lds[10240 + G_TOTAL];
+    float* ldsw = lds;
+    float* ldsg = lds + 10240;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    obs_stage_all(a, P, ldsw, tid);
+    for (int i = tid; i < G_TOTAL; i += 256) ldsg[i] = 0.0f;
+    __syncthreads();
+    // per-lane gradient rows kept in registers across this wave's traces
+    float gF1[OBS_EMAX], gF0[OBS_EMAX], gW1[OBS_HIDMAX], gW0[OBS_INMAX];
+    float gbF1 = 0.f, gbF0 = 0.f, gb1 = 0.f, gb0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < OBS_EMAX; ++k) gF1[k] = gF0[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < OBS_HIDMAX; ++k) gW1[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < OBS_INMAX; ++k) gW0[k] = 0.0f;
+    // which observable this lane belongs to, as a concat unit and as a hidden unit
+    int oc = -1, jc = 0, oh = -1, jh = 0, cin = 0;
+    {
+        int co = 0, ci = 0;
+        for (int o = 0; o < a.n_obs; ++o) {
+            if (lane >= co && lane < co + a.out[o]) { oc = o; jc = lane - co; }
+            if (lane >= a.hoff[o] && lane < a.hoff[o] + a.hid[o]) { oh = o; jh = lane - a.hoff[o]; cin = ci; }
+            co += a.out[o];
+            ci += a.in[o];
+        }
+    }
+    const bool acte = lane < a.e_obs;
+    const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
+    for (int t = 0; t < traces_per_wave; ++t) {
+        const int b = b0 + t;
+        if (b >= n_traces) break;   // wave-uniform
+        const float dz2 = acte ? dE[(int64_t)b * a.e_ld + lane] : 0.0f;   // already masked by E > 0
+        const float f1v = acte ? f1[(int64_t)b * a.e_ld + lane] : 0.0f;
+        const float catv = acte ? cat[(int64_t)b * a.e_ld + lane] : 0.0f;
+        // final layer 1: dW[j][k] += dz2_j * f1_k
+#pragma unroll
+        for (int k = 0; k < OBS_EMAX; ++k)
+            if (k < a.e_obs) gF1[k] += dz2 * bcast(f1v, k);
+        gbF1 += dz2;
+        float dz1 = obs_dense_t(ldsw, a.f1, lane, acte, dz2, 0);
+        dz1 = f1v > 0.0f ? dz1 : 0.0f;
+        // final layer 0
+#pragma unroll
+        for (int k = 0; k < OBS_EMAX; ++k)
+            if (k < a.e_obs) gF0[k] += dz1 * bcast(catv, k);
+        gbF0 += dz1;
+        float dzc = obs_dense_t(ldsw, a.f0, lane, acte, dz1, 0);
+        dzc = catv > 0.0f ? dzc : 0.0f;
+        // per-observable layer 1 (lane = concat unit) and layer 0 (lane = hidden unit)
+        float hv = 0.0f;
+        if (oh >= 0) hv = a.obs_h[oh][(int64_t)b * a.ohid_ld[oh] + jh];
+        float dh = 0.0f;
+        int co = 0;
+        for (int o = 0; o < a.n_obs; ++o) {
+            // dW1[jc][k] += dzc * h_k  for the lanes of this observable
+#pragma unroll
+            for (int k = 0; k < OBS_HIDMAX; ++k)
+                if (k < a.hid[o]) {
+                    const float hk = bcast(hv, a.hoff[o] + k);
+                    if (oc == o) gW1[k] += dzc * hk;
+                }
+            // dh_k = sum_j dzc_j W1[j][k]
+            const bool acth = (oh == o);
+            const float d = obs_dense_t(ldsw, a.l1[o], jh, acth, dzc, co);
+            if (acth) dh = d;
+            co += a.out[o];
+        }
+        if (oc >= 0) gb1 += dzc;
+        if (oh >= 0) {
+            dh = hv > 0.0f ? dh : 0.0f;
+            gb0 += dh;
+#pragma unroll
+            for (int i = 0; i < OBS_INMAX; ++i)
+                if (i < a.in[oh]) gW0[i] += dh * obs[(int64_t)b * a.width + cin + i];
+        }
+    }
+    // combine the four waves in LDS (one wave at a time: plain read-modify-write, static register indices), then one
+    // global atomic per parameter per workgroup
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int k = 0; k < OBS_EMAX; ++k) {
+                ldsg[G_F1 + lane * 65 + k] += gF1[k];
+                ldsg[G_F0 + lane * 65 + k] += gF0[k];
+            }
+#pragma unroll
+            for (int k = 0; k < OBS_HIDMAX; ++k) ldsg[G_W1 + lane * 33 + k] += gW1[k];
+#pragma unroll
+            for (int i = 0; i < OBS_INMAX; ++i) ldsg[G_W0 + lane * 9 + i] += gW0[i];
+            ldsg[G_B + lane] += gbF1;
+            ldsg[G_B + 64 + lane] += gbF0;
+            ldsg[G_B + 128 + lane] += gb1;
+            ldsg[G_B + 192 + lane] += gb0;
+        }
+        __syncthreads();
+    }
+    obs_flush_weight(a.f1, ldsg + G_F1, 65, 0, grads, tid);
+    obs_flush_weight(a.f0, ldsg + G_F0, 65, 0, grads, tid);
+    for (int i = tid; i < a.e_obs; i += 256) {
+        atomicAdd(grads + a.f1.b_off + i, ldsg[G_B + i]);
+        atomicAdd(grads + a.f0.b_off + i, ldsg[G_B + 64 + i]);
+    }
+    int co = 0;
+    for (int o = 0; o < a.n_obs; ++o) {
+        obs_flush_weight(a.l1[o], ldsg + G_W1, 33, co, grads, tid);            // rows = concat lanes of observable o
+        obs_flush_weight(a.l0[o], ldsg + G_W0, 9, a.hoff[o], grads, tid);      // rows = hidden lanes of observable o
+        for (int i = tid; i < a.out[o]; i += 256) atomicAdd(grads + a.l1[o].b_off + i, ldsg[G_B + 128 + co + i]);
+        for (int i = tid; i < a.hid[o]; i += 256) atomicAdd(grads + a.l0[o].b_off + i, ldsg[G_B + 192 + a.hoff[o] + i]);
+        co += a.out[o];
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+bool obs_fused_supported(const pp_net* net) {
+    if (net->e_obs > OBS_EMAX) return false;
+    int hsum = 0;
+    for (int o = 0; o < net->n_obs; ++o) {
+        if (net->obs_in[o] > OBS_INMAX || net->obs_hid[o] > OBS_HIDMAX || net->obs_hid[o] < 1) return false;
+        hsum += net->obs_hid[o];
+    }
+    return hsum <= 64;
+}
+
+static bool obs_fused_args(const pp_net* net, float* const* obs_h, ObsFusedArgs& a) {
+    for (int o = 0; o < PP_MAX_OBS; ++o) a.obs_h[o] = o < net->n_obs ? obs_h[o] : nullptr;
+    a.n_obs = net->n_obs;
+    a.e_obs = net->e_obs;
+    a.e_ld = round4(net->e_obs);
+    int lds = 0, hoff = 0, width = 0;
+    auto layer = [&](ObsLayer& L, int64_t w, int64_t b, int rows, int cols) {
+        L.w_off = w; L.b_off = b; L.rows = rows; L.cols = cols;
+        L.lds_w = lds; lds += rows * (cols + 1);
+        L.lds_b = lds; lds += rows;
+    };
+    for (int o = 0; o < net->n_obs; ++o) {
+        a.in[o] = net->obs_in[o]; a.hid[o] = net->obs_hid[o]; a.out[o] = net->obs_out[o];
+        a.hoff[o] = hoff; hoff += a.hid[o];
+        a.ohid_ld[o] = round4(a.hid[o]);
+        width += a.in[o];
+        layer(a.l0[o], net->obs_w0[o], net->obs_b0[o], a.hid[o], a.in[o]);
+        layer(a.l1[o], net->obs_w1[o], net->obs_b1[o], a.out[o], a.hid[o]);
+    }
+    a.width = width;
+    layer(a.f0, net->fin_w0, net->fin_b0, net->e_obs, net->e_obs);
+    layer(a.f1, net->fin_w1, net->fin_b1, net->e_obs, net->e_obs);
+    a.lds_total = lds;
+    return lds <= 10240;
+}
+
+static int pick_traces_per_wave(int n, int target_blocks) {
+    if (const char* e = getenv("PP_OBS_TPW")) return std::max(atoi(e), 1);   // tuning knob
+    return std::max((n + 4 * target_blocks - 1) / (4 * target_blocks), 1);
+}
+
+// obs_h: host array of n_obs device pointers; E/cat/f1 leading dim = round4(e_obs)
+int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
+                        float* cat, float* f1, float* E, hipStream_t st) {
+    ObsFusedArgs a;
+    if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
+    const int tpw = pick_traces_per_wave(n_traces, 256);   // forward: staging is cheap, spread the traces
+    hipLaunchKernelGGL(obs_embed_fwd_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat,
+                       f1, E);
+    PP_LAUNCH_CHECK("obs_embed_fwd_fused");
+    return 0;
+}
+
+int obs_embed_bwd_fused(const pp_net* net, const float* P, float* grads, const float* obs, int n_traces,
+                        float* const* obs_h, const float* cat, const float* f1, const float* dE, hipStream_t st) {
+    ObsFusedArgs a;
+    if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
+    // backward: every workgroup ends with ~10k global float atomics (measured ~16 ps each): fewer, longer workgroups
+    const int tpw = pick_traces_per_wave(n_traces, 64);
+    hipLaunchKernelGGL(obs_embed_bwd_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, grads, obs, n_traces, tpw,
+                       cat, f1, dE);
+    PP_LAUNCH_CHECK("obs_embed_bwd_fused");
+    return 0;
+}
+
+}  // namespace pp

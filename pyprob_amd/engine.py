@@ -155,6 +155,40 @@ class ICEngine:
         self.adam_step(lr, weight_decay=weight_decay)
         return loss
 
+    # ---- HIP graph replay of the step (static shapes) ------------------------------------------------------------
+    def capture_train_step(self, batch, lr, weight_decay=0.0):
+        """Capture zero_grad -> loss -> backward -> Adam for a batch of FIXED shape and FIXED buffer addresses into a
+        HIP graph (torch.cuda.CUDAGraph is the stream-capture plumbing; every node is one of this library's kernels or
+        a memset). Replaying it removes the per-launch host cost of the ~40 launches of a step. New data is fed by
+        copying the next minibatch into the captured batch's buffers (`PackedBatch.copy_columns_`). With data
+        parallelism the all-reduce stays outside: two graphs (loss+backward | Adam)."""
+        self._ensure_workspace(batch.n_traces, batch.n_rows)
+        self.loss(batch, backward=True)              # warm-up outside capture: workspace, presence map, lazy init
+        self.adam_step(lr, weight_decay=weight_decay)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        if self.world_size == 1:
+            with torch.cuda.graph(g1):
+                self.loss(batch, backward=True)
+                self.adam_step(lr, weight_decay=weight_decay)
+            self._graphs = (g1, None)
+        else:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self.loss(batch, backward=True)
+            with torch.cuda.graph(g2):
+                self.adam_step(lr, weight_decay=weight_decay)
+            self._graphs = (g1, g2)
+        return self._graphs
+
+    def replay_train_step(self):
+        g1, g2 = self._graphs
+        g1.replay()
+        if g2 is not None:
+            self.allreduce_grads()
+            g2.replay()
+        return self.loss_buf[:1]
+
     # ---- data parallel ------------------------------------------------------------------------------------
     def allreduce_grads(self):
         """ONE RCCL all-reduce (SUM) over [flat grads | presence map | loss]

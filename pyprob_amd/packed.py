@@ -155,6 +155,39 @@ class PackedBatch:
         return pb
 
 
+class ColumnarDataset:
+    """Packed offline dataset of homogeneous length-1 traces resident in HBM, stored minibatch-blocked:
+    block i = [obs (B x w) | value (B) | prior (B x 2)] contiguous, so a minibatch is ONE contiguous slice
+    (zero-copy view for eager steps, one device copy into the captured buffers for HIP-graph replay)."""
+
+    def __init__(self, obs, value, prior, batch_size):
+        import torch
+        n = (value.shape[0] // batch_size) * batch_size
+        self.B, self.w = batch_size, obs.shape[1]
+        self.n_batches = n // batch_size
+        B, w = self.B, self.w
+        blk = torch.cat([obs[:n].reshape(self.n_batches, B * w), value[:n].reshape(self.n_batches, B),
+                         prior[:n].reshape(self.n_batches, B * 2)], dim=1).contiguous()
+        self.blocks = blk                    # [n_batches, B*(w+3)]
+
+    def columns(self, i, block=None):
+        B, w = self.B, self.w
+        row = self.blocks[i % self.n_batches] if block is None else block
+        return row[:B * w].view(B, w), row[B * w:B * w + B], row[B * w + B:].view(B, 2)
+
+    def batch(self, i, addr_id, n_addr, index_cache):
+        return PackedBatch.from_device_columns(*self.columns(i), addr_id, n_addr, index_cache)
+
+    def staging_batch(self, addr_id, n_addr, index_cache):
+        """A batch whose buffers stay at fixed addresses (for graph capture); fill with `load_into`."""
+        import torch
+        self._stage = torch.empty_like(self.blocks[0])
+        return PackedBatch.from_device_columns(*self.columns(0, self._stage), addr_id, n_addr, index_cache)
+
+    def load_into_staging(self, i):
+        self._stage.copy_(self.blocks[i % self.n_batches])
+
+
 def pack_traces(traces, spec, obs_names):
     """list of pyprob-style Trace objects (duck-typed: .variables_controlled[*].{address, value, distribution},
     .named_variables[name].value) -> PackedBatch (host). Mirrors what Batch.__init__ + the torch.stack calls of
