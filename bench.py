@@ -117,7 +117,7 @@ def main():
     ap.add_argument('--dataset', type=int, default=1000000, help='offline traces resident in HBM (per job)')
     ap.add_argument('--particles', type=int, default=1000000, help='IS particles per job')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', type=int, default=1, help='replay the step as a captured HIP graph (1) or launch eagerly (0)')
+    ap.add_argument('--graph', type=int, default=0, help='replay the step as a captured HIP graph (1) or launch eagerly (0)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -38,21 +38,54 @@ void set_error(const char* fmt, ...);
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// 64-lane butterfly sum; every lane ends with the total.
+// ---- wave64 reductions on the VALU (DPP) -------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip per step); a reduction that sits on the critical
+// path of a latency-bound kernel is ~10x cheaper with DPP: quad_perm for xor 1/2, row_ror 4/8 for the 16-lane row,
+// then v_readlane of the four row totals. Every lane ends with the total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
+
+// Cooperative global -> LDS copy by a 256-thread workgroup with 8 independent loads in flight per thread (a plain
+// `for (i = tid; i < n; i += 256) lds[i] = g[i]` is compiled load -> wait -> store and pays a full memory round trip
+// per element: ~1 us each at low occupancy).
+__device__ __forceinline__ void stage_to_lds(float* __restrict__ lds, const float* __restrict__ g, int n, int tid) {
+    for (int base = tid; base < n; base += 256 * 8) {
+        float v[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 256 * u;
+            v[u] = i < n ? g[i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 256 * u;
+            if (i < n) lds[i] = v[u];
+        }
+    }
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -2,6 +2,7 @@
 // the step-major packed trace batch. No allocation, no host synchronisation: every launch goes to the caller's stream.
 #include "common.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -28,6 +29,11 @@ int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh
 int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
                  int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
                  hipStream_t st);
+bool head_tail_supported(int kind, int hid, int n_out);
+int head_tail(int kind, const float* A1, int64_t lda1, const float* W2, const float* b2, int hid, int n_out,
+              const int32_t* rows, const float* value, const float* prior, int n, float grad_scale, float* lp_out,
+              float* DY, int64_t lddy, float* dZ1, int64_t lddz, float* db1, float* db2, float* loss_acc,
+              int32_t* nonfinite, hipStream_t st);
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out,
                   hipStream_t st);
 int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
@@ -61,6 +67,41 @@ static void prof_end(int which, double flops, hipStream_t st) {
         g_prof.flops[g_prof.used] = flops;
         g_prof.used++;
     }
+}
+
+// ---- auxiliary stream: the weight-gradient products run beside the data-gradient chain -------------------------
+// Every kernel of a 1024-trace step is far too small to fill 256 CUs, and the weight-gradient GEMMs (dW = dz^T x) are
+// leaves of the dependency graph, so they are forked onto a second HIP stream with event dependencies (captured as
+// graph edges under HIP-graph capture). Opt-in with PP_TWO_STREAMS=1.
+struct Aux {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork[3] = {nullptr, nullptr, nullptr}, join = nullptr;
+    bool ok = false, tried = false;
+};
+static Aux g_aux;
+
+static bool aux_ready() {
+    if (g_aux.tried) return g_aux.ok;
+    g_aux.tried = true;
+    // measured on MI355X (round 1): no gain over one stream for the 1024-trace step (330 vs 332 us), so opt-in only
+    const char* e = getenv("PP_TWO_STREAMS");
+    if (!e || atoi(e) == 0) return false;
+    if (hipStreamCreateWithFlags(&g_aux.stream, hipStreamNonBlocking) != hipSuccess) return false;
+    for (auto& ev : g_aux.fork)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&g_aux.join, hipEventDisableTiming) != hipSuccess) return false;
+    g_aux.ok = true;
+    return true;
+}
+
+// aux stream waits for everything issued so far on `st`
+static void aux_fork(int i, hipStream_t st) {
+    (void)hipEventRecord(g_aux.fork[i], st);
+    (void)hipStreamWaitEvent(g_aux.stream, g_aux.fork[i], 0);
+}
+static void aux_join(hipStream_t st) {
+    (void)hipEventRecord(g_aux.join, g_aux.stream);
+    (void)hipStreamWaitEvent(st, g_aux.join, 0);
 }
 
 // ---- workspace carving ------------------------------------------------------------------------------
@@ -141,7 +182,7 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.dF1 = c.take<float>((int64_t)B * w.e4);
     w.dCat = c.take<float>((int64_t)B * w.e4);
     w.dObsH = c.take<float>((int64_t)B * w.maxohid4);
-    w.loss_acc = c.take<float>(128);   // one 512-byte region: [loss accumulator | non-finite flag], zeroed by one memset
+    w.loss_acc = c.take<float>(128);   // one 512-byte region: [64 loss accumulator slots | non-finite flag], one memset
     w.flag = reinterpret_cast<int32_t*>(w.loss_acc ? w.loss_acc + 64 : nullptr);
     w.bytes = c.off + 256;
 }
@@ -270,6 +311,18 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         float* A1 = w.A1 + (int64_t)g0 * w.hid4;
         float* Y = w.Y + (int64_t)g0 * w.out4;
         PP_TRY(linear_fwd(w.Hs, H, bt->grp_rows + g0, P + ad.w1, P + ad.b1, A1, w.hid4, n, H, ad.hid, true, nullptr, st));
+        if (head_tail_supported(ad.kind, ad.hid, ad.n_out)) {
+            // fused tail: layer 2 + log_prob + loss (+ dy, dz1, db1, db2 when training) in one launch
+            PP_TRY(head_tail(ad.kind, A1, w.hid4, P + ad.w2, P + ad.b2, ad.hid, ad.n_out, bt->grp_rows + g0, bt->value,
+                             bt->prior, n, gscale, (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr,
+                             bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr, w.out4, w.dZ1 + (int64_t)g0 * w.hid4, w.hid4,
+                             nullptr, nullptr, w.loss_acc, w.flag, st));
+            if (bwd) {   // bias gradients by the low-contention column-sum kernel
+                PP_TRY(colsum_f32(w.DY + (int64_t)g0 * w.out4, w.out4, nullptr, n, ad.n_out, grads + ad.b2, nullptr, st));
+                PP_TRY(colsum_f32(w.dZ1 + (int64_t)g0 * w.hid4, w.hid4, nullptr, n, ad.hid, grads + ad.b1, nullptr, st));
+            }
+            continue;
+        }
         PP_TRY(linear_fwd(A1, w.hid4, nullptr, P + ad.w2, P + ad.b2, Y, w.out4, n, ad.hid, ad.n_out, false, nullptr, st));
         PP_TRY(head_logprob(ad.kind, Y, w.out4, bt->grp_rows + g0, bt->value, bt->prior, n, ad.n_out, gscale,
                             (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr, bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr,
@@ -279,6 +332,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     if (!bwd) return 0;
 
     // ---------------- backward ----------------
+    // `sw` carries the weight-gradient leaves (second stream when available), `st` the data-gradient chain.
+    const bool two = aux_ready();
+    hipStream_t sw = two ? g_aux.stream : st;
+    if (two) aux_fork(0, st);   // DY, A1 ready
     for (int a = 0; a < net->n_addr; ++a) {
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
         if (n <= 0) continue;
@@ -286,10 +343,20 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const float* A1 = w.A1 + (int64_t)g0 * w.hid4;
         const float* DY = w.DY + (int64_t)g0 * w.out4;
         float* dZ1 = w.dZ1 + (int64_t)g0 * w.hid4;
-        PP_TRY(linear_wgrad(DY, w.out4, A1, w.hid4, nullptr, grads + ad.w2, grads + ad.b2, nullptr, n, ad.hid, ad.n_out, st));
-        PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st,
-                            grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
-        PP_TRY(linear_wgrad(dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, nullptr, nullptr, n, H, ad.hid, st));
+        const bool fused = head_tail_supported(ad.kind, ad.hid, ad.n_out);   // dz1, db1, db2 already produced forward
+        PP_TRY(linear_wgrad(DY, w.out4, A1, w.hid4, nullptr, grads + ad.w2, fused ? nullptr : grads + ad.b2, nullptr, n,
+                            ad.hid, ad.n_out, sw));
+        if (!fused)
+            PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st,
+                                grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
+    }
+    if (two) aux_fork(1, st);   // dZ1 ready
+    for (int a = 0; a < net->n_addr; ++a) {
+        const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
+        if (n <= 0) continue;
+        const pp_addr& ad = net->addrs[a];
+        float* dZ1 = w.dZ1 + (int64_t)g0 * w.hid4;
+        PP_TRY(linear_wgrad(dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, nullptr, nullptr, n, H, ad.hid, sw));
         PP_TRY(linear_dgrad(dZ1, w.hid4, P + ad.w1, w.dH, H, bt->grp_rows + g0, nullptr, 0, n, H, ad.hid, false, st));
     }
     for (int t = T - 1; t >= 0; --t) {
@@ -304,11 +371,12 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                                 H, 4 * H, true, st));
     }
     // LSTM parameter gradients
-    PP_TRY(linear_wgrad(w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, nullptr, nullptr, R, I, 4 * H, st));
+    if (two) aux_fork(2, st);   // dG ready
+    PP_TRY(linear_wgrad(w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, nullptr, nullptr, R, I, 4 * H, sw));
     if (T > 1) {
         const int r1 = bt->row_off[1];
         PP_TRY(linear_wgrad(w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, nullptr, nullptr,
-                            R - r1, H, 4 * H, st));
+                            R - r1, H, 4 * H, sw));
     }
     // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding
     PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, false, st));
@@ -333,6 +401,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));
     if (obs_fused_supported(net)) {
         PP_TRY(obs_embed_bwd_fused(net, P, grads, bt->obs, B, w.obs_h, w.cat, w.f1, w.dE, st));
+        if (two) aux_join(st);
         return 0;
     }
     const int e = net->e_obs;
@@ -353,6 +422,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         ci += in;
         co += out;
     }
+    if (two) aux_join(st);
     return 0;
 }
 

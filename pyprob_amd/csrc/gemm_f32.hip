@@ -42,14 +42,24 @@ struct GemmParams {
 
 // ---- global -> register staging of one [ROWS x BK] operand slab ------------------------------------------
 // KM = false: element (row, k) at P[ix(row0+row)*ld + k0+k]; KM = true: at P[ix(k0+k)*ld + row0+row].
+// Everything that does not depend on the slab (row gather, base pointers, edge predicates) is resolved once in
+// init(); the K loop only adds the slab offset and issues the loads.
 template <int ROWS, bool KM, int VEC>
 struct Stager {
     static constexpr int PER_THREAD = ROWS * BK / 256;  // floats per thread
     static constexpr int NV = PER_THREAD / VEC;         // vector slots per thread
-    float r[PER_THREAD];
+    float r[2][PER_THREAD];      // two register sets (software pipeline, static indices only)
+    const float* base[NV];       // !KM: &P[ix(row)*ld + k_slot];  KM: &P[row_slot] (k added per slab)
+    int kslot[NV];               // this slot's k inside a slab
+    bool ok[NV];                 // row inside the matrix
+    bool vec[NV];                // KM: all VEC rows of the slot inside the matrix
+    const int32_t* idx;
+    int64_t ld;
+    int K, nrows, grow0[NV];
 
-    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, const int32_t* __restrict__ idx,
-                                         int row0, int nrows, int k0, int K, int tid) {
+    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld_, const int32_t* __restrict__ idx_,
+                                         int row0, int nrows_, int K_, int tid) {
+        idx = idx_; ld = ld_; K = K_; nrows = nrows_;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int s = tid + 256 * p;
@@ -61,44 +71,64 @@ struct Stager {
                 k = s / (ROWS / VEC);
                 row = (s % (ROWS / VEC)) * VEC;
             }
-            const int grow = row0 + row, gk = k0 + k;
+            const int grow = row0 + row;
+            kslot[p] = k;
+            grow0[p] = grow;
+            ok[p] = grow < nrows;
+            vec[p] = grow + VEC - 1 < nrows;
             if (!KM) {
-                if (grow < nrows && gk < K) {
-                    const int64_t rr = idx ? (int64_t)idx[grow] : (int64_t)grow;
-                    const float* src = P + rr * ld + gk;
-                    if (VEC == 4 && gk + 3 < K) {
+                const int64_t rr = (ok[p] && idx) ? (int64_t)idx[grow] : (int64_t)(ok[p] ? grow : 0);
+                base[p] = P + rr * ld + k;
+            } else {
+                base[p] = P + (ok[p] ? grow : 0);
+            }
+        }
+    }
+
+    template <int SET>
+    __device__ __forceinline__ void load(int k0) {
+        const bool full = k0 + BK <= K;   // block-uniform
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            float* dst = &r[SET][p * VEC];
+            if (!KM) {
+                const float* src = base[p] + k0;
+                const int gk = k0 + kslot[p];
+                if (ok[p] && (full || gk + VEC - 1 < K)) {
+                    if (VEC == 4) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = v[e];
+                        for (int e = 0; e < VEC; ++e) dst[e] = v[e];
                     } else {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = (gk + e < K) ? src[e] : 0.0f;
+                        dst[0] = src[0];
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) r[p * VEC + e] = 0.0f;
+                    for (int e = 0; e < VEC; ++e) dst[e] = (ok[p] && gk + e < K) ? src[e] : 0.0f;
                 }
             } else {
-                if (gk < K && grow < nrows) {
+                const int gk = k0 + kslot[p];
+                if (ok[p] && gk < K) {
                     const int64_t kk = idx ? (int64_t)idx[gk] : (int64_t)gk;
-                    const float* src = P + kk * ld + grow;
-                    if (VEC == 4 && grow + 3 < nrows) {
+                    const float* src = base[p] + kk * ld;
+                    if (VEC == 4 && vec[p]) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = v[e];
+                        for (int e = 0; e < VEC; ++e) dst[e] = v[e];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) r[p * VEC + e] = (grow + e < nrows) ? src[e] : 0.0f;
+                        for (int e = 0; e < VEC; ++e) dst[e] = (grow0[p] + e < nrows) ? src[e] : 0.0f;
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) r[p * VEC + e] = 0.0f;
+                    for (int e = 0; e < VEC; ++e) dst[e] = 0.0f;
                 }
             }
         }
     }
 
     // LDS image: !KM -> [ROWS][BK+KPAD], KM -> [BK][ROWS+KPAD]
+    template <int SET>
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -114,10 +144,10 @@ struct Stager {
             if (VEC == 4) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = r[p * VEC + e];
+                for (int e = 0; e < 4; ++e) v[e] = r[SET][p * VEC + e];
                 *reinterpret_cast<f32x4*>(S + off) = v;
             } else {
-                S[off] = r[p];
+                S[off] = r[SET][p];
             }
         }
     }
@@ -169,8 +199,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 
     // two register sets: the loads of slab i+2 are issued before the MFMAs of slab i and consumed after the MFMAs
     // of slab i+1, so ~2 slabs of matrix work cover one HBM/L2 round trip.
-    Stager<BM, A_KM, VEC> sa0, sa1;
-    Stager<BN, B_KM, VEC> sb0, sb1;
+    Stager<BM, A_KM, VEC> sa;
+    Stager<BN, B_KM, VEC> sb;
+    sa.init(p.A, p.lda, p.a_idx, m0, p.M, p.K, tid);
+    sb.init(p.B, p.ldb, p.b_idx, n0, p.N, p.K, tid);
     auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
@@ -188,37 +220,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
     };
-    sa0.load(p.A, p.lda, p.a_idx, m0, p.M, s_begin * BK, p.K, tid);
-    sb0.load(p.B, p.ldb, p.b_idx, n0, p.N, s_begin * BK, p.K, tid);
+    const int kb = s_begin * BK;
+    sa.template load<0>(kb);
+    sb.template load<0>(kb);
     if (nslab > 1) {
-        sa1.load(p.A, p.lda, p.a_idx, m0, p.M, (s_begin + 1) * BK, p.K, tid);
-        sb1.load(p.B, p.ldb, p.b_idx, n0, p.N, (s_begin + 1) * BK, p.K, tid);
+        sa.template load<1>(kb + BK);
+        sb.template load<1>(kb + BK);
     }
-    sa0.store(As, tid);
-    sb0.store(Bs, tid);
+    sa.template store<0>(As, tid);
+    sb.template store<0>(Bs, tid);
     __syncthreads();
     for (int i = 0; i < nslab; i += 2) {
         // LDS holds slab i, set 1 holds slab i+1 (in flight), set 0 is free
         if (i + 2 < nslab) {
-            sa0.load(p.A, p.lda, p.a_idx, m0, p.M, (s_begin + i + 2) * BK, p.K, tid);
-            sb0.load(p.B, p.ldb, p.b_idx, n0, p.N, (s_begin + i + 2) * BK, p.K, tid);
+            sa.template load<0>(kb + (i + 2) * BK);
+            sb.template load<0>(kb + (i + 2) * BK);
         }
         compute();
         if (i + 1 >= nslab) break;
         __syncthreads();
-        sa1.store(As, tid);
-        sb1.store(Bs, tid);
+        sa.template store<1>(As, tid);
+        sb.template store<1>(Bs, tid);
         __syncthreads();
         // LDS holds slab i+1, set 0 holds slab i+2 (in flight), set 1 is free
         if (i + 3 < nslab) {
-            sa1.load(p.A, p.lda, p.a_idx, m0, p.M, (s_begin + i + 3) * BK, p.K, tid);
-            sb1.load(p.B, p.ldb, p.b_idx, n0, p.N, (s_begin + i + 3) * BK, p.K, tid);
+            sa.template load<1>(kb + (i + 3) * BK);
+            sb.template load<1>(kb + (i + 3) * BK);
         }
         compute();
         if (i + 2 >= nslab) break;
         __syncthreads();
-        sa0.store(As, tid);
-        sb0.store(Bs, tid);
+        sa.template store<0>(As, tid);
+        sb.template store<0>(Bs, tid);
         __syncthreads();
     }
 

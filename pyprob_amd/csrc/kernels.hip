@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -579,10 +580,202 @@ int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, con
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fused proposal-head tail for the mixture heads: second FF layer (y = a1 W2^T + b2), proposal transforms, mixture
+// log_prob, loss, d lp/d y, bias gradients and the masked data gradient dz1 = (dy W2) * [a1 > 0] in ONE kernel.
+// One wavefront per row: lanes split the hidden units (coalesced a1 / dz1 rows, conflict-free LDS reads of W2),
+// wave reductions give y; lanes 0..K-1 then own one mixture component each, so the exp/log/erf work is spread over
+// lanes instead of serialised in one thread. W2 is staged once per workgroup in LDS.
+// Replaces: Y GEMM (unaligned W2 rows -> scalar loads), head_mixture_kernel, dz1 GEMM, colsum(db2) = 4 launches.
+// ------------------------------------------------------------------------------------------------------
+constexpr int TAIL_MAX_Q = 16;        // hidden units per lane: hid <= 1024
+constexpr int TAIL_LDS_FLOATS = 16384;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ A1, int64_t lda1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        int hid, int K, const int32_t* __restrict__ rows,
+                                                        const float* __restrict__ value,
+                                                        const float* __restrict__ prior, int n, int rows_per_wave,
+                                                        float grad_scale, float* __restrict__ lp_out,
+                                                        float* __restrict__ DY, int64_t lddy,
+                                                        float* __restrict__ dZ1, int64_t lddz,
+                                                        float* __restrict__ db1, float* __restrict__ db2,
+                                                        float* __restrict__ loss_acc, int32_t* __restrict__ nonfinite) {
+    __shared__ float w2s[TAIL_LDS_FLOATS];
+    __shared__ float ys[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_out = 3 * K;
+    stage_to_lds(w2s, W2, n_out * hid, tid);
+    __syncthreads();
+    const int nq = (hid + 63) / 64;
+    const bool bwd = DY != nullptr;
+    float gb1[TAIL_MAX_Q];
+#pragma unroll
+    for (int q = 0; q < TAIL_MAX_Q; ++q) gb1[q] = 0.0f;
+    float gb2a = 0.f, gb2b = 0.f, gb2c = 0.f, loss_local = 0.f;
+    bool bad_any = false;
+    const bool comp = lane < K;
+    const int i0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+    for (int t = 0; t < rows_per_wave; ++t) {
+        const int i = i0 + t;
+        if (i >= n) break;   // wave-uniform
+        const int r = rows ? rows[i] : i;
+        float a1[TAIL_MAX_Q];
+#pragma unroll
+        for (int q = 0; q < TAIL_MAX_Q; ++q) {
+            const int j = lane + 64 * q;
+            a1[q] = (q < nq && j < hid) ? A1[(int64_t)i * lda1 + j] : 0.0f;
+        }
+        // second layer: y_o = b2[o] + sum_j a1_j W2[o][j]
+        for (int o = 0; o < n_out; ++o) {
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < TAIL_MAX_Q; ++q) {
+                const int j = lane + 64 * q;
+                if (q < nq && j < hid) part += a1[q] * w2s[o * hid + j];
+            }
+            part = wave_sum(part);
+            if (lane == 0) ys[wave][o] = part + b2[o];
+        }
+        // one mixture component per lane
+        const float v = value[r], pa = prior[2 * r], pb = prior[2 * r + 1];
+        const float ymu = comp ? ys[wave][lane] : 0.0f, ysd = comp ? ys[wave][K + lane] : 0.0f;
+        const float yz = comp ? ys[wave][2 * K + lane] : -INFINITY;
+        const float zmax = wave_max(yz);
+        const float e = comp ? expf(yz - zmax) : 0.0f;
+        const float pi = e / wave_sum(e);
+        const float ps = wave_sum(pi);
+        const float p = pi / ps;
+        float mu, sd, sm = 0.f, ss = 0.f, rng = pb - pa;
+        if (KIND == 0) {
+            mu = pa + ymu * pb;
+            sd = expf(ysd) * pb;
+        } else {
+            sm = sigmoidf_(ymu);
+            ss = sigmoidf_(ysd);
+            mu = pa + sm * rng;
+            sd = rng / 1000.0f + ss * rng * 10.0f;
+        }
+        const float tt = (v - mu) / sd;
+        float cl, alpha = 0.f, beta = 0.f, Z = 1.f;
+        if (KIND == 0) {
+            cl = -0.5f * tt * tt - logf(sd) - kHalfLog2Pi;
+        } else {
+            alpha = (pa - mu) / sd;
+            beta = (pb - mu) / sd;
+            Z = std_cdf(beta) - std_cdf(alpha);
+            const bool inside = v >= pa && v <= pb;
+            cl = (inside ? 0.0f : -INFINITY) + (-0.5f * tt * tt - kHalfLog2Pi) - logf(sd * Z);
+        }
+        const float a = comp ? logf(fminf(fmaxf(p, kFp32Eps), 1.0f - kFp32Eps)) + cl : -INFINITY;
+        const float amax = wave_max(a);
+        float lp = amax;
+        if (amax > -INFINITY) lp = amax + logf(wave_sum(comp ? expf(a - amax) : 0.0f));
+        else if (amax != amax) lp = amax;
+        // NaN in any component poisons the max/sum like the reference's logsumexp would
+        const float anan = wave_sum((comp && a != a) ? 1.0f : 0.0f);
+        if (anan > 0.0f) lp = NAN;
+        if (lp_out && lane == 0) lp_out[r] = lp;
+        const bool rescued = (lp == -INFINITY);
+        const bool bad = !rescued && !isfinite(lp);
+        bad_any |= bad;
+        if (lane == 0) loss_local += rescued ? -kLogEps : -lp;
+        if (!bwd) continue;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        const bool live = !(rescued || bad);
+        {
+            const float resp = (comp && live) ? expf(a - lp) : 0.0f;
+            const bool in = (p >= kFp32Eps) && (p <= 1.0f - kFp32Eps);
+            float dp = (comp && in) ? resp / p : 0.0f;
+            const float dpp = wave_sum(dp * p);
+            dp = comp ? (dp - dpp) / ps : 0.0f;
+            const float dpipi = wave_sum(dp * pi);
+            if (comp && live) {
+                if (KIND == 0) {
+                    d0 = grad_scale * resp * tt / sd * pb;
+                    d1 = grad_scale * resp * (tt * tt - 1.0f);
+                } else {
+                    const float fa = std_pdf(alpha), fb = std_pdf(beta);
+                    const float dmu = resp * (tt / sd - (fa - fb) / (sd * Z));
+                    const float dsd = resp * ((tt * tt - 1.0f) / sd - (alpha * fa - beta * fb) / (sd * Z));
+                    d0 = grad_scale * dmu * rng * sm * (1.0f - sm);
+                    d1 = grad_scale * dsd * rng * 10.0f * ss * (1.0f - ss);
+                }
+                d2 = grad_scale * pi * (dp - dpipi);
+            }
+        }
+        if (comp) {
+            float* dy = DY + (int64_t)i * lddy;
+            dy[lane] = d0; dy[K + lane] = d1; dy[2 * K + lane] = d2;
+            ys[wave][lane] = d0; ys[wave][K + lane] = d1; ys[wave][2 * K + lane] = d2;
+            gb2a += d0; gb2b += d1; gb2c += d2;
+        }
+        // dz1_j = [a1_j > 0] * sum_o dy_o W2[o][j]     (ys[wave][*] written and read by the same wave: in order)
+        float dz[TAIL_MAX_Q];
+#pragma unroll
+        for (int q = 0; q < TAIL_MAX_Q; ++q) dz[q] = 0.0f;
+        for (int o = 0; o < n_out; ++o) {
+            const float dyo = ys[wave][o];
+#pragma unroll
+            for (int q = 0; q < TAIL_MAX_Q; ++q) {
+                const int j = lane + 64 * q;
+                if (q < nq && j < hid) dz[q] += dyo * w2s[o * hid + j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TAIL_MAX_Q; ++q) {
+            const int j = lane + 64 * q;
+            if (q < nq && j < hid) {
+                const float d = a1[q] > 0.0f ? dz[q] : 0.0f;
+                dZ1[(int64_t)i * lddz + j] = d;
+                gb1[q] += d;
+            }
+        }
+    }
+    // loss: one atomic per wave, spread over 64 accumulator slots (same-address float atomics serialise at ~40 ns
+    // each in L2; a thousand waves on one word cost ~40 us). loss_finalize sums the slots.
+    if (lane == 0 && loss_acc && loss_local != 0.0f) atomicAdd(loss_acc + ((blockIdx.x * 4 + wave) & 63), loss_local);
+    if (bad_any && nonfinite && lane == 0) atomicOr(nonfinite, 1);
+    // The bias gradients db1 = colsum(dz1), db2 = colsum(dy) are NOT accumulated here: ~1000 waves adding to the
+    // same few hundred addresses serialise in L2 (measured: +40 us); the caller runs the 16-way colsum kernel instead.
+    (void)gb1; (void)gb2a; (void)gb2b; (void)gb2c; (void)db1; (void)db2;
+}
+
+bool head_tail_supported(int kind, int hid, int n_out) {
+    static const bool disabled = getenv("PP_NO_HEAD_TAIL") && atoi(getenv("PP_NO_HEAD_TAIL")) != 0;   // A/B knob
+    if (disabled) return false;
+    if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE) return false;
+    if (n_out % 3 != 0 || n_out / 3 > MAXK || n_out / 3 < 1) return false;
+    return hid <= 64 * TAIL_MAX_Q && (int64_t)hid * n_out <= TAIL_LDS_FLOATS;
+}
+
+int head_tail(int kind, const float* A1, int64_t lda1, const float* W2, const float* b2, int hid, int n_out,
+              const int32_t* rows, const float* value, const float* prior, int n, float grad_scale, float* lp_out,
+              float* DY, int64_t lddy, float* dZ1, int64_t lddz, float* db1, float* db2, float* loss_acc,
+              int32_t* nonfinite, hipStream_t st) {
+    PP_CHECK_ARG(head_tail_supported(kind, hid, n_out), "head_tail: unsupported head shape");
+    PP_CHECK_ARG(!DY || dZ1, "head_tail: backward needs dZ1");
+    if (n <= 0) return 0;
+    // ~256 workgroups: W2 staging (n_out*hid floats) is amortised over rows_per_wave rows per wave
+    const int rpw = std::max((n + 4 * 256 - 1) / (4 * 256), 1);
+    dim3 grid(cdiv(n, 4 * rpw)), block(256);
+    if (kind == PP_HEAD_NORMAL_MIXTURE)
+        hipLaunchKernelGGL(head_tail_kernel<0>, grid, block, 0, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n,
+                           rpw, grad_scale, lp_out, DY, lddy, dZ1, lddz, db1, db2, loss_acc, nonfinite);
+    else
+        hipLaunchKernelGGL(head_tail_kernel<1>, grid, block, 0, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n,
+                           rpw, grad_scale, lp_out, DY, lddy, dZ1, lddz, db1, db2, loss_acc, nonfinite);
+    PP_LAUNCH_CHECK("head_tail");
+    return 0;
+}
+
 // loss = acc / B, status = non-finite flag
 __global__ void loss_finalize_kernel(const float* __restrict__ acc, const int32_t* __restrict__ flag, float inv_b,
                                      float* __restrict__ loss_out, int32_t* __restrict__ status_out) {
-    const float l = acc[0] * inv_b;
+    float tot = 0.0f;
+    for (int k = 0; k < 64; ++k) tot += acc[k];   // accumulator slots
+    const float l = tot * inv_b;
     loss_out[0] = l;
     if (status_out) status_out[0] = (flag[0] != 0 || !isfinite(l)) ? 1 : 0;
 }

@@ -42,9 +42,22 @@ __device__ __forceinline__ float bcast(float x, int idx) {
 
 __device__ __forceinline__ void obs_stage_layer(const ObsLayer& L, const float* __restrict__ P, float* lds, int tid) {
     const int n = L.rows * L.cols;
-    for (int i = tid; i < n; i += 256) {   // flat index: every lane busy even for the 1-column layers
-        const int r = i / L.cols, c = i - r * L.cols;
-        lds[L.lds_w + r * (L.cols + 1) + c] = P[L.w_off + i];
+    const float* g = P + L.w_off;
+    for (int base = tid; base < n; base += 256 * 8) {   // 8 loads in flight per thread, then the padded-row stores
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 256 * u;
+            v[u] = i < n ? g[i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 256 * u;
+            if (i < n) {
+                const int r = i / L.cols, c = i - r * L.cols;
+                lds[L.lds_w + r * (L.cols + 1) + c] = v[u];
+            }
+        }
     }
     for (int i = tid; i < L.rows; i += 256) lds[L.lds_b + i] = P[L.b_off + i];
 }
@@ -330,7 +343,7 @@ int obs_embed_bwd_fused(const pp_net* net, const float* P, float* grads, const f
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
     // backward: every workgroup ends with ~10k global float atomics (measured ~16 ps each): fewer, longer workgroups
-    const int tpw = pick_traces_per_wave(n_traces, 64);
+    const int tpw = pick_traces_per_wave(n_traces, 128);   // A/B on MI355X: 128 workgroups best (0.338 vs 0.348/0.355 ms/step)
     hipLaunchKernelGGL(obs_embed_bwd_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, grads, obs, n_traces, tpw,
                        cat, f1, dE);
     PP_LAUNCH_CHECK("obs_embed_bwd_fused");
