@@ -270,6 +270,13 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
 int pp_prof_arm(int32_t which, int32_t max_samples);          /* allocate event pairs; 0 disarms */
 int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_out); /* syncs the events */
 
+/* Diagnostic: one wave runs `iters` dependent FMAs; out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed
+ * 100 MHz wall ticks (s_memrealtime). Effective shader clock = out[0] / (out[1] * 10 ns): used by bench.py to report the
+ * DVFS state the timed region ran in (MI355X_MICROARCH.md "DVFS give-back"). */
+/* Diagnostic: when set, the fused head-tail kernel writes per-phase s_memtime stamps of workgroups 0 and 100 to buf. */
+int pp_debug_timeline(long long* buf /*dev [16] or NULL*/);
+int pp_debug_clock_probe(int32_t iters, long long* out /*dev [2]*/, float* sink /*dev [1]*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

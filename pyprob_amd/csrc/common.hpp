@@ -10,6 +10,9 @@ namespace pp {
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 void set_error(const char* fmt, ...);
 
 #define PP_CHECK_ARG(cond, ...)          \

@@ -40,6 +40,8 @@ int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_p
               const float* active, int32_t* tensor_step, float* corr, int n_tensors, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t st);
 
+extern long long* g_timeline;   // kernels.hip
+
 // obs_embed.hip
 bool obs_fused_supported(const pp_net* net);
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
@@ -494,6 +496,33 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
                     int32_t* nonfinite, void* stream) {
     return pp::head_logprob(kind, y, ldy, rows, value, prior, n, n_out, grad_scale, lp_out, dy, loss_acc, nonfinite,
                             pp::as_stream(stream));
+}
+
+// Shader-clock probe: one wave spins for `iters` dependent FMAs and records s_memtime (shader cycles) and
+// s_memrealtime (100 MHz wall clock) before and after. out[0] = shader cycles, out[1] = wall ticks (10 ns).
+__global__ void clock_probe_kernel(int iters, long long* out, float* sink) {
+    float x = (float)threadIdx.x;
+    const long long c0 = clock64();
+    const long long w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) x = x * 1.0000001f + 0.5f;
+    const long long c1 = clock64();
+    const long long w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w1 - w0;
+    }
+    if (x == 123.456f) sink[0] = x;
+}
+
+int pp_debug_clock_probe(int32_t iters, long long* out /*dev [2]*/, float* sink /*dev [1]*/, void* stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, pp::as_stream(stream), iters, out, sink);
+    PP_LAUNCH_CHECK("pp_debug_clock_probe");
+    return 0;
+}
+
+int pp_debug_timeline(long long* buf /*dev [16] or NULL*/) {
+    pp::g_timeline = buf;
+    return 0;
 }
 
 int pp_prof_arm(int32_t which, int32_t max_samples) {

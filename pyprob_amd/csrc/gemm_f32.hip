@@ -23,8 +23,6 @@
 
 namespace pp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int KPAD = 4;

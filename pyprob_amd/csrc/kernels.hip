@@ -588,10 +588,11 @@ int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, con
 // lanes instead of serialised in one thread. W2 is staged once per workgroup in LDS.
 // Replaces: Y GEMM (unaligned W2 rows -> scalar loads), head_mixture_kernel, dz1 GEMM, colsum(db2) = 4 launches.
 // ------------------------------------------------------------------------------------------------------
-constexpr int TAIL_MAX_Q = 16;        // hidden units per lane: hid <= 1024
 constexpr int TAIL_LDS_FLOATS = 16384;
 
-template <int KIND>
+// NQ4 = float4 groups per lane: lane l owns hidden units j = 256 q + 4 l + e (q < NQ4, e < 4), so a1 / dz1 rows move as
+// 16-byte accesses and every W2 row (LDS stride hid4 = round4(hid)) is read with one ds_read_b128 per 4 FMAs.
+template <int KIND, int NQ4>
 __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ A1, int64_t lda1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
                                                         int hid, int K, const int32_t* __restrict__ rows,
@@ -600,48 +601,87 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
                                                         float grad_scale, float* __restrict__ lp_out,
                                                         float* __restrict__ DY, int64_t lddy,
                                                         float* __restrict__ dZ1, int64_t lddz,
-                                                        float* __restrict__ db1, float* __restrict__ db2,
-                                                        float* __restrict__ loss_acc, int32_t* __restrict__ nonfinite) {
-    __shared__ float w2s[TAIL_LDS_FLOATS];
-    __shared__ float ys[4][64];
+                                                        float* __restrict__ loss_acc, int32_t* __restrict__ nonfinite,
+                                                        long long* __restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) float w2s[TAIL_LDS_FLOATS];
+#define PP_STAMP(k) do { if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) dbg[(blockIdx.x ? 8 : 0) + (k)] = clock64(); } while (0)
+    PP_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_out = 3 * K;
-    stage_to_lds(w2s, W2, n_out * hid, tid);
-    __syncthreads();
-    const int nq = (hid + 63) / 64;
-    const bool bwd = DY != nullptr;
-    float gb1[TAIL_MAX_Q];
+    const int hid4 = (hid + 3) & ~3;
+    // stage W2 [n_out, hid] into LDS rows of stride hid4, zero padded: wave w takes rows w, w+4, ...; the (at most
+    // 16) loads of a row are all issued before the first store
+    for (int o = wave; o < n_out; o += 4) {
+        float v[16];
 #pragma unroll
-    for (int q = 0; q < TAIL_MAX_Q; ++q) gb1[q] = 0.0f;
-    float gb2a = 0.f, gb2b = 0.f, gb2c = 0.f, loss_local = 0.f;
+        for (int u = 0; u < 16; ++u) {
+            const int j = lane + 64 * u;
+            v[u] = (j < hid) ? W2[o * hid + j] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = lane + 64 * u;
+            if (j < hid4) w2s[o * hid4 + j] = v[u];
+        }
+    }
+    // bias of the three outputs this lane owns as mixture component `lane`
+    const bool comp0 = lane < K;
+    const float b2mu = comp0 ? b2[lane] : 0.0f, b2sd = comp0 ? b2[K + lane] : 0.0f, b2z = comp0 ? b2[2 * K + lane] : 0.0f;
+    __syncthreads();
+    PP_STAMP(1);
+    const bool bwd = DY != nullptr;
+    float loss_local = 0.f;
     bool bad_any = false;
     const bool comp = lane < K;
+    bool qok[NQ4];
+#pragma unroll
+    for (int q = 0; q < NQ4; ++q) qok[q] = 256 * q + 4 * lane < hid4;
     const int i0 = (blockIdx.x * 4 + wave) * rows_per_wave;
     for (int t = 0; t < rows_per_wave; ++t) {
         const int i = i0 + t;
         if (i >= n) break;   // wave-uniform
         const int r = rows ? rows[i] : i;
-        float a1[TAIL_MAX_Q];
+        f32x4 a1[NQ4];
 #pragma unroll
-        for (int q = 0; q < TAIL_MAX_Q; ++q) {
-            const int j = lane + 64 * q;
-            a1[q] = (q < nq && j < hid) ? A1[(int64_t)i * lda1 + j] : 0.0f;
+        for (int q = 0; q < NQ4; ++q) {
+            const int j = 256 * q + 4 * lane;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (qok[q]) v = *reinterpret_cast<const f32x4*>(A1 + (int64_t)i * lda1 + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e >= hid) v[e] = 0.0f;   // the pad columns of the workspace row are not initialised
+            a1[q] = v;
         }
-        // second layer: y_o = b2[o] + sum_j a1_j W2[o][j]
-        for (int o = 0; o < n_out; ++o) {
-            float part = 0.0f;
+        PP_STAMP(2);
+        // second layer, one mixture component per iteration: y_k, y_{K+k}, y_{2K+k} = three independent dot products
+        // (ILP), reduced on the VALU; lane k keeps its component's three values
+        float ymu = 0.0f, ysd = 0.0f, yz = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
 #pragma unroll
-            for (int q = 0; q < TAIL_MAX_Q; ++q) {
-                const int j = lane + 64 * q;
-                if (q < nq && j < hid) part += a1[q] * w2s[o * hid + j];
+            for (int q = 0; q < NQ4; ++q) {
+                if (qok[q]) {
+                    const int off = 256 * q + 4 * lane;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w2s + k * hid4 + off);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(w2s + (K + k) * hid4 + off);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2s + (2 * K + k) * hid4 + off);
+                    p0 += a1[q][0] * w0[0] + a1[q][1] * w0[1] + a1[q][2] * w0[2] + a1[q][3] * w0[3];
+                    p1 += a1[q][0] * w1[0] + a1[q][1] * w1[1] + a1[q][2] * w1[2] + a1[q][3] * w1[3];
+                    p2 += a1[q][0] * w2[0] + a1[q][1] * w2[1] + a1[q][2] * w2[2] + a1[q][3] * w2[3];
+                }
             }
-            part = wave_sum(part);
-            if (lane == 0) ys[wave][o] = part + b2[o];
+            p0 = wave_sum(p0);
+            p1 = wave_sum(p1);
+            p2 = wave_sum(p2);
+            if (lane == k) {
+                ymu = p0 + b2mu;
+                ysd = p1 + b2sd;
+                yz = p2 + b2z;
+            }
         }
+        PP_STAMP(3);
         // one mixture component per lane
         const float v = value[r], pa = prior[2 * r], pb = prior[2 * r + 1];
-        const float ymu = comp ? ys[wave][lane] : 0.0f, ysd = comp ? ys[wave][K + lane] : 0.0f;
-        const float yz = comp ? ys[wave][2 * K + lane] : -INFINITY;
         const float zmax = wave_max(yz);
         const float e = comp ? expf(yz - zmax) : 0.0f;
         const float pi = e / wave_sum(e);
@@ -672,10 +712,9 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
         const float amax = wave_max(a);
         float lp = amax;
         if (amax > -INFINITY) lp = amax + logf(wave_sum(comp ? expf(a - amax) : 0.0f));
-        else if (amax != amax) lp = amax;
-        // NaN in any component poisons the max/sum like the reference's logsumexp would
-        const float anan = wave_sum((comp && a != a) ? 1.0f : 0.0f);
-        if (anan > 0.0f) lp = NAN;
+        // NaN in any component poisons the result like the reference's logsumexp would
+        if (wave_sum((comp && a != a) ? 1.0f : 0.0f) > 0.0f) lp = NAN;
+        PP_STAMP(4);
         if (lp_out && lane == 0) lp_out[r] = lp;
         const bool rescued = (lp == -INFINITY);
         const bool bad = !rescued && !isfinite(lp);
@@ -708,38 +747,42 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
         if (comp) {
             float* dy = DY + (int64_t)i * lddy;
             dy[lane] = d0; dy[K + lane] = d1; dy[2 * K + lane] = d2;
-            ys[wave][lane] = d0; ys[wave][K + lane] = d1; ys[wave][2 * K + lane] = d2;
-            gb2a += d0; gb2b += d1; gb2c += d2;
         }
-        // dz1_j = [a1_j > 0] * sum_o dy_o W2[o][j]     (ys[wave][*] written and read by the same wave: in order)
-        float dz[TAIL_MAX_Q];
+        PP_STAMP(5);
+        // dz1_j = [a1_j > 0] * sum_o dy_o W2[o][j]: dy of component k is broadcast from lane k (v_readlane)
+        f32x4 dz[NQ4];
 #pragma unroll
-        for (int q = 0; q < TAIL_MAX_Q; ++q) dz[q] = 0.0f;
-        for (int o = 0; o < n_out; ++o) {
-            const float dyo = ys[wave][o];
+        for (int q = 0; q < NQ4; ++q) dz[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; ++k) {
+            const float e0 = lane_bcast(d0, k), e1 = lane_bcast(d1, k), e2 = lane_bcast(d2, k);
 #pragma unroll
-            for (int q = 0; q < TAIL_MAX_Q; ++q) {
-                const int j = lane + 64 * q;
-                if (q < nq && j < hid) dz[q] += dyo * w2s[o * hid + j];
+            for (int q = 0; q < NQ4; ++q) {
+                if (qok[q]) {
+                    const int off = 256 * q + 4 * lane;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w2s + k * hid4 + off);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(w2s + (K + k) * hid4 + off);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2s + (2 * K + k) * hid4 + off);
+                    dz[q] += e0 * w0 + e1 * w1 + e2 * w2;
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < TAIL_MAX_Q; ++q) {
-            const int j = lane + 64 * q;
-            if (q < nq && j < hid) {
-                const float d = a1[q] > 0.0f ? dz[q] : 0.0f;
-                dZ1[(int64_t)i * lddz + j] = d;
-                gb1[q] += d;
+        for (int q = 0; q < NQ4; ++q) {
+            if (qok[q]) {
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = a1[q][e] > 0.0f ? dz[q][e] : 0.0f;
+                *reinterpret_cast<f32x4*>(dZ1 + (int64_t)i * lddz + 256 * q + 4 * lane) = d;
             }
         }
     }
+    PP_STAMP(6);
     // loss: one atomic per wave, spread over 64 accumulator slots (same-address float atomics serialise at ~40 ns
     // each in L2; a thousand waves on one word cost ~40 us). loss_finalize sums the slots.
     if (lane == 0 && loss_acc && loss_local != 0.0f) atomicAdd(loss_acc + ((blockIdx.x * 4 + wave) & 63), loss_local);
     if (bad_any && nonfinite && lane == 0) atomicOr(nonfinite, 1);
     // The bias gradients db1 = colsum(dz1), db2 = colsum(dy) are NOT accumulated here: ~1000 waves adding to the
     // same few hundred addresses serialise in L2 (measured: +40 us); the caller runs the 16-way colsum kernel instead.
-    (void)gb1; (void)gb2a; (void)gb2b; (void)gb2c; (void)db1; (void)db2;
 }
 
 bool head_tail_supported(int kind, int hid, int n_out) {
@@ -747,25 +790,47 @@ bool head_tail_supported(int kind, int hid, int n_out) {
     if (disabled) return false;
     if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE) return false;
     if (n_out % 3 != 0 || n_out / 3 > MAXK || n_out / 3 < 1) return false;
-    return hid <= 64 * TAIL_MAX_Q && (int64_t)hid * n_out <= TAIL_LDS_FLOATS;
+    const int hid4 = (hid + 3) & ~3;
+    return hid4 <= 1024 && (int64_t)hid4 * n_out <= TAIL_LDS_FLOATS;
+}
+
+long long* g_timeline = nullptr;   // debug: per-phase clock64() stamps of workgroups 0 and 100 (pp_debug_timeline)
+
+template <int KIND>
+static void head_tail_launch(int nq4, dim3 grid, hipStream_t st, const float* A1, int64_t lda1, const float* W2,
+                             const float* b2, int hid, int K, const int32_t* rows, const float* value, const float* prior,
+                             int n, int rpw, float gs, float* lp_out, float* DY, int64_t lddy, float* dZ1, int64_t lddz,
+                             float* loss_acc, int32_t* nonfinite) {
+#define PP_TAIL(NQ) hipLaunchKernelGGL((head_tail_kernel<KIND, NQ>), grid, dim3(256), 0, st, A1, lda1, W2, b2, hid, K, rows, \
+                                       value, prior, n, rpw, gs, lp_out, DY, lddy, dZ1, lddz, loss_acc, nonfinite, g_timeline)
+    switch (nq4) {
+        case 1: PP_TAIL(1); break;
+        case 2: PP_TAIL(2); break;
+        case 3: PP_TAIL(3); break;
+        default: PP_TAIL(4); break;
+    }
+#undef PP_TAIL
 }
 
 int head_tail(int kind, const float* A1, int64_t lda1, const float* W2, const float* b2, int hid, int n_out,
               const int32_t* rows, const float* value, const float* prior, int n, float grad_scale, float* lp_out,
               float* DY, int64_t lddy, float* dZ1, int64_t lddz, float* db1, float* db2, float* loss_acc,
               int32_t* nonfinite, hipStream_t st) {
+    (void)db1; (void)db2;
     PP_CHECK_ARG(head_tail_supported(kind, hid, n_out), "head_tail: unsupported head shape");
     PP_CHECK_ARG(!DY || dZ1, "head_tail: backward needs dZ1");
+    PP_CHECK_ARG(lda1 % 4 == 0 && (!dZ1 || lddz % 4 == 0), "head_tail: leading dimensions must be multiples of 4");
     if (n <= 0) return 0;
     // ~256 workgroups: W2 staging (n_out*hid floats) is amortised over rows_per_wave rows per wave
     const int rpw = std::max((n + 4 * 256 - 1) / (4 * 256), 1);
-    dim3 grid(cdiv(n, 4 * rpw)), block(256);
+    dim3 grid(cdiv(n, 4 * rpw));
+    const int nq4 = (((hid + 3) & ~3) + 255) / 256;
     if (kind == PP_HEAD_NORMAL_MIXTURE)
-        hipLaunchKernelGGL(head_tail_kernel<0>, grid, block, 0, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n,
-                           rpw, grad_scale, lp_out, DY, lddy, dZ1, lddz, db1, db2, loss_acc, nonfinite);
+        head_tail_launch<0>(nq4, grid, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n, rpw, grad_scale, lp_out, DY,
+                            lddy, dZ1, lddz, loss_acc, nonfinite);
     else
-        hipLaunchKernelGGL(head_tail_kernel<1>, grid, block, 0, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n,
-                           rpw, grad_scale, lp_out, DY, lddy, dZ1, lddz, db1, db2, loss_acc, nonfinite);
+        head_tail_launch<1>(nq4, grid, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n, rpw, grad_scale, lp_out, DY,
+                            lddy, dZ1, lddz, loss_acc, nonfinite);
     PP_LAUNCH_CHECK("head_tail");
     return 0;
 }
@@ -809,7 +874,6 @@ __global__ void adam_prepare_kernel(const float* __restrict__ active, int32_t* _
     }
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, const float* __restrict__ Gr,
                                                    float* __restrict__ M, float* __restrict__ V,

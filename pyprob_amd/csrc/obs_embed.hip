@@ -14,6 +14,9 @@
 
 namespace pp {
 
+extern long long* g_timeline;   // kernels.hip (debug phase stamps)
+#define OBS_STAMP(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[(k)] = clock64(); } while (0)
+
 constexpr int OBS_EMAX = 64;    // lanes
 constexpr int OBS_HIDMAX = 32;  // per-observable hidden width kept in registers
 constexpr int OBS_INMAX = 8;
@@ -40,35 +43,65 @@ __device__ __forceinline__ float bcast(float x, int idx) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), idx));
 }
 
-__device__ __forceinline__ void obs_stage_layer(const ObsLayer& L, const float* __restrict__ P, float* lds, int tid) {
-    const int n = L.rows * L.cols;
-    const float* g = P + L.w_off;
-    for (int base = tid; base < n; base += 256 * 8) {   // 8 loads in flight per thread, then the padded-row stores
-        float v[8];
+// ---- weights -> LDS (rows of stride cols+1) ---------------------------------------------------------------
+// The parameters were just rewritten by Adam on other XCDs, so every load is a long trip (~1-2 us). ALL loads of ALL
+// layers are therefore issued first (one round trip), and only then the LDS stores.
+template <int U>
+struct ObsStage {
+    float v[U];
+    __device__ __forceinline__ void load(const float* __restrict__ g, int n, int tid) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + 256 * u;
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + 256 * u;
             v[u] = i < n ? g[i] : 0.0f;
         }
+    }
+    __device__ __forceinline__ void store(float* lds, int lds_w, int rows, int cols, int tid) const {
+        const int n = rows * cols;
+        const bool pow2 = (cols & (cols - 1)) == 0;
+        const int sh = 31 - __clz(cols);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + 256 * u;
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + 256 * u;
             if (i < n) {
-                const int r = i / L.cols, c = i - r * L.cols;
-                lds[L.lds_w + r * (L.cols + 1) + c] = v[u];
+                const int r = pow2 ? (i >> sh) : (i / cols);
+                lds[lds_w + r * (cols + 1) + (i - r * cols)] = v[u];
             }
         }
     }
-    for (int i = tid; i < L.rows; i += 256) lds[L.lds_b + i] = P[L.b_off + i];
-}
+};
 
 __device__ __forceinline__ void obs_stage_all(const ObsFusedArgs& a, const float* __restrict__ P, float* lds, int tid) {
-    for (int o = 0; o < a.n_obs; ++o) {
-        obs_stage_layer(a.l0[o], P, lds, tid);
-        obs_stage_layer(a.l1[o], P, lds, tid);
+    ObsStage<16> sf0, sf1;                 // 64 x 64
+    ObsStage<8> s1[PP_MAX_OBS];            // out x hid <= 64 x 32
+    ObsStage<1> s0[PP_MAX_OBS];            // hid x in  <= 32 x 8
+    float bf0, bf1, b1[PP_MAX_OBS], b0[PP_MAX_OBS];
+    sf0.load(P + a.f0.w_off, a.f0.rows * a.f0.cols, tid);
+    sf1.load(P + a.f1.w_off, a.f1.rows * a.f1.cols, tid);
+    bf0 = tid < a.f0.rows ? P[a.f0.b_off + tid] : 0.0f;
+    bf1 = tid < a.f1.rows ? P[a.f1.b_off + tid] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < PP_MAX_OBS; ++o) {
+        if (o < a.n_obs) {
+            s1[o].load(P + a.l1[o].w_off, a.l1[o].rows * a.l1[o].cols, tid);
+            s0[o].load(P + a.l0[o].w_off, a.l0[o].rows * a.l0[o].cols, tid);
+            b1[o] = tid < a.l1[o].rows ? P[a.l1[o].b_off + tid] : 0.0f;
+            b0[o] = tid < a.l0[o].rows ? P[a.l0[o].b_off + tid] : 0.0f;
+        }
     }
-    obs_stage_layer(a.f0, P, lds, tid);
-    obs_stage_layer(a.f1, P, lds, tid);
+    sf0.store(lds, a.f0.lds_w, a.f0.rows, a.f0.cols, tid);
+    sf1.store(lds, a.f1.lds_w, a.f1.rows, a.f1.cols, tid);
+    if (tid < a.f0.rows) lds[a.f0.lds_b + tid] = bf0;
+    if (tid < a.f1.rows) lds[a.f1.lds_b + tid] = bf1;
+#pragma unroll
+    for (int o = 0; o < PP_MAX_OBS; ++o) {
+        if (o < a.n_obs) {
+            s1[o].store(lds, a.l1[o].lds_w, a.l1[o].rows, a.l1[o].cols, tid);
+            s0[o].store(lds, a.l0[o].lds_w, a.l0[o].rows, a.l0[o].cols, tid);
+            if (tid < a.l1[o].rows) lds[a.l1[o].lds_b + tid] = b1[o];
+            if (tid < a.l0[o].rows) lds[a.l0[o].lds_b + tid] = b0[o];
+        }
+    }
 }
 
 // y_lane = relu(b[lane] + sum_k W[lane][k] * x_k), x_k held by lane k (+ x_lane0) of the wave
@@ -160,31 +193,33 @@ constexpr int G_TOTAL = G_B + 4 * 64;   // 11264 floats
 __device__ __forceinline__ void obs_flush_weight(const ObsLayer& L, const float* g, int g_ld, int g_row0,
                                                  float* __restrict__ grads, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    for (int r = wave; r < L.rows; r += 4)
-        for (int c = lane; c < L.cols; c += 64) atomicAdd(grads + L.w_off + (int64_t)r * L.cols + c, g[(g_row0 + r) * g_ld + c]);
+    for (int c = lane; c < L.cols; c += 64) {
+        for (int r0 = wave; r0 < L.rows; r0 += 32) {   // 8 rows per pass: LDS reads batched ahead of the atomics
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 4 * u;
+                v[u] = r < L.rows ? g[(g_row0 + r) * g_ld + c] + g[G_TOTAL + (g_row0 + r) * g_ld + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 4 * u;
+                if (r < L.rows) atomicAdd(grads + L.w_off + (int64_t)r * L.cols + c, v[u]);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void obs_embed_bwd_kernel(const ObsFusedArgs a, const float* __restrict__ P,
                                                             float* __restrict__ grads, const float* __restrict__ obs,
                                                             int n_traces, int traces_per_wave,
                                                             const float* __restrict__ cat, const float* __restrict__ f1,
-                                                            const float* __restrict__ dE) {
-    __shared__ float lds[10240 + G_TOTAL];
+                                                            const float* __restrict__ dE, long long* __restrict__ dbg) {
+    __shared__ float lds[10240 + 2 * G_TOTAL];   // weights | gradient image A | gradient image B  (130 KB)
+    OBS_STAMP(0);
     float* ldsw = lds;
     float* ldsg = lds + 10240;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    obs_stage_all(a, P, ldsw, tid);
-    for (int i = tid; i < G_TOTAL; i += 256) ldsg[i] = 0.0f;
-    __syncthreads();
-    // per-lane gradient rows kept in registers across this wave's traces
-    float gF1[OBS_EMAX], gF0[OBS_EMAX], gW1[OBS_HIDMAX], gW0[OBS_INMAX];
-    float gbF1 = 0.f, gbF0 = 0.f, gb1 = 0.f, gb0 = 0.f;
-#pragma unroll
-    for (int k = 0; k < OBS_EMAX; ++k) gF1[k] = gF0[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < OBS_HIDMAX; ++k) gW1[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < OBS_INMAX; ++k) gW0[k] = 0.0f;
     // which observable this lane belongs to, as a concat unit and as a hidden unit
     int oc = -1, jc = 0, oh = -1, jh = 0, cin = 0;
     {
@@ -198,29 +233,67 @@ __global__ __launch_bounds__(256) void obs_embed_bwd_kernel(const ObsFusedArgs a
     }
     const bool acte = lane < a.e_obs;
     const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
+    // first trace's inputs: issued BEFORE the weight staging so both memory round trips overlap
+    float nx_dz2 = 0.f, nx_f1 = 0.f, nx_cat = 0.f, nx_h = 0.f, nx_obs[OBS_INMAX];
+#pragma unroll
+    for (int i = 0; i < OBS_INMAX; ++i) nx_obs[i] = 0.0f;
+    if (b0 < n_traces) {   // dE is already masked by E > 0 (obs_grad_kernel)
+        nx_dz2 = acte ? dE[(int64_t)b0 * a.e_ld + lane] : 0.0f;
+        nx_f1 = acte ? f1[(int64_t)b0 * a.e_ld + lane] : 0.0f;
+        nx_cat = acte ? cat[(int64_t)b0 * a.e_ld + lane] : 0.0f;
+        nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)b0 * a.ohid_ld[oh] + jh] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < OBS_INMAX; ++i)
+            nx_obs[i] = (oh >= 0 && i < a.in[oh]) ? obs[(int64_t)b0 * a.width + cin + i] : 0.0f;
+    }
+    obs_stage_all(a, P, ldsw, tid);
+    __syncthreads();
+    OBS_STAMP(1);
+    // per-lane gradient rows kept in registers across this wave's traces
+    float gF1[OBS_EMAX], gF0[OBS_EMAX], gW1[OBS_HIDMAX], gW0[OBS_INMAX];
+    float gbF1 = 0.f, gbF0 = 0.f, gb1 = 0.f, gb0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < OBS_EMAX; ++k) gF1[k] = gF0[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < OBS_HIDMAX; ++k) gW1[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < OBS_INMAX; ++k) gW0[k] = 0.0f;
     for (int t = 0; t < traces_per_wave; ++t) {
         const int b = b0 + t;
         if (b >= n_traces) break;   // wave-uniform
-        const float dz2 = acte ? dE[(int64_t)b * a.e_ld + lane] : 0.0f;   // already masked by E > 0
-        const float f1v = acte ? f1[(int64_t)b * a.e_ld + lane] : 0.0f;
-        const float catv = acte ? cat[(int64_t)b * a.e_ld + lane] : 0.0f;
-        // final layer 1: dW[j][k] += dz2_j * f1_k
+        // this trace's inputs were prefetched one iteration ahead (nx_*); issue the loads of the next trace now
+        const float dz2 = nx_dz2, f1v = nx_f1, catv = nx_cat, hv = nx_h;
+        float obsv[OBS_INMAX];
 #pragma unroll
-        for (int k = 0; k < OBS_EMAX; ++k)
-            if (k < a.e_obs) gF1[k] += dz2 * bcast(f1v, k);
+        for (int i = 0; i < OBS_INMAX; ++i) obsv[i] = nx_obs[i];
+        if (t + 1 < traces_per_wave && b + 1 < n_traces) {
+            const int bn = b + 1;
+            nx_dz2 = acte ? dE[(int64_t)bn * a.e_ld + lane] : 0.0f;
+            nx_f1 = acte ? f1[(int64_t)bn * a.e_ld + lane] : 0.0f;
+            nx_cat = acte ? cat[(int64_t)bn * a.e_ld + lane] : 0.0f;
+            nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)bn * a.ohid_ld[oh] + jh] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < OBS_INMAX; ++i)
+                nx_obs[i] = (oh >= 0 && i < a.in[oh]) ? obs[(int64_t)bn * a.width + cin + i] : 0.0f;
+        }
+        if (t == 0) OBS_STAMP(2);
+        // final layer 1: dW[j][k] += dz2_j * f1_k
+        // (lanes >= e_obs hold zeros, so no guard: 64 straight v_readlane + v_fmac pairs)
+#pragma unroll
+        for (int k = 0; k < OBS_EMAX; ++k) gF1[k] += dz2 * bcast(f1v, k);
         gbF1 += dz2;
+        if (t == 0) OBS_STAMP(3);
         float dz1 = obs_dense_t(ldsw, a.f1, lane, acte, dz2, 0);
         dz1 = f1v > 0.0f ? dz1 : 0.0f;
+        if (t == 0) OBS_STAMP(4);
         // final layer 0
 #pragma unroll
-        for (int k = 0; k < OBS_EMAX; ++k)
-            if (k < a.e_obs) gF0[k] += dz1 * bcast(catv, k);
+        for (int k = 0; k < OBS_EMAX; ++k) gF0[k] += dz1 * bcast(catv, k);
         gbF0 += dz1;
         float dzc = obs_dense_t(ldsw, a.f0, lane, acte, dz1, 0);
         dzc = catv > 0.0f ? dzc : 0.0f;
+        if (t == 0) OBS_STAMP(5);
         // per-observable layer 1 (lane = concat unit) and layer 0 (lane = hidden unit)
-        float hv = 0.0f;
-        if (oh >= 0) hv = a.obs_h[oh][(int64_t)b * a.ohid_ld[oh] + jh];
         float dh = 0.0f;
         int co = 0;
         for (int o = 0; o < a.n_obs; ++o) {
@@ -243,43 +316,68 @@ __global__ __launch_bounds__(256) void obs_embed_bwd_kernel(const ObsFusedArgs a
             gb0 += dh;
 #pragma unroll
             for (int i = 0; i < OBS_INMAX; ++i)
-                if (i < a.in[oh]) gW0[i] += dh * obs[(int64_t)b * a.width + cin + i];
+                gW0[i] += dh * obsv[i];
         }
+        if (t == 0) OBS_STAMP(6);
     }
-    // combine the four waves in LDS (one wave at a time: plain read-modify-write, static register indices), then one
-    // global atomic per parameter per workgroup
-    for (int turn = 0; turn < 4; ++turn) {
-        if (wave == turn) {
+    OBS_STAMP(7);
+    // combine the four waves in LDS with static register indices: waves 0/1 STORE their rows into images A/B, then
+    // waves 2/3 add theirs (all reads of a row issued before the adds and the writes); the flush sums A + B.
+    float* img = ldsg + (wave & 1) * G_TOTAL;
+    if (wave < 2) {
 #pragma unroll
-            for (int k = 0; k < OBS_EMAX; ++k) {
-                ldsg[G_F1 + lane * 65 + k] += gF1[k];
-                ldsg[G_F0 + lane * 65 + k] += gF0[k];
-            }
-#pragma unroll
-            for (int k = 0; k < OBS_HIDMAX; ++k) ldsg[G_W1 + lane * 33 + k] += gW1[k];
-#pragma unroll
-            for (int i = 0; i < OBS_INMAX; ++i) ldsg[G_W0 + lane * 9 + i] += gW0[i];
-            ldsg[G_B + lane] += gbF1;
-            ldsg[G_B + 64 + lane] += gbF0;
-            ldsg[G_B + 128 + lane] += gb1;
-            ldsg[G_B + 192 + lane] += gb0;
+        for (int k = 0; k < OBS_EMAX; ++k) {
+            img[G_F1 + lane * 65 + k] = gF1[k];
+            img[G_F0 + lane * 65 + k] = gF0[k];
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < OBS_HIDMAX; ++k) img[G_W1 + lane * 33 + k] = gW1[k];
+#pragma unroll
+        for (int i = 0; i < OBS_INMAX; ++i) img[G_W0 + lane * 9 + i] = gW0[i];
+        img[G_B + lane] = gbF1;
+        img[G_B + 64 + lane] = gbF0;
+        img[G_B + 128 + lane] = gb1;
+        img[G_B + 192 + lane] = gb0;
     }
+    __syncthreads();
+    if (wave >= 2) {
+        float t1[OBS_EMAX], t0[OBS_EMAX];
+#pragma unroll
+        for (int k = 0; k < OBS_EMAX; ++k) {
+            t1[k] = img[G_F1 + lane * 65 + k];
+            t0[k] = img[G_F0 + lane * 65 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < OBS_EMAX; ++k) {
+            img[G_F1 + lane * 65 + k] = t1[k] + gF1[k];
+            img[G_F0 + lane * 65 + k] = t0[k] + gF0[k];
+        }
+#pragma unroll
+        for (int k = 0; k < OBS_HIDMAX; ++k) img[G_W1 + lane * 33 + k] += gW1[k];
+#pragma unroll
+        for (int i = 0; i < OBS_INMAX; ++i) img[G_W0 + lane * 9 + i] += gW0[i];
+        img[G_B + lane] += gbF1;
+        img[G_B + 64 + lane] += gbF0;
+        img[G_B + 128 + lane] += gb1;
+        img[G_B + 192 + lane] += gb0;
+    }
+    __syncthreads();
+    OBS_STAMP(8);
     obs_flush_weight(a.f1, ldsg + G_F1, 65, 0, grads, tid);
     obs_flush_weight(a.f0, ldsg + G_F0, 65, 0, grads, tid);
     for (int i = tid; i < a.e_obs; i += 256) {
-        atomicAdd(grads + a.f1.b_off + i, ldsg[G_B + i]);
-        atomicAdd(grads + a.f0.b_off + i, ldsg[G_B + 64 + i]);
+        atomicAdd(grads + a.f1.b_off + i, ldsg[G_B + i] + ldsg[G_TOTAL + G_B + i]);
+        atomicAdd(grads + a.f0.b_off + i, ldsg[G_B + 64 + i] + ldsg[G_TOTAL + G_B + 64 + i]);
     }
     int co = 0;
     for (int o = 0; o < a.n_obs; ++o) {
         obs_flush_weight(a.l1[o], ldsg + G_W1, 33, co, grads, tid);            // rows = concat lanes of observable o
         obs_flush_weight(a.l0[o], ldsg + G_W0, 9, a.hoff[o], grads, tid);      // rows = hidden lanes of observable o
-        for (int i = tid; i < a.out[o]; i += 256) atomicAdd(grads + a.l1[o].b_off + i, ldsg[G_B + 128 + co + i]);
-        for (int i = tid; i < a.hid[o]; i += 256) atomicAdd(grads + a.l0[o].b_off + i, ldsg[G_B + 192 + a.hoff[o] + i]);
+        for (int i = tid; i < a.out[o]; i += 256) atomicAdd(grads + a.l1[o].b_off + i, ldsg[G_B + 128 + co + i] + ldsg[G_TOTAL + G_B + 128 + co + i]);
+        for (int i = tid; i < a.hid[o]; i += 256) atomicAdd(grads + a.l0[o].b_off + i, ldsg[G_B + 192 + a.hoff[o] + i] + ldsg[G_TOTAL + G_B + 192 + a.hoff[o] + i]);
         co += a.out[o];
     }
+    OBS_STAMP(9);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -345,7 +443,7 @@ int obs_embed_bwd_fused(const pp_net* net, const float* P, float* grads, const f
     // backward: every workgroup ends with ~10k global float atomics (measured ~16 ps each): fewer, longer workgroups
     const int tpw = pick_traces_per_wave(n_traces, 128);   // A/B on MI355X: 128 workgroups best (0.338 vs 0.348/0.355 ms/step)
     hipLaunchKernelGGL(obs_embed_bwd_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, grads, obs, n_traces, tpw,
-                       cat, f1, dE);
+                       cat, f1, dE, g_timeline);
     PP_LAUNCH_CHECK("obs_embed_bwd_fused");
     return 0;
 }
