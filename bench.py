@@ -200,8 +200,16 @@ def main():
         if cnt.value > 0:
             avg_ms = float(ms[:cnt.value].mean())
             ach = float(fl[0]) / (avg_ms * 1e-3) / 1e12
+            traffic = None      # HBM bytes per launch from the committed PMC passes (rocprof cannot run inside bench.py)
+            try:
+                with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as f:
+                    pmc = json.load(f)
+                if B == 1024 and args.lstm_dim == 512:
+                    traffic = pmc['traffic_bytes_per_launch']
+            except (OSError, KeyError, ValueError):
+                pass
             out['roofline'] = dict(bound='mfma', achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
-                                   frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
+                                   frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic,
                                    kernel='gemm_f32_kernel<64,64,32,32,NT,vec4> (forward X*W_ih^T, %dx%dx%d)'
                                           % (B, 4 * args.lstm_dim, eng.spec.lstm_in),
                                    avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=int(cnt.value),

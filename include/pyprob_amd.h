@@ -234,6 +234,9 @@ typedef struct pp_gemm_args {
  * gradients: embedding_feedforward.py:40, inference_network_lstm.py:188). *_idx are optional dev row-index
  * (gather/scatter) arrays: the "address-dispatch gather" of the proposal heads. */
 int pp_gemm_f32(const pp_gemm_args* args, void* stream);
+/* `count` independent products with identical operand layouts (a_kmajor/b_kmajor) in as few launches as possible
+ * (up to 8 problems per launch): the weight-gradient leaves of a backward pass, the per-address head products. */
+int pp_gemm_f32_grouped(const pp_gemm_args* args, int32_t count, void* stream);
 
 /* out[c] += sum_i X[ix(i)*ldx + c] for c < n_cols (bias and embedding-table gradients). out2 optional. */
 int pp_colsum_f32(const float* X, int64_t ldx, const int32_t* row_idx, int32_t n_rows, int32_t n_cols,

@@ -13,6 +13,11 @@ namespace pp {
 // kernels.hip / gemm_f32.hip
 const char* last_error();
 int gemm_f32(const pp_gemm_args* a, hipStream_t st);
+int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st);
+struct ColsumJob {
+    const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
+};
+int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st);
 int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
                hipStream_t st);
 int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
@@ -69,41 +74,6 @@ static void prof_end(int which, double flops, hipStream_t st) {
         g_prof.flops[g_prof.used] = flops;
         g_prof.used++;
     }
-}
-
-// ---- auxiliary stream: the weight-gradient products run beside the data-gradient chain -------------------------
-// Every kernel of a 1024-trace step is far too small to fill 256 CUs, and the weight-gradient GEMMs (dW = dz^T x) are
-// leaves of the dependency graph, so they are forked onto a second HIP stream with event dependencies (captured as
-// graph edges under HIP-graph capture). Opt-in with PP_TWO_STREAMS=1.
-struct Aux {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork[3] = {nullptr, nullptr, nullptr}, join = nullptr;
-    bool ok = false, tried = false;
-};
-static Aux g_aux;
-
-static bool aux_ready() {
-    if (g_aux.tried) return g_aux.ok;
-    g_aux.tried = true;
-    // measured on MI355X (round 1): no gain over one stream for the 1024-trace step (330 vs 332 us), so opt-in only
-    const char* e = getenv("PP_TWO_STREAMS");
-    if (!e || atoi(e) == 0) return false;
-    if (hipStreamCreateWithFlags(&g_aux.stream, hipStreamNonBlocking) != hipSuccess) return false;
-    for (auto& ev : g_aux.fork)
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&g_aux.join, hipEventDisableTiming) != hipSuccess) return false;
-    g_aux.ok = true;
-    return true;
-}
-
-// aux stream waits for everything issued so far on `st`
-static void aux_fork(int i, hipStream_t st) {
-    (void)hipEventRecord(g_aux.fork[i], st);
-    (void)hipStreamWaitEvent(g_aux.stream, g_aux.fork[i], 0);
-}
-static void aux_join(hipStream_t st) {
-    (void)hipEventRecord(g_aux.join, g_aux.stream);
-    (void)hipStreamWaitEvent(st, g_aux.join, 0);
 }
 
 // ---- workspace carving ------------------------------------------------------------------------------
@@ -211,9 +181,10 @@ static int linear_fwd(const float* x, int64_t ldx, const int32_t* x_idx, const f
     return gemm_f32(&g, st);
 }
 
-// dW[out, in] += dz^T x ; db[out] += colsum(dz); dz [n, out] (lddz), x [n, in] (ldx, optional k-gather x_idx)
-static int linear_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, const int32_t* x_idx, float* dW,
-                        float* db, float* db2, int n, int in, int out, hipStream_t st) {
+// dW[out, in] += dz^T x  (dz [n, out] (lddz), x [n, in] (ldx, optional k-gather x_idx)): queued; all weight-gradient
+// products of a backward pass are leaves of the dependency graph and run as one grouped launch (gemm_f32_grouped)
+static void queue_wgrad(std::vector<pp_gemm_args>& q, const float* dz, int64_t lddz, const float* x, int64_t ldx,
+                        const int32_t* x_idx, float* dW, int n, int in, int out) {
     pp_gemm_args g{};
     g.A = dz; g.lda = lddz; g.a_kmajor = 1;
     g.B = x; g.ldb = ldx; g.b_kmajor = 1; g.b_idx = x_idx;
@@ -221,7 +192,14 @@ static int linear_wgrad(const float* dz, int64_t lddz, const float* x, int64_t l
     g.M = out; g.N = in; g.K = n;
     g.accumulate = 1;
     g.split_k = 1;
-    PP_TRY(gemm_f32(&g, st));
+    q.push_back(g);
+}
+
+static int linear_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, const int32_t* x_idx, float* dW,
+                        float* db, float* db2, int n, int in, int out, hipStream_t st) {
+    std::vector<pp_gemm_args> q;
+    queue_wgrad(q, dz, lddz, x, ldx, x_idx, dW, n, in, out);
+    PP_TRY(gemm_f32(&q[0], st));
     if (db) PP_TRY(colsum_f32(dz, lddz, nullptr, n, out, db, db2, st));
     return 0;
 }
@@ -306,6 +284,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(lstm_cell_fwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.Hs + (int64_t)r0 * H, n, H, st));
     }
     const float gscale = -1.0f / (float)B;
+    std::vector<ColsumJob> cs;
     for (int a = 0; a < net->n_addr; ++a) {
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
         if (n <= 0) continue;
@@ -319,9 +298,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                              bt->prior, n, gscale, (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr,
                              bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr, w.out4, w.dZ1 + (int64_t)g0 * w.hid4, w.hid4,
                              nullptr, nullptr, w.loss_acc, w.flag, st));
-            if (bwd) {   // bias gradients by the low-contention column-sum kernel
-                PP_TRY(colsum_f32(w.DY + (int64_t)g0 * w.out4, w.out4, nullptr, n, ad.n_out, grads + ad.b2, nullptr, st));
-                PP_TRY(colsum_f32(w.dZ1 + (int64_t)g0 * w.hid4, w.hid4, nullptr, n, ad.hid, grads + ad.b1, nullptr, st));
+            if (bwd) {   // bias gradients by the low-contention column-sum kernel (one multi-job launch below)
+                cs.push_back(ColsumJob{w.DY + (int64_t)g0 * w.out4, w.out4, nullptr, n, ad.n_out, grads + ad.b2, nullptr});
+                cs.push_back(ColsumJob{w.dZ1 + (int64_t)g0 * w.hid4, w.hid4, nullptr, n, ad.hid, grads + ad.b1, nullptr});
             }
             continue;
         }
@@ -332,12 +311,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
     if (!bwd) return 0;
+    PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+    cs.clear();
 
     // ---------------- backward ----------------
-    // `sw` carries the weight-gradient leaves (second stream when available), `st` the data-gradient chain.
-    const bool two = aux_ready();
-    hipStream_t sw = two ? g_aux.stream : st;
-    if (two) aux_fork(0, st);   // DY, A1 ready
+    std::vector<pp_gemm_args> wq;   // weight-gradient leaves, flushed as one grouped launch once dG is complete
     for (int a = 0; a < net->n_addr; ++a) {
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
         if (n <= 0) continue;
@@ -345,20 +323,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const float* A1 = w.A1 + (int64_t)g0 * w.hid4;
         const float* DY = w.DY + (int64_t)g0 * w.out4;
         float* dZ1 = w.dZ1 + (int64_t)g0 * w.hid4;
-        const bool fused = head_tail_supported(ad.kind, ad.hid, ad.n_out);   // dz1, db1, db2 already produced forward
-        PP_TRY(linear_wgrad(DY, w.out4, A1, w.hid4, nullptr, grads + ad.w2, fused ? nullptr : grads + ad.b2, nullptr, n,
-                            ad.hid, ad.n_out, sw));
-        if (!fused)
+        const bool fused = head_tail_supported(ad.kind, ad.hid, ad.n_out);   // dz1 already produced by the forward tail
+        queue_wgrad(wq, DY, w.out4, A1, w.hid4, nullptr, grads + ad.w2, n, ad.hid, ad.n_out);
+        if (!fused) {
+            PP_TRY(colsum_f32(DY, w.out4, nullptr, n, ad.n_out, grads + ad.b2, nullptr, st));
             PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st,
                                 grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
-    }
-    if (two) aux_fork(1, st);   // dZ1 ready
-    for (int a = 0; a < net->n_addr; ++a) {
-        const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
-        if (n <= 0) continue;
-        const pp_addr& ad = net->addrs[a];
-        float* dZ1 = w.dZ1 + (int64_t)g0 * w.hid4;
-        PP_TRY(linear_wgrad(dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, nullptr, nullptr, n, H, ad.hid, sw));
+        }
+        queue_wgrad(wq, dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, n, H, ad.hid);
         PP_TRY(linear_dgrad(dZ1, w.hid4, P + ad.w1, w.dH, H, bt->grp_rows + g0, nullptr, 0, n, H, ad.hid, false, st));
     }
     for (int t = T - 1; t >= 0; --t) {
@@ -372,14 +344,13 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             PP_TRY(linear_dgrad(Gt, 4 * H, P + net->w_hh, w.dH + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0, n,
                                 H, 4 * H, true, st));
     }
-    // LSTM parameter gradients
-    if (two) aux_fork(2, st);   // dG ready
-    PP_TRY(linear_wgrad(w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, nullptr, nullptr, R, I, 4 * H, sw));
+    // LSTM parameter gradients, together with every head's weight gradients
+    queue_wgrad(wq, w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, R, I, 4 * H);
     if (T > 1) {
         const int r1 = bt->row_off[1];
-        PP_TRY(linear_wgrad(w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, nullptr, nullptr,
-                            R - r1, H, 4 * H, sw));
+        queue_wgrad(wq, w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, R - r1, H, 4 * H);
     }
+    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
     // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding
     PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, false, st));
     const int c1 = net->e_obs, c2 = c1 + net->smp_dim, c3 = c2 + net->dtype_dim, c4 = c3 + net->addr_dim,
@@ -388,22 +359,22 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const pp_addr& ad = net->addrs[a];
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
         if (n > 0) {  // rows where `a` is the current address
-            PP_TRY(colsum_f32(w.dX + c4, w.i4, bt->grp_rows + g0, n, net->dtype_dim, grads + ad.dtype_emb, nullptr, st));
-            PP_TRY(colsum_f32(w.dX + c5, w.i4, bt->grp_rows + g0, n, net->addr_dim, grads + ad.addr_emb, nullptr, st));
+            cs.push_back(ColsumJob{w.dX + c4, w.i4, bt->grp_rows + g0, n, net->dtype_dim, grads + ad.dtype_emb, nullptr});
+            cs.push_back(ColsumJob{w.dX + c5, w.i4, bt->grp_rows + g0, n, net->addr_dim, grads + ad.addr_emb, nullptr});
         }
         const int q0 = bt->nxt_off[a], m = bt->nxt_off[a + 1] - q0;
         if (m > 0) {  // rows whose previous variable has address `a`
-            PP_TRY(colsum_f32(w.dX + c2, w.i4, bt->nxt_rows + q0, m, net->dtype_dim, grads + ad.dtype_emb, nullptr, st));
-            PP_TRY(colsum_f32(w.dX + c3, w.i4, bt->nxt_rows + q0, m, net->addr_dim, grads + ad.addr_emb, nullptr, st));
+            cs.push_back(ColsumJob{w.dX + c2, w.i4, bt->nxt_rows + q0, m, net->dtype_dim, grads + ad.dtype_emb, nullptr});
+            cs.push_back(ColsumJob{w.dX + c3, w.i4, bt->nxt_rows + q0, m, net->addr_dim, grads + ad.addr_emb, nullptr});
         }
     }
+    PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
     if (T > 1)
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
     // observe embedding backward (dE already carries the ReLU mask of the last layer)
     PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));
     if (obs_fused_supported(net)) {
         PP_TRY(obs_embed_bwd_fused(net, P, grads, bt->obs, B, w.obs_h, w.cat, w.f1, w.dE, st));
-        if (two) aux_join(st);
         return 0;
     }
     const int e = net->e_obs;
@@ -424,7 +395,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         ci += in;
         co += out;
     }
-    if (two) aux_join(st);
     return 0;
 }
 

@@ -165,11 +165,11 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ S, int row, 
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
+                                          float* smem) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * (BK + KPAD)];
     float* As = smem;
     float* Bs = smem + BM * (BK + KPAD);
 
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -189,11 +189,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 
     // split-K: blockIdx.z owns a contiguous range of K slabs and adds its partial tile with float atomics
     const int nslab_total = (p.K + BK - 1) / BK;
-    const int per = (nslab_total + gridDim.z - 1) / gridDim.z;
-    const int s_begin = blockIdx.z * per;
+    const int per = (nslab_total + nz - 1) / nz;
+    const int s_begin = bz * per;
     const int nslab = min(nslab_total, s_begin + per) - s_begin;
     if (nslab <= 0) return;
-    const bool split = gridDim.z > 1;
+    const bool split = nz > 1;
 
     // two register sets: the loads of slab i+2 are issued before the MFMAs of slab i and consumed after the MFMAs
     // of slab i+1, so ~2 slabs of matrix work cover one HBM/L2 round trip.
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 
     // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool lead = blockIdx.z == 0;
+    const bool lead = bz == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -292,6 +292,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * (BK + KPAD)];
+    gemm_tile<BM, BN, WM, WN, A_KM, B_KM, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem);
+}
+
+// Several independent products in ONE launch (the weight-gradient leaves of the backward pass, the per-address head
+// products of a ragged batch): workgroup b finds its problem in the prefix table and runs the same tile code.
+constexpr int GROUP_MAX = 8;
+struct GroupedParams {
+    GemmParams p[GROUP_MAX];
+    int first[GROUP_MAX + 1];   // first workgroup of problem q; first[count] = total
+    int gx[GROUP_MAX], gy[GROUP_MAX], gz[GROUP_MAX];
+    int count;
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedParams g) {
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * (BK + KPAD)];
+    const int b = blockIdx.x;
+    int q = 0;
+    while (q + 1 < g.count && b >= g.first[q + 1]) ++q;   // workgroup-uniform
+    int l = b - g.first[q];
+    const int bx = l % g.gx[q];
+    l /= g.gx[q];
+    const int by = l % g.gy[q], bz = l / g.gy[q];
+    gemm_tile<BM, BN, WM, WN, A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], smem);
+}
+
 template <int BM, int BN, int WM, int WN, int VEC>
 static int launch_layout(const GemmParams& p, bool akm, bool bkm, int splits, hipStream_t st) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), splits);
@@ -306,11 +335,7 @@ static int launch_layout(const GemmParams& p, bool akm, bool bkm, int splits, hi
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
-    PP_CHECK_ARG(a && a->A && a->B && a->C, "pp_gemm_f32: null operand");
-    PP_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0, "pp_gemm_f32: negative dimension");
-    if (a->M == 0 || a->N == 0) return 0;
-    GemmParams p;
+static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.A = a->A; p.lda = a->lda; p.a_idx = a->a_idx;
     p.B = a->B; p.ldb = a->ldb; p.b_idx = a->b_idx;
     p.C = a->C; p.ldc = a->ldc; p.c_idx = a->c_idx;
@@ -318,29 +343,47 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
     p.bias = a->bias; p.bias2 = a->bias2; p.mask = a->mask; p.ldmask = a->ldmask;
     p.relu = a->relu; p.accumulate = a->accumulate;
     p.colsum = a->colsum;
-    const bool vec = (a->lda % 4 == 0) && (a->ldb % 4 == 0) && aligned16(a->A) && aligned16(a->B);
+}
+
+static bool vec_ok(const pp_gemm_args* a) {
+    return (a->lda % 4 == 0) && (a->ldb % 4 == 0) && aligned16(a->A) && aligned16(a->B);
+}
+
+// Split-K: the weight-gradient products have K = rows of the batch and only a handful of output tiles; one
+// workgroup per tile would walk dozens of slabs serially while most CUs idle. Spread the slabs over
+// ~2 workgroups per CU and combine with float atomics (the gradient buffers are zero-initialised accumulators).
+// Only for linear epilogues into a dense or pre-zeroed destination, and only when the caller opts in (split_k).
+static int pick_splits(const pp_gemm_args* a, int64_t budget_blocks) {
+    const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
+    const int nslab = cdiv(a->K, BK);
+    const bool linear = !a->relu && !a->mask && !a->colsum;
+    if (!(a->split_k && linear && nslab >= 4 && tiles64 < 384 && (a->accumulate || !a->c_idx))) return 1;
+    int splits = (int)std::min<int64_t>(std::min<int64_t>((budget_blocks + tiles64 - 1) / tiles64, nslab / 2), 32);
+    return std::max(splits, 1);
+}
+
+static int zero_for_split(const pp_gemm_args* a, hipStream_t st) {   // partial tiles are added atomically: start from zero
+    hipError_t e = hipMemset2DAsync(a->C, (size_t)a->ldc * sizeof(float), 0, (size_t)a->N * sizeof(float), a->M, st);
+    if (e != hipSuccess) {
+        set_error("pp_gemm_f32: hipMemset2DAsync failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
+    PP_CHECK_ARG(a && a->A && a->B && a->C, "pp_gemm_f32: null operand");
+    PP_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0, "pp_gemm_f32: negative dimension");
+    if (a->M == 0 || a->N == 0) return 0;
+    GemmParams p;
+    fill_params(a, p);
+    const bool vec = vec_ok(a);
     // Tile choice: the hot-path GEMMs are small (<= a few thousand rows); 64x64 tiles give >= 2 workgroups per CU
     // on the 1024x2048x212 input GEMM. Very tall problems (batched IS) use 128x128 tiles.
     const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
     const bool big = tiles64 >= 4096 && a->N >= 128;
-    // Split-K: the weight-gradient products have K = rows of the batch and only a handful of output tiles; one
-    // workgroup per tile would walk dozens of slabs serially while most CUs idle. Spread the slabs over
-    // ~2 workgroups per CU and combine with float atomics (the gradient buffers are zero-initialised accumulators).
-    // Only for linear epilogues into a dense or pre-zeroed destination.
-    int splits = 1;
-    const int nslab = cdiv(a->K, BK);
-    const bool linear = !a->relu && !a->mask && !a->colsum;
-    if (a->split_k && !big && linear && nslab >= 4 && tiles64 < 384 && (a->accumulate || !a->c_idx)) {
-        splits = (int)std::min<int64_t>(std::min<int64_t>((512 + tiles64 - 1) / tiles64, nslab / 2), 32);
-        if (splits < 1) splits = 1;
-    }
-    if (splits > 1 && !a->accumulate) {   // partial tiles are added atomically: start from zero
-        hipError_t e = hipMemset2DAsync(a->C, (size_t)a->ldc * sizeof(float), 0, (size_t)a->N * sizeof(float), a->M, st);
-        if (e != hipSuccess) {
-            set_error("pp_gemm_f32: hipMemset2DAsync failed: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-    }
+    const int splits = big ? 1 : pick_splits(a, 512);
+    if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
     if (big) {
         return vec ? launch_layout<128, 128, 64, 64, 4>(p, a->a_kmajor, a->b_kmajor, 1, st)
                    : launch_layout<128, 128, 64, 64, 1>(p, a->a_kmajor, a->b_kmajor, 1, st);
@@ -349,6 +392,51 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
                : launch_layout<64, 64, 32, 32, 1>(p, a->a_kmajor, a->b_kmajor, splits, st);
 }
 
+template <int VEC>
+static int launch_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
+    dim3 grid(g.first[g.count]), block(256);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, false, false, VEC>), grid, block, 0, st, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, false, true, VEC>), grid, block, 0, st, g);
+    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, true, false, VEC>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, true, true, VEC>), grid, block, 0, st, g);
+    PP_LAUNCH_CHECK("pp_gemm_f32_grouped");
+    return 0;
+}
+
+// `count` independent products with the same operand layouts in as few launches as possible (GROUP_MAX per launch).
+int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
+    PP_CHECK_ARG(count >= 0 && (count == 0 || args), "pp_gemm_f32_grouped: bad argument");
+    int i = 0;
+    while (i < count) {
+        GroupedParams g;
+        g.count = 0;
+        g.first[0] = 0;
+        bool vec = true;
+        const int akm = args[i].a_kmajor, bkm = args[i].b_kmajor;
+        int j = i;
+        for (; j < count && g.count < GROUP_MAX; ++j) {
+            const pp_gemm_args* a = &args[j];
+            PP_CHECK_ARG(a->A && a->B && a->C && a->M >= 0 && a->N >= 0 && a->K >= 0, "pp_gemm_f32_grouped: bad problem");
+            if (a->a_kmajor != akm || a->b_kmajor != bkm) break;   // next launch
+            if (a->M == 0 || a->N == 0) continue;
+            const int q = g.count++;
+            fill_params(a, g.p[q]);
+            vec = vec && vec_ok(a);
+            // the group shares the chip: aim for ~1024 workgroups in total
+            const int splits = pick_splits(a, std::max<int64_t>(1024 / std::max(count - i, 1), 64));
+            if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
+            g.gx[q] = cdiv(a->N, 64); g.gy[q] = cdiv(a->M, 64); g.gz[q] = splits;
+            g.first[q + 1] = g.first[q] + g.gx[q] * g.gy[q] * splits;
+        }
+        if (g.count > 0) PP_TRY(vec ? launch_grouped<4>(g, akm, bkm, st) : launch_grouped<1>(g, akm, bkm, st));
+        i = j;
+    }
+    return 0;
+}
+
 }  // namespace pp
 
 extern "C" int pp_gemm_f32(const pp_gemm_args* args, void* stream) { return pp::gemm_f32(args, pp::as_stream(stream)); }
+extern "C" int pp_gemm_f32_grouped(const pp_gemm_args* args, int32_t count, void* stream) {
+    return pp::gemm_f32_grouped(args, count, pp::as_stream(stream));
+}

@@ -25,15 +25,28 @@ const char* last_error() { return g_err; }
 // 256 threads = 64 columns x 4 row lanes; each workgroup reduces ROWS_PER_BLOCK rows, one atomic per column.
 // ------------------------------------------------------------------------------------------------------
 constexpr int COLSUM_ROWS = 64;
+constexpr int COLSUM_MAX_JOBS = 8;
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx,
-                                                     const int32_t* __restrict__ idx, int n_rows, int n_cols,
-                                                     float* __restrict__ out, float* __restrict__ out2) {
+struct ColsumJob {
+    const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
+};
+struct ColsumJobs {
+    ColsumJob j[COLSUM_MAX_JOBS];
+};
+
+// blockIdx.z selects the job: several independent column reductions (bias / embedding-table gradients) per launch
+__global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs) {
     __shared__ float part[4][64];
+    const ColsumJob& jb = jobs.j[blockIdx.z];
+    const int n_rows = jb.n_rows, n_cols = jb.n_cols;
     const int tid = threadIdx.x;
     const int cl = tid & 63, rl = tid >> 6;
     const int col = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * COLSUM_ROWS;
+    if (blockIdx.x * 64 >= n_cols || r0 >= n_rows) return;   // this job is smaller than the launch grid
+    const float* __restrict__ X = jb.X;
+    const int32_t* __restrict__ idx = jb.idx;
+    const int64_t ldx = jb.ldx;
     float acc = 0.0f;
     if (col < n_cols) {
         // 16 rows per lane, all loads issued before the adds (independent addresses: latency overlaps)
@@ -54,19 +67,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     __syncthreads();
     if (rl == 0 && col < n_cols) {
         const float s = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
-        atomicAdd(out + col, s);
-        if (out2) atomicAdd(out2 + col, s);
+        atomicAdd(jb.out + col, s);
+        if (jb.out2) atomicAdd(jb.out2 + col, s);
     }
+}
+
+int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st) {
+    int i = 0;
+    while (i < count) {
+        ColsumJobs pack;
+        int n = 0, max_rows = 0, max_cols = 0;
+        for (; i < count && n < COLSUM_MAX_JOBS; ++i) {
+            if (jobs[i].n_rows <= 0 || jobs[i].n_cols <= 0) continue;
+            PP_CHECK_ARG(jobs[i].X && jobs[i].out, "pp_colsum_f32: null pointer");
+            pack.j[n++] = jobs[i];
+            max_rows = std::max(max_rows, jobs[i].n_rows);
+            max_cols = std::max(max_cols, jobs[i].n_cols);
+        }
+        if (n == 0) continue;
+        dim3 grid(cdiv(max_cols, 64), cdiv(max_rows, COLSUM_ROWS), n);
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, pack);
+        PP_LAUNCH_CHECK("pp_colsum_f32");
+    }
+    return 0;
 }
 
 int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
                hipStream_t st) {
     PP_CHECK_ARG(X && out, "pp_colsum_f32: null pointer");
-    if (n_rows <= 0 || n_cols <= 0) return 0;
-    dim3 grid(cdiv(n_cols, 64), cdiv(n_rows, COLSUM_ROWS));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, X, ldx, idx, n_rows, n_cols, out, out2);
-    PP_LAUNCH_CHECK("pp_colsum_f32");
-    return 0;
+    ColsumJob j{X, ldx, idx, n_rows, n_cols, out, out2};
+    return colsum_multi(&j, 1, st);
 }
 
 // ------------------------------------------------------------------------------------------------------

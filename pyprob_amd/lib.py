@@ -67,6 +67,7 @@ PROTOTYPES = {
     'pp_axpy': (C.c_int, [C.c_float, vp, vp, i32, vp]),
     'pp_is_stats': (C.c_int, [vp, vp, i32, vp, vp, vp]),
     'pp_gemm_f32': (C.c_int, [C.POINTER(pp_gemm_args), vp]),
+    'pp_gemm_f32_grouped': (C.c_int, [C.POINTER(pp_gemm_args), i32, vp]),
     'pp_colsum_f32': (C.c_int, [vp, i64, vp, i32, i32, vp, vp, vp]),
     'pp_lstm_input_gather': (C.c_int, [C.POINTER(pp_net), vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]),
     'pp_lstm_cell_fwd': (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),

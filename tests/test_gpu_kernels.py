@@ -167,6 +167,29 @@ def test_gemm_split_k_and_fused_colsum(env):
     np.testing.assert_allclose(cs.cpu().numpy(), 1 + ref.sum(0), rtol=1e-4, atol=1e-3)
 
 
+def test_gemm_grouped_launch(env):
+    """Independent products of different shapes in one launch equal the separate launches."""
+    L, lib, device = env
+    rng = np.random.default_rng(33)
+    shapes = [(30, 271, 1024), (271, 512, 1024), (2048, 212, 1024), (64, 64, 1024), (16, 4, 100)]
+    args = (L.pp_gemm_args * len(shapes))()
+    keep, refs = [], []
+    for q, (M, N, K) in enumerate(shapes):
+        A = rng.uniform(-1, 1, (K, ((M + 3) // 4) * 4)).astype(np.float32)
+        B = rng.uniform(-1, 1, (K, ((N + 3) // 4) * 4)).astype(np.float32)
+        init = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        dA, dB, dC = dev(A, device), dev(B, device), dev(init, device)
+        keep += [dA, dB, dC]
+        g = args[q]
+        g.A, g.lda, g.a_kmajor, g.B, g.ldb, g.b_kmajor = dA.data_ptr(), A.shape[1], 1, dB.data_ptr(), B.shape[1], 1
+        g.C, g.ldc, g.M, g.N, g.K, g.accumulate, g.split_k = dC.data_ptr(), N, M, N, K, 1, 1
+        refs.append((dC, init + A[:, :M].astype(np.float64).T @ B[:, :N].astype(np.float64)))
+    L.check(lib.pp_gemm_f32_grouped(args, len(shapes), L.stream_ptr()), 'pp_gemm_f32_grouped')
+    torch.cuda.synchronize()
+    for dC, ref in refs:
+        assert np.abs(dC.cpu().numpy() - ref).max() / np.abs(ref).max() < 3e-6
+
+
 def test_gemm_large_tile_path(env):
     rng = np.random.default_rng(9)
     M, N, K = 8192, 2048, 212          # >= 4096 tiles -> 128x128 configuration
