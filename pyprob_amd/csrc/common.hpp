@@ -72,6 +72,20 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Touch every 64-byte line of the kernel-argument segment with ONE vector load per workgroup wave: the host wrote the
+// arguments just before the launch, so each line's first scalar load is an HBM-latency miss (~1-2 us); a kernel with a
+// ~1 KB by-value argument struct otherwise pays those misses one after another as its s_load's reach new lines.
+__device__ __forceinline__ void warm_kernargs(int bytes) {
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    if (lane * 64 < bytes) {
+        int t;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t) : "v"(ka + lane * 64) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(t));
+    }
+}
+
 // Cooperative global -> LDS copy by a 256-thread workgroup with 8 independent loads in flight per thread (a plain
 // `for (i = tid; i < n; i += 256) lds[i] = g[i]` is compiled load -> wait -> store and pays a full memory round trip
 // per element: ~1 us each at low occupancy).

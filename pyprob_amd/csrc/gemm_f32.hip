@@ -311,6 +311,7 @@ struct GroupedParams {
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedParams g) {
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * (BK + KPAD)];
+    warm_kernargs((int)sizeof(GroupedParams));
     const int b = blockIdx.x;
     int q = 0;
     while (q + 1 < g.count && b >= g.first[q + 1]) ++q;   // workgroup-uniform

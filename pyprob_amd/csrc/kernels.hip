@@ -639,19 +639,26 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_out = 3 * K;
     const int hid4 = (hid + 3) & ~3;
-    // stage W2 [n_out, hid] into LDS rows of stride hid4, zero padded: wave w takes rows w, w+4, ...; the (at most
-    // 16) loads of a row are all issued before the first store
-    for (int o = wave; o < n_out; o += 4) {
-        float v[16];
+    // stage W2 [n_out, hid] into LDS rows of stride hid4, zero padded. Branch-free flat copy, 16 loads in flight per
+    // thread; row = floor(i / hid4) through an exact float reciprocal (i < 2^14).
+    {
+        const int total = n_out * hid4;
+        const float inv = 1.0f / (float)hid4;
+        for (int base = tid; base < total; base += 256 * 16) {
+            float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = lane + 64 * u;
-            v[u] = (j < hid) ? W2[o * hid + j] : 0.0f;
-        }
+            for (int u = 0; u < 16; ++u) {
+                const int i = min(base + 256 * u, total - 1);
+                const int o = (int)(((float)i + 0.5f) * inv);
+                const int j = i - o * hid4;
+                const float x = W2[o * hid + min(j, hid - 1)];
+                v[u] = j < hid ? x : 0.0f;
+            }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = lane + 64 * u;
-            if (j < hid4) w2s[o * hid4 + j] = v[u];
+            for (int u = 0; u < 16; ++u) {
+                const int i = base + 256 * u;
+                if (i < total) w2s[i] = v[u];
+            }
         }
     }
     // bias of the three outputs this lane owns as mixture component `lane`
