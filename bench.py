@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='train', choices=['train', 'is'])
+    ap.add_argument('--workload', default='train', choices=['train', 'train_gumm', 'is'])
     ap.add_argument('--lstm-dim', type=int, default=512)
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--dataset', type=int, default=1000000, help='offline traces resident in HBM (per job)')
@@ -219,6 +219,47 @@ def main():
                       traces_in_hbm=per_rank * world, params=eng.spec.num_parameters(), global_batch=B * world,
                       parallelism='dp%d' % world, optimizer='Adam lr=1e-3*sqrt(world)', final_loss=round(final_loss, 4),
                       launch='hip_graph_replay' if args.graph else 'eager')
+    elif args.workload == 'train_gumm':
+        # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
+        # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded
+        # BEFORE the timed region (inputs resident in HBM); a parity case, reported for completeness.
+        sys.path.insert(0, os.path.join(REPO, 'tests'))
+        from helpers import synthetic_gumm_arrays
+        B = args.batch
+        nb = 16
+        arrays0, addresses = synthetic_gumm_arrays(8, seed=0, max_iter=6)
+        eng.add_addresses([(a, 'Uniform', None) for a in addresses])
+        batches = []
+        for i in range(nb):
+            arr, _ = synthetic_gumm_arrays(B, seed=100 + rank * nb + i, max_iter=6)
+            ids = np.array([eng.spec.address_id[addresses[j]] for j in arr['addr_idx']])
+            batches.append(PackedBatch.from_ragged(arr['trace_len'], ids, arr['values'], arr['prior'], arr['obs'],
+                                                   len(eng.spec.addresses)).to(device))
+        lr = 1e-3 * (world ** 0.5)
+        for i in range(W):
+            eng.train_step(batches[i % nb], lr)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            eng.train_step(batches[(W + i) % nb], lr)
+        barrier()
+        dt = time.perf_counter() - t0
+        units = B * K
+        metric, unit = 'ic_train_traces_per_sec', 'traces/s'
+        mean_len = float(np.mean([b.mean_length_controlled for b in batches]))
+        config = dict(workload='GaussianUnknownMeanMarsaglia IC training (ragged traces, mean controlled length %.2f, %d '
+                               'addresses/heads), LSTM hidden=%d, batch=%d per GPU' % (mean_len, len(addresses),
+                                                                                       args.lstm_dim, B),
+                      params=eng.spec.num_parameters(), global_batch=B * world, parallelism='dp%d' % world,
+                      final_loss=round(float(eng.loss_buf[0].item()), 4), launch='eager')
+        flops_step = 0.0
+        for b in batches[:1]:
+            n_later = b.n_rows - b.n_traces
+            flops_step = 3.0 * (B * 18496 + b.n_rows * (868352 + 293764 + 8) + n_later * 2097152)
+        out['roofline'] = dict(bound='mfma', achieved=round(flops_step * K / dt / 1e12, 3), peak=FP32_MATRIX_PEAK_TFLOPS,
+                               unit='TFLOP/s', frac=round(flops_step * K / dt / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
+                               kernel='whole step (all GEMM + elementwise kernels), algorithmic FLOPs of SURVEY.md 8(d) x3 for '
+                                      'training / wall-clock step time')
     else:
         from pyprob_amd.is_engine import ISRunner, gum_posterior
         n = args.particles // world
@@ -233,14 +274,16 @@ def main():
         dt = time.perf_counter() - t0
         units = n * K
         metric, unit = 'is_posterior_particles_per_sec', 'particles/s'
-        # HBM roofline of the sampling/scoring chain: algorithmic bytes per particle = value 4 + log q 4 written,
-        # then 4 log-weight passes reading 4-8 B and read-modify-writing lw (8 B): 8 + 4*12 + stats 8 = 64 B
-        bytes_per_particle = 64.0
+        # HBM roofline of the per-particle chain (the network itself runs once for one shared row): algorithmic bytes per
+        # particle = sample kernel writes value + log q (8) ; fused log-weight pass reads them and writes lw (12) ; the two
+        # statistics passes read lw twice and the value once (12) = 32 B
+        bytes_per_particle = 32.0
         ach = units * bytes_per_particle / dt / 1e9
         out['roofline'] = dict(bound='hbm', achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s',
                                frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                               kernel='is_mixture_kernel + logweight_kernel x3 + axpy + is_stats (whole posterior call, '
-                                      'wall-clock; per-kernel event timing not armed for this workload)')
+                               kernel='is_mixture_kernel<0> + logweight_multi_kernel + is_stats_{max,sum}_kernel (whole '
+                                      'posterior call incl. the batch-1 network evaluation, wall-clock; the sampling kernel '
+                                      'is transcendental-bound, see profiles/)')
         config = dict(workload='GaussianUnknownMean posterior_results IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, '
                                'LSTM hidden=%d, %d particles per posterior call per GPU' % (args.lstm_dim, n),
                       particles_per_call=n * world, parallelism='particles sharded x%d' % world,

@@ -180,17 +180,19 @@ int pp_is_init(const pp_net* net, const float* params, const float* obs, float* 
  *   e_obs_vec  dev [e_obs]   output of pp_is_init (shared by all particles)
  *   prev_value dev [n]       values sampled at the previous statement (ignored when prev_addr_id < 0)
  *   prior      dev [n,2] or [2] (prior_stride 0 = same prior parameters for every particle)
- *   h, c       dev [n, H]    LSTM state, updated in place (zeroed internally when prev_addr_id < 0)
+ *   h, c       dev [n, H]    LSTM state, updated in place
+ *   state_rows 1 or n: rows of (h, c) that are valid on entry. The first statement of a trace (prev_addr_id < 0) ignores
+ *              the state, evaluates the network for ONE row (every particle has the same input and zero state) and
+ *              writes row 0 only: the caller passes state_rows = 1 to the next call, which turns the shared recurrent
+ *              term into a bias row and writes all n rows; afterwards state_rows = n.
  *   value_in   dev [n] or NULL: if given, score these values instead of sampling (re-scoring / parity tests)
  *   value_out  dev [n]       sampled (or copied) values
  *   logq_out   dev [n]       proposal log_prob of value (Mixture.log_prob / Categorical.log_prob)
  *   seed, offset             Philox4x32-10 counter-based RNG: particle i uses counter (offset + i)
- * When every particle shares the LSTM input (first statement of the trace: no previous value) the network is
- * evaluated once for one row and the head output is broadcast -- same arithmetic, N-fold less work.
  */
 int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
                const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride,
-               float* h, float* c, const float* value_in, float* value_out, float* logq_out,
+               float* h, float* c, int32_t state_rows, const float* value_in, float* value_out, float* logq_out,
                uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream);
 
 /* log p(value) for Normal / Uniform / Categorical priors and likelihood terms, accumulated into the
@@ -202,12 +204,23 @@ int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, co
                             const float* x, int32_t x_stride, float scale, float* lw /*dev [n]*/, float* lp_out,
                             int32_t n, void* stream);
 
+/* Up to four log-weight terms in ONE pass over the particles:
+ *   lw[i] (+)= sum_t scale_t * term_t(i);  kind 0: Normal log_prob, 1: Uniform log_prob, 2: the value x itself (e.g. -log q)
+ * overwrite != 0 starts from 0 instead of the current lw (saves the zero-fill). */
+typedef struct pp_lw_term {
+    int32_t kind, p0_stride, p1_stride, x_stride;
+    const float *p0, *p1, *x;
+    float scale;
+} pp_lw_term;
+int pp_logweight_terms(const pp_lw_term* terms, int32_t count, float* lw /*dev [n]*/, int32_t n, int32_t overwrite,
+                       void* stream);
+
 /* lw[i] += scale * term[i] (e.g. -log q). */
 int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream);
 
 /* Wavefront-reduced importance statistics over n particles (pyprob/distributions/empirical.py:298-309,
  * 451-466, 758-766): out (dev, double[6]) = { max lw, sum w, sum w^2, sum w*x, sum w*x^2, count finite } with
- * w = exp(lw - max lw). ESS = (sum w)^2 / sum w^2. Two passes; `scratch` dev >= 64 doubles. */
+ * w = exp(lw - max lw). ESS = (sum w)^2 / sum w^2. Two launches over 64 workgroups; `scratch` dev >= 64 doubles. */
 int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

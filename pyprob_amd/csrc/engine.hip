@@ -28,7 +28,7 @@ int sample_embed_bwd(const pp_net* net, const float* params, const float* value,
                      hipStream_t st);
 int obs_grad(const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max, int n_traces, int e_obs,
              const float* E, int64_t lde, float* dE, int64_t ldde, hipStream_t st);
-int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st);
+int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st, int c_prev_shared = 0);
 int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
                   int H, float* db, float* db2, hipStream_t st);
 int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,

@@ -23,6 +23,8 @@
 
 namespace pp {
 
+extern long long* g_timeline;   // kernels.hip (debug phase stamps)
+#define GEMM_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && bx == 1 && by == 1 && bz == 0) p.dbg[10 + (k)] = clock64(); } while (0)
 
 constexpr int BK = 32;
 constexpr int KPAD = 4;
@@ -36,6 +38,7 @@ struct GemmParams {
     const float* mask; int64_t ldmask;
     float* colsum;   // optional: colsum[n] += sum_m result[m, n] (bias gradients fused into the producing GEMM)
     int relu, accumulate;
+    long long* dbg;  // debug phase stamps (NULL normally)
 };
 
 // ---- global -> register staging of one [ROWS x BK] operand slab ------------------------------------------
@@ -170,6 +173,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    GEMM_STAMP(0);
     float* As = smem;
     float* Bs = smem + BM * (BK + KPAD);
 
@@ -225,9 +229,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
         sa.template load<1>(kb + BK);
         sb.template load<1>(kb + BK);
     }
+    GEMM_STAMP(1);
     sa.template store<0>(As, tid);
     sb.template store<0>(Bs, tid);
     __syncthreads();
+    GEMM_STAMP(2);
     for (int i = 0; i < nslab; i += 2) {
         // LDS holds slab i, set 1 holds slab i+1 (in flight), set 0 is free
         if (i + 2 < nslab) {
@@ -253,6 +259,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
         __syncthreads();
     }
 
+    GEMM_STAMP(3);
     // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool lead = bz == 0;
 #pragma unroll
@@ -290,6 +297,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
             }
         }
     }
+    GEMM_STAMP(4);
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
@@ -344,6 +352,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.bias = a->bias; p.bias2 = a->bias2; p.mask = a->mask; p.ldmask = a->ldmask;
     p.relu = a->relu; p.accumulate = a->accumulate;
     p.colsum = a->colsum;
+    p.dbg = (a->M == 1024 && a->N == 2048) ? g_timeline : nullptr;   // debug: stamp the forward input GEMM only
 }
 
 static bool vec_ok(const pp_gemm_args* a) {

@@ -15,7 +15,10 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st);
 int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
                       const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
                       int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st);
-int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st);
+int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st, int c_prev_shared = 0);
+bool obs_fused_supported(const pp_net* net);
+int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
+                        float* cat, float* f1, float* E, hipStream_t st);
 
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
@@ -198,19 +201,8 @@ __global__ __launch_bounds__(256) void is_categorical_kernel(const float* __rest
     logq_out[i] = logf(fminf(fmaxf(pv, kFp32Eps), 1.0f - kFp32Eps));
 }
 
-// h[i,:] = hs[0,:], c[i,:] = cs[0,:]
-__global__ __launch_bounds__(256) void broadcast_state_kernel(const float* __restrict__ hs, const float* __restrict__ cs,
-                                                              float* __restrict__ h, float* __restrict__ c, int n, int H) {
-    const int64_t total = (int64_t)n * H;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int j = (int)(e % H);
-        h[e] = hs[j];
-        c[e] = cs[j];
-    }
-}
-
 struct IsWorkspace {
-    float *X, *G, *A1, *Y, *hs, *cs;
+    float *X, *G, *A1, *Y, *rec, *c0;
     float *obs_h, *cat, *f1;
     int64_t i4, hid4, out4, e4, maxohid4;
     size_t bytes;
@@ -241,9 +233,9 @@ static void is_carve(const pp_net* net, int n, void* p, IsWorkspace& w) {
     w.G = take((int64_t)n * 4 * H);
     w.A1 = take((int64_t)n * w.hid4);
     w.Y = take((int64_t)n * w.out4);
-    w.hs = take(H);
-    w.cs = take(H);
-    w.obs_h = take(w.maxohid4);
+    w.rec = take(4 * H);   // shared recurrent row h0 W_hh^T + b_hh of the second statement
+    w.c0 = take(H);        // copy of the shared cell state row (c is rewritten in place)
+    w.obs_h = take(PP_MAX_OBS * w.maxohid4);
     w.cat = take(w.e4);
     w.f1 = take(w.e4);
     w.bytes = off + 256;
@@ -270,6 +262,11 @@ int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, v
         set_error("pp_is_init: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
         return PP_ENOSPACE;
     }
+    if (obs_fused_supported(net)) {   // one fused launch (obs_embed.hip); e_out has the same row stride round4(e_obs)
+        float* oh[PP_MAX_OBS];
+        for (int o = 0; o < PP_MAX_OBS; ++o) oh[o] = w.obs_h + (int64_t)o * w.maxohid4;
+        return obs_embed_fwd_fused(net, P, obs, 1, oh, w.cat, w.f1, e_out, st);
+    }
     int ci = 0, co = 0, width = 0;
     for (int o = 0; o < net->n_obs; ++o) width += net->obs_in[o];
     for (int o = 0; o < net->n_obs; ++o) {
@@ -286,16 +283,20 @@ int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, v
 }
 
 int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
-            const float* prev_value, const float* prior, int prior_stride, float* h, float* c, const float* value_in,
-            float* value_out, float* logq_out, uint64_t seed, uint64_t offset, void* ws, size_t ws_bytes,
-            hipStream_t st) {
+            const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
+            const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset, void* ws,
+            size_t ws_bytes, hipStream_t st) {
     PP_CHECK_ARG(net && P && e_obs_vec && h && c && value_out && logq_out && ws, "pp_is_step: null pointer");
     PP_CHECK_ARG(addr_id >= 0 && addr_id < net->n_addr && prev_addr_id < net->n_addr, "pp_is_step: address id out of range");
     PP_CHECK_ARG(prev_addr_id < 0 || prev_value, "pp_is_step: prev_value is required after the first statement");
+    PP_CHECK_ARG(prev_addr_id < 0 || state_rows == 1 || state_rows == n, "pp_is_step: state_rows must be 1 or n");
     if (n <= 0) return 0;
     const pp_addr& ad = net->addrs[addr_id];
     PP_CHECK_ARG(ad.kind == PP_HEAD_CATEGORICAL || prior, "pp_is_step: prior parameters required");
-    const bool shared = prev_addr_id < 0;  // identical LSTM input and zero state for every particle
+    // First statement of a trace: identical LSTM input and zero state for every particle -> ONE row is evaluated and
+    // only row 0 of (h, c) is written (the caller's state_rows becomes 1). Second statement: the inputs differ (previous
+    // value) but the recurrent term h0 W_hh^T is still one shared row -> it enters the batched GEMM as a bias.
+    const bool shared = prev_addr_id < 0;
     const int m = shared ? 1 : n;
     const int H = net->lstm_dim, I = net->lstm_in;
     IsWorkspace w;
@@ -306,21 +307,20 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     }
     PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
                              w.i4, st));
-    PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, P + net->b_hh, w.G, 4 * H, m, I, 4 * H, false, false, st));
-    const float* hcur;
     if (shared) {
-        PP_TRY(lstm_cell_fwd(w.G, nullptr, w.cs, w.hs, 1, H, st));
-        const int64_t total = (int64_t)n * H;
-        const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
-        hipLaunchKernelGGL(broadcast_state_kernel, dim3(blocks), dim3(256), 0, st, w.hs, w.cs, h, c, n, H);
-        PP_LAUNCH_CHECK("broadcast_state");
-        hcur = w.hs;
+        PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, P + net->b_hh, w.G, 4 * H, 1, I, 4 * H, false, false, st));
+        PP_TRY(lstm_cell_fwd(w.G, nullptr, c, h, 1, H, st));
+    } else if (state_rows == 1) {
+        PP_TRY(lin(h, H, P + net->w_hh, P + net->b_hh, nullptr, w.rec, 4 * H, 1, H, 4 * H, false, false, st));
+        PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, w.rec, w.G, 4 * H, n, I, 4 * H, false, false, st));
+        (void)hipMemcpyAsync(w.c0, c, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st);   // c is rewritten in place
+        PP_TRY(lstm_cell_fwd(w.G, w.c0, c, h, n, H, st, /*c_prev_shared=*/1));
     } else {
+        PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, P + net->b_hh, w.G, 4 * H, n, I, 4 * H, false, false, st));
         PP_TRY(lin(h, H, P + net->w_hh, nullptr, nullptr, w.G, 4 * H, n, H, 4 * H, false, true, st));
         PP_TRY(lstm_cell_fwd(w.G, c, c, h, n, H, st));
-        hcur = h;
     }
-    PP_TRY(lin(hcur, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
+    PP_TRY(lin(h, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
     PP_TRY(lin(w.A1, w.hid4, P + ad.w2, P + ad.b2, nullptr, w.Y, w.out4, m, ad.hid, ad.n_out, false, false, st));
     dim3 grid(cdiv(n, 256)), block(256);
     if (ad.kind == PP_HEAD_CATEGORICAL) {
@@ -363,27 +363,42 @@ __global__ __launch_bounds__(256) void axpy_kernel(float scale, const float* __r
     if (i < n) lw[i] += scale * t[i];
 }
 
-// Importance statistics in double: one workgroup of 1024 lanes, two passes (max, then sums), wavefront reductions.
-__global__ __launch_bounds__(1024) void is_stats_kernel(const float* __restrict__ lw, const float* __restrict__ x, int n,
-                                                        double* __restrict__ out) {
-    __shared__ double sh[16][5];
-    __shared__ float shmax[16];
+// Importance statistics in double, two launches over STAT_BLOCKS workgroups (a single workgroup took > 1 ms for 1M
+// particles): (1) per-workgroup max of the finite log-weights -> scratch; (2) every workgroup folds the partial maxima,
+// accumulates its share of sum w, sum w^2, sum w x, sum w x^2, count with wavefront reductions and adds them with one
+// double atomic per quantity (STAT_BLOCKS-way contention only).
+constexpr int STAT_BLOCKS = 64;
+
+__global__ __launch_bounds__(256) void is_stats_max_kernel(const float* __restrict__ lw, int n, double* __restrict__ out,
+                                                           double* __restrict__ scratch) {
+    __shared__ float shmax[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float m = -INFINITY;
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = blockIdx.x * 256 + tid; i < n; i += STAT_BLOCKS * 256) {
         const float l = lw[i];
         if (isfinite(l)) m = fmaxf(m, l);
     }
     m = wave_max(m);
     if (lane == 0) shmax[wave] = m;
     __syncthreads();
-    float gmax = shmax[0];
-    for (int k = 1; k < 16; ++k) gmax = fmaxf(gmax, shmax[k]);
+    if (tid == 0) {
+        scratch[blockIdx.x] = (double)fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
+        if (blockIdx.x == 0)
+            for (int q = 0; q < 6; ++q) out[q] = 0.0;   // accumulators of the second launch
+    }
+}
+
+__global__ __launch_bounds__(256) void is_stats_sum_kernel(const float* __restrict__ lw, const float* __restrict__ x, int n,
+                                                           double* __restrict__ out, const double* __restrict__ scratch) {
+    __shared__ double sh[4][5];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double gm = -INFINITY;
+    for (int k = 0; k < STAT_BLOCKS; ++k) gm = fmax(gm, scratch[k]);
     double s[5] = {0, 0, 0, 0, 0};
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = blockIdx.x * 256 + tid; i < n; i += STAT_BLOCKS * 256) {
         const float l = lw[i];
         if (!isfinite(l)) continue;   // Model._traces discards particles with non-finite weight (model.py:65-68)
-        const double wgt = exp((double)l - (double)gmax);
+        const double wgt = (double)expf((float)((double)l - gm));   // fp32 exp of an fp64 difference, fp64 sums
         const double xv = x ? (double)x[i] : 0.0;
         s[0] += wgt; s[1] += wgt * wgt; s[2] += wgt * xv; s[3] += wgt * xv * xv; s[4] += 1.0;
     }
@@ -393,13 +408,45 @@ __global__ __launch_bounds__(1024) void is_stats_kernel(const float* __restrict_
         if (lane == 0) sh[wave][q] = r;
     }
     __syncthreads();
-    if (tid == 0) {
-        double t[5] = {0, 0, 0, 0, 0};
-        for (int k = 0; k < 16; ++k)
-            for (int q = 0; q < 5; ++q) t[q] += sh[k][q];
-        out[0] = (double)gmax;
-        for (int q = 0; q < 5; ++q) out[1 + q] = t[q];
+    if (tid < 5) atomicAdd(out + 1 + tid, sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid]);
+    if (tid == 0 && blockIdx.x == 0) out[0] = gm;
+}
+
+// Several log-weight terms in one pass over the particles (state.py:211-217, 147-149):
+//   lw[i] += sum_t scale_t * term_t(i),  term kinds: 0 Normal log_prob, 1 Uniform log_prob, 2 identity (x itself)
+struct LwTerm {
+    int kind, s0, s1, sx;
+    const float *p0, *p1, *x;
+    float scale;
+};
+struct LwTerms {
+    LwTerm t[4];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void logweight_multi_kernel(const LwTerms terms, float* __restrict__ lw, int n,
+                                                              int overwrite) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = overwrite ? 0.0f : lw[i];
+    for (int q = 0; q < terms.count; ++q) {
+        const LwTerm& t = terms.t[q];
+        const float v = t.x[(int64_t)i * t.sx];
+        float lp;
+        if (t.kind == 2) {
+            lp = v;
+        } else {
+            const float a = t.p0[(int64_t)i * t.s0], b = t.p1[(int64_t)i * t.s1];
+            if (t.kind == 0) {
+                const float d = v - a;
+                lp = -(d * d) / (2.0f * b * b) - logf(b) - kHalfLog2Pi;
+            } else {
+                lp = (v >= a && v < b) ? -logf(b - a) : -INFINITY;
+            }
+        }
+        acc += t.scale * lp;
     }
+    lw[i] = acc;
 }
 
 }  // namespace pp
@@ -420,9 +467,10 @@ int pp_is_init(const pp_net* net, const float* params, const float* obs, float* 
 
 int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
                const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride, float* h,
-               float* c, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
-               void* workspace, size_t workspace_bytes, void* stream) {
-    return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, value_in,
+               float* c, int32_t state_rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed,
+               uint64_t offset, void* workspace, size_t workspace_bytes, void* stream) {
+    return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows,
+                       value_in,
                        value_out, logq_out, seed, offset, workspace, workspace_bytes, pp::as_stream(stream));
 }
 
@@ -449,10 +497,36 @@ int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream) 
 }
 
 int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream) {
-    (void)scratch;
-    if (!(lw && out) || n <= 0) return PP_EINVAL;
-    hipLaunchKernelGGL(pp::is_stats_kernel, dim3(1), dim3(1024), 0, pp::as_stream(stream), lw, x, n, out);
+    if (!(lw && out && scratch) || n <= 0) {
+        pp::set_error("pp_is_stats: bad argument (scratch of >= 64 doubles is required)");
+        return PP_EINVAL;
+    }
+    hipLaunchKernelGGL(pp::is_stats_max_kernel, dim3(pp::STAT_BLOCKS), dim3(256), 0, pp::as_stream(stream), lw, n, out, scratch);
+    hipLaunchKernelGGL(pp::is_stats_sum_kernel, dim3(pp::STAT_BLOCKS), dim3(256), 0, pp::as_stream(stream), lw, x, n, out,
+                       scratch);
     PP_LAUNCH_CHECK("pp_is_stats");
+    return 0;
+}
+
+int pp_logweight_terms(const pp_lw_term* terms, int32_t count, float* lw, int32_t n, int32_t overwrite, void* stream) {
+    if (!(terms && lw) || count < 1 || count > 4) {
+        pp::set_error("pp_logweight_terms: 1..4 terms");
+        return PP_EINVAL;
+    }
+    if (n <= 0) return 0;
+    pp::LwTerms t;
+    t.count = count;
+    for (int q = 0; q < count; ++q) {
+        const pp_lw_term& s = terms[q];
+        if (s.kind < 0 || s.kind > 2 || !s.x || (s.kind != 2 && !(s.p0 && s.p1))) {
+            pp::set_error("pp_logweight_terms: bad term %d", q);
+            return PP_EINVAL;
+        }
+        t.t[q] = pp::LwTerm{s.kind, s.p0_stride, s.p1_stride, s.x_stride, s.p0, s.p1, s.x, s.scale};
+    }
+    hipLaunchKernelGGL(pp::logweight_multi_kernel, dim3(pp::cdiv(n, 256)), dim3(256), 0, pp::as_stream(stream), t, lw, n,
+                       overwrite);
+    PP_LAUNCH_CHECK("pp_logweight_terms");
     return 0;
 }
 

@@ -284,7 +284,7 @@ constexpr int CELL_ROWS = 8;    // rows per workgroup; 256 threads = 64 hidden u
 
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ G, const float* __restrict__ c_prev,
                                                             float* __restrict__ c, float* __restrict__ h, int n,
-                                                            int H) {
+                                                            int H, int c_prev_shared) {
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     if (j >= H) return;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ 
         const float gf = sigmoidf_(g[H + j]);
         const float gg = tanhf(g[2 * H + j]);
         const float go = sigmoidf_(g[3 * H + j]);
-        const float cp = c_prev ? c_prev[e] : 0.0f;
+        const float cp = c_prev ? c_prev[c_prev_shared ? j : e] : 0.0f;
         const float cn = gf * cp + gi * gg;
         g[j] = gi;
         g[H + j] = gf;
@@ -309,10 +309,11 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ 
     }
 }
 
-int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st) {
+int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st, int c_prev_shared) {
     PP_CHECK_ARG(G && c && h && H > 0, "pp_lstm_cell_fwd: bad argument");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(H, 64), cdiv(n, CELL_ROWS)), dim3(256), 0, st, G, c_prev, c, h, n, H);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(H, 64), cdiv(n, CELL_ROWS)), dim3(256), 0, st, G, c_prev, c, h, n, H,
+                       c_prev_shared);
     PP_LAUNCH_CHECK("pp_lstm_cell_fwd");
     return 0;
 }

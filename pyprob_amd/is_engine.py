@@ -25,7 +25,17 @@ class ISRunner:
         self.ws_bytes = 0
         self.n = 0
         self.offset = 0
+        self._consts = {}
         self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self._stats_scratch = torch.zeros(64, dtype=torch.float64, device=self.dev)
+
+    def _const(self, v):
+        """1-element device tensor holding v (cached: no allocation / H2D copy in the steady state)."""
+        t = self._consts.get(v)
+        if t is None:
+            t = torch.tensor([v], dtype=torch.float32, device=self.dev)
+            self._consts[v] = t
+        return t
 
     def _ensure_ws(self, n):
         need = self.lib.pp_is_workspace_bytes(C.byref(self.eng.net), n)
@@ -50,6 +60,7 @@ class ISRunner:
             self.c = torch.empty(n, H, dtype=torch.float32, device=self.dev)
             self.n = n
         self.prev_value = None
+        self.state_rows = 1
         self.offset = int(offset)
         self._ensure_ws(n)
 
@@ -63,9 +74,10 @@ class ISRunner:
         rc = self.lib.pp_is_step(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id),
                                  -1 if prev_addr_id is None else int(prev_addr_id), n, self.e_obs.data_ptr(),
                                  L.ptr(self.prev_value), L.ptr(prior), stride, self.h.data_ptr(), self.c.data_ptr(),
-                                 L.ptr(value_in), value.data_ptr(), logq.data_ptr(), int(seed), self.offset,
+                                 self.state_rows, L.ptr(value_in), value.data_ptr(), logq.data_ptr(), int(seed), self.offset,
                                  self.ws.data_ptr(), self.ws_bytes, L.stream_ptr())
         L.check(rc, 'pp_is_step')
+        self.state_rows = 1 if prev_addr_id is None else n   # see include/pyprob_amd.h
         self.prev_value = value
         return value, logq
 
@@ -80,13 +92,28 @@ class ISRunner:
                                               float(scale), lw.data_ptr(), None, n, L.stream_ptr())
         L.check(rc, 'pp_logweight_accumulate')
 
+    def accumulate_terms(self, lw, terms, overwrite=False):
+        """One pass for up to four terms; terms = [(kind, p0, p1, x, scale)], kind 2 = the tensor x itself."""
+        arr = (L.pp_lw_term * len(terms))()
+
+        def s(t):
+            return 0 if (t is None or t.numel() == 1) else 1
+        for q, (kind, p0, p1, x, scale) in enumerate(terms):
+            arr[q].kind = int(kind)
+            arr[q].p0, arr[q].p1, arr[q].x = L.ptr(p0), L.ptr(p1), x.data_ptr()
+            arr[q].p0_stride, arr[q].p1_stride, arr[q].x_stride = s(p0), s(p1), s(x)
+            arr[q].scale = float(scale)
+        L.check(self.lib.pp_logweight_terms(arr, len(terms), lw.data_ptr(), lw.numel(), int(overwrite), L.stream_ptr()),
+                'pp_logweight_terms')
+
     def axpy(self, lw, scale, term):
         L.check(self.lib.pp_axpy(float(scale), term.data_ptr(), lw.data_ptr(), lw.numel(), L.stream_ptr()), 'pp_axpy')
 
     def stats(self, lw, x=None):
         """Importance statistics (Empirical.finalize / expectation / effective_sample_size,
         pyprob/distributions/empirical.py:298-309, 451-466, 758-766) reduced on the device in float64."""
-        rc = self.lib.pp_is_stats(lw.data_ptr(), L.ptr(x), lw.numel(), self._stats.data_ptr(), None, L.stream_ptr())
+        rc = self.lib.pp_is_stats(lw.data_ptr(), L.ptr(x), lw.numel(), self._stats.data_ptr(),
+                                  self._stats_scratch.data_ptr(), L.stream_ptr())
         L.check(rc, 'pp_is_stats')
         m, sw, sw2, swx, swx2, cnt = self._stats[:6].cpu().numpy().tolist()
         mean = swx / sw if sw > 0 else float('nan')
@@ -106,14 +133,17 @@ def gum_posterior(engine, num_particles, obs=(8.0, 9.0), prior_mean=1.0, prior_s
     dev = engine.device
     run.init(obs)
     run.begin(num_particles, offset=offset)
-    prior = torch.tensor([[prior_mean, prior_stddev]], dtype=torch.float32, device=dev)
+    key = ('prior', float(prior_mean), float(prior_stddev))
+    prior = run._consts.get(key)
+    if prior is None:
+        prior = run._consts[key] = torch.tensor([[prior_mean, prior_stddev]], dtype=torch.float32, device=dev)
     mu, logq = run.step(0, None, prior, seed=seed)
-    lw = torch.zeros(num_particles, dtype=torch.float32, device=dev)
-    run.accumulate(lw, 0, prior[0, 0:1], prior[0, 1:2], mu)            # + log p(mu)        state.py:211
-    run.axpy(lw, -1.0, logq)                                           # - log q(mu)        state.py:212,217
-    s = torch.tensor([likelihood_stddev], dtype=torch.float32, device=dev)
-    for y in obs:                                                      # + log p(y_j | mu)  state.py:147-149
-        run.accumulate(lw, 0, mu, s, torch.tensor([float(y)], dtype=torch.float32, device=dev))
+    lw = torch.empty(num_particles, dtype=torch.float32, device=dev)
+    s = run._const(likelihood_stddev)
+    # + log p(mu) (state.py:211)  - log q(mu) (state.py:212,217)  + log p(y_j | mu) (state.py:147-149): one fused pass
+    terms = [(0, prior[0, 0:1], prior[0, 1:2], mu, 1.0), (2, None, None, logq, -1.0)]
+    terms += [(0, mu, s, run._const(float(y)), 1.0) for y in obs]
+    run.accumulate_terms(lw, terms, overwrite=True)
     st = run.stats(lw, mu)
     st['std'] = float(np.sqrt(max(st['var'], 0.0)))
     if return_particles:

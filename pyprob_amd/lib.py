@@ -41,6 +41,11 @@ class pp_batch(C.Structure):
                 ('trace', vp), ('row_off_dev', vp), ('nxt_off', C.POINTER(i32)), ('nxt_rows', vp)]
 
 
+class pp_lw_term(C.Structure):
+    _fields_ = [('kind', i32), ('p0_stride', i32), ('p1_stride', i32), ('x_stride', i32),
+                ('p0', vp), ('p1', vp), ('x', vp), ('scale', C.c_float)]
+
+
 class pp_gemm_args(C.Structure):
     _fields_ = [('A', vp), ('lda', i64), ('a_idx', vp),
                 ('B', vp), ('ldb', i64), ('b_idx', vp),
@@ -61,9 +66,10 @@ PROTOTYPES = {
                                C.c_float, C.c_float, vp]),
     'pp_is_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32]),
     'pp_is_init': (C.c_int, [C.POINTER(pp_net), vp, vp, vp, vp, C.c_size_t, vp]),
-    'pp_is_step': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, C.c_uint64,
+    'pp_is_step': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, C.c_uint64,
                              C.c_uint64, vp, C.c_size_t, vp]),
     'pp_logweight_accumulate': (C.c_int, [i32, vp, i32, vp, i32, vp, i32, C.c_float, vp, vp, i32, vp]),
+    'pp_logweight_terms': (C.c_int, [C.POINTER(pp_lw_term), i32, vp, i32, i32, vp]),
     'pp_axpy': (C.c_int, [C.c_float, vp, vp, i32, vp]),
     'pp_is_stats': (C.c_int, [vp, vp, i32, vp, vp, vp]),
     'pp_gemm_f32': (C.c_int, [C.POINTER(pp_gemm_args), vp]),
