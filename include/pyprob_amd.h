@@ -248,7 +248,7 @@ typedef struct pp_gemm_args {
  * (gather/scatter) arrays: the "address-dispatch gather" of the proposal heads. */
 int pp_gemm_f32(const pp_gemm_args* args, void* stream);
 /* `count` independent products with identical operand layouts (a_kmajor/b_kmajor) in as few launches as possible
- * (up to 8 problems per launch): the weight-gradient leaves of a backward pass, the per-address head products. */
+ * (up to 16 problems per launch): the weight-gradient leaves of a backward pass, the per-address head products. */
 int pp_gemm_f32_grouped(const pp_gemm_args* args, int32_t count, void* stream);
 
 /* out[c] += sum_i X[ix(i)*ldx + c] for c < n_cols (bias and embedding-table gradients). out2 optional. */

@@ -35,10 +35,12 @@ int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, con
                  int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
                  hipStream_t st);
 bool head_tail_supported(int kind, int hid, int n_out);
-int head_tail(int kind, const float* A1, int64_t lda1, const float* W2, const float* b2, int hid, int n_out,
-              const int32_t* rows, const float* value, const float* prior, int n, float grad_scale, float* lp_out,
-              float* DY, int64_t lddy, float* dZ1, int64_t lddz, float* db1, float* db2, float* loss_acc,
-              int32_t* nonfinite, hipStream_t st);
+struct TailJob {
+    const float* A1; const float* W2; const float* b2; const int32_t* rows; float* DY; float* dZ1; int n;
+};
+int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int hid, int n_out, const float* value,
+                    const float* prior, float grad_scale, float* lp_out, int64_t lddy, int64_t lddz, float* loss_acc,
+                    int32_t* nonfinite, hipStream_t st);
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out,
                   hipStream_t st);
 int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
@@ -278,6 +280,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             g.C = Gt; g.ldc = 4 * H;
             g.M = n; g.N = 4 * H; g.K = H;
             g.accumulate = 1;
+            g.split_k = 1;   // few rows late in a ragged batch: spread K over workgroups (accumulation into G)
             PP_TRY(gemm_f32(&g, st));
             c_prev = w.C + (int64_t)rp * H;
         }
@@ -285,25 +288,51 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     const float gscale = -1.0f / (float)B;
     std::vector<ColsumJob> cs;
+    // heads: first FF layer of EVERY address group in one grouped launch (rows gathered by address: the dispatch
+    // gather), then the fused tails, grouped by (kind, shape)
+    {
+        std::vector<pp_gemm_args> hq;
+        for (int a = 0; a < net->n_addr; ++a) {
+            const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
+            if (n <= 0) continue;
+            const pp_addr& ad = net->addrs[a];
+            pp_gemm_args g{};
+            g.A = w.Hs; g.lda = H; g.a_idx = bt->grp_rows + g0;
+            g.B = P + ad.w1; g.ldb = H;
+            g.C = w.A1 + (int64_t)g0 * w.hid4; g.ldc = w.hid4;
+            g.M = n; g.N = ad.hid; g.K = H;
+            g.bias = P + ad.b1; g.relu = 1;
+            hq.push_back(g);
+        }
+        PP_TRY(gemm_f32_grouped(hq.data(), (int)hq.size(), st));
+    }
+    std::vector<char> done(net->n_addr, 0);
     for (int a = 0; a < net->n_addr; ++a) {
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
-        if (n <= 0) continue;
+        if (n <= 0 || done[a]) continue;
         const pp_addr& ad = net->addrs[a];
-        float* A1 = w.A1 + (int64_t)g0 * w.hid4;
-        float* Y = w.Y + (int64_t)g0 * w.out4;
-        PP_TRY(linear_fwd(w.Hs, H, bt->grp_rows + g0, P + ad.w1, P + ad.b1, A1, w.hid4, n, H, ad.hid, true, nullptr, st));
         if (head_tail_supported(ad.kind, ad.hid, ad.n_out)) {
-            // fused tail: layer 2 + log_prob + loss (+ dy, dz1, db1, db2 when training) in one launch
-            PP_TRY(head_tail(ad.kind, A1, w.hid4, P + ad.w2, P + ad.b2, ad.hid, ad.n_out, bt->grp_rows + g0, bt->value,
-                             bt->prior, n, gscale, (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr,
-                             bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr, w.out4, w.dZ1 + (int64_t)g0 * w.hid4, w.hid4,
-                             nullptr, nullptr, w.loss_acc, w.flag, st));
-            if (bwd) {   // bias gradients by the low-contention column-sum kernel (one multi-job launch below)
-                cs.push_back(ColsumJob{w.DY + (int64_t)g0 * w.out4, w.out4, nullptr, n, ad.n_out, grads + ad.b2, nullptr});
-                cs.push_back(ColsumJob{w.dZ1 + (int64_t)g0 * w.hid4, w.hid4, nullptr, n, ad.hid, grads + ad.b1, nullptr});
+            // fused tail (layer 2 + log_prob + loss [+ dy, dz1]) for this and every later group of the same head shape
+            std::vector<TailJob> tj;
+            for (int b = a; b < net->n_addr; ++b) {
+                const pp_addr& bd = net->addrs[b];
+                const int h0 = bt->grp_off[b], m = bt->grp_off[b + 1] - h0;
+                if (m <= 0 || done[b] || bd.kind != ad.kind || bd.hid != ad.hid || bd.n_out != ad.n_out) continue;
+                done[b] = 1;
+                tj.push_back(TailJob{w.A1 + (int64_t)h0 * w.hid4, P + bd.w2, P + bd.b2, bt->grp_rows + h0,
+                                     bwd ? w.DY + (int64_t)h0 * w.out4 : nullptr, w.dZ1 + (int64_t)h0 * w.hid4, m});
+                if (bwd) {   // bias gradients by the low-contention column-sum kernel (multi-job launches below)
+                    cs.push_back(ColsumJob{w.DY + (int64_t)h0 * w.out4, w.out4, nullptr, m, bd.n_out, grads + bd.b2, nullptr});
+                    cs.push_back(ColsumJob{w.dZ1 + (int64_t)h0 * w.hid4, w.hid4, nullptr, m, bd.hid, grads + bd.b1, nullptr});
+                }
             }
+            PP_TRY(head_tail_multi(ad.kind, tj.data(), (int)tj.size(), w.hid4, ad.hid, ad.n_out, bt->value, bt->prior, gscale,
+                                   (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr, w.out4, w.hid4, w.loss_acc, w.flag, st));
             continue;
         }
+        done[a] = 1;
+        float* A1 = w.A1 + (int64_t)g0 * w.hid4;
+        float* Y = w.Y + (int64_t)g0 * w.out4;
         PP_TRY(linear_fwd(A1, w.hid4, nullptr, P + ad.w2, P + ad.b2, Y, w.out4, n, ad.hid, ad.n_out, false, nullptr, st));
         PP_TRY(head_logprob(ad.kind, Y, w.out4, bt->grp_rows + g0, bt->value, bt->prior, n, ad.n_out, gscale,
                             (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr, bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr,
@@ -316,6 +345,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
 
     // ---------------- backward ----------------
     std::vector<pp_gemm_args> wq;   // weight-gradient leaves, flushed as one grouped launch once dG is complete
+    std::vector<pp_gemm_args> dq;   // per-address data gradients into dH
     for (int a = 0; a < net->n_addr; ++a) {
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
         if (n <= 0) continue;
@@ -331,8 +361,16 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                                 grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
         }
         queue_wgrad(wq, dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, n, H, ad.hid);
-        PP_TRY(linear_dgrad(dZ1, w.hid4, P + ad.w1, w.dH, H, bt->grp_rows + g0, nullptr, 0, n, H, ad.hid, false, st));
+        {   // dH[rows of this address] = dZ1 W1: queued, every address group in one grouped launch
+            pp_gemm_args g{};
+            g.A = dZ1; g.lda = w.hid4;
+            g.B = P + ad.w1; g.ldb = H; g.b_kmajor = 1;
+            g.C = w.dH; g.ldc = H; g.c_idx = bt->grp_rows + g0;
+            g.M = n; g.N = H; g.K = ad.hid;
+            dq.push_back(g);
+        }
     }
+    PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));
     for (int t = T - 1; t >= 0; --t) {
         const int n = bt->n_active[t], r0 = bt->row_off[t];
         const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 
 // Several independent products in ONE launch (the weight-gradient leaves of the backward pass, the per-address head
 // products of a ragged batch): workgroup b finds its problem in the prefix table and runs the same tile code.
-constexpr int GROUP_MAX = 8;
+constexpr int GROUP_MAX = 16;
 struct GroupedParams {
     GemmParams p[GROUP_MAX];
     int first[GROUP_MAX + 1];   // first workgroup of problem q; first[count] = total

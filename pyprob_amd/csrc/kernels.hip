@@ -25,7 +25,7 @@ const char* last_error() { return g_err; }
 // 256 threads = 64 columns x 4 row lanes; each workgroup reduces ROWS_PER_BLOCK rows, one atomic per column.
 // ------------------------------------------------------------------------------------------------------
 constexpr int COLSUM_ROWS = 64;
-constexpr int COLSUM_MAX_JOBS = 8;
+constexpr int COLSUM_MAX_JOBS = 16;
 
 struct ColsumJob {
     const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
@@ -623,19 +623,32 @@ constexpr int TAIL_LDS_FLOATS = 16384;
 
 // NQ4 = float4 groups per lane: lane l owns hidden units j = 256 q + 4 l + e (q < NQ4, e < 4), so a1 / dz1 rows move as
 // 16-byte accesses and every W2 row (LDS stride hid4 = round4(hid)) is read with one ds_read_b128 per 4 FMAs.
+constexpr int TAIL_MAX_JOBS = 16;
+struct TailJob {   // one address group: rows [0, n) of the group-compact head buffers
+    const float* A1; const float* W2; const float* b2; const int32_t* rows; float* DY; float* dZ1; int n;
+};
+struct TailJobs {
+    TailJob j[TAIL_MAX_JOBS];
+};
+
 template <int KIND, int NQ4>
-__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ A1, int64_t lda1,
-                                                        const float* __restrict__ W2, const float* __restrict__ b2,
-                                                        int hid, int K, const int32_t* __restrict__ rows,
+__global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int64_t lda1, int hid, int K,
                                                         const float* __restrict__ value,
-                                                        const float* __restrict__ prior, int n, int rows_per_wave,
-                                                        float grad_scale, float* __restrict__ lp_out,
-                                                        float* __restrict__ DY, int64_t lddy,
-                                                        float* __restrict__ dZ1, int64_t lddz,
-                                                        float* __restrict__ loss_acc, int32_t* __restrict__ nonfinite,
-                                                        long long* __restrict__ dbg) {
+                                                        const float* __restrict__ prior, int rows_per_wave,
+                                                        float grad_scale, float* __restrict__ lp_out, int64_t lddy,
+                                                        int64_t lddz, float* __restrict__ loss_acc,
+                                                        int32_t* __restrict__ nonfinite, long long* __restrict__ dbg) {
+    const TailJob& jb = jobs.j[blockIdx.y];   // blockIdx.y = address group (same head kind and shape in one launch)
+    const int n = jb.n;
+    if ((int)blockIdx.x * 4 * rows_per_wave >= n) return;   // this group has fewer rows than the launch grid
+    const float* __restrict__ A1 = jb.A1;
+    const float* __restrict__ W2 = jb.W2;
+    const float* __restrict__ b2 = jb.b2;
+    const int32_t* __restrict__ rows = jb.rows;
+    float* __restrict__ DY = jb.DY;
+    float* __restrict__ dZ1 = jb.dZ1;
     __shared__ __attribute__((aligned(16))) float w2s[TAIL_LDS_FLOATS];
-#define PP_STAMP(k) do { if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) dbg[(blockIdx.x ? 8 : 0) + (k)] = clock64(); } while (0)
+#define PP_STAMP(k) do { if (dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == 0) dbg[(k)] = clock64(); } while (0)
     PP_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_out = 3 * K;
@@ -817,7 +830,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     PP_STAMP(6);
     // loss: one atomic per wave, spread over 64 accumulator slots (same-address float atomics serialise at ~40 ns
     // each in L2; a thousand waves on one word cost ~40 us). loss_finalize sums the slots.
-    if (lane == 0 && loss_acc && loss_local != 0.0f) atomicAdd(loss_acc + ((blockIdx.x * 4 + wave) & 63), loss_local);
+    if (lane == 0 && loss_acc && loss_local != 0.0f) atomicAdd(loss_acc + ((blockIdx.x * 4 + wave + 7 * blockIdx.y) & 63), loss_local);
     if (bad_any && nonfinite && lane == 0) atomicOr(nonfinite, 1);
     // The bias gradients db1 = colsum(dz1), db2 = colsum(dy) are NOT accumulated here: ~1000 waves adding to the
     // same few hundred addresses serialise in L2 (measured: +40 us); the caller runs the 16-way colsum kernel instead.
@@ -835,12 +848,11 @@ bool head_tail_supported(int kind, int hid, int n_out) {
 long long* g_timeline = nullptr;   // debug: per-phase clock64() stamps of workgroups 0 and 100 (pp_debug_timeline)
 
 template <int KIND>
-static void head_tail_launch(int nq4, dim3 grid, hipStream_t st, const float* A1, int64_t lda1, const float* W2,
-                             const float* b2, int hid, int K, const int32_t* rows, const float* value, const float* prior,
-                             int n, int rpw, float gs, float* lp_out, float* DY, int64_t lddy, float* dZ1, int64_t lddz,
-                             float* loss_acc, int32_t* nonfinite) {
-#define PP_TAIL(NQ) hipLaunchKernelGGL((head_tail_kernel<KIND, NQ>), grid, dim3(256), 0, st, A1, lda1, W2, b2, hid, K, rows, \
-                                       value, prior, n, rpw, gs, lp_out, DY, lddy, dZ1, lddz, loss_acc, nonfinite, g_timeline)
+static void head_tail_launch(int nq4, dim3 grid, hipStream_t st, const TailJobs& jobs, int64_t lda1, int hid, int K,
+                             const float* value, const float* prior, int rpw, float gs, float* lp_out, int64_t lddy,
+                             int64_t lddz, float* loss_acc, int32_t* nonfinite) {
+#define PP_TAIL(NQ) hipLaunchKernelGGL((head_tail_kernel<KIND, NQ>), grid, dim3(256), 0, st, jobs, lda1, hid, K, value, prior, \
+                                       rpw, gs, lp_out, lddy, lddz, loss_acc, nonfinite, g_timeline)
     switch (nq4) {
         case 1: PP_TAIL(1); break;
         case 2: PP_TAIL(2); break;
@@ -850,26 +862,35 @@ static void head_tail_launch(int nq4, dim3 grid, hipStream_t st, const float* A1
 #undef PP_TAIL
 }
 
-int head_tail(int kind, const float* A1, int64_t lda1, const float* W2, const float* b2, int hid, int n_out,
-              const int32_t* rows, const float* value, const float* prior, int n, float grad_scale, float* lp_out,
-              float* DY, int64_t lddy, float* dZ1, int64_t lddz, float* db1, float* db2, float* loss_acc,
-              int32_t* nonfinite, hipStream_t st) {
-    (void)db1; (void)db2;
+// Address groups with the same head kind and shape (kind, hid, n_out) share launches (TAIL_MAX_JOBS per launch).
+int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int hid, int n_out, const float* value,
+                    const float* prior, float grad_scale, float* lp_out, int64_t lddy, int64_t lddz, float* loss_acc,
+                    int32_t* nonfinite, hipStream_t st) {
     PP_CHECK_ARG(head_tail_supported(kind, hid, n_out), "head_tail: unsupported head shape");
-    PP_CHECK_ARG(!DY || dZ1, "head_tail: backward needs dZ1");
-    PP_CHECK_ARG(lda1 % 4 == 0 && (!dZ1 || lddz % 4 == 0), "head_tail: leading dimensions must be multiples of 4");
-    if (n <= 0) return 0;
-    // ~256 workgroups: W2 staging (n_out*hid floats) is amortised over rows_per_wave rows per wave
-    const int rpw = std::max((n + 4 * 256 - 1) / (4 * 256), 1);
-    dim3 grid(cdiv(n, 4 * rpw));
+    PP_CHECK_ARG(lda1 % 4 == 0 && lddz % 4 == 0, "head_tail: leading dimensions must be multiples of 4");
     const int nq4 = (((hid + 3) & ~3) + 255) / 256;
-    if (kind == PP_HEAD_NORMAL_MIXTURE)
-        head_tail_launch<0>(nq4, grid, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n, rpw, grad_scale, lp_out, DY,
-                            lddy, dZ1, lddz, loss_acc, nonfinite);
-    else
-        head_tail_launch<1>(nq4, grid, st, A1, lda1, W2, b2, hid, n_out / 3, rows, value, prior, n, rpw, grad_scale, lp_out, DY,
-                            lddy, dZ1, lddz, loss_acc, nonfinite);
-    PP_LAUNCH_CHECK("head_tail");
+    int i = 0;
+    while (i < count) {
+        TailJobs pack;
+        int nj = 0, max_n = 0;
+        for (; i < count && nj < TAIL_MAX_JOBS; ++i) {
+            if (jobs[i].n <= 0) continue;
+            PP_CHECK_ARG(jobs[i].A1 && jobs[i].W2 && jobs[i].b2 && (!jobs[i].DY || jobs[i].dZ1), "head_tail: bad job");
+            pack.j[nj++] = jobs[i];
+            max_n = std::max(max_n, jobs[i].n);
+        }
+        if (nj == 0) continue;
+        // ~256 workgroups for the largest group: W2 staging (n_out*hid floats) is amortised over rows_per_wave rows
+        const int rpw = std::max((max_n + 4 * 256 - 1) / (4 * 256), 1);
+        dim3 grid(cdiv(max_n, 4 * rpw), nj);
+        if (kind == PP_HEAD_NORMAL_MIXTURE)
+            head_tail_launch<0>(nq4, grid, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy, lddz,
+                                loss_acc, nonfinite);
+        else
+            head_tail_launch<1>(nq4, grid, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy, lddz,
+                                loss_acc, nonfinite);
+        PP_LAUNCH_CHECK("head_tail");
+    }
     return 0;
 }
 
