@@ -129,7 +129,10 @@ def main():
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    # one process per GPU over RCCL; also taken with a single rank when launched through torch.distributed.run, so that
+    # the collective path can be exercised on a 1-GPU box
+    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('PP_BENCH_DIST', '1') != '0')
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', device_id=device)
 
@@ -139,13 +142,14 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     eng = make_engine(args.lstm_dim, device, seed=123)
     eng.world_size = world
-    if world > 1:
+    eng.force_allreduce = use_dist
+    if use_dist:
         eng.broadcast_params()
     out = {}
     K, W = args.steps, args.warmup
@@ -290,7 +294,7 @@ def main():
                       ess=round(st['ess'], 1), posterior_mean=round(st['mean'], 4))
 
     # max over ranks
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -304,7 +308,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline_train(args.lstm_dim, args.batch) if args.workload == 'train' \
                 else cpu_baseline_is()
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

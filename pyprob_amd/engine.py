@@ -28,6 +28,7 @@ class ICEngine:
         self.ws_shape = (0, 0)
         self.status_buf = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.world_size = 1
+        self.force_allreduce = False   # run the collective even with one rank (exercises the RCCL path)
         self._resize(initialise=list(spec.tensors.keys()))
 
     # ---- buffers -----------------------------------------------------------------------------------------
@@ -128,7 +129,7 @@ class ICEngine:
 
     def _set_active(self, batch):
         key = (tuple(batch.cur_counts > 0), tuple(batch.prev_counts > 0))
-        if key == self._active_key and self.world_size == 1:
+        if key == self._active_key and self.world_size == 1 and not self.force_allreduce:
             return          # presence map already in place (it is only overwritten by the DP all-reduce)
         act = self._active_cache.get(key)
         if act is None:
@@ -150,7 +151,7 @@ class ICEngine:
     def train_step(self, batch, lr, weight_decay=0.0):
         """zero_grad -> loss -> backward -> [all-reduce] -> Adam (inference_network.py:486-496). No host sync."""
         loss = self.loss(batch, backward=True)
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_allreduce:
             self.allreduce_grads()
         self.adam_step(lr, weight_decay=weight_decay)
         return loss

@@ -97,6 +97,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be in the process BEFORE this library
+    # is dlopen'ed so that both resolve to the same runtime -- otherwise two runtimes coexist and every launch on a
+    # torch stream fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError('%s not found: build it with `python -m pyprob_amd.build` (hipcc, gfx950). '
                               'pyprob_amd has no CPU fallback.' % LIB_PATH)

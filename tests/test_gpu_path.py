@@ -94,6 +94,22 @@ def test_benchmark_size_gum_against_oracle(H):
         assert rel_err(g[n], out['grads'][n]) < 2e-3 or np.abs(out['grads'][n]).max() < 1e-7, n
 
 
+def test_hidden_1024_against_oracle():
+    """config 5 network (LSTM hidden 1024, 5 636 415 parameters; head hidden 527 -> 3 float4 groups per lane)."""
+    eng = _fresh_engine(1024, ['mu'], 'Normal')
+    assert eng.spec.num_parameters() == 5636415
+    arrays = synthetic_gum_arrays(300, seed=6)
+    pb = _packed(arrays, eng.spec).to(eng.device)
+    l = eng.loss(pb, backward=True)
+    torch.cuda.synchronize()
+    params = {k: v.numpy() for k, v in eng.state_dict().items()}
+    out = _oracle_run(eng.spec, params, arrays, ['mu'], ['Normal'])
+    assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
+    g = eng.grad_dict()
+    for n in eng.spec.tensors:
+        assert rel_err(g[n], out['grads'][n]) < 2e-3 or np.abs(out['grads'][n]).max() < 1e-7, n
+
+
 def test_benchmark_size_gumm_ragged_against_oracle():
     """config 3 shape: GUMM (variable-length traces, one head per address), batch 1024, hidden 512."""
     arrays, addresses = synthetic_gumm_arrays(1024, seed=4, max_iter=6)
