@@ -24,7 +24,7 @@
 namespace pp {
 
 extern long long* g_timeline;   // kernels.hip (debug phase stamps)
-#define GEMM_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && bx == 1 && by == 1 && bz == 0) p.dbg[10 + (k)] = clock64(); } while (0)
+#define GEMM_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (p.dbg && threadIdx.x == 0 && bx == 1 && by == 1 && bz == 0) p.dbg[10 + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 constexpr int BK = 32;
 constexpr int KPAD = 4;
@@ -174,8 +174,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     GEMM_STAMP(0);
-    float* As = smem;
-    float* Bs = smem + BM * (BK + KPAD);
+    constexpr int BUF = (BM + BN) * (BK + KPAD);   // floats per LDS buffer: [A slab | B slab]
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -205,23 +204,31 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
     Stager<BN, B_KM, VEC> sb;
     sa.init(p.A, p.lda, p.a_idx, m0, p.M, p.K, tid);
     sb.init(p.B, p.ldb, p.b_idx, n0, p.N, p.K, tid);
-    auto compute = [&]() {
+    // One K slab: all eight fragment reads (4 sub-slabs x {A, B}) are issued before the first MFMA, so the LDS latency
+    // is paid once per slab instead of once per sub-slab (the MFMAs of a sub-slab depend on its reads).
+    auto compute = [&](const float* As, const float* Bs) {
+        float a[BK / 8][TM][4], b[BK / 8][TN][4];
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
-            float a[TM][4], b[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) read_frag<BM, A_KM>(As, wm * WM + i * 32 + l31, s, h, a[i]);
+            for (int i = 0; i < TM; ++i) read_frag<BM, A_KM>(As, wm * WM + i * 32 + l31, s, h, a[s][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) read_frag<BN, B_KM>(Bs, wn * WN + j * 32 + l31, s, h, b[j]);
+            for (int j = 0; j < TN; ++j) read_frag<BN, B_KM>(Bs, wn * WN + j * 32 + l31, s, h, b[s][j]);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
-        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i][q], b[s][j][q], acc[i][j], 0, 0, 0);
     };
+    // Pipeline: LDS is double buffered (ONE barrier per slab), global loads run two slabs ahead in two register sets.
+    //   iteration i: [store slab i+1 -> other LDS buffer] [issue loads of slab i+2] [MFMAs of slab i] [barrier]
+    float* const buf0 = smem;
+    float* const buf1 = smem + BUF;
     const int kb = s_begin * BK;
     sa.template load<0>(kb);
     sb.template load<0>(kb);
@@ -230,38 +237,65 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
         sb.template load<1>(kb + BK);
     }
     GEMM_STAMP(1);
-    sa.template store<0>(As, tid);
-    sb.template store<0>(Bs, tid);
+    sa.template store<0>(buf0, tid);
+    sb.template store<0>(buf0 + BM * (BK + KPAD), tid);
     __syncthreads();
     GEMM_STAMP(2);
     for (int i = 0; i < nslab; i += 2) {
-        // LDS holds slab i, set 1 holds slab i+1 (in flight), set 0 is free
+        // slab i is in buf0; set 1 holds slab i+1 (in flight); set 0 is free
+        if (i + 1 < nslab) {
+            sa.template store<1>(buf1, tid);
+            sb.template store<1>(buf1 + BM * (BK + KPAD), tid);
+        }
         if (i + 2 < nslab) {
             sa.template load<0>(kb + (i + 2) * BK);
             sb.template load<0>(kb + (i + 2) * BK);
         }
-        compute();
+        compute(buf0, buf0 + BM * (BK + KPAD));
         if (i + 1 >= nslab) break;
         __syncthreads();
-        sa.template store<1>(As, tid);
-        sb.template store<1>(Bs, tid);
-        __syncthreads();
-        // LDS holds slab i+1, set 0 holds slab i+2 (in flight), set 1 is free
+        // slab i+1 is in buf1; set 0 holds slab i+2 (in flight); set 1 is free
+        if (i + 2 < nslab) {
+            sa.template store<0>(buf0, tid);
+            sb.template store<0>(buf0 + BM * (BK + KPAD), tid);
+        }
         if (i + 3 < nslab) {
             sa.template load<1>(kb + (i + 3) * BK);
             sb.template load<1>(kb + (i + 3) * BK);
         }
-        compute();
+        compute(buf1, buf1 + BM * (BK + KPAD));
         if (i + 2 >= nslab) break;
-        __syncthreads();
-        sa.template store<0>(As, tid);
-        sb.template store<0>(Bs, tid);
         __syncthreads();
     }
 
+    if (p.dbg && acc[0][0][0] == 123456.789f) p.dbg[15] = 1;   // debug: the stamp below must follow the last MFMA
     GEMM_STAMP(3);
     // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool lead = bz == 0;
+    // Fast path (the forward products): interior tile, plain store, at most bias + ReLU. No per-element predicates,
+    // one base pointer per 32x32 fragment, 16 stores at constant row strides.
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    if (interior && !split && !p.c_idx && !p.mask && !p.colsum && !p.accumulate) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + wn * WN + j * 32 + l31;
+                float bsum = 0.0f;
+                if (p.bias) bsum += p.bias[gn];
+                if (p.bias2) bsum += p.bias2[gn];
+                float* base = p.C + (int64_t)(m0 + wm * WM + i * 32 + 4 * h) * p.ldc + gn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bsum;
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    base[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v;
+                }
+            }
+        }
+        GEMM_STAMP(4);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -302,7 +336,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * (BK + KPAD)];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + KPAD)];   // double-buffered K slabs
     gemm_tile<BM, BN, WM, WN, A_KM, B_KM, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem);
 }
 
@@ -318,7 +352,7 @@ struct GroupedParams {
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedParams g) {
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * (BK + KPAD)];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + KPAD)];   // double-buffered K slabs
     warm_kernargs((int)sizeof(GroupedParams));
     const int b = blockIdx.x;
     int q = 0;
