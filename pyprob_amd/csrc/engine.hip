@@ -16,6 +16,7 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st);
 int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st);
 struct ColsumJob {
     const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
+    const float* wgt; int64_t ldw; int out_stride;   // optional per-row weight (kernels.hip)
 };
 int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st);
 int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
@@ -53,8 +54,9 @@ extern long long* g_timeline;   // kernels.hip
 bool obs_fused_supported(const pp_net* net);
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
                         float* cat, float* f1, float* E, hipStream_t st);
-int obs_embed_bwd_fused(const pp_net* net, const float* P, float* grads, const float* obs, int n_traces,
-                        float* const* obs_h, const float* cat, const float* f1, const float* dE, hipStream_t st);
+int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
+                          const float* f1, const float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
+                          hipStream_t st);
 
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
@@ -113,7 +115,7 @@ struct Workspace {
     float* dE;                 // [B, e4]
     float* dF1;                // [B, e4]
     float* dCat;               // [B, e4]
-    float* dObsH;              // [B, maxhid4]
+    float* dObsH;              // n_obs x [B, maxhid4] (observable o at dObsH + o * B * maxhid4)
     float* loss_acc;           // [1]
     int32_t* flag;             // [1]
     int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
@@ -155,7 +157,7 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.dE = c.take<float>((int64_t)B * w.e4);
     w.dF1 = c.take<float>((int64_t)B * w.e4);
     w.dCat = c.take<float>((int64_t)B * w.e4);
-    w.dObsH = c.take<float>((int64_t)B * w.maxohid4);
+    w.dObsH = c.take<float>((int64_t)net->n_obs * B * w.maxohid4);
     w.loss_acc = c.take<float>(128);   // one 512-byte region: [64 loss accumulator slots | non-finite flag], one memset
     w.flag = reinterpret_cast<int32_t*>(w.loss_acc ? w.loss_acc + 64 : nullptr);
     w.bytes = c.off + 256;
@@ -388,7 +390,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const int r1 = bt->row_off[1];
         queue_wgrad(wq, w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, R - r1, H, 4 * H);
     }
-    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
+    // (wq is flushed at the very end, together with the observe-embedding weight gradients)
     // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding
     PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, false, st));
     const int c1 = net->e_obs, c2 = c1 + net->smp_dim, c3 = c2 + net->dtype_dim, c4 = c3 + net->addr_dim,
@@ -407,14 +409,42 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         }
     }
     PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+    cs.clear();
     if (T > 1)
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
     // observe embedding backward (dE already carries the ReLU mask of the last layer)
     PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));
     if (obs_fused_supported(net)) {
-        PP_TRY(obs_embed_bwd_fused(net, P, grads, bt->obs, B, w.obs_h, w.cat, w.f1, w.dE, st));
+        // data gradients of the whole stack in one fused launch; weight gradients join the grouped MFMA launch; bias
+        // gradients are column sums of the same buffers
+        const int64_t dhs = (int64_t)B * w.maxohid4;
+        PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, w.dE, w.dF1, w.dCat, w.dObsH, dhs, st));
+        static const bool sep = getenv("PP_OBS_WGRAD_SEPARATE") != nullptr;
+        if (sep) { PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st)); wq.clear(); }
+        const int e = net->e_obs;
+        queue_wgrad(wq, w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, B, e, e);
+        queue_wgrad(wq, w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, B, e, e);
+        cs.push_back(ColsumJob{w.dE, w.e4, nullptr, B, e, grads + net->fin_b1, nullptr});
+        cs.push_back(ColsumJob{w.dF1, w.e4, nullptr, B, e, grads + net->fin_b0, nullptr});
+        int ci = 0, co = 0;
+        for (int o = 0; o < net->n_obs; ++o) {
+            const int in = net->obs_in[o], hid = net->obs_hid[o], out = net->obs_out[o];
+            float* dHo = w.dObsH + (int64_t)o * dhs;
+            queue_wgrad(wq, w.dCat + co, w.e4, w.obs_h[o], w.ohid4[o], nullptr, grads + net->obs_w1[o], B, hid, out);
+            // dW0[:, k] = sum_b dh[b, :] obs[b, k]: a handful of input columns -> weighted column sums, not a GEMM
+            for (int k = 0; k < in; ++k)
+                cs.push_back(ColsumJob{dHo, w.ohid4[o], nullptr, B, hid, grads + net->obs_w0[o] + k, nullptr,
+                                       bt->obs + ci + k, bt->obs_width, in});
+            cs.push_back(ColsumJob{w.dCat + co, w.e4, nullptr, B, out, grads + net->obs_b1[o], nullptr});
+            cs.push_back(ColsumJob{dHo, w.ohid4[o], nullptr, B, hid, grads + net->obs_b0[o], nullptr});
+            ci += in;
+            co += out;
+        }
+        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+        PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
         return 0;
     }
+    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st,

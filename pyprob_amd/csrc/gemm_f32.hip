@@ -38,6 +38,7 @@ struct GemmParams {
     const float* mask; int64_t ldmask;
     float* colsum;   // optional: colsum[n] += sum_m result[m, n] (bias gradients fused into the producing GEMM)
     int relu, accumulate;
+    int vec;         // grouped launch: this problem's operands allow 16-byte loads
     long long* dbg;  // debug phase stamps (NULL normally)
 };
 
@@ -361,7 +362,10 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedPara
     const int bx = l % g.gx[q];
     l /= g.gx[q];
     const int by = l % g.gy[q], bz = l / g.gy[q];
-    gemm_tile<BM, BN, WM, WN, A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], smem);
+    // VEC == 4 instantiation: problems whose leading dimensions / pointers are not 16-byte friendly (e.g. the 2-wide
+    // observation matrix) fall back to scalar staging individually instead of degrading the whole group
+    if (VEC == 4 && !g.p[q].vec) gemm_tile<BM, BN, WM, WN, A_KM, B_KM, 1>(g.p[q], bx, by, bz, g.gz[q], smem);
+    else gemm_tile<BM, BN, WM, WN, A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], smem);
 }
 
 template <int BM, int BN, int WM, int WN, int VEC>
@@ -386,6 +390,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.bias = a->bias; p.bias2 = a->bias2; p.mask = a->mask; p.ldmask = a->ldmask;
     p.relu = a->relu; p.accumulate = a->accumulate;
     p.colsum = a->colsum;
+    p.vec = 1;
     p.dbg = (a->M == 1024 && a->N == 2048) ? g_timeline : nullptr;   // debug: stamp the forward input GEMM only
 }
 
@@ -397,13 +402,26 @@ static bool vec_ok(const pp_gemm_args* a) {
 // workgroup per tile would walk dozens of slabs serially while most CUs idle. Spread the slabs over
 // ~2 workgroups per CU and combine with float atomics (the gradient buffers are zero-initialised accumulators).
 // Only for linear epilogues into a dense or pre-zeroed destination, and only when the caller opts in (split_k).
+static bool split_allowed(const pp_gemm_args* a) {
+    const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
+    const bool linear = !a->relu && !a->mask && !a->colsum;
+    return a->split_k && linear && cdiv(a->K, BK) >= 4 && tiles64 < 384 && (a->accumulate || !a->c_idx);
+}
+
 static int pick_splits(const pp_gemm_args* a, int64_t budget_blocks) {
     const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
     const int nslab = cdiv(a->K, BK);
-    const bool linear = !a->relu && !a->mask && !a->colsum;
-    if (!(a->split_k && linear && nslab >= 4 && tiles64 < 384 && (a->accumulate || !a->c_idx))) return 1;
+    if (!split_allowed(a)) return 1;
     int splits = (int)std::min<int64_t>(std::min<int64_t>((budget_blocks + tiles64 - 1) / tiles64, nslab / 2), 32);
     return std::max(splits, 1);
+}
+
+// Grouped launch: every workgroup should walk about the same number of K slabs, whichever problem it belongs to
+// (an equal per-problem block budget left the largest product un-split and 4x slower than the rest of the group).
+static int pick_splits_by_work(const pp_gemm_args* a, int slabs_per_block) {
+    const int nslab = cdiv(a->K, BK);
+    if (!split_allowed(a)) return 1;
+    return std::max(1, std::min(std::min(cdiv(nslab, slabs_per_block), nslab / 2), 32));
 }
 
 static int zero_for_split(const pp_gemm_args* a, hipStream_t st) {   // partial tiles are added atomically: start from zero
@@ -455,8 +473,18 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
         GroupedParams g;
         g.count = 0;
         g.first[0] = 0;
-        bool vec = true;
         const int akm = args[i].a_kmajor, bkm = args[i].b_kmajor;
+        // slabs each workgroup walks so that the launch has ~target workgroups
+        static const int target = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
+        int64_t work = 0;
+        for (int k = i, c = 0; k < count && c < GROUP_MAX; ++k) {
+            const pp_gemm_args* a = &args[k];
+            if (a->a_kmajor != akm || a->b_kmajor != bkm) break;
+            if (a->M <= 0 || a->N <= 0) continue;
+            work += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) * cdiv(a->K, BK);
+            ++c;
+        }
+        const int spb = (int)std::max<int64_t>(2, (work + target - 1) / target);
         int j = i;
         for (; j < count && g.count < GROUP_MAX; ++j) {
             const pp_gemm_args* a = &args[j];
@@ -465,14 +493,13 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
             if (a->M == 0 || a->N == 0) continue;
             const int q = g.count++;
             fill_params(a, g.p[q]);
-            vec = vec && vec_ok(a);
-            // the group shares the chip: aim for ~1024 workgroups in total
-            const int splits = pick_splits(a, std::max<int64_t>(1024 / std::max(count - i, 1), 64));
+            g.p[q].vec = vec_ok(a) ? 1 : 0;
+            const int splits = pick_splits_by_work(a, spb);
             if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
             g.gx[q] = cdiv(a->N, 64); g.gy[q] = cdiv(a->M, 64); g.gz[q] = splits;
             g.first[q + 1] = g.first[q] + g.gx[q] * g.gy[q] * splits;
         }
-        if (g.count > 0) PP_TRY(vec ? launch_grouped<4>(g, akm, bkm, st) : launch_grouped<1>(g, akm, bkm, st));
+        if (g.count > 0) PP_TRY(launch_grouped<4>(g, akm, bkm, st));
         i = j;
     }
     return 0;

@@ -21,7 +21,8 @@ void set_error(const char* fmt, ...) {
 const char* last_error() { return g_err; }
 
 // ------------------------------------------------------------------------------------------------------
-// out[c] += sum_i X[ix(i)*ldx + c]
+// out[c * out_stride] += sum_i X[ix(i)*ldx + c] * (wgt ? wgt[i * ldw] : 1)
+// (the weighted form is the gradient of a layer with a handful of inputs: dW[:, k] = sum_i dz[i, :] x[i, k])
 // 256 threads = 64 columns x 4 row lanes; each workgroup reduces ROWS_PER_BLOCK rows, one atomic per column.
 // ------------------------------------------------------------------------------------------------------
 constexpr int COLSUM_ROWS = 64;
@@ -29,6 +30,7 @@ constexpr int COLSUM_MAX_JOBS = 16;
 
 struct ColsumJob {
     const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
+    const float* wgt; int64_t ldw; int out_stride;   // optional per-row weight; out_stride 0 = dense
 };
 struct ColsumJobs {
     ColsumJob j[COLSUM_MAX_JOBS];
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs) {
     const float* __restrict__ X = jb.X;
     const int32_t* __restrict__ idx = jb.idx;
     const int64_t ldx = jb.ldx;
+    const float* __restrict__ wgt = jb.wgt;
     float acc = 0.0f;
     if (col < n_cols) {
         // 16 rows per lane, all loads issued before the adds (independent addresses: latency overlaps)
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs) {
             if (i < n_rows) {
                 const int64_t r = idx ? (int64_t)idx[i] : (int64_t)i;
                 v[q] = X[r * ldx + col];
+                if (wgt) v[q] *= wgt[(int64_t)i * jb.ldw];
             }
         }
 #pragma unroll
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs) {
     __syncthreads();
     if (rl == 0 && col < n_cols) {
         const float s = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
-        atomicAdd(jb.out + col, s);
+        atomicAdd(jb.out + (int64_t)col * (jb.out_stride ? jb.out_stride : 1), s);
         if (jb.out2) atomicAdd(jb.out2 + col, s);
     }
 }
@@ -95,7 +99,7 @@ int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st) {
 int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
                hipStream_t st) {
     PP_CHECK_ARG(X && out, "pp_colsum_f32: null pointer");
-    ColsumJob j{X, ldx, idx, n_rows, n_cols, out, out2};
+    ColsumJob j{X, ldx, idx, n_rows, n_cols, out, out2, nullptr, 0, 0};
     return colsum_multi(&j, 1, st);
 }
 

@@ -14,9 +14,6 @@
 
 namespace pp {
 
-extern long long* g_timeline;   // kernels.hip (debug phase stamps)
-#define OBS_STAMP(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[(k)] = clock64(); } while (0)
-
 constexpr int OBS_EMAX = 64;    // lanes
 constexpr int OBS_HIDMAX = 32;  // per-observable hidden width kept in registers
 constexpr int OBS_INMAX = 8;
@@ -184,200 +181,64 @@ __device__ __forceinline__ float obs_dense_t(const float* lds, const ObsLayer& L
     return act ? (s0 + s1) + (s2 + s3) : 0.0f;
 }
 
-// LDS gradient image with FIXED strides (independent of the layer sizes) so that the register rows are written with
-// static indices: [gF1: 64 x 65][gF0: 64 x 65][gW1: 64 x 33][gW0: 64 x 9][biases: 4 x 64]
-constexpr int G_F1 = 0, G_F0 = 64 * 65, G_W1 = 2 * 64 * 65, G_W0 = G_W1 + 64 * 33, G_B = G_W0 + 64 * 9;
-constexpr int G_TOTAL = G_B + 4 * 64;   // 11264 floats
-
-__device__ __forceinline__ void obs_flush_weight(const ObsLayer& L, const float* g, int g_ld, int g_row0,
-                                                 float* __restrict__ grads, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int c = lane; c < L.cols; c += 64) {
-        for (int r0 = wave; r0 < L.rows; r0 += 32) {   // 8 rows per pass: LDS reads batched ahead of the atomics
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = r0 + 4 * u;
-                v[u] = r < L.rows ? g[(g_row0 + r) * g_ld + c] + g[G_TOTAL + (g_row0 + r) * g_ld + c] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = r0 + 4 * u;
-                if (r < L.rows) atomicAdd(grads + L.w_off + (int64_t)r * L.cols + c, v[u]);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void obs_embed_bwd_kernel(const ObsFusedArgs a, const float* __restrict__ P,
-                                                            float* __restrict__ grads, const float* __restrict__ obs,
-                                                            int n_traces, int traces_per_wave,
-                                                            const float* __restrict__ cat, const float* __restrict__ f1,
-                                                            const float* __restrict__ dE, long long* __restrict__ dbg) {
-    __shared__ float lds[10240 + 2 * G_TOTAL];   // weights | gradient image A | gradient image B  (130 KB)
-    OBS_STAMP(0);
+// Backward of the observe embedding, DATA gradients only: per trace (one wave)
+//   dz1 = (Wf1^T dz2) * [f1 > 0],  dzc = (Wf0^T dz1) * [cat > 0],  dh_o = (W1_o^T dzc_o) * [h_o > 0]
+// written to dF1 / dCat / dH_o. The weight gradients (dz^T x over the batch) are MFMA products with K = batch rows and
+// join the grouped weight-gradient launch of the backward pass; the bias gradients are column sums of the same
+// buffers. (A first version accumulated the weight gradients in registers and flushed ~10k atomics per workgroup:
+// 57 us; this split is 3x cheaper.)
+__global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs a, const float* __restrict__ P,
+                                                              int n_traces, int traces_per_wave,
+                                                              const float* __restrict__ cat, const float* __restrict__ f1,
+                                                              const float* __restrict__ dE, float* __restrict__ dF1,
+                                                              float* __restrict__ dCat, float* const dHo0,
+                                                              int64_t dh_stride) {
+    __shared__ float lds[10240];
     warm_kernargs((int)sizeof(ObsFusedArgs) + 96);
-    float* ldsw = lds;
-    float* ldsg = lds + 10240;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // which observable this lane belongs to, as a concat unit and as a hidden unit
-    int oc = -1, jc = 0, oh = -1, jh = 0, cin = 0;
-    {
-        int co = 0, ci = 0;
-        for (int o = 0; o < a.n_obs; ++o) {
-            if (lane >= co && lane < co + a.out[o]) { oc = o; jc = lane - co; }
-            if (lane >= a.hoff[o] && lane < a.hoff[o] + a.hid[o]) { oh = o; jh = lane - a.hoff[o]; cin = ci; }
-            co += a.out[o];
-            ci += a.in[o];
-        }
-    }
+    // which observable this lane belongs to as a hidden unit
+    int oh = -1, jh = 0;
+    for (int o = 0; o < a.n_obs; ++o)
+        if (lane >= a.hoff[o] && lane < a.hoff[o] + a.hid[o]) { oh = o; jh = lane - a.hoff[o]; }
     const bool acte = lane < a.e_obs;
     const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
     // first trace's inputs: issued BEFORE the weight staging so both memory round trips overlap
-    float nx_dz2 = 0.f, nx_f1 = 0.f, nx_cat = 0.f, nx_h = 0.f, nx_obs[OBS_INMAX];
-#pragma unroll
-    for (int i = 0; i < OBS_INMAX; ++i) nx_obs[i] = 0.0f;
+    float nx_dz2 = 0.f, nx_f1 = 0.f, nx_cat = 0.f, nx_h = 0.f;
     if (b0 < n_traces) {   // dE is already masked by E > 0 (obs_grad_kernel)
         nx_dz2 = acte ? dE[(int64_t)b0 * a.e_ld + lane] : 0.0f;
         nx_f1 = acte ? f1[(int64_t)b0 * a.e_ld + lane] : 0.0f;
         nx_cat = acte ? cat[(int64_t)b0 * a.e_ld + lane] : 0.0f;
         nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)b0 * a.ohid_ld[oh] + jh] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < OBS_INMAX; ++i)
-            nx_obs[i] = (oh >= 0 && i < a.in[oh]) ? obs[(int64_t)b0 * a.width + cin + i] : 0.0f;
     }
-    obs_stage_all(a, P, ldsw, tid);
+    obs_stage_all(a, P, lds, tid);
     __syncthreads();
-    OBS_STAMP(1);
-    // per-lane gradient rows kept in registers across this wave's traces
-    float gF1[OBS_EMAX], gF0[OBS_EMAX], gW1[OBS_HIDMAX], gW0[OBS_INMAX];
-    float gbF1 = 0.f, gbF0 = 0.f, gb1 = 0.f, gb0 = 0.f;
-#pragma unroll
-    for (int k = 0; k < OBS_EMAX; ++k) gF1[k] = gF0[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < OBS_HIDMAX; ++k) gW1[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < OBS_INMAX; ++k) gW0[k] = 0.0f;
     for (int t = 0; t < traces_per_wave; ++t) {
         const int b = b0 + t;
         if (b >= n_traces) break;   // wave-uniform
-        // this trace's inputs were prefetched one iteration ahead (nx_*); issue the loads of the next trace now
         const float dz2 = nx_dz2, f1v = nx_f1, catv = nx_cat, hv = nx_h;
-        float obsv[OBS_INMAX];
-#pragma unroll
-        for (int i = 0; i < OBS_INMAX; ++i) obsv[i] = nx_obs[i];
         if (t + 1 < traces_per_wave && b + 1 < n_traces) {
             const int bn = b + 1;
             nx_dz2 = acte ? dE[(int64_t)bn * a.e_ld + lane] : 0.0f;
             nx_f1 = acte ? f1[(int64_t)bn * a.e_ld + lane] : 0.0f;
             nx_cat = acte ? cat[(int64_t)bn * a.e_ld + lane] : 0.0f;
             nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)bn * a.ohid_ld[oh] + jh] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < OBS_INMAX; ++i)
-                nx_obs[i] = (oh >= 0 && i < a.in[oh]) ? obs[(int64_t)bn * a.width + cin + i] : 0.0f;
         }
-        if (t == 0) OBS_STAMP(2);
-        // final layer 1: dW[j][k] += dz2_j * f1_k
-        // (lanes >= e_obs hold zeros, so no guard: 64 straight v_readlane + v_fmac pairs)
-#pragma unroll
-        for (int k = 0; k < OBS_EMAX; ++k) gF1[k] += dz2 * bcast(f1v, k);
-        gbF1 += dz2;
-        if (t == 0) OBS_STAMP(3);
-        float dz1 = obs_dense_t(ldsw, a.f1, lane, acte, dz2, 0);
+        float dz1 = obs_dense_t(lds, a.f1, lane, acte, dz2, 0);
         dz1 = f1v > 0.0f ? dz1 : 0.0f;
-        if (t == 0) OBS_STAMP(4);
-        // final layer 0
-#pragma unroll
-        for (int k = 0; k < OBS_EMAX; ++k) gF0[k] += dz1 * bcast(catv, k);
-        gbF0 += dz1;
-        float dzc = obs_dense_t(ldsw, a.f0, lane, acte, dz1, 0);
+        if (acte) dF1[(int64_t)b * a.e_ld + lane] = dz1;
+        float dzc = obs_dense_t(lds, a.f0, lane, acte, dz1, 0);
         dzc = catv > 0.0f ? dzc : 0.0f;
-        if (t == 0) OBS_STAMP(5);
-        // per-observable layer 1 (lane = concat unit) and layer 0 (lane = hidden unit)
+        if (acte) dCat[(int64_t)b * a.e_ld + lane] = dzc;
         float dh = 0.0f;
         int co = 0;
         for (int o = 0; o < a.n_obs; ++o) {
-            // dW1[jc][k] += dzc * h_k  for the lanes of this observable
-#pragma unroll
-            for (int k = 0; k < OBS_HIDMAX; ++k)
-                if (k < a.hid[o]) {
-                    const float hk = bcast(hv, a.hoff[o] + k);
-                    if (oc == o) gW1[k] += dzc * hk;
-                }
-            // dh_k = sum_j dzc_j W1[j][k]
             const bool acth = (oh == o);
-            const float d = obs_dense_t(ldsw, a.l1[o], jh, acth, dzc, co);
+            const float d = obs_dense_t(lds, a.l1[o], jh, acth, dzc, co);   // dh_k = sum_j dzc_j W1[j][k]
             if (acth) dh = d;
             co += a.out[o];
         }
-        if (oc >= 0) gb1 += dzc;
-        if (oh >= 0) {
-            dh = hv > 0.0f ? dh : 0.0f;
-            gb0 += dh;
-#pragma unroll
-            for (int i = 0; i < OBS_INMAX; ++i)
-                gW0[i] += dh * obsv[i];
-        }
-        if (t == 0) OBS_STAMP(6);
+        if (oh >= 0) dHo0[(int64_t)oh * dh_stride + (int64_t)b * a.ohid_ld[oh] + jh] = hv > 0.0f ? dh : 0.0f;
     }
-    OBS_STAMP(7);
-    // combine the four waves in LDS with static register indices: waves 0/1 STORE their rows into images A/B, then
-    // waves 2/3 add theirs (all reads of a row issued before the adds and the writes); the flush sums A + B.
-    float* img = ldsg + (wave & 1) * G_TOTAL;
-    if (wave < 2) {
-#pragma unroll
-        for (int k = 0; k < OBS_EMAX; ++k) {
-            img[G_F1 + lane * 65 + k] = gF1[k];
-            img[G_F0 + lane * 65 + k] = gF0[k];
-        }
-#pragma unroll
-        for (int k = 0; k < OBS_HIDMAX; ++k) img[G_W1 + lane * 33 + k] = gW1[k];
-#pragma unroll
-        for (int i = 0; i < OBS_INMAX; ++i) img[G_W0 + lane * 9 + i] = gW0[i];
-        img[G_B + lane] = gbF1;
-        img[G_B + 64 + lane] = gbF0;
-        img[G_B + 128 + lane] = gb1;
-        img[G_B + 192 + lane] = gb0;
-    }
-    __syncthreads();
-    if (wave >= 2) {
-        float t1[OBS_EMAX], t0[OBS_EMAX];
-#pragma unroll
-        for (int k = 0; k < OBS_EMAX; ++k) {
-            t1[k] = img[G_F1 + lane * 65 + k];
-            t0[k] = img[G_F0 + lane * 65 + k];
-        }
-#pragma unroll
-        for (int k = 0; k < OBS_EMAX; ++k) {
-            img[G_F1 + lane * 65 + k] = t1[k] + gF1[k];
-            img[G_F0 + lane * 65 + k] = t0[k] + gF0[k];
-        }
-#pragma unroll
-        for (int k = 0; k < OBS_HIDMAX; ++k) img[G_W1 + lane * 33 + k] += gW1[k];
-#pragma unroll
-        for (int i = 0; i < OBS_INMAX; ++i) img[G_W0 + lane * 9 + i] += gW0[i];
-        img[G_B + lane] += gbF1;
-        img[G_B + 64 + lane] += gbF0;
-        img[G_B + 128 + lane] += gb1;
-        img[G_B + 192 + lane] += gb0;
-    }
-    __syncthreads();
-    OBS_STAMP(8);
-    obs_flush_weight(a.f1, ldsg + G_F1, 65, 0, grads, tid);
-    obs_flush_weight(a.f0, ldsg + G_F0, 65, 0, grads, tid);
-    for (int i = tid; i < a.e_obs; i += 256) {
-        atomicAdd(grads + a.f1.b_off + i, ldsg[G_B + i] + ldsg[G_TOTAL + G_B + i]);
-        atomicAdd(grads + a.f0.b_off + i, ldsg[G_B + 64 + i] + ldsg[G_TOTAL + G_B + 64 + i]);
-    }
-    int co = 0;
-    for (int o = 0; o < a.n_obs; ++o) {
-        obs_flush_weight(a.l1[o], ldsg + G_W1, 33, co, grads, tid);            // rows = concat lanes of observable o
-        obs_flush_weight(a.l0[o], ldsg + G_W0, 9, a.hoff[o], grads, tid);      // rows = hidden lanes of observable o
-        for (int i = tid; i < a.out[o]; i += 256) atomicAdd(grads + a.l1[o].b_off + i, ldsg[G_B + 128 + co + i] + ldsg[G_TOTAL + G_B + 128 + co + i]);
-        for (int i = tid; i < a.hid[o]; i += 256) atomicAdd(grads + a.l0[o].b_off + i, ldsg[G_B + 192 + a.hoff[o] + i] + ldsg[G_TOTAL + G_B + 192 + a.hoff[o] + i]);
-        co += a.out[o];
-    }
-    OBS_STAMP(9);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -436,15 +297,16 @@ int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int
     return 0;
 }
 
-int obs_embed_bwd_fused(const pp_net* net, const float* P, float* grads, const float* obs, int n_traces,
-                        float* const* obs_h, const float* cat, const float* f1, const float* dE, hipStream_t st) {
+// dHo: n_obs buffers of [B, round4(hid_o)] laid out `dh_stride` floats apart, starting at dHo0
+int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
+                          const float* f1, const float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
+                          hipStream_t st) {
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
-    // backward: every workgroup ends with ~10k global float atomics (measured ~16 ps each): fewer, longer workgroups
-    const int tpw = pick_traces_per_wave(n_traces, 128);   // A/B on MI355X: 128 workgroups best (0.338 vs 0.348/0.355 ms/step)
-    hipLaunchKernelGGL(obs_embed_bwd_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, grads, obs, n_traces, tpw,
-                       cat, f1, dE, g_timeline);
-    PP_LAUNCH_CHECK("obs_embed_bwd_fused");
+    const int tpw = pick_traces_per_wave(n_traces, 256);
+    hipLaunchKernelGGL(obs_embed_dgrad_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, n_traces, tpw, cat, f1, dE,
+                       dF1, dCat, dHo0, dh_stride);
+    PP_LAUNCH_CHECK("obs_embed_dgrad_fused");
     return 0;
 }
 
