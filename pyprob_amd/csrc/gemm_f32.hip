@@ -39,6 +39,7 @@ struct GemmParams {
     float* colsum;   // optional: colsum[n] += sum_m result[m, n] (bias gradients fused into the producing GEMM)
     int relu, accumulate;
     int vec;         // grouped launch: this problem's operands allow 16-byte loads
+    int vec_c;       // C rows allow 16-byte stores (direct tiles)
     long long* dbg;  // debug phase stamps (NULL normally)
 };
 
@@ -368,6 +369,304 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedPara
     else gemm_tile<BM, BN, WM, WN, A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], smem);
 }
 
+// ---- wave-direct tiles: small, latency-bound products ------------------------------------------------------
+// The LDS-staged tile above needs >= 2 resident workgroups per CU to hide its load -> LDS -> barrier -> MFMA chain; a
+// product with only ~100 64x64 tiles (the proposal-head layers, the data gradients, the weight gradients) leaves most
+// CUs idle and walks its K slabs at ~1.9 us each. Here a workgroup owns a 32x32 output tile and its four waves split
+// the K slabs between them (wave w: slabs w, w+4, ...): operands go global -> registers directly in MFMA operand
+// layout (no LDS staging, no barrier in the K loop, two register sets in flight), the four partial tiles are summed
+// through LDS and the epilogue runs row-contiguous (4 columns per thread). 4x the tiles, 1/4 of the serial chain.
+constexpr int DT = 32;           // direct tile edge
+constexpr int DPAD = DT + 1;     // LDS row stride of the partial tiles
+constexpr int DSTR = 40;         // LDS row stride of a wave-private k-major slab image: 4*DSTR = 32 (mod 64) puts the two
+                                 // half-waves of a fragment read on disjoint banks
+constexpr int DSLAB = BK * DSTR; // floats per wave-private slab image
+
+// One 32-row operand of a wave: fetch() global -> raw registers (16 floats per lane per slab), put() raw -> the wave's
+// private LDS image, frag() image -> MFMA operand registers f[4s + j] = element (row l31, k0 + 8s + 4h + j).
+// Lanes fetch 16-byte segments along the CONTIGUOUS direction of the operand, 8 lanes per 128-byte line (k for a
+// k-contiguous operand, rows for a k-major one), and the image transposes to the fragment layout - wave-local, no
+// workgroup barrier. (Fetching the fragment layout straight from global memory was tried first: 32 lines x 32 bytes
+// per load instruction for k-contiguous operands, sixteen 4-byte loads per slab for k-major ones; the L1/address
+// path became the bottleneck and the long-K products ran 1.6x slower than LDS-staged tiles.)
+//   k-contiguous image: [row][BK+KPAD]  (one ds_read_b128 per sub-slab, conflict free as in the staged kernel)
+//   k-major image:      [k][DSTR]       (ds_read_b32, consecutive rows on consecutive banks)
+template <bool KM, int VEC>
+struct DirectOperand {
+    const float* base[4];   // !KM: row pointer of raw slot i (+ this lane's k offset); KM: base[0] = &P[row0 + rcol]
+    const int32_t* idx;
+    int64_t ld;
+    bool okr[4];            // !KM: raw slot i's row inside the matrix
+    bool ok, ok4;
+    int h, l31, krow, rcol, nleft;
+    float* img;
+
+    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld_, const int32_t* __restrict__ idx_,
+                                         int row0, int nrows, int lane, float* img_) {
+        h = lane >> 5;
+        l31 = lane & 31;
+        krow = lane >> 3;
+        rcol = 4 * (lane & 7);
+        ld = ld_;
+        idx = idx_;
+        img = img_;
+        if (!KM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + krow + 8 * i;
+                okr[i] = row < nrows;
+                const int64_t rr = okr[i] ? (idx ? (int64_t)idx[row] : (int64_t)row) : 0;
+                base[i] = P + rr * ld + rcol;
+            }
+        } else {
+            nleft = nrows - (row0 + rcol);   // rows of this lane's segment inside the matrix
+            ok = nleft > 0;
+            ok4 = nleft >= 4;
+            base[0] = P + row0 + rcol;
+        }
+    }
+
+    __device__ __forceinline__ void fetch(float g[16], int k0, int K) const {
+        if (!KM) {
+            const int kleft = K - (k0 + rcol);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* src = base[i] + k0;
+                if (okr[i] && kleft >= 4) {
+                    if (VEC == 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[4 * i + e] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[4 * i + e] = src[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[4 * i + e] = (okr[i] && e < kleft) ? src[e] : 0.0f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + krow + 8 * i;
+                if (ok && k < K) {
+                    const int64_t kk = idx ? (int64_t)idx[k] : (int64_t)k;
+                    const float* src = base[0] + kk * ld;
+                    if (VEC == 4 && ok4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[4 * i + e] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[4 * i + e] = e < nleft ? src[e] : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[4 * i + e] = 0.0f;
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void put(const float g[16]) const {
+        constexpr int STR = KM ? DSTR : (BK + KPAD);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = g[4 * i + e];
+            *reinterpret_cast<f32x4*>(img + (krow + 8 * i) * STR + rcol) = v;
+        }
+    }
+
+    __device__ __forceinline__ void frag(float f[16]) const {
+        if (!KM) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(img + l31 * (BK + KPAD) + 8 * s + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[4 * s + j] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[4 * s + j] = img[(8 * s + 4 * h + j) * DSTR + l31];
+        }
+    }
+};
+
+template <bool A_KM, bool B_KM>
+constexpr int direct_lds_floats() {
+    constexpr int stage = 2 * 4 * DSLAB;   // A and B images of four waves
+    return stage > 4 * DT * DPAD ? stage : 4 * DT * DPAD;
+}
+
+template <bool A_KM, bool B_KM, int VEC>
+__device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
+                                                 float* red) {
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = by * DT, n0 = bx * DT;
+    const int nslab_total = (p.K + BK - 1) / BK;
+    const int per = (nslab_total + nz - 1) / nz;
+    const int s_begin = bz * per;
+    const int s_end = min(nslab_total, s_begin + per);
+    if (s_end <= s_begin) return;   // workgroup-uniform
+    const bool split = nz > 1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    DirectOperand<A_KM, VEC> oa;
+    DirectOperand<B_KM, VEC> ob;
+    oa.init(p.A, p.lda, p.a_idx, m0, p.M, lane, red + wave * DSLAB);
+    ob.init(p.B, p.ldb, p.b_idx, n0, p.N, lane, red + (4 + wave) * DSLAB);
+    float ga[16], gb[16], a[16], b[16];
+    int s = s_begin + wave;
+    if (s < s_end) {
+        oa.fetch(ga, s * BK, p.K);
+        ob.fetch(gb, s * BK, p.K);
+    }
+    while (s < s_end) {
+        oa.put(ga);
+        ob.put(gb);
+        // wave-private images: order the wave's writes before its reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        oa.frag(a);
+        ob.frag(b);
+        __builtin_amdgcn_wave_barrier();
+        s += 4;
+        if (s < s_end) {   // next slab's loads fly under this slab's MFMAs
+            oa.fetch(ga, s * BK, p.K);
+            ob.fetch(gb, s * BK, p.K);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+    }
+    __syncthreads();   // the partial tiles reuse the staging area
+    // partial tiles -> LDS (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    float* mine = red + wave * DT * DPAD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * DPAD + l31] = acc[r];
+    __syncthreads();
+    // epilogue: thread t owns row t>>3, columns 4*(t&7) .. +3
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    const int gm = m0 + row;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = row * DPAD + c4 + e;
+        v[e] = (red[o] + red[DT * DPAD + o]) + (red[2 * DT * DPAD + o] + red[3 * DT * DPAD + o]);
+    }
+    const bool rowok = gm < p.M;
+    const int64_t cm = rowok ? (p.c_idx ? (int64_t)p.c_idx[gm] : (int64_t)gm) : 0;
+    float* dst = p.C + cm * p.ldc + n0 + c4;
+    const bool lead = bz == 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int gn = n0 + c4 + e;
+        if (gn < p.N && lead) {
+            if (p.bias) v[e] += p.bias[gn];
+            if (p.bias2) v[e] += p.bias2[gn];
+        }
+    }
+    if (split) {
+        if (rowok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n0 + c4 + e < p.N) atomicAdd(dst + e, v[e]);
+        }
+        return;
+    }
+    if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    if (p.mask && rowok) {
+        const float* mk = p.mask + cm * p.ldmask + n0 + c4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + c4 + e < p.N) v[e] = mk[e] > 0.0f ? v[e] : 0.0f;
+    }
+    if (p.colsum) {   // workgroup-uniform: column sums of the finished tile (bias gradients)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[row * DPAD + c4 + e] = (rowok && n0 + c4 + e < p.N) ? v[e] : 0.0f;
+        __syncthreads();
+        if (tid < DT && n0 + tid < p.N) {
+            float cs = 0.0f;
+#pragma unroll 8
+            for (int r = 0; r < DT; ++r) cs += red[r * DPAD + tid];
+            atomicAdd(p.colsum + n0 + tid, cs);
+        }
+    }
+    if (!rowok) return;
+    if (p.vec_c && n0 + c4 + 3 < p.N) {
+        f32x4 o;
+        if (p.accumulate) {
+            o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e];
+        }
+        *reinterpret_cast<f32x4*>(dst) = o;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + c4 + e < p.N) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+    }
+}
+
+template <bool A_KM, bool B_KM, int VEC>
+__global__ __launch_bounds__(256) void gemm_f32_direct_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float red[direct_lds_floats<A_KM, B_KM>()];
+    gemm_tile_direct<A_KM, B_KM, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, red);
+}
+
+template <bool A_KM, bool B_KM, int VEC>
+__global__ __launch_bounds__(256) void gemm_f32_direct_grouped_kernel(const GroupedParams g) {
+    __shared__ __attribute__((aligned(16))) float red[direct_lds_floats<A_KM, B_KM>()];
+    warm_kernargs((int)sizeof(GroupedParams));
+    const int b = blockIdx.x;
+    int q = 0;
+    while (q + 1 < g.count && b >= g.first[q + 1]) ++q;   // workgroup-uniform
+    int l = b - g.first[q];
+    const int bx = l % g.gx[q];
+    l /= g.gx[q];
+    const int by = l % g.gy[q], bz = l / g.gy[q];
+    if (VEC == 4 && !g.p[q].vec) gemm_tile_direct<A_KM, B_KM, 1>(g.p[q], bx, by, bz, g.gz[q], red);
+    else gemm_tile_direct<A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], red);
+}
+
+template <int VEC>
+static int launch_direct(const GemmParams& p, bool akm, bool bkm, int splits, hipStream_t st) {
+    dim3 grid(cdiv(p.N, DT), cdiv(p.M, DT), splits);
+    dim3 block(256);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_direct_kernel<false, false, VEC>), grid, block, 0, st, p);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_direct_kernel<false, true, VEC>), grid, block, 0, st, p);
+    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f32_direct_kernel<true, false, VEC>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_direct_kernel<true, true, VEC>), grid, block, 0, st, p);
+    PP_LAUNCH_CHECK("pp_gemm_f32 (direct)");
+    return 0;
+}
+
+static int launch_direct_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
+    dim3 grid(g.first[g.count]), block(256);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_direct_grouped_kernel<false, false, 4>), grid, block, 0, st, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_direct_grouped_kernel<false, true, 4>), grid, block, 0, st, g);
+    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f32_direct_grouped_kernel<true, false, 4>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_direct_grouped_kernel<true, true, 4>), grid, block, 0, st, g);
+    PP_LAUNCH_CHECK("pp_gemm_f32_grouped (direct)");
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int VEC>
 static int launch_layout(const GemmParams& p, bool akm, bool bkm, int splits, hipStream_t st) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), splits);
@@ -391,6 +690,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.relu = a->relu; p.accumulate = a->accumulate;
     p.colsum = a->colsum;
     p.vec = 1;
+    p.vec_c = (a->ldc % 4 == 0 && aligned16(a->C)) ? 1 : 0;
     p.dbg = (a->M == 1024 && a->N == 2048) ? g_timeline : nullptr;   // debug: stamp the forward input GEMM only
 }
 
@@ -402,6 +702,20 @@ static bool vec_ok(const pp_gemm_args* a) {
 // workgroup per tile would walk dozens of slabs serially while most CUs idle. Spread the slabs over
 // ~2 workgroups per CU and combine with float atomics (the gradient buffers are zero-initialised accumulators).
 // Only for linear epilogues into a dense or pre-zeroed destination, and only when the caller opts in (split_k).
+// Which tile code runs a product (or a group) of `tiles64` 64x64 tiles: the wave-direct 32x32 tiles when the LDS-staged
+// kernel could not put ~2 workgroups on every CU and the K range is short (`slabs` = sum over tiles of their K slabs).
+// PP_GEMM_DIRECT=0/1 forces one of them (A/B measurements).
+static bool use_direct(int64_t tiles64, int64_t slabs) {
+    static const int mode = getenv("PP_GEMM_DIRECT") ? atoi(getenv("PP_GEMM_DIRECT")) : -1;
+    static const int limit = getenv("PP_GEMM_DIRECT_TILES") ? atoi(getenv("PP_GEMM_DIRECT_TILES")) : 384;
+    static const int kmax = getenv("PP_GEMM_DIRECT_SLABS") ? atoi(getenv("PP_GEMM_DIRECT_SLABS")) : 16;
+    if (mode == 0) return false;
+    if (mode == 1) return tiles64 < 4096;
+    // long-K products would need cross-workgroup split-K to occupy the chip; their float atomics cost more than the
+    // shorter chain saves (measured: dX 1024x212x2048 26.6 us staged / split 8, 28-41 us direct)
+    return tiles64 < limit && slabs <= kmax * tiles64;
+}
+
 static bool split_allowed(const pp_gemm_args* a) {
     const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
     const bool linear = !a->relu && !a->mask && !a->colsum;
@@ -444,6 +758,18 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
     // on the 1024x2048x212 input GEMM. Very tall problems (batched IS) use 128x128 tiles.
     const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
     const bool big = tiles64 >= 4096 && a->N >= 128;
+    if (use_direct(tiles64, tiles64 * cdiv(a->K, BK))) {
+        // 32x32 tiles, 4 waves share the K slabs: split further across workgroups only when the tiles alone do not
+        // give every CU a few workgroups
+        const int64_t tiles32 = (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT);
+        const int nslab = cdiv(a->K, BK);
+        int splits = 1;
+        static const int maxsplit = getenv("PP_DIRECT_MAXSPLIT") ? atoi(getenv("PP_DIRECT_MAXSPLIT")) : 16;
+        if (split_allowed(a)) splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv(1024, tiles32), nslab / 8), maxsplit));
+        if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
+        return vec ? launch_direct<4>(p, a->a_kmajor, a->b_kmajor, splits, st)
+                   : launch_direct<1>(p, a->a_kmajor, a->b_kmajor, splits, st);
+    }
     const int splits = big ? 1 : pick_splits(a, 512);
     if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
     if (big) {
@@ -476,15 +802,22 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
         const int akm = args[i].a_kmajor, bkm = args[i].b_kmajor;
         // slabs each workgroup walks so that the launch has ~target workgroups
         static const int target = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
-        int64_t work = 0;
+        static const int target_direct = getenv("PP_GROUP_BLOCKS_DIRECT") ? atoi(getenv("PP_GROUP_BLOCKS_DIRECT")) : 1536;
+        int64_t work = 0, work32 = 0, tiles = 0;
         for (int k = i, c = 0; k < count && c < GROUP_MAX; ++k) {
             const pp_gemm_args* a = &args[k];
             if (a->a_kmajor != akm || a->b_kmajor != bkm) break;
             if (a->M <= 0 || a->N <= 0) continue;
+            tiles += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
             work += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) * cdiv(a->K, BK);
+            work32 += (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT) * cdiv(a->K, BK);
             ++c;
         }
-        const int spb = (int)std::max<int64_t>(2, (work + target - 1) / target);
+        const bool direct = use_direct(tiles, work);
+        // direct tiles: a workgroup's four waves share its slabs, so it should own >= 8 of them
+        const int spb = direct ? (int)std::max<int64_t>(8, (work32 + target_direct - 1) / target_direct)
+                               : (int)std::max<int64_t>(2, (work + target - 1) / target);
+        const int tile = direct ? DT : 64;
         int j = i;
         for (; j < count && g.count < GROUP_MAX; ++j) {
             const pp_gemm_args* a = &args[j];
@@ -494,11 +827,14 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
             const int q = g.count++;
             fill_params(a, g.p[q]);
             g.p[q].vec = vec_ok(a) ? 1 : 0;
-            const int splits = pick_splits_by_work(a, spb);
+            const int splits = direct ? (split_allowed(a) ? std::max(1, std::min(cdiv(cdiv(a->K, BK), spb), 32)) : 1)
+                                      : pick_splits_by_work(a, spb);
             if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
-            g.gx[q] = cdiv(a->N, 64); g.gy[q] = cdiv(a->M, 64); g.gz[q] = splits;
+            g.gx[q] = cdiv(a->N, tile); g.gy[q] = cdiv(a->M, tile); g.gz[q] = splits;
             g.first[q + 1] = g.first[q] + g.gx[q] * g.gy[q] * splits;
         }
+        if (g.count > 0 && direct) PP_TRY(launch_direct_grouped(g, akm, bkm, st));
+        else
         if (g.count > 0) PP_TRY(launch_grouped<4>(g, akm, bkm, st));
         i = j;
     }
