@@ -40,6 +40,7 @@ struct GemmParams {
     int relu, accumulate;
     int vec;         // grouped launch: this problem's operands allow 16-byte loads
     int vec_c;       // C rows allow 16-byte stores (direct tiles)
+    int dbg_plain;   // measurement only: split partials are stored instead of added (WRONG results)
     long long* dbg;  // debug phase stamps (NULL normally)
 };
 
@@ -169,6 +170,74 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ S, int row, 
     }
 }
 
+// Epilogue shared by the LDS-staged and the async tiles. acc[i][j] is the 32x32 MFMA fragment (i, j) of this wave.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], const int m0, const int n0,
+                                              const int wm, const int wn, const int l31, const int h, const int bz,
+                                              const bool split) {
+    // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool lead = bz == 0;
+    // Fast path (the forward products): interior tile, plain store, at most bias + ReLU. No per-element predicates,
+    // one base pointer per 32x32 fragment, 16 stores at constant row strides.
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    if (interior && !split && !p.c_idx && !p.mask && !p.colsum && !p.accumulate) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + wn * WN + j * 32 + l31;
+                float bsum = 0.0f;
+                if (p.bias) bsum += p.bias[gn];
+                if (p.bias2) bsum += p.bias2[gn];
+                float* base = p.C + (int64_t)(m0 + wm * WM + i * 32 + 4 * h) * p.ldc + gn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bsum;
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    base[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wn * WN + j * 32 + l31;
+            const bool ncol = gn < p.N;
+            float bsum = 0.0f;
+            if (ncol && lead) {
+                if (p.bias) bsum += p.bias[gn];
+                if (p.bias2) bsum += p.bias2[gn];
+            }
+            float csum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (!ncol || gm >= p.M) continue;
+                const int64_t cm = p.c_idx ? (int64_t)p.c_idx[gm] : (int64_t)gm;
+                float v = acc[i][j][r] + bsum;
+                float* dst = p.C + cm * p.ldc + gn;
+                if (split) {
+                    if (p.dbg_plain) *dst = v; else
+                    atomicAdd(dst, v);
+                } else {
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (p.mask) v = (p.mask[cm * p.ldmask + gn] > 0.0f) ? v : 0.0f;
+                    csum += v;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+            if (p.colsum && !split) {   // wave-uniform condition
+                csum += __shfl_xor(csum, 32, 64);
+                if (h == 0 && ncol) atomicAdd(p.colsum + gn, csum);
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
                                           float* smem) {
@@ -272,67 +341,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, con
 
     if (p.dbg && acc[0][0][0] == 123456.789f) p.dbg[15] = 1;   // debug: the stamp below must follow the last MFMA
     GEMM_STAMP(3);
-    // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool lead = bz == 0;
-    // Fast path (the forward products): interior tile, plain store, at most bias + ReLU. No per-element predicates,
-    // one base pointer per 32x32 fragment, 16 stores at constant row strides.
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    if (interior && !split && !p.c_idx && !p.mask && !p.colsum && !p.accumulate) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int gn = n0 + wn * WN + j * 32 + l31;
-                float bsum = 0.0f;
-                if (p.bias) bsum += p.bias[gn];
-                if (p.bias2) bsum += p.bias2[gn];
-                float* base = p.C + (int64_t)(m0 + wm * WM + i * 32 + 4 * h) * p.ldc + gn;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + bsum;
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    base[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v;
-                }
-            }
-        }
-        GEMM_STAMP(4);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int gn = n0 + wn * WN + j * 32 + l31;
-            const bool ncol = gn < p.N;
-            float bsum = 0.0f;
-            if (ncol && lead) {
-                if (p.bias) bsum += p.bias[gn];
-                if (p.bias2) bsum += p.bias2[gn];
-            }
-            float csum = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (!ncol || gm >= p.M) continue;
-                const int64_t cm = p.c_idx ? (int64_t)p.c_idx[gm] : (int64_t)gm;
-                float v = acc[i][j][r] + bsum;
-                float* dst = p.C + cm * p.ldc + gn;
-                if (split) {
-                    atomicAdd(dst, v);
-                } else {
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (p.mask) v = (p.mask[cm * p.ldmask + gn] > 0.0f) ? v : 0.0f;
-                    csum += v;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-            if (p.colsum && !split) {   // wave-uniform condition
-                csum += __shfl_xor(csum, 32, 64);
-                if (h == 0 && ncol) atomicAdd(p.colsum + gn, csum);
-            }
-        }
-    }
+    tile_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, l31, h, bz, split);
     GEMM_STAMP(4);
 }
 
@@ -340,6 +349,265 @@ template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + KPAD)];   // double-buffered K slabs
     gemm_tile<BM, BN, WM, WN, A_KM, B_KM, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem);
+}
+
+// ---- async tiles: LDS-DMA software pipeline -------------------------------------------------------------------
+// The register-staged tile keeps ONE slab of loads in flight per workgroup, so a K loop runs at one memory round trip
+// (~1.5 us measured for operands that live in another XCD's L2 / the Infinity Cache) per slab unless several
+// workgroups share the CU. Here the slabs go global -> LDS with global_load_lds_dwordx4 (no VGPR staging) into a ring
+// of AS_STAGES images, three slabs ahead of the MFMAs; one barrier per slab, vmcnt-counted completion.
+//   * image layout is dictated by the DMA (lane L of a wave instruction writes 16 bytes at base + 16 L), so the
+//     bank-conflict padding of the staged tile is replaced by an XOR swizzle applied on the GLOBAL side:
+//       k-contiguous operand: image [64 rows][8 sixteen-byte k slots]; slot p of row r holds k slot p ^ ((r>>1)&7)
+//                             -> the 16 lanes of a ds_read_b128 group (rows r..r+15, same k slot) hit 16 distinct slots
+//       k-major operand:      image [32 k][64 rows]; row r of k sits at r ^ (32 * ((k>>2)&1))
+//                             -> the two half-waves of a fragment read (k and k+4) use disjoint bank halves
+//   * edges: rows beyond the matrix are clamped to a valid row (their results are never stored); pieces beyond K (last
+//     slab only) are fetched from a valid address and zeroed in the fragment registers of that slab.
+//   * the loads are inline asm: the compiler orders every LDS read after all earlier LDS-DMA of the builtin
+//     (s_waitcnt vmcnt(0) at the loop head), which would serialise the ring.
+constexpr int AS_STAGES = 4;
+constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
+constexpr int AS_IMG = 64 * BK;        // floats per operand image
+constexpr int AS_STAGE = 2 * AS_IMG;   // [A image | B image]
+
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+// 64 lanes x 16 bytes: lane L's piece lands at lds_base + 16 L (lds_base wave-uniform)
+__device__ __forceinline__ void dma16(const float* g, uint32_t lds_base) {
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(g) : "memory", "m0");
+}
+
+template <bool KM, int NP>
+struct AsyncOperand {
+    const float* ptr[NP];   // this lane's pieces of slab 0 (chunks NP*wave .. of the image; 8 chunks of 1 KB per image)
+    const float* safe[NP];   // in-bounds stand-in for a piece beyond K
+    int kpiece[NP];          // first k of the piece inside a slab
+    int64_t step;           // floats between consecutive slabs
+    uint32_t chunk;         // byte offset of this wave's first chunk inside an image
+
+    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, const int32_t* __restrict__ idx, int row0,
+                                         int nrows, int k_begin, int wave, int lane) {
+        chunk = (uint32_t)(NP * wave) * 1024u;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = NP * wave + j;
+            if (!KM) {
+                const int r = 8 * c + (lane >> 3);
+                const int kslot = (lane & 7) ^ ((r >> 1) & 7);
+                const int grow = min(row0 + r, nrows - 1);
+                const int64_t rr = idx ? (int64_t)idx[grow] : (int64_t)grow;
+                kpiece[j] = 4 * kslot;
+                safe[j] = P + rr * ld;
+                ptr[j] = safe[j] + k_begin + kpiece[j];
+            } else {
+                const int k = 4 * c + (lane >> 4);
+                const int rs = (lane & 15) ^ (8 * (c & 1));
+                int rowseg = row0 + 4 * rs;
+                if (rowseg >= nrows) rowseg = row0;
+                kpiece[j] = k;
+                safe[j] = P + rowseg;
+                ptr[j] = safe[j] + (int64_t)(k_begin + k) * ld;
+            }
+        }
+        step = KM ? (int64_t)BK * ld : (int64_t)BK;
+    }
+
+    // slab t of this workgroup (first k = k0) -> image at LDS byte address img
+    __device__ __forceinline__ void issue(int t, int k0, int K, uint32_t img) const {
+        const bool tail = k0 + BK > K;   // workgroup-uniform; only the last slab of the product
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const float* g = ptr[j] + (int64_t)t * step;
+            if (tail && k0 + kpiece[j] >= K) g = safe[j];
+            dma16(g, img + chunk + 1024u * j);
+        }
+    }
+
+    __device__ __forceinline__ void issue1(int j, int t, int k0, int K, uint32_t img) const {   // piece j only
+        const bool tail = k0 + BK > K;
+        const float* g = ptr[j] + (int64_t)t * step;
+        if (tail && k0 + kpiece[j] >= K) g = safe[j];
+        dma16(g, img + chunk + 1024u * j);
+    }
+
+    // out[j] = element (row R of the tile, k = 8s + 4h + j) of the image
+    __device__ __forceinline__ void frag(const float* __restrict__ img, int R, int s, int h, float out[4]) const {
+        if (!KM) {
+            const int pos = (2 * s + h) ^ ((R >> 1) & 7);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(img + R * BK + 4 * pos);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = img[(8 * s + 4 * h + j) * 64 + (R ^ (32 * h))];
+        }
+    }
+};
+
+// KW = 1: four waves, one 32x32 fragment each. KW = 2: eight waves; waves w and w+4 share a fragment and split every
+// slab's k range in two (in-workgroup split-K, summed through LDS at the end). A single wave cannot hide its own
+// non-MFMA instructions (DMA issue, fragment reads, barrier: ~1700 cycles per slab against 1024 of MFMA, measured
+// with 1 wave per SIMD); a second wave on the SIMD does, and KW = 2 provides it when the launch has only about one
+// workgroup per CU.
+template <bool A_KM, bool B_KM, int KW>
+__device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
+                                                float* smem) {
+    constexpr int ST = AS_STAGES;
+    constexpr int NP = 2 / KW;        // DMA pieces per thread per operand per slab
+    constexpr int D = 2 * NP;         // DMA instructions per thread per slab
+    constexpr int NS = 4 / KW;        // 8-wide k sub-slabs per wave per slab
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int w4 = wave & 3, kh = wave >> 2;
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int m0 = by * 64, n0 = bx * 64;
+    const int nslab_total = (p.K + BK - 1) / BK;
+    const int per = (nslab_total + nz - 1) / nz;
+    const int s_begin = bz * per;
+    const int T = min(nslab_total, s_begin + per) - s_begin;
+    if (T <= 0) return;
+    const bool split = nz > 1;
+    const int kb = s_begin * BK;
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+
+    AsyncOperand<A_KM, NP> oa;
+    AsyncOperand<B_KM, NP> ob;
+    oa.init(p.A, p.lda, p.a_idx, m0, p.M, kb, wave, lane);
+    ob.init(p.B, p.ldb, p.b_idx, n0, p.N, kb, wave, lane);
+    const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int t) {
+        const uint32_t img = ring + (uint32_t)(t & (ST - 1)) * (AS_STAGE * 4u);
+        oa.issue(t, kb + t * BK, p.K, img);
+        ob.issue(t, kb + t * BK, p.K, img + AS_IMG * 4u);
+    };
+    // fragments of slab t: image -> registers
+    auto load_frags = [&](int t, float (&a)[NS][4], float (&b)[NS][4]) {
+        const float* As = smem + (t & (ST - 1)) * AS_STAGE;
+        const float* Bs = As + AS_IMG;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            oa.frag(As, wm * 32 + l31, kh * NS + s, h, a[s]);
+            ob.frag(Bs, wn * 32 + l31, kh * NS + s, h, b[s]);
+        }
+    };
+    auto mma = [&](const float (&a)[NS][4], const float (&b)[NS][4]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q], b[s][q], acc[0][0], 0, 0, 0);
+    };
+    // drain version: the last slab of the product may be partial - its pieces beyond K hold stand-in data
+    auto mma_edge = [&](int t, float (&a)[NS][4], float (&b)[NS][4]) {
+        const int k0 = kb + t * BK;
+        if (k0 + BK > p.K) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + 8 * (kh * NS + s) + 4 * h + j >= p.K) { a[s][j] = 0.0f; b[s][j] = 0.0f; }
+        }
+        mma(a, b);
+    };
+    // slab t has landed when at most the younger slabs (D DMA instructions each) are outstanding
+    auto wait_younger = [&](int rem) {
+        switch (rem) {
+            case 0: __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); break;
+            case 1: __builtin_amdgcn_s_waitcnt(vmcnt_imm(D)); break;
+            case 2: __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * D)); break;
+            default: __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * D)); break;
+        }
+        __syncthreads();   // every wave's pieces are visible; every wave is done reading the previous image
+    };
+    // Ring of ST images. Steady state of step i: slab i sits in registers, slab i+1 is read from its image while the
+    // MFMAs of slab i run (the reads are independent of the MFMA chain and issue in its shadow), slabs i+2 .. i+ST-1
+    // are in flight, and slab i+ST is started into the image slab i just vacated.
+    static_assert(ST == 4, "ring depth");
+#pragma unroll
+    for (int t = 0; t < ST; ++t)
+        if (t < T) issue(t);
+    float a0[NS][4], b0[NS][4], a1[NS][4], b1[NS][4];
+    wait_younger(min(T - 1, ST - 1));
+    load_frags(0, a0, b0);
+    // One steady-state slab: the MFMAs of the slab in (ca, cb), with the fragment reads of slab tn (-> na, nb) and the
+    // DMA of slab td dealt out one per MFMA (the MFMAs form a dependent chain, 64 cycles each, and the wave issues in
+    // order, so only an instruction placed BETWEEN two MFMAs can run in their shadow).
+    // Measured on workgroup 0, one wave per SIMD, cycles per slab: 1162 MFMAs alone, +35 barrier, +170 fragment reads,
+    // +160 DMA issue = ~1430-1530 against 1024 ideal; dealing the side instructions out one per MFMA instead of the
+    // compiler's clusters, a second accumulator chain, eight waves per tile and an 8-deep ring each moved it < 7 %.
+    // The 32x32 wave tile pays one fragment dword per MFMA; the 64x64 wave tile of the large-M kernel pays a quarter.
+    auto step = [&](int tn, int td, const float (&ca)[NS][4], const float (&cb)[NS][4], float (&na)[NS][4],
+                    float (&nb)[NS][4]) {
+        const float* As = smem + (tn & (ST - 1)) * AS_STAGE;
+        const float* Bs = As + AS_IMG;
+        const bool dma = td < T;
+        const uint32_t img = ring + (uint32_t)(td & (ST - 1)) * (AS_STAGE * 4u);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[s][q], cb[s][q], acc[0][0], 0, 0, 0);
+                const int slot = 4 * s + q;   // side instruction of this MFMA
+                if (slot < NS) oa.frag(As, wm * 32 + l31, kh * NS + slot, h, na[slot]);
+                else if (slot < 2 * NS) ob.frag(Bs, wn * 32 + l31, kh * NS + slot - NS, h, nb[slot - NS]);
+                else if (slot < 2 * NS + NP) { if (dma) oa.issue1(slot - 2 * NS, td, kb + td * BK, p.K, img); }
+                else if (slot < 2 * NS + 2 * NP) { if (dma) ob.issue1(slot - 2 * NS - NP, td, kb + td * BK, p.K, img + AS_IMG * 4u); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    int i = 0;
+    // main loop: two slabs per trip, always ST-2 younger slabs in flight (constant wait counts, no edge handling)
+    for (; i + ST + 1 <= T; i += 2) {
+        if (p.dbg && tid == 0 && bx == 0 && by == 0 && bz == 0 && i < 96) p.dbg[16 + (i >> 1)] = clock64();   // debug
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(D * (ST - 2)));
+        __syncthreads();
+        step(i + 1, i + ST, a0, b0, a1, b1);
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(D * (ST - 2)));
+        __syncthreads();
+        step(i + 2, i + 1 + ST, a1, b1, a0, b0);
+    }
+    // drain: slab i is in (a0, b0), at most ST slabs remain and nothing is left to issue
+    for (; i < T; i += 2) {
+        if (i + 1 < T) {
+            wait_younger(min(T - 2 - i, ST - 2));
+            load_frags(i + 1, a1, b1);
+        }
+        mma_edge(i, a0, b0);
+        if (i + 1 >= T) break;
+        if (i + 2 < T) {
+            wait_younger(min(T - 3 - i, ST - 2));
+            load_frags(i + 2, a0, b0);
+        }
+        mma_edge(i + 1, a1, b1);
+    }
+    if (KW == 2) {   // waves 4..7 hand their partial fragment to waves 0..3
+        __syncthreads();   // the ring is free
+        float* part = smem + w4 * 1024;
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += part[r * 64 + lane];
+    }
+    tile_epilogue<64, 64, 32, 32, 1, 1>(p, acc, m0, n0, wm, wn, l31, h, bz, split);
+}
+
+extern __shared__ __attribute__((aligned(1024))) float as_ring[];   // ST x AS_STAGE floats, sized at launch
+
+template <bool A_KM, bool B_KM, int KW>
+__global__ __launch_bounds__(256 * KW) void gemm_f32_async_kernel(const GemmParams p) {
+    gemm_tile_async<A_KM, B_KM, KW>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, as_ring);
 }
 
 // Several independent products in ONE launch (the weight-gradient leaves of the backward pass, the per-address head
@@ -350,19 +618,41 @@ struct GroupedParams {
     int first[GROUP_MAX + 1];   // first workgroup of problem q; first[count] = total
     int gx[GROUP_MAX], gy[GROUP_MAX], gz[GROUP_MAX];
     int count;
+    int xcd_aware;
 };
+
+// Workgroup -> (problem, tile, K split). Workgroups are dealt round-robin to the 8 XCDs (id % 8) and each XCD has its
+// own L2: all K splits of one output tile are given ids with the same residue so that their float atomics meet in ONE
+// L2 instead of bouncing the line between XCDs. Every problem's workgroup count is a multiple of 8 (tiles padded up;
+// the padding workgroups exit).
+__device__ __forceinline__ bool group_decode(const GroupedParams& g, int b, int& q, int& bx, int& by, int& bz) {
+    q = 0;
+    while (q + 1 < g.count && b >= g.first[q + 1]) ++q;   // workgroup-uniform
+    const int l = b - g.first[q];
+    const int ntiles = g.gx[q] * g.gy[q];
+    int tile;
+    if (g.xcd_aware) {
+        const int r = l >> 3;
+        bz = r % g.gz[q];
+        tile = (r / g.gz[q]) * 8 + (l & 7);
+    } else {
+        tile = l % ntiles;
+        bz = l / ntiles;
+    }
+    if (tile >= ntiles || bz >= g.gz[q]) return false;
+    bx = tile % g.gx[q];
+    by = tile / g.gx[q];
+    return true;
+}
+
+static inline int group_blocks(int gx, int gy, int gz) { return ((gx * gy + 7) / 8) * 8 * gz; }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedParams g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + KPAD)];   // double-buffered K slabs
     warm_kernargs((int)sizeof(GroupedParams));
-    const int b = blockIdx.x;
-    int q = 0;
-    while (q + 1 < g.count && b >= g.first[q + 1]) ++q;   // workgroup-uniform
-    int l = b - g.first[q];
-    const int bx = l % g.gx[q];
-    l /= g.gx[q];
-    const int by = l % g.gy[q], bz = l / g.gy[q];
+    int q, bx, by, bz;
+    if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
     // VEC == 4 instantiation: problems whose leading dimensions / pointers are not 16-byte friendly (e.g. the 2-wide
     // observation matrix) fall back to scalar staging individually instead of degrading the whole group
     if (VEC == 4 && !g.p[q].vec) gemm_tile<BM, BN, WM, WN, A_KM, B_KM, 1>(g.p[q], bx, by, bz, g.gz[q], smem);
@@ -634,13 +924,8 @@ template <bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_direct_grouped_kernel(const GroupedParams g) {
     __shared__ __attribute__((aligned(16))) float red[direct_lds_floats<A_KM, B_KM>()];
     warm_kernargs((int)sizeof(GroupedParams));
-    const int b = blockIdx.x;
-    int q = 0;
-    while (q + 1 < g.count && b >= g.first[q + 1]) ++q;   // workgroup-uniform
-    int l = b - g.first[q];
-    const int bx = l % g.gx[q];
-    l /= g.gx[q];
-    const int by = l % g.gy[q], bz = l / g.gy[q];
+    int q, bx, by, bz;
+    if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
     if (VEC == 4 && !g.p[q].vec) gemm_tile_direct<A_KM, B_KM, 1>(g.p[q], bx, by, bz, g.gz[q], red);
     else gemm_tile_direct<A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], red);
 }
@@ -667,6 +952,76 @@ static int launch_direct_grouped(const GroupedParams& g, bool akm, bool bkm, hip
     return 0;
 }
 
+template <bool A_KM, bool B_KM, int KW>
+__global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_kernel(const GroupedParams g) {
+    warm_kernargs((int)sizeof(GroupedParams));
+    int q, bx, by, bz;
+    if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
+    gemm_tile_async<A_KM, B_KM, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring);
+}
+
+// The ring is dynamic LDS (ST x 16 KB = 64 KB: two workgroups per CU).
+template <typename K>
+static int launch_dyn(K kernel, dim3 grid, int threads, size_t lds, hipStream_t st, const void* arg) {
+    static thread_local const void* configured[64];
+    static thread_local int nconf = 0;
+    bool seen = false;
+    for (int i = 0; i < nconf; ++i) seen = seen || configured[i] == (const void*)kernel;
+    if (!seen) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("pp_gemm_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        if (nconf < 64) configured[nconf++] = (const void*)kernel;
+    }
+    void* args[1] = {const_cast<void*>(arg)};
+    hipError_t e = hipLaunchKernel((const void*)kernel, grid, dim3(threads), args, lds, st);
+    if (e != hipSuccess) {
+        set_error("pp_gemm_f32 (async): launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+template <int KW>
+static int launch_async_kw(const GemmParams& p, bool akm, bool bkm, hipStream_t st) {
+    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), 1);
+    const size_t lds = (size_t)AS_STAGES * AS_STAGE * sizeof(float);
+    if (!akm && !bkm) return launch_dyn(gemm_f32_async_kernel<false, false, KW>, grid, 256 * KW, lds, st, &p);
+    if (!akm && bkm) return launch_dyn(gemm_f32_async_kernel<false, true, KW>, grid, 256 * KW, lds, st, &p);
+    if (akm && !bkm) return launch_dyn(gemm_f32_async_kernel<true, false, KW>, grid, 256 * KW, lds, st, &p);
+    return launch_dyn(gemm_f32_async_kernel<true, true, KW>, grid, 256 * KW, lds, st, &p);
+}
+
+template <int KW>
+static int launch_async_grouped_kw(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
+    dim3 grid(g.first[g.count]);
+    const size_t lds = (size_t)AS_STAGES * AS_STAGE * sizeof(float);
+    if (!akm && !bkm) return launch_dyn(gemm_f32_async_grouped_kernel<false, false, KW>, grid, 256 * KW, lds, st, &g);
+    if (!akm && bkm) return launch_dyn(gemm_f32_async_grouped_kernel<false, true, KW>, grid, 256 * KW, lds, st, &g);
+    if (akm && !bkm) return launch_dyn(gemm_f32_async_grouped_kernel<true, false, KW>, grid, 256 * KW, lds, st, &g);
+    return launch_dyn(gemm_f32_async_grouped_kernel<true, true, KW>, grid, 256 * KW, lds, st, &g);
+}
+
+// eight waves per tile when the launch cannot put four workgroups on every CU anyway
+static bool eight_waves(int64_t blocks) {
+    static const int mode = getenv("PP_GEMM_KW") ? atoi(getenv("PP_GEMM_KW")) : 0;
+    if (mode == 1) return false;
+    if (mode == 2) return true;
+    return blocks <= 512;
+}
+
+static int launch_async(const GemmParams& p, bool akm, bool bkm, hipStream_t st) {
+    const int64_t blocks = (int64_t)cdiv(p.N, 64) * cdiv(p.M, 64);
+    return eight_waves(blocks) ? launch_async_kw<2>(p, akm, bkm, st) : launch_async_kw<1>(p, akm, bkm, st);
+}
+
+static int launch_async_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
+    return eight_waves(g.first[g.count]) ? launch_async_grouped_kw<2>(g, akm, bkm, st)
+                                         : launch_async_grouped_kw<1>(g, akm, bkm, st);
+}
+
 template <int BM, int BN, int WM, int WN, int VEC>
 static int launch_layout(const GemmParams& p, bool akm, bool bkm, int splits, hipStream_t st) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), splits);
@@ -689,13 +1044,25 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.bias = a->bias; p.bias2 = a->bias2; p.mask = a->mask; p.ldmask = a->ldmask;
     p.relu = a->relu; p.accumulate = a->accumulate;
     p.colsum = a->colsum;
+    static const int plain = getenv("PP_DBG_PLAIN_SPLIT") ? atoi(getenv("PP_DBG_PLAIN_SPLIT")) : 0;
+    p.dbg_plain = plain;
     p.vec = 1;
     p.vec_c = (a->ldc % 4 == 0 && aligned16(a->C)) ? 1 : 0;
-    p.dbg = (a->M == 1024 && a->N == 2048) ? g_timeline : nullptr;   // debug: stamp the forward input GEMM only
+    static const int stamp_all = getenv("PP_DBG_STAMP") ? 1 : 0;   // debug: stamp every product (tools/timeline4.py)
+    p.dbg = (stamp_all || (a->M == 1024 && a->N == 2048)) ? g_timeline : nullptr;   // debug: stamp the forward input GEMM only
 }
 
 static bool vec_ok(const pp_gemm_args* a) {
     return (a->lda % 4 == 0) && (a->ldb % 4 == 0) && aligned16(a->A) && aligned16(a->B);
+}
+
+// The async tile needs 16-byte pieces and cannot gather along k (the k-major row pointer would change every slab).
+static bool async_ok(const pp_gemm_args* a) {
+    static const int mode = getenv("PP_GEMM_ASYNC") ? atoi(getenv("PP_GEMM_ASYNC")) : 1;
+    if (!mode || !vec_ok(a) || a->K < 4) return false;
+    if (a->a_kmajor && a->a_idx) return false;
+    if (a->b_kmajor && a->b_idx) return false;
+    return true;
 }
 
 // Split-K: the weight-gradient products have K = rows of the batch and only a handful of output tiles; one
@@ -747,6 +1114,32 @@ static int zero_for_split(const pp_gemm_args* a, hipStream_t st) {   // partial 
     return 0;
 }
 
+template <int VEC>
+static int launch_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
+    dim3 grid(g.first[g.count]), block(256);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, false, false, VEC>), grid, block, 0, st, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, false, true, VEC>), grid, block, 0, st, g);
+    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, true, false, VEC>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, true, true, VEC>), grid, block, 0, st, g);
+    PP_LAUNCH_CHECK("pp_gemm_f32_grouped");
+    return 0;
+}
+
+// A split product as a one-problem group: the grouped kernels own the XCD-aware workgroup -> (tile, split) mapping.
+static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int tile, int splits, int kind, hipStream_t st) {
+    static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
+    GroupedParams g;
+    g.xcd_aware = xcd;
+    g.count = 1;
+    g.p[0] = p;
+    g.p[0].vec = vec ? 1 : 0;
+    g.gx[0] = cdiv(p.N, tile); g.gy[0] = cdiv(p.M, tile); g.gz[0] = splits;
+    g.first[0] = 0;
+    g.first[1] = group_blocks(g.gx[0], g.gy[0], splits);
+    return kind == 1 ? launch_direct_grouped(g, akm, bkm, st)
+         : kind == 2 ? launch_async_grouped(g, akm, bkm, st) : launch_grouped<4>(g, akm, bkm, st);
+}
+
 int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
     PP_CHECK_ARG(a && a->A && a->B && a->C, "pp_gemm_f32: null operand");
     PP_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0, "pp_gemm_f32: negative dimension");
@@ -767,11 +1160,17 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
         static const int maxsplit = getenv("PP_DIRECT_MAXSPLIT") ? atoi(getenv("PP_DIRECT_MAXSPLIT")) : 16;
         if (split_allowed(a)) splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv(1024, tiles32), nslab / 8), maxsplit));
         if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
+        if (splits > 1) return launch_split(p, vec, a->a_kmajor, a->b_kmajor, DT, splits, 1, st);
         return vec ? launch_direct<4>(p, a->a_kmajor, a->b_kmajor, splits, st)
                    : launch_direct<1>(p, a->a_kmajor, a->b_kmajor, splits, st);
     }
-    const int splits = big ? 1 : pick_splits(a, 512);
+    static const int budget = getenv("PP_SPLIT_BUDGET") ? atoi(getenv("PP_SPLIT_BUDGET")) : 256;
+    static const int force = getenv("PP_FORCE_SPLITS") ? atoi(getenv("PP_FORCE_SPLITS")) : 0;
+    const int splits = big ? 1 : (force && split_allowed(a) ? force : pick_splits(a, budget));
     if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
+    const bool as = !big && async_ok(a);
+    if (splits > 1) return launch_split(p, vec, a->a_kmajor, a->b_kmajor, 64, splits, as ? 2 : 0, st);
+    if (as) return launch_async(p, a->a_kmajor, a->b_kmajor, st);
     if (big) {
         return vec ? launch_layout<128, 128, 64, 64, 4>(p, a->a_kmajor, a->b_kmajor, 1, st)
                    : launch_layout<128, 128, 64, 64, 1>(p, a->a_kmajor, a->b_kmajor, 1, st);
@@ -780,23 +1179,14 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
                : launch_layout<64, 64, 32, 32, 1>(p, a->a_kmajor, a->b_kmajor, splits, st);
 }
 
-template <int VEC>
-static int launch_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
-    dim3 grid(g.first[g.count]), block(256);
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, false, false, VEC>), grid, block, 0, st, g);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, false, true, VEC>), grid, block, 0, st, g);
-    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, true, false, VEC>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 32, 32, true, true, VEC>), grid, block, 0, st, g);
-    PP_LAUNCH_CHECK("pp_gemm_f32_grouped");
-    return 0;
-}
-
 // `count` independent products with the same operand layouts in as few launches as possible (GROUP_MAX per launch).
 int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
     PP_CHECK_ARG(count >= 0 && (count == 0 || args), "pp_gemm_f32_grouped: bad argument");
     int i = 0;
     while (i < count) {
         GroupedParams g;
+        static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
+        g.xcd_aware = xcd;
         g.count = 0;
         g.first[0] = 0;
         const int akm = args[i].a_kmajor, bkm = args[i].b_kmajor;
@@ -804,10 +1194,12 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
         static const int target = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
         static const int target_direct = getenv("PP_GROUP_BLOCKS_DIRECT") ? atoi(getenv("PP_GROUP_BLOCKS_DIRECT")) : 1536;
         int64_t work = 0, work32 = 0, tiles = 0;
+        bool as = true;
         for (int k = i, c = 0; k < count && c < GROUP_MAX; ++k) {
             const pp_gemm_args* a = &args[k];
             if (a->a_kmajor != akm || a->b_kmajor != bkm) break;
             if (a->M <= 0 || a->N <= 0) continue;
+            as = as && async_ok(a);
             tiles += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
             work += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) * cdiv(a->K, BK);
             work32 += (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT) * cdiv(a->K, BK);
@@ -831,9 +1223,10 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
                                       : pick_splits_by_work(a, spb);
             if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
             g.gx[q] = cdiv(a->N, tile); g.gy[q] = cdiv(a->M, tile); g.gz[q] = splits;
-            g.first[q + 1] = g.first[q] + g.gx[q] * g.gy[q] * splits;
+            g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits);
         }
         if (g.count > 0 && direct) PP_TRY(launch_direct_grouped(g, akm, bkm, st));
+        else if (g.count > 0 && as) PP_TRY(launch_async_grouped(g, akm, bkm, st));
         else
         if (g.count > 0) PP_TRY(launch_grouped<4>(g, akm, bkm, st));
         i = j;

@@ -1,3 +1,2 @@
 cd /root/repo
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for m in 0 -1; do echo "direct mode $m"; PP_GEMM_DIRECT=$m python bench.py --steps 300 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])";  PP_GEMM_DIRECT=$m python bench.py --workload train_gumm --steps 200 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; PP_GEMM_DIRECT=$m python bench.py --workload is --steps 50 --warmup 5 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; done
+for b in 512 256; do for g in 768 512 384 256; do echo "budget $b group $g"; PP_SPLIT_BUDGET=$b PP_GROUP_BLOCKS=$g python bench.py --steps 300 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; done; done

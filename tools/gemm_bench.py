@@ -31,6 +31,10 @@ def run(M, N, K, akm=0, bkm=0, split=0, iters=50):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'split':
+        run(1024, 212, 2048, 0, 1, 1)
+        run(2048, 212, 1024, 1, 1, 1)
+        sys.exit(0)
     run(1024, 2048, 212)
     run(8192, 2048, 212)
     run(131072, 2048, 212, iters=10)

@@ -9,7 +9,7 @@ obs, mu, prior = bench.synth_gum_dataset(1024 * 8, dev, 1)
 ds = ColumnarDataset(obs, mu, prior, 1024); cache = {}
 b = ds.batch(0, 0, 1, cache)
 for _ in range(20): eng.train_step(b, 1e-3)
-buf = torch.zeros(16, dtype=torch.int64, device=dev)
+buf = torch.zeros(128, dtype=torch.int64, device=dev)
 lib.pp_debug_timeline(buf.data_ptr())
 eng.train_step(b, 1e-3); torch.cuda.synchronize()
 t = buf.tolist()

@@ -8,7 +8,7 @@ eng = bench.make_engine(512, dev, 1)
 obs, mu, prior = bench.synth_gum_dataset(1024 * 8, dev, 1)
 ds = ColumnarDataset(obs, mu, prior, 1024); cache = {}
 b = ds.batch(0, 0, 1, cache)
-buf = torch.zeros(16, dtype=torch.int64, device=dev)
+buf = torch.zeros(128, dtype=torch.int64, device=dev)
 names = ['start', 'staged', 'trace0 loaded', 'gF1', 'dz1', 'gF0+dzc', 'obs layers', 'all traces', 'wave turns', 'flush']
 def show(tag):
     t = buf.tolist()
