@@ -220,7 +220,9 @@ int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream);
 
 /* Wavefront-reduced importance statistics over n particles (pyprob/distributions/empirical.py:298-309,
  * 451-466, 758-766): out (dev, double[6]) = { max lw, sum w, sum w^2, sum w*x, sum w*x^2, count finite } with
- * w = exp(lw - max lw). ESS = (sum w)^2 / sum w^2. Two launches over 64 workgroups; `scratch` dev >= 64 doubles. */
+ * w = exp(lw - max lw). ESS = (sum w)^2 / sum w^2. One pass over the particles (per-workgroup maxima, rescaled by a
+ * one-workgroup combine); `scratch` dev >= PP_IS_STATS_SCRATCH doubles. */
+#define PP_IS_STATS_SCRATCH 1536
 int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -610,6 +610,80 @@ __global__ __launch_bounds__(256 * KW) void gemm_f32_async_kernel(const GemmPara
     gemm_tile_async<A_KM, B_KM, KW>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, as_ring);
 }
 
+// ---- a handful of rows (M <= GEMV_ROWS): one wave per output column ------------------------------------------
+// The first statement of a lock-step importance-sampling run evaluates the LSTM and the proposal head for ONE shared
+// row. A 32x32 MFMA tile would be 97 % padding and still walk the K slabs; here wave w of the launch owns column n,
+// its lanes stride over K with 16-byte loads of W[n, :] (k-contiguous B only), the A rows come from L1/L2, and a DPP
+// reduction finishes the dot products. Epilogue: bias, bias2, ReLU, accumulate.
+constexpr int GEMV_ROWS = 4;
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const GemmParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;   // wave-uniform
+    const int64_t bn = p.b_idx ? (int64_t)p.b_idx[n] : (int64_t)n;
+    const float* __restrict__ w = p.B + bn * p.ldb;
+    float acc[GEMV_ROWS];
+#pragma unroll
+    for (int m = 0; m < GEMV_ROWS; ++m) acc[m] = 0.0f;
+    const float* arow[GEMV_ROWS];
+#pragma unroll
+    for (int m = 0; m < GEMV_ROWS; ++m) {
+        const int mm = m < p.M ? m : 0;
+        arow[m] = p.A + (p.a_idx ? (int64_t)p.a_idx[mm] : (int64_t)mm) * p.lda;
+    }
+    if (VEC == 4) {
+        const int K4 = p.K & ~3;
+        for (int k = lane * 4; k < K4; k += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+            for (int m = 0; m < GEMV_ROWS; ++m) {
+                if (m < p.M) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(arow[m] + k);
+                    acc[m] += av[0] * wv[0] + av[1] * wv[1] + av[2] * wv[2] + av[3] * wv[3];
+                }
+            }
+        }
+        for (int k = K4 + lane; k < p.K; k += 64) {
+#pragma unroll
+            for (int m = 0; m < GEMV_ROWS; ++m)
+                if (m < p.M) acc[m] += arow[m][k] * w[k];
+        }
+    } else {
+        for (int k = lane; k < p.K; k += 64) {
+#pragma unroll
+            for (int m = 0; m < GEMV_ROWS; ++m)
+                if (m < p.M) acc[m] += arow[m][k] * w[k];
+        }
+    }
+    float bsum = 0.0f;
+    if (p.bias) bsum += p.bias[n];
+    if (p.bias2) bsum += p.bias2[n];
+#pragma unroll
+    for (int m = 0; m < GEMV_ROWS; ++m) {
+        if (m >= p.M) break;
+        float v = wave_sum(acc[m]) + bsum;
+        if (lane == 0) {
+            if (p.relu) v = fmaxf(v, 0.0f);
+            float* dst = p.C + (p.c_idx ? (int64_t)p.c_idx[m] : (int64_t)m) * p.ldc + n;
+            *dst = p.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+static bool gemv_ok(const pp_gemm_args* a) {
+    return a->M <= GEMV_ROWS && !a->a_kmajor && !a->b_kmajor && !a->mask && !a->colsum;
+}
+
+static int launch_gemv(const GemmParams& p, bool vec, hipStream_t st) {
+    dim3 grid(cdiv(p.N, 4)), block(256);
+    if (vec) hipLaunchKernelGGL(gemv_rows_kernel<4>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(gemv_rows_kernel<1>, grid, block, 0, st, p);
+    PP_LAUNCH_CHECK("pp_gemm_f32 (gemv)");
+    return 0;
+}
+
 // Several independent products in ONE launch (the weight-gradient leaves of the backward pass, the per-address head
 // products of a ragged batch): workgroup b finds its problem in the prefix table and runs the same tile code.
 constexpr int GROUP_MAX = 16;
@@ -1147,6 +1221,7 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
     GemmParams p;
     fill_params(a, p);
     const bool vec = vec_ok(a);
+    if (gemv_ok(a)) return launch_gemv(p, vec, st);
     // Tile choice: the hot-path GEMMs are small (<= a few thousand rows); 64x64 tiles give >= 2 workgroups per CU
     // on the 1024x2048x212 input GEMM. Very tall problems (batched IS) use 128x128 tiles.
     const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);

@@ -54,6 +54,104 @@ struct Philox {
 };
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
+// First statement of a lock-step run: every particle has the same LSTM state and prior, hence the SAME proposal.
+// The per-component quantities are computed once per workgroup into LDS (thread k owns component k); a particle then
+// costs one Philox block, the draw, and K fused multiply-adds + exps for log q instead of re-deriving softmax, means
+// and scales (10 exp + 30 divisions) itself. Same formulas as is_mixture_kernel below.
+template <int KIND>
+__global__ __launch_bounds__(256) void is_mixture_shared_kernel(const float* __restrict__ y, const float* __restrict__ prior,
+                                                                int n, int K, const float* __restrict__ value_in,
+                                                                float* __restrict__ value_out,
+                                                                float* __restrict__ logq_out, uint64_t seed,
+                                                                uint64_t offset) {
+    __shared__ float s_mu[MAXK], s_sd[MAXK], s_inv[MAXK], s_c[MAXK], s_cum[MAXK], s_ca[MAXK], s_cb[MAXK];
+    const float pa = prior[0], pb = prior[1];
+    if (threadIdx.x < MAXK) {
+        const int k = threadIdx.x;
+        float zmax = -INFINITY;
+        for (int j = 0; j < K; ++j) zmax = fmaxf(zmax, y[2 * K + j]);
+        float zs = 0.0f;
+        for (int j = 0; j < K; ++j) zs += expf(y[2 * K + j] - zmax);
+        float ps = 0.0f, cum = 0.0f;
+        for (int j = 0; j < K; ++j) ps += expf(y[2 * K + j] - zmax) / zs;
+        for (int j = 0; j <= k && j < K; ++j) cum += (expf(y[2 * K + j] - zmax) / zs) / ps;
+        if (k < K) {
+            const float pk = (expf(y[2 * K + k] - zmax) / zs) / ps;
+            float mu, sd;
+            if (KIND == 0) {
+                mu = pa + y[k] * pb;
+                sd = expf(y[K + k]) * pb;
+            } else {
+                const float rng = pb - pa;
+                mu = pa + sigmoidf_(y[k]) * rng;
+                sd = rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
+            }
+            const float lpk = logf(fminf(fmaxf(pk, kFp32Eps), 1.0f - kFp32Eps));
+            s_mu[k] = mu;
+            s_sd[k] = sd;
+            s_inv[k] = 1.0f / sd;
+            s_cum[k] = cum;
+            if (KIND == 0) {
+                s_c[k] = lpk - logf(sd) - kHalfLog2Pi;
+                s_ca[k] = s_cb[k] = 0.0f;
+            } else {
+                const float ca = std_cdf((pa - mu) / sd), cb = std_cdf((pb - mu) / sd);
+                s_ca[k] = ca;
+                s_cb[k] = cb;
+                s_c[k] = lpk - kHalfLog2Pi - logf(sd * (cb - ca));
+            }
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v;
+    if (value_in) {
+        v = value_in[i];
+    } else {
+        Philox rng(seed, offset + (uint64_t)i, 0x1C);
+        v = NAN;
+        for (int attempt = 0; attempt < 64; ++attempt) {
+            uint32_t r[4];
+            rng.next(r);
+            const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
+            int kk = K - 1;   // component index ~ Categorical(p)   (Mixture.sample, distributions/mixture.py:47-63)
+            for (int k = K - 2; k >= 0; --k)
+                if (u0 < s_cum[k]) kk = k;
+            const float mk = s_mu[kk], sk = s_sd[kk];
+            if (KIND == 0) {
+                v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);   // Box-Muller
+                break;
+            } else {
+                const float uu = s_ca[kk] + u1 * (s_cb[kk] - s_ca[kk]);
+                v = mk + sk * kSqrt2 * erfinvf(2.0f * uu - 1.0f);
+                if (isfinite(v) && v >= pa && v < pb) break;
+                v = NAN;
+            }
+        }
+    }
+    // log q(v) = logsumexp_k ( log p_k + log N(v; mu_k, sd_k) [- log Z_k] )   (Mixture.log_prob, mixture.py:42-44)
+    const bool inside = (KIND == 0) || (v >= pa && v <= pb);
+    float a[MAXK], amax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            const float t = (v - s_mu[k]) * s_inv[k];
+            a[k] = inside ? s_c[k] - 0.5f * t * t : -INFINITY;
+            amax = fmaxf(amax, a[k]);
+        }
+    float lp = amax;
+    if (amax > -INFINITY) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) sum += expf(a[k] - amax);
+        lp = amax + logf(sum);
+    }
+    value_out[i] = v;
+    logq_out[i] = lp;
+}
+
 // KIND 0: Normal mixture around a Normal prior; KIND 1: TruncatedNormal mixture inside a Uniform prior.
 template <int KIND>
 __global__ __launch_bounds__(256) void is_mixture_kernel(const float* __restrict__ Y, int64_t ldy, int y_shared,
@@ -328,7 +426,14 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
                            value_out, logq_out, seed, offset);
     } else {
         PP_CHECK_ARG(ad.n_out % 3 == 0 && ad.n_out / 3 <= MAXK, "pp_is_step: at most %d mixture components", MAXK);
-        if (ad.kind == PP_HEAD_NORMAL_MIXTURE)
+        const bool same_proposal = shared && prior_stride == 0;
+        if (same_proposal && ad.kind == PP_HEAD_NORMAL_MIXTURE)
+            hipLaunchKernelGGL(is_mixture_shared_kernel<0>, grid, block, 0, st, w.Y, prior, n, ad.n_out / 3, value_in, value_out,
+                               logq_out, seed, offset);
+        else if (same_proposal)
+            hipLaunchKernelGGL(is_mixture_shared_kernel<1>, grid, block, 0, st, w.Y, prior, n, ad.n_out / 3, value_in, value_out,
+                               logq_out, seed, offset);
+        else if (ad.kind == PP_HEAD_NORMAL_MIXTURE)
             hipLaunchKernelGGL(is_mixture_kernel<0>, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, prior, prior_stride,
                                n, ad.n_out / 3, value_in, value_out, logq_out, seed, offset);
         else
@@ -363,53 +468,90 @@ __global__ __launch_bounds__(256) void axpy_kernel(float scale, const float* __r
     if (i < n) lw[i] += scale * t[i];
 }
 
-// Importance statistics in double, two launches over STAT_BLOCKS workgroups (a single workgroup took > 1 ms for 1M
-// particles): (1) per-workgroup max of the finite log-weights -> scratch; (2) every workgroup folds the partial maxima,
-// accumulates its share of sum w, sum w^2, sum w x, sum w x^2, count with wavefront reductions and adds them with one
-// double atomic per quantity (STAT_BLOCKS-way contention only).
-constexpr int STAT_BLOCKS = 64;
+// Importance statistics, ONE pass over the particles: workgroup b keeps its slice relative to its OWN maximum
+//   m_b = max finite lw,  S_b = (sum e, sum e^2, sum e x, sum e x^2, count),  e = exp(lw - m_b)
+// (fp32 exp of an fp32 difference <= 0, fp64 sums) and a one-workgroup combine rescales the partials to the global
+// maximum: sum w = sum_b S_b[0] exp(m_b - M), sum w^2 = sum_b S_b[1] exp(2 (m_b - M)), ...
+// (two passes over the data with 64 workgroups took 8 + 23 us for 1M particles; a single workgroup > 1 ms).
+constexpr int STAT_BLOCKS = 256;      // scratch: STAT_BLOCKS x 6 doubles (PP_IS_STATS_SCRATCH)
+constexpr int STAT_PER_THREAD = 16;   // particles per thread per tile, held in registers between the two sweeps
 
-__global__ __launch_bounds__(256) void is_stats_max_kernel(const float* __restrict__ lw, int n, double* __restrict__ out,
-                                                           double* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void is_stats_partial_kernel(const float* __restrict__ lw, const float* __restrict__ x,
+                                                               int n, double* __restrict__ scratch) {
     __shared__ float shmax[4];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float m = -INFINITY;
-    for (int i = blockIdx.x * 256 + tid; i < n; i += STAT_BLOCKS * 256) {
-        const float l = lw[i];
-        if (isfinite(l)) m = fmaxf(m, l);
-    }
-    m = wave_max(m);
-    if (lane == 0) shmax[wave] = m;
-    __syncthreads();
-    if (tid == 0) {
-        scratch[blockIdx.x] = (double)fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
-        if (blockIdx.x == 0)
-            for (int q = 0; q < 6; ++q) out[q] = 0.0;   // accumulators of the second launch
-    }
-}
-
-__global__ __launch_bounds__(256) void is_stats_sum_kernel(const float* __restrict__ lw, const float* __restrict__ x, int n,
-                                                           double* __restrict__ out, const double* __restrict__ scratch) {
     __shared__ double sh[4][5];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double gm = -INFINITY;
-    for (int k = 0; k < STAT_BLOCKS; ++k) gm = fmax(gm, scratch[k]);
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * 256 + tid; i < n; i += STAT_BLOCKS * 256) {
-        const float l = lw[i];
-        if (!isfinite(l)) continue;   // Model._traces discards particles with non-finite weight (model.py:65-68)
-        const double wgt = (double)expf((float)((double)l - gm));   // fp32 exp of an fp64 difference, fp64 sums
-        const double xv = x ? (double)x[i] : 0.0;
-        s[0] += wgt; s[1] += wgt * wgt; s[2] += wgt * xv; s[3] += wgt * xv * xv; s[4] += 1.0;
+    const int tile = 256 * STAT_PER_THREAD;
+    double M = -INFINITY;   // running maximum of this workgroup
+    double S[5] = {0, 0, 0, 0, 0};
+    for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile) {
+        float l[STAT_PER_THREAD], xv[STAT_PER_THREAD];
+        float m = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < STAT_PER_THREAD; ++q) {
+            const int i = base + q * 256 + tid;
+            l[q] = i < n ? lw[i] : -INFINITY;
+            xv[q] = (x && i < n) ? x[i] : 0.0f;
+            if (isfinite(l[q])) m = fmaxf(m, l[q]);   // Model._traces drops non-finite weights (model.py:65-68)
+        }
+        m = wave_max(m);
+        if (lane == 0) shmax[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
+        __syncthreads();
+        if (m == -INFINITY) continue;   // workgroup-uniform: no finite weight in this tile
+        if ((double)m > M) {            // rescale what was accumulated so far (workgroup-uniform)
+            const double r = M == -INFINITY ? 0.0 : exp(M - (double)m);
+            S[0] *= r; S[1] *= r * r; S[2] *= r; S[3] *= r;
+            M = (double)m;
+        }
+        const float Mf = (float)M;
+#pragma unroll
+        for (int q = 0; q < STAT_PER_THREAD; ++q) {
+            if (!isfinite(l[q])) continue;
+            const double e = (double)expf(l[q] - Mf), xd = (double)xv[q];
+            S[0] += e; S[1] += e * e; S[2] += e * xd; S[3] += e * xd * xd; S[4] += 1.0;
+        }
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-        const double r = wave_sum(s[q]);
+        const double r = wave_sum(S[q]);
         if (lane == 0) sh[wave][q] = r;
     }
     __syncthreads();
-    if (tid < 5) atomicAdd(out + 1 + tid, sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid]);
-    if (tid == 0 && blockIdx.x == 0) out[0] = gm;
+    if (tid < 5) scratch[blockIdx.x * 6 + 1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    if (tid == 0) scratch[blockIdx.x * 6] = M;
+}
+
+__global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __restrict__ scratch, int nblocks,
+                                                               double* __restrict__ out) {
+    __shared__ double shm[4];
+    __shared__ double sh[4][5];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double m = tid < nblocks ? scratch[tid * 6] : -INFINITY;
+    double gm = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o, 64));
+    if (lane == 0) shm[wave] = gm;
+    __syncthreads();
+    gm = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+    double S[5] = {0, 0, 0, 0, 0};
+    if (tid < nblocks && m > -INFINITY) {
+        const double r = exp(m - gm);
+        S[0] = scratch[tid * 6 + 1] * r;
+        S[1] = scratch[tid * 6 + 2] * r * r;
+        S[2] = scratch[tid * 6 + 3] * r;
+        S[3] = scratch[tid * 6 + 4] * r;
+        S[4] = scratch[tid * 6 + 5];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double r = wave_sum(S[q]);
+        if (lane == 0) sh[wave][q] = r;
+    }
+    __syncthreads();
+    if (tid < 5) out[1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    if (tid == 0) out[0] = gm;
 }
 
 // Several log-weight terms in one pass over the particles (state.py:211-217, 147-149):
@@ -498,12 +640,13 @@ int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream) 
 
 int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream) {
     if (!(lw && out && scratch) || n <= 0) {
-        pp::set_error("pp_is_stats: bad argument (scratch of >= 64 doubles is required)");
+        pp::set_error("pp_is_stats: bad argument (scratch of PP_IS_STATS_SCRATCH doubles is required)");
         return PP_EINVAL;
     }
-    hipLaunchKernelGGL(pp::is_stats_max_kernel, dim3(pp::STAT_BLOCKS), dim3(256), 0, pp::as_stream(stream), lw, n, out, scratch);
-    hipLaunchKernelGGL(pp::is_stats_sum_kernel, dim3(pp::STAT_BLOCKS), dim3(256), 0, pp::as_stream(stream), lw, x, n, out,
-                       scratch);
+    const int tile = 256 * pp::STAT_PER_THREAD;
+    const int blocks = std::min(pp::STAT_BLOCKS, pp::cdiv(n, tile));
+    hipLaunchKernelGGL(pp::is_stats_partial_kernel, dim3(blocks), dim3(256), 0, pp::as_stream(stream), lw, x, n, scratch);
+    hipLaunchKernelGGL(pp::is_stats_combine_kernel, dim3(1), dim3(256), 0, pp::as_stream(stream), scratch, blocks, out);
     PP_LAUNCH_CHECK("pp_is_stats");
     return 0;
 }

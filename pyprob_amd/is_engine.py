@@ -27,7 +27,7 @@ class ISRunner:
         self.offset = 0
         self._consts = {}
         self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
-        self._stats_scratch = torch.zeros(64, dtype=torch.float64, device=self.dev)
+        self._stats_scratch = torch.zeros(L.PP_IS_STATS_SCRATCH, dtype=torch.float64, device=self.dev)
 
     def _const(self, v):
         """1-element device tensor holding v (cached: no allocation / H2D copy in the steady state)."""

@@ -11,6 +11,7 @@ PP_MAX_OBS = 8
 PP_ADDR_TABLE_COLS = 8
 PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL = 0, 1, 2
 PP_LOSS_BACKWARD, PP_LOSS_ZERO_GRADS, PP_LOSS_KEEP_LP = 1, 2, 4
+PP_IS_STATS_SCRATCH = 1536   # doubles (include/pyprob_amd.h)
 
 i32, i64, f32p, i32p, vp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p
 
