@@ -93,6 +93,34 @@ def test_gemm_layouts(env, akm, bkm, shape):
         assert err < 2e-6, (shape, akm, bkm, pad, err)
 
 
+@pytest.mark.parametrize('akm', [False, True])
+@pytest.mark.parametrize('bkm', [False, True])
+@pytest.mark.parametrize('shape', [(512, 200, 1500), (300, 130, 999), (2100, 1100, 600), (64, 70, 4100), (1, 2048, 212),
+                                   (3, 271, 512), (4, 30, 271)])
+def test_gemm_tile_families(env, akm, bkm, shape):
+    """Shapes that route to every tile family of pp_gemm_f32: LDS-DMA ring tiles with four and eight waves (long K,
+    K tails that are not multiples of 32 or of 4), the register-staged fallback (odd leading dimension), the
+    wave-direct 32x32 tiles and the few-row GEMV; with the bias/ReLU/accumulate epilogue and a row gather."""
+    M, N, K = shape
+    rng = np.random.default_rng(M * 11 + N * 5 + K)
+    for pad in (0, 1):
+        a_rows, a_cols = (K, M) if akm else (M, K)
+        b_rows, b_cols = (K, N) if bkm else (N, K)
+        lda = ((a_cols + 3) // 4) * 4 + pad
+        ldb = ((b_cols + 3) // 4) * 4 + pad
+        A = rng.uniform(-1, 1, (a_rows + 7, lda)).astype(np.float32)
+        B = rng.uniform(-1, 1, (b_rows, ldb)).astype(np.float32)
+        a_idx = rng.permutation(a_rows + 7)[:a_rows] if not akm else None   # row gather of a k-contiguous operand
+        bias = rng.uniform(-1, 1, N).astype(np.float32)
+        init = rng.uniform(-1, 1, (M, N + 3)).astype(np.float32)
+        got = run_gemm(env, A, B, M, N, K, akm, bkm, a_idx=a_idx, bias=bias, relu=True)[:, :N]
+        ref = ref_gemm(A, B, M, N, K, akm, bkm, a_idx, None)
+        scale = max(np.abs(ref).max(), 1e-9)
+        assert np.abs(got - np.maximum(ref + bias, 0)).max() / scale < 3e-6, (shape, akm, bkm, pad)
+        got = run_gemm(env, A, B, M, N, K, akm, bkm, a_idx=a_idx, acc_init=init)[:, :N]
+        assert np.abs(got - (ref + init[:, :N])).max() / scale < 3e-6, (shape, akm, bkm, pad)
+
+
 def test_gemm_is_transpose_detecting(env):
     """A = I with an asymmetric B: a swapped C write or operand would show."""
     M = N = K = 64
