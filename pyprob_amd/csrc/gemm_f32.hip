@@ -370,6 +370,8 @@ constexpr int AS_STAGES = 4;
 constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
 constexpr int AS_IMG = 64 * BK;        // floats per operand image
 constexpr int AS_STAGE = 2 * AS_IMG;   // [A image | B image]
+constexpr int AS_KSLABS = 32;          // a workgroup's K range may span this many slabs when an operand gathers along k
+constexpr int AS_KIDX = (AS_KSLABS + 1) * BK;   // ints per staged gather list
 
 __device__ __forceinline__ uint32_t lds_addr(const float* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
@@ -387,10 +389,17 @@ struct AsyncOperand {
     int kpiece[NP];          // first k of the piece inside a slab
     int64_t step;           // floats between consecutive slabs
     uint32_t chunk;         // byte offset of this wave's first chunk inside an image
+    // k gather of a k-major operand (rows of the batch picked by an index list): the workgroup's slice of the list is
+    // staged in LDS once (kidx), the row of slab t+1 is read while slab t is issued
+    const int32_t* kidx;
+    int64_t ldk;
+    int knext[NP];
 
     __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, const int32_t* __restrict__ idx, int row0,
-                                         int nrows, int k_begin, int wave, int lane) {
+                                         int nrows, int k_begin, int wave, int lane, const int32_t* kidx_lds) {
         chunk = (uint32_t)(NP * wave) * 1024u;
+        kidx = (KM && idx) ? kidx_lds : nullptr;
+        ldk = ld;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int c = NP * wave + j;
@@ -410,27 +419,28 @@ struct AsyncOperand {
                 kpiece[j] = k;
                 safe[j] = P + rowseg;
                 ptr[j] = safe[j] + (int64_t)(k_begin + k) * ld;
+                knext[j] = kidx ? kidx[k] : 0;
             }
         }
         step = KM ? (int64_t)BK * ld : (int64_t)BK;
     }
 
-    // slab t of this workgroup (first k = k0) -> image at LDS byte address img
-    __device__ __forceinline__ void issue(int t, int k0, int K, uint32_t img) const {
+    // piece j of slab t of this workgroup (first k = k0) -> image at LDS byte address img; slabs are issued in order
+    __device__ __forceinline__ void issue1(int j, int t, int k0, int K, uint32_t img) {
         const bool tail = k0 + BK > K;   // workgroup-uniform; only the last slab of the product
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const float* g = ptr[j] + (int64_t)t * step;
+        const float* g;
+        if (KM && kidx) {   // workgroup-uniform
+            g = safe[j] + (int64_t)knext[j] * ldk;   // the staged list is clamped to valid rows: no stand-in needed
+            knext[j] = kidx[(t + 1) * BK + kpiece[j]];
+        } else {
+            g = ptr[j] + (int64_t)t * step;
             if (tail && k0 + kpiece[j] >= K) g = safe[j];
-            dma16(g, img + chunk + 1024u * j);
         }
-    }
-
-    __device__ __forceinline__ void issue1(int j, int t, int k0, int K, uint32_t img) const {   // piece j only
-        const bool tail = k0 + BK > K;
-        const float* g = ptr[j] + (int64_t)t * step;
-        if (tail && k0 + kpiece[j] >= K) g = safe[j];
         dma16(g, img + chunk + 1024u * j);
+    }
+    __device__ __forceinline__ void issue(int t, int k0, int K, uint32_t img) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue1(j, t, k0, K, img);
     }
 
     // out[j] = element (row R of the tile, k = 8s + 4h + j) of the image
@@ -477,10 +487,21 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
 
+    // k-gather lists of this workgroup's K range, clamped to the last valid entry, one extra slab of padding
+    int32_t* kia = reinterpret_cast<int32_t*>(smem + ST * AS_STAGE);
+    int32_t* kib = kia + AS_KIDX;
+    if ((A_KM && p.a_idx) || (B_KM && p.b_idx)) {   // workgroup-uniform
+        for (int e = tid; e < (T + 1) * BK; e += 256 * KW) {
+            const int k = min(kb + e, p.K - 1);
+            if (A_KM && p.a_idx) kia[e] = p.a_idx[k];
+            if (B_KM && p.b_idx) kib[e] = p.b_idx[k];
+        }
+        __syncthreads();
+    }
     AsyncOperand<A_KM, NP> oa;
     AsyncOperand<B_KM, NP> ob;
-    oa.init(p.A, p.lda, p.a_idx, m0, p.M, kb, wave, lane);
-    ob.init(p.B, p.ldb, p.b_idx, n0, p.N, kb, wave, lane);
+    oa.init(p.A, p.lda, p.a_idx, m0, p.M, kb, wave, lane, kia);
+    ob.init(p.B, p.ldb, p.b_idx, n0, p.N, kb, wave, lane, kib);
     const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue = [&](int t) {
         const uint32_t img = ring + (uint32_t)(t & (ST - 1)) * (AS_STAGE * 4u);
@@ -1058,10 +1079,12 @@ static int launch_dyn(K kernel, dim3 grid, int threads, size_t lds, hipStream_t 
     return 0;
 }
 
+static size_t as_lds_bytes() { return (size_t)AS_STAGES * AS_STAGE * sizeof(float) + 2 * AS_KIDX * sizeof(int32_t); }
+
 template <int KW>
 static int launch_async_kw(const GemmParams& p, bool akm, bool bkm, hipStream_t st) {
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), 1);
-    const size_t lds = (size_t)AS_STAGES * AS_STAGE * sizeof(float);
+    const size_t lds = as_lds_bytes();
     if (!akm && !bkm) return launch_dyn(gemm_f32_async_kernel<false, false, KW>, grid, 256 * KW, lds, st, &p);
     if (!akm && bkm) return launch_dyn(gemm_f32_async_kernel<false, true, KW>, grid, 256 * KW, lds, st, &p);
     if (akm && !bkm) return launch_dyn(gemm_f32_async_kernel<true, false, KW>, grid, 256 * KW, lds, st, &p);
@@ -1071,7 +1094,7 @@ static int launch_async_kw(const GemmParams& p, bool akm, bool bkm, hipStream_t 
 template <int KW>
 static int launch_async_grouped_kw(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
     dim3 grid(g.first[g.count]);
-    const size_t lds = (size_t)AS_STAGES * AS_STAGE * sizeof(float);
+    const size_t lds = as_lds_bytes();
     if (!akm && !bkm) return launch_dyn(gemm_f32_async_grouped_kernel<false, false, KW>, grid, 256 * KW, lds, st, &g);
     if (!akm && bkm) return launch_dyn(gemm_f32_async_grouped_kernel<false, true, KW>, grid, 256 * KW, lds, st, &g);
     if (akm && !bkm) return launch_dyn(gemm_f32_async_grouped_kernel<true, false, KW>, grid, 256 * KW, lds, st, &g);
@@ -1133,10 +1156,14 @@ static bool vec_ok(const pp_gemm_args* a) {
 // The async tile needs 16-byte pieces and cannot gather along k (the k-major row pointer would change every slab).
 static bool async_ok(const pp_gemm_args* a) {
     static const int mode = getenv("PP_GEMM_ASYNC") ? atoi(getenv("PP_GEMM_ASYNC")) : 1;
-    if (!mode || !vec_ok(a) || a->K < 4) return false;
-    if (a->a_kmajor && a->a_idx) return false;
-    if (a->b_kmajor && a->b_idx) return false;
-    return true;
+    return mode && vec_ok(a) && a->K >= 4;
+}
+// a k-major operand that gathers along k stages its index list in LDS: the workgroup's K range must fit
+static bool async_split_ok(const pp_gemm_args* a, int splits) {
+    static const int allow = getenv("PP_ASYNC_KGATHER") ? atoi(getenv("PP_ASYNC_KGATHER")) : 1;
+    const bool kgather = (a->a_kmajor && a->a_idx) || (a->b_kmajor && a->b_idx);
+    if (kgather && !allow) return false;
+    return !kgather || cdiv(cdiv(a->K, BK), splits) <= AS_KSLABS;
 }
 
 // Split-K: the weight-gradient products have K = rows of the batch and only a handful of output tiles; one
@@ -1243,7 +1270,7 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
     static const int force = getenv("PP_FORCE_SPLITS") ? atoi(getenv("PP_FORCE_SPLITS")) : 0;
     const int splits = big ? 1 : (force && split_allowed(a) ? force : pick_splits(a, budget));
     if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
-    const bool as = !big && async_ok(a);
+    const bool as = !big && async_ok(a) && async_split_ok(a, splits);
     if (splits > 1) return launch_split(p, vec, a->a_kmajor, a->b_kmajor, 64, splits, as ? 2 : 0, st);
     if (as) return launch_async(p, a->a_kmajor, a->b_kmajor, st);
     if (big) {
@@ -1266,7 +1293,8 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
         g.first[0] = 0;
         const int akm = args[i].a_kmajor, bkm = args[i].b_kmajor;
         // slabs each workgroup walks so that the launch has ~target workgroups
-        static const int target = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
+        static const int target_staged = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
+        static const int target_async = getenv("PP_GROUP_BLOCKS_ASYNC") ? atoi(getenv("PP_GROUP_BLOCKS_ASYNC")) : 320;
         static const int target_direct = getenv("PP_GROUP_BLOCKS_DIRECT") ? atoi(getenv("PP_GROUP_BLOCKS_DIRECT")) : 1536;
         int64_t work = 0, work32 = 0, tiles = 0;
         bool as = true;
@@ -1281,6 +1309,8 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
             ++c;
         }
         const bool direct = use_direct(tiles, work);
+        // the async tiles stream a long K range at full rate, so they want fewer, longer workgroups (fewer atomics)
+        const int target = as ? target_async : target_staged;
         // direct tiles: a workgroup's four waves share its slabs, so it should own >= 8 of them
         const int spb = direct ? (int)std::max<int64_t>(8, (work32 + target_direct - 1) / target_direct)
                                : (int)std::max<int64_t>(2, (work + target - 1) / target);
@@ -1297,6 +1327,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
             const int splits = direct ? (split_allowed(a) ? std::max(1, std::min(cdiv(cdiv(a->K, BK), spb), 32)) : 1)
                                       : pick_splits_by_work(a, spb);
             if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
+            as = as && async_split_ok(a, splits);
             g.gx[q] = cdiv(a->N, tile); g.gy[q] = cdiv(a->M, tile); g.gz[q] = splits;
             g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits);
         }
