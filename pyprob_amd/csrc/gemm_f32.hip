@@ -1156,7 +1156,7 @@ static bool vec_ok(const pp_gemm_args* a) {
 // The async tile needs 16-byte pieces and cannot gather along k (the k-major row pointer would change every slab).
 static bool async_ok(const pp_gemm_args* a) {
     static const int mode = getenv("PP_GEMM_ASYNC") ? atoi(getenv("PP_GEMM_ASYNC")) : 1;
-    return mode && vec_ok(a) && a->K >= 4;
+    return mode && vec_ok(a) && a->K >= 1;
 }
 // a k-major operand that gathers along k stages its index list in LDS: the workgroup's K range must fit
 static bool async_split_ok(const pp_gemm_args* a, int splits) {
@@ -1302,6 +1302,10 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
             const pp_gemm_args* a = &args[k];
             if (a->a_kmajor != akm || a->b_kmajor != bkm) break;
             if (a->M <= 0 || a->N <= 0) continue;
+            static const int trace = getenv("PP_GEMM_TRACE") ? 1 : 0;
+            if (trace && !async_ok(a))
+                fprintf(stderr, "[pp_gemm] group problem not async: M=%d N=%d K=%d lda=%lld ldb=%lld A%%16=%d B%%16=%d\n", a->M, a->N,
+                        a->K, (long long)a->lda, (long long)a->ldb, (int)((uintptr_t)a->A & 15), (int)((uintptr_t)a->B & 15));
             as = as && async_ok(a);
             tiles += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
             work += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) * cdiv(a->K, BK);
@@ -1324,8 +1328,11 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
             const int q = g.count++;
             fill_params(a, g.p[q]);
             g.p[q].vec = vec_ok(a) ? 1 : 0;
-            const int splits = direct ? (split_allowed(a) ? std::max(1, std::min(cdiv(cdiv(a->K, BK), spb), 32)) : 1)
-                                      : pick_splits_by_work(a, spb);
+            int splits = direct ? (split_allowed(a) ? std::max(1, std::min(cdiv(cdiv(a->K, BK), spb), 32)) : 1)
+                                : pick_splits_by_work(a, spb);
+            // a gathered k range must fit the LDS index list of the async tile
+            if (as && !direct && split_allowed(a) && !async_split_ok(a, splits))
+                splits = std::min(cdiv(cdiv(a->K, BK), AS_KSLABS), 32);
             if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
             as = as && async_split_ok(a, splits);
             g.gx[q] = cdiv(a->N, tile); g.gy[q] = cdiv(a->M, tile); g.gz[q] = splits;

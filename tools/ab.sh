@@ -1,4 +1,4 @@
 cd /root/repo
-for g in 128 192 256 320; do echo "async group blocks $g"; PP_GROUP_BLOCKS_ASYNC=$g python bench.py --steps 300 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; PP_GROUP_BLOCKS_ASYNC=$g python bench.py --workload train_gumm --steps 200 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; done
-echo staged; PP_ASYNC_KGATHER=0 python bench.py --steps 300 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
-PP_ASYNC_KGATHER=0 python bench.py --workload train_gumm --steps 200 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for m in 0 1; do PP_ASYNC_KGATHER=$m python bench.py --workload train_gumm --steps 200 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; done
+PP_GEMM_TRACE=1 python bench.py --workload train_gumm --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep pp_gemm | sort | uniq -c | head
