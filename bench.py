@@ -177,47 +177,58 @@ def main():
         for i in range(W):
             step(i)
         if not args.graph:
-            lib.pp_prof_arm(0, K)
+            lib.pp_prof_arm(1, K)      # kernel class 1: the grouped weight-gradient launch, the longest kernel of the step
         barrier()
         t0 = time.perf_counter()
         for i in range(K):
             step(W + i)
         barrier()
         dt = time.perf_counter() - t0
-        ms = np.zeros(K, np.float32)
-        fl = np.zeros(K, np.float64)
-        cnt = C.c_int32(0)
-        if args.graph:
-            # HIP events cannot be recorded inside a captured graph: time the dominant kernel on the same stream in a
+
+        def collect(which, n):
+            ms = np.zeros(n, np.float32)
+            fl = np.zeros(n, np.float64)
+            cnt = C.c_int32(0)
+            lib.pp_prof_collect(ms.ctypes.data, n, C.byref(cnt), fl.ctypes.data)
+            lib.pp_prof_arm(which, 0)
+            return (float(ms[:cnt.value].mean()), float(fl[0]), int(cnt.value)) if cnt.value > 0 else None
+
+        def eager_pass(which, n):
+            # HIP events cannot be recorded inside a captured graph, and only one kernel class is timed at a time: a
             # short eager pass of the same step right after the timed region (same kernels, same shapes).
-            nroof = min(K, 50)
-            batches = [ds.batch(i, 0, 1, cache) for i in range(min(ds.n_batches, nroof))]
-            lib.pp_prof_arm(0, nroof)
-            for i in range(nroof):
-                eng.train_step(batches[i % len(batches)], lr)
+            bl = [ds.batch(i, 0, 1, cache) for i in range(min(ds.n_batches, n))]
+            lib.pp_prof_arm(which, n)
+            for i in range(n):
+                eng.train_step(bl[i % len(bl)], lr)
             torch.cuda.synchronize()
-        lib.pp_prof_collect(ms.ctypes.data, K, C.byref(cnt), fl.ctypes.data)
-        lib.pp_prof_arm(0, 0)
+            return collect(which, n)
+
+        dominant = eager_pass(1, min(K, 50)) if args.graph else collect(1, K)
+        second = eager_pass(0, min(K, 50))
         final_loss = float(eng.loss_buf[0].item())
         units = B * K
         metric, unit = 'ic_train_traces_per_sec', 'traces/s'
-        if cnt.value > 0:
-            avg_ms = float(ms[:cnt.value].mean())
-            ach = float(fl[0]) / (avg_ms * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from the committed PMC passes (rocprof cannot run inside bench.py)
-            try:
-                with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as f:
-                    pmc = json.load(f)
-                if B == 1024 and args.lstm_dim == 512:
-                    traffic = pmc['traffic_bytes_per_launch']
-            except (OSError, KeyError, ValueError):
-                pass
-            out['roofline'] = dict(bound='mfma', achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
-                                   frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic,
-                                   kernel='gemm_f32_kernel<64,64,32,32,NT,vec4> (forward X*W_ih^T, %dx%dx%d)'
-                                          % (B, 4 * args.lstm_dim, eng.spec.lstm_in),
-                                   avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=int(cnt.value),
-                                   flops_per_launch=float(fl[0]))
+        pmc = {}
+        try:   # HBM bytes per launch from the committed PMC passes (rocprof cannot run inside bench.py)
+            with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as f:
+                pmc = json.load(f)['kernels'] if (B == 1024 and args.lstm_dim == 512) else {}
+        except (OSError, KeyError, ValueError):
+            pass
+
+        def roof(sample, key, label):
+            avg_ms, flops, n = sample
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            return dict(bound='mfma', achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=pmc.get(key, {}).get('traffic_bytes_per_launch'),
+                        algorithmic_bytes=pmc.get(key, {}).get('algorithmic_bytes_per_launch'), kernel=label,
+                        avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=n, flops_per_launch=flops)
+        if dominant:
+            out['roofline'] = roof(dominant, 'wgrad_group',
+                                   'gemm_f32_async_grouped_kernel<TN> (weight-gradient group of the backward pass: dW_ih '
+                                   '%dx%dx%d + head and observe-embedding leaves, one launch)' % (4 * args.lstm_dim, eng.spec.lstm_in, B))
+            if second:
+                out['roofline']['second_kernel'] = roof(second, 'input_gemm', 'gemm_f32_async_kernel<NT> (forward X*W_ih^T, '
+                                                        '%dx%dx%d)' % (B, 4 * args.lstm_dim, eng.spec.lstm_in))
         config = dict(workload='GaussianUnknownMean IC training, offline traces resident in HBM, LSTM hidden=%d, '
                                'batch=%d per GPU' % (args.lstm_dim, B),
                       traces_in_hbm=per_rank * world, params=eng.spec.num_parameters(), global_batch=B * world,

@@ -283,7 +283,8 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
 
 /* ------------------------------------------------------------------------------------------------------
  * In-stream kernel timing for bench.py's roofline leg: when armed, pp_ic_loss records a hipEvent pair
- * around the kernel class `which` (0: forward input GEMM X*W_ih^T) on its stream, once per call.
+ * around the kernel class `which` (0: forward input GEMM X*W_ih^T; 1: the grouped weight-gradient launch of the
+ * backward pass) on its stream, once per call.
  * ---------------------------------------------------------------------------------------------------- */
 int pp_prof_arm(int32_t which, int32_t max_samples);          /* allocate event pairs; 0 disarms */
 int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_out); /* syncs the events */

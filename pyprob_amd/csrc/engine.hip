@@ -187,6 +187,16 @@ static int linear_fwd(const float* x, int64_t ldx, const int32_t* x_idx, const f
 
 // dW[out, in] += dz^T x  (dz [n, out] (lddz), x [n, in] (ldx, optional k-gather x_idx)): queued; all weight-gradient
 // products of a backward pass are leaves of the dependency graph and run as one grouped launch (gemm_f32_grouped)
+// the weight-gradient leaves of the backward pass, one grouped launch (timed as kernel class 1 when armed)
+static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st) {
+    double flops = 0.0;
+    for (const auto& g : wq) flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+    prof_begin(1, st);
+    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
+    prof_end(1, flops, st);
+    return 0;
+}
+
 static void queue_wgrad(std::vector<pp_gemm_args>& q, const float* dz, int64_t lddz, const float* x, int64_t ldx,
                         const int32_t* x_idx, float* dW, int n, int in, int out) {
     pp_gemm_args g{};
@@ -419,8 +429,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         // gradients are column sums of the same buffers
         const int64_t dhs = (int64_t)B * w.maxohid4;
         PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, w.dE, w.dF1, w.dCat, w.dObsH, dhs, st));
-        static const bool sep = getenv("PP_OBS_WGRAD_SEPARATE") != nullptr;
-        if (sep) { PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st)); wq.clear(); }
         const int e = net->e_obs;
         queue_wgrad(wq, w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, B, e, e);
         queue_wgrad(wq, w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, B, e, e);
@@ -441,10 +449,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             co += out;
         }
         PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-        PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
+        PP_TRY(launch_wgrads(wq, st));
         return 0;
     }
-    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
+    PP_TRY(launch_wgrads(wq, st));
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st,
