@@ -296,7 +296,7 @@ def main():
         ach = units * bytes_per_particle / dt / 1e9
         out['roofline'] = dict(bound='hbm', achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s',
                                frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                               kernel='is_mixture_kernel<0> + logweight_multi_kernel + is_stats_{max,sum}_kernel (whole '
+                               kernel='is_mixture_shared_kernel<0> + logweight_multi_kernel + is_stats_partial_kernel (whole '
                                       'posterior call incl. the batch-1 network evaluation, wall-clock; the sampling kernel '
                                       'is transcendental-bound, see profiles/)')
         config = dict(workload='GaussianUnknownMean posterior_results IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, '
