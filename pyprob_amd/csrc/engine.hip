@@ -23,7 +23,8 @@ int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int 
                hipStream_t st);
 int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
                       const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
-                      int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st);
+                      int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st, float* zero_like = nullptr,
+                      float* zero_small = nullptr, int n_small = 0);
 int sample_embed_bwd(const pp_net* net, const float* params, const float* value, const int32_t* addr,
                      const int32_t* prev_row, int row_begin, int n_rows, const float* dX, int64_t ldx, float* grads,
                      hipStream_t st);
@@ -271,12 +272,13 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         set_error("pp_ic_loss: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
         return PP_ENOSPACE;
     }
-    (void)hipMemsetAsync(w.loss_acc, 0, 512, st);
     if (bwd && (flags & PP_LOSS_ZERO_GRADS)) (void)hipMemsetAsync(grads, 0, (size_t)net->n_params * sizeof(float), st);
 
     // ---------------- forward ----------------
     PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
-    PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st));
+    // (also clears the loss slots and, for a backward pass, dX: see the kernel)
+    PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
+                             bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), 128));
     prof_begin(0, st);
     PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st));
     prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
@@ -352,8 +354,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
     if (!bwd) return 0;
-    PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-    cs.clear();
+    // (the bias / table column sums queued in `cs` are launched once, at the end of the backward pass)
 
     // ---------------- backward ----------------
     std::vector<pp_gemm_args> wq;   // weight-gradient leaves, flushed as one grouped launch once dG is complete
@@ -402,7 +403,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     // (wq is flushed at the very end, together with the observe-embedding weight gradients)
     // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding
-    PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, false, st));
+    PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, true, st));   // dX was cleared by the gather kernel
     const int c1 = net->e_obs, c2 = c1 + net->smp_dim, c3 = c2 + net->dtype_dim, c4 = c3 + net->addr_dim,
               c5 = c4 + net->dtype_dim;
     for (int a = 0; a < net->n_addr; ++a) {
@@ -418,8 +419,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             cs.push_back(ColsumJob{w.dX + c3, w.i4, bt->nxt_rows + q0, m, net->addr_dim, grads + ad.addr_emb, nullptr});
         }
     }
-    PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-    cs.clear();
     if (T > 1)
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
     // observe embedding backward (dE already carries the ReLU mask of the last layer)
@@ -452,6 +451,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(launch_wgrads(wq, st));
         return 0;
     }
+    PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
     PP_TRY(launch_wgrads(wq, st));
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
