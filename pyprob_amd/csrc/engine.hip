@@ -56,7 +56,8 @@ bool obs_fused_supported(const pp_net* net);
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
                         float* cat, float* f1, float* E, hipStream_t st);
 int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
-                          const float* f1, const float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
+                          const float* f1, const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max,
+                          const float* E, float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
                           hipStream_t st);
 
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -421,13 +422,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     if (T > 1)
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
-    // observe embedding backward (dE already carries the ReLU mask of the last layer)
-    PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));
+    // observe embedding backward
     if (obs_fused_supported(net)) {
-        // data gradients of the whole stack in one fused launch; weight gradients join the grouped MFMA launch; bias
-        // gradients are column sums of the same buffers
+        // dE (sum over the trace's time steps of dX, masked by the last ReLU) and the data gradients of the whole stack
+        // in one fused launch; weight gradients join the grouped MFMA launch; bias gradients are column sums of the same
+        // buffers
         const int64_t dhs = (int64_t)B * w.maxohid4;
-        PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, w.dE, w.dF1, w.dCat, w.dObsH, dhs, st));
+        PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, w.dX, w.i4, bt->row_off_dev, T, w.E, w.dE, w.dF1, w.dCat,
+                                     w.dObsH, dhs, st));
         const int e = net->e_obs;
         queue_wgrad(wq, w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, B, e, e);
         queue_wgrad(wq, w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, B, e, e);
@@ -451,6 +453,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(launch_wgrads(wq, st));
         return 0;
     }
+    PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
     PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
     PP_TRY(launch_wgrads(wq, st));
     const int e = net->e_obs;

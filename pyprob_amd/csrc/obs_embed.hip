@@ -190,9 +190,11 @@ __device__ __forceinline__ float obs_dense_t(const float* lds, const ObsLayer& L
 __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs a, const float* __restrict__ P,
                                                               int n_traces, int traces_per_wave,
                                                               const float* __restrict__ cat, const float* __restrict__ f1,
-                                                              const float* __restrict__ dE, float* __restrict__ dF1,
-                                                              float* __restrict__ dCat, float* const dHo0,
-                                                              int64_t dh_stride) {
+                                                              const float* __restrict__ dX, int64_t ldx,
+                                                              const int32_t* __restrict__ row_off, int t_max,
+                                                              const float* __restrict__ E, float* __restrict__ dE,
+                                                              float* __restrict__ dF1, float* __restrict__ dCat,
+                                                              float* const dHo0, int64_t dh_stride) {
     __shared__ float lds[10240];
     warm_kernargs((int)sizeof(ObsFusedArgs) + 96);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,10 +204,25 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
         if (lane >= a.hoff[o] && lane < a.hoff[o] + a.hid[o]) { oh = o; jh = lane - a.hoff[o]; }
     const bool acte = lane < a.e_obs;
     const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
+    // Gradient into the embedding output of trace b: every time step of the trace consumed E[b], so
+    // dE[b, c] = (E[b, c] > 0) * sum_t dX[row_off[t] + b, c] (deterministic, no atomics); it is also written out as
+    // the operand of the final layer's weight / bias gradients.
+    auto load_dz2 = [&](int b) {
+        float acc = 0.0f;
+        if (acte) {
+            for (int t = 0; t < t_max; ++t) {
+                const int r0 = row_off[t];
+                if (b >= row_off[t + 1] - r0) break;
+                acc += dX[(int64_t)(r0 + b) * ldx + lane];
+            }
+            acc = E[(int64_t)b * a.e_ld + lane] > 0.0f ? acc : 0.0f;
+        }
+        return acc;
+    };
     // first trace's inputs: issued BEFORE the weight staging so both memory round trips overlap
     float nx_dz2 = 0.f, nx_f1 = 0.f, nx_cat = 0.f, nx_h = 0.f;
-    if (b0 < n_traces) {   // dE is already masked by E > 0 (obs_grad_kernel)
-        nx_dz2 = acte ? dE[(int64_t)b0 * a.e_ld + lane] : 0.0f;
+    if (b0 < n_traces) {
+        nx_dz2 = load_dz2(b0);
         nx_f1 = acte ? f1[(int64_t)b0 * a.e_ld + lane] : 0.0f;
         nx_cat = acte ? cat[(int64_t)b0 * a.e_ld + lane] : 0.0f;
         nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)b0 * a.ohid_ld[oh] + jh] : 0.0f;
@@ -218,11 +235,12 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
         const float dz2 = nx_dz2, f1v = nx_f1, catv = nx_cat, hv = nx_h;
         if (t + 1 < traces_per_wave && b + 1 < n_traces) {
             const int bn = b + 1;
-            nx_dz2 = acte ? dE[(int64_t)bn * a.e_ld + lane] : 0.0f;
+            nx_dz2 = load_dz2(bn);
             nx_f1 = acte ? f1[(int64_t)bn * a.e_ld + lane] : 0.0f;
             nx_cat = acte ? cat[(int64_t)bn * a.e_ld + lane] : 0.0f;
             nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)bn * a.ohid_ld[oh] + jh] : 0.0f;
         }
+        if (acte) dE[(int64_t)b * a.e_ld + lane] = dz2;
         float dz1 = obs_dense_t(lds, a.f1, lane, acte, dz2, 0);
         dz1 = f1v > 0.0f ? dz1 : 0.0f;
         if (acte) dF1[(int64_t)b * a.e_ld + lane] = dz1;
@@ -299,13 +317,14 @@ int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int
 
 // dHo: n_obs buffers of [B, round4(hid_o)] laid out `dh_stride` floats apart, starting at dHo0
 int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
-                          const float* f1, const float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
+                          const float* f1, const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max,
+                          const float* E, float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
                           hipStream_t st) {
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
     const int tpw = pick_traces_per_wave(n_traces, 256);
-    hipLaunchKernelGGL(obs_embed_dgrad_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, n_traces, tpw, cat, f1, dE,
-                       dF1, dCat, dHo0, dh_stride);
+    hipLaunchKernelGGL(obs_embed_dgrad_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, n_traces, tpw, cat, f1, dX,
+                       ldx, row_off_dev, t_max, E, dE, dF1, dCat, dHo0, dh_stride);
     PP_LAUNCH_CHECK("obs_embed_dgrad_fused");
     return 0;
 }
