@@ -631,7 +631,7 @@ int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, con
 // lanes instead of serialised in one thread. W2 is staged once per workgroup in LDS.
 // Replaces: Y GEMM (unaligned W2 rows -> scalar loads), head_mixture_kernel, dz1 GEMM, colsum(db2) = 4 launches.
 // ------------------------------------------------------------------------------------------------------
-constexpr int TAIL_LDS_FLOATS = 16384;
+constexpr int TAIL_LDS_FLOATS = 32768;   // dynamic LDS budget of the fused head tail (128 KB)
 
 // NQ4 = float4 groups per lane: lane l owns hidden units j = 256 q + 4 l + e (q < NQ4, e < 4), so a1 / dz1 rows move as
 // 16-byte accesses and every W2 row (LDS stride hid4 = round4(hid)) is read with one ds_read_b128 per 4 FMAs.
@@ -643,13 +643,23 @@ struct TailJobs {
     TailJob j[TAIL_MAX_JOBS];
 };
 
-template <int KIND, int NQ4>
+__device__ __forceinline__ void wave_lds_sync() {   // order this wave's LDS writes before its LDS reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS: W2 as [n_out][ws] (ws = hid made odd: lane o of the layer-2 products reads row o, an odd stride spreads the 32
+// rows over the 32 banks; when hid is odd already the image is the parameter tensor itself and is staged with one
+// round of 16-byte loads), then per wave the activation row a1 [hid4] and the 64 + 64 floats of y and dy.
+template <int KIND, int NE>
 __global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int64_t lda1, int hid, int K,
                                                         const float* __restrict__ value,
                                                         const float* __restrict__ prior, int rows_per_wave,
                                                         float grad_scale, float* __restrict__ lp_out, int64_t lddy,
                                                         int64_t lddz, float* __restrict__ loss_acc,
                                                         int32_t* __restrict__ nonfinite, long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) float tail_lds[];
     const TailJob& jb = jobs.j[blockIdx.y];   // blockIdx.y = address group (same head kind and shape in one launch)
     const int n = jb.n;
     if ((int)blockIdx.x * 4 * rows_per_wave >= n) return;   // this group has fewer rows than the launch grid
@@ -659,89 +669,100 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int
     const int32_t* __restrict__ rows = jb.rows;
     float* __restrict__ DY = jb.DY;
     float* __restrict__ dZ1 = jb.dZ1;
-    __shared__ __attribute__((aligned(16))) float w2s[TAIL_LDS_FLOATS];
 #define PP_STAMP(k) do { if (dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == 0) dbg[(k)] = clock64(); } while (0)
     PP_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_out = 3 * K;
     const int hid4 = (hid + 3) & ~3;
-    // stage W2 [n_out, hid] into LDS rows of stride hid4, zero padded. Branch-free flat copy, 16 loads in flight per
-    // thread; row = floor(i / hid4) through an exact float reciprocal (i < 2^14).
-    {
-        const int total = n_out * hid4;
-        const float inv = 1.0f / (float)hid4;
-        for (int base = tid; base < total; base += 256 * 16) {
+    const int ws = hid | 1;
+    const int wtot = n_out * ws, wtot4 = (wtot + 3) & ~3;
+    float* const w2s = tail_lds;
+    float* const a1s = tail_lds + wtot4 + wave * hid4;
+    float* const ys = tail_lds + wtot4 + 4 * hid4 + wave * 128;
+    float* const dys = ys + 64;
+    if (ws == hid && (reinterpret_cast<uintptr_t>(W2) & 15) == 0) {
+        // the image IS the tensor: flat 16-byte copy, every load of a thread in flight at once (one round trip)
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(W2);
+        const int n4 = wtot >> 2;
+        for (int base = tid; base < n4; base += 256 * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(base + 256 * u, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + 256 * u < n4) *reinterpret_cast<f32x4*>(w2s + 4 * (base + 256 * u)) = v[u];
+        }
+        for (int i = 4 * n4 + tid; i < wtot; i += 256) w2s[i] = W2[i];
+    } else {
+        // row stride differs (even hid) or unaligned tensor: branch-free scalar copy, 16 loads in flight per thread;
+        // row = floor(i / ws) through an exact float reciprocal (i < 2^15)
+        const float inv = 1.0f / (float)ws;
+        for (int base = tid; base < wtot; base += 256 * 16) {
             float v[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int i = min(base + 256 * u, total - 1);
+                const int i = min(base + 256 * u, wtot - 1);
                 const int o = (int)(((float)i + 0.5f) * inv);
-                const int j = i - o * hid4;
-                const float x = W2[o * hid + min(j, hid - 1)];
-                v[u] = j < hid ? x : 0.0f;
+                const int j = i - o * ws;
+                v[u] = W2[o * hid + min(j, hid - 1)];
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = base + 256 * u;
-                if (i < total) w2s[i] = v[u];
-            }
+            for (int u = 0; u < 16; ++u)
+                if (base + 256 * u < wtot) w2s[base + 256 * u] = v[u];
         }
     }
     // bias of the three outputs this lane owns as mixture component `lane`
-    const bool comp0 = lane < K;
-    const float b2mu = comp0 ? b2[lane] : 0.0f, b2sd = comp0 ? b2[K + lane] : 0.0f, b2z = comp0 ? b2[2 * K + lane] : 0.0f;
+    const bool comp = lane < K;
+    const float b2mu = comp ? b2[lane] : 0.0f, b2sd = comp ? b2[K + lane] : 0.0f, b2z = comp ? b2[2 * K + lane] : 0.0f;
     __syncthreads();
     PP_STAMP(1);
     const bool bwd = DY != nullptr;
     float loss_local = 0.f;
     bool bad_any = false;
-    const bool comp = lane < K;
-    bool qok[NQ4];
+    const int half = lane >> 5, l31 = lane & 31;
+    const int jh = ((hid + 7) >> 3) << 2;                 // k range of a half-wave in the layer-2 products (multiple of 4)
+    const int jbeg = half * jh, jend = min(hid, jbeg + jh);
+    int jc[NE];                                           // this lane's columns j = lane + 64 e, clamped
 #pragma unroll
-    for (int q = 0; q < NQ4; ++q) qok[q] = 256 * q + 4 * lane < hid4;
+    for (int e = 0; e < NE; ++e) jc[e] = min(lane + 64 * e, hid - 1);
     const int i0 = (blockIdx.x * 4 + wave) * rows_per_wave;
     for (int t = 0; t < rows_per_wave; ++t) {
         const int i = i0 + t;
         if (i >= n) break;   // wave-uniform
         const int r = rows ? rows[i] : i;
-        f32x4 a1[NQ4];
+        float a1v[NE];
 #pragma unroll
-        for (int q = 0; q < NQ4; ++q) {
-            const int j = 256 * q + 4 * lane;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (qok[q]) v = *reinterpret_cast<const f32x4*>(A1 + (int64_t)i * lda1 + j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (j + e >= hid) v[e] = 0.0f;   // the pad columns of the workspace row are not initialised
-            a1[q] = v;
+        for (int e = 0; e < NE; ++e) {
+            const int j = lane + 64 * e;
+            a1v[e] = j < hid ? A1[(int64_t)i * lda1 + j] : 0.0f;   // pad columns of the workspace row are not initialised
+            if (j < hid4) a1s[j] = a1v[e];
         }
+        wave_lds_sync();
         PP_STAMP(2);
-        // second layer, one mixture component per iteration: y_k, y_{K+k}, y_{2K+k} = three independent dot products
-        // (ILP), reduced on the VALU; lane k keeps its component's three values
-        float ymu = 0.0f, ysd = 0.0f, yz = -INFINITY;
-        for (int k = 0; k < K; ++k) {
-            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < NQ4; ++q) {
-                if (qok[q]) {
-                    const int off = 256 * q + 4 * lane;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w2s + k * hid4 + off);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(w2s + (K + k) * hid4 + off);
-                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2s + (2 * K + k) * hid4 + off);
-                    p0 += a1[q][0] * w0[0] + a1[q][1] * w0[1] + a1[q][2] * w0[2] + a1[q][3] * w0[3];
-                    p1 += a1[q][0] * w1[0] + a1[q][1] * w1[1] + a1[q][2] * w1[2] + a1[q][3] * w1[3];
-                    p2 += a1[q][0] * w2[0] + a1[q][1] * w2[1] + a1[q][2] * w2[2] + a1[q][3] * w2[3];
-                }
+        // second layer: lane (o, half) owns output o over half of the k range: no cross-lane reduction except the
+        // final exchange between the half-waves; a1 is read as 16-byte broadcasts, W2 row o with an odd stride
+        for (int ob = 0; ob < n_out; ob += 32) {
+            const int o = ob + l31;
+            const float* __restrict__ wr = w2s + min(o, n_out - 1) * ws;
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+            int j = jbeg;
+#pragma unroll 4
+            for (; j + 3 < jend; j += 4) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a1s + j);
+                p0 += av[0] * wr[j];
+                p1 += av[1] * wr[j + 1];
+                p2 += av[2] * wr[j + 2];
+                p3 += av[3] * wr[j + 3];
             }
-            p0 = wave_sum(p0);
-            p1 = wave_sum(p1);
-            p2 = wave_sum(p2);
-            if (lane == k) {
-                ymu = p0 + b2mu;
-                ysd = p1 + b2sd;
-                yz = p2 + b2z;
-            }
+            for (; j < jend; ++j) p0 += a1s[j] * wr[j];
+            float acc = (p0 + p1) + (p2 + p3);
+            acc += __shfl_xor(acc, 32, 64);
+            if (half == 0 && o < n_out) ys[o] = acc;
         }
+        wave_lds_sync();
+        const float ymu = comp ? ys[lane] + b2mu : 0.0f;
+        const float ysd = comp ? ys[K + lane] + b2sd : 0.0f;
+        const float yz = comp ? ys[2 * K + lane] + b2z : -INFINITY;
         PP_STAMP(3);
         // one mixture component per lane
         const float v = value[r], pa = prior[2 * r], pb = prior[2 * r + 1];
@@ -810,34 +831,28 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int
         if (comp) {
             float* dy = DY + (int64_t)i * lddy;
             dy[lane] = d0; dy[K + lane] = d1; dy[2 * K + lane] = d2;
+            dys[lane] = d0; dys[K + lane] = d1; dys[2 * K + lane] = d2;
         }
+        wave_lds_sync();
         PP_STAMP(5);
-        // dz1_j = [a1_j > 0] * sum_o dy_o W2[o][j]: dy of component k is broadcast from lane k (v_readlane)
-        f32x4 dz[NQ4];
+        // dz1_j = [a1_j > 0] * sum_o dy_o W2[o][j]: lane owns columns j = lane + 64 e (consecutive lanes, consecutive
+        // banks), dy_o is an LDS broadcast
+        float dz[NE];
 #pragma unroll
-        for (int q = 0; q < NQ4; ++q) dz[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < K; ++k) {
-            const float e0 = lane_bcast(d0, k), e1 = lane_bcast(d1, k), e2 = lane_bcast(d2, k);
+        for (int e = 0; e < NE; ++e) dz[e] = 0.0f;
+#pragma unroll 2
+        for (int o = 0; o < n_out; ++o) {
+            const float d = dys[o];
+            const float* __restrict__ wr = w2s + o * ws;
 #pragma unroll
-            for (int q = 0; q < NQ4; ++q) {
-                if (qok[q]) {
-                    const int off = 256 * q + 4 * lane;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w2s + k * hid4 + off);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(w2s + (K + k) * hid4 + off);
-                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2s + (2 * K + k) * hid4 + off);
-                    dz[q] += e0 * w0 + e1 * w1 + e2 * w2;
-                }
-            }
+            for (int e = 0; e < NE; ++e) dz[e] += d * wr[jc[e]];
         }
 #pragma unroll
-        for (int q = 0; q < NQ4; ++q) {
-            if (qok[q]) {
-                f32x4 d;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = a1[q][e] > 0.0f ? dz[q][e] : 0.0f;
-                *reinterpret_cast<f32x4*>(dZ1 + (int64_t)i * lddz + 256 * q + 4 * lane) = d;
-            }
+        for (int e = 0; e < NE; ++e) {
+            const int j = lane + 64 * e;
+            if (j < hid4) dZ1[(int64_t)i * lddz + j] = (j < hid && a1v[e] > 0.0f) ? dz[e] : 0.0f;
         }
+        wave_lds_sync();   // a1s / ys / dys are rewritten by the next row
     }
     PP_STAMP(6);
     // loss: one atomic per wave, spread over 64 accumulator slots (same-address float atomics serialise at ~40 ns
@@ -848,29 +863,52 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int
     // same few hundred addresses serialise in L2 (measured: +40 us); the caller runs the 16-way colsum kernel instead.
 }
 
+static size_t head_tail_lds_floats(int hid, int n_out) {
+    const int hid4 = (hid + 3) & ~3;
+    return (size_t)((n_out * (hid | 1) + 3) & ~3) + 4 * (size_t)hid4 + 4 * 128;
+}
+
 bool head_tail_supported(int kind, int hid, int n_out) {
     static const bool disabled = getenv("PP_NO_HEAD_TAIL") && atoi(getenv("PP_NO_HEAD_TAIL")) != 0;   // A/B knob
     if (disabled) return false;
     if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE) return false;
     if (n_out % 3 != 0 || n_out / 3 > MAXK || n_out / 3 < 1) return false;
-    const int hid4 = (hid + 3) & ~3;
-    return hid4 <= 1024 && (int64_t)hid4 * n_out <= TAIL_LDS_FLOATS;
+    return hid >= 1 && hid <= 1024 && head_tail_lds_floats(hid, n_out) <= TAIL_LDS_FLOATS;
 }
 
 long long* g_timeline = nullptr;   // debug: per-phase clock64() stamps of workgroups 0 and 100 (pp_debug_timeline)
 
-template <int KIND>
-static void head_tail_launch(int nq4, dim3 grid, hipStream_t st, const TailJobs& jobs, int64_t lda1, int hid, int K,
-                             const float* value, const float* prior, int rpw, float gs, float* lp_out, int64_t lddy,
-                             int64_t lddz, float* loss_acc, int32_t* nonfinite) {
-#define PP_TAIL(NQ) hipLaunchKernelGGL((head_tail_kernel<KIND, NQ>), grid, dim3(256), 0, st, jobs, lda1, hid, K, value, prior, \
-                                       rpw, gs, lp_out, lddy, lddz, loss_acc, nonfinite, g_timeline)
-    switch (nq4) {
-        case 1: PP_TAIL(1); break;
-        case 2: PP_TAIL(2); break;
-        case 3: PP_TAIL(3); break;
-        default: PP_TAIL(4); break;
+template <int KIND, int NE>
+static int head_tail_launch_ne(dim3 grid, size_t lds, hipStream_t st, const TailJobs& jobs, int64_t lda1, int hid, int K,
+                               const float* value, const float* prior, int rpw, float gs, float* lp_out, int64_t lddy,
+                               int64_t lddz, float* loss_acc, int32_t* nonfinite) {
+    static thread_local bool configured = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)head_tail_kernel<KIND, NE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(TAIL_LDS_FLOATS * sizeof(float)));
+        if (e != hipSuccess) {
+            set_error("head_tail: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        configured = true;
     }
+    hipLaunchKernelGGL((head_tail_kernel<KIND, NE>), grid, dim3(256), lds, st, jobs, lda1, hid, K, value, prior, rpw, gs, lp_out,
+                       lddy, lddz, loss_acc, nonfinite, g_timeline);
+    return 0;
+}
+
+template <int KIND>
+static int head_tail_launch(int ne, dim3 grid, size_t lds, hipStream_t st, const TailJobs& jobs, int64_t lda1, int hid, int K,
+                            const float* value, const float* prior, int rpw, float gs, float* lp_out, int64_t lddy,
+                            int64_t lddz, float* loss_acc, int32_t* nonfinite) {
+#define PP_TAIL(N) return head_tail_launch_ne<KIND, N>(grid, lds, st, jobs, lda1, hid, K, value, prior, rpw, gs, lp_out, lddy, \
+                                                       lddz, loss_acc, nonfinite)
+    if (ne <= 2) PP_TAIL(2);
+    if (ne <= 4) PP_TAIL(4);
+    if (ne <= 6) PP_TAIL(6);
+    if (ne <= 8) PP_TAIL(8);
+    if (ne <= 12) PP_TAIL(12);
+    PP_TAIL(16);
 #undef PP_TAIL
 }
 
@@ -880,7 +918,8 @@ int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int 
                     int32_t* nonfinite, hipStream_t st) {
     PP_CHECK_ARG(head_tail_supported(kind, hid, n_out), "head_tail: unsupported head shape");
     PP_CHECK_ARG(lda1 % 4 == 0 && lddz % 4 == 0, "head_tail: leading dimensions must be multiples of 4");
-    const int nq4 = (((hid + 3) & ~3) + 255) / 256;
+    const int ne = (hid + 63) / 64;   // columns per lane
+    const size_t lds = head_tail_lds_floats(hid, n_out) * sizeof(float);
     int i = 0;
     while (i < count) {
         TailJobs pack;
@@ -896,11 +935,11 @@ int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int 
         const int rpw = std::max((max_n + 4 * 256 - 1) / (4 * 256), 1);
         dim3 grid(cdiv(max_n, 4 * rpw), nj);
         if (kind == PP_HEAD_NORMAL_MIXTURE)
-            head_tail_launch<0>(nq4, grid, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy, lddz,
-                                loss_acc, nonfinite);
+            PP_TRY(head_tail_launch<0>(ne, grid, lds, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy,
+                                       lddz, loss_acc, nonfinite));
         else
-            head_tail_launch<1>(nq4, grid, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy, lddz,
-                                loss_acc, nonfinite);
+            PP_TRY(head_tail_launch<1>(ne, grid, lds, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy,
+                                       lddz, loss_acc, nonfinite));
         PP_LAUNCH_CHECK("head_tail");
     }
     return 0;

@@ -1,4 +1,3 @@
-cd /root/repo
-timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --steps 300 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
-python bench.py --workload train_gumm --steps 200 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_g -o e -- python /root/repo/bench.py --steps 100 --warmup 20 --no-cpu-baseline > /root/repo/gpurun_out/e.log 2>&1; tail -1 /root/repo/gpurun_out/e.log | cut -c1-120; python /root/repo/tools/prof_top.py /root/repo/gpurun_out/prof_g/e_results.db "%" 2>&1 | grep -v "at::" | head -12
+rm -rf /root/repo/gpurun_out/prof_g

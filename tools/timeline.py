@@ -16,5 +16,3 @@ t = buf.tolist()
 names = ['start', 'staged', 'a1 loaded', 'y done', 'mixture done', 'dy written', 'end']
 for blk, off in ((0, 0), (100, 8)):
     print('workgroup', blk, ' '.join('%s +%d' % (names[k], t[off + k] - t[off + k - 1]) for k in range(1, 7)), ' total cycles', t[off + 6] - t[off])
-names = ['start', 'staged+zeroed', 'trace0 loaded', 'gF1', 'dz1 (dense_t)', 'gF0+dzc', 'obs layers', 'all traces', 'wave turns', 'flush']
-print('obs_bwd wg0:', ' '.join('%s +%d' % (names[k], t[k] - t[k - 1]) for k in range(1, 10)), ' total', t[9] - t[0])
