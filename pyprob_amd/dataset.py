@@ -1,0 +1,406 @@
+"""Packed on-disk trace dataset and loader.
+
+The reference stores offline traces as pickled, zlib-compressed `Trace` objects in shelve/sqlite files
+(pyprob/nn/dataset.py:121-172 `OfflineDatasetFile`, pyprob/util.py:347-355), prunes every trace on write
+(`_prune_trace`, dataset.py:64-119), sorts them on open by (controlled length, Python `hash()` of the address string)
+into yet another shelf (dataset.py:217-259) and decodes one trace at a time when training (~1.1-1.4 k traces/s). A
+minibatch only needs, per trace, the observed values and, per controlled sample statement, (address, value, prior
+parameters) - so this module stores exactly those columns:
+
+    <dir>/meta.json        version, counts, observable names/widths, address table, trace-type table
+    <dir>/trace_len.npy    int32  [N]     controlled length of every trace
+    <dir>/trace_type.npy   int32  [N]     index into the trace-type table (one type = one address sequence)
+    <dir>/row_off.npy      int64  [N+1]   first row of every trace
+    <dir>/obs.npy          float32[N, W]  observed values, observables concatenated in `obs_names` order
+    <dir>/value.npy        float32[R]     sampled values (R = sum of lengths)
+    <dir>/prior.npy        float32[R, 2]  prior parameters as the proposal heads need them (Normal: mean, stddev;
+                                          Uniform: low, high; Categorical: unused)
+    <dir>/addr.npy         int32  [R]     index into the address table
+
+Traces are written SORTED by (length, type hash) - the order the reference's sampler wants (dataset.py:328-343) - with
+a process-independent FNV-1a hash instead of Python's salted `hash()` (dataset.py:237). Every column is a plain .npy
+file, opened with `np.load(mmap_mode='r')`: a minibatch is a handful of fancy-index reads and goes straight into
+`PackedBatch.from_ragged`, no per-trace Python objects. `PackedTraceDataset` concatenates any number of such
+directories (shards), exposes the reference's `OfflineDataset` surface (`len`, `dataset[i]` as a pruned Trace) and
+yields device batches through a prefetching loader; `DistributedTraceBatchSampler` (parallel.py) partitions the
+sorted index space across ranks exactly like the reference.
+"""
+import json
+import os
+import queue
+import threading
+
+import numpy as np
+
+from .packed import PackedBatch, distribution_params
+
+FORMAT_VERSION = 1
+_COLUMNS = ('trace_len', 'trace_type', 'row_off', 'obs', 'value', 'prior', 'addr')
+
+
+def fnv1a64(data):
+    """64-bit FNV-1a of a bytes object (stable across processes and machines)."""
+    h = 0xcbf29ce484222325
+    for b in data:
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def trace_type_hash(addresses):
+    """Hash of a controlled address sequence: what dataset.py:237 computes with the salted built-in hash()."""
+    return fnv1a64('\0'.join(addresses).encode('utf-8'))
+
+
+class PackedTraceWriter:
+    """Accumulates traces (objects or columns) and writes one sorted shard directory on close()."""
+
+    def __init__(self, path, obs_names, obs_widths=None):
+        self.path = path
+        self.obs_names = list(obs_names)
+        self.obs_widths = None if obs_widths is None else [int(w) for w in obs_widths]
+        self._addr_table = []        # [(address, distribution name, n_categories)]
+        self._addr_id = {}
+        self._types = []             # [(hash, tuple(address ids))]
+        self._type_id = {}
+        self._len, self._type, self._obs, self._value, self._prior, self._addr = [], [], [], [], [], []
+
+    # ---- address / type tables --------------------------------------------------------------------------
+    def _address(self, address, dist_name, n_categories=None):
+        i = self._addr_id.get(address)
+        if i is None:
+            i = self._addr_id[address] = len(self._addr_table)
+            self._addr_table.append((address, dist_name, None if n_categories is None else int(n_categories)))
+        return i
+
+    def _trace_type(self, ids):
+        key = tuple(int(i) for i in ids)
+        t = self._type_id.get(key)
+        if t is None:
+            t = self._type_id[key] = len(self._types)
+            self._types.append((trace_type_hash([self._addr_table[i][0] for i in key]), key))
+        return t
+
+    # ---- input ------------------------------------------------------------------------------------------
+    def add_trace(self, trace):
+        """One pyprob-style Trace: keeps what `_prune_trace` keeps for training (dataset.py:64-119)."""
+        vc = trace.variables_controlled
+        if len(vc) == 0:
+            raise ValueError('Trace of length zero.')
+        ids = []
+        for v in vc:
+            d = v.distribution
+            ids.append(self._address(v.address, d.name, getattr(d, 'num_categories', None) if d.name == 'Categorical' else None))
+            self._value.append(np.float32(float(v.value)))
+            self._prior.append(distribution_params(d))
+        self._addr.append(np.asarray(ids, np.int32))
+        row = []
+        for n in self.obs_names:
+            val = trace.named_variables[n].value
+            val = val.detach().cpu().numpy() if hasattr(val, 'detach') else np.asarray(val)
+            row.append(val.astype(np.float32).reshape(-1))
+        if self.obs_widths is None:
+            self.obs_widths = [len(r) for r in row]
+        self._obs.append(np.concatenate(row) if row else np.zeros(0, np.float32))
+        self._len.append(len(vc))
+        self._type.append(self._trace_type(ids))
+
+    def add_columns(self, trace_len, addresses, address_ids, values, prior, obs):
+        """Vectorised input (trace generators, converters): `addresses` = [(address, distribution name, n_categories)]
+        is the table `address_ids` [R] indexes; trace_len [B], values [R], prior [R, 2], obs [B, W]."""
+        trace_len = np.asarray(trace_len, np.int64)
+        if np.any(trace_len <= 0):
+            raise ValueError('Trace of length zero.')
+        remap = np.asarray([self._address(*a) for a in addresses], np.int32)
+        ids = remap[np.asarray(address_ids, np.int64)]
+        off = np.concatenate([[0], np.cumsum(trace_len)])
+        obs = np.asarray(obs, np.float32).reshape(len(trace_len), -1)
+        if self.obs_widths is None:
+            self.obs_widths = [obs.shape[1]] if len(self.obs_names) == 1 else [obs.shape[1] // max(len(self.obs_names), 1)] * len(self.obs_names)
+        self._value.append(np.asarray(values, np.float32).reshape(-1))
+        self._prior.append(np.asarray(prior, np.float32).reshape(-1, 2))
+        self._addr.append(ids)
+        self._obs.append(obs)
+        self._len.append(trace_len.astype(np.int32))
+        # trace types: unique address sequences, found per distinct length with a row-wise unique
+        types = np.empty(len(trace_len), np.int32)
+        for L in np.unique(trace_len):
+            sel = np.nonzero(trace_len == L)[0]
+            seqs = ids[(off[sel][:, None] + np.arange(L)[None, :])]
+            uniq, inv = np.unique(seqs, axis=0, return_inverse=True)
+            tids = np.asarray([self._trace_type(u) for u in uniq], np.int32)
+            types[sel] = tids[inv.reshape(-1)]
+        self._type.append(types)
+
+    # ---- output -----------------------------------------------------------------------------------------
+    def close(self):
+        def cat(parts, dtype, shape_tail=()):
+            arrs = [np.asarray(p, dtype).reshape((-1,) + shape_tail) for p in parts]
+            return np.concatenate(arrs) if arrs else np.zeros((0,) + shape_tail, dtype)
+        trace_len = cat(self._len, np.int32)
+        N = len(trace_len)
+        if N == 0:
+            raise ValueError('empty dataset')
+        W = int(sum(self.obs_widths or [0]))
+        trace_type = cat(self._type, np.int32)
+        obs = cat(self._obs, np.float32, (W,))
+        value = cat(self._value, np.float32)
+        prior = cat(self._prior, np.float32, (2,))
+        addr = cat(self._addr, np.int32)
+        off = np.concatenate([[0], np.cumsum(trace_len.astype(np.int64))])
+        # sort by (length, type hash): the order OfflineDataset builds on open (dataset.py:217-259)
+        hashes = np.asarray([h for h, _ in self._types], np.uint64)
+        order = np.lexsort((np.arange(N), hashes[trace_type], trace_len))
+        lens = trace_len[order].astype(np.int64)
+        new_off = np.concatenate([[0], np.cumsum(lens)])
+        rows = np.repeat(off[order] - new_off[:-1], lens) + np.arange(int(new_off[-1]))
+        os.makedirs(self.path, exist_ok=True)
+        cols = dict(trace_len=trace_len[order], trace_type=trace_type[order], row_off=new_off.astype(np.int64),
+                    obs=obs[order], value=value[rows], prior=prior[rows], addr=addr[rows])
+        for name in _COLUMNS:
+            np.save(os.path.join(self.path, name + '.npy'), np.ascontiguousarray(cols[name]))
+        meta = dict(format='pyprob_amd packed traces', version=FORMAT_VERSION, n_traces=int(N), n_rows=int(new_off[-1]),
+                    obs_names=self.obs_names, obs_widths=[int(w) for w in (self.obs_widths or [])],
+                    addresses=[dict(address=a, distribution=d, n_categories=c) for a, d, c in self._addr_table],
+                    trace_types=[dict(hash='%016x' % h, address_ids=list(k)) for h, k in self._types],
+                    sorted_by=['trace_len', 'trace_type_hash'])
+        with open(os.path.join(self.path, 'meta.json'), 'w') as f:
+            json.dump(meta, f)
+        return meta
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+
+
+class _Shard:
+    def __init__(self, path):
+        with open(os.path.join(path, 'meta.json')) as f:
+            self.meta = json.load(f)
+        if self.meta.get('version') != FORMAT_VERSION:
+            raise RuntimeError('unsupported packed trace format in {}: {}'.format(path, self.meta.get('version')))
+        for name in _COLUMNS:
+            setattr(self, name, np.load(os.path.join(path, name + '.npy'), mmap_mode='r'))
+        self.n = int(self.meta['n_traces'])
+
+
+class PackedTraceDataset:
+    """All shards under `dataset_dir` (or an explicit list of shard directories) as one indexable dataset.
+
+    Mirrors OfflineDataset (dataset.py:175-263): `len(ds)`, `ds[i]` (a pruned Trace, slow path), sorted indices for the
+    sampler; plus the vectorised `gather` / `batch` / `loader` the hot path uses."""
+
+    def __init__(self, dataset_dir):
+        if isinstance(dataset_dir, (list, tuple)):
+            paths = list(dataset_dir)
+        elif os.path.exists(os.path.join(dataset_dir, 'meta.json')):
+            paths = [dataset_dir]
+        else:
+            paths = sorted(os.path.join(dataset_dir, d) for d in os.listdir(dataset_dir)
+                           if os.path.exists(os.path.join(dataset_dir, d, 'meta.json')))
+        if not paths:
+            raise RuntimeError('no packed trace shards in {}'.format(dataset_dir))
+        self._shards = [_Shard(p) for p in paths]
+        first = self._shards[0].meta
+        self.obs_names, self.obs_widths = first['obs_names'], first['obs_widths']
+        self.obs_width = int(sum(self.obs_widths))
+        # global address / trace-type tables and per-shard remaps
+        self.addresses, self._addr_id = [], {}
+        self.trace_types, self._type_id = [], {}
+        self._addr_remap, self._type_remap = [], []
+        for s in self._shards:
+            if s.meta['obs_names'] != self.obs_names or s.meta['obs_widths'] != self.obs_widths:
+                raise RuntimeError('shards disagree on the observables')
+            ar = []
+            for a in s.meta['addresses']:
+                key = a['address']
+                if key not in self._addr_id:
+                    self._addr_id[key] = len(self.addresses)
+                    self.addresses.append((a['address'], a['distribution'], a['n_categories']))
+                ar.append(self._addr_id[key])
+            ar = np.asarray(ar, np.int32)
+            tr = []
+            for t in s.meta['trace_types']:
+                key = tuple(int(ar[i]) for i in t['address_ids'])
+                if key not in self._type_id:
+                    self._type_id[key] = len(self.trace_types)
+                    self.trace_types.append((int(t['hash'], 16), key))
+                tr.append(self._type_id[key])
+            self._addr_remap.append(ar)
+            self._type_remap.append(np.asarray(tr, np.int32))
+        self._first = np.concatenate([[0], np.cumsum([s.n for s in self._shards])]).astype(np.int64)
+        self._length = int(self._first[-1])
+        self.trace_len = np.concatenate([np.asarray(s.trace_len) for s in self._shards])
+        self.trace_type = np.concatenate([r[np.asarray(s.trace_type)] for s, r in zip(self._shards, self._type_remap)])
+        self._sorted = None
+
+    def __len__(self):
+        return self._length
+
+    # ---- sampler support --------------------------------------------------------------------------------
+    def sorted_indices(self):
+        """Trace indices ordered by (length, type hash) (dataset.py:217-259); one shard is already in this order."""
+        if self._sorted is None:
+            hashes = np.asarray([h for h, _ in self.trace_types], np.uint64)[self.trace_type]
+            self._sorted = np.lexsort((np.arange(self._length), hashes, self.trace_len))
+        return self._sorted
+
+    def sampler(self, batch_size, rank=0, world_size=1, num_buckets=None, shuffle_batches=True, shuffle_buckets=True):
+        from .parallel import DistributedTraceBatchSampler
+        return DistributedTraceBatchSampler(self.sorted_indices().tolist(), batch_size, rank, world_size, num_buckets,
+                                            shuffle_batches, shuffle_buckets)
+
+    # ---- vectorised access ------------------------------------------------------------------------------
+    def gather(self, indices):
+        """Ragged columns of the given traces, in the given order: (trace_len [B], addr [R] global address ids,
+        value [R], prior [R, 2], obs [B, W])."""
+        idx = np.asarray(indices, np.int64)
+        if idx.size == 0:
+            raise ValueError('empty batch')
+        if np.any(idx < 0) or np.any(idx >= self._length):
+            raise IndexError('trace index out of range')
+        shard = np.searchsorted(self._first, idx, side='right') - 1
+        lens = self.trace_len[idx].astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)])
+        R = int(off[-1])
+        addr = np.empty(R, np.int32)
+        value = np.empty(R, np.float32)
+        prior = np.empty((R, 2), np.float32)
+        obs = np.empty((len(idx), self.obs_width), np.float32)
+        for s_id in np.unique(shard):
+            s = self._shards[s_id]
+            sel = np.nonzero(shard == s_id)[0]
+            local = idx[sel] - self._first[s_id]
+            l = lens[sel]
+            src0 = s.row_off[local]
+            tot = int(l.sum())
+            pos = np.concatenate([[0], np.cumsum(l)])[:-1]
+            src = np.repeat(np.asarray(src0, np.int64) - pos, l) + np.arange(tot)
+            dst = np.repeat(off[sel] - pos, l) + np.arange(tot)
+            addr[dst] = self._addr_remap[s_id][s.addr[src]]
+            value[dst] = s.value[src]
+            prior[dst] = s.prior[src]
+            obs[sel] = s.obs[local]
+        return lens, addr, value, prior, obs
+
+    def batch(self, indices, spec):
+        """Host PackedBatch of the given traces for a network with address table `spec` (unknown address -> KeyError,
+        the caller polymorphs first)."""
+        lens, addr, value, prior, obs = self.gather(indices)
+        to_engine = np.asarray([spec.address_id.get(a[0], -1) for a in self.addresses], np.int64)
+        ids = to_engine[addr]
+        if np.any(ids < 0):
+            raise KeyError('Address unknown by inference network: {}'.format(self.addresses[int(addr[np.argmax(ids < 0)])][0]))
+        return PackedBatch.from_ragged(lens, ids, value, prior, obs, len(spec.addresses))
+
+    def addresses_of(self, indices):
+        """[(address, distribution name, n_categories)] used by the given traces, in first-statement order: what
+        `_polymorph` needs (inference_network_lstm.py:34-80) without materialising Trace objects."""
+        types = np.unique(self.trace_type[np.asarray(indices, np.int64)])
+        seen, out = set(), []
+        for t in types:
+            for a in self.trace_types[t][1]:
+                if a not in seen:
+                    seen.add(a)
+                    out.append(self.addresses[a])
+        return out
+
+    def loader(self, spec, batch_size, device, rank=0, world_size=1, num_buckets=None, prefetch=4, epochs=None,
+               shuffle_batches=True, shuffle_buckets=True):
+        """Iterator of device PackedBatches: a background thread walks the sampler and packs minibatches on the host
+        (`gather` + `from_ragged`, numpy releases the GIL in the copies), the consumer uploads them (one float and one
+        int32 copy per batch, `PackedBatch.to`). `epochs=None` repeats forever like the reference's training loop."""
+        sampler = self.sampler(batch_size, rank, world_size, num_buckets, shuffle_batches, shuffle_buckets)
+        q = queue.Queue(maxsize=max(int(prefetch), 1))
+        stop = threading.Event()
+
+        def produce():
+            try:
+                e = 0
+                while not stop.is_set() and (epochs is None or e < epochs):
+                    for ids in sampler:
+                        if stop.is_set():
+                            return
+                        q.put(self.batch(ids, spec))
+                    e += 1
+                q.put(None)
+            except BaseException as exc:   # surfaced in the consumer
+                q.put(exc)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item.to(device)
+        finally:
+            stop.set()
+            while not q.empty():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+
+    # ---- OfflineDataset compatibility (slow path) ---------------------------------------------------------
+    def __getitem__(self, i):
+        """A pruned Trace like OfflineDataset.__getitem__ (dataset.py:197-205): controlled variables with address,
+        value and prior distribution, named observed variables with their values."""
+        from . import distributions as D
+        from .trace import Trace, Variable
+        if i < 0:
+            i += self._length
+        lens, addr, value, prior, obs = self.gather([i])
+        tr = Trace()
+        for r in range(int(lens[0])):
+            address, dname, ncat = self.addresses[addr[r]]
+            if dname == 'Normal':
+                dist = D.Normal(float(prior[r, 0]), float(prior[r, 1]))
+            elif dname == 'Uniform':
+                dist = D.Uniform(float(prior[r, 0]), float(prior[r, 1]))
+            elif dname == 'Categorical':
+                dist = D.Categorical([1.0 / ncat] * ncat)
+            else:
+                raise RuntimeError('Distribution currently unsupported: {}'.format(dname))
+            v = Variable(distribution=dist, value=float(value[r]), address=address, control=True)
+            tr.add(v)
+        c = 0
+        for name, w in zip(self.obs_names, self.obs_widths):
+            v = Variable(value=obs[0, c:c + w].copy(), address='__observed__' + name, name=name, observed=True)
+            tr.add(v)
+            c += w
+        # a pruned trace carries no log-probabilities (dataset.py:64-119): fill the collections end() would fill
+        tr.variables_controlled = [v for v in tr.variables if v.control]
+        tr.variables_observed = [v for v in tr.variables if v.observed]
+        tr.named_variables = {v.name: v for v in tr.variables if v.name is not None}
+        tr.length = len(tr.variables)
+        tr.length_controlled = len(tr.variables_controlled)
+        return tr
+
+
+def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=None, *args, **kwargs):
+    """Model.save_dataset (pyprob/model.py:227-232, pyprob/nn/dataset.py:50-62 + 121-144): run the model in
+    PRIOR_FOR_INFERENCE_NETWORK mode and write `ceil(num_traces / num_traces_per_file)` packed shards."""
+    from .state import TraceMode
+    os.makedirs(dataset_dir, exist_ok=True)
+    gen = model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, *args, **kwargs)
+    existing = [d for d in os.listdir(dataset_dir) if d.startswith('pyprob_traces_packed_')]
+    shard, written = len(existing), 0
+    while written < num_traces:
+        n = min(num_traces_per_file, num_traces - written)
+        traces = [next(gen) for _ in range(n)]
+        names = obs_names
+        if names is None:
+            names = [k for k, v in traces[0].named_variables.items() if v.observed or getattr(v, 'observable', False)]
+        path = os.path.join(dataset_dir, 'pyprob_traces_packed_{:06d}_{}'.format(shard, n))
+        with PackedTraceWriter(path, names) as w:
+            for t in traces:
+                w.add_trace(t)
+        shard += 1
+        written += n
+    return shard

@@ -96,8 +96,13 @@ class Model:
     def learn_inference_network(self, num_traces, observe_embeddings={}, batch_size=64, lstm_dim=512, lstm_depth=1,
                                 proposal_mixture_components=10, learning_rate_init=0.001, learning_rate_end=1e-6,
                                 learning_rate_scheduler_type=None, weight_decay=0., distributed_backend=None,
-                                device='cuda:0', seed=None, dataset=None, log_file_name=None):
-        """pyprob/model.py:186-215 with inference_network=InferenceNetwork.LSTM."""
+                                device='cuda:0', seed=None, dataset=None, log_file_name=None, dataset_dir=None,
+                                distributed_num_buckets=None):
+        """pyprob/model.py:186-215 with inference_network=InferenceNetwork.LSTM. `dataset_dir` = a directory written by
+        `save_dataset` (packed shards, pyprob_amd/dataset.py): offline training like the reference's OfflineDataset."""
+        if dataset is None and dataset_dir is not None:
+            from .dataset import PackedTraceDataset
+            dataset = PackedTraceDataset(dataset_dir)
         if dataset is None:
             dataset = OnlineDataset(model=self)
         if self._inference_network is None:
@@ -112,7 +117,12 @@ class Model:
                                          learning_rate_init=learning_rate_init, learning_rate_end=learning_rate_end,
                                          learning_rate_scheduler_type=learning_rate_scheduler_type,
                                          weight_decay=weight_decay, distributed_backend=distributed_backend,
-                                         log_file_name=log_file_name)
+                                         log_file_name=log_file_name, distributed_num_buckets=distributed_num_buckets)
+
+    def save_dataset(self, dataset_dir, num_traces, num_traces_per_file, *args, **kwargs):
+        """pyprob/model.py:227-232: prior traces for offline training, as packed shards (pyprob_amd/dataset.py)."""
+        from .dataset import save_dataset
+        return save_dataset(self, dataset_dir, num_traces, num_traces_per_file, *args, **kwargs)
 
     def save_inference_network(self, file_name):
         if self._inference_network is None:

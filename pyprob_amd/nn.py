@@ -43,6 +43,16 @@ class Batch:
         return self.traces[key]
 
 
+class _PackedIds:
+    """A minibatch of a PackedTraceDataset before packing: trace ids + the addresses the network has not seen yet."""
+
+    def __init__(self, dataset, ids, new_addresses):
+        self.dataset, self.ids, self.new_addresses = dataset, ids, new_addresses
+        self.size = len(ids)
+        self.sub_batches = []
+        self.mean_length_controlled = 0.0
+
+
 class OnlineDataset:
     """pyprob/nn/dataset.py:50-62: every item runs the model once in PRIOR_FOR_INFERENCE_NETWORK mode."""
 
@@ -144,7 +154,11 @@ class InferenceNetworkLSTM:
         items = []
         spec = self._engine.spec
         seen = set()
-        for sub_batch in batch.sub_batches:
+        if isinstance(batch, _PackedIds):
+            for a, dname, ncat in batch.new_addresses:
+                items.append((a, dname, ncat))
+                print('New layers, address: {}, distribution: {}'.format(a[:60], dname))
+        for sub_batch in ([] if isinstance(batch, _PackedIds) else batch.sub_batches):
             for variable in sub_batch[0].variables_controlled:
                 a = variable.address
                 if a not in spec.address_id and a not in seen:
@@ -262,7 +276,8 @@ class InferenceNetworkLSTM:
 
     def optimize(self, num_traces, dataset, batch_size=64, learning_rate_init=0.0001, learning_rate_end=1e-6,
                  learning_rate_scheduler_type=None, weight_decay=1e-5, num_traces_end=1e9, distributed_backend=None,
-                 distributed_params_sync_every_iter=10000, stop_with_bad_loss=False, log_file_name=None, verbose=True):
+                 distributed_params_sync_every_iter=10000, stop_with_bad_loss=False, log_file_name=None, verbose=True,
+                 distributed_num_buckets=None):
         """The training loop of inference_network.py:381-599 for Optimizer.ADAM: per minibatch _polymorph ->
         zero_grad -> _loss -> backward -> [all-reduce, divide by world] -> Adam step, traces/s bookkeeping."""
         if not self._layers_initialized:
@@ -297,16 +312,38 @@ class InferenceNetworkLSTM:
         stop = False
         last = time_start
         i_item = 0
+        # Packed offline dataset (pyprob_amd/dataset.py): minibatches come from the reference's bucketed sampler over the
+        # (length, type)-sorted index space (dataset.py:328-400) and are packed from memory-mapped columns - no Trace
+        # objects. Anything else is indexed trace by trace like the reference's DataLoader does.
+        packed = hasattr(dataset, 'gather') and hasattr(dataset, 'sorted_indices')
+        if packed:
+            sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
+            sampler_iter = iter(sampler)
         while not stop:
-            traces = [dataset[i_item + k] for k in range(batch_size)]
-            i_item += batch_size
-            batch = Batch(traces)
+            if packed:
+                try:
+                    ids = next(sampler_iter)
+                except StopIteration:
+                    sampler_iter = iter(sampler)                                      # next epoch (:461-464)
+                    ids = next(sampler_iter)
+                new = [a for a in dataset.addresses_of(ids) if a[0] not in self._engine.spec.address_id]
+                batch = _PackedIds(dataset, ids, new)
+            else:
+                traces = [dataset[i_item + k] for k in range(batch_size)]
+                i_item += batch_size
+                batch = Batch(traces)
             if world > 1 and self._total_train_iterations % distributed_params_sync_every_iter == 0:
                 self._engine.broadcast_params()                                       # :473-474
             layers_changed = False if self._layers_pre_generated else self._polymorph(batch)
             if layers_changed:
                 self._engine.reset_optimizer()                                        # :481-483
-            success, loss = self._loss(batch, backward=True)
+            if packed:
+                host = dataset.batch(ids, self._engine.spec)
+                batch.mean_length_controlled = host.mean_length_controlled
+                batch.sub_batches = [None] * len(np.unique(dataset.trace_type[np.asarray(ids)]))
+                success, loss = self._loss(host.to(self._engine.device), backward=True)
+            else:
+                success, loss = self._loss(batch, backward=True)
             if success and int(self._engine.status_buf[0].item()) != 0:
                 success = False
             if not success:

@@ -1,0 +1,163 @@
+"""Packed on-disk trace dataset (pyprob_amd/dataset.py): format round trip, the reference's sort order
+and sampler semantics, shard concatenation, minibatch packing. CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pyprob_amd.dataset import PackedTraceDataset, PackedTraceWriter, fnv1a64, trace_type_hash
+from pyprob_amd.packed import PackedBatch
+from pyprob_amd.parallel import DistributedTraceBatchSampler
+
+
+def ragged(n, seed, n_addr=5, max_len=4):
+    """Synthetic ragged traces: a trace of length L visits addresses start, start+1, ... (mod n_addr)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, max_len + 1, n)
+    start = rng.integers(0, 2, n)
+    ids = np.concatenate([(s + np.arange(L)) % n_addr for s, L in zip(start, lens)])
+    R = int(lens.sum())
+    value = rng.normal(size=R).astype(np.float32)
+    prior = np.stack([rng.normal(size=R), rng.uniform(0.5, 2.0, R)], 1).astype(np.float32)
+    obs = rng.normal(size=(n, 2)).astype(np.float32)
+    table = [('addr_%d' % a, 'Normal' if a % 2 == 0 else 'Uniform', None) for a in range(n_addr)]
+    return lens, table, ids, value, prior, obs
+
+
+def write(path, n, seed, **kw):
+    cols = ragged(n, seed, **kw)
+    with PackedTraceWriter(path, ['obs0', 'obs1'], [1, 1]) as w:
+        w.add_columns(*cols)
+    return cols
+
+
+def test_fnv_is_process_independent():
+    assert fnv1a64(b'') == 0xcbf29ce484222325
+    assert fnv1a64(b'a') == 0xaf63dc4c8601ec8c           # published FNV-1a test vector
+    assert trace_type_hash(['x', 'y']) != trace_type_hash(['xy'])
+
+
+def test_round_trip_and_sort_order(tmp_path):
+    lens, table, ids, value, prior, obs = write(str(tmp_path / 's0'), 500, 1)
+    ds = PackedTraceDataset(str(tmp_path / 's0'))
+    assert len(ds) == 500 and ds.obs_width == 2
+    meta = json.load(open(tmp_path / 's0' / 'meta.json'))
+    assert meta['n_rows'] == int(lens.sum()) and meta['version'] == 1
+    # sorted by (length, type hash), like OfflineDataset's sorted index (dataset.py:217-259)
+    hashes = np.asarray([h for h, _ in ds.trace_types], np.uint64)[ds.trace_type]
+    key = list(zip(ds.trace_len.tolist(), hashes.tolist()))
+    assert key == sorted(key)
+    assert np.array_equal(ds.sorted_indices(), np.arange(500))
+    # every stored trace is one of the written traces (multiset equality over (obs, values, addresses))
+    off = np.concatenate([[0], np.cumsum(lens)])
+    want = sorted((tuple(obs[i]), tuple(value[off[i]:off[i + 1]]), tuple(table[a][0] for a in ids[off[i]:off[i + 1]]))
+                  for i in range(500))
+    l2, a2, v2, p2, o2 = ds.gather(np.arange(500))
+    off2 = np.concatenate([[0], np.cumsum(l2)])
+    got = sorted((tuple(o2[i]), tuple(v2[off2[i]:off2[i + 1]]), tuple(ds.addresses[a][0] for a in a2[off2[i]:off2[i + 1]]))
+                 for i in range(500))
+    assert got == want
+    # gather honours the requested order and duplicates
+    sel = np.array([17, 3, 17, 499, 0])
+    l3, a3, v3, p3, o3 = ds.gather(sel)
+    assert np.array_equal(l3, l2[sel]) and np.array_equal(o3, o2[sel])
+    assert np.array_equal(v3[:l3[0]], v2[off2[17]:off2[18]])
+    assert np.array_equal(p3[l3[0]:l3[0] + l3[1]], p2[off2[3]:off2[4]])
+
+
+def test_shards_concatenate_with_different_address_tables(tmp_path):
+    write(str(tmp_path / 'a'), 200, 2, n_addr=3)
+    write(str(tmp_path / 'b'), 300, 3, n_addr=6)
+    ds = PackedTraceDataset(str(tmp_path))
+    assert len(ds) == 500 and len(ds.addresses) == 6
+    order = ds.sorted_indices()
+    assert sorted(order.tolist()) == list(range(500))
+    assert np.all(np.diff(ds.trace_len[order]) >= 0)
+    lens, addr, value, prior, obs = ds.gather(order[:64])
+    assert addr.max() < 6 and len(value) == lens.sum()
+    with pytest.raises(IndexError):
+        ds.gather([500])
+    with pytest.raises(ValueError):
+        ds.gather([])
+
+
+def test_pruned_trace_view_and_writer_from_traces(tmp_path):
+    write(str(tmp_path / 's'), 50, 4)
+    ds = PackedTraceDataset(str(tmp_path / 's'))
+    tr = ds[7]
+    lens, addr, value, prior, obs = ds.gather([7])
+    assert tr.length_controlled == lens[0] == len(tr.variables_controlled)
+    assert [v.address for v in tr.variables_controlled] == [ds.addresses[a][0] for a in addr]
+    assert np.allclose([float(v.value) for v in tr.variables_controlled], value)
+    assert np.allclose([float(tr.named_variables[n].value) for n in ('obs0', 'obs1')], obs[0])
+    d0 = tr.variables_controlled[0].distribution
+    assert d0.name == ds.addresses[addr[0]][1]
+    # Trace objects -> writer -> identical columns
+    with PackedTraceWriter(str(tmp_path / 't'), ['obs0', 'obs1']) as w:
+        for i in range(50):
+            w.add_trace(ds[i])
+    ds2 = PackedTraceDataset(str(tmp_path / 't'))
+    g1, g2 = ds.gather(np.arange(50)), ds2.gather(np.arange(50))
+    for k, (a, b) in enumerate(zip(g1, g2)):
+        if k == 1:      # address ids are per-file (first appearance): compare the address strings
+            assert [ds.addresses[i][0] for i in a] == [ds2.addresses[i][0] for i in b]
+        elif a.dtype.kind == 'f':
+            assert np.allclose(a, b, rtol=1e-6, atol=1e-6)
+        else:
+            assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        PackedTraceWriter(str(tmp_path / 'e'), ['obs0']).close()
+
+
+def test_sampler_partitions_like_the_reference(tmp_path):
+    write(str(tmp_path / 's'), 1000, 5)
+    ds = PackedTraceDataset(str(tmp_path / 's'))
+    world, bs = 2, 16
+    seen = []
+    for rank in range(world):
+        s = ds.sampler(bs, rank, world, num_buckets=4)
+        ref = DistributedTraceBatchSampler(ds.sorted_indices().tolist(), bs, rank, world, 4)
+        np.random.seed(0)
+        got = [list(b) for b in s]
+        np.random.seed(0)
+        assert got == [list(b) for b in ref]
+        for b in got:
+            assert len(b) == bs
+            assert ds.trace_len[b].max() - ds.trace_len[b].min() <= 1      # sorted by length: near-uniform minibatches
+        seen += [i for b in got for i in b]
+    assert len(seen) == len(set(seen))                                      # ranks take disjoint minibatches
+
+
+class _Spec:
+    def __init__(self, addresses):
+        self.addresses = addresses
+        self.address_id = {a[0]: i for i, a in enumerate(addresses)}
+
+
+def test_batch_matches_from_ragged_and_loader_prefetches(tmp_path):
+    write(str(tmp_path / 's'), 400, 6)
+    ds = PackedTraceDataset(str(tmp_path / 's'))
+    spec = _Spec(list(reversed(ds.addresses)))          # the network numbers addresses differently from the file
+    ids = ds.sorted_indices()[100:164]
+    pb = ds.batch(ids, spec)
+    lens, addr, value, prior, obs = ds.gather(ids)
+    remap = np.asarray([spec.address_id[a[0]] for a in ds.addresses])
+    ref = PackedBatch.from_ragged(lens, remap[addr], value, prior, obs, len(spec.addresses))
+    for name in ('obs', 'value', 'prior', 'addr', 'prev_row', 'trace', 'n_active', 'row_off', 'grp_rows', 'grp_off'):
+        assert np.array_equal(getattr(pb, name), getattr(ref, name)), name
+    assert ds.addresses_of(ids) and all(a in ds.addresses for a in ds.addresses_of(ids))
+
+    class Host(PackedBatch):
+        pass
+    # loader: same minibatches as the sampler, in order, then stops after `epochs`
+    import pyprob_amd.packed as P
+    uploaded = []
+    orig = P.PackedBatch.to
+    P.PackedBatch.to = lambda self, device: uploaded.append(self.n_traces) or self
+    try:
+        np.random.seed(1)
+        got = [b for b in ds.loader(spec, 32, 'cpu', epochs=2, prefetch=2, shuffle_batches=False)]
+    finally:
+        P.PackedBatch.to = orig
+    assert len(got) == 2 * (400 // 32) and uploaded == [32] * len(got)

@@ -112,3 +112,31 @@ def test_unknown_address_falls_back_to_prior(gum_trained):
         warnings.simplefilter('always')
         d = net._infer_step(Variable(distribution=prior, address='never_seen__Normal__1'))
     assert d is prior and len(w) == 1
+
+
+def test_offline_training_from_packed_dataset(tmp_path):
+    """Model.save_dataset -> packed shards -> learn_inference_network(dataset_dir=...) (reference: model.py:227-232,
+    nn/dataset.py:175-263): the packed minibatch gives the same loss as the same traces packed from Trace objects, and
+    offline training on a ragged program converges like online training."""
+    from pyprob_amd.dataset import PackedTraceDataset
+    from pyprob_amd.nn import Batch
+    torch.manual_seed(11)
+    model = GaussianWithUnknownMeanMarsaglia()
+    d = str(tmp_path / 'gumm')
+    assert model.save_dataset(d, 3000, 1000) == 3
+    ds = PackedTraceDataset(d)
+    assert len(ds) == 3000 and ds.obs_names == ['obs0', 'obs1']
+    assert np.all(np.diff(ds.trace_len[ds.sorted_indices()]) >= 0)
+    model.learn_inference_network(num_traces=20000, observe_embeddings=EMB, batch_size=100, lstm_dim=64, seed=3,
+                                  dataset_dir=d)
+    net = model._inference_network
+    assert len(net._engine.spec.addresses) >= 4
+    assert net._loss_previous < net._loss_init
+    assert net._total_train_traces >= 20000
+    # parity of the two packing routes on one minibatch
+    ids = ds.sorted_indices()[1500:1600]
+    known = [i for i in ids if all(a[0] in net._engine.spec.address_id for a in ds.addresses_of([i]))]
+    ok1, l1 = net._loss(ds.batch(known, net._engine.spec).to(net._engine.device))
+    ok2, l2 = net._loss(Batch([ds[i] for i in known]))
+    assert ok1 and ok2
+    assert abs(float(l1.item()) - float(l2.item())) < 1e-5 * max(1.0, abs(float(l2.item())))
