@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 1
+#define PP_ABI_VERSION 2
 #define PP_MAX_OBS 8
 
 /* error codes (negative; positive values are hipError_t) */
@@ -147,16 +147,26 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params /*d
 /*
  * torch.optim.Adam.step() over the flat buffer (pyprob/nn/inference_network.py:348,496), per-tensor skipping
  * of parameters whose grad is None (tensors that did not take part in the loss) and per-tensor step counts.
- *   chunk_tensor  dev [n_params/1024]  tensor id owning each 1024-float chunk (tensors are padded to 1024)
+ *   chunk_tensor  dev [n_params/1024]  tensor id owning each 1024-float chunk (tensors are padded to 1024 and laid
+ *                                      out in id order: the ids ascend)
  *   active        dev [n_tensors]      float >0 -> tensor has a gradient this step (DP: all-reduced presence map,
  *                                      pyprob/nn/inference_network.py:300-315)
  *   tensor_step   dev [n_tensors]      int32 Adam step count per tensor, incremented here when active
+ *   scratch       dev [PP_ADAM_SCRATCH * n_tensors] int32, opaque, owned by the optimizer state: ZERO before the
+ *                                      first call and whenever chunk_tensor changes (two-level arrival counters - the
+ *                                      last chunk of a tensor to finish advances its step count - and the cached
+ *                                      chunk run of each tensor)
  *   grad_scale    1/world_size for data-parallel averaging (:324-325), else 1
+ *   flags         PP_ADAM_ZERO_GRADS: clear every consumed gradient chunk (optimizer.zero_grad() of the next step,
+ *                 inference_network.py:486); the next pp_ic_loss can then run without PP_LOSS_ZERO_GRADS
+ * One launch (bias corrections are derived per chunk from the tensor's step count).
  */
-int pp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
-                 const int32_t* chunk_tensor, const float* active, int32_t* tensor_step,
-                 float* corr /*dev [2*n_tensors] scratch*/, int32_t n_tensors,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+#define PP_ADAM_ZERO_GRADS 1
+#define PP_ADAM_SCRATCH 40
+int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
+                 const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* scratch,
+                 int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                 int32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Importance sampling with the inference network, lock-step over N particles

@@ -45,9 +45,9 @@ int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int 
                     int32_t* nonfinite, hipStream_t st);
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out,
                   hipStream_t st);
-int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
-              const float* active, int32_t* tensor_step, float* corr, int n_tensors, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, hipStream_t st);
+int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
+              const float* active, int32_t* tensor_step, int32_t* arrived, int n_tensors, float lr, float beta1, float beta2,
+              float eps, float wd, float gscale, int flags, hipStream_t st);
 
 extern long long* g_timeline;   // kernels.hip
 
@@ -511,11 +511,12 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params, fl
                        pp::as_stream(stream));
 }
 
-int pp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
-                 const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, float* corr, int32_t n_tensors,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
-    return pp::adam_step(params, grads, exp_avg, exp_avg_sq, n_params, chunk_tensor, active, tensor_step, corr, n_tensors,
-                         lr, beta1, beta2, eps, weight_decay, grad_scale, pp::as_stream(stream));
+int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
+                 const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* arrived, int32_t n_tensors,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t flags,
+                 void* stream) {
+    return pp::adam_step(params, grads, exp_avg, exp_avg_sq, n_params, chunk_tensor, active, tensor_step, arrived, n_tensors,
+                         lr, beta1, beta2, eps, weight_decay, grad_scale, flags, pp::as_stream(stream));
 }
 
 int pp_colsum_f32(const float* X, int64_t ldx, const int32_t* row_idx, int32_t n_rows, int32_t n_cols, float* out,

@@ -967,37 +967,69 @@ int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* lo
 // Adam over the flat parameter buffer. Tensors are padded to 1024-float chunks; a chunk -> tensor map gives each
 // workgroup its tensor's presence flag and bias corrections (per-tensor step counts, as torch.optim.Adam keeps).
 // ------------------------------------------------------------------------------------------------------
-__global__ void adam_prepare_kernel(const float* __restrict__ active, int32_t* __restrict__ tensor_step,
-                                    float* __restrict__ corr, int n_tensors, float lr, float beta1, float beta2) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tensors) return;
-    if (active[t] > 0.0f) {
-        const int step = tensor_step[t] + 1;
-        tensor_step[t] = step;
-        const double bc1 = 1.0 - pow((double)beta1, (double)step);
-        const double bc2 = 1.0 - pow((double)beta2, (double)step);
-        corr[2 * t] = (float)((double)lr / bc1);
-        corr[2 * t + 1] = (float)(1.0 / sqrt(bc2));
-    } else {
-        corr[2 * t] = 0.0f;
-        corr[2 * t + 1] = 0.0f;
-    }
-}
-
-
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, const float* __restrict__ Gr,
-                                                   float* __restrict__ M, float* __restrict__ V,
-                                                   const int32_t* __restrict__ chunk_tensor,
-                                                   const float* __restrict__ active, const float* __restrict__ corr,
-                                                   float beta1, float beta2, float eps, float wd, float gscale) {
-    const int t = chunk_tensor[blockIdx.x];
-    if (t < 0 || !(active[t] > 0.0f)) return;
-    const float step_size = corr[2 * t], inv_sqrt_bc2 = corr[2 * t + 1];
-    const int64_t o = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+// One launch: the workgroup of a 1024-float chunk looks up its tensor, derives the bias corrections from the
+// tensor's step count (thread 0, double precision like torch.optim.Adam's Python floats), updates its chunk and -
+// as the LAST workgroup of that tensor to finish - advances the step count. Every workgroup reads the count before it
+// signals arrival, so all chunks of a tensor see the same step (a separate "prepare" launch did this before: 4.7 us of
+// a 170 us step). Arrival is counted in two levels, at most 32 workgroups per counter: same-address atomics
+// serialise at ~40 ns each and W_hh alone has 1024 chunks (a single counter per tensor made this kernel 68 us).
+// Optionally clears the gradient chunk it consumed (zero_grad of the NEXT step: saves a 6.5 MB memset launch).
+//
+// scratch, PP_ADAM_SCRATCH = 40 ints per tensor: [0..31] sub-counters (chunk index mod 32), [32] top counter,
+// [33] first chunk + 1 (0 = not cached yet), [34] number of chunks. All counters return to zero after every call.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float* __restrict__ Gr, float* __restrict__ M,
+                                                   float* __restrict__ V, const int32_t* __restrict__ chunk_tensor,
+                                                   int n_chunks, const float* __restrict__ active,
+                                                   int32_t* __restrict__ tensor_step, int32_t* __restrict__ scratch, float lr,
+                                                   float beta1, float beta2, float eps, float wd, float gscale,
+                                                   int zero_grads) {
+    __shared__ float s_corr[2];
+    const int b = blockIdx.x;
+    const int t = chunk_tensor[b];
+    if (t < 0 || !(active[t] > 0.0f)) return;   // workgroup-uniform; every chunk of a tensor takes the same branch
+    int32_t* const sc = scratch + (int64_t)t * PP_ADAM_SCRATCH;
+    // the chunk's loads are issued before thread 0 walks its dependent chain (step count, corrections)
+    const int64_t o = (int64_t)b * 1024 + threadIdx.x * 4;
     f32x4 p = *reinterpret_cast<f32x4*>(P + o);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gr + o);
     f32x4 m = *reinterpret_cast<f32x4*>(M + o);
     f32x4 v = *reinterpret_cast<f32x4*>(V + o);
+    int step_old = 0, first = 0, chunks = 0;
+    if (threadIdx.x == 0) {
+        first = __atomic_load_n(sc + 33, __ATOMIC_RELAXED) - 1;
+        chunks = __atomic_load_n(sc + 34, __ATOMIC_RELAXED);
+        if (first < 0) {
+            // chunks of one tensor are contiguous and the ids ascend: two binary searches (~20 dependent loads), done by
+            // every workgroup of the FIRST call only; the last one to arrive caches the run
+            int lo = 0, hi = b;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (chunk_tensor[mid] < t) lo = mid + 1; else hi = mid;
+            }
+            int lo2 = b, hi2 = n_chunks;
+            while (lo2 < hi2) {
+                const int mid = (lo2 + hi2) >> 1;
+                if (chunk_tensor[mid] <= t) lo2 = mid + 1; else hi2 = mid;
+            }
+            first = lo;
+            chunks = lo2 - lo;
+        }
+        step_old = __atomic_load_n(tensor_step + t, __ATOMIC_RELAXED);
+        const int step = step_old + 1;
+        // beta^step by repeated squaring (integer exponent): ~40 double multiplies instead of two generic pow() calls,
+        // which cost ~6 us on the single active lane every workgroup waits for
+        double p1 = 1.0, p2 = 1.0, q1 = (double)beta1, q2 = (double)beta2;
+        for (int e = step; e > 0; e >>= 1) {
+            if (e & 1) { p1 *= q1; p2 *= q2; }
+            q1 *= q1;
+            q2 *= q2;
+        }
+        const double bc1 = 1.0 - p1, bc2 = 1.0 - p2;
+        s_corr[0] = (float)((double)lr / bc1);
+        s_corr[1] = (float)(1.0 / sqrt(bc2));
+    }
+    __syncthreads();
+    const float step_size = s_corr[0], inv_sqrt_bc2 = s_corr[1];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float g = g0[e] * gscale;
@@ -1010,19 +1042,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, const 
     *reinterpret_cast<f32x4*>(P + o) = p;
     *reinterpret_cast<f32x4*>(M + o) = m;
     *reinterpret_cast<f32x4*>(V + o) = v;
+    if (zero_grads) *reinterpret_cast<f32x4*>(Gr + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x == 0) {
+        // no fence: the old step count was CONSUMED (bias corrections) before this point, so the load has completed; a
+        // device-scope __threadfence() here writes back / invalidates L2 in every workgroup (measured: 9 -> 66 us)
+        const int k = (b - first) & 31;                         // sub-counter of this chunk
+        const int quota = (chunks - k + 31) >> 5;               // chunks of the tensor that share it
+        if (atomicAdd(sc + k, 1) == quota - 1) {
+            __atomic_store_n(sc + k, 0, __ATOMIC_RELAXED);
+            if (atomicAdd(sc + 32, 1) == min(chunks, 32) - 1) {   // last chunk of the tensor: everyone has read the old count
+                __atomic_store_n(sc + 32, 0, __ATOMIC_RELAXED);
+                __atomic_store_n(sc + 33, first + 1, __ATOMIC_RELAXED);
+                __atomic_store_n(sc + 34, chunks, __ATOMIC_RELAXED);
+                __atomic_store_n(tensor_step + t, step_old + 1, __ATOMIC_RELAXED);
+            }
+        }
+    }
 }
 
-int adam_step(float* params, const float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
-              const float* active, int32_t* tensor_step, float* corr, int n_tensors, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, hipStream_t st) {
-    PP_CHECK_ARG(params && grads && m && v && chunk_tensor && active && tensor_step && corr, "pp_adam_step: null pointer");
+int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
+              const float* active, int32_t* tensor_step, int32_t* scratch, int n_tensors, float lr, float beta1, float beta2,
+              float eps, float wd, float gscale, int flags, hipStream_t st) {
+    PP_CHECK_ARG(params && grads && m && v && chunk_tensor && active && tensor_step && scratch, "pp_adam_step: null pointer");
     PP_CHECK_ARG(n_params % 1024 == 0, "pp_adam_step: n_params must be a multiple of 1024 (padded tensors)");
     if (n_tensors <= 0 || n_params == 0) return 0;
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(cdiv(n_tensors, 256)), dim3(256), 0, st, active, tensor_step, corr,
-                       n_tensors, lr, beta1, beta2);
-    PP_LAUNCH_CHECK("pp_adam_step(prepare)");
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(n_params / 1024)), dim3(256), 0, st, params, grads, m, v,
-                       chunk_tensor, active, corr, beta1, beta2, eps, wd, gscale);
+    const int n_chunks = (int)(n_params / 1024);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, params, grads, m, v, chunk_tensor, n_chunks,
+                       active, tensor_step, scratch, lr, beta1, beta2, eps, wd, gscale, (flags & PP_ADAM_ZERO_GRADS) ? 1 : 0);
     PP_LAUNCH_CHECK("pp_adam_step");
     return 0;
 }

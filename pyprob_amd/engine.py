@@ -55,7 +55,8 @@ class ICEngine:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.tensor_step = torch.zeros(spec.n_tensors, dtype=torch.int32, device=self.device)
-        self.corr = torch.zeros(2 * spec.n_tensors, dtype=torch.float32, device=self.device)
+        self.arrived = torch.zeros(L.PP_ADAM_SCRATCH * spec.n_tensors, dtype=torch.int32, device=self.device)   # pp_adam_step scratch
+        self._grads_clean = False      # the last Adam step cleared the gradient buffer (zero_grad of the next step)
         self.chunk_tensor = torch.from_numpy(spec.chunk_tensor_map()).to(self.device)
         self.addr_table = torch.from_numpy(spec.address_table()).to(self.device)
         self.net = spec.c_struct(self.addr_table.data_ptr())
@@ -113,8 +114,9 @@ class ICEngine:
         flags = 0
         if backward:
             flags |= L.PP_LOSS_BACKWARD
-            if zero_grads:
+            if zero_grads and not self._grads_clean:
                 flags |= L.PP_LOSS_ZERO_GRADS
+            self._grads_clean = False
         lp = None
         if keep_lp:
             flags |= L.PP_LOSS_KEEP_LP
@@ -138,22 +140,25 @@ class ICEngine:
         self.active.copy_(act)
         self._active_key = key
 
-    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, zero_grads=False):
         """optimizer.step() for optim.Adam (inference_network.py:348,496); grads are divided by world_size first
-        when data-parallel (inference_network.py:324-325)."""
+        when data-parallel (inference_network.py:324-325). zero_grads=True also performs the NEXT step's
+        optimizer.zero_grad() (:486) in the same pass: the consumed gradient chunks are cleared, gradients of tensors
+        without a gradient this step are zero already."""
         rc = self.lib.pp_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                    self.exp_avg_sq.data_ptr(), self.spec.n_params, self.chunk_tensor.data_ptr(),
-                                   self.active.data_ptr(), self.tensor_step.data_ptr(), self.corr.data_ptr(),
+                                   self.active.data_ptr(), self.tensor_step.data_ptr(), self.arrived.data_ptr(),
                                    self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
-                                   L.stream_ptr())
+                                   L.PP_ADAM_ZERO_GRADS if zero_grads else 0, L.stream_ptr())
         L.check(rc, 'pp_adam_step')
+        self._grads_clean = bool(zero_grads)
 
     def train_step(self, batch, lr, weight_decay=0.0):
         """zero_grad -> loss -> backward -> [all-reduce] -> Adam (inference_network.py:486-496). No host sync."""
         loss = self.loss(batch, backward=True)
         if self.world_size > 1 or self.force_allreduce:
             self.allreduce_grads()
-        self.adam_step(lr, weight_decay=weight_decay)
+        self.adam_step(lr, weight_decay=weight_decay, zero_grads=True)
         return loss
 
     # ---- HIP graph replay of the step (static shapes) ------------------------------------------------------------

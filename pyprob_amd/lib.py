@@ -6,11 +6,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 1
+PP_ABI_VERSION = 2
 PP_MAX_OBS = 8
 PP_ADDR_TABLE_COLS = 8
 PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL = 0, 1, 2
 PP_LOSS_BACKWARD, PP_LOSS_ZERO_GRADS, PP_LOSS_KEEP_LP = 1, 2, 4
+PP_ADAM_ZERO_GRADS = 1
+PP_ADAM_SCRATCH = 40          # int32 per tensor (include/pyprob_amd.h)
 PP_IS_STATS_SCRATCH = 1536   # doubles (include/pyprob_amd.h)
 
 i32, i64, f32p, i32p, vp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p
@@ -64,7 +66,7 @@ PROTOTYPES = {
     'pp_ic_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32, i32]),
     'pp_ic_loss': (C.c_int, [C.POINTER(pp_net), C.POINTER(pp_batch), vp, vp, vp, C.c_size_t, vp, vp, vp, i32, vp]),
     'pp_adam_step': (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
-                               C.c_float, C.c_float, vp]),
+                               C.c_float, C.c_float, i32, vp]),
     'pp_is_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32]),
     'pp_is_init': (C.c_int, [C.POINTER(pp_net), vp, vp, vp, vp, C.c_size_t, vp]),
     'pp_is_step': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, C.c_uint64,

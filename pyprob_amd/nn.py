@@ -353,7 +353,7 @@ class InferenceNetworkLSTM:
                 continue
             if world > 1:
                 self._engine.allreduce_grads()                                        # :494-495
-            self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay)
+            self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True)
             loss = float(loss.item()) / (world if world > 1 else 1)                  # tail is the all-reduced SUM
             now = time.time()
             if self._loss_init is None:

@@ -180,6 +180,30 @@ def test_adam_matches_torch_semantics():
             np.testing.assert_array_equal(sd[n].numpy(), params[n])
 
 
+def test_adam_clears_consumed_gradients_and_train_step_skips_the_memset():
+    """PP_ADAM_ZERO_GRADS: the optimizer pass performs the next step's zero_grad (inference_network.py:486). Two engines
+    from the same parameters - one zeroing in pp_ic_loss every step, one relying on Adam's clearing - stay identical."""
+    meta, params, batch, loss, isr = load_golden('gumm')
+    a, b = engine_from_golden(meta, params), engine_from_golden(meta, params)
+    pa, pb_ = (packed_from_golden(meta, batch, e.spec).to(e.device) for e in (a, b))
+    for step in range(3):
+        a.loss(pa, backward=True)                  # explicit zero_grad inside pp_ic_loss
+        a.adam_step(1e-3)
+        b.train_step(pb_, lr=1e-3)                 # Adam clears, the next loss runs without PP_LOSS_ZERO_GRADS
+        assert b._grads_clean
+        assert float(b.grads.abs().max().item()) == 0.0
+        assert int(b.arrived.view(-1, 40)[:, :33].abs().max().item()) == 0     # arrival counters reset themselves
+    sa, sb = a.state_dict(), b.state_dict()
+    # float atomics make the last bits of a gradient run-dependent: compare with the tolerance of one Adam step
+    assert max(rel_err(sa[n].numpy(), sb[n].numpy()) for n in sa) < 1e-4
+    assert torch.equal(a.tensor_step, b.tensor_step)
+    g = b.loss(pb_, backward=True)                 # flag consumed: this call must NOT see stale gradients
+    ga = a.loss(pa, backward=True)
+    assert abs(float(g.item()) - float(ga.item())) < 1e-5 * abs(float(ga.item()))
+    gb, gaa = b.grad_dict(), a.grad_dict()
+    assert max(rel_err(gb[n], gaa[n]) for n in gb) < 1e-3
+
+
 def test_train_steps_track_the_oracle():
     """Three full train steps (loss -> backward -> Adam) against the oracle doing the same in float64: the loss
     trajectory agrees; parameters agree up to Adam's sign-sensitivity for near-zero gradients."""

@@ -1,5 +1,7 @@
 cd /root/repo
-for i in 1 2; do python tools/host_time.py | tail -1; PP_NO_T0_BLOCKS=1 python tools/host_time.py | tail -1; done
+timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python tools/host_time.py | tail -2
+python bench.py --workload train_gumm --steps 200 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_g -o e -- python /root/repo/bench.py --steps 100 --warmup 20 --no-cpu-baseline > /root/repo/gpurun_out/e.log 2>&1; python /root/repo/tools/prof_top.py /root/repo/gpurun_out/prof_g/e_results.db "%gemm%" 2>&1 | head -8
+rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_g -o e -- python /root/repo/bench.py --steps 100 --warmup 20 --no-cpu-baseline > /root/repo/gpurun_out/e.log 2>&1; python /root/repo/tools/prof_top.py /root/repo/gpurun_out/prof_g/e_results.db "%adam%" 2>&1 | head -3
 rm -rf /root/repo/gpurun_out/prof_g
