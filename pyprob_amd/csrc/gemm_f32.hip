@@ -895,6 +895,7 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = by * DT, n0 = bx * DT;
+    if (p.dbg && tid == 0 && bx == 1 && by == 1 && bz == 0) p.dbg[32] = clock64();   // debug phase stamps
     const int nslab_total = (p.K + BK - 1) / BK;
     const int per = (nslab_total + nz - 1) / nz;
     const int s_begin = bz * per;
@@ -909,12 +910,20 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
     DirectOperand<B_KM, VEC> ob;
     oa.init(p.A, p.lda, p.a_idx, m0, p.M, lane, red + wave * DSLAB);
     ob.init(p.B, p.ldb, p.b_idx, n0, p.N, lane, red + (4 + wave) * DSLAB);
+    // (A three-deep register ring - three slabs of loads in flight - was tried: 182 VGPRs and no gain. Phase stamps of
+    // the head-layer product, tools/timeline5.py: init 0.7 us, issuing the first loads 1.2 us (~900 instructions of
+    // address arithmetic and edge predication), first data 2-3 us after issue (operands come from another XCD's L2 /
+    // HBM), the remaining slabs < 0.2 us: the kernel is start-up latency, not the K loop.)
+#define DSTAMP(k) do { if (p.dbg && tid == 0 && bx == 1 && by == 1 && bz == 0) p.dbg[32 + (k)] = clock64(); } while (0)
+    DSTAMP(1);
     float ga[16], gb[16], a[16], b[16];
     int s = s_begin + wave;
     if (s < s_end) {
         oa.fetch(ga, s * BK, p.K);
         ob.fetch(gb, s * BK, p.K);
     }
+    DSTAMP(2);
+    bool first_slab = true;
     while (s < s_end) {
         oa.put(ga);
         ob.put(gb);
@@ -932,7 +941,10 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+        if (first_slab) { DSTAMP(3); first_slab = false; }
     }
+    if (p.dbg && acc[0] == 123456.789f) p.dbg[63] = 1;   // debug: the stamp must follow the last MFMA
+    DSTAMP(4);
     __syncthreads();   // the partial tiles reuse the staging area
     // partial tiles -> LDS (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     float* mine = red + wave * DT * DPAD;
