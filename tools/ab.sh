@@ -1,6 +1,5 @@
 cd /root/repo
-timeout 800 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q 2>&1 | tail -3
-python tools/host_time.py | tail -2
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_g -o e -- python /root/repo/bench.py --steps 100 --warmup 20 --no-cpu-baseline > /root/repo/gpurun_out/e.log 2>&1; python /root/repo/tools/prof_top.py /root/repo/gpurun_out/prof_g/e_results.db "%direct%" 2>&1 | head -3
-rm -rf /root/repo/gpurun_out/prof_g
+timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+for m in 0 1 0 1; do echo "aux $m"; PP_AUX_STREAM=$m python tools/host_time.py | tail -1; done
+for m in 0 1; do PP_AUX_STREAM=$m python bench.py --workload train_gumm --steps 200 --warmup 30 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; done
+PP_AUX_STREAM=1 python bench.py --graph 1 --steps 200 --warmup 20 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('graph', d['ms_per_step'], d['value'])"
