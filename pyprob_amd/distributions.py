@@ -51,7 +51,9 @@ class Normal(Distribution):
         loc, scale = _t(loc).float(), _t(scale).float()
         if scale.device != loc.device:
             scale = scale.to(loc.device)
-        super().__init__('Normal', 'Normal', torch.distributions.Normal(loc, scale))
+        # per-particle parameters of a lock-step run may hold stale (even NaN) entries for particles that are not on the
+        # current control-flow path: no argument validation for vectors
+        super().__init__('Normal', 'Normal', torch.distributions.Normal(loc, scale, validate_args=None if loc.numel() == 1 else False))
 
     def _device(self):
         return self._torch_dist.loc.device

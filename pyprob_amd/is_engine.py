@@ -60,6 +60,7 @@ class ISRunner:
             self.c = torch.empty(n, H, dtype=torch.float32, device=self.dev)
             self.n = n
         self.prev_value = None
+        self.last_value = None
         self.state_rows = 1
         self.offset = int(offset)
         self._ensure_ws(n)
@@ -79,9 +80,56 @@ class ISRunner:
         L.check(rc, 'pp_is_step')
         self.state_rows = 1 if prev_addr_id is None else n   # see include/pyprob_amd.h
         self.prev_value = value
+        self.last_value = value
+        return value, logq
+
+    def step_rows(self, rows, addr_id, prev_addr_id, prior, seed=0):
+        """The same statement for a SUBSET of the particles (a diverged control-flow path): the rows' LSTM state and
+        previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor."""
+        m = int(rows.numel())
+        if self.state_rows == 1 and self.n > 1 and prev_addr_id is not None:
+            self.h[1:] = self.h[0]      # the shared first-statement state (row 0) becomes per-particle
+            self.c[1:] = self.c[0]
+            self.state_rows = self.n
+        h = self.h.index_select(0, rows)
+        c = self.c.index_select(0, rows)
+        prev = None if (prev_addr_id is None or self.prev_value is None) else self.prev_value.index_select(0, rows).contiguous()
+        if prior is not None and prior.shape[0] != 1:
+            prior = prior.index_select(0, rows).contiguous()
+        stride = 0 if (prior is None or prior.shape[0] == 1) else 1
+        value = torch.empty(m, dtype=torch.float32, device=self.dev)
+        logq = torch.empty(m, dtype=torch.float32, device=self.dev)
+        self._ensure_ws(m)
+        rc = self.lib.pp_is_step(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id),
+                                 -1 if prev_addr_id is None else int(prev_addr_id), m, self.e_obs.data_ptr(),
+                                 L.ptr(prev), L.ptr(prior), stride, h.data_ptr(), c.data_ptr(),
+                                 1 if prev_addr_id is None else m, None, value.data_ptr(), logq.data_ptr(), int(seed),
+                                 self.offset, self.ws.data_ptr(), self.ws_bytes, L.stream_ptr())
+        L.check(rc, 'pp_is_step')
+        if prev_addr_id is None:     # the call left the (shared) new state in row 0
+            h = h[:1].expand(m, -1)
+            c = c[:1].expand(m, -1)
+        self.h.index_copy_(0, rows, h)
+        self.c.index_copy_(0, rows, c)
         return value, logq
 
     # ---- log-weight terms ---------------------------------------------------------------------------------
+    def accumulate_masked(self, lw, kind, p0, p1, x, active, scale=1.0):
+        """accumulate() for the active particles of a diverged path: the term is evaluated for every particle (stale
+        entries of inactive particles may be anything) and added where `active` (None = everywhere)."""
+        if active is None:
+            return self.accumulate(lw, kind, p0, p1, x, scale=scale)
+        n = lw.numel()
+        lp = torch.empty(n, dtype=torch.float32, device=self.dev)
+
+        def s(t):
+            return 0 if t.numel() == 1 else 1
+        rc = self.lib.pp_logweight_accumulate(int(kind), p0.data_ptr(), s(p0), p1.data_ptr(), s(p1), x.data_ptr(), s(x),
+                                              1.0, None, lp.data_ptr(), n, L.stream_ptr())
+        L.check(rc, 'pp_logweight_accumulate')
+        lw.add_(torch.where(active, lp, torch.zeros_like(lp)), alpha=float(scale))
+
+
     def accumulate(self, lw, kind, p0, p1, x, scale=1.0):
         """lw += scale * log_prob(dist(p0, p1); x); p0/p1/x are device tensors of 1 (broadcast) or n elements."""
         n = lw.numel()

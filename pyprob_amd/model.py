@@ -49,7 +49,11 @@ class Model:
         return traces.finalize()
 
     def _traces_lockstep(self, num_traces, observe, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
-        """All particles of this rank advance through forward() together (straight-line programs)."""
+        """All particles of this rank advance through forward() together. A program whose control flow depends on
+        sampled values (written with tensor conditions: `while s >= 1:`) is executed once per distinct control-flow
+        path: an execution serves the particles that agree at every branch, the others are queued and re-run with their
+        recorded values as replay prefix (state.LockStepState). Every new sample statement is one C-ABI call for the
+        path's particles - the general batched IS executor of SURVEY.md 8f.2."""
         net = self._inference_network
         runner = net._is
         ls = state.LockStepState(runner, num_traces, seed, offset)
@@ -57,15 +61,36 @@ class Model:
                            inference_engine=InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
                            inference_network=net, observe=observe, likelihood_importance=likelihood_importance, lock_step=ls)
         runner.begin(num_traces, offset=offset)
-        state._begin_trace()
+        values = None
+        n_paths = 0
         try:
-            result = self.forward(*args, **kwargs)
+            while True:
+                state._begin_trace()
+                result = self.forward(*args, **kwargs)
+                n_paths += 1
+                if not torch.is_tensor(result):
+                    raise RuntimeError('lock-step importance sampling: forward() must return a per-particle tensor')
+                result = result.as_subclass(torch.Tensor).reshape(-1).to(runner.dev, torch.float32)
+                if ls.active is None:
+                    values = result.clone() if result.numel() == num_traces else result.expand(num_traces).clone()
+                else:
+                    if values is None:
+                        values = torch.zeros(num_traces, dtype=torch.float32, device=runner.dev)
+                    values = torch.where(ls.active, result.expand(num_traces) if result.numel() == 1 else result, values)
+                if not ls.pending:
+                    break
+                if n_paths > 4096:
+                    raise RuntimeError('lock-step importance sampling: more than 4096 control-flow paths')
+                active, decisions, st_done, ob_done = ls.pending.pop()
+                ls.path_id += 1
+                ls.start_path(active, decisions, st_done, ob_done)
         finally:
             state._lock_step = None
             state._current_trace = None
-        emp = Empirical(values=result, log_weights=ls.lw)
+        emp = Empirical(values=values, log_weights=ls.lw)
         emp.finalize()
-        emp.device_stats = runner.stats(ls.lw, result if torch.is_tensor(result) else None)
+        emp.device_stats = runner.stats(ls.lw, values)
+        emp.num_paths = n_paths
         return emp
 
     def prior_results(self, num_traces=10, *args, **kwargs):

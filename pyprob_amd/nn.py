@@ -244,27 +244,80 @@ class InferenceNetworkLSTM:
         return ProposalSample(value.cpu(), logq.cpu())
 
     def _infer_step_lockstep(self, address, distribution, ls):
+        """One controlled sample statement of a lock-step run for the ACTIVE particles of the current execution path:
+        LSTM step + proposal + draw + log q in one C-ABI call (all particles, or the gathered rows of a diverged path),
+        then lw += log p(v) - log q(v) (state.py:211-217). A statement inside the replayed prefix of a path returns the
+        values recorded when a superset of these particles executed it. Returns a ParticleTensor [n]."""
+        from .state import ParticleTensor
         spec = self._engine.spec
-        if address not in spec.address_id:
-            raise RuntimeError('lock-step importance sampling: no proposal for address {}'.format(address))
+        runner = ls.runner
+        j = ls.statement
+        ls.statement += 1
+        if j < ls.replay_statements:
+            values, a = ls.log[j][address]
+            if a is not None:
+                ls.prev_addr_id = a
+                runner.prev_value = runner.last_value = values
+            return ParticleTensor.wrap(values)
+        prev_unknown = getattr(ls, 'prev_unknown', False)
+        ls.prev_unknown = address not in spec.address_id
+        if ls.prev_unknown or prev_unknown:
+            # no proposal layers for this address or for the previous one (never seen in training): the prior is the
+            # proposal, log p - log q = 0, and the LSTM state is not advanced (inference_network_lstm.py:100-104, 132-134)
+            warnings.warn('Using prior. No proposal for address: {}'.format(address))
+            entry = ls.log[j].get(address) if j < len(ls.log) else None
+            values = entry[0] if entry is not None else torch.zeros(ls.n, dtype=torch.float32, device=runner.dev)
+            draw = distribution.sample()
+            draw = torch.as_tensor(draw, dtype=torch.float32).reshape(-1)
+            if draw.numel() == 1:     # shared prior: one draw per particle
+                draw = distribution._torch_dist.sample((ls.n,)).reshape(-1).float()
+            draw = draw.to(runner.dev)
+            values = draw if ls.active is None else torch.where(ls.active, draw, values)
+            while len(ls.log) <= j:
+                ls.log.append({})
+            ls.log[j][address] = (values, spec.address_id.get(address))
+            if not ls.prev_unknown:      # a known address after an unknown one: it is the next statement's "previous"
+                ls.prev_addr_id = spec.address_id[address]
+                runner.prev_value = runner.last_value = values
+            return ParticleTensor.wrap(values)
         a = spec.address_id[address]
         prior = self._prior_tensor(distribution)
-        value, logq = ls.runner.step(a, ls.prev_addr_id, prior, seed=ls.seed + 7919 * ls.statement)
+        seed = ls.seed + 7919 * j + 104729 * ls.path_id
+        if ls.active is None:
+            value, logq = runner.step(a, ls.prev_addr_id, prior, seed=seed)
+            values = value
+        else:
+            entry = ls.log[j].get(address) if j < len(ls.log) else None
+            values = entry[0] if entry is not None else torch.zeros(ls.n, dtype=torch.float32, device=runner.dev)
+            value, logq = runner.step_rows(ls.rows, a, ls.prev_addr_id, prior, seed=seed)
+            values.index_copy_(0, ls.rows, value)
+        while len(ls.log) <= j:
+            ls.log.append({})
+        ls.log[j][address] = (values, a)
+        runner.prev_value = runner.last_value = values     # previous-sample embedding input of the next statement (full size)
+        self._accumulate_prior(ls, distribution, values)             # + log p(value)   state.py:211
+        if ls.active is None:
+            runner.axpy(ls.lw, -1.0, logq)                           # - log q(value)   state.py:212,217
+        else:
+            ls.lw.index_add_(0, ls.rows, logq, alpha=-1.0)
         ls.prev_addr_id = a
-        ls.statement += 1
-        return value, logq, a
+        return ParticleTensor.wrap(values)
 
     def _accumulate_prior(self, ls, distribution, value):
         dev = self._engine.device
         if distribution.name == 'Normal':
-            ls.runner.accumulate(ls.lw, 0, distribution.mean.reshape(-1).to(dev), distribution.stddev.reshape(-1).to(dev), value)
+            kind, p0, p1 = 0, distribution.mean, distribution.stddev
         elif distribution.name == 'Uniform':
-            ls.runner.accumulate(ls.lw, 1, distribution.low.reshape(-1).to(dev), distribution.high.reshape(-1).to(dev), value)
-        else:
+            kind, p0, p1 = 1, distribution.low, distribution.high
+        else:   # e.g. Categorical: scored on the host
             lp = distribution.log_prob(value.cpu()).to(dev, torch.float32).contiguous()
+            if ls.active is not None:
+                lp = torch.where(ls.active, lp, torch.zeros_like(lp))
             ls.runner.axpy(ls.lw, 1.0, lp)
+            return
+        ls.runner.accumulate_masked(ls.lw, kind, torch.as_tensor(p0).reshape(-1).to(dev), torch.as_tensor(p1).reshape(-1).to(dev),
+                                    value, ls.active)
 
-    # ---- optimisation ---------------------------------------------------------------------------------------
     def _learning_rate(self):
         """POLY1 / POLY2 decay driven by the trace count (inference_network.py:357-379, :568)."""
         t = self._learning_rate_scheduler_type

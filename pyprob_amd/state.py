@@ -68,17 +68,79 @@ def _extract_address_from_caller():
     return '{}__{}'.format(ip, '__'.join(reversed(names)))
 
 
+class ParticleTensor(torch.Tensor):
+    """A per-particle value of a lock-step run: an ordinary tensor (every torch op works and keeps the type) whose truth
+    value is a BRANCH of the program. `while s >= 1:` on N particles asks the executor (LockStepState.branch): if the
+    active particles agree that is the answer, otherwise the run splits - this execution continues with the particles
+    that said True, the others are re-run later down the other branch with their recorded values."""
+
+    @staticmethod
+    def wrap(t):
+        return t if isinstance(t, ParticleTensor) else torch.as_tensor(t).as_subclass(ParticleTensor)
+
+    def __bool__(self):
+        plain = self.as_subclass(torch.Tensor)
+        ls = _lock_step
+        if ls is None or plain.numel() != ls.n:
+            return bool(plain)
+        return ls.branch(plain)
+
+
 class LockStepState:
-    """Per-call state of lock-step importance sampling: particle count, log-weight accumulator, IS runner."""
+    """State of a lock-step importance-sampling run over n particles (particles with stochastic control
+    flow served in address-grouped batches).
+
+    All per-particle quantities are full-size [n] tensors. One EXECUTION of the program follows one control-flow path
+    for the particles in `active`; statements already executed for these particles (a prefix shared with an earlier
+    execution) are REPLAYED from the statement log instead of being sampled again. `pending` holds the paths still to
+    run: (active mask, recorded branch decisions, statements done, observes done)."""
 
     def __init__(self, runner, n, seed, offset):
         self.runner = runner
         self.n = n
         self.seed = seed
         self.offset = offset
-        self.statement = 0
-        self.prev_addr_id = None
         self.lw = torch.zeros(n, dtype=torch.float32, device=runner.dev)
+        self.log = []                 # per statement index: {address: (values [n], address id)}
+        self.pending = []
+        self.path_id = 0
+        self.start_path(None, [], 0, 0)
+
+    def start_path(self, active, decisions, statements_done, observes_done):
+        self.active = active          # bool [n] on the device, or None = every particle
+        self.rows = None if active is None else torch.nonzero(active).reshape(-1)
+        self.n_active = self.n if active is None else int(self.rows.numel())
+        self.decisions = list(decisions)
+        self.decisions_seen = 0
+        self.replay_statements = statements_done
+        self.replay_observes = observes_done
+        self.statement = 0
+        self.observes = 0
+        self.prev_addr_id = None
+        self.prev_unknown = False
+
+    def branch(self, cond):
+        """Truth value of a per-particle condition for the active particles (ParticleTensor.__bool__)."""
+        k = self.decisions_seen
+        self.decisions_seen += 1
+        if k < len(self.decisions):
+            return self.decisions[k]             # replayed prefix: this path already knows its way
+        c = cond.reshape(-1).to(self.runner.dev) != 0
+        t = c if self.active is None else (c & self.active)
+        n_true = int(t.sum().item())
+        if n_true == self.n_active:
+            decision = True
+        elif n_true == 0:
+            decision = False
+        else:   # diverge: the False side is queued with everything this execution has done so far as its replay prefix
+            other = ~c if self.active is None else (self.active & ~c)
+            self.pending.append((other, self.decisions + [False], self.statement, self.observes))
+            self.active = t
+            self.rows = torch.nonzero(t).reshape(-1)
+            self.n_active = n_true
+            decision = True
+        self.decisions.append(decision)
+        return decision
 
 
 def observe(distribution, value=None, name=None, address=None):
@@ -98,15 +160,17 @@ def observe(distribution, value=None, name=None, address=None):
         ls = _lock_step
         dev = ls.runner.dev
         v = torch.as_tensor(value, dtype=torch.float32).reshape(-1).to(dev)
-        if isinstance(distribution, Normal):
-            ls.runner.accumulate(ls.lw, 0, distribution.mean.reshape(-1).to(dev), distribution.stddev.reshape(-1).to(dev), v,
-                                 scale=_likelihood_importance)
-        elif isinstance(distribution, Uniform):
-            ls.runner.accumulate(ls.lw, 1, distribution.low.reshape(-1).to(dev), distribution.high.reshape(-1).to(dev), v,
-                                 scale=_likelihood_importance)
-        else:
-            raise RuntimeError('lock-step importance sampling supports Normal and Uniform likelihoods; got {}'.format(
-                distribution.name))
+        ls.observes += 1
+        if ls.observes > ls.replay_observes:      # (a replayed prefix has already been scored for these particles)
+            if isinstance(distribution, Normal):
+                kind, p0, p1 = 0, distribution.mean, distribution.stddev
+            elif isinstance(distribution, Uniform):
+                kind, p0, p1 = 1, distribution.low, distribution.high
+            else:
+                raise RuntimeError('lock-step importance sampling supports Normal and Uniform likelihoods; got {}'.format(
+                    distribution.name))
+            ls.runner.accumulate_masked(ls.lw, kind, torch.as_tensor(p0).reshape(-1).to(dev), torch.as_tensor(p1).reshape(-1).to(dev),
+                                        v, ls.active, scale=_likelihood_importance)
         variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
                             log_prob=None, log_importance_weight=None, observed=True, name=name)
         _current_trace.add(variable)
@@ -144,9 +208,7 @@ def sample(distribution, name=None, address=None, control=True):
             raise RuntimeError('lock-step mode runs controlled samples with the inference network only')
         ls = _lock_step
         net = _current_trace_inference_network
-        value, logq, addr_id = net._infer_step_lockstep(addr, distribution, ls)
-        net._accumulate_prior(ls, distribution, value)             # + log p(value)   state.py:211
-        ls.runner.axpy(ls.lw, -1.0, logq)                          # - log q(value)   state.py:212,217
+        value = net._infer_step_lockstep(addr, distribution, ls)   # samples, scores and weights (or replays) the statement
         variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
                             log_prob=None, control=True, name=name)
         _current_trace.add(variable)

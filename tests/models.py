@@ -56,3 +56,18 @@ class CategoricalThenNormal(Model):
         pyprob.observe(likelihood, name='obs0')
         pyprob.observe(likelihood, name='obs1')
         return mu
+
+
+class GaussianWithUnknownMeanMarsagliaLockStep(GaussianWithUnknownMeanMarsaglia):
+    """The same program with the rejection loop written as a tensor condition (`while s >= 1:` instead of
+    `while float(s) >= 1:`): runs unchanged one particle at a time AND with all particles in lock step, where the
+    condition is a per-particle branch (pyprob_amd.state.ParticleTensor)."""
+
+    def marsaglia(self, mean, stddev):
+        uniform = Uniform(-1, 1)
+        s = 1
+        while s >= 1:
+            x = pyprob.sample(uniform)
+            y = pyprob.sample(uniform)
+            s = x * x + y * y
+        return mean + stddev * (x * torch.sqrt(-2 * torch.log(s) / s))

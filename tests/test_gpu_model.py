@@ -140,3 +140,50 @@ def test_offline_training_from_packed_dataset(tmp_path):
     ok2, l2 = net._loss(Batch([ds[i] for i in known]))
     assert ok1 and ok2
     assert abs(float(l1.item()) - float(l2.item())) < 1e-5 * max(1.0, abs(float(l2.item())))
+
+
+def test_lockstep_with_stochastic_control_flow():
+    """a program whose control flow depends on sampled values runs in lock step, one execution per
+    distinct control-flow path. Same addresses/network as the per-trace engine; the posterior agrees with the per-trace
+    run and with the analytic posterior of the Gaussian-unknown-mean model."""
+    from models import GaussianWithUnknownMeanMarsagliaLockStep
+    torch.manual_seed(13)
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    model.learn_inference_network(num_traces=30000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=4)
+    obs = {'obs0': 4, 'obs1': 5}
+    n = 20000
+    post = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=5)
+    assert post.num_paths >= 2                              # the rejection loop diverged
+    lw = post.device_stats
+    assert lw['count'] == n                                 # every particle finished with a finite weight
+    # analytic posterior of mu | y0, y1 with prior N(1, 5), likelihood N(mu, 2): precision 1/5 + 2/2
+    prec = 1 / 5 + 2 / 2
+    mean = (1 / 5 + (4 + 5) / 2) / prec
+    assert abs(post.mean - mean) < 0.4
+    assert abs(post.stddev - np.sqrt(1 / prec)) < 0.4
+    assert post.effective_sample_size > 0.02 * n
+    torch.manual_seed(6)
+    ref = model.posterior_results(300, IC, observe=obs)     # one particle per forward(), like the reference
+    assert abs(ref.mean - post.mean) < 0.6
+    # particles are independent: two runs with different seeds give different draws, same statistics
+    post2 = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=6)
+    assert abs(post2.mean - post.mean) < 0.2
+    assert not torch.equal(post2.values_tensor() if hasattr(post2, 'values_tensor') else post2._values, post._values)
+
+
+def test_lockstep_unknown_address_uses_the_prior():
+    """Deep iterations of the rejection loop hit addresses the network never trained on: the prior is the proposal
+    there (inference_network_lstm.py:100-104), the weights stay finite and the run completes."""
+    from models import GaussianWithUnknownMeanMarsagliaLockStep
+    import warnings
+    torch.manual_seed(17)
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    model.learn_inference_network(num_traces=600, observe_embeddings=EMB, batch_size=100, lstm_dim=64, seed=5)
+    known = len(model._inference_network._engine.spec.addresses)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        post = model.posterior_results(200000, IC, observe={'obs0': 4, 'obs1': 5}, lock_step=True, seed=2)
+    assert post.num_paths > known // 2                      # deeper paths than the network has heads for
+    assert any('Using prior' in str(x.message) for x in w)
+    assert post.device_stats['count'] == 200000
+    assert np.isfinite(post.mean) and abs(post.mean - 3.917) < 1.5
