@@ -307,45 +307,89 @@ class PackedTraceDataset:
                     out.append(self.addresses[a])
         return out
 
-    def loader(self, spec, batch_size, device, rank=0, world_size=1, num_buckets=None, prefetch=4, epochs=None,
-               shuffle_batches=True, shuffle_buckets=True):
-        """Iterator of device PackedBatches: a background thread walks the sampler and packs minibatches on the host
-        (`gather` + `from_ragged`, numpy releases the GIL in the copies), the consumer uploads them (one float and one
-        int32 copy per batch, `PackedBatch.to`). `epochs=None` repeats forever like the reference's training loop."""
+    def loader(self, spec, batch_size, device, rank=0, world_size=1, num_buckets=None, prefetch=6, epochs=None,
+               shuffle_batches=True, shuffle_buckets=True, workers=1):
+        """Iterator of device PackedBatches, in sampler order. `workers` background threads take minibatch index lists
+        from the sampler, pack them on the host (`gather` + `from_ragged`) and UPLOAD them (one H2D copy per batch on a
+        side stream; numpy and the copy release the GIL), so the consumer only enqueues training steps. More than one
+        worker does not help: the packing is many small numpy calls and the threads contend for the GIL with the
+        consumer (measured: 2.06 / 2.00 / 1.37 M traces/s with 1 / 2 / 3 workers). `epochs=None` repeats forever like
+        the reference's training loop."""
+        import torch
         sampler = self.sampler(batch_size, rank, world_size, num_buckets, shuffle_batches, shuffle_buckets)
-        q = queue.Queue(maxsize=max(int(prefetch), 1))
+        on_gpu = torch.device(device).type == 'cuda'
+        lock = threading.Condition()
+        state = dict(next_seq=0, done=False, error=None, want=0)
+        ready = {}                       # seq -> (batch, event)
         stop = threading.Event()
 
-        def produce():
+        def tickets():
+            e = 0
+            while epochs is None or e < epochs:
+                for ids in sampler:
+                    yield ids
+                e += 1
+        source = tickets()
+
+        def work():
+            stream = torch.cuda.Stream(device=device) if on_gpu else None
             try:
-                e = 0
-                while not stop.is_set() and (epochs is None or e < epochs):
-                    for ids in sampler:
+                while not stop.is_set():
+                    with lock:
+                        while not stop.is_set() and state['next_seq'] - state['want'] >= max(int(prefetch), 1):
+                            lock.wait(0.05)      # bounded look-ahead
                         if stop.is_set():
                             return
-                        q.put(self.batch(ids, spec))
-                    e += 1
-                q.put(None)
+                        try:
+                            ids = next(source)
+                        except StopIteration:
+                            state['done'] = True
+                            lock.notify_all()
+                            return
+                        seq = state['next_seq']
+                        state['next_seq'] += 1
+                    host = self.batch(ids, spec)
+                    ev = None
+                    if on_gpu:
+                        with torch.cuda.stream(stream):
+                            host.to(device)
+                            ev = torch.cuda.Event()
+                            ev.record(stream)
+                    else:
+                        host.to(device)
+                    with lock:
+                        ready[seq] = (host, ev)
+                        lock.notify_all()
             except BaseException as exc:   # surfaced in the consumer
-                q.put(exc)
+                with lock:
+                    state['error'] = exc
+                    lock.notify_all()
 
-        th = threading.Thread(target=produce, daemon=True)
-        th.start()
+        threads = [threading.Thread(target=work, daemon=True) for _ in range(max(int(workers), 1))]
+        for th in threads:
+            th.start()
         try:
             while True:
-                item = q.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                yield item.to(device)
+                with lock:
+                    while state['want'] not in ready and state['error'] is None and \
+                            not (state['done'] and state['want'] >= state['next_seq']):
+                        lock.wait(0.05)
+                    if state['error'] is not None:
+                        raise state['error']
+                    if state['want'] not in ready:
+                        return
+                    batch, ev = ready.pop(state['want'])
+                    state['want'] += 1
+                    lock.notify_all()
+                if ev is not None:
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(ev)
+                    batch.dev['_buf'].record_stream(cur)    # allocated on the worker's stream, consumed on this one
+                yield batch
         finally:
             stop.set()
-            while not q.empty():
-                try:
-                    q.get_nowait()
-                except queue.Empty:
-                    break
+            with lock:
+                lock.notify_all()
 
     # ---- OfflineDataset compatibility (slow path) ---------------------------------------------------------
     def __getitem__(self, i):

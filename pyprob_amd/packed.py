@@ -89,12 +89,16 @@ class PackedBatch:
         """Upload (one float buffer + one int32 buffer) and build the C struct. PyTorch is the allocator."""
         import torch
         B, R = self.n_traces, self.n_rows
-        fl = np.concatenate([self.obs.reshape(-1), self.value, self.prior.reshape(-1)]).astype(np.float32)
         nx = len(self.nxt_rows)
-        it = np.concatenate([self.addr, self.prev_row, self.grp_rows, self.trace, self.row_off,
-                             self.nxt_rows if nx else np.zeros(1, np.int32)]).astype(np.int32)
-        f = torch.from_numpy(fl).to(device, non_blocking=False)
-        i = torch.from_numpy(it).to(device, non_blocking=False)
+        nf = B * self.obs.shape[1] + 3 * R
+        # ONE host buffer and ONE copy: float columns first, then the int32 index columns (bit patterns in a float32 array)
+        host = np.empty(nf + 4 * R + (self.t_max + 1) + max(nx, 1), np.float32)
+        host[:nf] = np.concatenate([self.obs.reshape(-1), self.value, self.prior.reshape(-1)])
+        host[nf:].view(np.int32)[:] = np.concatenate([self.addr, self.prev_row, self.grp_rows, self.trace, self.row_off,
+                                                      self.nxt_rows if nx else np.zeros(1, np.int32)])
+        buf = torch.from_numpy(host).to(device, non_blocking=False)
+        f = buf[:nf]
+        i = buf[nf:].view(torch.int32)
         ow = self.obs.shape[1]
         d = {}
         d['obs'] = f[:B * ow].view(B, ow)
@@ -105,7 +109,7 @@ class PackedBatch:
                         ('nxt_rows', max(nx, 1))):
             d[name] = i[o:o + n]
             o += n
-        d['_f'], d['_i'] = f, i
+        d['_f'], d['_i'], d['_buf'] = f, i, buf
         self.dev = d
         self._fill_struct(ow)
         return self

@@ -65,7 +65,7 @@ try:
         torch.cuda.synchronize()
         t5 = time.perf_counter()
         steps = 0
-        for b in ds.loader(eng.spec, B, dev, epochs=1, prefetch=8):
+        for b in ds.loader(eng.spec, B, dev, epochs=1, prefetch=8, workers=int(os.environ.get('PP_LOADER_WORKERS', '2'))):
             eng.train_step(b, 1e-3)
             steps += 1
             if steps == 400:
