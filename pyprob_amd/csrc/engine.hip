@@ -32,7 +32,9 @@ int obs_grad(const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max
              const float* E, int64_t lde, float* dE, int64_t ldde, hipStream_t st);
 int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st, int c_prev_shared = 0);
 int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
-                  int H, float* db, float* db2, hipStream_t st);
+                  int H, float* db, float* db2, hipStream_t st, const float* fin_acc = nullptr,
+                  const int32_t* fin_flag = nullptr, int fin_traces = 0, float* fin_loss = nullptr,
+                  int32_t* fin_status = nullptr);
 int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
                  int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
                  hipStream_t st);
@@ -353,8 +355,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                             (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr, bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr,
                             w.loss_acc, w.flag, st));
     }
-    PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
-    if (!bwd) return 0;
+    if (!bwd) {
+        PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
+        return 0;
+    }
+    // (with a backward pass the loss slots are folded by the first LSTM-cell launch below)
     // (the bias / table column sums queued in `cs` are launched once, at the end of the backward pass)
 
     // ---------------- backward ----------------
@@ -390,8 +395,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
         float* Gt = w.G + (int64_t)r0 * 4 * H;
         const float* c_prev = t > 0 ? w.C + (int64_t)bt->row_off[t - 1] * H : nullptr;
+        const bool fin = t == T - 1;
         PP_TRY(lstm_cell_bwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.dH + (int64_t)r0 * H, w.dC, n, n_next, H,
-                             grads + net->b_ih, grads + net->b_hh, st));   // bias gradients fused
+                             grads + net->b_ih, grads + net->b_hh, st, fin ? w.loss_acc : nullptr, w.flag, B, loss_out,
+                             status_out));   // bias gradients fused
         if (t > 0)  // dh_{t-1} += dG_t W_hh
             PP_TRY(linear_dgrad(Gt, 4 * H, P + net->w_hh, w.dH + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0, n,
                                 H, 4 * H, true, st));

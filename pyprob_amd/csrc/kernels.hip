@@ -330,12 +330,25 @@ int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int 
     return 0;
 }
 
+struct LossFinalize {   // loss = sum of the 64 accumulator slots / B, status = non-finite flag (see loss_finalize_kernel)
+    const float* acc; const int32_t* flag; float inv_b; float* loss_out; int32_t* status_out;
+};
+
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ G, const float* __restrict__ c_prev,
                                                             const float* __restrict__ c,
                                                             const float* __restrict__ dh,
                                                             float* __restrict__ dc_carry, int n, int n_next, int H,
-                                                            float* __restrict__ db, float* __restrict__ db2) {
+                                                            float* __restrict__ db, float* __restrict__ db2,
+                                                            LossFinalize fin) {
     __shared__ float part[4][4][64];
+    // the backward pass's first cell launch also turns the loss slots into the loss (one launch less per step)
+    if (fin.acc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (int k = 0; k < 64; ++k) tot += fin.acc[k];
+        const float l = tot * fin.inv_b;
+        fin.loss_out[0] = l;
+        if (fin.status_out) fin.status_out[0] = (fin.flag[0] != 0 || !isfinite(l)) ? 1 : 0;
+    }
     const int jl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -373,11 +386,13 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ 
 }
 
 int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
-                  int H, float* db, float* db2, hipStream_t st) {
+                  int H, float* db, float* db2, hipStream_t st, const float* fin_acc, const int32_t* fin_flag,
+                  int fin_traces, float* fin_loss, int32_t* fin_status) {
     PP_CHECK_ARG(G && c && dh && dc_carry && H > 0 && n_next <= n, "pp_lstm_cell_bwd: bad argument");
     if (n <= 0) return 0;
+    LossFinalize fin{fin_acc, fin_flag, fin_traces > 0 ? 1.0f / (float)fin_traces : 0.0f, fin_loss, fin_status};
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(H, 64), cdiv(n, CELL_ROWS)), dim3(256), 0, st, G, c_prev, c, dh,
-                       dc_carry, n, n_next, H, db, db2);
+                       dc_carry, n, n_next, H, db, db2, fin);
     PP_LAUNCH_CHECK("pp_lstm_cell_bwd");
     return 0;
 }
