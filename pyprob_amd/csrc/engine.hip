@@ -1,6 +1,7 @@
 // Host-side orchestration behind the C ABI: InferenceNetworkLSTM._loss (+ backward) as a chain of HIP kernels over
 // the step-major packed trace batch. No allocation, no host synchronisation: every launch goes to the caller's stream.
 #include "common.hpp"
+#include "gather.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -56,7 +57,7 @@ extern long long* g_timeline;   // kernels.hip
 // obs_embed.hip
 bool obs_fused_supported(const pp_net* net);
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
-                        float* cat, float* f1, float* E, hipStream_t st);
+                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows = nullptr);
 int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
                           const float* f1, const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max,
                           const float* E, float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
@@ -278,10 +279,24 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     if (bwd && (flags & PP_LOSS_ZERO_GRADS)) (void)hipMemsetAsync(grads, 0, (size_t)net->n_params * sizeof(float), st);
 
     // ---------------- forward ----------------
-    PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
-    // (also clears the loss slots and, for a backward pass, dX: see the kernel)
-    PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
-                             bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), 128));
+    // First kernel: observe embedding; for small embeddings the same launch assembles the LSTM input rows of its traces
+    // and clears the loss slots and (backward) dX. Otherwise embedding GEMMs + the stand-alone gather kernel.
+    const bool fused_obs = obs_fused_supported(net);
+    if (fused_obs && T <= 2) {   // (long traces: a wave would write all rows of its trace serially - separate gather)
+        RowBuild rb{};
+        rb.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+        rb.params = P; rb.at = net->addr_table; rb.row_off = bt->row_off_dev; rb.t_max = T;
+        rb.value = bt->value; rb.addr = bt->addr; rb.prev_row = bt->prev_row;
+        rb.X = w.X; rb.ldx = w.i4;
+        rb.zero_like = bwd ? w.dX : nullptr;
+        rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = 128;
+        PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb));
+    } else {
+        PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
+        // (also clears the loss slots and, for a backward pass, dX: see the kernel)
+        PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
+                                 bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), 128));
+    }
     prof_begin(0, st);
     PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st));
     prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);

@@ -3,6 +3,7 @@
 // sampling (Philox4x32-10), proposal / prior / likelihood log-probs, per-particle log-weight accumulation and the
 // wavefront-reduced importance statistics (ESS, weighted mean / variance).
 #include "common.hpp"
+#include "gather.hpp"
 
 #include <math.h>
 #include <string.h>
@@ -19,7 +20,7 @@ int lstm_input_gather(const pp_net* net, const float* params, const float* E, in
 int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st, int c_prev_shared = 0);
 bool obs_fused_supported(const pp_net* net);
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
-                        float* cat, float* f1, float* E, hipStream_t st);
+                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows = nullptr);
 
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
 

@@ -2,6 +2,7 @@
 // proposal transforms + mixture log-prob with a wavefront-reduced loss accumulator, column reductions for bias /
 // embedding-table gradients, flat Adam. All fp32, gfx950 wave64.
 #include "common.hpp"
+#include "gather.hpp"
 
 #include <math.h>
 #include <stdarg.h>
@@ -108,26 +109,6 @@ int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int 
 // One thread per output element; consecutive lanes write consecutive columns (coalesced row writes); the
 // embedding rows are looked up through the per-address offset table (address dispatch).
 // ------------------------------------------------------------------------------------------------------
-struct GatherDims {
-    int e_obs, smp, dtype, addr, I;
-};
-
-__device__ __forceinline__ float sample_embed_elem(const float* __restrict__ params, const int64_t* __restrict__ at,
-                                                   int a, int j, float v) {
-    const int smp_in = (int)at[a * PP_ADDR_TABLE_COLS + PP_AT_SMP_IN];
-    const float* w = params + at[a * PP_ADDR_TABLE_COLS + PP_AT_SMP_W];
-    const float* b = params + at[a * PP_ADDR_TABLE_COLS + PP_AT_SMP_B];
-    float s;
-    if (smp_in == 1) {
-        s = w[j] * v + b[j];
-    } else {
-        int c = (int)v;
-        c = c < 0 ? 0 : (c >= smp_in ? smp_in - 1 : c);
-        s = w[j * smp_in + c] + b[j];
-    }
-    return fmaxf(s, 0.0f);
-}
-
 __global__ __launch_bounds__(256) void lstm_input_gather_kernel(
     GatherDims d, const float* __restrict__ params, const int64_t* __restrict__ at, const float* __restrict__ E,
     int64_t e_stride, const int32_t* __restrict__ trace, const float* __restrict__ value,
@@ -144,12 +125,10 @@ __global__ __launch_bounds__(256) void lstm_input_gather_kernel(
         const int r = (int)(e / d.I);
         const int c = (int)(e - (int64_t)r * d.I);
         float out;
-        const int c1 = d.e_obs, c2 = c1 + d.smp, c3 = c2 + d.dtype, c4 = c3 + d.addr, c5 = c4 + d.dtype;
-        if (c < c1) {
+        if (c < d.e_obs) {
             const int64_t b = trace ? (int64_t)trace[r] : (int64_t)r;
             out = E[b * e_stride + c];
-        } else if (c < c4) {
-            // previous-variable part
+        } else {
             int ap;
             float v = 0.0f;
             if (prev_row) {
@@ -160,19 +139,7 @@ __global__ __launch_bounds__(256) void lstm_input_gather_kernel(
                 ap = fixed_prev_addr;
                 if (ap >= 0) v = value[r];
             }
-            if (ap < 0) {
-                out = 0.0f;
-            } else if (c < c2) {
-                out = sample_embed_elem(params, at, ap, c - c1, v);
-            } else if (c < c3) {
-                out = params[at[ap * PP_ADDR_TABLE_COLS + PP_AT_DTYPE_EMB] + (c - c2)];
-            } else {
-                out = params[at[ap * PP_ADDR_TABLE_COLS + PP_AT_ADDR_EMB] + (c - c3)];
-            }
-        } else {
-            const int a = addr ? addr[r] : fixed_addr;
-            if (c < c5) out = params[at[a * PP_ADDR_TABLE_COLS + PP_AT_DTYPE_EMB] + (c - c4)];
-            else out = params[at[a * PP_ADDR_TABLE_COLS + PP_AT_ADDR_EMB] + (c - c5)];
+            out = gather_embedding_elem(d, params, at, c, ap, v, addr ? addr[r] : fixed_addr);
         }
         X[(int64_t)r * ldx + c] = out;
         if (zero_like) zero_like[(int64_t)r * ldx + c] = 0.0f;

@@ -7,6 +7,7 @@
 // weight-gradient rows in registers across its traces, combines the four waves with LDS float atomics and flushes one
 // atomic per parameter per workgroup. Larger embeddings take the generic GEMM path (engine.hip).
 #include "common.hpp"
+#include "gather.hpp"
 
 #include <stdlib.h>
 
@@ -122,10 +123,14 @@ __device__ __forceinline__ float obs_dense(const float* lds, const ObsLayer& L, 
 __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a, const float* __restrict__ P,
                                                             const float* __restrict__ obs, int n_traces,
                                                             int traces_per_wave, float* __restrict__ cat,
-                                                            float* __restrict__ f1, float* __restrict__ E) {
+                                                            float* __restrict__ f1, float* __restrict__ E,
+                                                            const RowBuild rb) {
     __shared__ float lds[10240];
     warm_kernargs((int)sizeof(ObsFusedArgs) + 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // training step: this is the first kernel - clear the loss slots that later kernels add into
+    if (rb.zero_small && blockIdx.x == 0)
+        for (int q = tid; q < rb.n_small; q += 256) rb.zero_small[q] = 0.0f;
     obs_stage_all(a, P, lds, tid);
     __syncthreads();
     const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
@@ -159,6 +164,27 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
         if (acte) f1[(int64_t)b * a.e_ld + lane] = y1;
         const float y2 = obs_dense(lds, a.f1, lane, acte, y1, 0);
         if (acte) E[(int64_t)b * a.e_ld + lane] = y2;
+        if (rb.X) {
+            // LSTM input rows of this trace, one per time step it is alive in (step-major rows: row_off[t] + b): the
+            // embedding just computed sits in lane c < e_obs, the address / previous-sample columns come from the tables
+            // (a separate gather launch did this before: one launch and one read of E less). Also clears dX.
+            for (int t = 0; t < rb.t_max; ++t) {
+                const int r0 = rb.row_off[t];
+                if (b >= rb.row_off[t + 1] - r0) break;   // wave-uniform
+                const int r = r0 + b;
+                const int pr = rb.prev_row[r];
+                const int ap = pr < 0 ? -1 : rb.addr[pr];
+                const float v = pr < 0 ? 0.0f : rb.value[pr];
+                const int ad = rb.addr[r];
+                float* xr = rb.X + (int64_t)r * rb.ldx;
+                if (acte) xr[lane] = y2;
+                for (int c = rb.d.e_obs + lane; c < rb.d.I; c += 64) xr[c] = gather_embedding_elem(rb.d, rb.params, rb.at, c, ap, v, ad);
+                if (rb.zero_like) {
+                    float* zr = rb.zero_like + (int64_t)r * rb.ldx;
+                    for (int c = lane; c < rb.d.I; c += 64) zr[c] = 0.0f;
+                }
+            }
+        }
     }
 }
 
@@ -305,12 +331,14 @@ static int pick_traces_per_wave(int n, int target_blocks) {
 
 // obs_h: host array of n_obs device pointers; E/cat/f1 leading dim = round4(e_obs)
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
-                        float* cat, float* f1, float* E, hipStream_t st) {
+                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows) {
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
     const int tpw = pick_traces_per_wave(n_traces, 256);   // forward: staging is cheap, spread the traces
+    RowBuild rb{};
+    if (rows) rb = *rows;
     hipLaunchKernelGGL(obs_embed_fwd_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat,
-                       f1, E);
+                       f1, E, rb);
     PP_LAUNCH_CHECK("obs_embed_fwd_fused");
     return 0;
 }
