@@ -186,23 +186,52 @@ class _Shard:
         self.n = int(self.meta['n_traces'])
 
 
+class _MemoryShard:
+    """The columns of one shard held in memory (vectorised online generation): same attributes as _Shard."""
+
+    def __init__(self, obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs):
+        w = PackedTraceWriter(None, obs_names, obs_widths)
+        w.add_columns(trace_len, address_table, address_ids, values, prior, obs)
+        self.meta = dict(version=FORMAT_VERSION, n_traces=int(len(trace_len)), obs_names=list(obs_names),
+                         obs_widths=[int(x) for x in w.obs_widths],
+                         addresses=[dict(address=a, distribution=d, n_categories=c) for a, d, c in w._addr_table],
+                         trace_types=[dict(hash='%016x' % h, address_ids=list(k)) for h, k in w._types])
+        self.trace_len = np.asarray(trace_len, np.int32)
+        self.trace_type = np.concatenate(w._type).astype(np.int32)
+        self.row_off = np.concatenate([[0], np.cumsum(self.trace_len.astype(np.int64))])
+        self.obs = np.asarray(obs, np.float32).reshape(len(trace_len), -1)
+        self.value = np.asarray(values, np.float32).reshape(-1)
+        self.prior = np.asarray(prior, np.float32).reshape(-1, 2)
+        self.addr = np.concatenate(w._addr).astype(np.int32)
+        self.n = int(len(trace_len))
+
+
 class PackedTraceDataset:
     """All shards under `dataset_dir` (or an explicit list of shard directories) as one indexable dataset.
 
     Mirrors OfflineDataset (dataset.py:175-263): `len(ds)`, `ds[i]` (a pruned Trace, slow path), sorted indices for the
     sampler; plus the vectorised `gather` / `batch` / `loader` the hot path uses."""
 
+    @classmethod
+    def from_columns(cls, obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs):
+        """An in-memory dataset from ragged columns (e.g. Model.prior_traces_packed): no files, same interface."""
+        return cls([_MemoryShard(obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs)])
+
     def __init__(self, dataset_dir):
-        if isinstance(dataset_dir, (list, tuple)):
-            paths = list(dataset_dir)
+        if isinstance(dataset_dir, (list, tuple)) and dataset_dir and not isinstance(dataset_dir[0], str):
+            paths, shards = [], list(dataset_dir)      # ready-made shard objects
+        elif isinstance(dataset_dir, (list, tuple)):
+            paths, shards = list(dataset_dir), None
         elif os.path.exists(os.path.join(dataset_dir, 'meta.json')):
-            paths = [dataset_dir]
+            paths, shards = [dataset_dir], None
         else:
-            paths = sorted(os.path.join(dataset_dir, d) for d in os.listdir(dataset_dir)
-                           if os.path.exists(os.path.join(dataset_dir, d, 'meta.json')))
-        if not paths:
-            raise RuntimeError('no packed trace shards in {}'.format(dataset_dir))
-        self._shards = [_Shard(p) for p in paths]
+            paths, shards = sorted(os.path.join(dataset_dir, d) for d in os.listdir(dataset_dir)
+                                   if os.path.exists(os.path.join(dataset_dir, d, 'meta.json'))), None
+        if shards is None:
+            if not paths:
+                raise RuntimeError('no packed trace shards in {}'.format(dataset_dir))
+            shards = [_Shard(p) for p in paths]
+        self._shards = shards
         first = self._shards[0].meta
         self.obs_names, self.obs_widths = first['obs_names'], first['obs_widths']
         self.obs_width = int(sum(self.obs_widths))
@@ -425,6 +454,31 @@ class PackedTraceDataset:
         tr.length = len(tr.variables)
         tr.length_controlled = len(tr.variables_controlled)
         return tr
+
+
+class VectorisedOnlineDataset:
+    """OnlineDataset (pyprob/nn/dataset.py:50-62) without the one-forward()-per-trace loop: chunks of `chunk_traces`
+    prior traces are generated in lock step (Model.prior_traces_packed) and served as an in-memory PackedTraceDataset;
+    `refresh()` draws the next chunk (online training never sees a trace twice)."""
+
+    def __init__(self, model, obs_names, chunk_traces=65536, device='cpu'):
+        self._model, self.obs_names, self._chunk, self._device = model, list(obs_names), int(chunk_traces), device
+        self.generated = 0
+        self.refresh()
+
+    def refresh(self):
+        cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device)
+        self._ds = PackedTraceDataset.from_columns(self.obs_names, None, *cols)
+        self.generated += self._chunk
+
+    def __len__(self):
+        return int(1e9)
+
+    def __getitem__(self, i):
+        return self._ds[i % len(self._ds)]
+
+    def __getattr__(self, name):        # gather / batch / sampler / addresses_of / sorted_indices / trace_type ...
+        return getattr(self._ds, name)
 
 
 def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=None, *args, **kwargs):

@@ -77,13 +77,8 @@ class Model:
                     if values is None:
                         values = torch.zeros(num_traces, dtype=torch.float32, device=runner.dev)
                     values = torch.where(ls.active, result.expand(num_traces) if result.numel() == 1 else result, values)
-                if not ls.pending:
+                if not ls.next_path():
                     break
-                if n_paths > 4096:
-                    raise RuntimeError('lock-step importance sampling: more than 4096 control-flow paths')
-                active, decisions, st_done, ob_done = ls.pending.pop()
-                ls.path_id += 1
-                ls.start_path(active, decisions, st_done, ob_done)
         finally:
             state._lock_step = None
             state._current_trace = None
@@ -92,6 +87,26 @@ class Model:
         emp.device_stats = runner.stats(ls.lw, values)
         emp.num_paths = n_paths
         return emp
+
+    def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, **kwargs):
+        """num_traces traces of the program in PRIOR_FOR_INFERENCE_NETWORK mode, generated TOGETHER (one execution of
+        forward() per distinct control-flow path, state.PriorLockStep) and returned as ragged columns
+        (trace_len, address table, address ids, values, prior parameters, observations) - what a training minibatch is
+        packed from. The vectorised replacement of OnlineDataset's one-forward()-per-trace loop
+        (pyprob/nn/dataset.py:50-62). The program must be lock-step safe (tensor conditions)."""
+        ls = state.PriorLockStep(num_traces, device)
+        state._init_traces(func=self.forward, trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, lock_step=ls)
+        try:
+            while True:
+                state._begin_trace()
+                self.forward(*args, **kwargs)
+                ls.finish_path()
+                if not ls.next_path():
+                    break
+        finally:
+            state._lock_step = None
+            state._current_trace = None
+        return ls.columns(obs_names)
 
     def prior_results(self, num_traces=10, *args, **kwargs):
         return self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=trace_result, *args, **kwargs)
@@ -122,12 +137,24 @@ class Model:
                                 proposal_mixture_components=10, learning_rate_init=0.001, learning_rate_end=1e-6,
                                 learning_rate_scheduler_type=None, weight_decay=0., distributed_backend=None,
                                 device='cuda:0', seed=None, dataset=None, log_file_name=None, dataset_dir=None,
-                                distributed_num_buckets=None):
+                                distributed_num_buckets=None, vectorised_prior=None, prior_chunk_traces=None):
         """pyprob/model.py:186-215 with inference_network=InferenceNetwork.LSTM. `dataset_dir` = a directory written by
         `save_dataset` (packed shards, pyprob_amd/dataset.py): offline training like the reference's OfflineDataset."""
         if dataset is None and dataset_dir is not None:
             from .dataset import PackedTraceDataset
             dataset = PackedTraceDataset(dataset_dir)
+        if dataset is None and vectorised_prior is not False and observe_embeddings:
+            # online training: generate prior traces in lock step (one forward() per control-flow path and chunk) when
+            # the program allows it - it must not turn sampled values into Python scalars; else one trace per forward()
+            from .dataset import VectorisedOnlineDataset
+            try:
+                self.prior_traces_packed(8, list(observe_embeddings.keys()))
+                dataset = VectorisedOnlineDataset(self, list(observe_embeddings.keys()),
+                                                  chunk_traces=prior_chunk_traces or max(64 * batch_size, 16384))
+            except Exception as exc:   # noqa: BLE001 - any failure of the probe means "not lock-step safe"
+                if vectorised_prior:
+                    raise
+                print('Prior traces are generated one forward() at a time (program is not lock-step safe: {})'.format(exc))
         if dataset is None:
             dataset = OnlineDataset(model=self)
         if self._inference_network is None:

@@ -377,6 +377,9 @@ class InferenceNetworkLSTM:
                 try:
                     ids = next(sampler_iter)
                 except StopIteration:
+                    if hasattr(dataset, 'refresh'):                                   # online: fresh prior traces
+                        dataset.refresh()
+                        sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
                     sampler_iter = iter(sampler)                                      # next epoch (:461-464)
                     ids = next(sampler_iter)
                 new = [a for a in dataset.addresses_of(ids) if a[0] not in self._engine.spec.address_id]

@@ -5,10 +5,12 @@ Module-global trace state, `sample` / `observe`, address extraction from the cal
   * per-trace mode  -- one particle / one prior trace per run of `forward()`, as pyprob does (state.py:158-293,
                        118-155); the IC branch (state.py:203-219) calls `InferenceNetworkLSTM._infer_step`, which
                        is one `pp_is_step` C call (LSTM step + head + sample + log q) with n = 1;
-  * lock-step mode  -- N particles run `forward()` ONCE with N-wide device tensors as values (straight-line
-                       programs such as GaussianUnknownMean): every `sample` is one `pp_is_step` for all particles,
-                       every `observe` one fused log-prob/accumulate kernel. Programs with data-dependent Python
-                       control flow must use per-trace mode.
+  * lock-step mode  -- N particles run `forward()` with N-wide tensors as values (ParticleTensor): every `sample`
+                       is one `pp_is_step` for all particles of the current control-flow path, every `observe` one
+                       fused log-prob/accumulate kernel. A per-particle condition (`while s >= 1:`) splits the run
+                       into one execution per distinct path (LockStepState). The same machinery generates PRIOR
+                       traces for training N at a time (PriorLockStep: vectorised OnlineDataset).
+                       Programs that turn sampled values into Python scalars (`float(s)`) must use per-trace mode.
 
 MCMC engines, prior inflation, `tag`/`factor` and the address dictionary are out of scope.
 """
@@ -86,28 +88,22 @@ class ParticleTensor(torch.Tensor):
         return ls.branch(plain)
 
 
-class LockStepState:
-    """State of a lock-step importance-sampling run over n particles (particles with stochastic control
-    flow served in address-grouped batches).
+class PathExecutor:
+    """Control-flow bookkeeping shared by the lock-step executors: one EXECUTION of the program follows one
+    control-flow path for the particles in `active`; statements already executed for these particles (a prefix shared
+    with an earlier execution) are REPLAYED from the statement log instead of being sampled again. `pending` holds the
+    paths still to run: (active mask, recorded branch decisions, statements done, observes done)."""
 
-    All per-particle quantities are full-size [n] tensors. One EXECUTION of the program follows one control-flow path
-    for the particles in `active`; statements already executed for these particles (a prefix shared with an earlier
-    execution) are REPLAYED from the statement log instead of being sampled again. `pending` holds the paths still to
-    run: (active mask, recorded branch decisions, statements done, observes done)."""
-
-    def __init__(self, runner, n, seed, offset):
-        self.runner = runner
+    def __init__(self, n, device):
         self.n = n
-        self.seed = seed
-        self.offset = offset
-        self.lw = torch.zeros(n, dtype=torch.float32, device=runner.dev)
-        self.log = []                 # per statement index: {address: (values [n], address id)}
+        self.dev = device
+        self.log = []                 # per statement index: {address: recorded values ...}
         self.pending = []
         self.path_id = 0
         self.start_path(None, [], 0, 0)
 
     def start_path(self, active, decisions, statements_done, observes_done):
-        self.active = active          # bool [n] on the device, or None = every particle
+        self.active = active          # bool [n], or None = every particle
         self.rows = None if active is None else torch.nonzero(active).reshape(-1)
         self.n_active = self.n if active is None else int(self.rows.numel())
         self.decisions = list(decisions)
@@ -119,13 +115,24 @@ class LockStepState:
         self.prev_addr_id = None
         self.prev_unknown = False
 
+    def next_path(self):
+        """Switch to the next queued path; False when none is left."""
+        if not self.pending:
+            return False
+        active, decisions, st_done, ob_done = self.pending.pop()
+        self.path_id += 1
+        if self.path_id > 4096:
+            raise RuntimeError('lock-step execution: more than 4096 control-flow paths')
+        self.start_path(active, decisions, st_done, ob_done)
+        return True
+
     def branch(self, cond):
         """Truth value of a per-particle condition for the active particles (ParticleTensor.__bool__)."""
         k = self.decisions_seen
         self.decisions_seen += 1
         if k < len(self.decisions):
             return self.decisions[k]             # replayed prefix: this path already knows its way
-        c = cond.reshape(-1).to(self.runner.dev) != 0
+        c = cond.reshape(-1).to(self.dev) != 0
         t = c if self.active is None else (c & self.active)
         n_true = int(t.sum().item())
         if n_true == self.n_active:
@@ -143,6 +150,129 @@ class LockStepState:
         return decision
 
 
+class LockStepState(PathExecutor):
+    """Lock-step importance sampling over n particles (particles with stochastic control flow served
+    in address-grouped batches). All per-particle quantities are full-size [n] device tensors."""
+    mode = 'is'
+
+    def __init__(self, runner, n, seed, offset):
+        self.runner = runner
+        self.seed = seed
+        self.offset = offset
+        self.lw = torch.zeros(n, dtype=torch.float32, device=runner.dev)
+        super().__init__(n, runner.dev)
+
+
+def _vector_draw(distribution, n):
+    """n independent draws: one per particle for shared parameters, elementwise for per-particle parameters."""
+    td = distribution._torch_dist
+    batch = td.batch_shape.numel() if len(td.batch_shape) else 1
+    draw = td.sample((n,)).reshape(-1) if batch == 1 else td.sample().reshape(-1)
+    return draw.float()
+
+
+def _vector_params(distribution, n, device):
+    """Prior parameters as the proposal heads read them (packed.distribution_params), one row per particle."""
+    name = distribution.name
+    if name == 'Normal':
+        p = (distribution.mean, distribution.stddev)
+    elif name == 'Uniform':
+        p = (distribution.low, distribution.high)
+    elif name == 'Categorical':
+        p = (torch.zeros(1), torch.zeros(1))
+    else:
+        raise RuntimeError('Distribution currently unsupported: {}'.format(name))
+    return [torch.as_tensor(q, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(device).expand(n) for q in p]
+
+
+class PriorLockStep(PathExecutor):
+    """n PRIOR traces generated together (trace mode PRIOR_FOR_INFERENCE_NETWORK, pyprob/nn/dataset.py:50-62 run n
+    times): every `sample` draws from the prior for the particles of the current control-flow path, every `observe`
+    draws the synthetic observation; per path the statement list is recorded, so the traces come out directly as the
+    ragged columns a minibatch is packed from (no Trace objects)."""
+    mode = 'prior'
+
+    def __init__(self, n, device='cpu'):
+        self.obs_log = []             # per observe index: {name: values [n]}
+        self.paths = []               # finished executions: (active mask or None, [(j, address)], [(i, name)])
+        super().__init__(n, torch.device(device))
+
+    def start_path(self, active, decisions, statements_done, observes_done):
+        super().start_path(active, decisions, statements_done, observes_done)
+        self.seq, self.obs_seq = [], []
+
+    def _merge(self, new, old):
+        return new if (self.active is None or old is None) else torch.where(self.active, new, old)
+
+    def sample_statement(self, address, distribution, control):
+        j = self.statement
+        self.statement += 1
+        if j < self.replay_statements:
+            if control:
+                self.seq.append((j, address))
+            return ParticleTensor.wrap(self.log[j][address][0])
+        while len(self.log) <= j:
+            self.log.append({})
+        old = self.log[j].get(address)
+        values = self._merge(_vector_draw(distribution, self.n).to(self.dev), None if old is None else old[0])
+        p0, p1 = _vector_params(distribution, self.n, self.dev)
+        if old is not None and self.active is not None:
+            p0, p1 = torch.where(self.active, p0, old[1]), torch.where(self.active, p1, old[2])
+        ncat = distribution.num_categories if distribution.name == 'Categorical' else None
+        self.log[j][address] = (values, p0, p1, distribution.name, ncat)
+        if control:
+            self.seq.append((j, address))
+        return ParticleTensor.wrap(values)
+
+    def observe_statement(self, name, distribution, value):
+        i = self.observes
+        self.observes += 1
+        if i >= self.replay_observes:
+            while len(self.obs_log) <= i:
+                self.obs_log.append({})
+            if value is None:
+                draw = _vector_draw(distribution, self.n).to(self.dev)
+            else:
+                draw = torch.as_tensor(value, dtype=torch.float32).reshape(-1).to(self.dev).expand(self.n)
+            self.obs_log[i][name] = self._merge(draw, self.obs_log[i].get(name))
+        if name is not None:
+            self.obs_seq.append((i, name))
+        return ParticleTensor.wrap(self.obs_log[i][name])
+
+    def finish_path(self):
+        self.paths.append((self.active, list(self.seq), list(self.obs_seq)))
+
+    def columns(self, obs_names):
+        """(trace_len [n], address table [(address, distribution, n_categories)], address ids [R], values [R],
+        prior [R, 2], obs [n, W]) as numpy arrays; traces are grouped by control-flow path."""
+        import numpy as np
+        table, ids_of = [], {}
+        lens, ids, vals, pri, obs = [], [], [], [], []
+        for active, seq, obs_seq in self.paths:
+            rows = slice(None) if active is None else torch.nonzero(active).reshape(-1)
+            m = self.n if active is None else int(rows.numel())
+            if m == 0:
+                continue
+            if not seq:
+                raise ValueError('Trace of length zero.')
+            row_ids = []
+            for j, address in seq:
+                if address not in ids_of:
+                    ids_of[address] = len(table)
+                    e = self.log[j][address]
+                    table.append((address, e[3], e[4]))
+                row_ids.append(ids_of[address])
+            lens.append(np.full(m, len(seq), np.int64))
+            ids.append(np.tile(np.asarray(row_ids, np.int64), m))
+            vals.append(torch.stack([self.log[j][a][0][rows] for j, a in seq], 1).reshape(-1).cpu().numpy())
+            pri.append(torch.stack([torch.stack([self.log[j][a][1][rows], self.log[j][a][2][rows]], 1) for j, a in seq],
+                                   1).reshape(-1, 2).cpu().numpy())
+            by_name = dict((name, i) for i, name in obs_seq)
+            obs.append(torch.stack([self.obs_log[by_name[name]][name][rows] for name in obs_names], 1).cpu().numpy())
+        return (np.concatenate(lens), table, np.concatenate(ids), np.concatenate(vals).astype(np.float32),
+                np.concatenate(pri).astype(np.float32), np.concatenate(obs).astype(np.float32))
+
+
 def observe(distribution, value=None, name=None, address=None):
     """state.observe, pyprob/state.py:118-155."""
     if _current_trace is None:
@@ -156,6 +286,10 @@ def observe(distribution, value=None, name=None, address=None):
         value = distribution.sample()
     else:
         value = None
+    if _lock_step is not None and _lock_step.mode == 'prior':
+        given = _current_trace_observed_variables.get(name) if name in _current_trace_observed_variables else (
+            None if value is None else value)
+        return _lock_step.observe_statement(name, distribution, given)
     if _lock_step is not None and value is not None:
         ls = _lock_step
         dev = ls.runner.dev
@@ -203,6 +337,11 @@ def sample(distribution, name=None, address=None, control=True):
 
     ic = (_trace_mode == TraceMode.POSTERIOR and
           _inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK and control)
+    if _lock_step is not None and _lock_step.mode == 'prior':
+        value = _lock_step.sample_statement(addr, distribution, control)
+        _current_trace.add(Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                                    control=control, name=name))     # (instance counting of the next statements)
+        return value
     if _lock_step is not None:
         if not ic:
             raise RuntimeError('lock-step mode runs controlled samples with the inference network only')

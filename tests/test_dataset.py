@@ -161,3 +161,51 @@ def test_batch_matches_from_ragged_and_loader_prefetches(tmp_path):
     finally:
         P.PackedBatch.to = orig
     assert len(got) == 2 * (400 // 32) and uploaded == [32] * len(got)
+
+
+def test_vectorised_prior_traces_match_the_per_trace_generator():
+    """Model.prior_traces_packed: prior traces generated in lock step, one forward() per control-flow
+    path, have the per-trace generator's addresses (instance counters included), the rejection-loop structure and the
+    right marginals. CPU only."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(__file__))
+    from models import GaussianWithUnknownMean, GaussianWithUnknownMeanMarsagliaLockStep
+    from pyprob_amd.dataset import VectorisedOnlineDataset
+    from pyprob_amd.state import TraceMode
+    torch.manual_seed(3)
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    lens, table, ids, vals, prior, obs = model.prior_traces_packed(30000, ['obs0', 'obs1'])
+    assert len(lens) == 30000 and lens.sum() == len(vals) == len(ids) and obs.shape == (30000, 2)
+    assert np.all(lens % 2 == 0) and np.all(prior == np.array([-1.0, 1.0], np.float32))
+    # per-trace generator: same address strings for the same statements
+    gen = model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK)
+    seen = {}
+    for _ in range(300):
+        tr = next(gen)
+        seen[tr.length_controlled] = [v.address for v in tr.variables_controlled]
+    names = [t[0] for t in table]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for L, addrs in seen.items():
+        i = int(np.nonzero(lens == L)[0][0])
+        assert [names[a] for a in ids[off[i]:off[i + 1]]] == addrs
+    # rejection structure: only the last (x, y) pair of a trace lies inside the unit disc
+    for i in range(0, 30000, 37):
+        s2 = (vals[off[i]:off[i + 1]].reshape(-1, 2) ** 2).sum(1)
+        assert s2[-1] < 1 and np.all(s2[:-1] >= 1)
+    # P(length = 2k) = (pi/4)(1 - pi/4)^(k-1); observations ~ N(mu, 2) with mu ~ N(1, 5)
+    p1 = np.mean(lens == 2)
+    assert abs(p1 - np.pi / 4) < 0.01
+    assert abs(obs.mean() - 1.0) < 0.05 and abs(obs.var() - 7.0) < 0.3
+    # straight-line program: one path, exact prior moments
+    lens, table, ids, vals, prior, obs = GaussianWithUnknownMean().prior_traces_packed(200000, ['obs0', 'obs1'])
+    assert len(table) == 1 and np.all(lens == 1)
+    assert abs(vals.mean() - 1.0) < 0.02 and abs(vals.std() - np.sqrt(5)) < 0.02
+    assert np.allclose(prior[0], [1.0, np.sqrt(5)], atol=1e-6)
+    # served as an online dataset: fresh traces on refresh, same interface as the on-disk dataset
+    ds = VectorisedOnlineDataset(model, ['obs0', 'obs1'], chunk_traces=4096)
+    first = ds.gather(np.arange(16))[2].copy()
+    ds.refresh()
+    assert ds.generated == 8192 and not np.array_equal(first, ds.gather(np.arange(16))[2])
+    assert ds[0].length_controlled == ds.trace_len[0]
+    assert len([b for b in ds.sampler(256)]) == 4096 // 256
