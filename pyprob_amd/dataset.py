@@ -489,16 +489,24 @@ def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=
     gen = model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, *args, **kwargs)
     existing = [d for d in os.listdir(dataset_dir) if d.startswith('pyprob_traces_packed_')]
     shard, written = len(existing), 0
+    names = obs_names
+    if names is None:    # one per-trace run tells which named variables are observed
+        probe = next(gen)
+        names = [k for k, v in probe.named_variables.items() if v.observed or getattr(v, 'observable', False)]
+    vectorised = True
+    try:                 # lock-step-safe programs are generated n traces at a time (Model.prior_traces_packed)
+        model.prior_traces_packed(8, names, *args, **kwargs)
+    except Exception:    # noqa: BLE001 - e.g. float(tensor) in the program: one forward() per trace
+        vectorised = False
     while written < num_traces:
         n = min(num_traces_per_file, num_traces - written)
-        traces = [next(gen) for _ in range(n)]
-        names = obs_names
-        if names is None:
-            names = [k for k, v in traces[0].named_variables.items() if v.observed or getattr(v, 'observable', False)]
         path = os.path.join(dataset_dir, 'pyprob_traces_packed_{:06d}_{}'.format(shard, n))
         with PackedTraceWriter(path, names) as w:
-            for t in traces:
-                w.add_trace(t)
+            if vectorised:
+                w.add_columns(*model.prior_traces_packed(n, names, *args, **kwargs))
+            else:
+                for _ in range(n):
+                    w.add_trace(next(gen))
         shard += 1
         written += n
     return shard
