@@ -800,55 +800,66 @@ struct DirectOperand {
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + krow + 8 * i;
                 okr[i] = row < nrows;
-                const int64_t rr = okr[i] ? (idx ? (int64_t)idx[row] : (int64_t)row) : 0;
+                const int rc = min(row, nrows - 1);      // a row beyond the matrix reads the last one and is zeroed
+                const int64_t rr = idx ? (int64_t)idx[rc] : (int64_t)rc;
                 base[i] = P + rr * ld + rcol;
             }
         } else {
             nleft = nrows - (row0 + rcol);   // rows of this lane's segment inside the matrix
             ok = nleft > 0;
             ok4 = nleft >= 4;
-            base[0] = P + row0 + rcol;
+            base[0] = P + row0 + (ok ? rcol : 0);   // a segment beyond the matrix reads the tile's first one and is zeroed
         }
     }
 
+    // VEC == 4 is branch-free: the load address is clamped into the matrix (rows at init, k here) and elements outside
+    // are zeroed with selects. The predicated element-wise fallback this replaces cost ~900 instructions (124 exec
+    // branches) for the first slab of a workgroup - 1.2 us of a 10 us kernel (tools/timeline5.py).
     __device__ __forceinline__ void fetch(float g[16], int k0, int K) const {
         if (!KM) {
             const int kleft = K - (k0 + rcol);
+            if (VEC == 4) {
+                // a piece that starts inside K may straddle it: the row is ld >= round4(K) floats long, so the read stays
+                // inside the row; a piece beyond K is read from the row start instead
+                const int koff = kleft > 0 ? k0 : -rcol;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float* src = base[i] + k0;
-                if (okr[i] && kleft >= 4) {
-                    if (VEC == 4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(base[i] + koff);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g[4 * i + e] = v[e];
-                    } else {
+                    for (int e = 0; e < 4; ++e) g[4 * i + e] = (okr[i] && e < kleft) ? v[e] : 0.0f;
+                }
+            } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g[4 * i + e] = src[e];
-                    }
-                } else {
+                for (int i = 0; i < 4; ++i) {
+                    const float* src = base[i] + k0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[4 * i + e] = (okr[i] && e < kleft) ? src[e] : 0.0f;
                 }
             }
         } else {
+            if (VEC == 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = k0 + krow + 8 * i;
-                if (ok && k < K) {
-                    const int64_t kk = idx ? (int64_t)idx[k] : (int64_t)k;
-                    const float* src = base[0] + kk * ld;
-                    if (VEC == 4 && ok4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + krow + 8 * i;
+                    const int kc = min(k, K - 1);
+                    const int64_t kk = idx ? (int64_t)idx[kc] : (int64_t)kc;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(base[0] + kk * ld);   // base[0] is clamped at init
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g[4 * i + e] = v[e];
-                    } else {
+                    for (int e = 0; e < 4; ++e) g[4 * i + e] = (k < K && e < nleft) ? v[e] : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + krow + 8 * i;
+                    if (ok && k < K) {
+                        const int64_t kk = idx ? (int64_t)idx[k] : (int64_t)k;
+                        const float* src = base[0] + kk * ld;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g[4 * i + e] = e < nleft ? src[e] : 0.0f;
-                    }
-                } else {
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[4 * i + e] = 0.0f;
+                        for (int e = 0; e < 4; ++e) g[4 * i + e] = 0.0f;
+                    }
                 }
             }
         }
