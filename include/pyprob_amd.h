@@ -46,6 +46,7 @@ extern "C" {
 #define PP_HEAD_NORMAL_MIXTURE       0  /* ProposalNormalNormalMixture: prior Normal(mean, stddev) */
 #define PP_HEAD_TRUNCNORMAL_MIXTURE  1  /* ProposalUniformTruncatedNormalMixture: prior Uniform(low, high) */
 #define PP_HEAD_CATEGORICAL          2  /* ProposalCategoricalCategorical: prior Categorical(C) */
+#define PP_HEAD_POISSON_TN_MIXTURE   3  /* ProposalPoissonTruncatedNormalMixture: prior Poisson; (p0, p1) = (low, high) = (0, 40) */
 
 int         pp_abi_version(void);
 const char* pp_last_error(void);

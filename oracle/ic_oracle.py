@@ -302,6 +302,49 @@ def head_truncated_normal_mixture(y, prior, v, K):
     return lp, dy, (mu, sd, p)
 
 
+POISSON_LOW, POISSON_HIGH = 0.0, 40.0   # ProposalPoissonTruncatedNormalMixture defaults (low=0, high=40)
+
+
+def head_poisson_truncated_normal_mixture(y, v, K, low=POISSON_LOW, high=POISSON_HIGH):
+    """ProposalPoissonTruncatedNormalMixture.forward (pyprob/nn/proposal_poisson_truncated_normal_mixture.py:19-37)
+    followed by Mixture.log_prob: means = low + sigmoid(y) (high - low), stddevs = exp(y) (not scaled), TruncatedNormal
+    components on the FIXED interval [low, high] - the prior's rate does not enter the proposal."""
+    rng = high - low
+    sm = sigmoid(y[:, :K])
+    mu = low + sm * rng
+    sd = np.exp(y[:, K:2 * K])
+    pi = softmax(y[:, 2 * K:])
+    lo = np.full((y.shape[0], 1), low, y.dtype)
+    hi = np.full((y.shape[0], 1), high, y.dtype)
+    comp = truncated_normal_log_prob(v[:, None], mu, sd, lo, hi)
+    p, logp = mixture_log_probs(pi)
+    a = logp + comp
+    lp = logsumexp(a, axis=1)
+    with np.errstate(invalid='ignore'):
+        r = np.exp(a - lp[:, None])
+    r = np.where(np.isfinite(lp)[:, None], r, 0.0)
+    alpha = (lo - mu) / sd
+    beta = (hi - mu) / sd
+    Z = std_normal_cdf(beta) - std_normal_cdf(alpha)
+    pa, pb = std_normal_pdf(alpha), std_normal_pdf(beta)
+    t = (v[:, None] - mu) / sd
+    d_mu = r * (t / sd - (pa - pb) / (sd * Z))
+    d_sd = r * ((t * t - 1.0) / sd - (alpha * pa - beta * pb) / (sd * Z))
+    dy = np.zeros_like(y)
+    dy[:, :K] = d_mu * rng * sm * (1 - sm)
+    dy[:, K:2 * K] = d_sd * sd
+    dy[:, 2 * K:] = _mixture_logit_grad(r, pi, p)
+    return lp, dy, (mu, sd, p)
+
+
+def poisson_log_prob(v, rate):
+    """torch.distributions.Poisson.log_prob: v log(rate) - rate - lgamma(v + 1) (defined for non-integer v too)."""
+    from math import lgamma
+    v = np.asarray(v, np.float64)
+    lg = np.vectorize(lgamma)(v + 1.0)
+    return v * np.log(rate) - rate - lg
+
+
 def head_categorical(y, v):
     """ProposalCategoricalCategorical.forward (pyprob/nn/proposal_categorical_categorical.py:16-20) + log_prob."""
     pi = softmax(y)
@@ -330,6 +373,8 @@ def head_forward(net, address, dist_name, h, prior, v):
         lp, dy, params = head_truncated_normal_mixture(y, prior, v, net.K)
     elif dist_name == 'Categorical':
         lp, dy, params = head_categorical(y, v)
+    elif dist_name == 'Poisson':
+        lp, dy, params = head_poisson_truncated_normal_mixture(y, v, net.K)
     else:
         raise RuntimeError('Distribution currently unsupported: ' + dist_name)
     return lp, (dy, acts, Ws), params
@@ -476,6 +521,8 @@ def prior_log_prob(dist_name, prior, v):
         return uniform_log_prob(v, prior[..., 0], prior[..., 1])
     if dist_name == 'Categorical':
         return categorical_log_prob(v, prior)
+    if dist_name == 'Poisson':
+        return poisson_log_prob(v, prior[..., 0])
     raise RuntimeError(dist_name)
 
 

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void is_mixture_shared_kernel(const float* __r
             } else {
                 const float rng = pb - pa;
                 mu = pa + sigmoidf_(y[k]) * rng;
-                sd = rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
+                sd = KIND == 2 ? expf(y[K + k]) : rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
             }
             const float lpk = logf(fminf(fmaxf(pk, kFp32Eps), 1.0f - kFp32Eps));
             s_mu[k] = mu;
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void is_mixture_shared_kernel(const float* __r
     logq_out[i] = lp;
 }
 
-// KIND 0: Normal mixture around a Normal prior; KIND 1: TruncatedNormal mixture inside a Uniform prior.
+// KIND 0: Normal mixture around a Normal prior; KIND 1: TruncatedNormal mixture inside a Uniform prior; KIND 2: the
+// Poisson head (TruncatedNormal mixture on [0, 40], stddev = exp(y)).
 template <int KIND>
 __global__ __launch_bounds__(256) void is_mixture_kernel(const float* __restrict__ Y, int64_t ldy, int y_shared,
                                                          const float* __restrict__ prior, int prior_stride, int n,
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void is_mixture_kernel(const float* __restrict
             } else {
                 const float rng = pb - pa;
                 mu[k] = pa + sigmoidf_(y[k]) * rng;
-                sd[k] = rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
+                sd[k] = KIND == 2 ? expf(y[K + k]) : rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
             }
         }
     float v;
@@ -432,14 +433,20 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
         if (same_proposal && ad.kind == PP_HEAD_NORMAL_MIXTURE)
             hipLaunchKernelGGL(is_mixture_shared_kernel<0>, grid, block, 0, st, w.Y, prior, n, ad.n_out / 3, value_in, value_out,
                                logq_out, seed, offset);
-        else if (same_proposal)
+        else if (same_proposal && ad.kind == PP_HEAD_TRUNCNORMAL_MIXTURE)
             hipLaunchKernelGGL(is_mixture_shared_kernel<1>, grid, block, 0, st, w.Y, prior, n, ad.n_out / 3, value_in, value_out,
+                               logq_out, seed, offset);
+        else if (same_proposal)
+            hipLaunchKernelGGL(is_mixture_shared_kernel<2>, grid, block, 0, st, w.Y, prior, n, ad.n_out / 3, value_in, value_out,
                                logq_out, seed, offset);
         else if (ad.kind == PP_HEAD_NORMAL_MIXTURE)
             hipLaunchKernelGGL(is_mixture_kernel<0>, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, prior, prior_stride,
                                n, ad.n_out / 3, value_in, value_out, logq_out, seed, offset);
-        else
+        else if (ad.kind == PP_HEAD_TRUNCNORMAL_MIXTURE)
             hipLaunchKernelGGL(is_mixture_kernel<1>, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, prior, prior_stride,
+                               n, ad.n_out / 3, value_in, value_out, logq_out, seed, offset);
+        else
+            hipLaunchKernelGGL(is_mixture_kernel<2>, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, prior, prior_stride,
                                n, ad.n_out / 3, value_in, value_out, logq_out, seed, offset);
     }
     PP_LAUNCH_CHECK("pp_is_step(sample)");

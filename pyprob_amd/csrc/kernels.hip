@@ -382,7 +382,9 @@ struct MixtureParams {
     float pisum;
 };
 
-// kind 0: Normal components around a Normal prior; kind 1: TruncatedNormal components inside a Uniform prior.
+// KIND 0: Normal components around a Normal prior; KIND 1: TruncatedNormal components inside a Uniform prior
+// (stddev = range/1000 + sigmoid(y) 10 range); KIND 2: the Poisson head - TruncatedNormal components on the fixed
+// interval [pa, pb] = [0, 40] with stddev = exp(y) (proposal_poisson_truncated_normal_mixture.py:19-37).
 template <int KIND>
 __device__ __forceinline__ void mixture_params(const float* __restrict__ y, int K, float pa, float pb,
                                                MixtureParams& m, float sm[MAXK], float ss[MAXK]) {
@@ -417,7 +419,7 @@ __device__ __forceinline__ void mixture_params(const float* __restrict__ y, int 
                 sm[k] = sigmoidf_(y[k]);
                 ss[k] = sigmoidf_(y[K + k]);
                 m.mu[k] = pa + sm[k] * rng;
-                m.sd[k] = rng / 1000.0f + ss[k] * rng * 10.0f;
+                m.sd[k] = KIND == 2 ? expf(y[K + k]) : rng / 1000.0f + ss[k] * rng * 10.0f;
             }
         }
 }
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(64) void head_mixture_kernel(const float* __restric
                             dmu = resp[k] * (t / m.sd[k] - (fa - fb) / (m.sd[k] * Z));
                             dsd = resp[k] * ((t * t - 1.0f) / m.sd[k] - (alpha * fa - beta * fb) / (m.sd[k] * Z));
                             dy[k] = grad_scale * dmu * rng * sm[k] * (1.0f - sm[k]);
-                            dy[K + k] = grad_scale * dsd * rng * 10.0f * ss[k] * (1.0f - ss[k]);
+                            dy[K + k] = grad_scale * dsd * (KIND == 2 ? m.sd[k] : rng * 10.0f * ss[k] * (1.0f - ss[k]));
                         }
                         dy[2 * K + k] = grad_scale * m.pi[k] * (dp[k] - dpipi);
                     }
@@ -597,6 +599,9 @@ int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, con
                                grad_scale, lp_out, dy, loss_acc, nonfinite);
         else if (kind == PP_HEAD_TRUNCNORMAL_MIXTURE)
             hipLaunchKernelGGL(head_mixture_kernel<1>, grid, block, 0, st, y, ldy, rows, value, prior, n, n_out / 3,
+                               grad_scale, lp_out, dy, loss_acc, nonfinite);
+        else if (kind == PP_HEAD_POISSON_TN_MIXTURE)
+            hipLaunchKernelGGL(head_mixture_kernel<2>, grid, block, 0, st, y, ldy, rows, value, prior, n, n_out / 3,
                                grad_scale, lp_out, dy, loss_acc, nonfinite);
         else
             PP_CHECK_ARG(false, "pp_head_logprob: unknown head kind %d", kind);
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int
             sm = sigmoidf_(ymu);
             ss = sigmoidf_(ysd);
             mu = pa + sm * rng;
-            sd = rng / 1000.0f + ss * rng * 10.0f;
+            sd = KIND == 2 ? expf(ysd) : rng / 1000.0f + ss * rng * 10.0f;
         }
         const float tt = (v - mu) / sd;
         float cl, alpha = 0.f, beta = 0.f, Z = 1.f;
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int
                     const float dmu = resp * (tt / sd - (fa - fb) / (sd * Z));
                     const float dsd = resp * ((tt * tt - 1.0f) / sd - (alpha * fa - beta * fb) / (sd * Z));
                     d0 = grad_scale * dmu * rng * sm * (1.0f - sm);
-                    d1 = grad_scale * dsd * rng * 10.0f * ss * (1.0f - ss);
+                    d1 = grad_scale * dsd * (KIND == 2 ? sd : rng * 10.0f * ss * (1.0f - ss));
                 }
                 d2 = grad_scale * pi * (dp - dpipi);
             }
@@ -853,7 +858,7 @@ static size_t head_tail_lds_floats(int hid, int n_out) {
 bool head_tail_supported(int kind, int hid, int n_out) {
     static const bool disabled = getenv("PP_NO_HEAD_TAIL") && atoi(getenv("PP_NO_HEAD_TAIL")) != 0;   // A/B knob
     if (disabled) return false;
-    if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE) return false;
+    if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE && kind != PP_HEAD_POISSON_TN_MIXTURE) return false;
     if (n_out % 3 != 0 || n_out / 3 > MAXK || n_out / 3 < 1) return false;
     return hid >= 1 && hid <= 1024 && head_tail_lds_floats(hid, n_out) <= TAIL_LDS_FLOATS;
 }
@@ -919,8 +924,11 @@ int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int 
         if (kind == PP_HEAD_NORMAL_MIXTURE)
             PP_TRY(head_tail_launch<0>(ne, grid, lds, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy,
                                        lddz, loss_acc, nonfinite));
-        else
+        else if (kind == PP_HEAD_TRUNCNORMAL_MIXTURE)
             PP_TRY(head_tail_launch<1>(ne, grid, lds, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy,
+                                       lddz, loss_acc, nonfinite));
+        else
+            PP_TRY(head_tail_launch<2>(ne, grid, lds, st, pack, lda1, hid, n_out / 3, value, prior, rpw, grad_scale, lp_out, lddy,
                                        lddz, loss_acc, nonfinite));
         PP_LAUNCH_CHECK("head_tail");
     }

@@ -438,6 +438,8 @@ class PackedTraceDataset:
                 dist = D.Uniform(float(prior[r, 0]), float(prior[r, 1]))
             elif dname == 'Categorical':
                 dist = D.Categorical([1.0 / ncat] * ncat)
+            elif dname == 'Poisson':    # the rate is not stored: training only reads the head's fixed interval
+                dist = D.Poisson(1.0)
             else:
                 raise RuntimeError('Distribution currently unsupported: {}'.format(dname))
             v = Variable(distribution=dist, value=float(value[r]), address=address, control=True)

@@ -81,6 +81,20 @@ class Uniform(Distribution):
         return self._torch_dist.high
 
 
+class Poisson(Distribution):
+    """pyprob/distributions/poisson.py:7-21. The inference network proposes a continuous TruncatedNormal mixture on
+    [0, 40] for a Poisson variable (proposal_poisson_truncated_normal_mixture.py), so log_prob must accept non-integer
+    values like the reference's torch did: no argument validation."""
+
+    def __init__(self, rate):
+        rate = _t(rate).float()
+        super().__init__('Poisson', 'Poisson', torch.distributions.Poisson(rate, validate_args=False))
+
+    @property
+    def rate(self):
+        return self._torch_dist.mean
+
+
 class Categorical(Distribution):
     """pyprob/distributions/categorical.py:7-39"""
 

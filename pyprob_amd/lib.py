@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 PP_ABI_VERSION = 2
 PP_MAX_OBS = 8
 PP_ADDR_TABLE_COLS = 8
-PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL = 0, 1, 2
+PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL, PP_HEAD_POISSON_TN_MIXTURE = 0, 1, 2, 3
 PP_LOSS_BACKWARD, PP_LOSS_ZERO_GRADS, PP_LOSS_KEEP_LP = 1, 2, 4
 PP_ADAM_ZERO_GRADS = 1
 PP_ADAM_SCRATCH = 40          # int32 per tensor (include/pyprob_amd.h)

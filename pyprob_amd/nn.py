@@ -215,6 +215,9 @@ class InferenceNetworkLSTM:
             p = torch.stack([distribution.mean.reshape(-1), distribution.stddev.reshape(-1)], 1)
         elif distribution.name == 'Uniform':
             p = torch.stack([distribution.low.reshape(-1), distribution.high.reshape(-1)], 1)
+        elif distribution.name == 'Poisson':      # the head's fixed interval, not the rate
+            from .packed import POISSON_LOW_HIGH
+            p = torch.tensor([POISSON_LOW_HIGH], dtype=torch.float32)
         else:
             return None
         return p.to(self._engine.device, torch.float32).contiguous()

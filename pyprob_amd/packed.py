@@ -217,6 +217,9 @@ def pack_traces(traces, spec, obs_names):
                                    np.asarray(obs, np.float32), len(spec.addresses))
 
 
+POISSON_LOW_HIGH = (0.0, 40.0)
+
+
 def distribution_params(dist):
     """(p0, p1) of a prior as the heads need it: Normal -> (mean, stddev) (proposal_normal_normal_mixture.py:26-27),
     Uniform -> (low, high) (proposal_uniform_truncated_normal_mixture.py:28-29), Categorical -> unused."""
@@ -227,4 +230,6 @@ def distribution_params(dist):
         return (float(dist.low), float(dist.high))
     if name == 'Categorical':
         return (0.0, 0.0)
+    if name == 'Poisson':      # the Poisson head proposes on a FIXED interval (proposal_poisson_truncated_normal_mixture.py:10)
+        return POISSON_LOW_HIGH
     raise RuntimeError('Distribution currently unsupported: {}'.format(name))

@@ -16,7 +16,7 @@ from . import lib as L
 CHUNK = 1024
 
 DIST_KIND = {'Normal': L.PP_HEAD_NORMAL_MIXTURE, 'Uniform': L.PP_HEAD_TRUNCNORMAL_MIXTURE,
-             'Categorical': L.PP_HEAD_CATEGORICAL}
+             'Categorical': L.PP_HEAD_CATEGORICAL, 'Poisson': L.PP_HEAD_POISSON_TN_MIXTURE}
 
 
 class AddressInfo:

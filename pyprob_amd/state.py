@@ -180,6 +180,9 @@ def _vector_params(distribution, n, device):
         p = (distribution.low, distribution.high)
     elif name == 'Categorical':
         p = (torch.zeros(1), torch.zeros(1))
+    elif name == 'Poisson':      # the Poisson head's fixed interval (packed.distribution_params)
+        from .packed import POISSON_LOW_HIGH
+        p = (torch.tensor([POISSON_LOW_HIGH[0]]), torch.tensor([POISSON_LOW_HIGH[1]]))
     else:
         raise RuntimeError('Distribution currently unsupported: {}'.format(name))
     return [torch.as_tensor(q, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(device).expand(n) for q in p]

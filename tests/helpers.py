@@ -14,7 +14,7 @@ def spec_from_golden(meta, params):
             a = k[len('_layers_address_embedding.'):]
             if a not in meta['addresses']:
                 suffix = a.split('__')[-2]
-                pairs.append((a, [d for d in ('Normal', 'Uniform', 'Categorical') if suffix.startswith(d)][0]))
+                pairs.append((a, [d for d in ('Normal', 'Uniform', 'Categorical', 'Poisson') if suffix.startswith(d)][0]))
     for a, d in pairs:
         ncat = None
         if d == 'Categorical':
@@ -37,8 +37,20 @@ def engine_from_golden(meta, params, device='cuda:0'):
 def packed_from_golden(meta, batch, spec):
     from pyprob_amd.packed import PackedBatch
     ids = np.array([spec.address_id[meta['addresses'][i]] for i in batch['addr_idx']], np.int64)
-    return PackedBatch.from_ragged(batch['trace_len'], ids, batch['values'], batch['prior'], batch['obs'],
-                                   len(spec.addresses))
+    return PackedBatch.from_ragged(batch['trace_len'], ids, batch['values'], head_prior(meta, batch['addr_idx'], batch['prior']),
+                                   batch['obs'], len(spec.addresses))
+
+
+def head_prior(meta, addr_idx, prior, dist_names=None):
+    """Prior parameters as the proposal heads read them: the golden files hold the prior's own parameters (Poisson:
+    the rate), the Poisson head works on the fixed interval [0, 40] (pyprob_amd.packed.distribution_params)."""
+    from pyprob_amd.packed import POISSON_LOW_HIGH
+    names = np.asarray(meta['dist_names'] if dist_names is None else dist_names)[np.asarray(addr_idx)]
+    out = np.zeros((len(prior), 2), np.float32)
+    w = min(2, prior.shape[1])
+    out[:, :w] = prior[:, :w]
+    out[names == 'Poisson'] = POISSON_LOW_HIGH
+    return out
 
 
 def rel_err(got, ref):

@@ -5,7 +5,7 @@ import math
 import torch
 
 import pyprob_amd as pyprob
-from pyprob_amd.distributions import Normal, Uniform, Categorical
+from pyprob_amd.distributions import Normal, Uniform, Categorical, Poisson
 from pyprob_amd.model import Model
 
 
@@ -71,3 +71,16 @@ class GaussianWithUnknownMeanMarsagliaLockStep(GaussianWithUnknownMeanMarsaglia)
             y = pyprob.sample(uniform)
             s = x * x + y * y
         return mean + stddev * (x * torch.sqrt(-2 * torch.log(s) / s))
+
+
+class PoissonThenNormal(Model):
+    """n ~ Poisson(4); mu ~ Normal(n / 2, 1); two Normal observations (the program of the `poi` golden case):
+    exercises the Poisson proposal head (TruncatedNormal mixture on [0, 40])."""
+
+    def forward(self):
+        n = pyprob.sample(Poisson(4.0))
+        mu = pyprob.sample(Normal(n * 0.5, 1.0))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu

@@ -274,7 +274,8 @@ def test_is_rescoring_matches_reference_records(golden):
             a = eng.spec.address_id[addresses[isr['addr'][r]]]
             info = eng.spec.addresses[a]
             v = torch.tensor([isr['value'][r]], dtype=torch.float32, device=eng.device)
-            pr = torch.tensor(isr['prior'][r, :2].reshape(1, 2), dtype=torch.float32, device=eng.device)
+            pr = isr['prior'][r, :2] if info.dist_name != 'Poisson' else np.array([0.0, 40.0], np.float32)   # fixed interval
+            pr = torch.tensor(pr.reshape(1, 2), dtype=torch.float32, device=eng.device)
             _, logq = run.step(a, prev, pr, value_in=v)
             q_all[r] = float(logq.item())
             prev = a
