@@ -163,7 +163,7 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params /*d
  * One launch (bias corrections are derived per chunk from the tensor's step count).
  */
 #define PP_ADAM_ZERO_GRADS 1
-#define PP_ADAM_SCRATCH 40
+#define PP_ADAM_SCRATCH 1056
 int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
                  const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* scratch,
                  int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,

@@ -6,6 +6,8 @@
 
 #include "../../include/pyprob_amd.h"
 
+#define PP_LOSS_SLOTS_FLOATS (64 * 32 + 32)   /* 64 loss slots at a 128-byte stride + the non-finite flag's line */
+
 namespace pp {
 
 constexpr int kWave = 64;  // CDNA wavefront

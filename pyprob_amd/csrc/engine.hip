@@ -163,8 +163,10 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.dF1 = c.take<float>((int64_t)B * w.e4);
     w.dCat = c.take<float>((int64_t)B * w.e4);
     w.dObsH = c.take<float>((int64_t)net->n_obs * B * w.maxohid4);
-    w.loss_acc = c.take<float>(128);   // one 512-byte region: [64 loss accumulator slots | non-finite flag], one memset
-    w.flag = reinterpret_cast<int32_t*>(w.loss_acc ? w.loss_acc + 64 : nullptr);
+    // 64 loss accumulator slots, one per 128-byte line (atomics to one line serialise in its L2 channel), then the
+    // non-finite flag; cleared by the step's first kernel
+    w.loss_acc = c.take<float>(PP_LOSS_SLOTS_FLOATS);
+    w.flag = reinterpret_cast<int32_t*>(w.loss_acc ? w.loss_acc + 64 * 32 : nullptr);
     w.bytes = c.off + 256;
 }
 
@@ -289,13 +291,13 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         rb.value = bt->value; rb.addr = bt->addr; rb.prev_row = bt->prev_row;
         rb.X = w.X; rb.ldx = w.i4;
         rb.zero_like = bwd ? w.dX : nullptr;
-        rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = 128;
+        rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = PP_LOSS_SLOTS_FLOATS;
         PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb));
     } else {
         PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
         // (also clears the loss slots and, for a backward pass, dX: see the kernel)
         PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
-                                 bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), 128));
+                                 bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), PP_LOSS_SLOTS_FLOATS));
     }
     prof_begin(0, st);
     PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st));

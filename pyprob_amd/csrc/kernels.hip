@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ 
     // the backward pass's first cell launch also turns the loss slots into the loss (one launch less per step)
     if (fin.acc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         float tot = 0.0f;
-        for (int k = 0; k < 64; ++k) tot += fin.acc[k];
+        for (int k = 0; k < 64; ++k) tot += fin.acc[32 * k];
         const float l = tot * fin.inv_b;
         fin.loss_out[0] = l;
         if (fin.status_out) fin.status_out[0] = (fin.flag[0] != 0 || !isfinite(l)) ? 1 : 0;
@@ -842,9 +842,10 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailJobs jobs, int
         wave_lds_sync();   // a1s / ys / dys are rewritten by the next row
     }
     PP_STAMP(6);
-    // loss: one atomic per wave, spread over 64 accumulator slots (same-address float atomics serialise at ~40 ns
-    // each in L2; a thousand waves on one word cost ~40 us). loss_finalize sums the slots.
-    if (lane == 0 && loss_acc && loss_local != 0.0f) atomicAdd(loss_acc + ((blockIdx.x * 4 + wave + 7 * blockIdx.y) & 63), loss_local);
+    // loss: one atomic per wave, spread over 64 accumulator slots on 64 different 128-byte lines (same-address float
+    // atomics serialise at ~40 ns each in L2 - a thousand waves on one word cost ~40 us - and atomics to different
+    // words of ONE line still queue in that line's L2 channel). loss_finalize sums the slots.
+    if (lane == 0 && loss_acc && loss_local != 0.0f) atomicAdd(loss_acc + 32 * ((blockIdx.x * 4 + wave + 7 * blockIdx.y) & 63), loss_local);
     if (bad_any && nonfinite && lane == 0) atomicOr(nonfinite, 1);
     // The bias gradients db1 = colsum(dz1), db2 = colsum(dy) are NOT accumulated here: ~1000 waves adding to the
     // same few hundred addresses serialise in L2 (measured: +40 us); the caller runs the 16-way colsum kernel instead.
@@ -939,7 +940,7 @@ int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int 
 __global__ void loss_finalize_kernel(const float* __restrict__ acc, const int32_t* __restrict__ flag, float inv_b,
                                      float* __restrict__ loss_out, int32_t* __restrict__ status_out) {
     float tot = 0.0f;
-    for (int k = 0; k < 64; ++k) tot += acc[k];   // accumulator slots
+    for (int k = 0; k < 64; ++k) tot += acc[32 * k];   // accumulator slots (128-byte stride)
     const float l = tot * inv_b;
     loss_out[0] = l;
     if (status_out) status_out[0] = (flag[0] != 0 || !isfinite(l)) ? 1 : 0;
@@ -965,14 +966,17 @@ int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* lo
 // serialise at ~40 ns each and W_hh alone has 1024 chunks (a single counter per tensor made this kernel 68 us).
 // Optionally clears the gradient chunk it consumed (zero_grad of the NEXT step: saves a 6.5 MB memset launch).
 //
-// scratch, PP_ADAM_SCRATCH = 40 ints per tensor: [0..31] sub-counters (chunk index mod 32), [32] top counter,
-// [33] first chunk + 1 (0 = not cached yet), [34] number of chunks. All counters return to zero after every call.
+// scratch, PP_ADAM_SCRATCH = 1056 ints per tensor: 32 sub-counters (chunk index mod 32) on separate 128-byte lines
+// (atomics to one line serialise in its L2 channel whatever the address), then the top counter, first chunk + 1
+// (0 = not cached yet) and the number of chunks. All counters return to zero after every call.
+constexpr int ADAM_TOP = 1024, ADAM_FIRST = 1025, ADAM_CHUNKS = 1026;   // after 32 sub-counters, one per 128-byte line
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float* __restrict__ Gr, float* __restrict__ M,
                                                    float* __restrict__ V, const int32_t* __restrict__ chunk_tensor,
                                                    int n_chunks, const float* __restrict__ active,
                                                    int32_t* __restrict__ tensor_step, int32_t* __restrict__ scratch, float lr,
                                                    float beta1, float beta2, float eps, float wd, float gscale,
-                                                   int zero_grads) {
+                                                   int zero_grads, int dbg) {
     __shared__ float s_corr[2];
     const int b = blockIdx.x;
     const int t = chunk_tensor[b];
@@ -985,9 +989,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     f32x4 m = *reinterpret_cast<f32x4*>(M + o);
     f32x4 v = *reinterpret_cast<f32x4*>(V + o);
     int step_old = 0, first = 0, chunks = 0;
+    if (dbg == 2) { if (threadIdx.x == 0) { s_corr[0] = lr; s_corr[1] = 1.0f; } } else
     if (threadIdx.x == 0) {
-        first = __atomic_load_n(sc + 33, __ATOMIC_RELAXED) - 1;
-        chunks = __atomic_load_n(sc + 34, __ATOMIC_RELAXED);
+        first = __atomic_load_n(sc + ADAM_FIRST, __ATOMIC_RELAXED) - 1;
+        chunks = __atomic_load_n(sc + ADAM_CHUNKS, __ATOMIC_RELAXED);
         if (first < 0) {
             // chunks of one tensor are contiguous and the ids ascend: two binary searches (~20 dependent loads), done by
             // every workgroup of the FIRST call only; the last one to arrive caches the run
@@ -1020,6 +1025,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     }
     __syncthreads();
     const float step_size = s_corr[0], inv_sqrt_bc2 = s_corr[1];
+    // Arrival is signalled NOW (every workgroup has read the old step count by the time it gets here) and the returned
+    // ticket is only looked at after the update below, so the atomic's round trip overlaps the chunk's arithmetic and
+    // stores. No fence: the step count was CONSUMED (bias corrections) before this point, so that load has completed;
+    // a device-scope __threadfence() writes back / invalidates L2 in every workgroup (measured: 9 -> 66 us).
+    const int k = (b - first) & 31;                         // sub-counter of this chunk
+    const int quota = (chunks - k + 31) >> 5;               // chunks of the tensor that share it
+    int ticket = -1;
+    if (threadIdx.x == 0 && dbg != 1) ticket = atomicAdd(sc + 32 * k, 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float g = g0[e] * gscale;
@@ -1033,19 +1046,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     *reinterpret_cast<f32x4*>(M + o) = m;
     *reinterpret_cast<f32x4*>(V + o) = v;
     if (zero_grads) *reinterpret_cast<f32x4*>(Gr + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (threadIdx.x == 0) {
-        // no fence: the old step count was CONSUMED (bias corrections) before this point, so the load has completed; a
-        // device-scope __threadfence() here writes back / invalidates L2 in every workgroup (measured: 9 -> 66 us)
-        const int k = (b - first) & 31;                         // sub-counter of this chunk
-        const int quota = (chunks - k + 31) >> 5;               // chunks of the tensor that share it
-        if (atomicAdd(sc + k, 1) == quota - 1) {
-            __atomic_store_n(sc + k, 0, __ATOMIC_RELAXED);
-            if (atomicAdd(sc + 32, 1) == min(chunks, 32) - 1) {   // last chunk of the tensor: everyone has read the old count
-                __atomic_store_n(sc + 32, 0, __ATOMIC_RELAXED);
-                __atomic_store_n(sc + 33, first + 1, __ATOMIC_RELAXED);
-                __atomic_store_n(sc + 34, chunks, __ATOMIC_RELAXED);
-                __atomic_store_n(tensor_step + t, step_old + 1, __ATOMIC_RELAXED);
-            }
+    if (threadIdx.x == 0 && ticket == quota - 1) {
+        __atomic_store_n(sc + 32 * k, 0, __ATOMIC_RELAXED);
+        if (atomicAdd(sc + ADAM_TOP, 1) == min(chunks, 32) - 1) {   // last chunk of the tensor
+            __atomic_store_n(sc + ADAM_TOP, 0, __ATOMIC_RELAXED);
+            __atomic_store_n(sc + ADAM_FIRST, first + 1, __ATOMIC_RELAXED);
+            __atomic_store_n(sc + ADAM_CHUNKS, chunks, __ATOMIC_RELAXED);
+            __atomic_store_n(tensor_step + t, step_old + 1, __ATOMIC_RELAXED);
         }
     }
 }
@@ -1058,7 +1065,8 @@ int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params,
     if (n_tensors <= 0 || n_params == 0) return 0;
     const int n_chunks = (int)(n_params / 1024);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, params, grads, m, v, chunk_tensor, n_chunks,
-                       active, tensor_step, scratch, lr, beta1, beta2, eps, wd, gscale, (flags & PP_ADAM_ZERO_GRADS) ? 1 : 0);
+                       active, tensor_step, scratch, lr, beta1, beta2, eps, wd, gscale, (flags & PP_ADAM_ZERO_GRADS) ? 1 : 0,
+                       getenv("PP_ADAM_DBG") ? atoi(getenv("PP_ADAM_DBG")) : 0);
     PP_LAUNCH_CHECK("pp_adam_step");
     return 0;
 }

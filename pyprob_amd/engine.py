@@ -13,6 +13,10 @@ from . import lib as L
 from .spec import NetSpec
 
 
+import os
+_ADAM_CLEARS = os.environ.get('PP_ADAM_ZERO', '1') != '0'   # A/B knob: let pp_ic_loss memset the gradients instead
+
+
 class ICEngine:
     def __init__(self, spec: NetSpec, device='cuda:0', seed=None):
         self.lib = L.load()
@@ -158,7 +162,7 @@ class ICEngine:
         loss = self.loss(batch, backward=True)
         if self.world_size > 1 or self.force_allreduce:
             self.allreduce_grads()
-        self.adam_step(lr, weight_decay=weight_decay, zero_grads=True)
+        self.adam_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS)
         return loss
 
     # ---- HIP graph replay of the step (static shapes) ------------------------------------------------------------
