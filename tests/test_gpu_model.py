@@ -214,3 +214,26 @@ def test_poisson_program_trains_and_infers():
     torch.manual_seed(3)
     one = model.posterior_results(300, IC, observe=obs)              # one particle per forward()
     assert abs(one.mean - ref_mean) < 0.4
+
+
+def test_lockstep_categorical_program_matches_per_trace():
+    """Categorical proposal head + one-hot sample embedding in lock step: same posterior as one particle per forward()."""
+    torch.manual_seed(9)
+    model = CategoricalThenNormal()
+    model.learn_inference_network(num_traces=40000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=8)
+    obs = {'obs0': 1.2, 'obs1': 0.7}
+    lock = model.posterior_results(100000, IC, observe=obs, lock_step=True, seed=3)
+    assert lock.num_paths == 1 and lock.device_stats['count'] == 100000
+    # exact posterior mean by enumeration: c in {0,1,2}, mu | c ~ N(2c-1, 1.5), y | mu ~ N(mu, 0.8) twice
+    pri = np.array([0.2, 0.3, 0.5])
+    m0 = 2.0 * np.arange(3) - 1.0
+    s2, l2 = 1.5 ** 2, 0.8 ** 2
+    ybar, n = (1.2 + 0.7) / 2, 2
+    post_var = 1 / (1 / s2 + n / l2)
+    post_mean = post_var * (m0 / s2 + n * ybar / l2)
+    ev = pri * np.exp(-0.5 * (ybar - m0) ** 2 / (s2 + l2 / n)) / np.sqrt(s2 + l2 / n)
+    exact = float((ev * post_mean).sum() / ev.sum())
+    assert abs(lock.mean - exact) < 0.05, (lock.mean, exact)
+    torch.manual_seed(4)
+    one = model.posterior_results(400, IC, observe=obs)
+    assert abs(one.mean - exact) < 0.3
