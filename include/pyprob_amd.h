@@ -123,6 +123,30 @@ typedef struct pp_batch {
 } pp_batch;
 
 /* ------------------------------------------------------------------------------------------------------
+ * Host-side minibatch packing (no device access): ragged trace-major columns -> the step-major pp_batch layout.
+ * Replaces Batch.__init__ (pyprob/nn/dataset.py:21-37) and the per-trace torch.stack / torch.cat of _loss
+ * (pyprob/nn/inference_network_lstm.py:146-196). `out` receives ONE buffer of 4-byte words: the first
+ * info->device_words words are what the device needs (upload them with one copy), the rest are the host-side arrays of
+ * pp_batch; every info field below is a word offset into `out`.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct pp_pack_info {
+    int64_t n_traces, n_rows, t_max, device_words;
+    int64_t obs, value, prior, addr, prev_row, grp_rows, trace, row_off_dev, nxt_rows;   /* device part */
+    int64_t n_active, row_off, grp_off, nxt_off;                                         /* host part of pp_batch */
+    int64_t order;      /* [B] packed trace position -> input trace index (traces are sorted longest-first) */
+    int64_t src_row;    /* [R] packed row -> row of the trace-major input */
+} pp_pack_info;
+
+/* words `out` must hold; t_max = longest trace */
+int64_t pp_pack_words(int32_t n_traces, int64_t n_rows, int32_t t_max, int32_t obs_width, int32_t n_addr);
+
+/* trace_len [B]; addr_ids / values [R] and prior [R, prior_width] trace-major; obs [B, obs_width]. Errors: a trace of
+ * length zero ("Trace of length zero.", dataset.py:28-29), an address id outside [0, n_addr), a short buffer. */
+int pp_pack_ragged(const int32_t* trace_len, const int32_t* addr_ids, const float* values, const float* prior,
+                   int32_t prior_width, const float* obs, int32_t n_traces, int32_t obs_width, int32_t n_addr,
+                   void* out, int64_t out_words, pp_pack_info* info);
+
+/* ------------------------------------------------------------------------------------------------------
  * Whole-path entry points
  * ---------------------------------------------------------------------------------------------------- */
 

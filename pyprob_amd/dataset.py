@@ -337,19 +337,26 @@ class PackedTraceDataset:
         return out
 
     def loader(self, spec, batch_size, device, rank=0, world_size=1, num_buckets=None, prefetch=6, epochs=None,
-               shuffle_batches=True, shuffle_buckets=True, workers=1):
-        """Iterator of device PackedBatches, in sampler order. `workers` background threads take minibatch index lists
-        from the sampler, pack them on the host (`gather` + `from_ragged`) and UPLOAD them (one H2D copy per batch on a
-        side stream; numpy and the copy release the GIL), so the consumer only enqueues training steps. More than one
-        worker does not help: the packing is many small numpy calls and the threads contend for the GIL with the
-        consumer (measured: 2.06 / 2.00 / 1.37 M traces/s with 1 / 2 / 3 workers). `epochs=None` repeats forever like
-        the reference's training loop."""
+               shuffle_batches=True, shuffle_buckets=True, workers=0):
+        """Iterator of device PackedBatches, in sampler order. workers=0 (default): a minibatch is packed (`gather` + the
+        native packer, ~110 us) and uploaded (one 40-60 KB H2D copy, ~55 us) in the consumer's thread, right before it is
+        used - its 165 us hide behind the previous step's GPU time (measured 242 us per step = 4.2 M traces/s for GUM,
+        tools/loader_probe.py). workers >= 1 moves that work to background threads with a bounded look-ahead; for these
+        small minibatches that is SLOWER (437 us per step with one worker: the threads convoy on the GIL with the thread
+        that enqueues the kernels), it only pays when packing is much heavier than a step. `epochs=None` repeats forever
+        like the reference's training loop."""
         import torch
         sampler = self.sampler(batch_size, rank, world_size, num_buckets, shuffle_batches, shuffle_buckets)
-        on_gpu = torch.device(device).type == 'cuda'
+        if int(workers) <= 0:
+            e = 0
+            while epochs is None or e < epochs:
+                for ids in sampler:
+                    yield self.batch(ids, spec).to(device)
+                e += 1
+            return
         lock = threading.Condition()
         state = dict(next_seq=0, done=False, error=None, want=0)
-        ready = {}                       # seq -> (batch, event)
+        ready = {}                       # seq -> uploaded batch
         stop = threading.Event()
 
         def tickets():
@@ -361,7 +368,6 @@ class PackedTraceDataset:
         source = tickets()
 
         def work():
-            stream = torch.cuda.Stream(device=device) if on_gpu else None
             try:
                 while not stop.is_set():
                     with lock:
@@ -377,17 +383,12 @@ class PackedTraceDataset:
                             return
                         seq = state['next_seq']
                         state['next_seq'] += 1
-                    host = self.batch(ids, spec)
-                    ev = None
-                    if on_gpu:
-                        with torch.cuda.stream(stream):
-                            host.to(device)
-                            ev = torch.cuda.Event()
-                            ev.record(stream)
-                    else:
-                        host.to(device)
+                    # pack + upload on the device's default stream: the 40-60 KB copy is ordered before the consumer's
+                    # kernels by the stream itself (a side stream + event per batch cost 460 us per minibatch in torch's
+                    # per-stream allocator and event plumbing, tools/loader_probe.py)
+                    host = self.batch(ids, spec).to(device)
                     with lock:
-                        ready[seq] = (host, ev)
+                        ready[seq] = host
                         lock.notify_all()
             except BaseException as exc:   # surfaced in the consumer
                 with lock:
@@ -407,13 +408,9 @@ class PackedTraceDataset:
                         raise state['error']
                     if state['want'] not in ready:
                         return
-                    batch, ev = ready.pop(state['want'])
+                    batch = ready.pop(state['want'])
                     state['want'] += 1
                     lock.notify_all()
-                if ev is not None:
-                    cur = torch.cuda.current_stream()
-                    cur.wait_event(ev)
-                    batch.dev['_buf'].record_stream(cur)    # allocated on the worker's stream, consumed on this one
                 yield batch
         finally:
             stop.set()

@@ -58,8 +58,16 @@ class pp_gemm_args(C.Structure):
                 ('colsum', vp), ('split_k', i32), ('_pad', i32)]
 
 
+class pp_pack_info(C.Structure):
+    _fields_ = [(n, i64) for n in ('n_traces', 'n_rows', 't_max', 'device_words', 'obs', 'value', 'prior', 'addr', 'prev_row',
+                                   'grp_rows', 'trace', 'row_off_dev', 'nxt_rows', 'n_active', 'row_off', 'grp_off',
+                                   'nxt_off', 'order', 'src_row')]
+
+
 # name -> (restype, argtypes); every symbol include/pyprob_amd.h declares
 PROTOTYPES = {
+    'pp_pack_words': (i64, [i32, i64, i32, i32, i32]),
+    'pp_pack_ragged': (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, i64, vp]),
     'pp_abi_version': (C.c_int, []),
     'pp_last_error': (C.c_char_p, []),
     'pp_device_count': (C.c_int, []),

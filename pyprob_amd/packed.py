@@ -37,7 +37,51 @@ class PackedBatch:
     # ---------------------------------------------------------------------------------------------------
     @staticmethod
     def from_ragged(trace_len, addr_ids, values, prior, obs, n_addr):
-        """trace-major ragged arrays -> step-major packed batch.
+        """trace-major ragged arrays -> step-major packed batch, by the native packer of the C ABI (pp_pack_ragged: one
+        pass over the rows into ONE buffer that `.to()` uploads with one copy). Same result as `from_ragged_numpy`.
+
+        trace_len [B] controlled length of every trace; addr_ids [R] engine address id per variable;
+        values [R]; prior [R, >=2]; obs [B, obs_width]."""
+        lib = L.load()
+        trace_len = np.ascontiguousarray(trace_len, np.int32).reshape(-1)
+        B = len(trace_len)
+        if B == 0:
+            raise ValueError('empty batch')
+        if np.any(trace_len <= 0):
+            raise ValueError('Trace of length zero.')        # pyprob/nn/dataset.py:28-29
+        addr_ids = np.ascontiguousarray(addr_ids, np.int32).reshape(-1)
+        values = np.ascontiguousarray(values, np.float32).reshape(-1)
+        prior = np.ascontiguousarray(prior, np.float32)
+        pw = prior.shape[1] if prior.ndim == 2 else 0
+        obs = np.ascontiguousarray(obs, np.float32).reshape(B, -1)
+        R, T = int(trace_len.sum()), int(trace_len.max())
+        if len(addr_ids) != R or len(values) != R or (pw and len(prior) != R):
+            raise ValueError('ragged columns do not match the trace lengths')
+        words = lib.pp_pack_words(B, R, T, obs.shape[1], int(n_addr))
+        buf = np.empty(words, np.float32)
+        info = L.pp_pack_info()
+        L.check(lib.pp_pack_ragged(trace_len.ctypes.data, addr_ids.ctypes.data, values.ctypes.data,
+                                   prior.ctypes.data if pw else None, pw, obs.ctypes.data, B, obs.shape[1], int(n_addr),
+                                   buf.ctypes.data, words, C.byref(info)), 'pp_pack_ragged')
+        ib = buf.view(np.int32)
+        W = obs.shape[1]
+
+        def f(o, n):
+            return buf[o:o + n]
+
+        def i(o, n):
+            return ib[o:o + n]
+        nx = max(R - B, 0)
+        pb = PackedBatch(B, R, n_addr, f(info.obs, B * W).reshape(B, W), f(info.value, R), f(info.prior, 2 * R).reshape(R, 2),
+                         i(info.addr, R), i(info.prev_row, R), i(info.trace, R), i(info.n_active, T), i(info.row_off, T + 1),
+                         i(info.grp_rows, R), i(info.grp_off, n_addr + 1), i(info.nxt_rows, nx), i(info.nxt_off, n_addr + 1),
+                         i(info.order, B).astype(np.int64), i(info.src_row, R).astype(np.int64), float(R) / B)
+        pb._buf, pb._dev_words, pb._info = buf, int(info.device_words), info
+        return pb
+
+    @staticmethod
+    def from_ragged_numpy(trace_len, addr_ids, values, prior, obs, n_addr):
+        """The numpy statement of the packing algorithm (the checker of the native packer in the tests).
 
         trace_len [B] controlled length of every trace; addr_ids [R] engine address id per variable;
         values [R]; prior [R, >=2]; obs [B, obs_width]."""
@@ -91,11 +135,14 @@ class PackedBatch:
         B, R = self.n_traces, self.n_rows
         nx = len(self.nxt_rows)
         nf = B * self.obs.shape[1] + 3 * R
-        # ONE host buffer and ONE copy: float columns first, then the int32 index columns (bit patterns in a float32 array)
-        host = np.empty(nf + 4 * R + (self.t_max + 1) + max(nx, 1), np.float32)
-        host[:nf] = np.concatenate([self.obs.reshape(-1), self.value, self.prior.reshape(-1)])
-        host[nf:].view(np.int32)[:] = np.concatenate([self.addr, self.prev_row, self.grp_rows, self.trace, self.row_off,
-                                                      self.nxt_rows if nx else np.zeros(1, np.int32)])
+        if getattr(self, '_buf', None) is not None:     # packed natively: the device part is already one buffer
+            host = self._buf[:self._dev_words]
+        else:
+            # ONE host buffer and ONE copy: float columns first, then the int32 index columns (bit patterns in float32)
+            host = np.empty(nf + 4 * R + (self.t_max + 1) + max(nx, 1), np.float32)
+            host[:nf] = np.concatenate([self.obs.reshape(-1), self.value, self.prior.reshape(-1)])
+            host[nf:].view(np.int32)[:] = np.concatenate([self.addr, self.prev_row, self.grp_rows, self.trace, self.row_off,
+                                                          self.nxt_rows if nx else np.zeros(1, np.int32)])
         buf = torch.from_numpy(host).to(device, non_blocking=False)
         f = buf[:nf]
         i = buf[nf:].view(torch.int32)

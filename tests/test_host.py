@@ -136,3 +136,30 @@ def test_ragged_synthetic_generator_lengths():
     # GUMM trace length: mean 2/(pi/4) = 2.546 (reference tests/test_model.py:80 pins 2.563 +- tolerance)
     assert abs(arr['trace_len'].mean() - 2.546) < 0.1
     assert arr['trace_len'].min() == 2
+
+
+def test_native_packer_matches_the_numpy_statement():
+    """pp_pack_ragged (C ABI, host code) against packed.PackedBatch.from_ragged_numpy on ragged / uniform / single-trace
+    minibatches, wide prior columns, and its error behaviour (dataset.py:28-29)."""
+    from pyprob_amd.packed import PackedBatch
+    rng = np.random.default_rng(5)
+    fields = ('obs', 'value', 'prior', 'addr', 'prev_row', 'trace', 'n_active', 'row_off', 'grp_rows', 'grp_off', 'nxt_rows',
+              'nxt_off', 'order', 'src_row', 'cur_counts', 'prev_counts')
+    for B, max_len, n_addr, pw, W in ((1, 1, 1, 2, 2), (7, 1, 3, 2, 1), (64, 5, 4, 3, 2), (1024, 12, 12, 2, 2), (33, 3, 2, 1, 0)):
+        lens = rng.integers(1, max_len + 1, B)
+        R = int(lens.sum())
+        ids = rng.integers(0, n_addr, R)
+        vals = rng.normal(size=R).astype(np.float32)
+        prior = rng.normal(size=(R, pw)).astype(np.float32)
+        obs = rng.normal(size=(B, W)).astype(np.float32)
+        a = PackedBatch.from_ragged(lens, ids, vals, prior, obs, n_addr)
+        b = PackedBatch.from_ragged_numpy(lens, ids, vals, prior, obs, n_addr)
+        for n in fields:
+            assert np.array_equal(getattr(a, n), getattr(b, n)), (B, n)
+        assert a.t_max == b.t_max and a.n_rows == b.n_rows and abs(a.mean_length_controlled - b.mean_length_controlled) < 1e-12
+    with pytest.raises(ValueError, match='Trace of length zero'):
+        PackedBatch.from_ragged([2, 0], [0, 0], [0.0, 0.0], np.zeros((2, 2)), np.zeros((2, 1)), 1)
+    with pytest.raises(ValueError):
+        PackedBatch.from_ragged([], [], [], np.zeros((0, 2)), np.zeros((0, 1)), 1)
+    with pytest.raises(RuntimeError):      # address id outside the table: rejected by the C side
+        PackedBatch.from_ragged([1], [5], [0.0], np.zeros((1, 2)), np.zeros((1, 1)), 2)

@@ -4,6 +4,9 @@ import os, sys, time, tempfile, shutil
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np
+if os.environ.get('PP_SWITCH'):
+    sys.setswitchinterval(float(os.environ['PP_SWITCH']))
+import torch  # noqa: F401  (first import of a fresh box takes seconds: keep it out of the timed loops)
 from pyprob_amd.dataset import PackedTraceDataset, PackedTraceWriter
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
@@ -65,7 +68,7 @@ try:
         torch.cuda.synchronize()
         t5 = time.perf_counter()
         steps = 0
-        for b in ds.loader(eng.spec, B, dev, epochs=1, prefetch=8, workers=int(os.environ.get('PP_LOADER_WORKERS', '2'))):
+        for b in ds.loader(eng.spec, B, dev, epochs=1, prefetch=8, workers=int(os.environ.get('PP_LOADER_WORKERS', '0'))):
             eng.train_step(b, 1e-3)
             steps += 1
             if steps == 400:
