@@ -146,6 +146,24 @@ int pp_pack_ragged(const int32_t* trace_len, const int32_t* addr_ids, const floa
                    int32_t prior_width, const float* obs, int32_t n_traces, int32_t obs_width, int32_t n_addr,
                    void* out, int64_t out_words, pp_pack_info* info);
 
+/* The same packing straight from the columns of a packed on-disk trace dataset (pyprob_amd/dataset.py: memory-mapped
+ * .npy columns, one struct per shard): minibatch = the traces with global indices ids[0..n_ids). `first` [n_shards+1]
+ * is the global index of every shard's first trace. addr_remap (or NULL) maps a shard's address ids to the network's;
+ * an unmapped address (-1) is an error (the caller polymorphs first, inference_network_lstm.py:150-152). Replaces
+ * OfflineDataset.__getitem__ + the DataLoader collate (pyprob/nn/dataset.py:197-205, 262). */
+typedef struct pp_shard_columns {
+    const int32_t* trace_len;   /* [n] */
+    const int64_t* row_off;     /* [n+1] */
+    const float*   obs;         /* [n, obs_width] */
+    const float*   value;       /* [rows] */
+    const float*   prior;       /* [rows, 2] */
+    const int32_t* addr;        /* [rows] shard-local address ids */
+    const int32_t* addr_remap;  /* [shard addresses] -> network address id, or NULL for identity */
+} pp_shard_columns;
+
+int pp_pack_indexed(const pp_shard_columns* shards, int32_t n_shards, const int64_t* first, const int64_t* ids,
+                    int32_t n_ids, int32_t obs_width, int32_t n_addr, void* out, int64_t out_words, pp_pack_info* info);
+
 /* ------------------------------------------------------------------------------------------------------
  * Whole-path entry points
  * ---------------------------------------------------------------------------------------------------- */
@@ -184,6 +202,8 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params /*d
  *   grad_scale    1/world_size for data-parallel averaging (:324-325), else 1
  *   flags         PP_ADAM_ZERO_GRADS: clear every consumed gradient chunk (optimizer.zero_grad() of the next step,
  *                 inference_network.py:486); the next pp_ic_loss can then run without PP_LOSS_ZERO_GRADS
+ *   skip          dev int32[1] or NULL: when non-zero the call does nothing - pass pp_ic_loss's status_out to skip a
+ *                 batch whose loss is not finite (inference_network_lstm.py:216-217) without reading it on the host
  * One launch (bias corrections are derived per chunk from the tensor's step count).
  */
 #define PP_ADAM_ZERO_GRADS 1
@@ -191,7 +211,7 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params /*d
 int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
                  const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* scratch,
                  int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                 int32_t flags, void* stream);
+                 int32_t flags, const int32_t* skip, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Importance sampling with the inference network, lock-step over N particles

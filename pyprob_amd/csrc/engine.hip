@@ -50,7 +50,7 @@ int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* lo
                   hipStream_t st);
 int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
               const float* active, int32_t* tensor_step, int32_t* arrived, int n_tensors, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, int flags, hipStream_t st);
+              float eps, float wd, float gscale, int flags, const int32_t* skip, hipStream_t st);
 
 extern long long* g_timeline;   // kernels.hip
 
@@ -538,9 +538,9 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params, fl
 int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
                  const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* arrived, int32_t n_tensors,
                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t flags,
-                 void* stream) {
+                 const int32_t* skip, void* stream) {
     return pp::adam_step(params, grads, exp_avg, exp_avg_sq, n_params, chunk_tensor, active, tensor_step, arrived, n_tensors,
-                         lr, beta1, beta2, eps, weight_decay, grad_scale, flags, pp::as_stream(stream));
+                         lr, beta1, beta2, eps, weight_decay, grad_scale, flags, skip, pp::as_stream(stream));
 }
 
 int pp_colsum_f32(const float* X, int64_t ldx, const int32_t* row_idx, int32_t n_rows, int32_t n_cols, float* out,

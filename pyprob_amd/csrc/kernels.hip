@@ -977,11 +977,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
                                                    int n_chunks, const float* __restrict__ active,
                                                    int32_t* __restrict__ tensor_step, int32_t* __restrict__ scratch, float lr,
                                                    float beta1, float beta2, float eps, float wd, float gscale,
-                                                   int zero_grads, int dbg) {
+                                                   int zero_grads, const int32_t* __restrict__ skip) {
     __shared__ float s_corr[2];
     const int b = blockIdx.x;
+    // the loss of this step was not finite: the reference skips the batch (inference_network_lstm.py:216-217, no
+    // optimizer step); checked on the device so that the host does not have to synchronise every iteration
+    const bool skipped = skip && skip[0] != 0;
     const int t = chunk_tensor[b];
     if (t < 0 || !(active[t] > 0.0f)) return;   // workgroup-uniform; every chunk of a tensor takes the same branch
+    if (skipped) {   // no update, no step count; the (non-finite) gradients are still cleared for the next step
+        if (zero_grads) *reinterpret_cast<f32x4*>(Gr + (int64_t)b * 1024 + threadIdx.x * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     int32_t* const sc = scratch + (int64_t)t * PP_ADAM_SCRATCH;
     // the chunk's loads are issued before thread 0 walks its dependent chain (step count, corrections)
     const int64_t o = (int64_t)b * 1024 + threadIdx.x * 4;
@@ -990,7 +997,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     f32x4 m = *reinterpret_cast<f32x4*>(M + o);
     f32x4 v = *reinterpret_cast<f32x4*>(V + o);
     int step_old = 0, first = 0, chunks = 0;
-    if (dbg == 2) { if (threadIdx.x == 0) { s_corr[0] = lr; s_corr[1] = 1.0f; } } else
     if (threadIdx.x == 0) {
         first = __atomic_load_n(sc + ADAM_FIRST, __ATOMIC_RELAXED) - 1;
         chunks = __atomic_load_n(sc + ADAM_CHUNKS, __ATOMIC_RELAXED);
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     const int k = (b - first) & 31;                         // sub-counter of this chunk
     const int quota = (chunks - k + 31) >> 5;               // chunks of the tensor that share it
     int ticket = -1;
-    if (threadIdx.x == 0 && dbg != 1) ticket = atomicAdd(sc + 32 * k, 1);
+    if (threadIdx.x == 0) ticket = atomicAdd(sc + 32 * k, 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float g = g0[e] * gscale;
@@ -1060,14 +1066,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
 
 int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
               const float* active, int32_t* tensor_step, int32_t* scratch, int n_tensors, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, int flags, hipStream_t st) {
+              float eps, float wd, float gscale, int flags, const int32_t* skip, hipStream_t st) {
     PP_CHECK_ARG(params && grads && m && v && chunk_tensor && active && tensor_step && scratch, "pp_adam_step: null pointer");
     PP_CHECK_ARG(n_params % 1024 == 0, "pp_adam_step: n_params must be a multiple of 1024 (padded tensors)");
     if (n_tensors <= 0 || n_params == 0) return 0;
     const int n_chunks = (int)(n_params / 1024);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, params, grads, m, v, chunk_tensor, n_chunks,
-                       active, tensor_step, scratch, lr, beta1, beta2, eps, wd, gscale, (flags & PP_ADAM_ZERO_GRADS) ? 1 : 0,
-                       getenv("PP_ADAM_DBG") ? atoi(getenv("PP_ADAM_DBG")) : 0);
+                       active, tensor_step, scratch, lr, beta1, beta2, eps, wd, gscale, (flags & PP_ADAM_ZERO_GRADS) ? 1 : 0, skip);
     PP_LAUNCH_CHECK("pp_adam_step");
     return 0;
 }

@@ -35,6 +35,7 @@ import numpy as np
 from .packed import PackedBatch, distribution_params
 
 FORMAT_VERSION = 1
+_PINNED_RING = dict(slots=[], next=0)   # staging buffers of PackedTraceDataset.device_batch
 _COLUMNS = ('trace_len', 'trace_type', 'row_off', 'obs', 'value', 'prior', 'addr')
 
 
@@ -104,9 +105,12 @@ class PackedTraceWriter:
         self._len.append(len(vc))
         self._type.append(self._trace_type(ids))
 
-    def add_columns(self, trace_len, addresses, address_ids, values, prior, obs):
+    def add_columns(self, trace_len, addresses, address_ids, values, prior, obs, trace_types=None):
         """Vectorised input (trace generators, converters): `addresses` = [(address, distribution name, n_categories)]
-        is the table `address_ids` [R] indexes; trace_len [B], values [R], prior [R, 2], obs [B, W]."""
+        is the table `address_ids` [R] indexes; trace_len [B], values [R], prior [R, 2], obs [B, W]. `trace_types` =
+        (type index per trace [B], [address-id sequence of every type]) when the producer already knows which traces
+        share an address sequence (the lock-step generator: one type per control-flow path); otherwise the types are
+        found with a row-wise unique per trace length (an argsort over all traces)."""
         trace_len = np.asarray(trace_len, np.int64)
         if np.any(trace_len <= 0):
             raise ValueError('Trace of length zero.')
@@ -121,6 +125,11 @@ class PackedTraceWriter:
         self._addr.append(ids)
         self._obs.append(obs)
         self._len.append(trace_len.astype(np.int32))
+        if trace_types is not None:
+            type_of, seqs = trace_types
+            tids = np.asarray([self._trace_type(remap[np.asarray(q, np.int64)]) for q in seqs], np.int32)
+            self._type.append(tids[np.asarray(type_of, np.int64)])
+            return
         # trace types: unique address sequences, found per distinct length with a row-wise unique
         types = np.empty(len(trace_len), np.int32)
         for L in np.unique(trace_len):
@@ -189,9 +198,9 @@ class _Shard:
 class _MemoryShard:
     """The columns of one shard held in memory (vectorised online generation): same attributes as _Shard."""
 
-    def __init__(self, obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs):
+    def __init__(self, obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs, trace_types=None):
         w = PackedTraceWriter(None, obs_names, obs_widths)
-        w.add_columns(trace_len, address_table, address_ids, values, prior, obs)
+        w.add_columns(trace_len, address_table, address_ids, values, prior, obs, trace_types)
         self.meta = dict(version=FORMAT_VERSION, n_traces=int(len(trace_len)), obs_names=list(obs_names),
                          obs_widths=[int(x) for x in w.obs_widths],
                          addresses=[dict(address=a, distribution=d, n_categories=c) for a, d, c in w._addr_table],
@@ -213,9 +222,9 @@ class PackedTraceDataset:
     sampler; plus the vectorised `gather` / `batch` / `loader` the hot path uses."""
 
     @classmethod
-    def from_columns(cls, obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs):
+    def from_columns(cls, obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs, trace_types=None):
         """An in-memory dataset from ragged columns (e.g. Model.prior_traces_packed): no files, same interface."""
-        return cls([_MemoryShard(obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs)])
+        return cls([_MemoryShard(obs_names, obs_widths, trace_len, address_table, address_ids, values, prior, obs, trace_types)])
 
     def __init__(self, dataset_dir):
         if isinstance(dataset_dir, (list, tuple)) and dataset_dir and not isinstance(dataset_dir[0], str):
@@ -314,15 +323,79 @@ class PackedTraceDataset:
             obs[sel] = s.obs[local]
         return lens, addr, value, prior, obs
 
-    def batch(self, indices, spec):
-        """Host PackedBatch of the given traces for a network with address table `spec` (unknown address -> KeyError,
-        the caller polymorphs first)."""
-        lens, addr, value, prior, obs = self.gather(indices)
-        to_engine = np.asarray([spec.address_id.get(a[0], -1) for a in self.addresses], np.int64)
-        ids = to_engine[addr]
-        if np.any(ids < 0):
-            raise KeyError('Address unknown by inference network: {}'.format(self.addresses[int(addr[np.argmax(ids < 0)])][0]))
-        return PackedBatch.from_ragged(lens, ids, value, prior, obs, len(spec.addresses))
+    def batch(self, indices, spec, out=None):
+        """Host PackedBatch of the given traces for a network with address table `spec`: ONE call of the native packer
+        (pp_pack_indexed) reads the shard columns (memory-mapped) in place and writes the step-major layout - no
+        intermediate ragged arrays. An address the network does not know raises KeyError (the caller polymorphs
+        first). `gather` + `PackedBatch.from_ragged` is the two-step equivalent (and the test oracle of this path)."""
+        import ctypes as C
+        from . import lib as L
+        lib = L.load()
+        ids = np.ascontiguousarray(indices, np.int64).reshape(-1)
+        if ids.size == 0:
+            raise ValueError('empty batch')
+        if np.any(ids < 0) or np.any(ids >= self._length):
+            raise IndexError('trace index out of range')
+        n_addr = len(spec.addresses)
+        key = (id(spec), n_addr)
+        if getattr(self, '_native_key', None) != key:      # (re)build the per-shard address maps for this network
+            to_engine = np.asarray([spec.address_id.get(a[0], -1) for a in self.addresses], np.int32)
+            self._native_remap = [np.ascontiguousarray(to_engine[r]) for r in self._addr_remap]
+            arr = (L.pp_shard_columns * len(self._shards))()
+            keep = []
+            for k, s in enumerate(self._shards):
+                cols = [np.asarray(getattr(s, n)) if not isinstance(getattr(s, n), np.memmap) else getattr(s, n)
+                        for n in ('trace_len', 'row_off', 'obs', 'value', 'prior', 'addr')]
+                keep.append(cols)
+                (arr[k].trace_len, arr[k].row_off, arr[k].obs, arr[k].value, arr[k].prior, arr[k].addr) = [c.ctypes.data for c in cols]
+                arr[k].addr_remap = self._native_remap[k].ctypes.data
+            self._native_shards, self._native_keep, self._native_key = arr, keep, key
+        lens = self.trace_len[ids]
+        B, R, T = len(ids), int(lens.sum()), int(lens.max())
+        words = lib.pp_pack_words(B, R, T, self.obs_width, n_addr)
+        buf = np.empty(words, np.float32) if out is None else out(words)     # out: callable giving a float32 buffer
+        info = L.pp_pack_info()
+        rc = lib.pp_pack_indexed(self._native_shards, len(self._shards), self._first.ctypes.data, ids.ctypes.data, B,
+                                 self.obs_width, n_addr, buf.ctypes.data, words, C.byref(info))
+        if rc != 0:
+            msg = lib.pp_last_error().decode()
+            if 'address' in msg:
+                raise KeyError('Address unknown by inference network ({})'.format(msg))
+            raise RuntimeError('pp_pack_indexed failed: ' + msg)
+        return PackedBatch._wrap_native(buf, info, self.obs_width, n_addr)
+
+    def device_batch(self, indices, spec, device):
+        """`batch(...).to(device)` through a ring of PINNED host buffers: the packer writes straight into page-locked
+        memory and the upload is one asynchronous DMA (a pageable source is staged and synchronised by the runtime:
+        55-570 us per copy measured, tools/loader_probe.py). A slot is reused only after its copy has completed."""
+        import torch
+        if torch.device(device).type != 'cuda':
+            return self.batch(indices, spec).to(device)
+        ring = _PINNED_RING        # process-wide: page-locking memory costs ~1 ms per buffer, datasets come and go
+        depth = 8
+        if len(ring['slots']) < depth:
+            ring['slots'].append(dict(tensor=None, event=None))
+        slot = ring['slots'][ring['next'] % len(ring['slots'])]
+        ring['next'] += 1
+        if slot['event'] is not None:
+            slot['event'].synchronize()
+
+        def out(words):
+            if slot['tensor'] is None or slot['tensor'].numel() < words:
+                slot['tensor'] = torch.empty(max(words, 1 << 16), dtype=torch.float32).pin_memory()
+            return slot['tensor'].numpy()[:words]
+        pb = self.batch(indices, spec, out=out)
+        # the host-side arrays of the batch must outlive the slot: detach them from the ring
+        for name in ('n_active', 'row_off', 'grp_off', 'nxt_off', 'order', 'src_row', 'cur_counts', 'prev_counts'):
+            setattr(pb, name, np.array(getattr(pb, name)))
+        pb._pinned = slot['tensor']
+        pb.to(device)
+        if slot['event'] is None:
+            slot['event'] = torch.cuda.Event()
+        slot['event'].record()
+        pb._buf = pb._pinned = None       # the device copy is the batch now; host views into the ring are gone
+        pb.obs = pb.value = pb.prior = pb.addr = pb.prev_row = pb.trace = pb.grp_rows = pb.nxt_rows = None
+        return pb
 
     def addresses_of(self, indices):
         """[(address, distribution name, n_categories)] used by the given traces, in first-statement order: what
@@ -351,7 +424,7 @@ class PackedTraceDataset:
             e = 0
             while epochs is None or e < epochs:
                 for ids in sampler:
-                    yield self.batch(ids, spec).to(device)
+                    yield self.device_batch(ids, spec, device)
                 e += 1
             return
         lock = threading.Condition()
@@ -466,7 +539,7 @@ class VectorisedOnlineDataset:
         self.refresh()
 
     def refresh(self):
-        cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device)
+        cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device, return_types=True)
         self._ds = PackedTraceDataset.from_columns(self.obs_names, None, *cols)
         self.generated += self._chunk
 
@@ -502,7 +575,7 @@ def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=
         path = os.path.join(dataset_dir, 'pyprob_traces_packed_{:06d}_{}'.format(shard, n))
         with PackedTraceWriter(path, names) as w:
             if vectorised:
-                w.add_columns(*model.prior_traces_packed(n, names, *args, **kwargs))
+                w.add_columns(*model.prior_traces_packed(n, names, *args, return_types=True, **kwargs))
             else:
                 for _ in range(n):
                     w.add_trace(next(gen))

@@ -109,7 +109,7 @@ class ICEngine:
         return {name: self.tensor(name, self.grads).detach().cpu().numpy().copy() for name in self.spec.tensors}
 
     # ---- the hot path ----------------------------------------------------------------------------------------
-    def loss(self, batch, backward=False, keep_lp=False, zero_grads=True):
+    def loss(self, batch, backward=False, keep_lp=False, zero_grads=True, loss_out=None, status_out=None):
         """InferenceNetworkLSTM._loss(batch) (+ backward). Returns the device loss scalar (1-element view); the
         non-finite status stays on the device in self.status_buf[0] (no host sync here)."""
         if batch.c is None:
@@ -127,7 +127,9 @@ class ICEngine:
             lp = torch.empty(batch.n_rows, dtype=torch.float32, device=self.device)
         rc = self.lib.pp_ic_loss(C.byref(self.net), C.byref(batch.c), self.params.data_ptr(),
                                  self.grads.data_ptr() if backward else None, self.workspace.data_ptr(), self.ws_bytes,
-                                 self.loss_buf.data_ptr(), self.status_buf.data_ptr(), L.ptr(lp), flags, L.stream_ptr())
+                                 (self.loss_buf if loss_out is None else loss_out).data_ptr(),
+                                 (self.status_buf if status_out is None else status_out).data_ptr(), L.ptr(lp), flags,
+                                 L.stream_ptr())
         L.check(rc, 'pp_ic_loss')
         if backward:
             self._set_active(batch)
@@ -144,7 +146,7 @@ class ICEngine:
         self.active.copy_(act)
         self._active_key = key
 
-    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, zero_grads=False):
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, zero_grads=False, skip=None):
         """optimizer.step() for optim.Adam (inference_network.py:348,496); grads are divided by world_size first
         when data-parallel (inference_network.py:324-325). zero_grads=True also performs the NEXT step's
         optimizer.zero_grad() (:486) in the same pass: the consumed gradient chunks are cleared, gradients of tensors
@@ -153,7 +155,7 @@ class ICEngine:
                                    self.exp_avg_sq.data_ptr(), self.spec.n_params, self.chunk_tensor.data_ptr(),
                                    self.active.data_ptr(), self.tensor_step.data_ptr(), self.arrived.data_ptr(),
                                    self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
-                                   L.PP_ADAM_ZERO_GRADS if zero_grads else 0, L.stream_ptr())
+                                   L.PP_ADAM_ZERO_GRADS if zero_grads else 0, L.ptr(skip), L.stream_ptr())
         L.check(rc, 'pp_adam_step')
         self._grads_clean = bool(zero_grads)
 

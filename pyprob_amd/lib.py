@@ -64,8 +64,13 @@ class pp_pack_info(C.Structure):
                                    'nxt_off', 'order', 'src_row')]
 
 
+class pp_shard_columns(C.Structure):
+    _fields_ = [(n, vp) for n in ('trace_len', 'row_off', 'obs', 'value', 'prior', 'addr', 'addr_remap')]
+
+
 # name -> (restype, argtypes); every symbol include/pyprob_amd.h declares
 PROTOTYPES = {
+    'pp_pack_indexed': (C.c_int, [vp, i32, vp, vp, i32, i32, i32, vp, i64, vp]),
     'pp_pack_words': (i64, [i32, i64, i32, i32, i32]),
     'pp_pack_ragged': (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, i64, vp]),
     'pp_abi_version': (C.c_int, []),
@@ -74,7 +79,7 @@ PROTOTYPES = {
     'pp_ic_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32, i32]),
     'pp_ic_loss': (C.c_int, [C.POINTER(pp_net), C.POINTER(pp_batch), vp, vp, vp, C.c_size_t, vp, vp, vp, i32, vp]),
     'pp_adam_step': (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
-                               C.c_float, C.c_float, i32, vp]),
+                               C.c_float, C.c_float, i32, vp, vp]),
     'pp_is_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32]),
     'pp_is_init': (C.c_int, [C.POINTER(pp_net), vp, vp, vp, vp, C.c_size_t, vp]),
     'pp_is_step': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, C.c_uint64,

@@ -88,7 +88,7 @@ class Model:
         emp.num_paths = n_paths
         return emp
 
-    def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, **kwargs):
+    def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, return_types=False, **kwargs):
         """num_traces traces of the program in PRIOR_FOR_INFERENCE_NETWORK mode, generated TOGETHER (one execution of
         forward() per distinct control-flow path, state.PriorLockStep) and returned as ragged columns
         (trace_len, address table, address ids, values, prior parameters, observations) - what a training minibatch is
@@ -106,7 +106,7 @@ class Model:
         finally:
             state._lock_step = None
             state._current_trace = None
-        return ls.columns(obs_names)
+        return ls.columns(obs_names, return_types)
 
     def prior_results(self, num_traces=10, *args, **kwargs):
         return self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=trace_result, *args, **kwargs)

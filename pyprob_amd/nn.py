@@ -371,6 +371,11 @@ class InferenceNetworkLSTM:
         # Packed offline dataset (pyprob_amd/dataset.py): minibatches come from the reference's bucketed sampler over the
         # (length, type)-sorted index space (dataset.py:328-400) and are packed from memory-mapped columns - no Trace
         # objects. Anything else is indexed trace by trace like the reference's DataLoader does.
+        sync_every = 1 if (log_file_name or world > 1 or stop_with_bad_loss) else 16
+        ring_n = 64
+        loss_ring = torch.zeros(ring_n, dtype=torch.float32, device=self._engine.device)
+        status_ring = torch.zeros(ring_n, dtype=torch.int32, device=self._engine.device)
+        pending = []
         packed = hasattr(dataset, 'gather') and hasattr(dataset, 'sorted_indices')
         if packed:
             sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
@@ -396,44 +401,72 @@ class InferenceNetworkLSTM:
             layers_changed = False if self._layers_pre_generated else self._polymorph(batch)
             if layers_changed:
                 self._engine.reset_optimizer()                                        # :481-483
+            # The loss and the non-finite status of a step stay on the device: a slot of a small ring per iteration, read
+            # back every `sync_every` iterations (1 = the reference's behaviour: float(loss) every iteration,
+            # inference_network.py:497; used whenever a log file wants per-iteration timestamps or ranks must agree).
+            # Adam checks the status flag itself (pp_adam_step `skip`), so a bad batch is skipped without a host sync.
+            slot = len(pending) % ring_n
+            l_out, s_out = loss_ring[slot:slot + 1], status_ring[slot:slot + 1]
             if packed:
-                host = dataset.batch(ids, self._engine.spec)
-                batch.mean_length_controlled = host.mean_length_controlled
+                dev_batch = dataset.device_batch(ids, self._engine.spec, self._engine.device)
+                batch.mean_length_controlled = dev_batch.mean_length_controlled
                 batch.sub_batches = [None] * len(np.unique(dataset.trace_type[np.asarray(ids)]))
-                success, loss = self._loss(host.to(self._engine.device), backward=True)
+                pb = dev_batch
             else:
-                success, loss = self._loss(batch, backward=True)
-            if success and int(self._engine.status_buf[0].item()) != 0:
-                success = False
-            if not success:
-                print('Cannot compute loss, skipping batch. Loss: {}'.format(loss))
-                if stop_with_bad_loss:
-                    return
-                continue
+                pb = self._pack(batch)
+                if pb is None:
+                    print('Cannot compute loss, skipping batch. Loss: {}'.format(0))
+                    if stop_with_bad_loss:
+                        return
+                    continue
+            for info_id, n in enumerate(pb.cur_counts):
+                if n > 0:
+                    self._engine.spec.addresses[info_id].total_train_iterations += 1      # :198
             if world > 1:
+                self._engine.loss(pb, backward=True)                                  # loss in the all-reduced tail
                 self._engine.allreduce_grads()                                        # :494-495
-            self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True)
-            loss = float(loss.item()) / (world if world > 1 else 1)                  # tail is the all-reduced SUM
-            now = time.time()
-            if self._loss_init is None:
-                self._loss_init = self._loss_max = loss
-            self._loss_min = min(self._loss_min, loss)
-            self._loss_max = max(self._loss_max, loss)
-            self._loss_previous = loss
-            self._total_train_iterations += 1
+                l_out.copy_(self._engine.loss_buf[:1])
+                s_out.copy_(self._engine.status_buf[:1])
+                self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True,
+                                       skip=self._engine.status_buf)
+            else:
+                self._engine.loss(pb, backward=True, loss_out=l_out, status_out=s_out)
+                self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True, skip=s_out)
+            pending.append((batch.size, batch.mean_length_controlled, len(batch.sub_batches)))
             trace += batch.size * world
-            self._total_train_traces += batch.size * world
-            self._total_train_seconds = prev_seconds + (now - time_start)
-            self._history_train_loss.append(loss)
-            self._history_train_loss_trace.append(self._total_train_traces)
-            tps = batch.size * world / max(now - last, 1e-9)
+            stop = trace >= num_traces
+            if len(pending) < sync_every and not stop:
+                continue
+            # ---- read back and book-keep the pending iterations ------------------------------------------------------
+            losses = loss_ring[:len(pending)].cpu().numpy()
+            bad = status_ring[:len(pending)].cpu().numpy()
+            now = time.time()
+            dt_each = (now - last) / len(pending)
+            for k, (bsize, mean_len, n_sub) in enumerate(pending):
+                loss = float(losses[k]) / (world if world > 1 else 1)                # tail is the all-reduced SUM
+                if bad[k] != 0:
+                    print('Cannot compute loss, skipping batch. Loss: {}'.format(loss))
+                    trace -= bsize * world
+                    stop = trace >= num_traces
+                    if stop_with_bad_loss:
+                        return
+                    continue
+                if self._loss_init is None:
+                    self._loss_init = self._loss_max = loss
+                self._loss_min = min(self._loss_min, loss)
+                self._loss_max = max(self._loss_max, loss)
+                self._loss_previous = loss
+                self._total_train_iterations += 1
+                self._total_train_traces += bsize * world
+                self._total_train_seconds = prev_seconds + (last + dt_each * (k + 1) - time_start)
+                self._history_train_loss.append(loss)
+                self._history_train_loss_trace.append(self._total_train_traces)
+                if log_file:
+                    log_file.write('{}, {}, {}, {}, {}, {}, {}, {}\n'.format(
+                        self._total_train_seconds, self._total_train_iterations, self._total_train_traces, loss,
+                        self._learning_rate(), mean_len, n_sub, bsize * world / max(dt_each, 1e-9)))
             last = now
-            if log_file:
-                log_file.write('{}, {}, {}, {}, {}, {}, {}, {}\n'.format(self._total_train_seconds, self._total_train_iterations,
-                               self._total_train_traces, loss, self._learning_rate(), batch.mean_length_controlled,
-                               len(batch.sub_batches), tps))
-            if trace >= num_traces:
-                stop = True
+            pending = []
         if verbose and rank == 0:
             print('Stop condition reached. num_traces: {}  loss {:+.3e}  traces/s {:,.0f}'.format(
                 num_traces, self._loss_previous, self._total_train_traces / max(self._total_train_seconds, 1e-9)))

@@ -63,8 +63,13 @@ class PackedBatch:
         L.check(lib.pp_pack_ragged(trace_len.ctypes.data, addr_ids.ctypes.data, values.ctypes.data,
                                    prior.ctypes.data if pw else None, pw, obs.ctypes.data, B, obs.shape[1], int(n_addr),
                                    buf.ctypes.data, words, C.byref(info)), 'pp_pack_ragged')
+        return PackedBatch._wrap_native(buf, info, obs.shape[1], n_addr)
+
+    @staticmethod
+    def _wrap_native(buf, info, W, n_addr):
+        """Views into the one buffer the native packer filled (pp_pack_info word offsets)."""
         ib = buf.view(np.int32)
-        W = obs.shape[1]
+        B, R, T = int(info.n_traces), int(info.n_rows), int(info.t_max)
 
         def f(o, n):
             return buf[o:o + n]
@@ -75,7 +80,7 @@ class PackedBatch:
         pb = PackedBatch(B, R, n_addr, f(info.obs, B * W).reshape(B, W), f(info.value, R), f(info.prior, 2 * R).reshape(R, 2),
                          i(info.addr, R), i(info.prev_row, R), i(info.trace, R), i(info.n_active, T), i(info.row_off, T + 1),
                          i(info.grp_rows, R), i(info.grp_off, n_addr + 1), i(info.nxt_rows, nx), i(info.nxt_off, n_addr + 1),
-                         i(info.order, B).astype(np.int64), i(info.src_row, R).astype(np.int64), float(R) / B)
+                         i(info.order, B), i(info.src_row, R), float(R) / B)
         pb._buf, pb._dev_words, pb._info = buf, int(info.device_words), info
         return pb
 
@@ -135,7 +140,11 @@ class PackedBatch:
         B, R = self.n_traces, self.n_rows
         nx = len(self.nxt_rows)
         nf = B * self.obs.shape[1] + 3 * R
-        if getattr(self, '_buf', None) is not None:     # packed natively: the device part is already one buffer
+        if getattr(self, '_pinned', None) is not None:   # packed natively into page-locked memory: one asynchronous DMA
+            buf = torch.empty(self._dev_words, dtype=torch.float32, device=device)
+            buf.copy_(self._pinned[:self._dev_words], non_blocking=True)
+            host = None
+        elif getattr(self, '_buf', None) is not None:    # packed natively: the device part is already one buffer
             host = self._buf[:self._dev_words]
         else:
             # ONE host buffer and ONE copy: float columns first, then the int32 index columns (bit patterns in float32)
@@ -143,7 +152,8 @@ class PackedBatch:
             host[:nf] = np.concatenate([self.obs.reshape(-1), self.value, self.prior.reshape(-1)])
             host[nf:].view(np.int32)[:] = np.concatenate([self.addr, self.prev_row, self.grp_rows, self.trace, self.row_off,
                                                           self.nxt_rows if nx else np.zeros(1, np.int32)])
-        buf = torch.from_numpy(host).to(device, non_blocking=False)
+        if host is not None:
+            buf = torch.from_numpy(host).to(device, non_blocking=False)
         f = buf[:nf]
         i = buf[nf:].view(torch.int32)
         ow = self.obs.shape[1]

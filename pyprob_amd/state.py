@@ -245,12 +245,14 @@ class PriorLockStep(PathExecutor):
     def finish_path(self):
         self.paths.append((self.active, list(self.seq), list(self.obs_seq)))
 
-    def columns(self, obs_names):
+    def columns(self, obs_names, return_types=False):
         """(trace_len [n], address table [(address, distribution, n_categories)], address ids [R], values [R],
-        prior [R, 2], obs [n, W]) as numpy arrays; traces are grouped by control-flow path."""
+        prior [R, 2], obs [n, W]) as numpy arrays; traces are grouped by control-flow path. return_types appends
+        (type index per trace, [address-id sequence per type]): every path is one trace type."""
         import numpy as np
         table, ids_of = [], {}
         lens, ids, vals, pri, obs = [], [], [], [], []
+        type_of, seqs = [], []
         for active, seq, obs_seq in self.paths:
             rows = slice(None) if active is None else torch.nonzero(active).reshape(-1)
             m = self.n if active is None else int(rows.numel())
@@ -266,14 +268,17 @@ class PriorLockStep(PathExecutor):
                     table.append((address, e[3], e[4]))
                 row_ids.append(ids_of[address])
             lens.append(np.full(m, len(seq), np.int64))
+            type_of.append(np.full(m, len(seqs), np.int64))
+            seqs.append(list(row_ids))
             ids.append(np.tile(np.asarray(row_ids, np.int64), m))
             vals.append(torch.stack([self.log[j][a][0][rows] for j, a in seq], 1).reshape(-1).cpu().numpy())
             pri.append(torch.stack([torch.stack([self.log[j][a][1][rows], self.log[j][a][2][rows]], 1) for j, a in seq],
                                    1).reshape(-1, 2).cpu().numpy())
             by_name = dict((name, i) for i, name in obs_seq)
             obs.append(torch.stack([self.obs_log[by_name[name]][name][rows] for name in obs_names], 1).cpu().numpy())
-        return (np.concatenate(lens), table, np.concatenate(ids), np.concatenate(vals).astype(np.float32),
-                np.concatenate(pri).astype(np.float32), np.concatenate(obs).astype(np.float32))
+        out = (np.concatenate(lens), table, np.concatenate(ids), np.concatenate(vals).astype(np.float32),
+               np.concatenate(pri).astype(np.float32), np.concatenate(obs).astype(np.float32))
+        return out + ((np.concatenate(type_of), seqs),) if return_types else out
 
 
 def observe(distribution, value=None, name=None, address=None):

@@ -52,7 +52,7 @@ try:
         if k == 200:
             break
     t4 = time.perf_counter()
-    print('host packing (gather + from_ragged), one thread: %.2f M traces/s (%.2f ms per 1024-trace minibatch)' % (k * B / (t4 - t3) / 1e6, (t4 - t3) / k * 1e3))
+    print('host packing (native, straight from the mapped columns), one thread: %.2f M traces/s (%.2f ms per 1024-trace minibatch)' % (k * B / (t4 - t3) / 1e6, (t4 - t3) / k * 1e3))
     import torch
     if torch.cuda.is_available():
         import bench
