@@ -5,9 +5,9 @@ __version__ = '0.1.0'
 
 
 def __getattr__(name):
-    """Lazy pyprob-style top level: pyprob_amd.sample / observe / Model / InferenceEngine ... (importing the package
+    """Lazy pyprob-style top level: pyprob_amd.sample / observe / Model / InferenceEngine / PriorInflation ... (importing the package
     must not require torch or a GPU)."""
-    if name in ('sample', 'observe', 'TraceMode', 'InferenceEngine'):
+    if name in ('sample', 'observe', 'TraceMode', 'InferenceEngine', 'PriorInflation'):
         from . import state
         return getattr(state, name)
     if name == 'Model':

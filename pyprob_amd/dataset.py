@@ -397,10 +397,17 @@ class PackedTraceDataset:
         pb.obs = pb.value = pb.prior = pb.addr = pb.prev_row = pb.trace = pb.grp_rows = pb.nxt_rows = None
         return pb
 
-    def addresses_of(self, indices):
+    def types_of(self, indices):
+        """Distinct trace types (ids into self.trace_types) of the given traces: one per reference sub-batch."""
+        t = self.trace_type[np.asarray(indices, np.int64)]
+        if len(self.trace_types) <= 64:                       # a bit set beats the sort inside np.unique
+            return np.flatnonzero(np.bincount(t, minlength=len(self.trace_types)))
+        return np.unique(t)
+
+    def addresses_of(self, indices, types=None):
         """[(address, distribution name, n_categories)] used by the given traces, in first-statement order: what
         `_polymorph` needs (inference_network_lstm.py:34-80) without materialising Trace objects."""
-        types = np.unique(self.trace_type[np.asarray(indices, np.int64)])
+        types = self.types_of(indices) if types is None else types
         seen, out = set(), []
         for t in types:
             for a in self.trace_types[t][1]:
@@ -533,13 +540,16 @@ class VectorisedOnlineDataset:
     prior traces are generated in lock step (Model.prior_traces_packed) and served as an in-memory PackedTraceDataset;
     `refresh()` draws the next chunk (online training never sees a trace twice)."""
 
-    def __init__(self, model, obs_names, chunk_traces=65536, device='cpu'):
+    def __init__(self, model, obs_names, chunk_traces=65536, device='cpu', prior_inflation=None):
+        from .state import PriorInflation
         self._model, self.obs_names, self._chunk, self._device = model, list(obs_names), int(chunk_traces), device
+        self._prior_inflation = PriorInflation.DISABLED if prior_inflation is None else prior_inflation
         self.generated = 0
         self.refresh()
 
     def refresh(self):
-        cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device, return_types=True)
+        cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device, return_types=True,
+                                               prior_inflation=self._prior_inflation)
         self._ds = PackedTraceDataset.from_columns(self.obs_names, None, *cols)
         self.generated += self._chunk
 
@@ -553,12 +563,15 @@ class VectorisedOnlineDataset:
         return getattr(self._ds, name)
 
 
-def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=None, *args, **kwargs):
+def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=None, *args, prior_inflation=None,
+                 **kwargs):
     """Model.save_dataset (pyprob/model.py:227-232, pyprob/nn/dataset.py:50-62 + 121-144): run the model in
     PRIOR_FOR_INFERENCE_NETWORK mode and write `ceil(num_traces / num_traces_per_file)` packed shards."""
-    from .state import TraceMode
+    from .state import PriorInflation, TraceMode
+    prior_inflation = PriorInflation.DISABLED if prior_inflation is None else prior_inflation
     os.makedirs(dataset_dir, exist_ok=True)
-    gen = model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, *args, **kwargs)
+    gen = model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, prior_inflation=prior_inflation,
+                                 *args, **kwargs)
     existing = [d for d in os.listdir(dataset_dir) if d.startswith('pyprob_traces_packed_')]
     shard, written = len(existing), 0
     names = obs_names
@@ -575,7 +588,8 @@ def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=
         path = os.path.join(dataset_dir, 'pyprob_traces_packed_{:06d}_{}'.format(shard, n))
         with PackedTraceWriter(path, names) as w:
             if vectorised:
-                w.add_columns(*model.prior_traces_packed(n, names, *args, return_types=True, **kwargs))
+                w.add_columns(*model.prior_traces_packed(n, names, *args, return_types=True,
+                                                         prior_inflation=prior_inflation, **kwargs))
             else:
                 for _ in range(n):
                     w.add_trace(next(gen))

@@ -7,7 +7,7 @@ import torch
 from . import state
 from .distributions import Empirical
 from .nn import InferenceNetworkLSTM, OnlineDataset
-from .state import InferenceEngine, TraceMode
+from .state import InferenceEngine, PriorInflation, TraceMode
 
 
 def trace_result(trace):
@@ -23,21 +23,25 @@ class Model:
         raise RuntimeError('Model instances must provide a forward method.')
 
     def _trace_generator(self, trace_mode=TraceMode.PRIOR, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING,
-                         inference_network=None, observe=None, likelihood_importance=1., *args, **kwargs):
+                         inference_network=None, observe=None, likelihood_importance=1.,
+                         prior_inflation=PriorInflation.DISABLED, *args, **kwargs):
         """pyprob/model.py:39-45"""
         state._init_traces(func=self.forward, trace_mode=trace_mode, inference_engine=inference_engine,
-                           inference_network=inference_network, observe=observe, likelihood_importance=likelihood_importance)
+                           inference_network=inference_network, observe=observe, likelihood_importance=likelihood_importance,
+                           prior_inflation=prior_inflation)
         while True:
             state._begin_trace()
             result = self.forward(*args, **kwargs)
             yield state._end_trace(result)
 
     def _traces(self, num_traces=10, trace_mode=TraceMode.PRIOR, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING,
-                inference_network=None, map_func=None, observe=None, likelihood_importance=1., *args, **kwargs):
+                inference_network=None, map_func=None, observe=None, likelihood_importance=1.,
+                prior_inflation=PriorInflation.DISABLED, *args, **kwargs):
         """pyprob/model.py:47-88: one particle per forward() run; non-finite weights are discarded."""
         gen = self._trace_generator(trace_mode=trace_mode, inference_engine=inference_engine,
                                     inference_network=inference_network, observe=observe,
-                                    likelihood_importance=likelihood_importance, *args, **kwargs)
+                                    likelihood_importance=likelihood_importance, prior_inflation=prior_inflation,
+                                    *args, **kwargs)
         traces = Empirical()
         map_func = map_func or (lambda t: t)
         for _ in range(num_traces):
@@ -88,14 +92,16 @@ class Model:
         emp.num_paths = n_paths
         return emp
 
-    def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, return_types=False, **kwargs):
+    def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, return_types=False,
+                            prior_inflation=PriorInflation.DISABLED, **kwargs):
         """num_traces traces of the program in PRIOR_FOR_INFERENCE_NETWORK mode, generated TOGETHER (one execution of
         forward() per distinct control-flow path, state.PriorLockStep) and returned as ragged columns
         (trace_len, address table, address ids, values, prior parameters, observations) - what a training minibatch is
         packed from. The vectorised replacement of OnlineDataset's one-forward()-per-trace loop
         (pyprob/nn/dataset.py:50-62). The program must be lock-step safe (tensor conditions)."""
         ls = state.PriorLockStep(num_traces, device)
-        state._init_traces(func=self.forward, trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, lock_step=ls)
+        state._init_traces(func=self.forward, trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, lock_step=ls,
+                           prior_inflation=prior_inflation)
         try:
             while True:
                 state._begin_trace()
@@ -108,8 +114,10 @@ class Model:
             state._current_trace = None
         return ls.columns(obs_names, return_types)
 
-    def prior_results(self, num_traces=10, *args, **kwargs):
-        return self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=trace_result, *args, **kwargs)
+    def prior_results(self, num_traces=10, prior_inflation=PriorInflation.DISABLED, *args, **kwargs):
+        """pyprob/model.py:97-104"""
+        return self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=trace_result,
+                            prior_inflation=prior_inflation, *args, **kwargs)
 
     def posterior_results(self, num_traces=10, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING, observe=None,
                           lock_step=False, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
@@ -137,7 +145,8 @@ class Model:
                                 proposal_mixture_components=10, learning_rate_init=0.001, learning_rate_end=1e-6,
                                 learning_rate_scheduler_type=None, weight_decay=0., distributed_backend=None,
                                 device='cuda:0', seed=None, dataset=None, log_file_name=None, dataset_dir=None,
-                                distributed_num_buckets=None, vectorised_prior=None, prior_chunk_traces=None):
+                                distributed_num_buckets=None, vectorised_prior=None, prior_chunk_traces=None,
+                                prior_inflation=PriorInflation.DISABLED):
         """pyprob/model.py:186-215 with inference_network=InferenceNetwork.LSTM. `dataset_dir` = a directory written by
         `save_dataset` (packed shards, pyprob_amd/dataset.py): offline training like the reference's OfflineDataset."""
         if dataset is None and dataset_dir is not None:
@@ -150,13 +159,14 @@ class Model:
             try:
                 self.prior_traces_packed(8, list(observe_embeddings.keys()))
                 dataset = VectorisedOnlineDataset(self, list(observe_embeddings.keys()),
-                                                  chunk_traces=prior_chunk_traces or max(64 * batch_size, 16384))
+                                                  chunk_traces=prior_chunk_traces or max(64 * batch_size, 16384),
+                                                  prior_inflation=prior_inflation)
             except Exception as exc:   # noqa: BLE001 - any failure of the probe means "not lock-step safe"
                 if vectorised_prior:
                     raise
                 print('Prior traces are generated one forward() at a time (program is not lock-step safe: {})'.format(exc))
         if dataset is None:
-            dataset = OnlineDataset(model=self)
+            dataset = OnlineDataset(model=self, prior_inflation=prior_inflation)
         if self._inference_network is None:
             print('Creating new inference network...')
             self._inference_network = InferenceNetworkLSTM(model=self, observe_embeddings=observe_embeddings,
@@ -171,10 +181,12 @@ class Model:
                                          weight_decay=weight_decay, distributed_backend=distributed_backend,
                                          log_file_name=log_file_name, distributed_num_buckets=distributed_num_buckets)
 
-    def save_dataset(self, dataset_dir, num_traces, num_traces_per_file, *args, **kwargs):
+    def save_dataset(self, dataset_dir, num_traces, num_traces_per_file, prior_inflation=PriorInflation.DISABLED,
+                     *args, **kwargs):
         """pyprob/model.py:227-232: prior traces for offline training, as packed shards (pyprob_amd/dataset.py)."""
         from .dataset import save_dataset
-        return save_dataset(self, dataset_dir, num_traces, num_traces_per_file, *args, **kwargs)
+        return save_dataset(self, dataset_dir, num_traces, num_traces_per_file, *args, prior_inflation=prior_inflation,
+                            **kwargs)
 
     def save_inference_network(self, file_name):
         if self._inference_network is None:

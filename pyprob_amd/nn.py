@@ -56,16 +56,19 @@ class _PackedIds:
 class OnlineDataset:
     """pyprob/nn/dataset.py:50-62: every item runs the model once in PRIOR_FOR_INFERENCE_NETWORK mode."""
 
-    def __init__(self, model, length=None):
+    def __init__(self, model, length=None, prior_inflation=None):
+        from .state import PriorInflation
         self._model = model
         self._length = int(1e6) if length is None else length
+        self._prior_inflation = PriorInflation.DISABLED if prior_inflation is None else prior_inflation
 
     def __len__(self):
         return self._length
 
     def __getitem__(self, idx):
         from .state import TraceMode
-        return next(self._model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK))
+        return next(self._model._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK,
+                                                 prior_inflation=self._prior_inflation))
 
 
 class ProposalSample:
@@ -390,7 +393,8 @@ class InferenceNetworkLSTM:
                         sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
                     sampler_iter = iter(sampler)                                      # next epoch (:461-464)
                     ids = next(sampler_iter)
-                new = [a for a in dataset.addresses_of(ids) if a[0] not in self._engine.spec.address_id]
+                types = dataset.types_of(ids)
+                new = [a for a in dataset.addresses_of(ids, types) if a[0] not in self._engine.spec.address_id]
                 batch = _PackedIds(dataset, ids, new)
             else:
                 traces = [dataset[i_item + k] for k in range(batch_size)]
@@ -410,7 +414,7 @@ class InferenceNetworkLSTM:
             if packed:
                 dev_batch = dataset.device_batch(ids, self._engine.spec, self._engine.device)
                 batch.mean_length_controlled = dev_batch.mean_length_controlled
-                batch.sub_batches = [None] * len(np.unique(dataset.trace_type[np.asarray(ids)]))
+                batch.sub_batches = [None] * len(types)
                 pb = dev_batch
             else:
                 pb = self._pack(batch)

@@ -12,7 +12,7 @@ Module-global trace state, `sample` / `observe`, address extraction from the cal
                        traces for training N at a time (PriorLockStep: vectorised OnlineDataset).
                        Programs that turn sampled values into Python scalars (`float(s)`) must use per-trace mode.
 
-MCMC engines, prior inflation, `tag`/`factor` and the address dictionary are out of scope.
+MCMC engines, `tag`/`factor` and the address dictionary are out of scope.
 """
 import enum
 import sys
@@ -35,7 +35,13 @@ class InferenceEngine(enum.Enum):
     IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK = 1
 
 
+class PriorInflation(enum.Enum):       # pyprob/__init__.py; state.py:87-93
+    DISABLED = 0
+    ENABLED = 1
+
+
 _trace_mode = TraceMode.PRIOR
+_prior_inflation = PriorInflation.DISABLED
 _inference_engine = InferenceEngine.IMPORTANCE_SAMPLING
 _likelihood_importance = 1.
 _current_trace = None
@@ -163,6 +169,19 @@ class LockStepState(PathExecutor):
         super().__init__(n, runner.dev)
 
 
+def _inflate(distribution):
+    """state._inflate, pyprob/state.py:87-93: with prior inflation the VALUE of a Normal is drawn with 3x the standard
+    deviation and that of a Categorical uniformly; the variable keeps the original distribution (the prior parameters
+    the proposal heads see, and log_prob, are those of the program's own prior)."""
+    if _prior_inflation == PriorInflation.ENABLED:
+        from .distributions import Categorical, Normal
+        if distribution.name == 'Categorical':
+            return Categorical(torch.full((distribution.num_categories,), 1. / distribution.num_categories))
+        if distribution.name == 'Normal':
+            return Normal(distribution.mean, distribution.stddev * 3)
+    return None
+
+
 def _vector_draw(distribution, n):
     """n independent draws: one per particle for shared parameters, elementwise for per-particle parameters."""
     td = distribution._torch_dist
@@ -217,7 +236,8 @@ class PriorLockStep(PathExecutor):
         while len(self.log) <= j:
             self.log.append({})
         old = self.log[j].get(address)
-        values = self._merge(_vector_draw(distribution, self.n).to(self.dev), None if old is None else old[0])
+        values = self._merge(_vector_draw(_inflate(distribution) or distribution, self.n).to(self.dev),
+                             None if old is None else old[0])
         p0, p1 = _vector_params(distribution, self.n, self.dev)
         if old is not None and self.active is not None:
             p0, p1 = torch.where(self.active, p0, old[1]), torch.where(self.active, p1, old[2])
@@ -376,19 +396,24 @@ def sample(distribution, name=None, address=None, control=True):
                             log_prob=log_prob, log_importance_weight=log_importance_weight, control=control, name=name)
         _current_trace_previous_variable = variable
     else:
-        value = distribution.sample()
+        inflated = _inflate(distribution)            # state.py:194-202, 280-288
+        value = distribution.sample() if inflated is None else inflated.sample()
         log_prob = distribution.log_prob(value, sum=True)
+        if inflated is not None:                     # to account for prior inflation
+            log_importance_weight = float(log_prob) - float(inflated.log_prob(value, sum=True))
         variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
-                            log_prob=log_prob, log_importance_weight=None, control=control, name=name)
+                            log_prob=log_prob, log_importance_weight=log_importance_weight, control=control, name=name)
     _current_trace.add(variable)
     return variable.value
 
 
 def _init_traces(func, trace_mode=TraceMode.PRIOR, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING,
-                 inference_network=None, observe=None, likelihood_importance=1., lock_step=None):
+                 inference_network=None, observe=None, likelihood_importance=1., lock_step=None,
+                 prior_inflation=PriorInflation.DISABLED):
     """state._init_traces, pyprob/state.py:296-336."""
     global _trace_mode, _inference_engine, _likelihood_importance, _current_trace_root_function_name
-    global _current_trace_inference_network, _current_trace_observed_variables, _lock_step
+    global _current_trace_inference_network, _current_trace_observed_variables, _lock_step, _prior_inflation
+    _prior_inflation = prior_inflation
     _trace_mode = trace_mode
     _inference_engine = inference_engine
     _likelihood_importance = likelihood_importance

@@ -209,3 +209,62 @@ def test_vectorised_prior_traces_match_the_per_trace_generator():
     assert ds.generated == 8192 and not np.array_equal(first, ds.gather(np.arange(16))[2])
     assert ds[0].length_controlled == ds.trace_len[0]
     assert len([b for b in ds.sampler(256)]) == 4096 // 256
+
+
+def test_known_trace_types_equal_detected_types():
+    """add_columns(trace_types=...) (the lock-step generator knows one type per control-flow path) builds the same
+    dataset as the row-wise unique detection."""
+    lens, table, ids, value, prior, obs = ragged(400, 9)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    seqs, index, type_of = [], {}, np.empty(400, np.int64)
+    for i in range(400):
+        key = tuple(ids[off[i]:off[i + 1]].tolist())
+        if key not in index:
+            index[key] = len(seqs)
+            seqs.append(list(key))
+        type_of[i] = index[key]
+    a = PackedTraceDataset.from_columns(['obs0', 'obs1'], [1, 1], lens, table, ids, value, prior, obs)
+    b = PackedTraceDataset.from_columns(['obs0', 'obs1'], [1, 1], lens, table, ids, value, prior, obs,
+                                        trace_types=(type_of, seqs))
+    ha = np.asarray([h for h, _ in a.trace_types], np.uint64)[a.trace_type]
+    hb = np.asarray([h for h, _ in b.trace_types], np.uint64)[b.trace_type]
+    assert np.array_equal(ha, hb) and np.array_equal(a.trace_len, b.trace_len)
+    for x, y in zip(a.gather(np.arange(400)), b.gather(np.arange(400))):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_prior_inflation_draws_wider_values_and_keeps_the_prior_parameters():
+    """PriorInflation.ENABLED (pyprob/state.py:87-93, 280-288): Normal values are drawn with 3x the standard deviation
+    and Categorical values uniformly, the prior parameters the heads see stay the program's; the per-trace generator
+    carries the correcting importance weight. Both generators (per trace and lock step)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(__file__))
+    from models import CategoricalThenNormal, GaussianWithUnknownMean
+    from pyprob_amd.state import PriorInflation, TraceMode
+    torch.manual_seed(11)
+    gum = GaussianWithUnknownMean()
+    for inflation, sd in ((PriorInflation.DISABLED, np.sqrt(5.0)), (PriorInflation.ENABLED, 3 * np.sqrt(5.0))):
+        lens, table, ids, vals, prior, obs = gum.prior_traces_packed(40000, ['obs0', 'obs1'], prior_inflation=inflation)
+        assert abs(vals.std() - sd) < 0.03 * sd and abs(vals.mean() - 1.0) < 0.1
+        assert np.allclose(prior, np.array([1.0, np.sqrt(5.0)], np.float32))
+    gen = gum._trace_generator(trace_mode=TraceMode.PRIOR_FOR_INFERENCE_NETWORK, prior_inflation=PriorInflation.ENABLED)
+    tr = [next(gen) for _ in range(3000)]
+    v = np.asarray([float(t.variables_controlled[0].value) for t in tr])
+    assert abs(v.std() - 3 * np.sqrt(5.0)) < 0.5
+    var = tr[0].variables_controlled[0]
+    want = float(var.distribution.log_prob(var.value)) - float(
+        torch.distributions.Normal(1.0, 3 * np.sqrt(5.0)).log_prob(var.value))
+    assert abs(var.log_importance_weight - want) < 1e-5 and abs(float(var.distribution.stddev) - np.sqrt(5.0)) < 1e-6
+    # importance weights undo the inflation: the weighted prior mean/variance of mu are the program's
+    lw = np.asarray([t.log_importance_weight for t in tr])
+    w = np.exp(lw - lw.max())
+    w /= w.sum()
+    m = (w * v).sum()
+    assert abs(m - 1.0) < 0.25 and abs((w * (v - m) ** 2).sum() - 5.0) < 0.8
+    # Categorical: uniform draws
+    cat = CategoricalThenNormal()
+    lens, table, ids, vals, prior, obs = cat.prior_traces_packed(30000, ['obs0', 'obs1'],
+                                                                 prior_inflation=PriorInflation.ENABLED)
+    c = vals.reshape(-1, 2)[:, 0]
+    assert np.allclose(np.bincount(c.astype(int), minlength=3) / 30000.0, 1 / 3, atol=0.015)
