@@ -119,7 +119,8 @@ class Net:
         self.P = {k: np.asarray(v, dtype) for k, v in params.items()}
         self.obs_names = list(obs_names)
         self.K = K
-        self.H = self.P['_layers_lstm.weight_hh_l0'].shape[1]
+        # (InferenceNetworkFeedForward has no LSTM: its heads read the observe embedding)
+        self.H = self.P['_layers_lstm.weight_hh_l0'].shape[1] if '_layers_lstm.weight_hh_l0' in self.P else 0
 
     def ff(self, prefix):
         """(W list, b list) of an EmbeddingFeedForward stored under `prefix`._layers.N.{weight,bias}."""
@@ -508,6 +509,96 @@ def loss_and_grads(net, batch, addresses, dist_names, want_grads=True):
     out['loss'] = total / B
     out['grads'] = grads
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# InferenceNetworkFeedForward: pyprob/nn/inference_network_feedforward.py
+# ------------------------------------------------------------------------------------------------
+def loss_and_grads_feedforward(net, batch, addresses, dist_names, want_grads=True):
+    """InferenceNetworkFeedForward._loss, pyprob/nn/inference_network_feedforward.py:68-98: per sub-batch the observe
+    embedding is computed once (:72) and EVERY time step's proposal layer reads it (:85); no LSTM, no address / sample
+    embeddings. Same rescue of -inf rows (:87-96) and the same division by batch.size (:98). Returns
+    dict(loss, lp (list per (sub-batch, t)), grads, sub_batches)."""
+    dt = net.dtype
+    P = net.P
+    trace_len = np.asarray(batch['trace_len'])
+    addr_idx = np.asarray(batch['addr_idx'])
+    values = np.asarray(batch['values'], dt)
+    prior = np.asarray(batch['prior'], dt)
+    obs = np.asarray(batch['obs'], dt)
+    B = len(trace_len)
+    subs, off = split_sub_batches(trace_len, addr_idx)
+    grads = {k: np.zeros_like(v) for k, v in P.items()} if want_grads else None
+    out = dict(lp=[], sub_batches=subs)
+    total = 0.0
+    for sb in subs:
+        sb = np.asarray(sb)
+        T = int(trace_len[sb[0]])
+        rows = off[sb][None, :] + np.arange(T)[:, None]
+        seq = [int(a) for a in addr_idx[off[sb[0]]:off[sb[0] + 1]]]
+        E, obs_cache = embed_observe(net, obs[sb])
+        dE = np.zeros_like(E)
+        for t in range(T):
+            a_cur, d_cur = addresses[seq[t]], dist_names[seq[t]]
+            lp, (dy, acts, Ws), _ = head_forward(net, a_cur, d_cur, E, prior[rows[t]], values[rows[t]])
+            out['lp'].append(lp.copy())
+            neg_inf = np.isneginf(lp)
+            lp = np.where(neg_inf, LOG_EPSILON, lp)
+            total += -lp.sum()
+            if want_grads:
+                g = np.where(neg_inf, 0.0, -1.0 / B)[:, None]
+                dyg = np.where(neg_inf[:, None], 0.0, dy) * g
+                dh, dWs, dbs = ff_backward(dyg, acts, Ws, False)
+                dE += dh
+                for i in range(len(Ws)):
+                    grads['_layers_proposal.%s._ff._layers.%d.weight' % (a_cur, i)] += dWs[i]
+                    grads['_layers_proposal.%s._ff._layers.%d.bias' % (a_cur, i)] += dbs[i]
+        if not want_grads:
+            continue
+        caches, acts_final = obs_cache
+        Ws, _ = net.ff('_layers_observe_embedding_final')
+        dcat, dWs, dbs = ff_backward(dE, acts_final, Ws, True)
+        for i in range(len(Ws)):
+            grads['_layers_observe_embedding_final._layers.%d.weight' % i] += dWs[i]
+            grads['_layers_observe_embedding_final._layers.%d.bias' % i] += dbs[i]
+        c = 0
+        for j, name in enumerate(net.obs_names):
+            Ws, _ = net.ff('_layers_observe_embedding.' + name)
+            w = Ws[-1].shape[0]
+            _, dWs, dbs = ff_backward(dcat[:, c:c + w], caches[j], Ws, True)
+            c += w
+            for i in range(len(Ws)):
+                grads['_layers_observe_embedding.%s._layers.%d.weight' % (name, i)] += dWs[i]
+                grads['_layers_observe_embedding.%s._layers.%d.bias' % (name, i)] += dbs[i]
+    out['loss'] = total / B
+    out['grads'] = grads
+    return out
+
+
+def is_rescore_feedforward(net, observe, trace_len, addr_idx, values, prior, addresses, dist_names):
+    """is_rescore for InferenceNetworkFeedForward._infer_step (inference_network_feedforward.py:52-66): the proposal of
+    every controlled variable is its address's layer applied to the observe embedding of `_infer_init`."""
+    dt = net.dtype
+    E, _ = embed_observe(net, np.asarray(observe, dt).reshape(1, -1))
+    off = np.concatenate([[0], np.cumsum(trace_len)]).astype(np.int64)
+    R = int(off[-1])
+    prior_lp, prop_lp, prop_params = np.zeros(R), np.zeros(R), []
+    lw = np.zeros(len(trace_len))
+    for b in range(len(trace_len)):
+        for r in range(off[b], off[b + 1]):
+            a_cur, d_cur = addresses[addr_idx[r]], dist_names[addr_idx[r]]
+            v = np.asarray(values[r:r + 1], dt)
+            q_lp, _, params = head_forward(net, a_cur, d_cur, E, np.asarray(prior[r:r + 1], dt), v)
+            if d_cur == 'Categorical':
+                C = params[0].shape[1]
+                p_lp = categorical_log_prob(v, np.asarray(prior[r, :C], dt))
+            else:
+                p_lp = prior_log_prob(d_cur, np.asarray(prior[r], dt), v[0])
+            prior_lp[r] = float(np.float32(np.asarray(p_lp).reshape(-1)[0]))
+            prop_lp[r] = float(np.float32(q_lp[0]))
+            prop_params.append(params)
+            lw[b] += prior_lp[r] - prop_lp[r]
+    return prior_lp, prop_lp, prop_params, lw
 
 
 # ------------------------------------------------------------------------------------------------

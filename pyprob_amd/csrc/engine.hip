@@ -26,6 +26,8 @@ int lstm_input_gather(const pp_net* net, const float* params, const float* E, in
                       const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
                       int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st, float* zero_like = nullptr,
                       float* zero_small = nullptr, int n_small = 0);
+int embedding_rows(const float* E, int64_t lde, const int32_t* trace, int n_rows, int e_obs, float* Hs, int64_t ldh,
+                   float* zero_small, int n_small, hipStream_t st);
 int sample_embed_bwd(const pp_net* net, const float* params, const float* value, const int32_t* addr,
                      const int32_t* prev_row, int row_begin, int n_rows, const float* dX, int64_t ldx, float* grads,
                      hipStream_t st);
@@ -129,7 +131,8 @@ struct Workspace {
 
 static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspace& w) {
     Carver c(p, cap);
-    const int H = net->lstm_dim;
+    const bool ff = net->lstm_dim == 0;   // FeedForward network: no LSTM buffers, the heads read rows of width e_obs
+    const int H = ff ? net->e_obs : net->lstm_dim;
     w.e4 = round4(net->e_obs);
     w.i4 = round4(net->lstm_in);
     int64_t hid = 1, out = 1;
@@ -148,17 +151,17 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.cat = c.take<float>((int64_t)B * w.e4);
     w.f1 = c.take<float>((int64_t)B * w.e4);
     w.E = c.take<float>((int64_t)B * w.e4);
-    w.X = c.take<float>((int64_t)R * w.i4);
-    w.G = c.take<float>((int64_t)R * 4 * H);
-    w.C = c.take<float>((int64_t)R * H);
+    w.X = c.take<float>(ff ? 0 : (int64_t)R * w.i4);
+    w.G = c.take<float>(ff ? 0 : (int64_t)R * 4 * H);
+    w.C = c.take<float>(ff ? 0 : (int64_t)R * H);
     w.Hs = c.take<float>((int64_t)R * H);
     w.A1 = c.take<float>((int64_t)R * w.hid4);
     w.Y = c.take<float>((int64_t)R * w.out4);
     w.DY = c.take<float>((int64_t)R * w.out4);
     w.dZ1 = c.take<float>((int64_t)R * w.hid4);
     w.dH = c.take<float>((int64_t)R * H);
-    w.dC = c.take<float>((int64_t)B * H);
-    w.dX = c.take<float>((int64_t)R * w.i4);
+    w.dC = c.take<float>(ff ? 0 : (int64_t)B * H);
+    w.dX = c.take<float>(ff ? 0 : (int64_t)R * w.i4);
     w.dE = c.take<float>((int64_t)B * w.e4);
     w.dF1 = c.take<float>((int64_t)B * w.e4);
     w.dCat = c.take<float>((int64_t)B * w.e4);
@@ -173,9 +176,13 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
 static int check_net(const pp_net* net) {
     PP_CHECK_ARG(net, "null pp_net");
     PP_CHECK_ARG(net->n_obs >= 1 && net->n_obs <= PP_MAX_OBS, "pp_net: n_obs=%d out of range", net->n_obs);
-    PP_CHECK_ARG(net->lstm_dim > 0 && net->lstm_in > 0 && net->e_obs > 0, "pp_net: bad dimensions");
-    PP_CHECK_ARG(net->lstm_in == net->e_obs + net->smp_dim + 2 * (net->addr_dim + net->dtype_dim),
-                 "pp_net: lstm_in != e_obs + smp_dim + 2*(addr_dim+dtype_dim)");
+    PP_CHECK_ARG(net->lstm_dim >= 0 && net->e_obs > 0, "pp_net: bad dimensions");
+    if (net->lstm_dim == 0) {   // InferenceNetworkFeedForward: no LSTM, no address / sample embeddings
+        PP_CHECK_ARG(net->lstm_in == 0, "pp_net: a FeedForward network (lstm_dim 0) has lstm_in 0");
+    } else {
+        PP_CHECK_ARG(net->lstm_in > 0 && net->lstm_in == net->e_obs + net->smp_dim + 2 * (net->addr_dim + net->dtype_dim),
+                     "pp_net: lstm_in != e_obs + smp_dim + 2*(addr_dim+dtype_dim)");
+    }
     PP_CHECK_ARG(net->n_addr == 0 || net->addrs, "pp_net: addrs is null");
     return 0;
 }
@@ -271,7 +278,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                  "pp_ic_loss: incomplete pp_batch");
     const bool bwd = flags & PP_LOSS_BACKWARD;
     PP_CHECK_ARG(!bwd || grads, "pp_ic_loss: PP_LOSS_BACKWARD needs a gradient buffer");
-    const int B = bt->n_traces, R = bt->n_rows, T = bt->t_max, H = net->lstm_dim, I = net->lstm_in;
+    const bool ff = net->lstm_dim == 0;   // FeedForward network (inference_network_feedforward.py:68-98)
+    const int B = bt->n_traces, R = bt->n_rows, T = bt->t_max, H = ff ? net->e_obs : net->lstm_dim, I = net->lstm_in;
     Workspace w;
     carve(net, B, R, ws, ws_bytes, w);
     if (w.bytes > ws_bytes) {
@@ -284,7 +292,15 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // First kernel: observe embedding; for small embeddings the same launch assembles the LSTM input rows of its traces
     // and clears the loss slots and (backward) dX. Otherwise embedding GEMMs + the stand-alone gather kernel.
     const bool fused_obs = obs_fused_supported(net);
-    if (fused_obs && T <= 2) {   // (long traces: a wave would write all rows of its trace serially - separate gather)
+    if (ff) {
+        // every time step's proposal layer reads the observe embedding of its trace (:72,85): Hs rows = E[trace]
+        if (fused_obs)
+            PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, nullptr));
+        else
+            PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
+        PP_TRY(embedding_rows(w.E, w.e4, bt->trace, R, net->e_obs, w.Hs, H, reinterpret_cast<float*>(w.loss_acc),
+                              PP_LOSS_SLOTS_FLOATS, st));
+    } else if (fused_obs && T <= 2) {   // (long traces: a wave would write all rows of its trace serially - separate gather)
         RowBuild rb{};
         rb.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
         rb.params = P; rb.at = net->addr_table; rb.row_off = bt->row_off_dev; rb.t_max = T;
@@ -299,10 +315,12 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
                                  bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), PP_LOSS_SLOTS_FLOATS));
     }
+    if (!ff) {
     prof_begin(0, st);
     PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st));
     prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
-    for (int t = 0; t < T; ++t) {
+    }
+    for (int t = 0; t < T && !ff; ++t) {
         const int n = bt->n_active[t], r0 = bt->row_off[t];
         float* Gt = w.G + (int64_t)r0 * 4 * H;
         const float* c_prev = nullptr;
@@ -407,7 +425,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         }
     }
     PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));
-    for (int t = T - 1; t >= 0; --t) {
+    if (ff) PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
+    for (int t = T - 1; t >= 0 && !ff; --t) {
         const int n = bt->n_active[t], r0 = bt->row_off[t];
         const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
         float* Gt = w.G + (int64_t)r0 * 4 * H;
@@ -420,7 +439,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             PP_TRY(linear_dgrad(Gt, 4 * H, P + net->w_hh, w.dH + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0, n,
                                 H, 4 * H, true, st));
     }
+    // the gradient of the observe embedding is summed over the time steps from dX[:, :e_obs] (LSTM) / from dH (FF)
+    const float* dXs = ff ? w.dH : w.dX;
+    const int64_t ldxs = ff ? H : w.i4;
     // LSTM parameter gradients, together with every head's weight gradients
+    if (!ff) {
     queue_wgrad(wq, w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, R, I, 4 * H);
     if (T > 1) {
         const int r1 = bt->row_off[1];
@@ -446,13 +469,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     if (T > 1)
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
+    }   // !ff
     // observe embedding backward
     if (obs_fused_supported(net)) {
         // dE (sum over the trace's time steps of dX, masked by the last ReLU) and the data gradients of the whole stack
         // in one fused launch; weight gradients join the grouped MFMA launch; bias gradients are column sums of the same
         // buffers
         const int64_t dhs = (int64_t)B * w.maxohid4;
-        PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, w.dX, w.i4, bt->row_off_dev, T, w.E, w.dE, w.dF1, w.dCat,
+        PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, dXs, ldxs, bt->row_off_dev, T, w.E, w.dE, w.dF1, w.dCat,
                                      w.dObsH, dhs, st));
         const int e = net->e_obs;
         queue_wgrad(wq, w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, B, e, e);
@@ -477,7 +501,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(launch_wgrads(wq, st));
         return 0;
     }
-    PP_TRY(obs_grad(w.dX, w.i4, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
+    PP_TRY(obs_grad(dXs, ldxs, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
     PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
     PP_TRY(launch_wgrads(wq, st));
     const int e = net->e_obs;

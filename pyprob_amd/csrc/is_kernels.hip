@@ -387,28 +387,34 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
             const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
             const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset, void* ws,
             size_t ws_bytes, hipStream_t st) {
-    PP_CHECK_ARG(net && P && e_obs_vec && h && c && value_out && logq_out && ws, "pp_is_step: null pointer");
+    const bool ff = net && net->lstm_dim == 0;   // FeedForward network: the proposal layer reads the observe embedding
+    PP_CHECK_ARG(net && P && e_obs_vec && (ff || (h && c)) && value_out && logq_out && ws, "pp_is_step: null pointer");
     PP_CHECK_ARG(addr_id >= 0 && addr_id < net->n_addr && prev_addr_id < net->n_addr, "pp_is_step: address id out of range");
-    PP_CHECK_ARG(prev_addr_id < 0 || prev_value, "pp_is_step: prev_value is required after the first statement");
-    PP_CHECK_ARG(prev_addr_id < 0 || state_rows == 1 || state_rows == n, "pp_is_step: state_rows must be 1 or n");
+    PP_CHECK_ARG(ff || prev_addr_id < 0 || prev_value, "pp_is_step: prev_value is required after the first statement");
+    PP_CHECK_ARG(ff || prev_addr_id < 0 || state_rows == 1 || state_rows == n, "pp_is_step: state_rows must be 1 or n");
     if (n <= 0) return 0;
     const pp_addr& ad = net->addrs[addr_id];
     PP_CHECK_ARG(ad.kind == PP_HEAD_CATEGORICAL || prior, "pp_is_step: prior parameters required");
     // First statement of a trace: identical LSTM input and zero state for every particle -> ONE row is evaluated and
     // only row 0 of (h, c) is written (the caller's state_rows becomes 1). Second statement: the inputs differ (previous
     // value) but the recurrent term h0 W_hh^T is still one shared row -> it enters the batched GEMM as a bias.
-    const bool shared = prev_addr_id < 0;
+    // FeedForward network (inference_network_feedforward.py:52-66): no state at all - every statement's proposal is its
+    // layer applied to the ONE observe embedding row, identical for all particles.
+    const bool shared = ff || prev_addr_id < 0;
     const int m = shared ? 1 : n;
-    const int H = net->lstm_dim, I = net->lstm_in;
+    const int H = ff ? net->e_obs : net->lstm_dim, I = net->lstm_in;
     IsWorkspace w;
     is_carve(net, m, ws, w);
     if (w.bytes > ws_bytes) {
         set_error("pp_is_step: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
         return PP_ENOSPACE;
     }
-    PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
-                             w.i4, st));
-    if (shared) {
+    if (!ff)
+        PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
+                                 w.i4, st));
+    if (ff) {
+        h = const_cast<float*>(e_obs_vec);   // (read only below)
+    } else if (shared) {
         PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, P + net->b_hh, w.G, 4 * H, 1, I, 4 * H, false, false, st));
         PP_TRY(lstm_cell_fwd(w.G, nullptr, c, h, 1, H, st));
     } else if (state_rows == 1) {

@@ -162,6 +162,32 @@ int lstm_input_gather(const pp_net* net, const float* params, const float* E, in
     return 0;
 }
 
+// FeedForward network (pyprob/nn/inference_network_feedforward.py:72,85): the proposal layer of every time step reads
+// the observe embedding of its trace, so the "hidden state" rows of the heads are copies of E; the same launch clears
+// the loss slots (it is the first kernel after the observe embedding).
+__global__ __launch_bounds__(256) void embedding_rows_kernel(const float* __restrict__ E, int64_t lde,
+                                                             const int32_t* __restrict__ trace, int n_rows, int e_obs,
+                                                             float* __restrict__ Hs, int64_t ldh,
+                                                             float* __restrict__ zero_small, int n_small) {
+    if (zero_small && blockIdx.x == 0)
+        for (int q = threadIdx.x; q < n_small; q += 256) zero_small[q] = 0.0f;
+    const int64_t total = (int64_t)n_rows * e_obs;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / e_obs), c = (int)(e - (int64_t)r * e_obs);
+        Hs[(int64_t)r * ldh + c] = E[(int64_t)trace[r] * lde + c];
+    }
+}
+
+int embedding_rows(const float* E, int64_t lde, const int32_t* trace, int n_rows, int e_obs, float* Hs, int64_t ldh,
+                   float* zero_small, int n_small, hipStream_t st) {
+    const int64_t total = (int64_t)n_rows * e_obs;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(embedding_rows_kernel, dim3(blocks), dim3(256), 0, st, E, lde, trace, n_rows, e_obs, Hs, ldh,
+                       zero_small, n_small);
+    PP_LAUNCH_CHECK("embedding_rows");
+    return 0;
+}
+
 // Gradient of the sample-embedding layers (one Linear + ReLU per address) from dX[:, e_obs : e_obs+smp].
 // lane -> row; when a wave's rows share the previous address (the common case in step-major order) the
 // contributions are wave-reduced and one lane issues the atomics.

@@ -54,7 +54,7 @@ class ISRunner:
 
     def begin(self, n, offset=0):
         """Start n traces in lock step (state._begin_trace, state.py:339-345): LSTM state is reset by the first step."""
-        H = self.eng.spec.lstm_dim
+        H = max(self.eng.spec.lstm_dim, 1)       # (FeedForward network: no LSTM state, 1-wide placeholders)
         if n != self.n:
             self.h = torch.empty(n, H, dtype=torch.float32, device=self.dev)
             self.c = torch.empty(n, H, dtype=torch.float32, device=self.dev)

@@ -6,8 +6,8 @@ import torch
 
 from . import state
 from .distributions import Empirical
-from .nn import InferenceNetworkLSTM, OnlineDataset
-from .state import InferenceEngine, PriorInflation, TraceMode
+from .nn import InferenceNetworkFeedForward, InferenceNetworkLSTM, OnlineDataset
+from .state import InferenceEngine, InferenceNetwork, PriorInflation, TraceMode
 
 
 def trace_result(trace):
@@ -141,13 +141,14 @@ class Model:
             post.rename('Posterior, IS, traces: {:,}, ESS: {:,.2f}'.format(post.length, post.effective_sample_size))
         return post
 
-    def learn_inference_network(self, num_traces, observe_embeddings={}, batch_size=64, lstm_dim=512, lstm_depth=1,
+    def learn_inference_network(self, num_traces, inference_network=InferenceNetwork.FEEDFORWARD, observe_embeddings={},
+                                batch_size=64, lstm_dim=512, lstm_depth=1,
                                 proposal_mixture_components=10, learning_rate_init=0.001, learning_rate_end=1e-6,
                                 learning_rate_scheduler_type=None, weight_decay=0., distributed_backend=None,
                                 device='cuda:0', seed=None, dataset=None, log_file_name=None, dataset_dir=None,
                                 distributed_num_buckets=None, vectorised_prior=None, prior_chunk_traces=None,
                                 prior_inflation=PriorInflation.DISABLED):
-        """pyprob/model.py:186-215 with inference_network=InferenceNetwork.LSTM. `dataset_dir` = a directory written by
+        """pyprob/model.py:186-215 (inference_network: FEEDFORWARD, the reference's default, or LSTM). `dataset_dir` = a directory written by
         `save_dataset` (packed shards, pyprob_amd/dataset.py): offline training like the reference's OfflineDataset."""
         if dataset is None and dataset_dir is not None:
             from .dataset import PackedTraceDataset
@@ -169,10 +170,15 @@ class Model:
             dataset = OnlineDataset(model=self, prior_inflation=prior_inflation)
         if self._inference_network is None:
             print('Creating new inference network...')
-            self._inference_network = InferenceNetworkLSTM(model=self, observe_embeddings=observe_embeddings,
-                                                           lstm_dim=lstm_dim, lstm_depth=lstm_depth,
-                                                           proposal_mixture_components=proposal_mixture_components,
-                                                           device=device, seed=seed)
+            if inference_network == InferenceNetwork.LSTM:
+                cls = InferenceNetworkLSTM
+            elif inference_network == InferenceNetwork.FEEDFORWARD:
+                cls = InferenceNetworkFeedForward
+            else:
+                raise ValueError('Unknown inference_network: {}'.format(inference_network))   # model.py:203-204
+            self._inference_network = cls(model=self, observe_embeddings=observe_embeddings, lstm_dim=lstm_dim,
+                                          lstm_depth=lstm_depth, proposal_mixture_components=proposal_mixture_components,
+                                          device=device, seed=seed)
         else:
             print('Continuing to train existing inference network...')
         self._inference_network.optimize(num_traces=num_traces, dataset=dataset, batch_size=batch_size,

@@ -88,6 +88,8 @@ class ProposalSample:
 
 class InferenceNetworkLSTM:
     # observe_embeddings example: {'obs1': {'dim': 32}}   (FEEDFORWARD, depth 2)
+    _network = 'lstm'           # NetSpec(network=...): 'lstm' | 'feedforward' (class InferenceNetworkFeedForward below)
+
     def __init__(self, model=None, observe_embeddings={}, lstm_dim=512, lstm_depth=1, sample_embedding_dim=4,
                  address_embedding_dim=64, distribution_type_embedding_dim=8, proposal_mixture_components=10,
                  device='cuda:0', seed=None):
@@ -148,7 +150,7 @@ class InferenceNetworkLSTM:
         spec = NetSpec(self._obs_spec, lstm_dim=self._lstm_dim, sample_embedding_dim=self._sample_embedding_dim,
                        address_embedding_dim=self._address_embedding_dim,
                        distribution_type_embedding_dim=self._distribution_type_embedding_dim,
-                       proposal_mixture_components=self._proposal_mixture_components)
+                       proposal_mixture_components=self._proposal_mixture_components, network=self._network)
         self._engine = ICEngine(spec, device=self._device, seed=self._seed)
         self._is = ISRunner(self._engine)
 
@@ -231,6 +233,8 @@ class InferenceNetworkLSTM:
         spec = self._engine.spec
         address = variable.address
         distribution = variable.distribution
+        if spec.feedforward:            # inference_network_feedforward.py:52-66: no state, no previous variable
+            prev_variable = None
         if address not in spec.address_id or (prev_variable is not None and prev_variable.address not in spec.address_id):
             warnings.warn('Using prior. No proposal for address: {}'.format(address))
             return distribution
@@ -265,7 +269,7 @@ class InferenceNetworkLSTM:
                 ls.prev_addr_id = a
                 runner.prev_value = runner.last_value = values
             return ParticleTensor.wrap(values)
-        prev_unknown = getattr(ls, 'prev_unknown', False)
+        prev_unknown = getattr(ls, 'prev_unknown', False) and not spec.feedforward    # (FF: no previous-variable input)
         ls.prev_unknown = address not in spec.address_id
         if ls.prev_unknown or prev_unknown:
             # no proposal layers for this address or for the previous one (never seen in training): the prior is the
@@ -483,7 +487,7 @@ class InferenceNetworkLSTM:
 
     def _save(self, file_name):
         spec = self._engine.spec
-        torch.save(dict(state_dict=self.state_dict(), obs_spec=self._obs_spec, lstm_dim=self._lstm_dim,
+        torch.save(dict(state_dict=self.state_dict(), obs_spec=self._obs_spec, lstm_dim=self._lstm_dim, network=self._network,
                         K=self._proposal_mixture_components,
                         addresses=[(a.address, a.dist_name, a.num_categories, a.total_train_iterations) for a in spec.addresses],
                         total_train_traces=self._total_train_traces, total_train_iterations=self._total_train_iterations,
@@ -493,8 +497,8 @@ class InferenceNetworkLSTM:
     @staticmethod
     def _load(file_name, device='cuda:0'):
         d = torch.load(file_name, weights_only=False)
-        net = InferenceNetworkLSTM(observe_embeddings=d['obs_spec'], lstm_dim=d['lstm_dim'],
-                                   proposal_mixture_components=d['K'], device=device)
+        cls = InferenceNetworkFeedForward if d.get('network', 'lstm') == 'feedforward' else InferenceNetworkLSTM
+        net = cls(observe_embeddings=d['obs_spec'], lstm_dim=d['lstm_dim'], proposal_mixture_components=d['K'], device=device)
         net._obs_spec = d['obs_spec']
         net._obs_names = list(d['obs_spec'].keys())
         net._init_layers()
@@ -509,3 +513,10 @@ class InferenceNetworkLSTM:
         net._total_train_traces = d['total_train_traces']
         net._total_train_iterations = d['total_train_iterations']
         return net
+
+
+class InferenceNetworkFeedForward(InferenceNetworkLSTM):
+    """pyprob/nn/inference_network_feedforward.py: the proposal layer of every address reads the observe embedding (no
+    LSTM, no address / sample embeddings; `lstm_dim` and the embedding dimensions are ignored). Same engine, same C
+    calls: the network description carries lstm_dim = 0 (NetSpec(network='feedforward'))."""
+    _network = 'feedforward'

@@ -1,4 +1,6 @@
-"""Network description and flat parameter layout of the LSTM inference network.
+"""Network description and flat parameter layout of the LSTM inference network (and of the FeedForward variant,
+pyprob/nn/inference_network_feedforward.py: `network='feedforward'`, no LSTM and no address / sample embeddings - the
+proposal layers read the observe embedding).
 
 Tensor names and shapes are exactly the reference's `state_dict` (pyprob/nn/inference_network_lstm.py:29-80,
 pyprob/nn/inference_network.py:80-130, pyprob/nn/embedding_feedforward.py:22-33), so that
@@ -35,7 +37,11 @@ class NetSpec:
     """Dimensions + ordered tensor table. Grows when `_polymorph` meets a new address."""
 
     def __init__(self, observe_embeddings, lstm_dim=512, sample_embedding_dim=4, address_embedding_dim=64,
-                 distribution_type_embedding_dim=8, proposal_mixture_components=10):
+                 distribution_type_embedding_dim=8, proposal_mixture_components=10, network='lstm'):
+        if network not in ('lstm', 'feedforward'):
+            raise ValueError('network must be lstm or feedforward')
+        self.network = network
+        self.feedforward = network == 'feedforward'
         # observe_embeddings: ordered {name: {'dim': D, 'input_dim': d_in}}  (FEEDFORWARD, depth 2 only)
         self.obs = []
         for name, v in observe_embeddings.items():
@@ -53,9 +59,10 @@ class NetSpec:
         self.smp_dim = sample_embedding_dim
         self.addr_dim = address_embedding_dim
         self.dtype_dim = distribution_type_embedding_dim
-        self.lstm_dim = lstm_dim
+        self.lstm_dim = 0 if self.feedforward else lstm_dim
+        self.head_in = self.e_obs if self.feedforward else lstm_dim       # input width of the proposal layers
         self.K = proposal_mixture_components
-        self.lstm_in = self.e_obs + self.smp_dim + 2 * (self.addr_dim + self.dtype_dim)
+        self.lstm_in = 0 if self.feedforward else self.e_obs + self.smp_dim + 2 * (self.addr_dim + self.dtype_dim)
         self.addresses = []          # AddressInfo, index = address id
         self.address_id = {}
         self.dtypes = []             # distribution type names, index = dtype id
@@ -69,8 +76,9 @@ class NetSpec:
         p = '_layers_observe_embedding_final._layers.'
         self._add(p + '0.weight', (e, e)); self._add(p + '0.bias', (e,))
         self._add(p + '1.weight', (e, e)); self._add(p + '1.bias', (e,))
-        self._add('_layers_lstm.weight_ih_l0', (4 * H, I)); self._add('_layers_lstm.weight_hh_l0', (4 * H, H))
-        self._add('_layers_lstm.bias_ih_l0', (4 * H,)); self._add('_layers_lstm.bias_hh_l0', (4 * H,))
+        if not self.feedforward:
+            self._add('_layers_lstm.weight_ih_l0', (4 * H, I)); self._add('_layers_lstm.weight_hh_l0', (4 * H, H))
+            self._add('_layers_lstm.bias_ih_l0', (4 * H,)); self._add('_layers_lstm.bias_hh_l0', (4 * H,))
         self.n_core_tensors = len(self.tensors)
 
     # ---- layout ------------------------------------------------------------------------------------
@@ -95,7 +103,7 @@ class NetSpec:
 
     def head_dims(self, info):
         n_out = info.num_categories if info.kind == L.PP_HEAD_CATEGORICAL else 3 * self.K
-        hid = int((self.lstm_dim + n_out) / 2)    # embedding_feedforward.py:26
+        hid = int((self.head_in + n_out) / 2)     # embedding_feedforward.py:26
         smp_in = info.num_categories if info.kind == L.PP_HEAD_CATEGORICAL else 1
         return n_out, hid, smp_in
 
@@ -107,16 +115,19 @@ class NetSpec:
         info = AddressInfo(address, dist_name, num_categories)
         created = []
         n0 = len(self.tensors)
-        self._add('_layers_address_embedding.' + address, (self.addr_dim,))
+        if not self.feedforward:
+            self._add('_layers_address_embedding.' + address, (self.addr_dim,))
         if dist_name not in self.dtypes:
             self.dtypes.append(dist_name)
-            self._add('_layers_distribution_type_embedding.' + dist_name, (self.dtype_dim,))
+            if not self.feedforward:
+                self._add('_layers_distribution_type_embedding.' + dist_name, (self.dtype_dim,))
         n_out, hid, smp_in = self.head_dims(info)
         p = '_layers_proposal.%s._ff._layers.' % address
-        self._add(p + '0.weight', (hid, self.lstm_dim)); self._add(p + '0.bias', (hid,))
+        self._add(p + '0.weight', (hid, self.head_in)); self._add(p + '0.bias', (hid,))
         self._add(p + '1.weight', (n_out, hid)); self._add(p + '1.bias', (n_out,))
-        p = '_layers_sample_embedding.%s._layers.0.' % address
-        self._add(p + 'weight', (self.smp_dim, smp_in)); self._add(p + 'bias', (self.smp_dim,))
+        if not self.feedforward:
+            p = '_layers_sample_embedding.%s._layers.0.' % address
+            self._add(p + 'weight', (self.smp_dim, smp_in)); self._add(p + 'bias', (self.smp_dim,))
         created = list(self.tensors.keys())[n0:]
         self.address_id[address] = len(self.addresses)
         self.addresses.append(info)
@@ -152,13 +163,13 @@ class NetSpec:
         for a, info in enumerate(self.addresses):
             cur = cur_counts[a] > 0
             prev = prev_counts[a] > 0
-            if cur or prev:
+            if (cur or prev) and not self.feedforward:
                 act[index['_layers_address_embedding.' + info.address]] = 1.0
                 act[index['_layers_distribution_type_embedding.' + info.dist_name]] = 1.0
             if cur:
                 for s in ('0.weight', '0.bias', '1.weight', '1.bias'):
                     act[index['_layers_proposal.%s._ff._layers.%s' % (info.address, s)]] = 1.0
-            if prev:
+            if prev and not self.feedforward:
                 for s in ('weight', 'bias'):
                     act[index['_layers_sample_embedding.%s._layers.0.%s' % (info.address, s)]] = 1.0
         return act
@@ -176,6 +187,9 @@ class NetSpec:
         t = np.zeros((max(len(self.addresses), 1), L.PP_ADDR_TABLE_COLS), np.int64)
         for a, info in enumerate(self.addresses):
             n_out, hid, smp_in = self.head_dims(info)
+            if self.feedforward:          # no embeddings: the table only carries the head kind / width
+                t[a] = [info.kind, smp_in, 0, 0, 0, 0, n_out, 0]
+                continue
             t[a] = [info.kind, smp_in, self.offset('_layers_address_embedding.' + info.address),
                     self.offset('_layers_distribution_type_embedding.' + info.dist_name),
                     self.offset('_layers_sample_embedding.%s._layers.0.weight' % info.address),
@@ -194,9 +208,10 @@ class NetSpec:
         p = '_layers_observe_embedding_final._layers.'
         net.fin_w0, net.fin_b0 = self.offset(p + '0.weight'), self.offset(p + '0.bias')
         net.fin_w1, net.fin_b1 = self.offset(p + '1.weight'), self.offset(p + '1.bias')
-        net.lstm_in, net.lstm_dim = self.lstm_in, self.lstm_dim
-        net.w_ih, net.w_hh = self.offset('_layers_lstm.weight_ih_l0'), self.offset('_layers_lstm.weight_hh_l0')
-        net.b_ih, net.b_hh = self.offset('_layers_lstm.bias_ih_l0'), self.offset('_layers_lstm.bias_hh_l0')
+        net.lstm_in, net.lstm_dim = self.lstm_in, self.lstm_dim          # lstm_dim == 0: FeedForward network
+        if not self.feedforward:
+            net.w_ih, net.w_hh = self.offset('_layers_lstm.weight_ih_l0'), self.offset('_layers_lstm.weight_hh_l0')
+            net.b_ih, net.b_hh = self.offset('_layers_lstm.bias_ih_l0'), self.offset('_layers_lstm.bias_hh_l0')
         net.n_addr, net.n_dtype = len(self.addresses), len(self.dtypes)
         arr = (L.pp_addr * max(len(self.addresses), 1))()
         for a, info in enumerate(self.addresses):
@@ -204,10 +219,11 @@ class NetSpec:
             r = arr[a]
             r.kind, r.n_out, r.hid, r.smp_in = info.kind, n_out, hid, smp_in
             r.dtype_id = self.dtypes.index(info.dist_name)
-            r.addr_emb = self.offset('_layers_address_embedding.' + info.address)
-            r.dtype_emb = self.offset('_layers_distribution_type_embedding.' + info.dist_name)
-            r.smp_w = self.offset('_layers_sample_embedding.%s._layers.0.weight' % info.address)
-            r.smp_b = self.offset('_layers_sample_embedding.%s._layers.0.bias' % info.address)
+            if not self.feedforward:
+                r.addr_emb = self.offset('_layers_address_embedding.' + info.address)
+                r.dtype_emb = self.offset('_layers_distribution_type_embedding.' + info.dist_name)
+                r.smp_w = self.offset('_layers_sample_embedding.%s._layers.0.weight' % info.address)
+                r.smp_b = self.offset('_layers_sample_embedding.%s._layers.0.bias' % info.address)
             p = '_layers_proposal.%s._ff._layers.' % info.address
             r.w1, r.b1 = self.offset(p + '0.weight'), self.offset(p + '0.bias')
             r.w2, r.b2 = self.offset(p + '1.weight'), self.offset(p + '1.bias')

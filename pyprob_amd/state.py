@@ -35,6 +35,11 @@ class InferenceEngine(enum.Enum):
     IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK = 1
 
 
+class InferenceNetwork(enum.Enum):     # pyprob/__init__.py
+    FEEDFORWARD = 0
+    LSTM = 1
+
+
 class PriorInflation(enum.Enum):       # pyprob/__init__.py; state.py:87-93
     DISABLED = 0
     ENABLED = 1

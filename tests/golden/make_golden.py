@@ -17,7 +17,8 @@ reference is copied: we call its public API and record inputs/outputs:
                           (pyprob/state.py:203-219, pyprob/trace.py:123-125): sampled values, prior log_prob,
                           proposal parameters, proposal log_prob, per-trace log_importance_weight.
 
-Cases: gum (GaussianUnknownMean, tests/test_inference.py:97-109), gumm (…Marsaglia, :252-275), both with
+Cases ff / ffc: the same records for InferenceNetworkFeedForward (pyprob/nn/inference_network_feedforward.py) on the
+gumm / cat programs (no LSTM records). Cases: gum (GaussianUnknownMean, tests/test_inference.py:97-109), gumm (…Marsaglia, :252-275), both with
 lstm_dim=64 so the fixtures stay small, and cat (a Categorical->Normal toy model exercising
 ProposalCategoricalCategorical and the one-hot sample embedding).
 """
@@ -147,12 +148,14 @@ def dump_batch(traces, obs_names):
     return arrays, meta
 
 
-def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_particles, observe):
+def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_particles, observe, network='lstm'):
     print('=' * 30, case)
     pyprob.seed(123)
     obs_emb = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
     model.learn_inference_network(num_traces=train_traces, batch_size=train_batch,
-                                  observe_embeddings=obs_emb, inference_network=InferenceNetwork.LSTM,
+                                  observe_embeddings=obs_emb,
+                                  inference_network=(InferenceNetwork.LSTM if network == 'lstm' else
+                                                     InferenceNetwork.FEEDFORWARD),
                                   lstm_dim=lstm_dim, lstm_depth=1, proposal_mixture_components=10,
                                   learning_rate_init=1e-3, weight_decay=0.)
     net = model._inference_network
@@ -171,7 +174,7 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
         rec['lstm_in'].append(i[0].detach().numpy().copy())
         rec['lstm_out'].append(o[0].detach().numpy().copy())
 
-    hook = net._layers_lstm.register_forward_hook(lstm_hook)
+    hook = net._layers_lstm.register_forward_hook(lstm_hook) if network == 'lstm' else None
     orig_mix_lp = Mixture.log_prob
     orig_cat_lp = Categorical.log_prob
 
@@ -193,7 +196,8 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
     loss.backward()
     Mixture.log_prob = orig_mix_lp
     Categorical.log_prob = orig_cat_lp
-    hook.remove()
+    if hook is not None:
+        hook.remove()
     names = [n for n, _ in net.named_parameters()]
     grads = {}
     for n, p in net.named_parameters():
@@ -207,7 +211,8 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
     meta['sub_batches'] = sub_batches
     meta['param_names'] = names
     meta['has_grad'] = has_grad
-    meta['lstm_dim'] = lstm_dim
+    meta['lstm_dim'] = lstm_dim if network == 'lstm' else 0
+    meta['network'] = network
     meta['mixture_components'] = 10
     meta['observe_embedding_dims'] = {'obs0': 32, 'obs1': 32}
     meta['num_params'] = int(sum(p.numel() for p in net.parameters()))
@@ -301,8 +306,13 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
 
 if __name__ == '__main__':
     obs = {'obs0': 8, 'obs1': 9}
-    only_poi = len(sys.argv) > 1 and sys.argv[1] == 'poi'   # only the Poisson case (the other fixtures stay byte-identical)
-    if not only_poi:
+    only = sys.argv[1] if len(sys.argv) > 1 else None        # e.g. `poi` / `ff`: the other fixtures stay byte-identical
+    if only == 'ff':
+        # InferenceNetworkFeedForward (pyprob/nn/inference_network_feedforward.py): heads read the observe embedding
+        run_case('ff', GaussianWithUnknownMeanMarsaglia(), 0, 2560, 128, 96, 48, obs, network='feedforward')
+        run_case('ffc', CategoricalThenNormal(), 0, 1280, 64, 48, 32, {'obs0': 1.2, 'obs1': 0.7}, network='feedforward')
+        sys.exit(0)
+    if only is None:
         run_case('gum', GaussianWithUnknownMean(), 64, 1280, 64, 64, 64, obs)
         run_case('gumm', GaussianWithUnknownMeanMarsaglia(), 64, 2560, 128, 96, 48, obs)
         run_case('cat', CategoricalThenNormal(), 64, 1280, 64, 48, 32, {'obs0': 1.2, 'obs1': 0.7})

@@ -6,12 +6,13 @@ from pyprob_amd.spec import NetSpec
 
 def spec_from_golden(meta, params):
     obs = {n: {'dim': meta['observe_embedding_dims'][n], 'input_dim': 1} for n in meta['obs_names']}
-    spec = NetSpec(obs, lstm_dim=meta['lstm_dim'], proposal_mixture_components=meta['mixture_components'])
+    spec = NetSpec(obs, lstm_dim=meta['lstm_dim'], proposal_mixture_components=meta['mixture_components'],
+                   network=meta.get('network', 'lstm'))
     pairs = list(zip(meta['addresses'], meta['dist_names']))
     # addresses the network knows but this batch does not contain (GUMM): dist type from the address suffix
     for k in params:
-        if k.startswith('_layers_address_embedding.'):
-            a = k[len('_layers_address_embedding.'):]
+        if k.startswith('_layers_proposal.') and k.endswith('._ff._layers.0.weight'):
+            a = k[len('_layers_proposal.'):-len('._ff._layers.0.weight')]
             if a not in meta['addresses']:
                 suffix = a.split('__')[-2]
                 pairs.append((a, [d for d in ('Normal', 'Uniform', 'Categorical', 'Poisson') if suffix.startswith(d)][0]))

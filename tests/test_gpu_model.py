@@ -4,8 +4,11 @@ same programs the reference tests use (tests/models.py), thresholds from referen
 import numpy as np
 import pytest
 
-from models import GaussianWithUnknownMean, GaussianWithUnknownMeanMarsaglia, CategoricalThenNormal
+from models import (GaussianWithUnknownMean, GaussianWithUnknownMeanMarsaglia, CategoricalThenNormal,
+                    GaussianWithUnknownMeanMarsagliaLockStep)
 from pyprob_amd.state import InferenceEngine, TraceMode
+from pyprob_amd.state import InferenceNetwork
+LSTM = InferenceNetwork.LSTM
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
@@ -18,7 +21,7 @@ EMB = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
 def gum_trained():
     torch.manual_seed(123)
     model = GaussianWithUnknownMean()
-    model.learn_inference_network(num_traces=40000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=1)
+    model.learn_inference_network(inference_network=LSTM, num_traces=40000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=1)
     return model
 
 
@@ -53,7 +56,7 @@ def test_gum_per_trace_posterior_matches_lockstep(gum_trained):
 def test_gumm_training_and_per_trace_posterior():
     torch.manual_seed(7)
     model = GaussianWithUnknownMeanMarsaglia()
-    model.learn_inference_network(num_traces=25000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=2)
+    model.learn_inference_network(inference_network=LSTM, num_traces=25000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=2)
     net = model._inference_network
     assert len(net._engine.spec.addresses) >= 4
     assert net._loss_previous < net._loss_init
@@ -70,7 +73,7 @@ def test_gumm_training_and_per_trace_posterior():
 def test_categorical_program_trains():
     torch.manual_seed(9)
     model = CategoricalThenNormal()
-    model.learn_inference_network(num_traces=6000, observe_embeddings=EMB, batch_size=64, lstm_dim=64, seed=3)
+    model.learn_inference_network(inference_network=LSTM, num_traces=6000, observe_embeddings=EMB, batch_size=64, lstm_dim=64, seed=3)
     net = model._inference_network
     kinds = sorted(a.dist_name for a in net._engine.spec.addresses)
     assert kinds == ['Categorical', 'Normal']
@@ -96,7 +99,7 @@ def test_save_load_round_trip(gum_trained, tmp_path):
     assert abs(p1.mean - p2.mean) < 1e-6 and abs(p1.effective_sample_size - p2.effective_sample_size) < 1e-3
     # continuing training keeps the Adam step counts (reference tests/test_train.py:107-203 checks the same)
     before = int(b._engine.tensor_step.max().item())
-    m2.learn_inference_network(num_traces=256, observe_embeddings=EMB, batch_size=128)
+    m2.learn_inference_network(inference_network=LSTM, num_traces=256, observe_embeddings=EMB, batch_size=128)
     assert int(b._engine.tensor_step.max().item()) == before + 2
 
 
@@ -127,7 +130,7 @@ def test_offline_training_from_packed_dataset(tmp_path):
     ds = PackedTraceDataset(d)
     assert len(ds) == 3000 and ds.obs_names == ['obs0', 'obs1']
     assert np.all(np.diff(ds.trace_len[ds.sorted_indices()]) >= 0)
-    model.learn_inference_network(num_traces=20000, observe_embeddings=EMB, batch_size=100, lstm_dim=64, seed=3,
+    model.learn_inference_network(inference_network=LSTM, num_traces=20000, observe_embeddings=EMB, batch_size=100, lstm_dim=64, seed=3,
                                   dataset_dir=d)
     net = model._inference_network
     assert len(net._engine.spec.addresses) >= 4
@@ -149,7 +152,7 @@ def test_lockstep_with_stochastic_control_flow():
     from models import GaussianWithUnknownMeanMarsagliaLockStep
     torch.manual_seed(13)
     model = GaussianWithUnknownMeanMarsagliaLockStep()
-    model.learn_inference_network(num_traces=30000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=4)
+    model.learn_inference_network(inference_network=LSTM, num_traces=30000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=4)
     obs = {'obs0': 4, 'obs1': 5}
     n = 20000
     post = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=5)
@@ -178,7 +181,7 @@ def test_lockstep_unknown_address_uses_the_prior():
     import warnings
     torch.manual_seed(17)
     model = GaussianWithUnknownMeanMarsagliaLockStep()
-    model.learn_inference_network(num_traces=600, observe_embeddings=EMB, batch_size=100, lstm_dim=64, seed=5)
+    model.learn_inference_network(inference_network=LSTM, num_traces=600, observe_embeddings=EMB, batch_size=100, lstm_dim=64, seed=5)
     known = len(model._inference_network._engine.spec.addresses)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
@@ -195,7 +198,7 @@ def test_poisson_program_trains_and_infers():
     from models import PoissonThenNormal
     torch.manual_seed(21)
     model = PoissonThenNormal()
-    model.learn_inference_network(num_traces=60000, observe_embeddings=EMB, batch_size=256, lstm_dim=64, seed=6)
+    model.learn_inference_network(inference_network=LSTM, num_traces=60000, observe_embeddings=EMB, batch_size=256, lstm_dim=64, seed=6)
     net = model._inference_network
     assert [a.dist_name for a in net._engine.spec.addresses] == ['Poisson', 'Normal']
     assert net._engine.spec.num_parameters() == 89790              # the reference's count for this program (poi golden)
@@ -220,7 +223,7 @@ def test_lockstep_categorical_program_matches_per_trace():
     """Categorical proposal head + one-hot sample embedding in lock step: same posterior as one particle per forward()."""
     torch.manual_seed(9)
     model = CategoricalThenNormal()
-    model.learn_inference_network(num_traces=40000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=8)
+    model.learn_inference_network(inference_network=LSTM, num_traces=40000, observe_embeddings=EMB, batch_size=128, lstm_dim=64, seed=8)
     obs = {'obs0': 1.2, 'obs1': 0.7}
     lock = model.posterior_results(100000, IC, observe=obs, lock_step=True, seed=3)
     assert lock.num_paths == 1 and lock.device_stats['count'] == 100000
@@ -237,3 +240,43 @@ def test_lockstep_categorical_program_matches_per_trace():
     torch.manual_seed(4)
     one = model.posterior_results(400, IC, observe=obs)
     assert abs(one.mean - exact) < 0.3
+
+
+def test_feedforward_network_is_the_default_and_recovers_the_posterior(tmp_path):
+    """learn_inference_network's default network is FEEDFORWARD like the reference (model.py:186); GUM posterior checks
+    of tests/test_inference.py:173-202 with it, per trace and in lock step; save / load keeps the network type."""
+    from pyprob_amd.nn import InferenceNetworkFeedForward
+    from pyprob_amd.model import Model
+    torch.manual_seed(21)
+    model = GaussianWithUnknownMean()
+    model.learn_inference_network(num_traces=40000, observe_embeddings=EMB, batch_size=128, seed=9)
+    net = model._inference_network
+    assert isinstance(net, InferenceNetworkFeedForward) and net._engine.spec.lstm_dim == 0
+    assert net._engine.spec.num_parameters() == 1152 + 8320 + (47 * 64 + 47 + 30 * 47 + 30)    # obs + final + one head
+    assert net._loss_previous < net._loss_init
+    lock = model.posterior_results(50000, IC, observe=OBS, lock_step=True, seed=3)
+    assert abs(lock.mean - 7.25) < 0.75 and abs(lock.stddev - np.sqrt(1 / 1.2)) < 0.75
+    assert lock.effective_sample_size > 0.15 * 50000
+    torch.manual_seed(4)
+    post = model.posterior_results(300, IC, observe=OBS)
+    assert abs(post.mean - lock.mean) < 0.5
+    f = str(tmp_path / 'ff.network')
+    model.save_inference_network(f)
+    m2 = GaussianWithUnknownMean()
+    m2.load_inference_network(f)
+    assert isinstance(m2._inference_network, InferenceNetworkFeedForward)
+    again = m2.posterior_results(50000, IC, observe=OBS, lock_step=True, seed=3)
+    assert abs(again.mean - lock.mean) < 1e-4
+
+
+def test_feedforward_network_with_control_flow_and_categorical():
+    """FF network on the rejection-loop program (one head per address, ragged traces) and on Categorical -> Normal."""
+    torch.manual_seed(31)
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    model.learn_inference_network(num_traces=40000, observe_embeddings=EMB, batch_size=256, seed=10)
+    post = model.posterior_results(40000, IC, observe=OBS, lock_step=True, seed=5)
+    assert abs(post.mean - 7.25) < 1.0 and post.effective_sample_size > 50
+    cat = CategoricalThenNormal()
+    cat.learn_inference_network(num_traces=30000, observe_embeddings=EMB, batch_size=128, seed=11)
+    p = cat.posterior_results(20000, IC, observe={'obs0': 1.2, 'obs1': 0.7}, lock_step=True, seed=6)
+    assert np.isfinite(p.mean) and p.effective_sample_size > 0.05 * 20000

@@ -129,6 +129,41 @@ def test_benchmark_size_gumm_ragged_against_oracle():
     assert not bad, bad[:5]
 
 
+def test_feedforward_network_benchmark_size_against_oracle():
+    """InferenceNetworkFeedForward (inference_network_feedforward.py:68-98) at batch 1024 on ragged GUMM traces: the
+    gradient of the observe embedding sums over each trace's time steps, one head per address."""
+    from pyprob_amd.engine import ICEngine
+    from pyprob_amd.spec import NetSpec
+    arrays, addresses = synthetic_gumm_arrays(1024, seed=8, max_iter=6)
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, network='feedforward')
+    for a in addresses:
+        spec.add_address(a, 'Uniform')
+    assert spec.lstm_dim == 0 and not any(n.startswith('_layers_lstm') for n in spec.tensors)
+    eng = ICEngine(spec, seed=2)
+    pb = _packed(arrays, eng.spec).to(eng.device)
+    l, lp = eng.loss(pb, backward=True, keep_lp=True)
+    fwd = eng.loss(pb).clone()                       # forward-only entry point: same loss
+    torch.cuda.synchronize()
+    assert int(eng.status_buf[0].item()) == 0
+    params = {k: v.numpy() for k, v in eng.state_dict().items()}
+    net = O.Net(params, [o[0] for o in spec.obs], K=spec.K)
+    out = O.loss_and_grads_feedforward(net, arrays, addresses, ['Uniform'] * len(addresses))
+    assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
+    assert abs(float(fwd.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
+    g = eng.grad_dict()
+    bad = []
+    for n in eng.spec.tensors:
+        scale = np.abs(out['grads'][n]).max()
+        if scale > 1e-7 and rel_err(g[n], out['grads'][n]) > 3e-3:
+            bad.append((n, rel_err(g[n], out['grads'][n])))
+    assert not bad, bad[:5]
+    # a few Adam steps reduce the loss
+    first = float(l.item())
+    for _ in range(30):
+        last = eng.train_step(pb, 1e-3)
+    assert float(last.item()) < first
+
+
 def test_loss_is_permutation_invariant_and_additive():
     """Size-independent properties: the loss does not depend on trace order, and the loss of a union of two
     batches is the size-weighted mean of their losses."""

@@ -56,8 +56,8 @@ def test_param_counts(golden):
 def _run(golden, dtype=np.float64, want_grads=True):
     case, meta, params, batch, loss, isr = golden
     net = O.Net(params, meta['obs_names'], K=meta['mixture_components'], dtype=dtype)
-    out = O.loss_and_grads(net, batch, meta['addresses'], meta['dist_names'], want_grads=want_grads)
-    return out
+    fn = O.loss_and_grads_feedforward if meta.get('network') == 'feedforward' else O.loss_and_grads
+    return fn(net, batch, meta['addresses'], meta['dist_names'], want_grads=want_grads)
 
 
 def test_sub_batching_matches_reference(golden):
@@ -70,7 +70,7 @@ def test_loss_forward_matches_reference(golden):
     case, meta, params, batch, loss, isr = golden
     out = _run(golden, want_grads=False)
     assert abs(out['loss'] - float(loss['loss'])) <= 2e-6 * abs(float(loss['loss']))
-    for i in range(len(out['lstm_in'])):
+    for i in range(len(out.get('lstm_in', []))):
         np.testing.assert_allclose(out['lstm_in'][i], loss['lstm_in_%d' % i], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(out['lstm_out'][i], loss['lstm_out_%d' % i], rtol=1e-5, atol=2e-6)
     for k, (si, t) in enumerate(meta['lp_index']):
@@ -106,7 +106,8 @@ def test_is_log_weights_match_reference(golden):
     addr_to_dist = dict(zip(meta['addresses'], meta['dist_names']))
     addresses = meta['is_addresses']
     dist_names = [addr_to_dist[a] for a in addresses]
-    p_lp, q_lp, qparams, lw = O.is_rescore(net, isr['observe'], isr['trace_len'], isr['addr'], isr['value'],
+    rescore = O.is_rescore_feedforward if meta.get('network') == 'feedforward' else O.is_rescore
+    p_lp, q_lp, qparams, lw = rescore(net, isr['observe'], isr['trace_len'], isr['addr'], isr['value'],
                                            isr['prior'], addresses, dist_names)
     np.testing.assert_allclose(p_lp, isr['prior_lp'], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(q_lp, isr['prop_lp'], rtol=1e-4, atol=1e-4)

@@ -6,12 +6,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from models import GaussianWithUnknownMeanMarsagliaLockStep
 from pyprob_amd.state import InferenceEngine
+from pyprob_amd.state import InferenceNetwork
+LSTM = InferenceNetwork.LSTM
 IC = InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
 EMB = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
 warnings.simplefilter('ignore')
 torch.manual_seed(1)
 model = GaussianWithUnknownMeanMarsagliaLockStep()
-model.learn_inference_network(num_traces=20000, observe_embeddings=EMB, batch_size=256, lstm_dim=512, seed=1)
+model.learn_inference_network(inference_network=LSTM, num_traces=20000, observe_embeddings=EMB, batch_size=256, lstm_dim=512, seed=1)
 obs = {'obs0': 4, 'obs1': 5}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 model.posterior_results(10000, IC, observe=obs, lock_step=True, seed=1)

@@ -6,13 +6,15 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from models import GaussianWithUnknownMean, GaussianWithUnknownMeanMarsagliaLockStep
 EMB = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
+from pyprob_amd.state import InferenceNetwork
+LSTM = InferenceNetwork.LSTM
 warnings.simplefilter('ignore')
 for cls, n in ((GaussianWithUnknownMean, 2000000), (GaussianWithUnknownMeanMarsagliaLockStep, 600000)):
     for vec, m in ((True, n), (False, 20000)):
         torch.manual_seed(1)
         model = cls()
         t0 = time.perf_counter()
-        model.learn_inference_network(num_traces=m, observe_embeddings=EMB, batch_size=1024, lstm_dim=512, seed=1,
+        model.learn_inference_network(inference_network=LSTM, num_traces=m, observe_embeddings=EMB, batch_size=1024, lstm_dim=512, seed=1,
                                       vectorised_prior=vec, prior_chunk_traces=131072)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
