@@ -34,13 +34,14 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 2
+#define PP_ABI_VERSION 3
 #define PP_MAX_OBS 8
 
 /* error codes (negative; positive values are hipError_t) */
 #define PP_EINVAL   (-1)   /* bad argument (shape, alignment, null pointer) */
 #define PP_ENOSPACE (-2)   /* workspace too small */
 #define PP_ENODEV   (-3)   /* no gfx950 device / kernels not loadable */
+#define PP_EHIP     (-4)   /* a HIP runtime call failed (pp_last_error() has the text) */
 
 /* proposal head kinds (pyprob/nn/inference_network_lstm.py:52-66) */
 #define PP_HEAD_NORMAL_MIXTURE       0  /* ProposalNormalNormalMixture: prior Normal(mean, stddev) */
@@ -68,7 +69,7 @@ typedef struct pp_addr {
     int64_t dtype_emb;   /* [dtype_dim]           _layers_distribution_type_embedding.<DistName> */
     int64_t smp_w;       /* [smp_dim, smp_in]     _layers_sample_embedding.<addr>._layers.0.weight */
     int64_t smp_b;       /* [smp_dim] */
-    int64_t w1, b1;      /* [hid, H], [hid]       _layers_proposal.<addr>._ff._layers.0 */
+    int64_t w1, b1;      /* [hid, H], [hid]       _layers_proposal.<addr>._ff._layers.0 (FeedForward network: [hid, e_obs]) */
     int64_t w2, b2;      /* [n_out, hid], [n_out] _layers_proposal.<addr>._ff._layers.1 */
 } pp_addr;
 
@@ -82,7 +83,9 @@ typedef struct pp_net {
     int32_t smp_dim, addr_dim, dtype_dim;
     int64_t fin_w0, fin_b0, fin_w1, fin_b1;   /* _layers_observe_embedding_final (e_obs -> e_obs -> e_obs) */
     int32_t lstm_in;                  /* I = e_obs + smp_dim + 2*(addr_dim+dtype_dim), inference_network_lstm.py:30 */
-    int32_t lstm_dim;                 /* H */
+    int32_t lstm_dim;                 /* H; 0 = InferenceNetworkFeedForward (inference_network_feedforward.py): no LSTM and
+                                         no address / sample embeddings (lstm_in = 0, their offsets unused); the proposal
+                                         layers [hid, e_obs] read the observe embedding of the trace */
     int64_t w_ih, w_hh, b_ih, b_hh;   /* _layers_lstm.{weight_ih,weight_hh,bias_ih,bias_hh}_l0 */
     int32_t n_addr;
     int32_t n_dtype;
@@ -213,6 +216,51 @@ int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                  int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                  int32_t flags, const int32_t* skip, void* stream);
 
+/*
+ * The body of the training loop (InferenceNetwork.optimize, pyprob/nn/inference_network.py:461-499: next minibatch ->
+ * zero_grad -> _loss -> backward -> optimizer.step) for a RUN of minibatches whose traces come from packed dataset
+ * columns, without returning to the caller between steps. Per step i: the traces ids[step_off[i] .. step_off[i+1]) are
+ * packed (pp_pack_indexed) into a pinned staging slot together with the minibatch's presence map, uploaded with one
+ * asynchronous copy, and pp_ic_loss(PP_LOSS_BACKWARD) + pp_adam_step(lr[i], PP_ADAM_ZERO_GRADS, skip = the step's own
+ * non-finite flag) are enqueued on `stream`. loss_ring[i] / status_ring[i] receive the step's loss and non-finite flag
+ * (a flagged step leaves the parameters untouched, :493-499). Single rank (data parallel runs keep the per-step
+ * all-reduce on the caller's side). The caller polymorphs beforehand: an address unknown to `net` is PP_EINVAL.
+ *   pp_tensor_roles  which tensors a minibatch gives a gradient to (grad is not None in the reference): tensor t is
+ *                    present if role[t] & 4, or if one of its addresses addr[off[t] .. off[t+1]) occurs as a current
+ *                    (role & 1) / previous (role & 2) variable of the minibatch (inference_network_lstm.py:168-171).
+ *   staging          pinned host memory, device_batch device memory: n_slots slots of slot_words 4-byte words each,
+ *                    slot_words >= pp_train_slot_words(...) of the largest step; slots rotate, a slot is rewritten
+ *                    only after its upload completed.
+ *   workspace        pp_ic_workspace_bytes(net, most traces, most rows of any step)
+ *   grads_clean      non-zero: `grads` is all zero on entry (left so by PP_ADAM_ZERO_GRADS); it is on return.
+ *   addr_iterations  host [n_addr] or NULL: += 1 per step in which the address occurs (proposal_layer.
+ *                    _total_train_iterations, inference_network_lstm.py:198)
+ * Returns after the last step is enqueued and the staging slots are reusable; the losses are read by the caller.
+ */
+typedef struct pp_train_buffers {
+    float* params; float* grads; float* exp_avg; float* exp_avg_sq;             /* dev [n_params] */
+    const int32_t* chunk_tensor; int32_t* tensor_step; int32_t* adam_scratch;   /* dev, as in pp_adam_step */
+    void* workspace; size_t workspace_bytes;                                     /* dev */
+    void* staging; void* device_batch; int64_t slot_words;                       /* pinned host / dev */
+    float* loss_ring; int32_t* status_ring;                                      /* dev [n_steps] */
+    int32_t n_tensors; int32_t n_slots;
+} pp_train_buffers;
+
+typedef struct pp_tensor_roles {
+    const int32_t* off;    /* host [n_tensors + 1] */
+    const int32_t* addr;   /* host [off[n_tensors]] address ids */
+    const int32_t* role;   /* host [n_tensors] bit 0: current variable, bit 1: previous variable, bit 2: always */
+} pp_tensor_roles;
+
+int64_t pp_train_slot_words(int32_t n_traces, int64_t n_rows, int32_t t_max, int32_t obs_width, int32_t n_addr,
+                            int32_t n_tensors);
+
+int pp_train_steps(const pp_net* net, const pp_train_buffers* buffers, const pp_tensor_roles* roles,
+                   const pp_shard_columns* shards, int32_t n_shards, const int64_t* first, int32_t obs_width,
+                   const int64_t* ids, const int64_t* step_off, int32_t n_steps, const float* lr /*host [n_steps]*/,
+                   float beta1, float beta2, float eps, float weight_decay, int32_t grads_clean,
+                   int64_t* addr_iterations, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Importance sampling with the inference network, lock-step over N particles
  * (pyprob/state.py:203-219, pyprob/nn/inference_network_lstm.py:82-134, pyprob/trace.py:123-125)
@@ -240,6 +288,8 @@ int pp_is_init(const pp_net* net, const float* params, const float* obs, float* 
  *              the state, evaluates the network for ONE row (every particle has the same input and zero state) and
  *              writes row 0 only: the caller passes state_rows = 1 to the next call, which turns the shared recurrent
  *              term into a bias row and writes all n rows; afterwards state_rows = n.
+ *              FeedForward network (lstm_dim 0; inference_network_feedforward.py:52-66): no state - h, c, prev_value,
+ *              prev_addr_id and state_rows are ignored (h, c may be NULL); the layer of addr_id is applied to e_obs_vec.
  *   value_in   dev [n] or NULL: if given, score these values instead of sampling (re-scoring / parity tests)
  *   value_out  dev [n]       sampled (or copied) values
  *   logq_out   dev [n]       proposal log_prob of value (Mixture.log_prob / Categorical.log_prob)

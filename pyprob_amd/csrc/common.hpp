@@ -109,4 +109,8 @@ __device__ __forceinline__ void stage_to_lds(float* __restrict__ lds, const floa
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// torch.relu keeps NaN (fmaxf would turn it into 0): a non-finite observation or activation must reach the loss so that
+// the minibatch is flagged and skipped like in the reference (inference_network_lstm.py:203-217).
+__device__ __forceinline__ float relu_keep_nan(float v) { return v > 0.0f ? v : (v == v ? 0.0f : v); }
+
 }  // namespace pp

@@ -23,7 +23,7 @@ __device__ __forceinline__ float sample_embed_elem(const float* __restrict__ par
         c = c < 0 ? 0 : (c >= smp_in ? smp_in - 1 : c);
         s = w[j * smp_in + c] + b[j];
     }
-    return fmaxf(s, 0.0f);
+    return relu_keep_nan(s);
 }
 
 // column c >= e_obs of a row whose previous statement has address `ap` (< 0: none) and value v, current address `a`

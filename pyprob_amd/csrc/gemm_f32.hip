@@ -193,7 +193,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r] + bsum;
-                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (p.relu) v = relu_keep_nan(v);
                     base[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v;
                 }
             }
@@ -223,7 +223,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16 (&acc)
                     if (p.dbg_plain) *dst = v; else
                     atomicAdd(dst, v);
                 } else {
-                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (p.relu) v = relu_keep_nan(v);
                     if (p.mask) v = (p.mask[cm * p.ldmask + gn] > 0.0f) ? v : 0.0f;
                     csum += v;
                     if (p.accumulate) v += *dst;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const GemmParams p) {
         if (m >= p.M) break;
         float v = wave_sum(acc[m]) + bsum;
         if (lane == 0) {
-            if (p.relu) v = fmaxf(v, 0.0f);
+            if (p.relu) v = relu_keep_nan(v);
             float* dst = p.C + (p.c_idx ? (int64_t)p.c_idx[m] : (int64_t)m) * p.ldc + n;
             *dst = p.accumulate ? *dst + v : v;
         }
@@ -993,7 +993,7 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
     }
     if (p.relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        for (int e = 0; e < 4; ++e) v[e] = relu_keep_nan(v[e]);
     }
     if (p.mask && rowok) {
         const float* mk = p.mask + cm * p.ldmask + n0 + c4;

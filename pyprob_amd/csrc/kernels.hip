@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) void head_categorical_kernel(const float* __res
         }
         const float piv = expf(y[vi] - zmax) / zs;
         const float pv = (piv + 1e-8f) / S;
-        const float lp = logf(fminf(fmaxf(pv, kFp32Eps), 1.0f - kFp32Eps));
+        const float lp = pv == pv ? logf(fminf(fmaxf(pv, kFp32Eps), 1.0f - kFp32Eps)) : pv;   // (clamp would drop a NaN)
         if (lp_out) lp_out[r] = lp;
         bad = !isfinite(lp);
         contrib = -lp;

@@ -117,7 +117,7 @@ __device__ __forceinline__ float obs_dense(const float* lds, const ObsLayer& L, 
     }
     for (; k < L.cols; ++k) s0 += w[k] * bcast(x, x_lane0 + k);
     const float s = (s0 + s1) + (s2 + s3);
-    return act ? fmaxf(s + lds[L.lds_b + row], 0.0f) : 0.0f;
+    return act ? relu_keep_nan(s + lds[L.lds_b + row]) : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a, const float* __restrict__ P,
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
                 const float* w = lds + a.l0[o].lds_w + jh * (a.in[o] + 1);
                 float s = lds[a.l0[o].lds_b + jh];
                 for (int i = 0; i < a.in[o]; ++i) s += w[i] * obs[(int64_t)b * a.width + ci + i];
-                h = fmaxf(s, 0.0f);
+                h = relu_keep_nan(s);
                 a.obs_h[o][(int64_t)b * a.ohid_ld[o] + jh] = h;
             }
             ci += a.in[o];

@@ -1,0 +1,120 @@
+// Native training loop: the body of InferenceNetwork.optimize (pyprob/nn/inference_network.py:461-499) for a run of
+// minibatches, entirely on the host side of the C ABI - per step: pack the minibatch straight from the dataset columns
+// into a pinned staging slot (pp_pack_indexed), ONE asynchronous upload, pp_ic_loss (loss + backward), pp_adam_step. The
+// Python host only decides which traces form which minibatch, the learning rates, and reads the losses back once per
+// run. Measured motivation: a training step is 0.16 ms on the GPU, while Python spent 0.25-0.38 ms
+// per step on packing calls, torch tensor wrappers and ctypes marshalling.
+#include "common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace pp {
+void set_error(const char* fmt, ...);
+int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads, void* ws, size_t ws_bytes, float* loss_out,
+            int32_t* status_out, float* lp_out, int flags, hipStream_t st);
+int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
+              const float* active, int32_t* tensor_step, int32_t* arrived, int n_tensors, float lr, float beta1, float beta2,
+              float eps, float wd, float gscale, int flags, const int32_t* skip, hipStream_t st);
+}  // namespace pp
+
+extern "C" {
+
+int64_t pp_train_slot_words(int32_t n_traces, int64_t n_rows, int32_t t_max, int32_t obs_width, int32_t n_addr,
+                            int32_t n_tensors) {
+    return ((pp_pack_words(n_traces, n_rows, t_max, obs_width, n_addr) + n_tensors + 63) / 64) * 64;
+}
+
+int pp_train_steps(const pp_net* net, const pp_train_buffers* tb, const pp_tensor_roles* roles,
+                   const pp_shard_columns* shards, int32_t n_shards, const int64_t* first, int32_t obs_width,
+                   const int64_t* ids, const int64_t* step_off, int32_t n_steps, const float* lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t grads_clean, int64_t* addr_iterations, void* stream) {
+    if (!(net && tb && roles && shards && first && ids && step_off && lr) || n_steps < 0) {
+        pp::set_error("pp_train_steps: null pointer");
+        return PP_EINVAL;
+    }
+    if (!(tb->params && tb->grads && tb->exp_avg && tb->exp_avg_sq && tb->chunk_tensor && tb->tensor_step && tb->adam_scratch &&
+          tb->workspace && tb->staging && tb->device_batch && tb->loss_ring && tb->status_ring) ||
+        tb->n_slots < 1 || tb->n_slots > 64 || tb->slot_words <= 0 || tb->n_tensors <= 0) {
+        pp::set_error("pp_train_steps: incomplete pp_train_buffers");
+        return PP_EINVAL;
+    }
+    hipStream_t st = pp::as_stream(stream);
+    const int n_addr = net->n_addr, n_tensors = tb->n_tensors;
+    hipEvent_t ev[64];
+    int n_ev = 0;
+    int rc = 0;
+    for (int i = 0; i < n_steps && rc == 0; ++i) {
+        const int slot = i % tb->n_slots;
+        if (slot >= n_ev) {
+            if (hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming) != hipSuccess) {
+                pp::set_error("pp_train_steps: hipEventCreate failed");
+                rc = PP_EHIP;
+                break;
+            }
+            ++n_ev;
+        } else {
+            (void)hipEventSynchronize(ev[slot]);   // the upload that last read this staging slot has completed
+        }
+        float* host = static_cast<float*>(tb->staging) + (int64_t)slot * tb->slot_words;
+        int32_t* hosti = reinterpret_cast<int32_t*>(host);
+        float* dev = static_cast<float*>(tb->device_batch) + (int64_t)slot * tb->slot_words;
+        int32_t* devi = reinterpret_cast<int32_t*>(dev);
+        const int64_t n = step_off[i + 1] - step_off[i];
+        if (n <= 0 || n > INT32_MAX) {
+            pp::set_error("pp_train_steps: step %d has %lld traces", i, (long long)n);
+            rc = PP_EINVAL;
+            break;
+        }
+        pp_pack_info info;
+        rc = pp_pack_indexed(shards, n_shards, first, ids + step_off[i], (int32_t)n, obs_width, n_addr, host,
+                             tb->slot_words - n_tensors, &info);
+        if (rc != 0) break;
+        const int64_t words = info.src_row + info.n_rows;   // end of the packed buffer (pp_pack_words)
+        // presence map of this minibatch (which tensors have grad != None in the reference): after the packed words
+        const int32_t* goff = hosti + info.grp_off;
+        const int32_t* noff = hosti + info.nxt_off;
+        float* act = host + words;
+        for (int t = 0; t < n_tensors; ++t) {
+            const int role = roles->role[t];
+            bool on = role & 4;
+            for (int q = roles->off[t]; q < roles->off[t + 1] && !on; ++q) {
+                const int a = roles->addr[q];
+                on = ((role & 1) && goff[a + 1] > goff[a]) || ((role & 2) && noff[a + 1] > noff[a]);
+            }
+            act[t] = on ? 1.0f : 0.0f;
+        }
+        if (addr_iterations)
+            for (int a = 0; a < n_addr; ++a) addr_iterations[a] += goff[a + 1] > goff[a];   // inference_network_lstm.py:198
+        if (hipMemcpyAsync(dev, host, (size_t)(words + n_tensors) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipEventRecord(ev[slot], st) != hipSuccess) {
+            pp::set_error("pp_train_steps: upload failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = PP_EHIP;
+            break;
+        }
+        pp_batch bt{};
+        bt.n_traces = (int32_t)info.n_traces; bt.n_rows = (int32_t)info.n_rows; bt.t_max = (int32_t)info.t_max;
+        bt.obs_width = obs_width;
+        bt.n_active = hosti + info.n_active; bt.row_off = hosti + info.row_off; bt.grp_off = goff; bt.nxt_off = noff;
+        bt.obs = dev + info.obs; bt.value = dev + info.value; bt.prior = dev + info.prior;
+        bt.addr = devi + info.addr; bt.prev_row = devi + info.prev_row; bt.grp_rows = devi + info.grp_rows;
+        bt.trace = devi + info.trace; bt.row_off_dev = devi + info.row_off_dev; bt.nxt_rows = devi + info.nxt_rows;
+        const int flags = PP_LOSS_BACKWARD | ((i == 0 && !grads_clean) ? PP_LOSS_ZERO_GRADS : 0);
+        rc = pp::ic_loss(net, &bt, tb->params, tb->grads, tb->workspace, tb->workspace_bytes, tb->loss_ring + i,
+                         tb->status_ring + i, nullptr, flags, st);
+        if (rc != 0) break;
+        // Adam checks the step's non-finite flag itself (`skip`) and clears the gradients it consumed (the next step's
+        // zero_grad, :486)
+        rc = pp::adam_step(tb->params, tb->grads, tb->exp_avg, tb->exp_avg_sq, net->n_params, tb->chunk_tensor, dev + words,
+                           tb->tensor_step, tb->adam_scratch, n_tensors, lr[i], beta1, beta2, eps, weight_decay, 1.0f,
+                           PP_ADAM_ZERO_GRADS, tb->status_ring + i, st);
+    }
+    // the staging slots are the caller's again once their uploads are done
+    for (int s = 0; s < n_ev; ++s) {
+        (void)hipEventSynchronize(ev[s]);
+        (void)hipEventDestroy(ev[s]);
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -280,6 +280,8 @@ class PackedTraceDataset:
     # ---- sampler support --------------------------------------------------------------------------------
     def sorted_indices(self):
         """Trace indices ordered by (length, type hash) (dataset.py:217-259); one shard is already in this order."""
+        if self._sorted is None and len(self._shards) == 1:
+            self._sorted = np.arange(self._length)
         if self._sorted is None:
             hashes = np.asarray([h for h, _ in self.trace_types], np.uint64)[self.trace_type]
             self._sorted = np.lexsort((np.arange(self._length), hashes, self.trace_len))
@@ -287,7 +289,7 @@ class PackedTraceDataset:
 
     def sampler(self, batch_size, rank=0, world_size=1, num_buckets=None, shuffle_batches=True, shuffle_buckets=True):
         from .parallel import DistributedTraceBatchSampler
-        return DistributedTraceBatchSampler(self.sorted_indices().tolist(), batch_size, rank, world_size, num_buckets,
+        return DistributedTraceBatchSampler(self.sorted_indices(), batch_size, rank, world_size, num_buckets,
                                             shuffle_batches, shuffle_buckets)
 
     # ---- vectorised access ------------------------------------------------------------------------------
@@ -337,19 +339,7 @@ class PackedTraceDataset:
         if np.any(ids < 0) or np.any(ids >= self._length):
             raise IndexError('trace index out of range')
         n_addr = len(spec.addresses)
-        key = (id(spec), n_addr)
-        if getattr(self, '_native_key', None) != key:      # (re)build the per-shard address maps for this network
-            to_engine = np.asarray([spec.address_id.get(a[0], -1) for a in self.addresses], np.int32)
-            self._native_remap = [np.ascontiguousarray(to_engine[r]) for r in self._addr_remap]
-            arr = (L.pp_shard_columns * len(self._shards))()
-            keep = []
-            for k, s in enumerate(self._shards):
-                cols = [np.asarray(getattr(s, n)) if not isinstance(getattr(s, n), np.memmap) else getattr(s, n)
-                        for n in ('trace_len', 'row_off', 'obs', 'value', 'prior', 'addr')]
-                keep.append(cols)
-                (arr[k].trace_len, arr[k].row_off, arr[k].obs, arr[k].value, arr[k].prior, arr[k].addr) = [c.ctypes.data for c in cols]
-                arr[k].addr_remap = self._native_remap[k].ctypes.data
-            self._native_shards, self._native_keep, self._native_key = arr, keep, key
+        self.native_columns(spec)
         lens = self.trace_len[ids]
         B, R, T = len(ids), int(lens.sum()), int(lens.max())
         words = lib.pp_pack_words(B, R, T, self.obs_width, n_addr)
@@ -363,6 +353,26 @@ class PackedTraceDataset:
                 raise KeyError('Address unknown by inference network ({})'.format(msg))
             raise RuntimeError('pp_pack_indexed failed: ' + msg)
         return PackedBatch._wrap_native(buf, info, self.obs_width, n_addr)
+
+    def native_columns(self, spec):
+        """(pp_shard_columns array, n_shards, `first` array) of this dataset for a network with address table `spec`: the
+        shard columns in place (memory-mapped files or arrays) + per-shard maps from shard-local address ids to the
+        network's. Cached until the network grows."""
+        from . import lib as L
+        key = (id(spec), len(spec.addresses))
+        if getattr(self, '_native_key', None) != key:      # (re)build the per-shard address maps for this network
+            to_engine = np.asarray([spec.address_id.get(a[0], -1) for a in self.addresses], np.int32)
+            self._native_remap = [np.ascontiguousarray(to_engine[r]) for r in self._addr_remap]
+            arr = (L.pp_shard_columns * len(self._shards))()
+            keep = []
+            for k, s in enumerate(self._shards):
+                cols = [np.asarray(getattr(s, n)) if not isinstance(getattr(s, n), np.memmap) else getattr(s, n)
+                        for n in ('trace_len', 'row_off', 'obs', 'value', 'prior', 'addr')]
+                keep.append(cols)
+                (arr[k].trace_len, arr[k].row_off, arr[k].obs, arr[k].value, arr[k].prior, arr[k].addr) = [c.ctypes.data for c in cols]
+                arr[k].addr_remap = self._native_remap[k].ctypes.data
+            self._native_shards, self._native_keep, self._native_key = arr, keep, key
+        return self._native_shards, len(self._shards), self._first
 
     def device_batch(self, indices, spec, device):
         """`batch(...).to(device)` through a ring of PINNED host buffers: the packer writes straight into page-locked
@@ -545,13 +555,50 @@ class VectorisedOnlineDataset:
         self._model, self.obs_names, self._chunk, self._device = model, list(obs_names), int(chunk_traces), device
         self._prior_inflation = PriorInflation.DISABLED if prior_inflation is None else prior_inflation
         self.generated = 0
+        self._worker = self._prepared = None
         self.refresh()
 
-    def refresh(self):
+    def _generate(self):
         cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device, return_types=True,
                                                prior_inflation=self._prior_inflation)
-        self._ds = PackedTraceDataset.from_columns(self.obs_names, None, *cols)
+        return PackedTraceDataset.from_columns(self.obs_names, None, *cols)
+
+    def refresh(self):
+        """Serve the next chunk of fresh prior traces (the one `start_prefetch` prepared, if any)."""
+        worker, self._worker = self._worker, None
+        if worker is not None or self._prepared is not None:
+            if worker is not None:
+                worker.join()
+            ds, err = self._prepared
+            self._prepared = None
+            if err is not None:
+                raise err
+        else:
+            ds = self._generate()
+        self._ds = ds
         self.generated += self._chunk
+
+    def wait_prefetch(self):
+        """Block until a running prefetch has finished (its chunk is kept for the next refresh): model code and the
+        generator share the module-global trace state, so the caller waits before running the model itself."""
+        if self._worker is not None:
+            self._worker.join()
+
+    def start_prefetch(self):
+        """Generate the NEXT chunk in a worker thread while the caller trains on the current one. Meant for the native
+        training loop: the trainer spends its time inside one C call per run of steps (pp_train_steps, GIL released), so
+        the generator's Python runs concurrently. The caller must not execute model code until the next refresh()."""
+        import threading
+        if self._worker is not None or self._prepared is not None:
+            return
+
+        def work():
+            try:
+                self._prepared = (self._generate(), None)
+            except BaseException as exc:      # noqa: BLE001 - re-raised by refresh() in the training thread
+                self._prepared = (None, exc)
+        self._worker = threading.Thread(target=work, name='pyprob_amd-prior-generator', daemon=True)
+        self._worker.start()
 
     def __len__(self):
         return int(1e9)

@@ -167,6 +167,69 @@ class ICEngine:
         self.adam_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS)
         return loss
 
+    def train_run(self, dataset, id_lists, lrs, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """A run of training steps in ONE C call (pp_train_steps): step i trains on the traces id_lists[i] of a packed
+        dataset (pyprob_amd/dataset.py) with learning rate lrs[i] - packing, upload, loss + backward and Adam per step
+        without returning to Python (single rank). Returns (losses, statuses): device tensors [n_steps], not synchronised.
+        The caller polymorphs first; per-address iteration counters (inference_network_lstm.py:198) are updated here."""
+        if self.world_size != 1 or self.force_allreduce:
+            raise RuntimeError('train_run is the single-rank loop; data-parallel training steps go through train_step')
+        n_steps = len(id_lists)
+        spec = self.spec
+        shards, n_shards, first = dataset.native_columns(spec)
+        sizes = np.fromiter((len(x) for x in id_lists), np.int64, n_steps)
+        step_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int64).reshape(-1) for x in id_lists]))
+        if ids.size == 0 or np.any(sizes <= 0):
+            raise ValueError('empty batch')
+        if np.any(ids < 0) or np.any(ids >= len(dataset.trace_len)):
+            raise IndexError('trace index out of range')
+        lens = dataset.trace_len[ids].astype(np.int64)
+        b_max, t_max = int(sizes.max()), int(lens.max())
+        r_max = int(np.add.reduceat(lens, step_off[:-1]).max())
+        self._ensure_workspace(b_max, r_max)
+        key = (id(spec), spec.n_tensors)
+        if getattr(self, '_roles_key', None) != key:
+            off, addr, role = spec.tensor_roles()
+            self._roles_arrays = (off, addr, role)
+            self._roles = L.pp_tensor_roles(off.ctypes.data, addr.ctypes.data, role.ctypes.data)
+            self._roles_key = key
+        n_slots = 8
+        slot_words = int(self.lib.pp_train_slot_words(b_max, r_max, t_max, dataset.obs_width, len(spec.addresses),
+                                                      spec.n_tensors))
+        if getattr(self, '_slot_words', 0) < slot_words:
+            self._staging = torch.empty(n_slots * slot_words, dtype=torch.float32).pin_memory()
+            self._device_batch = torch.empty(n_slots * slot_words, dtype=torch.float32, device=self.device)
+            self._slot_words = slot_words
+        if getattr(self, '_ring_n', 0) < n_steps:
+            self._ring_n = max(n_steps, 64)
+            self._loss_ring = torch.zeros(self._ring_n, dtype=torch.float32, device=self.device)
+            self._status_ring = torch.zeros(self._ring_n, dtype=torch.int32, device=self.device)
+        tb = L.pp_train_buffers(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                self.exp_avg_sq.data_ptr(), self.chunk_tensor.data_ptr(), self.tensor_step.data_ptr(),
+                                self.arrived.data_ptr(), self.workspace.data_ptr(), self.ws_bytes,
+                                self._staging.data_ptr(), self._device_batch.data_ptr(), self._slot_words,
+                                self._loss_ring.data_ptr(), self._status_ring.data_ptr(), spec.n_tensors, n_slots)
+        lr = np.ascontiguousarray(lrs, np.float32).reshape(-1)
+        if len(lr) != n_steps:
+            raise ValueError('one learning rate per step')
+        iters = np.zeros(max(len(spec.addresses), 1), np.int64)
+        rc = self.lib.pp_train_steps(C.byref(self.net), C.byref(tb), C.byref(self._roles), shards, n_shards,
+                                     first.ctypes.data, dataset.obs_width, ids.ctypes.data, step_off.ctypes.data, n_steps,
+                                     lr.ctypes.data, beta1, beta2, eps, weight_decay, 1 if self._grads_clean else 0,
+                                     iters.ctypes.data, L.stream_ptr())
+        if rc != 0:
+            msg = self.lib.pp_last_error().decode()
+            self._grads_clean = False
+            if 'address' in msg:
+                raise KeyError('Address unknown by inference network ({})'.format(msg))
+            raise RuntimeError('pp_train_steps failed (rc=%d): %s' % (rc, msg))
+        self._grads_clean = True
+        self._active_key = None        # (self.active was not used: the per-step maps live in the batch slots)
+        for a, k in enumerate(iters[:len(spec.addresses)]):
+            spec.addresses[a].total_train_iterations += int(k)
+        return self._loss_ring[:n_steps], self._status_ring[:n_steps]
+
     # ---- HIP graph replay of the step (static shapes) ------------------------------------------------------------
     def capture_train_step(self, batch, lr, weight_decay=0.0):
         """Capture zero_grad -> loss -> backward -> Adam for a batch of FIXED shape and FIXED buffer addresses into a

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 2
+PP_ABI_VERSION = 3
 PP_MAX_OBS = 8
 PP_ADDR_TABLE_COLS = 8
 PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL, PP_HEAD_POISSON_TN_MIXTURE = 0, 1, 2, 3
@@ -68,8 +68,23 @@ class pp_shard_columns(C.Structure):
     _fields_ = [(n, vp) for n in ('trace_len', 'row_off', 'obs', 'value', 'prior', 'addr', 'addr_remap')]
 
 
+class pp_train_buffers(C.Structure):
+    _fields_ = [('params', vp), ('grads', vp), ('exp_avg', vp), ('exp_avg_sq', vp),
+                ('chunk_tensor', vp), ('tensor_step', vp), ('adam_scratch', vp),
+                ('workspace', vp), ('workspace_bytes', C.c_size_t),
+                ('staging', vp), ('device_batch', vp), ('slot_words', i64),
+                ('loss_ring', vp), ('status_ring', vp), ('n_tensors', i32), ('n_slots', i32)]
+
+
+class pp_tensor_roles(C.Structure):
+    _fields_ = [('off', vp), ('addr', vp), ('role', vp)]
+
+
 # name -> (restype, argtypes); every symbol include/pyprob_amd.h declares
 PROTOTYPES = {
+    'pp_train_slot_words': (i64, [i32, i64, i32, i32, i32, i32]),
+    'pp_train_steps': (C.c_int, [C.POINTER(pp_net), C.POINTER(pp_train_buffers), C.POINTER(pp_tensor_roles), vp, i32, vp, i32,
+                                 vp, vp, i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp, vp]),
     'pp_pack_indexed': (C.c_int, [vp, i32, vp, vp, i32, i32, i32, vp, i64, vp]),
     'pp_pack_words': (i64, [i32, i64, i32, i32, i32]),
     'pp_pack_ragged': (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, i64, vp]),

@@ -5,6 +5,7 @@ pyprob/nn/inference_network.py:25-599, pyprob/nn/inference_network_lstm.py:11-22
 engine's (`ICEngine`, one C-ABI call per loss / optimizer step / IS statement).
 """
 import math
+import os
 import time
 import warnings
 
@@ -328,13 +329,14 @@ class InferenceNetworkLSTM:
         ls.runner.accumulate_masked(ls.lw, kind, torch.as_tensor(p0).reshape(-1).to(dev), torch.as_tensor(p1).reshape(-1).to(dev),
                                     value, ls.active)
 
-    def _learning_rate(self):
+    def _learning_rate(self, traces=None):
         """POLY1 / POLY2 decay driven by the trace count (inference_network.py:357-379, :568)."""
+        traces = self._total_train_traces if traces is None else traces
         t = self._learning_rate_scheduler_type
         if t in (None, 'NONE'):
             return self._learning_rate_init
         power = 1.0 if t == 'POLY1' else 2.0
-        frac = max(0.0, 1.0 - self._total_train_traces / self._total_train_traces_end)
+        frac = max(0.0, 1.0 - traces / self._total_train_traces_end)
         return (self._learning_rate_init - self._learning_rate_end) * (frac ** power) + self._learning_rate_end
 
     def optimize(self, num_traces, dataset, batch_size=64, learning_rate_init=0.0001, learning_rate_end=1e-6,
@@ -387,6 +389,98 @@ class InferenceNetworkLSTM:
         if packed:
             sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
             sampler_iter = iter(sampler)
+
+        def book(pending, losses, bad):
+            """Per-iteration bookkeeping of inference_network.py:497-531 for the iterations whose loss / non-finite flag
+            were just read back. Returns True when training must stop (stop_with_bad_loss)."""
+            nonlocal trace, stop, last
+            now = time.time()
+            dt_each = (now - last) / len(pending)
+            for k, (bsize, mean_len, n_sub) in enumerate(pending):
+                loss = float(losses[k]) / (world if world > 1 else 1)                # tail is the all-reduced SUM
+                if bad[k] != 0:
+                    print('Cannot compute loss, skipping batch. Loss: {}'.format(loss))
+                    trace -= bsize * world
+                    stop = trace >= num_traces
+                    if stop_with_bad_loss:
+                        return True
+                    continue
+                if self._loss_init is None:
+                    self._loss_init = self._loss_max = loss
+                self._loss_min = min(self._loss_min, loss)
+                self._loss_max = max(self._loss_max, loss)
+                self._loss_previous = loss
+                self._total_train_iterations += 1
+                self._total_train_traces += bsize * world
+                self._total_train_seconds = prev_seconds + (last + dt_each * (k + 1) - time_start)
+                self._history_train_loss.append(loss)
+                self._history_train_loss_trace.append(self._total_train_traces)
+                if log_file:
+                    log_file.write('{}, {}, {}, {}, {}, {}, {}, {}\n'.format(
+                        self._total_train_seconds, self._total_train_iterations, self._total_train_traces, loss,
+                        self._learning_rate(), mean_len, n_sub, bsize * world / max(dt_each, 1e-9)))
+            last = now
+            return False
+
+        # Single rank + packed dataset: runs of up to `chunk_steps` iterations execute inside ONE C call (pp_train_steps:
+        # pack -> upload -> loss + backward -> Adam per step, no Python in between); Python plans the minibatches of a
+        # run, polymorphs at exactly the iteration where a new address first appears (a run ends before it), computes
+        # the learning rates, and reads the run's losses back once. PP_PYTHON_LOOP=1 keeps the per-step Python loop.
+        native = packed and world == 1 and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
+        chunk_steps = 1 if sync_every == 1 else 64
+        carry = None
+        # While a run trains inside the C call, a worker thread generates the next chunk of prior traces
+        # (VectorisedOnlineDataset.start_prefetch). torch's intra-op pool must not fan that work out over all host cores:
+        # measured (tools/prefetch_probe.py, 256-core host) a 128-thread torch.normal next to pp_train_steps slows a
+        # step from 180 us to 650-1100 us, with one intra-op thread there is no interference.
+        prefetching = native and hasattr(dataset, 'start_prefetch')
+        cpu_threads = torch.get_num_threads()
+        if prefetching:
+            torch.set_num_threads(1)
+
+        def end_prefetch():
+            if hasattr(dataset, 'wait_prefetch'):
+                dataset.wait_prefetch()    # the prior generator shares the module-global trace state with model code
+            if prefetching:
+                torch.set_num_threads(cpu_threads)
+        while native and not stop:
+            steps, metas, planned, epoch_end = [], [], trace, False
+            while len(steps) < chunk_steps and planned < num_traces:
+                if carry is not None:
+                    ids, carry = carry, None
+                else:
+                    try:
+                        ids = next(sampler_iter)
+                    except StopIteration:
+                        epoch_end = True
+                        break
+                types = dataset.types_of(ids)
+                if not self._layers_pre_generated:
+                    new = [a for a in dataset.addresses_of(ids, types) if a[0] not in self._engine.spec.address_id]
+                    if new and steps:
+                        carry = ids             # train the planned iterations with the current layers first
+                        break
+                    if new and self._polymorph(_PackedIds(dataset, ids, new)):
+                        self._engine.reset_optimizer()                                # :481-483
+                steps.append(ids)
+                metas.append((len(ids), float(dataset.trace_len[ids].mean()) if log_file else 0.0, len(types)))
+                planned += len(ids)
+            if steps:
+                seen = self._total_train_traces + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
+                lrs = [self._learning_rate(t) for t in seen]
+                losses_t, status_t = self._engine.train_run(dataset, steps, lrs, weight_decay=self._weight_decay)
+                trace = planned
+                stop = trace >= num_traces
+                if book(metas, losses_t.cpu().numpy(), status_t.cpu().numpy()):
+                    end_prefetch()
+                    return
+            if epoch_end:
+                if hasattr(dataset, 'refresh'):                                       # online: fresh prior traces
+                    dataset.refresh()
+                    sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
+                    if hasattr(dataset, 'start_prefetch') and not stop:
+                        dataset.start_prefetch()     # the next chunk is generated while this one trains (C call, no GIL)
+                sampler_iter = iter(sampler)                                          # next epoch (:461-464)
         while not stop:
             if packed:
                 try:
@@ -446,35 +540,10 @@ class InferenceNetworkLSTM:
             if len(pending) < sync_every and not stop:
                 continue
             # ---- read back and book-keep the pending iterations ------------------------------------------------------
-            losses = loss_ring[:len(pending)].cpu().numpy()
-            bad = status_ring[:len(pending)].cpu().numpy()
-            now = time.time()
-            dt_each = (now - last) / len(pending)
-            for k, (bsize, mean_len, n_sub) in enumerate(pending):
-                loss = float(losses[k]) / (world if world > 1 else 1)                # tail is the all-reduced SUM
-                if bad[k] != 0:
-                    print('Cannot compute loss, skipping batch. Loss: {}'.format(loss))
-                    trace -= bsize * world
-                    stop = trace >= num_traces
-                    if stop_with_bad_loss:
-                        return
-                    continue
-                if self._loss_init is None:
-                    self._loss_init = self._loss_max = loss
-                self._loss_min = min(self._loss_min, loss)
-                self._loss_max = max(self._loss_max, loss)
-                self._loss_previous = loss
-                self._total_train_iterations += 1
-                self._total_train_traces += bsize * world
-                self._total_train_seconds = prev_seconds + (last + dt_each * (k + 1) - time_start)
-                self._history_train_loss.append(loss)
-                self._history_train_loss_trace.append(self._total_train_traces)
-                if log_file:
-                    log_file.write('{}, {}, {}, {}, {}, {}, {}, {}\n'.format(
-                        self._total_train_seconds, self._total_train_iterations, self._total_train_traces, loss,
-                        self._learning_rate(), mean_len, n_sub, bsize * world / max(dt_each, 1e-9)))
-            last = now
+            if book(pending, loss_ring[:len(pending)].cpu().numpy(), status_ring[:len(pending)].cpu().numpy()):
+                return
             pending = []
+        end_prefetch()
         if verbose and rank == 0:
             print('Stop condition reached. num_traces: {}  loss {:+.3e}  traces/s {:,.0f}'.format(
                 num_traces, self._loss_previous, self._total_train_traces / max(self._total_train_seconds, 1e-9)))

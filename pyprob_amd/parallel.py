@@ -44,16 +44,14 @@ class DistributedTraceBatchSampler:
     def __init__(self, sorted_indices, batch_size, rank, world_size, num_buckets=None, shuffle_batches=True,
                  shuffle_buckets=True):
         self._world_size, self._rank = world_size, rank
-        idx = list(sorted_indices)
+        idx = np.asarray(sorted_indices, np.int64).reshape(-1)       # (minibatches are rows of one array: no Python lists)
         num_batches_to_drop = math.floor(len(idx) / batch_size) % world_size
         num_traces_to_drop = num_batches_to_drop * batch_size
         rng = np.random.RandomState(0)             # every rank drops the same traces
         if num_traces_to_drop:
-            drop = set(rng.choice(len(idx), num_traces_to_drop, replace=False).tolist())
-            idx = [v for i, v in enumerate(idx) if i not in drop]
-        self._batches = [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
-        if self._batches and len(self._batches[-1]) < batch_size:
-            del self._batches[-1]
+            idx = np.delete(idx, rng.choice(len(idx), num_traces_to_drop, replace=False))
+        n_full = len(idx) // batch_size            # a short last minibatch is dropped (dataset.py:345-346)
+        self._batches = list(idx[:n_full * batch_size].reshape(n_full, batch_size))
         if not self._batches:
             raise RuntimeError('dataset too small for batch_size:{} and world_size:{}'.format(batch_size, world_size))
         if num_buckets is None:

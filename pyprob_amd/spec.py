@@ -174,6 +174,34 @@ class NetSpec:
                     act[index['_layers_sample_embedding.%s._layers.0.%s' % (info.address, s)]] = 1.0
         return act
 
+    def tensor_roles(self):
+        """active_mask as tables for the native training loop (pp_tensor_roles, include/pyprob_amd.h): per tensor the
+        addresses whose occurrence gives it a gradient and how (bit 0: as current variable, bit 1: as previous variable,
+        bit 2: always). Returns int32 arrays (off [n_tensors+1], addr, role [n_tensors])."""
+        off, addr, role = [0], [], []
+        by_dtype = {}
+        for a, info in enumerate(self.addresses):
+            by_dtype.setdefault(info.dist_name, []).append(a)
+        for i, name in enumerate(self.tensors):
+            if i < self.n_core_tensors:
+                role.append(4)
+            elif name.startswith('_layers_address_embedding.'):
+                addr.append(self.address_id[name[len('_layers_address_embedding.'):]])
+                role.append(3)
+            elif name.startswith('_layers_distribution_type_embedding.'):
+                addr.extend(by_dtype[name[len('_layers_distribution_type_embedding.'):]])
+                role.append(3)
+            elif name.startswith('_layers_proposal.'):
+                addr.append(self.address_id[name[len('_layers_proposal.'):name.index('._ff._layers.')]])
+                role.append(1)
+            elif name.startswith('_layers_sample_embedding.'):
+                addr.append(self.address_id[name[len('_layers_sample_embedding.'):name.index('._layers.0.')]])
+                role.append(2)
+            else:
+                raise RuntimeError('tensor without a role: ' + name)
+            off.append(len(addr))
+        return np.asarray(off, np.int32), np.asarray(addr + [0], np.int32), np.asarray(role, np.int32)
+
     def chunk_tensor_map(self):
         m = np.empty(self.n_params // CHUNK, np.int32)
         offs = [o for o, _ in self.tensors.values()] + [self.n_params]

@@ -164,6 +164,53 @@ def test_feedforward_network_benchmark_size_against_oracle():
     assert float(last.item()) < first
 
 
+def test_native_training_loop_matches_the_per_step_calls():
+    """pp_train_steps (pack -> upload -> loss + backward -> Adam for a run of minibatches in one C call) against the same
+    minibatches stepped one C call at a time: same losses, same parameters, same per-address iteration counters; a
+    non-finite minibatch is flagged and leaves the parameters alone."""
+    from pyprob_amd.dataset import PackedTraceDataset
+    arrays, addresses = synthetic_gumm_arrays(6000, seed=12, max_iter=5)
+    table = [(a, 'Uniform', None) for a in addresses]
+    ds = PackedTraceDataset.from_columns(['obs0', 'obs1'], [1, 1], arrays['trace_len'], table, arrays['addr_idx'],
+                                         arrays['values'], arrays['prior'], arrays['obs'])
+    rng = np.random.default_rng(5)
+    steps = [rng.choice(6000, size=n, replace=False) for n in (256, 256, 300, 17, 256, 1, 256, 500, 256, 256, 256, 64)]
+    lrs = [1e-3 * (1 + 0.1 * k) for k in range(len(steps))]
+    a, b = _fresh_engine(64, addresses, 'Uniform', seed=3), _fresh_engine(64, addresses, 'Uniform', seed=3)
+    ref_losses = []
+    for ids, lr in zip(steps, lrs):
+        pb = ds.device_batch(ids, a.spec, a.device)
+        for info_id, n in enumerate(pb.cur_counts):
+            a.spec.addresses[info_id].total_train_iterations += int(n > 0)
+        ref_losses.append(float(a.loss(pb, backward=True).item()))
+        a.adam_step(lr, weight_decay=1e-5, zero_grads=True)
+    losses, status = b.train_run(ds, steps[:5], lrs[:5], weight_decay=1e-5)
+    got = losses.cpu().numpy().tolist()
+    losses, status2 = b.train_run(ds, steps[5:], lrs[5:], weight_decay=1e-5)       # a second run continues the first
+    got += losses.cpu().numpy().tolist()
+    assert not status.cpu().numpy().any() and not status2.cpu().numpy().any()
+    np.testing.assert_allclose(got, ref_losses, rtol=2e-5)
+    # (Adam normalises the gradient: an element whose gradient is at round-off level may move by +-lr in either run)
+    for n in a.spec.tensors:
+        d = np.abs(b.tensor(n).cpu().numpy() - a.tensor(n).cpu().numpy())
+        assert d.mean() < 2e-5 and d.max() < 4e-3, (n, d.mean(), d.max())
+    assert [i.total_train_iterations for i in b.spec.addresses] == [i.total_train_iterations for i in a.spec.addresses]
+    assert torch.equal(b.tensor_step.cpu(), a.tensor_step.cpu())
+    # a minibatch with a non-finite observation (torch.relu keeps the NaN, so does the embedding here): flagged,
+    # parameters untouched, the run goes on
+    bad = dict(arrays)
+    bad['obs'] = arrays['obs'].copy()
+    bad['obs'][10] = np.nan
+    ds2 = PackedTraceDataset.from_columns(['obs0', 'obs1'], [1, 1], bad['trace_len'], table, bad['addr_idx'], bad['values'],
+                                          bad['prior'], bad['obs'])
+    victim = int(np.nonzero(np.isnan(ds2.gather(np.arange(6000))[4]).any(1))[0][0])
+    before = b.params.clone()
+    losses, status = b.train_run(ds2, [np.array([victim, 1, 2, 3])], [1e-3])
+    assert int(status.cpu()[0]) != 0 and torch.equal(b.params, before)
+    losses, status = b.train_run(ds2, [np.arange(1, 200) if victim == 0 else np.delete(np.arange(200), victim)], [1e-3])
+    assert int(status.cpu()[0]) == 0 and not torch.equal(b.params, before)
+
+
 def test_loss_is_permutation_invariant_and_additive():
     """Size-independent properties: the loss does not depend on trace order, and the loss of a union of two
     batches is the size-weighted mean of their losses."""

@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol(lib):
     assert declared == set(L.PROTOTYPES.keys()), declared ^ set(L.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.pp_abi_version() == 2
+    assert lib.pp_abi_version() == 3
 
 
 def test_struct_sizes_match_header_layout():
@@ -163,3 +163,24 @@ def test_native_packer_matches_the_numpy_statement():
         PackedBatch.from_ragged([], [], [], np.zeros((0, 2)), np.zeros((0, 1)), 1)
     with pytest.raises(RuntimeError):      # address id outside the table: rejected by the C side
         PackedBatch.from_ragged([1], [5], [0.0], np.zeros((1, 2)), np.zeros((1, 1)), 2)
+
+
+def test_tensor_roles_reproduce_the_presence_map(golden):
+    """spec.tensor_roles() (the tables of pp_train_steps) evaluates to spec.active_mask() for any occurrence pattern."""
+    case, meta, params, batch, loss, isr = golden
+    spec = spec_from_golden(meta, params)
+    off, addr, role = spec.tensor_roles()
+    assert len(off) == spec.n_tensors + 1 and len(role) == spec.n_tensors
+    rng = np.random.default_rng(0)
+    n = len(spec.addresses)
+    for _ in range(20):
+        cur = rng.integers(0, 2, n) * rng.integers(1, 5, n)
+        prev = rng.integers(0, 2, n) * rng.integers(1, 5, n)
+        want = spec.active_mask(cur, prev)
+        got = np.zeros(spec.n_tensors, np.float32)
+        for t in range(spec.n_tensors):
+            on = bool(role[t] & 4)
+            for a in addr[off[t]:off[t + 1]]:
+                on = on or bool(role[t] & 1 and cur[a] > 0) or bool(role[t] & 2 and prev[a] > 0)
+            got[t] = on
+        assert np.array_equal(got, want)
