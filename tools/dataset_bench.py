@@ -75,6 +75,18 @@ try:
                 break
         torch.cuda.synchronize()
         t6 = time.perf_counter()
-        print('offline training fed by the loader (disk -> host pack -> H2D -> step): %.2f M traces/s (%.3f ms/step)' % (steps * B / (t6 - t5) / 1e6, (t6 - t5) / steps * 1e3))
+        print('offline training fed by the loader (disk -> host pack -> H2D -> step), Python per step: %.2f M traces/s (%.3f ms/step)' % (steps * B / (t6 - t5) / 1e6, (t6 - t5) / steps * 1e3))
+        # the route learn_inference_network(dataset_dir=...) takes: runs of 64 steps inside pp_train_steps
+        it = iter(ds.sampler(B, 0, 1))
+        runs = [[next(it) for _ in range(64)] for _ in range(8)]
+        eng.train_run(ds, runs[0], [1e-3] * 64)
+        torch.cuda.synchronize()
+        t7 = time.perf_counter()
+        for r in runs[1:]:
+            l, s_ = eng.train_run(ds, r, [1e-3] * 64)
+            l.cpu()
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        print('offline training, native loop (pp_train_steps, 64 steps per call): %.2f M traces/s (%.3f ms/step)' % (7 * 64 * B / (t8 - t7) / 1e6, (t8 - t7) / (7 * 64) * 1e3))
 finally:
     shutil.rmtree(root, ignore_errors=True)
