@@ -443,44 +443,46 @@ class InferenceNetworkLSTM:
                 dataset.wait_prefetch()    # the prior generator shares the module-global trace state with model code
             if prefetching:
                 torch.set_num_threads(cpu_threads)
-        while native and not stop:
-            steps, metas, planned, epoch_end = [], [], trace, False
-            while len(steps) < chunk_steps and planned < num_traces:
-                if carry is not None:
-                    ids, carry = carry, None
-                else:
-                    try:
-                        ids = next(sampler_iter)
-                    except StopIteration:
-                        epoch_end = True
-                        break
-                types = dataset.types_of(ids)
-                if not self._layers_pre_generated:
-                    new = [a for a in dataset.addresses_of(ids, types) if a[0] not in self._engine.spec.address_id]
-                    if new and steps:
-                        carry = ids             # train the planned iterations with the current layers first
-                        break
-                    if new and self._polymorph(_PackedIds(dataset, ids, new)):
-                        self._engine.reset_optimizer()                                # :481-483
-                steps.append(ids)
-                metas.append((len(ids), float(dataset.trace_len[ids].mean()) if log_file else 0.0, len(types)))
-                planned += len(ids)
-            if steps:
-                seen = self._total_train_traces + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
-                lrs = [self._learning_rate(t) for t in seen]
-                losses_t, status_t = self._engine.train_run(dataset, steps, lrs, weight_decay=self._weight_decay)
-                trace = planned
-                stop = trace >= num_traces
-                if book(metas, losses_t.cpu().numpy(), status_t.cpu().numpy()):
-                    end_prefetch()
-                    return
-            if epoch_end:
-                if hasattr(dataset, 'refresh'):                                       # online: fresh prior traces
-                    dataset.refresh()
-                    sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
-                    if hasattr(dataset, 'start_prefetch') and not stop:
-                        dataset.start_prefetch()     # the next chunk is generated while this one trains (C call, no GIL)
-                sampler_iter = iter(sampler)                                          # next epoch (:461-464)
+        try:
+            while native and not stop:
+                steps, metas, planned, epoch_end = [], [], trace, False
+                while len(steps) < chunk_steps and planned < num_traces:
+                    if carry is not None:
+                        ids, carry = carry, None
+                    else:
+                        try:
+                            ids = next(sampler_iter)
+                        except StopIteration:
+                            epoch_end = True
+                            break
+                    types = dataset.types_of(ids)
+                    if not self._layers_pre_generated:
+                        new = [a for a in dataset.addresses_of(ids, types) if a[0] not in self._engine.spec.address_id]
+                        if new and steps:
+                            carry = ids             # train the planned iterations with the current layers first
+                            break
+                        if new and self._polymorph(_PackedIds(dataset, ids, new)):
+                            self._engine.reset_optimizer()                                # :481-483
+                    steps.append(ids)
+                    metas.append((len(ids), float(dataset.trace_len[ids].mean()) if log_file else 0.0, len(types)))
+                    planned += len(ids)
+                if steps:
+                    seen = self._total_train_traces + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
+                    lrs = [self._learning_rate(t) for t in seen]
+                    losses_t, status_t = self._engine.train_run(dataset, steps, lrs, weight_decay=self._weight_decay)
+                    trace = planned
+                    stop = trace >= num_traces
+                    if book(metas, losses_t.cpu().numpy(), status_t.cpu().numpy()):
+                        return
+                if epoch_end:
+                    if hasattr(dataset, 'refresh'):                                       # online: fresh prior traces
+                        dataset.refresh()
+                        sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
+                        if hasattr(dataset, 'start_prefetch') and not stop:
+                            dataset.start_prefetch()     # the next chunk is generated while this one trains (C call, no GIL)
+                    sampler_iter = iter(sampler)                                          # next epoch (:461-464)
+        finally:
+            end_prefetch()
         while not stop:
             if packed:
                 try:
@@ -543,7 +545,6 @@ class InferenceNetworkLSTM:
             if book(pending, loss_ring[:len(pending)].cpu().numpy(), status_ring[:len(pending)].cpu().numpy()):
                 return
             pending = []
-        end_prefetch()
         if verbose and rank == 0:
             print('Stop condition reached. num_traces: {}  loss {:+.3e}  traces/s {:,.0f}'.format(
                 num_traces, self._loss_previous, self._total_train_traces / max(self._total_train_seconds, 1e-9)))

@@ -184,3 +184,21 @@ def test_tensor_roles_reproduce_the_presence_map(golden):
                 on = on or bool(role[t] & 1 and cur[a] > 0) or bool(role[t] & 2 and prev[a] > 0)
             got[t] = on
         assert np.array_equal(got, want)
+
+
+def test_train_steps_rejects_incomplete_arguments(lib):
+    """pp_train_steps validates its arguments before touching the device (callable without a GPU)."""
+    import ctypes as C
+    from pyprob_amd import lib as L
+    assert lib.pp_train_steps(None, None, None, None, 0, None, 0, None, None, 0, None, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1
+    assert b'null pointer' in lib.pp_last_error()
+    spec = spec_from_golden(*load_golden('gum')[:2])
+    net = spec.c_struct(0)
+    tb, roles = L.pp_train_buffers(), L.pp_tensor_roles()
+    one = np.zeros(4, np.int64)
+    lr = np.zeros(1, np.float32)
+    shards = (L.pp_shard_columns * 1)()
+    rc = lib.pp_train_steps(C.byref(net), C.byref(tb), C.byref(roles), shards, 1, one.ctypes.data, 2, one.ctypes.data,
+                            one.ctypes.data, 0, lr.ctypes.data, 0.9, 0.999, 1e-8, 0.0, 0, None, None)
+    assert rc == -1 and b'pp_train_buffers' in lib.pp_last_error()
+    assert lib.pp_train_slot_words(1024, 1024, 1, 2, 1, 20) >= lib.pp_pack_words(1024, 1024, 1, 2, 1) + 20
