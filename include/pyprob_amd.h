@@ -229,13 +229,16 @@ int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
  *                    present if role[t] & 4, or if one of its addresses addr[off[t] .. off[t+1]) occurs as a current
  *                    (role & 1) / previous (role & 2) variable of the minibatch (inference_network_lstm.py:168-171).
  *   staging          pinned host memory, device_batch device memory: n_slots slots of slot_words 4-byte words each,
- *                    slot_words >= pp_train_slot_words(...) of the largest step; slots rotate, a slot is rewritten
- *                    only after its upload completed.
+ *                    slot_words >= pp_train_slot_words(...) of the largest step. The slots form two halves: a group of
+ *                    up to n_slots/2 consecutive steps is packed into one half and uploaded with ONE copy (group
+ *                    sizes ramp 1, 2, 4, ...); a half is rewritten only after its upload completed.
  *   workspace        pp_ic_workspace_bytes(net, most traces, most rows of any step)
  *   grads_clean      non-zero: `grads` is all zero on entry (left so by PP_ADAM_ZERO_GRADS); it is on return.
  *   addr_iterations  host [n_addr] or NULL: += 1 per step in which the address occurs (proposal_layer.
  *                    _total_train_iterations, inference_network_lstm.py:198)
- * Returns after the last step is enqueued and the staging slots are reusable; the losses are read by the caller.
+ * Returns as soon as the last step is enqueued (the last uploads may still be pending: the next call waits for them
+ * before it rewrites a staging half; pp_train_sync() waits for them explicitly - call it before freeing or reusing the
+ * staging memory). One training run at a time per process. The losses are read by the caller.
  */
 typedef struct pp_train_buffers {
     float* params; float* grads; float* exp_avg; float* exp_avg_sq;             /* dev [n_params] */
@@ -254,6 +257,8 @@ typedef struct pp_tensor_roles {
 
 int64_t pp_train_slot_words(int32_t n_traces, int64_t n_rows, int32_t t_max, int32_t obs_width, int32_t n_addr,
                             int32_t n_tensors);
+
+int pp_train_sync(void);
 
 int pp_train_steps(const pp_net* net, const pp_train_buffers* buffers, const pp_tensor_roles* roles,
                    const pp_shard_columns* shards, int32_t n_shards, const int64_t* first, int32_t obs_width,

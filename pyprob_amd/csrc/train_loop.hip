@@ -4,7 +4,7 @@
 // Python host only decides which traces form which minibatch, the learning rates, and reads the losses back once per
 // run. Measured motivation: a training step is 0.16 ms on the GPU, while Python spent 0.25-0.38 ms
 // per step on packing calls, torch tensor wrappers and ctypes marshalling.
-// The upload shares the compute stream on purpose: a dedicated copy stream with event hand-offs (upload i+1 under
+// The uploads share the compute stream on purpose: a dedicated copy stream with event hand-offs (upload i+1 under
 // step i) was measured SLOWER on this runtime - 224 instead of 180 us per LSTM step, 191 instead of 104 us per
 // FeedForward step (tools/train_loop_bench.py) - the cross-stream waits cost more than the ~10 us copy they hide.
 #include "common.hpp"
@@ -20,6 +20,10 @@ int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params,
               const float* active, int32_t* tensor_step, int32_t* arrived, int n_tensors, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, int flags, const int32_t* skip, hipStream_t st);
 }  // namespace pp
+
+// upload-complete events of the two staging halves; one training run at a time per process (like the reference's loop)
+static hipEvent_t g_half_event[2];
+static bool g_have_event[2] = {false, false};
 
 extern "C" {
 
@@ -44,80 +48,106 @@ int pp_train_steps(const pp_net* net, const pp_train_buffers* tb, const pp_tenso
     }
     hipStream_t st = pp::as_stream(stream);
     const int n_addr = net->n_addr, n_tensors = tb->n_tensors;
-    hipEvent_t ev[64];
-    int n_ev = 0;
+    // Minibatches are uploaded in GROUPS: the slots form two halves; a group of up to n_slots/2 steps is packed into one
+    // half and crosses PCIe as ONE copy, then its steps are enqueued back to back. A copy on the compute stream costs
+    // ~15-20 us of idle GPU per occurrence (it waits for the previous step, then pays the DMA latency): per step that
+    // was 11 % of a 160 us step, per group of 8 it is 1.5 %. Group sizes ramp 1, 2, 4, ... so the GPU starts at once.
+    const int G = std::max(1, tb->n_slots / 2);
+    hipEvent_t* ev = g_half_event;
+    bool* have_ev = g_have_event;
+    struct Packed { pp_pack_info info; int64_t words; };
+    std::vector<Packed> pk(G);
     int rc = 0;
-    for (int i = 0; i < n_steps && rc == 0; ++i) {
-        const int slot = i % tb->n_slots;
-        if (slot >= n_ev) {
-            if (hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming) != hipSuccess) {
+    for (int i = 0, gi = 0; i < n_steps && rc == 0; ++gi) {
+        const int half = tb->n_slots >= 2 ? (gi & 1) : 0;
+        const int gs = std::min({G, 1 << std::min(gi, 16), n_steps - i});
+        if (!have_ev[half]) {
+            if (hipEventCreateWithFlags(&ev[half], hipEventDisableTiming) != hipSuccess) {
                 pp::set_error("pp_train_steps: hipEventCreate failed");
                 rc = PP_EHIP;
                 break;
             }
-            ++n_ev;
+            have_ev[half] = true;
         } else {
-            (void)hipEventSynchronize(ev[slot]);   // the upload that last read this staging slot has completed
+            (void)hipEventSynchronize(ev[half]);   // the copy that last read this staging half has completed
         }
-        float* host = static_cast<float*>(tb->staging) + (int64_t)slot * tb->slot_words;
-        int32_t* hosti = reinterpret_cast<int32_t*>(host);
-        float* dev = static_cast<float*>(tb->device_batch) + (int64_t)slot * tb->slot_words;
-        int32_t* devi = reinterpret_cast<int32_t*>(dev);
-        const int64_t n = step_off[i + 1] - step_off[i];
-        if (n <= 0 || n > INT32_MAX) {
-            pp::set_error("pp_train_steps: step %d has %lld traces", i, (long long)n);
-            rc = PP_EINVAL;
-            break;
-        }
-        pp_pack_info info;
-        rc = pp_pack_indexed(shards, n_shards, first, ids + step_off[i], (int32_t)n, obs_width, n_addr, host,
-                             tb->slot_words - n_tensors, &info);
-        if (rc != 0) break;
-        const int64_t words = info.src_row + info.n_rows;   // end of the packed buffer (pp_pack_words)
-        // presence map of this minibatch (which tensors have grad != None in the reference): after the packed words
-        const int32_t* goff = hosti + info.grp_off;
-        const int32_t* noff = hosti + info.nxt_off;
-        float* act = host + words;
-        for (int t = 0; t < n_tensors; ++t) {
-            const int role = roles->role[t];
-            bool on = role & 4;
-            for (int q = roles->off[t]; q < roles->off[t + 1] && !on; ++q) {
-                const int a = roles->addr[q];
-                on = ((role & 1) && goff[a + 1] > goff[a]) || ((role & 2) && noff[a + 1] > noff[a]);
+        float* host0 = static_cast<float*>(tb->staging) + (int64_t)half * G * tb->slot_words;
+        float* dev0 = static_cast<float*>(tb->device_batch) + (int64_t)half * G * tb->slot_words;
+        for (int k = 0; k < gs && rc == 0; ++k) {
+            float* host = host0 + (int64_t)k * tb->slot_words;
+            const int32_t* hosti = reinterpret_cast<const int32_t*>(host);
+            const int64_t n = step_off[i + k + 1] - step_off[i + k];
+            if (n <= 0 || n > INT32_MAX) {
+                pp::set_error("pp_train_steps: step %d has %lld traces", i + k, (long long)n);
+                rc = PP_EINVAL;
+                break;
             }
-            act[t] = on ? 1.0f : 0.0f;
+            pp_pack_info& info = pk[k].info;
+            rc = pp_pack_indexed(shards, n_shards, first, ids + step_off[i + k], (int32_t)n, obs_width, n_addr, host,
+                                 tb->slot_words - n_tensors, &info);
+            if (rc != 0) break;
+            pk[k].words = info.src_row + info.n_rows;   // end of the packed buffer (pp_pack_words)
+            // presence map of this minibatch (which tensors have grad != None in the reference): after the packed words
+            const int32_t* goff = hosti + info.grp_off;
+            const int32_t* noff = hosti + info.nxt_off;
+            float* act = host + pk[k].words;
+            for (int t = 0; t < n_tensors; ++t) {
+                const int role = roles->role[t];
+                bool on = role & 4;
+                for (int q = roles->off[t]; q < roles->off[t + 1] && !on; ++q) {
+                    const int a = roles->addr[q];
+                    on = ((role & 1) && goff[a + 1] > goff[a]) || ((role & 2) && noff[a + 1] > noff[a]);
+                }
+                act[t] = on ? 1.0f : 0.0f;
+            }
+            if (addr_iterations)   // inference_network_lstm.py:198
+                for (int a = 0; a < n_addr; ++a) addr_iterations[a] += goff[a + 1] > goff[a];
         }
-        if (addr_iterations)
-            for (int a = 0; a < n_addr; ++a) addr_iterations[a] += goff[a + 1] > goff[a];   // inference_network_lstm.py:198
-        if (hipMemcpyAsync(dev, host, (size_t)(words + n_tensors) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipEventRecord(ev[slot], st) != hipSuccess) {
+        if (rc != 0) break;
+        const size_t bytes = ((size_t)(gs - 1) * tb->slot_words + pk[gs - 1].words + n_tensors) * 4;
+        if (hipMemcpyAsync(dev0, host0, bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipEventRecord(ev[half], st) != hipSuccess) {
             pp::set_error("pp_train_steps: upload failed: %s", hipGetErrorString(hipGetLastError()));
             rc = PP_EHIP;
             break;
         }
-        pp_batch bt{};
-        bt.n_traces = (int32_t)info.n_traces; bt.n_rows = (int32_t)info.n_rows; bt.t_max = (int32_t)info.t_max;
-        bt.obs_width = obs_width;
-        bt.n_active = hosti + info.n_active; bt.row_off = hosti + info.row_off; bt.grp_off = goff; bt.nxt_off = noff;
-        bt.obs = dev + info.obs; bt.value = dev + info.value; bt.prior = dev + info.prior;
-        bt.addr = devi + info.addr; bt.prev_row = devi + info.prev_row; bt.grp_rows = devi + info.grp_rows;
-        bt.trace = devi + info.trace; bt.row_off_dev = devi + info.row_off_dev; bt.nxt_rows = devi + info.nxt_rows;
-        const int flags = PP_LOSS_BACKWARD | ((i == 0 && !grads_clean) ? PP_LOSS_ZERO_GRADS : 0);
-        rc = pp::ic_loss(net, &bt, tb->params, tb->grads, tb->workspace, tb->workspace_bytes, tb->loss_ring + i,
-                         tb->status_ring + i, nullptr, flags, st);
-        if (rc != 0) break;
-        // Adam checks the step's non-finite flag itself (`skip`) and clears the gradients it consumed (the next step's
-        // zero_grad, :486)
-        rc = pp::adam_step(tb->params, tb->grads, tb->exp_avg, tb->exp_avg_sq, net->n_params, tb->chunk_tensor, dev + words,
-                           tb->tensor_step, tb->adam_scratch, n_tensors, lr[i], beta1, beta2, eps, weight_decay, 1.0f,
-                           PP_ADAM_ZERO_GRADS, tb->status_ring + i, st);
+        for (int k = 0; k < gs && rc == 0; ++k, ++i) {
+            const pp_pack_info& info = pk[k].info;
+            const int32_t* hosti = reinterpret_cast<const int32_t*>(host0 + (int64_t)k * tb->slot_words);
+            float* dev = dev0 + (int64_t)k * tb->slot_words;
+            const int32_t* devi = reinterpret_cast<const int32_t*>(dev);
+            pp_batch bt{};
+            bt.n_traces = (int32_t)info.n_traces; bt.n_rows = (int32_t)info.n_rows; bt.t_max = (int32_t)info.t_max;
+            bt.obs_width = obs_width;
+            bt.n_active = hosti + info.n_active; bt.row_off = hosti + info.row_off;
+            bt.grp_off = hosti + info.grp_off; bt.nxt_off = hosti + info.nxt_off;
+            bt.obs = dev + info.obs; bt.value = dev + info.value; bt.prior = dev + info.prior;
+            bt.addr = devi + info.addr; bt.prev_row = devi + info.prev_row; bt.grp_rows = devi + info.grp_rows;
+            bt.trace = devi + info.trace; bt.row_off_dev = devi + info.row_off_dev; bt.nxt_rows = devi + info.nxt_rows;
+            const int flags = PP_LOSS_BACKWARD | ((i == 0 && !grads_clean) ? PP_LOSS_ZERO_GRADS : 0);
+            rc = pp::ic_loss(net, &bt, tb->params, tb->grads, tb->workspace, tb->workspace_bytes, tb->loss_ring + i,
+                             tb->status_ring + i, nullptr, flags, st);
+            if (rc != 0) break;
+            // Adam checks the step's non-finite flag itself (`skip`) and clears the gradients it consumed (the next
+            // step's zero_grad, :486)
+            rc = pp::adam_step(tb->params, tb->grads, tb->exp_avg, tb->exp_avg_sq, net->n_params, tb->chunk_tensor,
+                               dev + pk[k].words, tb->tensor_step, tb->adam_scratch, n_tensors, lr[i], beta1, beta2, eps,
+                               weight_decay, 1.0f, PP_ADAM_ZERO_GRADS, tb->status_ring + i, st);
+        }
     }
-    // the staging slots are the caller's again once their uploads are done
-    for (int s = 0; s < n_ev; ++s) {
-        (void)hipEventSynchronize(ev[s]);
-        (void)hipEventDestroy(ev[s]);
-    }
+    // Returns with the last groups still queued: the caller plans its next run meanwhile. The staging halves stay
+    // guarded by the two (process-wide) events - the next call waits on them before rewriting a half, and
+    // pp_train_sync() waits for both (before the staging memory is freed or reused for something else).
     return rc;
+}
+
+int pp_train_sync(void) {
+    for (int h = 0; h < 2; ++h)
+        if (g_have_event[h] && hipEventSynchronize(g_half_event[h]) != hipSuccess) {
+            pp::set_error("pp_train_sync: %s", hipGetErrorString(hipGetLastError()));
+            return PP_EHIP;
+        }
+    return 0;
 }
 
 }  // extern "C"

@@ -194,10 +194,12 @@ class ICEngine:
             self._roles_arrays = (off, addr, role)
             self._roles = L.pp_tensor_roles(off.ctypes.data, addr.ctypes.data, role.ctypes.data)
             self._roles_key = key
-        n_slots = 8
+        n_slots = 16       # two halves of 8: a group of up to 8 minibatches is uploaded with one copy
         slot_words = int(self.lib.pp_train_slot_words(b_max, r_max, t_max, dataset.obs_width, len(spec.addresses),
                                                       spec.n_tensors))
         if getattr(self, '_slot_words', 0) < slot_words:
+            L.check(self.lib.pp_train_sync(), 'pp_train_sync')      # pending uploads still read the old staging memory
+            torch.cuda.synchronize(self.device)
             self._staging = torch.empty(n_slots * slot_words, dtype=torch.float32).pin_memory()
             self._device_batch = torch.empty(n_slots * slot_words, dtype=torch.float32, device=self.device)
             self._slot_words = slot_words
@@ -229,6 +231,31 @@ class ICEngine:
         for a, k in enumerate(iters[:len(spec.addresses)]):
             spec.addresses[a].total_train_iterations += int(k)
         return self._loss_ring[:n_steps], self._status_ring[:n_steps]
+
+    def read_back(self, losses, statuses):
+        """Start an asynchronous device-to-host copy of a run's (losses, statuses) and return a zero-argument function
+        that waits for THAT copy only (not for work enqueued later) and returns the two numpy arrays."""
+        n = losses.numel()
+        pool = getattr(self, '_readback_pool', None)
+        if pool is None:
+            pool = self._readback_pool = []
+        k = getattr(self, '_readback_next', 0)
+        self._readback_next = k + 1
+        if len(pool) < 4:
+            pool.append(None)
+        slot = k % len(pool)
+        if pool[slot] is None or pool[slot][0].numel() < n:
+            pool[slot] = (torch.empty(max(n, 64), dtype=torch.float32).pin_memory(),
+                          torch.empty(max(n, 64), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        h_loss, h_status, event = pool[slot]
+        h_loss[:n].copy_(losses, non_blocking=True)
+        h_status[:n].copy_(statuses, non_blocking=True)
+        event.record()
+
+        def wait():
+            event.synchronize()
+            return h_loss[:n].numpy().copy(), h_status[:n].numpy().copy()
+        return wait
 
     # ---- HIP graph replay of the step (static shapes) ------------------------------------------------------------
     def capture_train_step(self, batch, lr, weight_decay=0.0):

@@ -429,6 +429,7 @@ class InferenceNetworkLSTM:
         native = packed and world == 1 and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
         chunk_steps = 1 if sync_every == 1 else 64
         carry = None
+        type_key, type_known = None, None
         # While a run trains inside the C call, a worker thread generates the next chunk of prior traces
         # (VectorisedOnlineDataset.start_prefetch). torch's intra-op pool must not fan that work out over all host cores:
         # measured (tools/prefetch_probe.py, 256-core host) a 128-thread torch.normal next to pp_train_steps slows a
@@ -443,8 +444,21 @@ class InferenceNetworkLSTM:
                 dataset.wait_prefetch()    # the prior generator shares the module-global trace state with model code
             if prefetching:
                 torch.set_num_threads(cpu_threads)
+        # The bookkeeping of a run lags one run behind: pp_train_steps returns while its last steps are still queued,
+        # the losses travel to the host asynchronously, and Python plans and launches the NEXT run before it settles the
+        # previous one - the GPU never waits for the interpreter. (Runs of one step - log file, stop_with_bad_loss - are
+        # settled immediately, like the reference's float(loss) per iteration.)
+        inflight = None
         try:
-            while native and not stop:
+            while native:
+                if stop:          # everything is planned: settle the run in flight (a skipped minibatch reopens the loop)
+                    if inflight is not None:
+                        (metas_p, wait), inflight = inflight, None
+                        if book(metas_p, *wait()):
+                            return
+                    if stop:
+                        break
+                    continue
                 steps, metas, planned, epoch_end = [], [], trace, False
                 while len(steps) < chunk_steps and planned < num_traces:
                     if carry is not None:
@@ -455,8 +469,18 @@ class InferenceNetworkLSTM:
                         except StopIteration:
                             epoch_end = True
                             break
-                    types = dataset.types_of(ids)
-                    if not self._layers_pre_generated:
+                    # Planning cost per minibatch is one fancy index: a trace TYPE whose addresses all have layers is
+                    # "known" (table rebuilt when the network grows or the dataset chunk changes); only a minibatch with
+                    # an unknown type takes the address-by-address route of _polymorph.
+                    tkey = (getattr(dataset, 'generated', 0), len(self._engine.spec.addresses))
+                    if tkey != type_key:
+                        aid = self._engine.spec.address_id
+                        type_known = np.asarray([all(dataset.addresses[a][0] in aid for a in seq)
+                                                 for _, seq in dataset.trace_types], bool)
+                        type_key = tkey
+                    ttypes = dataset.trace_type[ids]
+                    if not self._layers_pre_generated and not type_known[ttypes].all():
+                        types = dataset.types_of(ids)
                         new = [a for a in dataset.addresses_of(ids, types) if a[0] not in self._engine.spec.address_id]
                         if new and steps:
                             carry = ids             # train the planned iterations with the current layers first
@@ -464,16 +488,25 @@ class InferenceNetworkLSTM:
                         if new and self._polymorph(_PackedIds(dataset, ids, new)):
                             self._engine.reset_optimizer()                                # :481-483
                     steps.append(ids)
-                    metas.append((len(ids), float(dataset.trace_len[ids].mean()) if log_file else 0.0, len(types)))
+                    if log_file:
+                        metas.append((len(ids), float(dataset.trace_len[ids].mean()), len(dataset.types_of(ids))))
+                    else:
+                        metas.append((len(ids), 0.0, 0))
                     planned += len(ids)
                 if steps:
                     seen = self._total_train_traces + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
                     lrs = [self._learning_rate(t) for t in seen]
                     losses_t, status_t = self._engine.train_run(dataset, steps, lrs, weight_decay=self._weight_decay)
+                    launched = (metas, self._engine.read_back(losses_t, status_t))
                     trace = planned
                     stop = trace >= num_traces
-                    if book(metas, losses_t.cpu().numpy(), status_t.cpu().numpy()):
-                        return
+                    if chunk_steps == 1:
+                        inflight, launched = launched, None
+                    if inflight is not None:
+                        (metas_p, wait), inflight = inflight, None
+                        if book(metas_p, *wait()):
+                            return
+                    inflight = launched
                 if epoch_end:
                     if hasattr(dataset, 'refresh'):                                       # online: fresh prior traces
                         dataset.refresh()
