@@ -19,7 +19,9 @@ struct ColsumJob {
     const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
     const float* wgt; int64_t ldw; int out_stride;   // optional per-row weight (kernels.hip)
 };
-int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st);
+int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st, const float* fin_acc = nullptr,
+                 const int32_t* fin_flag = nullptr, int fin_traces = 0, float* fin_loss = nullptr,
+                 int32_t* fin_status = nullptr);
 int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
                hipStream_t st);
 int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
@@ -292,14 +294,28 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // First kernel: observe embedding; for small embeddings the same launch assembles the LSTM input rows of its traces
     // and clears the loss slots and (backward) dX. Otherwise embedding GEMMs + the stand-alone gather kernel.
     const bool fused_obs = obs_fused_supported(net);
+    const float* heads_in = w.Hs;     // input rows of the proposal layers: LSTM outputs, or observe embeddings (FF)
+    int64_t heads_ld = H;
     if (ff) {
         // every time step's proposal layer reads the observe embedding of its trace (:72,85): Hs rows = E[trace]
-        if (fused_obs)
-            PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, nullptr));
-        else
+        // (single-statement batches: row r IS trace r, the heads read E in place and the embedding kernel clears the
+        // loss slots - one launch less)
+        const bool in_place = fused_obs && T == 1;
+        if (fused_obs) {
+            RowBuild rb{};
+            rb.zero_small = in_place ? reinterpret_cast<float*>(w.loss_acc) : nullptr;
+            rb.n_small = PP_LOSS_SLOTS_FLOATS;
+            PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb));
+        } else {
             PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
-        PP_TRY(embedding_rows(w.E, w.e4, bt->trace, R, net->e_obs, w.Hs, H, reinterpret_cast<float*>(w.loss_acc),
-                              PP_LOSS_SLOTS_FLOATS, st));
+        }
+        if (in_place) {
+            heads_in = w.E;
+            heads_ld = w.e4;
+        } else {
+            PP_TRY(embedding_rows(w.E, w.e4, bt->trace, R, net->e_obs, w.Hs, H, reinterpret_cast<float*>(w.loss_acc),
+                                  PP_LOSS_SLOTS_FLOATS, st));
+        }
     } else if (fused_obs && T <= 2) {   // (long traces: a wave would write all rows of its trace serially - separate gather)
         RowBuild rb{};
         rb.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
@@ -349,7 +365,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             if (n <= 0) continue;
             const pp_addr& ad = net->addrs[a];
             pp_gemm_args g{};
-            g.A = w.Hs; g.lda = H; g.a_idx = bt->grp_rows + g0;
+            g.A = heads_in; g.lda = heads_ld; g.a_idx = bt->grp_rows + g0;
             g.B = P + ad.w1; g.ldb = H;
             g.C = w.A1 + (int64_t)g0 * w.hid4; g.ldc = w.hid4;
             g.M = n; g.N = ad.hid; g.K = H;
@@ -414,7 +430,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st,
                                 grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
         }
-        queue_wgrad(wq, dZ1, w.hid4, w.Hs, H, bt->grp_rows + g0, grads + ad.w1, n, H, ad.hid);
+        queue_wgrad(wq, dZ1, w.hid4, heads_in, heads_ld, bt->grp_rows + g0, grads + ad.w1, n, H, ad.hid);
         {   // dH[rows of this address] = dZ1 W1: queued, every address group in one grouped launch
             pp_gemm_args g{};
             g.A = dZ1; g.lda = w.hid4;
@@ -425,7 +441,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         }
     }
     PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));
-    if (ff) PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
     for (int t = T - 1; t >= 0 && !ff; --t) {
         const int n = bt->n_active[t], r0 = bt->row_off[t];
         const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
@@ -497,12 +512,18 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             ci += in;
             co += out;
         }
-        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+        if (ff)   // (LSTM: the first cell launch of the backward pass finalises the loss)
+            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, w.loss_acc, w.flag, B, loss_out, status_out));
+        else
+            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
         PP_TRY(launch_wgrads(wq, st));
         return 0;
     }
     PP_TRY(obs_grad(dXs, ldxs, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
-    PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+    if (ff)
+        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, w.loss_acc, w.flag, B, loss_out, status_out));
+    else
+        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
     PP_TRY(launch_wgrads(wq, st));
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));

@@ -36,10 +36,23 @@ struct ColsumJob {
 struct ColsumJobs {
     ColsumJob j[COLSUM_MAX_JOBS];
 };
+int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out, hipStream_t st);
+struct LossFinalize {   // loss = sum of the 64 accumulator slots / B, status = non-finite flag (see loss_finalize_kernel)
+    const float* acc; const int32_t* flag; float inv_b; float* loss_out; int32_t* status_out;
+};
+__device__ __forceinline__ void loss_finalize_inline(const LossFinalize& fin) {
+    float tot = 0.0f;
+    for (int k = 0; k < 64; ++k) tot += fin.acc[32 * k];
+    const float l = tot * fin.inv_b;
+    fin.loss_out[0] = l;
+    if (fin.status_out) fin.status_out[0] = (fin.flag[0] != 0 || !isfinite(l)) ? 1 : 0;
+}
 
 // blockIdx.z selects the job: several independent column reductions (bias / embedding-table gradients) per launch
-__global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs) {
+__global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs, const LossFinalize fin) {
     __shared__ float part[4][64];
+    // (FeedForward network: this launch of the backward pass also turns the loss slots into the loss)
+    if (fin.acc && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) loss_finalize_inline(fin);
     const ColsumJob& jb = jobs.j[blockIdx.z];
     const int n_rows = jb.n_rows, n_cols = jb.n_cols;
     const int tid = threadIdx.x;
@@ -77,7 +90,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs) {
     }
 }
 
-int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st) {
+int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st, const float* fin_acc, const int32_t* fin_flag,
+                 int fin_traces, float* fin_loss, int32_t* fin_status) {
+    LossFinalize fin{fin_acc, fin_flag, fin_traces > 0 ? 1.0f / (float)fin_traces : 0.0f, fin_loss, fin_status};
     int i = 0;
     while (i < count) {
         ColsumJobs pack;
@@ -91,9 +106,11 @@ int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st) {
         }
         if (n == 0) continue;
         dim3 grid(cdiv(max_cols, 64), cdiv(max_rows, COLSUM_ROWS), n);
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, pack);
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, pack, fin);
         PP_LAUNCH_CHECK("pp_colsum_f32");
+        fin.acc = nullptr;      // only the first launch finalises
     }
+    if (fin.acc) return loss_finalize(fin_acc, fin_flag, fin_traces, fin_loss, fin_status, st);   // (no job was launched)
     return 0;
 }
 
@@ -101,7 +118,7 @@ int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int 
                hipStream_t st) {
     PP_CHECK_ARG(X && out, "pp_colsum_f32: null pointer");
     ColsumJob j{X, ldx, idx, n_rows, n_cols, out, out2, nullptr, 0, 0};
-    return colsum_multi(&j, 1, st);
+    return colsum_multi(&j, 1, st, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -324,10 +341,6 @@ int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int 
     return 0;
 }
 
-struct LossFinalize {   // loss = sum of the 64 accumulator slots / B, status = non-finite flag (see loss_finalize_kernel)
-    const float* acc; const int32_t* flag; float inv_b; float* loss_out; int32_t* status_out;
-};
-
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ G, const float* __restrict__ c_prev,
                                                             const float* __restrict__ c,
                                                             const float* __restrict__ dh,
@@ -336,13 +349,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ 
                                                             LossFinalize fin) {
     __shared__ float part[4][4][64];
     // the backward pass's first cell launch also turns the loss slots into the loss (one launch less per step)
-    if (fin.acc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        float tot = 0.0f;
-        for (int k = 0; k < 64; ++k) tot += fin.acc[32 * k];
-        const float l = tot * fin.inv_b;
-        fin.loss_out[0] = l;
-        if (fin.status_out) fin.status_out[0] = (fin.flag[0] != 0 || !isfinite(l)) ? 1 : 0;
-    }
+    if (fin.acc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) loss_finalize_inline(fin);
     const int jl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
