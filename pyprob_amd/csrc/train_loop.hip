@@ -7,6 +7,8 @@
 // The uploads share the compute stream on purpose: a dedicated copy stream with event hand-offs (upload i+1 under
 // step i) was measured SLOWER on this runtime - 224 instead of 180 us per LSTM step, 191 instead of 104 us per
 // FeedForward step (tools/train_loop_bench.py) - the cross-stream waits cost more than the ~10 us copy they hide.
+// Packing in a second host thread (pack group g+1 while this thread enqueues group g) was measured too: +-2 us per
+// step in an A/B on one box - packing (50 us) hides behind the GPU's step either way - so the loop stays single-threaded.
 #include "common.hpp"
 
 #include <algorithm>
