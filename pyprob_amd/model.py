@@ -114,20 +114,42 @@ class Model:
             state._current_trace = None
         return ls.columns(obs_names, return_types)
 
+    def _lock_step_safe(self, observe, *args, **kwargs):
+        """Can this program run with all particles in lock step? Decided once per model by a probe of 4 particles: a
+        program that turns a sampled value into a Python scalar (`float(s)`, `.item()`, `if` on a plain tensor of several
+        elements) raises there and is served one particle per forward() instead."""
+        ok = getattr(self, '_lock_step_ok', None)
+        if ok is None:
+            import warnings
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    self._traces_lockstep(4, observe, *args, **kwargs)
+                ok = True
+            except Exception:   # noqa: BLE001 - any failure of the probe means "not lock-step safe"
+                ok = False
+            self._lock_step_ok = ok
+        return ok
+
     def prior_results(self, num_traces=10, prior_inflation=PriorInflation.DISABLED, *args, **kwargs):
         """pyprob/model.py:97-104"""
         return self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=trace_result,
                             prior_inflation=prior_inflation, *args, **kwargs)
 
     def posterior_results(self, num_traces=10, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING, observe=None,
-                          lock_step=False, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
-        """pyprob/model.py:106-117,180-181 for the IS engines. lock_step=True runs all particles together on the
-        device (programs without data-dependent Python control flow)."""
+                          lock_step=None, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
+        """pyprob/model.py:106-117,180-181 for the IS engines. With the inference network, lock_step=True runs all
+        particles together on the device (one forward() per control-flow path; the program's conditions must be tensor
+        expressions), lock_step=False one particle per forward() like the reference; None (default) = lock step when a
+        probe run of a few particles shows the program allows it (same auto-detection as the vectorised prior of
+        learn_inference_network), else per trace."""
         if inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK:
             if self._inference_network is None:
                 raise RuntimeError('Cannot run inference engine IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK because no '
                                    'inference network for this model is available. Use learn_inference_network or '
                                    'load_inference_network first.')
+            if lock_step is None:
+                lock_step = self._lock_step_safe(observe, *args, **kwargs)
             if lock_step:
                 post = self._traces_lockstep(num_traces, observe, seed=seed, offset=offset,
                                              likelihood_importance=likelihood_importance, *args, **kwargs)

@@ -41,7 +41,7 @@ def test_gum_lockstep_posterior_statistics(gum_trained):
 def test_gum_per_trace_posterior_matches_lockstep(gum_trained):
     model = gum_trained
     torch.manual_seed(5)
-    post = model.posterior_results(400, IC, observe=OBS)          # one particle per forward(), like the reference
+    post = model.posterior_results(400, IC, lock_step=False, observe=OBS)          # one particle per forward(), like the reference
     lock = model.posterior_results(50000, IC, observe=OBS, lock_step=True, seed=11)
     assert abs(post.mean - lock.mean) < 0.4
     assert post.effective_sample_size > 0.1 * 400
@@ -63,7 +63,7 @@ def test_gumm_training_and_per_trace_posterior():
     # the reference trains 50k traces WITH prior inflation for obs (8, 9); without inflation use an observation
     # inside the bulk of the prior predictive and keep the reference's ESS bar (tests/test_inference.py:339-366)
     obs = {'obs0': 4, 'obs1': 5}
-    post = model.posterior_results(400, IC, observe=obs)
+    post = model.posterior_results(400, IC, lock_step=False, observe=obs)
     assert post.length > 350 and np.all(np.isfinite(post.log_weights))
     assert post.effective_sample_size > 0.016 * 400
     exact = (1 / 5 + 9 / 2) / (1 / 5 + 2 / 2)          # conjugate posterior mean for obs (4, 5): 3.9167
@@ -78,7 +78,7 @@ def test_categorical_program_trains():
     kinds = sorted(a.dist_name for a in net._engine.spec.addresses)
     assert kinds == ['Categorical', 'Normal']
     assert net._loss_previous < net._loss_init
-    post = model.posterior_results(200, IC, observe={'obs0': 1.2, 'obs1': 0.7})
+    post = model.posterior_results(200, IC, lock_step=False, observe={'obs0': 1.2, 'obs1': 0.7})
     assert np.all(np.isfinite(post.log_weights)) and post.effective_sample_size > 2
 
 
@@ -166,7 +166,7 @@ def test_lockstep_with_stochastic_control_flow():
     assert abs(post.stddev - np.sqrt(1 / prec)) < 0.4
     assert post.effective_sample_size > 0.02 * n
     torch.manual_seed(6)
-    ref = model.posterior_results(300, IC, observe=obs)     # one particle per forward(), like the reference
+    ref = model.posterior_results(300, IC, lock_step=False, observe=obs)     # one particle per forward(), like the reference
     assert abs(ref.mean - post.mean) < 0.6
     # particles are independent: two runs with different seeds give different draws, same statistics
     post2 = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=6)
@@ -215,7 +215,7 @@ def test_poisson_program_trains_and_infers():
     assert abs(post.mean - ref_mean) < 0.1, (post.mean, ref_mean)
     assert post.effective_sample_size > 0.01 * 100000
     torch.manual_seed(3)
-    one = model.posterior_results(300, IC, observe=obs)              # one particle per forward()
+    one = model.posterior_results(300, IC, lock_step=False, observe=obs)              # one particle per forward()
     assert abs(one.mean - ref_mean) < 0.4
 
 
@@ -238,7 +238,7 @@ def test_lockstep_categorical_program_matches_per_trace():
     exact = float((ev * post_mean).sum() / ev.sum())
     assert abs(lock.mean - exact) < 0.05, (lock.mean, exact)
     torch.manual_seed(4)
-    one = model.posterior_results(400, IC, observe=obs)
+    one = model.posterior_results(400, IC, lock_step=False, observe=obs)
     assert abs(one.mean - exact) < 0.3
 
 
@@ -258,7 +258,7 @@ def test_feedforward_network_is_the_default_and_recovers_the_posterior(tmp_path)
     assert abs(lock.mean - 7.25) < 0.75 and abs(lock.stddev - np.sqrt(1 / 1.2)) < 0.75
     assert lock.effective_sample_size > 0.15 * 50000
     torch.manual_seed(4)
-    post = model.posterior_results(300, IC, observe=OBS)
+    post = model.posterior_results(300, IC, lock_step=False, observe=OBS)
     assert abs(post.mean - lock.mean) < 0.5
     f = str(tmp_path / 'ff.network')
     model.save_inference_network(f)
@@ -282,3 +282,19 @@ def test_feedforward_network_with_control_flow_and_categorical():
     cat.learn_inference_network(num_traces=30000, observe_embeddings=EMB, batch_size=128, seed=11)
     p = cat.posterior_results(20000, IC, observe={'obs0': 1.2, 'obs1': 0.7}, lock_step=True, seed=6)
     assert np.isfinite(p.mean) and p.effective_sample_size > 0.05 * 20000
+
+
+def test_posterior_picks_lock_step_automatically(gum_trained):
+    """posterior_results without a lock_step argument (the reference's signature): a program written with tensor
+    conditions runs in lock step, the reference's `while float(s) >= 1:` program falls back to one particle per forward()."""
+    model = gum_trained
+    model._lock_step_ok = None
+    post = model.posterior_results(20000, IC, observe=OBS, seed=2)
+    assert model._lock_step_ok is True and hasattr(post, 'device_stats') and post.length == 20000
+    assert abs(post.mean - 7.25) < 0.75
+    torch.manual_seed(3)
+    ref_style = GaussianWithUnknownMeanMarsaglia()
+    ref_style.learn_inference_network(inference_network=LSTM, num_traces=3000, observe_embeddings=EMB, batch_size=64,
+                                      lstm_dim=64, seed=4)
+    p = ref_style.posterior_results(50, IC, observe=OBS)
+    assert ref_style._lock_step_ok is False and not hasattr(p, 'device_stats') and np.isfinite(p.mean)

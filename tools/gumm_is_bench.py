@@ -24,6 +24,6 @@ for rep in range(3):
     print('lock-step: %d particles, %d control-flow paths, %.1f ms -> %.2f M particles/s; mean %.3f std %.3f ESS %.0f' % (
         n, post.num_paths, (t1 - t0) * 1e3, n / (t1 - t0) / 1e6, post.mean, post.stddev, post.effective_sample_size))
 t0 = time.perf_counter()
-ref = model.posterior_results(300, IC, observe=obs)
+ref = model.posterior_results(300, IC, lock_step=False, observe=obs)
 t1 = time.perf_counter()
 print('one particle per forward(): %.0f particles/s (mean %.3f)' % (300 / (t1 - t0), ref.mean))
