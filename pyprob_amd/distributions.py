@@ -6,6 +6,7 @@ uniform,categorical,empirical}.py): thin objects carrying `name`, parameters, `s
 proposal distributions themselves (Mixture / TruncatedNormal) live in the HIP kernels.
 """
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -117,19 +118,51 @@ class Categorical(Distribution):
 
 
 class Empirical:
-    """Weighted samples (pyprob/distributions/empirical.py: add :315-340, finalize :298-309, expectation :451-466,
-    effective_sample_size :758-766). Memory-backed only; values are floats/tensors, weights are log-weights."""
+    """Weighted samples: the result type of Model.prior / posterior (pyprob/distributions/empirical.py). Memory-backed;
+    values are floats / tensors / arbitrary objects (or ONE device tensor for lock-step runs), weights are log-weights.
+    The reductions (finalize :298-309, expectation :451-466, moments :668-690, effective_sample_size :758-766) are
+    vectorised over the weight array instead of looping over the values; the transformation methods (map, condition,
+    resample, thin, unweighted, slicing, concatenation :568-664, :768-773) return new Empiricals like the reference."""
 
-    def __init__(self, values=None, log_weights=None, name='Empirical'):
+    def __init__(self, values=None, log_weights=None, weights=None, concat_empiricals=None, name='Empirical'):
         self.name = name
-        self._values = [] if values is None else values
-        self._log_weights = [] if log_weights is None else log_weights
-        self._finalized = False
         self._metadata = {}
+        self._finalized = False
+        self.length = 0
+        if concat_empiricals is not None:        # ParallelModel's merge (model.py:395-404)
+            parts = list(concat_empiricals)
+            self._values = [v for e in parts for v in e.get_values()]
+            self._log_weights = np.concatenate([e.log_weights_numpy() for e in parts]) if parts else []
+            self.finalize()
+            return
+        if weights is not None:
+            if log_weights is not None:
+                raise ValueError('Expecting log_weights or weights, not both.')
+            with np.errstate(divide='ignore'):
+                log_weights = np.log(np.asarray(weights, np.float64))
+        self._values = [] if values is None else values
+        if log_weights is None:
+            log_weights = [] if values is None else np.zeros(len(values))
+        self._log_weights = log_weights
+        if values is not None and len(values) > 0:
+            self.finalize()
 
-    def add(self, value, log_weight=None):
+    # ---- construction ------------------------------------------------------------------------------------
+    def add(self, value, log_weight=None, weight=None):
+        if weight is not None:
+            log_weight = math.log(weight) if weight > 0 else float('-inf')
+        if not isinstance(self._values, list) or not isinstance(self._log_weights, list):
+            lw = self._lw if self._finalized else self._log_weights
+            lw = lw.cpu().numpy() if torch.is_tensor(lw) else lw
+            self._values = list(self.get_values()) if self._finalized else list(self._values)
+            self._log_weights = [float(x) for x in np.asarray(lw, np.float64)]
         self._values.append(value)
         self._log_weights.append(0.0 if log_weight is None else float(log_weight))
+        self._finalized = False
+
+    def add_sequence(self, values, log_weights=None, weights=None):
+        for i, v in enumerate(values):
+            self.add(v, None if log_weights is None else log_weights[i], None if weights is None else weights[i])
 
     def finalize(self):
         lw = np.asarray(self._log_weights.cpu() if torch.is_tensor(self._log_weights) else self._log_weights, np.float64)
@@ -138,8 +171,14 @@ class Empirical:
         m = np.max(lw) if self.length else 0.0
         w = np.exp(lw - m)
         self._w = w / w.sum() if self.length else w
+        self._uniform = bool(self.length) and bool(np.all(lw == lw[0]))
+        self._cum = None
         self._finalized = True
         return self
+
+    def _check_finalized(self):
+        if not self._finalized:
+            raise RuntimeError('Empirical not finalized. Call finalize first.')
 
     def __len__(self):
         return self.length
@@ -152,8 +191,40 @@ class Empirical:
         self._metadata.update(kwargs)
 
     @property
+    def metadata(self):
+        return self._metadata
+
+    def _like(self, values, log_weights, **meta):
+        out = Empirical(name=self.name)
+        out._values, out._log_weights = values, log_weights
+        out.finalize()
+        out._metadata = dict(self._metadata)
+        out.add_metadata(**meta)
+        return out
+
+    # ---- access ---------------------------------------------------------------------------------------------
+    @property
     def log_weights(self):
         return self._lw
+
+    @property
+    def weights(self):
+        return torch.from_numpy(self._w)
+
+    @property
+    def weighted(self):
+        return not self._uniform
+
+    def weights_numpy(self):
+        return self._w
+
+    def log_weights_numpy(self):
+        return self._lw
+
+    def get_values(self):
+        self._check_finalized()
+        v = self._values
+        return list(v.detach().cpu().unbind(0)) if torch.is_tensor(v) else v
 
     def values_numpy(self):
         v = self._values
@@ -161,10 +232,102 @@ class Empirical:
             return v.detach().cpu().double().numpy()
         return np.asarray([float(x) for x in v], np.float64)
 
+    def _value(self, i):
+        v = self._values
+        return v[i].detach().cpu() if torch.is_tensor(v) else v[i]
+
+    def __iter__(self):
+        self._check_finalized()
+        for i in range(self.length):
+            yield self._value(i)
+
+    def __getitem__(self, index):
+        self._check_finalized()
+        if isinstance(index, slice):
+            return self._like(self.get_values()[index], self._lw[index], op='slice', index=str(index))
+        if isinstance(index, (int, np.integer)):
+            return self._value(int(index))
+        raise RuntimeError('Cannot use the given value ({}) as index'.format(index))
+
+    def _draw_indices(self, n, lo=None, hi=None):
+        """n indices distributed like the (renormalised) weights of [lo, hi); randomness from torch's global generator
+        (so pyprob.seed / torch.manual_seed make it reproducible)."""
+        lo = 0 if lo is None else lo
+        hi = self.length if hi is None else hi
+        if hi <= lo:
+            raise ValueError('empty index range')
+        u = torch.rand(n, dtype=torch.float64).numpy()
+        if self._uniform:
+            return lo + np.minimum((u * (hi - lo)).astype(np.int64), hi - lo - 1)
+        if self._cum is None:
+            self._cum = np.cumsum(self._w)
+        base = self._cum[lo - 1] if lo > 0 else 0.0
+        total = self._cum[hi - 1] - base
+        return np.minimum(np.searchsorted(self._cum, base + u * total, side='right'), hi - 1)
+
+    def sample(self, min_index=None, max_index=None):
+        """One value drawn according to the weights (empirical.py:392-408; min_index inclusive, max_index exclusive)."""
+        self._check_finalized()
+        return self._value(int(self._draw_indices(1, min_index, max_index)[0]))
+
+    # ---- transformations (each returns a new Empirical) ------------------------------------------------------
+    def map(self, func, min_index=None, max_index=None):
+        self._check_finalized()
+        if self.length == 0:
+            return self
+        sl = slice(min_index or 0, self.length if max_index is None else max_index)
+        return self._like([func(v) for v in self.get_values()[sl]], self._lw[sl], op='map', length=self.length)
+
+    def condition(self, criterion, min_index=None, max_index=None):
+        self._check_finalized()
+        if self.length == 0:
+            return self
+        lo, hi = min_index or 0, self.length if max_index is None else max_index
+        vals = self.get_values()
+        keep = [i for i in range(lo, hi) if criterion(vals[i])]
+        return self._like([vals[i] for i in keep], self._lw[keep], op='condition', length=self.length, length_after=len(keep))
+
+    def filter(self, *args, **kwargs):
+        warnings.warn('Empirical.filter will be deprecated in future releases. Use Empirical.condition instead.')
+        return self.condition(*args, **kwargs)
+
+    def resample(self, num_samples, map_func=None, min_index=None, max_index=None):
+        """num_samples unweighted draws (empirical.py:617-637)."""
+        self._check_finalized()
+        ess = self.effective_sample_size
+        idx = self._draw_indices(int(num_samples), min_index, max_index)
+        vals = self.get_values()
+        out = [vals[i] if map_func is None else map_func(vals[i]) for i in idx]
+        return self._like(out, np.zeros(len(out)), op='resample', length=self.length, num_samples=int(num_samples),
+                          ess_before=ess)
+
+    def thin(self, num_samples, map_func=None, min_index=None, max_index=None):
+        self._check_finalized()
+        lo, hi = min_index or 0, self.length if max_index is None else max_index
+        step = max(1, math.floor((hi - lo) / num_samples))
+        idx = list(range(lo, hi, step))
+        vals = self.get_values()
+        out = [vals[i] if map_func is None else map_func(vals[i]) for i in idx]
+        return self._like(out, self._lw[idx], op='thin', length=self.length, num_samples=int(num_samples), step=int(step))
+
+    def unweighted(self):
+        return self._like(list(self.get_values()), np.zeros(self.length), op='discard_weights')
+
+    # ---- reductions ------------------------------------------------------------------------------------------
     def expectation(self, func):
+        """sum_i w_i func(x_i) (empirical.py:451-466). func is tried on the whole value array (numpy, then a torch tensor
+        for functions like torch.sin) before falling back to one call per value."""
+        self._check_finalized()
         v = self.values_numpy()
-        return float(np.sum(self._w * np.asarray([func(x) for x in v]) if not isinstance(func(v[0]), np.ndarray)
-                            else self._w * func(v)))
+        for conv in ((lambda a: a), torch.from_numpy):
+            try:
+                fv = func(conv(v))
+                fv = np.asarray(fv.detach().cpu() if torch.is_tensor(fv) else fv, np.float64)
+                if fv.shape == v.shape:
+                    return float(np.sum(self._w * fv))
+            except Exception:   # noqa: BLE001 - func works on one value at a time, or on the other array type
+                pass
+        return float(np.sum(self._w * np.asarray([float(func(x)) for x in self.get_values()])))
 
     @property
     def mean(self):
@@ -180,5 +343,56 @@ class Empirical:
         return math.sqrt(self.variance)
 
     @property
+    def skewness(self):
+        v = self.values_numpy()
+        return float(np.sum(self._w * ((v - self.mean) / self.stddev) ** 3))
+
+    @property
+    def kurtosis(self):
+        v = self.values_numpy()
+        return float(np.sum(self._w * ((v - self.mean) / self.stddev) ** 4))
+
+    @property
     def effective_sample_size(self):
         return float(1.0 / np.sum(self._w ** 2))
+
+    @property
+    def mode(self):
+        """Highest-weight value; with uniform weights the most frequent (hashable) value (empirical.py:693-712)."""
+        self._check_finalized()
+        if self._uniform:
+            counts = {}
+            for v in self.get_values():
+                k = float(v) if torch.is_tensor(v) and v.numel() == 1 else v
+                counts[k] = counts.get(k, 0) + 1
+            return max(counts.items(), key=lambda kv: kv[1])[0]
+        return self._value(int(np.argmax(self._lw)))
+
+    @property
+    def median(self):
+        self._check_finalized()
+        if self._uniform:
+            return float(np.median(self.values_numpy()))
+        return self.resample(1000).median           # empirical.py:727
+
+    @property
+    def min(self):
+        return float(np.min(self.values_numpy()))
+
+    @property
+    def max(self):
+        return float(np.max(self.values_numpy()))
+
+    def arg_max(self, map_func):
+        vals = self.get_values()
+        return vals[int(np.argmax([float(map_func(v)) for v in vals]))]
+
+    def arg_min(self, map_func):
+        vals = self.get_values()
+        return vals[int(np.argmin([float(map_func(v)) for v in vals]))]
+
+    def __repr__(self):
+        try:
+            return 'Empirical(items:{}, weighted:{}, mean:{}, stddev:{})'.format(self.length, self.weighted, self.mean, self.stddev)
+        except Exception:   # noqa: BLE001 - values that are not scalars
+            return 'Empirical(items:{})'.format(self.length)

@@ -100,3 +100,43 @@ def test_categorical_program_traces():
         names = [v.distribution.name for v in t.variables_controlled]
         assert names == ['Categorical', 'Normal']
         assert t.variables_controlled[0].distribution.num_categories == 3
+
+
+# ---- Empirical: known answers of the reference's own tests (reference tests/test_distributions.py) ----------------
+def test_empirical_known_answers():
+    from pyprob_amd.distributions import Empirical
+    torch.manual_seed(1)
+    dist = Empirical(torch.tensor([1., 2., 3.]), torch.tensor([1., 2., 3.]))           # :30-71
+    assert abs(dist.mean - 2.5752103328704834) < 1e-6 and abs(dist.stddev - 0.6514633893966675) < 1e-6
+    assert abs(dist.expectation(torch.sin) - 0.3921678960323334) < 1e-6
+    assert abs(dist.map(torch.sin).mean - 0.3921678960323334) < 1e-6
+    assert dist.min == 1 and dist.max == 3 and float(dist.mode) == 3 and dist.weighted
+    un = dist.unweighted()
+    assert abs(un.mean - 2) < 1e-12 and abs(un.stddev - 0.816497) < 1e-5 and not un.weighted
+    drawn = Empirical([dist.sample() for _ in range(20000)])
+    assert abs(drawn.mean - 2.5752) < 0.03 and abs(drawn.stddev - 0.6515) < 0.03
+    assert abs(dist.effective_sample_size - 1.0 / np.sum(dist.weights_numpy() ** 2)) < 1e-12
+    assert list(Empirical([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]).thin(4).values_numpy()) == [1, 4, 7, 10]     # :374-384
+    d = Empirical([0, 1, 2, 3, 4, 5])                                                                       # :401-415
+    assert d[0:3].get_values() == [0, 1, 2] and d[0] == 0 and d[-1] == 5 and list(d) == [0, 1, 2, 3, 4, 5]
+    d = Empirical([2, 2, 2, 2, 3, 3, 3, 4, 4])                                                              # :434-448
+    assert d.sample(min_index=0, max_index=3) == 2 and d.sample(min_index=4, max_index=6) == 3
+    assert d.sample(min_index=7, max_index=8) == 4
+    vals = torch.distributions.Normal(2.0, 5.0).sample((20000,))                                            # :338-353
+    r = Empirical(list(vals)).resample(10000)
+    assert len(r) == 10000 and abs(r.mean - 2) < 0.25 and abs(r.stddev - 5) < 0.25 and r.metadata['op'] == 'resample'
+    z = Empirical(list(torch.randn(20000)))                                                                 # :774-785
+    assert abs(z.skewness) < 0.1 and abs(z.kurtosis - 3.0) < 0.15
+    e = Empirical(list(torch.distributions.Exponential(1.5).sample((20000,))))                              # :801-813
+    assert abs(e.mean - 0.666667) < 0.03 and abs(e.median - 0.462098) < 0.03
+    # weighted resampling reproduces the weighted moments; condition keeps the weights of what it keeps (:885-905)
+    w = Empirical(list(range(10)), log_weights=list(np.linspace(-3, 0, 10)))
+    assert abs(w.resample(40000).mean - w.mean) < 0.05
+    c = w.condition(lambda x: x >= 5)
+    assert len(c) == 5 and abs(c.mean - np.sum(w.weights_numpy()[5:] * np.arange(5, 10)) / w.weights_numpy()[5:].sum()) < 1e-12
+    # concatenation (ParallelModel's merge, model.py:395-404; reference test :674-702)
+    a, b = Empirical([1., 2.], log_weights=[0., 1.]), Empirical([3.], log_weights=[2.])
+    cat = Empirical(concat_empiricals=[a, b])
+    ref = Empirical([1., 2., 3.], log_weights=[0., 1., 2.])
+    assert len(cat) == 3 and abs(cat.mean - ref.mean) < 1e-12 and abs(cat.effective_sample_size - ref.effective_sample_size) < 1e-12
+    assert Empirical([1., 2.], weights=[1., 3.]).mean == 1.75
