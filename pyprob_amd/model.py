@@ -163,6 +163,26 @@ class Model:
             post.rename('Posterior, IS, traces: {:,}, ESS: {:,.2f}'.format(post.length, post.effective_sample_size))
         return post
 
+    def posterior_results_distributed(self, num_traces, observe=None, seed=0, likelihood_importance=1., *args, **kwargs):
+        """posterior_results(IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK) with the particles sharded over the ranks of the
+        initialised torch.distributed group (one process per GPU): every rank runs its contiguous shard in lock step with
+        its own Philox counter range, one all-gather returns all particles to every rank. The reference's ParallelModel
+        (pyprob/model.py:339-406) shards the same way over processes and merges the per-process files."""
+        import torch.distributed as dist
+        from .parallel import gather_particles, shard_range
+        if self._inference_network is None:
+            raise RuntimeError('Cannot run inference engine IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK because no '
+                               'inference network for this model is available. Use learn_inference_network or '
+                               'load_inference_network first.')
+        offset, count = shard_range(num_traces, dist.get_rank(), dist.get_world_size())
+        local = self._traces_lockstep(count, observe, seed=seed, offset=offset,
+                                      likelihood_importance=likelihood_importance, *args, **kwargs)
+        values, lw = gather_particles(local._values, local._log_weights, num_traces)
+        post = Empirical(values=values, log_weights=lw)
+        post.device_stats = self._inference_network._is.stats(lw.contiguous(), values.contiguous())
+        post.rename('Posterior, IC, traces: {:,}, ESS: {:,.2f}'.format(post.length, post.effective_sample_size))
+        return post
+
     def learn_inference_network(self, num_traces, inference_network=InferenceNetwork.FEEDFORWARD, observe_embeddings={},
                                 batch_size=64, lstm_dim=512, lstm_depth=1,
                                 proposal_mixture_components=10, learning_rate_init=0.001, learning_rate_end=1e-6,

@@ -38,6 +38,27 @@ def shard_range(n, rank, world):
     return offset, count
 
 
+def gather_particles(values, log_weights, num_traces):
+    """Every rank contributes its particle shard (shard_range order) and receives all `num_traces` (values, log-weights):
+    what ParallelModel does with per-process files and a concatenated Empirical (pyprob/model.py:395-404), as ONE
+    all-gather of [value | log-weight] pairs (shards differ by at most one particle: padded to the longest)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = [shard_range(num_traces, r, world)[1] for r in range(world)]
+    if values.numel() != counts[rank] or log_weights.numel() != counts[rank]:
+        raise ValueError('rank %d holds %d particles, its shard has %d' % (rank, values.numel(), counts[rank]))
+    width = max(counts)
+    mine = torch.zeros(2, width, dtype=torch.float32, device=values.device)
+    mine[0, :counts[rank]] = values.reshape(-1)
+    mine[1, :counts[rank]] = log_weights.reshape(-1)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    v = torch.cat([p[0, :c] for p, c in zip(parts, counts)])
+    lw = torch.cat([p[1, :c] for p, c in zip(parts, counts)])
+    return v, lw
+
+
 class DistributedTraceBatchSampler:
     """Mirror of pyprob/nn/dataset.py:328-400 over a list of sorted trace indices."""
 

@@ -113,3 +113,33 @@ def test_particle_shards_cover_the_range():
             assert shards[0][0] == 0 and sum(c for _, c in shards) == n
             for (o0, c0), (o1, _) in zip(shards, shards[1:]):
                 assert o0 + c0 == o1
+
+
+def _gather_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyprob_amd.parallel import gather_particles, shard_range
+    n = 1003
+    off, cnt = shard_range(n, rank, world)
+    v, lw = gather_particles(torch.arange(off, off + cnt, dtype=torch.float32), -torch.arange(off, off + cnt, dtype=torch.float32), n)
+    ok = torch.equal(v, torch.arange(n, dtype=torch.float32)) and torch.equal(lw, -torch.arange(n, dtype=torch.float32))
+    bad = False
+    try:
+        gather_particles(torch.zeros(cnt + 1), torch.zeros(cnt + 1), n)
+    except ValueError:
+        bad = True
+    torch.save(dict(ok=ok, bad=bad), out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_particle_gather_concatenates_the_rank_shards(tmp_path):
+    """IS shards: every rank ends up with all particles in shard order (ParallelModel's merge)."""
+    world, port = 2, 31500 + os.getpid() % 2000
+    out = str(tmp_path / 'g.pt')
+    mp.spawn(_gather_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        d = torch.load(out + '.%d' % r)
+        assert d['ok'] and d['bad']

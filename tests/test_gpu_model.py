@@ -298,3 +298,25 @@ def test_posterior_picks_lock_step_automatically(gum_trained):
                                       lstm_dim=64, seed=4)
     p = ref_style.posterior_results(50, IC, observe=OBS)
     assert ref_style._lock_step_ok is False and not hasattr(p, 'device_stats') and np.isfinite(p.mean)
+
+
+def test_distributed_posterior_on_a_single_rank_group(gum_trained):
+    """posterior_results_distributed over an RCCL group of one rank (the N=1 case of the sharded IS path): same
+    particles as the local lock-step run with the same seed."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 2000))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        model = gum_trained
+        post = model.posterior_results_distributed(30000, observe=OBS, seed=4)
+        local = model.posterior_results(30000, IC, observe=OBS, lock_step=True, seed=4)
+        assert post.length == 30000 and abs(post.mean - local.mean) < 1e-6
+        assert abs(post.effective_sample_size - local.effective_sample_size) < 1e-6 * local.effective_sample_size
+        assert abs(post.device_stats['mean'] - post.mean) < 1e-3
+    finally:
+        if created:
+            dist.destroy_process_group()
