@@ -131,10 +131,37 @@ class Model:
             self._lock_step_ok = ok
         return ok
 
-    def prior_results(self, num_traces=10, prior_inflation=PriorInflation.DISABLED, *args, **kwargs):
-        """pyprob/model.py:97-104"""
-        return self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=trace_result,
-                            prior_inflation=prior_inflation, *args, **kwargs)
+    def prior(self, num_traces=10, prior_inflation=PriorInflation.DISABLED, map_func=None, likelihood_importance=1.,
+              *args, **kwargs):
+        """pyprob/model.py:97-101: an Empirical of prior traces (or of map_func(trace))."""
+        prior = self._traces(num_traces=num_traces, trace_mode=TraceMode.PRIOR, map_func=map_func,
+                             prior_inflation=prior_inflation, likelihood_importance=likelihood_importance, *args, **kwargs)
+        prior.rename('Prior, traces: {:,}'.format(prior.length))
+        prior.add_metadata(op='prior', num_traces=num_traces, prior_inflation=str(prior_inflation),
+                           likelihood_importance=likelihood_importance)
+        return prior
+
+    def prior_results(self, num_traces=10, prior_inflation=PriorInflation.DISABLED, map_func=trace_result, *args, **kwargs):
+        """pyprob/model.py:103-104"""
+        return self.prior(num_traces=num_traces, prior_inflation=prior_inflation, map_func=map_func, *args, **kwargs)
+
+    def posterior(self, num_traces=10, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING, map_func=None, observe=None,
+                  likelihood_importance=1., *args, **kwargs):
+        """pyprob/model.py:106-117 for the IS engines: an Empirical of posterior TRACES (or of map_func(trace)), one
+        particle per forward() like the reference. `posterior_results` is the fast path when only the results are
+        needed (all particles in lock step on the device)."""
+        if inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK and self._inference_network is None:
+            raise RuntimeError('Cannot run inference engine IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK because no '
+                               'inference network for this model is available. Use learn_inference_network or '
+                               'load_inference_network first.')
+        net = self._inference_network if inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK else None
+        post = self._traces(num_traces, TraceMode.POSTERIOR, inference_engine, net, map_func, observe, likelihood_importance,
+                            *args, **kwargs)
+        kind = 'IC' if net is not None else 'IS'
+        post.rename('Posterior, {}, traces: {:,}, ESS: {:,.2f}'.format(kind, post.length, post.effective_sample_size))
+        post.add_metadata(op='posterior', num_traces=num_traces, inference_engine=str(inference_engine),
+                          effective_sample_size=post.effective_sample_size, likelihood_importance=likelihood_importance)
+        return post
 
     def posterior_results(self, num_traces=10, inference_engine=InferenceEngine.IMPORTANCE_SAMPLING, observe=None,
                           lock_step=None, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):

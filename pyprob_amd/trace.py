@@ -67,6 +67,15 @@ class Trace:
             if v.log_importance_weight is not None:
                 self.log_importance_weight += v.log_importance_weight
 
+    def __getitem__(self, variable_name):
+        """Value of a named variable (pyprob/trace.py:192-196)."""
+        if variable_name in self.named_variables:
+            return self.named_variables[variable_name].value
+        raise RuntimeError('Trace does not include variable with name: {}'.format(variable_name))
+
+    def __contains__(self, variable_name):
+        return variable_name in self.named_variables
+
     def __repr__(self):
         return 'Trace(variables:{}, controlled:{}, log_importance_weight:{})'.format(
             self.length, self.length_controlled, self.log_importance_weight)

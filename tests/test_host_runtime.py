@@ -140,3 +140,22 @@ def test_empirical_known_answers():
     ref = Empirical([1., 2., 3.], log_weights=[0., 1., 2.])
     assert len(cat) == 3 and abs(cat.mean - ref.mean) < 1e-12 and abs(cat.effective_sample_size - ref.effective_sample_size) < 1e-12
     assert Empirical([1., 2.], weights=[1., 3.]).mean == 1.75
+
+
+def test_prior_and_posterior_return_empiricals_of_traces():
+    """Model.prior / posterior (pyprob/model.py:97-117): Empiricals of Trace objects; trace['name'] reads a named
+    variable (trace.py:192-196); map / condition on them like reference tests/test_distributions.py:885-905."""
+    torch.manual_seed(8)
+    model = GaussianWithUnknownMean()
+    prior = model.prior(300)
+    assert len(prior) == 300 and not prior.weighted and 'obs0' in prior[0] and prior.metadata['op'] == 'prior'
+    assert prior[0]['obs0'] is None        # TraceMode.PRIOR leaves an unobserved `observe` without a value (state.py:139)
+    mu = prior.map(lambda t: float(t.result))
+    assert abs(mu.mean - 1.0) < 0.6
+    assert len(prior.condition(lambda t: float(t.result) > 1.0)) < 300
+    post = model.posterior(2000, InferenceEngine.IMPORTANCE_SAMPLING, observe={'obs0': 8, 'obs1': 9})
+    assert post.weighted and abs(post.map(lambda t: float(t.result)).mean - 7.25) < 0.8
+    with pytest.raises(RuntimeError):
+        prior[0]['nope']
+    res = model.prior_results(50)
+    assert len(res) == 50 and np.isfinite(res.mean)
