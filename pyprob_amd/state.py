@@ -349,11 +349,24 @@ class PriorLockStep(PathExecutor):
             type_of.append(np.full(m, len(seqs), np.int64))
             seqs.append(list(row_ids))
             ids.append(np.tile(np.asarray(row_ids, np.int64), m))
-            vals.append(torch.stack([self.log[j][a][0][rows] for j, a in seq], 1).reshape(-1).cpu().numpy())
-            pri.append(torch.stack([torch.stack([self.log[j][a][1][rows], self.log[j][a][2][rows]], 1) for j, a in seq],
-                                   1).reshape(-1, 2).cpu().numpy())
+            def column(rec):          # the path's elements of a full-size record, as a numpy vector (or a scalar)
+                if rec.dim() and rec.stride(0) == 0:
+                    return float(rec[0])
+                return rec[rows].cpu().numpy()
+            v = np.empty((m, len(seq)), np.float32)
+            p = np.empty((m, len(seq), 2), np.float32)
+            for k, (j, a) in enumerate(seq):
+                e = self.log[j][a]
+                v[:, k] = column(e[0])
+                p[:, k, 0] = column(e[1])
+                p[:, k, 1] = column(e[2])
+            vals.append(v.reshape(-1))
+            pri.append(p.reshape(-1, 2))
             by_name = dict((name, i) for i, name in obs_seq)
-            obs.append(torch.stack([self.obs_log[by_name[name]][name][rows] for name in obs_names], 1).cpu().numpy())
+            o = np.empty((m, len(obs_names)), np.float32)
+            for k, name in enumerate(obs_names):
+                o[:, k] = column(self.obs_log[by_name[name]][name])
+            obs.append(o)
         out = (np.concatenate(lens), table, np.concatenate(ids), np.concatenate(vals).astype(np.float32),
                np.concatenate(pri).astype(np.float32), np.concatenate(obs).astype(np.float32))
         return out + ((np.concatenate(type_of), seqs),) if return_types else out
