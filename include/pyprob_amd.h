@@ -47,6 +47,11 @@ extern "C" {
 #define PP_HEAD_NORMAL_MIXTURE       0  /* ProposalNormalNormalMixture: prior Normal(mean, stddev) */
 #define PP_HEAD_TRUNCNORMAL_MIXTURE  1  /* ProposalUniformTruncatedNormalMixture: prior Uniform(low, high) */
 #define PP_HEAD_CATEGORICAL          2  /* ProposalCategoricalCategorical: prior Categorical(C) */
+#define PP_HEAD_BERNOULLI            4  /* ProposalBernoulliBernoulli (proposal_bernoulli_bernoulli.py:16-20), n_out = 1. In the
+                                           training loss the reference broadcasts probs [n, 1] against values [n] to an
+                                           [n, n] log_prob matrix per sub-batch step and sums it (inference_network_lstm.py:
+                                           195-202); the row's `prior` pair carries (n, sum of the n values) of its sub-batch
+                                           step so that the row term sum_j log Bernoulli(v_j; p_row) is computed in place */
 #define PP_HEAD_POISSON_TN_MIXTURE   3  /* ProposalPoissonTruncatedNormalMixture: prior Poisson; (p0, p1) = (low, high) = (0, 40) */
 
 int         pp_abi_version(void);

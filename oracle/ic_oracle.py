@@ -363,6 +363,33 @@ def head_categorical(y, v):
     return lp, dy, (p,)
 
 
+def head_bernoulli(y, v):
+    """ProposalBernoulliBernoulli.forward (pyprob/nn/proposal_bernoulli_bernoulli.py:16-20): probs = sigmoid(y) + 1e-8
+    with shape [n, 1]. `_loss` then calls Bernoulli.log_prob on the stacked values of shape [n]
+    (inference_network_lstm.py:195-202): torch broadcasts [n, 1] against [n] to an [n, n] MATRIX - every trace's proposal
+    scored against every value of the sub-batch step - and `-torch.sum(log_prob)` adds all n^2 entries. Restated as the
+    reference computes it: returns the row sums lp[i] = sum_j log Bernoulli(v_j; p_i), d lp[i] / d y[i], and the matrix.
+    torch's Bernoulli clamps probs to [eps, 1 - eps] when turning them into logits (torch/distributions/utils.py)."""
+    y = np.asarray(y)
+    v = np.asarray(v, y.dtype).reshape(-1)
+    sg = sigmoid(y[:, 0])
+    p = sg + EPSILON
+    inside = (p >= FP32_EPS) & (p <= 1 - FP32_EPS)
+    pc = np.clip(p, FP32_EPS, 1 - FP32_EPS)
+    mat = v[None, :] * np.log(pc)[:, None] + (1 - v)[None, :] * np.log1p(-pc)[:, None]
+    n, n1 = float(len(v)), float(v.sum())
+    dp = np.where(inside, n1 / pc - (n - n1) / (1 - pc), 0.0)
+    dy = (dp * sg * (1 - sg))[:, None]
+    return mat.sum(1), dy, (p[:, None], mat)
+
+
+def bernoulli_log_prob(v, probs):
+    """torch.distributions.Bernoulli(probs).log_prob(v) (probs clamped to [eps, 1 - eps])."""
+    pc = np.clip(np.asarray(probs, np.float64), FP32_EPS, 1 - FP32_EPS)
+    v = np.asarray(v, np.float64)
+    return v * np.log(pc) + (1 - v) * np.log1p(-pc)
+
+
 def head_forward(net, address, dist_name, h, prior, v):
     """`_layers_proposal[address].forward(h, variables)` + `.log_prob(values)` (inference_network_lstm.py:197-202).
     Returns lp, caches for backward, proposal params."""
@@ -376,6 +403,8 @@ def head_forward(net, address, dist_name, h, prior, v):
         lp, dy, params = head_categorical(y, v)
     elif dist_name == 'Poisson':
         lp, dy, params = head_poisson_truncated_normal_mixture(y, v, net.K)
+    elif dist_name == 'Bernoulli':
+        lp, dy, params = head_bernoulli(y, v)
     else:
         raise RuntimeError('Distribution currently unsupported: ' + dist_name)
     return lp, (dy, acts, Ws), params
@@ -614,6 +643,8 @@ def prior_log_prob(dist_name, prior, v):
         return categorical_log_prob(v, prior)
     if dist_name == 'Poisson':
         return poisson_log_prob(v, prior[..., 0])
+    if dist_name == 'Bernoulli':
+        return bernoulli_log_prob(v, prior[..., 0])
     raise RuntimeError(dist_name)
 
 

@@ -302,6 +302,30 @@ __global__ __launch_bounds__(256) void is_categorical_kernel(const float* __rest
     logq_out[i] = logf(fminf(fmaxf(pv, kFp32Eps), 1.0f - kFp32Eps));
 }
 
+// Bernoulli proposal (proposal_bernoulli_bernoulli.py:16-20): probs = sigmoid(y) + 1e-8; value ~ Bernoulli(probs),
+// log q with torch's clamp of probs to [eps, 1 - eps].
+__global__ __launch_bounds__(256) void is_bernoulli_kernel(const float* __restrict__ Y, int64_t ldy, int y_shared, int n,
+                                                           const float* __restrict__ value_in,
+                                                           float* __restrict__ value_out, float* __restrict__ logq_out,
+                                                           uint64_t seed, uint64_t offset) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float y = Y[y_shared ? 0 : (int64_t)i * ldy];
+    const float p = sigmoidf_(y) + 1e-8f;
+    float v;
+    if (value_in) {
+        v = value_in[i];
+    } else {
+        Philox rng(seed, offset + (uint64_t)i, 0x1C);
+        uint32_t r[4];
+        rng.next(r);
+        v = u01(r[0]) < p ? 1.0f : 0.0f;
+    }
+    const float pc = fminf(fmaxf(p, kFp32Eps), 1.0f - kFp32Eps);
+    value_out[i] = v;
+    logq_out[i] = p == p ? v * logf(pc) + (1.0f - v) * log1pf(-pc) : p;
+}
+
 struct IsWorkspace {
     float *X, *G, *A1, *Y, *rec, *c0;
     float *obs_h, *cat, *f1;
@@ -394,7 +418,8 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     PP_CHECK_ARG(ff || prev_addr_id < 0 || state_rows == 1 || state_rows == n, "pp_is_step: state_rows must be 1 or n");
     if (n <= 0) return 0;
     const pp_addr& ad = net->addrs[addr_id];
-    PP_CHECK_ARG(ad.kind == PP_HEAD_CATEGORICAL || prior, "pp_is_step: prior parameters required");
+    PP_CHECK_ARG(ad.kind == PP_HEAD_CATEGORICAL || ad.kind == PP_HEAD_BERNOULLI || prior,
+                 "pp_is_step: prior parameters required");
     // First statement of a trace: identical LSTM input and zero state for every particle -> ONE row is evaluated and
     // only row 0 of (h, c) is written (the caller's state_rows becomes 1). Second statement: the inputs differ (previous
     // value) but the recurrent term h0 W_hh^T is still one shared row -> it enters the batched GEMM as a bias.
@@ -433,6 +458,9 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     if (ad.kind == PP_HEAD_CATEGORICAL) {
         hipLaunchKernelGGL(is_categorical_kernel, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, n, ad.n_out, value_in,
                            value_out, logq_out, seed, offset);
+    } else if (ad.kind == PP_HEAD_BERNOULLI) {
+        hipLaunchKernelGGL(is_bernoulli_kernel, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, n, value_in, value_out,
+                           logq_out, seed, offset);
     } else {
         PP_CHECK_ARG(ad.n_out % 3 == 0 && ad.n_out / 3 <= MAXK, "pp_is_step: at most %d mixture components", MAXK);
         const bool same_proposal = shared && prior_stride == 0;

@@ -615,6 +615,40 @@ __global__ __launch_bounds__(64) void head_categorical_kernel(const float* __res
     if (bad && nonfinite) atomicOr(nonfinite, 1);
 }
 
+// Bernoulli head as the reference's `_loss` evaluates it (PP_HEAD_BERNOULLI, pyprob_amd.h): the row's proposal
+// p = sigmoid(y) + 1e-8 is scored against all n values of its sub-batch step, of which n1 are 1 (prior = (n, n1)):
+// lp_row = n1 log p + (n - n1) log(1 - p), probs clamped to [eps, 1 - eps] like torch's probs_to_logits.
+__global__ __launch_bounds__(64) void head_bernoulli_kernel(const float* __restrict__ Y, int64_t ldy,
+                                                             const int32_t* __restrict__ rows,
+                                                             const float* __restrict__ prior, int n, float grad_scale,
+                                                             float* __restrict__ lp_out, float* __restrict__ DY,
+                                                             float* __restrict__ loss_acc,
+                                                             int32_t* __restrict__ nonfinite) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    float contrib = 0.0f;
+    bool bad = false;
+    if (i < n) {
+        const int r = rows ? rows[i] : i;
+        const float y = Y[(int64_t)i * ldy];
+        const float cnt = prior[2 * (int64_t)r], ones = prior[2 * (int64_t)r + 1];
+        const float sg = sigmoidf_(y);
+        const float p = sg + 1e-8f;
+        const bool in = p >= kFp32Eps && p <= 1.0f - kFp32Eps;
+        const float pc = fminf(fmaxf(p, kFp32Eps), 1.0f - kFp32Eps);
+        const float lp = p == p ? ones * logf(pc) + (cnt - ones) * log1pf(-pc) : p;
+        if (lp_out) lp_out[r] = lp;
+        bad = !isfinite(lp);
+        contrib = -lp;
+        if (DY) {
+            const float dp = in ? ones / pc - (cnt - ones) / (1.0f - pc) : 0.0f;
+            DY[(int64_t)i * ldy] = bad ? 0.0f : grad_scale * dp * sg * (1.0f - sg);
+        }
+    }
+    const float ws = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0 && loss_acc && ws != 0.0f) atomicAdd(loss_acc, ws);
+    if (bad && nonfinite) atomicOr(nonfinite, 1);
+}
+
 int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
                  int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
                  hipStream_t st) {
@@ -624,6 +658,10 @@ int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, con
     if (kind == PP_HEAD_CATEGORICAL) {
         hipLaunchKernelGGL(head_categorical_kernel, grid, block, 0, st, y, ldy, rows, value, n, n_out, grad_scale,
                            lp_out, dy, loss_acc, nonfinite);
+    } else if (kind == PP_HEAD_BERNOULLI) {
+        PP_CHECK_ARG(prior && n_out == 1, "pp_head_logprob: the Bernoulli head needs (n, n1) per row and n_out = 1");
+        hipLaunchKernelGGL(head_bernoulli_kernel, grid, block, 0, st, y, ldy, rows, prior, n, grad_scale, lp_out, dy,
+                           loss_acc, nonfinite);
     } else {
         PP_CHECK_ARG(prior, "pp_head_logprob: mixture heads need prior parameters");
         PP_CHECK_ARG(n_out % 3 == 0 && n_out / 3 <= MAXK && n_out > 0,

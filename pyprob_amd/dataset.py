@@ -360,6 +360,10 @@ class PackedTraceDataset:
         network's. Cached until the network grows."""
         from . import lib as L
         key = (id(spec), len(spec.addresses))
+        if any(getattr(info, 'dist_name', None) == 'Bernoulli' for info in spec.addresses):
+            # the Bernoulli head's rows carry statistics of their sub-batch step (packed.bernoulli_group_stats), which
+            # the column packers do not compute: such programs train through the Trace route (Batch -> pack_traces)
+            raise NotImplementedError('packed datasets do not support programs with Bernoulli proposals')
         if getattr(self, '_native_key', None) != key:      # (re)build the per-shard address maps for this network
             to_engine = np.asarray([spec.address_id.get(a[0], -1) for a in self.addresses], np.int32)
             self._native_remap = [np.ascontiguousarray(to_engine[r]) for r in self._addr_remap]

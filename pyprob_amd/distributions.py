@@ -117,6 +117,18 @@ class Categorical(Distribution):
         return self._probs
 
 
+class Bernoulli(Distribution):
+    """pyprob/distributions/bernoulli.py"""
+
+    def __init__(self, probs):
+        probs = _t(probs).float()
+        super().__init__('Bernoulli', 'Bernoulli', torch.distributions.Bernoulli(probs=probs, validate_args=False))
+
+    @property
+    def probs(self):
+        return self._torch_dist.probs
+
+
 class Empirical:
     """Weighted samples: the result type of Model.prior / posterior (pyprob/distributions/empirical.py). Memory-backed;
     values are floats / tensors / arbitrary objects (or ONE device tensor for lock-step runs), weights are log-weights.

@@ -10,6 +10,7 @@ PP_ABI_VERSION = 3
 PP_MAX_OBS = 8
 PP_ADDR_TABLE_COLS = 8
 PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL, PP_HEAD_POISSON_TN_MIXTURE = 0, 1, 2, 3
+PP_HEAD_BERNOULLI = 4
 PP_LOSS_BACKWARD, PP_LOSS_ZERO_GRADS, PP_LOSS_KEEP_LP = 1, 2, 4
 PP_ADAM_ZERO_GRADS = 1
 PP_ADAM_SCRATCH = 1056          # int32 per tensor (include/pyprob_amd.h)

@@ -270,8 +270,34 @@ def pack_traces(traces, spec, obs_names):
             row.extend(np.asarray(val, np.float32).reshape(-1).tolist() if not hasattr(val, 'detach')
                        else val.detach().float().reshape(-1).tolist())
         obs.append(row)
-    return PackedBatch.from_ragged(trace_len, addr_ids, values, np.asarray(prior, np.float32),
-                                   np.asarray(obs, np.float32), len(spec.addresses))
+    prior = np.asarray(prior, np.float32)
+    bernoulli = [a for a, info in enumerate(spec.addresses) if info.dist_name == 'Bernoulli']
+    if bernoulli:
+        prior = bernoulli_group_stats(trace_len, addr_ids, values, prior, bernoulli)
+    return PackedBatch.from_ragged(trace_len, addr_ids, values, prior, np.asarray(obs, np.float32), len(spec.addresses))
+
+
+def bernoulli_group_stats(trace_len, addr_ids, values, prior, bernoulli_ids):
+    """The `prior` pair of a row whose address has a Bernoulli proposal: (n, sum of values) over the rows of the same
+    SUB-BATCH STEP (traces with the same address sequence, Batch.__init__ pyprob/nn/dataset.py:21-37, same time step) -
+    the reference scores every proposal of such a step against every value of it (PP_HEAD_BERNOULLI, pyprob_amd.h)."""
+    trace_len = np.asarray(trace_len, np.int64)
+    addr_ids = np.asarray(addr_ids, np.int64)
+    values = np.asarray(values, np.float64)
+    prior = np.array(prior, np.float32, copy=True).reshape(len(addr_ids), -1)[:, :2]
+    off = np.concatenate([[0], np.cumsum(trace_len)])
+    is_b = np.isin(addr_ids, np.asarray(bernoulli_ids, np.int64))
+    groups = {}
+    for b in range(len(trace_len)):
+        key = tuple(addr_ids[off[b]:off[b + 1]].tolist())
+        for t in range(int(trace_len[b])):
+            r = off[b] + t
+            if is_b[r]:
+                groups.setdefault((key, t), []).append(r)
+    for rows in groups.values():
+        prior[rows, 0] = len(rows)
+        prior[rows, 1] = values[rows].sum()
+    return prior
 
 
 POISSON_LOW_HIGH = (0.0, 40.0)
@@ -289,4 +315,6 @@ def distribution_params(dist):
         return (0.0, 0.0)
     if name == 'Poisson':      # the Poisson head proposes on a FIXED interval (proposal_poisson_truncated_normal_mixture.py:10)
         return POISSON_LOW_HIGH
+    if name == 'Bernoulli':    # placeholder: pack_traces fills in the sub-batch step statistics (bernoulli_group_stats)
+        return (1.0, 0.0)
     raise RuntimeError('Distribution currently unsupported: {}'.format(name))

@@ -18,7 +18,8 @@ from . import lib as L
 CHUNK = 1024
 
 DIST_KIND = {'Normal': L.PP_HEAD_NORMAL_MIXTURE, 'Uniform': L.PP_HEAD_TRUNCNORMAL_MIXTURE,
-             'Categorical': L.PP_HEAD_CATEGORICAL, 'Poisson': L.PP_HEAD_POISSON_TN_MIXTURE}
+             'Categorical': L.PP_HEAD_CATEGORICAL, 'Poisson': L.PP_HEAD_POISSON_TN_MIXTURE,
+             'Bernoulli': L.PP_HEAD_BERNOULLI}
 
 
 class AddressInfo:
@@ -102,7 +103,8 @@ class NetSpec:
         return int(sum(int(np.prod(s)) for _, s in self.tensors.values()))
 
     def head_dims(self, info):
-        n_out = info.num_categories if info.kind == L.PP_HEAD_CATEGORICAL else 3 * self.K
+        n_out = (info.num_categories if info.kind == L.PP_HEAD_CATEGORICAL else
+                 1 if info.kind == L.PP_HEAD_BERNOULLI else 3 * self.K)     # proposal_bernoulli_bernoulli.py:13
         hid = int((self.head_in + n_out) / 2)     # embedding_feedforward.py:26
         smp_in = info.num_categories if info.kind == L.PP_HEAD_CATEGORICAL else 1
         return n_out, hid, smp_in

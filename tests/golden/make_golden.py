@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import pyprob  # noqa: E402
 from pyprob import Model, InferenceEngine, InferenceNetwork  # noqa: E402
-from pyprob.distributions import Normal, Uniform, Categorical, Mixture, Poisson  # noqa: E402
+from pyprob.distributions import Normal, Uniform, Categorical, Mixture, Poisson, Bernoulli  # noqa: E402
 from pyprob.nn import Batch  # noqa: E402
 
 torch.set_num_threads(4)
@@ -111,6 +111,21 @@ class PoissonThenNormal(Model):
         return mu
 
 
+class BernoulliThenNormal(Model):
+    """b ~ Bernoulli(0.3); mu ~ Normal(2 b - 1, 1); two Normal observations (ProposalBernoulliBernoulli)."""
+
+    def __init__(self):
+        super().__init__('Bernoulli then Normal')
+
+    def forward(self):
+        b = pyprob.sample(Bernoulli(0.3))
+        mu = pyprob.sample(Normal(b * 2.0 - 1.0, 1.0))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
 def prior_params(dist):
     if isinstance(dist, Normal):
         return 'Normal', [float(dist.mean), float(dist.stddev)]
@@ -120,6 +135,8 @@ def prior_params(dist):
         return 'Categorical', [float(p) for p in dist.probs.view(-1)]
     if isinstance(dist, Poisson):
         return 'Poisson', [float(dist.rate)]
+    if isinstance(dist, Bernoulli):
+        return 'Bernoulli', [float(dist.probs)]
     raise RuntimeError(dist.name)
 
 
@@ -188,14 +205,24 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
         rec['log_prob'].append(lp.detach().numpy().copy().reshape(-1))
         return lp
 
+    orig_ber_lp = Bernoulli.log_prob
+
+    def ber_lp(self, value, sum=False):
+        lp = orig_ber_lp(self, value, sum=sum)
+        if self.probs.dim() == 2:      # the proposal (probs [B, 1]); the broadcast [B, B] result of _loss is kept as is
+            rec['log_prob'].append(lp.detach().numpy().copy().reshape(-1))
+        return lp
+
     Mixture.log_prob = mix_lp
     Categorical.log_prob = cat_lp
+    Bernoulli.log_prob = ber_lp
     net.zero_grad()
     ok, loss = net._loss(batch)
     assert ok
     loss.backward()
     Mixture.log_prob = orig_mix_lp
     Categorical.log_prob = orig_cat_lp
+    Bernoulli.log_prob = orig_ber_lp
     if hook is not None:
         hook.remove()
     names = [n for n, _ in net.named_parameters()]
@@ -307,6 +334,12 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
 if __name__ == '__main__':
     obs = {'obs0': 8, 'obs1': 9}
     only = sys.argv[1] if len(sys.argv) > 1 else None        # e.g. `poi` / `ff`: the other fixtures stay byte-identical
+    if only == 'ber':
+        # ProposalBernoulliBernoulli: in _loss its probs [B, 1] broadcast against values [B] to a [B, B] log_prob matrix
+        # (every proposal scored against every value of the sub-batch step); recorded as the reference computes it.
+        torch.distributions.Distribution.set_default_validate_args(False)
+        run_case('ber', BernoulliThenNormal(), 64, 1280, 64, 48, 32, {'obs0': 1.2, 'obs1': 0.7})
+        sys.exit(0)
     if only == 'ff':
         # InferenceNetworkFeedForward (pyprob/nn/inference_network_feedforward.py): heads read the observe embedding
         run_case('ff', GaussianWithUnknownMeanMarsaglia(), 0, 2560, 128, 96, 48, obs, network='feedforward')

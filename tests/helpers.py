@@ -15,7 +15,7 @@ def spec_from_golden(meta, params):
             a = k[len('_layers_proposal.'):-len('._ff._layers.0.weight')]
             if a not in meta['addresses']:
                 suffix = a.split('__')[-2]
-                pairs.append((a, [d for d in ('Normal', 'Uniform', 'Categorical', 'Poisson') if suffix.startswith(d)][0]))
+                pairs.append((a, [d for d in ('Normal', 'Uniform', 'Categorical', 'Poisson', 'Bernoulli') if suffix.startswith(d)][0]))
     for a, d in pairs:
         ncat = None
         if d == 'Categorical':
@@ -37,9 +37,13 @@ def engine_from_golden(meta, params, device='cuda:0'):
 
 def packed_from_golden(meta, batch, spec):
     from pyprob_amd.packed import PackedBatch
+    from pyprob_amd.packed import bernoulli_group_stats
     ids = np.array([spec.address_id[meta['addresses'][i]] for i in batch['addr_idx']], np.int64)
-    return PackedBatch.from_ragged(batch['trace_len'], ids, batch['values'], head_prior(meta, batch['addr_idx'], batch['prior']),
-                                   batch['obs'], len(spec.addresses))
+    prior = head_prior(meta, batch['addr_idx'], batch['prior'])
+    bernoulli = [a for a, info in enumerate(spec.addresses) if info.dist_name == 'Bernoulli']
+    if bernoulli:
+        prior = bernoulli_group_stats(batch['trace_len'], ids, batch['values'], prior, bernoulli)
+    return PackedBatch.from_ragged(batch['trace_len'], ids, batch['values'], prior, batch['obs'], len(spec.addresses))
 
 
 def head_prior(meta, addr_idx, prior, dist_names=None):

@@ -5,7 +5,7 @@ import math
 import torch
 
 import pyprob_amd as pyprob
-from pyprob_amd.distributions import Normal, Uniform, Categorical, Poisson
+from pyprob_amd.distributions import Normal, Uniform, Categorical, Poisson, Bernoulli
 from pyprob_amd.model import Model
 
 
@@ -80,6 +80,18 @@ class PoissonThenNormal(Model):
     def forward(self):
         n = pyprob.sample(Poisson(4.0))
         mu = pyprob.sample(Normal(n * 0.5, 1.0))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+class BernoulliThenNormal(Model):
+    """b ~ Bernoulli(0.3); mu ~ Normal(2 b - 1, 1); two Normal observations (the program of the `ber` golden case)."""
+
+    def forward(self):
+        b = pyprob.sample(Bernoulli(0.3))
+        mu = pyprob.sample(Normal(b * 2.0 - 1.0, 1.0))
         likelihood = Normal(mu, 0.8)
         pyprob.observe(likelihood, name='obs0')
         pyprob.observe(likelihood, name='obs1')

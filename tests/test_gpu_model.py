@@ -320,3 +320,21 @@ def test_distributed_posterior_on_a_single_rank_group(gum_trained):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bernoulli_program_trains_and_infers():
+    """ProposalBernoulliBernoulli through the host API: layers like the reference (87 408 parameters at H=64), training
+    through the Trace route (the vectorised generator does not cover Bernoulli), IS per trace and in lock step."""
+    from models import BernoulliThenNormal
+    torch.manual_seed(41)
+    model = BernoulliThenNormal()
+    model.learn_inference_network(inference_network=LSTM, num_traces=3000, observe_embeddings=EMB, batch_size=64,
+                                  lstm_dim=64, seed=12)
+    net = model._inference_network
+    assert net._engine.spec.num_parameters() == 87408
+    assert np.isfinite(net._loss_previous)
+    obs = {'obs0': 1.2, 'obs1': 0.7}
+    one = model.posterior_results(200, IC, lock_step=False, observe=obs)
+    lock = model.posterior_results(20000, IC, lock_step=True, observe=obs, seed=3)
+    ref = model.posterior_results(20000, InferenceEngine.IMPORTANCE_SAMPLING, observe=obs)     # prior proposals
+    assert np.isfinite(one.mean) and abs(lock.mean - ref.mean) < 0.15
