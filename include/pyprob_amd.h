@@ -120,7 +120,8 @@ typedef struct pp_batch {
     const int32_t* grp_off;      /* host [n_addr+1] rows grouped by address: group a = grp_rows[grp_off[a]:grp_off[a+1]] */
     const float*   obs;          /* dev [B, obs_width] observed values, trace order = packed order */
     const float*   value;        /* dev [R] sampled value of every controlled variable (category index as float) */
-    const float*   prior;        /* dev [R, 2] (mean, stddev) | (low, high) | unused */
+    const float*   prior;        /* dev [R, 2] (mean, stddev) | (low, high) | Poisson: (0, 40) | Bernoulli: (n, n1) of the
+                                    row's sub-batch step (PP_HEAD_BERNOULLI) | Categorical: unused */
     const int32_t* addr;         /* dev [R] address id of the row */
     const int32_t* prev_row;     /* dev [R] row of the previous time step of the same trace, -1 at t = 0 */
     const int32_t* grp_rows;     /* dev [R] row ids sorted by address id */
