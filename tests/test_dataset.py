@@ -268,3 +268,40 @@ def test_prior_inflation_draws_wider_values_and_keeps_the_prior_parameters():
                                                                  prior_inflation=PriorInflation.ENABLED)
     c = vals.reshape(-1, 2)[:, 0]
     assert np.allclose(np.bincount(c.astype(int), minlength=3) / 30000.0, 1 / 3, atol=0.015)
+
+
+def test_online_dataset_prefetches_the_next_chunk_in_a_worker_thread():
+    """VectorisedOnlineDataset: refresh() serves the chunk a worker thread prepared (start_prefetch), or generates one;
+    a failing generator surfaces in refresh(); wait_prefetch() joins without swapping."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(__file__))
+    from models import GaussianWithUnknownMeanMarsagliaLockStep
+    from pyprob_amd.dataset import VectorisedOnlineDataset
+    torch.manual_seed(2)
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    ds = VectorisedOnlineDataset(model, ['obs0', 'obs1'], chunk_traces=2000)
+    first = ds.obs_view = np.array(ds.gather(np.arange(5))[4])
+    assert len(ds.trace_len) == 2000 and ds.generated == 2000
+    ds.start_prefetch()
+    ds.start_prefetch()                    # (idempotent while a chunk is pending)
+    ds.wait_prefetch()
+    assert ds.generated == 2000 and np.array_equal(np.array(ds.gather(np.arange(5))[4]), first)   # not swapped yet
+    ds.refresh()
+    assert ds.generated == 4000 and not np.array_equal(np.array(ds.gather(np.arange(5))[4]), first)
+    ds.refresh()                           # nothing prepared: generated on the spot
+    assert ds.generated == 6000 and len(ds.trace_len) == 2000
+
+    class Broken(GaussianWithUnknownMeanMarsagliaLockStep):
+        calls = 0
+
+        def forward(self):
+            Broken.calls += 1
+            if Broken.calls > 40:
+                raise RuntimeError('generator failed')
+            return super().forward()
+    bad = VectorisedOnlineDataset(Broken(), ['obs0', 'obs1'], chunk_traces=500)
+    Broken.calls = 1000
+    bad.start_prefetch()
+    with pytest.raises(RuntimeError, match='generator failed'):
+        bad.refresh()
