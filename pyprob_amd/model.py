@@ -216,9 +216,14 @@ class Model:
                                 learning_rate_scheduler_type=None, weight_decay=0., distributed_backend=None,
                                 device='cuda:0', seed=None, dataset=None, log_file_name=None, dataset_dir=None,
                                 distributed_num_buckets=None, vectorised_prior=None, prior_chunk_traces=None,
-                                prior_inflation=PriorInflation.DISABLED):
+                                prior_inflation=PriorInflation.DISABLED, num_traces_end=1e9, optimizer_type='ADAM',
+                                momentum=0.9, save_file_name_prefix=None, save_every_sec=600, pre_generate_layers=False,
+                                distributed_params_sync_every_iter=10000, dataloader_offline_num_workers=0,
+                                stop_with_bad_loss=True):
         """pyprob/model.py:186-215 (inference_network: FEEDFORWARD, the reference's default, or LSTM). `dataset_dir` = a directory written by
         `save_dataset` (packed shards, pyprob_amd/dataset.py): offline training like the reference's OfflineDataset."""
+        if str(optimizer_type).split('.')[-1].upper() != 'ADAM':
+            raise ValueError('pyprob_amd trains with Optimizer.ADAM (the reference default); got {}'.format(optimizer_type))
         if dataset is None and dataset_dir is not None:
             from .dataset import PackedTraceDataset
             dataset = PackedTraceDataset(dataset_dir)
@@ -248,9 +253,15 @@ class Model:
             self._inference_network = cls(model=self, observe_embeddings=observe_embeddings, lstm_dim=lstm_dim,
                                           lstm_depth=lstm_depth, proposal_mixture_components=proposal_mixture_components,
                                           device=device, seed=seed)
+            if pre_generate_layers:        # model.py:205-209: all layers before the first step (and no _polymorph later)
+                self._inference_network._pre_generate_layers(dataset, batch_size=batch_size,
+                                                             save_file_name_prefix=save_file_name_prefix)
         else:
             print('Continuing to train existing inference network...')
         self._inference_network.optimize(num_traces=num_traces, dataset=dataset, batch_size=batch_size,
+                                         num_traces_end=num_traces_end, save_file_name_prefix=save_file_name_prefix,
+                                         save_every_sec=save_every_sec, stop_with_bad_loss=stop_with_bad_loss,
+                                         distributed_params_sync_every_iter=distributed_params_sync_every_iter,
                                          learning_rate_init=learning_rate_init, learning_rate_end=learning_rate_end,
                                          learning_rate_scheduler_type=learning_rate_scheduler_type,
                                          weight_decay=weight_decay, distributed_backend=distributed_backend,

@@ -182,6 +182,26 @@ class InferenceNetworkLSTM:
             self._history_num_params_trace.append(self._total_train_traces)
         return layers_changed
 
+    def _pre_generate_layers(self, dataset, batch_size=64, save_file_name_prefix=None):
+        """inference_network.py:270-288: create the layers of every address the dataset contains before training; later
+        minibatches are not polymorphed (optimize skips _polymorph, :476-479). Needed for data-parallel runs, where all
+        ranks must hold the same parameter set."""
+        if not self._layers_initialized:
+            self._init_layers_observe_embedding(self._observe_embeddings, example_trace=dataset[0])
+            self._init_layers()
+            self._layers_initialized = True
+        self._layers_pre_generated = True
+        changed = False
+        if hasattr(dataset, 'addresses') and hasattr(dataset, 'trace_types'):       # packed dataset: the address table
+            new = [a for a in dataset.addresses if a[0] not in self._engine.spec.address_id]
+            changed = bool(new) and self._polymorph(_PackedIds(dataset, [], new))
+        else:
+            n = len(dataset) if hasattr(dataset, '__len__') else 0
+            for i in range(0, min(n, int(1e5)), batch_size):
+                changed |= bool(self._polymorph(Batch([dataset[k] for k in range(i, min(i + batch_size, n))])))
+        if changed and save_file_name_prefix is not None:
+            self._save('{}_00000000_pre_generated.network'.format(save_file_name_prefix))
+
     # ---- training loss --------------------------------------------------------------------------------------
     def _pack(self, batch):
         if isinstance(batch, PackedBatch):
@@ -342,7 +362,7 @@ class InferenceNetworkLSTM:
     def optimize(self, num_traces, dataset, batch_size=64, learning_rate_init=0.0001, learning_rate_end=1e-6,
                  learning_rate_scheduler_type=None, weight_decay=1e-5, num_traces_end=1e9, distributed_backend=None,
                  distributed_params_sync_every_iter=10000, stop_with_bad_loss=False, log_file_name=None, verbose=True,
-                 distributed_num_buckets=None):
+                 distributed_num_buckets=None, save_file_name_prefix=None, save_every_sec=600):
         """The training loop of inference_network.py:381-599 for Optimizer.ADAM: per minibatch _polymorph ->
         zero_grad -> _loss -> backward -> [all-reduce, divide by world] -> Adam step, traces/s bookkeeping."""
         if not self._layers_initialized:
@@ -380,7 +400,10 @@ class InferenceNetworkLSTM:
         # Packed offline dataset (pyprob_amd/dataset.py): minibatches come from the reference's bucketed sampler over the
         # (length, type)-sorted index space (dataset.py:328-400) and are packed from memory-mapped columns - no Trace
         # objects. Anything else is indexed trace by trace like the reference's DataLoader does.
-        sync_every = 1 if (log_file_name or world > 1 or stop_with_bad_loss) else 16
+        # (stop_with_bad_loss does not force per-iteration syncs: a flagged minibatch never touches the parameters - Adam
+        # skips it on the device - and training stops when its status is read back, at most two runs later)
+        sync_every = 1 if (log_file_name or world > 1) else 16
+        save_state = [time_start - (save_every_sec or 0)]       # (the reference saves at the first iteration, :461-462)
         ring_n = 64
         loss_ring = torch.zeros(ring_n, dtype=torch.float32, device=self._engine.device)
         status_ring = torch.zeros(ring_n, dtype=torch.int32, device=self._engine.device)
@@ -420,6 +443,11 @@ class InferenceNetworkLSTM:
                         self._total_train_seconds, self._total_train_iterations, self._total_train_traces, loss,
                         self._learning_rate(), mean_len, n_sub, bsize * world / max(dt_each, 1e-9)))
             last = now
+            if rank == 0 and save_file_name_prefix is not None and save_every_sec is not None \
+                    and now - save_state[0] > save_every_sec:                      # inference_network.py:550-556
+                save_state[0] = now
+                self._save('{}_{}_traces_{}.network'.format(save_file_name_prefix, time.strftime('%Y%m%d_%H%M%S'),
+                                                            self._total_train_traces))
             return False
 
         # Single rank + packed dataset: runs of up to `chunk_steps` iterations execute inside ONE C call (pp_train_steps:
@@ -578,6 +606,9 @@ class InferenceNetworkLSTM:
             if book(pending, loss_ring[:len(pending)].cpu().numpy(), status_ring[:len(pending)].cpu().numpy()):
                 return
             pending = []
+        if rank == 0 and save_file_name_prefix is not None:                               # inference_network.py:596-599
+            self._save('{}_{}_traces_{}.network'.format(save_file_name_prefix, time.strftime('%Y%m%d_%H%M%S'),
+                                                        self._total_train_traces))
         if verbose and rank == 0:
             print('Stop condition reached. num_traces: {}  loss {:+.3e}  traces/s {:,.0f}'.format(
                 num_traces, self._loss_previous, self._total_train_traces / max(self._total_train_seconds, 1e-9)))

@@ -338,3 +338,29 @@ def test_bernoulli_program_trains_and_infers():
     lock = model.posterior_results(20000, IC, lock_step=True, observe=obs, seed=3)
     ref = model.posterior_results(20000, InferenceEngine.IMPORTANCE_SAMPLING, observe=obs)     # prior proposals
     assert np.isfinite(one.mean) and abs(lock.mean - ref.mean) < 0.15
+
+
+def test_checkpoint_files_and_pre_generated_layers(tmp_path):
+    """learn_inference_network(pre_generate_layers=True, save_file_name_prefix=...) like the reference (model.py:205-209,
+    inference_network.py:270-288, 550-556, 596-599): all layers exist before the first step, a pre-generated and a final
+    checkpoint are written and load back."""
+    import glob
+    torch.manual_seed(51)
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    d = str(tmp_path / 'ds')
+    model.save_dataset(d, 4000, 2000)
+    prefix = str(tmp_path / 'ckpt')
+    model.learn_inference_network(inference_network=LSTM, num_traces=4000, dataset_dir=d, observe_embeddings=EMB,
+                                  batch_size=100, lstm_dim=64, seed=13, pre_generate_layers=True,
+                                  save_file_name_prefix=prefix, save_every_sec=0)
+    net = model._inference_network
+    from pyprob_amd.dataset import PackedTraceDataset
+    assert len(net._engine.spec.addresses) == len(PackedTraceDataset(d).addresses) and net._layers_pre_generated
+    files = sorted(glob.glob(prefix + '_*.network'))
+    assert any(f.endswith('_00000000_pre_generated.network') for f in files) and len(files) >= 2
+    final = [f for f in files if f.endswith('_traces_%d.network' % net._total_train_traces)]
+    m2 = GaussianWithUnknownMeanMarsagliaLockStep()
+    m2.load_inference_network(final[-1])
+    assert m2._inference_network._total_train_traces == net._total_train_traces
+    with pytest.raises(ValueError):
+        model.learn_inference_network(num_traces=10, observe_embeddings=EMB, optimizer_type='SGD')
