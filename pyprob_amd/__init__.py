@@ -7,7 +7,8 @@ __version__ = '0.1.0'
 def __getattr__(name):
     """Lazy pyprob-style top level: pyprob_amd.sample / observe / Model / InferenceEngine / PriorInflation ... (importing the package
     must not require torch or a GPU)."""
-    if name in ('sample', 'observe', 'TraceMode', 'InferenceEngine', 'PriorInflation', 'InferenceNetwork'):
+    if name in ('sample', 'observe', 'TraceMode', 'InferenceEngine', 'PriorInflation', 'InferenceNetwork', 'LearningRateScheduler',
+                'Optimizer'):
         from . import state
         return getattr(state, name)
     if name == 'Model':

@@ -7,7 +7,7 @@ import torch
 from . import state
 from .distributions import Empirical
 from .nn import InferenceNetworkFeedForward, InferenceNetworkLSTM, OnlineDataset
-from .state import InferenceEngine, InferenceNetwork, PriorInflation, TraceMode
+from .state import InferenceEngine, InferenceNetwork, Optimizer, PriorInflation, TraceMode
 
 
 def trace_result(trace):
@@ -216,7 +216,7 @@ class Model:
                                 learning_rate_scheduler_type=None, weight_decay=0., distributed_backend=None,
                                 device='cuda:0', seed=None, dataset=None, log_file_name=None, dataset_dir=None,
                                 distributed_num_buckets=None, vectorised_prior=None, prior_chunk_traces=None,
-                                prior_inflation=PriorInflation.DISABLED, num_traces_end=1e9, optimizer_type='ADAM',
+                                prior_inflation=PriorInflation.DISABLED, num_traces_end=1e9, optimizer_type=Optimizer.ADAM,
                                 momentum=0.9, save_file_name_prefix=None, save_every_sec=600, pre_generate_layers=False,
                                 distributed_params_sync_every_iter=10000, dataloader_offline_num_workers=0,
                                 stop_with_bad_loss=True):

@@ -353,8 +353,11 @@ class InferenceNetworkLSTM:
         """POLY1 / POLY2 decay driven by the trace count (inference_network.py:357-379, :568)."""
         traces = self._total_train_traces if traces is None else traces
         t = self._learning_rate_scheduler_type
+        t = None if t is None else str(t).split('.')[-1].upper()      # 'POLY1' or LearningRateScheduler.POLY1
         if t in (None, 'NONE'):
             return self._learning_rate_init
+        if t not in ('POLY1', 'POLY2'):
+            raise ValueError('Unknown learning_rate_scheduler_type: {}'.format(self._learning_rate_scheduler_type))
         power = 1.0 if t == 'POLY1' else 2.0
         frac = max(0.0, 1.0 - traces / self._total_train_traces_end)
         return (self._learning_rate_init - self._learning_rate_end) * (frac ** power) + self._learning_rate_end

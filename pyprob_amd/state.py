@@ -40,6 +40,19 @@ class InferenceNetwork(enum.Enum):     # pyprob/__init__.py
     LSTM = 1
 
 
+class LearningRateScheduler(enum.Enum):    # pyprob/__init__.py
+    NONE = 0
+    POLY1 = 1
+    POLY2 = 2
+
+
+class Optimizer(enum.Enum):                # pyprob/__init__.py (this engine implements ADAM)
+    ADAM = 0
+    SGD = 1
+    ADAM_LARC = 2
+    SGD_LARC = 3
+
+
 class PriorInflation(enum.Enum):       # pyprob/__init__.py; state.py:87-93
     DISABLED = 0
     ENABLED = 1

@@ -159,3 +159,21 @@ def test_prior_and_posterior_return_empiricals_of_traces():
         prior[0]['nope']
     res = model.prior_results(50)
     assert len(res) == 50 and np.isfinite(res.mean)
+
+
+def test_learning_rate_schedules_match_the_reference_formula():
+    """POLY1 / POLY2 decay over the trace count (pyprob/nn/inference_network.py:357-379); enum or string."""
+    import pyprob_amd
+    from pyprob_amd.nn import InferenceNetworkLSTM
+    net = InferenceNetworkLSTM(observe_embeddings={'obs0': {'dim': 8}})
+    net._learning_rate_init, net._learning_rate_end, net._total_train_traces_end = 1e-3, 1e-6, 1e6
+    for kind, power in ((pyprob_amd.LearningRateScheduler.POLY1, 1.0), ('POLY2', 2.0)):
+        net._learning_rate_scheduler_type = kind
+        for traces in (0, 250000, 999999, 2000000):
+            want = (1e-3 - 1e-6) * (max(0.0, 1 - traces / 1e6) ** power) + 1e-6
+            assert abs(net._learning_rate(traces) - want) < 1e-15
+    net._learning_rate_scheduler_type = pyprob_amd.LearningRateScheduler.NONE
+    assert net._learning_rate(12345) == 1e-3
+    net._learning_rate_scheduler_type = 'COSINE'
+    with pytest.raises(ValueError):
+        net._learning_rate(1)
