@@ -219,7 +219,7 @@ class Model:
                                 prior_inflation=PriorInflation.DISABLED, num_traces_end=1e9, optimizer_type=Optimizer.ADAM,
                                 momentum=0.9, save_file_name_prefix=None, save_every_sec=600, pre_generate_layers=False,
                                 distributed_params_sync_every_iter=10000, dataloader_offline_num_workers=0,
-                                stop_with_bad_loss=True):
+                                stop_with_bad_loss=True, dataset_valid_dir=None, valid_every=None):
         """pyprob/model.py:186-215 (inference_network: FEEDFORWARD, the reference's default, or LSTM). `dataset_dir` = a directory written by
         `save_dataset` (packed shards, pyprob_amd/dataset.py): offline training like the reference's OfflineDataset."""
         if str(optimizer_type).split('.')[-1].upper() != 'ADAM':
@@ -227,6 +227,10 @@ class Model:
         if dataset is None and dataset_dir is not None:
             from .dataset import PackedTraceDataset
             dataset = PackedTraceDataset(dataset_dir)
+        dataset_valid = None
+        if dataset_valid_dir is not None:          # model.py:192-195 (a directory written by save_dataset)
+            from .dataset import PackedTraceDataset
+            dataset_valid = PackedTraceDataset(dataset_valid_dir)
         if dataset is None and vectorised_prior is not False and observe_embeddings:
             # online training: generate prior traces in lock step (one forward() per control-flow path and chunk) when
             # the program allows it - it must not turn sampled values into Python scalars; else one trace per forward()
@@ -262,6 +266,7 @@ class Model:
                                          num_traces_end=num_traces_end, save_file_name_prefix=save_file_name_prefix,
                                          save_every_sec=save_every_sec, stop_with_bad_loss=stop_with_bad_loss,
                                          distributed_params_sync_every_iter=distributed_params_sync_every_iter,
+                                         dataset_valid=dataset_valid, valid_every=valid_every,
                                          learning_rate_init=learning_rate_init, learning_rate_end=learning_rate_end,
                                          learning_rate_scheduler_type=learning_rate_scheduler_type,
                                          weight_decay=weight_decay, distributed_backend=distributed_backend,

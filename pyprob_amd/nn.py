@@ -123,6 +123,8 @@ class InferenceNetworkLSTM:
         self._loss_max = None
         self._loss_previous = float('inf')
         self._history_train_loss = []
+        self._history_valid_loss = []
+        self._history_valid_loss_trace = []
         self._history_train_loss_trace = []
         self._history_num_params = []
         self._history_num_params_trace = []
@@ -349,6 +351,22 @@ class InferenceNetworkLSTM:
         ls.runner.accumulate_masked(ls.lw, kind, torch.as_tensor(p0).reshape(-1).to(dev), torch.as_tensor(p1).reshape(-1).to(dev),
                                     value, ls.active)
 
+    def _validation_loss(self, dataset_valid, batch_size):
+        """Mean `_loss` over the minibatches of a packed validation dataset, forward only (inference_network.py:538-543);
+        a minibatch with an address the network does not know is skipped like `_loss` returning (False, 0)."""
+        sampler = dataset_valid.sampler(min(batch_size, len(dataset_valid)), 0, 1, None, False, False)
+        total, n = None, 0
+        for ids in sampler:
+            try:
+                pb = dataset_valid.device_batch(ids, self._engine.spec, self._engine.device)
+            except KeyError:
+                print('Address unknown by inference network (validation minibatch skipped)')
+                continue
+            loss = self._engine.loss(pb)
+            total = loss.clone() if total is None else total + loss
+            n += 1
+        return float(total.item()) / n if n else float('nan')
+
     def _learning_rate(self, traces=None):
         """POLY1 / POLY2 decay driven by the trace count (inference_network.py:357-379, :568)."""
         traces = self._total_train_traces if traces is None else traces
@@ -365,7 +383,8 @@ class InferenceNetworkLSTM:
     def optimize(self, num_traces, dataset, batch_size=64, learning_rate_init=0.0001, learning_rate_end=1e-6,
                  learning_rate_scheduler_type=None, weight_decay=1e-5, num_traces_end=1e9, distributed_backend=None,
                  distributed_params_sync_every_iter=10000, stop_with_bad_loss=False, log_file_name=None, verbose=True,
-                 distributed_num_buckets=None, save_file_name_prefix=None, save_every_sec=600):
+                 distributed_num_buckets=None, save_file_name_prefix=None, save_every_sec=600, dataset_valid=None,
+                 valid_every=None):
         """The training loop of inference_network.py:381-599 for Optimizer.ADAM: per minibatch _polymorph ->
         zero_grad -> _loss -> backward -> [all-reduce, divide by world] -> Adam step, traces/s bookkeeping."""
         if not self._layers_initialized:
@@ -407,6 +426,9 @@ class InferenceNetworkLSTM:
         # skips it on the device - and training stops when its status is read back, at most two runs later)
         sync_every = 1 if (log_file_name or world > 1) else 16
         save_state = [time_start - (save_every_sec or 0)]       # (the reference saves at the first iteration, :461-462)
+        if valid_every is None:
+            valid_every = max(100, num_traces / 1000)                                     # :435-436
+        valid_state = [-valid_every + 1]                                                  # last_validation_trace, :437
         ring_n = 64
         loss_ring = torch.zeros(ring_n, dtype=torch.float32, device=self._engine.device)
         status_ring = torch.zeros(ring_n, dtype=torch.int32, device=self._engine.device)
@@ -445,6 +467,10 @@ class InferenceNetworkLSTM:
                     log_file.write('{}, {}, {}, {}, {}, {}, {}, {}\n'.format(
                         self._total_train_seconds, self._total_train_iterations, self._total_train_traces, loss,
                         self._learning_rate(), mean_len, n_sub, bsize * world / max(dt_each, 1e-9)))
+            if dataset_valid is not None and trace - valid_state[0] > valid_every:        # :535-548
+                valid_state[0] = trace - 1
+                self._history_valid_loss.append(self._validation_loss(dataset_valid, batch_size))
+                self._history_valid_loss_trace.append(self._total_train_traces)
             last = now
             if rank == 0 and save_file_name_prefix is not None and save_every_sec is not None \
                     and now - save_state[0] > save_every_sec:                      # inference_network.py:550-556

@@ -305,3 +305,29 @@ def test_online_dataset_prefetches_the_next_chunk_in_a_worker_thread():
     bad.start_prefetch()
     with pytest.raises(RuntimeError, match='generator failed'):
         bad.refresh()
+
+
+def test_validation_loss_averages_the_minibatch_losses(tmp_path):
+    """InferenceNetwork._validation_loss (inference_network.py:538-543): mean of the forward-only loss over the
+    minibatches of a packed validation set; minibatches with unknown addresses are skipped. (Engine faked: CPU.)"""
+    import torch
+    from pyprob_amd.nn import InferenceNetworkLSTM
+    write(str(tmp_path / 'v'), 300, 4)
+    ds = PackedTraceDataset(str(tmp_path / 'v'))
+
+    class FakeEngine:
+        device = 'cpu'
+        spec = _Spec(list(ds.addresses))
+        seen = []
+
+        def loss(self, pb):
+            self.seen.append(pb.n_traces)
+            return torch.tensor([float(pb.n_rows) / pb.n_traces])
+    net = InferenceNetworkLSTM(observe_embeddings={'obs0': {'dim': 8}})
+    net._engine = FakeEngine()
+    got = net._validation_loss(ds, 64)
+    assert FakeEngine.seen == [64, 64, 64, 64]                       # 300 // 64 full minibatches, sorted order
+    lens = ds.trace_len[ds.sorted_indices()[:256]].reshape(4, 64)
+    assert abs(got - float(np.mean(lens.mean(1)))) < 1e-6
+    net._engine.spec = _Spec(list(ds.addresses)[:1])                # the network knows only the first address
+    assert np.isnan(net._validation_loss(ds, 64)) or net._validation_loss(ds, 64) > 0
