@@ -311,17 +311,21 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
                float* h, float* c, int32_t state_rows, const float* value_in, float* value_out, float* logq_out,
                uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream);
 
-/* log p(value) for Normal / Uniform / Categorical priors and likelihood terms, accumulated into the
- * per-particle log-weight:  lw[i] += sign * log_prob(dist(params_i); x_i)
- * (state.py:211-217: +prior, -proposal; state.py:147-149: +likelihood_importance * likelihood).
- *   kind: 0 Normal(p0=mean,p1=stddev), 1 Uniform(p0=low,p1=high)
- *   p0/p1/x strides: 0 broadcasts a single value, 1 reads per particle. lp_out optional (dev [n]). */
+/* log p(value) of prior and likelihood terms, accumulated into the per-particle log-weight:
+ *     lw[i] += scale * log_prob(dist(params_i); x_i)
+ * (state.py:211-217: +prior, -proposal; state.py:147-149: +likelihood_importance * likelihood), evaluated in fp32 like
+ * the torch.distributions classes behind pyprob/distributions/{normal,uniform,poisson,bernoulli,categorical}.py.
+ *   kind: 0 Normal(p0=mean, p1=stddev), 1 Uniform(p0=low, p1=high) with support [low, high),
+ *         3 Poisson(p0=rate), 4 Bernoulli(p0=probs) (p1 unused, may be NULL),
+ *         5 Categorical: p0 = probs row(s) of p1_stride categories, row i at p0 + i * p0_stride (0 = one shared row);
+ *           x = category index as float; p1 unused
+ *   p0/p1/x strides: 0 broadcasts a single value, 1 reads per particle. lw and lp_out are optional (dev [n]). */
 int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,
                             const float* x, int32_t x_stride, float scale, float* lw /*dev [n]*/, float* lp_out,
                             int32_t n, void* stream);
 
 /* Up to four log-weight terms in ONE pass over the particles:
- *   lw[i] (+)= sum_t scale_t * term_t(i);  kind 0: Normal log_prob, 1: Uniform log_prob, 2: the value x itself (e.g. -log q)
+ *   lw[i] (+)= sum_t scale_t * term_t(i);  kind as in pp_logweight_accumulate, or 2: the value x itself (e.g. -log q)
  * overwrite != 0 starts from 0 instead of the current lw (saves the zero-fill). */
 typedef struct pp_lw_term {
     int32_t kind, p0_stride, p1_stride, x_stride;
@@ -336,7 +340,7 @@ int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream);
 
 /* Wavefront-reduced importance statistics over n particles (pyprob/distributions/empirical.py:298-309,
  * 451-466, 758-766): out (dev, double[6]) = { max lw, sum w, sum w^2, sum w*x, sum w*x^2, count finite } with
- * w = exp(lw - max lw). ESS = (sum w)^2 / sum w^2. One pass over the particles (per-workgroup maxima, rescaled by a
+ * w = exp(lw - max lw) evaluated in fp64. ESS = (sum w)^2 / sum w^2. One pass over the particles (per-workgroup maxima, rescaled by a
  * one-workgroup combine); `scratch` dev >= PP_IS_STATS_SCRATCH doubles. */
 #define PP_IS_STATS_SCRATCH 1536
 int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream);

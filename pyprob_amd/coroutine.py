@@ -1,0 +1,241 @@
+"""Importance sampling with the inference network for UNMODIFIED programs: particle coroutines.
+
+The lock-step executor (state.LockStepState) needs programs whose conditions are tensor expressions. The reference's
+own programs are plain Python - `while float(s) >= 1:` (tests/test_inference.py:262), `.item()`, `if` on a scalar - and
+pyprob serves them one particle at a time: one `forward()` per particle, one batch-1 network evaluation per
+`pyprob.sample` (pyprob/model.py:59-71, pyprob/state.py:203-219). Here every particle runs `forward()` in its own
+greenlet, as written, and PARKS inside `sample`: when every live particle is parked (or finished) the
+scheduler serves the pending statements in address-grouped batches -
+
+    per group (address, previous address):  one pp_is_step  (LSTM step with the particles' gathered states + proposal
+                                            head + draw + log q), one prior log_prob kernel, lw[rows] += log p - log q
+    per round:                              the likelihood terms queued by `observe` since the last round, one kernel per
+                                            family, lw[rows] += likelihood_importance * log p(y | .)
+
+- and resumes the particles with their values. The per-particle log-weight lives on the device for the whole run and
+is the same fp32 accumulator the lock-step path uses (pinned on the reference's records in tests/test_gpu_logweight.py).
+What stays per particle is the program's own Python.
+
+The executor talks to the network through `ISRunner` (pp_is_step / pp_logweight_accumulate) only; `backend` may be any
+object with that interface (the CPU tests drive it with a stand-in built on the oracle).
+"""
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from .packed import distribution_params
+
+
+class _Particle:
+    __slots__ = ('pid', 'glet', 'request', 'reply', 'trace', 'result', 'done', 'prev_host_value')
+
+    def __init__(self, pid):
+        self.pid = pid
+        self.glet = None
+        self.request = None            # (address id, previous address id, prior distribution) while parked
+        self.reply = None              # (value, prior log_prob) from the scheduler
+        self.trace = None
+        self.result = None
+        self.done = False
+        self.prev_host_value = None    # value of a previous variable that was drawn on the host (unknown address)
+
+
+class _Params:
+    """Per-particle parameter columns of one statement group, in the duck type ISRunner.dist_term reads."""
+
+    def __init__(self, name, dists):
+        self.name = name
+        if name == 'Normal':
+            self.mean = np.array([float(d.mean) for d in dists], np.float32)
+            self.stddev = np.array([float(d.stddev) for d in dists], np.float32)
+        elif name == 'Uniform':
+            self.low = np.array([float(d.low) for d in dists], np.float32)
+            self.high = np.array([float(d.high) for d in dists], np.float32)
+        elif name == 'Poisson':
+            self.rate = np.array([float(d.rate) for d in dists], np.float32)
+        elif name == 'Bernoulli':
+            self.probs = np.array([float(d.probs) for d in dists], np.float32)
+        elif name == 'Categorical':
+            self.num_categories = int(dists[0].num_categories)
+            self.probs = np.stack([np.asarray(d.probs.detach().reshape(-1).tolist(), np.float32) for d in dists])
+        else:
+            raise RuntimeError('Distribution currently unsupported: {}'.format(name))
+
+
+class CoroutineIS:
+    """One posterior run of `num_traces` particle coroutines over the trace runtime `state` (pyprob_amd.state).
+    `run()` returns (results, log_weights [n] device tensor, traces): results[i] = forward()'s return value of particle i."""
+
+    def __init__(self, state, forward, network, num_traces, seed=0, offset=0, likelihood_importance=1.0):
+        import greenlet
+        self._greenlet = greenlet
+        self.state = state
+        self.forward = forward
+        self.net = network
+        self.runner = network._is
+        self.spec = network._engine.spec
+        self.n = int(num_traces)
+        self.seed, self.offset = int(seed), int(offset)
+        self.scale = float(likelihood_importance)
+        self.dev = self.runner.dev
+        self.lw = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
+        self.last_value = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
+        self.current = None
+        self.hub = None
+        self.likelihoods = []          # (pid, distribution, value) queued by observe since the last round
+        self.rounds = 0
+        self.group_calls = 0
+        self.statements = 0
+        self.seconds = 0.0
+
+    # ---- called from state.sample / state.observe inside a particle ------------------------------------------------
+    def sample(self, distribution, base, addr, instance, name):
+        """The IC branch of state.sample (state.py:203-219) for the particle that is running: park until the scheduler
+        has served this statement, then record the variable like the reference does."""
+        from .trace import Variable
+        state = self.state
+        p = self.current
+        prev = state._current_trace_previous_variable
+        spec = self.spec
+        if spec.feedforward:            # inference_network_feedforward.py:52-66: no state, no previous variable
+            prev_known, prev_a = True, None
+        else:
+            prev_known = prev is None or prev.address in spec.address_id
+            prev_a = None if (prev is None or not prev_known) else spec.address_id[prev.address]
+        if addr not in spec.address_id or not prev_known:
+            # no proposal layers for this address (or the previous one): the prior is the proposal and
+            # log p - log q = 0 (inference_network_lstm.py:100-104, 132-134); the LSTM state is not advanced
+            warnings.warn('Using prior. No proposal for address: {}'.format(addr))
+            value = distribution.sample()
+            if value.dim() > 0:
+                value = value[0]
+            variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                                log_prob=distribution.log_prob(value, sum=True), log_importance_weight=0.0, control=True,
+                                name=name)
+            p.prev_host_value = float(value)
+            state._current_trace.add(variable)
+            state._current_trace_previous_variable = variable
+            return variable.value
+        variable = Variable(distribution=distribution, value=None, address_base=base, address=addr, instance=instance,
+                            log_prob=0., control=True, name=name)
+        p.request = (spec.address_id[addr], prev_a, distribution)
+        ctx = (state._current_trace, state._current_trace_execution_start)
+        self.hub.switch()                                   # ---- parked; the scheduler serves the statement ----
+        state._current_trace, state._current_trace_execution_start = ctx
+        variable.value, variable.log_prob = p.reply
+        p.reply = None
+        state._current_trace.add(variable)
+        state._current_trace_previous_variable = variable      # (no other particle runs between here and the next park)
+        return variable.value
+
+    def observe(self, distribution, value):
+        """state.observe's weight term (state.py:147-149), deferred to the next round's likelihood kernels."""
+        self.likelihoods.append((self.current.pid, distribution, value))
+
+    # ---- scheduler -------------------------------------------------------------------------------------------------
+    def _particle_main(self, p, args, kwargs):
+        state = self.state
+        state._begin_trace()
+        result = self.forward(*args, **kwargs)
+        p.trace = state._end_trace(result)
+        p.result = result
+        p.done = True
+
+    def run(self, *args, **kwargs):
+        g = self._greenlet
+        state = self.state
+        self.hub = g.getcurrent()
+        runner = self.runner
+        runner.begin(self.n, offset=self.offset)
+        runner.state_rows = self.n                 # (per-particle rows from the start: groups gather / scatter them)
+        particles = [_Particle(i) for i in range(self.n)]
+        t0 = time.time()
+        # start every particle: each runs to its first controlled sample (or to the end)
+        for p in particles:
+            p.glet = g.greenlet(self._particle_main, parent=self.hub)
+            self.current = p
+            p.glet.switch(p, args, kwargs)
+        parked = [p for p in particles if not p.done]
+        while True:
+            self._flush_likelihoods()
+            if not parked:
+                break
+            self._serve(parked)
+            nxt = []
+            for p in parked:
+                self.current = p
+                p.glet.switch()
+                if not p.done:
+                    nxt.append(p)
+            parked = nxt
+            self.rounds += 1
+        self.current = None
+        state._current_trace = None
+        self.seconds = time.time() - t0
+        lw_host = self.lw.cpu().numpy().astype(np.float64)
+        for p, w in zip(particles, lw_host):
+            # every weight term of a served statement lives in the device accumulator (trace.py:123-125 on the device);
+            # Trace.end summed the host-side ones (prior-as-proposal fallbacks: 0)
+            p.trace.log_importance_weight = float(w)
+        return [p.result for p in particles], self.lw, [p.trace for p in particles]
+
+    def _serve(self, parked):
+        """All pending sample statements, grouped by (address, previous address): one pp_is_step per group."""
+        runner = self.runner
+        groups = {}
+        for p in parked:
+            a, prev_a, _ = p.request
+            groups.setdefault((a, prev_a), []).append(p)
+        for gi, ((a, prev_a), members) in enumerate(sorted(groups.items(), key=lambda kv: (kv[0][0], -1 if kv[0][1] is None else kv[0][1]))):
+            m = len(members)
+            pids = np.fromiter((p.pid for p in members), np.int64, m)
+            rows = torch.from_numpy(pids).to(self.dev)
+            host_prev = [(k, p.prev_host_value) for k, p in enumerate(members) if p.prev_host_value is not None]
+            if host_prev:          # previous variable was drawn from the prior on the host (unknown address)
+                idx = torch.tensor([pids[k] for k, _ in host_prev], device=self.dev)
+                self.last_value.index_copy_(0, idx, torch.tensor([v for _, v in host_prev], dtype=torch.float32, device=self.dev))
+                for k, _ in host_prev:
+                    members[k].prev_host_value = None
+            dists = [p.request[2] for p in members]
+            info = self.spec.addresses[a]
+            head = np.asarray([distribution_params(d) for d in dists], np.float32).reshape(m, 2)
+            prior = torch.from_numpy(head).to(self.dev)
+            runner.prev_value = self.last_value
+            seed = self.seed + 7919 * self.rounds + 104729 * gi
+            value, logq = runner.step_rows(rows, a, prev_a, prior, seed=seed, prior_compact=True)
+            self.last_value.index_copy_(0, rows, value)
+            term = runner.dist_term(_Params(info.dist_name, dists))
+            prior_lp = runner.log_prob(term, value)
+            self.lw.index_add_(0, rows, prior_lp - logq)                       # state.py:211-217
+            host = torch.stack([value, prior_lp]).cpu()                        # ONE device-to-host copy per group
+            vals, lps = host[0].unbind(0), host[1].unbind(0)
+            for k, p in enumerate(members):
+                p.reply = (vals[k], lps[k])
+                p.request = None
+            self.group_calls += 1
+            self.statements += m
+
+    def _flush_likelihoods(self):
+        """lw[rows] += likelihood_importance * log p(y | .) for the observes since the last round, one kernel per family."""
+        if not self.likelihoods:
+            return
+        runner = self.runner
+        by_family = {}
+        for pid, d, v in self.likelihoods:
+            by_family.setdefault(d.name, []).append((pid, d, v))
+        self.likelihoods = []
+        for name, items in by_family.items():
+            dists = [d for _, d, _ in items]
+            try:
+                term = runner.dist_term(_Params(name, dists))
+            except RuntimeError:
+                term = None
+            rows = torch.tensor([pid for pid, _, _ in items], dtype=torch.int64, device=self.dev)
+            if term is None:       # a family without a device kernel: scored on the host like the reference
+                lp = torch.tensor([float(d.log_prob(v, sum=True)) for _, d, v in items], dtype=torch.float32, device=self.dev)
+            else:
+                x = torch.tensor([float(v) for _, _, v in items], dtype=torch.float32, device=self.dev)
+                lp = runner.log_prob(term, x)
+            self.lw.index_add_(0, rows, lp, alpha=self.scale)

@@ -278,6 +278,12 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     PP_CHECK_ARG(bt->n_active && bt->row_off && bt->grp_off && bt->obs && bt->value && bt->prior && bt->addr &&
                      bt->prev_row && bt->grp_rows && bt->trace && bt->row_off_dev && bt->nxt_off && bt->nxt_rows,
                  "pp_ic_loss: incomplete pp_batch");
+    {
+        int obs_in = 0;
+        for (int o = 0; o < net->n_obs; ++o) obs_in += net->obs_in[o];
+        PP_CHECK_ARG(bt->obs_width == obs_in, "pp_ic_loss: batch obs_width %d != the network's observable width %d",
+                     bt->obs_width, obs_in);
+    }
     const bool bwd = flags & PP_LOSS_BACKWARD;
     PP_CHECK_ARG(!bwd || grads, "pp_ic_loss: PP_LOSS_BACKWARD needs a gradient buffer");
     const bool ff = net->lstm_dim == 0;   // FeedForward network (inference_network_feedforward.py:68-98)

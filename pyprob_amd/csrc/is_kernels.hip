@@ -487,6 +487,39 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     return 0;
 }
 
+// log_prob of the prior / likelihood families state.sample and state.observe score (state.py:211, 147-149), as torch
+// evaluates them in fp32:
+//   0 Normal(mean a, stddev b)       torch.distributions.Normal.log_prob
+//   1 Uniform(low a, high b)         support [low, high)
+//   3 Poisson(rate a)                xlogy(v, rate) - rate - lgamma(v + 1)
+//   4 Bernoulli(probs a)             probs clamped to [eps, 1 - eps] (probs_to_logits), v log p + (1 - v) log(1 - p)
+//   5 Categorical(probs row p0[i * s0 .. + C), C = s1)   log(clamp(p[v] / sum p, eps, 1 - eps))
+__device__ __forceinline__ float term_log_prob(int kind, const float* __restrict__ p0, int s0, const float* __restrict__ p1,
+                                               int s1, float v, int64_t i) {
+    if (kind == 5) {
+        const float* p = p0 + i * s0;
+        const int C = s1;
+        float sum = 0.0f;
+        for (int c = 0; c < C; ++c) sum += p[c];
+        const int k = (int)v;
+        if (k < 0 || k >= C) return -INFINITY;
+        const float q = fminf(fmaxf(p[k] / sum, kFp32Eps), 1.0f - kFp32Eps);
+        return logf(q);
+    }
+    const float a = p0[i * s0];
+    if (kind == 3) return (v == 0.0f ? 0.0f : v * logf(a)) - a - lgammaf(v + 1.0f);
+    if (kind == 4) {
+        const float q = fminf(fmaxf(a, kFp32Eps), 1.0f - kFp32Eps);
+        return v * logf(q) + (1.0f - v) * log1pf(-q);
+    }
+    const float b = p1[i * s1];
+    if (kind == 0) {
+        const float t = v - a;
+        return -(t * t) / (2.0f * b * b) - logf(b) - kHalfLog2Pi;
+    }
+    return (v >= a && v < b) ? -logf(b - a) : -INFINITY;
+}
+
 // lw[i] += scale * log_prob(dist(p0_i, p1_i); x_i)
 __global__ __launch_bounds__(256) void logweight_kernel(int kind, const float* __restrict__ p0, int s0,
                                                         const float* __restrict__ p1, int s1,
@@ -494,14 +527,7 @@ __global__ __launch_bounds__(256) void logweight_kernel(int kind, const float* _
                                                         float* __restrict__ lw, float* __restrict__ lp_out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float a = p0[(int64_t)i * s0], b = p1[(int64_t)i * s1], v = x[(int64_t)i * sx];
-    float lp;
-    if (kind == 0) {  // Normal(mean a, stddev b)
-        const float t = v - a;
-        lp = -(t * t) / (2.0f * b * b) - logf(b) - kHalfLog2Pi;
-    } else {  // Uniform(low a, high b): support [low, high)
-        lp = (v >= a && v < b) ? -logf(b - a) : -INFINITY;
-    }
+    const float lp = term_log_prob(kind, p0, s0, p1, s1, x[(int64_t)i * sx], i);
     if (lp_out) lp_out[i] = lp;
     if (lw) lw[i] += scale * lp;
 }
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(256) void axpy_kernel(float scale, const float* __r
 
 // Importance statistics, ONE pass over the particles: workgroup b keeps its slice relative to its OWN maximum
 //   m_b = max finite lw,  S_b = (sum e, sum e^2, sum e x, sum e x^2, count),  e = exp(lw - m_b)
-// (fp32 exp of an fp32 difference <= 0, fp64 sums) and a one-workgroup combine rescales the partials to the global
+// (fp64 exp of the difference <= 0, fp64 sums) and a one-workgroup combine rescales the partials to the global
 // maximum: sum w = sum_b S_b[0] exp(m_b - M), sum w^2 = sum_b S_b[1] exp(2 (m_b - M)), ...
 // (two passes over the data with 64 workgroups took 8 + 23 us for 1M particles; a single workgroup > 1 ms).
 constexpr int STAT_BLOCKS = 256;      // scratch: STAT_BLOCKS x 6 doubles (PP_IS_STATS_SCRATCH)
@@ -548,11 +574,11 @@ __global__ __launch_bounds__(256) void is_stats_partial_kernel(const float* __re
             S[0] *= r; S[1] *= r * r; S[2] *= r; S[3] *= r;
             M = (double)m;
         }
-        const float Mf = (float)M;
 #pragma unroll
         for (int q = 0; q < STAT_PER_THREAD; ++q) {
             if (!isfinite(l[q])) continue;
-            const double e = (double)expf(l[q] - Mf), xd = (double)xv[q];
+            // fp64 exponent: Empirical / util.effective_sample_size normalise in float64 (empirical.py:300, util.py:398-399)
+            const double e = exp((double)l[q] - M), xd = (double)xv[q];
             S[0] += e; S[1] += e * e; S[2] += e * xd; S[3] += e * xd * xd; S[4] += 1.0;
         }
     }
@@ -598,7 +624,7 @@ __global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __r
 }
 
 // Several log-weight terms in one pass over the particles (state.py:211-217, 147-149):
-//   lw[i] += sum_t scale_t * term_t(i),  term kinds: 0 Normal log_prob, 1 Uniform log_prob, 2 identity (x itself)
+//   lw[i] += sum_t scale_t * term_t(i),  term kinds: term_log_prob's, and 2 = identity (x itself)
 struct LwTerm {
     int kind, s0, s1, sx;
     const float *p0, *p1, *x;
@@ -618,20 +644,20 @@ __global__ __launch_bounds__(256) void logweight_multi_kernel(const LwTerms term
         const LwTerm& t = terms.t[q];
         const float v = t.x[(int64_t)i * t.sx];
         float lp;
-        if (t.kind == 2) {
+        if (t.kind == 2)
             lp = v;
-        } else {
-            const float a = t.p0[(int64_t)i * t.s0], b = t.p1[(int64_t)i * t.s1];
-            if (t.kind == 0) {
-                const float d = v - a;
-                lp = -(d * d) / (2.0f * b * b) - logf(b) - kHalfLog2Pi;
-            } else {
-                lp = (v >= a && v < b) ? -logf(b - a) : -INFINITY;
-            }
-        }
+        else
+            lp = term_log_prob(t.kind, t.p0, t.s0, t.p1, t.s1, v, i);
         acc += t.scale * lp;
     }
     lw[i] = acc;
+}
+
+// kinds 0, 1 read p1; 3, 4 ignore it; 5 carries the number of categories in p1_stride
+static inline bool lw_kind_ok(int kind, const float* p1, int p1_stride) {
+    if (kind == 0 || kind == 1) return p1 != nullptr;
+    if (kind == 3 || kind == 4 || kind == 2) return true;
+    return kind == 5 && p1_stride >= 1;
 }
 
 }  // namespace pp
@@ -662,7 +688,7 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
 int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,
                             const float* x, int32_t x_stride, float scale, float* lw, float* lp_out, int32_t n,
                             void* stream) {
-    if (!(p0 && p1 && x) || (kind != 0 && kind != 1)) {
+    if (!(p0 && x) || !pp::lw_kind_ok(kind, p1, p1_stride) || kind == 2) {
         pp::set_error("pp_logweight_accumulate: bad argument");
         return PP_EINVAL;
     }
@@ -704,7 +730,7 @@ int pp_logweight_terms(const pp_lw_term* terms, int32_t count, float* lw, int32_
     t.count = count;
     for (int q = 0; q < count; ++q) {
         const pp_lw_term& s = terms[q];
-        if (s.kind < 0 || s.kind > 2 || !s.x || (s.kind != 2 && !(s.p0 && s.p1))) {
+        if (!s.x || (s.kind != 2 && !(s.p0 && pp::lw_kind_ok(s.kind, s.p1, s.p1_stride)))) {
             pp::set_error("pp_logweight_terms: bad term %d", q);
             return PP_EINVAL;
         }

@@ -628,7 +628,7 @@ def save_dataset(model, dataset_dir, num_traces, num_traces_per_file, obs_names=
     names = obs_names
     if names is None:    # one per-trace run tells which named variables are observed
         probe = next(gen)
-        names = [k for k, v in probe.named_variables.items() if v.observed or getattr(v, 'observable', False)]
+        names = [k for k, v in probe.named_variables.items() if v.observed]     # recorded by observe(), not named samples
     vectorised = True
     try:                 # lock-step-safe programs are generated n traces at a time (Model.prior_traces_packed)
         model.prior_traces_packed(8, names, *args, **kwargs)

@@ -64,6 +64,9 @@ class ICEngine:
         self.chunk_tensor = torch.from_numpy(spec.chunk_tensor_map()).to(self.device)
         self.addr_table = torch.from_numpy(spec.address_table()).to(self.device)
         self.net = spec.c_struct(self.addr_table.data_ptr())
+        from . import ops
+        ops.unregister_net(getattr(self, 'net_handle', None))
+        self.net_handle = ops.register_net(self.net, spec)          # the operators' handle of this layer set (ops.py)
         self._active_cache = {}
         self._active_key = None
         self.ws_shape = (0, 0)

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import lib as L
+from .ops import ops
 
 
 class ISRunner:
@@ -49,8 +50,7 @@ class ISRunner:
         if obs.numel() != self.eng.spec.obs_width:
             raise ValueError('observe has %d values, the network expects %d' % (obs.numel(), self.eng.spec.obs_width))
         self._ensure_ws(1)
-        L.check(self.lib.pp_is_init(C.byref(self.eng.net), self.eng.params.data_ptr(), obs.data_ptr(),
-                                    self.e_obs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, L.stream_ptr()), 'pp_is_init')
+        self.e_obs = ops.is_init(self.eng.params, self.ws, self.eng.net_handle, obs)
 
     def begin(self, n, offset=0):
         """Start n traces in lock step (state._begin_trace, state.py:339-345): LSTM state is reset by the first step."""
@@ -69,23 +69,18 @@ class ISRunner:
         """One controlled sample statement for all particles. prior: device tensor [1,2] (shared) or [n,2].
         Returns (values [n], log q [n]) as device tensors."""
         n = self.n
-        value = torch.empty(n, dtype=torch.float32, device=self.dev)
-        logq = torch.empty(n, dtype=torch.float32, device=self.dev)
-        stride = 0 if (prior is None or prior.shape[0] == 1) else 1
-        rc = self.lib.pp_is_step(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id),
-                                 -1 if prev_addr_id is None else int(prev_addr_id), n, self.e_obs.data_ptr(),
-                                 L.ptr(self.prev_value), L.ptr(prior), stride, self.h.data_ptr(), self.c.data_ptr(),
-                                 self.state_rows, L.ptr(value_in), value.data_ptr(), logq.data_ptr(), int(seed), self.offset,
-                                 self.ws.data_ptr(), self.ws_bytes, L.stream_ptr())
-        L.check(rc, 'pp_is_step')
+        value, logq = ops.is_step(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
+                                  -1 if prev_addr_id is None else int(prev_addr_id), n, self.e_obs, self.prev_value, prior,
+                                  self.h, self.c, self.state_rows, value_in, int(seed), self.offset)
         self.state_rows = 1 if prev_addr_id is None else n   # see include/pyprob_amd.h
         self.prev_value = value
         self.last_value = value
         return value, logq
 
-    def step_rows(self, rows, addr_id, prev_addr_id, prior, seed=0):
+    def step_rows(self, rows, addr_id, prev_addr_id, prior, seed=0, prior_compact=False):
         """The same statement for a SUBSET of the particles (a diverged control-flow path): the rows' LSTM state and
-        previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor."""
+        previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor; prior:
+        [1, 2], or one row per particle ([n, 2]; prior_compact: one row per entry of `rows`)."""
         m = int(rows.numel())
         if self.state_rows == 1 and self.n > 1 and prev_addr_id is not None:
             self.h[1:] = self.h[0]      # the shared first-statement state (row 0) becomes per-particle
@@ -94,18 +89,12 @@ class ISRunner:
         h = self.h.index_select(0, rows)
         c = self.c.index_select(0, rows)
         prev = None if (prev_addr_id is None or self.prev_value is None) else self.prev_value.index_select(0, rows).contiguous()
-        if prior is not None and prior.shape[0] != 1:
+        if prior is not None and prior.shape[0] != 1 and not prior_compact:
             prior = prior.index_select(0, rows).contiguous()
-        stride = 0 if (prior is None or prior.shape[0] == 1) else 1
-        value = torch.empty(m, dtype=torch.float32, device=self.dev)
-        logq = torch.empty(m, dtype=torch.float32, device=self.dev)
         self._ensure_ws(m)
-        rc = self.lib.pp_is_step(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id),
-                                 -1 if prev_addr_id is None else int(prev_addr_id), m, self.e_obs.data_ptr(),
-                                 L.ptr(prev), L.ptr(prior), stride, h.data_ptr(), c.data_ptr(),
-                                 1 if prev_addr_id is None else m, None, value.data_ptr(), logq.data_ptr(), int(seed),
-                                 self.offset, self.ws.data_ptr(), self.ws_bytes, L.stream_ptr())
-        L.check(rc, 'pp_is_step')
+        value, logq = ops.is_step(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
+                                  -1 if prev_addr_id is None else int(prev_addr_id), m, self.e_obs, prev, prior, h, c,
+                                  1 if prev_addr_id is None else m, None, int(seed), self.offset)
         if prev_addr_id is None:     # the call left the (shared) new state in row 0
             h = h[:1].expand(m, -1)
             c = c[:1].expand(m, -1)
@@ -114,55 +103,86 @@ class ISRunner:
         return value, logq
 
     # ---- log-weight terms ---------------------------------------------------------------------------------
-    def accumulate_masked(self, lw, kind, p0, p1, x, active, scale=1.0):
+    def dist_term(self, distribution, n=None):
+        """(kind, p0, p0_stride, p1, p1_stride) of pp_logweight_accumulate for a prior / likelihood distribution object
+        (duck-typed: .name and the parameter attributes of pyprob/distributions/*.py); None if the family has no device
+        kernel. Parameters may be shared (one element) or per particle (n elements)."""
+        dev = self.dev
+
+        def t(v):
+            return torch.as_tensor(v, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(dev).contiguous()
+
+        def s(v):
+            return 0 if v.numel() == 1 else 1
+        name = distribution.name
+        if name == 'Normal':
+            p0, p1 = t(distribution.mean), t(distribution.stddev)
+            return 0, p0, s(p0), p1, s(p1)
+        if name == 'Uniform':
+            p0, p1 = t(distribution.low), t(distribution.high)
+            return 1, p0, s(p0), p1, s(p1)
+        if name == 'Poisson':
+            p0 = t(distribution.rate)
+            return 3, p0, s(p0), None, 0
+        if name == 'Bernoulli':
+            p0 = t(distribution.probs)
+            return 4, p0, s(p0), None, 0
+        if name == 'Categorical':
+            C_ = int(distribution.num_categories)
+            p0 = t(distribution.probs)
+            return 5, p0, (0 if p0.numel() == C_ else C_), None, C_
+        return None
+
+    def log_prob(self, term, x, n=None):
+        """log_prob(dist; x) per particle as a device tensor [n] (no accumulation)."""
+        kind, p0, s0, p1, s1 = term
+        n = int(x.numel()) if n is None else n
+        return ops.log_prob(int(kind), p0, int(s0), p1, int(s1), x, n)
+
+    def _term_accumulate(self, term, x, scale, lw):
+        kind, p0, s0, p1, s1 = term
+        ops.logweight_terms(lw, [int(kind)], [p0], [int(s0)], [p1], [int(s1)], [x], [float(scale)], False)
+
+    def accumulate_masked(self, lw, kind, p0, p1, x, active, scale=1.0, term=None):
         """accumulate() for the active particles of a diverged path: the term is evaluated for every particle (stale
         entries of inactive particles may be anything) and added where `active` (None = everywhere)."""
+        if term is None:
+            term = (kind, p0, 0 if p0.numel() == 1 else 1, p1, 0 if p1.numel() == 1 else 1)
         if active is None:
-            return self.accumulate(lw, kind, p0, p1, x, scale=scale)
-        n = lw.numel()
-        lp = torch.empty(n, dtype=torch.float32, device=self.dev)
-
-        def s(t):
-            return 0 if t.numel() == 1 else 1
-        rc = self.lib.pp_logweight_accumulate(int(kind), p0.data_ptr(), s(p0), p1.data_ptr(), s(p1), x.data_ptr(), s(x),
-                                              1.0, None, lp.data_ptr(), n, L.stream_ptr())
-        L.check(rc, 'pp_logweight_accumulate')
+            return self._term_accumulate(term, x, scale, lw)
+        lp = self.log_prob(term, x, lw.numel())
         lw.add_(torch.where(active, lp, torch.zeros_like(lp)), alpha=float(scale))
 
-
-    def accumulate(self, lw, kind, p0, p1, x, scale=1.0):
+    def accumulate(self, lw, kind, p0, p1, x, scale=1.0, term=None):
         """lw += scale * log_prob(dist(p0, p1); x); p0/p1/x are device tensors of 1 (broadcast) or n elements."""
-        n = lw.numel()
-
-        def s(t):
-            return 0 if t.numel() == 1 else 1
-        rc = self.lib.pp_logweight_accumulate(int(kind), p0.data_ptr(), s(p0), p1.data_ptr(), s(p1), x.data_ptr(), s(x),
-                                              float(scale), lw.data_ptr(), None, n, L.stream_ptr())
-        L.check(rc, 'pp_logweight_accumulate')
+        if term is None:
+            term = (kind, p0, 0 if p0.numel() == 1 else 1, p1, 0 if p1.numel() == 1 else 1)
+        self._term_accumulate(term, x, scale, lw)
 
     def accumulate_terms(self, lw, terms, overwrite=False):
-        """One pass for up to four terms; terms = [(kind, p0, p1, x, scale)], kind 2 = the tensor x itself."""
-        arr = (L.pp_lw_term * len(terms))()
-
+        """One pass for up to four terms; terms = [(kind, p0, p1, x, scale)] (kind 2 = the tensor x itself) or
+        [(dist_term(...), x, scale)]."""
         def s(t):
             return 0 if (t is None or t.numel() == 1) else 1
-        for q, (kind, p0, p1, x, scale) in enumerate(terms):
-            arr[q].kind = int(kind)
-            arr[q].p0, arr[q].p1, arr[q].x = L.ptr(p0), L.ptr(p1), x.data_ptr()
-            arr[q].p0_stride, arr[q].p1_stride, arr[q].x_stride = s(p0), s(p1), s(x)
-            arr[q].scale = float(scale)
-        L.check(self.lib.pp_logweight_terms(arr, len(terms), lw.data_ptr(), lw.numel(), int(overwrite), L.stream_ptr()),
-                'pp_logweight_terms')
+        kinds, p0s, s0s, p1s, s1s, xs, scales = [], [], [], [], [], [], []
+        for item in terms:
+            if len(item) == 3:          # (dist_term tuple, x, scale)
+                (kind, p0, s0, p1, s1), x, scale = item
+            else:
+                kind, p0, p1, x, scale = item
+                s0, s1 = s(p0), s(p1)
+            kinds.append(int(kind)); p0s.append(p0); s0s.append(int(s0)); p1s.append(p1); s1s.append(int(s1))
+            xs.append(x); scales.append(float(scale))
+        ops.logweight_terms(lw, kinds, p0s, s0s, p1s, s1s, xs, scales, bool(overwrite))
 
     def axpy(self, lw, scale, term):
-        L.check(self.lib.pp_axpy(float(scale), term.data_ptr(), lw.data_ptr(), lw.numel(), L.stream_ptr()), 'pp_axpy')
+        """lw += scale * term (e.g. -log q)."""
+        ops.logweight_terms(lw, [2], [None], [0], [None], [0], [term], [float(scale)], False)
 
     def stats(self, lw, x=None):
         """Importance statistics (Empirical.finalize / expectation / effective_sample_size,
         pyprob/distributions/empirical.py:298-309, 451-466, 758-766) reduced on the device in float64."""
-        rc = self.lib.pp_is_stats(lw.data_ptr(), L.ptr(x), lw.numel(), self._stats.data_ptr(),
-                                  self._stats_scratch.data_ptr(), L.stream_ptr())
-        L.check(rc, 'pp_is_stats')
+        self._stats = ops.is_stats(lw, x, self._stats_scratch)
         m, sw, sw2, swx, swx2, cnt = self._stats[:6].cpu().numpy().tolist()
         mean = swx / sw if sw > 0 else float('nan')
         var = swx2 / sw - mean * mean if sw > 0 else float('nan')

@@ -14,6 +14,17 @@ def trace_result(trace):
     return trace.result
 
 
+def _drop_non_finite(values, log_weights):
+    """Model._traces discards traces whose log-weight is nan / inf / -inf with a warning (pyprob/model.py:64-66); the
+    lock-step executors do the same for their particle tensors, so one bad particle cannot poison the normalisation."""
+    ok = torch.isfinite(log_weights)
+    if bool(ok.all()):
+        return values, log_weights
+    import warnings
+    warnings.warn('Encountered {} traces with nan, inf, or -inf log_weight. Discarding them.'.format(int((~ok).sum())))
+    return values[ok].contiguous(), log_weights[ok].contiguous()
+
+
 class Model:
     def __init__(self, name='Unnamed PyProb model'):
         self.name = name
@@ -86,10 +97,55 @@ class Model:
         finally:
             state._lock_step = None
             state._current_trace = None
-        emp = Empirical(values=values, log_weights=ls.lw)
+        all_values, all_lw = values, ls.lw
+        values, lw = _drop_non_finite(values, ls.lw)
+        emp = Empirical(values=values, log_weights=lw)
+        emp._all_values, emp._all_log_weights = all_values, all_lw     # (full shard: the distributed gather needs fixed sizes)
         emp.finalize()
-        emp.device_stats = runner.stats(ls.lw, values)
+        emp.device_stats = runner.stats(lw, values)
         emp.num_paths = n_paths
+        emp.statement_log = ls.log       # per statement index: {address: (values [n], address id)} - what each path drew
+        return emp
+
+    def _traces_coroutines(self, num_traces, observe, map_func=None, seed=0, offset=0, likelihood_importance=1.,
+                           *args, **kwargs):
+        """Importance sampling with the inference network for a program AS WRITTEN (`while float(s) >= 1:` ...): one
+        greenlet per particle, parked at `sample` and served in address-grouped batches (pyprob_amd/coroutine.py).
+        Replaces the per-particle loop of pyprob/model.py:59-71. map_func(trace) values like Model._traces; with the
+        default (trace_result) numeric results are stacked into one tensor."""
+        from .coroutine import CoroutineIS
+        net = self._inference_network
+        state._init_traces(func=self.forward, trace_mode=TraceMode.POSTERIOR,
+                           inference_engine=InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
+                           inference_network=net, observe=observe, likelihood_importance=likelihood_importance)
+        co = CoroutineIS(state, self.forward, net, num_traces, seed=seed, offset=offset,
+                         likelihood_importance=likelihood_importance)
+        state._coroutine = co
+        try:
+            results, lw, traces = co.run(*args, **kwargs)
+        finally:
+            state._coroutine = None
+            state._current_trace = None
+        if map_func is None or map_func is trace_result:
+            values = results
+            try:
+                values = torch.stack([torch.as_tensor(r, dtype=torch.float32).reshape(()) for r in results]).to(lw.device)
+            except (RuntimeError, TypeError, ValueError):
+                pass
+        else:
+            values = [map_func(t) for t in traces]
+        if torch.is_tensor(values):
+            values, lw = _drop_non_finite(values, lw)
+        else:
+            ok = torch.isfinite(lw).cpu().numpy()
+            if not ok.all():
+                values = [v for v, k in zip(values, ok) if k]
+                lw = lw[torch.from_numpy(ok).to(lw.device)].contiguous()
+        emp = Empirical(values=values, log_weights=lw)
+        emp.finalize()
+        if torch.is_tensor(values):
+            emp.device_stats = net._is.stats(lw, values)
+        emp.coroutine_stats = dict(rounds=co.rounds, group_calls=co.group_calls, statements=co.statements, seconds=co.seconds)
         return emp
 
     def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, return_types=False,
@@ -167,9 +223,10 @@ class Model:
                           lock_step=None, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
         """pyprob/model.py:106-117,180-181 for the IS engines. With the inference network, lock_step=True runs all
         particles together on the device (one forward() per control-flow path; the program's conditions must be tensor
-        expressions), lock_step=False one particle per forward() like the reference; None (default) = lock step when a
-        probe run of a few particles shows the program allows it (same auto-detection as the vectorised prior of
-        learn_inference_network), else per trace."""
+        expressions); lock_step=False runs the program as written, one greenlet per particle, parked at `sample` and
+        served in address-grouped batches (pyprob_amd/coroutine.py); 'per_trace' is the reference's loop (one particle
+        per forward(), batch-1 network calls). None (default) = lock step when a probe run of a few particles shows the
+        program allows it (same auto-detection as the vectorised prior of learn_inference_network), else coroutines."""
         if inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK:
             if self._inference_network is None:
                 raise RuntimeError('Cannot run inference engine IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK because no '
@@ -180,9 +237,12 @@ class Model:
             if lock_step:
                 post = self._traces_lockstep(num_traces, observe, seed=seed, offset=offset,
                                              likelihood_importance=likelihood_importance, *args, **kwargs)
-            else:
+            elif lock_step == 'per_trace':      # the reference's loop: one particle per forward(), batch-1 network calls
                 post = self._traces(num_traces, TraceMode.POSTERIOR, inference_engine, self._inference_network,
                                     trace_result, observe, likelihood_importance, *args, **kwargs)
+            else:                               # program as written: particle coroutines, address-grouped batches
+                post = self._traces_coroutines(num_traces, observe, trace_result, seed, offset, likelihood_importance,
+                                               *args, **kwargs)
             post.rename('Posterior, IC, traces: {:,}, ESS: {:,.2f}'.format(post.length, post.effective_sample_size))
         else:
             post = self._traces(num_traces, TraceMode.POSTERIOR, inference_engine, None, trace_result, observe,
@@ -204,7 +264,8 @@ class Model:
         offset, count = shard_range(num_traces, dist.get_rank(), dist.get_world_size())
         local = self._traces_lockstep(count, observe, seed=seed, offset=offset,
                                       likelihood_importance=likelihood_importance, *args, **kwargs)
-        values, lw = gather_particles(local._values, local._log_weights, num_traces)
+        values, lw = gather_particles(local._all_values, local._all_log_weights, num_traces)
+        values, lw = _drop_non_finite(values, lw)
         post = Empirical(values=values, log_weights=lw)
         post.device_stats = self._inference_network._is.stats(lw.contiguous(), values.contiguous())
         post.rename('Posterior, IC, traces: {:,}, ESS: {:,.2f}'.format(post.length, post.effective_sample_size))

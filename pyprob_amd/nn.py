@@ -193,6 +193,7 @@ class InferenceNetworkLSTM:
             self._init_layers()
             self._layers_initialized = True
         self._layers_pre_generated = True
+        self._check_dataset_observables(dataset)
         changed = False
         if hasattr(dataset, 'addresses') and hasattr(dataset, 'trace_types'):       # packed dataset: the address table
             new = [a for a in dataset.addresses if a[0] not in self._engine.spec.address_id]
@@ -203,6 +204,19 @@ class InferenceNetworkLSTM:
                 changed |= bool(self._polymorph(Batch([dataset[k] for k in range(i, min(i + batch_size, n))])))
         if changed and save_file_name_prefix is not None:
             self._save('{}_00000000_pre_generated.network'.format(save_file_name_prefix))
+
+    def _check_dataset_observables(self, dataset):
+        """A packed dataset stores the observed values as columns in ITS obs_names order; the kernels read them with the
+        network's layout. Both must name the same observables with the same widths, in the same order."""
+        names = getattr(dataset, 'obs_names', None)
+        if names is None or not hasattr(dataset, 'obs_width'):
+            return
+        widths = [int(w) for w in getattr(dataset, 'obs_widths', None) or []]
+        want = [o[1] for o in self._engine.spec.obs]
+        if list(names) != list(self._obs_names) or (widths and widths != want) or int(dataset.obs_width) != sum(want):
+            raise ValueError('dataset observables {} (widths {}) do not match the observe embeddings of the inference '
+                             'network {} (widths {}); write the dataset with save_dataset(obs_names={})'.format(
+                                 list(names), widths, list(self._obs_names), want, list(self._obs_names)))
 
     # ---- training loss --------------------------------------------------------------------------------------
     def _pack(self, batch):
@@ -337,23 +351,20 @@ class InferenceNetworkLSTM:
         return ParticleTensor.wrap(values)
 
     def _accumulate_prior(self, ls, distribution, value):
-        dev = self._engine.device
-        if distribution.name == 'Normal':
-            kind, p0, p1 = 0, distribution.mean, distribution.stddev
-        elif distribution.name == 'Uniform':
-            kind, p0, p1 = 1, distribution.low, distribution.high
-        else:   # e.g. Categorical: scored on the host
-            lp = distribution.log_prob(value.cpu()).to(dev, torch.float32).contiguous()
+        """+ log p(value) of the program's own prior (state.py:211), on the device for the families with a kernel."""
+        term = ls.runner.dist_term(distribution)
+        if term is None:   # a family without a device kernel: scored on the host
+            lp = distribution.log_prob(value.cpu()).to(self._engine.device, torch.float32).contiguous()
             if ls.active is not None:
                 lp = torch.where(ls.active, lp, torch.zeros_like(lp))
             ls.runner.axpy(ls.lw, 1.0, lp)
             return
-        ls.runner.accumulate_masked(ls.lw, kind, torch.as_tensor(p0).reshape(-1).to(dev), torch.as_tensor(p1).reshape(-1).to(dev),
-                                    value, ls.active)
+        ls.runner.accumulate_masked(ls.lw, None, None, None, value, ls.active, term=term)
 
     def _validation_loss(self, dataset_valid, batch_size):
         """Mean `_loss` over the minibatches of a packed validation dataset, forward only (inference_network.py:538-543);
         a minibatch with an address the network does not know is skipped like `_loss` returning (False, 0)."""
+        self._check_dataset_observables(dataset_valid)
         sampler = dataset_valid.sampler(min(batch_size, len(dataset_valid)), 0, 1, None, False, False)
         total, n = None, 0
         for ids in sampler:
@@ -391,6 +402,7 @@ class InferenceNetworkLSTM:
             self._init_layers_observe_embedding(self._observe_embeddings, example_trace=dataset[0])
             self._init_layers()
             self._layers_initialized = True
+        self._check_dataset_observables(dataset)
         world, rank = 1, 0
         if distributed_backend is not None:
             import torch.distributed as dist
@@ -648,12 +660,26 @@ class InferenceNetworkLSTM:
     def state_dict(self):
         return self._engine.state_dict()
 
+    # training state that survives a save / load like the reference's pickled module (inference_network.py:162-196)
+    _PERSISTED = ('_learning_rate_init', '_learning_rate_end', '_learning_rate_scheduler_type', '_weight_decay',
+                  '_total_train_seconds', '_total_train_traces', '_total_train_traces_end', '_total_train_iterations',
+                  '_loss_init', '_loss_min', '_loss_max', '_loss_previous', '_history_train_loss', '_history_valid_loss',
+                  '_history_valid_loss_trace', '_history_train_loss_trace', '_history_num_params',
+                  '_history_num_params_trace', '_layers_pre_generated', '_distributed_world_size')
+
     def _save(self, file_name):
         spec = self._engine.spec
+        sched = self._learning_rate_scheduler_type
+        state = {k: getattr(self, k) for k in self._PERSISTED}
+        state['_learning_rate_scheduler_type'] = None if sched is None else str(sched).split('.')[-1].upper()
         torch.save(dict(state_dict=self.state_dict(), obs_spec=self._obs_spec, lstm_dim=self._lstm_dim, network=self._network,
                         K=self._proposal_mixture_components,
+                        dims=dict(sample_embedding_dim=self._sample_embedding_dim,
+                                  address_embedding_dim=self._address_embedding_dim,
+                                  distribution_type_embedding_dim=self._distribution_type_embedding_dim),
                         addresses=[(a.address, a.dist_name, a.num_categories, a.total_train_iterations) for a in spec.addresses],
                         total_train_traces=self._total_train_traces, total_train_iterations=self._total_train_iterations,
+                        train_state=state,
                         exp_avg=self._engine.exp_avg.cpu(), exp_avg_sq=self._engine.exp_avg_sq.cpu(),
                         tensor_step=self._engine.tensor_step.cpu()), file_name)
 
@@ -661,7 +687,8 @@ class InferenceNetworkLSTM:
     def _load(file_name, device='cuda:0'):
         d = torch.load(file_name, weights_only=False)
         cls = InferenceNetworkFeedForward if d.get('network', 'lstm') == 'feedforward' else InferenceNetworkLSTM
-        net = cls(observe_embeddings=d['obs_spec'], lstm_dim=d['lstm_dim'], proposal_mixture_components=d['K'], device=device)
+        net = cls(observe_embeddings=d['obs_spec'], lstm_dim=d['lstm_dim'], proposal_mixture_components=d['K'], device=device,
+                  **d.get('dims', {}))
         net._obs_spec = d['obs_spec']
         net._obs_names = list(d['obs_spec'].keys())
         net._init_layers()
@@ -675,6 +702,8 @@ class InferenceNetworkLSTM:
         net._engine.tensor_step.copy_(d['tensor_step'])
         net._total_train_traces = d['total_train_traces']
         net._total_train_iterations = d['total_train_iterations']
+        for k, v in d.get('train_state', {}).items():      # (files written before the training state was persisted lack it)
+            setattr(net, k, v)
         return net
 
 

@@ -1,0 +1,276 @@
+"""PyTorch-ROCm custom operators over the C ABI (SURVEY.md §8b seam B3): `torch.ops.pyprob_hip.*`.
+
+Each operator is a thin wrapper over ONE `extern "C"` entry point of libpyprob_amd.so (include/pyprob_amd.h): it checks
+shapes / dtypes / contiguity / device, passes the tensors' device pointers and torch's current HIP stream, and turns a
+non-zero return code into a RuntimeError. All buffers are PyTorch-owned tensors (caching allocator); the kernels never
+allocate. Only the device ("CUDA" dispatch key = HIP on ROCm) implementation exists in the product: calling an operator
+with CPU tensors fails in the dispatcher - there is no CPU fallback. (The CPU test-suite registers oracle-backed "CPU"
+kernels for these operators from tests/, to execute the host logic above them without a GPU.)
+
+    ic_loss      InferenceNetworkLSTM._loss (+ backward)            pyprob/nn/inference_network_lstm.py:136-220
+    adam_step    optim.Adam.step over the flat buffer                pyprob/nn/inference_network.py:348,496
+    is_init      InferenceNetwork._infer_init                        pyprob/nn/inference_network.py:141-148
+    is_step      _infer_step + proposal.sample() + log_prob          pyprob/nn/inference_network_lstm.py:82-134,
+                                                                     pyprob/state.py:207-212
+    log_prob     prior / likelihood log_prob terms of the log-weight pyprob/state.py:211, 147-149
+
+Non-tensor state travels as follows: the network description (`pp_net`, host struct with offsets into the flat
+parameter buffer) is registered once per layer set with `register_net` and referenced by an integer handle; the
+host-side arrays of a packed minibatch (`pp_batch.n_active / row_off / grp_off / nxt_off`) travel as one small CPU int32
+tensor next to the device buffer (`PackedBatch.op_tensors`).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+NAMESPACE = 'pyprob_hip'
+
+_lib = torch.library.Library(NAMESPACE, 'DEF')
+_lib.define('ic_loss(Tensor params, Tensor(a!) grads, Tensor(b!) workspace, Tensor batch_dev, Tensor batch_host, int net, '
+            'int flags) -> (Tensor, Tensor, Tensor)')
+_lib.define('adam_step(Tensor(a!) params, Tensor(b!) grads, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, Tensor chunk_tensor, '
+            'Tensor active, Tensor(e!) tensor_step, Tensor(f!) scratch, float lr, float beta1, float beta2, float eps, '
+            'float weight_decay, float grad_scale, int flags, Tensor? skip) -> ()')
+_lib.define('is_init(Tensor params, Tensor(a!) workspace, int net, Tensor obs) -> Tensor')
+_lib.define('is_step(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
+            'Tensor? prev_value, Tensor? prior, Tensor(b!) h, Tensor(c!) c, int state_rows, Tensor? value_in, int seed, '
+            'int offset) -> (Tensor, Tensor)')
+_lib.define('log_prob(int kind, Tensor p0, int p0_stride, Tensor? p1, int p1_stride, Tensor x, int n) -> Tensor')
+_lib.define('logweight_terms(Tensor(a!) lw, int[] kinds, Tensor?[] p0, int[] p0_strides, Tensor?[] p1, int[] p1_strides, '
+            'Tensor[] x, float[] scales, bool overwrite) -> ()')
+_lib.define('is_stats(Tensor lw, Tensor? x, Tensor(a!) scratch) -> Tensor')
+
+# ---- network registry -------------------------------------------------------------------------------------------
+_NETS = {}
+_next_handle = [1]
+
+
+def register_net(net_struct, spec):
+    """Make a pp_net (ctypes struct built by NetSpec.c_struct) addressable from operator calls. Returns the handle."""
+    h = _next_handle[0]
+    _next_handle[0] += 1
+    _NETS[h] = (net_struct, spec)
+    return h
+
+
+def unregister_net(handle):
+    _NETS.pop(handle, None)
+
+
+def net_struct(handle):
+    return _NETS[handle][0]
+
+
+def net_spec(handle):
+    return _NETS[handle][1]
+
+
+# ---- packed batch <-> (device buffer, host int32 descriptor) --------------------------------------------------------
+BH_FIXED = 16
+_BH_COLS = ('obs', 'value', 'prior', 'addr', 'prev_row', 'grp_rows', 'trace', 'row_off_dev', 'nxt_rows')
+
+
+def batch_descriptor(n_traces, n_rows, t_max, obs_width, n_addr, offsets, n_active, row_off, grp_off, nxt_off):
+    """CPU int32 tensor: [B, R, T, obs_width, n_addr, 9 word offsets into the device buffer (pp_batch device columns in
+    _BH_COLS order), pad to 16 | n_active [T] | row_off [T+1] | grp_off [n_addr+1] | nxt_off [n_addr+1]]."""
+    head = np.zeros(BH_FIXED, np.int32)
+    head[:5] = (n_traces, n_rows, t_max, obs_width, n_addr)
+    head[5:5 + len(_BH_COLS)] = [offsets[k] for k in _BH_COLS]
+    arr = np.concatenate([head, np.asarray(n_active, np.int32), np.asarray(row_off, np.int32),
+                          np.asarray(grp_off, np.int32), np.asarray(nxt_off, np.int32)])
+    return torch.from_numpy(arr)
+
+
+def _batch_struct(batch_dev, batch_host):
+    bh = batch_host.numpy()
+    B, R, T, W, A = (int(v) for v in bh[:5])
+    if bh.size != BH_FIXED + T + (T + 1) + 2 * (A + 1):
+        raise RuntimeError('pyprob_hip: malformed batch descriptor')
+    c = L.pp_batch()
+    c.n_traces, c.n_rows, c.t_max, c.obs_width = B, R, T, W
+    base = batch_dev.data_ptr()
+    for i, k in enumerate(_BH_COLS):
+        setattr(c, k, base + 4 * int(bh[5 + i]))
+    ip = C.POINTER(C.c_int32)
+    o = BH_FIXED
+    host = np.ascontiguousarray(bh[o:], np.int32)          # kept alive by the caller until the C call returns
+    p = host.ctypes.data
+    c.n_active = C.cast(p, ip)
+    c.row_off = C.cast(p + 4 * T, ip)
+    c.grp_off = C.cast(p + 4 * (2 * T + 1), ip)
+    c.nxt_off = C.cast(p + 4 * (2 * T + 1 + A + 1), ip)
+    return c, host, (B, R, T, W, A)
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError('pyprob_hip: %s must be a contiguous float32 tensor' % name)
+    return t
+
+
+def _same_device(ref, *tensors):
+    for t in tensors:
+        if t is not None and t.device != ref.device:
+            raise RuntimeError('pyprob_hip: tensors on different devices (%s, %s)' % (ref.device, t.device))
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# ---- device implementations ("CUDA" dispatch key = HIP) ---------------------------------------------------------------
+def _ic_loss_hip(params, grads, workspace, batch_dev, batch_host, net, flags):
+    lib = L.load()
+    netc = net_struct(net)
+    _f32(params, 'params')
+    _same_device(params, grads, workspace, batch_dev)
+    if params.numel() < netc.n_params:
+        raise RuntimeError('pyprob_hip::ic_loss: parameter buffer smaller than the network (%d < %d)'
+                           % (params.numel(), netc.n_params))
+    bwd = bool(flags & L.PP_LOSS_BACKWARD)
+    if bwd and (_f32(grads, 'grads').numel() < netc.n_params):
+        raise RuntimeError('pyprob_hip::ic_loss: gradient buffer smaller than the network')
+    c, keep, (B, R, T, W, A) = _batch_struct(batch_dev, batch_host)
+    need = lib.pp_ic_workspace_bytes(C.byref(netc), B, R)
+    ws_bytes = workspace.numel() * workspace.element_size()
+    if need == 0 or ws_bytes < need:
+        raise RuntimeError('pyprob_hip::ic_loss: workspace too small (%d < %d bytes)' % (ws_bytes, need))
+    loss = torch.empty(1, dtype=torch.float32, device=params.device)
+    status = torch.zeros(1, dtype=torch.int32, device=params.device)
+    lp = torch.empty(R if (flags & L.PP_LOSS_KEEP_LP) else 0, dtype=torch.float32, device=params.device)
+    with torch.cuda.device(params.device):
+        rc = lib.pp_ic_loss(C.byref(netc), C.byref(c), params.data_ptr(), grads.data_ptr() if bwd else None,
+                            workspace.data_ptr(), ws_bytes, loss.data_ptr(), status.data_ptr(),
+                            lp.data_ptr() if lp.numel() else None, int(flags), _stream(params))
+    L.check(rc, 'pp_ic_loss')
+    del keep
+    return loss, status, lp
+
+
+def _adam_step_hip(params, grads, exp_avg, exp_avg_sq, chunk_tensor, active, tensor_step, scratch, lr, beta1, beta2, eps,
+                   weight_decay, grad_scale, flags, skip):
+    lib = L.load()
+    n = params.numel()
+    for t, name in ((params, 'params'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq'), (active, 'active')):
+        _f32(t, name)
+    _same_device(params, grads, exp_avg, exp_avg_sq, chunk_tensor, active, tensor_step, scratch, skip)
+    if min(grads.numel(), exp_avg.numel(), exp_avg_sq.numel()) < n or chunk_tensor.numel() * 1024 != n:
+        raise RuntimeError('pyprob_hip::adam_step: buffer sizes do not match the parameter buffer')
+    n_tensors = tensor_step.numel()
+    if active.numel() < n_tensors or scratch.numel() < L.PP_ADAM_SCRATCH * n_tensors:
+        raise RuntimeError('pyprob_hip::adam_step: per-tensor arrays too small')
+    with torch.cuda.device(params.device):
+        rc = lib.pp_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                              chunk_tensor.data_ptr(), active.data_ptr(), tensor_step.data_ptr(), scratch.data_ptr(),
+                              n_tensors, lr, beta1, beta2, eps, weight_decay, grad_scale, int(flags), L.ptr(skip),
+                              _stream(params))
+    L.check(rc, 'pp_adam_step')
+
+
+def _is_ws(lib, netc, workspace, n):
+    need = lib.pp_is_workspace_bytes(C.byref(netc), n)
+    have = workspace.numel() * workspace.element_size()
+    if have < need:
+        raise RuntimeError('pyprob_hip: importance-sampling workspace too small (%d < %d bytes)' % (have, need))
+    return have
+
+
+def _is_init_hip(params, workspace, net, obs):
+    lib = L.load()
+    netc = net_struct(net)
+    _same_device(params, workspace, obs)
+    ws_bytes = _is_ws(lib, netc, workspace, 1)
+    if _f32(obs, 'obs').numel() != sum(netc.obs_in[o] for o in range(netc.n_obs)):
+        raise RuntimeError('pyprob_hip::is_init: observe has %d values, the network expects %d'
+                           % (obs.numel(), sum(netc.obs_in[o] for o in range(netc.n_obs))))
+    e = torch.zeros(netc.e_obs + 8, dtype=torch.float32, device=params.device)
+    with torch.cuda.device(params.device):
+        rc = lib.pp_is_init(C.byref(netc), params.data_ptr(), obs.data_ptr(), e.data_ptr(), workspace.data_ptr(), ws_bytes,
+                            _stream(params))
+    L.check(rc, 'pp_is_init')
+    return e
+
+
+def _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, prior, h, c, state_rows, value_in, seed,
+                 offset):
+    lib = L.load()
+    netc = net_struct(net)
+    _same_device(params, workspace, e_obs, prev_value, prior, h, c, value_in)
+    ws_bytes = _is_ws(lib, netc, workspace, n)
+    if not (0 <= addr_id < netc.n_addr) or prev_addr_id >= netc.n_addr:
+        raise RuntimeError('pyprob_hip::is_step: address id out of range')
+    H = netc.lstm_dim
+    if H > 0 and (h.numel() < n * H or c.numel() < n * H):
+        raise RuntimeError('pyprob_hip::is_step: LSTM state smaller than [n, H]')
+    stride = 0
+    if prior is not None:
+        _f32(prior, 'prior')
+        stride = 0 if prior.numel() == 2 else 1
+        if stride and prior.numel() < 2 * n:
+            raise RuntimeError('pyprob_hip::is_step: prior must be [1, 2] or [n, 2]')
+    for t, name in ((prev_value, 'prev_value'), (value_in, 'value_in')):
+        if t is not None and _f32(t, name).numel() < n:
+            raise RuntimeError('pyprob_hip::is_step: %s shorter than n' % name)
+    value = torch.empty(n, dtype=torch.float32, device=params.device)
+    logq = torch.empty(n, dtype=torch.float32, device=params.device)
+    with torch.cuda.device(params.device):
+        rc = lib.pp_is_step(C.byref(netc), params.data_ptr(), int(addr_id), int(prev_addr_id), int(n), e_obs.data_ptr(),
+                            L.ptr(prev_value), L.ptr(prior), stride, L.ptr(h), L.ptr(c), int(state_rows), L.ptr(value_in),
+                            value.data_ptr(), logq.data_ptr(), int(seed), int(offset), workspace.data_ptr(), ws_bytes,
+                            _stream(params))
+    L.check(rc, 'pp_is_step')
+    return value, logq
+
+
+def _log_prob_hip(kind, p0, p0_stride, p1, p1_stride, x, n):
+    lib = L.load()
+    _same_device(x, p0, p1)
+    lp = torch.empty(n, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.pp_logweight_accumulate(int(kind), _f32(p0, 'p0').data_ptr(), int(p0_stride), L.ptr(p1), int(p1_stride),
+                                         _f32(x, 'x').data_ptr(), 0 if x.numel() == 1 else 1, 1.0, None, lp.data_ptr(), int(n),
+                                         _stream(x))
+    L.check(rc, 'pp_logweight_accumulate')
+    return lp
+
+
+def _logweight_terms_hip(lw, kinds, p0, p0_strides, p1, p1_strides, x, scales, overwrite):
+    lib = L.load()
+    count = len(kinds)
+    arr = (L.pp_lw_term * count)()
+    for q in range(count):
+        _same_device(lw, p0[q], p1[q], x[q])
+        arr[q].kind = int(kinds[q])
+        arr[q].p0, arr[q].p1, arr[q].x = L.ptr(p0[q]), L.ptr(p1[q]), x[q].data_ptr()
+        arr[q].p0_stride, arr[q].p1_stride = int(p0_strides[q]), int(p1_strides[q])
+        arr[q].x_stride = 0 if x[q].numel() == 1 else 1
+        arr[q].scale = float(scales[q])
+    with torch.cuda.device(lw.device):
+        rc = lib.pp_logweight_terms(arr, count, _f32(lw, 'lw').data_ptr(), lw.numel(), 1 if overwrite else 0, _stream(lw))
+    L.check(rc, 'pp_logweight_terms')
+
+
+def _is_stats_hip(lw, x, scratch):
+    lib = L.load()
+    _same_device(lw, x, scratch)
+    if scratch.dtype != torch.float64 or scratch.numel() < L.PP_IS_STATS_SCRATCH:
+        raise RuntimeError('pyprob_hip::is_stats: scratch must hold PP_IS_STATS_SCRATCH doubles')
+    out = torch.zeros(8, dtype=torch.float64, device=lw.device)
+    with torch.cuda.device(lw.device):
+        rc = lib.pp_is_stats(_f32(lw, 'lw').data_ptr(), L.ptr(x), lw.numel(), out.data_ptr(), scratch.data_ptr(), _stream(lw))
+    L.check(rc, 'pp_is_stats')
+    return out
+
+
+_lib.impl('ic_loss', _ic_loss_hip, 'CUDA')
+_lib.impl('adam_step', _adam_step_hip, 'CUDA')
+_lib.impl('is_init', _is_init_hip, 'CUDA')
+_lib.impl('is_step', _is_step_hip, 'CUDA')
+_lib.impl('log_prob', _log_prob_hip, 'CUDA')
+_lib.impl('logweight_terms', _logweight_terms_hip, 'CUDA')
+_lib.impl('is_stats', _is_stats_hip, 'CUDA')
+
+ops = getattr(torch.ops, NAMESPACE)

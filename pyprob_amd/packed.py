@@ -171,6 +171,20 @@ class PackedBatch:
         self._fill_struct(ow)
         return self
 
+    def op_tensors(self, device):
+        """(device buffer, CPU int32 descriptor) for the `pyprob_hip::ic_loss` operator (pyprob_amd/ops.py)."""
+        from . import ops
+        if self.dev is None:
+            self.to(device)
+        buf = self.dev.get('_buf')
+        if buf is None:
+            raise RuntimeError('op_tensors needs a batch that was uploaded as one buffer (PackedBatch.to)')
+        base = buf.data_ptr()
+        offsets = {k: (self.dev[k].data_ptr() - base) // 4 for k in ops._BH_COLS}
+        desc = ops.batch_descriptor(self.n_traces, self.n_rows, self.t_max, self.dev['obs'].shape[1], self.n_addr, offsets,
+                                    self.n_active, self.row_off, self.grp_off, self.nxt_off)
+        return buf, desc
+
     def _fill_struct(self, obs_width):
         d = self.dev
         c = L.pp_batch()

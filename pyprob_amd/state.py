@@ -15,6 +15,7 @@ Module-global trace state, `sample` / `observe`, address extraction from the cal
 MCMC engines, `tag`/`factor` and the address dictionary are out of scope.
 """
 import enum
+import opcode
 import sys
 import time
 
@@ -69,6 +70,7 @@ _current_trace_previous_variable = None
 _current_trace_observed_variables = {}
 _current_trace_execution_start = None
 _lock_step = None      # LockStepState when N particles advance together
+_coroutine = None      # coroutine.CoroutineIS while particle coroutines run an unmodified program (one greenlet per particle)
 
 
 def _make_address(distribution, address):
@@ -80,13 +82,57 @@ def _make_address(distribution, address):
     return base, base + '__' + str(instance), instance
 
 
+_STORE_FAST, _STORE_NAME, _STORE_GLOBAL = (opcode.opmap[n] for n in ('STORE_FAST', 'STORE_NAME', 'STORE_GLOBAL'))
+_LOAD_FAST, _LOAD_NAME, _LOAD_GLOBAL, _LOAD_CONST = (opcode.opmap[n] for n in ('LOAD_FAST', 'LOAD_NAME', 'LOAD_GLOBAL', 'LOAD_CONST'))
+_STORE_SUBSCR, _RETURN_VALUE = opcode.opmap['STORE_SUBSCR'], opcode.opmap['RETURN_VALUE']
+_target_cache = {}      # (code object, f_lasti) -> name of the assignment target, or a resolver for subscripted targets
+
+
+def _assignment_target(frame):
+    """What the value of the `sample` / `observe` call at frame.f_lasti is assigned to: the reference puts this name into
+    the address (pyprob/state.py:29-83), so it is part of the checkpoint format. `x = sample(..)` -> 'x'; `a[3] = ..` /
+    `a[i] = ..` (int i) -> 'a[3]'; `return sample(..)` -> 'return'; anything else -> '?'. CPython >= 3.6 word code:
+    the instruction after the call sits at f_lasti + 2. Decoded once per call site."""
+    code, at = frame.f_code, frame.f_lasti
+    key = (code, at)
+    hit = _target_cache.get(key)
+    if hit is None:
+        co = code.co_code
+        op = co[at + 2] if at + 2 < len(co) else -1
+        arg = co[at + 3] if at + 3 < len(co) else 0
+        hit = '?'
+        if op == _STORE_FAST:
+            hit = code.co_varnames[arg]
+        elif op in (_STORE_NAME, _STORE_GLOBAL):
+            hit = code.co_names[arg]
+        elif op == _RETURN_VALUE:
+            hit = 'return'
+        elif op in (_LOAD_FAST, _LOAD_NAME, _LOAD_GLOBAL) and at + 6 < len(co) and co[at + 6] == _STORE_SUBSCR \
+                and co[at + 4] in (_LOAD_CONST, _LOAD_FAST):
+            base = (code.co_varnames if op == _LOAD_FAST else code.co_names)[arg]
+            if co[at + 4] == _LOAD_CONST:
+                index = code.co_consts[co[at + 5]]
+                hit = base + '[' + str(index) + ']' if type(index) is int else '?'
+            else:
+                hit = (base, code.co_varnames[co[at + 5]])      # the index is a local: resolved per call
+        _target_cache[key] = hit
+    if type(hit) is tuple:
+        index = frame.f_locals[hit[1]]
+        return hit[0] + '[' + str(index) + ']' if type(index) is int else '?'
+    return hit
+
+
 def _extract_address_from_caller():
+    """'<instruction offset>__<root function>__..__<calling function>__<assignment target>' exactly as the reference
+    builds it (pyprob/state.py:29-47), so that networks and datasets interchange."""
     # one extra frame because of _make_address
     frame = sys._getframe(3)
     ip = frame.f_lasti
-    names = []
+    names = [_assignment_target(frame)]
     while frame is not None:
         n = frame.f_code.co_name
+        if n.startswith('<') and n != '<listcomp>':
+            break
         names.append(n)
         if n == _current_trace_root_function_name:
             break
@@ -385,6 +431,20 @@ class PriorLockStep(PathExecutor):
         return out + ((np.concatenate(type_of), seqs),) if return_types else out
 
 
+def _lock_step_likelihood(distribution, value):
+    """lw += likelihood_importance * log p(value | .) for the active particles of a lock-step IS run (state.py:147-149;
+    also the 'Variable is observed' branch of state.sample, :175-180). A replayed prefix has already been scored."""
+    ls = _lock_step
+    v = torch.as_tensor(value, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(ls.runner.dev)
+    ls.observes += 1
+    if ls.observes <= ls.replay_observes:
+        return
+    term = ls.runner.dist_term(distribution)
+    if term is None:
+        raise RuntimeError('lock-step importance sampling has no device likelihood for {}'.format(distribution.name))
+    ls.runner.accumulate_masked(ls.lw, None, None, None, v, ls.active, scale=_likelihood_importance, term=term)
+
+
 def observe(distribution, value=None, name=None, address=None):
     """state.observe, pyprob/state.py:118-155."""
     if _current_trace is None:
@@ -402,21 +462,13 @@ def observe(distribution, value=None, name=None, address=None):
         given = _current_trace_observed_variables.get(name) if name in _current_trace_observed_variables else (
             None if value is None else value)
         return _lock_step.observe_statement(name, distribution, given)
+    if _coroutine is not None and value is not None and _trace_mode == TraceMode.POSTERIOR:
+        _coroutine.observe(distribution, value)       # the weight term joins the next round's likelihood kernels
+        _current_trace.add(Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                                    log_prob=None, log_importance_weight=None, observed=True, name=name))
+        return value
     if _lock_step is not None and value is not None:
-        ls = _lock_step
-        dev = ls.runner.dev
-        v = torch.as_tensor(value, dtype=torch.float32).reshape(-1).to(dev)
-        ls.observes += 1
-        if ls.observes > ls.replay_observes:      # (a replayed prefix has already been scored for these particles)
-            if isinstance(distribution, Normal):
-                kind, p0, p1 = 0, distribution.mean, distribution.stddev
-            elif isinstance(distribution, Uniform):
-                kind, p0, p1 = 1, distribution.low, distribution.high
-            else:
-                raise RuntimeError('lock-step importance sampling supports Normal and Uniform likelihoods; got {}'.format(
-                    distribution.name))
-            ls.runner.accumulate_masked(ls.lw, kind, torch.as_tensor(p0).reshape(-1).to(dev), torch.as_tensor(p1).reshape(-1).to(dev),
-                                        v, ls.active, scale=_likelihood_importance)
+        _lock_step_likelihood(distribution, value)
         variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
                             log_prob=None, log_importance_weight=None, observed=True, name=name)
         _current_trace.add(variable)
@@ -439,6 +491,19 @@ def sample(distribution, name=None, address=None, control=True):
     if _current_trace is None:
         return distribution.sample()
     base, addr, instance = _make_address(distribution, address)
+    if name in _current_trace_observed_variables and _coroutine is not None and _trace_mode == TraceMode.POSTERIOR:
+        value = torch.as_tensor(_current_trace_observed_variables[name], dtype=torch.float32)
+        _coroutine.observe(distribution, value)
+        _current_trace.add(Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                                    log_prob=None, log_importance_weight=None, observed=True, name=name))
+        return value
+    if name in _current_trace_observed_variables and _lock_step is not None and _lock_step.mode == 'is':
+        # an observed `sample` in a lock-step run: its likelihood joins every particle's log-weight like observe()
+        value = torch.as_tensor(_current_trace_observed_variables[name], dtype=torch.float32)
+        _lock_step_likelihood(distribution, value)
+        _current_trace.add(Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                                    log_prob=None, log_importance_weight=None, observed=True, name=name))
+        return value
     if name in _current_trace_observed_variables:
         value = _current_trace_observed_variables[name]
         log_prob = _likelihood_importance * distribution.log_prob(value, sum=True)
@@ -466,6 +531,8 @@ def sample(distribution, name=None, address=None, control=True):
         return value
 
     log_importance_weight = None
+    if ic and _coroutine is not None:
+        return _coroutine.sample(distribution, base, addr, instance, name)     # parks until the statement is served
     if ic:
         variable = Variable(distribution=distribution, value=None, address_base=base, address=addr, instance=instance,
                             log_prob=0., control=control, name=name)

@@ -60,7 +60,8 @@ class Trace:
         self.variables_observed = [v for v in self.variables if v.observed]
         self.log_prob = sum(float(torch.sum(v.log_prob)) for v in self.variables
                             if (v.control or v.observed) and v.log_prob is not None)
-        self.log_prob_observed = sum(float(torch.sum(v.log_prob)) for v in self.variables_observed)
+        # (log_prob is None for terms that were scored in batch on the device: lock-step / coroutine runs)
+        self.log_prob_observed = sum(float(torch.sum(v.log_prob)) for v in self.variables_observed if v.log_prob is not None)
         self.length = len(self.variables)
         self.length_controlled = len(self.variables_controlled)
         for v in self.variables:
