@@ -130,9 +130,10 @@ def test_sampler_partitions_like_the_reference(tmp_path):
 
 
 class _Spec:
-    def __init__(self, addresses):
+    def __init__(self, addresses, obs=(('obs0', 1, 4, 8), ('obs1', 1, 4, 8))):
         self.addresses = addresses
         self.address_id = {a[0]: i for i, a in enumerate(addresses)}
+        self.obs = list(obs)          # (name, input width, hidden, output) like NetSpec.obs
 
 
 def test_batch_matches_from_ragged_and_loader_prefetches(tmp_path):
@@ -323,11 +324,33 @@ def test_validation_loss_averages_the_minibatch_losses(tmp_path):
         def loss(self, pb):
             self.seen.append(pb.n_traces)
             return torch.tensor([float(pb.n_rows) / pb.n_traces])
-    net = InferenceNetworkLSTM(observe_embeddings={'obs0': {'dim': 8}})
+    net = InferenceNetworkLSTM(observe_embeddings={'obs0': {'dim': 8}, 'obs1': {'dim': 8}})
     net._engine = FakeEngine()
+    net._obs_names = ['obs0', 'obs1']
     got = net._validation_loss(ds, 64)
     assert FakeEngine.seen == [64, 64, 64, 64]                       # 300 // 64 full minibatches, sorted order
     lens = ds.trace_len[ds.sorted_indices()[:256]].reshape(4, 64)
     assert abs(got - float(np.mean(lens.mean(1)))) < 1e-6
     net._engine.spec = _Spec(list(ds.addresses)[:1])                # the network knows only the first address
     assert np.isnan(net._validation_loss(ds, 64)) or net._validation_loss(ds, 64) > 0
+    # a dataset whose observable columns are not the network's (order, names or widths) is refused, not mis-read
+    net._obs_names = ['obs1', 'obs0']
+    with pytest.raises(ValueError, match='do not match the observe embeddings'):
+        net._validation_loss(ds, 64)
+
+
+def test_save_dataset_detects_observed_variables_only(tmp_path):
+    """Auto-detected observables are the variables recorded by observe(), not every NAMED variable: a named latent
+    sample must not become an input column of the inference network."""
+    import pyprob_amd as pyprob
+    from pyprob_amd.distributions import Normal
+    from pyprob_amd.model import Model
+
+    class NamedLatent(Model):
+        def forward(self):
+            mu = pyprob.sample(Normal(0., 1.), name='mu')
+            pyprob.observe(Normal(mu, 1.), name='obs')
+            return mu
+    NamedLatent().save_dataset(str(tmp_path / 'd'), 50, 50)
+    ds = PackedTraceDataset(str(tmp_path / 'd'))
+    assert ds.obs_names == ['obs'] and ds.obs_width == 1
