@@ -64,102 +64,64 @@ class _Params:
             raise RuntimeError('Distribution currently unsupported: {}'.format(name))
 
 
-class CoroutineIS:
-    """One posterior run of `num_traces` particle coroutines over the trace runtime `state` (pyprob_amd.state).
-    `run()` returns (results, log_weights [n] device tensor, traces): results[i] = forward()'s return value of particle i."""
+class ParticleScheduler:
+    """N particle greenlets over one ISRunner: particles park with a request (address id, previous address id, prior
+    distribution); when all live particles are parked the scheduler serves the requests in groups of equal (address,
+    previous address) - one pp_is_step per group on the gathered LSTM rows - and resumes them. Subclasses decide what a
+    served particle receives (`_reply`) and what else happens per group (`_after_group`)."""
 
-    def __init__(self, state, forward, network, num_traces, seed=0, offset=0, likelihood_importance=1.0):
+    def __init__(self, runner, spec, num_traces, seed=0, offset=0):
         import greenlet
         self._greenlet = greenlet
-        self.state = state
-        self.forward = forward
-        self.net = network
-        self.runner = network._is
-        self.spec = network._engine.spec
+        self.runner = runner
+        self.spec = spec
         self.n = int(num_traces)
         self.seed, self.offset = int(seed), int(offset)
-        self.scale = float(likelihood_importance)
-        self.dev = self.runner.dev
-        self.lw = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
+        self.dev = runner.dev
         self.last_value = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
         self.current = None
         self.hub = None
-        self.likelihoods = []          # (pid, distribution, value) queued by observe since the last round
         self.rounds = 0
         self.group_calls = 0
         self.statements = 0
         self.seconds = 0.0
 
-    # ---- called from state.sample / state.observe inside a particle ------------------------------------------------
-    def sample(self, distribution, base, addr, instance, name):
-        """The IC branch of state.sample (state.py:203-219) for the particle that is running: park until the scheduler
-        has served this statement, then record the variable like the reference does."""
-        from .trace import Variable
-        state = self.state
-        p = self.current
-        prev = state._current_trace_previous_variable
+    def resolve(self, address, prev_address):
+        """(address id, previous address id) of a statement, or None when the network has no layers for the address or
+        for the previous one (the prior is then the proposal, inference_network_lstm.py:100-104, 132-134)."""
         spec = self.spec
-        if spec.feedforward:            # inference_network_feedforward.py:52-66: no state, no previous variable
-            prev_known, prev_a = True, None
-        else:
-            prev_known = prev is None or prev.address in spec.address_id
-            prev_a = None if (prev is None or not prev_known) else spec.address_id[prev.address]
-        if addr not in spec.address_id or not prev_known:
-            # no proposal layers for this address (or the previous one): the prior is the proposal and
-            # log p - log q = 0 (inference_network_lstm.py:100-104, 132-134); the LSTM state is not advanced
-            warnings.warn('Using prior. No proposal for address: {}'.format(addr))
-            value = distribution.sample()
-            if value.dim() > 0:
-                value = value[0]
-            variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
-                                log_prob=distribution.log_prob(value, sum=True), log_importance_weight=0.0, control=True,
-                                name=name)
-            p.prev_host_value = float(value)
-            state._current_trace.add(variable)
-            state._current_trace_previous_variable = variable
-            return variable.value
-        variable = Variable(distribution=distribution, value=None, address_base=base, address=addr, instance=instance,
-                            log_prob=0., control=True, name=name)
-        p.request = (spec.address_id[addr], prev_a, distribution)
-        ctx = (state._current_trace, state._current_trace_execution_start)
-        self.hub.switch()                                   # ---- parked; the scheduler serves the statement ----
-        state._current_trace, state._current_trace_execution_start = ctx
-        variable.value, variable.log_prob = p.reply
-        p.reply = None
-        state._current_trace.add(variable)
-        state._current_trace_previous_variable = variable      # (no other particle runs between here and the next park)
-        return variable.value
+        a = spec.address_id.get(address)
+        if a is None:
+            return None
+        if spec.feedforward or prev_address is None:      # inference_network_feedforward.py:52-66: no previous variable
+            return a, None
+        prev_a = spec.address_id.get(prev_address)
+        return None if prev_a is None else (a, prev_a)
 
-    def observe(self, distribution, value):
-        """state.observe's weight term (state.py:147-149), deferred to the next round's likelihood kernels."""
-        self.likelihoods.append((self.current.pid, distribution, value))
+    def park(self, a, prev_a, distribution):
+        """Called inside a particle: wait for this statement to be served; returns the reply."""
+        p = self.current
+        p.request = (a, prev_a, distribution)
+        self.hub.switch()
+        reply, p.reply = p.reply, None
+        return reply
 
-    # ---- scheduler -------------------------------------------------------------------------------------------------
-    def _particle_main(self, p, args, kwargs):
-        state = self.state
-        state._begin_trace()
-        result = self.forward(*args, **kwargs)
-        p.trace = state._end_trace(result)
-        p.result = result
-        p.done = True
-
-    def run(self, *args, **kwargs):
+    def run_particles(self, particle_main):
+        """particle_main(particle) runs one trace inside the particle's greenlet. Returns the particles."""
         g = self._greenlet
-        state = self.state
         self.hub = g.getcurrent()
         runner = self.runner
         runner.begin(self.n, offset=self.offset)
         runner.state_rows = self.n                 # (per-particle rows from the start: groups gather / scatter them)
         particles = [_Particle(i) for i in range(self.n)]
         t0 = time.time()
-        # start every particle: each runs to its first controlled sample (or to the end)
-        for p in particles:
-            p.glet = g.greenlet(self._particle_main, parent=self.hub)
+        for p in particles:                        # every particle runs to its first controlled sample (or to the end)
+            p.glet = g.greenlet(particle_main, parent=self.hub)
             self.current = p
-            p.glet.switch(p, args, kwargs)
+            p.glet.switch(p)
         parked = [p for p in particles if not p.done]
         while True:
-            self._flush_likelihoods()
+            self._between_rounds()
             if not parked:
                 break
             self._serve(parked)
@@ -172,14 +134,11 @@ class CoroutineIS:
             parked = nxt
             self.rounds += 1
         self.current = None
-        state._current_trace = None
         self.seconds = time.time() - t0
-        lw_host = self.lw.cpu().numpy().astype(np.float64)
-        for p, w in zip(particles, lw_host):
-            # every weight term of a served statement lives in the device accumulator (trace.py:123-125 on the device);
-            # Trace.end summed the host-side ones (prior-as-proposal fallbacks: 0)
-            p.trace.log_importance_weight = float(w)
-        return [p.result for p in particles], self.lw, [p.trace for p in particles]
+        return particles
+
+    def _between_rounds(self):
+        pass
 
     def _serve(self, parked):
         """All pending sample statements, grouped by (address, previous address): one pp_is_step per group."""
@@ -188,7 +147,8 @@ class CoroutineIS:
         for p in parked:
             a, prev_a, _ = p.request
             groups.setdefault((a, prev_a), []).append(p)
-        for gi, ((a, prev_a), members) in enumerate(sorted(groups.items(), key=lambda kv: (kv[0][0], -1 if kv[0][1] is None else kv[0][1]))):
+        order = sorted(groups.items(), key=lambda kv: (kv[0][0], -1 if kv[0][1] is None else kv[0][1]))
+        for gi, ((a, prev_a), members) in enumerate(order):
             m = len(members)
             pids = np.fromiter((p.pid for p in members), np.int64, m)
             rows = torch.from_numpy(pids).to(self.dev)
@@ -199,23 +159,104 @@ class CoroutineIS:
                 for k, _ in host_prev:
                     members[k].prev_host_value = None
             dists = [p.request[2] for p in members]
-            info = self.spec.addresses[a]
             head = np.asarray([distribution_params(d) for d in dists], np.float32).reshape(m, 2)
             prior = torch.from_numpy(head).to(self.dev)
             runner.prev_value = self.last_value
             seed = self.seed + 7919 * self.rounds + 104729 * gi
             value, logq = runner.step_rows(rows, a, prev_a, prior, seed=seed, prior_compact=True)
             self.last_value.index_copy_(0, rows, value)
-            term = runner.dist_term(_Params(info.dist_name, dists))
-            prior_lp = runner.log_prob(term, value)
-            self.lw.index_add_(0, rows, prior_lp - logq)                       # state.py:211-217
-            host = torch.stack([value, prior_lp]).cpu()                        # ONE device-to-host copy per group
-            vals, lps = host[0].unbind(0), host[1].unbind(0)
-            for k, p in enumerate(members):
-                p.reply = (vals[k], lps[k])
+            replies = self._after_group(a, rows, dists, value, logq)
+            for p, r in zip(members, replies):
+                p.reply = r
                 p.request = None
             self.group_calls += 1
             self.statements += m
+
+    def _after_group(self, a, rows, dists, value, logq):
+        """Replies of a served group: (value, log q) per particle, as 0-d host tensors (ONE device-to-host copy)."""
+        host = torch.stack([value, logq]).cpu()
+        return list(zip(host[0].unbind(0), host[1].unbind(0)))
+
+
+class CoroutineIS(ParticleScheduler):
+    """One posterior run of `num_traces` particle coroutines over the trace runtime `state` (pyprob_amd.state), with the
+    whole log-weight on the device. `run()` returns (results, log_weights [n] device tensor, traces): results[i] =
+    forward()'s return value of particle i."""
+
+    def __init__(self, state, forward, network, num_traces, seed=0, offset=0, likelihood_importance=1.0):
+        super().__init__(network._is, network._engine.spec, num_traces, seed, offset)
+        self.state = state
+        self.forward = forward
+        self.net = network
+        self.scale = float(likelihood_importance)
+        self.lw = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
+        self.likelihoods = []          # (pid, distribution, value) queued by observe since the last round
+
+    # ---- called from state.sample / state.observe inside a particle ------------------------------------------------
+    def sample(self, distribution, base, addr, instance, name):
+        """The IC branch of state.sample (state.py:203-219) for the particle that is running: park until the scheduler
+        has served this statement, then record the variable like the reference does."""
+        from .trace import Variable
+        state = self.state
+        prev = state._current_trace_previous_variable
+        ids = self.resolve(addr, None if prev is None else prev.address)
+        if ids is None:
+            # no proposal layers for this address (or the previous one): the prior is the proposal and
+            # log p - log q = 0 (inference_network_lstm.py:100-104, 132-134); the LSTM state is not advanced
+            warnings.warn('Using prior. No proposal for address: {}'.format(addr))
+            value = distribution.sample()
+            if value.dim() > 0:
+                value = value[0]
+            variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
+                                log_prob=distribution.log_prob(value, sum=True), log_importance_weight=0.0, control=True,
+                                name=name)
+            self.current.prev_host_value = float(value)
+            state._current_trace.add(variable)
+            state._current_trace_previous_variable = variable
+            return variable.value
+        variable = Variable(distribution=distribution, value=None, address_base=base, address=addr, instance=instance,
+                            log_prob=0., control=True, name=name)
+        ctx = (state._current_trace, state._current_trace_execution_start)
+        reply = self.park(ids[0], ids[1], distribution)     # ---- parked; the scheduler serves the statement ----
+        state._current_trace, state._current_trace_execution_start = ctx
+        variable.value, variable.log_prob = reply
+        state._current_trace.add(variable)
+        state._current_trace_previous_variable = variable      # (no other particle runs between here and the next park)
+        return variable.value
+
+    def observe(self, distribution, value):
+        """state.observe's weight term (state.py:147-149), deferred to the next round's likelihood kernels."""
+        self.likelihoods.append((self.current.pid, distribution, value))
+
+    # ---- scheduler -------------------------------------------------------------------------------------------------
+    def run(self, *args, **kwargs):
+        state = self.state
+
+        def particle_main(p):
+            state._begin_trace()
+            result = self.forward(*args, **kwargs)
+            p.trace = state._end_trace(result)
+            p.result = result
+            p.done = True
+        particles = self.run_particles(particle_main)
+        state._current_trace = None
+        lw_host = self.lw.cpu().numpy().astype(np.float64)
+        for p, w in zip(particles, lw_host):
+            # every weight term of a served statement lives in the device accumulator (trace.py:123-125 on the device);
+            # Trace.end summed the host-side ones (prior-as-proposal fallbacks: 0)
+            p.trace.log_importance_weight = float(w)
+        return [p.result for p in particles], self.lw, [p.trace for p in particles]
+
+    def _after_group(self, a, rows, dists, value, logq):
+        runner = self.runner
+        term = runner.dist_term(_Params(self.spec.addresses[a].dist_name, dists))
+        prior_lp = runner.log_prob(term, value)
+        self.lw.index_add_(0, rows, prior_lp - logq)                       # state.py:211-217
+        host = torch.stack([value, prior_lp]).cpu()                        # ONE device-to-host copy per group
+        return list(zip(host[0].unbind(0), host[1].unbind(0)))
+
+    def _between_rounds(self):
+        self._flush_likelihoods()
 
     def _flush_likelihoods(self):
         """lw[rows] += likelihood_importance * log p(y | .) for the observes since the last round, one kernel per family."""

@@ -84,7 +84,7 @@ class ProposalSample:
 
     def log_prob(self, value, sum=False):
         # state.sample scores exactly the value it just drew (state.py:208-212)
-        return self._log_q[0] if sum else self._log_q
+        return self._log_q.reshape(-1)[0] if sum else self._log_q
 
 
 class InferenceNetworkLSTM:

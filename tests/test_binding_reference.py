@@ -1,0 +1,271 @@
+"""The reference-side binding EXECUTED: pyprob's own `Model.learn_inference_network`, `optimize()`
+loop, `_save` / `_load` and `posterior` run through pyprob_amd/binding.py.
+
+Runs only where the reference is available (this container: /root/reference + the import stubs of oracle/refstubs);
+skipped on the GPU box. The device is absent here, so the `pyprob_hip::*` operators execute their oracle-backed CPU
+kernels (tests/oracle_ops.py) and the engine's buffers are CPU tensors - everything ABOVE the operators (parameter
+re-binding, `_polymorph` growth, the autograd.Function, `grad is None` semantics, HipAdam inside the reference's
+optimizer / scheduler protocol, pickling, the coroutine `_traces`) is the code that ships.
+The GPU twin of the gradient check is tests/test_gpu_binding.py."""
+import functools
+import math
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+REFERENCE = '/root/reference'
+if not os.path.isdir(os.path.join(REFERENCE, 'pyprob')):
+    pytest.skip('the reference tree is not available on this machine', allow_module_level=True)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'oracle', 'refstubs'))
+sys.path.insert(1, REFERENCE)
+
+import pyprob  # noqa: E402
+from pyprob import InferenceEngine, InferenceNetwork, Model  # noqa: E402
+from pyprob.distributions import Normal, Uniform  # noqa: E402
+
+import oracle_ops  # noqa: E402  (CPU kernels of the operators)
+import pyprob_amd.binding as hip  # noqa: E402
+from oracle import ic_oracle as O  # noqa: E402
+
+hip._HipNetworkMixin._hip_device = 'cpu'
+hip._HipNetworkMixin._hip_engine_factory = staticmethod(lambda spec, device: oracle_ops.CpuBufferEngine(spec))
+
+IC = InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
+EMB = {'obs0': {'dim': 16}, 'obs1': {'dim': 16}}
+
+
+class GaussianWithUnknownMean(Model):           # reference tests/test_inference.py:97-109
+    def __init__(self):
+        super().__init__('Gaussian with unknown mean')
+
+    def forward(self):
+        mu = pyprob.sample(Normal(1, math.sqrt(5)))
+        likelihood = Normal(mu, math.sqrt(2))
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+class GaussianWithUnknownMeanMarsaglia(Model):  # reference tests/test_inference.py:252-275, as written
+    def __init__(self):
+        super().__init__('Gaussian with unknown mean (Marsaglia)')
+
+    def marsaglia(self, mean, stddev):
+        uniform = Uniform(-1, 1)
+        s = 1
+        while float(s) >= 1:
+            x = pyprob.sample(uniform)
+            y = pyprob.sample(uniform)
+            s = x * x + y * y
+        return mean + stddev * (x * torch.sqrt(-2 * torch.log(s) / s))
+
+    def forward(self):
+        mu = self.marsaglia(1, math.sqrt(5))
+        likelihood = Normal(mu, math.sqrt(2))
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+@pytest.fixture
+def installed():
+    hip.install()
+    yield
+    hip.uninstall()
+
+
+def _train(model_cls, use_hip, num_traces, seed=3, **kw):
+    (hip.install if use_hip else hip.uninstall)()
+    try:
+        pyprob.seed(seed)
+        model = model_cls()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model.learn_inference_network(num_traces=num_traces, batch_size=32, observe_embeddings=EMB,
+                                          inference_network=InferenceNetwork.LSTM, lstm_dim=24, learning_rate_init=1e-3,
+                                          **kw)
+        return model
+    finally:
+        hip.uninstall()
+
+
+@pytest.mark.parametrize('program', [GaussianWithUnknownMean, GaussianWithUnknownMeanMarsaglia], ids=['gum', 'gumm'])
+def test_learn_inference_network_matches_the_stock_reference(program):
+    """Same seed, same program: the reference's optimize() loop driving the HIP-side network produces the stock
+    reference's loss trajectory, parameter set and final weights (fp32 reference vs fp64 oracle kernels: 1e-4)."""
+    stock = _train(program, False, 320)
+    bound = _train(program, True, 320)
+    ns, nb = stock._inference_network, bound._inference_network
+    assert type(nb).__name__ == 'InferenceNetworkLSTMHip' and isinstance(nb, type(ns))
+    assert isinstance(nb, torch.nn.Module)
+    assert [n for n, _ in nb.named_parameters()] == [n for n, _ in ns.named_parameters()]
+    assert nb._total_train_traces == ns._total_train_traces and nb._total_train_iterations == ns._total_train_iterations
+    np.testing.assert_allclose(nb._history_train_loss, ns._history_train_loss, rtol=2e-4, atol=2e-4)
+    assert nb._history_num_params == ns._history_num_params
+    sd_s, sd_b = ns.state_dict(), nb.state_dict()
+    for k in sd_s:
+        np.testing.assert_allclose(sd_b[k].numpy(), sd_s[k].numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
+    # every parameter IS a view of the engine's flat buffer
+    eng = nb._hip_engine
+    for name, p in nb.named_parameters():
+        assert isinstance(p, torch.nn.Parameter) and p.data_ptr() == eng.tensor(name).data_ptr()
+    for a, layer in nb._layers_proposal.items():
+        assert layer._total_train_iterations == ns._layers_proposal[a]._total_train_iterations
+
+
+def test_gradients_and_grad_none_set_match_the_reference(installed):
+    """One minibatch through both `_loss` implementations on identical weights: same loss, same gradients, and
+    `grad is None` for exactly the parameters the reference's autograd leaves untouched (the presence map of
+    _distributed_sync_grad, inference_network.py:300)."""
+    from pyprob.nn import Batch
+    stock = _train(GaussianWithUnknownMeanMarsaglia, False, 320)
+    hip.install()
+    ns = stock._inference_network
+    pyprob.seed(11)
+    gen = stock._trace_generator(trace_mode=pyprob.TraceMode.PRIOR_FOR_INFERENCE_NETWORK)
+    traces = []
+    while len(traces) < 24:            # short traces only: several addresses of the network stay untouched
+        t = next(gen)
+        if t.length_controlled <= 4:
+            traces.append(t)
+    batch = Batch(traces)
+    nb = hip.InferenceNetworkLSTMHip(model=stock, observe_embeddings=EMB, lstm_dim=24)
+    nb._init_layers_observe_embedding(EMB, example_trace=traces[0])
+    nb._init_layers()
+    nb._layers_initialized = True
+    full = Batch([next(gen) for _ in range(200)])
+    ns._polymorph(full)
+    nb._polymorph(full)
+    nb.load_state_dict(ns.state_dict())               # in place: writes through the views into the flat buffer
+    ns.zero_grad()
+    ok_s, loss_s = ns._loss(batch)
+    loss_s.backward()
+    ok_b, loss_b = nb._loss(batch)
+    assert ok_s and ok_b and loss_b.dim() == 0 and loss_b.requires_grad
+    loss_b.backward()
+    assert abs(float(loss_b) - float(loss_s)) < 1e-4 * abs(float(loss_s))
+    gs = dict((n, p.grad) for n, p in ns.named_parameters())
+    none_b = {n for n, p in nb.named_parameters() if p.grad is None}
+    assert none_b == {n for n, g in gs.items() if g is None} and len(none_b) > 0
+    for n, p in nb.named_parameters():
+        if p.grad is not None:
+            ref = gs[n].numpy()
+            err = np.abs(p.grad.numpy() - ref).max() / max(np.abs(ref).max(), 1e-6)
+            assert err < 2e-3, (n, err)
+    # a scaled loss scales the gradients (autograd contract of the Function)
+    g1 = {n: p.grad.clone() for n, p in nb.named_parameters() if p.grad is not None}
+    for p in nb.parameters():
+        p.grad = None
+    ok, loss = nb._loss(batch)
+    (3.0 * loss).backward()
+    for n, p in nb.named_parameters():
+        if n in g1:
+            np.testing.assert_allclose(p.grad.numpy(), 3.0 * g1[n].numpy(), rtol=1e-5, atol=1e-7)
+    # unknown address -> (False, 0) like inference_network_lstm.py:150-152
+    nb2 = hip.InferenceNetworkLSTMHip(model=stock, observe_embeddings=EMB, lstm_dim=24)
+    nb2._init_layers_observe_embedding(EMB, example_trace=traces[0])
+    nb2._init_layers()
+    nb2._layers_initialized = True
+    nb2._polymorph(Batch([t for t in traces if t.length_controlled == 2][:4]))
+    longer = [t for t in full.traces if t.length_controlled >= 4][:4]
+    assert nb2._loss(Batch(longer)) == (False, 0)
+
+
+def test_save_load_round_trip_and_continue_training(installed, tmp_path, monkeypatch):
+    """`_save` pickles the module (inference_network.py:162-196): the HIP-side state is rebuilt on load, Adam moments and
+    per-tensor step counts come back through HipAdam.load_state_dict, and training continues on the loaded network."""
+    monkeypatch.setattr(torch, 'load', functools.partial(torch.load, weights_only=False))
+    bound = _train(GaussianWithUnknownMean, True, 320)
+    hip.install()
+    net = bound._inference_network
+    fn = str(tmp_path / 'net.network')
+    bound.save_inference_network(fn)
+    other = GaussianWithUnknownMean()
+    other.load_inference_network(fn)
+    ln = other._inference_network
+    assert type(ln).__name__ == 'InferenceNetworkLSTMHip' and ln._hip_engine is not None
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ln.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.detach(), p2.detach())
+        assert p2.data_ptr() == ln._hip_engine.tensor(n2).data_ptr()
+    assert torch.equal(ln._hip_engine.tensor_step, net._hip_engine.tensor_step)
+    assert torch.equal(ln._hip_engine.exp_avg, net._hip_engine.exp_avg)
+    assert ln._total_train_traces == net._total_train_traces and ln._history_train_loss == net._history_train_loss
+    before = ln._total_train_traces
+    pyprob.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        other.learn_inference_network(num_traces=64, batch_size=32, observe_embeddings=EMB,
+                                      inference_network=InferenceNetwork.LSTM, lstm_dim=24)
+    assert ln._total_train_traces == before + 64 and int(ln._hip_engine.tensor_step.max()) == 12
+    assert np.isfinite(ln._history_train_loss[-1])
+
+
+def test_learning_rate_scheduler_and_weight_decay_drive_hip_adam(installed):
+    """LambdaLR (POLY2, inference_network.py:357-379) steps the HipAdam instance like any torch optimizer."""
+    pyprob.seed(2)
+    model = GaussianWithUnknownMean()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model.learn_inference_network(num_traces=160, batch_size=32, observe_embeddings=EMB, lstm_dim=24,
+                                      inference_network=InferenceNetwork.LSTM, learning_rate_init=1e-3, learning_rate_end=1e-5,
+                                      learning_rate_scheduler_type=pyprob.LearningRateScheduler.POLY2, num_traces_end=1000,
+                                      weight_decay=1e-4)
+    net = model._inference_network
+    assert isinstance(net._optimizer, hip.HipAdam)
+    lr = net._optimizer.param_groups[0]['lr']
+    want = (1e-3 - 1e-5) * (1 - 160 / 1000) ** 2 + 1e-5
+    assert abs(lr - want) < 1e-9
+    assert net._optimizer.param_groups[0]['weight_decay'] == 1e-4
+
+
+@pytest.mark.parametrize('program,case', [(GaussianWithUnknownMean, 'gum'), (GaussianWithUnknownMeanMarsaglia, 'gumm')],
+                         ids=['gum', 'gumm'])
+def test_posterior_through_the_binding_is_rescored_by_the_oracle(installed, program, case):
+    """`Model.posterior(IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK)` of the reference, particles as coroutines parked in
+    `_infer_step`: the Empirical holds the reference's own Trace objects; their log-weights (summed by the reference's
+    Trace.end from the reference's log p and the served log q) equal the oracle's re-scoring of their values."""
+    from is_helpers import rescore
+    bound = _train(program, True, 640)
+    hip.install()
+    net = bound._inference_network
+    observe = {'obs0': 8, 'obs1': 9}
+    pyprob.seed(4)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = bound.posterior(60, inference_engine=IC, observe=observe)
+    assert post.length == 60 and hasattr(post, '_hip_coroutine_stats')
+    traces = [post._get_value(i) for i in range(post.length)]
+    params = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    meta = dict(obs_names=['obs0', 'obs1'], mixture_components=10)
+    ref = rescore(case, meta, params, traces, observe, math.sqrt(2))
+    lw = np.array([float(t.log_importance_weight) for t in traces])
+    np.testing.assert_allclose(lw, ref, rtol=1e-4, atol=1e-4)
+    st = post._hip_coroutine_stats
+    assert st['statements'] == sum(t.length_controlled for t in traces)
+    if case == 'gumm':
+        assert st['group_calls'] < st['statements']        # batches, not one network call per statement
+    # the per-particle path of the reference (no coroutines) agrees statistically and is scored the same way
+    os.environ['PYPROB_HIP_COROUTINES'] = '0'
+    try:
+        pyprob.seed(4)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            one = bound.posterior(12, inference_engine=IC, observe=observe)
+    finally:
+        del os.environ['PYPROB_HIP_COROUTINES']
+    traces1 = [one._get_value(i) for i in range(one.length)]
+    ref1 = rescore(case, meta, params, traces1, observe, math.sqrt(2))
+    np.testing.assert_allclose([float(t.log_importance_weight) for t in traces1], ref1, rtol=1e-4, atol=1e-4)
+
+
+def test_operators_fail_loudly_without_a_kernel_for_the_device():
+    """The product registers device kernels only; a dispatch key without a kernel raises (no silent fallback)."""
+    x = torch.zeros(4, device='meta')
+    with pytest.raises(NotImplementedError):
+        torch.ops.pyprob_hip.log_prob(0, x, 0, x, 0, x, 4)
