@@ -41,10 +41,13 @@ def test_gum_lockstep_posterior_statistics(gum_trained):
 def test_gum_per_trace_posterior_matches_lockstep(gum_trained):
     model = gum_trained
     torch.manual_seed(5)
-    post = model.posterior_results(400, IC, lock_step=False, observe=OBS)          # one particle per forward(), like the reference
+    post = model.posterior_results(400, IC, lock_step='per_trace', observe=OBS)    # one particle per forward(), like the reference
     lock = model.posterior_results(50000, IC, observe=OBS, lock_step=True, seed=11)
     assert abs(post.mean - lock.mean) < 0.4
     assert post.effective_sample_size > 0.1 * 400
+    co = model.posterior_results(4000, IC, lock_step=False, observe=OBS, seed=6)    # the same program in particle coroutines
+    assert abs(co.mean - lock.mean) < 0.2 and co.effective_sample_size > 0.1 * 4000
+    assert co.coroutine_stats['group_calls'] == 1 and co.coroutine_stats['statements'] == 4000
     # a per-trace log weight equals the re-scored one: log p + likelihoods - log q
     gen = model._trace_generator(trace_mode=TraceMode.POSTERIOR, inference_engine=IC,
                                  inference_network=model._inference_network, observe=OBS)
@@ -97,10 +100,20 @@ def test_save_load_round_trip(gum_trained, tmp_path):
     p1 = model.posterior_results(20000, IC, observe=OBS, lock_step=True, seed=4)
     p2 = m2.posterior_results(20000, IC, observe=OBS, lock_step=True, seed=4)
     assert abs(p1.mean - p2.mean) < 1e-6 and abs(p1.effective_sample_size - p2.effective_sample_size) < 1e-3
-    # continuing training keeps the Adam step counts (reference tests/test_train.py:107-203 checks the same)
+    # the training state survives like the reference's pickled module (inference_network.py:162-196): schedule, history
+    for k in ('_learning_rate_init', '_learning_rate_end', '_weight_decay', '_total_train_traces_end', '_loss_init', '_loss_min',
+              '_history_train_loss', '_history_train_loss_trace', '_history_num_params', '_layers_pre_generated'):
+        assert getattr(a, k) == getattr(b, k), k
+    assert b._total_train_seconds == a._total_train_seconds and b._total_train_seconds > 0
+    # continuing training keeps the Adam step counts (reference tests/test_train.py:107-203 checks the same), the learning
+    # rate the network was created with (a new learning_rate_init is ignored, inference_network.py:446-449) and the history
     before = int(b._engine.tensor_step.max().item())
-    m2.learn_inference_network(inference_network=LSTM, num_traces=256, observe_embeddings=EMB, batch_size=128)
+    n_hist, lr0 = len(b._history_train_loss), b._learning_rate_init
+    m2.learn_inference_network(inference_network=LSTM, num_traces=256, observe_embeddings=EMB, batch_size=128,
+                               learning_rate_init=0.5)
     assert int(b._engine.tensor_step.max().item()) == before + 2
+    assert b._learning_rate_init == lr0 and len(b._history_train_loss) == n_hist + 2
+    assert b._history_train_loss_trace[-1] == a._total_train_traces + 256
 
 
 def test_unknown_address_falls_back_to_prior(gum_trained):
@@ -286,7 +299,8 @@ def test_feedforward_network_with_control_flow_and_categorical():
 
 def test_posterior_picks_lock_step_automatically(gum_trained):
     """posterior_results without a lock_step argument (the reference's signature): a program written with tensor
-    conditions runs in lock step, the reference's `while float(s) >= 1:` program falls back to one particle per forward()."""
+    conditions runs in lock step, the reference's `while float(s) >= 1:` program runs as written in particle coroutines
+    (served in address-grouped batches); the reference's own one-particle-per-forward() loop stays available."""
     model = gum_trained
     model._lock_step_ok = None
     post = model.posterior_results(20000, IC, observe=OBS, seed=2)
@@ -296,8 +310,14 @@ def test_posterior_picks_lock_step_automatically(gum_trained):
     ref_style = GaussianWithUnknownMeanMarsaglia()
     ref_style.learn_inference_network(inference_network=LSTM, num_traces=3000, observe_embeddings=EMB, batch_size=64,
                                       lstm_dim=64, seed=4)
-    p = ref_style.posterior_results(50, IC, observe=OBS)
-    assert ref_style._lock_step_ok is False and not hasattr(p, 'device_stats') and np.isfinite(p.mean)
+    p = ref_style.posterior_results(2000, IC, observe=OBS)
+    assert ref_style._lock_step_ok is False and np.isfinite(p.mean) and p.length == 2000
+    st = p.coroutine_stats
+    assert st['group_calls'] < st['statements'] / 20 and st['rounds'] >= 2        # batches, not per-particle calls
+    assert abs(p.device_stats['ess'] - p.effective_sample_size) < 1e-3 * p.effective_sample_size
+    one = ref_style.posterior_results(50, IC, observe=OBS, lock_step='per_trace')    # the reference's loop
+    assert not hasattr(one, 'coroutine_stats') and np.isfinite(one.mean)
+    assert abs(one.mean - p.mean) < 1.5
 
 
 def test_distributed_posterior_on_a_single_rank_group(gum_trained):
