@@ -40,6 +40,17 @@ void set_error(const char* fmt, ...);
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// A block of an output C[M, N] = A B^T whose tiles may skip part of the summation: for rows [m0, m1) x columns [n0, n1)
+// the K indices [k0, k1) multiply zeros (or the block's result is not used at all: k = [0, K)). Element units; the
+// kernels skip whole 64 x 64 tiles / whole K slabs inside the block only.
+struct GemmHole {
+    int m0, m1, n0, n1, k0, k1;
+};
+
+// gemm_f32.hip
+int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole = nullptr);
+int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes = nullptr);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -13,8 +13,6 @@ namespace pp {
 
 // kernels.hip / gemm_f32.hip
 const char* last_error();
-int gemm_f32(const pp_gemm_args* a, hipStream_t st);
-int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st);
 struct ColsumJob {
     const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
     const float* wgt; int64_t ldw; int out_stride;   // optional per-row weight (kernels.hip)
@@ -191,30 +189,73 @@ static int check_net(const pp_net* net) {
 
 // y = act(x W^T + b): x [n, in] (ldx), W [out, in], y [n, out] (ldy)
 static int linear_fwd(const float* x, int64_t ldx, const int32_t* x_idx, const float* W, const float* b, float* y,
-                      int64_t ldy, int n, int in, int out, bool relu, const float* bias2, hipStream_t st) {
+                      int64_t ldy, int n, int in, int out, bool relu, const float* bias2, hipStream_t st,
+                      const GemmHole* hole = nullptr) {
     pp_gemm_args g{};
     g.A = x; g.lda = ldx; g.a_idx = x_idx;
     g.B = W; g.ldb = in;
     g.C = y; g.ldc = ldy;
     g.M = n; g.N = out; g.K = in;
     g.bias = b; g.bias2 = bias2; g.relu = relu ? 1 : 0;
-    return gemm_f32(&g, st);
+    return gemm_f32(&g, st, hole);
 }
 
 // dW[out, in] += dz^T x  (dz [n, out] (lddz), x [n, in] (ldx, optional k-gather x_idx)): queued; all weight-gradient
 // products of a backward pass are leaves of the dependency graph and run as one grouped launch (gemm_f32_grouped)
 // the weight-gradient leaves of the backward pass, one grouped launch (timed as kernel class 1 when armed)
-static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st) {
+static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st, const std::vector<GemmHole>* holes = nullptr,
+                         bool timed = true) {
+    if (wq.empty()) return 0;
     double flops = 0.0;
     for (const auto& g : wq) flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
-    prof_begin(1, st);
-    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st));
-    prof_end(1, flops, st);
+    if (timed) prof_begin(1, st);
+    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st, holes ? holes->data() : nullptr));
+    if (timed) prof_end(1, flops, st);
+    return 0;
+}
+
+// ---- side stream: the weight-gradient products are LEAVES of the backward pass ---------------------------------------
+// They read what the data-gradient chain produced (dG, dZ1, DY and the saved activations) and write gradient tensors
+// nothing else in the step touches, so they run on a second HIP stream next to the chain dH -> cell backward -> dX ->
+// observe-embedding backward -> column sums instead of after it: fork after the head tails (head weight gradients),
+// fork again when dG is complete (LSTM weight gradients), join before pp_ic_loss returns. The stream and its events
+// are created once per host thread (no device memory involved). PP_SIDE_STREAM=0 keeps everything on the caller's stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork0 = nullptr, fork1 = nullptr, join = nullptr;
+    int state = 0;   // 0: not tried, 1: ready, -1: unavailable
+};
+static SideStream* side_stream() {
+    static thread_local SideStream ss;
+    static const int enabled = getenv("PP_SIDE_STREAM") ? atoi(getenv("PP_SIDE_STREAM")) : 1;
+    if (!enabled) return nullptr;
+    if (ss.state == 0) {
+        ss.state = -1;
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fork0, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fork1, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
+            ss.state = 1;
+        else
+            (void)hipGetLastError();
+    }
+    return ss.state == 1 ? &ss : nullptr;
+}
+static int fork_to(hipStream_t main, hipEvent_t ev, hipStream_t side) {
+    if (hipEventRecord(ev, main) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
+        set_error("pp_ic_loss: side-stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        return PP_EHIP;
+    }
     return 0;
 }
 
 static void queue_wgrad(std::vector<pp_gemm_args>& q, const float* dz, int64_t lddz, const float* x, int64_t ldx,
-                        const int32_t* x_idx, float* dW, int n, int in, int out) {
+                        const int32_t* x_idx, float* dW, int n, int in, int out, std::vector<GemmHole>* holes = nullptr,
+                        GemmHole hole = GemmHole{0, 0, 0, 0, 0, 0}) {
+    if (holes) {
+        holes->resize(q.size(), GemmHole{0, 0, 0, 0, 0, 0});
+        holes->push_back(hole);
+    }
     pp_gemm_args g{};
     g.A = dz; g.lda = lddz; g.a_kmajor = 1;
     g.B = x; g.ldb = ldx; g.b_kmajor = 1; g.b_idx = x_idx;
@@ -237,7 +278,7 @@ static int linear_wgrad(const float* dz, int64_t lddz, const float* x, int64_t l
 // dx[n, in] (lddx, optional scatter idx) = (dz W) (* relu mask); W [out, in]
 static int linear_dgrad(const float* dz, int64_t lddz, const float* W, float* dx, int64_t lddx, const int32_t* dx_idx,
                         const float* mask, int64_t ldmask, int n, int in, int out, bool accumulate, hipStream_t st,
-                        float* colsum = nullptr) {
+                        float* colsum = nullptr, const GemmHole* hole = nullptr) {
     pp_gemm_args g{};
     g.A = dz; g.lda = lddz;
     g.B = W; g.ldb = in; g.b_kmajor = 1;
@@ -247,7 +288,7 @@ static int linear_dgrad(const float* dz, int64_t lddz, const float* W, float* dx
     g.accumulate = accumulate ? 1 : 0;
     g.colsum = colsum;
     g.split_k = 1;
-    return gemm_f32(&g, st);
+    return gemm_f32(&g, st, hole);
 }
 
 static int observe_embedding_fwd(const pp_net* net, const float* P, const float* obs, int64_t ldobs, int B, Workspace& w,
@@ -338,8 +379,12 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                                  bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), PP_LOSS_SLOTS_FLOATS));
     }
     if (!ff) {
+    // a trace's first time step has no previous variable: columns [e_obs, c4) of its LSTM input row are zero
+    // (inference_network_lstm.py:159-162) - rows [0, B) of the step-major layout
+    const GemmHole x_zero{0, B, 0, 4 * H, net->e_obs, net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim};
     prof_begin(0, st);
-    PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st));
+    PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st,
+                      &x_zero));
     prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
     }
     for (int t = 0; t < T && !ff; ++t) {
@@ -420,7 +465,27 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // (the bias / table column sums queued in `cs` are launched once, at the end of the backward pass)
 
     // ---------------- backward ----------------
-    std::vector<pp_gemm_args> wq;   // weight-gradient leaves, flushed as one grouped launch once dG is complete
+    // Weight-gradient leaves: queued and flushed as grouped launches - on the side stream as soon as their inputs are
+    // complete (heads after the tails, LSTM after the cell backward), or all at once at the end on the caller's stream.
+    SideStream* ss = side_stream();
+    std::vector<pp_gemm_args> wq;
+    std::vector<GemmHole> wholes;
+    bool forked = false;
+    auto flush_wgrads = [&](hipStream_t stream, bool timed) -> int {
+        wholes.resize(wq.size(), GemmHole{0, 0, 0, 0, 0, 0});
+        PP_TRY(launch_wgrads(wq, stream, &wholes, timed));
+        wq.clear();
+        wholes.clear();
+        return 0;
+    };
+    auto join_side = [&]() -> int {   // the caller's stream continues only after the side stream's products
+        if (!forked) return 0;
+        if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) {
+            set_error("pp_ic_loss: side-stream join failed: %s", hipGetErrorString(hipGetLastError()));
+            return PP_EHIP;
+        }
+        return 0;
+    };
     std::vector<pp_gemm_args> dq;   // per-address data gradients into dH
     for (int a = 0; a < net->n_addr; ++a) {
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
@@ -446,6 +511,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             dq.push_back(g);
         }
     }
+    if (ss) {   // the heads' weight gradients need nothing but the tails' outputs: start them next to dH / the cell backward
+        PP_TRY(fork_to(st, ss->fork0, ss->s));
+        forked = true;
+        PP_TRY(flush_wgrads(ss->s, ff));
+    }
     PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));
     for (int t = T - 1; t >= 0 && !ff; --t) {
         const int n = bt->n_active[t], r0 = bt->row_off[t];
@@ -465,14 +535,24 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     const int64_t ldxs = ff ? H : w.i4;
     // LSTM parameter gradients, together with every head's weight gradients
     if (!ff) {
-    queue_wgrad(wq, w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, R, I, 4 * H);
+    const int cz0 = net->e_obs, cz1 = net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim;   // previous-variable columns
+    // dW_ih[:, previous-variable columns] gets nothing from the rows of first time steps (their inputs are zero there)
+    queue_wgrad(wq, w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, R, I, 4 * H, &wholes,
+                GemmHole{0, 4 * H, cz0, cz1, 0, B});
     if (T > 1) {
         const int r1 = bt->row_off[1];
         queue_wgrad(wq, w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, R - r1, H, 4 * H);
     }
-    // (wq is flushed at the very end, together with the observe-embedding weight gradients)
-    // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding
-    PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, true, st));   // dX was cleared by the gather kernel
+    if (ss) {   // dG is complete: the LSTM weight gradients run next to dX and the observe-embedding backward
+        PP_TRY(fork_to(st, ss->fork1, ss->s));
+        PP_TRY(flush_wgrads(ss->s, true));
+    }
+    // (without a side stream wq is flushed at the very end, together with the observe-embedding weight gradients)
+    // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding. Nobody reads the
+    // previous-variable columns of first-time-step rows (no previous variable, no parameter behind them).
+    const GemmHole dx_unused{0, B, cz0, cz1, 0, 4 * H};
+    PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, true, st, nullptr,
+                        &dx_unused));   // dX was cleared by the gather kernel
     const int c1 = net->e_obs, c2 = c1 + net->smp_dim, c3 = c2 + net->dtype_dim, c4 = c3 + net->addr_dim,
               c5 = c4 + net->dtype_dim;
     for (int a = 0; a < net->n_addr; ++a) {
@@ -522,15 +602,16 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, w.loss_acc, w.flag, B, loss_out, status_out));
         else
             PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-        PP_TRY(launch_wgrads(wq, st));
-        return 0;
+        PP_TRY(flush_wgrads(st, !ss));
+        return join_side();
     }
     PP_TRY(obs_grad(dXs, ldxs, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
     if (ff)
         PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, w.loss_acc, w.flag, B, loss_out, status_out));
     else
         PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-    PP_TRY(launch_wgrads(wq, st));
+    PP_TRY(flush_wgrads(st, !ss));
+    PP_TRY(join_side());
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st,

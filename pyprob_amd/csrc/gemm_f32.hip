@@ -41,6 +41,9 @@ struct GemmParams {
     int vec;         // grouped launch: this problem's operands allow 16-byte loads
     int vec_c;       // C rows allow 16-byte stores (direct tiles)
     int dbg_plain;   // measurement only: split partials are stored instead of added (WRONG results)
+    // zero block (GemmHole): for output tiles inside rows [hm0, hm1) x columns [hn0, hn1) the K slabs [hs0, hs1) hold
+    // nothing but zeros (or the tile is not used at all) and are skipped. hs1 <= hs0: no zero block.
+    int hm0, hm1, hn0, hn1, hs0, hs1;
     long long* dbg;  // debug phase stamps (NULL normally)
 };
 
@@ -475,13 +478,25 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     const int w4 = wave & 3, kh = wave >> 2;
     const int wm = w4 >> 1, wn = w4 & 1;
     const int m0 = by * 64, n0 = bx * 64;
-    const int nslab_total = (p.K + BK - 1) / BK;
+    const int nslab_all = (p.K + BK - 1) / BK;
+    // Zero block: the slabs [hs0, hs0 + hlen) contribute nothing to this tile and are left out of its slab sequence
+    // (the LSTM input of a trace's first time step has no previous-variable columns: inference_network_lstm.py:159-162).
+    int hs0 = 0, hlen = 0;
+    if (p.hs1 > p.hs0 && m0 >= p.hm0 && min(m0 + 64, p.M) <= p.hm1 && n0 >= p.hn0 && min(n0 + 64, p.N) <= p.hn1 &&
+        !((A_KM && p.a_idx) || (B_KM && p.b_idx))) {   // workgroup-uniform
+        hs0 = p.hs0;
+        hlen = max(min(p.hs1, nslab_all) - p.hs0, 0);
+    }
+    const int nslab_total = nslab_all - hlen;
     const int per = (nslab_total + nz - 1) / nz;
     const int s_begin = bz * per;
     const int T = min(nslab_total, s_begin + per) - s_begin;
     if (T <= 0) return;
     const bool split = nz > 1;
-    const int kb = s_begin * BK;
+    // slab t of this workgroup = entry s_begin + t of the sequence without the zero block; srel(t) counts from its first
+    auto slab_of = [&](int t) { const int u = s_begin + t; return u < hs0 ? u : u + hlen; };
+    const int kb = slab_of(0) * BK;
+    auto srel = [&](int t) { return slab_of(t) - kb / BK; };
 
     f32x16 acc[1][1];
 #pragma unroll
@@ -505,8 +520,9 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue = [&](int t) {
         const uint32_t img = ring + (uint32_t)(t & (ST - 1)) * (AS_STAGE * 4u);
-        oa.issue(t, kb + t * BK, p.K, img);
-        ob.issue(t, kb + t * BK, p.K, img + AS_IMG * 4u);
+        const int sr = srel(t);
+        oa.issue(sr, kb + sr * BK, p.K, img);
+        ob.issue(sr, kb + sr * BK, p.K, img + AS_IMG * 4u);
     };
     // fragments of slab t: image -> registers
     auto load_frags = [&](int t, float (&a)[NS][4], float (&b)[NS][4]) {
@@ -527,7 +543,7 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     };
     // drain version: the last slab of the product may be partial - its pieces beyond K hold stand-in data
     auto mma_edge = [&](int t, float (&a)[NS][4], float (&b)[NS][4]) {
-        const int k0 = kb + t * BK;
+        const int k0 = kb + srel(t) * BK;
         if (k0 + BK > p.K) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
@@ -570,6 +586,7 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
         const float* Bs = As + AS_IMG;
         const bool dma = td < T;
         const uint32_t img = ring + (uint32_t)(td & (ST - 1)) * (AS_STAGE * 4u);
+        const int sd = srel(td);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -578,8 +595,8 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
                 const int slot = 4 * s + q;   // side instruction of this MFMA
                 if (slot < NS) oa.frag(As, wm * 32 + l31, kh * NS + slot, h, na[slot]);
                 else if (slot < 2 * NS) ob.frag(Bs, wn * 32 + l31, kh * NS + slot - NS, h, nb[slot - NS]);
-                else if (slot < 2 * NS + NP) { if (dma) oa.issue1(slot - 2 * NS, td, kb + td * BK, p.K, img); }
-                else if (slot < 2 * NS + 2 * NP) { if (dma) ob.issue1(slot - 2 * NS - NP, td, kb + td * BK, p.K, img + AS_IMG * 4u); }
+                else if (slot < 2 * NS + NP) { if (dma) oa.issue1(slot - 2 * NS, sd, kb + sd * BK, p.K, img); }
+                else if (slot < 2 * NS + 2 * NP) { if (dma) ob.issue1(slot - 2 * NS - NP, sd, kb + sd * BK, p.K, img + AS_IMG * 4u); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1156,6 +1173,16 @@ static int launch_layout(const GemmParams& p, bool akm, bool bkm, int splits, hi
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// element ranges -> the slab interval the tiles may skip: only whole slabs inside [k0, k1) (k1 >= K: up to the last slab)
+static void set_hole(GemmParams& p, const GemmHole* h) {
+    p.hm0 = p.hm1 = p.hn0 = p.hn1 = p.hs0 = p.hs1 = 0;
+    static const int enabled = getenv("PP_GEMM_HOLES") ? atoi(getenv("PP_GEMM_HOLES")) : 1;
+    if (!h || !enabled || h->k1 <= h->k0) return;
+    p.hm0 = h->m0; p.hm1 = h->m1; p.hn0 = h->n0; p.hn1 = h->n1;
+    p.hs0 = cdiv(h->k0, BK);
+    p.hs1 = h->k1 >= p.K ? cdiv(p.K, BK) : h->k1 / BK;
+}
+
 static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.A = a->A; p.lda = a->lda; p.a_idx = a->a_idx;
     p.B = a->B; p.ldb = a->ldb; p.b_idx = a->b_idx;
@@ -1166,6 +1193,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.colsum = a->colsum;
     static const int plain = getenv("PP_DBG_PLAIN_SPLIT") ? atoi(getenv("PP_DBG_PLAIN_SPLIT")) : 0;
     p.dbg_plain = plain;
+    p.hm0 = p.hm1 = p.hn0 = p.hn1 = p.hs0 = p.hs1 = 0;
     p.vec = 1;
     p.vec_c = (a->ldc % 4 == 0 && aligned16(a->C)) ? 1 : 0;
     static const int stamp_all = getenv("PP_DBG_STAMP") ? 1 : 0;   // debug: stamp every product (tools/timeline4.py)
@@ -1264,12 +1292,13 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
          : kind == 2 ? launch_async_grouped(g, akm, bkm, st) : launch_grouped<4>(g, akm, bkm, st);
 }
 
-int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
+int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole) {
     PP_CHECK_ARG(a && a->A && a->B && a->C, "pp_gemm_f32: null operand");
     PP_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0, "pp_gemm_f32: negative dimension");
     if (a->M == 0 || a->N == 0) return 0;
     GemmParams p;
     fill_params(a, p);
+    set_hole(p, hole);
     const bool vec = vec_ok(a);
     if (gemv_ok(a)) return launch_gemv(p, vec, st);
     // Tile choice: the hot-path GEMMs are small (<= a few thousand rows); 64x64 tiles give >= 2 workgroups per CU
@@ -1305,7 +1334,7 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st) {
 }
 
 // `count` independent products with the same operand layouts in as few launches as possible (GROUP_MAX per launch).
-int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
+int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes) {
     PP_CHECK_ARG(count >= 0 && (count == 0 || args), "pp_gemm_f32_grouped: bad argument");
     int i = 0;
     while (i < count) {
@@ -1350,6 +1379,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
             if (a->M == 0 || a->N == 0) continue;
             const int q = g.count++;
             fill_params(a, g.p[q]);
+            set_hole(g.p[q], holes ? &holes[j] : nullptr);
             g.p[q].vec = vec_ok(a) ? 1 : 0;
             int splits = direct ? (split_allowed(a) ? std::max(1, std::min(cdiv(cdiv(a->K, BK), spb), 32)) : 1)
                                 : pick_splits_by_work(a, spb);
@@ -1372,7 +1402,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st) {
 
 }  // namespace pp
 
-extern "C" int pp_gemm_f32(const pp_gemm_args* args, void* stream) { return pp::gemm_f32(args, pp::as_stream(stream)); }
+extern "C" int pp_gemm_f32(const pp_gemm_args* args, void* stream) { return pp::gemm_f32(args, pp::as_stream(stream), nullptr); }
 extern "C" int pp_gemm_f32_grouped(const pp_gemm_args* args, int32_t count, void* stream) {
-    return pp::gemm_f32_grouped(args, count, pp::as_stream(stream));
+    return pp::gemm_f32_grouped(args, count, pp::as_stream(stream), nullptr);
 }

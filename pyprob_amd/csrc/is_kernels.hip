@@ -12,7 +12,6 @@
 
 namespace pp {
 
-int gemm_f32(const pp_gemm_args* a, hipStream_t st);
 int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
                       const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
                       int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st, float* zero_like = nullptr,

@@ -1,0 +1,64 @@
+"""Zero-block skipping of the async GEMM tile and the side-stream weight gradients: same numbers as the plain path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import engine_from_golden, packed_from_golden, rel_err, synthetic_gumm_arrays
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(repo)r); sys.path.insert(0, %(repo)r + '/tests')
+from helpers import synthetic_gumm_arrays, synthetic_gum_arrays
+from pyprob_amd.engine import ICEngine
+from pyprob_amd.packed import PackedBatch
+from pyprob_amd.spec import NetSpec
+out = {}
+for name, H in (('gum', 512), ('gumm', 256)):
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=H)
+    if name == 'gum':
+        arr = synthetic_gum_arrays(1024, seed=3); addresses = ['mu']
+        spec.add_address('mu', 'Normal')
+    else:
+        arr, addresses = synthetic_gumm_arrays(700, seed=4, max_iter=4)
+        for a in addresses: spec.add_address(a, 'Uniform')
+    eng = ICEngine(spec, device='cuda:0', seed=5)
+    ids = np.array([spec.address_id[addresses[j]] for j in arr['addr_idx']])
+    pb = PackedBatch.from_ragged(arr['trace_len'], ids, arr['values'], arr['prior'], arr['obs'], len(spec.addresses)).to(eng.device)
+    l = eng.loss(pb, backward=True)
+    torch.cuda.synchronize()
+    out[name + '_loss'] = l.cpu().numpy()
+    out[name + '_grads'] = eng.grads.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def _run(tmp_path, tag, **env):
+    f = str(tmp_path / (tag + '.npz'))
+    e = dict(os.environ, PP_DETERMINISTIC='0', **env)
+    subprocess.run([sys.executable, '-c', SCRIPT % dict(repo=REPO), f], check=True, env=e, timeout=600)
+    return dict(np.load(f))
+
+
+def test_zero_blocks_and_side_stream_change_no_result(tmp_path):
+    """The same minibatches with (a) zero-block skipping and the side stream on (default), (b) both off: equal losses and
+    gradients up to the summation order of the split-K atomics."""
+    fast = _run(tmp_path, 'fast')
+    plain = _run(tmp_path, 'plain', PP_GEMM_HOLES='0', PP_SIDE_STREAM='0')
+    for k in fast:
+        if k.endswith('_loss'):
+            assert abs(float(fast[k][0]) - float(plain[k][0])) <= 1e-6 * abs(float(plain[k][0])), k
+        else:
+            assert rel_err(fast[k], plain[k]) < 2e-5, (k, rel_err(fast[k], plain[k]))
+            # per tensor region too: a skipped block that mattered would show up as a large relative error there
+            a, b = fast[k].reshape(-1, 1024), plain[k].reshape(-1, 1024)
+            scale = np.abs(b).max(1) + 1e-12
+            big = scale > 1e-6
+            assert (np.abs(a - b).max(1)[big] / scale[big]).max() < 5e-4
