@@ -383,7 +383,9 @@ int pp_lstm_input_gather(const pp_net* net, const float* params, const float* E,
                          const float* value, const int32_t* addr, const int32_t* prev_row, int32_t n_rows,
                          float* X, int64_t ldx, void* stream);
 
-/* Pointwise LSTM cell, gate order i,f,g,o (torch.nn.LSTM). G: [n,4H] pre-activations in, activated gates out. */
+/* Pointwise LSTM cell, gate order i,f,g,o (torch.nn.LSTM). G: [n,4H] pre-activations in, activated gates out.
+ * c_prev NULL = first time step of a trace (c_{-1} = 0, inference_network_lstm.py:186-187): the forget gate multiplies zero,
+ * its columns [H, 2H) of G are NOT read (pp_ic_loss leaves them uncomputed) and 0 is stored there for the backward pass. */
 int pp_lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int32_t n, int32_t H, void* stream);
 /* Backward of the cell for one time step. G: gates in, dG (pre-activation grads) out. dc_carry: dev [n,H];
  * rows < n_next hold dL/dc_t from step t+1 on entry; on exit rows < n hold dL/dc_{t-1}. */

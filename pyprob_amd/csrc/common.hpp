@@ -40,11 +40,14 @@ void set_error(const char* fmt, ...);
         if (rc__ != 0) return rc__; \
     } while (0)
 
-// A block of an output C[M, N] = A B^T whose tiles may skip part of the summation: for rows [m0, m1) x columns [n0, n1)
+// Blocks of an output C[M, N] = A B^T whose tiles may skip part of the summation: for rows [m0, m1) x columns [n0, n1)
 // the K indices [k0, k1) multiply zeros (or the block's result is not used at all: k = [0, K)). Element units; the
-// kernels skip whole 64 x 64 tiles / whole K slabs inside the block only.
-struct GemmHole {
+// kernels skip whole 64 x 64 tiles / whole K slabs inside a block only. Up to two blocks per product.
+struct GemmBlock {
     int m0, m1, n0, n1, k0, k1;
+};
+struct GemmHole {
+    GemmBlock b[2];
 };
 
 // gemm_f32.hip

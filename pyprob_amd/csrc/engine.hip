@@ -219,7 +219,7 @@ static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st, const st
 // nothing else in the step touches, so they run on a second HIP stream next to the chain dH -> cell backward -> dX ->
 // observe-embedding backward -> column sums instead of after it: fork after the head tails (head weight gradients),
 // fork again when dG is complete (LSTM weight gradients), join before pp_ic_loss returns. The stream and its events
-// are created once per host thread (no device memory involved). PP_SIDE_STREAM=0 keeps everything on the caller's stream.
+// are created once per host thread (no device memory involved). Opt-in (PP_SIDE_STREAM=1), see side_stream().
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork0 = nullptr, fork1 = nullptr, join = nullptr;
@@ -227,7 +227,10 @@ struct SideStream {
 };
 static SideStream* side_stream() {
     static thread_local SideStream ss;
-    static const int enabled = getenv("PP_SIDE_STREAM") ? atoi(getenv("PP_SIDE_STREAM")) : 1;
+    // Measured on MI355X (profiles/r02_b_*): the two forks and the join cost more than the overlap hides (GUM step, B = 1024,
+    // H = 512: 0.157 ms on one stream, 0.166 ms with the side stream; the kernels of both streams slow each other down
+    // and a cross-queue event wait is ~5 us) - off unless PP_SIDE_STREAM=1.
+    static const int enabled = getenv("PP_SIDE_STREAM") ? atoi(getenv("PP_SIDE_STREAM")) : 0;
     if (!enabled) return nullptr;
     if (ss.state == 0) {
         ss.state = -1;
@@ -251,9 +254,9 @@ static int fork_to(hipStream_t main, hipEvent_t ev, hipStream_t side) {
 
 static void queue_wgrad(std::vector<pp_gemm_args>& q, const float* dz, int64_t lddz, const float* x, int64_t ldx,
                         const int32_t* x_idx, float* dW, int n, int in, int out, std::vector<GemmHole>* holes = nullptr,
-                        GemmHole hole = GemmHole{0, 0, 0, 0, 0, 0}) {
+                        GemmHole hole = GemmHole{}) {
     if (holes) {
-        holes->resize(q.size(), GemmHole{0, 0, 0, 0, 0, 0});
+        holes->resize(q.size(), GemmHole{});
         holes->push_back(hole);
     }
     pp_gemm_args g{};
@@ -381,7 +384,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     if (!ff) {
     // a trace's first time step has no previous variable: columns [e_obs, c4) of its LSTM input row are zero
     // (inference_network_lstm.py:159-162) - rows [0, B) of the step-major layout
-    const GemmHole x_zero{0, B, 0, 4 * H, net->e_obs, net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim};
+    // ... and no previous cell state: its forget gate multiplies c_{-1} = 0, so columns [H, 2H) of its pre-activations are
+    // never looked at (lstm_cell_fwd/bwd with c_prev == NULL) - not computed at all
+    const GemmHole x_zero{{{0, B, 0, 4 * H, net->e_obs, net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim},
+                           {0, B, H, 2 * H, 0, I}}};
     prof_begin(0, st);
     PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st,
                       &x_zero));
@@ -472,7 +478,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     std::vector<GemmHole> wholes;
     bool forked = false;
     auto flush_wgrads = [&](hipStream_t stream, bool timed) -> int {
-        wholes.resize(wq.size(), GemmHole{0, 0, 0, 0, 0, 0});
+        wholes.resize(wq.size(), GemmHole{});
         PP_TRY(launch_wgrads(wq, stream, &wholes, timed));
         wq.clear();
         wholes.clear();
@@ -537,8 +543,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     if (!ff) {
     const int cz0 = net->e_obs, cz1 = net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim;   // previous-variable columns
     // dW_ih[:, previous-variable columns] gets nothing from the rows of first time steps (their inputs are zero there)
+    // ... and the forget-gate rows of dW_ih get nothing from them either (dG[:, H:2H] = 0 where c_{t-1} = 0)
     queue_wgrad(wq, w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, R, I, 4 * H, &wholes,
-                GemmHole{0, 4 * H, cz0, cz1, 0, B});
+                GemmHole{{{0, 4 * H, cz0, cz1, 0, B}, {H, 2 * H, 0, I, 0, B}}});
     if (T > 1) {
         const int r1 = bt->row_off[1];
         queue_wgrad(wq, w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, R - r1, H, 4 * H);
@@ -550,7 +557,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // (without a side stream wq is flushed at the very end, together with the observe-embedding weight gradients)
     // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding. Nobody reads the
     // previous-variable columns of first-time-step rows (no previous variable, no parameter behind them).
-    const GemmHole dx_unused{0, B, cz0, cz1, 0, 4 * H};
+    // The forget-gate part of the summation over the gates is zero for those rows.
+    const GemmHole dx_unused{{{0, B, cz0, cz1, 0, 4 * H}, {0, B, 0, I, H, 2 * H}}};
     PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, true, st, nullptr,
                         &dx_unused));   // dX was cleared by the gather kernel
     const int c1 = net->e_obs, c2 = c1 + net->smp_dim, c3 = c2 + net->dtype_dim, c4 = c3 + net->addr_dim,

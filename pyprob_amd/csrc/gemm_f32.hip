@@ -42,8 +42,9 @@ struct GemmParams {
     int vec_c;       // C rows allow 16-byte stores (direct tiles)
     int dbg_plain;   // measurement only: split partials are stored instead of added (WRONG results)
     // zero block (GemmHole): for output tiles inside rows [hm0, hm1) x columns [hn0, hn1) the K slabs [hs0, hs1) hold
-    // nothing but zeros (or the tile is not used at all) and are skipped. hs1 <= hs0: no zero block.
-    int hm0, hm1, hn0, hn1, hs0, hs1;
+    // nothing but zeros (or the tile is not used at all) and are skipped. hs1 <= hs0: no zero block. Two blocks per
+    // product; a tile inside both skips the longer slab interval.
+    int hm0[2], hm1[2], hn0[2], hn1[2], hs0[2], hs1[2];
     long long* dbg;  // debug phase stamps (NULL normally)
 };
 
@@ -482,10 +483,16 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     // Zero block: the slabs [hs0, hs0 + hlen) contribute nothing to this tile and are left out of its slab sequence
     // (the LSTM input of a trace's first time step has no previous-variable columns: inference_network_lstm.py:159-162).
     int hs0 = 0, hlen = 0;
-    if (p.hs1 > p.hs0 && m0 >= p.hm0 && min(m0 + 64, p.M) <= p.hm1 && n0 >= p.hn0 && min(n0 + 64, p.N) <= p.hn1 &&
-        !((A_KM && p.a_idx) || (B_KM && p.b_idx))) {   // workgroup-uniform
-        hs0 = p.hs0;
-        hlen = max(min(p.hs1, nslab_all) - p.hs0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // workgroup-uniform
+        if (p.hs1[q] > p.hs0[q] && m0 >= p.hm0[q] && min(m0 + 64, p.M) <= p.hm1[q] && n0 >= p.hn0[q] &&
+            min(n0 + 64, p.N) <= p.hn1[q] && !((A_KM && p.a_idx) || (B_KM && p.b_idx))) {
+            const int len = min(p.hs1[q], nslab_all) - p.hs0[q];
+            if (len > hlen) {
+                hs0 = p.hs0[q];
+                hlen = len;
+            }
+        }
     }
     const int nslab_total = nslab_all - hlen;
     const int per = (nslab_total + nz - 1) / nz;
@@ -1174,13 +1181,20 @@ static int launch_layout(const GemmParams& p, bool akm, bool bkm, int splits, hi
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // element ranges -> the slab interval the tiles may skip: only whole slabs inside [k0, k1) (k1 >= K: up to the last slab)
+static void clear_holes(GemmParams& p) {
+    for (int q = 0; q < 2; ++q) p.hm0[q] = p.hm1[q] = p.hn0[q] = p.hn1[q] = p.hs0[q] = p.hs1[q] = 0;
+}
 static void set_hole(GemmParams& p, const GemmHole* h) {
-    p.hm0 = p.hm1 = p.hn0 = p.hn1 = p.hs0 = p.hs1 = 0;
+    clear_holes(p);
     static const int enabled = getenv("PP_GEMM_HOLES") ? atoi(getenv("PP_GEMM_HOLES")) : 1;
-    if (!h || !enabled || h->k1 <= h->k0) return;
-    p.hm0 = h->m0; p.hm1 = h->m1; p.hn0 = h->n0; p.hn1 = h->n1;
-    p.hs0 = cdiv(h->k0, BK);
-    p.hs1 = h->k1 >= p.K ? cdiv(p.K, BK) : h->k1 / BK;
+    if (!h || !enabled) return;
+    for (int q = 0; q < 2; ++q) {
+        const GemmBlock& b = h->b[q];
+        if (b.k1 <= b.k0 || (q == 1 && enabled == 2)) continue;      // (PP_GEMM_HOLES=2: first block only, A/B measurements)
+        p.hm0[q] = b.m0; p.hm1[q] = b.m1; p.hn0[q] = b.n0; p.hn1[q] = b.n1;
+        p.hs0[q] = cdiv(b.k0, BK);
+        p.hs1[q] = b.k1 >= p.K ? cdiv(p.K, BK) : b.k1 / BK;
+    }
 }
 
 static void fill_params(const pp_gemm_args* a, GemmParams& p) {
@@ -1193,7 +1207,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.colsum = a->colsum;
     static const int plain = getenv("PP_DBG_PLAIN_SPLIT") ? atoi(getenv("PP_DBG_PLAIN_SPLIT")) : 0;
     p.dbg_plain = plain;
-    p.hm0 = p.hm1 = p.hn0 = p.hn1 = p.hs0 = p.hs1 = 0;
+    clear_holes(p);
     p.vec = 1;
     p.vec_c = (a->ldc % 4 == 0 && aligned16(a->C)) ? 1 : 0;
     static const int stamp_all = getenv("PP_DBG_STAMP") ? 1 : 0;   // debug: stamp every product (tools/timeline4.py)

@@ -318,11 +318,15 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ 
         float* g = G + (int64_t)r * 4 * H;
         const int64_t e = (int64_t)r * H + j;
         const float gi = sigmoidf_(g[j]);
-        const float gf = sigmoidf_(g[H + j]);
         const float gg = tanhf(g[2 * H + j]);
         const float go = sigmoidf_(g[3 * H + j]);
-        const float cp = c_prev ? c_prev[c_prev_shared ? j : e] : 0.0f;
-        const float cn = gf * cp + gi * gg;
+        // first time step (h0 = c0 = 0, inference_network_lstm.py:186-187): the forget gate multiplies zero; its
+        // pre-activation is not even computed (engine.hip, zero blocks of the input GEMM) and 0 is recorded for backward
+        float gf = 0.0f, cn = gi * gg;
+        if (c_prev) {
+            gf = sigmoidf_(g[H + j]);
+            cn += gf * c_prev[c_prev_shared ? j : e];
+        }
         g[j] = gi;
         g[H + j] = gf;
         g[2 * H + j] = gg;

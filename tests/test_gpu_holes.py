@@ -48,9 +48,9 @@ def _run(tmp_path, tag, **env):
 
 
 def test_zero_blocks_and_side_stream_change_no_result(tmp_path):
-    """The same minibatches with (a) zero-block skipping and the side stream on (default), (b) both off: equal losses and
+    """The same minibatches with (a) zero-block skipping (default) and the opt-in side stream on, (b) both off: equal losses and
     gradients up to the summation order of the split-K atomics."""
-    fast = _run(tmp_path, 'fast')
+    fast = _run(tmp_path, 'fast', PP_SIDE_STREAM='1')
     plain = _run(tmp_path, 'plain', PP_GEMM_HOLES='0', PP_SIDE_STREAM='0')
     for k in fast:
         if k.endswith('_loss'):

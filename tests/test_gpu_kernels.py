@@ -278,6 +278,17 @@ def test_lstm_cell_forward_backward(env, n, H):
     dG2 = dev(G, device)
     L.check(lib.pp_lstm_cell_fwd(dG2.data_ptr(), None, c.data_ptr(), h.data_ptr(), n, H, L.stream_ptr()))
     np.testing.assert_allclose(c.cpu().numpy(), i * gg, rtol=1e-5, atol=2e-6)
+    # ... and the forget gate is not read at all (pp_ic_loss does not even compute its pre-activation for those rows):
+    # garbage there changes nothing, the recorded gate is 0 so that the backward pass gives it a zero gradient
+    G3 = G.copy()
+    G3[:, H:2 * H] = np.nan
+    dG3 = dev(G3, device)
+    L.check(lib.pp_lstm_cell_fwd(dG3.data_ptr(), None, c.data_ptr(), h.data_ptr(), n, H, L.stream_ptr()))
+    np.testing.assert_allclose(c.cpu().numpy(), i * gg, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(h.cpu().numpy(), o * np.tanh(i * gg), rtol=1e-5, atol=2e-6)
+    assert float(dG3[:, H:2 * H].abs().max()) == 0.0
+    L.check(lib.pp_lstm_cell_bwd(dG3.data_ptr(), None, c.data_ptr(), ddh.data_ptr(), ddc.data_ptr(), n, 0, H, L.stream_ptr()))
+    assert torch.isfinite(dG3).all() and float(dG3[:, H:2 * H].abs().max()) == 0.0
 
 
 def _head_case(kind, n, K, rng):
