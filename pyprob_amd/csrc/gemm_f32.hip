@@ -736,35 +736,67 @@ struct GroupedParams {
     GemmParams p[GROUP_MAX];
     int first[GROUP_MAX + 1];   // first workgroup of problem q; first[count] = total
     int gx[GROUP_MAX], gy[GROUP_MAX], gz[GROUP_MAX];
+    int pmode[GROUP_MAX];       // XCD placement of the problem's tiles, see group_decode
     int count;
     int xcd_aware;
 };
 
 // Workgroup -> (problem, tile, K split). Workgroups are dealt round-robin to the 8 XCDs (id % 8) and each XCD has its
-// own L2: all K splits of one output tile are given ids with the same residue so that their float atomics meet in ONE
-// L2 instead of bouncing the line between XCDs. Every problem's workgroup count is a multiple of 8 (tiles padded up;
-// the padding workgroups exit).
+// own 4 MB L2; every problem starts at a workgroup id that is a multiple of 8, so local id & 7 IS the XCD.
+//   * all K splits of one output tile get the same residue: their float atomics meet in ONE L2;
+//   * pmode 1 (M-panel placement): all tiles of the row panel `by` run on XCD by % 8, column tiles and splits of a
+//     panel on consecutive ids - the A panel (the large operand of dW_ih = dG^T X and of dX = dG W_ih: dG, 8 MB) comes
+//     from HBM into ONE L2 once instead of once per column tile, B (X / W_ih, < 2 MB) lives in every L2;
+//   * pmode 2: the same along N (B panel shared), for products whose B operand is the large one;
+//   * pmode 0: tiles round-robin over the XCDs (few tiles in both directions).
+// Workgroup counts are padded (panels to a multiple of 8); the padding workgroups exit.
 __device__ __forceinline__ bool group_decode(const GroupedParams& g, int b, int& q, int& bx, int& by, int& bz) {
     q = 0;
     while (q + 1 < g.count && b >= g.first[q + 1]) ++q;   // workgroup-uniform
     const int l = b - g.first[q];
-    const int ntiles = g.gx[q] * g.gy[q];
+    const int gx = g.gx[q], gy = g.gy[q], gz = g.gz[q];
+    if (g.xcd_aware && g.pmode[q] == 1) {
+        const int r = l >> 3, per = gx * gz, w = r % per;
+        by = (r / per) * 8 + (l & 7);
+        bx = w % gx;
+        bz = w / gx;
+        return by < gy;
+    }
+    if (g.xcd_aware && g.pmode[q] == 2) {
+        const int r = l >> 3, per = gy * gz, w = r % per;
+        bx = (r / per) * 8 + (l & 7);
+        by = w % gy;
+        bz = w / gy;
+        return bx < gx;
+    }
+    const int ntiles = gx * gy;
     int tile;
     if (g.xcd_aware) {
         const int r = l >> 3;
-        bz = r % g.gz[q];
-        tile = (r / g.gz[q]) * 8 + (l & 7);
+        bz = r % gz;
+        tile = (r / gz) * 8 + (l & 7);
     } else {
         tile = l % ntiles;
         bz = l / ntiles;
     }
-    if (tile >= ntiles || bz >= g.gz[q]) return false;
-    bx = tile % g.gx[q];
-    by = tile / g.gx[q];
+    if (tile >= ntiles || bz >= gz) return false;
+    bx = tile % gx;
+    by = tile / gx;
     return true;
 }
 
-static inline int group_blocks(int gx, int gy, int gz) { return ((gx * gy + 7) / 8) * 8 * gz; }
+// placement of a problem: share the panel of the LARGER operand if that direction has at least 8 tiles to spread
+static inline int pick_pmode(int M, int N, int gx, int gy) {
+    static const int mode = getenv("PP_XCD_PANEL") ? atoi(getenv("PP_XCD_PANEL")) : 1;
+    if (!mode) return 0;
+    if (M >= N) return gy >= 8 ? 1 : (gx >= 8 ? 2 : 0);
+    return gx >= 8 ? 2 : (gy >= 8 ? 1 : 0);
+}
+static inline int group_blocks(int gx, int gy, int gz, int pmode = 0) {
+    if (pmode == 1) return ((gy + 7) / 8) * 8 * gx * gz;
+    if (pmode == 2) return ((gx + 7) / 8) * 8 * gy * gz;
+    return ((gx * gy + 7) / 8) * 8 * gz;
+}
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedParams g) {
@@ -1300,8 +1332,9 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
     g.p[0] = p;
     g.p[0].vec = vec ? 1 : 0;
     g.gx[0] = cdiv(p.N, tile); g.gy[0] = cdiv(p.M, tile); g.gz[0] = splits;
+    g.pmode[0] = pick_pmode(p.M, p.N, g.gx[0], g.gy[0]);
     g.first[0] = 0;
-    g.first[1] = group_blocks(g.gx[0], g.gy[0], splits);
+    g.first[1] = group_blocks(g.gx[0], g.gy[0], splits, g.pmode[0]);
     return kind == 1 ? launch_direct_grouped(g, akm, bkm, st)
          : kind == 2 ? launch_async_grouped(g, akm, bkm, st) : launch_grouped<4>(g, akm, bkm, st);
 }
@@ -1347,6 +1380,28 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole) {
                : launch_layout<64, 64, 32, 32, 1>(p, a->a_kmajor, a->b_kmajor, splits, st);
 }
 
+// 64 x 64 tile-slabs a product really walks once its zero blocks are left out (what the launch's work is split by)
+static int64_t effective_work(const pp_gemm_args* a, const GemmHole* h) {
+    const int gx = cdiv(a->N, 64), gy = cdiv(a->M, 64), nslab = cdiv(a->K, BK);
+    int64_t work = (int64_t)gx * gy * nslab;
+    static const int enabled = getenv("PP_GEMM_HOLES") ? atoi(getenv("PP_GEMM_HOLES")) : 1;
+    if (!h || !enabled || (a->a_kmajor && a->a_idx) || (a->b_kmajor && a->b_idx)) return work;
+    for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+            int best = 0;
+            for (int q = 0; q < 2; ++q) {
+                const GemmBlock& b = h->b[q];
+                if (b.k1 <= b.k0) continue;
+                const int m0 = by * 64, n0 = bx * 64;
+                if (m0 < b.m0 || std::min(m0 + 64, a->M) > b.m1 || n0 < b.n0 || std::min(n0 + 64, a->N) > b.n1) continue;
+                const int s0 = cdiv(b.k0, BK), s1 = b.k1 >= a->K ? nslab : b.k1 / BK;
+                best = std::max(best, std::min(s1, nslab) - s0);
+            }
+            work -= best;
+        }
+    return work;
+}
+
 // `count` independent products with the same operand layouts in as few launches as possible (GROUP_MAX per launch).
 int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes) {
     PP_CHECK_ARG(count >= 0 && (count == 0 || args), "pp_gemm_f32_grouped: bad argument");
@@ -1374,7 +1429,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
                         a->K, (long long)a->lda, (long long)a->ldb, (int)((uintptr_t)a->A & 15), (int)((uintptr_t)a->B & 15));
             as = as && async_ok(a);
             tiles += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
-            work += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) * cdiv(a->K, BK);
+            work += effective_work(a, holes ? &holes[k] : nullptr);
             work32 += (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT) * cdiv(a->K, BK);
             ++c;
         }
@@ -1403,7 +1458,8 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
             if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
             as = as && async_split_ok(a, splits);
             g.gx[q] = cdiv(a->N, tile); g.gy[q] = cdiv(a->M, tile); g.gz[q] = splits;
-            g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits);
+            g.pmode[q] = pick_pmode(a->M, a->N, g.gx[q], g.gy[q]);
+            g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits, g.pmode[q]);
         }
         if (g.count > 0 && direct) PP_TRY(launch_direct_grouped(g, akm, bkm, st));
         else if (g.count > 0 && as) PP_TRY(launch_async_grouped(g, akm, bkm, st));

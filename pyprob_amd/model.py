@@ -234,12 +234,12 @@ class Model:
                                    'load_inference_network first.')
             if lock_step is None:
                 lock_step = self._lock_step_safe(observe, *args, **kwargs)
-            if lock_step:
-                post = self._traces_lockstep(num_traces, observe, seed=seed, offset=offset,
-                                             likelihood_importance=likelihood_importance, *args, **kwargs)
-            elif lock_step == 'per_trace':      # the reference's loop: one particle per forward(), batch-1 network calls
+            if lock_step == 'per_trace':        # the reference's loop: one particle per forward(), batch-1 network calls
                 post = self._traces(num_traces, TraceMode.POSTERIOR, inference_engine, self._inference_network,
                                     trace_result, observe, likelihood_importance, *args, **kwargs)
+            elif lock_step:
+                post = self._traces_lockstep(num_traces, observe, seed=seed, offset=offset,
+                                             likelihood_importance=likelihood_importance, *args, **kwargs)
             else:                               # program as written: particle coroutines, address-grouped batches
                 post = self._traces_coroutines(num_traces, observe, trace_result, seed, offset, likelihood_importance,
                                                *args, **kwargs)
