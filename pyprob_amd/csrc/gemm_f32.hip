@@ -1193,9 +1193,9 @@ static int launch_async(const GemmParams& p, bool akm, bool bkm, hipStream_t st)
     return eight_waves(blocks) ? launch_async_kw<2>(p, akm, bkm, st) : launch_async_kw<1>(p, akm, bkm, st);
 }
 
-static int launch_async_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_t st) {
-    return eight_waves(g.first[g.count]) ? launch_async_grouped_kw<2>(g, akm, bkm, st)
-                                         : launch_async_grouped_kw<1>(g, akm, bkm, st);
+static int launch_async_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_t st, int64_t active_blocks = -1) {
+    return eight_waves(active_blocks >= 0 ? active_blocks : g.first[g.count]) ? launch_async_grouped_kw<2>(g, akm, bkm, st)
+                                                                              : launch_async_grouped_kw<1>(g, akm, bkm, st);
 }
 
 template <int BM, int BN, int WM, int WN, int VEC>
@@ -1381,9 +1381,10 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole) {
 }
 
 // 64 x 64 tile-slabs a product really walks once its zero blocks are left out (what the launch's work is split by)
-static int64_t effective_work(const pp_gemm_args* a, const GemmHole* h) {
+static int64_t effective_work(const pp_gemm_args* a, const GemmHole* h, int* active_tiles = nullptr) {
     const int gx = cdiv(a->N, 64), gy = cdiv(a->M, 64), nslab = cdiv(a->K, BK);
     int64_t work = (int64_t)gx * gy * nslab;
+    if (active_tiles) *active_tiles = gx * gy;
     static const int enabled = getenv("PP_GEMM_HOLES") ? atoi(getenv("PP_GEMM_HOLES")) : 1;
     if (!h || !enabled || (a->a_kmajor && a->a_idx) || (a->b_kmajor && a->b_idx)) return work;
     for (int by = 0; by < gy; ++by)
@@ -1398,6 +1399,7 @@ static int64_t effective_work(const pp_gemm_args* a, const GemmHole* h) {
                 best = std::max(best, std::min(s1, nslab) - s0);
             }
             work -= best;
+            if (best >= nslab && active_tiles) --*active_tiles;
         }
     return work;
 }
@@ -1429,7 +1431,9 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
                         a->K, (long long)a->lda, (long long)a->ldb, (int)((uintptr_t)a->A & 15), (int)((uintptr_t)a->B & 15));
             as = as && async_ok(a);
             tiles += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
-            work += effective_work(a, holes ? &holes[k] : nullptr);
+            static const int effw = getenv("PP_GROUP_EFFWORK") ? atoi(getenv("PP_GROUP_EFFWORK")) : 1;
+            work += effw ? effective_work(a, holes ? &holes[k] : nullptr)
+                         : (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) * cdiv(a->K, BK);
             work32 += (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT) * cdiv(a->K, BK);
             ++c;
         }
@@ -1440,6 +1444,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         const int spb = direct ? (int)std::max<int64_t>(8, (work32 + target_direct - 1) / target_direct)
                                : (int)std::max<int64_t>(2, (work + target - 1) / target);
         const int tile = direct ? DT : 64;
+        int64_t active_blocks = 0;   // workgroups that have slabs to walk (tiles inside a zero block exit at once)
         int j = i;
         for (; j < count && g.count < GROUP_MAX; ++j) {
             const pp_gemm_args* a = &args[j];
@@ -1458,11 +1463,16 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
             if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
             as = as && async_split_ok(a, splits);
             g.gx[q] = cdiv(a->N, tile); g.gy[q] = cdiv(a->M, tile); g.gz[q] = splits;
+            {
+                int act = g.gx[q] * g.gy[q];
+                if (tile == 64) (void)effective_work(a, holes ? &holes[j] : nullptr, &act);
+                active_blocks += (int64_t)act * splits;
+            }
             g.pmode[q] = pick_pmode(a->M, a->N, g.gx[q], g.gy[q]);
             g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits, g.pmode[q]);
         }
         if (g.count > 0 && direct) PP_TRY(launch_direct_grouped(g, akm, bkm, st));
-        else if (g.count > 0 && as) PP_TRY(launch_async_grouped(g, akm, bkm, st));
+        else if (g.count > 0 && as) PP_TRY(launch_async_grouped(g, akm, bkm, st, active_blocks));
         else
         if (g.count > 0) PP_TRY(launch_grouped<4>(g, akm, bkm, st));
         i = j;
