@@ -1417,7 +1417,9 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         const int akm = args[i].a_kmajor, bkm = args[i].b_kmajor;
         // slabs each workgroup walks so that the launch has ~target workgroups
         static const int target_staged = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
-        static const int target_async = getenv("PP_GROUP_BLOCKS_ASYNC") ? atoi(getenv("PP_GROUP_BLOCKS_ASYNC")) : 320;
+        // (with the zero blocks left out of the work estimate: 128-256 active workgroups measured equal, 0.152 ms per GUM
+        // step; 320+ costs 4 us in split-K atomics, one split per tile 3 us in idle CUs - profiles/r02_e/f_ab_*.json)
+        static const int target_async = getenv("PP_GROUP_BLOCKS_ASYNC") ? atoi(getenv("PP_GROUP_BLOCKS_ASYNC")) : 192;
         static const int target_direct = getenv("PP_GROUP_BLOCKS_DIRECT") ? atoi(getenv("PP_GROUP_BLOCKS_DIRECT")) : 1536;
         int64_t work = 0, work32 = 0, tiles = 0;
         bool as = true;
