@@ -11,10 +11,15 @@ hidden 512, 1 643 583 parameters, fp32. For N > 1 the driver launches one proces
 (torch.distributed.run); per-GPU work is fixed (weak scaling), value = whole-job traces/s.
 
 The JSON line also carries
-  roofline     : the dominant kernel (fp32 MFMA GEMM, forward X*W_ih^T launch) timed live with HIP events on the
-                 stream it runs on, priced against the fp32-matrix peak (157.3 TFLOP/s)
+  roofline     : the dominant kernel of the step - the grouped weight-gradient launch of the backward pass (fp32 MFMA) -
+                 timed live with HIP events on the stream it runs on inside the timed region, priced against the
+                 fp32-matrix peak (157.3 TFLOP/s); `second_kernel` = the forward input GEMM, `hbm_kernels` = the
+                 HBM-bound launches (observe embedding + LSTM input rows, i.e. the gather path; the Adam pass) in
+                 algorithmic GB/s against 8 TB/s, `whole_step` = SURVEY.md 8(d)'s algorithmic FLOPs of the whole step /
+                 wall-clock step time; `traffic` = HBM bytes per launch from the committed PMC passes (`traffic_source`)
   cpu_baseline : the numpy oracle port of the same step (forward + backward + Adam) timed on this host's cores on a
-                 bounded sample (rank 0, N = 1 only)
+                 bounded sample (rank 0, N = 1 only); `cpu_baseline_torch` = the torch-CPU restatement of the reference's
+                 step (nn.LSTM / nn.Linear / autograd / optim.Adam, oracle/torch_ref.py) timed the same way
 """
 import argparse
 import ctypes as C
@@ -78,6 +83,43 @@ def cpu_baseline_train(lstm_dim, batch, budget_s=12.0):
     return dict(value=steps * batch / dt, unit='traces/s', cores=os.cpu_count(), kind='port',
                 sample='%d steps of %d GUM traces, H=%d: oracle/ic_oracle.py loss_and_grads + adam_step (numpy fp32, '
                        'BLAS threads = all cores)' % (steps, batch, lstm_dim))
+
+
+def cpu_baseline_torch(lstm_dim, batch, budget_s=10.0):
+    """The reference's own host kernels for this step (torch CPU: nn.LSTM, nn.Linear, autograd, optim.Adam), vectorised
+    over the minibatch (oracle/torch_ref.py): an upper bound of what pyprob itself reaches on these cores."""
+    from oracle.torch_ref import time_training_steps
+    cores = os.cpu_count()
+    rate, steps, threads = time_training_steps(lstm_dim, batch, budget_s=budget_s, threads=min(cores, 64))
+    return dict(value=rate, unit='traces/s', cores=threads, kind='port',
+                sample='%d steps of %d GUM traces, H=%d: oracle/torch_ref.py (torch %s CPU nn.LSTM + nn.Linear + autograd + '
+                       'optim.Adam, %d intra-op threads of %d host cores; no per-trace Python, i.e. an upper bound of the '
+                       'reference)' % (steps, batch, lstm_dim, torch.__version__, threads, cores))
+
+
+def cpu_baseline_gumm(lstm_dim, batch, budget_s=10.0):
+    """Oracle port of one ragged (GaussianUnknownMeanMarsaglia) training step."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from helpers import synthetic_gumm_arrays
+    from oracle import ic_oracle as O
+    from pyprob_amd.spec import NetSpec
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=lstm_dim)
+    arr, addresses = synthetic_gumm_arrays(batch, seed=1, max_iter=6)
+    for a in addresses:
+        spec.add_address(a, 'Uniform')
+    rng = np.random.default_rng(0)
+    P = {n: spec.init_tensor(n, rng) for n in spec.tensors}
+    steps, t0 = 0, time.time()
+    while True:
+        net = O.Net(P, ['obs0', 'obs1'], K=10, dtype=np.float32)
+        O.loss_and_grads(net, arr, addresses, ['Uniform'] * len(addresses))
+        steps += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return dict(value=steps * batch / dt, unit='traces/s', cores=os.cpu_count(), kind='port',
+                sample='%d steps of %d GUMM traces (ragged, %d heads), H=%d: oracle/ic_oracle.py loss_and_grads (numpy fp32, '
+                       'per-sub-batch loops like the reference, no optimizer)' % (steps, batch, len(addresses), lstm_dim))
 
 
 def cpu_baseline_is(n=20000):
@@ -205,30 +247,58 @@ def main():
 
         dominant = eager_pass(1, min(K, 50)) if args.graph else collect(1, K)
         second = eager_pass(0, min(K, 50))
+        gather = eager_pass(2, min(K, 50))
+        adam = eager_pass(3, min(K, 50))
         final_loss = float(eng.loss_buf[0].item())
         units = B * K
         metric, unit = 'ic_train_traces_per_sec', 'traces/s'
-        pmc = {}
+        pmc, pmc_file = {}, os.path.join('profiles', 'r02_pmc_traffic.json')
         try:   # HBM bytes per launch from the committed PMC passes (rocprof cannot run inside bench.py)
-            with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as f:
+            with open(os.path.join(REPO, pmc_file)) as f:
                 pmc = json.load(f)['kernels'] if (B == 1024 and args.lstm_dim == 512) else {}
         except (OSError, KeyError, ValueError):
             pass
 
-        def roof(sample, key, label):
-            avg_ms, flops, n = sample
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            return dict(bound='mfma', achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=pmc.get(key, {}).get('traffic_bytes_per_launch'),
-                        algorithmic_bytes=pmc.get(key, {}).get('algorithmic_bytes_per_launch'), kernel=label,
-                        avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=n, flops_per_launch=flops)
+        def roof(sample, key, label, bound='mfma'):
+            avg_ms, work, n = sample
+            if bound == 'mfma':
+                ach, peak, u = work / (avg_ms * 1e-3) / 1e12, FP32_MATRIX_PEAK_TFLOPS, 'TFLOP/s'
+            else:
+                ach, peak, u = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
+            d = dict(bound=bound, achieved=round(ach, 3), peak=peak, unit=u, frac=round(ach / peak, 4),
+                     traffic=pmc.get(key, {}).get('traffic_bytes_per_launch'),
+                     algorithmic_bytes=pmc.get(key, {}).get('algorithmic_bytes_per_launch') if bound == 'mfma' else work,
+                     kernel=label, avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=n)
+            d['flops_per_launch' if bound == 'mfma' else 'bytes_per_launch'] = work
+            d['traffic_source'] = (pmc_file + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)') \
+                if d['traffic'] is not None else None
+            return d
+        H, I = args.lstm_dim, eng.spec.lstm_in
         if dominant:
             out['roofline'] = roof(dominant, 'wgrad_group',
                                    'gemm_f32_async_grouped_kernel<TN> (weight-gradient group of the backward pass: dW_ih '
-                                   '%dx%dx%d + head and observe-embedding leaves, one launch)' % (4 * args.lstm_dim, eng.spec.lstm_in, B))
+                                   '%dx%dx%d + head and observe-embedding leaves, one launch; FLOPs by SURVEY.md 8(d), the '
+                                   'kernel skips the zero blocks of first-time-step rows)' % (4 * H, I, B))
             if second:
                 out['roofline']['second_kernel'] = roof(second, 'input_gemm', 'gemm_f32_async_kernel<NT> (forward X*W_ih^T, '
-                                                        '%dx%dx%d)' % (B, 4 * args.lstm_dim, eng.spec.lstm_in))
+                                                        '%dx%dx%d)' % (B, 4 * H, I))
+            hbm = []
+            if gather:
+                hbm.append(roof(gather, 'obs_embed_fwd', 'obs_embed_fwd_kernel (observe embedding + fused address-dispatch '
+                                'gather of the LSTM input rows; latency-bound: %d traces x ~3 KB)' % B, bound='hbm'))
+            if adam:
+                hbm.append(roof(adam, 'adam', 'adam_kernel (one pass over params, grads, both moments; clears the gradients)',
+                                bound='hbm'))
+            out['roofline']['hbm_kernels'] = hbm
+            # training FLOPs per GUM trace = 3 x (18 496 + 2 I 4H + 2 (H hid + hid 3K) + 8)
+            hid = int((H + 30) / 2)
+            flops_trace = 3.0 * (18496 + 2 * I * 4 * H + 2 * (H * hid + hid * 30) + 8)
+            step_s = dt / K
+            ws = flops_trace * B / step_s / 1e12
+            out['roofline']['whole_step'] = dict(bound='mfma', achieved=round(ws, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+                                                 frac=round(ws / FP32_MATRIX_PEAK_TFLOPS, 4), flops_per_step=flops_trace * B,
+                                                 note='algorithmic FLOPs of the whole step (SURVEY.md 8d, x3 for training) / '
+                                                      'wall-clock step time of the timed region')
         config = dict(workload='GaussianUnknownMean IC training, offline traces resident in HBM, LSTM hidden=%d, '
                                'batch=%d per GPU' % (args.lstm_dim, B),
                       traces_in_hbm=per_rank * world, params=eng.spec.num_parameters(), global_batch=B * world,
@@ -253,12 +323,18 @@ def main():
         lr = 1e-3 * (world ** 0.5)
         for i in range(W):
             eng.train_step(batches[i % nb], lr)
+        lib.pp_prof_arm(1, K)
         barrier()
         t0 = time.perf_counter()
         for i in range(K):
             eng.train_step(batches[(W + i) % nb], lr)
         barrier()
         dt = time.perf_counter() - t0
+        ms = np.zeros(K, np.float32)
+        fl = np.zeros(K, np.float64)
+        cnt = C.c_int32(0)
+        lib.pp_prof_collect(ms.ctypes.data, K, C.byref(cnt), fl.ctypes.data)
+        lib.pp_prof_arm(1, 0)
         units = B * K
         metric, unit = 'ic_train_traces_per_sec', 'traces/s'
         mean_len = float(np.mean([b.mean_length_controlled for b in batches]))
@@ -275,18 +351,32 @@ def main():
                                unit='TFLOP/s', frac=round(flops_step * K / dt / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
                                kernel='whole step (all GEMM + elementwise kernels), algorithmic FLOPs of SURVEY.md 8(d) x3 for '
                                       'training / wall-clock step time')
+        if cnt.value > 0:
+            avg_ms, flops = float(ms[:cnt.value].mean()), float(fl[:cnt.value].mean())
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            out['roofline']['dominant_kernel'] = dict(
+                bound='mfma', achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=int(cnt.value),
+                flops_per_launch=flops, kernel='grouped weight-gradient launch holding dW_ih / dW_hh of the backward pass '
+                                               '(the head products of the %d addresses ride in the same grouped launches)' % len(addresses))
     else:
         from pyprob_amd.is_engine import ISRunner, gum_posterior
         n = args.particles // world
         run = ISRunner(eng)
         for i in range(W):
             gum_posterior(eng, n, seed=rank, offset=rank * n, runner=run)
+        lib.pp_prof_arm(4, K)
         barrier()
         t0 = time.perf_counter()
         for i in range(K):
             st = gum_posterior(eng, n, seed=7 + i, offset=rank * n, runner=run)
         barrier()
         dt = time.perf_counter() - t0
+        ms = np.zeros(K, np.float32)
+        fl = np.zeros(K, np.float64)
+        cnt = C.c_int32(0)
+        lib.pp_prof_collect(ms.ctypes.data, K, C.byref(cnt), fl.ctypes.data)
+        lib.pp_prof_arm(4, 0)
         units = n * K
         metric, unit = 'is_posterior_particles_per_sec', 'particles/s'
         # HBM roofline of the per-particle chain (the network itself runs once for one shared row): algorithmic bytes per
@@ -299,6 +389,14 @@ def main():
                                kernel='is_mixture_shared_kernel<0> + logweight_multi_kernel + is_stats_partial_kernel (whole '
                                       'posterior call incl. the batch-1 network evaluation, wall-clock; the sampling kernel '
                                       'is transcendental-bound, see profiles/)')
+        if cnt.value > 0:
+            avg_ms, nbytes = float(ms[:cnt.value].mean()), float(fl[0])
+            k_ach = nbytes / (avg_ms * 1e-3) / 1e9
+            out['roofline']['dominant_kernel'] = dict(
+                bound='hbm', achieved=round(k_ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(k_ach / HBM_PEAK_GBS, 5),
+                avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=int(cnt.value), bytes_per_launch=nbytes,
+                kernel='is_mixture_shared_kernel<0> (Philox draw of the mixture component and the value + log q per particle; '
+                       'transcendental-bound: logsumexp over K components, inverse CDF)')
         config = dict(workload='GaussianUnknownMean posterior_results IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, '
                                'LSTM hidden=%d, %d particles per posterior call per GPU' % (args.lstm_dim, n),
                       particles_per_call=n * world, parallelism='particles sharded x%d' % world,
@@ -316,8 +414,13 @@ def main():
                     dtype='f32', data='synthetic', config=config)
         line.update(out)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline_train(args.lstm_dim, args.batch) if args.workload == 'train' \
-                else cpu_baseline_is()
+            if args.workload == 'train':
+                line['cpu_baseline'] = cpu_baseline_train(args.lstm_dim, args.batch)
+                line['cpu_baseline_torch'] = cpu_baseline_torch(args.lstm_dim, args.batch)
+            elif args.workload == 'train_gumm':
+                line['cpu_baseline'] = cpu_baseline_gumm(args.lstm_dim, args.batch)
+            else:
+                line['cpu_baseline'] = cpu_baseline_is()
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

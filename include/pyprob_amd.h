@@ -404,9 +404,14 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
                     float* loss_acc, int32_t* nonfinite, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * In-stream kernel timing for bench.py's roofline leg: when armed, pp_ic_loss records a hipEvent pair
- * around the kernel class `which` (0: forward input GEMM X*W_ih^T; 1: the grouped weight-gradient launch of the
- * backward pass) on its stream, once per call.
+ * In-stream kernel timing for bench.py's roofline leg: when armed, pp_ic_loss / pp_adam_step record a hipEvent pair
+ * around the kernel class `which` on their stream, once per call:
+ *   0  forward input GEMM X*W_ih^T                                   work = FLOPs
+ *   1  the grouped weight-gradient launch of the backward pass       work = FLOPs
+ *   2  observe embedding + LSTM input rows (the gather path)         work = algorithmic bytes
+ *   3  pp_adam_step (optimizer pass over the flat buffers)           work = algorithmic bytes
+ *   4  the draw + log q kernel of pp_is_step                         work = algorithmic bytes
+ * pp_prof_collect returns the elapsed milliseconds and the work of every recorded launch (flops_out).
  * ---------------------------------------------------------------------------------------------------- */
 int pp_prof_arm(int32_t which, int32_t max_samples);          /* allocate event pairs; 0 disarms */
 int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_out); /* syncs the events */

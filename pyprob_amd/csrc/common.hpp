@@ -50,6 +50,10 @@ struct GemmHole {
     GemmBlock b[2];
 };
 
+// engine.hip: in-stream kernel timing (pp_prof_arm / pp_prof_collect)
+void prof_begin(int which, hipStream_t st);
+void prof_end(int which, double work, hipStream_t st);
+
 // gemm_f32.hip
 int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole = nullptr);
 int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes = nullptr);

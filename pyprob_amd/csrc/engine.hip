@@ -76,10 +76,10 @@ struct Prof {
 };
 static Prof g_prof;
 
-static void prof_begin(int which, hipStream_t st) {
+void prof_begin(int which, hipStream_t st) {
     if (g_prof.which == which && g_prof.used < (int)g_prof.ev0.size()) (void)hipEventRecord(g_prof.ev0[g_prof.used], st);
 }
-static void prof_end(int which, double flops, hipStream_t st) {
+void prof_end(int which, double flops, hipStream_t st) {
     if (g_prof.which == which && g_prof.used < (int)g_prof.ev0.size()) {
         (void)hipEventRecord(g_prof.ev1[g_prof.used], st);
         g_prof.flops[g_prof.used] = flops;
@@ -346,6 +346,13 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     const bool fused_obs = obs_fused_supported(net);
     const float* heads_in = w.Hs;     // input rows of the proposal layers: LSTM outputs, or observe embeddings (FF)
     int64_t heads_ld = H;
+    // kernel class 2 of the in-stream timing: observe embedding + LSTM input rows (the gather path). Algorithmic bytes:
+    // observations and per-row (value, address, previous row) in; X rows, E / cat / f1 and the observables' hidden
+    // activations out (4 I per trace-step written, 4 n_obs per trace read)
+    double gather_bytes = 4.0 * B * bt->obs_width + 12.0 * R + 4.0 * (ff ? 0.0 : (double)R * I) + 3.0 * 4.0 * B * net->e_obs;
+    if (!ff && (flags & PP_LOSS_BACKWARD)) gather_bytes += 4.0 * R * I;   // the same launch clears dX
+    for (int o = 0; o < net->n_obs; ++o) gather_bytes += 4.0 * B * net->obs_hid[o];
+    prof_begin(2, st);
     if (ff) {
         // every time step's proposal layer reads the observe embedding of its trace (:72,85): Hs rows = E[trace]
         // (single-statement batches: row r IS trace r, the heads read E in place and the embedding kernel clears the
@@ -381,6 +388,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
                                  bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), PP_LOSS_SLOTS_FLOATS));
     }
+    prof_end(2, gather_bytes, st);
     if (!ff) {
     // a trace's first time step has no previous variable: columns [e_obs, c4) of its LSTM input row are zero
     // (inference_network_lstm.py:159-162) - rows [0, B) of the step-major layout
@@ -679,8 +687,13 @@ int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                  const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* arrived, int32_t n_tensors,
                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t flags,
                  const int32_t* skip, void* stream) {
-    return pp::adam_step(params, grads, exp_avg, exp_avg_sq, n_params, chunk_tensor, active, tensor_step, arrived, n_tensors,
-                         lr, beta1, beta2, eps, weight_decay, grad_scale, flags, skip, pp::as_stream(stream));
+    // kernel class 3 of the in-stream timing: the optimizer pass over the flat buffers (HBM bound): reads of params, grads
+    // and both moments, writes of params, both moments and the cleared gradients - 8 x 4 bytes per (padded) parameter
+    pp::prof_begin(3, pp::as_stream(stream));
+    const int rc = pp::adam_step(params, grads, exp_avg, exp_avg_sq, n_params, chunk_tensor, active, tensor_step, arrived,
+                                 n_tensors, lr, beta1, beta2, eps, weight_decay, grad_scale, flags, skip, pp::as_stream(stream));
+    pp::prof_end(3, ((flags & PP_ADAM_ZERO_GRADS) ? 32.0 : 28.0) * (double)n_params, pp::as_stream(stream));
+    return rc;
 }
 
 int pp_colsum_f32(const float* X, int64_t ldx, const int32_t* row_idx, int32_t n_rows, int32_t n_cols, float* out,

@@ -454,6 +454,8 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     PP_TRY(lin(h, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
     PP_TRY(lin(w.A1, w.hid4, P + ad.w2, P + ad.b2, nullptr, w.Y, w.out4, m, ad.hid, ad.n_out, false, false, st));
     dim3 grid(cdiv(n, 256)), block(256);
+    // kernel class 4 of the in-stream timing: draw + log q per particle (writes value and log q: 8 algorithmic bytes each)
+    prof_begin(4, st);
     if (ad.kind == PP_HEAD_CATEGORICAL) {
         hipLaunchKernelGGL(is_categorical_kernel, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, n, ad.n_out, value_in,
                            value_out, logq_out, seed, offset);
@@ -482,6 +484,7 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
             hipLaunchKernelGGL(is_mixture_kernel<2>, grid, block, 0, st, w.Y, w.out4, shared ? 1 : 0, prior, prior_stride,
                                n, ad.n_out / 3, value_in, value_out, logq_out, seed, offset);
     }
+    prof_end(4, 8.0 * n + (value_in ? 4.0 * n : 0.0), st);
     PP_LAUNCH_CHECK("pp_is_step(sample)");
     return 0;
 }

@@ -137,3 +137,31 @@ def test_neg_inf_rescue():
     lp, dy, _ = O.head_truncated_normal_mixture(y, prior, np.array([0.3, 1.5]), 10)
     assert np.isfinite(lp[0]) and np.isneginf(lp[1])
     assert np.all(np.isfinite(dy[0])) and np.all(dy[1, :20] == 0)
+
+
+def test_torch_restatement_matches_the_reference_records():
+    """oracle/torch_ref.py (the torch-CPU restatement bench.py times as `cpu_baseline_torch`): loss and every gradient of
+    the `gum` golden minibatch, as the reference recorded them (same torch kernels: agreement to the last bits)."""
+    import torch
+    from conftest import load_golden
+    from oracle.torch_ref import GumNetwork
+    meta, params, batch, loss, isr = load_golden('gum')
+    net = GumNetwork(meta['lstm_dim'], K=meta['mixture_components'])
+    address = meta['addresses'][0]
+    net.load_reference_state(params, meta['obs_names'], address)
+    out = net.loss(torch.tensor(batch['obs']), torch.tensor(batch['values']), torch.tensor(batch['prior'][:, 0]),
+                   torch.tensor(batch['prior'][:, 1]))
+    assert abs(float(out.detach()) - float(loss['loss'])) < 1e-6
+    out.backward()
+    gold = {n: loss['g%d' % i] for i, n in enumerate(meta['param_names'])}
+    pairs = {'_layers_lstm.weight_ih_l0': net.lstm.weight_ih_l0, '_layers_lstm.weight_hh_l0': net.lstm.weight_hh_l0,
+             '_layers_lstm.bias_ih_l0': net.lstm.bias_ih_l0,
+             '_layers_proposal.%s._ff._layers.0.weight' % address: net.proposal[0].weight,
+             '_layers_proposal.%s._ff._layers.1.bias' % address: net.proposal[1].bias,
+             '_layers_observe_embedding_final._layers.0.weight': net.final[0].weight,
+             '_layers_observe_embedding.obs0._layers.0.weight': net.obs[0][0].weight,
+             '_layers_address_embedding.' + address: net.address_embedding}
+    for name, p in pairs.items():
+        ref = gold[name]
+        got = np.zeros_like(ref) if p.grad is None else p.grad.numpy()
+        assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-6), name

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_train_pmc_{FETCH,WRITE}_SIZE.csv (tools/pmc_summary.py of the two rocprofv3 --pmc passes) ->
+profiles/<round>_pmc_traffic.json, the per-launch HBM traffic bench.py quotes in `roofline.traffic`.
+FETCH_SIZE / WRITE_SIZE count KB; on gfx950 FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md, HBM
+section) and is doubled."""
+import csv
+import json
+import sys
+
+KEYS = [('wgrad_group', 'gemm_f32_async_grouped_kernel<true, true', 17499912,
+         'weight-gradient leaves of the backward pass (dW_ih 2048x212x1024, dW1 271x512x1024, dW2 30x271x1024, observe-embedding leaves)'),
+        ('input_gemm', 'gemm_f32_async_kernel<false, false', 11010048, 'forward X*W_ih^T, 1024x2048x212'),
+        ('dx_gemm', 'gemm_f32_async_grouped_kernel<false, true', 10995712, 'dX = dG W_ih, 1024x212x2048'),
+        ('obs_embed_fwd', 'obs_embed_fwd_kernel', None, 'observe embedding + LSTM input rows'),
+        ('adam', 'adam_kernel', None, 'Adam pass over the flat buffers')]
+
+
+def load(path):
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        rows.setdefault(r['kernel'], []).append(r)
+    return rows
+
+
+def main(tag, out):
+    fetch, write = load('profiles/%s_train_pmc_FETCH_SIZE.csv' % tag), load('profiles/%s_train_pmc_WRITE_SIZE.csv' % tag)
+    kernels = {}
+    for key, needle, algo, what in KEYS:
+        f = [r for k, v in fetch.items() if needle in k for r in v]
+        w = [r for k, v in write.items() if needle in k for r in v]
+        if not f or not w:
+            continue
+        f, w = max(f, key=lambda r: float(r['avg_duration_ns'])), max(w, key=lambda r: float(r['avg_duration_ns']))
+        fk, wk = float(f['avg_value']), float(w['avg_value'])
+        kernels[key] = dict(kernel='%s grid (%s,%s,%s): %s' % (needle, f['wg_x'], f['wg_y'], f['wg_z'], what), FETCH_SIZE_KB_raw=fk,
+                            WRITE_SIZE_KB=wk, traffic_bytes_per_launch=int(round((2.0 * fk + wk) * 1024)),
+                            algorithmic_bytes_per_launch=algo)
+    doc = dict(source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_train.sh) of '
+                      '`python bench.py --steps 20 --warmup 5 --no-cpu-baseline`; per-kernel averages in profiles/%s_train_pmc_*.csv' % tag,
+               gfx950_fetch_correction='FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section): '
+                                       'doubled; counter unit KB = 1024 bytes', kernels=kernels)
+    json.dump(doc, open(out, 'w'), indent=1)
+    for k, v in kernels.items():
+        print(k, v['traffic_bytes_per_launch'], v['algorithmic_bytes_per_launch'])
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
