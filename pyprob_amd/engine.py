@@ -51,11 +51,15 @@ class ICEngine:
         self.params = new
         for name, arr in host.items():
             self.set_tensor(name, arr)
-        # grads carry a tail: [n_tensors presence flags | loss] so that DP needs ONE all-reduce
-        self.grads_full = torch.zeros(n + spec.n_tensors + 1, dtype=torch.float32, device=self.device)
+        # grads carry a tail: [n_tensors presence flags | loss | non-finite flag] so that DP needs ONE all-reduce
+        #  and every rank sees the SAME skip decision: a batch whose loss is not finite on ANY rank is
+        # skipped by ALL ranks (the sum of the flags is > 0 everywhere; the NaN gradients it summed in are discarded)
+        self.grads_full = torch.zeros(n + spec.n_tensors + 2, dtype=torch.float32, device=self.device)
         self.grads = self.grads_full[:n]
         self.active = self.grads_full[n:n + spec.n_tensors]
-        self.loss_buf = self.grads_full[n + spec.n_tensors:]     # the loss kernel writes straight into the tail
+        self.loss_buf = self.grads_full[n + spec.n_tensors:n + spec.n_tensors + 1]   # the loss kernel writes into the tail
+        self.status_tail = self.grads_full[n + spec.n_tensors + 1:]                  # float copy of the non-finite flag
+        self.dp_skip = []      # (offset, count) float ranges left out of the gradient all-reduce, see skip_recurrent_weights
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.tensor_step = torch.zeros(spec.n_tensors, dtype=torch.int32, device=self.device)
@@ -128,12 +132,21 @@ class ICEngine:
         if keep_lp:
             flags |= L.PP_LOSS_KEEP_LP
             lp = torch.empty(batch.n_rows, dtype=torch.float32, device=self.device)
-        rc = self.lib.pp_ic_loss(C.byref(self.net), C.byref(batch.c), self.params.data_ptr(),
-                                 self.grads.data_ptr() if backward else None, self.workspace.data_ptr(), self.ws_bytes,
-                                 (self.loss_buf if loss_out is None else loss_out).data_ptr(),
-                                 (self.status_buf if status_out is None else status_out).data_ptr(), L.ptr(lp), flags,
-                                 L.stream_ptr())
-        L.check(rc, 'pp_ic_loss')
+        if getattr(self, '_use_ops', False):     # through the operators (pyprob_amd/ops.py) instead of the direct C call
+            from .ops import ops
+            bdev, bhost = batch.op_tensors(self.device)
+            l_, s_, lp_ = ops.ic_loss(self.params, self.grads, self.workspace, bdev, bhost, self.net_handle, flags)
+            (self.loss_buf if loss_out is None else loss_out)[:1].copy_(l_)
+            (self.status_buf if status_out is None else status_out)[:1].copy_(s_)
+            if keep_lp:
+                lp.copy_(lp_)
+        else:
+            rc = self.lib.pp_ic_loss(C.byref(self.net), C.byref(batch.c), self.params.data_ptr(),
+                                     self.grads.data_ptr() if backward else None, self.workspace.data_ptr(), self.ws_bytes,
+                                     (self.loss_buf if loss_out is None else loss_out).data_ptr(),
+                                     (self.status_buf if status_out is None else status_out).data_ptr(), L.ptr(lp), flags,
+                                     L.stream_ptr())
+            L.check(rc, 'pp_ic_loss')
         if backward:
             self._set_active(batch)
         return (self.loss_buf[:1], lp) if keep_lp else self.loss_buf[:1]
@@ -154,20 +167,29 @@ class ICEngine:
         when data-parallel (inference_network.py:324-325). zero_grads=True also performs the NEXT step's
         optimizer.zero_grad() (:486) in the same pass: the consumed gradient chunks are cleared, gradients of tensors
         without a gradient this step are zero already."""
-        rc = self.lib.pp_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                   self.exp_avg_sq.data_ptr(), self.spec.n_params, self.chunk_tensor.data_ptr(),
-                                   self.active.data_ptr(), self.tensor_step.data_ptr(), self.arrived.data_ptr(),
-                                   self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
-                                   L.PP_ADAM_ZERO_GRADS if zero_grads else 0, L.ptr(skip), L.stream_ptr())
-        L.check(rc, 'pp_adam_step')
+        if getattr(self, '_use_ops', False):
+            from .ops import ops
+            ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.chunk_tensor, self.active,
+                          self.tensor_step, self.arrived, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
+                          L.PP_ADAM_ZERO_GRADS if zero_grads else 0, skip)
+        else:
+            rc = self.lib.pp_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.spec.n_params, self.chunk_tensor.data_ptr(),
+                                       self.active.data_ptr(), self.tensor_step.data_ptr(), self.arrived.data_ptr(),
+                                       self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
+                                       L.PP_ADAM_ZERO_GRADS if zero_grads else 0, L.ptr(skip), L.stream_ptr())
+            L.check(rc, 'pp_adam_step')
         self._grads_clean = bool(zero_grads)
 
     def train_step(self, batch, lr, weight_decay=0.0):
-        """zero_grad -> loss -> backward -> [all-reduce] -> Adam (inference_network.py:486-496). No host sync."""
+        """zero_grad -> loss -> backward -> [all-reduce] -> Adam (inference_network.py:486-496). No host sync.
+        Data parallel: the non-finite flag travels in the reduced tail, so every rank skips the same batches."""
         loss = self.loss(batch, backward=True)
         if self.world_size > 1 or self.force_allreduce:
             self.allreduce_grads()
-        self.adam_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS)
+            self.adam_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS, skip=self.reduced_status())
+        else:
+            self.adam_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS, skip=self.status_buf)
         return loss
 
     def train_run(self, dataset, id_lists, lrs, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
@@ -296,10 +318,37 @@ class ICEngine:
 
     # ---- data parallel ------------------------------------------------------------------------------------
     def allreduce_grads(self):
-        """ONE RCCL all-reduce (SUM) over [flat grads | presence map | loss]
-        (replaces the per-tensor loop of _distributed_sync_grad, inference_network.py:296-333)."""
+        """ONE RCCL all-reduce (SUM) over [flat grads | presence map | loss | non-finite flag]
+        (replaces the per-tensor loop of _distributed_sync_grad, inference_network.py:296-333). With `dp_skip` ranges
+        (gradients that are zero on every rank by construction) the remaining pieces are reduced instead."""
         from .parallel import allreduce_flat_
-        allreduce_flat_(self.grads_full)
+        self.status_tail.copy_(self.status_buf[:1])          # int32 flag -> float, into the reduced tail
+        if not self.dp_skip:
+            allreduce_flat_(self.grads_full)
+            return
+        pos = 0
+        for off, cnt in self.dp_skip:
+            if off > pos:
+                allreduce_flat_(self.grads_full[pos:off])
+            pos = off + cnt
+        allreduce_flat_(self.grads_full[pos:])
+
+    def reduced_status(self):
+        """The all-reduced non-finite flag as the int32 word pp_adam_step's `skip` reads: a sum of 0.0 / 1.0 floats is
+        non-zero (any bit set) exactly when some rank flagged its batch."""
+        return self.status_tail.view(torch.int32)
+
+    def skip_recurrent_weights(self, enable=True):
+        """Data-parallel runs over a dataset in which EVERY trace has one controlled variable (GaussianUnknownMean): no
+        time step has a predecessor, so dL/dW_hh is exactly zero on every rank, every step (h_0 = 0,
+        inference_network_lstm.py:186-187). W_hh is 2/3 (H = 512) to 3/4 (H = 1024) of the flat gradient: leaving its
+        range out of the all-reduce changes no bit of the result (Adam still steps the tensor with its zero gradient,
+        like the reference). The caller asserts the property for the whole dataset - it must hold on all ranks."""
+        self.dp_skip = []
+        if enable and not self.spec.feedforward:
+            off, shape = self.spec.tensors['_layers_lstm.weight_hh_l0']
+            n = int(np.prod(shape))
+            self.dp_skip = [(off, ((n + 1023) // 1024) * 1024)]
 
     def broadcast_params(self):
         """_distributed_sync_parameters (inference_network.py:290-294) as one broadcast of the flat buffer."""

@@ -632,9 +632,10 @@ class InferenceNetworkLSTM:
                 self._engine.loss(pb, backward=True)                                  # loss in the all-reduced tail
                 self._engine.allreduce_grads()                                        # :494-495
                 l_out.copy_(self._engine.loss_buf[:1])
-                s_out.copy_(self._engine.status_buf[:1])
+                # the non-finite flag was reduced with the gradients: every rank skips (and books) the same iterations
+                s_out.copy_(self._engine.status_tail[:1])
                 self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True,
-                                       skip=self._engine.status_buf)
+                                       skip=self._engine.reduced_status())
             else:
                 self._engine.loss(pb, backward=True, loss_out=l_out, status_out=s_out)
                 self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True, skip=s_out)

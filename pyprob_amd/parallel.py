@@ -60,52 +60,59 @@ def gather_particles(values, log_weights, num_traces):
 
 
 class DistributedTraceBatchSampler:
-    """Mirror of pyprob/nn/dataset.py:328-400 over a list of sorted trace indices."""
+    """The minibatch partition of pyprob/nn/dataset.py:328-400 as array views: the sorted trace indices become ONE int64
+    table [n_batches, batch_size]; buckets are row ranges of it, a rank's share of a bucket is a strided row slice.
+    Same semantics as the reference: a seed-0 random subset of traces is dropped so that the number of minibatches is a
+    multiple of the world size, the last short bucket is merged into its predecessor, all ranks walk the buckets in the
+    same (epoch-seeded) order and take `floor(len / world)` minibatches of each, rank r the rows r, r + world, ..."""
 
     def __init__(self, sorted_indices, batch_size, rank, world_size, num_buckets=None, shuffle_batches=True,
                  shuffle_buckets=True):
-        self._world_size, self._rank = world_size, rank
-        idx = np.asarray(sorted_indices, np.int64).reshape(-1)       # (minibatches are rows of one array: no Python lists)
-        num_batches_to_drop = math.floor(len(idx) / batch_size) % world_size
-        num_traces_to_drop = num_batches_to_drop * batch_size
-        rng = np.random.RandomState(0)             # every rank drops the same traces
-        if num_traces_to_drop:
-            idx = np.delete(idx, rng.choice(len(idx), num_traces_to_drop, replace=False))
-        n_full = len(idx) // batch_size            # a short last minibatch is dropped (dataset.py:345-346)
-        self._batches = list(idx[:n_full * batch_size].reshape(n_full, batch_size))
-        if not self._batches:
+        self._world_size, self._rank = int(world_size), int(rank)
+        idx = np.asarray(sorted_indices, np.int64).reshape(-1)
+        drop = ((len(idx) // batch_size) % self._world_size) * batch_size
+        if drop:       # every rank drops the same traces (seed 0)
+            idx = np.delete(idx, np.random.RandomState(0).choice(len(idx), drop, replace=False))
+        n_batches = len(idx) // batch_size           # a short last minibatch is dropped (dataset.py:345-346)
+        if n_batches == 0:
             raise RuntimeError('dataset too small for batch_size:{} and world_size:{}'.format(batch_size, world_size))
-        if num_buckets is None:
-            num_buckets = len(self._batches) / world_size
-        self._num_buckets = num_buckets
-        self._bucket_size = math.ceil(len(self._batches) / num_buckets)
-        if self._bucket_size < world_size:
+        self._table = idx[:n_batches * batch_size].reshape(n_batches, batch_size)
+        self._num_buckets = n_batches / self._world_size if num_buckets is None else num_buckets
+        self._bucket_size = math.ceil(n_batches / self._num_buckets)
+        if self._bucket_size < self._world_size:
             raise RuntimeError('batch_size:{} and num_buckets:{} imply a bucket_size:{} smaller than world_size:{}'.format(
-                batch_size, num_buckets, self._bucket_size, world_size))
-        self._buckets = [self._batches[i:i + self._bucket_size] for i in range(0, len(self._batches), self._bucket_size)]
-        if len(self._buckets[-1]) < self._bucket_size:
-            if len(self._buckets) < 2:
+                batch_size, self._num_buckets, self._bucket_size, world_size))
+        starts = np.arange(0, n_batches, self._bucket_size)
+        ends = np.minimum(starts + self._bucket_size, n_batches)
+        if ends[-1] - starts[-1] < self._bucket_size and n_batches % self._bucket_size:
+            if len(starts) < 2:
                 raise RuntimeError('dataset too small for given batch_size:{} and num_buckets:{}'.format(batch_size, num_buckets))
-            self._buckets[-2].extend(self._buckets[-1])
-            del self._buckets[-1]
+            starts, ends = starts[:-1], np.concatenate([ends[:-2], ends[-1:]])      # the short tail joins its predecessor
+        self._bounds = np.stack([starts, ends], 1)                                   # [n_buckets, 2] row ranges of the table
         self._shuffle_batches, self._shuffle_buckets = shuffle_batches, shuffle_buckets
         self._epoch = 0
         self._current_bucket_id = 0
 
+    @property
+    def _batches(self):
+        return list(self._table)
+
+    @property
+    def _buckets(self):
+        return [list(self._table[a:b]) for a, b in self._bounds]
+
     def __iter__(self):
         self._epoch += 1
-        bucket_ids = list(range(len(self._buckets)))
+        order = np.arange(len(self._bounds))
         if self._shuffle_buckets:
-            np.random.RandomState(self._epoch).shuffle(bucket_ids)   # same order on every rank
-        for bucket_id in bucket_ids:
-            bucket = self._buckets[bucket_id]
-            self._current_bucket_id = bucket_id
-            num_batches = math.floor(len(bucket) / self._world_size)
-            batches = bucket[self._rank:len(bucket):self._world_size][:num_batches]
+            np.random.RandomState(self._epoch).shuffle(order)      # same order on every rank
+        for bucket_id in order:
+            a, b = self._bounds[bucket_id]
+            self._current_bucket_id = int(bucket_id)
+            mine = self._table[a + self._rank:b:self._world_size][:(b - a) // self._world_size]
             if self._shuffle_batches:
-                np.random.shuffle(batches)
-            for batch in batches:
-                yield batch
+                mine = mine[np.random.permutation(len(mine))]
+            yield from mine
 
     def __len__(self):
-        return len(self._batches)
+        return len(self._table)

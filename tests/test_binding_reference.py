@@ -269,3 +269,28 @@ def test_operators_fail_loudly_without_a_kernel_for_the_device():
     x = torch.zeros(4, device='meta')
     with pytest.raises(NotImplementedError):
         torch.ops.pyprob_hip.log_prob(0, x, 0, x, 0, x, 4)
+
+
+@pytest.mark.parametrize('n,batch_size,world,num_buckets', [(1024, 16, 4, 5), (960, 16, 2, None), (2048, 32, 8, 3)])
+def test_array_sampler_equals_the_reference_sampler(monkeypatch, n, batch_size, world, num_buckets):
+    """pyprob_amd.parallel.DistributedTraceBatchSampler (one index table + row ranges) against the reference's list-of-lists
+    sampler (pyprob/nn/dataset.py:328-400) on datasets that need no random drop: same minibatches, same buckets, same
+    epoch-seeded bucket order, same per-rank selection."""
+    import torch.distributed as dist
+    from pyprob.nn.dataset import DistributedTraceBatchSampler as RefSampler, OfflineDataset
+    from pyprob_amd.parallel import DistributedTraceBatchSampler
+    ds = object.__new__(OfflineDataset)
+    ds._sorted_indices = list(np.random.RandomState(1).permutation(n))
+    ds._length = n
+    monkeypatch.setattr(OfflineDataset, '__len__', lambda self: self._length)
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a, **k: world)
+    for rank in range(world):
+        monkeypatch.setattr(dist, 'get_rank', lambda *a, **k: rank)
+        ref = RefSampler(ds, batch_size, shuffle_batches=False, num_buckets=num_buckets)
+        mine = DistributedTraceBatchSampler(ds._sorted_indices, batch_size, rank, world, num_buckets, shuffle_batches=False)
+        assert len(mine) == len(ref) and mine._bucket_size == ref._bucket_size
+        assert [[list(b) for b in bk] for bk in mine._buckets] == [[list(b) for b in bk] for bk in ref._buckets]
+        for epoch in range(3):
+            a = [list(b) for b in ref]
+            b = [list(x) for x in mine]
+            assert a == b and mine._current_bucket_id == ref._current_bucket_id

@@ -143,3 +143,148 @@ def test_particle_gather_concatenates_the_rank_shards(tmp_path):
     for r in range(world):
         d = torch.load(out + '.%d' % r)
         assert d['ok'] and d['bad']
+
+
+# ---- the ENGINE's data-parallel step (buffer layout, reduced tail, skip logic) on two gloo ranks ---------------------
+def _local_batches(meta, batch, rank):
+    """Rank 0 trains on the 2-statement traces of the golden GUMM minibatch, rank 1 on the longer ones: the ranks touch
+    DIFFERENT proposal heads / embeddings (the presence map has to be merged)."""
+    lens = batch['trace_len']
+    off = np.concatenate([[0], np.cumsum(lens)])
+    pick = np.nonzero(lens == 2)[0][:16] if rank == 0 else np.nonzero(lens > 2)[0][:16]
+    rows = np.concatenate([np.arange(off[b], off[b + 1]) for b in pick])
+    return dict(trace_len=lens[pick], addr_idx=batch['addr_idx'][rows], values=batch['values'][rows].copy(),
+                prior=batch['prior'][rows], obs=batch['obs'][pick].copy())
+
+
+def _engine_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle_ops
+    from pyprob_amd.packed import PackedBatch
+    meta, params, batch, loss, isr = load_golden('gumm')
+    spec = spec_from_golden(meta, params)
+    eng = oracle_ops.CpuBufferEngine(spec)
+    eng._use_ops = True
+    eng.load_state_dict(params)
+    eng.world_size = world
+    local = _local_batches(meta, batch, rank)
+    ids = np.array([spec.address_id[meta['addresses'][i]] for i in local['addr_idx']])
+
+    def packed(arr):
+        return PackedBatch.from_ragged(arr['trace_len'], ids, arr['values'], arr['prior'], arr['obs'], len(spec.addresses)).to('cpu')
+    rec = {}
+    eng.train_step(packed(local), lr=1e-3)                                   # step 1: both ranks fine
+    rec['p1'] = eng.params.clone()
+    rec['steps1'] = eng.tensor_step.clone()
+    rec['active1'] = eng.active.clone()
+    rec['loss1'] = float(eng.loss_buf[0]) / world
+    bad = {k: v.copy() for k, v in local.items()}
+    if rank == 1:
+        bad['obs'][0, 0] = np.nan                                           # step 2: rank 1's minibatch is broken
+    eng.train_step(packed(bad), lr=1e-3)
+    rec['p2'] = eng.params.clone()
+    rec['steps2'] = eng.tensor_step.clone()
+    rec['status2'] = float(eng.status_tail[0])
+    rec['grads_clean2'] = bool((eng.grads == 0).all())
+    eng.train_step(packed(local), lr=1e-3)                                   # step 3: training goes on, no NaN left behind
+    rec['p3'] = eng.params.clone()
+    rec['steps3'] = eng.tensor_step.clone()
+    torch.save(rec, out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_engine_data_parallel_step_merges_presence_and_skips_together(tmp_path):
+    """ICEngine.train_step with world_size 2 (buffers on CPU, operators backed by the oracle): ONE all-reduce of
+    [grads | presence | loss | non-finite flag]; ranks that touch different heads end with IDENTICAL parameters equal to
+    Adam on the averaged gradient with the merged presence map (inference_network.py:296-333); a non-finite loss on one
+    rank makes BOTH ranks skip that iteration (no parameter, no step count changes) and leaves no NaN behind."""
+    world, port = 2, 33500 + os.getpid() % 2000
+    out = str(tmp_path / 'eng.pt')
+    mp.spawn(_engine_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)
+    for k in ('p1', 'p2', 'p3', 'steps1', 'steps2', 'steps3', 'active1'):
+        assert torch.equal(r0[k], r1[k]), k                                  # the ranks never diverge
+    from oracle import ic_oracle as O
+    meta, params, batch, loss, isr = load_golden('gumm')
+    spec = spec_from_golden(meta, params)
+    net = O.Net(params, meta['obs_names'], K=10)
+    outs = [O.loss_and_grads(net, _local_batches(meta, batch, r), meta['addresses'], meta['dist_names']) for r in range(world)]
+    assert abs(r0['loss1'] - 0.5 * (outs[0]['loss'] + outs[1]['loss'])) < 1e-5
+    masks = []
+    for r in range(world):
+        lb = _local_batches(meta, batch, r)
+        ids = np.array([spec.address_id[meta['addresses'][i]] for i in lb['addr_idx']])
+        loff = np.concatenate([[0], np.cumsum(lb['trace_len'])])
+        not_last = np.ones(len(ids), bool)
+        not_last[loff[1:] - 1] = False
+        masks.append(spec.active_mask(np.bincount(ids, minlength=len(spec.addresses)),
+                                      np.bincount(ids[not_last], minlength=len(spec.addresses))))
+    merged = np.maximum(masks[0], masks[1])
+    assert (masks[0] != masks[1]).any()                                      # the ranks really touched different tensors
+    assert np.array_equal(r0['active1'].numpy() > 0, merged > 0)
+    names = list(spec.tensors.keys())
+    p1 = r0['p1'].numpy()
+    for i, n in enumerate(names):
+        o_, shape = spec.tensors[n]
+        cnt = int(np.prod(shape))
+        got = p1[o_:o_ + cnt].reshape(shape)
+        if merged[i] > 0:
+            want = params[n].astype(np.float64).copy()
+            g = 0.5 * (outs[0]['grads'][n] + outs[1]['grads'][n])
+            O.adam_step(want, g, np.zeros_like(want), np.zeros_like(want), 1, 1e-3)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=n)
+            assert int(r0['steps1'][i]) == 1
+        else:
+            np.testing.assert_array_equal(got, params[n])
+            assert int(r0['steps1'][i]) == 0
+    # step 2: skipped everywhere
+    assert r0['status2'] > 0 and r1['status2'] > 0
+    assert torch.equal(r0['p2'], r0['p1']) and torch.equal(r0['steps2'], r0['steps1'])
+    assert r0['grads_clean2'] and r1['grads_clean2']
+    # step 3: finite, one more Adam step on the touched tensors
+    assert torch.isfinite(r0['p3']).all() and not torch.equal(r0['p3'], r0['p2'])
+    assert torch.equal(r0['steps3'], r0['steps1'] * 2)
+
+
+def _skip_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle_ops
+    from helpers import packed_from_golden
+    meta, params, batch, loss, isr = load_golden('gum')
+    spec = spec_from_golden(meta, params)
+    res = []
+    for skip in (False, True):
+        eng = oracle_ops.CpuBufferEngine(spec)
+        eng._use_ops = True
+        eng.load_state_dict(params)
+        eng.world_size = world
+        eng.skip_recurrent_weights(skip)
+        b = {k: v[rank::world] if k != 'addr_idx' else v[rank::world] for k, v in batch.items()}
+        pb = packed_from_golden(meta, b, spec).to('cpu')
+        for _ in range(2):
+            eng.train_step(pb, lr=1e-3)
+        res.append((eng.params.clone(), eng.tensor_step.clone()))
+    torch.save(dict(same_params=torch.equal(res[0][0], res[1][0]), same_steps=torch.equal(res[0][1], res[1][1]),
+                    segments=len(eng.dp_skip)), out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_recurrent_weight_range_can_be_left_out_of_the_allreduce(tmp_path):
+    """Single-statement datasets (GUM): dL/dW_hh = 0 on every rank; reducing the flat buffer WITHOUT that range gives
+    bit-identical parameters and step counts."""
+    world, port = 2, 35500 + os.getpid() % 2000
+    out = str(tmp_path / 'skip.pt')
+    mp.spawn(_skip_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        d = torch.load(out + '.%d' % r)
+        assert d['same_params'] and d['same_steps'] and d['segments'] == 1
