@@ -870,7 +870,7 @@ struct DirectOperand {
 
     // VEC == 4 is branch-free: the load address is clamped into the matrix (rows at init, k here) and elements outside
     // are zeroed with selects. The predicated element-wise fallback this replaces cost ~900 instructions (124 exec
-    // branches) for the first slab of a workgroup - 1.2 us of a 10 us kernel (tools/timeline5.py).
+    // branches) for the first slab of a workgroup - 1.2 us of a 10 us kernel (tools/kernel_timeline.py).
     __device__ __forceinline__ void fetch(float g[16], int k0, int K) const {
         if (!KM) {
             const int kleft = K - (k0 + rcol);
@@ -978,7 +978,7 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
     oa.init(p.A, p.lda, p.a_idx, m0, p.M, lane, red + wave * DSLAB);
     ob.init(p.B, p.ldb, p.b_idx, n0, p.N, lane, red + (4 + wave) * DSLAB);
     // (A three-deep register ring - three slabs of loads in flight - was tried: 182 VGPRs and no gain. Phase stamps of
-    // the head-layer product, tools/timeline5.py: init 0.7 us, issuing the first loads 1.2 us (~900 instructions of
+    // the head-layer product, tools/kernel_timeline.py: init 0.7 us, issuing the first loads 1.2 us (~900 instructions of
     // address arithmetic and edge predication), first data 2-3 us after issue (operands come from another XCD's L2 /
     // HBM), the remaining slabs < 0.2 us: the kernel is start-up latency, not the K loop.)
 #define DSTAMP(k) do { if (p.dbg && tid == 0 && bx == 1 && by == 1 && bz == 0) p.dbg[32 + (k)] = clock64(); } while (0)
@@ -1242,7 +1242,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     clear_holes(p);
     p.vec = 1;
     p.vec_c = (a->ldc % 4 == 0 && aligned16(a->C)) ? 1 : 0;
-    static const int stamp_all = getenv("PP_DBG_STAMP") ? 1 : 0;   // debug: stamp every product (tools/timeline4.py)
+    static const int stamp_all = getenv("PP_DBG_STAMP") ? 1 : 0;   // debug: stamp every product (tools/kernel_timeline.py)
     p.dbg = (stamp_all || (a->M == 1024 && a->N == 2048)) ? g_timeline : nullptr;   // debug: stamp the forward input GEMM only
 }
 

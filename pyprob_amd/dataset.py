@@ -381,7 +381,7 @@ class PackedTraceDataset:
     def device_batch(self, indices, spec, device):
         """`batch(...).to(device)` through a ring of PINNED host buffers: the packer writes straight into page-locked
         memory and the upload is one asynchronous DMA (a pageable source is staged and synchronised by the runtime:
-        55-570 us per copy measured, tools/loader_probe.py). A slot is reused only after its copy has completed."""
+        55-570 us per copy measured; round-1 probe). A slot is reused only after its copy has completed."""
         import torch
         if torch.device(device).type != 'cuda':
             return self.batch(indices, spec).to(device)
@@ -435,7 +435,7 @@ class PackedTraceDataset:
         """Iterator of device PackedBatches, in sampler order. workers=0 (default): a minibatch is packed (`gather` + the
         native packer, ~110 us) and uploaded (one 40-60 KB H2D copy, ~55 us) in the consumer's thread, right before it is
         used - its 165 us hide behind the previous step's GPU time (measured 242 us per step = 4.2 M traces/s for GUM,
-        tools/loader_probe.py). workers >= 1 moves that work to background threads with a bounded look-ahead; for these
+        round-1 probe). workers >= 1 moves that work to background threads with a bounded look-ahead; for these
         small minibatches that is SLOWER (437 us per step with one worker: the threads convoy on the GIL with the thread
         that enqueues the kernels), it only pays when packing is much heavier than a step. `epochs=None` repeats forever
         like the reference's training loop."""
@@ -479,7 +479,7 @@ class PackedTraceDataset:
                         state['next_seq'] += 1
                     # pack + upload on the device's default stream: the 40-60 KB copy is ordered before the consumer's
                     # kernels by the stream itself (a side stream + event per batch cost 460 us per minibatch in torch's
-                    # per-stream allocator and event plumbing, tools/loader_probe.py)
+                    # per-stream allocator and event plumbing; round-1 probe)
                     host = self.batch(ids, spec).to(device)
                     with lock:
                         ready[seq] = host

@@ -501,7 +501,7 @@ class InferenceNetworkLSTM:
         type_key, type_known = None, None
         # While a run trains inside the C call, a worker thread generates the next chunk of prior traces
         # (VectorisedOnlineDataset.start_prefetch). torch's intra-op pool must not fan that work out over all host cores:
-        # measured (tools/prefetch_probe.py, 256-core host) a 128-thread torch.normal next to pp_train_steps slows a
+        # measured (round-1 probe, 256-core host) a 128-thread torch.normal next to pp_train_steps slows a
         # step from 180 us to 650-1100 us, with one intra-op thread there is no interference.
         prefetching = native and hasattr(dataset, 'start_prefetch')
         cpu_threads = torch.get_num_threads()
