@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 3
+#define PP_ABI_VERSION 4
 #define PP_MAX_OBS 8
+#define PP_MAX_LSTM_DEPTH 4
 
 /* error codes (negative; positive values are hipError_t) */
 #define PP_EINVAL   (-1)   /* bad argument (shape, alignment, null pointer) */
@@ -97,6 +98,11 @@ typedef struct pp_net {
     const pp_addr* addrs;             /* host array [n_addr] */
     const int64_t* addr_table;        /* dev  [n_addr, PP_ADDR_TABLE_COLS] same records for per-row dispatch */
     int64_t n_params;                 /* floats in the flat buffer (incl. padding) */
+    int32_t lstm_depth;               /* layers of nn.LSTM(I, H, depth) (inference_network_lstm.py:31); 0 is read as 1 */
+    int32_t _pad2;
+    /* _layers_lstm.{weight_ih,weight_hh,bias_ih,bias_hh}_l<k> of every layer; entry 0 repeats w_ih .. b_hh above. Layer
+     * k >= 1 reads the hidden states of layer k-1: weight_ih_l<k> is [4H, H] */
+    int64_t lstm_w_ih[PP_MAX_LSTM_DEPTH], lstm_w_hh[PP_MAX_LSTM_DEPTH], lstm_b_ih[PP_MAX_LSTM_DEPTH], lstm_b_hh[PP_MAX_LSTM_DEPTH];
 } pp_net;
 
 /* columns of the device address table */
@@ -294,7 +300,7 @@ int pp_is_init(const pp_net* net, const float* params, const float* obs, float* 
  *   e_obs_vec  dev [e_obs]   output of pp_is_init (shared by all particles)
  *   prev_value dev [n]       values sampled at the previous statement (ignored when prev_addr_id < 0)
  *   prior      dev [n,2] or [2] (prior_stride 0 = same prior parameters for every particle)
- *   h, c       dev [n, H]    LSTM state, updated in place
+ *   h, c       dev [depth, n, H] LSTM state of every layer (layer k at offset k * n * H), updated in place
  *   state_rows 1 or n: rows of (h, c) that are valid on entry. The first statement of a trace (prev_addr_id < 0) ignores
  *              the state, evaluates the network for ONE row (every particle has the same input and zero state) and
  *              writes row 0 only: the caller passes state_rows = 1 to the next call, which turns the shared recurrent

@@ -121,6 +121,11 @@ class Net:
         self.K = K
         # (InferenceNetworkFeedForward has no LSTM: its heads read the observe embedding)
         self.H = self.P['_layers_lstm.weight_hh_l0'].shape[1] if '_layers_lstm.weight_hh_l0' in self.P else 0
+        self.depth = sum(1 for k in self.P if k.startswith('_layers_lstm.weight_hh_l'))     # nn.LSTM(I, H, depth)
+
+    def lstm_layer(self, k):
+        """(W_ih, W_hh, b_ih, b_hh) of layer k (torch.nn.LSTM parameter names weight_ih_l<k> ...)."""
+        return tuple(self.P['_layers_lstm.%s_l%d' % (n, k)] for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'))
 
     def ff(self, prefix):
         """(W list, b list) of an EmbeddingFeedForward stored under `prefix`._layers.N.{weight,bias}."""
@@ -477,7 +482,12 @@ def loss_and_grads(net, batch, addresses, dist_names, want_grads=True):
             c2 = col + S_emb + Ed + Ea
             x[t, :, c2:c2 + Ed] = P['_layers_distribution_type_embedding.' + d_cur]
             x[t, :, c2 + Ed:c2 + Ed + Ea] = P['_layers_address_embedding.' + a_cur]
-        hs, cache, _ = lstm_forward(x, W_ih, W_hh, b_ih, b_hh)
+        # nn.LSTM(I, H, depth) (inference_network_lstm.py:31): layer k reads the hidden states of layer k - 1
+        layer_in, layer_cache = [x], []
+        for k in range(net.depth):
+            hs, cache, _ = lstm_forward(layer_in[k], *net.lstm_layer(k))
+            layer_cache.append(cache)
+            layer_in.append(hs)
         out['lstm_in'].append(x)
         out['lstm_out'].append(hs)
         dh_seq = np.zeros_like(hs)
@@ -499,11 +509,14 @@ def loss_and_grads(net, batch, addresses, dist_names, want_grads=True):
                     grads['_layers_proposal.%s._ff._layers.%d.bias' % (a_cur, i)] += dbs[i]
         if not want_grads:
             continue
-        dx, dW_ih, dW_hh, db = lstm_backward(dh_seq, x, cache, W_ih, W_hh)
-        grads['_layers_lstm.weight_ih_l0'] += dW_ih
-        grads['_layers_lstm.weight_hh_l0'] += dW_hh
-        grads['_layers_lstm.bias_ih_l0'] += db
-        grads['_layers_lstm.bias_hh_l0'] += db
+        dx = dh_seq
+        for k in reversed(range(net.depth)):
+            Wk_ih, Wk_hh, _, _ = net.lstm_layer(k)
+            dx, dW_ih, dW_hh, db = lstm_backward(dx, layer_in[k], layer_cache[k], Wk_ih, Wk_hh)
+            grads['_layers_lstm.weight_ih_l%d' % k] += dW_ih
+            grads['_layers_lstm.weight_hh_l%d' % k] += dW_hh
+            grads['_layers_lstm.bias_ih_l%d' % k] += db
+            grads['_layers_lstm.bias_hh_l%d' % k] += db
         col = E.shape[1]
         dE = dx[:, :, :col].sum(0)
         for t in range(T):
@@ -668,7 +681,7 @@ def is_rescore(net, observe, trace_len, addr_idx, values, prior, addresses, dist
     prop_params = []
     lw = np.zeros(len(trace_len))
     for b in range(len(trace_len)):
-        h = c = None
+        state = [(None, None)] * net.depth          # (h, c) of every layer, reset when prev_variable is None (:84-91)
         for t in range(int(trace_len[b])):
             r = off[b] + t
             a_cur, d_cur = addresses[addr_idx[r]], dist_names[addr_idx[r]]
@@ -685,7 +698,9 @@ def is_rescore(net, observe, trace_len, addr_idx, values, prior, addresses, dist
             c2 = col + S_emb + Ed + Ea
             x[0, 0, c2:c2 + Ed] = P['_layers_distribution_type_embedding.' + d_cur]
             x[0, 0, c2 + Ed:c2 + Ed + Ea] = P['_layers_address_embedding.' + a_cur]
-            hs, _, (h, c) = lstm_forward(x, W_ih, W_hh, b_ih, b_hh, h, c)
+            hs = x
+            for k in range(net.depth):
+                hs, _, state[k] = lstm_forward(hs, *net.lstm_layer(k), *state[k])
             v = np.asarray(values[r:r + 1], dt)
             q_lp, _, params = head_forward(net, a_cur, d_cur, hs[0], np.asarray(prior[r:r + 1], dt), v)
             if d_cur == 'Categorical':

@@ -109,11 +109,9 @@ class _HipNetworkMixin:
             raise RuntimeError('inference network layers are not initialised yet')
         named = self._hip_named_parameters()
         if self._hip_engine is None:
-            if self._hip_kind == 'lstm' and self._lstm_depth != 1:
-                raise NotImplementedError('the HIP engine implements lstm_depth=1 (the reference default)')
             kw = dict(proposal_mixture_components=self._proposal_mixture_components, network=self._hip_kind)
             if self._hip_kind == 'lstm':
-                kw.update(lstm_dim=self._lstm_dim, sample_embedding_dim=self._sample_embedding_dim,
+                kw.update(lstm_dim=self._lstm_dim, lstm_depth=self._lstm_depth, sample_embedding_dim=self._sample_embedding_dim,
                           address_embedding_dim=self._address_embedding_dim,
                           distribution_type_embedding_dim=self._distribution_type_embedding_dim)
             spec = NetSpec(self._hip_obs_spec(), **kw)

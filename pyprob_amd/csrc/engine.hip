@@ -108,9 +108,13 @@ struct Workspace {
     float* f1;                 // [B, e4] hidden layer of the final observe embedding
     float* E;                  // [B, e4] observe embedding
     float* X;                  // [R, i4] LSTM input rows
-    float* G;                  // [R, 4H] gate pre-activations -> gates -> dG
+    float* G;                  // [R, 4H] gate pre-activations -> gates -> dG   (layer 0; layer k: Gl[k] ...)
     float* C;                  // [R, H]
-    float* Hs;                 // [R, H]
+    float* Hs;                 // [R, H] hidden states of the TOP layer (what the proposal heads read)
+    float* Gl[PP_MAX_LSTM_DEPTH];   // per layer of nn.LSTM(I, H, depth): Gl[0] == G, Hl[depth - 1] == Hs
+    float* Cl[PP_MAX_LSTM_DEPTH];
+    float* Hl[PP_MAX_LSTM_DEPTH];
+    float* dH2;                // [R, H] gradient into the hidden states of the layer below (depth > 1)
     float* A1;                 // [R, hid4] head hidden activations, group-compact row order
     float* Y;                  // [R, out4] head outputs
     float* DY;                 // [R, out4]
@@ -152,9 +156,17 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.f1 = c.take<float>((int64_t)B * w.e4);
     w.E = c.take<float>((int64_t)B * w.e4);
     w.X = c.take<float>(ff ? 0 : (int64_t)R * w.i4);
-    w.G = c.take<float>(ff ? 0 : (int64_t)R * 4 * H);
-    w.C = c.take<float>(ff ? 0 : (int64_t)R * H);
-    w.Hs = c.take<float>((int64_t)R * H);
+    const int L = ff ? 1 : std::max(1, std::min((int)net->lstm_depth, PP_MAX_LSTM_DEPTH));
+    for (int l = 0; l < PP_MAX_LSTM_DEPTH; ++l) w.Gl[l] = w.Cl[l] = w.Hl[l] = nullptr;
+    for (int l = 0; l < L; ++l) {
+        w.Gl[l] = c.take<float>(ff ? 0 : (int64_t)R * 4 * H);
+        w.Cl[l] = c.take<float>(ff ? 0 : (int64_t)R * H);
+        w.Hl[l] = c.take<float>((int64_t)R * H);
+    }
+    w.G = w.Gl[0];
+    w.C = w.Cl[0];
+    w.Hs = w.Hl[L - 1];
+    w.dH2 = c.take<float>(L > 1 ? (int64_t)R * H : 0);
     w.A1 = c.take<float>((int64_t)R * w.hid4);
     w.Y = c.take<float>((int64_t)R * w.out4);
     w.DY = c.take<float>((int64_t)R * w.out4);
@@ -184,6 +196,7 @@ static int check_net(const pp_net* net) {
                      "pp_net: lstm_in != e_obs + smp_dim + 2*(addr_dim+dtype_dim)");
     }
     PP_CHECK_ARG(net->n_addr == 0 || net->addrs, "pp_net: addrs is null");
+    PP_CHECK_ARG(net->lstm_depth >= 0 && net->lstm_depth <= PP_MAX_LSTM_DEPTH, "pp_net: lstm_depth %d out of range", net->lstm_depth);
     return 0;
 }
 
@@ -389,35 +402,45 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                                  bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), PP_LOSS_SLOTS_FLOATS));
     }
     prof_end(2, gather_bytes, st);
-    if (!ff) {
-    // a trace's first time step has no previous variable: columns [e_obs, c4) of its LSTM input row are zero
-    // (inference_network_lstm.py:159-162) - rows [0, B) of the step-major layout
-    // ... and no previous cell state: its forget gate multiplies c_{-1} = 0, so columns [H, 2H) of its pre-activations are
-    // never looked at (lstm_cell_fwd/bwd with c_prev == NULL) - not computed at all
-    const GemmHole x_zero{{{0, B, 0, 4 * H, net->e_obs, net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim},
-                           {0, B, H, 2 * H, 0, I}}};
-    prof_begin(0, st);
-    PP_TRY(linear_fwd(w.X, w.i4, nullptr, P + net->w_ih, P + net->b_ih, w.G, 4 * H, R, I, 4 * H, false, P + net->b_hh, st,
-                      &x_zero));
-    prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
-    }
-    for (int t = 0; t < T && !ff; ++t) {
-        const int n = bt->n_active[t], r0 = bt->row_off[t];
-        float* Gt = w.G + (int64_t)r0 * 4 * H;
-        const float* c_prev = nullptr;
-        if (t > 0) {
-            const int rp = bt->row_off[t - 1];
-            pp_gemm_args g{};
-            g.A = w.Hs + (int64_t)rp * H; g.lda = H;
-            g.B = P + net->w_hh; g.ldb = H;
-            g.C = Gt; g.ldc = 4 * H;
-            g.M = n; g.N = 4 * H; g.K = H;
-            g.accumulate = 1;
-            g.split_k = 1;   // few rows late in a ragged batch: spread K over workgroups (accumulation into G)
-            PP_TRY(gemm_f32(&g, st));
-            c_prev = w.C + (int64_t)rp * H;
+    // nn.LSTM(I, H, depth), inference_network_lstm.py:31,186-188: layer k reads the hidden states of layer k - 1
+    const int L = ff ? 0 : std::max(1, (int)net->lstm_depth);
+    auto lw_ih = [&](int l) { return l == 0 ? net->w_ih : net->lstm_w_ih[l]; };
+    auto lw_hh = [&](int l) { return l == 0 ? net->w_hh : net->lstm_w_hh[l]; };
+    auto lb_ih = [&](int l) { return l == 0 ? net->b_ih : net->lstm_b_ih[l]; };
+    auto lb_hh = [&](int l) { return l == 0 ? net->b_hh : net->lstm_b_hh[l]; };
+    for (int l = 0; l < L; ++l) {
+        const float* in = l == 0 ? w.X : w.Hl[l - 1];
+        const int64_t in_ld = l == 0 ? w.i4 : H;
+        const int in_w = l == 0 ? I : H;
+        // a trace's first time step has no previous variable: columns [e_obs, c4) of its LSTM input row are zero
+        // (inference_network_lstm.py:159-162) - rows [0, B) of the step-major layout, layer 0 -
+        // ... and no previous cell state in any layer: its forget gate multiplies c_{-1} = 0, so columns [H, 2H) of its
+        // pre-activations are never looked at (lstm_cell_fwd/bwd with c_prev == NULL) - not computed at all
+        GemmHole zero{};
+        zero.b[1] = GemmBlock{0, B, H, 2 * H, 0, in_w};
+        if (l == 0) zero.b[0] = GemmBlock{0, B, 0, 4 * H, net->e_obs, net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim};
+        if (l == 0) prof_begin(0, st);
+        PP_TRY(linear_fwd(in, in_ld, nullptr, P + lw_ih(l), P + lb_ih(l), w.Gl[l], 4 * H, R, in_w, 4 * H, false, P + lb_hh(l), st,
+                          &zero));
+        if (l == 0) prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
+        for (int t = 0; t < T; ++t) {
+            const int n = bt->n_active[t], r0 = bt->row_off[t];
+            float* Gt = w.Gl[l] + (int64_t)r0 * 4 * H;
+            const float* c_prev = nullptr;
+            if (t > 0) {
+                const int rp = bt->row_off[t - 1];
+                pp_gemm_args g{};
+                g.A = w.Hl[l] + (int64_t)rp * H; g.lda = H;
+                g.B = P + lw_hh(l); g.ldb = H;
+                g.C = Gt; g.ldc = 4 * H;
+                g.M = n; g.N = 4 * H; g.K = H;
+                g.accumulate = 1;
+                g.split_k = 1;   // few rows late in a ragged batch: spread K over workgroups (accumulation into G)
+                PP_TRY(gemm_f32(&g, st));
+                c_prev = w.Cl[l] + (int64_t)rp * H;
+            }
+            PP_TRY(lstm_cell_fwd(Gt, c_prev, w.Cl[l] + (int64_t)r0 * H, w.Hl[l] + (int64_t)r0 * H, n, H, st));
         }
-        PP_TRY(lstm_cell_fwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.Hs + (int64_t)r0 * H, n, H, st));
     }
     const float gscale = -1.0f / (float)B;
     std::vector<ColsumJob> cs;
@@ -531,33 +554,51 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(flush_wgrads(ss->s, ff));
     }
     PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));
-    for (int t = T - 1; t >= 0 && !ff; --t) {
-        const int n = bt->n_active[t], r0 = bt->row_off[t];
-        const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
-        float* Gt = w.G + (int64_t)r0 * 4 * H;
-        const float* c_prev = t > 0 ? w.C + (int64_t)bt->row_off[t - 1] * H : nullptr;
-        const bool fin = t == T - 1;
-        PP_TRY(lstm_cell_bwd(Gt, c_prev, w.C + (int64_t)r0 * H, w.dH + (int64_t)r0 * H, w.dC, n, n_next, H,
-                             grads + net->b_ih, grads + net->b_hh, st, fin ? w.loss_acc : nullptr, w.flag, B, loss_out,
-                             status_out));   // bias gradients fused
-        if (t > 0)  // dh_{t-1} += dG_t W_hh
-            PP_TRY(linear_dgrad(Gt, 4 * H, P + net->w_hh, w.dH + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0, n,
-                                H, 4 * H, true, st));
-    }
     // the gradient of the observe embedding is summed over the time steps from dX[:, :e_obs] (LSTM) / from dH (FF)
     const float* dXs = ff ? w.dH : w.dX;
     const int64_t ldxs = ff ? H : w.i4;
-    // LSTM parameter gradients, together with every head's weight gradients
-    if (!ff) {
     const int cz0 = net->e_obs, cz1 = net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim;   // previous-variable columns
-    // dW_ih[:, previous-variable columns] gets nothing from the rows of first time steps (their inputs are zero there)
-    // ... and the forget-gate rows of dW_ih get nothing from them either (dG[:, H:2H] = 0 where c_{t-1} = 0)
-    queue_wgrad(wq, w.G, 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, R, I, 4 * H, &wholes,
-                GemmHole{{{0, 4 * H, cz0, cz1, 0, B}, {H, 2 * H, 0, I, 0, B}}});
-    if (T > 1) {
-        const int r1 = bt->row_off[1];
-        queue_wgrad(wq, w.G + (int64_t)r1 * 4 * H, 4 * H, w.Hs, H, bt->prev_row + r1, grads + net->w_hh, R - r1, H, 4 * H);
+    float* dH_cur = w.dH;          // gradient into the hidden states of the layer being processed (top: from the heads)
+    float* dH_other = w.dH2;
+    for (int l = L - 1; l >= 0; --l) {
+        for (int t = T - 1; t >= 0; --t) {
+            const int n = bt->n_active[t], r0 = bt->row_off[t];
+            const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
+            float* Gt = w.Gl[l] + (int64_t)r0 * 4 * H;
+            const float* c_prev = t > 0 ? w.Cl[l] + (int64_t)bt->row_off[t - 1] * H : nullptr;
+            const bool fin = l == L - 1 && t == T - 1;   // the backward pass's first cell launch folds the loss slots
+            PP_TRY(lstm_cell_bwd(Gt, c_prev, w.Cl[l] + (int64_t)r0 * H, dH_cur + (int64_t)r0 * H, w.dC, n, n_next, H,
+                                 grads + lb_ih(l), grads + lb_hh(l), st, fin ? w.loss_acc : nullptr, w.flag, B, loss_out,
+                                 status_out));   // bias gradients fused
+            if (t > 0)  // dh_{t-1} += dG_t W_hh
+                PP_TRY(linear_dgrad(Gt, 4 * H, P + lw_hh(l), dH_cur + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0,
+                                    n, H, 4 * H, true, st));
+        }
+        // parameter gradients of this layer (leaves, grouped with every head's weight gradients). First-time-step rows give
+        // nothing to the forget-gate rows (dG[:, H:2H] = 0 where c_{t-1} = 0) and, in layer 0, nothing to the
+        // previous-variable columns of dW_ih (their inputs are zero there)
+        const float* in = l == 0 ? w.X : w.Hl[l - 1];
+        const int64_t in_ld = l == 0 ? w.i4 : H;
+        const int in_w = l == 0 ? I : H;
+        GemmHole wh{};
+        wh.b[1] = GemmBlock{H, 2 * H, 0, in_w, 0, B};
+        if (l == 0) wh.b[0] = GemmBlock{0, 4 * H, cz0, cz1, 0, B};
+        queue_wgrad(wq, w.Gl[l], 4 * H, in, in_ld, nullptr, grads + lw_ih(l), R, in_w, 4 * H, &wholes, wh);
+        if (T > 1) {
+            const int r1 = bt->row_off[1];
+            queue_wgrad(wq, w.Gl[l] + (int64_t)r1 * 4 * H, 4 * H, w.Hl[l], H, bt->prev_row + r1, grads + lw_hh(l), R - r1, H,
+                        4 * H);
+        }
+        if (l > 0) {   // gradient into the hidden states of the layer below: dH_{l-1} = dG_l W_ih_l (the forget-gate part of
+            GemmHole dh{};                                         // the sum is zero for first-time-step rows)
+            dh.b[0] = GemmBlock{0, B, 0, H, H, 2 * H};
+            PP_TRY(linear_dgrad(w.Gl[l], 4 * H, P + lw_ih(l), dH_other, H, nullptr, nullptr, 0, R, H, 4 * H, false, st, nullptr,
+                                &dh));
+            std::swap(dH_cur, dH_other);
+        }
     }
+    // LSTM parameter gradients are queued; layer 0's data gradient follows
+    if (!ff) {
     if (ss) {   // dG is complete: the LSTM weight gradients run next to dX and the observe-embedding backward
         PP_TRY(fork_to(st, ss->fork1, ss->s));
         PP_TRY(flush_wgrads(ss->s, true));

@@ -436,22 +436,39 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     if (!ff)
         PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
                                  w.i4, st));
+    const float* top = h;    // hidden rows the proposal layer reads
     if (ff) {
-        h = const_cast<float*>(e_obs_vec);   // (read only below)
-    } else if (shared) {
-        PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, P + net->b_hh, w.G, 4 * H, 1, I, 4 * H, false, false, st));
-        PP_TRY(lstm_cell_fwd(w.G, nullptr, c, h, 1, H, st));
-    } else if (state_rows == 1) {
-        PP_TRY(lin(h, H, P + net->w_hh, P + net->b_hh, nullptr, w.rec, 4 * H, 1, H, 4 * H, false, false, st));
-        PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, w.rec, w.G, 4 * H, n, I, 4 * H, false, false, st));
-        (void)hipMemcpyAsync(w.c0, c, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st);   // c is rewritten in place
-        PP_TRY(lstm_cell_fwd(w.G, w.c0, c, h, n, H, st, /*c_prev_shared=*/1));
+        top = e_obs_vec;
     } else {
-        PP_TRY(lin(w.X, w.i4, P + net->w_ih, P + net->b_ih, P + net->b_hh, w.G, 4 * H, n, I, 4 * H, false, false, st));
-        PP_TRY(lin(h, H, P + net->w_hh, nullptr, nullptr, w.G, 4 * H, n, H, 4 * H, false, true, st));
-        PP_TRY(lstm_cell_fwd(w.G, c, c, h, n, H, st));
+        // nn.LSTM(I, H, depth): layer k reads the new hidden rows of layer k - 1; (h, c) hold [depth, n, H]
+        const int L = std::max(1, (int)net->lstm_depth);
+        for (int l = 0; l < L; ++l) {
+            float* hl = h + (int64_t)l * n * H;
+            float* cl = c + (int64_t)l * n * H;
+            const float* in = l == 0 ? w.X : h + (int64_t)(l - 1) * n * H;
+            const int64_t in_ld = l == 0 ? w.i4 : H;
+            const int in_w = l == 0 ? I : H;
+            const float* Wih = P + (l == 0 ? net->w_ih : net->lstm_w_ih[l]);
+            const float* Whh = P + (l == 0 ? net->w_hh : net->lstm_w_hh[l]);
+            const float* bih = P + (l == 0 ? net->b_ih : net->lstm_b_ih[l]);
+            const float* bhh = P + (l == 0 ? net->b_hh : net->lstm_b_hh[l]);
+            if (shared) {
+                PP_TRY(lin(in, in_ld, Wih, bih, bhh, w.G, 4 * H, 1, in_w, 4 * H, false, false, st));
+                PP_TRY(lstm_cell_fwd(w.G, nullptr, cl, hl, 1, H, st));
+            } else if (state_rows == 1) {
+                PP_TRY(lin(hl, H, Whh, bhh, nullptr, w.rec, 4 * H, 1, H, 4 * H, false, false, st));
+                PP_TRY(lin(in, in_ld, Wih, bih, w.rec, w.G, 4 * H, n, in_w, 4 * H, false, false, st));
+                (void)hipMemcpyAsync(w.c0, cl, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st);   // c is rewritten in place
+                PP_TRY(lstm_cell_fwd(w.G, w.c0, cl, hl, n, H, st, /*c_prev_shared=*/1));
+            } else {
+                PP_TRY(lin(in, in_ld, Wih, bih, bhh, w.G, 4 * H, n, in_w, 4 * H, false, false, st));
+                PP_TRY(lin(hl, H, Whh, nullptr, nullptr, w.G, 4 * H, n, H, 4 * H, false, true, st));
+                PP_TRY(lstm_cell_fwd(w.G, cl, cl, hl, n, H, st));
+            }
+        }
+        top = h + (int64_t)(L - 1) * n * H;
     }
-    PP_TRY(lin(h, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
+    PP_TRY(lin(top, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
     PP_TRY(lin(w.A1, w.hid4, P + ad.w2, P + ad.b2, nullptr, w.Y, w.out4, m, ad.hid, ad.n_out, false, false, st));
     dim3 grid(cdiv(n, 256)), block(256);
     // kernel class 4 of the in-stream timing: draw + log q per particle (writes value and log q: 8 algorithmic bytes each)

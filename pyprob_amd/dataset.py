@@ -352,7 +352,28 @@ class PackedTraceDataset:
             if 'address' in msg:
                 raise KeyError('Address unknown by inference network ({})'.format(msg))
             raise RuntimeError('pp_pack_indexed failed: ' + msg)
-        return PackedBatch._wrap_native(buf, info, self.obs_width, n_addr)
+        pb = PackedBatch._wrap_native(buf, info, self.obs_width, n_addr)
+        bern = [a for a, info_ in enumerate(spec.addresses) if getattr(info_, 'dist_name', None) == 'Bernoulli']
+        if bern:
+            self._bernoulli_step_stats(pb, ids, bern)
+        return pb
+
+    def _bernoulli_step_stats(self, pb, ids, bernoulli_ids):
+        """The `prior` pair of a row with a Bernoulli proposal = (n, sum of values) over the rows of its SUB-BATCH STEP
+        (PP_HEAD_BERNOULLI, include/pyprob_amd.h; packed.bernoulli_group_stats for Trace objects): the reference scores
+        every proposal of a sub-batch step against every value of it. Traces of one sub-batch share the address sequence,
+        i.e. the dataset's trace type: grouped by (type, time step), written in place before the batch is uploaded."""
+        types = self.trace_type[ids][np.asarray(pb.order)]            # type of every packed trace
+        t_of_row = np.repeat(np.arange(pb.t_max), pb.n_active)        # time step of every packed row (step-major)
+        rows = np.nonzero(np.isin(pb.addr, np.asarray(bernoulli_ids, np.int32)))[0]
+        if rows.size == 0:
+            return
+        key = types[pb.trace[rows]].astype(np.int64) * (pb.t_max + 1) + t_of_row[rows]
+        uniq, inv = np.unique(key, return_inverse=True)
+        n = np.bincount(inv, minlength=len(uniq)).astype(np.float32)
+        n1 = np.bincount(inv, weights=pb.value[rows].astype(np.float64), minlength=len(uniq)).astype(np.float32)
+        pb.prior[rows, 0] = n[inv]
+        pb.prior[rows, 1] = n1[inv]
 
     def native_columns(self, spec):
         """(pp_shard_columns array, n_shards, `first` array) of this dataset for a network with address table `spec`: the
@@ -360,10 +381,6 @@ class PackedTraceDataset:
         network's. Cached until the network grows."""
         from . import lib as L
         key = (id(spec), len(spec.addresses))
-        if any(getattr(info, 'dist_name', None) == 'Bernoulli' for info in spec.addresses):
-            # the Bernoulli head's rows carry statistics of their sub-batch step (packed.bernoulli_group_stats), which
-            # the column packers do not compute: such programs train through the Trace route (Batch -> pack_traces)
-            raise NotImplementedError('packed datasets do not support programs with Bernoulli proposals')
         if getattr(self, '_native_key', None) != key:      # (re)build the per-shard address maps for this network
             to_engine = np.asarray([spec.address_id.get(a[0], -1) for a in self.addresses], np.int32)
             self._native_remap = [np.ascontiguousarray(to_engine[r]) for r in self._addr_remap]
@@ -531,6 +548,8 @@ class PackedTraceDataset:
                 dist = D.Categorical([1.0 / ncat] * ncat)
             elif dname == 'Poisson':    # the rate is not stored: training only reads the head's fixed interval
                 dist = D.Poisson(1.0)
+            elif dname == 'Bernoulli':  # (the probability is not stored either: the head reads the values only)
+                dist = D.Bernoulli(0.5)
             else:
                 raise RuntimeError('Distribution currently unsupported: {}'.format(dname))
             v = Variable(distribution=dist, value=float(value[r]), address=address, control=True)

@@ -55,9 +55,10 @@ class ISRunner:
     def begin(self, n, offset=0):
         """Start n traces in lock step (state._begin_trace, state.py:339-345): LSTM state is reset by the first step."""
         H = max(self.eng.spec.lstm_dim, 1)       # (FeedForward network: no LSTM state, 1-wide placeholders)
+        D = self.eng.spec.lstm_depth             # nn.LSTM(I, H, depth): state of every layer, [depth, n, H]
         if n != self.n:
-            self.h = torch.empty(n, H, dtype=torch.float32, device=self.dev)
-            self.c = torch.empty(n, H, dtype=torch.float32, device=self.dev)
+            self.h = torch.empty(D, n, H, dtype=torch.float32, device=self.dev)
+            self.c = torch.empty(D, n, H, dtype=torch.float32, device=self.dev)
             self.n = n
         self.prev_value = None
         self.last_value = None
@@ -83,11 +84,11 @@ class ISRunner:
         [1, 2], or one row per particle ([n, 2]; prior_compact: one row per entry of `rows`)."""
         m = int(rows.numel())
         if self.state_rows == 1 and self.n > 1 and prev_addr_id is not None:
-            self.h[1:] = self.h[0]      # the shared first-statement state (row 0) becomes per-particle
-            self.c[1:] = self.c[0]
+            self.h[:, 1:] = self.h[:, :1]      # the shared first-statement state (row 0) becomes per-particle
+            self.c[:, 1:] = self.c[:, :1]
             self.state_rows = self.n
-        h = self.h.index_select(0, rows)
-        c = self.c.index_select(0, rows)
+        h = self.h.index_select(1, rows)
+        c = self.c.index_select(1, rows)
         prev = None if (prev_addr_id is None or self.prev_value is None) else self.prev_value.index_select(0, rows).contiguous()
         if prior is not None and prior.shape[0] != 1 and not prior_compact:
             prior = prior.index_select(0, rows).contiguous()
@@ -95,11 +96,11 @@ class ISRunner:
         value, logq = ops.is_step(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
                                   -1 if prev_addr_id is None else int(prev_addr_id), m, self.e_obs, prev, prior, h, c,
                                   1 if prev_addr_id is None else m, None, int(seed), self.offset)
-        if prev_addr_id is None:     # the call left the (shared) new state in row 0
-            h = h[:1].expand(m, -1)
-            c = c[:1].expand(m, -1)
-        self.h.index_copy_(0, rows, h)
-        self.c.index_copy_(0, rows, c)
+        if prev_addr_id is None:     # the call left the (shared) new state in row 0 of every layer
+            h = h[:, :1].expand(-1, m, -1)
+            c = c[:, :1].expand(-1, m, -1)
+        self.h.index_copy_(1, rows, h)
+        self.c.index_copy_(1, rows, c)
         return value, logq
 
     # ---- log-weight terms ---------------------------------------------------------------------------------

@@ -6,8 +6,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 3
+PP_ABI_VERSION = 4
 PP_MAX_OBS = 8
+PP_MAX_LSTM_DEPTH = 4
 PP_ADDR_TABLE_COLS = 8
 PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL, PP_HEAD_POISSON_TN_MIXTURE = 0, 1, 2, 3
 PP_HEAD_BERNOULLI = 4
@@ -35,7 +36,10 @@ class pp_net(C.Structure):
                 ('lstm_in', i32), ('lstm_dim', i32),
                 ('w_ih', i64), ('w_hh', i64), ('b_ih', i64), ('b_hh', i64),
                 ('n_addr', i32), ('n_dtype', i32),
-                ('addrs', C.POINTER(pp_addr)), ('addr_table', vp), ('n_params', i64)]
+                ('addrs', C.POINTER(pp_addr)), ('addr_table', vp), ('n_params', i64),
+                ('lstm_depth', i32), ('_pad2', i32),
+                ('lstm_w_ih', i64 * PP_MAX_LSTM_DEPTH), ('lstm_w_hh', i64 * PP_MAX_LSTM_DEPTH),
+                ('lstm_b_ih', i64 * PP_MAX_LSTM_DEPTH), ('lstm_b_hh', i64 * PP_MAX_LSTM_DEPTH)]
 
 
 class pp_batch(C.Structure):

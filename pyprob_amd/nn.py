@@ -94,8 +94,7 @@ class InferenceNetworkLSTM:
     def __init__(self, model=None, observe_embeddings={}, lstm_dim=512, lstm_depth=1, sample_embedding_dim=4,
                  address_embedding_dim=64, distribution_type_embedding_dim=8, proposal_mixture_components=10,
                  device='cuda:0', seed=None):
-        if lstm_depth != 1:
-            raise ValueError('pyprob_amd implements lstm_depth=1 (the reference default)')
+        self._lstm_depth = int(lstm_depth)
         self._model = model
         self._observe_embeddings = observe_embeddings
         self._lstm_dim = lstm_dim
@@ -153,7 +152,8 @@ class InferenceNetworkLSTM:
         spec = NetSpec(self._obs_spec, lstm_dim=self._lstm_dim, sample_embedding_dim=self._sample_embedding_dim,
                        address_embedding_dim=self._address_embedding_dim,
                        distribution_type_embedding_dim=self._distribution_type_embedding_dim,
-                       proposal_mixture_components=self._proposal_mixture_components, network=self._network)
+                       proposal_mixture_components=self._proposal_mixture_components, network=self._network,
+                       lstm_depth=self._lstm_depth)
         self._engine = ICEngine(spec, device=self._device, seed=self._seed)
         self._is = ISRunner(self._engine)
 
@@ -495,7 +495,11 @@ class InferenceNetworkLSTM:
         # pack -> upload -> loss + backward -> Adam per step, no Python in between); Python plans the minibatches of a
         # run, polymorphs at exactly the iteration where a new address first appears (a run ends before it), computes
         # the learning rates, and reads the run's losses back once. PP_PYTHON_LOOP=1 keeps the per-step Python loop.
-        native = packed and world == 1 and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
+        # (a Bernoulli head's rows carry statistics of their sub-batch step, filled in by the Python packer only
+        # - dataset._bernoulli_step_stats -: such programs keep the per-step loop)
+        has_bernoulli = any(a.dist_name == 'Bernoulli' for a in self._engine.spec.addresses) or \
+            (packed and any(a[1] == 'Bernoulli' for a in getattr(dataset, 'addresses', [])))
+        native = packed and world == 1 and not has_bernoulli and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
         chunk_steps = 1 if sync_every == 1 else 64
         carry = None
         type_key, type_known = None, None
@@ -674,6 +678,7 @@ class InferenceNetworkLSTM:
         state = {k: getattr(self, k) for k in self._PERSISTED}
         state['_learning_rate_scheduler_type'] = None if sched is None else str(sched).split('.')[-1].upper()
         torch.save(dict(state_dict=self.state_dict(), obs_spec=self._obs_spec, lstm_dim=self._lstm_dim, network=self._network,
+                        lstm_depth=self._lstm_depth,
                         K=self._proposal_mixture_components,
                         dims=dict(sample_embedding_dim=self._sample_embedding_dim,
                                   address_embedding_dim=self._address_embedding_dim,
@@ -689,7 +694,7 @@ class InferenceNetworkLSTM:
         d = torch.load(file_name, weights_only=False)
         cls = InferenceNetworkFeedForward if d.get('network', 'lstm') == 'feedforward' else InferenceNetworkLSTM
         net = cls(observe_embeddings=d['obs_spec'], lstm_dim=d['lstm_dim'], proposal_mixture_components=d['K'], device=device,
-                  **d.get('dims', {}))
+                  lstm_depth=d.get('lstm_depth', 1), **d.get('dims', {}))
         net._obs_spec = d['obs_spec']
         net._obs_names = list(d['obs_spec'].keys())
         net._init_layers()

@@ -203,8 +203,9 @@ def _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_v
     if not (0 <= addr_id < netc.n_addr) or prev_addr_id >= netc.n_addr:
         raise RuntimeError('pyprob_hip::is_step: address id out of range')
     H = netc.lstm_dim
-    if H > 0 and (h.numel() < n * H or c.numel() < n * H):
-        raise RuntimeError('pyprob_hip::is_step: LSTM state smaller than [n, H]')
+    depth = max(1, int(netc.lstm_depth))
+    if H > 0 and (h.numel() < depth * n * H or c.numel() < depth * n * H):
+        raise RuntimeError('pyprob_hip::is_step: LSTM state smaller than [depth, n, H]')
     stride = 0
     if prior is not None:
         _f32(prior, 'prior')

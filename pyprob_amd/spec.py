@@ -38,9 +38,12 @@ class NetSpec:
     """Dimensions + ordered tensor table. Grows when `_polymorph` meets a new address."""
 
     def __init__(self, observe_embeddings, lstm_dim=512, sample_embedding_dim=4, address_embedding_dim=64,
-                 distribution_type_embedding_dim=8, proposal_mixture_components=10, network='lstm'):
+                 distribution_type_embedding_dim=8, proposal_mixture_components=10, network='lstm', lstm_depth=1):
         if network not in ('lstm', 'feedforward'):
             raise ValueError('network must be lstm or feedforward')
+        if not 1 <= int(lstm_depth) <= L.PP_MAX_LSTM_DEPTH:
+            raise ValueError('lstm_depth must be 1..%d' % L.PP_MAX_LSTM_DEPTH)
+        self.lstm_depth = 1 if network == 'feedforward' else int(lstm_depth)
         self.network = network
         self.feedforward = network == 'feedforward'
         # observe_embeddings: ordered {name: {'dim': D, 'input_dim': d_in}}  (FEEDFORWARD, depth 2 only)
@@ -78,8 +81,10 @@ class NetSpec:
         self._add(p + '0.weight', (e, e)); self._add(p + '0.bias', (e,))
         self._add(p + '1.weight', (e, e)); self._add(p + '1.bias', (e,))
         if not self.feedforward:
-            self._add('_layers_lstm.weight_ih_l0', (4 * H, I)); self._add('_layers_lstm.weight_hh_l0', (4 * H, H))
-            self._add('_layers_lstm.bias_ih_l0', (4 * H,)); self._add('_layers_lstm.bias_hh_l0', (4 * H,))
+            for k in range(self.lstm_depth):     # nn.LSTM parameter order: per layer w_ih, w_hh, b_ih, b_hh
+                self._add('_layers_lstm.weight_ih_l%d' % k, (4 * H, I if k == 0 else H))
+                self._add('_layers_lstm.weight_hh_l%d' % k, (4 * H, H))
+                self._add('_layers_lstm.bias_ih_l%d' % k, (4 * H,)); self._add('_layers_lstm.bias_hh_l%d' % k, (4 * H,))
         self.n_core_tensors = len(self.tensors)
 
     # ---- layout ------------------------------------------------------------------------------------
@@ -242,6 +247,12 @@ class NetSpec:
         if not self.feedforward:
             net.w_ih, net.w_hh = self.offset('_layers_lstm.weight_ih_l0'), self.offset('_layers_lstm.weight_hh_l0')
             net.b_ih, net.b_hh = self.offset('_layers_lstm.bias_ih_l0'), self.offset('_layers_lstm.bias_hh_l0')
+            net.lstm_depth = self.lstm_depth
+            for k in range(self.lstm_depth):
+                net.lstm_w_ih[k] = self.offset('_layers_lstm.weight_ih_l%d' % k)
+                net.lstm_w_hh[k] = self.offset('_layers_lstm.weight_hh_l%d' % k)
+                net.lstm_b_ih[k] = self.offset('_layers_lstm.bias_ih_l%d' % k)
+                net.lstm_b_hh[k] = self.offset('_layers_lstm.bias_hh_l%d' % k)
         net.n_addr, net.n_dtype = len(self.addresses), len(self.dtypes)
         arr = (L.pp_addr * max(len(self.addresses), 1))()
         for a, info in enumerate(self.addresses):

@@ -17,6 +17,7 @@ reference is copied: we call its public API and record inputs/outputs:
                           (pyprob/state.py:203-219, pyprob/trace.py:123-125): sampled values, prior log_prob,
                           proposal parameters, proposal log_prob, per-trace log_importance_weight.
 
+Case gumm2: the gumm program with lstm_depth=2 (stacked nn.LSTM layers, lstm_dim=32).
 Cases ff / ffc: the same records for InferenceNetworkFeedForward (pyprob/nn/inference_network_feedforward.py) on the
 gumm / cat programs (no LSTM records). Cases: gum (GaussianUnknownMean, tests/test_inference.py:97-109), gumm (…Marsaglia, :252-275), both with
 lstm_dim=64 so the fixtures stay small, and cat (a Categorical->Normal toy model exercising
@@ -165,7 +166,8 @@ def dump_batch(traces, obs_names):
     return arrays, meta
 
 
-def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_particles, observe, network='lstm'):
+def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_particles, observe, network='lstm',
+             lstm_depth=1):
     print('=' * 30, case)
     pyprob.seed(123)
     obs_emb = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
@@ -173,7 +175,7 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
                                   observe_embeddings=obs_emb,
                                   inference_network=(InferenceNetwork.LSTM if network == 'lstm' else
                                                      InferenceNetwork.FEEDFORWARD),
-                                  lstm_dim=lstm_dim, lstm_depth=1, proposal_mixture_components=10,
+                                  lstm_dim=lstm_dim, lstm_depth=lstm_depth, proposal_mixture_components=10,
                                   learning_rate_init=1e-3, weight_decay=0.)
     net = model._inference_network
     net.train()
@@ -239,6 +241,7 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
     meta['param_names'] = names
     meta['has_grad'] = has_grad
     meta['lstm_dim'] = lstm_dim if network == 'lstm' else 0
+    meta['lstm_depth'] = lstm_depth
     meta['network'] = network
     meta['mixture_components'] = 10
     meta['observe_embedding_dims'] = {'obs0': 32, 'obs1': 32}
@@ -339,6 +342,10 @@ if __name__ == '__main__':
         # (every proposal scored against every value of the sub-batch step); recorded as the reference computes it.
         torch.distributions.Distribution.set_default_validate_args(False)
         run_case('ber', BernoulliThenNormal(), 64, 1280, 64, 48, 32, {'obs0': 1.2, 'obs1': 0.7})
+        sys.exit(0)
+    if only == 'gumm2':
+        # nn.LSTM(I, H, 2) (learn_inference_network(lstm_depth=2), inference_network_lstm.py:31): stacked layers
+        run_case('gumm2', GaussianWithUnknownMeanMarsaglia(), 32, 1280, 64, 48, 24, obs, lstm_depth=2)
         sys.exit(0)
     if only == 'ff':
         # InferenceNetworkFeedForward (pyprob/nn/inference_network_feedforward.py): heads read the observe embedding

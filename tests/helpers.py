@@ -7,7 +7,7 @@ from pyprob_amd.spec import NetSpec
 def spec_from_golden(meta, params):
     obs = {n: {'dim': meta['observe_embedding_dims'][n], 'input_dim': 1} for n in meta['obs_names']}
     spec = NetSpec(obs, lstm_dim=meta['lstm_dim'], proposal_mixture_components=meta['mixture_components'],
-                   network=meta.get('network', 'lstm'))
+                   network=meta.get('network', 'lstm'), lstm_depth=meta.get('lstm_depth', 1))
     pairs = list(zip(meta['addresses'], meta['dist_names']))
     # addresses the network knows but this batch does not contain (GUMM): dist type from the address suffix
     for k in params:

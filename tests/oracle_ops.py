@@ -188,18 +188,21 @@ def _is_step_cpu(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_v
         x[0, :, c2:c2 + spec.dtype_dim] = Pm['_layers_distribution_type_embedding.' + d_cur]
         x[0, :, c2 + spec.dtype_dim:c2 + spec.dtype_dim + spec.addr_dim] = Pm['_layers_address_embedding.' + a_cur]
         H = spec.lstm_dim
-        hv, cv = h.view(-1, H), c.view(-1, H)
-        if first:
-            h0 = c0 = None
-        elif state_rows == 1:      # the shared first-statement state of row 0 (include/pyprob_amd.h, pp_is_step)
-            h0 = np.tile(hv[:1].numpy().astype(DT), (n, 1))
-            c0 = np.tile(cv[:1].numpy().astype(DT), (n, 1))
-        else:
-            h0, c0 = hv[:n].numpy().astype(DT), cv[:n].numpy().astype(DT)
-        out, _, (hn, cn) = O.lstm_forward(x, Pm['_layers_lstm.weight_ih_l0'], Pm['_layers_lstm.weight_hh_l0'],
-                                          Pm['_layers_lstm.bias_ih_l0'], Pm['_layers_lstm.bias_hh_l0'], h0, c0)
-        hv[:rows] = torch.from_numpy(hn.astype(np.float32))
-        cv[:rows] = torch.from_numpy(cn.astype(np.float32))
+        D = spec.lstm_depth
+        hv, cv = h.reshape(D, -1, H), c.reshape(D, -1, H)     # [depth, n, H] (views of the caller's state)
+        xin = x
+        for k in range(D):
+            if first:
+                h0 = c0 = None
+            elif state_rows == 1:      # the shared first-statement state of row 0 (include/pyprob_amd.h, pp_is_step)
+                h0 = np.tile(hv[k, :1].numpy().astype(DT), (n, 1))
+                c0 = np.tile(cv[k, :1].numpy().astype(DT), (n, 1))
+            else:
+                h0, c0 = hv[k, :n].numpy().astype(DT), cv[k, :n].numpy().astype(DT)
+            out, _, (hn, cn) = O.lstm_forward(xin, *onet.lstm_layer(k), h0, c0)
+            hv[k, :rows] = torch.from_numpy(hn.astype(np.float32))
+            cv[k, :rows] = torch.from_numpy(cn.astype(np.float32))
+            xin = out
         hs = np.tile(out[0], (n, 1)) if first else out[0]
     dummy = np.zeros(n, DT)
     if value_in is None:

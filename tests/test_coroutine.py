@@ -25,7 +25,8 @@ CASES = [('gum', GaussianWithUnknownMean, {'obs0': 8, 'obs1': 9}, math.sqrt(2)),
          ('cat', CategoricalThenNormal, {'obs0': 1.2, 'obs1': 0.7}, 0.8),
          ('poi', PoissonThenNormal, {'obs0': 2.2, 'obs1': 1.7}, 0.8),
          ('ber', BernoulliThenNormal, {'obs0': 1.2, 'obs1': 0.7}, 0.8),
-         ('ff', GaussianWithUnknownMeanMarsaglia, {'obs0': 8, 'obs1': 9}, math.sqrt(2))]
+         ('ff', GaussianWithUnknownMeanMarsaglia, {'obs0': 8, 'obs1': 9}, math.sqrt(2)),
+         ('gumm2', GaussianWithUnknownMeanMarsaglia, {'obs0': 8, 'obs1': 9}, math.sqrt(2))]        # nn.LSTM depth 2
 
 
 @pytest.mark.parametrize('case,program,observe,sigma', CASES, ids=[c[0] for c in CASES])

@@ -354,3 +354,29 @@ def test_save_dataset_detects_observed_variables_only(tmp_path):
     NamedLatent().save_dataset(str(tmp_path / 'd'), 50, 50)
     ds = PackedTraceDataset(str(tmp_path / 'd'))
     assert ds.obs_names == ['obs'] and ds.obs_width == 1
+
+
+def test_bernoulli_programs_pack_from_a_dataset(tmp_path):
+    """A program with a Bernoulli proposal (proposal_bernoulli_bernoulli.py): the rows of its head carry (n, sum of
+    values) of their sub-batch step. The dataset route (columns -> pp_pack_indexed + the step statistics) gives the same
+    packed minibatch as the Trace route (Batch -> pack_traces + bernoulli_group_stats)."""
+    from models import BernoulliThenNormal
+    from pyprob_amd.packed import pack_traces
+    from pyprob_amd.spec import NetSpec
+    torch = pytest.importorskip('torch')
+    torch.manual_seed(3)
+    BernoulliThenNormal().save_dataset(str(tmp_path / 'b'), 300, 150)
+    ds = PackedTraceDataset(str(tmp_path / 'b'))
+    spec = NetSpec({'obs0': {'dim': 8}, 'obs1': {'dim': 8}}, lstm_dim=16)
+    for a, d, nc in ds.addresses:
+        spec.add_address(a, d, nc)
+    assert any(a.dist_name == 'Bernoulli' for a in spec.addresses)
+    ids = ds.sorted_indices()[40:140]
+    got = ds.batch(ids, spec)
+    ref = pack_traces([ds[int(i)] for i in ids], spec, ['obs0', 'obs1'])
+    np.testing.assert_array_equal(got.addr, ref.addr)
+    np.testing.assert_array_equal(got.value, ref.value)
+    np.testing.assert_allclose(got.prior, ref.prior)
+    b = spec.address_id[[a.address for a in spec.addresses if a.dist_name == 'Bernoulli'][0]]
+    rows = got.addr == b
+    assert np.all(got.prior[rows, 0] == rows.sum()) and np.all(got.prior[rows, 1] == got.value[rows].sum())

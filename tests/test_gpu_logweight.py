@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 # likelihood of the two observations of every golden program (tests/golden/make_golden.py): Normal(result, sigma)
-LIKELIHOOD_STDDEV = {'gum': 2.0 ** 0.5, 'gumm': 2.0 ** 0.5, 'ff': 2.0 ** 0.5, 'cat': 0.8, 'poi': 0.8, 'ber': 0.8, 'ffc': 0.8}
+LIKELIHOOD_STDDEV = {'gum': 2.0 ** 0.5, 'gumm': 2.0 ** 0.5, 'gumm2': 2.0 ** 0.5, 'ff': 2.0 ** 0.5, 'cat': 0.8, 'poi': 0.8, 'ber': 0.8, 'ffc': 0.8}
 
 
 class _Dist:
@@ -243,7 +243,7 @@ def test_lock_step_gumm_run_rescored_by_the_oracle():
     np.testing.assert_allclose(post._all_values.cpu().numpy()[ok], results[ok], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('case', ['gum', 'gumm', 'cat', 'poi', 'ber', 'ff'])
+@pytest.mark.parametrize('case', ['gum', 'gumm', 'cat', 'poi', 'ber', 'ff', 'gumm2'])
 def test_coroutine_run_rescored_by_the_oracle(case):
     """The reference's programs AS WRITTEN (`while float(s) >= 1`) through the particle-coroutine scheduler on the
     device: every particle's trace (addresses, values, priors) re-scored by the oracle equals its device log-weight."""
