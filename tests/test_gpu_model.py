@@ -384,3 +384,21 @@ def test_checkpoint_files_and_pre_generated_layers(tmp_path):
     assert m2._inference_network._total_train_traces == net._total_train_traces
     with pytest.raises(ValueError):
         model.learn_inference_network(num_traces=10, observe_embeddings=EMB, optimizer_type='SGD')
+
+
+def test_two_layer_lstm_trains_and_infers():
+    """learn_inference_network(lstm_depth=2) (nn.LSTM(I, H, 2), inference_network_lstm.py:31): parameter names of the
+    second layer, training reduces the loss, lock-step and coroutine posteriors run on the stacked state."""
+    torch.manual_seed(13)
+    model = GaussianWithUnknownMeanMarsaglia()
+    model.learn_inference_network(inference_network=LSTM, num_traces=30000, observe_embeddings=EMB, batch_size=128, lstm_dim=32,
+                                  lstm_depth=2, seed=5)
+    net = model._inference_network
+    sd = net.state_dict()
+    assert sd['_layers_lstm.weight_ih_l1'].shape == (128, 32) and sd['_layers_lstm.weight_hh_l1'].shape == (128, 32)
+    hist = np.asarray(net._history_train_loss)
+    assert hist[-15:].mean() < hist[:15].mean() - 0.05      # (single minibatch losses of this ragged program are noisy)
+    assert float(net._engine.tensor(
+        '_layers_lstm.weight_hh_l1', net._engine.exp_avg_sq).abs().max()) > 0       # the second layer's recurrence trains
+    post = model.posterior_results(600, IC, observe={'obs0': 4, 'obs1': 5}, lock_step=False, seed=1)
+    assert post.length > 500 and np.isfinite(post.mean) and post.effective_sample_size > 3
