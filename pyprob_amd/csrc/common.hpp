@@ -1,6 +1,7 @@
 // Shared device/host helpers for libpyprob_amd (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -49,6 +50,16 @@ struct GemmBlock {
 struct GemmHole {
     GemmBlock b[2];
 };
+
+// PP_DETERMINISTIC=1: every floating-point reduction of pp_ic_loss runs in a FIXED order - no split-K float atomics
+// (one workgroup per output tile walks all of K), column sums / sample-embedding gradients / the loss by single-writer
+// kernels with a fixed row order - so that the same inputs give bit-identical losses and gradients on every run (the
+// reference on CPU is deterministic; the default mode is not, in the last bits: float atomics commute only in exact
+// arithmetic). Slower: see DESIGN.md.
+static inline bool deterministic_mode() {
+    static const int on = getenv("PP_DETERMINISTIC") ? atoi(getenv("PP_DETERMINISTIC")) : 0;
+    return on != 0;
+}
 
 // engine.hip: in-stream kernel timing (pp_prof_arm / pp_prof_collect)
 void prof_begin(int which, hipStream_t st);

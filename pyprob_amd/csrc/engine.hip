@@ -50,6 +50,11 @@ int head_tail_multi(int kind, const TailJob* jobs, int count, int64_t lda1, int 
                     int32_t* nonfinite, hipStream_t st);
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out,
                   hipStream_t st);
+int loss_from_rows(const float* lp, int n_rows, int n_traces, const int32_t* flag, float* loss_out, int32_t* status_out,
+                   hipStream_t st);
+int sample_embed_bwd_det(const pp_net* net, const float* params, const float* value, const int32_t* prev_row,
+                         const int32_t* nxt_rows, const int32_t* nxt_off, const float* dX, int64_t ldx, float* grads,
+                         hipStream_t st);
 int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
               const float* active, int32_t* tensor_step, int32_t* arrived, int n_tensors, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, int flags, const int32_t* skip, hipStream_t st);
@@ -129,6 +134,7 @@ struct Workspace {
     float* dObsH;              // n_obs x [B, maxhid4] (observable o at dObsH + o * B * maxhid4)
     float* loss_acc;           // [1]
     int32_t* flag;             // [1]
+    float* lp_rows;            // [R] per-row proposal log_prob (deterministic mode: the loss is reduced from it)
     int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
     size_t bytes;
 };
@@ -182,6 +188,7 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     // non-finite flag; cleared by the step's first kernel
     w.loss_acc = c.take<float>(PP_LOSS_SLOTS_FLOATS);
     w.flag = reinterpret_cast<int32_t*>(w.loss_acc ? w.loss_acc + 64 * 32 : nullptr);
+    w.lp_rows = c.take<float>(deterministic_mode() ? R : 0);
     w.bytes = c.off + 256;
 }
 
@@ -444,6 +451,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     const float gscale = -1.0f / (float)B;
     std::vector<ColsumJob> cs;
+    // deterministic mode: the heads write the per-row log_prob only; the loss is a fixed-order sum over the rows
+    const bool det = deterministic_mode();
+    float* const lp_rows = det ? (((flags & PP_LOSS_KEEP_LP) && lp_out) ? lp_out : w.lp_rows)
+                               : ((flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr);
+    float* const loss_slots = det ? nullptr : w.loss_acc;
     // heads: first FF layer of EVERY address group in one grouped launch (rows gathered by address: the dispatch
     // gather), then the fused tails, grouped by (kind, shape)
     {
@@ -483,7 +495,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 }
             }
             PP_TRY(head_tail_multi(ad.kind, tj.data(), (int)tj.size(), w.hid4, ad.hid, ad.n_out, bt->value, bt->prior, gscale,
-                                   (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr, w.out4, w.hid4, w.loss_acc, w.flag, st));
+                                   lp_rows, w.out4, w.hid4, loss_slots, w.flag, st));
             continue;
         }
         done[a] = 1;
@@ -491,13 +503,15 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         float* Y = w.Y + (int64_t)g0 * w.out4;
         PP_TRY(linear_fwd(A1, w.hid4, nullptr, P + ad.w2, P + ad.b2, Y, w.out4, n, ad.hid, ad.n_out, false, nullptr, st));
         PP_TRY(head_logprob(ad.kind, Y, w.out4, bt->grp_rows + g0, bt->value, bt->prior, n, ad.n_out, gscale,
-                            (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr, bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr,
-                            w.loss_acc, w.flag, st));
+                            lp_rows, bwd ? w.DY + (int64_t)g0 * w.out4 : nullptr, loss_slots, w.flag, st));
     }
+    if (det) PP_TRY(loss_from_rows(lp_rows, R, B, w.flag, loss_out, status_out, st));
     if (!bwd) {
-        PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
+        if (!det) PP_TRY(loss_finalize(w.loss_acc, w.flag, B, loss_out, status_out, st));
         return 0;
     }
+    // (deterministic mode: the loss is final; the kernels below get no loss slots to fold)
+    const float* const fin_acc = det ? nullptr : w.loss_acc;
     // (with a backward pass the loss slots are folded by the first LSTM-cell launch below)
     // (the bias / table column sums queued in `cs` are launched once, at the end of the backward pass)
 
@@ -536,7 +550,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         if (!fused) {
             PP_TRY(colsum_f32(DY, w.out4, nullptr, n, ad.n_out, grads + ad.b2, nullptr, st));
             PP_TRY(linear_dgrad(DY, w.out4, P + ad.w2, dZ1, w.hid4, nullptr, A1, w.hid4, n, ad.hid, ad.n_out, false, st,
-                                grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
+                                det ? nullptr : grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
+            if (det) cs.push_back(ColsumJob{dZ1, w.hid4, nullptr, n, ad.hid, grads + ad.b1, nullptr});
         }
         queue_wgrad(wq, dZ1, w.hid4, heads_in, heads_ld, bt->grp_rows + g0, grads + ad.w1, n, H, ad.hid);
         {   // dH[rows of this address] = dZ1 W1: queued, every address group in one grouped launch
@@ -568,12 +583,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             const float* c_prev = t > 0 ? w.Cl[l] + (int64_t)bt->row_off[t - 1] * H : nullptr;
             const bool fin = l == L - 1 && t == T - 1;   // the backward pass's first cell launch folds the loss slots
             PP_TRY(lstm_cell_bwd(Gt, c_prev, w.Cl[l] + (int64_t)r0 * H, dH_cur + (int64_t)r0 * H, w.dC, n, n_next, H,
-                                 grads + lb_ih(l), grads + lb_hh(l), st, fin ? w.loss_acc : nullptr, w.flag, B, loss_out,
-                                 status_out));   // bias gradients fused
+                                 det ? nullptr : grads + lb_ih(l), det ? nullptr : grads + lb_hh(l), st,
+                                 fin ? fin_acc : nullptr, w.flag, B, loss_out, status_out));   // bias gradients fused
             if (t > 0)  // dh_{t-1} += dG_t W_hh
                 PP_TRY(linear_dgrad(Gt, 4 * H, P + lw_hh(l), dH_cur + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0,
                                     n, H, 4 * H, true, st));
         }
+        if (det)   // bias gradients = column sums of the complete dG of this layer, by the single-writer kernel
+            cs.push_back(ColsumJob{w.Gl[l], 4 * H, nullptr, R, 4 * H, grads + lb_ih(l), grads + lb_hh(l)});
         // parameter gradients of this layer (leaves, grouped with every head's weight gradients). First-time-step rows give
         // nothing to the forget-gate rows (dG[:, H:2H] = 0 where c_{t-1} = 0) and, in layer 0, nothing to the
         // previous-variable columns of dW_ih (their inputs are zero there)
@@ -625,7 +642,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             cs.push_back(ColsumJob{w.dX + c3, w.i4, bt->nxt_rows + q0, m, net->addr_dim, grads + ad.addr_emb, nullptr});
         }
     }
-    if (T > 1)
+    if (T > 1 && det)
+        PP_TRY(sample_embed_bwd_det(net, P, bt->value, bt->prev_row, bt->nxt_rows, bt->nxt_off, w.dX, w.i4, grads, st));
+    else if (T > 1)
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
     }   // !ff
     // observe embedding backward
@@ -656,7 +675,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             co += out;
         }
         if (ff)   // (LSTM: the first cell launch of the backward pass finalises the loss)
-            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, w.loss_acc, w.flag, B, loss_out, status_out));
+            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
         else
             PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
         PP_TRY(flush_wgrads(st, !ss));
@@ -664,7 +683,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     PP_TRY(obs_grad(dXs, ldxs, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
     if (ff)
-        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, w.loss_acc, w.flag, B, loss_out, status_out));
+        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
     else
         PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
     PP_TRY(flush_wgrads(st, !ss));
@@ -672,7 +691,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st,
-                        grads + net->fin_b0));
+                        det ? nullptr : grads + net->fin_b0));
+    if (det) PP_TRY(colsum_f32(w.dF1, w.e4, nullptr, B, e, grads + net->fin_b0, nullptr, st));
     PP_TRY(linear_wgrad(w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, nullptr, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dF1, w.e4, P + net->fin_w0, w.dCat, w.e4, nullptr, w.cat, w.e4, B, e, e, false, st));
     int ci = 0, co = 0;
@@ -681,7 +701,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         PP_TRY(linear_wgrad(w.dCat + co, w.e4, w.obs_h[o], w.ohid4[o], nullptr, grads + net->obs_w1[o],
                             grads + net->obs_b1[o], nullptr, B, hid, out, st));
         PP_TRY(linear_dgrad(w.dCat + co, w.e4, P + net->obs_w1[o], w.dObsH, w.ohid4[o], nullptr, w.obs_h[o], w.ohid4[o], B,
-                            hid, out, false, st, grads + net->obs_b0[o]));
+                            hid, out, false, st, det ? nullptr : grads + net->obs_b0[o]));
+        if (det) PP_TRY(colsum_f32(w.dObsH, w.ohid4[o], nullptr, B, hid, grads + net->obs_b0[o], nullptr, st));
         PP_TRY(linear_wgrad(w.dObsH, w.ohid4[o], bt->obs + ci, bt->obs_width, nullptr, grads + net->obs_w0[o], nullptr,
                             nullptr, B, in, hid, st));
         ci += in;

@@ -1282,6 +1282,7 @@ static bool use_direct(int64_t tiles64, int64_t slabs) {
 }
 
 static bool split_allowed(const pp_gemm_args* a) {
+    if (deterministic_mode()) return false;   // no float atomics: one workgroup per tile walks all of K
     const int64_t tiles64 = (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
     const bool linear = !a->relu && !a->mask && !a->colsum;
     return a->split_k && linear && cdiv(a->K, BK) >= 4 && tiles64 < 384 && (a->accumulate || !a->c_idx);

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 namespace pp {
 
@@ -90,8 +91,89 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs, cons
     }
 }
 
+// Deterministic variant (PP_DETERMINISTIC): workgroup (column block, group) owns its 64 destination columns - ONE
+// writer - and walks the jobs of its group (all jobs with the same destination) in order; each thread sums its rows
+// sequentially, the four row lanes are combined in a fixed order.
+struct ColsumGroups {
+    ColsumJob j[COLSUM_MAX_JOBS];
+    int first[COLSUM_MAX_JOBS + 1];   // jobs [first[g], first[g+1]) form group g
+};
+
+__global__ __launch_bounds__(256) void colsum_det_kernel(const ColsumGroups g) {
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int j0 = g.first[blockIdx.y], j1 = g.first[blockIdx.y + 1];
+    float total = 0.0f;
+    for (int q = j0; q < j1; ++q) {
+        const ColsumJob& jb = g.j[q];
+        float acc = 0.0f;
+        if (col < jb.n_cols) {
+            for (int i = rl; i < jb.n_rows; i += 4) {
+                const int64_t r = jb.idx ? (int64_t)jb.idx[i] : (int64_t)i;
+                float v = jb.X[r * jb.ldx + col];
+                if (jb.wgt) v *= jb.wgt[(int64_t)i * jb.ldw];
+                acc += v;
+            }
+        }
+        part[rl][cl] = acc;
+        __syncthreads();
+        if (rl == 0) total += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        __syncthreads();
+    }
+    const ColsumJob& j = g.j[j0];
+    if (rl == 0 && col < j.n_cols) {
+        float* dst = j.out + (int64_t)col * (j.out_stride ? j.out_stride : 1);
+        *dst += total;
+        if (j.out2) j.out2[col] += total;
+    }
+}
+
+static int colsum_multi_det(const ColsumJob* jobs, int count, hipStream_t st) {
+    std::vector<char> done(count, 0);
+    int left = 0;
+    for (int i = 0; i < count; ++i) {
+        if (jobs[i].n_rows <= 0 || jobs[i].n_cols <= 0) done[i] = 1; else ++left;
+    }
+    while (left > 0) {
+        ColsumGroups pack;
+        int n = 0, groups = 0, max_cols = 0;
+        pack.first[0] = 0;
+        for (int i = 0; i < count && n < COLSUM_MAX_JOBS; ++i) {
+            if (done[i]) continue;
+            // a destination already packed in this launch but not as the group being built: wait for the next launch
+            bool clash = false;
+            for (int q = 0; q < n; ++q) clash = clash || pack.j[q].out == jobs[i].out;
+            if (clash) continue;
+            // group: this job and every later job with the same destination (same width), in job order
+            const int g0 = n;
+            for (int k = i; k < count && n < COLSUM_MAX_JOBS; ++k) {
+                if (done[k] || jobs[k].out != jobs[i].out) continue;
+                PP_CHECK_ARG(jobs[k].X && jobs[k].n_cols == jobs[i].n_cols && jobs[k].out2 == jobs[i].out2 &&
+                                 jobs[k].out_stride == jobs[i].out_stride, "pp_colsum_f32: inconsistent jobs for one destination");
+                pack.j[n++] = jobs[k];
+                done[k] = 1;
+                --left;
+            }
+            if (n > g0) {
+                pack.first[++groups] = n;
+                max_cols = std::max(max_cols, jobs[i].n_cols);
+            }
+        }
+        if (groups == 0) break;
+        hipLaunchKernelGGL(colsum_det_kernel, dim3(cdiv(max_cols, 64), groups), dim3(256), 0, st, pack);
+        PP_LAUNCH_CHECK("pp_colsum_f32 (deterministic)");
+    }
+    return 0;
+}
+
 int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st, const float* fin_acc, const int32_t* fin_flag,
                  int fin_traces, float* fin_loss, int32_t* fin_status) {
+    if (deterministic_mode()) {
+        PP_TRY(colsum_multi_det(jobs, count, st));
+        if (fin_acc) return loss_finalize(fin_acc, fin_flag, fin_traces, fin_loss, fin_status, st);
+        return 0;
+    }
     LossFinalize fin{fin_acc, fin_flag, fin_traces > 0 ? 1.0f / (float)fin_traces : 0.0f, fin_loss, fin_status};
     int i = 0;
     while (i < count) {
@@ -256,6 +338,66 @@ __global__ __launch_bounds__(256) void sample_embed_bwd_kernel(GatherDims d, con
             atomicAdd(gb + j, ds);
         }
     }
+}
+
+// Deterministic variant: thread o of workgroup (address a) owns ONE output of the address's sample-embedding layer -
+// weight element (j, k) for o < smp * smp_in, bias j after that - and scans the rows whose PREVIOUS variable has address
+// a (nxt_rows[q0 .. q0 + m), fixed order) on its own. No atomics, one writer per gradient element.
+struct SmpDetGroups {
+    int addr[32], q0[32], m[32];
+};
+__global__ __launch_bounds__(64) void sample_embed_bwd_det_kernel(GatherDims d, const float* __restrict__ params,
+                                                                  const int64_t* __restrict__ at,
+                                                                  const float* __restrict__ value,
+                                                                  const int32_t* __restrict__ prev_row,
+                                                                  const int32_t* __restrict__ nxt_rows, SmpDetGroups g,
+                                                                  const float* __restrict__ dX, int64_t ldx,
+                                                                  float* __restrict__ grads) {
+    const int a = g.addr[blockIdx.y], q0 = g.q0[blockIdx.y], m = g.m[blockIdx.y];
+    const int smp_in = (int)at[a * PP_ADDR_TABLE_COLS + PP_AT_SMP_IN];
+    const int n_w = d.smp * smp_in, o = blockIdx.x * 64 + threadIdx.x;
+    if (o >= n_w + d.smp) return;
+    const bool is_bias = o >= n_w;
+    const int j = is_bias ? o - n_w : o / smp_in, k = is_bias ? 0 : o % smp_in;
+    float acc = 0.0f;
+    for (int q = 0; q < m; ++q) {
+        const int r = nxt_rows[q0 + q];
+        const float v = value[prev_row[r]];
+        const float s = sample_embed_elem(params, at, a, j, v);
+        const float ds = s > 0.0f ? dX[(int64_t)r * ldx + d.e_obs + j] : 0.0f;
+        if (is_bias) acc += ds;
+        else if (smp_in == 1) acc += ds * v;
+        else {
+            int cat = (int)v;
+            cat = cat < 0 ? 0 : (cat >= smp_in ? smp_in - 1 : cat);
+            if (cat == k) acc += ds;
+        }
+    }
+    float* dst = grads + at[a * PP_ADDR_TABLE_COLS + (is_bias ? PP_AT_SMP_B : PP_AT_SMP_W)] + (is_bias ? j : o);
+    *dst += acc;
+}
+
+int sample_embed_bwd_det(const pp_net* net, const float* params, const float* value, const int32_t* prev_row,
+                         const int32_t* nxt_rows, const int32_t* nxt_off, const float* dX, int64_t ldx, float* grads,
+                         hipStream_t st) {
+    GatherDims d{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+    int a = 0;
+    while (a < net->n_addr) {
+        SmpDetGroups g;
+        int n = 0, max_out = 0;
+        for (; a < net->n_addr && n < 32; ++a) {
+            const int m = nxt_off[a + 1] - nxt_off[a];
+            if (m <= 0) continue;
+            g.addr[n] = a; g.q0[n] = nxt_off[a]; g.m[n] = m;
+            max_out = std::max(max_out, net->smp_dim * (net->addrs[a].smp_in + 1));
+            ++n;
+        }
+        if (n == 0) continue;
+        hipLaunchKernelGGL(sample_embed_bwd_det_kernel, dim3(cdiv(max_out, 64), n), dim3(64), 0, st, d, params, net->addr_table,
+                           value, prev_row, nxt_rows, g, dX, ldx, grads);
+        PP_LAUNCH_CHECK("sample_embed_bwd (deterministic)");
+    }
+    return 0;
 }
 
 int sample_embed_bwd(const pp_net* net, const float* params, const float* value, const int32_t* addr,
@@ -1020,6 +1162,47 @@ __global__ void loss_finalize_kernel(const float* __restrict__ acc, const int32_
     const float l = tot * inv_b;
     loss_out[0] = l;
     if (status_out) status_out[0] = (flag[0] != 0 || !isfinite(l)) ? 1 : 0;
+}
+
+// Deterministic loss (PP_DETERMINISTIC): the head kernels only write the per-row proposal log_prob; ONE workgroup sums
+// the rows in a fixed order, with the reference's -inf -> log(1e-8) rescue (inference_network_lstm.py:207-213) and the
+// non-finite check (:214-217).
+__global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict__ lp, int n_rows, float inv_b,
+                                                        const int32_t* __restrict__ flag, float* __restrict__ loss_out,
+                                                        int32_t* __restrict__ status_out) {
+    __shared__ double part[256];
+    __shared__ int bad[256];
+    double acc = 0.0;
+    int b = 0;
+    for (int r = threadIdx.x; r < n_rows; r += 256) {
+        float l = lp[r];
+        if (l == -INFINITY) l = kLogEps;
+        if (!isfinite(l)) b = 1;
+        acc -= (double)l;
+    }
+    part[threadIdx.x] = acc;
+    bad[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            part[threadIdx.x] += part[threadIdx.x + s];
+            bad[threadIdx.x] |= bad[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l = (float)(part[0] * (double)inv_b);
+        loss_out[0] = l;
+        if (status_out) status_out[0] = (bad[0] || (flag && flag[0] != 0) || !isfinite(l)) ? 1 : 0;
+    }
+}
+
+int loss_from_rows(const float* lp, int n_rows, int n_traces, const int32_t* flag, float* loss_out, int32_t* status_out,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(loss_rows_kernel, dim3(1), dim3(256), 0, st, lp, n_rows, 1.0f / (float)n_traces, flag, loss_out,
+                       status_out);
+    PP_LAUNCH_CHECK("loss_from_rows");
+    return 0;
 }
 
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out,

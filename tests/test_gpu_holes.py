@@ -62,3 +62,57 @@ def test_zero_blocks_and_side_stream_change_no_result(tmp_path):
             scale = np.abs(b).max(1) + 1e-12
             big = scale > 1e-6
             assert (np.abs(a - b).max(1)[big] / scale[big]).max() < 5e-4
+
+
+REPEAT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(repo)r); sys.path.insert(0, %(repo)r + '/tests')
+from helpers import synthetic_gumm_arrays, synthetic_gum_arrays
+from pyprob_amd.engine import ICEngine
+from pyprob_amd.packed import PackedBatch
+from pyprob_amd.spec import NetSpec
+out = {}
+for name, H, depth in (('gum', 512, 1), ('gumm', 128, 2)):
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=H, lstm_depth=depth)
+    if name == 'gum':
+        arr = synthetic_gum_arrays(1024, seed=3); addresses = ['mu']
+        spec.add_address('mu', 'Normal')
+    else:
+        arr, addresses = synthetic_gumm_arrays(900, seed=4, max_iter=5)
+        for a in addresses: spec.add_address(a, 'Uniform')
+    eng = ICEngine(spec, device='cuda:0', seed=5)
+    ids = np.array([spec.address_id[addresses[j]] for j in arr['addr_idx']])
+    pb = PackedBatch.from_ragged(arr['trace_len'], ids, arr['values'], arr['prior'], arr['obs'], len(spec.addresses)).to(eng.device)
+    for rep in range(4):
+        l = eng.loss(pb, backward=True)
+        torch.cuda.synchronize()
+        out['%%s_loss_%%d' %% (name, rep)] = l.cpu().numpy().copy()
+        out['%%s_grads_%%d' %% (name, rep)] = eng.grads.cpu().numpy().copy()
+    for rep in range(3):
+        eng.train_step(pb, lr=1e-3)
+    torch.cuda.synchronize()
+    out[name + '_params'] = eng.params.cpu().numpy().copy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_deterministic_mode_is_bitwise_repeatable(tmp_path):
+    """PP_DETERMINISTIC=1: no float atomics anywhere in pp_ic_loss (single split per GEMM tile, single-writer column
+    sums / sample-embedding gradients, fixed-order loss): four evaluations of the same minibatch give bit-identical
+    losses and gradients, two processes give bit-identical parameters after three training steps - and the numbers agree
+    with the default (atomic) mode to round-off."""
+    def run(tag, **env):
+        f = str(tmp_path / (tag + '.npz'))
+        subprocess.run([sys.executable, '-c', REPEAT % dict(repo=REPO), f], check=True, env=dict(os.environ, **env), timeout=900)
+        return dict(np.load(f))
+    d1 = run('det1', PP_DETERMINISTIC='1')
+    d2 = run('det2', PP_DETERMINISTIC='1')
+    fast = run('fast', PP_DETERMINISTIC='0')
+    for name in ('gum', 'gumm'):
+        for rep in range(1, 4):
+            assert np.array_equal(d1['%s_grads_0' % name], d1['%s_grads_%d' % (name, rep)]), (name, rep)
+            assert np.array_equal(d1['%s_loss_0' % name], d1['%s_loss_%d' % (name, rep)])
+        assert np.array_equal(d1[name + '_params'], d2[name + '_params'])          # across processes
+        assert np.array_equal(d1['%s_grads_0' % name], d2['%s_grads_0' % name])
+        assert rel_err(d1['%s_grads_0' % name], fast['%s_grads_0' % name]) < 2e-5
+        assert abs(float(d1['%s_loss_0' % name][0]) - float(fast['%s_loss_0' % name][0])) < 1e-5 * abs(float(fast['%s_loss_0' % name][0]))
