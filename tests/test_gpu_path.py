@@ -279,8 +279,10 @@ def test_adam_clears_consumed_gradients_and_train_step_skips_the_memset():
         assert float(b.grads.abs().max().item()) == 0.0
         assert int(b.arrived.view(-1, 1056)[:, :1025].abs().max().item()) == 0     # arrival counters reset themselves
     sa, sb = a.state_dict(), b.state_dict()
-    # float atomics make the last bits of a gradient run-dependent: compare with the tolerance of one Adam step
-    assert max(rel_err(sa[n].numpy(), sb[n].numpy()) for n in sa) < 1e-4
+    # float atomics make the last bits of a gradient run-dependent, and the first Adam steps move every weight by
+    # ~lr * sign(g): a near-zero gradient whose sign flips costs 2 lr. Compare with the tolerance of one such flip
+    # (bitwise equality of repeated runs is what PP_DETERMINISTIC=1 gives: tests/test_gpu_holes.py)
+    assert max(rel_err(sa[n].numpy(), sb[n].numpy()) for n in sa) < 1e-3
     assert torch.equal(a.tensor_step, b.tensor_step)
     g = b.loss(pb_, backward=True)                 # flag consumed: this call must NOT see stale gradients
     ga = a.loss(pa, backward=True)
