@@ -1444,8 +1444,11 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         // the async tiles stream a long K range at full rate, so they want fewer, longer workgroups (fewer atomics)
         const int target = as ? target_async : target_staged;
         // direct tiles: a workgroup's four waves share its slabs, so it should own >= 8 of them
+        // ... but no workgroup should walk more than ~24 slabs (~10 us of K loop): a ragged batch's dW_ih / dW_hh have
+        // K = 1600-2600 rows, and 82 slabs per workgroup made the weight-gradient launches of the GUMM step 98 + 89 us
+        static const int spb_max = getenv("PP_GROUP_SLABS_MAX") ? atoi(getenv("PP_GROUP_SLABS_MAX")) : 24;
         const int spb = direct ? (int)std::max<int64_t>(8, (work32 + target_direct - 1) / target_direct)
-                               : (int)std::max<int64_t>(2, (work + target - 1) / target);
+                               : (int)std::min<int64_t>(spb_max, std::max<int64_t>(2, (work + target - 1) / target));
         const int tile = direct ? DT : 64;
         int64_t active_blocks = 0;   // workgroups that have slabs to walk (tiles inside a zero block exit at once)
         int j = i;
