@@ -44,6 +44,22 @@ class _Particle:
 
 class _Params:
     """Per-particle parameter columns of one statement group, in the duck type ISRunner.dist_term reads."""
+    FIELDS = {'Normal': ('mean', 'stddev'), 'Uniform': ('low', 'high'), 'Poisson': ('rate',), 'Bernoulli': ('probs',),
+              'Categorical': ('probs',)}
+
+    @classmethod
+    def from_columns(cls, name, columns):
+        """columns: dict field -> array (what `columns()` returns; several of them concatenate row-wise)."""
+        self = cls.__new__(cls)
+        self.name = name
+        for k, v in columns.items():
+            setattr(self, k, v)
+        if name == 'Categorical':
+            self.num_categories = int(self.probs.shape[1])
+        return self
+
+    def columns(self):
+        return {k: getattr(self, k) for k in self.FIELDS[self.name]}
 
     def __init__(self, name, dists):
         self.name = name
@@ -110,9 +126,7 @@ class ParticleScheduler:
         """particle_main(particle) runs one trace inside the particle's greenlet. Returns the particles."""
         g = self._greenlet
         self.hub = g.getcurrent()
-        runner = self.runner
-        runner.begin(self.n, offset=self.offset)
-        runner.state_rows = self.n                 # (per-particle rows from the start: groups gather / scatter them)
+        self._begin()
         particles = [_Particle(i) for i in range(self.n)]
         t0 = time.time()
         for p in particles:                        # every particle runs to its first controlled sample (or to the end)
@@ -136,6 +150,10 @@ class ParticleScheduler:
         self.current = None
         self.seconds = time.time() - t0
         return particles
+
+    def _begin(self):
+        self.runner.begin(self.n, offset=self.offset)
+        self.runner.state_rows = self.n            # (per-particle rows from the start: groups gather / scatter them)
 
     def _between_rounds(self):
         pass
@@ -280,3 +298,215 @@ class CoroutineIS(ParticleScheduler):
                 x = torch.tensor([float(v) for _, _, v in items], dtype=torch.float32, device=self.dev)
                 lp = runner.log_prob(term, x)
             self.lw.index_add_(0, rows, lp, alpha=self.scale)
+
+
+# ---- particle shards in worker processes ---------------------------------------------------------------------------
+# One Python thread runs ~7 k particles/s of a torch-scalar program (the program's own interpreter time: ~140 us per
+# GUMM particle). The particles are independent, so the host side shards like the reference's ParallelModel
+# (pyprob/model.py:339-406): W forked workers run the greenlets of their contiguous particle range and talk to the parent
+# over pipes; the parent owns the device - per round it merges the workers' parked statements by (address, previous
+# address), serves every group with ONE pp_is_step over the gathered LSTM rows, adds the weight terms, and sends the
+# values back. Workers never touch the device.
+class _WorkerScheduler(CoroutineIS):
+    """CoroutineIS inside a forked worker: same trace-runtime hooks, but `_serve` ships the round to the parent."""
+
+    def __init__(self, state, forward, spec, lo, hi, conn, feed_forward_seed):
+        import greenlet
+        self._greenlet = greenlet
+        self.state, self.forward, self.spec = state, forward, spec
+        self.n, self.lo = hi - lo, lo
+        self.conn = conn
+        self.current = self.hub = None
+        self.rounds = self.group_calls = self.statements = 0
+        self.seconds = 0.0
+        self.likelihoods = []
+        self.runner = None
+
+    def _begin(self):
+        pass
+
+    def _likelihood_payload(self):
+        by_family = {}
+        for pid, d, v in self.likelihoods:
+            by_family.setdefault(d.name, []).append((pid, d, v))
+        self.likelihoods = []
+        out = []
+        for name, items in by_family.items():
+            cols = _Params(name, [d for _, d, _ in items]).columns()
+            out.append((name, cols, np.array([float(v) for _, _, v in items], np.float32),
+                        np.array([self.lo + pid for pid, _, _ in items], np.int64)))
+        return out
+
+    def _between_rounds(self):
+        pass          # the queued likelihood terms travel with the next message
+
+    def _serve(self, parked):
+        groups = {}
+        for p in parked:
+            a, prev_a, _ = p.request
+            groups.setdefault((a, prev_a), []).append(p)
+        payload, order = [], []
+        for (a, prev_a), members in groups.items():
+            dists = [p.request[2] for p in members]
+            head = np.asarray([distribution_params(d) for d in dists], np.float32).reshape(len(members), 2)
+            prev_host = np.array([np.nan if p.prev_host_value is None else p.prev_host_value for p in members], np.float32)
+            for p in members:
+                p.prev_host_value = None
+            payload.append((a, prev_a, np.array([self.lo + p.pid for p in members], np.int64), head,
+                            _Params(self.spec.addresses[a].dist_name, dists).columns(), prev_host))
+            order.append(members)
+        self.conn.send(dict(done=False, groups=payload, likelihoods=self._likelihood_payload()))
+        replies = self.conn.recv()
+        for members, (vals, lps) in zip(order, replies):
+            v, l = torch.from_numpy(vals).unbind(0), torch.from_numpy(lps).unbind(0)
+            for k, p in enumerate(members):
+                p.reply = (v[k], l[k])
+                p.request = None
+            self.statements += len(members)
+        self.group_calls += len(order)
+
+
+def _worker_main(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs):
+    try:
+        torch.set_num_threads(1)
+        torch.manual_seed(seed + 7919 * (worker + 1))       # (prior-as-proposal fallbacks draw on the host)
+        sched = _WorkerScheduler(state, forward, spec, lo, hi, conn, seed)
+        state._coroutine = sched
+
+        def particle_main(p):
+            state._begin_trace()
+            result = forward(*args, **kwargs)
+            p.trace = state._end_trace(result)
+            p.result = result
+            p.done = True
+        particles = sched.run_particles(particle_main)
+        if map_func is None:
+            try:
+                results = np.array([float(p.result) for p in particles], np.float32)
+            except (TypeError, ValueError):
+                results = [p.result for p in particles]
+        else:
+            results = [map_func(p.trace) for p in particles]
+        conn.send(dict(done=True, groups=[], likelihoods=sched._likelihood_payload(), results=results,
+                       stats=(sched.rounds, sched.group_calls, sched.statements)))
+        conn.recv()      # the parent's acknowledgement: the pipe is drained before the process goes away
+    except BaseException as exc:      # noqa: BLE001 - reported to the parent, which raises it
+        import traceback
+        try:
+            conn.send(dict(done=True, error='%s\n%s' % (exc, traceback.format_exc())))
+        except Exception:  # noqa: BLE001
+            pass
+    finally:
+        import os
+        os._exit(0)       # no destructors of the parent's device state in the child
+
+
+class ShardedCoroutineIS:
+    """posterior run of `num_traces` particle coroutines spread over `num_workers` forked processes; the parent serves the
+    device. `run()` returns (results, log_weights [n] device tensor, stats)."""
+
+    def __init__(self, state, forward, network, num_traces, num_workers, seed=0, offset=0, likelihood_importance=1.0,
+                 map_func=None):
+        self.state, self.forward, self.net = state, forward, network
+        self.runner, self.spec = network._is, network._engine.spec
+        self.n, self.workers = int(num_traces), max(1, min(int(num_workers), int(num_traces)))
+        self.seed, self.offset, self.scale = int(seed), int(offset), float(likelihood_importance)
+        self.map_func = map_func
+        self.dev = self.runner.dev
+
+    def run(self, *args, **kwargs):
+        import multiprocessing as mp
+        from .parallel import shard_range
+        ctx = mp.get_context('fork')          # the model is an arbitrary user object: inherited, not pickled
+        runner = self.runner
+        runner.begin(self.n, offset=self.offset)
+        runner.state_rows = self.n
+        lw = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
+        last_value = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
+        conns, procs, bounds = [], [], []
+        t0 = time.time()
+        for w in range(self.workers):
+            lo, cnt = shard_range(self.n, w, self.workers)
+            parent, child = ctx.Pipe()
+            pr = ctx.Process(target=_worker_main, args=(child, w, lo, lo + cnt, self.state, self.forward, self.spec,
+                                                        self.map_func, self.seed, args, kwargs), daemon=True)
+            pr.start()
+            child.close()
+            conns.append(parent); procs.append(pr); bounds.append((lo, lo + cnt))
+        live = set(range(self.workers))
+        results = [None] * self.workers
+        stats = [0, 0, 0]
+        rounds = 0
+        try:
+            while live:
+                msgs = {w: conns[w].recv() for w in sorted(live)}
+                for w, m in msgs.items():
+                    if m.get('error'):
+                        raise RuntimeError('particle worker %d failed: %s' % (w, m['error']))
+                # likelihood terms queued by the workers since their previous message: one kernel per family
+                fam = {}
+                for m in msgs.values():
+                    for name, cols, x, pids in m['likelihoods']:
+                        fam.setdefault(name, []).append((cols, x, pids))
+                for name, parts in fam.items():
+                    cols = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0]}
+                    x = torch.from_numpy(np.concatenate([p[1] for p in parts])).to(self.dev)
+                    rows = torch.from_numpy(np.concatenate([p[2] for p in parts])).to(self.dev)
+                    lp = runner.log_prob(runner.dist_term(_Params.from_columns(name, cols)), x)
+                    lw.index_add_(0, rows, lp, alpha=self.scale)
+                # parked statements of all workers, merged by (address, previous address)
+                merged = {}
+                for w, m in msgs.items():
+                    for gi, (a, prev_a, pids, head, cols, prev_host) in enumerate(m['groups']):
+                        merged.setdefault((a, prev_a), []).append((w, gi, pids, head, cols, prev_host))
+                replies = {w: [None] * len(m['groups']) for w, m in msgs.items()}
+                order = sorted(merged.items(), key=lambda kv: (kv[0][0], -1 if kv[0][1] is None else kv[0][1]))
+                for k, ((a, prev_a), parts) in enumerate(order):
+                    pids = np.concatenate([p[2] for p in parts])
+                    rows = torch.from_numpy(pids).to(self.dev)
+                    prev_host = np.concatenate([p[5] for p in parts])
+                    known = ~np.isnan(prev_host)
+                    if known.any():      # previous values that were drawn on the host (unknown address)
+                        last_value.index_copy_(0, rows[torch.from_numpy(known).to(self.dev)],
+                                               torch.from_numpy(prev_host[known]).to(self.dev))
+                    prior = torch.from_numpy(np.concatenate([p[3] for p in parts])).to(self.dev)
+                    runner.prev_value = last_value
+                    value, logq = runner.step_rows(rows, a, prev_a, prior, seed=self.seed + 7919 * rounds + 104729 * k,
+                                                   prior_compact=True)
+                    last_value.index_copy_(0, rows, value)
+                    cols = {c: np.concatenate([p[4][c] for p in parts]) for c in parts[0][4]}
+                    term = runner.dist_term(_Params.from_columns(self.spec.addresses[a].dist_name, cols))
+                    prior_lp = runner.log_prob(term, value)
+                    lw.index_add_(0, rows, prior_lp - logq)
+                    host = torch.stack([value, prior_lp]).cpu().numpy()
+                    pos = 0
+                    for w, gi, p_ids, _, _, _ in parts:
+                        m_ = len(p_ids)
+                        replies[w][gi] = (host[0, pos:pos + m_].copy(), host[1, pos:pos + m_].copy())
+                        pos += m_
+                    stats[1] += 1
+                for w, m in msgs.items():
+                    if m['done']:
+                        results[w] = m['results']
+                        stats[2] += m['stats'][2]
+                        conns[w].send(None)
+                        live.discard(w)
+                    else:
+                        conns[w].send(replies[w])
+                rounds += 1
+        finally:
+            for pr in procs:
+                pr.join(timeout=5)
+                if pr.is_alive():
+                    pr.terminate()
+            for c in conns:
+                c.close()
+        stats[0] = rounds
+        merged_results = []
+        if all(isinstance(r, np.ndarray) for r in results):
+            merged_results = np.concatenate(results)
+        else:
+            for r in results:
+                merged_results.extend(list(r))
+        return merged_results, lw, dict(rounds=stats[0], group_calls=stats[1], statements=stats[2], seconds=time.time() - t0,
+                                        workers=self.workers)

@@ -2,6 +2,7 @@
 sampling (with or without the inference network), learn_inference_network, save/load_inference_network."""
 import time
 
+import numpy as np
 import torch
 
 from . import state
@@ -108,7 +109,7 @@ class Model:
         return emp
 
     def _traces_coroutines(self, num_traces, observe, map_func=None, seed=0, offset=0, likelihood_importance=1.,
-                           *args, **kwargs):
+                           *args, num_workers=None, **kwargs):
         """Importance sampling with the inference network for a program AS WRITTEN (`while float(s) >= 1:` ...): one
         greenlet per particle, parked at `sample` and served in address-grouped batches (pyprob_amd/coroutine.py).
         Replaces the per-particle loop of pyprob/model.py:59-71. map_func(trace) values like Model._traces; with the
@@ -118,22 +119,44 @@ class Model:
         state._init_traces(func=self.forward, trace_mode=TraceMode.POSTERIOR,
                            inference_engine=InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
                            inference_network=net, observe=observe, likelihood_importance=likelihood_importance)
-        co = CoroutineIS(state, self.forward, net, num_traces, seed=seed, offset=offset,
-                         likelihood_importance=likelihood_importance)
-        state._coroutine = co
-        try:
-            results, lw, traces = co.run(*args, **kwargs)
-        finally:
-            state._coroutine = None
-            state._current_trace = None
-        if map_func is None or map_func is trace_result:
-            values = results
+        # One interpreter runs ~7 k particles/s of a torch-scalar program; large runs shard the particles over forked
+        # worker processes (the parent serves the device): num_workers / PP_IS_WORKERS, default one per 2 000 particles up
+        # to half the host cores.
+        import os
+        if num_workers is None:
+            num_workers = int(os.environ.get('PP_IS_WORKERS', 0)) or min(max(num_traces // 2000, 1),
+                                                                         max((os.cpu_count() or 2) // 2, 1), 64)
+        plain = map_func is None or map_func is trace_result
+        if num_workers > 1:
+            from .coroutine import ShardedCoroutineIS
+            sh = ShardedCoroutineIS(state, self.forward, net, num_traces, num_workers, seed=seed, offset=offset,
+                                    likelihood_importance=likelihood_importance, map_func=None if plain else map_func)
             try:
-                values = torch.stack([torch.as_tensor(r, dtype=torch.float32).reshape(()) for r in results]).to(lw.device)
-            except (RuntimeError, TypeError, ValueError):
-                pass
+                results, lw, cstats = sh.run(*args, **kwargs)
+            finally:
+                state._current_trace = None
+            if plain and isinstance(results, np.ndarray):
+                values = torch.from_numpy(results).to(lw.device)
+            else:
+                values = list(results)
         else:
-            values = [map_func(t) for t in traces]
+            co = CoroutineIS(state, self.forward, net, num_traces, seed=seed, offset=offset,
+                             likelihood_importance=likelihood_importance)
+            state._coroutine = co
+            try:
+                results, lw, traces = co.run(*args, **kwargs)
+            finally:
+                state._coroutine = None
+                state._current_trace = None
+            cstats = dict(rounds=co.rounds, group_calls=co.group_calls, statements=co.statements, seconds=co.seconds, workers=1)
+            if plain:
+                values = results
+                try:
+                    values = torch.stack([torch.as_tensor(r, dtype=torch.float32).reshape(()) for r in results]).to(lw.device)
+                except (RuntimeError, TypeError, ValueError):
+                    pass
+            else:
+                values = [map_func(t) for t in traces]
         if torch.is_tensor(values):
             values, lw = _drop_non_finite(values, lw)
         else:
@@ -145,7 +168,7 @@ class Model:
         emp.finalize()
         if torch.is_tensor(values):
             emp.device_stats = net._is.stats(lw, values)
-        emp.coroutine_stats = dict(rounds=co.rounds, group_calls=co.group_calls, statements=co.statements, seconds=co.seconds)
+        emp.coroutine_stats = cstats
         return emp
 
     def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, return_types=False,

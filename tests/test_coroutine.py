@@ -106,3 +106,33 @@ def test_lock_step_run_rescored_by_the_oracle():
     lw_ref, results = rescore_lockstep_run(post, net, meta, params, observe, math.sqrt(2))
     np.testing.assert_allclose(post._all_log_weights.numpy(), lw_ref, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(post._all_values.numpy(), results, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('case,program,observe,sigma', [CASES[1], CASES[2]], ids=['gumm', 'cat'])
+def test_sharded_coroutines_equal_rescored_traces(case, program, observe, sigma):
+    """The particles spread over forked worker processes (the parent serves the operators): the workers' parked
+    statements are merged by (address, previous address) each round; every returned trace re-scores to its log-weight."""
+    net, meta, params, isr = network_from_golden(case)
+    model = program()
+    model._inference_network = net
+    n = 45
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model._traces_coroutines(n, observe, map_func=_identity, seed=5, num_workers=3)
+    traces = post.get_values()
+    assert len(traces) == n and post.coroutine_stats['workers'] == 3
+    lw = post.log_weights_numpy() if hasattr(post, 'log_weights_numpy') else np.asarray(post.log_weights)
+    ref = rescore(case, meta, params, traces, observe, sigma)
+    np.testing.assert_allclose(np.asarray(lw, np.float64), ref, rtol=2e-5, atol=2e-5)
+    st = post.coroutine_stats
+    assert st['statements'] == sum(len(t.variables_controlled) for t in traces)
+    assert st['group_calls'] < st['statements']
+    # plain results come back as one tensor with device statistics
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        p2 = model._traces_coroutines(40, observe, seed=6, num_workers=2)
+    assert p2.length == 40 and np.isfinite(p2.mean) and 'ess' in p2.device_stats
+
+
+def _identity(trace):
+    return trace

@@ -268,3 +268,29 @@ def test_coroutine_run_rescored_by_the_oracle(case):
     np.testing.assert_allclose(lw, ref, rtol=1e-4, atol=2e-4)
     st = post.coroutine_stats
     assert st['statements'] == sum(len(t.variables_controlled) for t in traces)
+
+
+def _identity(trace):
+    return trace
+
+
+def test_sharded_coroutine_run_rescored_by_the_oracle():
+    """Particle shards in forked worker processes, the parent serving the device (pyprob_amd/coroutine.py
+    ShardedCoroutineIS): traces come back from the workers, their device log-weights equal the oracle's re-scoring."""
+    import math
+    import warnings
+    pytest.importorskip('greenlet')
+    from is_helpers import network_from_golden, rescore
+    from models import GaussianWithUnknownMeanMarsaglia
+    net, meta, params, isr = network_from_golden('gumm', 'cuda:0')
+    model = GaussianWithUnknownMeanMarsaglia()
+    model._inference_network = net
+    observe = {'obs0': 8, 'obs1': 9}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model._traces_coroutines(600, observe, map_func=_identity, seed=3, num_workers=4)
+    traces = post.get_values()
+    assert post.coroutine_stats['workers'] == 4 and len(traces) + (600 - post.length) == 600
+    lw = np.asarray(post.log_weights_numpy(), np.float64)
+    ref = rescore('gumm', meta, params, traces, observe, math.sqrt(2))
+    np.testing.assert_allclose(lw, ref, rtol=1e-4, atol=2e-4)
