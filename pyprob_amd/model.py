@@ -119,13 +119,14 @@ class Model:
         state._init_traces(func=self.forward, trace_mode=TraceMode.POSTERIOR,
                            inference_engine=InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
                            inference_network=net, observe=observe, likelihood_importance=likelihood_importance)
-        # One interpreter runs ~7 k particles/s of a torch-scalar program; large runs shard the particles over forked
-        # worker processes (the parent serves the device): num_workers / PP_IS_WORKERS, default one per 2 000 particles up
-        # to half the host cores.
+        # One interpreter runs ~7-11 k particles/s of a torch-scalar program; large runs shard the particles over forked
+        # worker processes (the parent serves the device): num_workers / PP_IS_WORKERS, default one per 5 000 particles up
+        # to 32 (forking a process that holds a device context costs ~40 ms: 64 workers were slower than 16 at 200 k
+        # particles, profiles/r02_m_is_executors.log).
         import os
         if num_workers is None:
-            num_workers = int(os.environ.get('PP_IS_WORKERS', 0)) or min(max(num_traces // 2000, 1),
-                                                                         max((os.cpu_count() or 2) // 2, 1), 64)
+            num_workers = int(os.environ.get('PP_IS_WORKERS', 0)) or min(max(num_traces // 5000, 1),
+                                                                         max((os.cpu_count() or 2) // 2, 1), 32)
         plain = map_func is None or map_func is trace_result
         if num_workers > 1:
             from .coroutine import ShardedCoroutineIS

@@ -47,7 +47,7 @@ for rep in range(2):
     st = post.coroutine_stats
     print('coroutines: %d particles in %.2f s -> %.0f particles/s (%d rounds, %d group calls, %d statements); mean %.3f ESS %.0f' % (
         nc, t1 - t0, nc / (t1 - t0), st['rounds'], st['group_calls'], st['statements'], post.mean, post.effective_sample_size))
-for workers in (16, 64):
+for workers in (16, 32):
     big = int(sys.argv[3]) if len(sys.argv) > 3 else 200000
     t0 = time.perf_counter()
     post = ref_style.posterior_results(big, IC, observe=obs, lock_step=False, seed=3, num_workers=workers)
