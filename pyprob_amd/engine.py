@@ -326,12 +326,27 @@ class ICEngine:
         if not self.dp_skip:
             allreduce_flat_(self.grads_full)
             return
-        pos = 0
+        # the pieces around the skipped ranges are staged into ONE contiguous buffer: one collective (a second one costs
+        # a full latency on 8 ranks; the four ~1 MB device copies cost ~10 us)
+        pieces, pos = [], 0
         for off, cnt in self.dp_skip:
             if off > pos:
-                allreduce_flat_(self.grads_full[pos:off])
+                pieces.append((pos, off))
             pos = off + cnt
-        allreduce_flat_(self.grads_full[pos:])
+        pieces.append((pos, self.grads_full.numel()))
+        total = sum(b - a for a, b in pieces)
+        stage = getattr(self, '_dp_stage', None)
+        if stage is None or stage.numel() != total:
+            stage = self._dp_stage = torch.empty(total, dtype=torch.float32, device=self.device)
+        o = 0
+        for a, b in pieces:
+            stage[o:o + b - a].copy_(self.grads_full[a:b])
+            o += b - a
+        allreduce_flat_(stage)
+        o = 0
+        for a, b in pieces:
+            self.grads_full[a:b].copy_(stage[o:o + b - a])
+            o += b - a
 
     def reduced_status(self):
         """The all-reduced non-finite flag as the int32 word pp_adam_step's `skip` reads: a sum of 0.0 / 1.0 floats is
