@@ -212,8 +212,11 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params /*d
  *   tensor_step   dev [n_tensors]      int32 Adam step count per tensor, incremented here when active
  *   scratch       dev [PP_ADAM_SCRATCH * n_tensors] int32, opaque, owned by the optimizer state: ZERO before the
  *                                      first call and whenever chunk_tensor changes (two-level arrival counters - the
- *                                      last chunk of a tensor to finish advances its step count - and the cached
- *                                      chunk run of each tensor)
+ *                                      last chunk of a tensor to finish advances its step count - the cached
+ *                                      chunk run of each tensor, and word PP_ADAM_SEEN: non-zero once the tensor had a
+ *                                      non-zero gradient. While it is 0 the tensor's moments are taken to be zero and
+ *                                      all-zero gradient chunks are skipped: a caller that writes exp_avg / exp_avg_sq
+ *                                      itself (checkpoint load) sets the word of every tensor to 1)
  *   grad_scale    1/world_size for data-parallel averaging (:324-325), else 1
  *   flags         PP_ADAM_ZERO_GRADS: clear every consumed gradient chunk (optimizer.zero_grad() of the next step,
  *                 inference_network.py:486); the next pp_ic_loss can then run without PP_LOSS_ZERO_GRADS
@@ -223,6 +226,7 @@ int pp_ic_loss(const pp_net* net, const pp_batch* batch, const float* params /*d
  */
 #define PP_ADAM_ZERO_GRADS 1
 #define PP_ADAM_SCRATCH 1056
+#define PP_ADAM_SEEN 1027
 int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_params,
                  const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* scratch,
                  int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,

@@ -116,6 +116,7 @@ class HipAdam(torch.optim.Optimizer):
             eng.tensor(name, eng.exp_avg_sq).copy_(st['exp_avg_sq'].reshape(p.shape))
             steps[names.index(name)] = int(st['step'])
         eng.tensor_step.copy_(steps)
+        eng.moments_written()
         for k, v in state_dict['param_groups'][0].items():
             if k != 'params':
                 self.param_groups[0][k] = v

@@ -1229,6 +1229,12 @@ int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* lo
 // (atomics to one line serialise in its L2 channel whatever the address), then the top counter, first chunk + 1
 // (0 = not cached yet) and the number of chunks. All counters return to zero after every call.
 constexpr int ADAM_TOP = 1024, ADAM_FIRST = 1025, ADAM_CHUNKS = 1026;   // after 32 sub-counters, one per 128-byte line
+// ADAM_SEEN: set once any chunk of the tensor had a non-zero gradient. While it is 0 both moments of the WHOLE tensor are
+// still zero (they start at zero and only a non-zero gradient moves them), so a chunk whose gradient is all zero is a
+// no-op of Adam (m = v = 0 -> update 0; no weight decay) and touches nothing but its gradient chunk: the recurrent
+// weights of a single-statement program (GaussianUnknownMean: dL/dW_hh = 0 forever) are 63 % of the parameters and cost
+// 1/8 of their Adam traffic this way. The host sets the flag when it writes moments itself (checkpoint load).
+constexpr int ADAM_SEEN = 1027;
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float* __restrict__ Gr, float* __restrict__ M,
                                                    float* __restrict__ V, const int32_t* __restrict__ chunk_tensor,
@@ -1250,10 +1256,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     int32_t* const sc = scratch + (int64_t)t * PP_ADAM_SCRATCH;
     // the chunk's loads are issued before thread 0 walks its dependent chain (step count, corrections)
     const int64_t o = (int64_t)b * 1024 + threadIdx.x * 4;
-    f32x4 p = *reinterpret_cast<f32x4*>(P + o);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gr + o);
-    f32x4 m = *reinterpret_cast<f32x4*>(M + o);
-    f32x4 v = *reinterpret_cast<f32x4*>(V + o);
+    // a tensor that never had a non-zero gradient: wait for the gradient chunk first; all zero -> nothing else is read
+    const bool seen = __atomic_load_n(sc + ADAM_SEEN, __ATOMIC_RELAXED) != 0;   // workgroup-uniform
+    bool idle = false;
+    if (!seen && wd == 0.0f) {
+        const bool zero = g0[0] == 0.0f && g0[1] == 0.0f && g0[2] == 0.0f && g0[3] == 0.0f;
+        idle = __syncthreads_and(zero ? 1 : 0) != 0;
+        if (!idle && threadIdx.x == 0) __atomic_store_n(sc + ADAM_SEEN, 1, __ATOMIC_RELAXED);
+    } else if (!seen && threadIdx.x == 0) {
+        __atomic_store_n(sc + ADAM_SEEN, 1, __ATOMIC_RELAXED);
+    }
+    f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f}, m = p, v = p;
+    if (!idle) {
+        p = *reinterpret_cast<f32x4*>(P + o);
+        m = *reinterpret_cast<f32x4*>(M + o);
+        v = *reinterpret_cast<f32x4*>(V + o);
+    }
     int step_old = 0, first = 0, chunks = 0;
     if (threadIdx.x == 0) {
         first = __atomic_load_n(sc + ADAM_FIRST, __ATOMIC_RELAXED) - 1;
@@ -1298,19 +1317,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     const int quota = (chunks - k + 31) >> 5;               // chunks of the tensor that share it
     int ticket = -1;
     if (threadIdx.x == 0) ticket = atomicAdd(sc + 32 * k, 1);
+    if (!idle) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float g = g0[e] * gscale;
-        if (wd != 0.0f) g += wd * p[e];
-        m[e] = beta1 * m[e] + (1.0f - beta1) * g;
-        v[e] = beta2 * v[e] + (1.0f - beta2) * g * g;
-        const float denom = sqrtf(v[e]) * inv_sqrt_bc2 + eps;
-        p[e] -= step_size * (m[e] / denom);
+        for (int e = 0; e < 4; ++e) {
+            float g = g0[e] * gscale;
+            if (wd != 0.0f) g += wd * p[e];
+            m[e] = beta1 * m[e] + (1.0f - beta1) * g;
+            v[e] = beta2 * v[e] + (1.0f - beta2) * g * g;
+            const float denom = sqrtf(v[e]) * inv_sqrt_bc2 + eps;
+            p[e] -= step_size * (m[e] / denom);
+        }
+        *reinterpret_cast<f32x4*>(P + o) = p;
+        *reinterpret_cast<f32x4*>(M + o) = m;
+        *reinterpret_cast<f32x4*>(V + o) = v;
+        if (zero_grads) *reinterpret_cast<f32x4*>(Gr + o) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    *reinterpret_cast<f32x4*>(P + o) = p;
-    *reinterpret_cast<f32x4*>(M + o) = m;
-    *reinterpret_cast<f32x4*>(V + o) = v;
-    if (zero_grads) *reinterpret_cast<f32x4*>(Gr + o) = f32x4{0.f, 0.f, 0.f, 0.f};
     if (threadIdx.x == 0 && ticket == quota - 1) {
         __atomic_store_n(sc + 32 * k, 0, __ATOMIC_RELAXED);
         if (atomicAdd(sc + ADAM_TOP, 1) == min(chunks, 32) - 1) {   // last chunk of the tensor

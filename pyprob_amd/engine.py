@@ -374,3 +374,9 @@ class ICEngine:
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         self.tensor_step.zero_()
+        self.arrived.view(-1, L.PP_ADAM_SCRATCH)[:, L.PP_ADAM_SEEN] = 0     # moments are zero again (pp_adam_step)
+
+    def moments_written(self):
+        """The caller filled exp_avg / exp_avg_sq itself (checkpoint load): pp_adam_step must not assume zero moments for
+        tensors that have not seen a gradient in THIS process (PP_ADAM_SEEN, include/pyprob_amd.h)."""
+        self.arrived.view(-1, L.PP_ADAM_SCRATCH)[:, L.PP_ADAM_SEEN] = 1

@@ -15,6 +15,7 @@ PP_HEAD_BERNOULLI = 4
 PP_LOSS_BACKWARD, PP_LOSS_ZERO_GRADS, PP_LOSS_KEEP_LP = 1, 2, 4
 PP_ADAM_ZERO_GRADS = 1
 PP_ADAM_SCRATCH = 1056          # int32 per tensor (include/pyprob_amd.h)
+PP_ADAM_SEEN = 1027
 PP_IS_STATS_SCRATCH = 1536   # doubles (include/pyprob_amd.h)
 
 i32, i64, f32p, i32p, vp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p

@@ -706,6 +706,7 @@ class InferenceNetworkLSTM:
         net._engine.exp_avg.copy_(d['exp_avg'])
         net._engine.exp_avg_sq.copy_(d['exp_avg_sq'])
         net._engine.tensor_step.copy_(d['tensor_step'])
+        net._engine.moments_written()
         net._total_train_traces = d['total_train_traces']
         net._total_train_iterations = d['total_train_iterations']
         for k, v in d.get('train_state', {}).items():      # (files written before the training state was persisted lack it)

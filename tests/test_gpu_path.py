@@ -455,3 +455,33 @@ def test_gum_posterior_statistics_after_training():
     assert abs(res['mean'] - 7.25) < 0.75
     assert abs(res['std'] - np.sqrt(1 / 1.2)) < 0.75
     assert res['ess'] > 0.15 * 50000
+
+
+def test_adam_skips_untouched_zero_gradient_tensors_exactly():
+    """A tensor that is 'present' with an all-zero gradient and has never had a non-zero one (W_hh of a single-statement
+    program): Adam's update is exactly zero - the kernel reads its gradient chunks only - but its step count advances like
+    torch's. Once a non-zero gradient arrives, or moments are loaded from a checkpoint, it takes the full path."""
+    from pyprob_amd import lib as L
+    meta, params, batch, loss, isr = load_golden('gum')
+    eng = engine_from_golden(meta, params)
+    pb = packed_from_golden(meta, batch, eng.spec).to(eng.device)
+    names = list(eng.spec.tensors.keys())
+    k = names.index('_layers_lstm.weight_hh_l0')
+    before = eng.tensor('_layers_lstm.weight_hh_l0').clone()
+    for _ in range(2):
+        eng.train_step(pb, lr=1e-2)
+    seen = eng.arrived.view(-1, L.PP_ADAM_SCRATCH)[:, L.PP_ADAM_SEEN].cpu().numpy()
+    assert seen[k] == 0 and seen[names.index('_layers_lstm.weight_ih_l0')] == 1
+    assert torch.equal(eng.tensor('_layers_lstm.weight_hh_l0'), before)
+    assert int(eng.tensor_step[k]) == 2
+    assert float(eng.tensor('_layers_lstm.weight_hh_l0', eng.exp_avg).abs().max()) == 0.0
+    # loaded moments: the flag is raised and the zero-gradient step applies them (m decays, the weight moves)
+    eng.tensor('_layers_lstm.weight_hh_l0', eng.exp_avg).fill_(0.5)
+    eng.tensor('_layers_lstm.weight_hh_l0', eng.exp_avg_sq).fill_(0.25)
+    eng.moments_written()
+    eng.train_step(pb, lr=1e-2)
+    m = eng.tensor('_layers_lstm.weight_hh_l0', eng.exp_avg)
+    assert abs(float(m.max()) - 0.45) < 1e-6 and not torch.equal(eng.tensor('_layers_lstm.weight_hh_l0'), before)
+    step = 3
+    want = before.cpu().numpy().astype(np.float64) - (1e-2 / (1 - 0.9 ** step)) * 0.45 / (np.sqrt(0.25 * 0.999) / np.sqrt(1 - 0.999 ** step) + 1e-8)
+    np.testing.assert_allclose(eng.tensor('_layers_lstm.weight_hh_l0').cpu().numpy(), want, rtol=1e-5, atol=1e-6)
