@@ -97,11 +97,13 @@ def test_benchmark_size_gum_against_oracle(H):
         assert rel_err(g[n], out['grads'][n]) < 2e-3 or np.abs(out['grads'][n]).max() < 1e-7, n
 
 
-def test_hidden_1024_against_oracle():
-    """config 5 network (LSTM hidden 1024, 5 636 415 parameters; head hidden 527 -> 3 float4 groups per lane)."""
+@pytest.mark.parametrize('B', [300, 1024])
+def test_hidden_1024_against_oracle(B):
+    """config 5 network (LSTM hidden 1024, 5 636 415 parameters; head hidden 527 -> 3 float4 groups per lane), at an odd
+    batch size and at the per-rank shape of config 5 (batch 1024)."""
     eng = _fresh_engine(1024, ['mu'], 'Normal')
     assert eng.spec.num_parameters() == 5636415
-    arrays = synthetic_gum_arrays(300, seed=6)
+    arrays = synthetic_gum_arrays(B, seed=6)
     pb = _packed(arrays, eng.spec).to(eng.device)
     l = eng.loss(pb, backward=True)
     torch.cuda.synchronize()
