@@ -34,9 +34,10 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 4
+#define PP_ABI_VERSION 5
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
+#define PP_MAX_OBS_DEPTH 4
 
 /* error codes (negative; positive values are hipError_t) */
 #define PP_EINVAL   (-1)   /* bad argument (shape, alignment, null pointer) */
@@ -103,6 +104,12 @@ typedef struct pp_net {
     /* _layers_lstm.{weight_ih,weight_hh,bias_ih,bias_hh}_l<k> of every layer; entry 0 repeats w_ih .. b_hh above. Layer
      * k >= 1 reads the hidden states of layer k-1: weight_ih_l<k> is [4H, H] */
     int64_t lstm_w_ih[PP_MAX_LSTM_DEPTH], lstm_w_hh[PP_MAX_LSTM_DEPTH], lstm_b_ih[PP_MAX_LSTM_DEPTH], lstm_b_hh[PP_MAX_LSTM_DEPTH];
+    /* observe embeddings of a depth other than 2 (EmbeddingFeedForward(num_layers = depth), embedding_feedforward.py:22-33,
+     * inference_network.py:110-118): depth 1 = Linear(in, out); depth d >= 2 = Linear(in, hid), (d - 2) x Linear(hid, hid),
+     * Linear(hid, out), ReLU after every layer. obs_depth[o] = 0 is read as 2 (obs_w0 .. obs_b1 above). For other depths
+     * layer l of observable o is obs_w[o][l] / obs_b[o][l] (_layers_observe_embedding.<name>._layers.<l>). */
+    int32_t obs_depth[PP_MAX_OBS];
+    int64_t obs_w[PP_MAX_OBS][PP_MAX_OBS_DEPTH], obs_b[PP_MAX_OBS][PP_MAX_OBS_DEPTH];
 } pp_net;
 
 /* columns of the device address table */

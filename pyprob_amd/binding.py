@@ -86,10 +86,10 @@ class _HipNetworkMixin:
         obs = {}
         for name, layer in self._layers_observe_embedding.items():
             layers = getattr(layer, '_layers', None)
-            if type(layer).__name__ != 'EmbeddingFeedForward' or layers is None or len(layers) != 2:
-                raise NotImplementedError('the HIP engine embeds observations with ObserveEmbedding.FEEDFORWARD, depth 2 '
-                                          '(observable {}: {})'.format(name, type(layer).__name__))
-            obs[name] = dict(input_dim=int(layer._input_dim), dim=int(layer._output_dim))
+            if type(layer).__name__ != 'EmbeddingFeedForward' or layers is None or not 1 <= len(layers) <= L.PP_MAX_OBS_DEPTH:
+                raise NotImplementedError('the HIP engine embeds observations with ObserveEmbedding.FEEDFORWARD of depth '
+                                          '1..{} (observable {}: {})'.format(L.PP_MAX_OBS_DEPTH, name, type(layer).__name__))
+            obs[name] = dict(input_dim=int(layer._input_dim), dim=int(layer._output_dim), depth=len(layers))
         return obs
 
     def _hip_address_items(self):

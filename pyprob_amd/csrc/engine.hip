@@ -108,7 +108,9 @@ struct Carver {
 
 struct Workspace {
     // forward activations
-    float* obs_h[PP_MAX_OBS];  // [B, round4(obs_hid)]
+    float* obs_h[PP_MAX_OBS];  // [B, round4(obs_hid)] (first hidden layer; depth 2: the only one)
+    float* obs_hl[PP_MAX_OBS][PP_MAX_OBS_DEPTH];   // hidden activations of layer l < depth - 1 (obs_hl[o][0] == obs_h[o])
+    float* dObsH2;             // second [B, maxhid4] scratch of the generic-depth backward
     float* cat;                // [B, e4] concatenated per-observable embeddings
     float* f1;                 // [B, e4] hidden layer of the final observe embedding
     float* E;                  // [B, e4] observe embedding
@@ -157,6 +159,10 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
         w.ohid4[o] = round4(net->obs_hid[o]);
         w.maxohid4 = std::max(w.maxohid4, w.ohid4[o]);
         w.obs_h[o] = c.take<float>((int64_t)B * w.ohid4[o]);
+        const int depth = net->obs_depth[o] ? net->obs_depth[o] : 2;
+        for (int l = 0; l < PP_MAX_OBS_DEPTH; ++l) w.obs_hl[o][l] = nullptr;
+        w.obs_hl[o][0] = w.obs_h[o];
+        for (int l = 1; l + 1 < depth; ++l) w.obs_hl[o][l] = c.take<float>((int64_t)B * w.ohid4[o]);
     }
     w.cat = c.take<float>((int64_t)B * w.e4);
     w.f1 = c.take<float>((int64_t)B * w.e4);
@@ -184,6 +190,7 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.dF1 = c.take<float>((int64_t)B * w.e4);
     w.dCat = c.take<float>((int64_t)B * w.e4);
     w.dObsH = c.take<float>((int64_t)net->n_obs * B * w.maxohid4);
+    w.dObsH2 = c.take<float>((int64_t)B * w.maxohid4);
     // 64 loss accumulator slots, one per 128-byte line (atomics to one line serialise in its L2 channel), then the
     // non-finite flag; cleared by the step's first kernel
     w.loss_acc = c.take<float>(PP_LOSS_SLOTS_FLOATS);
@@ -320,10 +327,21 @@ static int observe_embedding_fwd(const pp_net* net, const float* P, const float*
         return obs_embed_fwd_fused(net, P, obs, B, w.obs_h, w.cat, w.f1, w.E, st);
     int ci = 0, co = 0;
     for (int o = 0; o < net->n_obs; ++o) {
-        PP_TRY(linear_fwd(obs + ci, ldobs, nullptr, P + net->obs_w0[o], P + net->obs_b0[o], w.obs_h[o], w.ohid4[o], B,
-                          net->obs_in[o], net->obs_hid[o], true, nullptr, st));
-        PP_TRY(linear_fwd(w.obs_h[o], w.ohid4[o], nullptr, P + net->obs_w1[o], P + net->obs_b1[o], w.cat + co, w.e4, B,
-                          net->obs_hid[o], net->obs_out[o], true, nullptr, st));
+        // EmbeddingFeedForward(num_layers = depth), ReLU after every layer (embedding_feedforward.py:35-48)
+        const int depth = net->obs_depth[o] ? net->obs_depth[o] : 2;
+        const float* x = obs + ci;
+        int64_t ldx = ldobs;
+        int in = net->obs_in[o];
+        for (int l = 0; l < depth; ++l) {
+            const bool last = l == depth - 1;
+            const int out = last ? net->obs_out[o] : net->obs_hid[o];
+            float* y = last ? w.cat + co : w.obs_hl[o][l];
+            const int64_t ldy = last ? w.e4 : w.ohid4[o];
+            const int64_t wl = net->obs_depth[o] ? net->obs_w[o][l] : (l == 0 ? net->obs_w0[o] : net->obs_w1[o]);
+            const int64_t bl = net->obs_depth[o] ? net->obs_b[o][l] : (l == 0 ? net->obs_b0[o] : net->obs_b1[o]);
+            PP_TRY(linear_fwd(x, ldx, nullptr, P + wl, P + bl, y, ldy, B, in, out, true, nullptr, st));
+            x = y; ldx = ldy; in = out;
+        }
         ci += net->obs_in[o];
         co += net->obs_out[o];
     }
@@ -697,16 +715,29 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     PP_TRY(linear_dgrad(w.dF1, w.e4, P + net->fin_w0, w.dCat, w.e4, nullptr, w.cat, w.e4, B, e, e, false, st));
     int ci = 0, co = 0;
     for (int o = 0; o < net->n_obs; ++o) {
-        const int in = net->obs_in[o], hid = net->obs_hid[o], out = net->obs_out[o];
-        PP_TRY(linear_wgrad(w.dCat + co, w.e4, w.obs_h[o], w.ohid4[o], nullptr, grads + net->obs_w1[o],
-                            grads + net->obs_b1[o], nullptr, B, hid, out, st));
-        PP_TRY(linear_dgrad(w.dCat + co, w.e4, P + net->obs_w1[o], w.dObsH, w.ohid4[o], nullptr, w.obs_h[o], w.ohid4[o], B,
-                            hid, out, false, st, det ? nullptr : grads + net->obs_b0[o]));
-        if (det) PP_TRY(colsum_f32(w.dObsH, w.ohid4[o], nullptr, B, hid, grads + net->obs_b0[o], nullptr, st));
-        PP_TRY(linear_wgrad(w.dObsH, w.ohid4[o], bt->obs + ci, bt->obs_width, nullptr, grads + net->obs_w0[o], nullptr,
-                            nullptr, B, in, hid, st));
-        ci += in;
-        co += out;
+        // backward through EmbeddingFeedForward(num_layers = depth): dz of layer l (ReLU mask already applied) gives
+        // dW_l = dz^T x_l, db_l = colsum dz, and dz of layer l - 1 = (dz W_l) * [x_l > 0]
+        const int depth = net->obs_depth[o] ? net->obs_depth[o] : 2;
+        const float* dz = w.dCat + co;
+        int64_t lddz = w.e4;
+        float* scratch[2] = {w.dObsH, w.dObsH2};
+        for (int l = depth - 1; l >= 0; --l) {
+            const int out = l == depth - 1 ? net->obs_out[o] : net->obs_hid[o];
+            const int in = l == 0 ? net->obs_in[o] : net->obs_hid[o];
+            const float* x = l == 0 ? bt->obs + ci : w.obs_hl[o][l - 1];
+            const int64_t ldx = l == 0 ? bt->obs_width : w.ohid4[o];
+            const int64_t wl = net->obs_depth[o] ? net->obs_w[o][l] : (l == 0 ? net->obs_w0[o] : net->obs_w1[o]);
+            const int64_t bl = net->obs_depth[o] ? net->obs_b[o][l] : (l == 0 ? net->obs_b0[o] : net->obs_b1[o]);
+            PP_TRY(linear_wgrad(dz, lddz, x, ldx, nullptr, grads + wl, grads + bl, nullptr, B, in, out, st));
+            if (l > 0) {
+                float* dprev = scratch[l & 1];
+                PP_TRY(linear_dgrad(dz, lddz, P + wl, dprev, w.ohid4[o], nullptr, x, ldx, B, in, out, false, st));
+                dz = dprev;
+                lddz = w.ohid4[o];
+            }
+        }
+        ci += net->obs_in[o];
+        co += net->obs_out[o];
     }
     return 0;
 }

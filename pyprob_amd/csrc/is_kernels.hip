@@ -394,10 +394,20 @@ int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, v
     int ci = 0, co = 0, width = 0;
     for (int o = 0; o < net->n_obs; ++o) width += net->obs_in[o];
     for (int o = 0; o < net->n_obs; ++o) {
-        PP_TRY(lin(obs + ci, width, P + net->obs_w0[o], P + net->obs_b0[o], nullptr, w.obs_h, w.maxohid4, 1, net->obs_in[o],
-                   net->obs_hid[o], true, false, st));
-        PP_TRY(lin(w.obs_h, w.maxohid4, P + net->obs_w1[o], P + net->obs_b1[o], nullptr, w.cat + co, w.e4, 1, net->obs_hid[o],
-                   net->obs_out[o], true, false, st));
+        // EmbeddingFeedForward(num_layers = depth): the hidden rows ping-pong between two slots of obs_h
+        const int depth = net->obs_depth[o] ? net->obs_depth[o] : 2;
+        const float* x = obs + ci;
+        int64_t ldx = width;
+        int in = net->obs_in[o];
+        for (int l = 0; l < depth; ++l) {
+            const bool last = l == depth - 1;
+            const int out = last ? net->obs_out[o] : net->obs_hid[o];
+            float* y = last ? w.cat + co : w.obs_h + (int64_t)(l & 1) * w.maxohid4;
+            const int64_t wl = net->obs_depth[o] ? net->obs_w[o][l] : (l == 0 ? net->obs_w0[o] : net->obs_w1[o]);
+            const int64_t bl = net->obs_depth[o] ? net->obs_b[o][l] : (l == 0 ? net->obs_b0[o] : net->obs_b1[o]);
+            PP_TRY(lin(x, ldx, P + wl, P + bl, nullptr, y, last ? w.e4 : w.maxohid4, 1, in, out, true, false, st));
+            x = y; ldx = last ? w.e4 : w.maxohid4; in = out;
+        }
         ci += net->obs_in[o];
         co += net->obs_out[o];
     }

@@ -290,6 +290,8 @@ static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
 bool obs_fused_supported(const pp_net* net) {
     if (net->e_obs > OBS_EMAX) return false;
+    for (int o = 0; o < net->n_obs; ++o)
+        if (net->obs_depth[o] != 0 && net->obs_depth[o] != 2) return false;   // other depths: generic GEMM path (engine.hip)
     int hsum = 0;
     for (int o = 0; o < net->n_obs; ++o) {
         if (net->obs_in[o] > OBS_INMAX || net->obs_hid[o] > OBS_HIDMAX || net->obs_hid[o] < 1) return false;

@@ -6,9 +6,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 4
+PP_ABI_VERSION = 5
 PP_MAX_OBS = 8
 PP_MAX_LSTM_DEPTH = 4
+PP_MAX_OBS_DEPTH = 4
 PP_ADDR_TABLE_COLS = 8
 PP_HEAD_NORMAL_MIXTURE, PP_HEAD_TRUNCNORMAL_MIXTURE, PP_HEAD_CATEGORICAL, PP_HEAD_POISSON_TN_MIXTURE = 0, 1, 2, 3
 PP_HEAD_BERNOULLI = 4
@@ -40,7 +41,9 @@ class pp_net(C.Structure):
                 ('addrs', C.POINTER(pp_addr)), ('addr_table', vp), ('n_params', i64),
                 ('lstm_depth', i32), ('_pad2', i32),
                 ('lstm_w_ih', i64 * PP_MAX_LSTM_DEPTH), ('lstm_w_hh', i64 * PP_MAX_LSTM_DEPTH),
-                ('lstm_b_ih', i64 * PP_MAX_LSTM_DEPTH), ('lstm_b_hh', i64 * PP_MAX_LSTM_DEPTH)]
+                ('lstm_b_ih', i64 * PP_MAX_LSTM_DEPTH), ('lstm_b_hh', i64 * PP_MAX_LSTM_DEPTH),
+                ('obs_depth', i32 * PP_MAX_OBS),
+                ('obs_w', (i64 * PP_MAX_OBS_DEPTH) * PP_MAX_OBS), ('obs_b', (i64 * PP_MAX_OBS_DEPTH) * PP_MAX_OBS)]
 
 
 class pp_batch(C.Structure):

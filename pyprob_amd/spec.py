@@ -48,12 +48,15 @@ class NetSpec:
         self.feedforward = network == 'feedforward'
         # observe_embeddings: ordered {name: {'dim': D, 'input_dim': d_in}}  (FEEDFORWARD, depth 2 only)
         self.obs = []
+        self.obs_depth = {}
         for name, v in observe_embeddings.items():
-            if v.get('depth', 2) != 2:
-                raise ValueError('pyprob_amd supports FEEDFORWARD observe embeddings of depth 2 (the default)')
+            depth = int(v.get('depth', 2))          # default 2, inference_network.py:116
+            if not 1 <= depth <= L.PP_MAX_OBS_DEPTH:
+                raise ValueError('observe embedding depth must be 1..%d' % L.PP_MAX_OBS_DEPTH)
             d_in = int(v.get('input_dim', 1))
             d_out = int(v.get('dim', 256))          # default 256, inference_network.py:103
             self.obs.append((name, d_in, int((d_in + d_out) / 2), d_out))
+            self.obs_depth[name] = depth
         if not self.obs:
             raise ValueError('At least one observe embedding is needed to initialize inference network.')
         if len(self.obs) > L.PP_MAX_OBS:
@@ -75,8 +78,8 @@ class NetSpec:
         H, I, e = lstm_dim, self.lstm_in, self.e_obs
         for name, d_in, hid, d_out in self.obs:
             p = '_layers_observe_embedding.%s._layers.' % name
-            self._add(p + '0.weight', (hid, d_in)); self._add(p + '0.bias', (hid,))
-            self._add(p + '1.weight', (d_out, hid)); self._add(p + '1.bias', (d_out,))
+            for l, (rows, cols) in enumerate(self.obs_layer_shapes(name)):      # embedding_feedforward.py:22-33
+                self._add(p + '%d.weight' % l, (rows, cols)); self._add(p + '%d.bias' % l, (rows,))
         p = '_layers_observe_embedding_final._layers.'
         self._add(p + '0.weight', (e, e)); self._add(p + '0.bias', (e,))
         self._add(p + '1.weight', (e, e)); self._add(p + '1.bias', (e,))
@@ -86,6 +89,14 @@ class NetSpec:
                 self._add('_layers_lstm.weight_hh_l%d' % k, (4 * H, H))
                 self._add('_layers_lstm.bias_ih_l%d' % k, (4 * H,)); self._add('_layers_lstm.bias_hh_l%d' % k, (4 * H,))
         self.n_core_tensors = len(self.tensors)
+
+    def obs_layer_shapes(self, name):
+        """[(out, in)] of the Linear layers of observable `name` (EmbeddingFeedForward(num_layers = depth))."""
+        _, d_in, hid, d_out = [o for o in self.obs if o[0] == name][0]
+        depth = self.obs_depth[name]
+        if depth == 1:
+            return [(d_out, d_in)]
+        return [(hid, d_in)] + [(hid, hid)] * (depth - 2) + [(d_out, hid)]
 
     # ---- layout ------------------------------------------------------------------------------------
     def _add(self, name, shape):
@@ -237,8 +248,13 @@ class NetSpec:
         for o, (name, d_in, hid, d_out) in enumerate(self.obs):
             p = '_layers_observe_embedding.%s._layers.' % name
             net.obs_in[o], net.obs_hid[o], net.obs_out[o] = d_in, hid, d_out
-            net.obs_w0[o], net.obs_b0[o] = self.offset(p + '0.weight'), self.offset(p + '0.bias')
-            net.obs_w1[o], net.obs_b1[o] = self.offset(p + '1.weight'), self.offset(p + '1.bias')
+            depth = self.obs_depth[name]
+            net.obs_depth[o] = depth
+            for l in range(depth):
+                net.obs_w[o][l], net.obs_b[o][l] = self.offset(p + '%d.weight' % l), self.offset(p + '%d.bias' % l)
+            if depth == 2:
+                net.obs_w0[o], net.obs_b0[o] = self.offset(p + '0.weight'), self.offset(p + '0.bias')
+                net.obs_w1[o], net.obs_b1[o] = self.offset(p + '1.weight'), self.offset(p + '1.bias')
         net.e_obs, net.smp_dim, net.addr_dim, net.dtype_dim = self.e_obs, self.smp_dim, self.addr_dim, self.dtype_dim
         p = '_layers_observe_embedding_final._layers.'
         net.fin_w0, net.fin_b0 = self.offset(p + '0.weight'), self.offset(p + '0.bias')

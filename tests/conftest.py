@@ -27,6 +27,6 @@ def load_golden(case):
     return meta, params, batch, loss, isr
 
 
-@pytest.fixture(params=['gum', 'gumm', 'cat', 'poi', 'ff', 'ffc', 'ber', 'gumm2'])
+@pytest.fixture(params=['gum', 'gumm', 'cat', 'poi', 'ff', 'ffc', 'ber', 'gumm2', 'gumd'])
 def golden(request):
     return (request.param,) + load_golden(request.param)

@@ -17,6 +17,7 @@ reference is copied: we call its public API and record inputs/outputs:
                           (pyprob/state.py:203-219, pyprob/trace.py:123-125): sampled values, prior log_prob,
                           proposal parameters, proposal log_prob, per-trace log_importance_weight.
 
+Case gumd: the gum program with observe embeddings of depth 3 (obs0) and 1 (obs1).
 Case gumm2: the gumm program with lstm_depth=2 (stacked nn.LSTM layers, lstm_dim=32).
 Cases ff / ffc: the same records for InferenceNetworkFeedForward (pyprob/nn/inference_network_feedforward.py) on the
 gumm / cat programs (no LSTM records). Cases: gum (GaussianUnknownMean, tests/test_inference.py:97-109), gumm (…Marsaglia, :252-275), both with
@@ -167,10 +168,10 @@ def dump_batch(traces, obs_names):
 
 
 def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_particles, observe, network='lstm',
-             lstm_depth=1):
+             lstm_depth=1, obs_emb=None):
     print('=' * 30, case)
     pyprob.seed(123)
-    obs_emb = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
+    obs_emb = obs_emb or {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
     model.learn_inference_network(num_traces=train_traces, batch_size=train_batch,
                                   observe_embeddings=obs_emb,
                                   inference_network=(InferenceNetwork.LSTM if network == 'lstm' else
@@ -244,7 +245,8 @@ def run_case(case, model, lstm_dim, train_traces, train_batch, batch_size, num_p
     meta['lstm_depth'] = lstm_depth
     meta['network'] = network
     meta['mixture_components'] = 10
-    meta['observe_embedding_dims'] = {'obs0': 32, 'obs1': 32}
+    meta['observe_embedding_dims'] = {k: v['dim'] for k, v in obs_emb.items()}
+    meta['observe_embedding_depths'] = {k: v.get('depth', 2) for k, v in obs_emb.items()}
     meta['num_params'] = int(sum(p.numel() for p in net.parameters()))
     meta['python'] = sys.version.split()[0]
     meta['torch'] = torch.__version__
@@ -342,6 +344,11 @@ if __name__ == '__main__':
         # (every proposal scored against every value of the sub-batch step); recorded as the reference computes it.
         torch.distributions.Distribution.set_default_validate_args(False)
         run_case('ber', BernoulliThenNormal(), 64, 1280, 64, 48, 32, {'obs0': 1.2, 'obs1': 0.7})
+        sys.exit(0)
+    if only == 'gumd':
+        # observe embeddings of depth 3 and 1 (EmbeddingFeedForward(num_layers=depth), inference_network.py:110-118)
+        run_case('gumd', GaussianWithUnknownMean(), 32, 1280, 64, 48, 24, obs,
+                 obs_emb={'obs0': {'dim': 32, 'depth': 3}, 'obs1': {'dim': 16, 'depth': 1}})
         sys.exit(0)
     if only == 'gumm2':
         # nn.LSTM(I, H, 2) (learn_inference_network(lstm_depth=2), inference_network_lstm.py:31): stacked layers

@@ -5,7 +5,8 @@ from pyprob_amd.spec import NetSpec
 
 
 def spec_from_golden(meta, params):
-    obs = {n: {'dim': meta['observe_embedding_dims'][n], 'input_dim': 1} for n in meta['obs_names']}
+    depths = meta.get('observe_embedding_depths', {})
+    obs = {n: {'dim': meta['observe_embedding_dims'][n], 'input_dim': 1, 'depth': depths.get(n, 2)} for n in meta['obs_names']}
     spec = NetSpec(obs, lstm_dim=meta['lstm_dim'], proposal_mixture_components=meta['mixture_components'],
                    network=meta.get('network', 'lstm'), lstm_depth=meta.get('lstm_depth', 1))
     pairs = list(zip(meta['addresses'], meta['dist_names']))

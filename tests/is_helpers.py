@@ -23,7 +23,8 @@ def network_from_golden(case, device='cpu'):
     meta, params, batch, loss, isr = load_golden(case)
     spec = spec_from_golden(meta, params)
     cls = InferenceNetworkFeedForward if spec.feedforward else InferenceNetworkLSTM
-    net = cls(observe_embeddings={n: {'dim': meta['observe_embedding_dims'][n]} for n in meta['obs_names']},
+    depths = meta.get('observe_embedding_depths', {})
+    net = cls(observe_embeddings={n: {'dim': meta['observe_embedding_dims'][n], 'depth': depths.get(n, 2)} for n in meta['obs_names']},
               lstm_dim=meta['lstm_dim'] or 512, lstm_depth=meta.get('lstm_depth', 1), device=device)
     net._obs_names = list(meta['obs_names'])
     net._engine = _engine(spec, device)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 # likelihood of the two observations of every golden program (tests/golden/make_golden.py): Normal(result, sigma)
-LIKELIHOOD_STDDEV = {'gum': 2.0 ** 0.5, 'gumm': 2.0 ** 0.5, 'gumm2': 2.0 ** 0.5, 'ff': 2.0 ** 0.5, 'cat': 0.8, 'poi': 0.8, 'ber': 0.8, 'ffc': 0.8}
+LIKELIHOOD_STDDEV = {'gum': 2.0 ** 0.5, 'gumm': 2.0 ** 0.5, 'gumm2': 2.0 ** 0.5, 'gumd': 2.0 ** 0.5, 'ff': 2.0 ** 0.5, 'cat': 0.8, 'poi': 0.8, 'ber': 0.8, 'ffc': 0.8}
 
 
 class _Dist:
