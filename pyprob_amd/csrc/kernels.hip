@@ -1257,8 +1257,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ P, float*
     // the chunk's loads are issued before thread 0 walks its dependent chain (step count, corrections)
     const int64_t o = (int64_t)b * 1024 + threadIdx.x * 4;
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gr + o);
-    // a tensor that never had a non-zero gradient: wait for the gradient chunk first; all zero -> nothing else is read
-    const bool seen = __atomic_load_n(sc + ADAM_SEEN, __ATOMIC_RELAXED) != 0;   // workgroup-uniform
+    // a tensor that never had a non-zero gradient: wait for the gradient chunk first; all zero -> nothing else is read.
+    // ONE thread reads the flag (other workgroups of the tensor may be setting it right now: every thread reading it for
+    // itself could split the workgroup around the barrier below)
+    __shared__ int s_seen;
+    if (threadIdx.x == 0) s_seen = __atomic_load_n(sc + ADAM_SEEN, __ATOMIC_RELAXED);
+    __syncthreads();
+    const bool seen = s_seen != 0;   // workgroup-uniform
     bool idle = false;
     if (!seen && wd == 0.0f) {
         const bool zero = g0[0] == 0.0f && g0[1] == 0.0f && g0[2] == 0.0f && g0[3] == 0.0f;
