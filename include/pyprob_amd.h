@@ -190,7 +190,11 @@ int pp_pack_indexed(const pp_shard_columns* shards, int32_t n_shards, const int6
  * Whole-path entry points
  * ---------------------------------------------------------------------------------------------------- */
 
-/* Bytes of scratch HBM pp_ic_loss needs for a batch of at most n_traces traces / n_rows rows. */
+/* Bytes of scratch HBM pp_ic_loss needs for a batch of at most n_traces traces / n_rows rows.
+ * The workspace must be ZERO-FILLED once when it is allocated and must not be written by the caller afterwards: its
+ * first bytes (a size that depends on the network only) hold the exchange areas of the LSTM tail kernels
+ * (csrc/lstm_tail.hip), whose tagged words must never be mistaken for fresh ones. Everything else in it is scratch
+ * of a single call. */
 size_t pp_ic_workspace_bytes(const pp_net* net, int32_t n_traces, int32_t n_rows);
 
 #define PP_LOSS_BACKWARD   1   /* also write dLoss/dparams into `grads` */

@@ -8,6 +8,7 @@
 #include "../../include/pyprob_amd.h"
 
 #define PP_LOSS_SLOTS_FLOATS (64 * 32 + 32)   /* 64 loss slots at a 128-byte stride + the non-finite flag's line */
+#define PP_TAIL_TEAMS_MAX 16   /* lstm_tail.hip */
 
 namespace pp {
 
@@ -134,6 +135,17 @@ __device__ __forceinline__ void stage_to_lds(float* __restrict__ lds, const floa
             if (i < n) lds[i] = v[u];
         }
     }
+}
+
+struct LossFinalize {   // loss = sum of the 64 accumulator slots / B, status = non-finite flag (see loss_finalize_kernel)
+    const float* acc; const int32_t* flag; float inv_b; float* loss_out; int32_t* status_out;
+};
+__device__ __forceinline__ void loss_finalize_inline(const LossFinalize& fin) {
+    float tot = 0.0f;
+    for (int k = 0; k < 64; ++k) tot += fin.acc[32 * k];
+    const float l = tot * fin.inv_b;
+    fin.loss_out[0] = l;
+    if (fin.status_out) fin.status_out[0] = (fin.flag[0] != 0 || !isfinite(l)) ? 1 : 0;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

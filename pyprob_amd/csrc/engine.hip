@@ -31,6 +31,14 @@ int embedding_rows(const float* E, int64_t lde, const int32_t* trace, int n_rows
 int sample_embed_bwd(const pp_net* net, const float* params, const float* value, const int32_t* addr,
                      const int32_t* prev_row, int row_begin, int n_rows, const float* dX, int64_t ldx, float* grads,
                      hipStream_t st);
+// lstm_tail.hip: the late time steps of a ragged batch in one launch per direction
+int lstm_tail_plan(const int32_t* n_active, int T, int H, int* t0_out, int* teams_out);
+void lstm_tail_exchange_bytes(int H, size_t* fwd, size_t* bwd);
+int lstm_tail_fwd(float* G, float* C, float* Hs, const float* Whh, const int32_t* row_off_dev, int t0, int T, int H, int teams,
+                  void* xch_f, void* xch_b, int32_t* flag, hipStream_t st);
+int lstm_tail_bwd(float* G, const float* C, float* dH, float* dC, const float* Whh, const int32_t* row_off_dev, int t0, int T,
+                  int H, int teams, void* xch_f, void* xch_b, int32_t* flag, float* db, float* db2, const LossFinalize& fin,
+                  hipStream_t st);
 int obs_grad(const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max, int n_traces, int e_obs,
              const float* E, int64_t lde, float* dE, int64_t ldde, hipStream_t st);
 int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st, int c_prev_shared = 0);
@@ -136,6 +144,8 @@ struct Workspace {
     float* dObsH;              // n_obs x [B, maxhid4] (observable o at dObsH + o * B * maxhid4)
     float* loss_acc;           // [1]
     int32_t* flag;             // [1]
+    void* xch_f;               // granule exchange areas of the LSTM tail kernels: at the START of the workspace (a fixed
+    void* xch_b;               // place whatever the batch size), zero when the workspace was allocated (see the header)
     float* lp_rows;            // [R] per-row proposal log_prob (deterministic mode: the loss is reduced from it)
     int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
     size_t bytes;
@@ -145,6 +155,12 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     Carver c(p, cap);
     const bool ff = net->lstm_dim == 0;   // FeedForward network: no LSTM buffers, the heads read rows of width e_obs
     const int H = ff ? net->e_obs : net->lstm_dim;
+    {   // first, so that their place does not depend on (B, R): the tail kernels' tags outlive a call
+        size_t fb = 0, bb = 0;
+        if (!ff) lstm_tail_exchange_bytes(H, &fb, &bb);
+        w.xch_f = c.take<char>((int64_t)fb);
+        w.xch_b = c.take<char>((int64_t)bb);
+    }
     w.e4 = round4(net->e_obs);
     w.i4 = round4(net->lstm_in);
     int64_t hid = 1, out = 1;
@@ -382,6 +398,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // First kernel: observe embedding; for small embeddings the same launch assembles the LSTM input rows of its traces
     // and clears the loss slots and (backward) dX. Otherwise embedding GEMMs + the stand-alone gather kernel.
     const bool fused_obs = obs_fused_supported(net);
+    // ragged batches: the time steps t >= tail_t0 (few rows each) of every LSTM layer run in one launch per direction
+    int tail_t0 = T, tail_teams = 0;
+    if (!ff) lstm_tail_plan(bt->n_active, T, H, &tail_t0, &tail_teams);
+    const int n_clear = PP_LOSS_SLOTS_FLOATS;
     const float* heads_in = w.Hs;     // input rows of the proposal layers: LSTM outputs, or observe embeddings (FF)
     int64_t heads_ld = H;
     // kernel class 2 of the in-stream timing: observe embedding + LSTM input rows (the gather path). Algorithmic bytes:
@@ -399,7 +419,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         if (fused_obs) {
             RowBuild rb{};
             rb.zero_small = in_place ? reinterpret_cast<float*>(w.loss_acc) : nullptr;
-            rb.n_small = PP_LOSS_SLOTS_FLOATS;
+            rb.n_small = n_clear;
             PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb));
         } else {
             PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
@@ -409,7 +429,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             heads_ld = w.e4;
         } else {
             PP_TRY(embedding_rows(w.E, w.e4, bt->trace, R, net->e_obs, w.Hs, H, reinterpret_cast<float*>(w.loss_acc),
-                                  PP_LOSS_SLOTS_FLOATS, st));
+                                  n_clear, st));
         }
     } else if (fused_obs && T <= 2) {   // (long traces: a wave would write all rows of its trace serially - separate gather)
         RowBuild rb{};
@@ -418,13 +438,13 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         rb.value = bt->value; rb.addr = bt->addr; rb.prev_row = bt->prev_row;
         rb.X = w.X; rb.ldx = w.i4;
         rb.zero_like = bwd ? w.dX : nullptr;
-        rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = PP_LOSS_SLOTS_FLOATS;
+        rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = n_clear;
         PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb));
     } else {
         PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
         // (also clears the loss slots and, for a backward pass, dX: see the kernel)
         PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
-                                 bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), PP_LOSS_SLOTS_FLOATS));
+                                 bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), n_clear));
     }
     prof_end(2, gather_bytes, st);
     // nn.LSTM(I, H, depth), inference_network_lstm.py:31,186-188: layer k reads the hidden states of layer k - 1
@@ -449,6 +469,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                           &zero));
         if (l == 0) prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
         for (int t = 0; t < T; ++t) {
+            if (tail_teams && t == tail_t0) {   // all remaining time steps of this layer: one launch (lstm_tail.hip)
+                PP_TRY(lstm_tail_fwd(w.Gl[l], w.Cl[l], w.Hl[l], P + lw_hh(l), bt->row_off_dev, tail_t0, T, H, tail_teams,
+                                     w.xch_f, w.xch_b, w.flag, st));
+                break;
+            }
             const int n = bt->n_active[t], r0 = bt->row_off[t];
             float* Gt = w.Gl[l] + (int64_t)r0 * 4 * H;
             const float* c_prev = nullptr;
@@ -595,11 +620,20 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     float* dH_other = w.dH2;
     for (int l = L - 1; l >= 0; --l) {
         for (int t = T - 1; t >= 0; --t) {
+            if (tail_teams && t >= tail_t0) {   // steps T-1 .. tail_t0 in one launch; it leaves dh / dc of step tail_t0 - 1
+                const LossFinalize fin{l == L - 1 ? fin_acc : nullptr, w.flag, B > 0 ? 1.0f / (float)B : 0.0f, loss_out, status_out};
+                PP_TRY(lstm_tail_bwd(w.Gl[l], w.Cl[l], dH_cur, w.dC, P + lw_hh(l), bt->row_off_dev, tail_t0, T, H, tail_teams,
+                                     w.xch_f, w.xch_b, w.flag, det ? nullptr : grads + lb_ih(l), det ? nullptr : grads + lb_hh(l),
+                                     fin, st));
+                t = tail_t0;
+                continue;
+            }
             const int n = bt->n_active[t], r0 = bt->row_off[t];
             const int n_next = (t + 1 < T) ? bt->n_active[t + 1] : 0;
             float* Gt = w.Gl[l] + (int64_t)r0 * 4 * H;
             const float* c_prev = t > 0 ? w.Cl[l] + (int64_t)bt->row_off[t - 1] * H : nullptr;
-            const bool fin = l == L - 1 && t == T - 1;   // the backward pass's first cell launch folds the loss slots
+            // the backward pass's first cell launch folds the loss slots (the tail launch when there is one)
+            const bool fin = l == L - 1 && t == T - 1;
             PP_TRY(lstm_cell_bwd(Gt, c_prev, w.Cl[l] + (int64_t)r0 * H, dH_cur + (int64_t)r0 * H, w.dC, n, n_next, H,
                                  det ? nullptr : grads + lb_ih(l), det ? nullptr : grads + lb_hh(l), st,
                                  fin ? fin_acc : nullptr, w.flag, B, loss_out, status_out));   // bias gradients fused

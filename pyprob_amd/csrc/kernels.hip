@@ -28,7 +28,7 @@ const char* last_error() { return g_err; }
 // 256 threads = 64 columns x 4 row lanes; each workgroup reduces ROWS_PER_BLOCK rows, one atomic per column.
 // ------------------------------------------------------------------------------------------------------
 constexpr int COLSUM_ROWS = 64;
-constexpr int COLSUM_MAX_JOBS = 16;
+constexpr int COLSUM_MAX_JOBS = 48;   // (48 x 72 bytes: the by-value kernel arguments stay under 4 KB; 16 made 5 launches of a 12-address step)
 
 struct ColsumJob {
     const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
@@ -38,16 +38,6 @@ struct ColsumJobs {
     ColsumJob j[COLSUM_MAX_JOBS];
 };
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out, hipStream_t st);
-struct LossFinalize {   // loss = sum of the 64 accumulator slots / B, status = non-finite flag (see loss_finalize_kernel)
-    const float* acc; const int32_t* flag; float inv_b; float* loss_out; int32_t* status_out;
-};
-__device__ __forceinline__ void loss_finalize_inline(const LossFinalize& fin) {
-    float tot = 0.0f;
-    for (int k = 0; k < 64; ++k) tot += fin.acc[32 * k];
-    const float l = tot * fin.inv_b;
-    fin.loss_out[0] = l;
-    if (fin.status_out) fin.status_out[0] = (fin.flag[0] != 0 || !isfinite(l)) ? 1 : 0;
-}
 
 // blockIdx.z selects the job: several independent column reductions (bias / embedding-table gradients) per launch
 __global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs, const LossFinalize fin) {

@@ -91,7 +91,7 @@ class ICEngine:
         need = self.lib.pp_ic_workspace_bytes(C.byref(self.net), bt, br)
         if need == 0:
             raise RuntimeError('pp_ic_workspace_bytes failed: %s' % self.lib.pp_last_error().decode())
-        self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)     # (zero-filled: the header's contract)
         self.ws_bytes = need
         self.ws_shape = (bt, br)
 

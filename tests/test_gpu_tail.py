@@ -1,0 +1,112 @@
+"""LSTM tail kernels (csrc/lstm_tail.hip: all late time steps of a ragged batch in one launch per direction, slots of a
+team exchanging h_t / dG_t through memory inside the launch): same numbers as the per-step path and as the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (name, lstm_dim, lstm_depth, batch, max Marsaglia iterations): a team takes 8 rows per step, so the tail starts at the
+# first step with <= teams * 8 traces left - at step 1 for the small batches (the whole recurrence in the two launches)
+CASES = (('h512', 512, 1, 1024, 6), ('h512_small', 512, 1, 40, 5), ('h256_d2', 256, 2, 300, 5), ('h1024', 1024, 1, 64, 4))
+
+SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(repo)r); sys.path.insert(0, %(repo)r + '/tests')
+from helpers import synthetic_gumm_arrays
+from pyprob_amd.engine import ICEngine
+from pyprob_amd.packed import PackedBatch
+from pyprob_amd.spec import NetSpec
+out = {}
+for name, H, depth, B, iters in %(cases)r:
+    arrs = [synthetic_gumm_arrays(B, seed=11 + s, max_iter=iters) for s in range(4)]
+    addresses = arrs[0][1]
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=H, lstm_depth=depth)
+    for a in addresses: spec.add_address(a, 'Uniform')
+    eng = ICEngine(spec, device='cuda:0', seed=5)
+    def packed(arr, ad):
+        ids = np.array([spec.address_id[ad[j]] for j in arr['addr_idx']])
+        return PackedBatch.from_ragged(arr['trace_len'], ids, arr['values'], arr['prior'], arr['obs'], len(spec.addresses)).to(eng.device)
+    pbs = [packed(*x) for x in arrs]
+    l, lp = eng.loss(pbs[0], backward=True, keep_lp=True)
+    torch.cuda.synchronize()
+    out[name + '_loss'] = l.cpu().numpy(); out[name + '_lp'] = lp.cpu().numpy(); out[name + '_grads'] = eng.grads.cpu().numpy()
+    out[name + '_tmax'] = np.array([pbs[0].t_max]); out[name + '_nact'] = np.asarray(pbs[0].n_active)
+    # the same buffers again and again with other minibatches and moving parameters: a stale line anywhere in the in-launch
+    # hand-offs (h_t / dG_t of the previous step at the same addresses) would show up here
+    losses = []
+    for it in range(12):
+        losses.append(float(eng.train_step(pbs[it %% 4], lr=1e-3)))
+    torch.cuda.synchronize()
+    out[name + '_losses'] = np.array(losses); out[name + '_params'] = eng.params.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def _run(tmp_path, tag, **env):
+    f = str(tmp_path / (tag + '.npz'))
+    e = dict(os.environ, PP_DETERMINISTIC='0', **env)
+    subprocess.run([sys.executable, '-c', SCRIPT % dict(repo=REPO, cases=CASES), f], check=True, env=e, timeout=900)
+    return dict(np.load(f))
+
+
+def test_tail_kernels_equal_the_per_step_path(tmp_path):
+    tail = _run(tmp_path, 'tail', PP_LSTM_TAIL='1')
+    plain = _run(tmp_path, 'plain', PP_LSTM_TAIL='0')
+    for name, H, depth, B, iters in CASES:
+        nact = tail[name + '_nact']
+        assert int(tail[name + '_tmax'][0]) >= 4 and nact[-1] <= 8, (name, nact)   # the case does reach the tail path
+        assert abs(float(tail[name + '_loss'][0]) - float(plain[name + '_loss'][0])) <= 2e-6 * abs(float(plain[name + '_loss'][0])), name
+        np.testing.assert_allclose(tail[name + '_lp'], plain[name + '_lp'], rtol=2e-5, atol=2e-5, err_msg=name)
+        a, b = tail[name + '_grads'], plain[name + '_grads']
+        assert rel_err(a, b) < 2e-4, (name, rel_err(a, b))
+        n = (a.size // 1024) * 1024
+        a2, b2 = a[:n].reshape(-1, 1024), b[:n].reshape(-1, 1024)
+        scale = np.abs(b2).max(1) + 1e-12
+        big = scale > 1e-6
+        assert (np.abs(a2 - b2).max(1)[big] / scale[big]).max() < 1e-3, name
+        # twelve training steps later: same losses, same parameters
+        np.testing.assert_allclose(tail[name + '_losses'], plain[name + '_losses'], rtol=2e-4, err_msg=name)
+        assert np.isfinite(tail[name + '_losses']).all()
+        # (per element Adam turns the last-bit noise of a ~0 gradient into a step of +-lr: compare in the L2 sense)
+        pa, pb_ = tail[name + '_params'].astype(np.float64), plain[name + '_params'].astype(np.float64)
+        assert np.linalg.norm(pa - pb_) < 1e-2 * np.linalg.norm(pb_), name
+
+
+def test_tail_path_against_the_oracle():
+    """Ragged GUMM batch, hidden 256, two LSTM layers, 300 traces: loss, per-row log_prob and every gradient against the numpy
+    oracle with the tail kernels active (default)."""
+    from helpers import synthetic_gumm_arrays
+    import oracle.ic_oracle as O
+    from pyprob_amd.engine import ICEngine
+    from pyprob_amd.packed import PackedBatch
+    from pyprob_amd.spec import NetSpec
+    assert os.environ.get('PP_LSTM_TAIL', '1') != '0'
+    arrays, addresses = synthetic_gumm_arrays(300, seed=21, max_iter=5)
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=256, lstm_depth=2)
+    for a in addresses:
+        spec.add_address(a, 'Uniform')
+    eng = ICEngine(spec, device='cuda:0', seed=2)
+    pb = PackedBatch.from_ragged(arrays['trace_len'], arrays['addr_idx'], arrays['values'], arrays['prior'], arrays['obs'],
+                                 len(spec.addresses)).to(eng.device)
+    assert pb.t_max >= 4
+    l = eng.loss(pb, backward=True)
+    torch.cuda.synchronize()
+    params = {k: v.numpy() for k, v in eng.state_dict().items()}
+    net = O.Net(params, [o[0] for o in spec.obs], K=spec.K)
+    out = O.loss_and_grads(net, arrays, addresses, ['Uniform'] * len(addresses))
+    assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
+    g = eng.grad_dict()
+    bad = []
+    for n in spec.tensors:
+        scale = np.abs(out['grads'][n]).max()
+        if scale > 1e-7 and rel_err(g[n], out['grads'][n]) > 3e-3:
+            bad.append((n, rel_err(g[n], out['grads'][n])))
+    assert not bad, bad[:5]

@@ -22,5 +22,26 @@ def main(db, out, steps=None):
     print('wrote', out, 'kernels', len(rows), 'total_ms', total / 1e6)
 
 
+def sequence(db, out, marker='adam_kernel', which=-3):
+    """The kernels of ONE step in launch order (between two launches of `marker`, the `which`-th interval), with start offsets."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, grid_x, workgroup_x, start, end from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    a, b = marks[which - 1], marks[which]
+    t0 = rows[a + 1][3]
+    with open(out, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['start_us', 'duration_us', 'gap_before_us', 'workgroups', 'kernel'])
+        prev_end = rows[a][4]
+        for r in rows[a + 1:b + 1]:
+            w.writerow([round((r[3] - t0) / 1e3, 2), round((r[4] - r[3]) / 1e3, 2), round((r[3] - prev_end) / 1e3, 2),
+                        r[1] // max(r[2], 1), r[0].split('(')[0][:70]])
+            prev_end = r[4]
+    print(open(out).read())
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == 'sequence':
+        sequence(sys.argv[1], sys.argv[2])
+    else:
+        main(sys.argv[1], sys.argv[2])
