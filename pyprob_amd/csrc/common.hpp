@@ -62,13 +62,32 @@ static inline bool deterministic_mode() {
     return on != 0;
 }
 
+// Epilogue extensions of the tile kernels that the C ABI does not expose (engine.hip builds them):
+//   * rb: per-row address bias of the LSTM input product (gather.hpp, AddrBias): row m gets
+//     rb[(2 addr[m]) N + n] + (prev[m] >= 0 ? rb[(2 addr[prev[m]] + 1) N + n] : 0); async 64x64 tile only;
+//   * cell_H > 0: the product's 64-column tiles are gate-interleaved (tile bx = hidden units [16 bx, 16 bx + 16) of all
+//     four gates) and rows < cell_rows (first time steps: c_prev = 0) get the LSTM cell applied in the epilogue:
+//     gate activations -> C, cell state -> cell_c, hidden state -> cell_h (what lstm_cell_fwd would have done);
+//   * bw_G: the product is dH = dZ1 W1 of a batch of single-statement traces; its epilogue (direct 32x32 tile) runs the
+//     LSTM cell backward on the tile instead of storing dH: gates in bw_G -> dG in place, column sums of dG added to the
+//     problem's `colsum` pointer (4 bw_H wide: the per-address group sums of gather.hpp).
+struct GemmExt {
+    const float* rb; const int32_t* rb_addr; const int32_t* rb_prev;
+    float* cell_c; float* cell_h; int cell_H, cell_rows;
+    float* bw_G; const float* bw_C; int bw_H;
+};
+struct AuxJobs;
+
 // engine.hip: in-stream kernel timing (pp_prof_arm / pp_prof_collect)
 void prof_begin(int which, hipStream_t st);
 void prof_end(int which, double work, hipStream_t st);
 
 // gemm_f32.hip
-int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole = nullptr);
-int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes = nullptr);
+int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole = nullptr, const GemmExt* ext = nullptr);
+// aux: small reduction jobs (aux_jobs.hpp) that ride behind the tiles of the group's first launch
+int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes = nullptr,
+                     const GemmExt* ext = nullptr, const AuxJobs* aux = nullptr);
+int aux_jobs_launch(const AuxJobs& jobs, hipStream_t st);   // kernels.hip: the same jobs as their own launch
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

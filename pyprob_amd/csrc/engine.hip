@@ -2,6 +2,7 @@
 // the step-major packed trace batch. No allocation, no host synchronisation: every launch goes to the caller's stream.
 #include "common.hpp"
 #include "gather.hpp"
+#include "aux_jobs.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -13,19 +14,11 @@ namespace pp {
 
 // kernels.hip / gemm_f32.hip
 const char* last_error();
-struct ColsumJob {
-    const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
-    const float* wgt; int64_t ldw; int out_stride;   // optional per-row weight (kernels.hip)
-};
 int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st, const float* fin_acc = nullptr,
                  const int32_t* fin_flag = nullptr, int fin_traces = 0, float* fin_loss = nullptr,
                  int32_t* fin_status = nullptr);
 int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
                hipStream_t st);
-int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
-                      const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
-                      int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st, float* zero_like = nullptr,
-                      float* zero_small = nullptr, int n_small = 0);
 int embedding_rows(const float* E, int64_t lde, const int32_t* trace, int n_rows, int e_obs, float* Hs, int64_t ldh,
                    float* zero_small, int n_small, hipStream_t st);
 int sample_embed_bwd(const pp_net* net, const float* params, const float* value, const int32_t* addr,
@@ -71,8 +64,6 @@ extern long long* g_timeline;   // kernels.hip
 
 // obs_embed.hip
 bool obs_fused_supported(const pp_net* net);
-int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
-                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows = nullptr);
 int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
                           const float* f1, const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max,
                           const float* E, float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
@@ -147,9 +138,27 @@ struct Workspace {
     void* xch_f;               // granule exchange areas of the LSTM tail kernels: at the START of the workspace (a fixed
     void* xch_b;               // place whatever the batch size), zero when the workspace was allocated (see the header)
     float* lp_rows;            // [R] per-row proposal log_prob (deterministic mode: the loss is reduced from it)
+    float* AB;                 // [n_addr][2][4H] per-address bias vectors of the LSTM input (gather.hpp, AddrBias)
+    float* gsum;               // [n_addr][2][4H] column sums of dG per address group (current | previous statement)
+    bool compact;              // LSTM input rows are [E | s_prev] (i4 = round4(e_obs + smp_dim)), the table columns a bias
+    int xc;                    // columns of an LSTM input row: e_obs + smp_dim (compact) or lstm_in
     int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
     size_t bytes;
 };
+
+// The address terms of the LSTM input as a per-address bias (gather.hpp): the default for LSTM networks whose dimensions
+// allow 16-byte pieces; PP_ADDR_BIAS=0 and the deterministic mode keep the full-width rows (A/B measurements, tests).
+static bool compact_rows(const pp_net* net) {
+    static const int env = getenv("PP_ADDR_BIAS") ? atoi(getenv("PP_ADDR_BIAS")) : 1;
+    if (!env || deterministic_mode() || net->lstm_dim == 0) return false;
+    const int c2 = net->e_obs + net->smp_dim, ne = net->dtype_dim + net->addr_dim;
+    return net->lstm_in % 4 == 0 && c2 % 4 == 0 && net->lstm_dim % 16 == 0 && ne >= 1 && ne <= 128 && net->n_addr >= 1 &&
+           net->n_addr <= 1024 && net->addr_table != nullptr;
+}
+static int env_flag(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspace& w) {
     Carver c(p, cap);
@@ -162,7 +171,9 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
         w.xch_b = c.take<char>((int64_t)bb);
     }
     w.e4 = round4(net->e_obs);
-    w.i4 = round4(net->lstm_in);
+    w.compact = compact_rows(net);
+    w.xc = w.compact ? net->e_obs + net->smp_dim : net->lstm_in;
+    w.i4 = round4(w.xc);
     int64_t hid = 1, out = 1;
     for (int a = 0; a < net->n_addr; ++a) {
         hid = std::max<int64_t>(hid, net->addrs[a].hid);
@@ -212,6 +223,8 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.loss_acc = c.take<float>(PP_LOSS_SLOTS_FLOATS);
     w.flag = reinterpret_cast<int32_t*>(w.loss_acc ? w.loss_acc + 64 * 32 : nullptr);
     w.lp_rows = c.take<float>(deterministic_mode() ? R : 0);
+    w.AB = c.take<float>(w.compact ? (int64_t)net->n_addr * 2 * 4 * H : 0);
+    w.gsum = c.take<float>(w.compact ? (int64_t)net->n_addr * 2 * 4 * H : 0);
     w.bytes = c.off + 256;
 }
 
@@ -247,12 +260,12 @@ static int linear_fwd(const float* x, int64_t ldx, const int32_t* x_idx, const f
 // products of a backward pass are leaves of the dependency graph and run as one grouped launch (gemm_f32_grouped)
 // the weight-gradient leaves of the backward pass, one grouped launch (timed as kernel class 1 when armed)
 static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st, const std::vector<GemmHole>* holes = nullptr,
-                         bool timed = true) {
-    if (wq.empty()) return 0;
+                         bool timed = true, const AuxJobs* aux = nullptr) {
+    if (wq.empty()) return aux ? aux_jobs_launch(*aux, st) : 0;
     double flops = 0.0;
     for (const auto& g : wq) flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
     if (timed) prof_begin(1, st);
-    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st, holes ? holes->data() : nullptr));
+    PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st, holes ? holes->data() : nullptr, nullptr, aux));
     if (timed) prof_end(1, flops, st);
     return 0;
 }
@@ -407,8 +420,30 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // kernel class 2 of the in-stream timing: observe embedding + LSTM input rows (the gather path). Algorithmic bytes:
     // observations and per-row (value, address, previous row) in; X rows, E / cat / f1 and the observables' hidden
     // activations out (4 I per trace-step written, 4 n_obs per trace read)
-    double gather_bytes = 4.0 * B * bt->obs_width + 12.0 * R + 4.0 * (ff ? 0.0 : (double)R * I) + 3.0 * 4.0 * B * net->e_obs;
-    if (!ff && (flags & PP_LOSS_BACKWARD)) gather_bytes += 4.0 * R * I;   // the same launch clears dX
+    double gather_bytes = 4.0 * B * bt->obs_width + 12.0 * R + 4.0 * (ff ? 0.0 : (double)R * w.xc) + 3.0 * 4.0 * B * net->e_obs;
+    if (!ff && (flags & PP_LOSS_BACKWARD)) gather_bytes += 4.0 * R * w.xc;   // the same launch clears dX
+    // compact rows: the same launch computes the per-address bias vectors of the LSTM input (reads W_ih[:, c2:I] per
+    // present address, writes 2 x 4H, clears the group sums)
+    const bool compact = w.compact;
+    const int c2x = net->e_obs + net->smp_dim, ne_x = net->dtype_dim + net->addr_dim;
+    // single-statement batches have no previous statement at all: the sample-embedding columns are zero in every row
+    const int nx = (T == 1) ? net->e_obs : c2x;
+    AddrBias abias{};
+    if (compact) {
+        abias.AB = w.AB; abias.gsum = w.gsum;
+        abias.W = P + net->w_ih; abias.b_ih = P + net->b_ih; abias.b_hh = P + net->b_hh;
+        abias.params = P; abias.at = net->addr_table; abias.ldw = I;
+        abias.N = 4 * H; abias.c2 = c2x; abias.c3 = c2x + net->dtype_dim; abias.c4 = c2x + ne_x;
+        abias.c5 = abias.c4 + net->dtype_dim; abias.I = I; abias.n_addr = net->n_addr;
+        for (int q = 0; q < 32; ++q) abias.present[q] = 0u;
+        int n_present = 0;
+        for (int a = 0; a < net->n_addr; ++a)
+            if (bt->grp_off[a + 1] > bt->grp_off[a] || bt->nxt_off[a + 1] > bt->nxt_off[a]) {
+                abias.present[a >> 5] |= 1u << (a & 31);
+                ++n_present;
+            }
+        gather_bytes += (double)n_present * (4.0 * 4 * H * (2.0 * ne_x) + 4.0 * 4.0 * 4 * H);
+    }
     for (int o = 0; o < net->n_obs; ++o) gather_bytes += 4.0 * B * net->obs_hid[o];
     prof_begin(2, st);
     if (ff) {
@@ -436,15 +471,16 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         rb.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
         rb.params = P; rb.at = net->addr_table; rb.row_off = bt->row_off_dev; rb.t_max = T;
         rb.value = bt->value; rb.addr = bt->addr; rb.prev_row = bt->prev_row;
-        rb.X = w.X; rb.ldx = w.i4;
+        rb.X = w.X; rb.ldx = w.i4; rb.xcols = w.xc;
         rb.zero_like = bwd ? w.dX : nullptr;
         rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = n_clear;
-        PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb));
+        PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb, compact ? &abias : nullptr));
     } else {
         PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
         // (also clears the loss slots and, for a backward pass, dX: see the kernel)
         PP_TRY(lstm_input_gather(net, P, w.E, w.e4, bt->trace, bt->value, bt->addr, bt->prev_row, -1, -1, R, w.X, w.i4, st,
-                                 bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), n_clear));
+                                 bwd ? w.dX : nullptr, reinterpret_cast<float*>(w.loss_acc), n_clear, w.xc,
+                                 compact ? &abias : nullptr));
     }
     prof_end(2, gather_bytes, st);
     // nn.LSTM(I, H, depth), inference_network_lstm.py:31,186-188: layer k reads the hidden states of layer k - 1
@@ -465,9 +501,31 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         zero.b[1] = GemmBlock{0, B, H, 2 * H, 0, in_w};
         if (l == 0) zero.b[0] = GemmBlock{0, B, 0, 4 * H, net->e_obs, net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim};
         if (l == 0) prof_begin(0, st);
+        bool cell_done = false;   // the first time step's cell ran in the product's epilogue
+        if (l == 0 && compact) {
+            // G = [E | s_prev] W_ih[:, :c2]^T + cur[addr] + prev[previous addr] (gather.hpp); first-step rows have no previous
+            // statement: their sample-embedding columns are zero too
+            pp_gemm_args g{};
+            g.A = w.X; g.lda = w.i4;
+            g.B = P + net->w_ih; g.ldb = I;
+            g.C = w.Gl[0]; g.ldc = 4 * H;
+            g.M = R; g.N = 4 * H; g.K = nx;
+            GemmExt x{};
+            x.rb = w.AB; x.rb_addr = bt->addr; x.rb_prev = T > 1 ? bt->prev_row : nullptr;
+            static const int fuse_cell = env_flag("PP_FUSE_CELL", 1);
+            if (fuse_cell) {   // gate-interleaved tiles, LSTM cell of the first time step in the epilogue
+                x.cell_H = H; x.cell_rows = B; x.cell_c = w.Cl[0]; x.cell_h = w.Hl[0];
+                cell_done = true;
+            }
+            GemmHole zc{};
+            zc.b[0] = GemmBlock{0, B, 0, 4 * H, net->e_obs, nx};
+            PP_TRY(gemm_f32(&g, st, &zc, &x));
+            prof_end(0, 2.0 * R * (double)nx * 4.0 * H, st);
+        } else {
         PP_TRY(linear_fwd(in, in_ld, nullptr, P + lw_ih(l), P + lb_ih(l), w.Gl[l], 4 * H, R, in_w, 4 * H, false, P + lb_hh(l), st,
                           &zero));
         if (l == 0) prof_end(0, 2.0 * R * (double)I * 4.0 * H, st);
+        }
         for (int t = 0; t < T; ++t) {
             if (tail_teams && t == tail_t0) {   // all remaining time steps of this layer: one launch (lstm_tail.hip)
                 PP_TRY(lstm_tail_fwd(w.Gl[l], w.Cl[l], w.Hl[l], P + lw_hh(l), bt->row_off_dev, tail_t0, T, H, tail_teams,
@@ -489,6 +547,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 PP_TRY(gemm_f32(&g, st));
                 c_prev = w.Cl[l] + (int64_t)rp * H;
             }
+            if (t == 0 && cell_done) continue;
             PP_TRY(lstm_cell_fwd(Gt, c_prev, w.Cl[l] + (int64_t)r0 * H, w.Hl[l] + (int64_t)r0 * H, n, H, st));
         }
     }
@@ -561,17 +620,22 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // ---------------- backward ----------------
     // Weight-gradient leaves: queued and flushed as grouped launches - on the side stream as soon as their inputs are
     // complete (heads after the tails, LSTM after the cell backward), or all at once at the end on the caller's stream.
-    SideStream* ss = side_stream();
+    SideStream* ss = compact ? nullptr : side_stream();
     std::vector<pp_gemm_args> wq;
     std::vector<GemmHole> wholes;
     bool forked = false;
-    auto flush_wgrads = [&](hipStream_t stream, bool timed) -> int {
+    auto flush_wgrads = [&](hipStream_t stream, bool timed, const AuxJobs* aux = nullptr) -> int {
         wholes.resize(wq.size(), GemmHole{});
-        PP_TRY(launch_wgrads(wq, stream, &wholes, timed));
+        PP_TRY(launch_wgrads(wq, stream, &wholes, timed, aux));
         wq.clear();
         wholes.clear();
         return 0;
     };
+    // Single-statement batch, one LSTM layer: every row is a trace's only time step, so the cell backward needs nothing
+    // but dh from the heads - it runs in the epilogue of the dH product (gemm_tile_direct), which also adds each tile's
+    // column sums of dG to its address's group sums; the loss is finalised by the jobs behind the weight-gradient tiles.
+    static const int fuse_cell_bwd = env_flag("PP_FUSE_CELL_BWD", 1);
+    const bool fused_bwd = compact && T == 1 && L == 1 && fuse_cell_bwd;
     auto join_side = [&]() -> int {   // the caller's stream continues only after the side stream's products
         if (!forked) return 0;
         if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) {
@@ -603,6 +667,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             g.B = P + ad.w1; g.ldb = H; g.b_kmajor = 1;
             g.C = w.dH; g.ldc = H; g.c_idx = bt->grp_rows + g0;
             g.M = n; g.N = H; g.K = ad.hid;
+            if (fused_bwd) g.colsum = w.gsum + (int64_t)a * 2 * 4 * H;   // group sums of dG (current-address slot)
             dq.push_back(g);
         }
     }
@@ -611,7 +676,13 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         forked = true;
         PP_TRY(flush_wgrads(ss->s, ff));
     }
-    PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));
+    if (fused_bwd) {
+        GemmExt x{};
+        x.bw_G = w.Gl[0]; x.bw_C = w.Cl[0]; x.bw_H = H;
+        PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st, nullptr, &x));
+    } else {
+        PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));
+    }
     // the gradient of the observe embedding is summed over the time steps from dX[:, :e_obs] (LSTM) / from dH (FF)
     const float* dXs = ff ? w.dH : w.dX;
     const int64_t ldxs = ff ? H : w.i4;
@@ -620,6 +691,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     float* dH_other = w.dH2;
     for (int l = L - 1; l >= 0; --l) {
         for (int t = T - 1; t >= 0; --t) {
+            if (fused_bwd) break;   // dG is already in place
             if (tail_teams && t >= tail_t0) {   // steps T-1 .. tail_t0 in one launch; it leaves dh / dc of step tail_t0 - 1
                 const LossFinalize fin{l == L - 1 ? fin_acc : nullptr, w.flag, B > 0 ? 1.0f / (float)B : 0.0f, loss_out, status_out};
                 PP_TRY(lstm_tail_bwd(w.Gl[l], w.Cl[l], dH_cur, w.dC, P + lw_hh(l), bt->row_off_dev, tail_t0, T, H, tail_teams,
@@ -650,9 +722,16 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const int64_t in_ld = l == 0 ? w.i4 : H;
         const int in_w = l == 0 ? I : H;
         GemmHole wh{};
+        if (l == 0 && compact) {   // dW_ih[:, :c2] = dG^T [E | s_prev]; the table columns follow from the group sums (aux jobs)
+            wh.b[1] = GemmBlock{H, 2 * H, 0, nx, 0, B};
+            wh.b[0] = GemmBlock{0, 4 * H, cz0, nx, 0, B};
+            queue_wgrad(wq, w.Gl[0], 4 * H, w.X, w.i4, nullptr, grads + net->w_ih, R, nx, 4 * H, &wholes, wh);
+            wq.back().ldc = I;
+        } else {
         wh.b[1] = GemmBlock{H, 2 * H, 0, in_w, 0, B};
         if (l == 0) wh.b[0] = GemmBlock{0, 4 * H, cz0, cz1, 0, B};
         queue_wgrad(wq, w.Gl[l], 4 * H, in, in_ld, nullptr, grads + lw_ih(l), R, in_w, 4 * H, &wholes, wh);
+        }
         if (T > 1) {
             const int r1 = bt->row_off[1];
             queue_wgrad(wq, w.Gl[l] + (int64_t)r1 * 4 * H, 4 * H, w.Hl[l], H, bt->prev_row + r1, grads + lw_hh(l), R - r1, H,
@@ -676,12 +755,34 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding. Nobody reads the
     // previous-variable columns of first-time-step rows (no previous variable, no parameter behind them).
     // The forget-gate part of the summation over the gates is zero for those rows.
+    if (compact) {
+        // dX[:, :c2] = dG W_ih[:, :c2] (observe-embedding and sample-embedding columns; the table columns need no per-row
+        // gradient: their parameter gradients follow from the column sums of dG per address group)
+        const GemmHole dx_unused{{{0, B, cz0, nx, 0, 4 * H}, {0, B, 0, nx, H, 2 * H}}};
+        pp_gemm_args g{};
+        g.A = w.G; g.lda = 4 * H;
+        g.B = P + net->w_ih; g.ldb = I; g.b_kmajor = 1;
+        g.C = w.dX; g.ldc = w.i4;
+        g.M = R; g.N = nx; g.K = 4 * H;
+        g.accumulate = 1;   // dX was cleared by the gather kernel
+        g.split_k = 1;
+        PP_TRY(gemm_f32(&g, st, &dx_unused));
+        if (!fused_bwd) {   // group sums of dG by current / previous address (the fused dH epilogue produced the former)
+            for (int a = 0; a < net->n_addr; ++a) {
+                const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
+                if (n > 0) cs.push_back(ColsumJob{w.G, 4 * H, bt->grp_rows + g0, n, 4 * H, w.gsum + (int64_t)a * 2 * 4 * H, nullptr});
+                const int q0 = bt->nxt_off[a], m = bt->nxt_off[a + 1] - q0;
+                if (m > 0) cs.push_back(ColsumJob{w.G, 4 * H, bt->nxt_rows + q0, m, 4 * H, w.gsum + ((int64_t)a * 2 + 1) * 4 * H, nullptr});
+            }
+        }
+    } else {
     const GemmHole dx_unused{{{0, B, cz0, cz1, 0, 4 * H}, {0, B, 0, I, H, 2 * H}}};
     PP_TRY(linear_dgrad(w.G, 4 * H, P + net->w_ih, w.dX, w.i4, nullptr, nullptr, 0, R, I, 4 * H, true, st, nullptr,
                         &dx_unused));   // dX was cleared by the gather kernel
+    }
     const int c1 = net->e_obs, c2 = c1 + net->smp_dim, c3 = c2 + net->dtype_dim, c4 = c3 + net->addr_dim,
               c5 = c4 + net->dtype_dim;
-    for (int a = 0; a < net->n_addr; ++a) {
+    for (int a = 0; a < net->n_addr && !compact; ++a) {
         const pp_addr& ad = net->addrs[a];
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
         if (n > 0) {  // rows where `a` is the current address
@@ -699,6 +800,40 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     else if (T > 1)
         PP_TRY(sample_embed_bwd(net, P, bt->value, bt->addr, bt->prev_row, bt->row_off[1], R, w.dX, w.i4, grads, st));
     }   // !ff
+    // Column sums + weight-gradient leaves. Compact rows: the jobs that turn the group sums of dG into the table-column
+    // gradients (and, after the fused cell backward, the LSTM bias gradients and the loss) ride behind the tiles of the
+    // grouped weight-gradient launch; for a single-statement batch so do the column sums themselves (nothing in the
+    // launch depends on anything else in it), which removes the separate column-sum launch.
+    auto reduce_and_flush = [&]() -> int {
+        if (!compact) {
+            if (ff)   // (LSTM: the first cell launch of the backward pass finalises the loss)
+                PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
+            else
+                PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+            return flush_wgrads(st, !ss);
+        }
+        AuxJobs aux{};
+        static const int cs_ride_env = env_flag("PP_AUX_COLSUM", 1);
+        int n_live = 0;
+        for (const auto& j : cs) n_live += (j.n_rows > 0 && j.n_cols > 0) ? 1 : 0;
+        if (fused_bwd && cs_ride_env && n_live <= AUX_MAX_COLSUM) {
+            for (const auto& j : cs)
+                if (j.n_rows > 0 && j.n_cols > 0) aux.cs[aux.n_colsum++] = j;
+        } else {
+            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+        }
+        aux.gsum = w.gsum; aux.W = P + net->w_ih; aux.dW = grads + net->w_ih; aux.ldw = I;
+        aux.params = P; aux.grads = grads; aux.at = net->addr_table;
+        aux.N = 4 * H; aux.c2 = c2x; aux.c4 = c2x + ne_x; aux.nd = net->dtype_dim; aux.ne = ne_x; aux.n_addr = net->n_addr;
+        for (int q = 0; q < 32; ++q) aux.present[q] = abias.present[q];
+        aux.all_present = 0;
+        if (fused_bwd) {
+            aux.db_ih = grads + net->b_ih; aux.db_hh = grads + net->b_hh;
+            aux.fin = LossFinalize{fin_acc, w.flag, B > 0 ? 1.0f / (float)B : 0.0f, loss_out, status_out};
+        }
+        aux_layout(aux, true);
+        return flush_wgrads(st, true, &aux);
+    };
     // observe embedding backward
     if (obs_fused_supported(net)) {
         // dE (sum over the trace's time steps of dX, masked by the last ReLU) and the data gradients of the whole stack
@@ -726,19 +861,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             ci += in;
             co += out;
         }
-        if (ff)   // (LSTM: the first cell launch of the backward pass finalises the loss)
-            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
-        else
-            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-        PP_TRY(flush_wgrads(st, !ss));
+        PP_TRY(reduce_and_flush());
         return join_side();
     }
     PP_TRY(obs_grad(dXs, ldxs, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
-    if (ff)
-        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
-    else
-        PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-    PP_TRY(flush_wgrads(st, !ss));
+    PP_TRY(reduce_and_flush());
     PP_TRY(join_side());
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));

@@ -18,6 +18,7 @@
 //     lanes 0-31 and k = 8s + 4 + j from lanes 32-63 for BOTH operands.
 //   * global->register prefetch of slab i+1 overlaps the MFMAs of slab i (two barriers per slab).
 #include "common.hpp"
+#include "aux_jobs.hpp"
 
 #include <algorithm>
 
@@ -399,8 +400,10 @@ struct AsyncOperand {
     int64_t ldk;
     int knext[NP];
 
+    // gperm > 0 (k-contiguous operand only): the tile's 64 rows are rows [16 t, 16 t + 16) of four blocks of `gperm` rows
+    // (t = row0 / 64): the four gates of 16 hidden units of an LSTM weight matrix
     __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, const int32_t* __restrict__ idx, int row0,
-                                         int nrows, int k_begin, int wave, int lane, const int32_t* kidx_lds) {
+                                         int nrows, int k_begin, int wave, int lane, const int32_t* kidx_lds, int gperm = 0) {
         chunk = (uint32_t)(NP * wave) * 1024u;
         kidx = (KM && idx) ? kidx_lds : nullptr;
         ldk = ld;
@@ -410,7 +413,7 @@ struct AsyncOperand {
             if (!KM) {
                 const int r = 8 * c + (lane >> 3);
                 const int kslot = (lane & 7) ^ ((r >> 1) & 7);
-                const int grow = min(row0 + r, nrows - 1);
+                const int grow = gperm ? min((r >> 4) * gperm + (row0 >> 2) + (r & 15), nrows - 1) : min(row0 + r, nrows - 1);
                 const int64_t rr = idx ? (int64_t)idx[grow] : (int64_t)grow;
                 kpiece[j] = 4 * kslot;
                 safe[j] = P + rr * ld;
@@ -461,6 +464,85 @@ struct AsyncOperand {
     }
 };
 
+// Epilogue of the LSTM input product G = [E | s_prev] W_ih[:, :c2]^T (async tile, four waves, no split; GemmExt in
+// common.hpp): every row gets the bias vectors of its current and its previous address; with cell_H > 0 the tile holds
+// the four gates of 16 hidden units, and rows of a trace's first time step (c_prev = 0, inference_network_lstm.py:186)
+// go through the LSTM cell right here - pre-activations never travel to HBM and back, lstm_cell_fwd is not launched.
+__device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt& x, const f32x16& acc, const int m0,
+                                              const int bx, const int wm, const int wn, const int l31, const int h,
+                                              float* smem) {
+    const int H = x.cell_H;
+    const int nloc = wn * 32 + l31;
+    const int gn = H ? (nloc >> 4) * H + bx * 16 + (nloc & 15) : bx * 64 + nloc;
+    const bool ncol = gn < p.N;
+    const int gnc = ncol ? gn : 0;
+    const bool fused = H > 0 && m0 < x.cell_rows;   // workgroup-uniform
+    int ia[16], ip[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, p.M - 1);
+        ia[r] = x.rb_addr[gm];
+        ip[r] = x.rb_prev ? x.rb_prev[gm] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ip[r] = ip[r] >= 0 ? x.rb_addr[ip[r]] : -1;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float b = x.rb[(int64_t)(2 * ia[r]) * p.N + gnc];
+        if (ip[r] >= 0) b += x.rb[(int64_t)(2 * ip[r] + 1) * p.N + gnc];
+        v[r] = acc[r] + b;
+    }
+    if (!fused) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (gm < p.M && ncol) p.C[(int64_t)gm * p.ldc + gn] = v[r];
+        }
+        return;
+    }
+    constexpr int SS = 68;   // row stride of the exchange image (16-byte rows)
+    __syncthreads();         // every wave is done with the ring
+#pragma unroll
+    for (int r = 0; r < 16; ++r) smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * SS + nloc] = v[r];
+    __syncthreads();
+    // thread t: row t >> 2, hidden units 4 (t & 3) .. + 3 of the tile's 16, all four gates
+    const int tid = threadIdx.x;
+    const int row = tid >> 2, q = tid & 3;
+    const int gm = m0 + row;
+    if (gm >= p.M) return;
+    const float* sr = smem + row * SS + 4 * q;
+    const f32x4 vi = *reinterpret_cast<const f32x4*>(sr);
+    const f32x4 vf = *reinterpret_cast<const f32x4*>(sr + 16);
+    const f32x4 vg = *reinterpret_cast<const f32x4*>(sr + 32);
+    const f32x4 vo = *reinterpret_cast<const f32x4*>(sr + 48);
+    const int u0 = bx * 16 + 4 * q;
+    float* g = p.C + (int64_t)gm * p.ldc + u0;
+    if (gm < x.cell_rows) {   // torch.nn.LSTM gates i, f, g, o with c_prev = 0: the forget gate multiplies zero (0 recorded)
+        f32x4 gi, gg, go, cn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gi[e] = sigmoidf_(vi[e]);
+            gg[e] = tanhf(vg[e]);
+            go[e] = sigmoidf_(vo[e]);
+            cn[e] = gi[e] * gg[e];
+            hn[e] = go[e] * tanhf(cn[e]);
+        }
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        *reinterpret_cast<f32x4*>(g) = gi;
+        *reinterpret_cast<f32x4*>(g + H) = zero;
+        *reinterpret_cast<f32x4*>(g + 2 * H) = gg;
+        *reinterpret_cast<f32x4*>(g + 3 * H) = go;
+        *reinterpret_cast<f32x4*>(x.cell_c + (int64_t)gm * H + u0) = cn;
+        *reinterpret_cast<f32x4*>(x.cell_h + (int64_t)gm * H + u0) = hn;
+    } else {                  // a later time step in the same tile: pre-activations, the recurrent product follows
+        *reinterpret_cast<f32x4*>(g) = vi;
+        *reinterpret_cast<f32x4*>(g + H) = vf;
+        *reinterpret_cast<f32x4*>(g + 2 * H) = vg;
+        *reinterpret_cast<f32x4*>(g + 3 * H) = vo;
+    }
+}
+
 // KW = 1: four waves, one 32x32 fragment each. KW = 2: eight waves; waves w and w+4 share a fragment and split every
 // slab's k range in two (in-workgroup split-K, summed through LDS at the end). A single wave cannot hide its own
 // non-MFMA instructions (DMA issue, fragment reads, barrier: ~1700 cycles per slab against 1024 of MFMA, measured
@@ -468,7 +550,7 @@ struct AsyncOperand {
 // workgroup per CU.
 template <bool A_KM, bool B_KM, int KW>
 __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
-                                                float* smem) {
+                                                float* smem, const GemmExt* x = nullptr) {
     constexpr int ST = AS_STAGES;
     constexpr int NP = 2 / KW;        // DMA pieces per thread per operand per slab
     constexpr int D = 2 * NP;         // DMA instructions per thread per slab
@@ -523,7 +605,7 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     AsyncOperand<A_KM, NP> oa;
     AsyncOperand<B_KM, NP> ob;
     oa.init(p.A, p.lda, p.a_idx, m0, p.M, kb, wave, lane, kia);
-    ob.init(p.B, p.ldb, p.b_idx, n0, p.N, kb, wave, lane, kib);
+    ob.init(p.B, p.ldb, p.b_idx, n0, p.N, kb, wave, lane, kib, (!B_KM && x) ? x->cell_H : 0);
     const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue = [&](int t) {
         const uint32_t img = ring + (uint32_t)(t & (ST - 1)) * (AS_STAGE * 4u);
@@ -645,6 +727,10 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] += part[r * 64 + lane];
     }
+    if (KW == 1 && !A_KM && !B_KM && x && x->rb) {   // LSTM input product (workgroup-uniform)
+        lstm_epilogue(p, *x, acc[0][0], m0, bx, wm, wn, l31, h, smem);
+        return;
+    }
     tile_epilogue<64, 64, 32, 32, 1, 1>(p, acc, m0, n0, wm, wn, l31, h, bz, split);
 }
 
@@ -653,6 +739,11 @@ extern __shared__ __attribute__((aligned(1024))) float as_ring[];   // ST x AS_S
 template <bool A_KM, bool B_KM, int KW>
 __global__ __launch_bounds__(256 * KW) void gemm_f32_async_kernel(const GemmParams p) {
     gemm_tile_async<A_KM, B_KM, KW>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, as_ring);
+}
+
+// the LSTM input product: per-row address bias, gate-interleaved tiles, fused cell (lstm_epilogue)
+__global__ __launch_bounds__(256) void gemm_f32_async_lstm_kernel(const GemmParams p, const GemmExt x) {
+    gemm_tile_async<false, false, 1>(p, blockIdx.x, blockIdx.y, 0, 1, as_ring, &x);
 }
 
 // ---- a handful of rows (M <= GEMV_ROWS): one wave per output column ------------------------------------------
@@ -739,6 +830,7 @@ struct GroupedParams {
     int pmode[GROUP_MAX];       // XCD placement of the problem's tiles, see group_decode
     int count;
     int xcd_aware;
+    GemmExt ext;                // shared by the problems of the launch (cell backward in the dH epilogue)
 };
 
 // Workgroup -> (problem, tile, K split). Workgroups are dealt round-robin to the 8 XCDs (id % 8) and each XCD has its
@@ -957,7 +1049,7 @@ constexpr int direct_lds_floats() {
 
 template <bool A_KM, bool B_KM, int VEC>
 __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
-                                                 float* red) {
+                                                 float* red, const GemmExt* x = nullptr) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, h = lane >> 5;
@@ -1029,6 +1121,55 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
     }
     const bool rowok = gm < p.M;
     const int64_t cm = rowok ? (p.c_idx ? (int64_t)p.c_idx[gm] : (int64_t)gm) : 0;
+    if (!A_KM && B_KM && x && x->bw_G) {   // workgroup-uniform
+        // The tile is dh of 32 single-statement rows x 32 hidden units (dH = dZ1 W1, all rows of one address): run the
+        // LSTM cell backward here (no dc carry, c_prev = 0: lstm_cell_bwd_kernel with n_next = 0, c_prev = NULL) - the
+        // gates in bw_G become dG in place, dH is never stored - and add the tile's column sums of dG to the address's
+        // group sums (p.colsum: [4 H], the forget-gate part stays zero).
+        const int H = x->bw_H;
+        float d0[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f}, d3[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rowok && n0 + c4 < p.N) {   // (N = H is a multiple of 4: all four columns or none)
+            float* g = x->bw_G + cm * 4 * H + n0 + c4;
+            const f32x4 gi = *reinterpret_cast<const f32x4*>(g);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 2 * H);
+            const f32x4 go = *reinterpret_cast<const f32x4*>(g + 3 * H);
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(x->bw_C + cm * H + n0 + c4);
+            f32x4 o0, o2, o3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tc = tanhf(cc[e]);
+                const float dhv = v[e];
+                const float dc = dhv * go[e] * (1.0f - tc * tc);
+                d0[e] = dc * gg[e] * gi[e] * (1.0f - gi[e]);
+                d2[e] = dc * gi[e] * (1.0f - gg[e] * gg[e]);
+                d3[e] = dhv * tc * go[e] * (1.0f - go[e]);
+                o0[e] = d0[e]; o2[e] = d2[e]; o3[e] = d3[e];
+            }
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(g) = o0;
+            *reinterpret_cast<f32x4*>(g + H) = zero;
+            *reinterpret_cast<f32x4*>(g + 2 * H) = o2;
+            *reinterpret_cast<f32x4*>(g + 3 * H) = o3;
+        }
+        __syncthreads();   // the partial tiles have been read
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[row * DPAD + c4 + e] = d0[e];
+            red[(DT + row) * DPAD + c4 + e] = d2[e];
+            red[(2 * DT + row) * DPAD + c4 + e] = d3[e];
+        }
+        __syncthreads();
+        if (tid < 3 * DT && p.colsum) {
+            const int gate = tid >> 5, col = tid & 31;
+            if (n0 + col < p.N) {
+                float cs = 0.0f;
+#pragma unroll 8
+                for (int r = 0; r < DT; ++r) cs += red[(gate * DT + r) * DPAD + col];
+                atomicAdd(p.colsum + (gate == 0 ? 0 : gate + 1) * H + n0 + col, cs);
+            }
+        }
+        return;
+    }
     float* dst = p.C + cm * p.ldc + n0 + c4;
     const bool lead = bz == 0;
 #pragma unroll
@@ -1100,8 +1241,23 @@ __global__ __launch_bounds__(256) void gemm_f32_direct_grouped_kernel(const Grou
     warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
-    if (VEC == 4 && !g.p[q].vec) gemm_tile_direct<A_KM, B_KM, 1>(g.p[q], bx, by, bz, g.gz[q], red);
-    else gemm_tile_direct<A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], red);
+    if (VEC == 4 && !g.p[q].vec) gemm_tile_direct<A_KM, B_KM, 1>(g.p[q], bx, by, bz, g.gz[q], red, &g.ext);
+    else gemm_tile_direct<A_KM, B_KM, VEC>(g.p[q], bx, by, bz, g.gz[q], red, &g.ext);
+}
+
+// weight-gradient groups (both operands k-major) with the backward pass's small reduction jobs behind the tiles
+__global__ __launch_bounds__(256) void gemm_f32_direct_grouped_aux_kernel(const GroupedParams g, const AuxJobs aux) {
+    __shared__ __attribute__((aligned(16))) float red[direct_lds_floats<true, true>()];
+    const int nb = g.first[g.count];
+    if ((int)blockIdx.x >= nb) {
+        aux_job_run(aux, (int)blockIdx.x - nb, red);
+        return;
+    }
+    warm_kernargs((int)sizeof(GroupedParams));
+    int q, bx, by, bz;
+    if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
+    if (!g.p[q].vec) gemm_tile_direct<true, true, 1>(g.p[q], bx, by, bz, g.gz[q], red);
+    else gemm_tile_direct<true, true, 4>(g.p[q], bx, by, bz, g.gz[q], red);
 }
 
 template <int VEC>
@@ -1134,9 +1290,23 @@ __global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_kernel(const 
     gemm_tile_async<A_KM, B_KM, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring);
 }
 
+template <int KW>
+__global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_aux_kernel(const GroupedParams g, const AuxJobs aux) {
+    const int nb = g.first[g.count];
+    if ((int)blockIdx.x >= nb) {   // behind the tiles: the small reduction jobs (aux_jobs.hpp)
+        aux_job_run(aux, (int)blockIdx.x - nb, as_ring);
+        return;
+    }
+    warm_kernargs((int)sizeof(GroupedParams));
+    int q, bx, by, bz;
+    if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
+    gemm_tile_async<true, true, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring);
+}
+
 // The ring is dynamic LDS (ST x 16 KB = 64 KB: two workgroups per CU).
 template <typename K>
-static int launch_dyn(K kernel, dim3 grid, int threads, size_t lds, hipStream_t st, const void* arg) {
+static int launch_dyn(K kernel, dim3 grid, int threads, size_t lds, hipStream_t st, const void* arg,
+                      const void* arg2 = nullptr) {
     static thread_local const void* configured[64];
     static thread_local int nconf = 0;
     bool seen = false;
@@ -1149,7 +1319,7 @@ static int launch_dyn(K kernel, dim3 grid, int threads, size_t lds, hipStream_t 
         }
         if (nconf < 64) configured[nconf++] = (const void*)kernel;
     }
-    void* args[1] = {const_cast<void*>(arg)};
+    void* args[2] = {const_cast<void*>(arg), const_cast<void*>(arg2)};
     hipError_t e = hipLaunchKernel((const void*)kernel, grid, dim3(threads), args, lds, st);
     if (e != hipSuccess) {
         set_error("pp_gemm_f32 (async): launch failed: %s", hipGetErrorString(e));
@@ -1178,6 +1348,20 @@ static int launch_async_grouped_kw(const GroupedParams& g, bool akm, bool bkm, h
     if (!akm && bkm) return launch_dyn(gemm_f32_async_grouped_kernel<false, true, KW>, grid, 256 * KW, lds, st, &g);
     if (akm && !bkm) return launch_dyn(gemm_f32_async_grouped_kernel<true, false, KW>, grid, 256 * KW, lds, st, &g);
     return launch_dyn(gemm_f32_async_grouped_kernel<true, true, KW>, grid, 256 * KW, lds, st, &g);
+}
+
+// the group's tiles + the workgroups of the small reduction jobs behind them (both operands k-major only)
+static int launch_async_grouped_aux(const GroupedParams& g, const AuxJobs& aux, bool kw2, hipStream_t st) {
+    dim3 grid(g.first[g.count] + aux.n_blocks);
+    const size_t lds = as_lds_bytes();
+    if (kw2) return launch_dyn(gemm_f32_async_grouped_aux_kernel<2>, grid, 512, lds, st, &g, &aux);
+    return launch_dyn(gemm_f32_async_grouped_aux_kernel<1>, grid, 256, lds, st, &g, &aux);
+}
+static int launch_direct_grouped_aux(const GroupedParams& g, const AuxJobs& aux, hipStream_t st) {
+    dim3 grid(g.first[g.count] + aux.n_blocks), block(256);
+    hipLaunchKernelGGL(gemm_f32_direct_grouped_aux_kernel, grid, block, 0, st, g, aux);
+    PP_LAUNCH_CHECK("pp_gemm_f32_grouped (direct + jobs)");
+    return 0;
 }
 
 // eight waves per tile when the launch cannot put four workgroups on every CU anyway
@@ -1328,6 +1512,7 @@ static int launch_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_
 static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int tile, int splits, int kind, hipStream_t st) {
     static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
     GroupedParams g;
+    g.ext = GemmExt{};
     g.xcd_aware = xcd;
     g.count = 1;
     g.p[0] = p;
@@ -1340,7 +1525,7 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
          : kind == 2 ? launch_async_grouped(g, akm, bkm, st) : launch_grouped<4>(g, akm, bkm, st);
 }
 
-int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole) {
+int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const GemmExt* ext) {
     PP_CHECK_ARG(a && a->A && a->B && a->C, "pp_gemm_f32: null operand");
     PP_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0, "pp_gemm_f32: negative dimension");
     if (a->M == 0 || a->N == 0) return 0;
@@ -1348,6 +1533,16 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole) {
     fill_params(a, p);
     set_hole(p, hole);
     const bool vec = vec_ok(a);
+    if (ext && ext->rb) {   // the LSTM input product: its epilogue exists in the async 64x64 tile only
+        PP_CHECK_ARG(ext->rb_addr && vec && a->K >= 1 && !a->a_kmajor && !a->b_kmajor && !a->a_idx && !a->b_idx && !a->c_idx &&
+                         !a->mask && !a->colsum && !a->accumulate && !a->relu && !a->bias && !a->bias2,
+                     "pp_gemm_f32: unsupported LSTM input product");
+        PP_CHECK_ARG(ext->cell_H == 0 || (ext->cell_H % 16 == 0 && a->N == 4 * ext->cell_H && a->ldc % 4 == 0 && aligned16(a->C) &&
+                                          ext->cell_c && ext->cell_h),
+                     "pp_gemm_f32: bad fused-cell arguments");
+        dim3 grid(cdiv(a->N, 64), cdiv(a->M, 64), 1);
+        return launch_dyn(gemm_f32_async_lstm_kernel, grid, 256, as_lds_bytes(), st, &p, ext);
+    }
     if (gemv_ok(a)) return launch_gemv(p, vec, st);
     // Tile choice: the hot-path GEMMs are small (<= a few thousand rows); 64x64 tiles give >= 2 workgroups per CU
     // on the 1024x2048x212 input GEMM. Very tall problems (batched IS) use 128x128 tiles.
@@ -1406,11 +1601,17 @@ static int64_t effective_work(const pp_gemm_args* a, const GemmHole* h, int* act
 }
 
 // `count` independent products with the same operand layouts in as few launches as possible (GROUP_MAX per launch).
-int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes) {
+int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes, const GemmExt* ext,
+                     const AuxJobs* aux) {
     PP_CHECK_ARG(count >= 0 && (count == 0 || args), "pp_gemm_f32_grouped: bad argument");
     int i = 0;
+    bool aux_pending = aux && aux->n_blocks > 0;
+    // kernel arguments beyond 4 KB (GroupedParams + AuxJobs): if the runtime refuses the launch once, the jobs run as
+    // their own launch from then on
+    static bool aux_fused_ok = !(getenv("PP_AUX_FUSED") && atoi(getenv("PP_AUX_FUSED")) == 0);
     while (i < count) {
         GroupedParams g;
+        g.ext = ext ? *ext : GemmExt{};
         static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
         g.xcd_aware = xcd;
         g.count = 0;
@@ -1440,7 +1641,8 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
             work32 += (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT) * cdiv(a->K, BK);
             ++c;
         }
-        const bool direct = use_direct(tiles, work);
+        // (the cell-backward epilogue exists in the direct tile only)
+        const bool direct = (ext && ext->bw_G) ? true : use_direct(tiles, work);
         // the async tiles stream a long K range at full rate, so they want fewer, longer workgroups (fewer atomics)
         const int target = as ? target_async : target_staged;
         // direct tiles: a workgroup's four waves share its slabs, so it should own >= 8 of them
@@ -1477,18 +1679,32 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
             g.pmode[q] = pick_pmode(a->M, a->N, g.gx[q], g.gy[q]);
             g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits, g.pmode[q]);
         }
+        bool rode = false;
+        if (g.count > 0 && aux_pending && aux_fused_ok && akm && bkm && (direct || as)) {
+            const int rc = direct ? launch_direct_grouped_aux(g, *aux, st)
+                                  : launch_async_grouped_aux(g, *aux, eight_waves(active_blocks), st);
+            if (rc == 0) {
+                rode = true;
+                aux_pending = false;
+            } else {
+                (void)hipGetLastError();
+                aux_fused_ok = false;
+            }
+        }
+        if (rode) { i = j; continue; }
         if (g.count > 0 && direct) PP_TRY(launch_direct_grouped(g, akm, bkm, st));
         else if (g.count > 0 && as) PP_TRY(launch_async_grouped(g, akm, bkm, st, active_blocks));
         else
         if (g.count > 0) PP_TRY(launch_grouped<4>(g, akm, bkm, st));
         i = j;
     }
+    if (aux_pending) PP_TRY(aux_jobs_launch(*aux, st));
     return 0;
 }
 
 }  // namespace pp
 
-extern "C" int pp_gemm_f32(const pp_gemm_args* args, void* stream) { return pp::gemm_f32(args, pp::as_stream(stream), nullptr); }
+extern "C" int pp_gemm_f32(const pp_gemm_args* args, void* stream) { return pp::gemm_f32(args, pp::as_stream(stream), nullptr, nullptr); }
 extern "C" int pp_gemm_f32_grouped(const pp_gemm_args* args, int32_t count, void* stream) {
-    return pp::gemm_f32_grouped(args, count, pp::as_stream(stream), nullptr);
+    return pp::gemm_f32_grouped(args, count, pp::as_stream(stream), nullptr, nullptr, nullptr);
 }

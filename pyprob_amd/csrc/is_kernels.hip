@@ -12,14 +12,8 @@
 
 namespace pp {
 
-int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
-                      const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
-                      int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st, float* zero_like = nullptr,
-                      float* zero_small = nullptr, int n_small = 0);
 int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int H, hipStream_t st, int c_prev_shared = 0);
 bool obs_fused_supported(const pp_net* net);
-int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
-                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows = nullptr);
 
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
 

@@ -3,6 +3,7 @@
 // embedding-table gradients, flat Adam. All fp32, gfx950 wave64.
 #include "common.hpp"
 #include "gather.hpp"
+#include "aux_jobs.hpp"
 
 #include <math.h>
 #include <stdarg.h>
@@ -30,11 +31,7 @@ const char* last_error() { return g_err; }
 constexpr int COLSUM_ROWS = 64;
 constexpr int COLSUM_MAX_JOBS = 48;   // (48 x 72 bytes: the by-value kernel arguments stay under 4 KB; 16 made 5 launches of a 12-address step)
 
-struct ColsumJob {
-    const float* X; int64_t ldx; const int32_t* idx; int n_rows, n_cols; float* out; float* out2;
-    const float* wgt; int64_t ldw; int out_stride;   // optional per-row weight; out_stride 0 = dense
-};
-struct ColsumJobs {
+struct ColsumJobs {   // (ColsumJob: aux_jobs.hpp)
     ColsumJob j[COLSUM_MAX_JOBS];
 };
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out, hipStream_t st);
@@ -186,6 +183,19 @@ int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st, const float* 
     return 0;
 }
 
+// the jobs of aux_jobs.hpp as their own launch (when they cannot ride behind the weight-gradient tiles)
+__global__ __launch_bounds__(256) void aux_jobs_kernel(const AuxJobs jobs) {
+    __shared__ float lds[512];
+    aux_job_run(jobs, (int)blockIdx.x, lds);
+}
+
+int aux_jobs_launch(const AuxJobs& jobs, hipStream_t st) {
+    if (jobs.n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(aux_jobs_kernel, dim3(jobs.n_blocks), dim3(256), 0, st, jobs);
+    PP_LAUNCH_CHECK("pp_aux_jobs");
+    return 0;
+}
+
 int colsum_f32(const float* X, int64_t ldx, const int32_t* idx, int n_rows, int n_cols, float* out, float* out2,
                hipStream_t st) {
     PP_CHECK_ARG(X && out, "pp_colsum_f32: null pointer");
@@ -203,16 +213,23 @@ __global__ __launch_bounds__(256) void lstm_input_gather_kernel(
     int64_t e_stride, const int32_t* __restrict__ trace, const float* __restrict__ value,
     const int32_t* __restrict__ addr, const int32_t* __restrict__ prev_row, int32_t fixed_addr,
     int32_t fixed_prev_addr, int n_rows, float* __restrict__ X, int64_t ldx, float* __restrict__ zero_like,
-    float* __restrict__ zero_small, int n_small) {
+    float* __restrict__ zero_small, int n_small, int xcols, const AddrBias ab) {
+    __shared__ float ab_lds[192];
+    if (ab.AB && (int)blockIdx.x >= ab.first_block) {   // extra workgroups: per-address bias vectors (gather.hpp)
+        addr_bias_block(ab, (int)blockIdx.x - ab.first_block, ab_lds);
+        return;
+    }
     // The training step's first kernel also clears two accumulators that later kernels add into (saves two memset
     // launches, ~5 us each): dX (same shape as X; the split-K data-gradient product accumulates into it) and the loss
     // slots.
     if (zero_small && blockIdx.x == 0)
         for (int q = threadIdx.x; q < n_small; q += 256) zero_small[q] = 0.0f;
-    const int64_t total = (int64_t)n_rows * d.I;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int r = (int)(e / d.I);
-        const int c = (int)(e - (int64_t)r * d.I);
+    const int nb = ab.AB ? ab.first_block : (int)gridDim.x;   // workgroups that gather
+    // xcols < I: compact rows [E | s_prev]; the table columns enter the product as a per-address bias instead
+    const int64_t total = (int64_t)n_rows * xcols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)nb * 256) {
+        const int r = (int)(e / xcols);
+        const int c = (int)(e - (int64_t)r * xcols);
         float out;
         if (c < d.e_obs) {
             const int64_t b = trace ? (int64_t)trace[r] : (int64_t)r;
@@ -238,15 +255,23 @@ __global__ __launch_bounds__(256) void lstm_input_gather_kernel(
 int lstm_input_gather(const pp_net* net, const float* params, const float* E, int64_t e_stride, const int32_t* trace,
                       const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
                       int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st, float* zero_like,
-                      float* zero_small, int n_small) {
+                      float* zero_small, int n_small, int xcols, const AddrBias* bias) {
     PP_CHECK_ARG(net && params && E && X && net->addr_table, "pp_lstm_input_gather: null pointer");
     if (n_rows <= 0) return 0;
     GatherDims d{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
     PP_CHECK_ARG(d.I == d.e_obs + d.smp + 2 * (d.dtype + d.addr), "pp_lstm_input_gather: lstm_in mismatch");
-    const int64_t total = (int64_t)n_rows * d.I;
-    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    if (xcols <= 0) xcols = d.I;
+    const int64_t total = (int64_t)n_rows * xcols;
+    int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    AddrBias ab{};
+    if (bias && bias->AB) {
+        ab = *bias;
+        ab.first_block = blocks;
+        blocks += ab.n_addr * cdiv(ab.N, 256);
+    }
     hipLaunchKernelGGL(lstm_input_gather_kernel, dim3(blocks), dim3(256), 0, st, d, params, net->addr_table, E, e_stride,
-                       trace, value, addr, prev_row, fixed_addr, fixed_prev_addr, n_rows, X, ldx, zero_like, zero_small, n_small);
+                       trace, value, addr, prev_row, fixed_addr, fixed_prev_addr, n_rows, X, ldx, zero_like, zero_small, n_small,
+                       xcols, ab);
     PP_LAUNCH_CHECK("pp_lstm_input_gather");
     return 0;
 }

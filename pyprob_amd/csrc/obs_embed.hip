@@ -124,9 +124,13 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
                                                             const float* __restrict__ obs, int n_traces,
                                                             int traces_per_wave, float* __restrict__ cat,
                                                             float* __restrict__ f1, float* __restrict__ E,
-                                                            const RowBuild rb) {
+                                                            const RowBuild rb, const AddrBias ab) {
     __shared__ float lds[10240];
-    warm_kernargs((int)sizeof(ObsFusedArgs) + 64);
+    if (ab.AB && (int)blockIdx.x >= ab.first_block) {   // extra workgroups: per-address bias vectors of the LSTM input
+        addr_bias_block(ab, (int)blockIdx.x - ab.first_block, lds);
+        return;
+    }
+    warm_kernargs((int)(sizeof(ObsFusedArgs) + sizeof(RowBuild) + sizeof(AddrBias)) + 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // training step: this is the first kernel - clear the loss slots that later kernels add into
     if (rb.zero_small && blockIdx.x == 0)
@@ -178,10 +182,10 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
                 const int ad = rb.addr[r];
                 float* xr = rb.X + (int64_t)r * rb.ldx;
                 if (acte) xr[lane] = y2;
-                for (int c = rb.d.e_obs + lane; c < rb.d.I; c += 64) xr[c] = gather_embedding_elem(rb.d, rb.params, rb.at, c, ap, v, ad);
+                for (int c = rb.d.e_obs + lane; c < rb.xcols; c += 64) xr[c] = gather_embedding_elem(rb.d, rb.params, rb.at, c, ap, v, ad);
                 if (rb.zero_like) {
                     float* zr = rb.zero_like + (int64_t)r * rb.ldx;
-                    for (int c = lane; c < rb.d.I; c += 64) zr[c] = 0.0f;
+                    for (int c = lane; c < rb.xcols; c += 64) zr[c] = 0.0f;
                 }
             }
         }
@@ -333,14 +337,22 @@ static int pick_traces_per_wave(int n, int target_blocks) {
 
 // obs_h: host array of n_obs device pointers; E/cat/f1 leading dim = round4(e_obs)
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
-                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows) {
+                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows, const AddrBias* bias) {
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
     const int tpw = pick_traces_per_wave(n_traces, 256);   // forward: staging is cheap, spread the traces
     RowBuild rb{};
     if (rows) rb = *rows;
-    hipLaunchKernelGGL(obs_embed_fwd_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat,
-                       f1, E, rb);
+    if (rb.X && rb.xcols <= 0) rb.xcols = rb.d.I;
+    AddrBias ab{};
+    int blocks = cdiv(n_traces, 4 * tpw);
+    if (bias && bias->AB) {   // the bias job rides in this launch as extra workgroups
+        ab = *bias;
+        ab.first_block = blocks;
+        blocks += ab.n_addr * cdiv(ab.N, 256);
+    }
+    hipLaunchKernelGGL(obs_embed_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat,
+                       f1, E, rb, ab);
     PP_LAUNCH_CHECK("obs_embed_fwd_fused");
     return 0;
 }

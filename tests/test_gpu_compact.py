@@ -1,0 +1,104 @@
+"""Compact LSTM input rows (the address / distribution-type embeddings of the LSTM input as a per-address bias, their
+gradients from the column sums of dG per address group; fused LSTM cell in the input product's epilogue, cell backward in
+the dH product's epilogue, reduction jobs behind the weight-gradient tiles): same losses and gradients as the full-width
+path (PP_ADDR_BIAS=0, which is what the golden tests pinned in round 1), switch by switch."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(repo)r); sys.path.insert(0, %(repo)r + '/tests')
+from helpers import synthetic_gumm_arrays, synthetic_gum_arrays
+from pyprob_amd.engine import ICEngine
+from pyprob_amd.packed import PackedBatch
+from pyprob_amd.spec import NetSpec
+out = {}
+cases = (('gum', 512, 1024, 1), ('multi', 64, 1000, 1), ('gumm', 256, 700, 1), ('gumm2', 64, 300, 2))
+for name, H, n, depth in cases:
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=H, lstm_depth=depth)
+    if name == 'gum':
+        arr = synthetic_gum_arrays(n, seed=3); addresses = ['mu']
+        spec.add_address('mu', 'Normal')
+    elif name == 'multi':
+        # single-statement traces of three different addresses and two distribution types, batch not a multiple of 64
+        arr = synthetic_gum_arrays(n, seed=7); addresses = ['a0', 'a1', 'a2']
+        rng = np.random.default_rng(11)
+        arr['addr_idx'] = rng.integers(0, 3, n).astype(np.int32)
+        uni = arr['addr_idx'] == 1
+        arr['values'][uni] = rng.uniform(-1, 1, int(uni.sum())).astype(np.float32)
+        arr['prior'][uni] = np.array([-1.0, 1.0], np.float32)
+        spec.add_address('a0', 'Normal'); spec.add_address('a1', 'Uniform'); spec.add_address('a2', 'Normal')
+    else:
+        arr, addresses = synthetic_gumm_arrays(n, seed=4, max_iter=4)
+        for a in addresses: spec.add_address(a, 'Uniform')
+    eng = ICEngine(spec, device='cuda:0', seed=5)
+    ids = np.array([spec.address_id[addresses[j]] for j in arr['addr_idx']])
+    pb = PackedBatch.from_ragged(arr['trace_len'], ids, arr['values'], arr['prior'], arr['obs'], len(spec.addresses)).to(eng.device)
+    l = eng.loss(pb, backward=True)
+    torch.cuda.synchronize()
+    out[name + '_loss'] = l.cpu().numpy()
+    out[name + '_grads'] = eng.grads.cpu().numpy()
+    l2 = eng.loss(pb, backward=False)          # forward only (validation loss)
+    torch.cuda.synchronize()
+    out[name + '_fwdloss'] = l2.cpu().numpy()
+    for rep in range(3):
+        eng.train_step(pb, lr=1e-3)
+    torch.cuda.synchronize()
+    out[name + '_params'] = eng.params.cpu().numpy().copy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def _run(tmp_path, tag, **env):
+    f = str(tmp_path / (tag + '.npz'))
+    e = dict(os.environ, PP_DETERMINISTIC='0', **env)
+    subprocess.run([sys.executable, '-c', SCRIPT % dict(repo=REPO), f], check=True, env=e, timeout=900)
+    return dict(np.load(f))
+
+
+def _compare(a, b, tag):
+    for k in b:
+        if k.endswith('loss'):
+            assert abs(float(a[k][0]) - float(b[k][0])) <= 2e-6 * abs(float(b[k][0])), (tag, k, a[k], b[k])
+        elif k.endswith('_grads'):
+            assert rel_err(a[k], b[k]) < 2e-5, (tag, k, rel_err(a[k], b[k]))
+            # per 1024-float chunk (a tensor region): a column block that went missing shows up here, not in the global norm
+            x, y = a[k].reshape(-1, 1024), b[k].reshape(-1, 1024)
+            scale = np.abs(y).max(1) + 1e-12
+            big = scale > 1e-6
+            worst = (np.abs(x - y).max(1)[big] / scale[big])
+            assert worst.max() < 5e-4, (tag, k, int(np.argmax(worst)), float(worst.max()))
+            # chunks that are zero in the reference path are zero here too (nothing written where no gradient belongs)
+            assert np.abs(x[~big]).max(initial=0.0) < 1e-6, (tag, k)
+        else:   # parameters after three Adam steps (Adam amplifies round-off of tiny gradients: looser)
+            assert rel_err(a[k], b[k]) < 2e-3, (tag, k, rel_err(a[k], b[k]))
+
+
+@pytest.fixture(scope='module')
+def legacy(tmp_path_factory):
+    return _run(tmp_path_factory.mktemp('legacy'), 'legacy', PP_ADDR_BIAS='0')
+
+
+def test_compact_rows_match_the_full_width_path(tmp_path, legacy):
+    _compare(_run(tmp_path, 'compact'), legacy, 'default')
+
+
+@pytest.mark.parametrize('env', [
+    {'PP_FUSE_CELL': '0'},                                   # bias epilogue only, stand-alone cell kernels
+    {'PP_FUSE_CELL_BWD': '0'},                               # stand-alone cell backward, group sums by the column-sum launch
+    {'PP_AUX_COLSUM': '0'},                                  # column sums as their own launch, derived jobs behind the tiles
+    {'PP_AUX_FUSED': '0'},                                   # all reduction jobs as their own launch
+    {'PP_FUSE_CELL': '0', 'PP_FUSE_CELL_BWD': '0', 'PP_AUX_FUSED': '0'},
+])
+def test_each_fusion_switch_is_result_neutral(tmp_path, legacy, env):
+    _compare(_run(tmp_path, 'sw', **env), legacy, str(env))
