@@ -88,44 +88,71 @@ __device__ __forceinline__ bool addr_present(const uint32_t (&mask)[32], int all
     return all || ((mask[(a >> 5) & 31] >> (a & 31)) & 1u);
 }
 
-// block bb of the bias job: address bb / nchunk, rows (bb % nchunk) * nt .. of W_ih; one thread per row
-__device__ __forceinline__ void addr_bias_block(const AddrBias& ab, int bb, float* lds /* >= 160 floats */) {
-    const int nt = blockDim.x, tid = threadIdx.x;
-    const int nchunk = (ab.N + nt - 1) / nt;
-    const int a = bb / nchunk, n = (bb % nchunk) * nt + tid;
+constexpr int ADDR_BIAS_ROWS = 32;                       // rows of W_ih per workgroup of the bias job
+constexpr int ADDR_BIAS_LDS = 32 * (2 * 128 + 1) + 128;  // floats of LDS it needs at most (ne <= 128)
+static inline int addr_bias_blocks(const AddrBias& ab) { return ab.n_addr * ((ab.N + ADDR_BIAS_ROWS - 1) / ADDR_BIAS_ROWS); }
+
+// Workgroup bb of the bias job (256 threads): address bb / nchunk, rows (bb % nchunk) * 32 .. + 31 of W_ih. The rows'
+// table columns [c2, I) (2 ne contiguous floats per row) come in with coalesced 16-byte loads, all issued before the first
+// LDS store (one memory round trip); thread (row, part) then takes an eighth of the two dot products from LDS and the
+// eight partial sums meet through DPP. Needs ldw, c2 and ne to be multiples of 4, 2 and 2 (engine.hip checks).
+__device__ __forceinline__ void addr_bias_block(const AddrBias& ab, int bb, float* lds) {
+    const int tid = threadIdx.x;
+    const int nchunk = (ab.N + ADDR_BIAS_ROWS - 1) / ADDR_BIAS_ROWS;
+    const int a = bb / nchunk, n0 = (bb % nchunk) * ADDR_BIAS_ROWS;
     if (a >= ab.n_addr || !addr_present(ab.present, ab.all_present, a)) return;   // workgroup-uniform
-    const int nd = ab.c3 - ab.c2, na = ab.c4 - ab.c3, ne = nd + na;   // [d_a ; a_a]
+    const int nd = ab.c3 - ab.c2, ne = ab.c4 - ab.c2;   // [d_a ; a_a]
+    const int ncol = 2 * ne, q4 = ncol >> 2, ss = ncol + 1;
+    float* S = lds;                          // [32][2 ne + 1]
+    float* ev = lds + ADDR_BIAS_ROWS * ss;   // [ne]
     const float* dt = ab.params + ab.at[a * PP_ADDR_TABLE_COLS + PP_AT_DTYPE_EMB];
     const float* ad = ab.params + ab.at[a * PP_ADDR_TABLE_COLS + PP_AT_ADDR_EMB];
-    for (int k = tid; k < ne; k += nt) lds[k] = k < nd ? dt[k] : ad[k - nd];
-    __syncthreads();
-    if (n >= ab.N) return;
-    const float* w = ab.W + (int64_t)n * ab.ldw;
-    float sp0 = 0.0f, sp1 = 0.0f, sc0 = 0.0f, sc1 = 0.0f;
-    int k = 0;
-    if (((ab.ldw | ab.c2 | ab.c4) & 3) == 0) {
-        for (; k + 8 <= ne; k += 8) {
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(w + ab.c2 + k), p1 = *reinterpret_cast<const f32x4*>(w + ab.c2 + k + 4);
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(w + ab.c4 + k), q1 = *reinterpret_cast<const f32x4*>(w + ab.c4 + k + 4);
+    constexpr int U = 8;   // 16-byte pieces per thread: 32 rows x 2 ne / 4 <= 2048
+    f32x4 v[U];
+    const int total = ADDR_BIAS_ROWS * q4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sp0 += p0[e] * lds[k + e];
-                sp1 += p1[e] * lds[k + 4 + e];
-                sc0 += q0[e] * lds[k + e];
-                sc1 += q1[e] * lds[k + 4 + e];
-            }
+    for (int u = 0; u < U; ++u) {
+        const int i = min(tid + 256 * u, total - 1);
+        const int r = i / q4, c = i - r * q4;
+        const int n = min(n0 + r, ab.N - 1);
+        v[u] = *reinterpret_cast<const f32x4*>(ab.W + (int64_t)n * ab.ldw + ab.c2 + 4 * c);
+    }
+    float e0 = 0.0f;
+    if (tid < ne) e0 = tid < nd ? dt[tid] : ad[tid - nd];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = tid + 256 * u;
+        if (i < total) {
+            const int r = i / q4, c = i - r * q4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[r * ss + 4 * c + e] = v[u][e];
         }
     }
-    for (; k < ne; ++k) {
-        sp0 += w[ab.c2 + k] * lds[k];
-        sc0 += w[ab.c4 + k] * lds[k];
+    if (tid < ne) ev[tid] = e0;
+    __syncthreads();
+    const int row = tid >> 3, part = tid & 7;
+    const int per = (ne + 7) >> 3;
+    const int k0 = part * per, k1 = min(ne, k0 + per);
+    const float* sr = S + row * ss;
+    float sp = 0.0f, sc = 0.0f;
+    for (int k = k0; k < k1; ++k) {
+        sp += sr[k] * ev[k];
+        sc += sr[ne + k] * ev[k];
     }
-    float* out = ab.AB + (int64_t)a * 2 * ab.N;
-    out[n] = (sc0 + sc1) + (ab.b_ih[n] + ab.b_hh[n]);
-    out[ab.N + n] = sp0 + sp1;
-    float* gs = ab.gsum + (int64_t)a * 2 * ab.N;
-    gs[n] = 0.0f;
-    gs[ab.N + n] = 0.0f;
+    // sum over the eight lanes of a row: xor 1, xor 2 inside the quad, then the neighbouring quad (lanes with part < 4 end
+    // with the total; part 0 writes)
+    sp += dpp_mov<0xB1>(sp); sc += dpp_mov<0xB1>(sc);
+    sp += dpp_mov<0x4E>(sp); sc += dpp_mov<0x4E>(sc);
+    sp += dpp_mov<0x124>(sp); sc += dpp_mov<0x124>(sc);
+    const int n = n0 + row;
+    if (part == 0 && n < ab.N) {
+        float* out = ab.AB + (int64_t)a * 2 * ab.N;
+        out[n] = sc + (ab.b_ih[n] + ab.b_hh[n]);
+        out[ab.N + n] = sp;
+        float* gs = ab.gsum + (int64_t)a * 2 * ab.N;
+        gs[n] = 0.0f;
+        gs[ab.N + n] = 0.0f;
+    }
 }
 
 // kernels.hip / obs_embed.hip (host launchers shared by engine.hip and is_kernels.hip)

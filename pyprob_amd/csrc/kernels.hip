@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void lstm_input_gather_kernel(
     const int32_t* __restrict__ addr, const int32_t* __restrict__ prev_row, int32_t fixed_addr,
     int32_t fixed_prev_addr, int n_rows, float* __restrict__ X, int64_t ldx, float* __restrict__ zero_like,
     float* __restrict__ zero_small, int n_small, int xcols, const AddrBias ab) {
-    __shared__ float ab_lds[192];
+    __shared__ float ab_lds[ADDR_BIAS_LDS];
     if (ab.AB && (int)blockIdx.x >= ab.first_block) {   // extra workgroups: per-address bias vectors (gather.hpp)
         addr_bias_block(ab, (int)blockIdx.x - ab.first_block, ab_lds);
         return;
@@ -267,7 +267,7 @@ int lstm_input_gather(const pp_net* net, const float* params, const float* E, in
     if (bias && bias->AB) {
         ab = *bias;
         ab.first_block = blocks;
-        blocks += ab.n_addr * cdiv(ab.N, 256);
+        blocks += addr_bias_blocks(ab);
     }
     hipLaunchKernelGGL(lstm_input_gather_kernel, dim3(blocks), dim3(256), 0, st, d, params, net->addr_table, E, e_stride,
                        trace, value, addr, prev_row, fixed_addr, fixed_prev_addr, n_rows, X, ldx, zero_like, zero_small, n_small,

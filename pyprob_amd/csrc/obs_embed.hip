@@ -349,7 +349,7 @@ int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int
     if (bias && bias->AB) {   // the bias job rides in this launch as extra workgroups
         ab = *bias;
         ab.first_block = blocks;
-        blocks += ab.n_addr * cdiv(ab.N, 256);
+        blocks += addr_bias_blocks(ab);
     }
     hipLaunchKernelGGL(obs_embed_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat,
                        f1, E, rb, ab);

@@ -114,5 +114,7 @@ def test_deterministic_mode_is_bitwise_repeatable(tmp_path):
             assert np.array_equal(d1['%s_loss_0' % name], d1['%s_loss_%d' % (name, rep)])
         assert np.array_equal(d1[name + '_params'], d2[name + '_params'])          # across processes
         assert np.array_equal(d1['%s_grads_0' % name], d2['%s_grads_0' % name])
-        assert rel_err(d1['%s_grads_0' % name], fast['%s_grads_0' % name]) < 2e-5
+        # (the default mode associates the forward sums differently - compact LSTM input rows - and the proposal-bias
+        # gradients are heavily cancelled sums: tests/test_gpu_compact.py)
+        assert rel_err(d1['%s_grads_0' % name], fast['%s_grads_0' % name]) < 1e-4
         assert abs(float(d1['%s_loss_0' % name][0]) - float(fast['%s_loss_0' % name][0])) < 1e-5 * abs(float(fast['%s_loss_0' % name][0]))
