@@ -18,7 +18,7 @@ struct ColsumJob {
 constexpr int AUX_MAX_COLSUM = 24;
 constexpr int AUX_COLSUM_ROWS = 64;    // rows per column-sum workgroup
 constexpr int AUX_OUTER_ROWS = 16;     // rows of dW_ih per workgroup of the outer-product job
-constexpr int AUX_TABLE_ROWS = 256;    // rows of W_ih per workgroup of the table-gradient job
+constexpr int AUX_TABLE_ROWS = 128;    // rows of W_ih per workgroup of the table-gradient job
 constexpr int AUX_DBSUM_ROWS = 256;
 
 struct AuxJobs {
@@ -133,14 +133,28 @@ __device__ __forceinline__ void aux_table_block(const AuxJobs& j, int local, flo
     const float* gs = j.gsum + (int64_t)a * 2 * j.N;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // columns lane, lane + 64, ... of the run [c2, c2 + 2 ne)
     const int n1 = min(j.N, (chunk + 1) * AUX_TABLE_ROWS);
-    for (int n = chunk * AUX_TABLE_ROWS + wave; n < n1; n += nw) {
-        const float g0 = gs[n], g1 = gs[j.N + n];
-        const float* w = j.W + (int64_t)n * j.ldw + j.c2;
+    // eight rows per trip, every load of the trip issued before the first multiply (a row at a time would pay one memory
+    // round trip per row: measured 40 us for this job)
+    for (int nb = chunk * AUX_TABLE_ROWS + wave; nb < n1; nb += 8 * nw) {
+        float g0[8], g1[8], wv[8][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = lane + 64 * q;
-            if (col < ncol) acc[q] += w[col] * (col < j.ne ? g1 : g0);
+        for (int u = 0; u < 8; ++u) {
+            const int n = nb + u * nw;
+            const int nn = min(n, n1 - 1);
+            g0[u] = gs[nn];
+            g1[u] = gs[j.N + nn];
+            if (n >= n1) { g0[u] = 0.0f; g1[u] = 0.0f; }
+            const float* w = j.W + (int64_t)nn * j.ldw + j.c2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = lane + 64 * q;
+                wv[u][q] = col < ncol ? w[col] : 0.0f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += wv[u][q] * ((lane + 64 * q) < j.ne ? g1[u] : g0[u]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

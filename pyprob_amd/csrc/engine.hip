@@ -152,7 +152,7 @@ static bool compact_rows(const pp_net* net) {
     static const int env = getenv("PP_ADDR_BIAS") ? atoi(getenv("PP_ADDR_BIAS")) : 1;
     if (!env || deterministic_mode() || net->lstm_dim == 0) return false;
     const int c2 = net->e_obs + net->smp_dim, ne = net->dtype_dim + net->addr_dim;
-    return net->lstm_in % 4 == 0 && c2 % 4 == 0 && net->lstm_dim % 16 == 0 && ne >= 1 && ne <= 128 && net->n_addr >= 1 &&
+    return net->lstm_in % 4 == 0 && c2 % 4 == 0 && net->lstm_dim % 16 == 0 && ne >= 2 && ne % 2 == 0 && ne <= 128 && net->n_addr >= 1 &&
            net->n_addr <= 1024 && net->addr_table != nullptr;
 }
 static int env_flag(const char* name, int dflt) {

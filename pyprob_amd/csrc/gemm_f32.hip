@@ -468,15 +468,14 @@ struct AsyncOperand {
 // common.hpp): every row gets the bias vectors of its current and its previous address; with cell_H > 0 the tile holds
 // the four gates of 16 hidden units, and rows of a trace's first time step (c_prev = 0, inference_network_lstm.py:186)
 // go through the LSTM cell right here - pre-activations never travel to HBM and back, lstm_cell_fwd is not launched.
-__device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt& x, const f32x16& acc, const int m0,
-                                              const int bx, const int wm, const int wn, const int l31, const int h,
-                                              float* smem) {
+// (the bias of this lane's 16 accumulator rows: two dependent memory round trips - address ids, then the vectors - which
+// the tile starts BEFORE its K loop so that they overlap the operand DMA)
+__device__ __forceinline__ void lstm_row_bias(const GemmParams& p, const GemmExt& x, const int m0, const int bx, const int wm,
+                                              const int wn, const int l31, const int h, float (&rbv)[16]) {
     const int H = x.cell_H;
     const int nloc = wn * 32 + l31;
     const int gn = H ? (nloc >> 4) * H + bx * 16 + (nloc & 15) : bx * 64 + nloc;
-    const bool ncol = gn < p.N;
-    const int gnc = ncol ? gn : 0;
-    const bool fused = H > 0 && m0 < x.cell_rows;   // workgroup-uniform
+    const int gnc = gn < p.N ? gn : 0;
     int ia[16], ip[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -486,13 +485,25 @@ __device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) ip[r] = ip[r] >= 0 ? x.rb_addr[ip[r]] : -1;
-    float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float b = x.rb[(int64_t)(2 * ia[r]) * p.N + gnc];
         if (ip[r] >= 0) b += x.rb[(int64_t)(2 * ip[r] + 1) * p.N + gnc];
-        v[r] = acc[r] + b;
+        rbv[r] = b;
     }
+}
+
+__device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt& x, const f32x16& acc, const int m0,
+                                              const int bx, const int wm, const int wn, const int l31, const int h,
+                                              float* smem, const float (&rbv)[16]) {
+    const int H = x.cell_H;
+    const int nloc = wn * 32 + l31;
+    const int gn = H ? (nloc >> 4) * H + bx * 16 + (nloc & 15) : bx * 64 + nloc;
+    const bool ncol = gn < p.N;
+    const bool fused = H > 0 && m0 < x.cell_rows;   // workgroup-uniform
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + rbv[r];
     if (!fused) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -590,6 +601,9 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+    const bool lstm = KW == 1 && !A_KM && !B_KM && x && x->rb;   // LSTM input product (workgroup-uniform)
+    float rbv[16];
+    if (lstm) lstm_row_bias(p, *x, m0, bx, wm, wn, l31, h, rbv);
 
     // k-gather lists of this workgroup's K range, clamped to the last valid entry, one extra slab of padding
     int32_t* kia = reinterpret_cast<int32_t*>(smem + ST * AS_STAGE);
@@ -727,8 +741,8 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] += part[r * 64 + lane];
     }
-    if (KW == 1 && !A_KM && !B_KM && x && x->rb) {   // LSTM input product (workgroup-uniform)
-        lstm_epilogue(p, *x, acc[0][0], m0, bx, wm, wn, l31, h, smem);
+    if (lstm) {
+        lstm_epilogue(p, *x, acc[0][0], m0, bx, wm, wn, l31, h, smem, rbv);
         return;
     }
     tile_epilogue<64, 64, 32, 32, 1, 1>(p, acc, m0, n0, wm, wn, l31, h, bz, split);
@@ -1065,6 +1079,21 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // cell backward in the epilogue (below): this thread's gates and cell state are fetched now - row gather index, then
+    // four 16-byte loads: two dependent round trips that would otherwise sit at the end of the kernel
+    const bool cellbw = !A_KM && B_KM && x && x->bw_G;   // workgroup-uniform
+    f32x4 pgi = {0.f, 0.f, 0.f, 0.f}, pgg = pgi, pgo = pgi, pcc = pgi;
+    if (cellbw) {
+        const int prow = m0 + (tid >> 3), pc4 = (tid & 7) * 4;
+        if (prow < p.M && n0 + pc4 < p.N) {
+            const int64_t pcm = p.c_idx ? (int64_t)p.c_idx[prow] : (int64_t)prow;
+            const float* g = x->bw_G + pcm * 4 * x->bw_H + n0 + pc4;
+            pgi = *reinterpret_cast<const f32x4*>(g);
+            pgg = *reinterpret_cast<const f32x4*>(g + 2 * x->bw_H);
+            pgo = *reinterpret_cast<const f32x4*>(g + 3 * x->bw_H);
+            pcc = *reinterpret_cast<const f32x4*>(x->bw_C + pcm * x->bw_H + n0 + pc4);
+        }
+    }
     DirectOperand<A_KM, VEC> oa;
     DirectOperand<B_KM, VEC> ob;
     oa.init(p.A, p.lda, p.a_idx, m0, p.M, lane, red + wave * DSLAB);
@@ -1121,7 +1150,7 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
     }
     const bool rowok = gm < p.M;
     const int64_t cm = rowok ? (p.c_idx ? (int64_t)p.c_idx[gm] : (int64_t)gm) : 0;
-    if (!A_KM && B_KM && x && x->bw_G) {   // workgroup-uniform
+    if (cellbw) {
         // The tile is dh of 32 single-statement rows x 32 hidden units (dH = dZ1 W1, all rows of one address): run the
         // LSTM cell backward here (no dc carry, c_prev = 0: lstm_cell_bwd_kernel with n_next = 0, c_prev = NULL) - the
         // gates in bw_G become dG in place, dH is never stored - and add the tile's column sums of dG to the address's
@@ -1130,10 +1159,7 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
         float d0[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f}, d3[4] = {0.f, 0.f, 0.f, 0.f};
         if (rowok && n0 + c4 < p.N) {   // (N = H is a multiple of 4: all four columns or none)
             float* g = x->bw_G + cm * 4 * H + n0 + c4;
-            const f32x4 gi = *reinterpret_cast<const f32x4*>(g);
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 2 * H);
-            const f32x4 go = *reinterpret_cast<const f32x4*>(g + 3 * H);
-            const f32x4 cc = *reinterpret_cast<const f32x4*>(x->bw_C + cm * H + n0 + c4);
+            const f32x4 gi = pgi, gg = pgg, go = pgo, cc = pcc;   // (fetched before the K loop)
             f32x4 o0, o2, o3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
