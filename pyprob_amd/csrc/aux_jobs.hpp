@@ -15,7 +15,7 @@ struct ColsumJob {
     const float* wgt; int64_t ldw; int out_stride;   // optional per-row weight; out_stride 0 = dense
 };
 
-constexpr int AUX_MAX_COLSUM = 24;
+constexpr int AUX_MAX_COLSUM = 48;   // (48 x 72 bytes of kernel arguments; with GroupedParams ~7.5 KB per launch)
 constexpr int AUX_COLSUM_ROWS = 64;    // rows per column-sum workgroup
 constexpr int AUX_OUTER_ROWS = 16;     // rows of dW_ih per workgroup of the outer-product job
 constexpr int AUX_TABLE_ROWS = 128;    // rows of W_ih per workgroup of the table-gradient job

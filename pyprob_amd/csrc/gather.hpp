@@ -139,11 +139,10 @@ __device__ __forceinline__ void addr_bias_block(const AddrBias& ab, int bb, floa
         sp += sr[k] * ev[k];
         sc += sr[ne + k] * ev[k];
     }
-    // sum over the eight lanes of a row: xor 1, xor 2 inside the quad, then the neighbouring quad (lanes with part < 4 end
-    // with the total; part 0 writes)
+    // sum over the eight lanes of a row: xor 1, xor 2 inside the quad (DPP), then the other quad of the row
     sp += dpp_mov<0xB1>(sp); sc += dpp_mov<0xB1>(sc);
     sp += dpp_mov<0x4E>(sp); sc += dpp_mov<0x4E>(sc);
-    sp += dpp_mov<0x124>(sp); sc += dpp_mov<0x124>(sc);
+    sp += __shfl_xor(sp, 4, 64); sc += __shfl_xor(sc, 4, 64);
     const int n = n0 + row;
     if (part == 0 && n < ab.N) {
         float* out = ab.AB + (int64_t)a * 2 * ab.N;

@@ -31,52 +31,7 @@ const char* last_error() { return g_err; }
 constexpr int COLSUM_ROWS = 64;
 constexpr int COLSUM_MAX_JOBS = 48;   // (48 x 72 bytes: the by-value kernel arguments stay under 4 KB; 16 made 5 launches of a 12-address step)
 
-struct ColsumJobs {   // (ColsumJob: aux_jobs.hpp)
-    ColsumJob j[COLSUM_MAX_JOBS];
-};
 int loss_finalize(const float* acc, const int32_t* flag, int n_traces, float* loss_out, int32_t* status_out, hipStream_t st);
-
-// blockIdx.z selects the job: several independent column reductions (bias / embedding-table gradients) per launch
-__global__ __launch_bounds__(256) void colsum_kernel(const ColsumJobs jobs, const LossFinalize fin) {
-    __shared__ float part[4][64];
-    // (FeedForward network: this launch of the backward pass also turns the loss slots into the loss)
-    if (fin.acc && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) loss_finalize_inline(fin);
-    const ColsumJob& jb = jobs.j[blockIdx.z];
-    const int n_rows = jb.n_rows, n_cols = jb.n_cols;
-    const int tid = threadIdx.x;
-    const int cl = tid & 63, rl = tid >> 6;
-    const int col = blockIdx.x * 64 + cl;
-    const int r0 = blockIdx.y * COLSUM_ROWS;
-    if (blockIdx.x * 64 >= n_cols || r0 >= n_rows) return;   // this job is smaller than the launch grid
-    const float* __restrict__ X = jb.X;
-    const int32_t* __restrict__ idx = jb.idx;
-    const int64_t ldx = jb.ldx;
-    const float* __restrict__ wgt = jb.wgt;
-    float acc = 0.0f;
-    if (col < n_cols) {
-        // 16 rows per lane, all loads issued before the adds (independent addresses: latency overlaps)
-        float v[COLSUM_ROWS / 4];
-#pragma unroll
-        for (int q = 0; q < COLSUM_ROWS / 4; ++q) {
-            const int i = r0 + rl + 4 * q;
-            v[q] = 0.0f;
-            if (i < n_rows) {
-                const int64_t r = idx ? (int64_t)idx[i] : (int64_t)i;
-                v[q] = X[r * ldx + col];
-                if (wgt) v[q] *= wgt[(int64_t)i * jb.ldw];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < COLSUM_ROWS / 4; ++q) acc += v[q];
-    }
-    part[rl][cl] = acc;
-    __syncthreads();
-    if (rl == 0 && col < n_cols) {
-        const float s = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
-        atomicAdd(jb.out + (int64_t)col * (jb.out_stride ? jb.out_stride : 1), s);
-        if (jb.out2) atomicAdd(jb.out2 + col, s);
-    }
-}
 
 // Deterministic variant (PP_DETERMINISTIC): workgroup (column block, group) owns its 64 destination columns - ONE
 // writer - and walks the jobs of its group (all jobs with the same destination) in order; each thread sums its rows
@@ -161,25 +116,26 @@ int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st, const float* 
         if (fin_acc) return loss_finalize(fin_acc, fin_flag, fin_traces, fin_loss, fin_status, st);
         return 0;
     }
+    // One workgroup per (job, 64 columns, 64 rows) that exists - the job list of aux_jobs.hpp as its own launch. (A launch
+    // grid shaped by the LARGEST job, as before, started 24 000 workgroups for the 48 jobs of a ragged 12-address step,
+    // most of which only found out that their job was smaller: 23-29 us per launch.)
     LossFinalize fin{fin_acc, fin_flag, fin_traces > 0 ? 1.0f / (float)fin_traces : 0.0f, fin_loss, fin_status};
     int i = 0;
+    bool launched = false;
     while (i < count) {
-        ColsumJobs pack;
-        int n = 0, max_rows = 0, max_cols = 0;
-        for (; i < count && n < COLSUM_MAX_JOBS; ++i) {
+        AuxJobs pack{};
+        for (; i < count && pack.n_colsum < AUX_MAX_COLSUM; ++i) {
             if (jobs[i].n_rows <= 0 || jobs[i].n_cols <= 0) continue;
             PP_CHECK_ARG(jobs[i].X && jobs[i].out, "pp_colsum_f32: null pointer");
-            pack.j[n++] = jobs[i];
-            max_rows = std::max(max_rows, jobs[i].n_rows);
-            max_cols = std::max(max_cols, jobs[i].n_cols);
+            pack.cs[pack.n_colsum++] = jobs[i];
         }
-        if (n == 0) continue;
-        dim3 grid(cdiv(max_cols, 64), cdiv(max_rows, COLSUM_ROWS), n);
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, pack, fin);
-        PP_LAUNCH_CHECK("pp_colsum_f32");
-        fin.acc = nullptr;      // only the first launch finalises
+        if (pack.n_colsum == 0) continue;
+        if (!launched) pack.fin = fin;      // only the first launch finalises
+        aux_layout(pack, false);
+        PP_TRY(aux_jobs_launch(pack, st));
+        launched = true;
     }
-    if (fin.acc) return loss_finalize(fin_acc, fin_flag, fin_traces, fin_loss, fin_status, st);   // (no job was launched)
+    if (!launched && fin.acc) return loss_finalize(fin_acc, fin_flag, fin_traces, fin_loss, fin_status, st);   // (no job)
     return 0;
 }
 

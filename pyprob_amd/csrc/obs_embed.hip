@@ -172,7 +172,19 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
             // LSTM input rows of this trace, one per time step it is alive in (step-major rows: row_off[t] + b): the
             // embedding just computed sits in lane c < e_obs, the address / previous-sample columns come from the tables
             // (a separate gather launch did this before: one launch and one read of E less). Also clears dX.
-            for (int t = 0; t < rb.t_max; ++t) {
+            {   // t = 0 needs no index loads: row_off[0] = 0, every trace is alive, no previous statement (pr = -1) - the
+                // columns [e_obs, c4) are zero; only full-width rows look the current address up
+                const int c4 = rb.d.e_obs + rb.d.smp + rb.d.dtype + rb.d.addr;
+                const int ad = rb.xcols > c4 ? rb.addr[b] : 0;
+                float* xr = rb.X + (int64_t)b * rb.ldx;
+                if (acte) xr[lane] = y2;
+                for (int c = rb.d.e_obs + lane; c < rb.xcols; c += 64) xr[c] = gather_embedding_elem(rb.d, rb.params, rb.at, c, -1, 0.0f, ad);
+                if (rb.zero_like) {
+                    float* zr = rb.zero_like + (int64_t)b * rb.ldx;
+                    for (int c = lane; c < rb.xcols; c += 64) zr[c] = 0.0f;
+                }
+            }
+            for (int t = 1; t < rb.t_max; ++t) {
                 const int r0 = rb.row_off[t];
                 if (b >= rb.row_off[t + 1] - r0) break;   // wave-uniform
                 const int r = r0 + b;
@@ -240,7 +252,8 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
     auto load_dz2 = [&](int b) {
         float acc = 0.0f;
         if (acte) {
-            for (int t = 0; t < t_max; ++t) {
+            acc = dX[(int64_t)b * ldx + lane];   // t = 0: row b (row_off[0] = 0, every trace is alive) - no index load
+            for (int t = 1; t < t_max; ++t) {
                 const int r0 = row_off[t];
                 if (b >= row_off[t + 1] - r0) break;
                 acc += dX[(int64_t)(r0 + b) * ldx + lane];
