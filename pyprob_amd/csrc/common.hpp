@@ -75,6 +75,10 @@ struct GemmExt {
     const float* rb; const int32_t* rb_addr; const int32_t* rb_prev;
     float* cell_c; float* cell_h; int cell_H, cell_rows;
     float* bw_G; const float* bw_C; int bw_H;
+    // lean: single-statement batch whose backward runs in the dH epilogue with the zero blocks on - nobody reads the forget
+    // gate's columns of G / dG nor the stored cell state (c = i g when c_prev = 0): they are not written (cell_c and bw_C
+    // may be null)
+    int lean;
 };
 struct AuxJobs;
 

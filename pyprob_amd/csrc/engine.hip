@@ -428,6 +428,12 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     const int c2x = net->e_obs + net->smp_dim, ne_x = net->dtype_dim + net->addr_dim;
     // single-statement batches have no previous statement at all: the sample-embedding columns are zero in every row
     const int nx = (T == 1) ? net->e_obs : c2x;
+    // (see GemmExt::lean) the cell backward of a single-statement, single-layer batch runs in the dH epilogue, and with the
+    // zero blocks on neither dX nor dW_ih read the forget gate's columns of first-step rows
+    // (H a multiple of 64: the zero blocks then cover the forget gate's tiles and slabs exactly)
+    static const bool lean_env = env_flag("PP_FUSE_CELL_BWD", 1) && env_flag("PP_FUSE_CELL", 1) && env_flag("PP_GEMM_HOLES", 1) == 1 &&
+                                 env_flag("PP_CELL_LEAN", 1);
+    const bool lean_cell = compact && bwd && T == 1 && std::max(1, (int)net->lstm_depth) == 1 && H % 64 == 0 && lean_env;
     AddrBias abias{};
     if (compact) {
         abias.AB = w.AB; abias.gsum = w.gsum;
@@ -515,6 +521,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             static const int fuse_cell = env_flag("PP_FUSE_CELL", 1);
             if (fuse_cell) {   // gate-interleaved tiles, LSTM cell of the first time step in the epilogue
                 x.cell_H = H; x.cell_rows = B; x.cell_c = w.Cl[0]; x.cell_h = w.Hl[0];
+                x.lean = lean_cell ? 1 : 0;
                 cell_done = true;
             }
             GemmHole zc{};
@@ -678,7 +685,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     if (fused_bwd) {
         GemmExt x{};
-        x.bw_G = w.Gl[0]; x.bw_C = w.Cl[0]; x.bw_H = H;
+        x.bw_G = w.Gl[0]; x.bw_C = w.Cl[0]; x.bw_H = H; x.lean = lean_cell ? 1 : 0;
         PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st, nullptr, &x));
     } else {
         PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st));

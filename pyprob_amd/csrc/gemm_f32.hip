@@ -541,10 +541,12 @@ __device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt
         }
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
         *reinterpret_cast<f32x4*>(g) = gi;
-        *reinterpret_cast<f32x4*>(g + H) = zero;
         *reinterpret_cast<f32x4*>(g + 2 * H) = gg;
         *reinterpret_cast<f32x4*>(g + 3 * H) = go;
-        *reinterpret_cast<f32x4*>(x.cell_c + (int64_t)gm * H + u0) = cn;
+        if (!x.lean) {
+            *reinterpret_cast<f32x4*>(g + H) = zero;
+            *reinterpret_cast<f32x4*>(x.cell_c + (int64_t)gm * H + u0) = cn;
+        }
         *reinterpret_cast<f32x4*>(x.cell_h + (int64_t)gm * H + u0) = hn;
     } else {                  // a later time step in the same tile: pre-activations, the recurrent product follows
         *reinterpret_cast<f32x4*>(g) = vi;
@@ -1091,7 +1093,10 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
             pgi = *reinterpret_cast<const f32x4*>(g);
             pgg = *reinterpret_cast<const f32x4*>(g + 2 * x->bw_H);
             pgo = *reinterpret_cast<const f32x4*>(g + 3 * x->bw_H);
-            pcc = *reinterpret_cast<const f32x4*>(x->bw_C + pcm * x->bw_H + n0 + pc4);
+            if (!x->lean) pcc = *reinterpret_cast<const f32x4*>(x->bw_C + pcm * x->bw_H + n0 + pc4);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pcc[e] = pgi[e] * pgg[e];   // c = i g (c_prev = 0)
         }
     }
     DirectOperand<A_KM, VEC> oa;
@@ -1173,7 +1178,7 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int 
             }
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             *reinterpret_cast<f32x4*>(g) = o0;
-            *reinterpret_cast<f32x4*>(g + H) = zero;
+            if (!x->lean) *reinterpret_cast<f32x4*>(g + H) = zero;
             *reinterpret_cast<f32x4*>(g + 2 * H) = o2;
             *reinterpret_cast<f32x4*>(g + 3 * H) = o3;
         }
@@ -1564,7 +1569,7 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
                          !a->mask && !a->colsum && !a->accumulate && !a->relu && !a->bias && !a->bias2,
                      "pp_gemm_f32: unsupported LSTM input product");
         PP_CHECK_ARG(ext->cell_H == 0 || (ext->cell_H % 16 == 0 && a->N == 4 * ext->cell_H && a->ldc % 4 == 0 && aligned16(a->C) &&
-                                          ext->cell_c && ext->cell_h),
+                                          (ext->cell_c || ext->lean) && ext->cell_h),
                      "pp_gemm_f32: bad fused-cell arguments");
         dim3 grid(cdiv(a->N, 64), cdiv(a->M, 64), 1);
         return launch_dyn(gemm_f32_async_lstm_kernel, grid, 256, as_lds_bytes(), st, &p, ext);

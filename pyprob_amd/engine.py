@@ -326,27 +326,17 @@ class ICEngine:
         if not self.dp_skip:
             allreduce_flat_(self.grads_full)
             return
-        # the pieces around the skipped ranges are staged into ONE contiguous buffer: one collective (a second one costs
-        # a full latency on 8 ranks; the four ~1 MB device copies cost ~10 us)
+        # the pieces around the skipped ranges go out as ONE collective launch without staging copies: RCCL aggregates
+        # the all-reduces issued between ncclGroupStart / ncclGroupEnd (torch's coalescing manager). (Staging the pieces
+        # into one contiguous buffer, as before, cost eight ~1 MB device copies per step: ~30 us of a 125 us step.)
         pieces, pos = [], 0
         for off, cnt in self.dp_skip:
             if off > pos:
                 pieces.append((pos, off))
             pos = off + cnt
         pieces.append((pos, self.grads_full.numel()))
-        total = sum(b - a for a, b in pieces)
-        stage = getattr(self, '_dp_stage', None)
-        if stage is None or stage.numel() != total:
-            stage = self._dp_stage = torch.empty(total, dtype=torch.float32, device=self.device)
-        o = 0
-        for a, b in pieces:
-            stage[o:o + b - a].copy_(self.grads_full[a:b])
-            o += b - a
-        allreduce_flat_(stage)
-        o = 0
-        for a, b in pieces:
-            self.grads_full[a:b].copy_(stage[o:o + b - a])
-            o += b - a
+        from .parallel import allreduce_pieces_
+        allreduce_pieces_([self.grads_full[a:b] for a, b in pieces])
 
     def reduced_status(self):
         """The all-reduced non-finite flag as the int32 word pp_adam_step's `skip` reads: a sum of 0.0 / 1.0 floats is

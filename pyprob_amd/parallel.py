@@ -20,6 +20,45 @@ def allreduce_flat_(buf):
     return buf
 
 
+def allreduce_pieces_(views):
+    """all-reduce(SUM) of several views of one flat buffer, in place, as one launch where the backend can coalesce
+    (RCCL: ncclGroupStart / ncclGroupEnd around the calls), otherwise one collective per view (gloo in the CPU tests)."""
+    import torch.distributed as dist
+    if len(views) == 1:
+        dist.all_reduce(views[0])
+        return
+    if _coalescing_works(views[0].device):
+        with dist._coalescing_manager(device=views[0].device):
+            for v in views:
+                dist.all_reduce(v)
+        return
+    for v in views:
+        dist.all_reduce(v)
+
+
+_COALESCE = {}
+
+
+def _coalescing_works(device):
+    """Probed once per process on two scratch tensors (never on the gradients: a half-issued group must not be retried)."""
+    import torch
+    import torch.distributed as dist
+    key = (dist.get_backend(), str(device))
+    if key not in _COALESCE:
+        ok = False
+        if dist.get_backend() == 'nccl' and hasattr(dist, '_coalescing_manager'):
+            try:
+                a, b = torch.ones(4, device=device), torch.ones(4, device=device)
+                with dist._coalescing_manager(device=device):
+                    dist.all_reduce(a)
+                    dist.all_reduce(b)
+                ok = bool(torch.allclose(a, torch.full_like(a, float(dist.get_world_size()))) and torch.equal(a, b))
+            except (RuntimeError, TypeError, ValueError):
+                ok = False
+        _COALESCE[key] = ok
+    return _COALESCE[key]
+
+
 def finish_reduce(buf, n_params, n_tensors, world_size):
     """After the all-reduce: averaged gradients (inference_network.py:324-325), merged presence map (:300-315: a tensor
     is updated if ANY rank produced a gradient) and mean loss (:327-333). Returns views (grads, active, loss)."""
