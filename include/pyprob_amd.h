@@ -442,6 +442,9 @@ int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_ou
  * DVFS state the timed region ran in (MI355X_MICROARCH.md "DVFS give-back"). */
 /* Diagnostic: when set, the fused head-tail kernel writes per-phase s_memtime stamps of workgroups 0 and 100 to buf. */
 int pp_debug_timeline(long long* buf /*dev [16] or NULL*/);
+/* debug: per-workgroup {start, end, problem, split, operands ready, loads issued, first slab landed, K loop done} stamps (10 ns ticks) of the grouped async GEMM launches
+ * (mode 1: weight-gradient groups, 2: data-gradient products); buf = dev int64 [8 * cap] or NULL (tools/wg_trace.py) */
+int pp_debug_wgtrace(long long* buf, int32_t cap, int32_t mode);
 int pp_debug_clock_probe(int32_t iters, long long* out /*dev [2]*/, float* sink /*dev [1]*/, void* stream);
 
 #ifdef __cplusplus

@@ -64,7 +64,8 @@ static inline bool deterministic_mode() {
 
 // Epilogue extensions of the tile kernels that the C ABI does not expose (engine.hip builds them):
 //   * rb: per-row address bias of the LSTM input product (gather.hpp, AddrBias): row m gets
-//     rb[(2 addr[m]) N + n] + (prev[m] >= 0 ? rb[(2 addr[prev[m]] + 1) N + n] : 0); async 64x64 tile only;
+//     rb[(2 addr[m]) N + n] + (prev[m] >= 0 ? rb[(2 addr[prev[m]] + 1) N + n] : 0); async 64x64 tile only
+//     (rb_addr == nullptr: one address for all rows, none has a previous statement - rb points at its vector);
 //   * cell_H > 0: the product's 64-column tiles are gate-interleaved (tile bx = hidden units [16 bx, 16 bx + 16) of all
 //     four gates) and rows < cell_rows (first time steps: c_prev = 0) get the LSTM cell applied in the epilogue:
 //     gate activations -> C, cell state -> cell_c, hidden state -> cell_h (what lstm_cell_fwd would have done);
@@ -79,6 +80,10 @@ struct GemmExt {
     // gate's columns of G / dG nor the stored cell state (c = i g when c_prev = 0): they are not written (cell_c and bw_C
     // may be null)
     int lean;
+    // split_stride > 0 (single product, async tile): exactly force_splits K splits, split z STORES its partial tile at
+    // C + z * split_stride instead of adding it with float atomics - the consumer kernel adds the splits (a 64 x 64 tile
+    // of atomics costs its workgroup 6-8 us, tools/wg_trace.py)
+    int64_t split_stride; int force_splits;
 };
 struct AuxJobs;
 

@@ -67,7 +67,7 @@ bool obs_fused_supported(const pp_net* net);
 int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
                           const float* f1, const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max,
                           const float* E, float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
-                          hipStream_t st);
+                          hipStream_t st, int n_split = 1, int64_t split_stride = 0);
 
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
@@ -155,6 +155,7 @@ static bool compact_rows(const pp_net* net) {
     return net->lstm_in % 4 == 0 && c2 % 4 == 0 && net->lstm_dim % 16 == 0 && ne >= 2 && ne % 2 == 0 && ne <= 128 && net->n_addr >= 1 &&
            net->n_addr <= 1024 && net->addr_table != nullptr;
 }
+constexpr int DX_SPLITS = 16;
 static int env_flag(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -212,7 +213,8 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.dZ1 = c.take<float>((int64_t)R * w.hid4);
     w.dH = c.take<float>((int64_t)R * H);
     w.dC = c.take<float>(ff ? 0 : (int64_t)B * H);
-    w.dX = c.take<float>(ff ? 0 : (int64_t)R * w.i4);
+    // (compact rows: room for the partial tiles of up to DX_SPLITS K splits of dX, see ic_loss)
+    w.dX = c.take<float>(ff ? 0 : (int64_t)R * w.i4 * (w.compact ? DX_SPLITS : 1));
     w.dE = c.take<float>((int64_t)B * w.e4);
     w.dF1 = c.take<float>((int64_t)B * w.e4);
     w.dCat = c.take<float>((int64_t)B * w.e4);
@@ -434,7 +436,13 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     static const bool lean_env = env_flag("PP_FUSE_CELL_BWD", 1) && env_flag("PP_FUSE_CELL", 1) && env_flag("PP_GEMM_HOLES", 1) == 1 &&
                                  env_flag("PP_CELL_LEAN", 1);
     const bool lean_cell = compact && bwd && T == 1 && std::max(1, (int)net->lstm_depth) == 1 && H % 64 == 0 && lean_env;
+    // Single-statement batch: dX = dG W_ih[:, :e_obs] has ONE consumer, the observe-embedding backward kernel; its K splits
+    // store their partial tiles and that kernel adds them - no float atomics (6-8 us per 64 x 64 tile, tools/wg_trace.py)
+    // and no cleared dX
+    static const int dx_partials_env = env_flag("PP_DX_PARTIALS", 1);
+    const bool dx_partials = compact && bwd && T == 1 && dx_partials_env && obs_fused_supported(net);
     AddrBias abias{};
+    int n_present = 0, only_addr = 0;   // addresses that occur in the batch
     if (compact) {
         abias.AB = w.AB; abias.gsum = w.gsum;
         abias.W = P + net->w_ih; abias.b_ih = P + net->b_ih; abias.b_hh = P + net->b_hh;
@@ -442,11 +450,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         abias.N = 4 * H; abias.c2 = c2x; abias.c3 = c2x + net->dtype_dim; abias.c4 = c2x + ne_x;
         abias.c5 = abias.c4 + net->dtype_dim; abias.I = I; abias.n_addr = net->n_addr;
         for (int q = 0; q < 32; ++q) abias.present[q] = 0u;
-        int n_present = 0;
         for (int a = 0; a < net->n_addr; ++a)
             if (bt->grp_off[a + 1] > bt->grp_off[a] || bt->nxt_off[a + 1] > bt->nxt_off[a]) {
                 abias.present[a >> 5] |= 1u << (a & 31);
                 ++n_present;
+                only_addr = a;
             }
         gather_bytes += (double)n_present * (4.0 * 4 * H * (2.0 * ne_x) + 4.0 * 4.0 * 4 * H);
     }
@@ -478,7 +486,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         rb.params = P; rb.at = net->addr_table; rb.row_off = bt->row_off_dev; rb.t_max = T;
         rb.value = bt->value; rb.addr = bt->addr; rb.prev_row = bt->prev_row;
         rb.X = w.X; rb.ldx = w.i4; rb.xcols = w.xc;
-        rb.zero_like = bwd ? w.dX : nullptr;
+        rb.zero_like = (bwd && !dx_partials) ? w.dX : nullptr;
         rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = n_clear;
         PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb, compact ? &abias : nullptr));
     } else {
@@ -518,6 +526,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             g.M = R; g.N = 4 * H; g.K = nx;
             GemmExt x{};
             x.rb = w.AB; x.rb_addr = bt->addr; x.rb_prev = T > 1 ? bt->prev_row : nullptr;
+            if (T == 1 && n_present == 1) {   // one address in a single-statement batch: the bias is one vector
+                x.rb = w.AB + (int64_t)only_addr * 2 * 4 * H;
+                x.rb_addr = nullptr;
+            }
             static const int fuse_cell = env_flag("PP_FUSE_CELL", 1);
             if (fuse_cell) {   // gate-interleaved tiles, LSTM cell of the first time step in the epilogue
                 x.cell_H = H; x.cell_rows = B; x.cell_c = w.Cl[0]; x.cell_h = w.Hl[0];
@@ -643,6 +655,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // column sums of dG to its address's group sums; the loss is finalised by the jobs behind the weight-gradient tiles.
     static const int fuse_cell_bwd = env_flag("PP_FUSE_CELL_BWD", 1);
     const bool fused_bwd = compact && T == 1 && L == 1 && fuse_cell_bwd;
+    int dx_splits = 1;
     auto join_side = [&]() -> int {   // the caller's stream continues only after the side stream's products
         if (!forked) return 0;
         if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) {
@@ -771,9 +784,19 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         g.B = P + net->w_ih; g.ldb = I; g.b_kmajor = 1;
         g.C = w.dX; g.ldc = w.i4;
         g.M = R; g.N = nx; g.K = 4 * H;
+        if (dx_partials) {
+            // ~3 slabs per split (the K loop is short either way; more splits = more workgroups streaming dG)
+            const int nslab = 4 * H / 32;
+            dx_splits = std::max(1, std::min(DX_SPLITS, nslab / 4));
+            GemmExt x{};
+            x.split_stride = (int64_t)R * w.i4;
+            x.force_splits = dx_splits;
+            PP_TRY(gemm_f32(&g, st, &dx_unused, &x));
+        } else {
         g.accumulate = 1;   // dX was cleared by the gather kernel
         g.split_k = 1;
         PP_TRY(gemm_f32(&g, st, &dx_unused));
+        }
         if (!fused_bwd) {   // group sums of dG by current / previous address (the fused dH epilogue produced the former)
             for (int a = 0; a < net->n_addr; ++a) {
                 const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
@@ -848,7 +871,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         // buffers
         const int64_t dhs = (int64_t)B * w.maxohid4;
         PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, dXs, ldxs, bt->row_off_dev, T, w.E, w.dE, w.dF1, w.dCat,
-                                     w.dObsH, dhs, st));
+                                     w.dObsH, dhs, st, dx_splits, (int64_t)R * w.i4));
         const int e = net->e_obs;
         queue_wgrad(wq, w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, B, e, e);
         queue_wgrad(wq, w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, B, e, e);

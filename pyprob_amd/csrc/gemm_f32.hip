@@ -42,6 +42,7 @@ struct GemmParams {
     int vec;         // grouped launch: this problem's operands allow 16-byte loads
     int vec_c;       // C rows allow 16-byte stores (direct tiles)
     int dbg_plain;   // measurement only: split partials are stored instead of added (WRONG results)
+    int64_t split_stride;   // > 0: split bz STORES its partial tile at C + bz * split_stride (the consumer adds the splits)
     // zero block (GemmHole): for output tiles inside rows [hm0, hm1) x columns [hn0, hn1) the K slabs [hs0, hs1) hold
     // nothing but zeros (or the tile is not used at all) and are skipped. hs1 <= hs0: no zero block. Two blocks per
     // product; a tile inside both skips the longer slab interval.
@@ -225,8 +226,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16 (&acc)
                 float v = acc[i][j][r] + bsum;
                 float* dst = p.C + cm * p.ldc + gn;
                 if (split) {
-                    if (p.dbg_plain) *dst = v; else
-                    atomicAdd(dst, v);
+                    if (p.split_stride) dst[(int64_t)bz * p.split_stride] = v;
+                    else if (p.dbg_plain) *dst = v;
+                    else atomicAdd(dst, v);
                 } else {
                     if (p.relu) v = relu_keep_nan(v);
                     if (p.mask) v = (p.mask[cm * p.ldmask + gn] > 0.0f) ? v : 0.0f;
@@ -476,6 +478,12 @@ __device__ __forceinline__ void lstm_row_bias(const GemmParams& p, const GemmExt
     const int nloc = wn * 32 + l31;
     const int gn = H ? (nloc >> 4) * H + bx * 16 + (nloc & 15) : bx * 64 + nloc;
     const int gnc = gn < p.N ? gn : 0;
+    if (!x.rb_addr) {   // every row has the same current address and no previous one: rb IS its bias vector (one load)
+        const float b = x.rb[gnc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rbv[r] = b;
+        return;
+    }
     int ia[16], ip[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -563,8 +571,9 @@ __device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt
 // workgroup per CU.
 template <bool A_KM, bool B_KM, int KW>
 __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
-                                                float* smem, const GemmExt* x = nullptr) {
+                                                float* smem, const GemmExt* x = nullptr, long long* tr = nullptr) {
     constexpr int ST = AS_STAGES;
+#define AS_STAMP(k) do { if (tr && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); tr[k] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
     constexpr int NP = 2 / KW;        // DMA pieces per thread per operand per slab
     constexpr int D = 2 * NP;         // DMA instructions per thread per slab
     constexpr int NS = 4 / KW;        // 8-wide k sub-slabs per wave per slab
@@ -593,7 +602,15 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     const int per = (nslab_total + nz - 1) / nz;
     const int s_begin = bz * per;
     const int T = min(nslab_total, s_begin + per) - s_begin;
-    if (T <= 0) return;
+    if (T <= 0) {
+        if (p.split_stride && nz > 1) {   // a split without slabs still owns its partial tile: zeros (workgroup-uniform)
+            for (int e = tid; e < 64 * 64; e += 256 * KW) {
+                const int gm = m0 + (e >> 6), gn = n0 + (e & 63);
+                if (gm < p.M && gn < p.N) p.C[(int64_t)bz * p.split_stride + (int64_t)gm * p.ldc + gn] = 0.0f;
+            }
+        }
+        return;
+    }
     const bool split = nz > 1;
     // slab t of this workgroup = entry s_begin + t of the sequence without the zero block; srel(t) counts from its first
     auto slab_of = [&](int t) { const int u = s_begin + t; return u < hs0 ? u : u + hlen; };
@@ -672,11 +689,14 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
     // MFMAs of slab i run (the reads are independent of the MFMA chain and issue in its shadow), slabs i+2 .. i+ST-1
     // are in flight, and slab i+ST is started into the image slab i just vacated.
     static_assert(ST == 4, "ring depth");
+    AS_STAMP(4);
 #pragma unroll
     for (int t = 0; t < ST; ++t)
         if (t < T) issue(t);
     float a0[NS][4], b0[NS][4], a1[NS][4], b1[NS][4];
+    AS_STAMP(5);
     wait_younger(min(T - 1, ST - 1));
+    AS_STAMP(6);
     load_frags(0, a0, b0);
     // One steady-state slab: the MFMAs of the slab in (ca, cb), with the fragment reads of slab tn (-> na, nb) and the
     // DMA of slab td dealt out one per MFMA (the MFMAs form a dependent chain, 64 cycles each, and the wave issues in
@@ -731,6 +751,7 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int b
         }
         mma_edge(i + 1, a1, b1);
     }
+    AS_STAMP(7);
     if (KW == 2) {   // waves 4..7 hand their partial fragment to waves 0..3
         __syncthreads();   // the ring is free
         float* part = smem + w4 * 1024;
@@ -847,7 +868,18 @@ struct GroupedParams {
     int count;
     int xcd_aware;
     GemmExt ext;                // shared by the problems of the launch (cell backward in the dH epilogue)
+    long long* trace;           // debug (pp_debug_wgtrace): per workgroup {start, end} wall-clock ticks (10 ns), problem, split
 };
+long long* g_wgtrace = nullptr;   // device buffer [8 x workgroups] or nullptr
+int g_wgtrace_cap = 0, g_wgtrace_mode = 0;
+__device__ __forceinline__ void wg_trace(const GroupedParams& g, int slot, long long t0, int q, int bz) {
+    if (g.trace && threadIdx.x == 0) {
+        g.trace[8 * slot + 0] = t0;
+        g.trace[8 * slot + 1] = wall_clock64();
+        g.trace[8 * slot + 2] = q;
+        g.trace[8 * slot + 3] = bz;
+    }
+}
 
 // Workgroup -> (problem, tile, K split). Workgroups are dealt round-robin to the 8 XCDs (id % 8) and each XCD has its
 // own 4 MB L2; every problem starts at a workgroup id that is a multiple of 8, so local id & 7 IS the XCD.
@@ -1315,23 +1347,28 @@ static int launch_direct_grouped(const GroupedParams& g, bool akm, bool bkm, hip
 
 template <bool A_KM, bool B_KM, int KW>
 __global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_kernel(const GroupedParams g) {
+    const long long t0 = g.trace ? wall_clock64() : 0;
     warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
-    gemm_tile_async<A_KM, B_KM, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring);
+    gemm_tile_async<A_KM, B_KM, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring, nullptr, g.trace ? g.trace + 8 * blockIdx.x : nullptr);
+    wg_trace(g, blockIdx.x, t0, q, bz);
 }
 
 template <int KW>
 __global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_aux_kernel(const GroupedParams g, const AuxJobs aux) {
+    const long long t0 = g.trace ? wall_clock64() : 0;
     const int nb = g.first[g.count];
     if ((int)blockIdx.x >= nb) {   // behind the tiles: the small reduction jobs (aux_jobs.hpp)
         aux_job_run(aux, (int)blockIdx.x - nb, as_ring);
+        wg_trace(g, blockIdx.x, t0, 100 + (((int)blockIdx.x - nb) < aux.cs_first[aux.n_colsum] ? 0 : 1), 0);
         return;
     }
     warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
-    gemm_tile_async<true, true, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring);
+    gemm_tile_async<true, true, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring, nullptr, g.trace ? g.trace + 8 * blockIdx.x : nullptr);
+    wg_trace(g, blockIdx.x, t0, q, bz);
 }
 
 // The ring is dynamic LDS (ST x 16 KB = 64 KB: two workgroups per CU).
@@ -1454,6 +1491,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.colsum = a->colsum;
     static const int plain = getenv("PP_DBG_PLAIN_SPLIT") ? atoi(getenv("PP_DBG_PLAIN_SPLIT")) : 0;
     p.dbg_plain = plain;
+    p.split_stride = 0;
     clear_holes(p);
     p.vec = 1;
     p.vec_c = (a->ldc % 4 == 0 && aligned16(a->C)) ? 1 : 0;
@@ -1544,6 +1582,7 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
     static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
     GroupedParams g;
     g.ext = GemmExt{};
+    g.trace = nullptr;
     g.xcd_aware = xcd;
     g.count = 1;
     g.p[0] = p;
@@ -1552,6 +1591,8 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
     g.pmode[0] = pick_pmode(p.M, p.N, g.gx[0], g.gy[0]);
     g.first[0] = 0;
     g.first[1] = group_blocks(g.gx[0], g.gy[0], splits, g.pmode[0]);
+    if (g_wgtrace && ((g_wgtrace_mode == 1 && akm && bkm) || (g_wgtrace_mode == 2 && !akm && bkm)) && g.first[1] <= g_wgtrace_cap)
+        g.trace = g_wgtrace;
     return kind == 1 ? launch_direct_grouped(g, akm, bkm, st)
          : kind == 2 ? launch_async_grouped(g, akm, bkm, st) : launch_grouped<4>(g, akm, bkm, st);
 }
@@ -1565,7 +1606,7 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
     set_hole(p, hole);
     const bool vec = vec_ok(a);
     if (ext && ext->rb) {   // the LSTM input product: its epilogue exists in the async 64x64 tile only
-        PP_CHECK_ARG(ext->rb_addr && vec && a->K >= 1 && !a->a_kmajor && !a->b_kmajor && !a->a_idx && !a->b_idx && !a->c_idx &&
+        PP_CHECK_ARG((ext->rb_addr || !ext->rb_prev) && vec && a->K >= 1 && !a->a_kmajor && !a->b_kmajor && !a->a_idx && !a->b_idx && !a->c_idx &&
                          !a->mask && !a->colsum && !a->accumulate && !a->relu && !a->bias && !a->bias2,
                      "pp_gemm_f32: unsupported LSTM input product");
         PP_CHECK_ARG(ext->cell_H == 0 || (ext->cell_H % 16 == 0 && a->N == 4 * ext->cell_H && a->ldc % 4 == 0 && aligned16(a->C) &&
@@ -1591,6 +1632,13 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
         if (splits > 1) return launch_split(p, vec, a->a_kmajor, a->b_kmajor, DT, splits, 1, st);
         return vec ? launch_direct<4>(p, a->a_kmajor, a->b_kmajor, splits, st)
                    : launch_direct<1>(p, a->a_kmajor, a->b_kmajor, splits, st);
+    }
+    if (ext && ext->split_stride > 0) {   // K splits that STORE their partial tiles (async tile; the consumer adds them)
+        PP_CHECK_ARG(ext->force_splits >= 1 && ext->force_splits <= 32 && async_ok(a) && async_split_ok(a, ext->force_splits) &&
+                         !a->c_idx && !a->relu && !a->mask && !a->colsum && !a->bias && !a->bias2 && !a->accumulate,
+                     "pp_gemm_f32: unsupported split-store product");
+        p.split_stride = ext->force_splits > 1 ? ext->split_stride : 0;
+        return launch_split(p, vec, a->a_kmajor, a->b_kmajor, 64, ext->force_splits, 2, st);
     }
     static const int budget = getenv("PP_SPLIT_BUDGET") ? atoi(getenv("PP_SPLIT_BUDGET")) : 256;
     static const int force = getenv("PP_FORCE_SPLITS") ? atoi(getenv("PP_FORCE_SPLITS")) : 0;
@@ -1643,6 +1691,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
     while (i < count) {
         GroupedParams g;
         g.ext = ext ? *ext : GemmExt{};
+        g.trace = nullptr;
         static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
         g.xcd_aware = xcd;
         g.count = 0;
@@ -1710,6 +1759,9 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
             g.pmode[q] = pick_pmode(a->M, a->N, g.gx[q], g.gy[q]);
             g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits, g.pmode[q]);
         }
+        if (g_wgtrace && ((g_wgtrace_mode == 1 && akm && bkm) || (g_wgtrace_mode == 2 && !akm && bkm)) &&
+            g.first[g.count] + (aux_pending ? aux->n_blocks : 0) <= g_wgtrace_cap)
+            g.trace = g_wgtrace;
         bool rode = false;
         if (g.count > 0 && aux_pending && aux_fused_ok && akm && bkm && (direct || as)) {
             const int rc = direct ? launch_direct_grouped_aux(g, *aux, st)
@@ -1734,6 +1786,15 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
 }
 
 }  // namespace pp
+
+// debug: per-workgroup start / end stamps of the grouped async launches (mode 1: weight-gradient groups, 2: data-gradient
+// products); buf = device int64 [8 * cap] or NULL
+extern "C" int pp_debug_wgtrace(long long* buf, int32_t cap, int32_t mode) {
+    pp::g_wgtrace = buf;
+    pp::g_wgtrace_cap = cap;
+    pp::g_wgtrace_mode = mode;
+    return 0;
+}
 
 extern "C" int pp_gemm_f32(const pp_gemm_args* args, void* stream) { return pp::gemm_f32(args, pp::as_stream(stream), nullptr, nullptr); }
 extern "C" int pp_gemm_f32_grouped(const pp_gemm_args* args, int32_t count, void* stream) {

@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
                                                               const int32_t* __restrict__ row_off, int t_max,
                                                               const float* __restrict__ E, float* __restrict__ dE,
                                                               float* __restrict__ dF1, float* __restrict__ dCat,
-                                                              float* const dHo0, int64_t dh_stride) {
+                                                              float* const dHo0, int64_t dh_stride, int n_split,
+                                                              int64_t split_stride) {
     __shared__ float lds[10240];
     warm_kernargs((int)sizeof(ObsFusedArgs) + 96);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,6 +254,8 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
         float acc = 0.0f;
         if (acte) {
             acc = dX[(int64_t)b * ldx + lane];   // t = 0: row b (row_off[0] = 0, every trace is alive) - no index load
+            // (single-statement batches: dX arrives as the partial tiles of its K splits, stored instead of added)
+            for (int z = 1; z < n_split; ++z) acc += dX[(int64_t)z * split_stride + (int64_t)b * ldx + lane];
             for (int t = 1; t < t_max; ++t) {
                 const int r0 = row_off[t];
                 if (b >= row_off[t + 1] - r0) break;
@@ -374,12 +377,13 @@ int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int
 int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
                           const float* f1, const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max,
                           const float* E, float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
-                          hipStream_t st) {
+                          hipStream_t st, int n_split, int64_t split_stride) {
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
     const int tpw = pick_traces_per_wave(n_traces, 256);
     hipLaunchKernelGGL(obs_embed_dgrad_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, n_traces, tpw, cat, f1, dX,
-                       ldx, row_off_dev, t_max, E, dE, dF1, dCat, dHo0, dh_stride);
+                       ldx, row_off_dev, t_max, E, dE, dF1, dCat, dHo0, dh_stride, n_split > 1 && t_max == 1 ? n_split : 1,
+                       split_stride);
     PP_LAUNCH_CHECK("obs_embed_dgrad_fused");
     return 0;
 }

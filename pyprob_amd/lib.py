@@ -122,6 +122,7 @@ PROTOTYPES = {
     'pp_head_logprob': (C.c_int, [i32, vp, i64, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]),
     'pp_debug_clock_probe': (C.c_int, [i32, vp, vp, vp]),
     'pp_debug_timeline': (C.c_int, [vp]),
+    'pp_debug_wgtrace': (C.c_int, [vp, C.c_int32, C.c_int32]),
     'pp_prof_arm': (C.c_int, [i32, i32]),
     'pp_prof_collect': (C.c_int, [vp, i32, vp, vp]),
 }
