@@ -246,8 +246,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16 (&acc)
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
+__device__ __forceinline__ void gemm_tile(const GemmParams& pin, const int bx, const int by, const int bz, const int nz,
                                           float* smem) {
+    // A LOCAL copy of the problem description: through the reference (kernel-argument memory, indexed by the problem id in
+    // the grouped kernels) the compiler re-loaded every field at every use - ~130 scalar loads with a wait each in the
+    // 16-element epilogue loop, 4 us per workgroup (tools/wg_trace.py)
+    const GemmParams p = pin;
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
@@ -570,8 +574,12 @@ __device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt
 // with 1 wave per SIMD); a second wave on the SIMD does, and KW = 2 provides it when the launch has only about one
 // workgroup per CU.
 template <bool A_KM, bool B_KM, int KW>
-__device__ __forceinline__ void gemm_tile_async(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
-                                                float* smem, const GemmExt* x = nullptr, long long* tr = nullptr) {
+__device__ __forceinline__ void gemm_tile_async(const GemmParams& pin, const int bx, const int by, const int bz, const int nz,
+                                                float* smem, const GemmExt* xin = nullptr, long long* tr = nullptr) {
+    const GemmParams p = pin;   // local copies: see gemm_tile
+    GemmExt xv{};
+    if (xin) xv = *xin;
+    const GemmExt* const x = xin ? &xv : nullptr;
     constexpr int ST = AS_STAGES;
 #define AS_STAMP(k) do { if (tr && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); tr[k] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
     constexpr int NP = 2 / KW;        // DMA pieces per thread per operand per slab
@@ -1096,8 +1104,12 @@ constexpr int direct_lds_floats() {
 }
 
 template <bool A_KM, bool B_KM, int VEC>
-__device__ __forceinline__ void gemm_tile_direct(const GemmParams& p, const int bx, const int by, const int bz, const int nz,
-                                                 float* red, const GemmExt* x = nullptr) {
+__device__ __forceinline__ void gemm_tile_direct(const GemmParams& pin, const int bx, const int by, const int bz, const int nz,
+                                                 float* red, const GemmExt* xin = nullptr) {
+    const GemmParams p = pin;   // local copies: see gemm_tile
+    GemmExt xv{};
+    if (xin) xv = *xin;
+    const GemmExt* const x = xin ? &xv : nullptr;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, h = lane >> 5;
@@ -1745,6 +1757,14 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
             g.p[q].vec = vec_ok(a) ? 1 : 0;
             int splits = direct ? (split_allowed(a) ? std::max(1, std::min(cdiv(cdiv(a->K, BK), spb), 32)) : 1)
                                 : pick_splits_by_work(a, spb);
+            // (One- and two-tile problems of an async group - the observe-embedding leaves, whose operands were written by the
+            // kernel just before: first slab 7 us after the start, then a dozen slabs at 0.9 us - are the last workgroups of
+            // the weight-gradient launch to finish, tools/wg_trace.py. Giving them 3x / 6x the splits made the launch SLOWER,
+            // 24.5 -> 26.7 / 29 us: the launch is bound by its total number of float atomics, not by its longest workgroup.
+            // PP_GROUP_SMALL_DIV > 1 re-enables the experiment.)
+            static const int small_div = getenv("PP_GROUP_SMALL_DIV") ? atoi(getenv("PP_GROUP_SMALL_DIV")) : 1;
+            if (!direct && as && small_div > 1 && split_allowed(a) && (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) <= 2)
+                splits = std::max(splits, pick_splits_by_work(a, std::max(2, spb / small_div)));
             // a gathered k range must fit the LDS index list of the async tile
             if (as && !direct && split_allowed(a) && !async_split_ok(a, splits))
                 splits = std::min(cdiv(cdiv(a->K, BK), AS_KSLABS), 32);

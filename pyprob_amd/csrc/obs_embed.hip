@@ -66,17 +66,18 @@ struct ObsStage {
     }
 };
 
+template <int NOBS>
 __device__ __forceinline__ void obs_stage_all(const ObsFusedArgs& a, const float* __restrict__ P, float* lds, int tid) {
     ObsStage<16> sf0, sf1;                 // 64 x 64
-    ObsStage<8> s1[PP_MAX_OBS];            // out x hid <= 64 x 32
-    ObsStage<1> s0[PP_MAX_OBS];            // hid x in  <= 32 x 8
-    float bf0, bf1, b1[PP_MAX_OBS], b0[PP_MAX_OBS];
+    ObsStage<8> s1[NOBS];                  // out x hid <= 64 x 32
+    ObsStage<1> s0[NOBS];                  // hid x in  <= 32 x 8
+    float bf0, bf1, b1[NOBS], b0[NOBS];
     sf0.load(P + a.f0.w_off, a.f0.rows * a.f0.cols, tid);
     sf1.load(P + a.f1.w_off, a.f1.rows * a.f1.cols, tid);
     bf0 = tid < a.f0.rows ? P[a.f0.b_off + tid] : 0.0f;
     bf1 = tid < a.f1.rows ? P[a.f1.b_off + tid] : 0.0f;
 #pragma unroll
-    for (int o = 0; o < PP_MAX_OBS; ++o) {
+    for (int o = 0; o < NOBS; ++o) {
         if (o < a.n_obs) {
             s1[o].load(P + a.l1[o].w_off, a.l1[o].rows * a.l1[o].cols, tid);
             s0[o].load(P + a.l0[o].w_off, a.l0[o].rows * a.l0[o].cols, tid);
@@ -90,7 +91,7 @@ __device__ __forceinline__ void obs_stage_all(const ObsFusedArgs& a, const float
     if (tid < a.f0.rows) lds[a.f0.lds_b + tid] = bf0;
     if (tid < a.f1.rows) lds[a.f1.lds_b + tid] = bf1;
 #pragma unroll
-    for (int o = 0; o < PP_MAX_OBS; ++o) {
+    for (int o = 0; o < NOBS; ++o) {
         if (o < a.n_obs) {
             s1[o].store(lds, a.l1[o].lds_w, a.l1[o].rows, a.l1[o].cols, dummy, tid);
             s0[o].store(lds, a.l0[o].lds_w, a.l0[o].rows, a.l0[o].cols, dummy, tid);
@@ -120,12 +121,19 @@ __device__ __forceinline__ float obs_dense(const float* lds, const ObsLayer& L, 
     return act ? relu_keep_nan(s + lds[L.lds_b + row]) : 0.0f;
 }
 
-__global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a, const float* __restrict__ P,
+// NOBS: compile-time bound of the observable loops (1, 2, 4, 8 >= n_obs). With the loops unrolled every index into the
+// argument structs is static and the LOCAL copies below live in scalar registers; through the kernel-argument memory and
+// run-time indices the compiler re-loaded the layer descriptions at every use (136 scalar loads, each with a wait, on
+// the critical path of a kernel that runs one trace per wave).
+template <int NOBS>
+__global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs ain, const float* __restrict__ P,
                                                             const float* __restrict__ obs, int n_traces,
                                                             int traces_per_wave, float* __restrict__ cat,
                                                             float* __restrict__ f1, float* __restrict__ E,
-                                                            const RowBuild rb, const AddrBias ab) {
+                                                            const RowBuild rbin, const AddrBias ab) {
     __shared__ float lds[10240];
+    const ObsFusedArgs a = ain;
+    const RowBuild rb = rbin;
     if (ab.AB && (int)blockIdx.x >= ab.first_block) {   // extra workgroups: per-address bias vectors of the LSTM input
         addr_bias_block(ab, (int)blockIdx.x - ab.first_block, lds);
         return;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
     // training step: this is the first kernel - clear the loss slots that later kernels add into
     if (rb.zero_small && blockIdx.x == 0)
         for (int q = tid; q < rb.n_small; q += 256) rb.zero_small[q] = 0.0f;
-    obs_stage_all(a, P, lds, tid);
+    obs_stage_all<NOBS>(a, P, lds, tid);
     __syncthreads();
     const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
     for (int t = 0; t < traces_per_wave; ++t) {
@@ -143,7 +151,9 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
         if (b >= n_traces) break;   // wave-uniform
         float h = 0.0f, c = 0.0f;
         int ci = 0, co = 0;
-        for (int o = 0; o < a.n_obs; ++o) {
+#pragma unroll
+        for (int o = 0; o < NOBS; ++o) {
+            if (o >= a.n_obs) break;
             const int jh = lane - a.hoff[o];
             const bool acth = jh >= 0 && jh < a.hid[o];
             if (acth) {   // layer 0 reads the raw observation directly (no cross-lane traffic)
@@ -155,7 +165,9 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
             }
             ci += a.in[o];
         }
-        for (int o = 0; o < a.n_obs; ++o) {
+#pragma unroll
+        for (int o = 0; o < NOBS; ++o) {
+            if (o >= a.n_obs) break;
             const int jc = lane - co;
             const bool actc = jc >= 0 && jc < a.out[o];
             const float v = obs_dense(lds, a.l1[o], jc, actc, h, a.hoff[o]);
@@ -229,7 +241,8 @@ __device__ __forceinline__ float obs_dense_t(const float* lds, const ObsLayer& L
 // join the grouped weight-gradient launch of the backward pass; the bias gradients are column sums of the same
 // buffers. (A first version accumulated the weight gradients in registers and flushed ~10k atomics per workgroup:
 // 57 us; this split is 3x cheaper.)
-__global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs a, const float* __restrict__ P,
+template <int NOBS>
+__global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs ain, const float* __restrict__ P,
                                                               int n_traces, int traces_per_wave,
                                                               const float* __restrict__ cat, const float* __restrict__ f1,
                                                               const float* __restrict__ dX, int64_t ldx,
@@ -240,11 +253,18 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
                                                               int64_t split_stride) {
     __shared__ float lds[10240];
     warm_kernargs((int)sizeof(ObsFusedArgs) + 96);
+    const ObsFusedArgs a = ain;   // local copy, static indices: see obs_embed_fwd_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // which observable this lane belongs to as a hidden unit
+    // which observable this lane belongs to as a hidden unit (and that observable's hidden-activation buffer)
     int oh = -1, jh = 0;
-    for (int o = 0; o < a.n_obs; ++o)
-        if (lane >= a.hoff[o] && lane < a.hoff[o] + a.hid[o]) { oh = o; jh = lane - a.hoff[o]; }
+    const float* my_h = nullptr;
+    int64_t my_hld = 0;
+#pragma unroll
+    for (int o = 0; o < NOBS; ++o)
+        if (o < a.n_obs && lane >= a.hoff[o] && lane < a.hoff[o] + a.hid[o]) {
+            oh = o; jh = lane - a.hoff[o];
+            my_h = a.obs_h[o]; my_hld = a.ohid_ld[o];
+        }
     const bool acte = lane < a.e_obs;
     const int b0 = (blockIdx.x * 4 + wave) * traces_per_wave;
     // Gradient into the embedding output of trace b: every time step of the trace consumed E[b], so
@@ -255,7 +275,14 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
         if (acte) {
             acc = dX[(int64_t)b * ldx + lane];   // t = 0: row b (row_off[0] = 0, every trace is alive) - no index load
             // (single-statement batches: dX arrives as the partial tiles of its K splits, stored instead of added)
-            for (int z = 1; z < n_split; ++z) acc += dX[(int64_t)z * split_stride + (int64_t)b * ldx + lane];
+            // (eight loads in flight per trip: a load-add loop would pay one memory round trip per split)
+            for (int z0 = 1; z0 < n_split; z0 += 8) {
+                float pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    pv[u] = (z0 + u < n_split) ? dX[(int64_t)(z0 + u) * split_stride + (int64_t)b * ldx + lane] : 0.0f;
+                acc += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+            }
             for (int t = 1; t < t_max; ++t) {
                 const int r0 = row_off[t];
                 if (b >= row_off[t + 1] - r0) break;
@@ -271,9 +298,9 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
         nx_dz2 = load_dz2(b0);
         nx_f1 = acte ? f1[(int64_t)b0 * a.e_ld + lane] : 0.0f;
         nx_cat = acte ? cat[(int64_t)b0 * a.e_ld + lane] : 0.0f;
-        nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)b0 * a.ohid_ld[oh] + jh] : 0.0f;
+        nx_h = oh >= 0 ? my_h[(int64_t)b0 * my_hld + jh] : 0.0f;
     }
-    obs_stage_all(a, P, lds, tid);
+    obs_stage_all<NOBS>(a, P, lds, tid);
     __syncthreads();
     for (int t = 0; t < traces_per_wave; ++t) {
         const int b = b0 + t;
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
             nx_dz2 = load_dz2(bn);
             nx_f1 = acte ? f1[(int64_t)bn * a.e_ld + lane] : 0.0f;
             nx_cat = acte ? cat[(int64_t)bn * a.e_ld + lane] : 0.0f;
-            nx_h = oh >= 0 ? a.obs_h[oh][(int64_t)bn * a.ohid_ld[oh] + jh] : 0.0f;
+            nx_h = oh >= 0 ? my_h[(int64_t)bn * my_hld + jh] : 0.0f;
         }
         if (acte) dE[(int64_t)b * a.e_ld + lane] = dz2;
         float dz1 = obs_dense_t(lds, a.f1, lane, acte, dz2, 0);
@@ -295,13 +322,15 @@ __global__ __launch_bounds__(256) void obs_embed_dgrad_kernel(const ObsFusedArgs
         if (acte) dCat[(int64_t)b * a.e_ld + lane] = dzc;
         float dh = 0.0f;
         int co = 0;
-        for (int o = 0; o < a.n_obs; ++o) {
+#pragma unroll
+        for (int o = 0; o < NOBS; ++o) {
+            if (o >= a.n_obs) break;
             const bool acth = (oh == o);
             const float d = obs_dense_t(lds, a.l1[o], jh, acth, dzc, co);   // dh_k = sum_j dzc_j W1[j][k]
             if (acth) dh = d;
             co += a.out[o];
         }
-        if (oh >= 0) dHo0[(int64_t)oh * dh_stride + (int64_t)b * a.ohid_ld[oh] + jh] = hv > 0.0f ? dh : 0.0f;
+        if (oh >= 0) dHo0[(int64_t)oh * dh_stride + (int64_t)b * my_hld + jh] = hv > 0.0f ? dh : 0.0f;
     }
 }
 
@@ -367,8 +396,12 @@ int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int
         ab.first_block = blocks;
         blocks += addr_bias_blocks(ab);
     }
-    hipLaunchKernelGGL(obs_embed_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat,
-                       f1, E, rb, ab);
+#define PP_OBS_FWD(N) hipLaunchKernelGGL(obs_embed_fwd_kernel<N>, dim3(blocks), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat, f1, E, rb, ab)
+    if (a.n_obs <= 1) PP_OBS_FWD(1);
+    else if (a.n_obs <= 2) PP_OBS_FWD(2);
+    else if (a.n_obs <= 4) PP_OBS_FWD(4);
+    else PP_OBS_FWD(8);
+#undef PP_OBS_FWD
     PP_LAUNCH_CHECK("obs_embed_fwd_fused");
     return 0;
 }
@@ -381,9 +414,13 @@ int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
     const int tpw = pick_traces_per_wave(n_traces, 256);
-    hipLaunchKernelGGL(obs_embed_dgrad_kernel, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, n_traces, tpw, cat, f1, dX,
-                       ldx, row_off_dev, t_max, E, dE, dF1, dCat, dHo0, dh_stride, n_split > 1 && t_max == 1 ? n_split : 1,
-                       split_stride);
+    const int nsp = n_split > 1 && t_max == 1 ? n_split : 1;
+#define PP_OBS_BWD(N) hipLaunchKernelGGL(obs_embed_dgrad_kernel<N>, dim3(cdiv(n_traces, 4 * tpw)), dim3(256), 0, st, a, P, n_traces, tpw, cat, f1, dX, ldx, row_off_dev, t_max, E, dE, dF1, dCat, dHo0, dh_stride, nsp, split_stride)
+    if (a.n_obs <= 1) PP_OBS_BWD(1);
+    else if (a.n_obs <= 2) PP_OBS_BWD(2);
+    else if (a.n_obs <= 4) PP_OBS_BWD(4);
+    else PP_OBS_BWD(8);
+#undef PP_OBS_BWD
     PP_LAUNCH_CHECK("obs_embed_dgrad_fused");
     return 0;
 }
