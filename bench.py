@@ -256,15 +256,22 @@ def main():
         final_loss = float(eng.loss_buf[0].item())
         units = B * K
         metric, unit = 'ic_train_traces_per_sec', 'traces/s'
-        pmc, pmc_file = {}, os.path.join('profiles', 'r02_pmc_traffic.json')
+        pmc, pmc_file = {}, os.path.join('profiles', 'r02_pmc_traffic.json')   # (re-collected for the compact-row step: tools/pmc_train.sh)
         try:   # HBM bytes per launch from the committed PMC passes (rocprof cannot run inside bench.py)
             with open(os.path.join(REPO, pmc_file)) as f:
                 pmc = json.load(f)['kernels'] if (B == 1024 and args.lstm_dim == 512) else {}
         except (OSError, KeyError, ValueError):
             pass
 
-        def roof(sample, key, label, bound='mfma'):
+        def roof(sample, key, label, bound='mfma', algorithmic=None):
+            """achieved = ALGORITHMIC work per launch (what the reference's algorithm does in this launch) /
+            the measured launch duration. `algorithmic` overrides the work the C side reported for the launch, which is what
+            the kernel EXECUTES: with compact LSTM-input rows the embedding-table columns of W_ih never enter a
+            GEMM, so the executed FLOPs are fewer than the reference's; both are in the line."""
             avg_ms, work, n = sample
+            executed = work
+            if algorithmic is not None:
+                work = algorithmic
             if bound == 'mfma':
                 ach, peak, u = work / (avg_ms * 1e-3) / 1e12, FP32_MATRIX_PEAK_TFLOPS, 'TFLOP/s'
             else:
@@ -274,18 +281,30 @@ def main():
                      algorithmic_bytes=pmc.get(key, {}).get('algorithmic_bytes_per_launch') if bound == 'mfma' else work,
                      kernel=label, avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=n)
             d['flops_per_launch' if bound == 'mfma' else 'bytes_per_launch'] = work
+            if algorithmic is not None:
+                d['executed_flops_per_launch'] = executed
+                d['frac_executed'] = round(executed / (avg_ms * 1e-3) / 1e12 / peak, 4)
             d['traffic_source'] = (pmc_file + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)') \
                 if d['traffic'] is not None else None
             return d
         H, I = args.lstm_dim, eng.spec.lstm_in
         if dominant:
+            hid_ = int((H + 30) / 2)
+            # reference algorithm, weight gradients of one step: dW_ih [4H, I], dW1 [hid, H], dW2 [30, hid], the observe
+            # embedding's four weight matrices (64x64 twice, 32x16 twice); K = batch rows
+            wgrad_alg = 2.0 * B * (4 * H * I + hid_ * H + 30 * hid_ + 2 * 64 * 64 + 2 * 32 * 16)
             out['roofline'] = roof(dominant, 'wgrad_group',
-                                   'gemm_f32_async_grouped_kernel<TN> (weight-gradient group of the backward pass: dW_ih '
-                                   '%dx%dx%d + head and observe-embedding leaves, one launch; FLOPs by SURVEY.md 8(d), the '
-                                   'kernel skips the zero blocks of first-time-step rows)' % (4 * H, I, B))
+                                   'gemm_f32_async_grouped_aux_kernel (last launch of the backward pass: the weight-gradient '
+                                   'group dW_ih[:, :e_obs] %dx%dx%d + head and observe-embedding leaves as MFMA tiles with '
+                                   'split-K float atomics, and behind them the reduction jobs - column sums, table-column '
+                                   'gradients from the per-address sums of dG, LSTM bias gradients, loss; algorithmic FLOPs = the '
+                                   "reference's dW_ih %dx%dx%d + leaves, SURVEY.md 8(d))" % (4 * H, eng.spec.e_obs, B, 4 * H, I, B),
+                                   algorithmic=wgrad_alg)
             if second:
-                out['roofline']['second_kernel'] = roof(second, 'input_gemm', 'gemm_f32_async_kernel<NT> (forward X*W_ih^T, '
-                                                        '%dx%dx%d)' % (B, 4 * H, I))
+                out['roofline']['second_kernel'] = roof(second, 'input_gemm', 'gemm_f32_async_lstm_kernel (forward LSTM input '
+                                                        'product [E | s_prev] W_ih[:, :c2]^T + per-address bias, LSTM cell in '
+                                                        "the epilogue; algorithmic FLOPs = the reference's X W_ih^T %dx%dx%d)"
+                                                        % (B, 4 * H, I), algorithmic=2.0 * B * I * 4 * H)
             hbm = []
             if gather:
                 hbm.append(roof(gather, 'obs_embed_fwd', 'obs_embed_fwd_kernel (observe embedding + fused address-dispatch '

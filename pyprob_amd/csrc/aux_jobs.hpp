@@ -50,7 +50,8 @@ __device__ __forceinline__ bool aux_present(const AuxJobs& j, int a) {
     return j.all_present || ((j.present[(a >> 5) & 31] >> (a & 31)) & 1u);
 }
 
-__device__ __forceinline__ void aux_colsum_block(const ColsumJob& jb, int local, float* lds) {
+__device__ __forceinline__ void aux_colsum_block(const ColsumJob& jbin, int local, float* lds) {
+    const ColsumJob jb = jbin;   // local copy: fields read through the kernel-argument table are re-loaded at every use
     const int nt = blockDim.x, tid = threadIdx.x;
     const int nrl = nt >> 6;                        // row lanes
     const int cl = tid & 63, rl = tid >> 6;
@@ -96,20 +97,23 @@ __device__ __forceinline__ void aux_outer_block(const AuxJobs& j, int local) {
     float acc[MAXJ];
 #pragma unroll
     for (int q = 0; q < MAXJ; ++q) acc[q] = 0.0f;
-    const int ncol = 2 * j.ne;
-    for (int a = 0; a < j.n_addr; ++a) {
+    const int ne = j.ne, nd = j.nd, N = j.N, n_addr = j.n_addr, ncol = 2 * ne;
+    const float* const gsum = j.gsum;
+    const float* const params = j.params;
+    const int64_t* const at = j.at;
+    for (int a = 0; a < n_addr; ++a) {
         if (!aux_present(j, a)) continue;
-        const float* gs = j.gsum + (int64_t)a * 2 * j.N;
-        const float g0 = gs[n], g1 = gs[j.N + n];
-        const float* dt = j.params + j.at[a * PP_ADDR_TABLE_COLS + PP_AT_DTYPE_EMB];
-        const float* ad = j.params + j.at[a * PP_ADDR_TABLE_COLS + PP_AT_ADDR_EMB];
+        const float* gs = gsum + (int64_t)a * 2 * N;
+        const float g0 = gs[n], g1 = gs[N + n];
+        const float* dt = params + at[a * PP_ADDR_TABLE_COLS + PP_AT_DTYPE_EMB];
+        const float* ad = params + at[a * PP_ADDR_TABLE_COLS + PP_AT_ADDR_EMB];
 #pragma unroll
         for (int q = 0; q < MAXJ; ++q) {
             const int col = kq + 16 * q;
             if (col < ncol) {
-                const int k = col < j.ne ? col : col - j.ne;
-                const float e = k < j.nd ? dt[k] : ad[k - j.nd];
-                acc[q] += (col < j.ne ? g1 : g0) * e;
+                const int k = col < ne ? col : col - ne;
+                const float e = k < nd ? dt[k] : ad[k - nd];
+                acc[q] += (col < ne ? g1 : g0) * e;
             }
         }
     }

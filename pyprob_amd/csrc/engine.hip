@@ -639,7 +639,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // ---------------- backward ----------------
     // Weight-gradient leaves: queued and flushed as grouped launches - on the side stream as soon as their inputs are
     // complete (heads after the tails, LSTM after the cell backward), or all at once at the end on the caller's stream.
-    SideStream* ss = compact ? nullptr : side_stream();
+    SideStream* ss = (compact && T == 1) ? nullptr : side_stream();
     std::vector<pp_gemm_args> wq;
     std::vector<GemmHole> wholes;
     bool forked = false;

@@ -7,11 +7,16 @@ import csv
 import json
 import sys
 
-KEYS = [('wgrad_group', 'gemm_f32_async_grouped_kernel<true, true', 17499912,
-         'weight-gradient leaves of the backward pass (dW_ih 2048x212x1024, dW1 271x512x1024, dW2 30x271x1024, observe-embedding leaves)'),
-        ('input_gemm', 'gemm_f32_async_kernel<false, false', 11010048, 'forward X*W_ih^T, 1024x2048x212'),
-        ('dx_gemm', 'gemm_f32_async_grouped_kernel<false, true', 10995712, 'dX = dG W_ih, 1024x212x2048'),
-        ('obs_embed_fwd', 'obs_embed_fwd_kernel', None, 'observe embedding + LSTM input rows'),
+# (key, kernel-name needle, algorithmic bytes per launch of the EXECUTED algorithm at B = 1024, H = 512, what)
+KEYS = [('wgrad_group', 'gemm_f32_async_grouped_aux_kernel', 20200000,
+         'last launch of the backward pass: weight-gradient tiles (dW_ih[:, :64] 2048x64x1024 reads dG 8.4 MB once, dW1 271x512x1024, '
+         'dW2 30x271x1024, four observe-embedding leaves: operands 14.6 MB, outputs 1.2 MB) + reduction jobs (column sums 2 MB, '
+         'table-column gradients: W_ih[:, 68:212] read 1.2 MB, dW_ih[:, 68:212] written 1.2 MB)'),
+        ('input_gemm', 'gemm_f32_async_lstm_kernel', 9200000,
+         'forward [E | s_prev] W_ih[:, :64]^T + bias + LSTM cell, 1024x2048x64: reads 0.8 MB, writes gates i, g, o 6.3 MB + h 2.1 MB'),
+        ('dx_gemm', 'gemm_f32_async_grouped_kernel<false, true', 11000000,
+         'dX[:, :64] = dG W_ih[:, :64], 1024x64x2048 in 16 stored K splits: reads dG (i, g, o columns) 6.3 MB + W 0.5 MB, writes 16 x 0.26 MB'),
+        ('obs_embed_fwd', 'obs_embed_fwd_kernel', None, 'observe embedding + LSTM input rows + per-address bias vectors'),
         ('adam', 'adam_kernel', None, 'Adam pass over the flat buffers')]
 
 
