@@ -366,9 +366,9 @@ class _WorkerScheduler(CoroutineIS):
         self.group_calls += len(order)
 
 
-def _worker_main(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs):
+def _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs):
+    """One particle shard inside a worker process: the greenlets of particles [lo, hi), every round shipped to the parent."""
     try:
-        torch.set_num_threads(1)
         torch.manual_seed(seed + 7919 * (worker + 1))       # (prior-as-proposal fallbacks draw on the host)
         sched = _WorkerScheduler(state, forward, spec, lo, hi, conn, seed)
         state._coroutine = sched
@@ -389,16 +389,120 @@ def _worker_main(conn, worker, lo, hi, state, forward, spec, map_func, seed, arg
             results = [map_func(p.trace) for p in particles]
         conn.send(dict(done=True, groups=[], likelihoods=sched._likelihood_payload(), results=results,
                        stats=(sched.rounds, sched.group_calls, sched.statements)))
-        conn.recv()      # the parent's acknowledgement: the pipe is drained before the process goes away
+        conn.recv()      # the parent's acknowledgement: the pipe is drained before the next job / the end of the process
+        return True
     except BaseException as exc:      # noqa: BLE001 - reported to the parent, which raises it
         import traceback
         try:
             conn.send(dict(done=True, error='%s\n%s' % (exc, traceback.format_exc())))
         except Exception:  # noqa: BLE001
             pass
+        return False
     finally:
-        import os
+        state._coroutine = None
+
+
+def _worker_main(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs):
+    """A worker forked for ONE posterior call."""
+    import os
+    try:
+        torch.set_num_threads(1)
+        _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs)
+    finally:
         os._exit(0)       # no destructors of the parent's device state in the child
+
+
+# ---- persistent workers ------------------------------------------------------------------------------------------------
+# Forking a worker copies the page tables of a process that holds a HIP context: 16 workers cost ~1 s, 64 workers 2.5 s
+# per posterior call (tools/gumm_is_bench.py) - more than the particles themselves. The pool forks the workers of a
+# (program, worker count) pair ONCE; a posterior call sends each worker its job (particle range, seed, network
+# description, arguments) and the worker goes back to waiting afterwards. The workers hold the PROGRAM as it was when the
+# pool was forked (the network lives in the parent): `close_worker_pools()` after changing the model object, PP_IS_POOL=0
+# to fork per call as before.
+def _pool_worker_main(conn, worker, state, forward, inherited):
+    import os
+    try:
+        for c in inherited:      # pipe ends of the workers forked before this one
+            try:
+                c.close()
+            except OSError:
+                pass
+        torch.set_num_threads(1)
+        import pickle
+        while True:
+            try:
+                job = conn.recv()
+            except EOFError:
+                break
+            if job is None:
+                break
+            lo, hi, spec, seed, blob = job
+            map_func, args, kwargs = pickle.loads(blob)
+            _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs)
+    finally:
+        os._exit(0)
+
+
+class _WorkerPool:
+    def __init__(self, state, forward, workers):
+        import multiprocessing as mp
+        ctx = mp.get_context('fork')          # the model is an arbitrary user object: inherited, not pickled
+        self.state, self.forward, self.workers = state, forward, workers
+        self.conns, self.procs = [], []
+        for w in range(workers):
+            parent, child = ctx.Pipe()
+            pr = ctx.Process(target=_pool_worker_main, args=(child, w, state, forward, list(self.conns)), daemon=True)
+            pr.start()
+            child.close()
+            self.conns.append(parent)
+            self.procs.append(pr)
+
+    def healthy(self):
+        return all(pr.is_alive() for pr in self.procs)
+
+    def close(self, kill=False):
+        for c in self.conns:
+            try:
+                if not kill:
+                    c.send(None)
+                c.close()
+            except (OSError, BrokenPipeError):
+                pass
+        for pr in self.procs:
+            pr.join(timeout=0.2 if kill else 5)
+            if pr.is_alive():
+                pr.terminate()
+        self.conns, self.procs = [], []
+
+
+_POOLS = {}
+
+
+def _pool_key(state, forward, workers):
+    return (id(state), id(getattr(forward, '__self__', None)), id(getattr(forward, '__func__', forward)), int(workers))
+
+
+def _get_pool(state, forward, workers):
+    import os
+    if os.environ.get('PP_IS_POOL', '1') == '0':
+        return None
+    key = _pool_key(state, forward, workers)
+    pool = _POOLS.get(key)
+    if pool is not None and not pool.healthy():
+        pool.close(kill=True)
+        pool = None
+    if pool is None:
+        if not _POOLS:
+            import atexit
+            atexit.register(close_worker_pools)
+        pool = _POOLS[key] = _WorkerPool(state, forward, workers)
+    return pool
+
+
+def close_worker_pools():
+    """Stop the persistent particle workers (they hold the program objects as they were when first used)."""
+    for key in list(_POOLS):
+        _POOLS.pop(key).close()
 
 
 class ShardedCoroutineIS:
@@ -425,14 +529,32 @@ class ShardedCoroutineIS:
         last_value = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
         conns, procs, bounds = [], [], []
         t0 = time.time()
-        for w in range(self.workers):
-            lo, cnt = shard_range(self.n, w, self.workers)
-            parent, child = ctx.Pipe()
-            pr = ctx.Process(target=_worker_main, args=(child, w, lo, lo + cnt, self.state, self.forward, self.spec,
-                                                        self.map_func, self.seed, args, kwargs), daemon=True)
-            pr.start()
-            child.close()
-            conns.append(parent); procs.append(pr); bounds.append((lo, lo + cnt))
+        pool, blob = None, None
+        try:      # persistent workers need the per-call arguments as bytes
+            import pickle
+            try:
+                blob = pickle.dumps((self.map_func, args, kwargs))
+            except Exception:  # noqa: BLE001 - e.g. a lambda as map_func
+                import cloudpickle
+                blob = cloudpickle.dumps((self.map_func, args, kwargs))
+            pool = _get_pool(self.state, self.forward, self.workers)
+        except Exception:  # noqa: BLE001 - not picklable at all: fork per call (arguments inherited)
+            pool = None
+        if pool is not None:
+            conns = pool.conns
+            for w in range(self.workers):
+                lo, cnt = shard_range(self.n, w, self.workers)
+                conns[w].send((lo, lo + cnt, self.spec, self.seed, blob))
+                bounds.append((lo, lo + cnt))
+        else:
+            for w in range(self.workers):
+                lo, cnt = shard_range(self.n, w, self.workers)
+                parent, child = ctx.Pipe()
+                pr = ctx.Process(target=_worker_main, args=(child, w, lo, lo + cnt, self.state, self.forward, self.spec,
+                                                            self.map_func, self.seed, args, kwargs), daemon=True)
+                pr.start()
+                child.close()
+                conns.append(parent); procs.append(pr); bounds.append((lo, lo + cnt))
         live = set(range(self.workers))
         results = [None] * self.workers
         stats = [0, 0, 0]
@@ -494,13 +616,19 @@ class ShardedCoroutineIS:
                     else:
                         conns[w].send(replies[w])
                 rounds += 1
+        except BaseException:
+            if pool is not None:      # workers may be mid-protocol: this pool cannot be reused
+                _POOLS.pop(_pool_key(self.state, self.forward, self.workers), None)
+                pool.close(kill=True)
+            raise
         finally:
-            for pr in procs:
-                pr.join(timeout=5)
-                if pr.is_alive():
-                    pr.terminate()
-            for c in conns:
-                c.close()
+            if pool is None:
+                for pr in procs:
+                    pr.join(timeout=5)
+                    if pr.is_alive():
+                        pr.terminate()
+                for c in conns:
+                    c.close()
         stats[0] = rounds
         merged_results = []
         if all(isinstance(r, np.ndarray) for r in results):

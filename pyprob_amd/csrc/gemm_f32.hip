@@ -873,6 +873,7 @@ struct GroupedParams {
     int first[GROUP_MAX + 1];   // first workgroup of problem q; first[count] = total
     int gx[GROUP_MAX], gy[GROUP_MAX], gz[GROUP_MAX];
     int pmode[GROUP_MAX];       // XCD placement of the problem's tiles, see group_decode
+    int rot[GROUP_MAX];         // pmode 0: tile t of the problem runs on XCD (t + rot) % 8
     int count;
     int xcd_aware;
     GemmExt ext;                // shared by the problems of the launch (cell backward in the dH epilogue)
@@ -920,9 +921,12 @@ __device__ __forceinline__ bool group_decode(const GroupedParams& g, int b, int&
     const int ntiles = gx * gy;
     int tile;
     if (g.xcd_aware) {
+        // (rot continues the round robin across the problems of a group: without it tile 0 of EVERY problem - and all its K
+        // splits - sat on XCD 0; the four single-tile observe-embedding leaves of the weight-gradient group shared its 32 CUs
+        // with an eighth of everything else and were the last workgroups of the launch to finish, tools/wg_trace.py)
         const int r = l >> 3;
         bz = r % gz;
-        tile = (r / gz) * 8 + (l & 7);
+        tile = (r / gz) * 8 + (((l & 7) - g.rot[q]) & 7);
     } else {
         tile = l % ntiles;
         bz = l / ntiles;
@@ -1601,6 +1605,7 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
     g.p[0].vec = vec ? 1 : 0;
     g.gx[0] = cdiv(p.N, tile); g.gy[0] = cdiv(p.M, tile); g.gz[0] = splits;
     g.pmode[0] = pick_pmode(p.M, p.N, g.gx[0], g.gy[0]);
+    g.rot[0] = 0;
     g.first[0] = 0;
     g.first[1] = group_blocks(g.gx[0], g.gy[0], splits, g.pmode[0]);
     if (g_wgtrace && ((g_wgtrace_mode == 1 && akm && bkm) || (g_wgtrace_mode == 2 && !akm && bkm)) && g.first[1] <= g_wgtrace_cap)
@@ -1713,7 +1718,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         static const int target_staged = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
         // (with the zero blocks left out of the work estimate: 128-256 active workgroups measured equal, 0.152 ms per GUM
         // step; 320+ costs 4 us in split-K atomics, one split per tile 3 us in idle CUs - profiles/r02_e/f_ab_*.json)
-        static const int target_async = getenv("PP_GROUP_BLOCKS_ASYNC") ? atoi(getenv("PP_GROUP_BLOCKS_ASYNC")) : 192;
+        static const int target_async = getenv("PP_GROUP_BLOCKS_ASYNC") ? atoi(getenv("PP_GROUP_BLOCKS_ASYNC")) : 256;
         static const int target_direct = getenv("PP_GROUP_BLOCKS_DIRECT") ? atoi(getenv("PP_GROUP_BLOCKS_DIRECT")) : 1536;
         int64_t work = 0, work32 = 0, tiles = 0;
         bool as = true;
@@ -1745,6 +1750,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
                                : (int)std::min<int64_t>(spb_max, std::max<int64_t>(2, (work + target - 1) / target));
         const int tile = direct ? DT : 64;
         int64_t active_blocks = 0;   // workgroups that have slabs to walk (tiles inside a zero block exit at once)
+        int xcd_cursor = 0;          // next XCD of the round robin over the tiles of the round-robin-placed problems
         int j = i;
         for (; j < count && g.count < GROUP_MAX; ++j) {
             const pp_gemm_args* a = &args[j];
@@ -1777,6 +1783,9 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
                 active_blocks += (int64_t)act * splits;
             }
             g.pmode[q] = pick_pmode(a->M, a->N, g.gx[q], g.gy[q]);
+            static const int rotate = getenv("PP_XCD_ROTATE") ? atoi(getenv("PP_XCD_ROTATE")) : 1;
+            g.rot[q] = (g.pmode[q] == 0 && rotate) ? (xcd_cursor & 7) : 0;
+            if (g.pmode[q] == 0) xcd_cursor += g.gx[q] * g.gy[q];
             g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits, g.pmode[q]);
         }
         if (g_wgtrace && ((g_wgtrace_mode == 1 && akm && bkm) || (g_wgtrace_mode == 2 && !akm && bkm)) &&

@@ -134,5 +134,29 @@ def test_sharded_coroutines_equal_rescored_traces(case, program, observe, sigma)
     assert p2.length == 40 and np.isfinite(p2.mean) and 'ess' in p2.device_stats
 
 
+def test_persistent_workers_are_reused_and_give_the_same_particles(monkeypatch):
+    """The worker pool is forked once per (program, worker count): a second posterior call runs in the same processes and,
+    with the same seed, returns the same particles as a call with per-call forks (PP_IS_POOL=0)."""
+    from pyprob_amd import coroutine as CO
+    case, program, observe, sigma = CASES[1]
+    net, meta, params, isr = network_from_golden(case)
+    model = program()
+    model._inference_network = net
+    CO.close_worker_pools()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        a = model._traces_coroutines(30, observe, seed=11, num_workers=2)
+        pids = [pr.pid for pool in CO._POOLS.values() for pr in pool.procs]
+        assert len(CO._POOLS) == 1 and len(pids) == 2
+        b = model._traces_coroutines(30, observe, seed=11, num_workers=2)
+        assert [pr.pid for pool in CO._POOLS.values() for pr in pool.procs] == pids
+        monkeypatch.setenv('PP_IS_POOL', '0')
+        c = model._traces_coroutines(30, observe, seed=11, num_workers=2)
+    np.testing.assert_allclose(np.asarray(a.log_weights), np.asarray(b.log_weights), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(a.log_weights), np.asarray(c.log_weights), rtol=1e-6, atol=1e-6)
+    CO.close_worker_pools()
+    assert not CO._POOLS
+
+
 def _identity(trace):
     return trace

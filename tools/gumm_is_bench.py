@@ -47,14 +47,18 @@ for rep in range(2):
     st = post.coroutine_stats
     print('coroutines: %d particles in %.2f s -> %.0f particles/s (%d rounds, %d group calls, %d statements); mean %.3f ESS %.0f' % (
         nc, t1 - t0, nc / (t1 - t0), st['rounds'], st['group_calls'], st['statements'], post.mean, post.effective_sample_size))
-for workers in (16, 32):
+for workers in (16, 32, 64):
     big = int(sys.argv[3]) if len(sys.argv) > 3 else 200000
-    t0 = time.perf_counter()
-    post = ref_style.posterior_results(big, IC, observe=obs, lock_step=False, seed=3, num_workers=workers)
-    t1 = time.perf_counter()
-    st = post.coroutine_stats
-    print('coroutines in %d worker processes: %d particles in %.2f s -> %.0f particles/s (%d rounds, %d group calls); mean %.3f ESS %.0f'
-          % (st['workers'], big, t1 - t0, big / (t1 - t0), st['rounds'], st['group_calls'], post.mean, post.effective_sample_size))
+    for rep in range(3):      # the first call forks the persistent workers of this (program, worker count)
+        t0 = time.perf_counter()
+        post = ref_style.posterior_results(big, IC, observe=obs, lock_step=False, seed=3 + rep, num_workers=workers)
+        t1 = time.perf_counter()
+        st = post.coroutine_stats
+        print('coroutines in %d worker processes (call %d%s): %d particles in %.2f s -> %.0f particles/s (%d rounds, %d group calls); '
+              'mean %.3f ESS %.0f' % (st['workers'], rep + 1, ', forks the workers' if rep == 0 else '', big, t1 - t0,
+                                      big / (t1 - t0), st['rounds'], st['group_calls'], post.mean, post.effective_sample_size))
+from pyprob_amd.coroutine import close_worker_pools
+close_worker_pools()
 if os.environ.get('PP_PROFILE'):
     pr = cProfile.Profile()
     pr.enable()
