@@ -379,7 +379,14 @@ def _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args,
             p.trace = state._end_trace(result)
             p.result = result
             p.done = True
-        particles = sched.run_particles(particle_main)
+        import os
+        if worker == 0 and os.environ.get('PP_IS_WORKER_PROFILE'):      # where does a worker's time go? (stderr)
+            import cProfile, pstats, sys
+            pr = cProfile.Profile()
+            particles = pr.runcall(sched.run_particles, particle_main)
+            pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(22)
+        else:
+            particles = sched.run_particles(particle_main)
         if map_func is None:
             try:
                 results = np.array([float(p.result) for p in particles], np.float32)
@@ -560,8 +567,12 @@ class ShardedCoroutineIS:
         stats = [0, 0, 0]
         rounds = 0
         try:
+            tm = dict(wait=0.0, serve=0.0, send=0.0)      # parent's time: waiting for the workers / device + merge / replies
             while live:
+                tq = time.time()
                 msgs = {w: conns[w].recv() for w in sorted(live)}
+                tm['wait'] += time.time() - tq
+                tq = time.time()
                 for w, m in msgs.items():
                     if m.get('error'):
                         raise RuntimeError('particle worker %d failed: %s' % (w, m['error']))
@@ -607,6 +618,8 @@ class ShardedCoroutineIS:
                         replies[w][gi] = (host[0, pos:pos + m_].copy(), host[1, pos:pos + m_].copy())
                         pos += m_
                     stats[1] += 1
+                tm['serve'] += time.time() - tq
+                tq = time.time()
                 for w, m in msgs.items():
                     if m['done']:
                         results[w] = m['results']
@@ -615,6 +628,7 @@ class ShardedCoroutineIS:
                         live.discard(w)
                     else:
                         conns[w].send(replies[w])
+                tm['send'] += time.time() - tq
                 rounds += 1
         except BaseException:
             if pool is not None:      # workers may be mid-protocol: this pool cannot be reused
@@ -637,4 +651,4 @@ class ShardedCoroutineIS:
             for r in results:
                 merged_results.extend(list(r))
         return merged_results, lw, dict(rounds=stats[0], group_calls=stats[1], statements=stats[2], seconds=time.time() - t0,
-                                        workers=self.workers)
+                                        workers=self.workers, parent_seconds=tm)

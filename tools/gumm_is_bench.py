@@ -57,6 +57,8 @@ for workers in (16, 32, 64):
         print('coroutines in %d worker processes (call %d%s): %d particles in %.2f s -> %.0f particles/s (%d rounds, %d group calls); '
               'mean %.3f ESS %.0f' % (st['workers'], rep + 1, ', forks the workers' if rep == 0 else '', big, t1 - t0,
                                       big / (t1 - t0), st['rounds'], st['group_calls'], post.mean, post.effective_sample_size))
+        print('      inside run(): %.2f s; parent waited %.2f s for the workers, served %.2f s, replied %.2f s'
+              % (st['seconds'], st['parent_seconds']['wait'], st['parent_seconds']['serve'], st['parent_seconds']['send']))
 from pyprob_amd.coroutine import close_worker_pools
 close_worker_pools()
 if os.environ.get('PP_PROFILE'):
