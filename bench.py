@@ -191,7 +191,13 @@ def main():
     eng = make_engine(args.lstm_dim, device, seed=123)
     eng.world_size = world
     eng.force_allreduce = use_dist
+    dp_exchange = None
     if use_dist:
+        dp_exchange = 'torch.distributed all_reduce (RCCL), pieces coalesced into one launch'
+        if os.environ.get('PP_DP_NATIVE', '0') == '1':      # opt-in: this library's own communicator, exchange issued from C
+            from pyprob_amd.parallel import init_native_comm
+            if init_native_comm(device, lib):
+                dp_exchange = 'pp_dp_reduce_grads (ncclAllReduce from the C side, grouped pieces)'
         eng.broadcast_params()
         if args.workload == 'train':
             # every GaussianUnknownMean trace has ONE controlled variable: dL/dW_hh is zero on every rank, its range (2/3 to
@@ -327,7 +333,8 @@ def main():
                       traces_in_hbm=per_rank * world, params=eng.spec.num_parameters(), global_batch=B * world,
                       parallelism='dp%d' % world, optimizer='Adam lr=1e-3*sqrt(world)', final_loss=round(final_loss, 4),
                       launch='hip_graph_replay' if args.graph else 'eager',
-                      allreduce_bytes_per_step=(4 * (eng.grads_full.numel() - sum(c for _, c in eng.dp_skip)) if use_dist else 0))
+                      allreduce_bytes_per_step=(4 * (eng.grads_full.numel() - sum(c for _, c in eng.dp_skip)) if use_dist else 0),
+                      dp_exchange=dp_exchange)
     elif args.workload == 'train_gumm':
         # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
         # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded

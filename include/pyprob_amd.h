@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 5
+#define PP_ABI_VERSION 6
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -274,6 +274,12 @@ typedef struct pp_train_buffers {
     void* staging; void* device_batch; int64_t slot_words;                       /* pinned host / dev */
     float* loss_ring; int32_t* status_ring;                                      /* dev [n_steps] */
     int32_t n_tensors; int32_t n_slots;
+    /* data parallel (ABI 6): dp_world = size of the communicator of pp_dp_init (0: single rank). `grads` is then the flat
+     * buffer [n_params | n_tensors presence flags | loss | non-finite flag]; between backward and Adam of every step the
+     * loop all-reduces it (minus the dp_n_skip ranges [dp_skip_off, + dp_skip_cnt) that are zero on every rank), Adam divides
+     * by dp_world and every rank skips a step that any rank flagged (pyprob/nn/inference_network.py:296-333, 448) */
+    int32_t dp_world; int32_t dp_n_skip;
+    int64_t dp_skip_off[4], dp_skip_cnt[4];
 } pp_train_buffers;
 
 typedef struct pp_tensor_roles {
@@ -441,6 +447,25 @@ int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_ou
  * 100 MHz wall ticks (s_memrealtime). Effective shader clock = out[0] / (out[1] * 10 ns): used by bench.py to report the
  * DVFS state the timed region ran in (MI355X_MICROARCH.md "DVFS give-back"). */
 /* Diagnostic: when set, the fused head-tail kernel writes per-phase s_memtime stamps of workgroups 0 and 100 to buf. */
+/* ---- data parallel: RCCL from the C side (csrc/dp.hip) --------------------------------------------------------------
+ * Replaces _distributed_sync_grad (pyprob/nn/inference_network.py:296-333: one all-reduce per tensor + presence map + loss)
+ * with ONE grouped launch over the flat buffer. librccl.so is dlopen'ed from `rccl_path` (the copy torch loaded); the
+ * communicator belongs to this library: rank 0 creates a 128-byte id (pp_dp_unique_id), the host hands it to every rank
+ * (torch.distributed broadcast, pyprob_amd/parallel.py), all ranks call pp_dp_init (collective, current HIP device). */
+int pp_dp_unique_id(const char* rccl_path, void* id_out /*host [128]*/);
+int pp_dp_init(const char* rccl_path, const void* unique_id /*host [128]*/, int32_t rank, int32_t world);
+int pp_dp_world(void);       /* size of the communicator, 0 when there is none */
+int pp_dp_destroy(void);
+/* in-place sum over the ranks of the pieces [off[i], off[i] + cnt[i]) of base (floats): one grouped launch */
+int pp_dp_allreduce(float* base /*dev*/, const int64_t* off /*host*/, const int64_t* cnt /*host*/, int32_t n, void* stream);
+/* The exchange of one training step: grads_full = dev [n_params | n_tensors | loss | flag]. Copies `presence` (dev
+ * [n_tensors], or NULL when the tail already holds the step's presence map) and the step's non-finite flag `status` (dev
+ * int32) into the tail, all-reduces everything but the skip ranges, and writes the mean loss / the any-rank flag to
+ * loss_out / status_out (dev, may be NULL). Adam then runs with grad_scale = 1 / world on the reduced tail. */
+int pp_dp_reduce_grads(float* grads_full, int64_t n_params, int32_t n_tensors, const float* presence, const int32_t* status,
+                       const int64_t* skip_off /*host*/, const int64_t* skip_cnt /*host*/, int32_t n_skip, float* loss_out,
+                       int32_t* status_out, void* stream);
+
 int pp_debug_timeline(long long* buf /*dev [16] or NULL*/);
 /* debug: per-workgroup {start, end, problem, split, operands ready, loads issued, first slab landed, K loop done} stamps (10 ns ticks) of the grouped async GEMM launches
  * (mode 1: weight-gradient groups, 2: data-gradient products); buf = dev int64 [8 * cap] or NULL (tools/wg_trace.py) */

@@ -21,6 +21,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
 int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params, const int32_t* chunk_tensor,
               const float* active, int32_t* tensor_step, int32_t* arrived, int n_tensors, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, int flags, const int32_t* skip, hipStream_t st);
+int dp_world();
+int dp_reduce_grads(float* grads_full, int64_t n_params, int n_tensors, const float* presence, const int32_t* status,
+                    const int64_t* skip_off, const int64_t* skip_cnt, int n_skip, float* loss_out, int32_t* status_out,
+                    hipStream_t st);
 }  // namespace pp
 
 // upload-complete events of the two staging halves; one training run at a time per process (like the reference's loop)
@@ -50,6 +54,13 @@ int pp_train_steps(const pp_net* net, const pp_train_buffers* tb, const pp_tenso
     }
     hipStream_t st = pp::as_stream(stream);
     const int n_addr = net->n_addr, n_tensors = tb->n_tensors;
+    // data parallel: every step all-reduces [grads | presence | loss | flag] between backward and Adam (csrc/dp.hip)
+    const bool dp = tb->dp_world >= 1;
+    if (dp && (pp::dp_world() != tb->dp_world || tb->dp_n_skip < 0 || tb->dp_n_skip > 4)) {
+        pp::set_error("pp_train_steps: dp_world %d but the communicator has %d ranks (pp_dp_init)", tb->dp_world, pp::dp_world());
+        return PP_EINVAL;
+    }
+    float* const dp_tail = tb->grads + net->n_params;   // [n_tensors presence | loss | flag] (data parallel only)
     // Minibatches are uploaded in GROUPS: the slots form two halves; a group of up to n_slots/2 steps is packed into one
     // half and crosses PCIe as ONE copy, then its steps are enqueued back to back. A copy on the compute stream costs
     // ~15-20 us of idle GPU per occurrence (it waits for the previous step, then pays the DMA latency): per step that
@@ -127,14 +138,21 @@ int pp_train_steps(const pp_net* net, const pp_train_buffers* tb, const pp_tenso
             bt.addr = devi + info.addr; bt.prev_row = devi + info.prev_row; bt.grp_rows = devi + info.grp_rows;
             bt.trace = devi + info.trace; bt.row_off_dev = devi + info.row_off_dev; bt.nxt_rows = devi + info.nxt_rows;
             const int flags = PP_LOSS_BACKWARD | ((i == 0 && !grads_clean) ? PP_LOSS_ZERO_GRADS : 0);
-            rc = pp::ic_loss(net, &bt, tb->params, tb->grads, tb->workspace, tb->workspace_bytes, tb->loss_ring + i,
-                             tb->status_ring + i, nullptr, flags, st);
+            rc = pp::ic_loss(net, &bt, tb->params, tb->grads, tb->workspace, tb->workspace_bytes,
+                             dp ? dp_tail + n_tensors : tb->loss_ring + i, tb->status_ring + i, nullptr, flags, st);
             if (rc != 0) break;
+            if (dp) {   // presence map + flag into the tail, ONE grouped all-reduce, mean loss / any-rank flag back to the rings
+                rc = pp::dp_reduce_grads(tb->grads, net->n_params, n_tensors, dev + pk[k].words, tb->status_ring + i,
+                                         tb->dp_skip_off, tb->dp_skip_cnt, tb->dp_n_skip, tb->loss_ring + i, tb->status_ring + i,
+                                         st);
+                if (rc != 0) break;
+            }
             // Adam checks the step's non-finite flag itself (`skip`) and clears the gradients it consumed (the next
-            // step's zero_grad, :486)
+            // step's zero_grad, :486); data parallel: the merged presence map, the summed gradients / world
             rc = pp::adam_step(tb->params, tb->grads, tb->exp_avg, tb->exp_avg_sq, net->n_params, tb->chunk_tensor,
-                               dev + pk[k].words, tb->tensor_step, tb->adam_scratch, n_tensors, lr[i], beta1, beta2, eps,
-                               weight_decay, 1.0f, PP_ADAM_ZERO_GRADS, tb->status_ring + i, st);
+                               dp ? dp_tail : dev + pk[k].words, tb->tensor_step, tb->adam_scratch, n_tensors, lr[i], beta1, beta2,
+                               eps, weight_decay, dp ? 1.0f / (float)tb->dp_world : 1.0f, PP_ADAM_ZERO_GRADS,
+                               tb->status_ring + i, st);
         }
     }
     // Returns with the last groups still queued: the caller plans its next run meanwhile. The staging halves stay

@@ -197,8 +197,10 @@ class ICEngine:
         dataset (pyprob_amd/dataset.py) with learning rate lrs[i] - packing, upload, loss + backward and Adam per step
         without returning to Python (single rank). Returns (losses, statuses): device tensors [n_steps], not synchronised.
         The caller polymorphs first; per-address iteration counters (inference_network_lstm.py:198) are updated here."""
-        if self.world_size != 1 or self.force_allreduce:
-            raise RuntimeError('train_run is the single-rank loop; data-parallel training steps go through train_step')
+        dp = self.world_size != 1 or self.force_allreduce
+        if dp and self.lib.pp_dp_world() != self.world_size:
+            raise RuntimeError('train_run under data parallelism needs the native RCCL communicator '
+                               '(pyprob_amd.parallel.init_native_comm); without it the steps go through train_step')
         n_steps = len(id_lists)
         spec = self.spec
         shards, n_shards, first = dataset.native_columns(spec)
@@ -237,6 +239,10 @@ class ICEngine:
                                 self.arrived.data_ptr(), self.workspace.data_ptr(), self.ws_bytes,
                                 self._staging.data_ptr(), self._device_batch.data_ptr(), self._slot_words,
                                 self._loss_ring.data_ptr(), self._status_ring.data_ptr(), spec.n_tensors, n_slots)
+        if dp:      # (self.grads is the head of grads_full: the reduced tail follows the gradients)
+            tb.dp_world, tb.dp_n_skip = self.world_size, len(self.dp_skip)
+            for k, (off, cnt) in enumerate(self.dp_skip):
+                tb.dp_skip_off[k], tb.dp_skip_cnt[k] = off, cnt
         lr = np.ascontiguousarray(lrs, np.float32).reshape(-1)
         if len(lr) != n_steps:
             raise ValueError('one learning rate per step')
@@ -321,6 +327,17 @@ class ICEngine:
         """ONE RCCL all-reduce (SUM) over [flat grads | presence map | loss | non-finite flag]
         (replaces the per-tensor loop of _distributed_sync_grad, inference_network.py:296-333). With `dp_skip` ranges
         (gradients that are zero on every rank by construction) the remaining pieces are reduced instead."""
+        if self.lib.pp_dp_world() == self.world_size and not self.grads_full.is_cpu:
+            # this library's own communicator (pyprob_amd.parallel.init_native_comm): flag into the tail + ONE grouped
+            # ncclAllReduce from C, no torch operator on the way (the tail keeps the SUMS, like the torch path below)
+            n = self.grads.numel()
+            k = len(self.dp_skip)
+            off = (C.c_int64 * max(k, 1))(*[o for o, _ in self.dp_skip])
+            cnt = (C.c_int64 * max(k, 1))(*[c for _, c in self.dp_skip])
+            L.check(self.lib.pp_dp_reduce_grads(self.grads_full.data_ptr(), n, self.spec.n_tensors, None,
+                                                self.status_buf.data_ptr(), off, cnt, k, None, None, L.stream_ptr()),
+                    'pp_dp_reduce_grads')
+            return
         from .parallel import allreduce_flat_
         self.status_tail.copy_(self.status_buf[:1])          # int32 flag -> float, into the reduced tail
         if not self.dp_skip:

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 5
+PP_ABI_VERSION = 6
 PP_MAX_OBS = 8
 PP_MAX_LSTM_DEPTH = 4
 PP_MAX_OBS_DEPTH = 4
@@ -82,7 +82,8 @@ class pp_train_buffers(C.Structure):
                 ('chunk_tensor', vp), ('tensor_step', vp), ('adam_scratch', vp),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
                 ('staging', vp), ('device_batch', vp), ('slot_words', i64),
-                ('loss_ring', vp), ('status_ring', vp), ('n_tensors', i32), ('n_slots', i32)]
+                ('loss_ring', vp), ('status_ring', vp), ('n_tensors', i32), ('n_slots', i32),
+                ('dp_world', i32), ('dp_n_skip', i32), ('dp_skip_off', i64 * 4), ('dp_skip_cnt', i64 * 4)]
 
 
 class pp_tensor_roles(C.Structure):
@@ -121,6 +122,12 @@ PROTOTYPES = {
     'pp_lstm_cell_bwd': (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'pp_head_logprob': (C.c_int, [i32, vp, i64, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]),
     'pp_debug_clock_probe': (C.c_int, [i32, vp, vp, vp]),
+    'pp_dp_unique_id': (C.c_int, [C.c_char_p, vp]),
+    'pp_dp_init': (C.c_int, [C.c_char_p, vp, i32, i32]),
+    'pp_dp_world': (C.c_int, []),
+    'pp_dp_destroy': (C.c_int, []),
+    'pp_dp_allreduce': (C.c_int, [vp, vp, vp, i32, vp]),
+    'pp_dp_reduce_grads': (C.c_int, [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
     'pp_debug_timeline': (C.c_int, [vp]),
     'pp_debug_wgtrace': (C.c_int, [vp, C.c_int32, C.c_int32]),
     'pp_prof_arm': (C.c_int, [i32, i32]),

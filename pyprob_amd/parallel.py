@@ -59,6 +59,44 @@ def _coalescing_works(device):
     return _COALESCE[key]
 
 
+def init_native_comm(device, lib=None):
+    """This library's own RCCL communicator over the ranks of the default torch.distributed group (csrc/dp.hip): rank 0
+    creates the ncclUniqueId, a broadcast hands it to every rank, all ranks call ncclCommInitRank on their device; the
+    outcome is agreed on with a MIN all-reduce, so either every rank uses the native exchange or none does. Returns True
+    when the communicator is up (pp_dp_world() == world size)."""
+    import ctypes as C
+    import os
+    import torch
+    import torch.distributed as dist
+    from . import lib as L
+    lib = lib or L.load()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if lib.pp_dp_world() == world:
+        return True
+    path = os.environ.get('PP_RCCL_PATH') or os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+    ident = torch.zeros(128, dtype=torch.uint8)
+    ok = os.path.exists(path)
+    if ok and rank == 0:
+        raw = (C.c_char * 128)()
+        ok = lib.pp_dp_unique_id(path.encode(), raw) == 0
+        ident = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+    ident = ident.to(device)
+    dist.broadcast(ident, 0)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)        # rank 0 could not even create the id: nobody enters the collective init
+    if int(flag.item()) == 0:
+        return False
+    torch.cuda.set_device(device)
+    raw = ident.cpu().numpy().tobytes()
+    ok = lib.pp_dp_init(path.encode(), raw, rank, world) == 0
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        lib.pp_dp_destroy()
+        return False
+    return True
+
+
 def finish_reduce(buf, n_params, n_tensors, world_size):
     """After the all-reduce: averaged gradients (inference_network.py:324-325), merged presence map (:300-315: a tensor
     is updated if ANY rank produced a gradient) and mean loss (:327-333). Returns views (grads, active, loss)."""
