@@ -194,10 +194,12 @@ def main():
     dp_exchange = None
     if use_dist:
         dp_exchange = 'torch.distributed all_reduce (RCCL), pieces coalesced into one launch'
-        if os.environ.get('PP_DP_NATIVE', '0') == '1':      # opt-in: this library's own communicator, exchange issued from C
-            from pyprob_amd.parallel import init_native_comm
+        if os.environ.get('PP_DP_NATIVE', '1') == '1':      # this library's own communicator, exchange issued from C
+            from pyprob_amd.parallel import init_native_comm        # (all ranks agree; any failure -> the torch path above)
             if init_native_comm(device, lib):
+                eng.native_dp = True
                 dp_exchange = 'pp_dp_reduce_grads (ncclAllReduce from the C side, grouped pieces)'
+
         eng.broadcast_params()
         if args.workload == 'train':
             # every GaussianUnknownMean trace has ONE controlled variable: dL/dW_hh is zero on every rank, its range (2/3 to

@@ -60,6 +60,7 @@ class ICEngine:
         self.loss_buf = self.grads_full[n + spec.n_tensors:n + spec.n_tensors + 1]   # the loss kernel writes into the tail
         self.status_tail = self.grads_full[n + spec.n_tensors + 1:]                  # float copy of the non-finite flag
         self.dp_skip = []      # (offset, count) float ranges left out of the gradient all-reduce, see skip_recurrent_weights
+        self.native_dp = False   # set by the caller after pyprob_amd.parallel.init_native_comm() returned True on ALL ranks
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.tensor_step = torch.zeros(spec.n_tensors, dtype=torch.int32, device=self.device)
@@ -198,7 +199,7 @@ class ICEngine:
         without returning to Python (single rank). Returns (losses, statuses): device tensors [n_steps], not synchronised.
         The caller polymorphs first; per-address iteration counters (inference_network_lstm.py:198) are updated here."""
         dp = self.world_size != 1 or self.force_allreduce
-        if dp and self.lib.pp_dp_world() != self.world_size:
+        if dp and not (self.native_dp and self.lib.pp_dp_world() == self.world_size):
             raise RuntimeError('train_run under data parallelism needs the native RCCL communicator '
                                '(pyprob_amd.parallel.init_native_comm); without it the steps go through train_step')
         n_steps = len(id_lists)
@@ -327,7 +328,7 @@ class ICEngine:
         """ONE RCCL all-reduce (SUM) over [flat grads | presence map | loss | non-finite flag]
         (replaces the per-tensor loop of _distributed_sync_grad, inference_network.py:296-333). With `dp_skip` ranges
         (gradients that are zero on every rank by construction) the remaining pieces are reduced instead."""
-        if self.lib.pp_dp_world() == self.world_size and not self.grads_full.is_cpu:
+        if self.native_dp and self.lib.pp_dp_world() == self.world_size and not self.grads_full.is_cpu:
             # this library's own communicator (pyprob_amd.parallel.init_native_comm): flag into the tail + ONE grouped
             # ncclAllReduce from C, no torch operator on the way (the tail keeps the SUMS, like the torch path below)
             n = self.grads.numel()

@@ -411,6 +411,11 @@ class InferenceNetworkLSTM:
             world, rank = dist.get_world_size(), dist.get_rank()
         self._distributed_world_size = world
         self._engine.world_size = world
+        if world > 1 and distributed_backend == 'nccl' and os.environ.get('PP_DP_NATIVE', '1') == '1':
+            # this library's own RCCL communicator: the gradient exchange is issued from the C side, and the native loop
+            # pp_train_steps gets its data-parallel branch (every rank agrees on the outcome; otherwise torch.distributed)
+            from .parallel import init_native_comm
+            self._engine.native_dp = bool(init_native_comm(self._engine.device))
         if self._learning_rate_init is None:
             self._learning_rate_init = learning_rate_init * math.sqrt(world)            # :448
         if self._learning_rate_end is None:
@@ -499,7 +504,11 @@ class InferenceNetworkLSTM:
         # - dataset._bernoulli_step_stats -: such programs keep the per-step loop)
         has_bernoulli = any(a.dist_name == 'Bernoulli' for a in self._engine.spec.addresses) or \
             (packed and any(a[1] == 'Bernoulli' for a in getattr(dataset, 'addresses', [])))
-        native = packed and world == 1 and not has_bernoulli and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
+        # (data parallel: the C loop has an all-reduce branch - tests/test_gpu_dp_native.py on a one-rank group - but
+        # ranks must then cut their runs at the same steps; until that has run on a multi-GPU node it is opt-in,
+        # PP_DP_NATIVE_LOOP=1, and the default is the per-step loop with the exchange issued from C)
+        native = packed and (world == 1 or (self._engine.native_dp and os.environ.get('PP_DP_NATIVE_LOOP', '0') == '1')) and \
+            not has_bernoulli and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
         chunk_steps = 1 if sync_every == 1 else 64
         carry = None
         type_key, type_known = None, None

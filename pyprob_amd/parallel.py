@@ -88,11 +88,23 @@ def init_native_comm(device, lib=None):
         return False
     torch.cuda.set_device(device)
     raw = ident.cpu().numpy().tobytes()
-    ok = lib.pp_dp_init(path.encode(), raw, rank, world) == 0
+    # ncclCommInitRank is a collective: in a thread with a deadline, so that a rank whose peers never arrive falls back to
+    # the torch.distributed exchange instead of hanging the job (ctypes releases the GIL during the call)
+    import threading
+    box = {}
+
+    def _init():
+        torch.cuda.set_device(device)
+        box['rc'] = lib.pp_dp_init(path.encode(), raw, rank, world)
+    th = threading.Thread(target=_init, daemon=True)
+    th.start()
+    th.join(float(os.environ.get('PP_DP_INIT_TIMEOUT', '90')))
+    ok = (not th.is_alive()) and box.get('rc') == 0
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
-        lib.pp_dp_destroy()
+        if not th.is_alive():
+            lib.pp_dp_destroy()
         return False
     return True
 

@@ -53,8 +53,7 @@ def test_native_exchange_equals_the_torch_exchange(one_rank_group):
         eng = _engine(128, ['mu'], 'Normal', seed=9)
         eng.force_allreduce = True
         eng.skip_recurrent_weights(True)
-        if mode == 'torch':
-            eng.lib = _NoNative(lib)            # hides the communicator: the torch.distributed path
+        eng.native_dp = mode == 'native'        # (False: the torch.distributed path)
         ids = np.zeros(512, np.int64)
         pb = PackedBatch.from_ragged(arr['trace_len'], ids, arr['values'], arr['prior'], arr['obs'], 1).to(eng.device)
         losses = [float(eng.train_step(pb, 1e-3).item()) for _ in range(6)]
@@ -64,17 +63,6 @@ def test_native_exchange_equals_the_torch_exchange(one_rank_group):
     d = np.abs(runs['native'][1] - runs['torch'][1])
     assert np.linalg.norm(d) < 1e-3 * np.linalg.norm(runs['torch'][1])
     assert runs['native'][2] == 0.0
-
-
-class _NoNative:
-    def __init__(self, lib):
-        self._lib = lib
-
-    def pp_dp_world(self):
-        return 0
-
-    def __getattr__(self, name):
-        return getattr(self._lib, name)
 
 
 def test_native_loop_runs_its_data_parallel_branch(one_rank_group):
@@ -89,6 +77,7 @@ def test_native_loop_runs_its_data_parallel_branch(one_rank_group):
     a, b = _engine(64, addresses, 'Uniform', seed=3), _engine(64, addresses, 'Uniform', seed=3)
     la, sa = a.train_run(ds, steps, lrs)                  # single-rank loop
     b.force_allreduce = True                              # data-parallel branch over the one-rank communicator
+    b.native_dp = True
     lb, sb = b.train_run(ds, steps, lrs)
     torch.cuda.synchronize()
     np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=2e-5)
