@@ -26,6 +26,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Kernels whose launches count on TWO workgroups per CU (64-72 KB of LDS each): above 128 VGPRs an 8-wave workgroup gets a CU
+# to itself and the launch serialises - the reduction jobs that share `gemm_f32_async_grouped_aux_kernel` with the MFMA tiles
+# once pushed it to 169 registers and the config-2 step from 0.114 to 0.175 ms. The compile prints the resource remarks
+# (-Rpass-analysis) and the build fails if one of these kernels grows past the limit.
+VGPR_LIMITS = {'gemm_f32_async_grouped_aux_kernel': 128, 'gemm_f32_async_grouped_kernel': 128, 'gemm_f32_async_kernel': 128,
+               'gemm_f32_async_lstm_kernel': 128}
+
+
+def _check_registers(remarks):
+    name = None
+    for line in remarks.splitlines():
+        if 'Function Name:' in line:
+            name = line.split('Function Name:')[1].split()[0]
+        elif 'VGPRs:' in line and 'AGPRs' not in line and name:
+            n = int(line.split('VGPRs:')[1].split()[0])
+            for key, limit in VGPR_LIMITS.items():
+                if key in name and n > limit:
+                    raise RuntimeError('%s uses %d VGPRs (limit %d: two workgroups per CU)' % (name, n, limit))
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the C-ABI shared library. Returns the library path."""
     hipcc = _hipcc()
@@ -40,7 +60,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+            jobs.append([hipcc] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', s, '-o', o])
 
     def run(cmd):
         if verbose:
@@ -48,6 +68,7 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), r.stderr))
+        _check_registers(r.stderr)
         return r
 
     with ThreadPoolExecutor(max_workers=4) as ex:

@@ -50,8 +50,71 @@ __device__ __forceinline__ bool aux_present(const AuxJobs& j, int a) {
     return j.all_present || ((j.present[(a >> 5) & 31] >> (a & 31)) & 1u);
 }
 
+// Wide jobs (the per-address column sums of dG: 4H columns) take 256 columns per workgroup with 16-byte loads: a quarter of
+// the workgroups, four times the bytes in flight per thread (2864 workgroups of 64 x 64 floats made the column-sum launch of a
+// ragged 12-address step 27 us for 43 MB).
+__host__ __device__ __forceinline__ bool aux_colsum_wide(const ColsumJob& j) {
+    return j.n_cols >= 256 && (j.n_cols & 3) == 0 && (j.ldx & 3) == 0 && !j.wgt && j.out_stride <= 1 &&
+           (reinterpret_cast<uintptr_t>(j.X) & 15) == 0;
+}
+__host__ __device__ __forceinline__ int aux_colsum_blocks(const ColsumJob& j) {
+    const int cw = aux_colsum_wide(j) ? 256 : 64;
+    return ((j.n_cols + cw - 1) / cw) * ((j.n_rows + AUX_COLSUM_ROWS - 1) / AUX_COLSUM_ROWS);
+}
+
+__device__ __forceinline__ void aux_colsum_wide_block(const ColsumJob& jb, int local, float* lds) {
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const int nrl = nt >> 6;                        // row lanes
+    const int cl = tid & 63, rl = tid >> 6;
+    const int ncc = (jb.n_cols + 255) / 256;
+    const int bx = local % ncc, by = local / ncc;
+    const int col = bx * 256 + 4 * cl;              // this thread's four columns
+    const int r0 = by * AUX_COLSUM_ROWS;
+    const float* __restrict__ X = jb.X;
+    const int32_t* __restrict__ idx = jb.idx;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (col < jb.n_cols) {
+        // (four 16-byte loads in flight per trip: this code shares its kernel with the MFMA tiles, whose two workgroups per
+        // CU need the kernel to stay within 128 VGPRs - eight in flight pushed it to 169 and the weight-gradient launch of the
+        // config-2 step from 23 to 80 us)
+#pragma unroll 1
+        for (int q0 = 0; q0 < 16; q0 += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u;
+                const int i = r0 + rl + nrl * q;
+                v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (q * nrl < AUX_COLSUM_ROWS && i < jb.n_rows) {
+                    const int64_t r = idx ? (int64_t)idx[i] : (int64_t)i;
+                    v[u] = *reinterpret_cast<const f32x4*>(X + r * jb.ldx + col);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+    }
+    // row lanes meet in LDS: [nrl][256]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lds[rl * 256 + 4 * cl + e] = acc[e];
+    __syncthreads();
+    for (int c = tid; c < 256; c += nt) {
+        const int gc = bx * 256 + c;
+        if (gc < jb.n_cols) {
+            float sum = 0.0f;
+            for (int q = 0; q < nrl; ++q) sum += lds[q * 256 + c];
+            atomicAdd(jb.out + gc, sum);
+            if (jb.out2) atomicAdd(jb.out2 + gc, sum);
+        }
+    }
+}
+
 __device__ __forceinline__ void aux_colsum_block(const ColsumJob& jbin, int local, float* lds) {
     const ColsumJob jb = jbin;   // local copy: fields read through the kernel-argument table are re-loaded at every use
+    if (aux_colsum_wide(jb)) {   // workgroup-uniform
+        aux_colsum_wide_block(jb, local, lds);
+        return;
+    }
     const int nt = blockDim.x, tid = threadIdx.x;
     const int nrl = nt >> 6;                        // row lanes
     const int cl = tid & 63, rl = tid >> 6;
@@ -186,7 +249,7 @@ __device__ __forceinline__ void aux_dbsum_block(const AuxJobs& j, int local) {
     j.db_hh[n] += s;
 }
 
-// workgroup `b` (0 <= b < n_blocks) of the job list; lds: >= 512 floats
+// workgroup `b` (0 <= b < n_blocks) of the job list; lds: >= 2048 floats
 __device__ __forceinline__ void aux_job_run(const AuxJobs& j, int b, float* lds) {
     if (b < j.cs_first[j.n_colsum]) {
         int q = 0;
@@ -208,7 +271,7 @@ static inline void aux_layout(AuxJobs& j, bool derived) {
     int b = 0;
     j.cs_first[0] = 0;
     for (int q = 0; q < j.n_colsum; ++q) {
-        b += ((j.cs[q].n_cols + 63) / 64) * ((j.cs[q].n_rows + AUX_COLSUM_ROWS - 1) / AUX_COLSUM_ROWS);
+        b += aux_colsum_blocks(j.cs[q]);
         j.cs_first[q + 1] = b;
     }
     j.outer_first = j.table_first = j.dbsum_first = -1;

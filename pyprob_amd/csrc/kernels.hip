@@ -141,7 +141,7 @@ int colsum_multi(const ColsumJob* jobs, int count, hipStream_t st, const float* 
 
 // the jobs of aux_jobs.hpp as their own launch (when they cannot ride behind the weight-gradient tiles)
 __global__ __launch_bounds__(256) void aux_jobs_kernel(const AuxJobs jobs) {
-    __shared__ float lds[512];
+    __shared__ float lds[2048];
     aux_job_run(jobs, (int)blockIdx.x, lds);
 }
 
