@@ -75,6 +75,9 @@ static inline bool deterministic_mode() {
 struct GemmExt {
     const float* rb; const int32_t* rb_addr; const int32_t* rb_prev;
     float* cell_c; float* cell_h; int cell_H, cell_rows;
+    // cell_cprev != nullptr (rb == nullptr): the RECURRENT product of a later time step, G_t = pre-activations already in C
+    // (input part + biases) + h_{t-1} W_hh^T; every row goes through the cell with its previous cell state cell_cprev[m]
+    const float* cell_cprev;
     float* bw_G; const float* bw_C; int bw_H;
     // lean: single-statement batch whose backward runs in the dH epilogue with the zero blocks on - nobody reads the forget
     // gate's columns of G / dG nor the stored cell state (c = i g when c_prev = 0): they are not written (cell_c and bw_C

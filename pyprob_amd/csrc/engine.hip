@@ -499,6 +499,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     prof_end(2, gather_bytes, st);
     // nn.LSTM(I, H, depth), inference_network_lstm.py:31,186-188: layer k reads the hidden states of layer k - 1
     const int L = ff ? 0 : std::max(1, (int)net->lstm_depth);
+    const bool compact_ok_dims = !ff && !deterministic_mode();   // (fused epilogues use float4 stores and no fixed order is at stake)
     auto lw_ih = [&](int l) { return l == 0 ? net->w_ih : net->lstm_w_ih[l]; };
     auto lw_hh = [&](int l) { return l == 0 ? net->w_hh : net->lstm_w_hh[l]; };
     auto lb_ih = [&](int l) { return l == 0 ? net->b_ih : net->lstm_b_ih[l]; };
@@ -561,10 +562,21 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 g.B = P + lw_hh(l); g.ldb = H;
                 g.C = Gt; g.ldc = 4 * H;
                 g.M = n; g.N = 4 * H; g.K = H;
+                c_prev = w.Cl[l] + (int64_t)rp * H;
+                // Recurrent product with the cell in its epilogue (gate-interleaved tiles; one workgroup per tile walks all of
+                // K = H, the pre-activations are read instead of accumulated into): no lstm_cell_fwd launch, no round trip of
+                // G. Needs enough tiles to fill the chip without a K split: n >= 64 rows x 4H / 64 column tiles.
+                static const int fuse_rec = env_flag("PP_FUSE_CELL_REC", 1);
+                if (fuse_rec && compact_ok_dims && H % 16 == 0 && n >= 64) {
+                    GemmExt x{};
+                    x.cell_H = H; x.cell_rows = n; x.cell_c = w.Cl[l] + (int64_t)r0 * H; x.cell_h = w.Hl[l] + (int64_t)r0 * H;
+                    x.cell_cprev = c_prev;
+                    PP_TRY(gemm_f32(&g, st, nullptr, &x));
+                    continue;
+                }
                 g.accumulate = 1;
                 g.split_k = 1;   // few rows late in a ragged batch: spread K over workgroups (accumulation into G)
                 PP_TRY(gemm_f32(&g, st));
-                c_prev = w.Cl[l] + (int64_t)rp * H;
             }
             if (t == 0 && cell_done) continue;
             PP_TRY(lstm_cell_fwd(Gt, c_prev, w.Cl[l] + (int64_t)r0 * H, w.Hl[l] + (int64_t)r0 * H, n, H, st));

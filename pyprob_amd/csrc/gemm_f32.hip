@@ -482,6 +482,14 @@ __device__ __forceinline__ void lstm_row_bias(const GemmParams& p, const GemmExt
     const int nloc = wn * 32 + l31;
     const int gn = H ? (nloc >> 4) * H + bx * 16 + (nloc & 15) : bx * 64 + nloc;
     const int gnc = gn < p.N ? gn : 0;
+    if (!x.rb) {        // recurrent product: the "bias" of an element is its pre-activation, already in C
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, p.M - 1);
+            rbv[r] = p.C[(int64_t)gm * p.ldc + gnc];
+        }
+        return;
+    }
     if (!x.rb_addr) {   // every row has the same current address and no previous one: rb IS its bias vector (one load)
         const float b = x.rb[gnc];
 #pragma unroll
@@ -541,6 +549,26 @@ __device__ __forceinline__ void lstm_epilogue(const GemmParams& p, const GemmExt
     const f32x4 vo = *reinterpret_cast<const f32x4*>(sr + 48);
     const int u0 = bx * 16 + 4 * q;
     float* g = p.C + (int64_t)gm * p.ldc + u0;
+    if (x.cell_cprev) {       // a later time step: the full cell (lstm_cell_fwd_kernel)
+        const f32x4 cp = *reinterpret_cast<const f32x4*>(x.cell_cprev + (int64_t)gm * H + u0);
+        f32x4 gi, gf, gg, go, cn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gi[e] = sigmoidf_(vi[e]);
+            gf[e] = sigmoidf_(vf[e]);
+            gg[e] = tanhf(vg[e]);
+            go[e] = sigmoidf_(vo[e]);
+            cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+            hn[e] = go[e] * tanhf(cn[e]);
+        }
+        *reinterpret_cast<f32x4*>(g) = gi;
+        *reinterpret_cast<f32x4*>(g + H) = gf;
+        *reinterpret_cast<f32x4*>(g + 2 * H) = gg;
+        *reinterpret_cast<f32x4*>(g + 3 * H) = go;
+        *reinterpret_cast<f32x4*>(x.cell_c + (int64_t)gm * H + u0) = cn;
+        *reinterpret_cast<f32x4*>(x.cell_h + (int64_t)gm * H + u0) = hn;
+        return;
+    }
     if (gm < x.cell_rows) {   // torch.nn.LSTM gates i, f, g, o with c_prev = 0: the forget gate multiplies zero (0 recorded)
         f32x4 gi, gg, go, cn, hn;
 #pragma unroll
@@ -628,7 +656,7 @@ __device__ __forceinline__ void gemm_tile_async(const GemmParams& pin, const int
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
-    const bool lstm = KW == 1 && !A_KM && !B_KM && x && x->rb;   // LSTM input product (workgroup-uniform)
+    const bool lstm = KW == 1 && !A_KM && !B_KM && x && (x->rb || x->cell_cprev);   // LSTM input / recurrent product
     float rbv[16];
     if (lstm) lstm_row_bias(p, *x, m0, bx, wm, wn, l31, h, rbv);
 
@@ -1624,10 +1652,12 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
     fill_params(a, p);
     set_hole(p, hole);
     const bool vec = vec_ok(a);
-    if (ext && ext->rb) {   // the LSTM input product: its epilogue exists in the async 64x64 tile only
+    if (ext && (ext->rb || ext->cell_cprev)) {   // the LSTM input / recurrent product: epilogue in the async 64x64 tile only
         PP_CHECK_ARG((ext->rb_addr || !ext->rb_prev) && vec && a->K >= 1 && !a->a_kmajor && !a->b_kmajor && !a->a_idx && !a->b_idx && !a->c_idx &&
                          !a->mask && !a->colsum && !a->accumulate && !a->relu && !a->bias && !a->bias2,
                      "pp_gemm_f32: unsupported LSTM input product");
+        PP_CHECK_ARG(!ext->cell_cprev || (!ext->rb && ext->cell_H > 0 && ext->cell_rows >= a->M && !ext->lean),
+                     "pp_gemm_f32: bad recurrent-product arguments");
         PP_CHECK_ARG(ext->cell_H == 0 || (ext->cell_H % 16 == 0 && a->N == 4 * ext->cell_H && a->ldc % 4 == 0 && aligned16(a->C) &&
                                           (ext->cell_c || ext->lean) && ext->cell_h),
                      "pp_gemm_f32: bad fused-cell arguments");

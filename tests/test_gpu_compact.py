@@ -102,7 +102,8 @@ def test_compact_rows_match_the_full_width_path(tmp_path, legacy):
     {'PP_AUX_COLSUM': '0'},                                  # column sums as their own launch, derived jobs behind the tiles
     {'PP_AUX_FUSED': '0'},                                   # all reduction jobs as their own launch
     {'PP_DX_PARTIALS': '0'},                                 # dX accumulated with float atomics instead of stored split partials
-    {'PP_CELL_LEAN': '0'},                                   # forget-gate columns and cell state written although unused
+    {'PP_CELL_LEAN': '0'},
+    {'PP_FUSE_CELL_REC': '0'},                               # recurrent products accumulate into G, stand-alone cell kernels                                   # forget-gate columns and cell state written although unused
     {'PP_FUSE_CELL': '0', 'PP_FUSE_CELL_BWD': '0', 'PP_AUX_FUSED': '0'},
 ])
 def test_each_fusion_switch_is_result_neutral(tmp_path, legacy, env):
