@@ -38,7 +38,7 @@ int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int 
 int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
                   int H, float* db, float* db2, hipStream_t st, const float* fin_acc = nullptr,
                   const int32_t* fin_flag = nullptr, int fin_traces = 0, float* fin_loss = nullptr,
-                  int32_t* fin_status = nullptr);
+                  int32_t* fin_status = nullptr, const float* dh_parts = nullptr, int n_parts = 0, int64_t part_stride = 0);
 int head_logprob(int kind, const float* y, int64_t ldy, const int32_t* rows, const float* value, const float* prior,
                  int n, int n_out, float grad_scale, float* lp_out, float* dy, float* loss_acc, int32_t* nonfinite,
                  hipStream_t st);
@@ -128,6 +128,7 @@ struct Workspace {
     float* dZ1;                // [R, hid4]
     float* dH;                 // [R, H]
     float* dC;                 // [B, H]
+    float* dHp;                // [DH_SPLITS][B, H] partial tiles of the recurrent data-gradient product (see ic_loss)
     float* dX;                 // [R, i4]
     float* dE;                 // [B, e4]
     float* dF1;                // [B, e4]
@@ -156,6 +157,7 @@ static bool compact_rows(const pp_net* net) {
            net->n_addr <= 1024 && net->addr_table != nullptr;
 }
 constexpr int DX_SPLITS = 16;
+constexpr int DH_SPLITS = 8;
 static int env_flag(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -213,6 +215,7 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.dZ1 = c.take<float>((int64_t)R * w.hid4);
     w.dH = c.take<float>((int64_t)R * H);
     w.dC = c.take<float>(ff ? 0 : (int64_t)B * H);
+    w.dHp = c.take<float>(ff ? 0 : (int64_t)B * H * DH_SPLITS);   // stored K-split partials of dh_{t-1} += dG_t W_hh
     // (compact rows: room for the partial tiles of up to DX_SPLITS K splits of dX, see ic_loss)
     w.dX = c.take<float>(ff ? 0 : (int64_t)R * w.i4 * (w.compact ? DX_SPLITS : 1));
     w.dE = c.take<float>((int64_t)B * w.e4);
@@ -722,6 +725,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     float* dH_cur = w.dH;          // gradient into the hidden states of the layer being processed (top: from the heads)
     float* dH_other = w.dH2;
     for (int l = L - 1; l >= 0; --l) {
+        int dh_parts = 0;   // K splits of dG_{t+1} W_hh waiting in w.dHp for the cell backward of step t
         for (int t = T - 1; t >= 0; --t) {
             if (fused_bwd) break;   // dG is already in place
             if (tail_teams && t >= tail_t0) {   // steps T-1 .. tail_t0 in one launch; it leaves dh / dc of step tail_t0 - 1
@@ -740,10 +744,31 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             const bool fin = l == L - 1 && t == T - 1;
             PP_TRY(lstm_cell_bwd(Gt, c_prev, w.Cl[l] + (int64_t)r0 * H, dH_cur + (int64_t)r0 * H, w.dC, n, n_next, H,
                                  det ? nullptr : grads + lb_ih(l), det ? nullptr : grads + lb_hh(l), st,
-                                 fin ? fin_acc : nullptr, w.flag, B, loss_out, status_out));   // bias gradients fused
-            if (t > 0)  // dh_{t-1} += dG_t W_hh
-                PP_TRY(linear_dgrad(Gt, 4 * H, P + lw_hh(l), dH_cur + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0,
-                                    n, H, 4 * H, true, st));
+                                 fin ? fin_acc : nullptr, w.flag, B, loss_out, status_out, w.dHp, dh_parts,
+                                 (int64_t)B * H));   // bias gradients fused; + the stored partials of dG_{t+1} W_hh
+            dh_parts = 0;
+            if (t > 0) {  // dh_{t-1} += dG_t W_hh
+                // As K-split partial tiles that the NEXT cell-backward launch adds (rows [0, n) of step t - 1 are the same
+                // traces): no float atomics (6 us per 64 x 64 tile), no read-modify-write of dH
+                static const int dh_partials_env = env_flag("PP_DH_PARTIALS", 1);
+                const int tiles = cdiv(n, 64) * cdiv(H, 64), nslab = 4 * H / 32;
+                const int splits = std::max(1, std::min({DH_SPLITS, cdiv(256, tiles), nslab / 2}));
+                if (dh_partials_env && !det && splits > 1 && H % 4 == 0) {
+                    pp_gemm_args g{};
+                    g.A = Gt; g.lda = 4 * H;
+                    g.B = P + lw_hh(l); g.ldb = H; g.b_kmajor = 1;
+                    g.C = w.dHp; g.ldc = H;
+                    g.M = n; g.N = H; g.K = 4 * H;
+                    GemmExt x{};
+                    x.split_stride = (int64_t)B * H;
+                    x.force_splits = splits;
+                    PP_TRY(gemm_f32(&g, st, nullptr, &x));
+                    dh_parts = splits;
+                } else {
+                    PP_TRY(linear_dgrad(Gt, 4 * H, P + lw_hh(l), dH_cur + (int64_t)bt->row_off[t - 1] * H, H, nullptr, nullptr, 0,
+                                        n, H, 4 * H, true, st));
+                }
+            }
         }
         if (det)   // bias gradients = column sums of the complete dG of this layer, by the single-writer kernel
             cs.push_back(ColsumJob{w.Gl[l], 4 * H, nullptr, R, 4 * H, grads + lb_ih(l), grads + lb_hh(l)});

@@ -1664,6 +1664,13 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
         dim3 grid(cdiv(a->N, 64), cdiv(a->M, 64), 1);
         return launch_dyn(gemm_f32_async_lstm_kernel, grid, 256, as_lds_bytes(), st, &p, ext);
     }
+    if (ext && ext->split_stride > 0) {   // K splits that STORE their partial tiles (async tile; the consumer adds them)
+        PP_CHECK_ARG(ext->force_splits >= 1 && ext->force_splits <= 32 && async_ok(a) && async_split_ok(a, ext->force_splits) &&
+                         !a->c_idx && !a->relu && !a->mask && !a->colsum && !a->bias && !a->bias2 && !a->accumulate,
+                     "pp_gemm_f32: unsupported split-store product");
+        p.split_stride = ext->force_splits > 1 ? ext->split_stride : 0;
+        return launch_split(p, vec, a->a_kmajor, a->b_kmajor, 64, ext->force_splits, 2, st);
+    }
     if (gemv_ok(a)) return launch_gemv(p, vec, st);
     // Tile choice: the hot-path GEMMs are small (<= a few thousand rows); 64x64 tiles give >= 2 workgroups per CU
     // on the 1024x2048x212 input GEMM. Very tall problems (batched IS) use 128x128 tiles.
@@ -1681,13 +1688,6 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
         if (splits > 1) return launch_split(p, vec, a->a_kmajor, a->b_kmajor, DT, splits, 1, st);
         return vec ? launch_direct<4>(p, a->a_kmajor, a->b_kmajor, splits, st)
                    : launch_direct<1>(p, a->a_kmajor, a->b_kmajor, splits, st);
-    }
-    if (ext && ext->split_stride > 0) {   // K splits that STORE their partial tiles (async tile; the consumer adds them)
-        PP_CHECK_ARG(ext->force_splits >= 1 && ext->force_splits <= 32 && async_ok(a) && async_split_ok(a, ext->force_splits) &&
-                         !a->c_idx && !a->relu && !a->mask && !a->colsum && !a->bias && !a->bias2 && !a->accumulate,
-                     "pp_gemm_f32: unsupported split-store product");
-        p.split_stride = ext->force_splits > 1 ? ext->split_stride : 0;
-        return launch_split(p, vec, a->a_kmajor, a->b_kmajor, 64, ext->force_splits, 2, st);
     }
     static const int budget = getenv("PP_SPLIT_BUDGET") ? atoi(getenv("PP_SPLIT_BUDGET")) : 256;
     static const int force = getenv("PP_FORCE_SPLITS") ? atoi(getenv("PP_FORCE_SPLITS")) : 0;

@@ -463,7 +463,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ 
                                                             const float* __restrict__ dh,
                                                             float* __restrict__ dc_carry, int n, int n_next, int H,
                                                             float* __restrict__ db, float* __restrict__ db2,
-                                                            LossFinalize fin) {
+                                                            LossFinalize fin, const float* __restrict__ dh_parts,
+                                                            int n_parts, int64_t part_stride) {
     __shared__ float part[4][4][64];
     // the backward pass's first cell launch also turns the loss slots into the loss (one launch less per step)
     if (fin.acc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) loss_finalize_inline(fin);
@@ -479,7 +480,15 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ 
             const int64_t e = (int64_t)r * H + j;
             const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
             const float tc = tanhf(c[e]);
-            const float dhv = dh[e];
+            float dhv = dh[e];
+            // dh_t of the rows that have a next time step also holds dG_{t+1} W_hh: stored as the partial tiles of that
+            // product's K splits (no float atomics there), added here - up to eight loads in flight
+            if (n_parts > 0 && r < n_next) {
+                float pv[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) pv[z] = z < n_parts ? dh_parts[(int64_t)z * part_stride + e] : 0.0f;
+                dhv += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+            }
             const float dc = (r < n_next ? dc_carry[e] : 0.0f) + dhv * go * (1.0f - tc * tc);
             const float cp = c_prev ? c_prev[e] : 0.0f;
             const float d0 = dc * gg * gi * (1.0f - gi);
@@ -505,12 +514,14 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(float* __restrict__ 
 
 int lstm_cell_bwd(float* G, const float* c_prev, const float* c, const float* dh, float* dc_carry, int n, int n_next,
                   int H, float* db, float* db2, hipStream_t st, const float* fin_acc, const int32_t* fin_flag,
-                  int fin_traces, float* fin_loss, int32_t* fin_status) {
+                  int fin_traces, float* fin_loss, int32_t* fin_status, const float* dh_parts, int n_parts,
+                  int64_t part_stride) {
     PP_CHECK_ARG(G && c && dh && dc_carry && H > 0 && n_next <= n, "pp_lstm_cell_bwd: bad argument");
     if (n <= 0) return 0;
     LossFinalize fin{fin_acc, fin_flag, fin_traces > 0 ? 1.0f / (float)fin_traces : 0.0f, fin_loss, fin_status};
+    PP_CHECK_ARG(n_parts >= 0 && n_parts <= 8 && (n_parts == 0 || dh_parts), "pp_lstm_cell_bwd: bad split partials");
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(H, 64), cdiv(n, CELL_ROWS_BWD)), dim3(256), 0, st, G, c_prev, c, dh,
-                       dc_carry, n, n_next, H, db, db2, fin);
+                       dc_carry, n, n_next, H, db, db2, fin, dh_parts, n_parts, part_stride);
     PP_LAUNCH_CHECK("pp_lstm_cell_bwd");
     return 0;
 }

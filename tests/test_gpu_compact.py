@@ -55,6 +55,22 @@ for name, H, n, depth in cases:
         eng.train_step(pb, lr=1e-3)
     torch.cuda.synchronize()
     out[name + '_params'] = eng.params.cpu().numpy().copy()
+# minibatches of very different sizes through ONE engine (one workspace): stored split partials of a large batch must never
+# be read by a small one (a small product once took the direct tile, wrote one partial and the consumer added four)
+spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=64)
+arr, addresses = synthetic_gumm_arrays(600, seed=21, max_iter=5)
+for a in addresses: spec.add_address(a, 'Uniform')
+eng = ICEngine(spec, device='cuda:0', seed=8)
+ids = np.array([spec.address_id[addresses[j]] for j in arr['addr_idx']])
+off = np.concatenate([[0], np.cumsum(arr['trace_len'])])
+for n0, n1 in ((0, 500), (500, 517), (517, 518), (518, 582)):
+    r0, r1 = off[n0], off[n1]
+    pb = PackedBatch.from_ragged(arr['trace_len'][n0:n1], ids[r0:r1], arr['values'][r0:r1], arr['prior'][r0:r1],
+                                 arr['obs'][n0:n1], len(spec.addresses)).to(eng.device)
+    l = eng.loss(pb, backward=True)
+    torch.cuda.synchronize()
+    out['seq%%d_loss' %% (n1 - n0)] = l.cpu().numpy()
+    out['seq%%d_grads' %% (n1 - n0)] = eng.grads.cpu().numpy()
 np.savez(sys.argv[1], **out)
 '''
 
@@ -103,7 +119,8 @@ def test_compact_rows_match_the_full_width_path(tmp_path, legacy):
     {'PP_AUX_FUSED': '0'},                                   # all reduction jobs as their own launch
     {'PP_DX_PARTIALS': '0'},                                 # dX accumulated with float atomics instead of stored split partials
     {'PP_CELL_LEAN': '0'},
-    {'PP_FUSE_CELL_REC': '0'},                               # recurrent products accumulate into G, stand-alone cell kernels                                   # forget-gate columns and cell state written although unused
+    {'PP_FUSE_CELL_REC': '0'},
+    {'PP_DH_PARTIALS': '0'},                                 # dh_{t-1} += dG_t W_hh with float atomics instead of stored partials                               # recurrent products accumulate into G, stand-alone cell kernels                                   # forget-gate columns and cell state written although unused
     {'PP_FUSE_CELL': '0', 'PP_FUSE_CELL_BWD': '0', 'PP_AUX_FUSED': '0'},
 ])
 def test_each_fusion_switch_is_result_neutral(tmp_path, legacy, env):
