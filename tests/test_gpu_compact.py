@@ -96,7 +96,9 @@ def _compare(a, b, tag):
             scale = np.abs(y).max(1) + 1e-12
             big = scale > 1e-6
             worst = (np.abs(x - y).max(1)[big] / scale[big])
-            assert worst.max() < 5e-4, (tag, k, int(np.argmax(worst)), float(worst.max()))
+            # (tiny minibatches: a tensor region's own maximum is itself a cancelled sum of a few rows - 3e-3 there; a stale or
+            # missing partial shows up as an error of order 1 or more)
+            assert worst.max() < (3e-3 if k.startswith('seq') else 5e-4), (tag, k, int(np.argmax(worst)), float(worst.max()))
             # chunks that are zero in the reference path are zero here too (nothing written where no gradient belongs)
             assert np.abs(x[~big]).max(initial=0.0) < 1e-6, (tag, k)
         else:   # parameters after three Adam steps (Adam amplifies round-off of tiny gradients: looser)
