@@ -57,6 +57,19 @@ def synth_gum_dataset(n, device, seed):
     return obs.contiguous(), mu.contiguous(), prior
 
 
+def host_cores():
+    """Cores this process tree may really use: the cgroup CPU quota when there is one (the GPU boxes of this project
+    show 256 logical CPUs and a quota of 16, tools/cpu_scaling_probe.py), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_train(lstm_dim, batch, budget_s=12.0):
     """Oracle port of one training step (numpy fp32: _loss forward, manual backward, Adam), timed on host cores."""
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -80,16 +93,16 @@ def cpu_baseline_train(lstm_dim, batch, budget_s=12.0):
         if steps >= 3 and time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
-    return dict(value=steps * batch / dt, unit='traces/s', cores=os.cpu_count(), kind='port',
+    return dict(value=steps * batch / dt, unit='traces/s', cores=host_cores(), kind='port',
                 sample='%d steps of %d GUM traces, H=%d: oracle/ic_oracle.py loss_and_grads + adam_step (numpy fp32, '
-                       'BLAS threads = all cores)' % (steps, batch, lstm_dim))
+                       'BLAS threads = all logical CPUs, %d usable under the cgroup quota)' % (steps, batch, lstm_dim, host_cores()))
 
 
 def cpu_baseline_torch(lstm_dim, batch, budget_s=10.0):
     """The reference's own host kernels for this step (torch CPU: nn.LSTM, nn.Linear, autograd, optim.Adam), vectorised
     over the minibatch (oracle/torch_ref.py): an upper bound of what pyprob itself reaches on these cores."""
     from oracle.torch_ref import time_training_steps
-    cores = os.cpu_count()
+    cores = host_cores()
     rate, steps, threads = time_training_steps(lstm_dim, batch, budget_s=budget_s, threads=min(cores, 64))
     return dict(value=rate, unit='traces/s', cores=threads, kind='port',
                 sample='%d steps of %d GUM traces, H=%d: oracle/torch_ref.py (torch %s CPU nn.LSTM + nn.Linear + autograd + '
@@ -117,7 +130,7 @@ def cpu_baseline_gumm(lstm_dim, batch, budget_s=10.0):
         if time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
-    return dict(value=steps * batch / dt, unit='traces/s', cores=os.cpu_count(), kind='port',
+    return dict(value=steps * batch / dt, unit='traces/s', cores=host_cores(), kind='port',
                 sample='%d steps of %d GUMM traces (ragged, %d heads), H=%d: oracle/ic_oracle.py loss_and_grads (numpy fp32, '
                        'per-sub-batch loops like the reference, no optimizer)' % (steps, batch, len(addresses), lstm_dim))
 
