@@ -815,8 +815,15 @@ __global__ __launch_bounds__(256 * KW) void gemm_f32_async_kernel(const GemmPara
 }
 
 // the LSTM input product: per-row address bias, gate-interleaved tiles, fused cell (lstm_epilogue)
-__global__ __launch_bounds__(256) void gemm_f32_async_lstm_kernel(const GemmParams p, const GemmExt x) {
-    gemm_tile_async<false, false, 1>(p, blockIdx.x, blockIdx.y, 0, 1, as_ring, &x);
+// tiles_per_wg > 1: a workgroup walks that many consecutive column tiles of its row panel (a ragged batch's 2 600 rows x 32
+// column tiles are 1 344 workgroups of ~10 us of mostly start-up latency each for 512 resident slots: 28 us)
+__global__ __launch_bounds__(256) void gemm_f32_async_lstm_kernel(const GemmParams p, const GemmExt x, const int tiles_per_wg,
+                                                                  const int gx) {
+    const int b0 = blockIdx.x * tiles_per_wg, b1 = min(gx, b0 + tiles_per_wg);
+    for (int bx = b0; bx < b1; ++bx) {
+        gemm_tile_async<false, false, 1>(p, bx, blockIdx.y, 0, 1, as_ring, &x);
+        if (bx + 1 < b1) __syncthreads();   // the next tile's DMA reuses the ring / exchange image
+    }
 }
 
 // ---- a handful of rows (M <= GEMV_ROWS): one wave per output column ------------------------------------------
@@ -905,6 +912,7 @@ struct GroupedParams {
     int count;
     int xcd_aware;
     GemmExt ext;                // shared by the problems of the launch (cell backward in the dH epilogue)
+    int warm;                   // touch the argument lines with one vector load first (PP_WARM_KERNARGS, default 1)
     long long* trace;           // debug (pp_debug_wgtrace): per workgroup {start, end} wall-clock ticks (10 ns), problem, split
 };
 long long* g_wgtrace = nullptr;   // device buffer [8 x workgroups] or nullptr
@@ -981,7 +989,7 @@ static inline int group_blocks(int gx, int gy, int gz, int pmode = 0) {
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupedParams g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + KPAD)];   // double-buffered K slabs
-    warm_kernargs((int)sizeof(GroupedParams));
+    if (g.warm) warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
     // VEC == 4 instantiation: problems whose leading dimensions / pointers are not 16-byte friendly (e.g. the 2-wide
@@ -1345,7 +1353,7 @@ __global__ __launch_bounds__(256) void gemm_f32_direct_kernel(const GemmParams p
 template <bool A_KM, bool B_KM, int VEC>
 __global__ __launch_bounds__(256) void gemm_f32_direct_grouped_kernel(const GroupedParams g) {
     __shared__ __attribute__((aligned(16))) float red[direct_lds_floats<A_KM, B_KM>()];
-    warm_kernargs((int)sizeof(GroupedParams));
+    if (g.warm) warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
     if (VEC == 4 && !g.p[q].vec) gemm_tile_direct<A_KM, B_KM, 1>(g.p[q], bx, by, bz, g.gz[q], red, &g.ext);
@@ -1360,7 +1368,7 @@ __global__ __launch_bounds__(256) void gemm_f32_direct_grouped_aux_kernel(const 
         aux_job_run(aux, (int)blockIdx.x - nb, red);
         return;
     }
-    warm_kernargs((int)sizeof(GroupedParams));
+    if (g.warm) warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
     if (!g.p[q].vec) gemm_tile_direct<true, true, 1>(g.p[q], bx, by, bz, g.gz[q], red);
@@ -1392,7 +1400,7 @@ static int launch_direct_grouped(const GroupedParams& g, bool akm, bool bkm, hip
 template <bool A_KM, bool B_KM, int KW>
 __global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_kernel(const GroupedParams g) {
     const long long t0 = g.trace ? wall_clock64() : 0;
-    warm_kernargs((int)sizeof(GroupedParams));
+    if (g.warm) warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
     gemm_tile_async<A_KM, B_KM, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring, nullptr, g.trace ? g.trace + 8 * blockIdx.x : nullptr);
@@ -1408,7 +1416,7 @@ __global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_aux_kernel(co
         wg_trace(g, blockIdx.x, t0, 100 + (((int)blockIdx.x - nb) < aux.cs_first[aux.n_colsum] ? 0 : 1), 0);
         return;
     }
-    warm_kernargs((int)sizeof(GroupedParams));
+    if (g.warm) warm_kernargs((int)sizeof(GroupedParams));
     int q, bx, by, bz;
     if (!group_decode(g, blockIdx.x, q, bx, by, bz)) return;
     gemm_tile_async<true, true, KW>(g.p[q], bx, by, bz, g.gz[q], as_ring, nullptr, g.trace ? g.trace + 8 * blockIdx.x : nullptr);
@@ -1418,7 +1426,7 @@ __global__ __launch_bounds__(256 * KW) void gemm_f32_async_grouped_aux_kernel(co
 // The ring is dynamic LDS (ST x 16 KB = 64 KB: two workgroups per CU).
 template <typename K>
 static int launch_dyn(K kernel, dim3 grid, int threads, size_t lds, hipStream_t st, const void* arg,
-                      const void* arg2 = nullptr) {
+                      const void* arg2 = nullptr, const void* arg3 = nullptr, const void* arg4 = nullptr) {
     static thread_local const void* configured[64];
     static thread_local int nconf = 0;
     bool seen = false;
@@ -1431,7 +1439,7 @@ static int launch_dyn(K kernel, dim3 grid, int threads, size_t lds, hipStream_t 
         }
         if (nconf < 64) configured[nconf++] = (const void*)kernel;
     }
-    void* args[2] = {const_cast<void*>(arg), const_cast<void*>(arg2)};
+    void* args[4] = {const_cast<void*>(arg), const_cast<void*>(arg2), const_cast<void*>(arg3), const_cast<void*>(arg4)};
     hipError_t e = hipLaunchKernel((const void*)kernel, grid, dim3(threads), args, lds, st);
     if (e != hipSuccess) {
         set_error("pp_gemm_f32 (async): launch failed: %s", hipGetErrorString(e));
@@ -1629,6 +1637,8 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
     GroupedParams g;
     g.ext = GemmExt{};
     g.trace = nullptr;
+    static const int warm = getenv("PP_WARM_KERNARGS") ? atoi(getenv("PP_WARM_KERNARGS")) : 1;
+    g.warm = warm;
     g.xcd_aware = xcd;
     g.count = 1;
     g.p[0] = p;
@@ -1661,8 +1671,14 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
         PP_CHECK_ARG(ext->cell_H == 0 || (ext->cell_H % 16 == 0 && a->N == 4 * ext->cell_H && a->ldc % 4 == 0 && aligned16(a->C) &&
                                           (ext->cell_c || ext->lean) && ext->cell_h),
                      "pp_gemm_f32: bad fused-cell arguments");
-        dim3 grid(cdiv(a->N, 64), cdiv(a->M, 64), 1);
-        return launch_dyn(gemm_f32_async_lstm_kernel, grid, 256, as_lds_bytes(), st, &p, ext);
+        const int gx = cdiv(a->N, 64), gy = cdiv(a->M, 64);
+        static const int tpw_env = getenv("PP_LSTM_TILES_PER_WG") ? atoi(getenv("PP_LSTM_TILES_PER_WG")) : 0;
+        // (measured on the ragged step, 1 344 tiles: 1, 2 or 4 tiles per workgroup give the same 28 us - the tile, not the
+        // workgroup start, is what costs; the knob stays for experiments)
+        int tpw = tpw_env > 0 ? tpw_env : 1;
+        tpw = std::max(1, std::min(tpw, gx));
+        dim3 grid(cdiv(gx, tpw), gy, 1);
+        return launch_dyn(gemm_f32_async_lstm_kernel, grid, 256, as_lds_bytes(), st, &p, ext, &tpw, &gx);
     }
     if (ext && ext->split_stride > 0) {   // K splits that STORE their partial tiles (async tile; the consumer adds them)
         PP_CHECK_ARG(ext->force_splits >= 1 && ext->force_splits <= 32 && async_ok(a) && async_split_ok(a, ext->force_splits) &&
@@ -1741,6 +1757,8 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         GroupedParams g;
         g.ext = ext ? *ext : GemmExt{};
         g.trace = nullptr;
+        static const int warm = getenv("PP_WARM_KERNARGS") ? atoi(getenv("PP_WARM_KERNARGS")) : 1;
+        g.warm = warm;
         static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
         g.xcd_aware = xcd;
         g.count = 0;
