@@ -872,6 +872,21 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // grouped weight-gradient launch; for a single-statement batch so do the column sums themselves (nothing in the
     // launch depends on anything else in it), which removes the separate column-sum launch.
     auto reduce_and_flush = [&]() -> int {
+        if (!compact && ff && !det && !ss) {
+            // FeedForward network: no column sum depends on another launch's group sums, so they all ride behind the
+            // weight-gradient tiles (and the loss is finalised there): one launch less per step
+            static const int ff_ride = env_flag("PP_AUX_COLSUM", 1);
+            int n_live = 0;
+            for (const auto& j : cs) n_live += (j.n_rows > 0 && j.n_cols > 0) ? 1 : 0;
+            if (ff_ride && n_live <= AUX_MAX_COLSUM && !wq.empty()) {
+                AuxJobs aux{};
+                for (const auto& j : cs)
+                    if (j.n_rows > 0 && j.n_cols > 0) aux.cs[aux.n_colsum++] = j;
+                aux.fin = LossFinalize{fin_acc, w.flag, B > 0 ? 1.0f / (float)B : 0.0f, loss_out, status_out};
+                aux_layout(aux, false);
+                return flush_wgrads(st, true, &aux);
+            }
+        }
         if (!compact) {
             if (ff)   // (LSTM: the first cell launch of the backward pass finalises the loss)
                 PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
