@@ -100,12 +100,6 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole = nullp
 int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes = nullptr,
                      const GemmExt* ext = nullptr, const AuxJobs* aux = nullptr);
 int aux_jobs_launch(const AuxJobs& jobs, hipStream_t st);   // kernels.hip: the same jobs as their own launch
-// gemm_f32.hip: observe embedding + LSTM input product + cell of a single-statement batch in one kernel (0: launched, 1: not
-// covered - take the two-kernel route)
-int embed_input_fused(const pp_net* net, const float* P, const float* obs, int B, float* const* obs_h, float* cat, float* f1,
-                      float* E, float* X, int64_t ldx, int xcols, float* G, float* Cst, float* Hs, float* gsum,
-                      const int* present, int n_present, const int32_t* row_addr, float* zero_small, int n_small, int lean,
-                      hipStream_t st);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

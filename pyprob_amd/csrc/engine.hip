@@ -446,7 +446,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     const bool dx_partials = compact && bwd && T == 1 && dx_partials_env && obs_fused_supported(net);
     AddrBias abias{};
     int n_present = 0, only_addr = 0;   // addresses that occur in the batch
-    int present_ids[4] = {0, 0, 0, 0};  // (the first four of them)
     if (compact) {
         abias.AB = w.AB; abias.gsum = w.gsum;
         abias.W = P + net->w_ih; abias.b_ih = P + net->b_ih; abias.b_hh = P + net->b_hh;
@@ -457,24 +456,12 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         for (int a = 0; a < net->n_addr; ++a)
             if (bt->grp_off[a + 1] > bt->grp_off[a] || bt->nxt_off[a + 1] > bt->nxt_off[a]) {
                 abias.present[a >> 5] |= 1u << (a & 31);
-                if (n_present < 4) present_ids[n_present] = a;
                 ++n_present;
                 only_addr = a;
             }
         gather_bytes += (double)n_present * (4.0 * 4 * H * (2.0 * ne_x) + 4.0 * 4.0 * 4 * H);
     }
     for (int o = 0; o < net->n_obs; ++o) gather_bytes += 4.0 * B * net->obs_hid[o];
-    static const int embed_fused_env = env_flag("PP_FUSE_EMBED", 1);
-    int embed_rc = 1;
-    bool embed_done = false;   // layer 0's pre-activations, cell state and hidden state already exist
-    auto try_embed = [&]() -> bool {   // (the kernel counts as the input product for the in-stream timing, class 0)
-        prof_begin(0, st);
-        embed_rc = embed_input_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, w.X, w.i4, w.xc, w.Gl[0], w.Cl[0], w.Hl[0], w.gsum,
-                                     present_ids, n_present, bt->addr, reinterpret_cast<float*>(w.loss_acc), n_clear,
-                                     lean_cell ? 1 : 0, st);
-        if (embed_rc == 0) prof_end(0, 2.0 * R * (double)net->e_obs * 4.0 * H, st);
-        return embed_rc != 1;
-    };
     prof_begin(2, st);
     if (ff) {
         // every time step's proposal layer reads the observe embedding of its trace (:72,85): Hs rows = E[trace]
@@ -496,11 +483,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             PP_TRY(embedding_rows(w.E, w.e4, bt->trace, R, net->e_obs, w.Hs, H, reinterpret_cast<float*>(w.loss_acc),
                                   n_clear, st));
         }
-    } else if (fused_obs && T == 1 && compact && (dx_partials || !bwd) && embed_fused_env && try_embed()) {
-        // single-statement batch: observe embedding + LSTM input product + cell in ONE kernel (gemm_f32.hip,
-        // embed_input_kernel); 1 = not covered (shapes, > 4 addresses): the two-kernel route below
-        PP_TRY(embed_rc);
-        embed_done = true;
     } else if (fused_obs && T <= 2) {   // (long traces: a wave would write all rows of its trace serially - separate gather)
         RowBuild rb{};
         rb.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
@@ -536,11 +518,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         GemmHole zero{};
         zero.b[1] = GemmBlock{0, B, H, 2 * H, 0, in_w};
         if (l == 0) zero.b[0] = GemmBlock{0, B, 0, 4 * H, net->e_obs, net->e_obs + net->smp_dim + net->dtype_dim + net->addr_dim};
-        if (l == 0 && !embed_done) prof_begin(0, st);
+        if (l == 0) prof_begin(0, st);
         bool cell_done = false;   // the first time step's cell ran in the product's epilogue
-        if (l == 0 && embed_done) {
-            cell_done = true;     // (and so did the product itself: embed_input_kernel)
-        } else if (l == 0 && compact) {
+        if (l == 0 && compact) {
             // G = [E | s_prev] W_ih[:, :c2]^T + cur[addr] + prev[previous addr] (gather.hpp); first-step rows have no previous
             // statement: their sample-embedding columns are zero too
             pp_gemm_args g{};

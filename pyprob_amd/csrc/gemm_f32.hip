@@ -1864,262 +1864,6 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
     return 0;
 }
 
-
-// ---- observe embedding + LSTM input product + LSTM cell in ONE kernel (single-statement batches) -----------------------------
-// The first two launches of the step - the observe-embedding stack per trace (InferenceNetwork._embed_observe,
-// pyprob/nn/inference_network.py:132-139) and G = E W_ih[:, :e_obs]^T + bias with the cell in its epilogue - were two ~10 us
-// kernels of which the first did 19 MFLOP of arithmetic. Here every workgroup of the input product (64 rows x 16 hidden units
-// x 4 gates) recomputes the embedding of ITS 64 traces on the matrix cores: layer 0 on the VALU, then three 64 x 64 x (<= 64)
-// products (per-observable layer 1 as one block-diagonal product, the two final layers) chained through two LDS images, and the
-// fourth product with the W_ih tile takes its A operand from the last image. All B fragments (weights) go global -> registers
-// at the start (one round trip, 16 bytes per lane and 8-wide k step), so LDS holds activations only. The 32 column tiles of a row
-// panel repeat the embedding (~3 us of MFMA each, in parallel); the tiles bx == 0 store what the backward pass needs (hidden
-// activations, cat, f1, E, the LSTM input rows). The per-address bias vectors (gather.hpp) of the tile's 64 columns are
-// computed in place for the <= 4 addresses of the batch; the group sums are cleared here.
-constexpr int EI_MAXA = 4;
-constexpr int EI_SS = 68;   // row stride of the activation images (16-byte rows)
-struct EmbedInArgs {
-    const float* P; const float* obs; int B, width;
-    int n_obs, e_obs, hsum;
-    int in[PP_MAX_OBS], hid[PP_MAX_OBS], out[PP_MAX_OBS], hoff[PP_MAX_OBS], coff[PP_MAX_OBS], cin[PP_MAX_OBS];
-    int64_t w0[PP_MAX_OBS], b0[PP_MAX_OBS], w1[PP_MAX_OBS], b1[PP_MAX_OBS], fw0, fb0, fw1, fb1;
-    float* obs_h[PP_MAX_OBS]; int64_t ohid_ld[PP_MAX_OBS];
-    float* cat; float* f1; float* E; int64_t e_ld;
-    float* X; int64_t ldx; int xcols;
-    const float* Wih; int64_t ldw; const float* b_ih; const float* b_hh; int H;
-    float* G; float* Cst; float* Hs; int lean;
-    int n_present; int addr_id[EI_MAXA]; int64_t dt_off[EI_MAXA], ad_off[EI_MAXA]; int c4, nd, na;
-    const int32_t* row_addr;
-    float* gsum;
-    float* zero_small; int n_small;
-};
-
-__global__ __launch_bounds__(256) void embed_input_kernel(const EmbedInArgs ein) {
-    extern __shared__ __attribute__((aligned(16))) float ei_sm[];
-    const EmbedInArgs a = ein;   // local copy (see gemm_tile)
-    float* const act0 = ei_sm;
-    float* const act1 = ei_sm + 64 * EI_SS;
-    float* const hbuf = ei_sm + 2 * 64 * EI_SS;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int bx = blockIdx.x, by = blockIdx.y, m0 = by * 64;
-    const bool writer = bx == 0;
-    const int H = a.H, N4 = 4 * a.H;
-    if (a.zero_small && bx == 0 && by == 0)
-        for (int q = tid; q < a.n_small; q += 256) a.zero_small[q] = 0.0f;
-    const int nf = wn * 32 + l31;                                     // this lane's output column in the embedding layers
-    const int gn = (nf >> 4) * H + bx * 16 + (nf & 15);               // ... and in the gate-interleaved LSTM tile
-    if (by == 0 && wm == 0 && h == 0) {                                // group sums of dG: cleared for the batch's addresses
-        for (int q = 0; q < a.n_present; ++q) {
-            float* gs = a.gsum + (int64_t)a.addr_id[q] * 2 * N4;
-            gs[gn] = 0.0f;
-            gs[N4 + gn] = 0.0f;
-        }
-    }
-    // ---- B fragments of the four products: global -> registers, b[s][j] = W(column of this lane, k = 8s + 4h + j) ------------
-    int o1 = -1;
-#pragma unroll
-    for (int o = 0; o < PP_MAX_OBS; ++o)
-        if (o < a.n_obs && nf >= a.coff[o] && nf < a.coff[o] + a.out[o]) o1 = o;
-    int o1_hoff = 0, o1_hid = 0, o1_col = 0;
-    int64_t o1_w = 0, o1_b = 0;
-#pragma unroll
-    for (int o = 0; o < PP_MAX_OBS; ++o)
-        if (o == o1) { o1_hoff = a.hoff[o]; o1_hid = a.hid[o]; o1_col = nf - a.coff[o]; o1_w = a.w1[o]; o1_b = a.b1[o]; }
-    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 bw1[8], bf0[8], bf1[8], bwi[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int k0 = 8 * s + 4 * h;
-        bw1[s] = (o1 >= 0 && k0 >= o1_hoff && k0 < o1_hoff + o1_hid)
-                     ? *reinterpret_cast<const f32x4*>(a.P + o1_w + (int64_t)o1_col * o1_hid + (k0 - o1_hoff)) : zero4;
-        const bool kin = k0 < a.e_obs, cin_ = nf < a.e_obs;
-        bf0[s] = (kin && cin_) ? *reinterpret_cast<const f32x4*>(a.P + a.fw0 + (int64_t)nf * a.e_obs + k0) : zero4;
-        bf1[s] = (kin && cin_) ? *reinterpret_cast<const f32x4*>(a.P + a.fw1 + (int64_t)nf * a.e_obs + k0) : zero4;
-        bwi[s] = kin ? *reinterpret_cast<const f32x4*>(a.Wih + (int64_t)gn * a.ldw + k0) : zero4;
-    }
-    const float bias1 = o1 >= 0 ? a.P[o1_b + o1_col] : 0.0f;
-    const float biasf0 = nf < a.e_obs ? a.P[a.fb0 + nf] : 0.0f, biasf1 = nf < a.e_obs ? a.P[a.fb1 + nf] : 0.0f;
-    // per-address bias of this lane's LSTM column: b_ih + b_hh + W_ih[gn, c4:I] [d_a ; a_a]   (no previous statement at all)
-    float cur[EI_MAXA];
-    {
-        const float bsum = a.b_ih[gn] + a.b_hh[gn];
-        const float* wr = a.Wih + (int64_t)gn * a.ldw + a.c4;
-#pragma unroll
-        for (int q = 0; q < EI_MAXA; ++q) {
-            cur[q] = bsum;
-            if (q < a.n_present) {
-                const float* dt = a.P + a.dt_off[q];
-                const float* ad = a.P + a.ad_off[q];
-                float s0 = 0.0f, s1 = 0.0f;
-                for (int k = 0; k < a.nd; k += 4) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
-                    const f32x4 ev = *reinterpret_cast<const f32x4*>(dt + k);
-                    s0 += wv[0] * ev[0] + wv[1] * ev[1];
-                    s1 += wv[2] * ev[2] + wv[3] * ev[3];
-                }
-                for (int k = 0; k < a.na; k += 4) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + a.nd + k);
-                    const f32x4 ev = *reinterpret_cast<const f32x4*>(ad + k);
-                    s0 += wv[0] * ev[0] + wv[1] * ev[1];
-                    s1 += wv[2] * ev[2] + wv[3] * ev[3];
-                }
-                cur[q] += s0 + s1;
-            }
-        }
-    }
-    // ---- layer 0 of every observable on the VALU: thread = (hidden unit j, 16 rows); the unit's weights once, the 16 rows'
-    // observations in one batch of loads (a thread per (row, 16 units) paid a memory round trip per unit: 20 us) -----------
-    {
-        const int j = tid & 63, rg = tid >> 6;
-        int o = -1;
-#pragma unroll
-        for (int q = 0; q < PP_MAX_OBS; ++q)
-            if (q < a.n_obs && j >= a.hoff[q] && j < a.hoff[q] + a.hid[q]) o = q;
-        int o_hoff = 0, o_in = 0, o_cin = 0;
-        int64_t o_w = 0, o_b = 0, o_ld = 0;
-        float* o_h = nullptr;
-#pragma unroll
-        for (int q = 0; q < PP_MAX_OBS; ++q)
-            if (q == o) { o_hoff = a.hoff[q]; o_in = a.in[q]; o_cin = a.cin[q]; o_w = a.w0[q]; o_b = a.b0[q]; o_ld = a.ohid_ld[q]; o_h = a.obs_h[q]; }
-        const int jl = j - o_hoff;
-        float wj[8], bj = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wj[i] = (o >= 0 && i < o_in) ? a.P[o_w + (int64_t)jl * o_in + i] : 0.0f;
-        if (o >= 0) bj = a.P[o_b + jl];
-        float hv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) hv[u] = bj;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < o_in) {   // (uniform per 16/32-lane group of a unit's observable; o_in <= 8)
-                float xv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int gm = m0 + rg * 16 + u;
-                    xv[u] = (o >= 0 && gm < a.B) ? a.obs[(int64_t)gm * a.width + o_cin + i] : 0.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) hv[u] += wj[i] * xv[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int row = rg * 16 + u, gm = m0 + row;
-            const float v = (o >= 0 && gm < a.B) ? relu_keep_nan(hv[u]) : 0.0f;
-            hbuf[row * EI_SS + j] = v;
-            if (writer && o >= 0 && gm < a.B) o_h[(int64_t)gm * o_ld + jl] = v;
-        }
-    }
-    __syncthreads();
-    // one embedding layer: dst[64 x 64] = relu(src[64 x 64] W^T + bias); this wave owns rows wm*32.., columns wn*32..
-    auto layer = [&](const float* src, float* dst, const f32x4 (&bw)[8], const float bias, float* gdst, float* gdst2,
-                     const int64_t gld2) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const float* ar = src + (wm * 32 + l31) * EI_SS + 4 * h;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(ar + 8 * s);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bw[s][j], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int gm = m0 + row;
-            const float v = gm < a.B ? relu_keep_nan(acc[r] + bias) : 0.0f;
-            dst[row * EI_SS + nf] = v;
-            if (writer && gm < a.B && nf < a.e_obs) {
-                gdst[(int64_t)gm * a.e_ld + nf] = v;
-                if (gdst2) gdst2[(int64_t)gm * gld2 + nf] = v;
-            }
-        }
-    };
-    layer(hbuf, act0, bw1, bias1, a.cat, nullptr, 0);
-    __syncthreads();
-    layer(act0, act1, bf0, biasf0, a.f1, nullptr, 0);
-    __syncthreads();
-    layer(act1, act0, bf1, biasf1, a.E, a.X, a.ldx);   // E is also columns [0, e_obs) of the LSTM input rows
-    if (writer)                                          // ... whose sample-embedding columns are zero (no previous statement)
-        for (int q = tid; q < 64 * (a.xcols - a.e_obs); q += 256) {
-            const int row = q / (a.xcols - a.e_obs), c = q - row * (a.xcols - a.e_obs);
-            if (m0 + row < a.B) a.X[(int64_t)(m0 + row) * a.ldx + a.e_obs + c] = 0.0f;
-        }
-    __syncthreads();
-    // ---- LSTM input product on the embedding image + bias + cell (lstm_epilogue) --------------------------------------------
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    {
-        const float* ar = act0 + (wm * 32 + l31) * EI_SS + 4 * h;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(ar + 8 * s);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bwi[s][j], acc, 0, 0, 0);
-        }
-    }
-    float rbv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float b = cur[0];
-        if (a.n_present > 1) {
-            const int gm = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, a.B - 1);
-            const int ad = a.row_addr[gm];
-#pragma unroll
-            for (int q = 1; q < EI_MAXA; ++q)
-                if (q < a.n_present && ad == a.addr_id[q]) b = cur[q];
-        }
-        rbv[r] = b;
-    }
-    GemmParams p{};
-    p.C = a.G; p.ldc = N4; p.M = a.B; p.N = N4;
-    GemmExt x{};
-    x.cell_H = H; x.cell_rows = a.B; x.cell_c = a.Cst; x.cell_h = a.Hs; x.lean = a.lean;
-    lstm_epilogue(p, x, acc, m0, bx, wm, wn, l31, h, act1, rbv);
-}
-
-// 0: launched; 1: this network / batch is not covered (the caller takes the two-kernel route); < 0 or > 1: error
-int embed_input_fused(const pp_net* net, const float* P, const float* obs, int B, float* const* obs_h, float* cat, float* f1,
-                      float* E, float* X, int64_t ldx, int xcols, float* G, float* Cst, float* Hs, float* gsum,
-                      const int* present, int n_present, const int32_t* row_addr, float* zero_small, int n_small, int lean,
-                      hipStream_t st) {
-    const int H = net->lstm_dim, ne = net->dtype_dim + net->addr_dim, c4 = net->e_obs + net->smp_dim + ne;
-    if (net->n_obs < 1 || net->n_obs > PP_MAX_OBS || net->e_obs > 64 || net->e_obs % 4 || H % 16 || net->lstm_in % 4 || c4 % 4 ||
-        net->dtype_dim % 4 || net->addr_dim % 4 || n_present < 1 || n_present > EI_MAXA || xcols < net->e_obs)
-        return 1;
-    EmbedInArgs a{};
-    a.P = P; a.obs = obs; a.B = B;
-    int hoff = 0, coff = 0, cin = 0;
-    for (int o = 0; o < net->n_obs; ++o) {
-        if ((net->obs_depth[o] != 0 && net->obs_depth[o] != 2) || net->obs_hid[o] % 4 || net->obs_in[o] > 8 || net->obs_w1[o] % 4) return 1;
-        a.in[o] = net->obs_in[o]; a.hid[o] = net->obs_hid[o]; a.out[o] = net->obs_out[o];
-        a.hoff[o] = hoff; a.coff[o] = coff; a.cin[o] = cin;
-        a.w0[o] = net->obs_w0[o]; a.b0[o] = net->obs_b0[o]; a.w1[o] = net->obs_w1[o]; a.b1[o] = net->obs_b1[o];
-        a.obs_h[o] = obs_h[o]; a.ohid_ld[o] = (net->obs_hid[o] + 3) & ~3;
-        hoff += net->obs_hid[o]; coff += net->obs_out[o]; cin += net->obs_in[o];
-    }
-    if (hoff > 64 || coff != net->e_obs || net->fin_w0 % 4 || net->fin_w1 % 4 || net->w_ih % 4) return 1;
-    a.width = cin; a.n_obs = net->n_obs; a.e_obs = net->e_obs; a.hsum = hoff;
-    a.fw0 = net->fin_w0; a.fb0 = net->fin_b0; a.fw1 = net->fin_w1; a.fb1 = net->fin_b1;
-    a.cat = cat; a.f1 = f1; a.E = E; a.e_ld = (net->e_obs + 3) & ~3;
-    a.X = X; a.ldx = ldx; a.xcols = xcols;
-    a.Wih = P + net->w_ih; a.ldw = net->lstm_in; a.b_ih = P + net->b_ih; a.b_hh = P + net->b_hh; a.H = H;
-    a.G = G; a.Cst = Cst; a.Hs = Hs; a.lean = lean;
-    a.n_present = n_present; a.c4 = c4; a.nd = net->dtype_dim; a.na = net->addr_dim; a.row_addr = row_addr;
-    for (int q = 0; q < n_present; ++q) {
-        a.addr_id[q] = present[q];
-        a.dt_off[q] = net->addrs[present[q]].dtype_emb;
-        a.ad_off[q] = net->addrs[present[q]].addr_emb;
-        if (a.dt_off[q] % 4 || a.ad_off[q] % 4) return 1;
-    }
-    a.gsum = gsum; a.zero_small = zero_small; a.n_small = n_small;
-    dim3 grid(4 * H / 64, cdiv(B, 64), 1);
-    return launch_dyn(embed_input_kernel, grid, 256, sizeof(float) * 3 * 64 * EI_SS, st, &a);
-}
-
 }  // namespace pp
 
 // debug: per-workgroup start / end stamps of the grouped async launches (mode 1: weight-gradient groups, 2: data-gradient

@@ -122,8 +122,7 @@ def test_compact_rows_match_the_full_width_path(tmp_path, legacy):
     {'PP_DX_PARTIALS': '0'},                                 # dX accumulated with float atomics instead of stored split partials
     {'PP_CELL_LEAN': '0'},
     {'PP_FUSE_CELL_REC': '0'},
-    {'PP_DH_PARTIALS': '0'},
-    {'PP_FUSE_EMBED': '0'},                                  # observe embedding and LSTM input product as two kernels                                 # dh_{t-1} += dG_t W_hh with float atomics instead of stored partials                               # recurrent products accumulate into G, stand-alone cell kernels                                   # forget-gate columns and cell state written although unused
+    {'PP_DH_PARTIALS': '0'},                                 # dh_{t-1} += dG_t W_hh with float atomics instead of stored partials                               # recurrent products accumulate into G, stand-alone cell kernels                                   # forget-gate columns and cell state written although unused
     {'PP_FUSE_CELL': '0', 'PP_FUSE_CELL_BWD': '0', 'PP_AUX_FUSED': '0'},
 ])
 def test_each_fusion_switch_is_result_neutral(tmp_path, legacy, env):
