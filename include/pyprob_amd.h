@@ -292,6 +292,14 @@ int64_t pp_train_slot_words(int32_t n_traces, int64_t n_rows, int32_t t_max, int
                             int32_t n_tensors);
 
 int pp_train_sync(void);
+/* The same loop body (optimize, inference_network.py:486-496: zero_grad -> _loss -> backward -> [all-reduce] -> Adam) for
+ * minibatches that are ALREADY resident in HBM: batches[i] = pp_batch of step i (device arrays in place, host arrays valid
+ * for the duration of the call), active[i] = dev [n_tensors] presence map of that minibatch, lr[i] its learning rate; losses
+ * and flags go to tb->loss_ring / status_ring [n_steps] (staging / device_batch of tb are not used). One C call enqueues
+ * n_steps steps; tb->dp_world selects the data-parallel branch like in pp_train_steps. */
+int pp_train_resident(const pp_net* net, const pp_train_buffers* tb, const pp_batch* const* batches,
+                      const float* const* active, int32_t n_steps, const float* lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t grads_clean, void* stream);
 
 int pp_train_steps(const pp_net* net, const pp_train_buffers* buffers, const pp_tensor_roles* roles,
                    const pp_shard_columns* shards, int32_t n_shards, const int64_t* first, int32_t obs_width,

@@ -433,17 +433,19 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     const int c2x = net->e_obs + net->smp_dim, ne_x = net->dtype_dim + net->addr_dim;
     // single-statement batches have no previous statement at all: the sample-embedding columns are zero in every row
     const int nx = (T == 1) ? net->e_obs : c2x;
-    // (see GemmExt::lean) the cell backward of a single-statement, single-layer batch runs in the dH epilogue, and with the
-    // zero blocks on neither dX nor dW_ih read the forget gate's columns of first-step rows
-    // (H a multiple of 64: the zero blocks then cover the forget gate's tiles and slabs exactly)
-    static const bool lean_env = env_flag("PP_FUSE_CELL_BWD", 1) && env_flag("PP_FUSE_CELL", 1) && env_flag("PP_GEMM_HOLES", 1) == 1 &&
-                                 env_flag("PP_CELL_LEAN", 1);
-    const bool lean_cell = compact && bwd && T == 1 && std::max(1, (int)net->lstm_depth) == 1 && H % 64 == 0 && lean_env;
     // Single-statement batch: dX = dG W_ih[:, :e_obs] has ONE consumer, the observe-embedding backward kernel; its K splits
     // store their partial tiles and that kernel adds them - no float atomics (6-8 us per 64 x 64 tile, tools/wg_trace.py)
     // and no cleared dX
     static const int dx_partials_env = env_flag("PP_DX_PARTIALS", 1);
     const bool dx_partials = compact && bwd && T == 1 && dx_partials_env && obs_fused_supported(net);
+    // (see GemmExt::lean) the cell backward of a single-statement, single-layer batch runs in the dH epilogue, and with the
+    // zero blocks on neither dX nor dW_ih read the forget gate's columns of first-step rows
+    // (H a multiple of 64: the zero blocks then cover the forget gate's tiles and slabs exactly)
+    static const bool lean_env = env_flag("PP_FUSE_CELL_BWD", 1) && env_flag("PP_FUSE_CELL", 1) && env_flag("PP_GEMM_HOLES", 1) == 1 &&
+                                 env_flag("PP_CELL_LEAN", 1);
+    // (and dX as stored split partials: that product then runs on the async tiles, which skip the forget gate's K range)
+    const bool lean_cell = compact && bwd && T == 1 && std::max(1, (int)net->lstm_depth) == 1 && H % 64 == 0 && lean_env &&
+                           dx_partials;
     AddrBias abias{};
     int n_present = 0, only_addr = 0;   // addresses that occur in the batch
     if (compact) {

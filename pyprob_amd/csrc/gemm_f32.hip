@@ -1156,6 +1156,15 @@ __device__ __forceinline__ void gemm_tile_direct(const GemmParams& pin, const in
     const int m0 = by * DT, n0 = bx * DT;
     if (p.dbg && tid == 0 && bx == 1 && by == 1 && bz == 0) p.dbg[32] = clock64();   // debug phase stamps
     const int nslab_total = (p.K + BK - 1) / BK;
+    // Zero blocks (GemmHole): this tile family honours the case that matters for correctness - a tile that lies inside a block
+    // whose slab range is ALL of K contributes nothing and may be fed by columns nobody wrote (the forget gate's part of
+    // dG for first-time-step rows in the lean mode, GemmExt::lean): it is skipped. Partial-K blocks are simply computed.
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // workgroup-uniform
+        if (p.hs1[q] > p.hs0[q] && p.hs0[q] == 0 && p.hs1[q] >= nslab_total && m0 >= p.hm0[q] && min(m0 + DT, p.M) <= p.hm1[q] &&
+            n0 >= p.hn0[q] && min(n0 + DT, p.N) <= p.hn1[q] && !((A_KM && p.a_idx) || (B_KM && p.b_idx)))
+            return;
+    }
     const int per = (nslab_total + nz - 1) / nz;
     const int s_begin = bz * per;
     const int s_end = min(nslab_total, s_begin + per);

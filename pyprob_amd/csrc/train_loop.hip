@@ -161,6 +161,51 @@ int pp_train_steps(const pp_net* net, const pp_train_buffers* tb, const pp_tenso
     return rc;
 }
 
+// The same loop body for minibatches that are ALREADY resident in HBM (pp_batch structs whose device arrays are in place):
+// per step zero_grad -> _loss -> backward -> [all-reduce] -> Adam (pyprob/nn/inference_network.py:486-496), n_steps steps
+// in one C call. active[i] = device presence map [n_tensors] of step i's minibatch. Losses / flags go to the rings.
+int pp_train_resident(const pp_net* net, const pp_train_buffers* tb, const pp_batch* const* batches, const float* const* active,
+                      int32_t n_steps, const float* lr, float beta1, float beta2, float eps, float weight_decay,
+                      int32_t grads_clean, void* stream) {
+    if (!(net && tb && batches && active && lr) || n_steps < 0) {
+        pp::set_error("pp_train_resident: null pointer");
+        return PP_EINVAL;
+    }
+    if (!(tb->params && tb->grads && tb->exp_avg && tb->exp_avg_sq && tb->chunk_tensor && tb->tensor_step && tb->adam_scratch &&
+          tb->workspace && tb->loss_ring && tb->status_ring) || tb->n_tensors <= 0) {
+        pp::set_error("pp_train_resident: incomplete pp_train_buffers");
+        return PP_EINVAL;
+    }
+    hipStream_t st = pp::as_stream(stream);
+    const int n_tensors = tb->n_tensors;
+    const bool dp = tb->dp_world >= 1;
+    if (dp && (pp::dp_world() != tb->dp_world || tb->dp_n_skip < 0 || tb->dp_n_skip > 4)) {
+        pp::set_error("pp_train_resident: dp_world %d but the communicator has %d ranks (pp_dp_init)", tb->dp_world, pp::dp_world());
+        return PP_EINVAL;
+    }
+    float* const dp_tail = tb->grads + net->n_params;
+    for (int i = 0; i < n_steps; ++i) {
+        if (!batches[i] || !active[i]) {
+            pp::set_error("pp_train_resident: step %d has no batch / presence map", i);
+            return PP_EINVAL;
+        }
+        const int flags = PP_LOSS_BACKWARD | ((i == 0 && !grads_clean) ? PP_LOSS_ZERO_GRADS : 0);
+        int rc = pp::ic_loss(net, batches[i], tb->params, tb->grads, tb->workspace, tb->workspace_bytes,
+                             dp ? dp_tail + n_tensors : tb->loss_ring + i, tb->status_ring + i, nullptr, flags, st);
+        if (rc != 0) return rc;
+        if (dp) {
+            rc = pp::dp_reduce_grads(tb->grads, net->n_params, n_tensors, active[i], tb->status_ring + i, tb->dp_skip_off,
+                                     tb->dp_skip_cnt, tb->dp_n_skip, tb->loss_ring + i, tb->status_ring + i, st);
+            if (rc != 0) return rc;
+        }
+        rc = pp::adam_step(tb->params, tb->grads, tb->exp_avg, tb->exp_avg_sq, net->n_params, tb->chunk_tensor,
+                           dp ? dp_tail : active[i], tb->tensor_step, tb->adam_scratch, n_tensors, lr[i], beta1, beta2, eps,
+                           weight_decay, dp ? 1.0f / (float)tb->dp_world : 1.0f, PP_ADAM_ZERO_GRADS, tb->status_ring + i, st);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 int pp_train_sync(void) {
     for (int h = 0; h < 2; ++h)
         if (g_have_event[h] && hipEventSynchronize(g_half_event[h]) != hipSuccess) {

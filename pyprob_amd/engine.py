@@ -264,6 +264,52 @@ class ICEngine:
             spec.addresses[a].total_train_iterations += int(k)
         return self._loss_ring[:n_steps], self._status_ring[:n_steps]
 
+    def train_resident(self, batches, lrs, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """A run of training steps over minibatches that are already in HBM (PackedBatch objects on this device) in ONE C
+        call (pp_train_resident): step i = zero_grad -> loss + backward on batches[i] -> [all-reduce] -> Adam with lrs[i].
+        Returns (losses, statuses): device tensors [n_steps], not synchronised. Data parallel: needs the native communicator
+        (self.native_dp), every rank must pass the same number of steps."""
+        n_steps = len(batches)
+        dp = self.world_size != 1 or self.force_allreduce
+        if dp and not (self.native_dp and self.lib.pp_dp_world() == self.world_size):
+            raise RuntimeError('train_resident under data parallelism needs the native RCCL communicator')
+        b_max = max(b.n_traces for b in batches)
+        r_max = max(b.n_rows for b in batches)
+        self._ensure_workspace(b_max, r_max)
+        if getattr(self, '_ring_n', 0) < n_steps:
+            self._ring_n = max(n_steps, 64)
+            self._loss_ring = torch.zeros(self._ring_n, dtype=torch.float32, device=self.device)
+            self._status_ring = torch.zeros(self._ring_n, dtype=torch.int32, device=self.device)
+        acts = []
+        for b in batches:
+            if b.c is None:
+                b.to(self.device)
+            key = (tuple(b.cur_counts > 0), tuple(b.prev_counts > 0))
+            act = self._active_cache.get(key)
+            if act is None:
+                act = torch.from_numpy(self.spec.active_mask(b.cur_counts, b.prev_counts)).to(self.device)
+                self._active_cache[key] = act
+            acts.append(act)
+        bptr = (C.c_void_p * n_steps)(*[C.addressof(b.c) for b in batches])
+        aptr = (C.c_void_p * n_steps)(*[a.data_ptr() for a in acts])
+        lr = np.ascontiguousarray(lrs, np.float32).reshape(-1)
+        if len(lr) != n_steps:
+            raise ValueError('one learning rate per step')
+        tb = L.pp_train_buffers(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                self.exp_avg_sq.data_ptr(), self.chunk_tensor.data_ptr(), self.tensor_step.data_ptr(),
+                                self.arrived.data_ptr(), self.workspace.data_ptr(), self.ws_bytes, None, None, 0,
+                                self._loss_ring.data_ptr(), self._status_ring.data_ptr(), self.spec.n_tensors, 0)
+        if dp:
+            tb.dp_world, tb.dp_n_skip = self.world_size, len(self.dp_skip)
+            for k, (off, cnt) in enumerate(self.dp_skip):
+                tb.dp_skip_off[k], tb.dp_skip_cnt[k] = off, cnt
+        rc = self.lib.pp_train_resident(C.byref(self.net), C.byref(tb), bptr, aptr, n_steps, lr.ctypes.data, beta1, beta2, eps,
+                                        weight_decay, 1 if self._grads_clean else 0, L.stream_ptr())
+        L.check(rc, 'pp_train_resident')
+        self._grads_clean = True
+        self._active_key = None
+        return self._loss_ring[:n_steps], self._status_ring[:n_steps]
+
     def read_back(self, losses, statuses):
         """Start an asynchronous device-to-host copy of a run's (losses, statuses) and return a zero-argument function
         that waits for THAT copy only (not for work enqueued later) and returns the two numpy arrays."""

@@ -94,6 +94,8 @@ class pp_tensor_roles(C.Structure):
 PROTOTYPES = {
     'pp_train_slot_words': (i64, [i32, i64, i32, i32, i32, i32]),
     'pp_train_sync': (C.c_int, []),
+    'pp_train_resident': (C.c_int, [C.POINTER(pp_net), C.POINTER(pp_train_buffers), vp, vp, i32, vp, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, i32, vp]),
     'pp_train_steps': (C.c_int, [C.POINTER(pp_net), C.POINTER(pp_train_buffers), C.POINTER(pp_tensor_roles), vp, i32, vp, i32,
                                  vp, vp, i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp, vp]),
     'pp_pack_indexed': (C.c_int, [vp, i32, vp, vp, i32, i32, i32, vp, i64, vp]),

@@ -97,6 +97,29 @@ def test_native_loop_runs_its_data_parallel_branch(one_rank_group):
     assert torch.equal(before, b.params)
 
 
+def test_resident_loop_with_the_exchange(one_rank_group):
+    """pp_train_resident with its data-parallel branch (one-rank communicator) = the per-step loop with the native exchange."""
+    from pyprob_amd.packed import PackedBatch
+    a, b = _engine(64, ['mu'], 'Normal', seed=6), _engine(64, ['mu'], 'Normal', seed=6)
+    for eng in (a, b):
+        eng.force_allreduce = True
+        eng.native_dp = True
+        eng.skip_recurrent_weights(True)
+    ba, bb = [], []
+    for k, n in enumerate((256, 64, 300)):
+        arr = synthetic_gum_arrays(n, seed=40 + k)
+        for eng, lst in ((a, ba), (b, bb)):
+            lst.append(PackedBatch.from_ragged(arr['trace_len'], np.zeros(n, np.int64), arr['values'], arr['prior'], arr['obs'],
+                                               1).to(eng.device))
+    for pb in ba:
+        a.train_step(pb, 1e-3)
+    losses, status = b.train_resident(bb, [1e-3] * 3)
+    torch.cuda.synchronize()
+    assert not status.cpu().numpy().any() and np.isfinite(losses.cpu().numpy()).all()
+    pa, pb_ = a.params.cpu().numpy(), b.params.cpu().numpy()
+    assert np.linalg.norm(pa - pb_) < 1e-3 * np.linalg.norm(pa)
+
+
 def test_grouped_pieces(one_rank_group):
     lib = one_rank_group
     import ctypes as C

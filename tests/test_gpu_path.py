@@ -169,6 +169,31 @@ def test_feedforward_network_benchmark_size_against_oracle():
     assert float(last.item()) < first
 
 
+def test_resident_loop_matches_the_per_step_calls():
+    """pp_train_resident (a run of steps over minibatches already in HBM, one C call) against ICEngine.train_step per
+    minibatch: same losses, same parameters, same Adam step counts."""
+    from pyprob_amd.packed import PackedBatch
+    a, b = _fresh_engine(64, ['mu'], 'Normal', seed=4), _fresh_engine(64, ['mu'], 'Normal', seed=4)
+    batches_a, batches_b = [], []
+    for k, n in enumerate((256, 300, 128, 200, 256, 512, 128)):
+        arr = synthetic_gum_arrays(n, seed=30 + k)
+        for eng, lst in ((a, batches_a), (b, batches_b)):
+            lst.append(PackedBatch.from_ragged(arr['trace_len'], np.zeros(n, np.int64), arr['values'], arr['prior'], arr['obs'],
+                                               1).to(eng.device))
+    lrs = [1e-3 * (1 + 0.1 * k) for k in range(len(batches_a))]
+    ref = [float(a.train_step(pb, lr, weight_decay=1e-5).item()) for pb, lr in zip(batches_a, lrs)]
+    losses, status = b.train_resident(batches_b[:3], lrs[:3], weight_decay=1e-5)
+    got = losses.cpu().numpy().tolist()
+    losses, status2 = b.train_resident(batches_b[3:], lrs[3:], weight_decay=1e-5)
+    got += losses.cpu().numpy().tolist()
+    assert not status.cpu().numpy().any() and not status2.cpu().numpy().any()
+    np.testing.assert_allclose(got, ref, rtol=2e-5)
+    # (Adam normalises the gradient: an element whose gradient is at round-off level may move by +-lr in either run)
+    pa, pb_ = a.params.cpu().numpy().astype(np.float64), b.params.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(pa - pb_) < 5e-3 * np.linalg.norm(pa), np.linalg.norm(pa - pb_) / np.linalg.norm(pa)
+    assert torch.equal(b.tensor_step.cpu(), a.tensor_step.cpu())
+
+
 def test_native_training_loop_matches_the_per_step_calls():
     """pp_train_steps (pack -> upload -> loss + backward -> Adam for a run of minibatches in one C call) against the same
     minibatches stepped one C call at a time: same losses, same parameters, same per-address iteration counters; a
