@@ -274,6 +274,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& pin, const int bx, c
 
     // split-K: blockIdx.z owns a contiguous range of K slabs and adds its partial tile with float atomics
     const int nslab_total = (p.K + BK - 1) / BK;
+    // (zero blocks: like the direct tile, this family skips a tile only when it lies inside a block that covers ALL of K)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // workgroup-uniform
+        if (p.hs1[q] > p.hs0[q] && p.hs0[q] == 0 && p.hs1[q] >= nslab_total && m0 >= p.hm0[q] && min(m0 + BM, p.M) <= p.hm1[q] &&
+            n0 >= p.hn0[q] && min(n0 + BN, p.N) <= p.hn1[q] && !((A_KM && p.a_idx) || (B_KM && p.b_idx)))
+            return;
+    }
     const int per = (nslab_total + nz - 1) / nz;
     const int s_begin = bz * per;
     const int nslab = min(nslab_total, s_begin + per) - s_begin;
