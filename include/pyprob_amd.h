@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 6
+#define PP_ABI_VERSION 7
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -242,6 +242,35 @@ int pp_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                  const int32_t* chunk_tensor, const float* active, int32_t* tensor_step, int32_t* scratch,
                  int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                  int32_t flags, const int32_t* skip, void* stream);
+
+/*
+ * optimizer.step() for torch.optim.SGD(lr, momentum, nesterov, weight_decay) - Optimizer.SGD of
+ * InferenceNetwork._create_optimizer (pyprob/nn/inference_network.py:349-350, nesterov=True there) - over the same flat
+ * buffers as pp_adam_step (chunk_tensor / active / grad_scale / flags / skip mean the same):
+ *   g = grad * grad_scale + weight_decay * p;  buf = momentum * buf + g;  p -= lr * (nesterov ? g + momentum * buf : buf)
+ * momentum_buf (dev [n_params], may be NULL when momentum == 0) must be ZERO before a parameter's first step: that is
+ * torch's `buf = clone(grad)` of a first step. Tensors with active[t] == 0 are not touched (no decay, buffer unchanged).
+ * One launch.
+ */
+int pp_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n_params, const int32_t* chunk_tensor,
+                const float* active, int32_t n_tensors, float lr, float momentum, int32_t nesterov, float weight_decay,
+                float grad_scale, int32_t flags, const int32_t* skip, void* stream);
+
+/*
+ * The LARC wrapper of Optimizer.ADAM_LARC / SGD_LARC (pyprob/nn/optimizer_larc.py:72-107; inference_network.py:351-352
+ * constructs it with the defaults trust_coefficient 0.002, clip = 1, eps 1e-8, epsilon 1/16000): per tensor with a
+ * gradient,  local = (|p| != 0 && |g| != 0) ? trust * |p| / (|g| + weight_decay * |p| + eps) : epsilon,
+ * adaptive = clip ? min(local / lr, 1) : local,  and IN PLACE  grad = (grad * grad_scale + weight_decay * p) * adaptive
+ * (|g| is the norm of grad * grad_scale: the reference divides by the world size before the optimizer runs, :324-325).
+ * The wrapped optimizer then steps with weight_decay = 0 and grad_scale = 1 (optimizer_larc.py:81,105-107):
+ *   pp_larc_scale(..., lr, wd, 1/world, ...);  pp_adam_step / pp_sgd_step(..., lr, ..., 0.0f, 1.0f, ...).
+ * scratch: dev, PP_LARC_SCRATCH_FLOATS(n_params, n_tensors) floats, contents irrelevant. Three launches (chunk partial sums
+ * of squares, stored; per-tensor norms in fp64 in a fixed order; the rescaling pass): bit-reproducible. skip as above.
+ */
+#define PP_LARC_SCRATCH_FLOATS(n_params, n_tensors) (2 * ((n_params) / 1024) + (n_tensors))
+int pp_larc_scale(const float* params, float* grads, int64_t n_params, const int32_t* chunk_tensor, const float* active,
+                  int32_t n_tensors, float lr, float weight_decay, float grad_scale, float trust_coefficient, float eps,
+                  float epsilon, int32_t clip, float* scratch, const int32_t* skip, void* stream);
 
 /*
  * The body of the training loop (InferenceNetwork.optimize, pyprob/nn/inference_network.py:461-499: next minibatch ->

@@ -733,3 +733,28 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
     denom = np.sqrt(v) / math.sqrt(bc2) + eps
     p[:] = p - (lr / bc1) * m / denom
     return p
+
+
+def sgd_step(p, g, buf, lr, momentum=0.9, nesterov=True, weight_decay=0.0):
+    """torch.optim.SGD single-tensor update (dampening 0) as configured at inference_network.py:350. buf: the momentum
+    buffer, ZERO before the parameter's first step (torch then sets buf = clone(g): the same value)."""
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    if momentum != 0.0:
+        buf[:] = momentum * buf + g
+        g = g + momentum * buf if nesterov else buf
+    p[:] = p - lr * g
+    return p
+
+
+def larc_scale(p, g, lr, weight_decay=0.0, trust_coefficient=0.002, clip=True, eps=1e-8, epsilon=1.0 / 16000.0):
+    """The LARC wrapper's rewrite of one tensor's gradient (pyprob/nn/optimizer_larc.py:82-102); the wrapped optimizer then
+    steps with weight_decay 0. Returns the new gradient."""
+    pn = math.sqrt(float(np.sum(np.square(p, dtype=np.float64))))
+    gn = math.sqrt(float(np.sum(np.square(g, dtype=np.float64))))
+    if pn != 0.0 and gn != 0.0:
+        local = trust_coefficient * pn / (gn + pn * weight_decay + eps)
+    else:
+        local = epsilon
+    adaptive = min(local / lr, 1.0) if clip else local
+    return (g + weight_decay * p) * adaptive

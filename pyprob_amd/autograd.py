@@ -57,28 +57,39 @@ class HipLoss(torch.autograd.Function):
         return (None, None, None) + tuple(eng.tensor(n, eng.grads) for n in ctx.names)
 
 
-class HipAdam(torch.optim.Optimizer):
-    """optim.Adam(lr, weight_decay) (inference_network.py:348) as ONE kernel over the network's flat buffers."""
+class _HipOptimizer(torch.optim.Optimizer):
+    """Common part of the flat-buffer optimizers: the presence map (`grad is None` -> the tensor is not stepped, like
+    torch's per-parameter loop), the LARC wrapper (pyprob/nn/optimizer_larc.py, constructed with its defaults at
+    inference_network.py:351-352) as a gradient rewrite before the step, zero_grad by `grad = None`."""
 
-    def __init__(self, network, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, network, defaults, larc=False):
         self._network = network
-        super().__init__(list(network.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._larc = bool(larc)
+        super().__init__(list(network.parameters()), defaults)
         self._active_cache = {}
+        self._stepped = set()       # engine tensor indices that have optimizer state
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def _begin(self):
         net = self._network
         eng = net._hip_engine
-        group = self.param_groups[0]
         present = presence(net, bring_home=True)
         act = self._active_cache.get(present)
         if act is None:
             act = self._active_cache[present] = torch.tensor(present, dtype=torch.float32).to(eng.device)
+            self._stepped.update(i for i, f in enumerate(present) if f)
         eng.active.copy_(act)
-        b1, b2 = group['betas']
-        ops.adam_step(eng.params, eng.grads, eng.exp_avg, eng.exp_avg_sq, eng.chunk_tensor, eng.active, eng.tensor_step,
-                      eng.arrived, float(group['lr']), float(b1), float(b2), float(group['eps']),
-                      float(group['weight_decay']), float(net._hip_grad_scale), L.PP_ADAM_ZERO_GRADS, None)
+        group = self.param_groups[0]
+        wd, scale = float(group['weight_decay']), float(net._hip_grad_scale)
+        if self._larc:
+            need = L.larc_scratch_floats(eng.params.numel(), eng.active.numel())
+            if getattr(self, '_larc_scratch', None) is None or self._larc_scratch.numel() < need:
+                self._larc_scratch = torch.empty(need, dtype=torch.float32, device=eng.params.device)
+            ops.larc_scale(eng.params, eng.grads, eng.chunk_tensor, eng.active, float(group['lr']), wd, scale, 0.002, 1e-8,
+                           1.0 / 16000.0, True, self._larc_scratch, None)
+            wd, scale = 0.0, 1.0          # both are in the gradients now (optimizer_larc.py:81,101)
+        return net, eng, group, wd, scale
+
+    def _end(self, net):
         net._hip_grad_scale = 1.0
         net._hip_grads_clean = True       # the consumed gradient chunks were cleared (zero_grad of the next step)
 
@@ -86,6 +97,74 @@ class HipAdam(torch.optim.Optimizer):
         # the HIP path tracks "did this parameter take part" by `grad is None`, like the reference's presence map
         for p in self.param_groups[0]['params']:
             p.grad = None
+
+    def _groups_state(self):
+        groups = [dict((k, v) for k, v in self.param_groups[0].items() if k != 'params')]
+        groups[0]['params'] = list(range(len(self.param_groups[0]['params'])))
+        return groups
+
+    def _load_groups(self, state_dict):
+        for k, v in state_dict['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+
+
+class HipSGD(_HipOptimizer):
+    """optim.SGD(lr, momentum, nesterov=True, weight_decay) (inference_network.py:350) as ONE kernel over the network's flat
+    buffers; the momentum buffers live in the engine's `exp_avg` buffer. larc=True: Optimizer.SGD_LARC."""
+
+    def __init__(self, network, lr, momentum=0.9, weight_decay=0.0, nesterov=True, larc=False):
+        super().__init__(network, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=nesterov),
+                         larc=larc)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        net, eng, group, wd, scale = self._begin()
+        ops.sgd_step(eng.params, eng.grads, eng.exp_avg, eng.chunk_tensor, eng.active, float(group['lr']),
+                     float(group['momentum']), bool(group['nesterov']), wd, scale, L.PP_ADAM_ZERO_GRADS, None)
+        self._end(net)
+
+    def state_dict(self):
+        net = self._network
+        eng = net._hip_engine
+        names = list(eng.spec.tensors.keys())
+        state = {}
+        if float(self.param_groups[0]['momentum']) != 0.0:
+            for i, (name, p) in enumerate(net._hip_named_parameters()):
+                if names.index(name) in self._stepped:
+                    state[i] = dict(momentum_buffer=eng.tensor(name, eng.exp_avg).detach().cpu().clone())
+        return dict(state=state, param_groups=self._groups_state())
+
+    def load_state_dict(self, state_dict):
+        net = self._network
+        eng = net._hip_engine
+        names = list(eng.spec.tensors.keys())
+        eng.reset_optimizer()
+        self._stepped = set()
+        for i, (name, p) in enumerate(net._hip_named_parameters()):
+            st = state_dict['state'].get(i)
+            if st is None or st.get('momentum_buffer') is None:
+                continue
+            eng.tensor(name, eng.exp_avg).copy_(st['momentum_buffer'].reshape(p.shape))
+            self._stepped.add(names.index(name))
+        self._load_groups(state_dict)
+
+
+class HipAdam(_HipOptimizer):
+    """optim.Adam(lr, weight_decay) (inference_network.py:348) as ONE kernel over the network's flat buffers.
+    larc=True: Optimizer.ADAM_LARC."""
+
+    def __init__(self, network, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, larc=False):
+        super().__init__(network, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay), larc=larc)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        net, eng, group, wd, scale = self._begin()
+        b1, b2 = group['betas']
+        ops.adam_step(eng.params, eng.grads, eng.exp_avg, eng.exp_avg_sq, eng.chunk_tensor, eng.active, eng.tensor_step,
+                      eng.arrived, float(group['lr']), float(b1), float(b2), float(group['eps']), wd, scale,
+                      L.PP_ADAM_ZERO_GRADS, None)
+        self._end(net)
 
     def state_dict(self):
         net = self._network
@@ -98,9 +177,7 @@ class HipAdam(torch.optim.Optimizer):
             if steps[k] > 0:
                 state[i] = dict(step=torch.tensor(float(steps[k])), exp_avg=eng.tensor(name, eng.exp_avg).detach().cpu().clone(),
                                 exp_avg_sq=eng.tensor(name, eng.exp_avg_sq).detach().cpu().clone())
-        groups = [dict((k, v) for k, v in self.param_groups[0].items() if k != 'params')]
-        groups[0]['params'] = list(range(len(self.param_groups[0]['params'])))
-        return dict(state=state, param_groups=groups)
+        return dict(state=state, param_groups=self._groups_state())
 
     def load_state_dict(self, state_dict):
         net = self._network
@@ -117,6 +194,4 @@ class HipAdam(torch.optim.Optimizer):
             steps[names.index(name)] = int(st['step'])
         eng.tensor_step.copy_(steps)
         eng.moments_written()
-        for k, v in state_dict['param_groups'][0].items():
-            if k != 'params':
-                self.param_groups[0][k] = v
+        self._load_groups(state_dict)

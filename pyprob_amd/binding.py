@@ -43,7 +43,7 @@ from pyprob.nn import InferenceNetworkFeedForward as _RefFeedForward
 from pyprob.nn import InferenceNetworkLSTM as _RefLSTM
 
 from . import lib as L
-from .autograd import HipAdam, HipLoss, presence
+from .autograd import HipAdam, HipLoss, HipSGD, presence
 from .coroutine import ParticleScheduler
 from .is_engine import ISRunner
 from .nn import ProposalSample
@@ -164,12 +164,14 @@ class _HipNetworkMixin:
     def _create_optimizer(self, state_dict=None):
         if self._optimizer_type is None:           # happens when loading a pre-generated network (:344-345)
             return
-        if self._optimizer_type != pyprob.Optimizer.ADAM:
-            raise NotImplementedError('the HIP engine trains with Optimizer.ADAM (the reference default); got {}'.format(
-                self._optimizer_type))
         self._hip_ensure()
         self._hip_engine.reset_optimizer()         # a NEW optimizer: state is lost like in the reference (:481-483)
-        self._optimizer = HipAdam(self, lr=self._learning_rate_init, weight_decay=self._weight_decay)
+        larc = self._optimizer_type in (pyprob.Optimizer.ADAM_LARC, pyprob.Optimizer.SGD_LARC)    # :351-352
+        if self._optimizer_type in (pyprob.Optimizer.ADAM, pyprob.Optimizer.ADAM_LARC):           # :347-348
+            self._optimizer = HipAdam(self, lr=self._learning_rate_init, weight_decay=self._weight_decay, larc=larc)
+        else:                                                                                      # :349-350
+            self._optimizer = HipSGD(self, lr=self._learning_rate_init, momentum=self._momentum, weight_decay=self._weight_decay,
+                                     nesterov=True, larc=larc)
         if state_dict is not None:
             self._optimizer.load_state_dict(state_dict)
 

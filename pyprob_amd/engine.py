@@ -33,6 +33,7 @@ class ICEngine:
         self.status_buf = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.world_size = 1
         self.force_allreduce = False   # run the collective even with one rank (exercises the RCCL path)
+        self.optimizer = dict(kind='adam', larc=False, momentum=0.9)     # set_optimizer()
         self._resize(initialise=list(spec.tensors.keys()))
 
     # ---- buffers -----------------------------------------------------------------------------------------
@@ -163,34 +164,84 @@ class ICEngine:
         self.active.copy_(act)
         self._active_key = key
 
-    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, zero_grads=False, skip=None):
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, zero_grads=False, skip=None, grad_scale=None):
         """optimizer.step() for optim.Adam (inference_network.py:348,496); grads are divided by world_size first
         when data-parallel (inference_network.py:324-325). zero_grads=True also performs the NEXT step's
         optimizer.zero_grad() (:486) in the same pass: the consumed gradient chunks are cleared, gradients of tensors
         without a gradient this step are zero already."""
+        gs = 1.0 / self.world_size if grad_scale is None else grad_scale
         if getattr(self, '_use_ops', False):
             from .ops import ops
             ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.chunk_tensor, self.active,
-                          self.tensor_step, self.arrived, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
+                          self.tensor_step, self.arrived, lr, beta1, beta2, eps, weight_decay, gs,
                           L.PP_ADAM_ZERO_GRADS if zero_grads else 0, skip)
         else:
             rc = self.lib.pp_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.spec.n_params, self.chunk_tensor.data_ptr(),
                                        self.active.data_ptr(), self.tensor_step.data_ptr(), self.arrived.data_ptr(),
-                                       self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, 1.0 / self.world_size,
+                                       self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, gs,
                                        L.PP_ADAM_ZERO_GRADS if zero_grads else 0, L.ptr(skip), L.stream_ptr())
             L.check(rc, 'pp_adam_step')
         self._grads_clean = bool(zero_grads)
 
+    def set_optimizer(self, kind='adam', larc=False, momentum=0.9):
+        """Which optimizer `optimizer_step` / `train_step` run: Optimizer.ADAM / SGD / ADAM_LARC / SGD_LARC of
+        InferenceNetwork._create_optimizer (inference_network.py:343-355; SGD is built with nesterov=True there). A new
+        optimizer starts from empty state, like in the reference."""
+        kind = str(kind).lower()
+        if kind not in ('adam', 'sgd'):
+            raise ValueError('unknown optimizer {!r} (adam | sgd)'.format(kind))
+        self.optimizer = dict(kind=kind, larc=bool(larc), momentum=float(momentum))
+        self.reset_optimizer()
+
+    def sgd_step(self, lr, momentum=0.9, nesterov=True, weight_decay=0.0, zero_grads=False, skip=None, grad_scale=None):
+        """optimizer.step() for optim.SGD(momentum, nesterov=True) (inference_network.py:350). The momentum buffer lives in
+        `exp_avg` (same layout as the parameters)."""
+        from .ops import ops
+        gs = 1.0 / self.world_size if grad_scale is None else grad_scale
+        ops.sgd_step(self.params, self.grads, self.exp_avg, self.chunk_tensor, self.active, float(lr), float(momentum),
+                     bool(nesterov), float(weight_decay), float(gs), L.PP_ADAM_ZERO_GRADS if zero_grads else 0, skip)
+        self._grads_clean = bool(zero_grads)
+
+    def larc_scale(self, lr, weight_decay=0.0, skip=None, trust_coefficient=0.002, clip=True, eps=1e-8, epsilon=1.0 / 16000.0):
+        """The LARC wrapper's gradient rewrite (optimizer_larc.py:72-103, defaults as constructed at inference_network.py:352):
+        afterwards the gradients carry the weight decay, the 1 / world_size averaging and the per-tensor adaptive factor,
+        and the wrapped optimizer steps with weight_decay = 0, grad_scale = 1."""
+        from .ops import ops
+        need = L.larc_scratch_floats(self.spec.n_params, self.spec.n_tensors)
+        if getattr(self, '_larc_scratch', None) is None or self._larc_scratch.numel() < need:
+            self._larc_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+        ops.larc_scale(self.params, self.grads, self.chunk_tensor, self.active, float(lr), float(weight_decay),
+                       1.0 / self.world_size, float(trust_coefficient), float(eps), float(epsilon), bool(clip),
+                       self._larc_scratch, skip)
+
+    def optimizer_step(self, lr, weight_decay=0.0, zero_grads=False, skip=None):
+        """optimizer.step() of the optimizer chosen with set_optimizer (inference_network.py:496)."""
+        opt = self.optimizer
+        scale = None
+        if opt['larc']:
+            self.larc_scale(lr, weight_decay, skip=skip)
+            weight_decay, scale = 0.0, 1.0
+        if opt['kind'] == 'sgd':
+            self.sgd_step(lr, opt['momentum'], True, weight_decay, zero_grads, skip, grad_scale=scale)
+        elif scale is None:
+            self.adam_step(lr, weight_decay=weight_decay, zero_grads=zero_grads, skip=skip)
+        else:
+            self.adam_step(lr, weight_decay=0.0, zero_grads=zero_grads, skip=skip, grad_scale=1.0)
+
+    def _adam_only(self, what):
+        if self.optimizer['kind'] != 'adam' or self.optimizer['larc']:
+            raise RuntimeError('{} runs Optimizer.ADAM; other optimizers step through train_step'.format(what))
+
     def train_step(self, batch, lr, weight_decay=0.0):
-        """zero_grad -> loss -> backward -> [all-reduce] -> Adam (inference_network.py:486-496). No host sync.
+        """zero_grad -> loss -> backward -> [all-reduce] -> optimizer step (inference_network.py:486-496). No host sync.
         Data parallel: the non-finite flag travels in the reduced tail, so every rank skips the same batches."""
         loss = self.loss(batch, backward=True)
         if self.world_size > 1 or self.force_allreduce:
             self.allreduce_grads()
-            self.adam_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS, skip=self.reduced_status())
+            self.optimizer_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS, skip=self.reduced_status())
         else:
-            self.adam_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS, skip=self.status_buf)
+            self.optimizer_step(lr, weight_decay=weight_decay, zero_grads=_ADAM_CLEARS, skip=self.status_buf)
         return loss
 
     def train_run(self, dataset, id_lists, lrs, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
@@ -198,6 +249,7 @@ class ICEngine:
         dataset (pyprob_amd/dataset.py) with learning rate lrs[i] - packing, upload, loss + backward and Adam per step
         without returning to Python (single rank). Returns (losses, statuses): device tensors [n_steps], not synchronised.
         The caller polymorphs first; per-address iteration counters (inference_network_lstm.py:198) are updated here."""
+        self._adam_only('train_run (pp_train_steps)')
         dp = self.world_size != 1 or self.force_allreduce
         if dp and not (self.native_dp and self.lib.pp_dp_world() == self.world_size):
             raise RuntimeError('train_run under data parallelism needs the native RCCL communicator '
@@ -270,6 +322,7 @@ class ICEngine:
         Returns (losses, statuses): device tensors [n_steps], not synchronised. Data parallel: needs the native communicator
         (self.native_dp), every rank must pass the same number of steps."""
         n_steps = len(batches)
+        self._adam_only('train_resident (pp_train_resident)')
         dp = self.world_size != 1 or self.force_allreduce
         if dp and not (self.native_dp and self.lib.pp_dp_world() == self.world_size):
             raise RuntimeError('train_resident under data parallelism needs the native RCCL communicator')

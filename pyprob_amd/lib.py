@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 6
+PP_ABI_VERSION = 7
 PP_MAX_OBS = 8
 PP_MAX_LSTM_DEPTH = 4
 PP_MAX_OBS_DEPTH = 4
@@ -17,6 +17,13 @@ PP_LOSS_BACKWARD, PP_LOSS_ZERO_GRADS, PP_LOSS_KEEP_LP = 1, 2, 4
 PP_ADAM_ZERO_GRADS = 1
 PP_ADAM_SCRATCH = 1056          # int32 per tensor (include/pyprob_amd.h)
 PP_ADAM_SEEN = 1027
+
+
+def larc_scratch_floats(n_params, n_tensors):
+    """PP_LARC_SCRATCH_FLOATS (include/pyprob_amd.h)."""
+    return 2 * (int(n_params) // 1024) + int(n_tensors)
+
+
 PP_IS_STATS_SCRATCH = 1536   # doubles (include/pyprob_amd.h)
 
 i32, i64, f32p, i32p, vp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p
@@ -108,6 +115,9 @@ PROTOTYPES = {
     'pp_ic_loss': (C.c_int, [C.POINTER(pp_net), C.POINTER(pp_batch), vp, vp, vp, C.c_size_t, vp, vp, vp, i32, vp]),
     'pp_adam_step': (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, i32, vp, vp]),
+    'pp_sgd_step': (C.c_int, [vp, vp, vp, i64, vp, vp, i32, C.c_float, C.c_float, i32, C.c_float, C.c_float, i32, vp, vp]),
+    'pp_larc_scale': (C.c_int, [vp, vp, i64, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                i32, vp, vp, vp]),
     'pp_is_workspace_bytes': (C.c_size_t, [C.POINTER(pp_net), i32]),
     'pp_is_init': (C.c_int, [C.POINTER(pp_net), vp, vp, vp, vp, C.c_size_t, vp]),
     'pp_is_step': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, C.c_uint64,

@@ -307,8 +307,6 @@ class Model:
                                 stop_with_bad_loss=True, dataset_valid_dir=None, valid_every=None):
         """pyprob/model.py:186-215 (inference_network: FEEDFORWARD, the reference's default, or LSTM). `dataset_dir` = a directory written by
         `save_dataset` (packed shards, pyprob_amd/dataset.py): offline training like the reference's OfflineDataset."""
-        if str(optimizer_type).split('.')[-1].upper() != 'ADAM':
-            raise ValueError('pyprob_amd trains with Optimizer.ADAM (the reference default); got {}'.format(optimizer_type))
         if dataset is None and dataset_dir is not None:
             from .dataset import PackedTraceDataset
             dataset = PackedTraceDataset(dataset_dir)
@@ -355,7 +353,8 @@ class Model:
                                          learning_rate_init=learning_rate_init, learning_rate_end=learning_rate_end,
                                          learning_rate_scheduler_type=learning_rate_scheduler_type,
                                          weight_decay=weight_decay, distributed_backend=distributed_backend,
-                                         log_file_name=log_file_name, distributed_num_buckets=distributed_num_buckets)
+                                         log_file_name=log_file_name, distributed_num_buckets=distributed_num_buckets,
+                                         optimizer_type=optimizer_type, momentum=momentum)
 
     def save_dataset(self, dataset_dir, num_traces, num_traces_per_file, prior_inflation=PriorInflation.DISABLED,
                      *args, **kwargs):

@@ -113,6 +113,8 @@ class InferenceNetworkLSTM:
         self._learning_rate_end = None
         self._learning_rate_scheduler_type = None
         self._weight_decay = None
+        self._optimizer_type = None          # 'ADAM' | 'SGD' | 'ADAM_LARC' | 'SGD_LARC' (inference_network.py:39,439-440)
+        self._momentum = None
         self._total_train_seconds = 0
         self._total_train_traces = 0
         self._total_train_traces_end = None
@@ -395,9 +397,10 @@ class InferenceNetworkLSTM:
                  learning_rate_scheduler_type=None, weight_decay=1e-5, num_traces_end=1e9, distributed_backend=None,
                  distributed_params_sync_every_iter=10000, stop_with_bad_loss=False, log_file_name=None, verbose=True,
                  distributed_num_buckets=None, save_file_name_prefix=None, save_every_sec=600, dataset_valid=None,
-                 valid_every=None):
-        """The training loop of inference_network.py:381-599 for Optimizer.ADAM: per minibatch _polymorph ->
-        zero_grad -> _loss -> backward -> [all-reduce, divide by world] -> Adam step, traces/s bookkeeping."""
+                 valid_every=None, optimizer_type=None, momentum=0.9):
+        """The training loop of inference_network.py:381-599: per minibatch _polymorph -> zero_grad -> _loss -> backward ->
+        [all-reduce, divide by world] -> optimizer step (Optimizer.ADAM | SGD | ADAM_LARC | SGD_LARC, :343-355; the runs
+        inside one C call are Adam's, the other optimizers step per minibatch), traces/s bookkeeping."""
         if not self._layers_initialized:
             self._init_layers_observe_embedding(self._observe_embeddings, example_trace=dataset[0])
             self._init_layers()
@@ -424,6 +427,17 @@ class InferenceNetworkLSTM:
             self._learning_rate_scheduler_type = learning_rate_scheduler_type
         if self._weight_decay is None:
             self._weight_decay = weight_decay
+        if self._optimizer_type is None:                                                  # :439-442
+            self._optimizer_type = 'ADAM' if optimizer_type is None else str(optimizer_type).split('.')[-1].upper()
+        if self._momentum is None:
+            self._momentum = momentum
+        if self._optimizer_type not in ('ADAM', 'SGD', 'ADAM_LARC', 'SGD_LARC'):
+            raise ValueError('Unknown optimizer_type: {}'.format(self._optimizer_type))
+        want = dict(kind='sgd' if self._optimizer_type.startswith('SGD') else 'adam', larc=self._optimizer_type.endswith('LARC'),
+                    momentum=float(self._momentum))
+        if self._engine.optimizer != want:
+            self._engine.set_optimizer(**want)          # (a new optimizer: empty state)
+        plain_adam = want['kind'] == 'adam' and not want['larc']
         if self._total_train_traces_end is None:
             self._total_train_traces_end = num_traces_end
         prev_seconds = self._total_train_seconds
@@ -507,7 +521,7 @@ class InferenceNetworkLSTM:
         # (data parallel: the C loop has an all-reduce branch - tests/test_gpu_dp_native.py on a one-rank group - but
         # ranks must then cut their runs at the same steps; until that has run on a multi-GPU node it is opt-in,
         # PP_DP_NATIVE_LOOP=1, and the default is the per-step loop with the exchange issued from C)
-        native = packed and (world == 1 or (self._engine.native_dp and os.environ.get('PP_DP_NATIVE_LOOP', '0') == '1')) and \
+        native = packed and plain_adam and (world == 1 or (self._engine.native_dp and os.environ.get('PP_DP_NATIVE_LOOP', '0') == '1')) and \
             not has_bernoulli and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
         chunk_steps = 1 if sync_every == 1 else 64
         carry = None
@@ -647,11 +661,11 @@ class InferenceNetworkLSTM:
                 l_out.copy_(self._engine.loss_buf[:1])
                 # the non-finite flag was reduced with the gradients: every rank skips (and books) the same iterations
                 s_out.copy_(self._engine.status_tail[:1])
-                self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True,
-                                       skip=self._engine.reduced_status())
+                self._engine.optimizer_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True,
+                                            skip=self._engine.reduced_status())
             else:
                 self._engine.loss(pb, backward=True, loss_out=l_out, status_out=s_out)
-                self._engine.adam_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True, skip=s_out)
+                self._engine.optimizer_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True, skip=s_out)
             pending.append((batch.size, batch.mean_length_controlled, len(batch.sub_batches)))
             trace += batch.size * world
             stop = trace >= num_traces
@@ -676,6 +690,7 @@ class InferenceNetworkLSTM:
 
     # training state that survives a save / load like the reference's pickled module (inference_network.py:162-196)
     _PERSISTED = ('_learning_rate_init', '_learning_rate_end', '_learning_rate_scheduler_type', '_weight_decay',
+                  '_optimizer_type', '_momentum',
                   '_total_train_seconds', '_total_train_traces', '_total_train_traces_end', '_total_train_iterations',
                   '_loss_init', '_loss_min', '_loss_max', '_loss_previous', '_history_train_loss', '_history_valid_loss',
                   '_history_valid_loss_trace', '_history_train_loss_trace', '_history_num_params',
@@ -712,6 +727,10 @@ class InferenceNetworkLSTM:
         for info, (_, _, _, it) in zip(net._engine.spec.addresses, d['addresses']):
             info.total_train_iterations = it
         net._engine.load_state_dict(d['state_dict'])
+        ot = d.get('train_state', {}).get('_optimizer_type')
+        if ot is not None:         # before the optimizer state is restored: choosing an optimizer empties it
+            net._engine.set_optimizer('sgd' if ot.startswith('SGD') else 'adam', ot.endswith('LARC'),
+                                      d['train_state'].get('_momentum') or 0.9)
         net._engine.exp_avg.copy_(d['exp_avg'])
         net._engine.exp_avg_sq.copy_(d['exp_avg_sq'])
         net._engine.tensor_step.copy_(d['tensor_step'])

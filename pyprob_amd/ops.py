@@ -9,6 +9,8 @@ kernels for these operators from tests/, to execute the host logic above them wi
 
     ic_loss      InferenceNetworkLSTM._loss (+ backward)            pyprob/nn/inference_network_lstm.py:136-220
     adam_step    optim.Adam.step over the flat buffer                pyprob/nn/inference_network.py:348,496
+    sgd_step     optim.SGD(momentum, nesterov).step                  pyprob/nn/inference_network.py:350
+    larc_scale   the LARC wrapper's gradient rescaling               pyprob/nn/optimizer_larc.py:72-107
     is_init      InferenceNetwork._infer_init                        pyprob/nn/inference_network.py:141-148
     is_step      _infer_step + proposal.sample() + log_prob          pyprob/nn/inference_network_lstm.py:82-134,
                                                                      pyprob/state.py:207-212
@@ -34,6 +36,10 @@ _lib.define('ic_loss(Tensor params, Tensor(a!) grads, Tensor(b!) workspace, Tens
 _lib.define('adam_step(Tensor(a!) params, Tensor(b!) grads, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, Tensor chunk_tensor, '
             'Tensor active, Tensor(e!) tensor_step, Tensor(f!) scratch, float lr, float beta1, float beta2, float eps, '
             'float weight_decay, float grad_scale, int flags, Tensor? skip) -> ()')
+_lib.define('sgd_step(Tensor(a!) params, Tensor(b!) grads, Tensor(c!) momentum_buf, Tensor chunk_tensor, Tensor active, float lr, '
+            'float momentum, bool nesterov, float weight_decay, float grad_scale, int flags, Tensor? skip) -> ()')
+_lib.define('larc_scale(Tensor params, Tensor(a!) grads, Tensor chunk_tensor, Tensor active, float lr, float weight_decay, '
+            'float grad_scale, float trust_coefficient, float eps, float epsilon, bool clip, Tensor(b!) scratch, Tensor? skip) -> ()')
 _lib.define('is_init(Tensor params, Tensor(a!) workspace, int net, Tensor obs) -> Tensor')
 _lib.define('is_step(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
             'Tensor? prev_value, Tensor? prior, Tensor(b!) h, Tensor(c!) c, int state_rows, Tensor? value_in, int seed, '
@@ -170,6 +176,39 @@ def _adam_step_hip(params, grads, exp_avg, exp_avg_sq, chunk_tensor, active, ten
     L.check(rc, 'pp_adam_step')
 
 
+def _sgd_step_hip(params, grads, momentum_buf, chunk_tensor, active, lr, momentum, nesterov, weight_decay, grad_scale, flags, skip):
+    lib = L.load()
+    n = params.numel()
+    for t, name in ((params, 'params'), (grads, 'grads'), (momentum_buf, 'momentum_buf'), (active, 'active')):
+        _f32(t, name)
+    _same_device(params, grads, momentum_buf, chunk_tensor, active, skip)
+    if min(grads.numel(), momentum_buf.numel()) < n or chunk_tensor.numel() * 1024 != n:
+        raise RuntimeError('pyprob_hip::sgd_step: buffer sizes do not match the parameter buffer')
+    with torch.cuda.device(params.device):
+        rc = lib.pp_sgd_step(params.data_ptr(), grads.data_ptr(), momentum_buf.data_ptr(), n, chunk_tensor.data_ptr(),
+                             active.data_ptr(), active.numel(), lr, momentum, int(bool(nesterov)), weight_decay, grad_scale,
+                             int(flags), L.ptr(skip), _stream(params))
+    L.check(rc, 'pp_sgd_step')
+
+
+def _larc_scale_hip(params, grads, chunk_tensor, active, lr, weight_decay, grad_scale, trust_coefficient, eps, epsilon, clip,
+                    scratch, skip):
+    lib = L.load()
+    n = params.numel()
+    for t, name in ((params, 'params'), (grads, 'grads'), (active, 'active'), (scratch, 'scratch')):
+        _f32(t, name)
+    _same_device(params, grads, chunk_tensor, active, scratch, skip)
+    if grads.numel() < n or chunk_tensor.numel() * 1024 != n:
+        raise RuntimeError('pyprob_hip::larc_scale: buffer sizes do not match the parameter buffer')
+    if scratch.numel() < L.larc_scratch_floats(n, active.numel()):
+        raise RuntimeError('pyprob_hip::larc_scale: scratch too small')
+    with torch.cuda.device(params.device):
+        rc = lib.pp_larc_scale(params.data_ptr(), grads.data_ptr(), n, chunk_tensor.data_ptr(), active.data_ptr(),
+                               active.numel(), lr, weight_decay, grad_scale, trust_coefficient, eps, epsilon, int(bool(clip)),
+                               scratch.data_ptr(), L.ptr(skip), _stream(params))
+    L.check(rc, 'pp_larc_scale')
+
+
 def _is_ws(lib, netc, workspace, n):
     need = lib.pp_is_workspace_bytes(C.byref(netc), n)
     have = workspace.numel() * workspace.element_size()
@@ -268,6 +307,8 @@ def _is_stats_hip(lw, x, scratch):
 
 _lib.impl('ic_loss', _ic_loss_hip, 'CUDA')
 _lib.impl('adam_step', _adam_step_hip, 'CUDA')
+_lib.impl('sgd_step', _sgd_step_hip, 'CUDA')
+_lib.impl('larc_scale', _larc_scale_hip, 'CUDA')
 _lib.impl('is_init', _is_init_hip, 'CUDA')
 _lib.impl('is_step', _is_step_hip, 'CUDA')
 _lib.impl('log_prob', _log_prob_hip, 'CUDA')

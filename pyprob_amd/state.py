@@ -47,7 +47,7 @@ class LearningRateScheduler(enum.Enum):    # pyprob/__init__.py
     POLY2 = 2
 
 
-class Optimizer(enum.Enum):                # pyprob/__init__.py (this engine implements ADAM)
+class Optimizer(enum.Enum):                # pyprob/__init__.py
     ADAM = 0
     SGD = 1
     ADAM_LARC = 2

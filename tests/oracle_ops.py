@@ -36,6 +36,7 @@ class CpuBufferEngine(ICEngine):
         self.status_buf = torch.zeros(4, dtype=torch.int32)
         self.world_size = 1
         self.force_allreduce = False
+        self.optimizer = dict(kind='adam', larc=False, momentum=0.9)
         self._resize(initialise=list(spec.tensors.keys()))
 
 
@@ -117,6 +118,37 @@ def _adam_step_cpu(params, grads, exp_avg, exp_avg_sq, chunk_tensor, active, ten
             tensor_step[t] = step
         if flags & L.PP_ADAM_ZERO_GRADS:
             g[sl] = 0.0
+
+
+def _tensor_slices(chunk_tensor, active):
+    ct = chunk_tensor.numpy()
+    for t in range(active.numel()):
+        if not float(active[t]) > 0:
+            continue
+        chunks = np.nonzero(ct == t)[0]
+        yield t, slice(int(chunks[0]) * CHUNK, (int(chunks[-1]) + 1) * CHUNK)
+
+
+def _sgd_step_cpu(params, grads, momentum_buf, chunk_tensor, active, lr, momentum, nesterov, weight_decay, grad_scale, flags, skip):
+    skipped = skip is not None and int(skip.view(torch.int32)[0]) != 0
+    p, g, m = params.numpy(), grads.numpy(), momentum_buf.numpy()
+    for t, sl in _tensor_slices(chunk_tensor, active):
+        if not skipped:
+            P64, M64 = p[sl].astype(np.float64), m[sl].astype(np.float64)
+            O.sgd_step(P64, g[sl].astype(np.float64) * grad_scale, M64, lr, momentum, nesterov, weight_decay)
+            p[sl], m[sl] = P64, M64
+        if flags & L.PP_ADAM_ZERO_GRADS:
+            g[sl] = 0.0
+
+
+def _larc_scale_cpu(params, grads, chunk_tensor, active, lr, weight_decay, grad_scale, trust_coefficient, eps, epsilon, clip,
+                    scratch, skip):
+    if skip is not None and int(skip.view(torch.int32)[0]) != 0:
+        return
+    p, g = params.numpy(), grads.numpy()
+    for t, sl in _tensor_slices(chunk_tensor, active):
+        g[sl] = O.larc_scale(p[sl].astype(np.float64), g[sl].astype(np.float64) * grad_scale, lr, weight_decay,
+                             trust_coefficient, clip, eps, epsilon)
 
 
 def _is_init_cpu(params, workspace, net, obs):
@@ -278,7 +310,8 @@ def register():
     global _registered
     if _registered:
         return
-    for name, fn in (('ic_loss', _ic_loss_cpu), ('adam_step', _adam_step_cpu), ('is_init', _is_init_cpu),
+    for name, fn in (('ic_loss', _ic_loss_cpu), ('adam_step', _adam_step_cpu), ('sgd_step', _sgd_step_cpu),
+                     ('larc_scale', _larc_scale_cpu), ('is_init', _is_init_cpu),
                      ('is_step', _is_step_cpu), ('log_prob', _log_prob_cpu), ('logweight_terms', _logweight_terms_cpu),
                      ('is_stats', _is_stats_cpu)):
         P._lib.impl(name, fn, 'CPU')

@@ -294,3 +294,40 @@ def test_array_sampler_equals_the_reference_sampler(monkeypatch, n, batch_size, 
             a = [list(b) for b in ref]
             b = [list(x) for x in mine]
             assert a == b and mine._current_bucket_id == ref._current_bucket_id
+
+
+@pytest.mark.parametrize('opt', ['SGD', 'ADAM_LARC', 'SGD_LARC'])
+def test_the_other_optimizers_match_the_stock_reference(opt, tmp_path, monkeypatch):
+    """Optimizer.SGD (nesterov momentum) and the LARC-wrapped optimizers of _create_optimizer (inference_network.py:343-355)
+    through HipSGD / HipAdam(larc=True): same loss trajectory and weights as the stock reference, with weight decay, on the
+    program whose minibatches leave some proposal layers without gradient; the optimizer state survives _save / _load."""
+    kw = dict(optimizer_type=getattr(pyprob.Optimizer, opt), weight_decay=1e-3, momentum=0.8)
+    stock = _train(GaussianWithUnknownMeanMarsaglia, False, 320, **kw)
+    bound = _train(GaussianWithUnknownMeanMarsaglia, True, 320, **kw)
+    ns, nb = stock._inference_network, bound._inference_network
+    want = 'HipSGD' if opt.startswith('SGD') else 'HipAdam'
+    assert type(nb._optimizer).__name__ == want and nb._optimizer._larc == opt.endswith('LARC')
+    np.testing.assert_allclose(nb._history_train_loss, ns._history_train_loss, rtol=2e-4, atol=2e-4)
+    sd_s, sd_b = ns.state_dict(), nb.state_dict()
+    for k in sd_s:
+        np.testing.assert_allclose(sd_b[k].numpy(), sd_s[k].numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
+    # optimizer state in torch's format, and back
+    inner = ns._optimizer.optim if opt.endswith('LARC') else ns._optimizer
+    st_s, st_b = inner.state_dict()['state'], nb._optimizer.state_dict()['state']
+    assert set(st_b.keys()) == set(st_s.keys())
+    key = 'momentum_buffer' if opt.startswith('SGD') else 'exp_avg'
+    for i in st_s:
+        np.testing.assert_allclose(st_b[i][key].numpy(), st_s[i][key].numpy(), rtol=5e-3, atol=1e-5)
+    monkeypatch.setattr(torch, 'load', functools.partial(torch.load, weights_only=False))
+    hip.install()
+    try:
+        fn = str(tmp_path / 'net.network')
+        bound.save_inference_network(fn)
+        other = GaussianWithUnknownMeanMarsaglia()
+        other.load_inference_network(fn)
+        ln = other._inference_network
+        assert type(ln._optimizer).__name__ == want and ln._optimizer._larc == opt.endswith('LARC')
+        assert torch.equal(ln._hip_engine.exp_avg, nb._hip_engine.exp_avg)
+        assert ln._optimizer.param_groups[0]['lr'] == nb._optimizer.param_groups[0]['lr']
+    finally:
+        hip.uninstall()

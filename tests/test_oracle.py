@@ -168,3 +168,35 @@ def test_torch_restatement_matches_the_reference_records():
         ref = gold[name]
         got = np.zeros_like(ref) if p.grad is None else p.grad.numpy()
         assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-6), name
+
+
+@pytest.mark.parametrize('name', ['ADAM', 'SGD', 'ADAM_LARC', 'SGD_LARC'])
+def test_optimizer_restatements_follow_the_recorded_trajectories(name):
+    """O.adam_step / O.sgd_step / O.larc_scale against trajectories recorded from torch.optim.Adam / SGD(nesterov) and the
+    reference's LARC wrapper (tests/golden/make_optim_golden.py; inference_network.py:343-355, optimizer_larc.py:72-107),
+    float64, including a tensor without gradient at one step and an all-zero tensor (LARC's epsilon branch)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'optim_steps.npz'))
+    lr, momentum = float(g['lr']), float(g['momentum'])
+    for w, wd in enumerate(g['weight_decays']):
+        key = '{}_{}'.format(name, w)
+        P = [g['{}_p0_{}'.format(key, k)].copy() for k in range(3)]
+        B = [np.zeros_like(p) for p in P]
+        M = [np.zeros_like(p) for p in P]
+        V = [np.zeros_like(p) for p in P]
+        steps = [0, 0, 0]
+        for it in range(6):
+            present = g['{}_present{}'.format(key, it)]
+            for k in range(3):
+                if not present[k]:
+                    continue
+                grad, decay = g['{}_g{}_{}'.format(key, it, k)], float(wd)
+                if name.endswith('LARC'):
+                    grad, decay = O.larc_scale(P[k], grad, lr, decay), 0.0
+                if name.startswith('SGD'):
+                    O.sgd_step(P[k], grad, B[k], lr, momentum, True, decay)
+                else:
+                    steps[k] += 1
+                    O.adam_step(P[k], grad, M[k], V[k], steps[k], lr, weight_decay=decay)
+            for k in range(3):
+                np.testing.assert_allclose(P[k], g['{}_p{}_{}'.format(key, it + 1, k)], rtol=1e-12, atol=1e-14)
