@@ -382,8 +382,12 @@ def test_checkpoint_files_and_pre_generated_layers(tmp_path):
     m2 = GaussianWithUnknownMeanMarsagliaLockStep()
     m2.load_inference_network(final[-1])
     assert m2._inference_network._total_train_traces == net._total_train_traces
+    # continuing with another optimizer_type keeps the network's optimizer, like the reference (inference_network.py:439-440)
+    model.learn_inference_network(num_traces=200, dataset_dir=d, observe_embeddings=EMB, batch_size=100, optimizer_type='SGD')
+    assert net._optimizer_type == 'ADAM' and net._engine.optimizer['kind'] == 'adam'
     with pytest.raises(ValueError):
-        model.learn_inference_network(num_traces=10, observe_embeddings=EMB, optimizer_type='SGD')
+        GaussianWithUnknownMean().learn_inference_network(num_traces=10, observe_embeddings=EMB, inference_network=LSTM,
+                                                          optimizer_type='LBFGS')
 
 
 def test_two_layer_lstm_trains_and_infers():
