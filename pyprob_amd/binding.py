@@ -30,11 +30,9 @@ address-grouped batches (pyprob_amd/coroutine.py) - and returns the same `Empiri
 
 Everything else of pyprob (state, Trace, distributions, Empirical, datasets, the optimize loop) is the reference's code.
 """
-import math
 import os
 import warnings
 
-import numpy as np
 import torch
 
 import pyprob
@@ -47,7 +45,7 @@ from .autograd import HipAdam, HipLoss, HipSGD, presence
 from .coroutine import ParticleScheduler
 from .is_engine import ISRunner
 from .nn import ProposalSample
-from .ops import ops
+from .ops import ops  # noqa: F401  (importing registers the pyprob_hip operators)
 from .packed import pack_traces
 from .spec import NetSpec
 

@@ -27,7 +27,6 @@ sorted index space across ranks exactly like the reference.
 """
 import json
 import os
-import queue
 import threading
 
 import numpy as np

@@ -1,6 +1,5 @@
 """Model facade for the hot path (mirror of pyprob/model.py:24-215): prior, posterior_results with importance
 sampling (with or without the inference network), learn_inference_network, save/load_inference_network."""
-import time
 
 import numpy as np
 import torch

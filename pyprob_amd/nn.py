@@ -12,7 +12,6 @@ import warnings
 import numpy as np
 import torch
 
-from . import lib as L
 from .engine import ICEngine
 from .is_engine import ISRunner
 from .packed import PackedBatch, pack_traces

@@ -21,7 +21,7 @@ import time
 
 import torch
 
-from .distributions import Normal, Uniform
+from .distributions import Normal
 from .trace import Trace, Variable
 
 

@@ -9,7 +9,6 @@ import warnings
 
 import numpy as np
 import pytest
-import torch
 
 import oracle_ops  # noqa: F401  registers the CPU kernels of pyprob_hip::*
 from is_helpers import lockstep_network, network_from_golden, rescore, rescore_lockstep_run

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import REPO, load_golden
-from helpers import spec_from_golden, synthetic_gumm_arrays
+from helpers import spec_from_golden
 
 
 def _worker(rank, world, port, out):

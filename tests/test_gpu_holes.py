@@ -6,8 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import load_golden
-from helpers import engine_from_golden, packed_from_golden, rel_err, synthetic_gumm_arrays
+from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')

@@ -259,7 +259,6 @@ def test_feedforward_network_is_the_default_and_recovers_the_posterior(tmp_path)
     """learn_inference_network's default network is FEEDFORWARD like the reference (model.py:186); GUM posterior checks
     of tests/test_inference.py:173-202 with it, per trace and in lock step; save / load keeps the network type."""
     from pyprob_amd.nn import InferenceNetworkFeedForward
-    from pyprob_amd.model import Model
     torch.manual_seed(21)
     model = GaussianWithUnknownMean()
     model.learn_inference_network(num_traces=40000, observe_embeddings=EMB, batch_size=128, seed=9)

@@ -1,13 +1,12 @@
 """GPU parity of the whole hot path (InferenceNetworkLSTM._loss + backward, Adam, importance sampling) through the
 C ABI, against (a) the golden vectors recorded from the reference and (b) the numpy oracle at benchmark sizes, plus
 size-independent properties. Tolerance: north_star asks 1e-4 relative on log-weights; most checks are tighter."""
-import ctypes as C
 
 import numpy as np
 import pytest
 
 from conftest import load_golden
-from helpers import (engine_from_golden, packed_from_golden, rel_err, spec_from_golden, synthetic_gum_arrays,
+from helpers import (engine_from_golden, packed_from_golden, rel_err, synthetic_gum_arrays,
                      synthetic_gumm_arrays)
 from oracle import ic_oracle as O
 

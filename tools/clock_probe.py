@@ -1,5 +1,5 @@
 """Effective shader clock right after (a) idle, (b) a burst of training steps, (c) a burst of big GEMMs."""
-import ctypes as C, os, sys, time
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

@@ -1,4 +1,4 @@
-import sys, os, numpy as np, torch
+import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from helpers import synthetic_gum_arrays
 from pyprob_amd.engine import ICEngine
