@@ -197,23 +197,37 @@ class ICEngine:
     def sgd_step(self, lr, momentum=0.9, nesterov=True, weight_decay=0.0, zero_grads=False, skip=None, grad_scale=None):
         """optimizer.step() for optim.SGD(momentum, nesterov=True) (inference_network.py:350). The momentum buffer lives in
         `exp_avg` (same layout as the parameters)."""
-        from .ops import ops
         gs = 1.0 / self.world_size if grad_scale is None else grad_scale
-        ops.sgd_step(self.params, self.grads, self.exp_avg, self.chunk_tensor, self.active, float(lr), float(momentum),
-                     bool(nesterov), float(weight_decay), float(gs), L.PP_ADAM_ZERO_GRADS if zero_grads else 0, skip)
+        flags = L.PP_ADAM_ZERO_GRADS if zero_grads else 0
+        if getattr(self, '_use_ops', False):
+            from .ops import ops
+            ops.sgd_step(self.params, self.grads, self.exp_avg, self.chunk_tensor, self.active, float(lr), float(momentum),
+                         bool(nesterov), float(weight_decay), float(gs), flags, skip)
+        else:
+            rc = self.lib.pp_sgd_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.spec.n_params,
+                                      self.chunk_tensor.data_ptr(), self.active.data_ptr(), self.spec.n_tensors, lr, momentum,
+                                      int(bool(nesterov)), weight_decay, gs, flags, L.ptr(skip), L.stream_ptr())
+            L.check(rc, 'pp_sgd_step')
         self._grads_clean = bool(zero_grads)
 
     def larc_scale(self, lr, weight_decay=0.0, skip=None, trust_coefficient=0.002, clip=True, eps=1e-8, epsilon=1.0 / 16000.0):
         """The LARC wrapper's gradient rewrite (optimizer_larc.py:72-103, defaults as constructed at inference_network.py:352):
         afterwards the gradients carry the weight decay, the 1 / world_size averaging and the per-tensor adaptive factor,
         and the wrapped optimizer steps with weight_decay = 0, grad_scale = 1."""
-        from .ops import ops
         need = L.larc_scratch_floats(self.spec.n_params, self.spec.n_tensors)
         if getattr(self, '_larc_scratch', None) is None or self._larc_scratch.numel() < need:
             self._larc_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
-        ops.larc_scale(self.params, self.grads, self.chunk_tensor, self.active, float(lr), float(weight_decay),
-                       1.0 / self.world_size, float(trust_coefficient), float(eps), float(epsilon), bool(clip),
-                       self._larc_scratch, skip)
+        if getattr(self, '_use_ops', False):
+            from .ops import ops
+            ops.larc_scale(self.params, self.grads, self.chunk_tensor, self.active, float(lr), float(weight_decay),
+                           1.0 / self.world_size, float(trust_coefficient), float(eps), float(epsilon), bool(clip),
+                           self._larc_scratch, skip)
+        else:
+            rc = self.lib.pp_larc_scale(self.params.data_ptr(), self.grads.data_ptr(), self.spec.n_params,
+                                        self.chunk_tensor.data_ptr(), self.active.data_ptr(), self.spec.n_tensors, lr, weight_decay,
+                                        1.0 / self.world_size, trust_coefficient, eps, epsilon, int(bool(clip)),
+                                        self._larc_scratch.data_ptr(), L.ptr(skip), L.stream_ptr())
+            L.check(rc, 'pp_larc_scale')
 
     def optimizer_step(self, lr, weight_decay=0.0, zero_grads=False, skip=None):
         """optimizer.step() of the optimizer chosen with set_optimizer (inference_network.py:496)."""
