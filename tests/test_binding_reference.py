@@ -331,3 +331,66 @@ def test_the_other_optimizers_match_the_stock_reference(opt, tmp_path, monkeypat
         assert ln._optimizer.param_groups[0]['lr'] == nb._optimizer.param_groups[0]['lr']
     finally:
         hip.uninstall()
+
+
+def _dp_worker(rank, world, port, use_hip, dataset_dir, out):
+    """One rank of pyprob's own data-parallel training (optimize(distributed_backend=...), inference_network.py:381-599)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import contextlib
+    import io
+    (hip.install if use_hip else hip.uninstall)()
+    pyprob.seed(7)
+    model = GaussianWithUnknownMeanMarsaglia()
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter('ignore')
+        model.learn_inference_network(num_traces=256, batch_size=16, dataset_dir=dataset_dir, observe_embeddings=EMB,
+                                      inference_network=InferenceNetwork.LSTM, lstm_dim=24, learning_rate_init=1e-3,
+                                      distributed_backend='gloo', distributed_num_buckets=2, pre_generate_layers=True,
+                                      distributed_params_sync_every_iter=5)
+    net = model._inference_network
+    torch.save(dict(hist=list(net._history_train_loss), dist_hist=list(net._distributed_history_train_loss),
+                    sd={k: v.detach().clone() for k, v in net.state_dict().items()}, cls=type(net).__name__,
+                    iters=net._total_train_iterations, traces=net._total_train_traces,
+                    lr=net._optimizer.param_groups[0]['lr']), '{}.{}.{}'.format(out, int(use_hip), rank))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_through_the_binding_matches_the_stock_reference(tmp_path, monkeypatch):
+    """pyprob's OWN distributed loop on two gloo ranks - DistributedTraceBatchSampler over an OfflineDataset, _polymorph
+    skipped (pre-generated layers), _distributed_sync_parameters, loss.backward(), _distributed_sync_grad, optimizer.step(),
+    _distributed_update_train_loss (inference_network.py:290-333, 461-531) - with the HIP-side network bound in: its ONE
+    all-reduce of [flat gradients | presence map] and the 1 / world_size inside the optimizer kernel give the stock
+    reference's trajectory; the ranks touch different proposal layers and still hold identical parameters."""
+    import torch.multiprocessing as mp
+    monkeypatch.setattr(torch, 'load', functools.partial(torch.load, weights_only=False))
+    hip.uninstall()
+    pyprob.seed(21)
+    d = str(tmp_path / 'ds')
+    os.makedirs(d)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        GaussianWithUnknownMeanMarsaglia().save_dataset(d, 256, 64)
+    out = str(tmp_path / 'dp')
+    world = 2
+    for use_hip in (False, True):
+        port = 39500 + (os.getpid() + 7 * use_hip) % 2000
+        mp.spawn(_dp_worker, args=(world, port, use_hip, d, out), nprocs=world, join=True)
+    res = {(h, r): torch.load('{}.{}.{}'.format(out, h, r), weights_only=False) for h in (0, 1) for r in range(world)}
+    assert res[(1, 0)]['cls'] == 'InferenceNetworkLSTMHip' and res[(0, 0)]['cls'] == 'InferenceNetworkLSTM'
+    for h in (0, 1):                                  # the ranks of one run never diverge
+        a, b = res[(h, 0)], res[(h, 1)]
+        assert a['iters'] == b['iters'] and a['traces'] == b['traces'] and a['lr'] == b['lr']
+        for k in a['sd']:
+            assert torch.equal(a['sd'][k], b['sd'][k]), (h, k)
+        np.testing.assert_allclose(a['dist_hist'], b['dist_hist'], rtol=1e-6)
+    for r in range(world):                            # bound run = stock run, rank by rank
+        s, b = res[(0, r)], res[(1, r)]
+        assert s['iters'] == b['iters'] > 0 and s['traces'] == b['traces']
+        assert abs(s['lr'] - b['lr']) < 1e-12 and abs(s['lr'] - 1e-3 * math.sqrt(world)) < 1e-9       # :448
+        np.testing.assert_allclose(b['hist'], s['hist'], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(b['dist_hist'], s['dist_hist'], rtol=2e-4, atol=2e-4)
+        for k in s['sd']:
+            np.testing.assert_allclose(b['sd'][k].numpy(), s['sd'][k].numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
