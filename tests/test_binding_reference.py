@@ -394,3 +394,96 @@ def test_data_parallel_training_through_the_binding_matches_the_stock_reference(
         np.testing.assert_allclose(b['dist_hist'], s['dist_hist'], rtol=2e-4, atol=2e-4)
         for k in s['sd']:
             np.testing.assert_allclose(b['sd'][k].numpy(), s['sd'][k].numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
+
+
+class _CategoricalThenNormal(Model):            # the program of the `cat` golden case, with the reference's classes
+    def __init__(self):
+        super().__init__('categorical then normal')
+
+    def forward(self):
+        from pyprob.distributions import Categorical
+        c = pyprob.sample(Categorical([0.2, 0.3, 0.5]))
+        mu = pyprob.sample(Normal(c.float() * 2.0 - 1.0, 1.5))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+class _PoissonThenNormal(Model):                # `poi`
+    def __init__(self):
+        super().__init__('poisson then normal')
+
+    def forward(self):
+        from pyprob.distributions import Poisson
+        n = pyprob.sample(Poisson(4.0))
+        mu = pyprob.sample(Normal(n * 0.5, 1.0))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+class _BernoulliThenNormal(Model):              # `ber`
+    def __init__(self):
+        super().__init__('bernoulli then normal')
+
+    def forward(self):
+        from pyprob.distributions import Bernoulli
+        b = pyprob.sample(Bernoulli(0.3))
+        mu = pyprob.sample(Normal(b * 2.0 - 1.0, 1.0))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+@pytest.mark.parametrize('program,network', [(_CategoricalThenNormal, InferenceNetwork.LSTM),
+                                             (_PoissonThenNormal, InferenceNetwork.LSTM),
+                                             (_BernoulliThenNormal, InferenceNetwork.LSTM),
+                                             (GaussianWithUnknownMeanMarsaglia, InferenceNetwork.FEEDFORWARD),
+                                             (_CategoricalThenNormal, InferenceNetwork.FEEDFORWARD)],
+                         ids=['cat-lstm', 'poi-lstm', 'ber-lstm', 'gumm-ff', 'cat-ff'])
+def test_every_proposal_layer_and_both_networks_through_the_binding(program, network):
+    """The reference's training loop on programs with Categorical / Poisson / Bernoulli priors (ProposalCategoricalCategorical,
+    ProposalPoissonTruncatedNormalMixture, ProposalBernoulliBernoulli, inference_network_lstm.py:52-66) and with
+    InferenceNetworkFeedForward (inference_network_feedforward.py), HIP-side network bound in: the stock reference's loss
+    trajectory, parameter names and weights; then a posterior through the bound network (finite weights, the reference's
+    Empirical)."""
+    def train(use_hip):
+        (hip.install if use_hip else hip.uninstall)()
+        try:
+            pyprob.seed(5)
+            model = program()
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                model.learn_inference_network(num_traces=256, batch_size=32, observe_embeddings=EMB, inference_network=network,
+                                              lstm_dim=24, learning_rate_init=1e-3)
+            return model
+        finally:
+            hip.uninstall()
+    stock, bound = train(False), train(True)
+    ns, nb = stock._inference_network, bound._inference_network
+    assert type(nb).__name__ == type(ns).__name__ + 'Hip' and isinstance(nb, type(ns))
+    assert [n for n, _ in nb.named_parameters()] == [n for n, _ in ns.named_parameters()]
+    np.testing.assert_allclose(nb._history_train_loss, ns._history_train_loss, rtol=3e-4, atol=3e-4)
+    sd_s, sd_b = ns.state_dict(), nb.state_dict()
+    for k in sd_s:
+        np.testing.assert_allclose(sd_b[k].numpy(), sd_s[k].numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
+    hip.install()
+    # (the Poisson proposal is a mixture of truncated normals, proposal_poisson_truncated_normal_mixture.py: its draws are not
+    # integers, and torch's Poisson.log_prob rejects them since argument validation became the default - in the stock
+    # reference too; the golden records were made with validation off as well, tests/golden/make_golden.py)
+    validate = torch.distributions.Distribution._validate_args
+    torch.distributions.Distribution.set_default_validate_args(False)
+    try:
+        pyprob.seed(6)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            post = bound.posterior(40, inference_engine=IC, observe={'obs0': 0.5, 'obs1': 0.8})
+        assert post.length == 40
+        lw = np.array([float(post._get_value(i).log_importance_weight) for i in range(post.length)])
+        assert np.isfinite(lw).all() and np.isfinite(float(post.map(lambda t: t.result).mean))
+    finally:
+        torch.distributions.Distribution.set_default_validate_args(validate)
+        hip.uninstall()
