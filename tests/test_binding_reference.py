@@ -487,3 +487,38 @@ def test_every_proposal_layer_and_both_networks_through_the_binding(program, net
     finally:
         torch.distributions.Distribution.set_default_validate_args(validate)
         hip.uninstall()
+
+
+@pytest.mark.parametrize('kw', [dict(lstm_depth=2), dict(observe_embeddings={'obs0': {'dim': 16, 'depth': 3}, 'obs1': {'dim': 8, 'depth': 1}})],
+                         ids=['lstm-depth-2', 'embedding-depths-3-1'])
+def test_stacked_lstm_and_embedding_depths_through_the_binding(kw):
+    """nn.LSTM(input, hidden, lstm_depth) (inference_network_lstm.py:31) and EmbeddingFeedForward(depth)
+    (inference_network.py:110-118) created by the reference's code, re-bound to the flat buffer: the stock reference's
+    trajectory and weights, parameter names included (`weight_ih_l1`, `_layers.2.weight`, ...)."""
+    args = dict(observe_embeddings=EMB, lstm_depth=1)
+    args.update(kw)
+
+    def train(use_hip):
+        (hip.install if use_hip else hip.uninstall)()
+        try:
+            pyprob.seed(8)
+            model = GaussianWithUnknownMeanMarsaglia()
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                model.learn_inference_network(num_traces=256, batch_size=32, inference_network=InferenceNetwork.LSTM, lstm_dim=16,
+                                              learning_rate_init=1e-3, **args)
+            return model._inference_network
+        finally:
+            hip.uninstall()
+    ns, nb = train(False), train(True)
+    names = [n for n, _ in ns.named_parameters()]
+    assert [n for n, _ in nb.named_parameters()] == names
+    if 'lstm_depth' in kw:
+        assert '_layers_lstm.weight_hh_l1' in names and nb._hip_engine.spec.lstm_depth == 2
+    else:
+        assert '_layers_observe_embedding.obs0._layers.2.weight' in names
+        assert '_layers_observe_embedding.obs1._layers.1.weight' not in names
+    np.testing.assert_allclose(nb._history_train_loss, ns._history_train_loss, rtol=3e-4, atol=3e-4)
+    sd_s, sd_b = ns.state_dict(), nb.state_dict()
+    for k in sd_s:
+        np.testing.assert_allclose(sd_b[k].numpy(), sd_s[k].numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
