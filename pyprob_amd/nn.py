@@ -89,6 +89,7 @@ class ProposalSample:
 class InferenceNetworkLSTM:
     # observe_embeddings example: {'obs1': {'dim': 32}}   (FEEDFORWARD, depth 2)
     _network = 'lstm'           # NetSpec(network=...): 'lstm' | 'feedforward' (class InferenceNetworkFeedForward below)
+    _engine_factory = ICEngine  # (spec, device=, seed=) -> engine; the CPU tests of the training loop put buffers on the host
 
     def __init__(self, model=None, observe_embeddings={}, lstm_dim=512, lstm_depth=1, sample_embedding_dim=4,
                  address_embedding_dim=64, distribution_type_embedding_dim=8, proposal_mixture_components=10,
@@ -155,7 +156,7 @@ class InferenceNetworkLSTM:
                        distribution_type_embedding_dim=self._distribution_type_embedding_dim,
                        proposal_mixture_components=self._proposal_mixture_components, network=self._network,
                        lstm_depth=self._lstm_depth)
-        self._engine = ICEngine(spec, device=self._device, seed=self._seed)
+        self._engine = type(self)._engine_factory(spec, device=self._device, seed=self._seed)
         self._is = ISRunner(self._engine)
 
     def _polymorph(self, batch):

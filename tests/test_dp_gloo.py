@@ -370,3 +370,90 @@ def test_sgd_and_larc_under_data_parallelism(tmp_path):
                 np.testing.assert_allclose(have, P[n], err_msg='%s %s %s' % (kind, larc, n), **tol)
             else:
                 np.testing.assert_array_equal(have, params[n])
+
+
+def _cpu_engine_factory(spec, device='cpu', seed=None):
+    import oracle_ops
+    eng = oracle_ops.CpuBufferEngine(spec, seed=seed)
+    eng._use_ops = True
+    return eng
+
+
+def _gumm_dataset():
+    from helpers import synthetic_gumm_arrays
+    from pyprob_amd.dataset import PackedTraceDataset
+    arrays, addresses = synthetic_gumm_arrays(768, seed=17, max_iter=3)
+    table = [(a, 'Uniform', None) for a in addresses]
+    return PackedTraceDataset.from_columns(['obs0', 'obs1'], [1, 1], arrays['trace_len'], table, arrays['addr_idx'],
+                                           arrays['values'], arrays['prior'], arrays['obs'])
+
+
+def _loop_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import contextlib
+    import io
+    from models import GaussianWithUnknownMeanMarsaglia
+    from pyprob_amd import nn as N
+    from pyprob_amd.state import InferenceNetwork
+    N.InferenceNetworkLSTM._engine_factory = staticmethod(_cpu_engine_factory)
+    ds = _gumm_dataset()
+    used = []
+    device_batch = ds.device_batch
+
+    def logged(ids, spec, device):
+        used.append(np.asarray(ids).copy())
+        return device_batch(ids, spec, device)
+    ds.device_batch = logged
+    model = GaussianWithUnknownMeanMarsaglia()
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.learn_inference_network(num_traces=16 * 2 * 12, dataset=ds, inference_network=InferenceNetwork.LSTM,
+                                      observe_embeddings={'obs0': {'dim': 8}, 'obs1': {'dim': 8}}, lstm_dim=16, batch_size=16,
+                                      learning_rate_init=1e-3, weight_decay=0.0, distributed_backend='gloo',
+                                      distributed_num_buckets=3, pre_generate_layers=True, device='cpu', seed=5,
+                                      distributed_params_sync_every_iter=4)
+    net = model._inference_network
+    torch.save(dict(params=net._engine.params.clone(), used=used, iters=net._total_train_iterations,
+                    traces=net._total_train_traces, hist=list(net._history_train_loss), lr=net._learning_rate_init,
+                    steps=net._engine.tensor_step.clone()), out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loop_on_two_ranks_equals_steps_on_the_averaged_gradients(tmp_path):
+    """InferenceNetworkLSTM.optimize (the mirror of inference_network.py:381-599) with world_size 2 on gloo, buffers on the
+    host and operators backed by the oracle: bucketed sampler per rank, parameter broadcast every 4 iterations, one
+    all-reduce per iteration, lr * sqrt(world) (:448), loss read-back per iteration. The ranks see disjoint minibatches, end
+    with identical parameters and counters, and the parameters equal a single-process replay of the SAME minibatch pairs:
+    gradients of both minibatches summed, presence maps merged, Adam on the average."""
+    world, port = 2, 41500 + os.getpid() % 2000
+    out = str(tmp_path / 'loop.pt')
+    mp.spawn(_loop_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)
+    assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['steps'], r1['steps'])
+    assert r0['iters'] == r1['iters'] == 12 and r0['traces'] == r1['traces'] == 16 * 2 * 12
+    assert abs(r0['lr'] - 1e-3 * np.sqrt(2.0)) < 1e-12
+    np.testing.assert_allclose(r0['hist'], r1['hist'], rtol=1e-6)           # the all-reduced mean loss
+    assert len(r0['used']) == len(r1['used']) == 12
+    for a, b in zip(r0['used'], r1['used']):
+        assert len(a) == len(b) == 16 and not set(a.tolist()) & set(b.tolist())
+    # single-process replay
+    import oracle_ops  # noqa: F401
+    from pyprob_amd.spec import NetSpec
+    ds = _gumm_dataset()
+    spec = NetSpec({'obs0': {'dim': 8, 'input_dim': 1}, 'obs1': {'dim': 8, 'input_dim': 1}}, lstm_dim=16)
+    eng = _cpu_engine_factory(spec, seed=5)
+    eng.add_addresses([a for a in ds.addresses])
+    hist = []
+    for a, b in zip(r0['used'], r1['used']):
+        eng.loss(ds.device_batch(a, eng.spec, 'cpu'), backward=True)
+        g = eng.grads_full.clone()
+        eng.loss(ds.device_batch(b, eng.spec, 'cpu'), backward=True)
+        g += eng.grads_full
+        eng.grads_full.copy_(g)
+        hist.append(float(eng.loss_buf[0]) / 2)
+        eng.adam_step(r0['lr'], weight_decay=0.0, zero_grads=True, grad_scale=0.5)
+    np.testing.assert_allclose(r0['hist'], hist, rtol=1e-5)
+    d = (eng.params - r0['params']).abs().max().item()
+    assert d < 1e-6, d
