@@ -445,7 +445,8 @@ def test_training_loop_on_two_ranks_equals_steps_on_the_averaged_gradients(tmp_p
     spec = NetSpec({'obs0': {'dim': 8, 'input_dim': 1}, 'obs1': {'dim': 8, 'input_dim': 1}}, lstm_dim=16)
     eng = _cpu_engine_factory(spec, seed=5)
     eng.add_addresses([a for a in ds.addresses])
-    hist = []
+    eng.force_allreduce = True      # (the presence map is rewritten by every loss call, as in a data-parallel run: this replay
+    hist = []                       # overwrites it with the merged one)
     for a, b in zip(r0['used'], r1['used']):
         eng.loss(ds.device_batch(a, eng.spec, 'cpu'), backward=True)
         g = eng.grads_full.clone()
