@@ -78,6 +78,7 @@ class _HipOptimizer(torch.optim.Optimizer):
             act = self._active_cache[present] = torch.tensor(present, dtype=torch.float32).to(eng.device)
             self._stepped.update(i for i, f in enumerate(present) if f)
         eng.active.copy_(act)
+        eng._active_key = None          # (ICEngine.loss caches which presence map is in place)
         group = self.param_groups[0]
         wd, scale = float(group['weight_decay']), float(net._hip_grad_scale)
         if self._larc:

@@ -203,6 +203,7 @@ class _HipNetworkMixin:
         eng = self._hip_engine
         present = self._hip_presence(bring_home=True)
         eng.active.copy_(torch.tensor(present, dtype=torch.float32).to(eng.device))
+        eng._active_key = None
         eng.loss_buf.zero_()
         dist.all_reduce(eng.grads_full)
         merged = eng.active.cpu()
