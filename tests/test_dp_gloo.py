@@ -458,3 +458,53 @@ def test_training_loop_on_two_ranks_equals_steps_on_the_averaged_gradients(tmp_p
     np.testing.assert_allclose(r0['hist'], hist, rtol=1e-5)
     d = (eng.params - r0['params']).abs().max().item()
     assert d < 1e-6, d
+
+
+def _gum_model_on_host():
+    import oracle_ops  # noqa: F401  (CPU kernels of the operators)
+    from is_helpers import network_from_golden
+    from models import GaussianWithUnknownMean
+    net, meta, params, isr = network_from_golden('gum')
+    model = GaussianWithUnknownMean()
+    model._inference_network = net
+    return model
+
+
+def _posterior_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    model = _gum_model_on_host()
+    post = model.posterior_results_distributed(101, observe={'obs0': 8.0, 'obs1': 9.0}, seed=3)
+    torch.save(dict(values=post._all_values.clone() if hasattr(post, '_all_values') else torch.as_tensor(post.values_numpy()),
+                    lw=torch.as_tensor(np.asarray(post.log_weights)), mean=float(post.mean), ess=float(post.effective_sample_size),
+                    stats=dict(post.device_stats)), out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_posterior_on_two_ranks_is_the_concatenation_of_the_shards(tmp_path):
+    """Model.posterior_results_distributed (ParallelModel's sharding, pyprob/model.py:339-406) on two gloo ranks with the golden
+    GUM network on the host: shards of 51 + 50 particles with their own counter offsets, ONE all-gather; every rank holds
+    all 101 particles in shard order, equal to the two shards computed in one process, with the same statistics."""
+    world, port = 2, 43500 + os.getpid() % 2000
+    out = str(tmp_path / 'post.pt')
+    mp.spawn(_posterior_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)
+    assert torch.equal(r0['values'], r1['values']) and torch.equal(r0['lw'], r1['lw'])
+    assert r0['mean'] == r1['mean'] and r0['ess'] == r1['ess'] and r0['values'].numel() == 101
+    from pyprob_amd.parallel import shard_range
+    model = _gum_model_on_host()
+    vals, lws = [], []
+    for r in range(world):
+        off, cnt = shard_range(101, r, world)
+        local = model._traces_lockstep(cnt, {'obs0': 8.0, 'obs1': 9.0}, seed=3, offset=off)
+        vals.append(local._all_values)
+        lws.append(local._all_log_weights)
+    assert [v.numel() for v in vals] == [51, 50]
+    assert torch.equal(torch.cat(vals).cpu(), r0['values'].cpu())
+    np.testing.assert_allclose(torch.cat(lws).cpu().numpy(), r0['lw'].numpy(), rtol=0, atol=0)
+    assert abs(r0['stats']['ess'] - r0['ess']) < 1e-6 * r0['ess'] and r0['stats']['count'] == 101
+    assert abs(r0['mean'] - 7.25) < 1.5        # (the golden network is only briefly trained)
