@@ -200,3 +200,30 @@ def test_optimizer_restatements_follow_the_recorded_trajectories(name):
                     O.adam_step(P[k], grad, M[k], V[k], steps[k], lr, weight_decay=decay)
             for k in range(3):
                 np.testing.assert_allclose(P[k], g['{}_p{}_{}'.format(key, it + 1, k)], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize('case', ['gum', 'gumm'])
+def test_is_log_weights_of_ten_thousand_reference_particles(case):
+    """10^4 particles sampled and scored by the reference with the golden networks
+    (tests/golden/make_is_10k.py): log-weights from -2.7 down to -152. The oracle re-scores every 4th of them (the CPU
+    suite's time budget) - prior log_prob, proposal log_prob and the trace log-weight - to the north star's 1e-4."""
+    import os
+    from conftest import GOLDEN, load_golden
+    meta, params, batch, loss, isr = load_golden(case)
+    big = np.load(os.path.join(GOLDEN, case + '_is10k.npz'))
+    assert len(big['lw']) == 10000 and float(big['lw'].max() - big['lw'].min()) > 100
+    net = O.Net(params, meta['obs_names'], K=meta['mixture_components'])
+    addresses = [str(a) for a in big['addresses']]
+    dist_names = ['Normal' if '__Normal__' in a else 'Uniform' for a in addresses]
+    off = np.concatenate([[0], np.cumsum(big['trace_len'])])
+    pick = np.arange(0, 10000, 4)
+    rows = np.concatenate([np.arange(off[b], off[b + 1]) for b in pick])
+    p_lp, q_lp, _, lw = O.is_rescore(net, big['observe'], big['trace_len'][pick], big['addr'][rows], big['value'][rows],
+                                     big['prior'][rows], addresses, dist_names)
+    np.testing.assert_allclose(p_lp, big['prior_lp'][rows], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(q_lp, big['prop_lp'][rows], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lw + big['obs_lw'][pick], big['lw'][pick], rtol=1e-4, atol=1e-4)
+    # the records are self-consistent: lw = sum (log p - log q) + observed terms, for all 10^4 (trace.py:123-125)
+    d = big['prior_lp'] - big['prop_lp']
+    sums = np.add.reduceat(d, off[:-1])
+    np.testing.assert_allclose(sums + big['obs_lw'], big['lw'], rtol=1e-5, atol=1e-4)
