@@ -2,7 +2,6 @@
 (the mirror of pyprob/nn/inference_network.py:381-599), checkpoints and `posterior_results` driven end to end with the
 engine's buffers on the host and the `pyprob_hip::*` operators backed by the oracle (tests/oracle_ops.py) - the code above
 the operators is the code that ships; tests/test_gpu_model.py runs the same calls on the device."""
-import os
 
 import numpy as np
 import pytest
