@@ -109,19 +109,6 @@ def test_batched_log_weights_equal_per_particle(golden):
     _score_in_groups(case, engine_from_golden(meta, params), isr, meta['is_addresses'])
 
 
-@pytest.mark.parametrize('case', ['gum', 'gumm'])
-def test_ten_thousand_reference_particles(case):
-    """the log-weights of 10^4 particles the reference sampled and scored with the golden networks
-    (tests/golden/make_is_10k.py; weights from -2.7 down to -152), re-computed on the device in lock-step groups of
-    thousands of particles: 1e-4 (BASELINE.json north_star)."""
-    import os
-    from conftest import GOLDEN
-    meta, params, batch, loss, isr = load_golden(case)
-    big = dict(np.load(os.path.join(GOLDEN, case + '_is10k.npz')))
-    assert len(big['lw']) == 10000
-    _score_in_groups(case, engine_from_golden(meta, params), big, [str(a) for a in big['addresses']])
-
-
 def _score_in_groups(case, eng, isr, addresses):
     from pyprob_amd.is_engine import ISRunner
     run = ISRunner(eng)
