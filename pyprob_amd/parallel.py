@@ -148,10 +148,30 @@ def gather_particles(values, log_weights, num_traces):
     return v, lw
 
 
+def _seed0_drop_positions(n, drop):
+    """Positions (in the original list of n items) that `random.seed(0); for _ in range(drop): del l[random.randrange(len(l))]`
+    deletes - util.drop_items as DistributedTraceBatchSampler calls it - without the O(n) list deletions: the k-th item of
+    the current list is the smallest original position p with p - #(deleted <= p) == k."""
+    import bisect
+    import random
+    rnd = random.Random(0)
+    removed = []
+    for i in range(drop):
+        k = rnd.randrange(n - i)
+        p = k
+        while True:
+            q = k + bisect.bisect_right(removed, p)
+            if q == p:
+                break
+            p = q
+        bisect.insort(removed, p)
+    return np.asarray(removed, np.int64)
+
+
 class DistributedTraceBatchSampler:
     """The minibatch partition of pyprob/nn/dataset.py:328-400 as array views: the sorted trace indices become ONE int64
     table [n_batches, batch_size]; buckets are row ranges of it, a rank's share of a bucket is a strided row slice.
-    Same semantics as the reference: a seed-0 random subset of traces is dropped so that the number of minibatches is a
+    Same minibatches as the reference: the reference's seed-0 random subset of traces is dropped so that the number of minibatches is a
     multiple of the world size, the last short bucket is merged into its predecessor, all ranks walk the buckets in the
     same (epoch-seeded) order and take `floor(len / world)` minibatches of each, rank r the rows r, r + world, ..."""
 
@@ -160,8 +180,8 @@ class DistributedTraceBatchSampler:
         self._world_size, self._rank = int(world_size), int(rank)
         idx = np.asarray(sorted_indices, np.int64).reshape(-1)
         drop = ((len(idx) // batch_size) % self._world_size) * batch_size
-        if drop:       # every rank drops the same traces (seed 0)
-            idx = np.delete(idx, np.random.RandomState(0).choice(len(idx), drop, replace=False))
+        if drop:       # every rank drops the same traces: the reference's seed-0 choice (dataset.py:337-343, util.py:426-432)
+            idx = np.delete(idx, _seed0_drop_positions(len(idx), drop))
         n_batches = len(idx) // batch_size           # a short last minibatch is dropped (dataset.py:345-346)
         if n_batches == 0:
             raise RuntimeError('dataset too small for batch_size:{} and world_size:{}'.format(batch_size, world_size))

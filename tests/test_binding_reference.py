@@ -522,3 +522,45 @@ def test_stacked_lstm_and_embedding_depths_through_the_binding(kw):
     sd_s, sd_b = ns.state_dict(), nb.state_dict()
     for k in sd_s:
         np.testing.assert_allclose(sd_b[k].numpy(), sd_s[k].numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
+
+
+def test_array_sampler_equals_the_reference_sampler_on_arbitrary_sizes(monkeypatch):
+    """The same comparison on arbitrary dataset sizes (hypothesis), including those where the reference drops a seed-0 random
+    subset of traces so that the number of minibatches divides by the world size (dataset.py:337-343, util.drop_items): the
+    SAME traces are dropped, minibatches, buckets and per-rank order are identical; configurations the reference rejects are
+    rejected."""
+    import contextlib
+    import io
+    import torch.distributed as dist
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from pyprob.nn.dataset import DistributedTraceBatchSampler as RefSampler, OfflineDataset
+    from pyprob_amd.parallel import DistributedTraceBatchSampler
+    monkeypatch.setattr(OfflineDataset, '__len__', lambda self: self._length)
+    seen = dict(dropped=0, ok=0)
+
+    @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+    @given(st.integers(8, 700), st.sampled_from([1, 3, 8, 16]), st.integers(1, 5), st.sampled_from([None, 1, 2, 3, 7]),
+           st.integers(0, 10 ** 6))
+    def check(n, batch_size, world, num_buckets, seed):
+        ds = object.__new__(OfflineDataset)
+        ds._sorted_indices = list(np.random.RandomState(seed).permutation(n))
+        ds._length = n
+        monkeypatch.setattr(dist, 'get_world_size', lambda *a, **k: world)
+        for rank in range(world):
+            monkeypatch.setattr(dist, 'get_rank', lambda *a, **k: rank)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ref = RefSampler(ds, batch_size, shuffle_batches=False, num_buckets=num_buckets)
+            except (RuntimeError, IndexError, ZeroDivisionError, ValueError):
+                with pytest.raises((RuntimeError, ZeroDivisionError, ValueError)):
+                    DistributedTraceBatchSampler(ds._sorted_indices, batch_size, rank, world, num_buckets, shuffle_batches=False)
+                continue
+            mine = DistributedTraceBatchSampler(ds._sorted_indices, batch_size, rank, world, num_buckets, shuffle_batches=False)
+            assert [[list(b) for b in bk] for bk in mine._buckets] == [[list(b) for b in bk] for bk in ref._buckets]
+            for epoch in range(2):
+                assert [list(b) for b in ref] == [list(x) for x in mine]
+            seen['ok'] += 1
+            seen['dropped'] += int((n // batch_size) % world != 0)
+    check()
+    assert seen['ok'] > 50 and seen['dropped'] > 10
