@@ -417,7 +417,11 @@ class Empirical:
     def median(self):
         self._check_finalized()
         if self._uniform:
-            return float(np.median(self.values_numpy()))
+            v = self._values
+            if torch.is_tensor(v) or (len(v) and torch.is_tensor(v[0])):
+                # tensor values: torch.median, the LOWER of the two middle values of an even count (empirical.py:719-721)
+                return float(np.sort(self.values_numpy())[(self.length - 1) // 2])
+            return float(np.median(self.values_numpy()))       # :723-724
         return self.resample(1000).median           # empirical.py:727
 
     @property

@@ -564,3 +564,41 @@ def test_array_sampler_equals_the_reference_sampler_on_arbitrary_sizes(monkeypat
             seen['dropped'] += int((n // batch_size) % world != 0)
     check()
     assert seen['ok'] > 50 and seen['dropped'] > 10
+
+
+def test_empirical_statistics_equal_the_reference_class():
+    """pyprob_amd.distributions.Empirical (vectorised reductions) against pyprob.distributions.Empirical
+    (pyprob/distributions/empirical.py: finalize :298-309, expectation :451-466, moments :668-690, ESS :758-766, mode /
+    median / min / max) on arbitrary weighted samples, log-weights down to -150 (the range importance sampling produces)."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from pyprob.distributions import Empirical as RefEmpirical
+    from pyprob_amd.distributions import Empirical
+
+    @settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(st.integers(1, 200), st.integers(0, 10 ** 6), st.sampled_from([None, 1.0, 30.0, 150.0]))
+    def check(n, seed, spread):
+        rng = np.random.RandomState(seed)
+        values = rng.normal(size=n) * 3 + 1
+        lw = None if spread is None else -rng.uniform(0, spread, n)
+        as_tensors = bool(seed & 1)            # forward() results are 0-d tensors or plain numbers
+        vals = [torch.tensor(float(v)) for v in values] if as_tensors else [float(v) for v in values]
+        ref = RefEmpirical(values=list(vals), log_weights=None if lw is None else [float(w) for w in lw])
+        mine = Empirical(values=list(vals), log_weights=None if lw is None else [float(w) for w in lw])
+        assert mine.length == ref.length == n
+        for name in ('mean', 'variance', 'stddev', 'effective_sample_size'):
+            a, b = float(getattr(mine, name)), float(getattr(ref, name))
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (name, a, b)
+        if n >= 3 and float(ref.stddev) > 1e-3:
+            for name in ('skewness', 'kurtosis'):
+                a, b = float(getattr(mine, name)), float(getattr(ref, name))
+                assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (name, a, b)
+        # (the median of a weighted Empirical is the median of a random resample in both classes, the mode of an unweighted one
+        # a count over hashable values: compared where they are deterministic)
+        for name in ('min', 'max') + (('median',) if lw is None else ('mode',)):
+            a, b = float(getattr(mine, name)), float(getattr(ref, name))
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (name, a, b)
+        a, b = float(mine.expectation(lambda x: x * x + 1)), float(ref.expectation(lambda x: x * x + 1))
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
+        np.testing.assert_allclose(np.asarray(mine.weights_numpy(), np.float64), ref.weights_numpy(), rtol=1e-4, atol=1e-9)
+    check()
