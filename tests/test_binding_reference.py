@@ -602,3 +602,35 @@ def test_empirical_statistics_equal_the_reference_class():
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
         np.testing.assert_allclose(np.asarray(mine.weights_numpy(), np.float64), ref.weights_numpy(), rtol=1e-4, atol=1e-9)
     check()
+
+
+def test_mirror_runtime_produces_the_reference_addresses():
+    """Addresses are `<bytecode offset>__<call stack>__<distribution>__<instance>` (pyprob/state.py:34-35, 168-186): the same
+    method source executed under pyprob and under the pyprob_amd trace runtime gives the same address strings, instance
+    counters included (the golden networks recorded from the reference are keyed by them)."""
+    import models as M
+    pyprob.seed(1)
+    ref_model = GaussianWithUnknownMeanMarsaglia()
+    ref_traces = [next(ref_model._trace_generator(trace_mode=pyprob.TraceMode.PRIOR)) for _ in range(60)]
+    torch.manual_seed(1)
+    mir_model = M.GaussianWithUnknownMeanMarsaglia()
+    from pyprob_amd.state import TraceMode
+    gen = mir_model._trace_generator(trace_mode=TraceMode.PRIOR)
+    mir_traces = [next(gen) for _ in range(60)]
+
+    def by_length(traces):
+        out = {}
+        for t in traces:
+            out.setdefault(len(t.variables_controlled), [v.address for v in t.variables_controlled])
+        return out
+    ref, mir = by_length(ref_traces), by_length(mir_traces)
+    common = sorted(set(ref) & set(mir))
+    assert len(common) >= 2 and 2 in common
+    for n in common:                       # x_1, y_1, x_2, y_2, ...: same offsets, same instance numbering
+        assert ref[n] == mir[n], (n, ref[n], mir[n])
+    meta = __import__('json').load(open(os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'gumm_meta.json')))
+    assert set(ref[2]) <= set(meta['addresses'])          # ... and they are the addresses of the recorded golden network
+    # the named observables: same distribution suffix and instance (the offset differs: the two forward() sources do)
+    for name in ('obs0', 'obs1'):
+        a, b = ref_traces[0].named_variables[name].address, mir_traces[0].named_variables[name].address
+        assert a.split('__', 1)[1] == b.split('__', 1)[1], (a, b)
