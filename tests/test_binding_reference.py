@@ -634,3 +634,43 @@ def test_mirror_runtime_produces_the_reference_addresses():
     for name in ('obs0', 'obs1'):
         a, b = ref_traces[0].named_variables[name].address, mir_traces[0].named_variables[name].address
         assert a.split('__', 1)[1] == b.split('__', 1)[1], (a, b)
+
+
+def test_host_distributions_equal_the_reference_classes():
+    """pyprob_amd.distributions.{Normal, Uniform, Poisson, Categorical, Bernoulli}.log_prob (the host-side prior / likelihood
+    scoring of per-trace runs, pyprob/distributions/*.py) against the reference classes on arbitrary parameters and values,
+    support edges included (Uniform: closed lower, open upper edge)."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    import pyprob.distributions as R
+    import pyprob_amd.distributions as D
+    validate = torch.distributions.Distribution._validate_args
+    torch.distributions.Distribution.set_default_validate_args(False)
+
+    @settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(st.integers(0, 10 ** 6))
+    def check(seed):
+        rng = np.random.RandomState(seed)
+        mean, sd = float(rng.normal() * 3), float(rng.uniform(0.05, 4))
+        low = float(rng.normal() * 2)
+        high = low + float(rng.uniform(0.1, 5))
+        rate = float(rng.uniform(0.1, 20))
+        probs = rng.dirichlet(np.ones(int(rng.randint(2, 7)))).astype(np.float32)
+        p = float(rng.uniform(0.01, 0.99))
+        cases = [(D.Normal(mean, sd), R.Normal(mean, sd), [mean, mean + 3 * sd, float(rng.normal() * 10)]),
+                 (D.Uniform(low, high), R.Uniform(low, high), [low, (low + high) / 2, high - 1e-4 * (high - low), high + 1.0, low - 1.0]),
+                 (D.Poisson(rate), R.Poisson(rate), [0.0, float(rng.randint(0, 40)), 3.0]),
+                 (D.Categorical(probs.tolist()), R.Categorical(probs.tolist()), [0, len(probs) - 1, int(rng.randint(0, len(probs)))]),
+                 (D.Bernoulli(p), R.Bernoulli(p), [0.0, 1.0])]
+        for mine, ref, values in cases:
+            for v in values:
+                a = float(mine.log_prob(torch.tensor(float(v)), sum=True))
+                b = float(ref.log_prob(torch.tensor(float(v)), sum=True))
+                if np.isinf(b) or np.isnan(b):
+                    assert (np.isinf(a) and a < 0) or np.isnan(a) == np.isnan(b), (type(ref).__name__, v, a, b)
+                else:
+                    assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (type(ref).__name__, v, a, b)
+    try:
+        check()
+    finally:
+        torch.distributions.Distribution.set_default_validate_args(validate)
