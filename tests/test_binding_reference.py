@@ -674,3 +674,57 @@ def test_host_distributions_equal_the_reference_classes():
         check()
     finally:
         torch.distributions.Distribution.set_default_validate_args(validate)
+
+
+@pytest.mark.parametrize('cfg', [dict(lstm_dim=8, K=3, dims=(4, 8), depth=1, seed=101),
+                                 dict(lstm_dim=24, K=10, dims=(16, 16), depth=1, seed=102),
+                                 dict(lstm_dim=12, K=5, dims=(8, 4), depth=2, seed=103),
+                                 dict(lstm_dim=40, K=7, dims=(32, 8), depth=1, seed=104)],
+                         ids=lambda c: 'H{lstm_dim}-K{K}-depth{depth}'.format(**c))
+def test_oracle_equals_the_live_reference_on_other_network_shapes(cfg):
+    """The oracle is pinned on nine recorded cases of fixed shape (tests/golden); here the reference itself runs next to it on
+    freshly initialised networks of other shapes - LSTM width, mixture components K (proposal_mixture_components), observe
+    embedding dims, stacked LSTM - on a ragged minibatch: `_loss` (inference_network_lstm.py:136-220) and every gradient of
+    loss.backward() against O.loss_and_grads on the same state_dict and the same traces."""
+    import importlib.util
+    from pyprob.nn import Batch
+    spec_ = importlib.util.spec_from_file_location('make_golden', os.path.join(HERE, 'golden', 'make_golden.py'))
+    G = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(G)
+    hip.uninstall()
+    pyprob.seed(cfg['seed'])
+    model = GaussianWithUnknownMeanMarsaglia()
+    emb = {'obs0': {'dim': cfg['dims'][0]}, 'obs1': {'dim': cfg['dims'][1]}}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model.learn_inference_network(num_traces=96, batch_size=48, observe_embeddings=emb, inference_network=InferenceNetwork.LSTM,
+                                      lstm_dim=cfg['lstm_dim'], lstm_depth=cfg['depth'], proposal_mixture_components=cfg['K'],
+                                      learning_rate_init=1e-3)
+    net = model._inference_network
+    gen = model._trace_generator(trace_mode=pyprob.TraceMode.PRIOR_FOR_INFERENCE_NETWORK)
+    known = set(net._layers_proposal.keys())
+    traces = []
+    while len(traces) < 40:
+        t = next(gen)
+        if all(v.address in known for v in t.variables_controlled):
+            traces.append(t)
+    batch = Batch(traces)
+    net.zero_grad()
+    ok, loss = net._loss(batch)
+    assert ok
+    loss.backward()
+    arrays, meta = G.dump_batch(traces, ['obs0', 'obs1'])
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in net.state_dict().items()}
+    onet = O.Net(params, ['obs0', 'obs1'], K=cfg['K'])
+    assert onet.depth == cfg['depth']
+    out = O.loss_and_grads(onet, arrays, meta['addresses'], meta['dist_names'])
+    assert abs(out['loss'] - float(loss)) <= 5e-6 * abs(float(loss)), (out['loss'], float(loss))
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            assert not np.any(out['grads'][n]), n
+            continue
+        ref = p.grad.numpy()
+        # (freshly initialised networks: gradients of ~1e-3 and below whose bias entries are cancelled sums over the rows -
+        # the fp32 reference's own round-off is ~1e-3 of a tensor's largest entry there, like for the gumm2 golden)
+        err = np.abs(out['grads'][n] - ref).max() / max(np.abs(ref).max(), 1e-6)
+        assert err < 3e-3, (n, err)
