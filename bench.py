@@ -161,6 +161,27 @@ def cpu_baseline_is(n=20000):
                        'reference)' % m)
 
 
+def _claim_stdout():
+    """stdout must carry exactly ONE line, rank 0's JSON. Everything else this process writes to file descriptor 1 - RCCL
+    prints a five-line version banner at its first communicator, libraries warn now and then - is sent to stderr: returns a
+    private duplicate of the original stdout for `_emit_line`."""
+    try:
+        sys.stdout.flush()
+        fd = os.dup(1)
+        os.dup2(2, 1)
+        return fd
+    except OSError:
+        return None
+
+
+def _emit_line(fd, text):
+    sys.stdout.flush()
+    if fd is None:
+        print(text, flush=True)
+        return
+    os.write(fd, (text + '\n').encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -174,6 +195,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a captured HIP graph (1) or launch eagerly (0)')
     args = ap.parse_args()
+    json_fd = _claim_stdout()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -481,7 +503,7 @@ def main():
                 line['cpu_baseline'] = cpu_baseline_gumm(args.lstm_dim, args.batch)
             else:
                 line['cpu_baseline'] = cpu_baseline_is()
-        print(json.dumps(line))
+        _emit_line(json_fd, json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
 

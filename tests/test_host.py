@@ -202,3 +202,23 @@ def test_train_steps_rejects_incomplete_arguments(lib):
                             one.ctypes.data, 0, lr.ctypes.data, 0.9, 0.999, 1e-8, 0.0, 0, None, None)
     assert rc == -1 and b'pp_train_buffers' in lib.pp_last_error()
     assert lib.pp_train_slot_words(1024, 1024, 1, 2, 1, 20) >= lib.pp_pack_words(1024, 1024, 1, 2, 1) + 20
+
+
+def test_bench_stdout_carries_only_the_json_line():
+    """bench.py's contract: rank 0 prints ONE JSON line. RCCL writes a version banner to the C-level stdout at its first
+    communicator (seen under torch.distributed.run): bench.py claims file descriptor 1 at start and sends everything but the
+    line to stderr."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, sys, bench\n"
+            "fd = bench._claim_stdout()\n"
+            "libc = ctypes.CDLL(None)\n"
+            "libc.puts(b'banner written by a C library')\n"
+            "libc.fflush(None)\n"
+            "print('python chatter')\n"
+            "bench._emit_line(fd, '{\"ok\": 1}')\n")
+    r = subprocess.run([sys.executable, '-c', code], cwd=repo, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"ok": 1}\n'
+    assert 'banner written by a C library' in r.stderr and 'python chatter' in r.stderr
