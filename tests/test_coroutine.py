@@ -159,3 +159,20 @@ def test_persistent_workers_are_reused_and_give_the_same_particles(monkeypatch):
 
 def _identity(trace):
     return trace
+
+
+@pytest.mark.parametrize('case', ['gum', 'gumm'])
+def test_ten_thousand_reference_particles_through_the_runner_on_host_buffers(case):
+    """The scoring loop of tests/test_gpu_ten_thousand_particles.py (ISRunner.begin / step(value_in=...) / dist_term /
+    accumulate_terms in lock-step groups) with the engine's buffers on the host and the operators backed by the oracle: the
+    10^4 particles the reference sampled and scored (tests/golden/make_is_10k.py) come out at 1e-4."""
+    import os
+    from conftest import GOLDEN, load_golden
+    from helpers import spec_from_golden
+    from test_gpu_logweight import _score_in_groups
+    meta, params, batch, loss, isr = load_golden(case)
+    eng = oracle_ops.CpuBufferEngine(spec_from_golden(meta, params))
+    eng._use_ops = True
+    eng.load_state_dict(params)
+    big = dict(np.load(os.path.join(GOLDEN, case + '_is10k.npz')))
+    _score_in_groups(case, eng, big, [str(a) for a in big['addresses']])
