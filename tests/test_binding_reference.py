@@ -728,3 +728,71 @@ def test_oracle_equals_the_live_reference_on_other_network_shapes(cfg):
         # the fp32 reference's own round-off is ~1e-3 of a tensor's largest entry there, like for the gumm2 golden)
         err = np.abs(out['grads'][n] - ref).max() / max(np.abs(ref).max(), 1e-6)
         assert err < 3e-3, (n, err)
+
+
+class _AllFamilies(Model):
+    """One controlled variable of every prior family the inference networks have proposal layers for."""
+
+    def __init__(self, categories):
+        super().__init__('all families')
+        self.categories = categories
+
+    def forward(self):
+        from pyprob.distributions import Bernoulli, Categorical, Poisson
+        a = pyprob.sample(Normal(0.0, 1.0))
+        b = pyprob.sample(Uniform(-1.0, 2.0))
+        c = pyprob.sample(Categorical([1.0 / self.categories] * self.categories))
+        d = pyprob.sample(Poisson(3.0))
+        e = pyprob.sample(Bernoulli(0.4))
+        mu = a + b + c.float() + 0.1 * d + e
+        pyprob.observe(Normal(mu, 1.0), name='obs0')
+        pyprob.observe(Normal(mu, 2.0), name='obs1')
+        return mu
+
+
+@pytest.mark.parametrize('network', ['lstm', 'feedforward'])
+def test_parameter_layout_equals_the_reference_modules(network):
+    """NetSpec (names, shapes, order of creation, parameter count - the layout of the flat HBM buffer and of checkpoints)
+    against the modules the reference builds (inference_network_lstm.py:23-80, inference_network_feedforward.py,
+    embedding_feedforward.py, the five proposal layers) for arbitrary hyper-parameters (hypothesis): LSTM width and depth,
+    embedding dims and depths, sample / address / distribution-type embedding dims, mixture components, categories."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from pyprob.nn import Batch, InferenceNetworkFeedForward, InferenceNetworkLSTM
+    from pyprob_amd.spec import NetSpec
+    hip.uninstall()
+
+    @settings(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(st.sampled_from([4, 10, 33]), st.integers(1, 3), st.sampled_from([3, 10]), st.sampled_from([2, 5]),
+           st.sampled_from([(8, 2), (5, 1), (16, 3)]), st.sampled_from([(3, 6, 2), (4, 64, 8)]))
+    def check(lstm_dim, lstm_depth, K, categories, emb, dims):
+        model = _AllFamilies(categories)
+        pyprob.seed(1)
+        gen = model._trace_generator(trace_mode=pyprob.TraceMode.PRIOR_FOR_INFERENCE_NETWORK)
+        traces = [next(gen) for _ in range(4)]
+        obs_emb = {'obs0': {'dim': emb[0], 'depth': emb[1]}, 'obs1': {'dim': 2 * emb[0]}}
+        if network == 'lstm':
+            net = InferenceNetworkLSTM(model=model, observe_embeddings=obs_emb, lstm_dim=lstm_dim, lstm_depth=lstm_depth,
+                                       sample_embedding_dim=dims[0], address_embedding_dim=dims[1],
+                                       distribution_type_embedding_dim=dims[2], proposal_mixture_components=K)
+        else:
+            net = InferenceNetworkFeedForward(model=model, observe_embeddings=obs_emb, proposal_mixture_components=K)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            net._init_layers_observe_embedding(obs_emb, example_trace=traces[0])
+            net._init_layers()
+            net._layers_initialized = True
+            net._polymorph(Batch(traces))
+        ref = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        spec = NetSpec({'obs0': {'dim': emb[0], 'depth': emb[1], 'input_dim': 1}, 'obs1': {'dim': 2 * emb[0], 'input_dim': 1}},
+                       lstm_dim=lstm_dim, sample_embedding_dim=dims[0], address_embedding_dim=dims[1],
+                       distribution_type_embedding_dim=dims[2], proposal_mixture_components=K, network=network,
+                       lstm_depth=lstm_depth)
+        for v in traces[0].variables_controlled:
+            d = v.distribution
+            spec.add_address(v.address, d.name, d.num_categories if d.name == 'Categorical' else None)
+        mine = {k: tuple(shape) for k, (off, shape) in spec.tensors.items()}
+        assert mine == ref, (set(mine) ^ set(ref), [(k, mine[k], ref[k]) for k in mine if k in ref and mine[k] != ref[k]])
+        assert spec.num_parameters() == sum(p.numel() for p in net.parameters())
+    check()
