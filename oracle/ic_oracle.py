@@ -9,7 +9,11 @@ Parity status: PINNED. tests/test_oracle.py checks this file against
   * the known-answer log_probs of the reference's own tests (tests/test_distributions.py:1190,1223,1326,1363,
     1439,1474,1503,2101,2137), and
   * golden vectors produced by running the reference itself (tests/golden/make_golden.py): loss, LSTM
-    input/output, per-row proposal log_prob, every parameter gradient, and importance-sampling log-weights.
+    input/output, per-row proposal log_prob, every parameter gradient, and importance-sampling log-weights
+    (nine recorded programs / network shapes; 10 000 reference particles per program, tests/golden/make_is_10k.py;
+    optimizer trajectories of torch.optim.Adam / SGD and the reference's LARC class, tests/golden/make_optim_golden.py);
+and, where /root/reference exists (the build container), tests/test_binding_reference.py runs the reference next to it on
+freshly initialised networks of other shapes.
 
 Each function cites the reference lines it restates. Arithmetic is float64 by default (the reference is fp32;
 agreement is to fp32 round-off), or float32 with dtype=np.float32.
