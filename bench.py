@@ -110,6 +110,54 @@ def cpu_baseline_torch(lstm_dim, batch, budget_s=10.0):
                        'reference)' % (steps, batch, lstm_dim, torch.__version__, threads, cores))
 
 
+def cpu_baseline_reference(lstm_dim, batch, workload='train'):
+    """The UNMODIFIED reference timed live on this host (tools/cpu_reference_bench.py) - only where a pyprob checkout is
+    importable (the build container; the GPU box has none). Returns None otherwise."""
+    ref = os.environ.get('PYPROB_REFERENCE', '/root/reference')
+    if not os.path.isdir(os.path.join(ref, 'pyprob')):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(REPO, 'tools'))
+        import cpu_reference_bench as R
+        pyprob = R.import_reference()
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        pyprob.seed(123)
+        GUM, GUMM = R.make_models(pyprob)
+        if workload == 'is':
+            model, _ = R.end_to_end(pyprob, GUM, 2 * batch, lstm_dim, batch)
+            post = R.posterior(pyprob, model, 2000)
+            return dict(value=post['particles_per_sec'], unit='particles/s', cores=cores, kind='reference',
+                        sample='%d particles, %s' % (post['particles'], post['definition']), detail=post)
+        cls = GUMM if workload == 'train_gumm' else GUM
+        model, e2e = R.end_to_end(pyprob, cls, 8 * batch, lstm_dim, batch)
+        nn = R.nn_only(pyprob, model, batch, 3, 8)
+        return dict(value=e2e['traces_per_sec'], unit='traces/s', cores=cores, kind='reference',
+                    sample='%d traces end to end through pyprob %s learn_inference_network (online dataset, H=%d, batch %d): %s'
+                           % (e2e['traces'], pyprob.__version__, lstm_dim, batch, e2e['definition']),
+                    nn_only=nn, end_to_end=e2e)
+    except Exception as exc:      # a broken checkout must not take the GPU measurement down with it
+        print('cpu_baseline_reference failed: %r' % (exc,), file=sys.stderr)
+        return None
+
+
+def recorded_reference():
+    """The reference's figures recorded in the build container (profiles/r03_cpu_reference.json, made by
+    tools/cpu_reference_bench.py): carried in the line when the reference itself cannot run on this box."""
+    src = os.path.join('profiles', 'r03_cpu_reference.json')
+    try:
+        with open(os.path.join(REPO, src)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    keep = {k: {a: b for a, b in d[k].items() if a != 'definition'} for k in
+            ('gum_end_to_end', 'gum_nn_only', 'gum_posterior', 'gumm_end_to_end', 'gumm_nn_only', 'gumm_posterior') if k in d}
+    keep.update(source=src, host_cores=d.get('host_cores'), cpu_model=d.get('cpu_model'), torch_threads=d.get('torch_threads'),
+                note='unmodified pyprob v1.5.0 on the build container (no GPU box has the reference); the 10x target of '
+                     'BASELINE.json is against gum_end_to_end')
+    return keep
+
+
 def cpu_baseline_gumm(lstm_dim, batch, budget_s=10.0):
     """Oracle port of one ragged (GaussianUnknownMeanMarsaglia) training step."""
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -182,6 +230,20 @@ def _emit_line(fd, text):
     os.write(fd, (text + '\n').encode())
 
 
+def _self_launch(n):
+    """Re-execute this command under torch.distributed.run with one rank per GPU (127.0.0.1 rendezvous on a free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -194,16 +256,20 @@ def main():
     ap.add_argument('--particles', type=int, default=1000000, help='IS particles per job')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a captured HIP graph (1) or launch eagerly (0)')
+    ap.add_argument('--prewarm-s', type=float, default=0.35, help='untimed steady-state pre-warm before the --warmup steps')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one process per GPU ourselves, the way the reference spawns
+        # its own workers (pyprob/model.py:339-406); rank 0 of the children prints the line
+        raise SystemExit(_self_launch(args.gpus))
     json_fd = _claim_stdout()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
-                             % (args.gpus, args.gpus))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with python -m torch.distributed.run '
+                         '--nproc-per-node %d, or without a launcher)' % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     # one process per GPU over RCCL; also taken with a single rank when launched through torch.distributed.run, so that
@@ -263,26 +329,58 @@ def main():
 
             def step(i):
                 eng.train_step(batches[i % len(batches)], lr)
-        # One Python iteration per step by default (two C calls; the GPU is the bottleneck: measured 0.1148 ms per step against
-        # 0.1166 ms when the native loop pp_train_resident enqueues up to 256 steps per C call). PP_BENCH_LOOP=native selects
-        # that loop; data parallel: only with the C-side exchange (the loop issues the all-reduce itself)
-        native_loop = (not args.graph) and os.environ.get('PP_BENCH_LOOP', 'python') == 'native' and \
-            (not use_dist or eng.native_dp)
+        # Two host loops over the same kernels: one Python iteration per step (two C calls) or the native loop
+        # pp_train_resident (up to 256 steps per C call: ~4x less host time per step, the robust choice on a slow or busy
+        # host). The untimed pre-warm measures both in the steady state and the timed region uses the faster one
+        # (PP_BENCH_LOOP=python|native pins it). Data parallel: the native loop needs the C-side exchange.
+        native_ok = (not args.graph) and (not use_dist or eng.native_dp)
+        forced = os.environ.get('PP_BENCH_LOOP', 'auto')
 
-        def run_steps(i0, n):
-            if not native_loop:
+        def run_steps(i0, n, native):
+            if not native:
                 for i in range(i0, i0 + n):
                     step(i)
                 return
             for c0 in range(0, n, 256):
                 m = min(256, n - c0)
                 eng.train_resident([batches[(i0 + c0 + j) % len(batches)] for j in range(m)], [lr] * m)
-        run_steps(0, W)
+
+        def wall(native, n):
+            barrier()
+            t = time.perf_counter()
+            run_steps(0, n, native)
+            barrier()
+            return (time.perf_counter() - t) / n
+
+        # ---- untimed pre-warm: code objects, clocks, host caches; then a probe of both loops (the
+        # driver's 20-step region after 5 warm-up steps used to start a few launches after process start)
+        t_pre = time.perf_counter()
+        run_steps(0, 30, False)
+        prewarm_steps = 30
+        probe = {}
+        n_probe = 200
+        for name, nat in (('python', False), ('native', True)):
+            if (nat and not native_ok) or (forced in ('python', 'native') and forced != name):
+                continue
+            wall(nat, 20)
+            probe[name] = min(wall(nat, n_probe), wall(nat, n_probe))
+            prewarm_steps += 20 + 2 * n_probe
+        if use_dist:      # every rank must take the same loop: decide on the slowest rank's numbers
+            tt = torch.tensor([probe.get('python', 1e9), probe.get('native', 1e9)], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            probe = {k: float(v) for k, v in zip(('python', 'native'), tt.tolist()) if v < 1e8}
+        native_loop = min(probe, key=probe.get) == 'native'
+        while time.perf_counter() - t_pre < args.prewarm_s:
+            run_steps(0, 100, native_loop)
+            prewarm_steps += 100
+            if use_dist:
+                break         # (ranks would disagree on the count; the probes above already ran > 0.1 s)
+        run_steps(0, W, native_loop)
         if not args.graph:
             lib.pp_prof_arm(1, K)      # kernel class 1: the grouped weight-gradient launch, the longest kernel of the step
         barrier()
         t0 = time.perf_counter()
-        run_steps(W, K)
+        run_steps(W, K, native_loop)
         barrier()
         dt = time.perf_counter() - t0
 
@@ -305,6 +403,16 @@ def main():
             return collect(which, n)
 
         dominant = eager_pass(1, min(K, 50)) if args.graph else collect(1, K)
+        # per-step times (event pairs between consecutive steps of one more untimed pass): the median next to the mean
+        n_med = min(max(K, 20), 200)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_med + 1)]
+        evs[0].record()
+        for i in range(n_med):
+            step(i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_med))
+        out['ms_per_step_median'] = round(per_step[n_med // 2], 4)
         second = eager_pass(0, min(K, 50))
         gather = eager_pass(2, min(K, 50))
         adam = eager_pass(3, min(K, 50))
@@ -316,6 +424,13 @@ def main():
             with open(os.path.join(REPO, pmc_file)) as f:
                 pmc = json.load(f)['kernels'] if (B == 1024 and args.lstm_dim == 512) else {}
         except (OSError, KeyError, ValueError):
+            pass
+
+        rocprof_avgs = {}    # per-kernel averages of the committed `rocprofv3 --kernel-trace --stats` run of this command
+        try:
+            with open(os.path.join(REPO, 'profiles', 'r03_kernel_avgs.json')) as f:
+                rocprof_avgs = json.load(f) if (B == 1024 and args.lstm_dim == 512) else {}
+        except (OSError, ValueError):
             pass
 
         def roof(sample, key, label, bound='mfma', algorithmic=None):
@@ -336,9 +451,14 @@ def main():
                      algorithmic_bytes=pmc.get(key, {}).get('algorithmic_bytes_per_launch') if bound == 'mfma' else work,
                      kernel=label, avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=n)
             d['flops_per_launch' if bound == 'mfma' else 'bytes_per_launch'] = work
-            if algorithmic is not None:
+            if algorithmic is not None and bound == 'mfma':
                 d['executed_flops_per_launch'] = executed
                 d['frac_executed'] = round(executed / (avg_ms * 1e-3) / 1e12 / peak, 4)
+            d['timing'] = 'HIP event pair around the launch on its stream (adds 4-12 us to a ~10 us kernel: frac is a lower bound)'
+            ravg = rocprof_avgs.get(key)
+            if ravg:
+                d['rocprof_avg_us'] = ravg
+                d['frac_rocprof'] = round(work / (ravg * 1e-6) / (1e12 if bound == 'mfma' else 1e9) / peak, 4)
             d['traffic_source'] = (pmc_file + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)') \
                 if d['traffic'] is not None else None
             return d
@@ -362,11 +482,27 @@ def main():
                                                         % (B, 4 * H, I), algorithmic=2.0 * B * I * 4 * H)
             hbm = []
             if gather:
-                hbm.append(roof(gather, 'obs_embed_fwd', 'obs_embed_fwd_kernel (observe embedding + fused address-dispatch '
-                                'gather of the LSTM input rows; latency-bound: %d traces x ~3 KB)' % B, bound='hbm'))
+                d = roof(gather, 'obs_embed_fwd', 'obs_embed_fwd_kernel (observe embedding + fused address-dispatch '
+                         'gather of the LSTM input rows)', bound='hbm')
+                d['bound'] = 'latency'      # %d traces x ~3 KB cannot load the memory system: priced against HBM for the record only
+                hbm.append(d)
             if adam:
-                hbm.append(roof(adam, 'adam', 'adam_kernel (one pass over params, grads, both moments; clears the gradients)',
-                                bound='hbm'))
+                # bytes the pass really moves: a tensor that never received a non-zero gradient (W_hh of a single-statement
+                # program: 63 % of the parameters) has zero moments and its chunks are no-ops that only read the gradient
+                # (4 B per parameter); a stepped chunk reads params, grads, both moments and writes params, both moments and
+                # the cleared gradient (32 B); tensors without a gradient this step are not touched. (The C side reports
+                # 32 B x all padded parameters.) 46 MB of flat buffers sit inside the 256 MB Infinity Cache: this is a
+                # cache-resident rate, not an HBM one.
+                seen = eng.arrived.view(-1, L.PP_ADAM_SCRATCH)[:, L.PP_ADAM_SEEN].cpu().numpy() != 0
+                act = eng.active.cpu().numpy() > 0
+                ct = eng.spec.chunk_tensor_map()
+                per_tensor = np.bincount(ct, minlength=eng.spec.n_tensors).astype(np.float64) * 1024
+                adam_bytes = float((per_tensor * (act & seen)).sum() * 32 + (per_tensor * (act & ~seen)).sum() * 4)
+                d = roof(adam, 'adam', 'adam_kernel (one pass over the stepped chunks of params, grads, both moments; clears the '
+                         'gradients; chunks of never-touched tensors only read their zero gradient)', bound='hbm',
+                         algorithmic=adam_bytes)
+                d['note'] = 'buffers are Infinity-Cache resident (46 MB); bytes = 32 B x stepped parameters + 4 B x idle ones'
+                hbm.append(d)
             out['roofline']['hbm_kernels'] = hbm
             # training FLOPs per GUM trace = 3 x (18 496 + 2 I 4H + 2 (H hid + hid 3K) + 8)
             hid = int((H + 30) / 2)
@@ -384,6 +520,8 @@ def main():
                       launch='hip_graph_replay' if args.graph else
                       ('native loop: up to 256 steps per C call (pp_train_resident), eager launches' if native_loop else
                        'one Python iteration per step (ICEngine.train_step), eager launches'),
+                      prewarm_steps=prewarm_steps, prewarm_s=args.prewarm_s,
+                      loop_probe_us_per_step={k: round(v * 1e6, 2) for k, v in probe.items()},
                       allreduce_bytes_per_step=(4 * (eng.grads_full.numel() - sum(c for _, c in eng.dp_skip)) if use_dist else 0),
                       dp_exchange=dp_exchange)
     elif args.workload == 'train_gumm':
@@ -496,13 +634,20 @@ def main():
                     dtype='f32', data='synthetic', config=config)
         line.update(out)
         if world == 1 and not args.no_cpu_baseline:
-            if args.workload == 'train':
-                line['cpu_baseline'] = cpu_baseline_train(args.lstm_dim, args.batch)
-                line['cpu_baseline_torch'] = cpu_baseline_torch(args.lstm_dim, args.batch)
+            # the live reference where it can be imported (kind "reference"); on the GPU box the torch port of the step
+            # (the stronger of the two ports) with the reference's recorded figures next to it
+            live = cpu_baseline_reference(args.lstm_dim, args.batch, args.workload)
+            if live is not None:
+                line['cpu_baseline'] = live
+            elif args.workload == 'train':
+                line['cpu_baseline'] = cpu_baseline_torch(args.lstm_dim, args.batch)
+                line['cpu_baseline_numpy'] = cpu_baseline_train(args.lstm_dim, args.batch, budget_s=6.0)
             elif args.workload == 'train_gumm':
                 line['cpu_baseline'] = cpu_baseline_gumm(args.lstm_dim, args.batch)
             else:
                 line['cpu_baseline'] = cpu_baseline_is()
+            if live is None:
+                line['cpu_baseline_reference_recorded'] = recorded_reference()
         _emit_line(json_fd, json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

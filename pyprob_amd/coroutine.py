@@ -80,6 +80,10 @@ class _Params:
             raise RuntimeError('Distribution currently unsupported: {}'.format(name))
 
 
+def _is_scalar(v):
+    return not hasattr(v, 'numel') or v.numel() == 1
+
+
 class ParticleScheduler:
     """N particle greenlets over one ISRunner: particles park with a request (address id, previous address id, prior
     distribution); when all live particles are parked the scheduler serves the requests in groups of equal (address,
@@ -102,12 +106,15 @@ class ParticleScheduler:
         self.statements = 0
         self.seconds = 0.0
 
-    def resolve(self, address, prev_address):
+    def resolve(self, address, prev_address, min_train_iterations=None):
         """(address id, previous address id) of a statement, or None when the network has no layers for the address or
-        for the previous one (the prior is then the proposal, inference_network_lstm.py:100-104, 132-134)."""
+        for the previous one (the prior is then the proposal, inference_network_lstm.py:100-104, 132-134) - or when the
+        address's proposal layer has trained for fewer than `min_train_iterations` iterations (:108-112)."""
         spec = self.spec
         a = spec.address_id.get(address)
         if a is None:
+            return None
+        if min_train_iterations is not None and spec.addresses[a].total_train_iterations < min_train_iterations:
             return None
         if spec.feedforward or prev_address is None:      # inference_network_feedforward.py:52-66: no previous variable
             return a, None
@@ -154,6 +161,10 @@ class ParticleScheduler:
     def _begin(self):
         self.runner.begin(self.n, offset=self.offset)
         self.runner.state_rows = self.n            # (per-particle rows from the start: groups gather / scatter them)
+        # h0 = c0 = 0 per trace (inference_network_lstm.py:89-91), also for a particle whose FIRST controlled sample fell
+        # back to the prior (unknown address) and is first served at a later statement with a known previous address
+        self.runner.h.zero_()
+        self.runner.c.zero_()
 
     def _between_rounds(self):
         pass
@@ -217,7 +228,8 @@ class CoroutineIS(ParticleScheduler):
         from .trace import Variable
         state = self.state
         prev = state._current_trace_previous_variable
-        ids = self.resolve(addr, None if prev is None else prev.address)
+        ids = self.resolve(addr, None if prev is None else prev.address,
+                           getattr(state, '_current_trace_inference_network_proposal_min_train_iterations', None))
         if ids is None:
             # no proposal layers for this address (or the previous one): the prior is the proposal and
             # log p - log q = 0 (inference_network_lstm.py:100-104, 132-134); the LSTM state is not advanced
@@ -283,12 +295,12 @@ class CoroutineIS(ParticleScheduler):
         runner = self.runner
         by_family = {}
         for pid, d, v in self.likelihoods:
-            by_family.setdefault(d.name, []).append((pid, d, v))
+            by_family.setdefault(d.name if _is_scalar(v) else '__host__', []).append((pid, d, v))
         self.likelihoods = []
         for name, items in by_family.items():
             dists = [d for _, d, _ in items]
-            try:
-                term = runner.dist_term(_Params(name, dists))
+            try:      # vector-valued observations (state.py:147-149 sums log_prob over the event) are scored on the host
+                term = None if name == '__host__' else runner.dist_term(_Params(name, dists))
             except RuntimeError:
                 term = None
             rows = torch.tensor([pid for pid, _, _ in items], dtype=torch.int64, device=self.dev)
@@ -328,13 +340,17 @@ class _WorkerScheduler(CoroutineIS):
     def _likelihood_payload(self):
         by_family = {}
         for pid, d, v in self.likelihoods:
-            by_family.setdefault(d.name, []).append((pid, d, v))
+            by_family.setdefault(d.name if _is_scalar(v) else '__host__', []).append((pid, d, v))
         self.likelihoods = []
         out = []
         for name, items in by_family.items():
+            pids = np.array([self.lo + pid for pid, _, _ in items], np.int64)
+            if name == '__host__':      # vector-valued observations: log p summed over the event here, added by the parent
+                lp = np.array([float(d.log_prob(v, sum=True)) for _, d, v in items], np.float32)
+                out.append((name, {}, lp, pids))
+                continue
             cols = _Params(name, [d for _, d, _ in items]).columns()
-            out.append((name, cols, np.array([float(v) for _, _, v in items], np.float32),
-                        np.array([self.lo + pid for pid, _, _ in items], np.int64)))
+            out.append((name, cols, np.array([float(v) for _, _, v in items], np.float32), pids))
         return out
 
     def _between_rounds(self):
@@ -419,6 +435,52 @@ def _worker_main(conn, worker, lo, hi, state, forward, spec, map_func, seed, arg
         os._exit(0)       # no destructors of the parent's device state in the child
 
 
+# ---- what a posterior call sets in the trace runtime --------------------------------------------------------------------
+# state._init_traces (pyprob/state.py:296-336) writes module globals: the observed values, the trace mode, the inference
+# engine, likelihood_importance ... A worker forked for an EARLIER call holds the values of THAT call, so every job carries
+# a snapshot of them (and of the model's plain hyper-parameter attributes) and the worker installs it before it runs the
+# shard: a second posterior_results(observe=other) must score the new y in observe() and in observed samples.
+_RUNTIME_GLOBALS = ('_trace_mode', '_inference_engine', '_prior_inflation', '_likelihood_importance',
+                    '_current_trace_root_function_name', '_current_trace_observed_variables', '_address_dictionary',
+                    '_current_trace_inference_network_proposal_min_train_iterations', '_lock_step')
+
+
+def _plain_value(v):
+    if v is None or isinstance(v, (bool, int, float, str, np.generic)):
+        return True
+    if isinstance(v, torch.Tensor):
+        return v.numel() <= 64 and not v.is_cuda
+    if isinstance(v, np.ndarray):
+        return v.size <= 64
+    return False
+
+
+def _runtime_snapshot(state, forward):
+    snap = {k: getattr(state, k) for k in _RUNTIME_GLOBALS if hasattr(state, k)}
+    obs = snap.get('_current_trace_observed_variables')
+    if isinstance(obs, dict):      # device tensors do not cross a pipe; the workers score on the host
+        snap['_current_trace_observed_variables'] = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v)
+                                                     for k, v in obs.items()}
+    model = getattr(forward, '__self__', None)
+    attrs = {}
+    if model is not None and hasattr(model, '__dict__'):
+        attrs = {k: v for k, v in vars(model).items() if not k.startswith('_') and _plain_value(v)}
+    return snap, attrs
+
+
+def _runtime_install(state, forward, snapshot):
+    snap, attrs = snapshot
+    for k, v in snap.items():
+        setattr(state, k, v)
+    model = getattr(forward, '__self__', None)
+    if model is not None:
+        for k, v in attrs.items():
+            try:
+                setattr(model, k, v)
+            except AttributeError:
+                pass
+
+
 # ---- persistent workers ------------------------------------------------------------------------------------------------
 # Forking a worker copies the page tables of a process that holds a HIP context: 16 workers cost ~1 s, 64 workers 2.5 s
 # per posterior call (tools/gumm_is_bench.py) - more than the particles themselves. The pool forks the workers of a
@@ -444,7 +506,8 @@ def _pool_worker_main(conn, worker, state, forward, inherited):
             if job is None:
                 break
             lo, hi, spec, seed, blob = job
-            map_func, args, kwargs = pickle.loads(blob)
+            map_func, args, kwargs, runtime = pickle.loads(blob)
+            _runtime_install(state, forward, runtime)       # this call's observe / trace mode / engine, not the fork's
             _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs)
     finally:
         os._exit(0)
@@ -455,6 +518,12 @@ class _WorkerPool:
         import multiprocessing as mp
         ctx = mp.get_context('fork')          # the model is an arbitrary user object: inherited, not pickled
         self.state, self.forward, self.workers = state, forward, workers
+        import weakref
+        model = getattr(forward, '__self__', None)
+        try:      # id() of a freed model can be re-used by a new one: the pool is valid for THIS object only
+            self.model_ref = weakref.ref(model) if model is not None else None
+        except TypeError:
+            self.model_ref = None
         self.conns, self.procs = [], []
         for w in range(workers):
             parent, child = ctx.Pipe()
@@ -466,6 +535,12 @@ class _WorkerPool:
 
     def healthy(self):
         return all(pr.is_alive() for pr in self.procs)
+
+    def owns(self, forward):
+        model = getattr(forward, '__self__', None)
+        if self.model_ref is None:
+            return model is None or not hasattr(model, '__weakref__')
+        return self.model_ref() is model
 
     def close(self, kill=False):
         for c in self.conns:
@@ -495,8 +570,8 @@ def _get_pool(state, forward, workers):
         return None
     key = _pool_key(state, forward, workers)
     pool = _POOLS.get(key)
-    if pool is not None and not pool.healthy():
-        pool.close(kill=True)
+    if pool is not None and not (pool.healthy() and pool.owns(forward)):
+        pool.close(kill=True)      # dead workers, or workers forked from another (freed) model at the same address
         pool = None
     if pool is None:
         if not _POOLS:
@@ -532,6 +607,8 @@ class ShardedCoroutineIS:
         runner = self.runner
         runner.begin(self.n, offset=self.offset)
         runner.state_rows = self.n
+        runner.h.zero_()       # (see ParticleScheduler._begin)
+        runner.c.zero_()
         lw = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
         last_value = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
         conns, procs, bounds = [], [], []
@@ -539,11 +616,12 @@ class ShardedCoroutineIS:
         pool, blob = None, None
         try:      # persistent workers need the per-call arguments as bytes
             import pickle
+            runtime = _runtime_snapshot(self.state, self.forward)
             try:
-                blob = pickle.dumps((self.map_func, args, kwargs))
+                blob = pickle.dumps((self.map_func, args, kwargs, runtime))
             except Exception:  # noqa: BLE001 - e.g. a lambda as map_func
                 import cloudpickle
-                blob = cloudpickle.dumps((self.map_func, args, kwargs))
+                blob = cloudpickle.dumps((self.map_func, args, kwargs, runtime))
             pool = _get_pool(self.state, self.forward, self.workers)
         except Exception:  # noqa: BLE001 - not picklable at all: fork per call (arguments inherited)
             pool = None
@@ -585,7 +663,7 @@ class ShardedCoroutineIS:
                     cols = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0]}
                     x = torch.from_numpy(np.concatenate([p[1] for p in parts])).to(self.dev)
                     rows = torch.from_numpy(np.concatenate([p[2] for p in parts])).to(self.dev)
-                    lp = runner.log_prob(runner.dist_term(_Params.from_columns(name, cols)), x)
+                    lp = x if name == '__host__' else runner.log_prob(runner.dist_term(_Params.from_columns(name, cols)), x)
                     lw.index_add_(0, rows, lp, alpha=self.scale)
                 # parked statements of all workers, merged by (address, previous address)
                 merged = {}

@@ -275,44 +275,6 @@ static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st, const st
     return 0;
 }
 
-// ---- side stream: the weight-gradient products are LEAVES of the backward pass ---------------------------------------
-// They read what the data-gradient chain produced (dG, dZ1, DY and the saved activations) and write gradient tensors
-// nothing else in the step touches, so they run on a second HIP stream next to the chain dH -> cell backward -> dX ->
-// observe-embedding backward -> column sums instead of after it: fork after the head tails (head weight gradients),
-// fork again when dG is complete (LSTM weight gradients), join before pp_ic_loss returns. The stream and its events
-// are created once per host thread (no device memory involved). Opt-in (PP_SIDE_STREAM=1), see side_stream().
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork0 = nullptr, fork1 = nullptr, join = nullptr;
-    int state = 0;   // 0: not tried, 1: ready, -1: unavailable
-};
-static SideStream* side_stream() {
-    static thread_local SideStream ss;
-    // Measured on MI355X (profiles/r02_b_*): the two forks and the join cost more than the overlap hides (GUM step, B = 1024,
-    // H = 512: 0.157 ms on one stream, 0.166 ms with the side stream; the kernels of both streams slow each other down
-    // and a cross-queue event wait is ~5 us) - off unless PP_SIDE_STREAM=1.
-    static const int enabled = getenv("PP_SIDE_STREAM") ? atoi(getenv("PP_SIDE_STREAM")) : 0;
-    if (!enabled) return nullptr;
-    if (ss.state == 0) {
-        ss.state = -1;
-        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.fork0, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.fork1, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
-            ss.state = 1;
-        else
-            (void)hipGetLastError();
-    }
-    return ss.state == 1 ? &ss : nullptr;
-}
-static int fork_to(hipStream_t main, hipEvent_t ev, hipStream_t side) {
-    if (hipEventRecord(ev, main) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
-        set_error("pp_ic_loss: side-stream fork failed: %s", hipGetErrorString(hipGetLastError()));
-        return PP_EHIP;
-    }
-    return 0;
-}
-
 static void queue_wgrad(std::vector<pp_gemm_args>& q, const float* dz, int64_t lddz, const float* x, int64_t ldx,
                         const int32_t* x_idx, float* dW, int n, int in, int out, std::vector<GemmHole>* holes = nullptr,
                         GemmHole hole = GemmHole{}) {
@@ -654,12 +616,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // (the bias / table column sums queued in `cs` are launched once, at the end of the backward pass)
 
     // ---------------- backward ----------------
-    // Weight-gradient leaves: queued and flushed as grouped launches - on the side stream as soon as their inputs are
-    // complete (heads after the tails, LSTM after the cell backward), or all at once at the end on the caller's stream.
-    SideStream* ss = (compact && T == 1) ? nullptr : side_stream();
+    // Weight-gradient leaves: queued and flushed as ONE grouped launch at the end of the backward pass.
+    // (a second stream for these leaves with fork / join events was measured twice and lost both times - 0.157 -> 0.166 ms
+    // on config 2, 183 vs 170 us with two grouped launches: a cross-queue event wait costs ~5 us - and is gone)
     std::vector<pp_gemm_args> wq;
     std::vector<GemmHole> wholes;
-    bool forked = false;
     auto flush_wgrads = [&](hipStream_t stream, bool timed, const AuxJobs* aux = nullptr) -> int {
         wholes.resize(wq.size(), GemmHole{});
         PP_TRY(launch_wgrads(wq, stream, &wholes, timed, aux));
@@ -673,14 +634,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     static const int fuse_cell_bwd = env_flag("PP_FUSE_CELL_BWD", 1);
     const bool fused_bwd = compact && T == 1 && L == 1 && fuse_cell_bwd;
     int dx_splits = 1;
-    auto join_side = [&]() -> int {   // the caller's stream continues only after the side stream's products
-        if (!forked) return 0;
-        if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) {
-            set_error("pp_ic_loss: side-stream join failed: %s", hipGetErrorString(hipGetLastError()));
-            return PP_EHIP;
-        }
-        return 0;
-    };
     std::vector<pp_gemm_args> dq;   // per-address data gradients into dH
     for (int a = 0; a < net->n_addr; ++a) {
         const int g0 = bt->grp_off[a], n = bt->grp_off[a + 1] - g0;
@@ -707,11 +660,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             if (fused_bwd) g.colsum = w.gsum + (int64_t)a * 2 * 4 * H;   // group sums of dG (current-address slot)
             dq.push_back(g);
         }
-    }
-    if (ss) {   // the heads' weight gradients need nothing but the tails' outputs: start them next to dH / the cell backward
-        PP_TRY(fork_to(st, ss->fork0, ss->s));
-        forked = true;
-        PP_TRY(flush_wgrads(ss->s, ff));
     }
     if (fused_bwd) {
         GemmExt x{};
@@ -806,11 +754,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     }
     // LSTM parameter gradients are queued; layer 0's data gradient follows
     if (!ff) {
-    if (ss) {   // dG is complete: the LSTM weight gradients run next to dX and the observe-embedding backward
-        PP_TRY(fork_to(st, ss->fork1, ss->s));
-        PP_TRY(flush_wgrads(ss->s, true));
-    }
-    // (without a side stream wq is flushed at the very end, together with the observe-embedding weight gradients)
+    // (wq is flushed at the very end, together with the observe-embedding weight gradients)
     // dX = dG W_ih, then scatter into the embedding tables / sample embeddings / observe embedding. Nobody reads the
     // previous-variable columns of first-time-step rows (no previous variable, no parameter behind them).
     // The forget-gate part of the summation over the gates is zero for those rows.
@@ -874,7 +818,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // grouped weight-gradient launch; for a single-statement batch so do the column sums themselves (nothing in the
     // launch depends on anything else in it), which removes the separate column-sum launch.
     auto reduce_and_flush = [&]() -> int {
-        if (!compact && ff && !det && !ss) {
+        if (!compact && ff && !det) {
             // FeedForward network: no column sum depends on another launch's group sums, so they all ride behind the
             // weight-gradient tiles (and the loss is finalised there): one launch less per step
             static const int ff_ride = env_flag("PP_AUX_COLSUM", 1);
@@ -894,7 +838,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
             else
                 PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
-            return flush_wgrads(st, !ss);
+            return flush_wgrads(st, true);
         }
         AuxJobs aux{};
         static const int cs_ride_env = env_flag("PP_AUX_COLSUM", 1);
@@ -945,12 +889,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             ci += in;
             co += out;
         }
-        PP_TRY(reduce_and_flush());
-        return join_side();
+        return reduce_and_flush();
     }
     PP_TRY(obs_grad(dXs, ldxs, bt->row_off_dev, T, B, net->e_obs, w.E, w.e4, w.dE, w.e4, st));   // dE, ReLU mask applied
     PP_TRY(reduce_and_flush());
-    PP_TRY(join_side());
     const int e = net->e_obs;
     PP_TRY(linear_wgrad(w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, grads + net->fin_b1, nullptr, B, e, e, st));
     PP_TRY(linear_dgrad(w.dE, w.e4, P + net->fin_w1, w.dF1, w.e4, nullptr, w.f1, w.e4, B, e, e, false, st,

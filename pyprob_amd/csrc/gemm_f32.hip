@@ -919,7 +919,7 @@ struct GroupedParams {
     int count;
     int xcd_aware;
     GemmExt ext;                // shared by the problems of the launch (cell backward in the dH epilogue)
-    int warm;                   // touch the argument lines with one vector load first (PP_WARM_KERNARGS, default 1)
+    int warm;                   // touch the argument lines with one vector load first
     long long* trace;           // debug (pp_debug_wgtrace): per workgroup {start, end} wall-clock ticks (10 ns), problem, split
 };
 long long* g_wgtrace = nullptr;   // device buffer [8 x workgroups] or nullptr
@@ -1653,8 +1653,7 @@ static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int t
     GroupedParams g;
     g.ext = GemmExt{};
     g.trace = nullptr;
-    static const int warm = getenv("PP_WARM_KERNARGS") ? atoi(getenv("PP_WARM_KERNARGS")) : 1;
-    g.warm = warm;
+    g.warm = 1;
     g.xcd_aware = xcd;
     g.count = 1;
     g.p[0] = p;
@@ -1688,11 +1687,9 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
                                           (ext->cell_c || ext->lean) && ext->cell_h),
                      "pp_gemm_f32: bad fused-cell arguments");
         const int gx = cdiv(a->N, 64), gy = cdiv(a->M, 64);
-        static const int tpw_env = getenv("PP_LSTM_TILES_PER_WG") ? atoi(getenv("PP_LSTM_TILES_PER_WG")) : 0;
-        // (measured on the ragged step, 1 344 tiles: 1, 2 or 4 tiles per workgroup give the same 28 us - the tile, not the
-        // workgroup start, is what costs; the knob stays for experiments)
-        int tpw = tpw_env > 0 ? tpw_env : 1;
-        tpw = std::max(1, std::min(tpw, gx));
+        // (measured on the ragged step, 1 344 tiles: 1, 2 or 4 column tiles per workgroup give the same 28 us - the tile,
+        // not the workgroup start, is what costs)
+        int tpw = 1;
         dim3 grid(cdiv(gx, tpw), gy, 1);
         return launch_dyn(gemm_f32_async_lstm_kernel, grid, 256, as_lds_bytes(), st, &p, ext, &tpw, &gx);
     }
@@ -1773,8 +1770,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         GroupedParams g;
         g.ext = ext ? *ext : GemmExt{};
         g.trace = nullptr;
-        static const int warm = getenv("PP_WARM_KERNARGS") ? atoi(getenv("PP_WARM_KERNARGS")) : 1;
-        g.warm = warm;
+        g.warm = 1;
         static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
         g.xcd_aware = xcd;
         g.count = 0;

@@ -376,7 +376,6 @@ static bool obs_fused_args(const pp_net* net, float* const* obs_h, ObsFusedArgs&
 }
 
 static int pick_traces_per_wave(int n, int target_blocks) {
-    if (const char* e = getenv("PP_OBS_TPW")) return std::max(atoi(e), 1);   // tuning knob
     return std::max((n + 4 * target_blocks - 1) / (4 * target_blocks), 1);
 }
 

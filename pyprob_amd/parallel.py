@@ -59,6 +59,9 @@ def _coalescing_works(device):
     return _COALESCE[key]
 
 
+_native_poisoned = [False]      # a native communicator init failed / timed out in this process: never retried
+
+
 def init_native_comm(device, lib=None):
     """This library's own RCCL communicator over the ranks of the default torch.distributed group (csrc/dp.hip): rank 0
     creates the ncclUniqueId, a broadcast hands it to every rank, all ranks call ncclCommInitRank on their device; the
@@ -71,7 +74,14 @@ def init_native_comm(device, lib=None):
     from . import lib as L
     lib = lib or L.load()
     world, rank = dist.get_world_size(), dist.get_rank()
-    if lib.pp_dp_world() == world:
+    # the early outs are agreed on by ALL ranks (a rank whose earlier init timed out must not return alone while its peers
+    # enter the collective init below): poisoned anywhere -> nobody retries; up everywhere -> everybody reuses
+    st = torch.tensor([0 if _native_poisoned[0] else 1, 1 if lib.pp_dp_world() == world else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(st, op=dist.ReduceOp.MIN)
+    healthy, up = (int(v) for v in st.tolist())
+    if not healthy:
+        return False
+    if up:
         return True
     path = os.environ.get('PP_RCCL_PATH') or os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
     ident = torch.zeros(128, dtype=torch.uint8)
@@ -103,8 +113,10 @@ def init_native_comm(device, lib=None):
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
-        if not th.is_alive():
-            lib.pp_dp_destroy()
+        # Some rank failed or timed out. Its init thread may still be inside ncclCommInitRank and could install a
+        # communicator later; peers must not destroy theirs while it may still be in the collective. The library's native
+        # exchange is never tried again in this process (ICEngine.native_dp stays False: torch.distributed exchanges).
+        _native_poisoned[0] = True
         return False
     return True
 

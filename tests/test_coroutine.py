@@ -157,6 +157,56 @@ def test_persistent_workers_are_reused_and_give_the_same_particles(monkeypatch):
     assert not CO._POOLS
 
 
+def test_pooled_workers_score_the_observations_of_the_current_call(monkeypatch):
+    """Persistent workers were forked during an EARLIER posterior call: the observed values, trace mode, engine and
+    likelihood_importance of the current call travel with every job (coroutine._runtime_snapshot). A pooled call with
+    obs2 after a pooled call with obs1 must equal a fresh-fork call with obs2 - and every trace re-scores with obs2."""
+    from pyprob_amd import coroutine as CO
+    case, program, obs1, sigma = CASES[1]
+    obs2 = {'obs0': 2.5, 'obs1': -1.0}
+    net, meta, params, isr = network_from_golden(case)
+    model = program()
+    model._inference_network = net
+    CO.close_worker_pools()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model._traces_coroutines(30, obs1, seed=3, num_workers=2)
+        pids = [pr.pid for pool in CO._POOLS.values() for pr in pool.procs]
+        pooled = model._traces_coroutines(30, obs2, map_func=_identity, seed=4, num_workers=2)
+        assert [pr.pid for pool in CO._POOLS.values() for pr in pool.procs] == pids       # same processes
+        monkeypatch.setenv('PP_IS_POOL', '0')
+        fresh = model._traces_coroutines(30, obs2, map_func=_identity, seed=4, num_workers=2)
+    lw_pooled, lw_fresh = np.asarray(pooled.log_weights, np.float64), np.asarray(fresh.log_weights, np.float64)
+    np.testing.assert_allclose(lw_pooled, lw_fresh, rtol=1e-6, atol=1e-6)
+    ref = rescore(case, meta, params, pooled.get_values(), obs2, sigma)
+    np.testing.assert_allclose(lw_pooled, ref, rtol=2e-5, atol=2e-5)
+    monkeypatch.delenv('PP_IS_POOL')
+    # a hyper-parameter of the model changed between two calls reaches the workers too
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model.likelihood_stddev = 0.9
+        pooled = model._traces_coroutines(30, obs2, map_func=_identity, seed=5, num_workers=2)
+    ref = rescore(case, meta, params, pooled.get_values(), obs2, 0.9)
+    np.testing.assert_allclose(np.asarray(pooled.log_weights, np.float64), ref, rtol=2e-5, atol=2e-5)
+    CO.close_worker_pools()
+
+
+def test_a_pool_is_not_reused_for_another_model_object():
+    from pyprob_amd import coroutine as CO
+    case, program, observe, sigma = CASES[1]
+    net, meta, params, isr = network_from_golden(case)
+    model = program()
+    model._inference_network = net
+    CO.close_worker_pools()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model._traces_coroutines(20, observe, seed=1, num_workers=2)
+    (key, pool), = CO._POOLS.items()
+    other = program()
+    assert pool.owns(model.forward) and not pool.owns(other.forward)
+    CO.close_worker_pools()
+
+
 def _identity(trace):
     return trace
 
