@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include "gather.hpp"
 #include "aux_jobs.hpp"
+#include "panel.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -141,6 +142,8 @@ struct Workspace {
     float* lp_rows;            // [R] per-row proposal log_prob (deterministic mode: the loss is reduced from it)
     float* AB;                 // [n_addr][2][4H] per-address bias vectors of the LSTM input (gather.hpp, AddrBias)
     float* gsum;               // [n_addr][2][4H] column sums of dG per address group (current | previous statement)
+    float* WihT;               // [e_obs][4H] k-major copy of W_ih[:, :e_obs] (panel.hpp), rewritten every step
+    float* W1T;                // [H][64 ceil(maxhid / 64)] k-major copy of the present address's first head layer
     bool compact;              // LSTM input rows are [E | s_prev] (i4 = round4(e_obs + smp_dim)), the table columns a bias
     int xc;                    // columns of an LSTM input row: e_obs + smp_dim (compact) or lstm_in
     int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
@@ -230,6 +233,9 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.lp_rows = c.take<float>(deterministic_mode() ? R : 0);
     w.AB = c.take<float>(w.compact ? (int64_t)net->n_addr * 2 * 4 * H : 0);
     w.gsum = c.take<float>(w.compact ? (int64_t)net->n_addr * 2 * 4 * H : 0);
+    const bool panel_shape = w.compact && (H == 512 || H == 1024);
+    w.WihT = c.take<float>(panel_shape ? (int64_t)net->e_obs * 4 * H : 0);
+    w.W1T = c.take<float>(panel_shape ? (int64_t)H * 64 * ((hid + 63) / 64) : 0);
     w.bytes = c.off + 256;
 }
 
@@ -426,6 +432,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         gather_bytes += (double)n_present * (4.0 * 4 * H * (2.0 * ne_x) + 4.0 * 4.0 * 4 * H);
     }
     for (int o = 0; o < net->n_obs; ++o) gather_bytes += 4.0 * B * net->obs_hid[o];
+    // Row-panel kernel (panel.hip): a single-statement batch with ONE address keeps input product + cell, head layer 1, the
+    // head tail, dz1, dH + cell backward and dX in one launch (rows of the one address group are the batch rows in order)
+    bool panel = false;
+    if (lean_cell && n_present == 1 && fused_obs && bt->grp_off[only_addr] == 0 && bt->grp_off[only_addr + 1] == R) {
+        const pp_addr& ad = net->addrs[only_addr];
+        panel = panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && head_tail_supported(ad.kind, ad.hid, ad.n_out) &&
+                w.hid4 <= ((ad.hid + 15) & ~15) && w.out4 <= 64 && (flags & PP_LOSS_KEEP_LP ? lp_out != nullptr : true);
+    }
     prof_begin(2, st);
     if (ff) {
         // every time step's proposal layer reads the observe embedding of its trace (:72,85): Hs rows = E[trace]
@@ -455,7 +469,17 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         rb.X = w.X; rb.ldx = w.i4; rb.xcols = w.xc;
         rb.zero_like = (bwd && !dx_partials) ? w.dX : nullptr;
         rb.zero_small = reinterpret_cast<float*>(w.loss_acc); rb.n_small = n_clear;
-        PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb, compact ? &abias : nullptr));
+        PanelTranspose ptr{};
+        if (panel) {
+            const pp_addr& ad = net->addrs[only_addr];
+            ptr.Wih = P + net->w_ih; ptr.ldw = I; ptr.WihT = w.WihT;
+            ptr.W1 = P + ad.w1; ptr.W1T = w.W1T; ptr.ld1T = 64 * ((ad.hid + 63) / 64);
+            ptr.H = H; ptr.hid = ad.hid; ptr.e = net->e_obs;
+            ptr.tiles_ih = 3 * H / 64;
+            ptr.n_blocks = panel_transpose_blocks(H, ad.hid);
+        }
+        PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb, compact ? &abias : nullptr,
+                                   panel ? &ptr : nullptr));
     } else {
         PP_TRY(observe_embedding_fwd(net, P, bt->obs, bt->obs_width, B, w, st));
         // (also clears the loss slots and, for a backward pass, dX: see the kernel)
@@ -506,8 +530,28 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             }
             GemmHole zc{};
             zc.b[0] = GemmBlock{0, B, 0, 4 * H, net->e_obs, nx};
+            if (panel) {
+                const pp_addr& ad = net->addrs[only_addr];
+                PanelArgs pa{};
+                pa.B = R; pa.H = H; pa.hid = ad.hid; pa.n_out = ad.n_out; pa.K = ad.n_out / 3; pa.e = net->e_obs;
+                pa.ldx = (int)w.i4; pa.lda1 = (int)w.hid4; pa.lddy = (int)w.out4; pa.ldw = I;
+                pa.X = w.X; pa.Wih = P + net->w_ih; pa.AB = w.AB + (int64_t)only_addr * 2 * 4 * H;
+                pa.WihT = w.WihT; pa.W1T = w.W1T;
+                pa.W1 = P + ad.w1; pa.b1 = P + ad.b1; pa.W2 = P + ad.w2; pa.b2 = P + ad.b2;
+                pa.value = bt->value; pa.prior = bt->prior;
+                pa.Hs = w.Hl[0]; pa.G = w.Gl[0]; pa.A1 = w.A1; pa.DY = w.DY; pa.dZ1 = w.dZ1; pa.dX = w.dX;
+                pa.gsum = w.gsum + (int64_t)only_addr * 2 * 4 * H;
+                pa.lp_out = (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr;
+                pa.loss_acc = w.loss_acc; pa.flag = w.flag; pa.grad_scale = -1.0f / (float)B;
+                pa.dbg = g_timeline;
+                PP_TRY(panel_t1(ad.kind, pa, st));
+                cell_done = true;
+                // executed data-path FLOPs of the launch: forward + backward products of the 8-row panels
+                prof_end(0, 2.0 * R * (2.0 * 3.0 * H * net->e_obs + 2.0 * (double)H * ad.hid + 2.0 * (double)ad.hid * ad.n_out), st);
+            } else {
             PP_TRY(gemm_f32(&g, st, &zc, &x));
             prof_end(0, 2.0 * R * (double)nx * 4.0 * H, st);
+            }
         } else {
         PP_TRY(linear_fwd(in, in_ld, nullptr, P + lw_ih(l), P + lb_ih(l), w.Gl[l], 4 * H, R, in_w, 4 * H, false, P + lb_hh(l), st,
                           &zero));
@@ -572,7 +616,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             g.bias = P + ad.b1; g.relu = 1;
             hq.push_back(g);
         }
-        PP_TRY(gemm_f32_grouped(hq.data(), (int)hq.size(), st));
+        if (!panel) PP_TRY(gemm_f32_grouped(hq.data(), (int)hq.size(), st));
     }
     std::vector<char> done(net->n_addr, 0);
     for (int a = 0; a < net->n_addr; ++a) {
@@ -594,8 +638,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                     cs.push_back(ColsumJob{w.dZ1 + (int64_t)h0 * w.hid4, w.hid4, nullptr, m, bd.hid, grads + bd.b1, nullptr});
                 }
             }
-            PP_TRY(head_tail_multi(ad.kind, tj.data(), (int)tj.size(), w.hid4, ad.hid, ad.n_out, bt->value, bt->prior, gscale,
-                                   lp_rows, w.out4, w.hid4, loss_slots, w.flag, st));
+            if (!panel)
+                PP_TRY(head_tail_multi(ad.kind, tj.data(), (int)tj.size(), w.hid4, ad.hid, ad.n_out, bt->value, bt->prior, gscale,
+                                       lp_rows, w.out4, w.hid4, loss_slots, w.flag, st));
             continue;
         }
         done[a] = 1;
@@ -661,7 +706,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             dq.push_back(g);
         }
     }
-    if (fused_bwd) {
+    if (panel) {
+        // (dG, the group sums and dX came out of the panel launch)
+    } else if (fused_bwd) {
         GemmExt x{};
         x.bw_G = w.Gl[0]; x.bw_C = w.Cl[0]; x.bw_H = H; x.lean = lean_cell ? 1 : 0;
         PP_TRY(gemm_f32_grouped(dq.data(), (int)dq.size(), st, nullptr, &x));
@@ -767,7 +814,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         g.B = P + net->w_ih; g.ldb = I; g.b_kmajor = 1;
         g.C = w.dX; g.ldc = w.i4;
         g.M = R; g.N = nx; g.K = 4 * H;
-        if (dx_partials) {
+        if (panel) {
+            dx_splits = 1;      // complete rows, written by the panel launch
+        } else if (dx_partials) {
             // ~3 slabs per split (the K loop is short either way; more splits = more workgroups streaming dG)
             const int nslab = 4 * H / 32;
             dx_splits = std::max(1, std::min(DX_SPLITS, nslab / 4));

@@ -159,8 +159,9 @@ int lstm_input_gather(const pp_net* net, const float* params, const float* E, in
                       const float* value, const int32_t* addr, const int32_t* prev_row, int32_t fixed_addr,
                       int32_t fixed_prev_addr, int n_rows, float* X, int64_t ldx, hipStream_t st, float* zero_like = nullptr,
                       float* zero_small = nullptr, int n_small = 0, int xcols = 0, const AddrBias* bias = nullptr);
+struct PanelTranspose;   // panel.hpp
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
                         float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows = nullptr,
-                        const AddrBias* bias = nullptr);
+                        const AddrBias* bias = nullptr, const PanelTranspose* transpose = nullptr);
 
 }  // namespace pp

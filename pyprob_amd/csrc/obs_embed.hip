@@ -8,6 +8,7 @@
 // atomic per parameter per workgroup. Larger embeddings take the generic GEMM path (engine.hip).
 #include "common.hpp"
 #include "gather.hpp"
+#include "panel.hpp"
 
 #include <stdlib.h>
 
@@ -130,15 +131,20 @@ __global__ __launch_bounds__(256) void obs_embed_fwd_kernel(const ObsFusedArgs a
                                                             const float* __restrict__ obs, int n_traces,
                                                             int traces_per_wave, float* __restrict__ cat,
                                                             float* __restrict__ f1, float* __restrict__ E,
-                                                            const RowBuild rbin, const AddrBias ab) {
+                                                            const RowBuild rbin, const AddrBias ab,
+                                                            const PanelTranspose tr) {
     __shared__ float lds[10240];
     const ObsFusedArgs a = ain;
     const RowBuild rb = rbin;
+    if (tr.n_blocks && (int)blockIdx.x >= tr.first_block) {   // extra workgroups: k-major weight copies for the panel kernel
+        panel_transpose_block(tr, (int)blockIdx.x - tr.first_block, lds);
+        return;
+    }
     if (ab.AB && (int)blockIdx.x >= ab.first_block) {   // extra workgroups: per-address bias vectors of the LSTM input
         addr_bias_block(ab, (int)blockIdx.x - ab.first_block, lds);
         return;
     }
-    warm_kernargs((int)(sizeof(ObsFusedArgs) + sizeof(RowBuild) + sizeof(AddrBias)) + 64);
+    warm_kernargs((int)(sizeof(ObsFusedArgs) + sizeof(RowBuild) + sizeof(AddrBias) + sizeof(PanelTranspose)) + 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // training step: this is the first kernel - clear the loss slots that later kernels add into
     if (rb.zero_small && blockIdx.x == 0)
@@ -381,7 +387,8 @@ static int pick_traces_per_wave(int n, int target_blocks) {
 
 // obs_h: host array of n_obs device pointers; E/cat/f1 leading dim = round4(e_obs)
 int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int n_traces, float* const* obs_h,
-                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows, const AddrBias* bias) {
+                        float* cat, float* f1, float* E, hipStream_t st, const RowBuild* rows, const AddrBias* bias,
+                        const PanelTranspose* transpose) {
     ObsFusedArgs a;
     if (!obs_fused_supported(net) || !obs_fused_args(net, obs_h, a)) return PP_EINVAL;
     const int tpw = pick_traces_per_wave(n_traces, 256);   // forward: staging is cheap, spread the traces
@@ -395,7 +402,13 @@ int obs_embed_fwd_fused(const pp_net* net, const float* P, const float* obs, int
         ab.first_block = blocks;
         blocks += addr_bias_blocks(ab);
     }
-#define PP_OBS_FWD(N) hipLaunchKernelGGL(obs_embed_fwd_kernel<N>, dim3(blocks), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat, f1, E, rb, ab)
+    PanelTranspose tr{};
+    if (transpose && transpose->n_blocks > 0) {   // behind the bias job
+        tr = *transpose;
+        tr.first_block = blocks;
+        blocks += tr.n_blocks;
+    }
+#define PP_OBS_FWD(N) hipLaunchKernelGGL(obs_embed_fwd_kernel<N>, dim3(blocks), dim3(256), 0, st, a, P, obs, n_traces, tpw, cat, f1, E, rb, ab, tr)
     if (a.n_obs <= 1) PP_OBS_FWD(1);
     else if (a.n_obs <= 2) PP_OBS_FWD(2);
     else if (a.n_obs <= 4) PP_OBS_FWD(4);

@@ -1,0 +1,111 @@
+"""The row-panel kernel of single-statement batches (csrc/panel.hip) against the tile-kernel path (PP_PANEL=0) and the
+oracle: loss, per-row log_prob, every gradient - for the benchmark shape (GUM, H = 512, B = 1024), a batch whose last
+panel is ragged (B = 1003), a Uniform prior (TruncatedNormal-mixture head, values partly outside the support) and a
+non-finite observation (the minibatch must be flagged exactly like on the tile path)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(repo)r); sys.path.insert(0, %(repo)r + '/tests')
+from helpers import synthetic_gum_arrays
+from pyprob_amd.engine import ICEngine
+from pyprob_amd.packed import PackedBatch
+from pyprob_amd.spec import NetSpec
+out = {}
+for name, B, dist in (('gum1024', 1024, 'Normal'), ('gum1003', 1003, 'Normal'), ('uni777', 777, 'Uniform'), ('nan64', 64, 'Normal')):
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
+    spec.add_address('mu', dist)
+    arr = synthetic_gum_arrays(B, seed=3 + B)
+    if dist == 'Uniform':       # prior U(-4, 6); a few values outside the support (log_prob -inf -> rescued rows)
+        arr['prior'] = np.tile(np.array([[-4.0, 6.0]], np.float32), (B, 1))
+        arr['values'] = np.clip(arr['values'], -3.9, 5.9).astype(np.float32)
+        arr['values'][::97] = 7.5
+    if name == 'nan64':
+        arr['obs'][5, 1] = np.nan
+    eng = ICEngine(spec, device='cuda:0', seed=5)
+    pb = PackedBatch.from_ragged(arr['trace_len'], arr['addr_idx'], arr['values'], arr['prior'], arr['obs'], 1).to(eng.device)
+    l, lp = eng.loss(pb, backward=True, keep_lp=True)
+    torch.cuda.synchronize()
+    out[name + '_loss'] = l.cpu().numpy()
+    out[name + '_lp'] = lp.cpu().numpy()
+    out[name + '_status'] = eng.status_buf[:1].cpu().numpy()
+    out[name + '_grads'] = eng.grads.cpu().numpy()
+    # a second, different minibatch through the same workspace (stale buffers of the first must not leak)
+    arr2 = synthetic_gum_arrays(B, seed=77 + B)
+    if dist == 'Uniform':
+        arr2['prior'] = arr['prior']; arr2['values'] = np.clip(arr2['values'], -3.9, 5.9).astype(np.float32)
+    pb2 = PackedBatch.from_ragged(arr2['trace_len'], arr2['addr_idx'], arr2['values'], arr2['prior'], arr2['obs'], 1).to(eng.device)
+    l2 = eng.loss(pb2, backward=True)
+    torch.cuda.synchronize()
+    out[name + '_loss2'] = l2.cpu().numpy()
+    out[name + '_grads2'] = eng.grads.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def _run(tmp_path, tag, **env):
+    f = str(tmp_path / (tag + '.npz'))
+    e = dict(os.environ, PP_DETERMINISTIC='0', **env)
+    subprocess.run([sys.executable, '-c', SCRIPT % dict(repo=REPO), f], check=True, env=e, timeout=900)
+    return dict(np.load(f))
+
+
+def test_panel_kernel_equals_the_tile_path(tmp_path):
+    panel = _run(tmp_path, 'panel', PP_PANEL='1')
+    tiles = _run(tmp_path, 'tiles', PP_PANEL='0')
+    for k in sorted(panel):
+        a, b = panel[k], tiles[k]
+        if k.startswith('nan64'):
+            if k.endswith('_status'):
+                assert int(a[0]) == 1 and int(b[0]) == 1, k
+            continue
+        if k.endswith('_status'):
+            assert int(a[0]) == int(b[0]) == 0, k
+        elif '_loss' in k:
+            assert abs(float(a[0]) - float(b[0])) <= 2e-6 * abs(float(b[0])), (k, a, b)
+        elif k.endswith('_lp'):
+            fin = np.isfinite(b)
+            assert np.array_equal(fin, np.isfinite(a)), k
+            np.testing.assert_allclose(a[fin], b[fin], rtol=2e-5, atol=2e-5, err_msg=k)
+        else:
+            assert rel_err(a, b) < 3e-5, (k, rel_err(a, b))
+            pa, pb = a.reshape(-1, 1024), b.reshape(-1, 1024)      # per 1024-float chunk: a wrong region shows up here
+            den = np.maximum(np.abs(pb).max(axis=1), 1e-6 * np.abs(b).max())
+            worst = (np.abs(pa - pb).max(axis=1) / den).max()
+            assert worst < 2e-3, (k, worst)
+
+
+def test_panel_kernel_against_the_oracle():
+    """GUM, H = 512, B = 256 with the panel kernel on: loss and every gradient against the float64 oracle."""
+    from helpers import synthetic_gum_arrays
+    from oracle import ic_oracle as O
+    from pyprob_amd.engine import ICEngine
+    from pyprob_amd.packed import PackedBatch
+    from pyprob_amd.spec import NetSpec
+    assert os.environ.get('PP_PANEL', '1') != '0'
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
+    spec.add_address('mu', 'Normal')
+    eng = ICEngine(spec, device='cuda:0', seed=11)
+    arr = synthetic_gum_arrays(250, seed=21)
+    pb = PackedBatch.from_ragged(arr['trace_len'], arr['addr_idx'], arr['values'], arr['prior'], arr['obs'], 1).to(eng.device)
+    loss, lp = eng.loss(pb, backward=True, keep_lp=True)
+    torch.cuda.synchronize()
+    P = {k: v.numpy().astype(np.float64) for k, v in eng.state_dict().items()}
+    net = O.Net(P, ['obs0', 'obs1'], K=10)
+    ref = O.loss_and_grads(net, arr, ['mu'], ['Normal'])
+    assert abs(float(loss.item()) - ref['loss']) <= 2e-5 * abs(ref['loss'])
+    g = eng.grad_dict()
+    for n in spec.tensors:
+        err = np.abs(g[n] - ref['grads'][n]).max() / max(np.abs(ref['grads'][n]).max(), 1e-6)
+        assert err < 2e-3, (n, err)
