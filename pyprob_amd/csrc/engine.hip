@@ -144,6 +144,7 @@ struct Workspace {
     float* gsum;               // [n_addr][2][4H] column sums of dG per address group (current | previous statement)
     float* WihT;               // [e_obs][4H] k-major copy of W_ih[:, :e_obs] (panel.hpp), rewritten every step
     float* W1T;                // [H][64 ceil(maxhid / 64)] k-major copy of the present address's first head layer
+    unsigned long long* xz; unsigned long long* xd; int32_t* epoch;   // pair hand-off of the panel launch (panel.hpp)
     bool compact;              // LSTM input rows are [E | s_prev] (i4 = round4(e_obs + smp_dim)), the table columns a bias
     int xc;                    // columns of an LSTM input row: e_obs + smp_dim (compact) or lstm_in
     int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
@@ -175,6 +176,8 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
         if (!ff) lstm_tail_exchange_bytes(H, &fb, &bb);
         w.xch_f = c.take<char>((int64_t)fb);
         w.xch_b = c.take<char>((int64_t)bb);
+        // epoch of the panel launch's pair hand-off: a fixed place too (it counts the steps of this workspace)
+        w.epoch = c.take<int32_t>(16);
     }
     w.e4 = round4(net->e_obs);
     w.compact = compact_rows(net);
@@ -234,8 +237,12 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.AB = c.take<float>(w.compact ? (int64_t)net->n_addr * 2 * 4 * H : 0);
     w.gsum = c.take<float>(w.compact ? (int64_t)net->n_addr * 2 * 4 * H : 0);
     const bool panel_shape = w.compact && (H == 512 || H == 1024);
-    w.WihT = c.take<float>(panel_shape ? (int64_t)net->e_obs * 4 * H : 0);
+    w.WihT = c.take<float>(panel_shape ? (int64_t)net->e_obs * (4 * H + 64) : 0);
     w.W1T = c.take<float>(panel_shape ? (int64_t)H * 64 * ((hid + 63) / 64) : 0);
+    // pair hand-off of the split panel launch: partial sums [panels][2][8][hid4] and [panels][2][8][64], flags, epoch
+    const int64_t n_pan = (B + 7) / 8;
+    w.xz = c.take<unsigned long long>(panel_shape ? n_pan * 2 * 8 * w.hid4 : 0);
+    w.xd = c.take<unsigned long long>(panel_shape ? n_pan * 2 * 8 * 64 : 0);
     w.bytes = c.off + 256;
 }
 
@@ -437,7 +444,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     bool panel = false;
     if (lean_cell && n_present == 1 && fused_obs && bt->grp_off[only_addr] == 0 && bt->grp_off[only_addr + 1] == R) {
         const pp_addr& ad = net->addrs[only_addr];
-        panel = panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && head_tail_supported(ad.kind, ad.hid, ad.n_out) &&
+        panel = panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && panel_t1_split(R, H) == 2 &&
+                head_tail_supported(ad.kind, ad.hid, ad.n_out) &&
                 w.hid4 <= ((ad.hid + 15) & ~15) && w.out4 <= 64 && (flags & PP_LOSS_KEEP_LP ? lp_out != nullptr : true);
     }
     prof_begin(2, st);
@@ -477,6 +485,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             ptr.H = H; ptr.hid = ad.hid; ptr.e = net->e_obs;
             ptr.tiles_ih = 3 * H / 64;
             ptr.n_blocks = panel_transpose_blocks(H, ad.hid);
+            ptr.epoch = w.epoch;
         }
         PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb, compact ? &abias : nullptr,
                                    panel ? &ptr : nullptr));
@@ -537,6 +546,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 pa.ldx = (int)w.i4; pa.lda1 = (int)w.hid4; pa.lddy = (int)w.out4; pa.ldw = I;
                 pa.X = w.X; pa.Wih = P + net->w_ih; pa.AB = w.AB + (int64_t)only_addr * 2 * 4 * H;
                 pa.WihT = w.WihT; pa.W1T = w.W1T;
+                pa.xz = w.xz; pa.xd = w.xd; pa.epoch = w.epoch;
                 pa.W1 = P + ad.w1; pa.b1 = P + ad.b1; pa.W2 = P + ad.w2; pa.b2 = P + ad.b2;
                 pa.value = bt->value; pa.prior = bt->prior;
                 pa.Hs = w.Hl[0]; pa.G = w.Gl[0]; pa.A1 = w.A1; pa.DY = w.DY; pa.dZ1 = w.dZ1; pa.dX = w.dX;

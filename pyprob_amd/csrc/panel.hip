@@ -47,6 +47,9 @@ constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
 constexpr float kLogEps = -18.420680743952367f;
 
+// sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each; absolute error of the results ~1e-7)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float std_cdf_(float x) { return 0.5f * (1.0f + erff(x * kInvSqrt2)); }
 __device__ __forceinline__ float std_pdf_(float x) { return kInvSqrt2Pi * expf(-0.5f * x * x); }
 
@@ -86,23 +89,23 @@ __device__ __forceinline__ void mma_unit(const float* act /* + row * pitch + k0 
     PP_MMA_STEP(8) PP_MMA_STEP(9) PP_MMA_STEP(10) PP_MMA_STEP(11) PP_MMA_STEP(12) PP_MMA_STEP(13) PP_MMA_STEP(14) PP_MMA_STEP(15)
 }
 
-// A stream of n 16-k units through three register sets, loads two units ahead of the MFMAs:
+// A stream of n 16-k units through NB register sets, loads NB - 1 units ahead of the MFMAs (a wave's stream is latency
+// bound: ~2 000 cycles from issue to use under load, ~350 cycles of MFMAs per unit; vmcnt holds at most 63 loads, so
+// NB = 4 = 48 + the unit being consumed is the deepest that fits):
 //   load(i, w)  issues the 16 loads of unit i into w;  use(i, w)  consumes unit i.
-template <typename Load, typename Use>
+template <int NB, typename Load, typename Use>
 __device__ __forceinline__ void stream_units(int n, Load load, Use use) {
-    float w0[16], w1[16], w2[16];
-    if (n > 0) load(0, w0);
-    if (n > 1) load(1, w1);
-    for (int i = 0; i < n; i += 3) {
-        if (i + 2 < n) load(i + 2, w2);
-        use(i, w0);
-        if (i + 1 < n) {
-            if (i + 3 < n) load(i + 3, w0);
-            use(i + 1, w1);
-        }
-        if (i + 2 < n) {
-            if (i + 4 < n) load(i + 4, w1);
-            use(i + 2, w2);
+    float w[NB][16];
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b)
+        if (b < n) load(b, w[b]);
+    for (int i = 0; i < n; i += NB) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            if (i + s < n) {
+                if (i + s + NB - 1 < n) load(i + s + NB - 1, w[(s + NB - 1) % NB]);
+                use(i + s, w[s]);
+            }
         }
     }
 }
@@ -120,7 +123,11 @@ __host__ __device__ inline PanelLds panel_lds(int H, int hid, int n_out, int e) 
     L.ws = hid | 1;
     int o = 0;
     L.sE = o; o += PANEL_ROWS * L.PE;
-    L.sH = o; o += (PANEL_ROWS * L.PH > PANEL_WAVES * PANEL_ROWS * 72 ? PANEL_ROWS * L.PH : PANEL_WAVES * PANEL_ROWS * 72);
+    // sH, later (with sZ behind it) the four tiles' dG staging images [tile][gate][8][72] of phases 5 / 6
+    {
+        const int stage = 4 * 3 * PANEL_ROWS * 72 - PANEL_ROWS * L.PZ;
+        L.sH = o; o += (PANEL_ROWS * L.PH > stage ? PANEL_ROWS * L.PH : stage);
+    }
     L.sZ = o; o += PANEL_ROWS * L.PZ;
     L.sDZ = o; o += PANEL_ROWS * L.PZ;
     L.sDY = o; o += PANEL_ROWS * 72;
@@ -134,15 +141,56 @@ __host__ __device__ inline PanelLds panel_lds(int H, int hid, int n_out, int e) 
     return L;
 }
 
+// ---- hand-off between the two workgroups of a pair -----------------------------------------------------------------
+// Every value crosses as ONE naturally aligned 8-byte granule {value, tag} written by one system-scope relaxed atomic store
+// (global_store_dwordx2 ... sc0 sc1: write-through) and polled by the thread that needs it with system-scope loads (no L1 /
+// L2 hit on the reading side): payload and "ready" arrive together, one memory round trip instead of payload + flag + payload
+// read. The tag is the step's epoch (incremented once per step by the first launch), so nothing is ever cleared. The two
+// workgroups of a pair are blocks b and b + 8 (the same XCD under round-robin placement; correctness does not depend on it).
+// A bounded spin traps instead of hanging the device if a partner never arrives.
+// (the tag word is a NaN bit pattern that no arithmetic produces - 0x7FC00000 + epoch, epoch >= 1 - so stale floats or
+// integers of another batch shape's workspace layout can never look like a ready granule)
+__device__ __forceinline__ unsigned gtag(int epoch) { return 0x7FC00000u + ((unsigned)epoch & 0x3FFFFFu); }
+__device__ __forceinline__ void gput(unsigned long long* p, float v, int epoch) {
+    const unsigned long long x = ((unsigned long long)gtag(epoch) << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float gget(const unsigned long long* p, int epoch) {
+    int spins = 0;
+    while (true) {
+        const unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(x >> 32) == gtag(epoch)) return __uint_as_float((unsigned)x);
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) __builtin_trap();
+    }
+}
+
 // KIND: head kind (0 Normal mixture, 1 TruncatedNormal mixture in a Uniform prior, 2 Poisson head), kernels.hip.
-// UT: 64-unit tiles of hidden units per wave (H = 512 UT).
-template <int KIND, int UT>
+// SPLIT: workgroups per panel. With SPLIT = 2 the two workgroups of a pair
+// own one half of the hidden units each: a workgroup streams HALF of every weight matrix (the stream of the weights through
+// one CU's L1 at ~25 B/clk is what bounds the kernel, profiles/r03_panel_v3_pmc_*.csv), the K-split partial sums of head
+// layer 1 and of dX cross between the pair through memory (two hand-offs of 8.7 KB and 2 KB), the small tail phases run
+// redundantly on both, each writes 4 of the 8 rows of the shared outputs. 1 024 rows then fill all 256 CUs.
+template <int KIND, int SPLIT>
 __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PanelArgs a = ain;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * PANEL_ROWS;
+    const int bx = blockIdx.x;
+    const int half = SPLIT == 2 ? ((bx >> 3) & 1) : 0;
+    const int panel = SPLIT == 2 ? ((bx >> 4) * 8 + (bx & 7)) : bx;
+    const int m0 = panel * PANEL_ROWS;
+    if (m0 >= a.B) return;                       // (both workgroups of a pair)
+    constexpr int NOWN = PANEL_WAVES / SPLIT;    // waves that own a 64-unit tile of hidden units
+    constexpr int NB = 4;                        // register sets of the weight streams
+    // SPLIT = 2: the workgroup's hidden units are 4 tiles; wave w < 4 OWNS tile w (gates in its registers), wave w + 4 HELPS
+    // it: in the products that run over an owner's columns (input product, dh, dX) the two split the K range and the
+    // helper's partial sums cross through LDS.
+    const int tw = wave % NOWN;                  // tile of this wave
+    const int hp = wave / NOWN;                  // 0 owner, 1 helper
+    constexpr int NH = SPLIT;                    // waves per tile
+    const bool own = hp == 0;
     const int H = a.H, hid = a.hid, e = a.e, n_out = a.n_out, K = a.K;
     const PanelLds L = panel_lds(H, hid, n_out, e);
     float* const sE = smem + L.sE;
@@ -157,12 +205,15 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
     const int rl = lane & 3;                 // this lane's row inside a row group (A operand)
     const int kl = lane >> 2;                // ... and its k inside a 16-k unit
     const uint32_t voff = 4u * (uint32_t)lane;
-    const int U0 = wave * 64 * UT;           // first hidden unit this wave owns
+    const int HS = H / SPLIT;                // hidden units of this workgroup
+    const int U0 = half * HS + tw * 64;      // first hidden unit of this wave's tile
+    const int KB = half * HS + wave * (HS / PANEL_WAVES);      // this wave's k range of head layer 1: [KB, KB + HS / 8)
+    const int epoch = *a.epoch;
     const int NT5 = (hid + 63) >> 6;         // 64-column tiles of the head's hidden layer
     const int KU = e >> 4;                   // 16-k units of the input product
-    const int64_t ldT = 4 * (int64_t)H;      // row pitch of WihT
+    const int64_t ldT = 4 * (int64_t)H + 64; // row pitch of WihT (+ 256 B: an 8 KB pitch would put all 16 rows of a unit on one L2 channel)
     const int64_t ld1T = 64 * (int64_t)NT5;  // row pitch of W1T
-    const int dbg_slot = (blockIdx.x == 0 ? 0 : (blockIdx.x == 77 ? 1 : -1));
+    const int dbg_slot = (bx == 0 ? 0 : (bx == 77 ? 1 : -1));
 #define PANEL_STAMP(k)                                                                                          \
     do {                                                                                                        \
         if (a.dbg && dbg_slot >= 0 && lane == 0 && (wave == 0 || wave == 5))                                    \
@@ -181,7 +232,79 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
         for (int i = tid; i < PANEL_ROWS * PZ; i += 512) { sZ[i] = 0.0f; sDZ[i] = 0.0f; }      // (the zero pads matter)
         for (int i = tid; i < PANEL_ROWS * 72; i += 512) sDY[i] = 0.0f;
     }
-    // W2 [n_out][hid] -> LDS image [n_out][ws]: the loads are issued here, the LDS stores happen after phase 2
+    // bias of this lane's hidden units (gates i, g, o), fetched now, used in the cell
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = a.AB[(g == 0 ? 0 : g + 1) * H + U0 + lane];
+    __syncthreads();
+    PANEL_STAMP(1);
+
+    // ---------------- phase 1: G = E W_ih[:, :e]^T + bias, LSTM cell (c0 = 0) ----------------
+    float gi[8], gg[8], go[8], tc[8];   // gate activations and tanh(c) of (row, unit U0 + lane): owners only
+    {
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { acc[g][0] = f32x4{0, 0, 0, 0}; acc[g][1] = f32x4{0, 0, 0, 0}; }
+        // units (gate, q): columns gate_row(g) H + U0 .., k = 16 q of WihT; owner and helper take half of the k units each
+        const int KQ1 = KU / NH, q0 = hp * KQ1;
+        stream_units<NB>(
+            3 * KQ1,
+            [&](int i, float (&w)[16]) {
+                const int g = i / KQ1, q = q0 + i - g * KQ1;
+                load_unit(a.WihT + (int64_t)(16 * q) * ldT + (g == 0 ? 0 : g + 1) * H + U0, ldT, voff, w);
+            },
+            [&](int i, const float (&w)[16]) {
+                const int g = i / KQ1, q = q0 + i - g * KQ1;
+                const float* act = sE + rl * PE + 16 * q + kl;
+                if (g == 0) mma_unit(act, PE, w, acc[0][0], acc[0][1]);
+                else if (g == 1) mma_unit(act, PE, w, acc[1][0], acc[1][1]);
+                else mma_unit(act, PE, w, acc[2][0], acc[2][1]);
+            });
+        if (NH == 2) {      // helper -> owner: 24 partial sums per lane through sP (not in use before phase 2)
+            float* hx = sP + tw * (24 * 64) + lane;
+            if (!own) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hx[((g * 2 + rg) * 4 + i) * 64] = acc[g][rg][i];
+            }
+            __syncthreads();
+            if (own) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[g][rg][i] += hx[((g * 2 + rg) * 4 + i) * 64];
+            }
+        }
+        // cell: rows 4 rg + i, unit u = U0 + lane. sigmoid and tanh through v_exp_f32 / v_rcp_f32 (absolute error ~1e-7:
+        // the accurate library forms cost ~1 000 instructions per wave here)
+        if (own) {
+            const int u = U0 + lane;
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * rg + i;
+                    const float vi = fast_sigmoid(acc[0][rg][i] + bias[0]);
+                    const float vg = fast_tanh(acc[1][rg][i] + bias[1]);
+                    const float vo = fast_sigmoid(acc[2][rg][i] + bias[2]);
+                    const float c = vi * vg;
+                    const float tcv = fast_tanh(c);
+                    const float h = vo * tcv;
+                    gi[r] = vi; gg[r] = vg; go[r] = vo; tc[r] = tcv;
+                    sH[r * PH + u] = h;
+                    if (m0 + r < a.B) a.Hs[(int64_t)(m0 + r) * H + u] = h;
+                }
+        }
+    }
+    PANEL_STAMP(2);
+    __syncthreads();     // sH complete
+    PANEL_STAMP(3);
+    // W2 [n_out][hid] -> LDS image [n_out][ws]: the loads are issued here, the LDS stores happen after phase 2's units
     const int wtot = n_out * hid;
     const bool w2flat = (ws == hid) && (reinterpret_cast<uintptr_t>(a.W2) & 15) == 0 && wtot <= 512 * 4 * 5;
     f32x4 w2v[5];
@@ -191,71 +314,20 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
 #pragma unroll
         for (int u = 0; u < 5; ++u) w2v[u] = src[min(tid + 512 * u, n4 - 1)];
     }
-    // bias of this lane's hidden units (gates i, g, o), fetched now, used in the cell
-    float bias[UT][3];
-#pragma unroll
-    for (int t = 0; t < UT; ++t)
-#pragma unroll
-        for (int g = 0; g < 3; ++g) bias[t][g] = a.AB[(g == 0 ? 0 : g + 1) * H + U0 + 64 * t + lane];
-    __syncthreads();
-    PANEL_STAMP(1);
-
-    // ---------------- phase 1: G = E W_ih[:, :e]^T + bias, LSTM cell (c0 = 0) ----------------
-    float gi[UT][8], gg[UT][8], go[UT][8], tc[UT][8];   // gate activations and tanh(c) of (row, unit U0 + 64 t + lane)
-#pragma unroll
-    for (int t = 0; t < UT; ++t) {
-        f32x4 acc[3][2];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { acc[g][0] = f32x4{0, 0, 0, 0}; acc[g][1] = f32x4{0, 0, 0, 0}; }
-        // units (gate, q): columns gate_row(g) H + U0 + 64 t .., k = 16 q of WihT
-        stream_units(
-            3 * KU,
-            [&](int i, float (&w)[16]) {
-                const int g = i / KU, q = i - g * KU;
-                load_unit(a.WihT + (int64_t)(16 * q) * ldT + (g == 0 ? 0 : g + 1) * H + U0 + 64 * t, ldT, voff, w);
-            },
-            [&](int i, const float (&w)[16]) {
-                const int g = i / KU, q = i - g * KU;
-                const float* act = sE + rl * PE + 16 * q + kl;
-                if (g == 0) mma_unit(act, PE, w, acc[0][0], acc[0][1]);
-                else if (g == 1) mma_unit(act, PE, w, acc[1][0], acc[1][1]);
-                else mma_unit(act, PE, w, acc[2][0], acc[2][1]);
-            });
-        // cell: rows 4 rg + i, unit u = U0 + 64 t + lane
-        const int u = U0 + 64 * t + lane;
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * rg + i;
-                const float vi = sigmoidf_(acc[0][rg][i] + bias[t][0]);
-                const float vg = tanhf(acc[1][rg][i] + bias[t][1]);
-                const float vo = sigmoidf_(acc[2][rg][i] + bias[t][2]);
-                const float c = vi * vg;
-                const float tcv = tanhf(c);
-                const float h = vo * tcv;
-                gi[t][r] = vi; gg[t][r] = vg; go[t][r] = vo; tc[t][r] = tcv;
-                sH[r * PH + u] = h;
-                if (m0 + r < a.B) a.Hs[(int64_t)(m0 + r) * H + u] = h;
-            }
-    }
-    PANEL_STAMP(2);
-    __syncthreads();     // sH complete
-    PANEL_STAMP(3);
     // ---------------- phase 2: z1 = relu(h W1^T + b1); K split over the waves, partial tiles meet in sZ ----------------
-    // this wave's k range is its own hidden units [U0, U0 + 64 UT); items = column tiles, 4 UT units each; one accumulator
+    // this wave's k range is an eighth of the workgroup's hidden units; items = column tiles, KQ units each; one accumulator
     {
-        const int KQ = 4 * UT;
+        const int KQ = HS / (PANEL_WAVES * 16);
         f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-        stream_units(
+        stream_units<NB>(
             NT5 * KQ,
             [&](int i, float (&w)[16]) {
                 const int t = i / KQ, q = i - t * KQ;
-                load_unit(a.W1T + (int64_t)(U0 + 16 * q) * ld1T + 64 * t, ld1T, voff, w);
+                load_unit(a.W1T + (int64_t)(KB + 16 * q) * ld1T + 64 * t, ld1T, voff, w);
             },
             [&](int i, const float (&w)[16]) {
                 const int t = i / KQ, q = i - t * KQ;
-                mma_unit(sH + rl * PH + U0 + 16 * q + kl, PH, w, c0, c1);
+                mma_unit(sH + rl * PH + KB + 16 * q + kl, PH, w, c0, c1);
                 if (q == KQ - 1) {      // the tile's partial sums over this wave's k range are complete
                     const int n = 64 * t + lane;
                     if (n < hid) {
@@ -295,18 +367,40 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
     PANEL_STAMP(4);
     __syncthreads();
     PANEL_STAMP(5);
-    for (int i = tid; i < PANEL_ROWS * a.lda1; i += 512) {   // bias + ReLU, A1 rows to memory (pad columns zero)
-        const int r = i / a.lda1, n = i - r * a.lda1;
-        float z = 0.0f;
-        if (n < hid) {
-            const float* pr = sP + r * PP + n;
-            float sum = a.b1[n];
+    {   // z1 = relu(b1 + this half's partial sums + the partner's); A1 rows to memory (pad columns zero)
+        unsigned long long* const xz_own = a.xz + (int64_t)(panel * 2 + half) * (PANEL_ROWS * a.lda1);
+        const unsigned long long* const xz_other = a.xz + (int64_t)(panel * 2 + (half ^ 1)) * (PANEL_ROWS * a.lda1);
+        constexpr int EPT = 5;      // elements per thread: 8 rows x lda1 <= 512 x 5 (hid <= 320)
+        float mine[EPT];
 #pragma unroll
-            for (int wv = 0; wv < PANEL_WAVES; ++wv) sum += pr[wv * (PANEL_ROWS * PP)];
-            z = relu_keep_nan(sum);
-            sZ[r * PZ + n] = z;
+        for (int k = 0; k < EPT; ++k) {
+            const int i = tid + 512 * k;
+            mine[k] = 0.0f;
+            if (i < PANEL_ROWS * a.lda1) {
+                const int r = i / a.lda1, n = i - r * a.lda1;
+                if (n < hid) {
+                    const float* pr = sP + r * PP + n;
+#pragma unroll
+                    for (int wv = 0; wv < PANEL_WAVES; ++wv) mine[k] += pr[wv * (PANEL_ROWS * PP)];
+                    gput(xz_own + i, mine[k], epoch);
+                }
+            }
         }
-        if (m0 + r < a.B) a.A1[(int64_t)(m0 + r) * a.lda1 + n] = z;
+        PANEL_STAMP(14);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = tid + 512 * k;
+            if (i < PANEL_ROWS * a.lda1) {
+                const int r = i / a.lda1, n = i - r * a.lda1;
+                float z = 0.0f;
+                if (n < hid) {      // (half 0) + (half 1), the same order on both sides: identical z1 in both workgroups
+                    const float theirs = gget(xz_other + i, epoch);
+                    z = relu_keep_nan((half == 0 ? mine[k] + theirs : theirs + mine[k]) + a.b1[n]);
+                    sZ[r * PZ + n] = z;
+                }
+                if (m0 + r < a.B && (r >> 2) == half) a.A1[(int64_t)(m0 + r) * a.lda1 + n] = z;
+            }
+        }
     }
     __syncthreads();
     PANEL_STAMP(6);
@@ -334,6 +428,7 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
     {
         const int r = wave;
         const bool rowok = m0 + r < a.B;
+        const bool mine = rowok && (SPLIT == 1 || (r >> 2) == half);     // this workgroup writes the row's shared outputs
         const int gr = min(m0 + r, a.B - 1);
         const bool comp = lane < K;
         float ymu = 0.0f, ysd = 0.0f, yz = -INFINITY;
@@ -382,7 +477,7 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
         if (wave_sum((comp && al != al) ? 1.0f : 0.0f) > 0.0f) lp = NAN;   // NaN in a component poisons the logsumexp
         const bool rescued = (lp == -INFINITY);
         const bool bad = !rescued && !isfinite(lp);
-        if (rowok && lane == 0) {
+        if (mine && lane == 0) {
             if (a.lp_out) a.lp_out[gr] = lp;
             atomicAdd(a.loss_acc + 32 * ((blockIdx.x * PANEL_WAVES + wave) & 63), rescued ? -kLogEps : -lp);
             if (bad) atomicOr(a.flag, 1);
@@ -412,12 +507,12 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
         }
         if (comp) {
             sDY[r * 72 + lane] = d0; sDY[r * 72 + K + lane] = d1; sDY[r * 72 + 2 * K + lane] = d2;
-            if (rowok) {
+            if (mine) {
                 float* dy = a.DY + (int64_t)gr * a.lddy;
                 dy[lane] = d0; dy[K + lane] = d1; dy[2 * K + lane] = d2;
             }
         }
-        if (rowok && lane >= n_out && lane < a.lddy) a.DY[(int64_t)gr * a.lddy + lane] = 0.0f;   // pad columns
+        if (mine && lane >= n_out && lane < a.lddy) a.DY[(int64_t)gr * a.lddy + lane] = 0.0f;   // pad columns
     }
     __syncthreads();
     PANEL_STAMP(8);
@@ -441,7 +536,7 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
                         const int r = 4 * rg + i;
                         const float d = (j < hid && sZ[r * PZ + j] > 0.0f) ? (rg ? c1[i] : c0[i]) : 0.0f;
                         sDZ[r * PZ + j] = d;
-                        if (j < a.lda1 && m0 + r < a.B) a.dZ1[(int64_t)(m0 + r) * a.lda1 + j] = d;
+                        if (j < a.lda1 && m0 + r < a.B && (SPLIT == 1 || rg == half)) a.dZ1[(int64_t)(m0 + r) * a.lda1 + j] = d;
                     }
             }
         }
@@ -451,69 +546,76 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
     const int KZ = zk >> 4;            // 16-k units over the head's hidden layer (rows beyond hid meet the zero pad of dz1)
     __syncthreads();     // sDZ complete (and sH is free: the dG staging of phase 6 lives there)
     PANEL_STAMP(10);
-    float dgi[UT][8], dgg[UT][8], dgo[UT][8];
-    float gs_i[UT], gs_g[UT], gs_o[UT];      // column sums of dG over this panel's rows
-#pragma unroll
-    for (int t = 0; t < UT; ++t) {
+    float gs_i = 0.f, gs_g = 0.f, gs_o = 0.f;      // column sums of dG over this panel's rows (owners)
+    // [gate][8 rows][64 k + 8]: the tile's dG, read by owner AND helper (the images run from sH into sZ: h and z1 are dead)
+    float* const stg3 = sH + tw * (3 * PANEL_ROWS * 72);
+    {
         f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-        const float* wcol = a.W1 + U0 + 64 * t;
-        stream_units(
-            KZ,
-            [&](int q, float (&w)[16]) {
+        const float* wcol = a.W1 + U0;
+        const int KZh = NH == 2 ? (KZ + 1) >> 1 : KZ;          // owner: units [0, KZh), helper: [KZh, KZ)
+        const int qb = hp * KZh, qn = hp == 0 ? KZh : KZ - KZh;
+        stream_units<NB>(
+            qn,
+            [&](int i, float (&w)[16]) {
+                const int q = qb + i;
                 if (16 * q + 16 <= hid) load_unit(wcol + (int64_t)(16 * q) * H, H, voff, w);
                 else load_unit_clamped(wcol, H, 16 * q, hid, voff, w);
             },
-            [&](int q, const float (&w)[16]) { mma_unit(sDZ + rl * PZ + 16 * q + kl, PZ, w, c0, c1); });
-        const int u = U0 + 64 * t + lane;
-        float si = 0.f, sg = 0.f, so = 0.f;
+            [&](int i, const float (&w)[16]) { mma_unit(sDZ + rl * PZ + 16 * (qb + i) + kl, PZ, w, c0, c1); });
+        if (NH == 2) {      // helper -> owner through sP (free between the mixture phase and the partial tiles of dX)
+            float* hx = sP + tw * (8 * 64) + lane;
+            if (!own) {
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * rg + i;
-                const float dh = rg ? c1[i] : c0[i];
-                const float vi = gi[t][r], vg = gg[t][r], vo = go[t][r], tcv = tc[t][r];
-                const float dc = dh * vo * (1.0f - tcv * tcv);
-                float d_i = dc * vg * vi * (1.0f - vi);
-                float d_g = dc * vi * (1.0f - vg * vg);
-                float d_o = dh * tcv * vo * (1.0f - vo);
-                if (m0 + r >= a.B) { d_i = 0.0f; d_g = 0.0f; d_o = 0.0f; }
-                dgi[t][r] = d_i; dgg[t][r] = d_g; dgo[t][r] = d_o;
-                si += d_i; sg += d_g; so += d_o;
-                if (m0 + r < a.B) {
-                    float* g = a.G + (int64_t)(m0 + r) * 4 * H;
-                    g[u] = d_i; g[2 * H + u] = d_g; g[3 * H + u] = d_o;
-                }
+                for (int i = 0; i < 4; ++i) { hx[i * 64] = c0[i]; hx[(4 + i) * 64] = c1[i]; }
             }
-        gs_i[t] = si; gs_g[t] = sg; gs_o[t] = so;
+            __syncthreads();
+            if (own) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { c0[i] += hx[i * 64]; c1[i] += hx[(4 + i) * 64]; }
+            }
+        }
+        if (own) {
+            const int u = U0 + lane;
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * rg + i;
+                    const float dh = rg ? c1[i] : c0[i];
+                    const float vi = gi[r], vg = gg[r], vo = go[r], tcv = tc[r];
+                    const float dc = dh * vo * (1.0f - tcv * tcv);
+                    float d_i = dc * vg * vi * (1.0f - vi);
+                    float d_g = dc * vi * (1.0f - vg * vg);
+                    float d_o = dh * tcv * vo * (1.0f - vo);
+                    if (m0 + r >= a.B) { d_i = 0.0f; d_g = 0.0f; d_o = 0.0f; }
+                    gs_i += d_i; gs_g += d_g; gs_o += d_o;
+                    // dG: to memory (the weight-gradient launch reads it) and into the tile's staging image (A operand of dX)
+                    stg3[(0 * 8 + r) * 72 + lane] = d_i;
+                    stg3[(1 * 8 + r) * 72 + lane] = d_g;
+                    stg3[(2 * 8 + r) * 72 + lane] = d_o;
+                    if (m0 + r < a.B) {
+                        float* g = a.G + (int64_t)(m0 + r) * 4 * H;
+                        g[u] = d_i; g[2 * H + u] = d_g; g[3 * H + u] = d_o;
+                    }
+                }
+        }
     }
     PANEL_STAMP(11);
-    // ---------------- phase 6: dX[:, :e] = dG W_ih[:, :e]; this wave's k range = its own dG ----------------
+    __syncthreads();     // the staging images are complete
+    // ---------------- phase 6: dX[:, :e] = dG W_ih[:, :e]; K = this tile's 3 x 64 gate rows, split owner / helper ----------------
     {
-        float* const stg = sH + wave * (PANEL_ROWS * 72);     // [8 rows][64 k + 8]: this wave's dG of one (t, gate)
         f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-        // units (t, gate, q): rows gate_row(g) H + U0 + 64 t + 16 q .. of W_ih, columns [0, 64)
-        stream_units(
-            UT * 12,
+        // units (gate, q): rows gate_row(g) H + U0 + 16 q .. of W_ih, columns [0, 64); owner and helper take two q each
+        const int KQ6 = 4 / NH, q0 = hp * KQ6;
+        stream_units<NB>(
+            3 * KQ6,
             [&](int i, float (&w)[16]) {
-                const int t = i / 12, g = (i >> 2) % 3, q = i & 3;
-                load_unit(a.Wih + (int64_t)((g == 0 ? 0 : g + 1) * H + U0 + 64 * t + 16 * q) * a.ldw, a.ldw, voff, w);
+                const int g = i / KQ6, q = q0 + i - g * KQ6;
+                load_unit(a.Wih + (int64_t)((g == 0 ? 0 : g + 1) * H + U0 + 16 * q) * a.ldw, a.ldw, voff, w);
             },
             [&](int i, const float (&w)[16]) {
-                const int t = i / 12, g = (i >> 2) % 3, q = i & 3;
-                if (q == 0) {      // this (t, gate)'s dG rows into the staging image
-                    wave_sync_lds();
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float v = 0.0f;
-#pragma unroll
-                        for (int tt = 0; tt < UT; ++tt)
-                            if (tt == t) v = g == 0 ? dgi[tt][r] : (g == 1 ? dgg[tt][r] : dgo[tt][r]);
-                        stg[r * 72 + lane] = v;
-                    }
-                    wave_sync_lds();
-                }
-                mma_unit(stg + rl * 72 + 16 * q + kl, 72, w, c0, c1);
+                const int g = i / KQ6, q = q0 + i - g * KQ6;
+                mma_unit(stg3 + (g * 8 + rl) * 72 + 16 * q + kl, 72, w, c0, c1);
             });
         float* pw = sP + wave * (PANEL_ROWS * PP) + lane;      // (free since the mixture phase read the tail's partials)
 #pragma unroll
@@ -525,22 +627,27 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
     PANEL_STAMP(12);
     // group sums of dG (this address's slot of gsum: LSTM bias and table-column gradients follow from them, aux_jobs.hpp):
     // one atomic per (gate, unit) per workgroup, issued last so that nothing in the kernel waits for them
-#pragma unroll
-    for (int t = 0; t < UT; ++t) {
-        const int u = U0 + 64 * t + lane;
-        atomicAdd(a.gsum + u, gs_i[t]);
-        atomicAdd(a.gsum + 2 * H + u, gs_g[t]);
-        atomicAdd(a.gsum + 3 * H + u, gs_o[t]);
+    if (own) {
+        const int u = U0 + lane;
+        atomicAdd(a.gsum + u, gs_i);
+        atomicAdd(a.gsum + 2 * H + u, gs_g);
+        atomicAdd(a.gsum + 3 * H + u, gs_o);
     }
     __syncthreads();
-    for (int i = tid; i < PANEL_ROWS * e; i += 512) {
-        const int r = i / e, c = i - r * e;
-        if (m0 + r < a.B) {
+    {   // dX rows: the eight waves' partial tiles + the partner's half of the K range
+        unsigned long long* const xd_own = a.xd + (int64_t)(panel * 2 + half) * (PANEL_ROWS * 64);
+        const unsigned long long* const xd_other = a.xd + (int64_t)(panel * 2 + (half ^ 1)) * (PANEL_ROWS * 64);
+        const int i = tid, r = i / e, c = i - r * e;      // 8 e <= 512: one element per thread
+        if (i < PANEL_ROWS * e) {
             const float* pr = sP + r * PP + c;
             float sum = 0.0f;
 #pragma unroll
             for (int wv = 0; wv < PANEL_WAVES; ++wv) sum += pr[wv * (PANEL_ROWS * PP)];
-            a.dX[(int64_t)(m0 + r) * a.ldx + c] = sum;
+            gput(xd_own + i, sum, epoch);
+            if (m0 + r < a.B && (r >> 2) == half) {      // (the other rows' sums are the partner's to write)
+                const float theirs = gget(xd_other + i, epoch);
+                a.dX[(int64_t)(m0 + r) * a.ldx + c] = half == 0 ? sum + theirs : theirs + sum;
+            }
         }
     }
     PANEL_STAMP(13);
@@ -556,18 +663,18 @@ bool panel_t1_supported(int kind, int H, int hid, int n_out, int e) {
     static const int env = getenv("PP_PANEL") ? atoi(getenv("PP_PANEL")) : 1;
     if (!env || deterministic_mode()) return false;
     if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE && kind != PP_HEAD_POISSON_TN_MIXTURE) return false;
-    if (H != 512 && H != 1024) return false;
+    if (H != 512) return false;      // (H = 1024: the LDS images do not fit; the tile kernels take it)
     if (n_out % 3 != 0 || n_out < 3 || n_out > 48) return false;
     if (hid < 16 || hid > 576) return false;
     if (e < 16 || e > 64 || e % 16 != 0) return false;
     return panel_lds_bytes(H, hid, n_out, e) <= 160 * 1024;
 }
 
-template <int KIND, int UT>
+template <int KIND, int SPLIT>
 static int panel_launch(const PanelArgs& a, size_t lds, hipStream_t st) {
     static thread_local bool configured = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)panel_t1_kernel<KIND, UT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)panel_t1_kernel<KIND, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) {
             set_error("panel_t1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -575,21 +682,25 @@ static int panel_launch(const PanelArgs& a, size_t lds, hipStream_t st) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((panel_t1_kernel<KIND, UT>), dim3(cdiv(a.B, PANEL_ROWS)), dim3(512), lds, st, a);
+    const int panels = cdiv(a.B, PANEL_ROWS);
+    const int grid = SPLIT == 2 ? 16 * cdiv(panels, 8) : panels;      // pairs are blocks (b, b + 8) of a 16-block window
+    hipLaunchKernelGGL((panel_t1_kernel<KIND, SPLIT>), dim3(grid), dim3(512), lds, st, a);
     return 0;
 }
+
+// The launch uses two workgroups per panel (pairs are blocks (b, b + 8) of a 16-block window); up to 256 panels.
+int panel_t1_split(int B, int H) { return (H == 512 && cdiv(B, PANEL_ROWS) <= 256) ? 2 : 0; }
 
 int panel_t1(int kind, const PanelArgs& a, hipStream_t st) {
     PP_CHECK_ARG(panel_t1_supported(kind, a.H, a.hid, a.n_out, a.e), "panel_t1: unsupported shape");
     PP_CHECK_ARG(a.ldx % 4 == 0 && a.ldw % 4 == 0 && a.lda1 % 4 == 0 && a.lda1 >= a.hid && a.lda1 <= ((a.hid + 15) & ~15) &&
-                     a.lddy <= 64 && a.lddy >= a.n_out && a.K * 3 == a.n_out,
+                     a.lddy <= 64 && a.lddy >= a.n_out && a.K * 3 == a.n_out && a.e * PANEL_ROWS <= 512 && PANEL_ROWS * a.lda1 <= 512 * 5,
                  "panel_t1: bad leading dimensions");
     const size_t lds = panel_lds_bytes(a.H, a.hid, a.n_out, a.e);
-    const int ut = a.H / 512;
-#define PP_PANEL_GO(KIND)                                            \
-    do {                                                             \
-        if (ut == 1) PP_TRY((panel_launch<KIND, 1>(a, lds, st)));    \
-        else PP_TRY((panel_launch<KIND, 2>(a, lds, st)));            \
+    PP_CHECK_ARG(panel_t1_split(a.B, a.H) == 2 && a.xz && a.xd && a.epoch, "panel_t1: too many rows, or no hand-off buffers");
+#define PP_PANEL_GO(KIND)                                                \
+    do {                                                                 \
+        PP_TRY((panel_launch<KIND, 2>(a, lds, st)));                     \
     } while (0)
     if (kind == PP_HEAD_NORMAL_MIXTURE) PP_PANEL_GO(0);
     else if (kind == PP_HEAD_TRUNCNORMAL_MIXTURE) PP_PANEL_GO(1);

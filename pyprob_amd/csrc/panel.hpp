@@ -17,6 +17,9 @@ struct PanelArgs {
     float* gsum;                         // [4H] column sums of dG for this address (atomics)
     float* lp_out; float* loss_acc; int32_t* flag;
     float grad_scale;
+    // pair hand-off (two workgroups per panel): 8-byte {value, epoch} granules of the partial sums of head layer 1
+    // [panels][2][8][lda1] and of dX [panels][2][8][64]; *epoch is incremented once per step by the first launch
+    unsigned long long* xz; unsigned long long* xd; const int* epoch;
     long long* dbg;                      // debug: clock64() stamps [2 workgroups][2 waves][16] (pp_debug_timeline) or nullptr
 };
 
@@ -27,23 +30,25 @@ struct PanelArgs {
 //   block b < tiles_ih : rows [n0, n0 + 64) of W_ih (gates i, g, o only), columns [0, e)  ->  WihT[k][n0 ..]
 //   the rest           : tile (ti, tj) of W1 [hid][H]  ->  W1T[64 tj ..][64 ti ..]; rows beyond hid are written as zeros
 struct PanelTranspose {
-    const float* Wih; int64_t ldw; float* WihT;   // WihT [e][4H]
+    const float* Wih; int64_t ldw; float* WihT;   // WihT [e][4H + 64]
     const float* W1; float* W1T; int64_t ld1T;    // W1 [hid][H], W1T [H][ld1T], ld1T = 64 ceil(hid / 64)
     int H, hid, e;
     int tiles_ih, first_block, n_blocks;           // 3 H / 64 tiles of W_ih; first workgroup of the job in its launch
+    int* epoch;                                    // the job's first workgroup advances the step's hand-off epoch
 };
 static inline int panel_transpose_blocks(int H, int hid) { return 3 * H / 64 + ((hid + 63) / 64) * (H / 64); }
 
 __device__ __forceinline__ void panel_transpose_block(const PanelTranspose& tr, int b, float* lds /* >= 64 * 65 floats */) {
     const int tid = threadIdx.x;       // 256 threads
     const int tx = tid & 63, ty = tid >> 6;
+    if (b == 0 && tid == 0 && tr.epoch) tr.epoch[0] += 1;
     const bool ih = b < tr.tiles_ih;
     const float* src; int64_t ld_src; int r0, c0, rmax, cmax;
     float* dst; int64_t ld_dst; int dr0, dc0, out_rows;
     if (ih) {
         const int n0 = (b * 64 < tr.H) ? b * 64 : b * 64 + tr.H;       // skip the forget gate's rows [H, 2H)
         src = tr.Wih; ld_src = tr.ldw; r0 = n0; c0 = 0; rmax = 4 * tr.H; cmax = tr.e;
-        dst = tr.WihT; ld_dst = 4 * (int64_t)tr.H; dr0 = 0; dc0 = n0; out_rows = tr.e < 64 ? tr.e : 64;
+        dst = tr.WihT; ld_dst = 4 * (int64_t)tr.H + 64; dr0 = 0; dc0 = n0; out_rows = tr.e < 64 ? tr.e : 64;
     } else {
         const int q = b - tr.tiles_ih, tjn = tr.H >> 6;
         const int ti = q / tjn, tj = q - ti * tjn;
@@ -72,5 +77,6 @@ bool panel_t1_supported(int kind, int H, int hid, int n_out, int e);
 size_t panel_lds_bytes(int H, int hid, int n_out, int e);
 // one launch: input product + cell, head layer 1, tail + loss + dy, dz1, dh + cell backward (dG, group sums), dX
 int panel_t1(int kind, const PanelArgs& a, hipStream_t st);
+int panel_t1_split(int B, int H);                   // 2 when the (two-workgroups-per-panel) launch takes this many rows, else 0
 
 }  // namespace pp

@@ -50,6 +50,29 @@ for name, B, dist in (('gum1024', 1024, 'Normal'), ('gum1003', 1003, 'Normal'), 
     torch.cuda.synchronize()
     out[name + '_loss2'] = l2.cpu().numpy()
     out[name + '_grads2'] = eng.grads.cpu().numpy()
+# a run of training steps over different minibatches (the pair hand-off of the split launch is re-used every step: a stale
+# payload would be ANOTHER minibatch's partial sums)
+spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
+spec.add_address('mu', 'Normal')
+eng = ICEngine(spec, device='cuda:0', seed=5)
+pbs = []
+for k in range(6):
+    arr = synthetic_gum_arrays(1024 if k %% 2 == 0 else 1000, seed=500 + k)
+    pbs.append(PackedBatch.from_ragged(arr['trace_len'], arr['addr_idx'], arr['values'], arr['prior'], arr['obs'], 1).to(eng.device))
+losses, gsums = [], []
+for it in range(60):        # fixed parameters: every visit of a minibatch must reproduce its loss and gradient
+    l = eng.loss(pbs[(it * 5) %% 6], backward=True)
+    losses.append(l.clone())
+    gsums.append(eng.grads.double().abs().sum().reshape(1))
+torch.cuda.synchronize()
+out['rep_losses'] = torch.cat(losses).cpu().numpy()
+out['rep_gsums'] = torch.cat(gsums).cpu().numpy()
+losses = []
+for it in range(48):        # and a run of training steps (Adam amplifies last-bit differences of near-zero gradients, so only
+    l = eng.train_step(pbs[(it * 5) %% 6], 1e-3)      # the loss trajectory is compared)
+    losses.append(l.clone())
+torch.cuda.synchronize()
+out['run_losses'] = torch.cat(losses).cpu().numpy()
 np.savez(sys.argv[1], **out)
 '''
 
@@ -62,9 +85,18 @@ def _run(tmp_path, tag, **env):
 
 
 def test_panel_kernel_equals_the_tile_path(tmp_path):
+    """Two workgroups per 8-row panel, partial sums handed over through memory (csrc/panel.hip)."""
     panel = _run(tmp_path, 'panel', PP_PANEL='1')
     tiles = _run(tmp_path, 'tiles', PP_PANEL='0')
+    np.testing.assert_allclose(panel['run_losses'], tiles['run_losses'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(panel['rep_losses'], tiles['rep_losses'], rtol=2e-6)
+    np.testing.assert_allclose(panel['rep_gsums'], tiles['rep_gsums'], rtol=2e-5)
+    for k in range(6, 60):      # visit k of a minibatch against its first visit (it * 5 % 6 has period 6)
+        assert abs(panel['rep_losses'][k] - panel['rep_losses'][k % 6]) <= 2e-6 * abs(panel['rep_losses'][k % 6]), k
+        assert abs(panel['rep_gsums'][k] - panel['rep_gsums'][k % 6]) <= 2e-5 * abs(panel['rep_gsums'][k % 6]), k
     for k in sorted(panel):
+        if k.startswith('run_') or k.startswith('rep_'):
+            continue
         a, b = panel[k], tiles[k]
         if k.startswith('nan64'):
             if k.endswith('_status'):

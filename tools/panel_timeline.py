@@ -31,6 +31,6 @@ for rep in range(3):
     print('--- step %d (cycles since the stamping wave started; 2400 cycles = 1 us)' % rep)
     for row, tag in zip(t, ('wg 0 wave 0', 'wg 0 wave 5', 'wg 77 wave 0', 'wg 77 wave 5')):
         base = row[0]
-        print('%-13s ' % tag + '  '.join('%s %d' % (NAMES[k], row[k] - row[k - 1]) for k in range(1, 14)) + '   | total %d' % (row[13] - base))
+        print('%-13s ' % tag + '  '.join('%s %d' % (NAMES[k], row[k] - row[k - 1]) for k in range(1, 14)) + '   | total %d | fixup: reduce+publish %d, wait+finish %d' % (row[13] - base, row[14] - row[5], row[6] - row[14]))
 
 lib.pp_debug_timeline(None)
