@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 7
+#define PP_ABI_VERSION 8
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -398,6 +398,24 @@ typedef struct pp_lw_term {
 } pp_lw_term;
 int pp_logweight_terms(const pp_lw_term* terms, int32_t count, float* lw /*dev [n]*/, int32_t n, int32_t overwrite,
                        void* stream);
+
+/* One posterior statement of a lock-step run in ONE pass over the particles (state.sample IC branch pyprob/state.py:203-219 +
+ * the state.observe terms that follow it :118-155 + Trace.end's sum pyprob/trace.py:123-125 + the Empirical reductions
+ * pyprob/distributions/empirical.py:298-309, 451-466, 758-766):
+ *   pp_is_step_net  the network part of pp_is_step (LSTM step + proposal layer); the head outputs stay in the workspace.
+ *   pp_is_fused     per particle: draw v ~ q (addr_id >= 0: the SHARED proposal of a trace's first statement, left in the
+ *                   workspace by pp_is_step_net; mixture heads; same Philox stream as pp_is_step), lw (+)= -log q(v) +
+ *                   sum_t scale_t term_t(i); value[i] = v. addr_id < 0: no draw, `value` is read. term_flags[t] bit 0 / 1 / 2:
+ *                   p0 / p1 / x of term t IS the particle's value (e.g. the mean of the likelihood Normal(mu, s) after
+ *                   mu = sample(...)). stats_out != NULL: the statistics of pp_is_stats over (lw, value) in the same pass.
+ *                   At most 8 terms. 8 bytes per particle reach memory. */
+int pp_is_step_net(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+                   const float* e_obs_vec, const float* prev_value, float* h, float* c, int32_t state_rows, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prior /*dev [2]*/, const pp_lw_term* terms,
+                const int32_t* term_flags, int32_t n_terms, float* value /*dev [n]*/, float* lw /*dev [n]*/, int32_t overwrite,
+                uint64_t seed, uint64_t offset, double* stats_out /*dev [6] or NULL*/, double* stats_scratch, void* workspace,
+                size_t workspace_bytes, void* stream);
 
 /* lw[i] += scale * term[i] (e.g. -log q). */
 int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream);

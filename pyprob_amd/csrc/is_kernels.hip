@@ -413,15 +413,15 @@ int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, v
 int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
             const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
             const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset, void* ws,
-            size_t ws_bytes, hipStream_t st) {
+            size_t ws_bytes, hipStream_t st, bool net_only = false) {
     const bool ff = net && net->lstm_dim == 0;   // FeedForward network: the proposal layer reads the observe embedding
-    PP_CHECK_ARG(net && P && e_obs_vec && (ff || (h && c)) && value_out && logq_out && ws, "pp_is_step: null pointer");
+    PP_CHECK_ARG(net && P && e_obs_vec && (ff || (h && c)) && (net_only || (value_out && logq_out)) && ws, "pp_is_step: null pointer");
     PP_CHECK_ARG(addr_id >= 0 && addr_id < net->n_addr && prev_addr_id < net->n_addr, "pp_is_step: address id out of range");
     PP_CHECK_ARG(ff || prev_addr_id < 0 || prev_value, "pp_is_step: prev_value is required after the first statement");
     PP_CHECK_ARG(ff || prev_addr_id < 0 || state_rows == 1 || state_rows == n, "pp_is_step: state_rows must be 1 or n");
     if (n <= 0) return 0;
     const pp_addr& ad = net->addrs[addr_id];
-    PP_CHECK_ARG(ad.kind == PP_HEAD_CATEGORICAL || ad.kind == PP_HEAD_BERNOULLI || prior,
+    PP_CHECK_ARG(net_only || ad.kind == PP_HEAD_CATEGORICAL || ad.kind == PP_HEAD_BERNOULLI || prior,
                  "pp_is_step: prior parameters required");
     // First statement of a trace: identical LSTM input and zero state for every particle -> ONE row is evaluated and
     // only row 0 of (h, c) is written (the caller's state_rows becomes 1). Second statement: the inputs differ (previous
@@ -474,6 +474,7 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     }
     PP_TRY(lin(top, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
     PP_TRY(lin(w.A1, w.hid4, P + ad.w2, P + ad.b2, nullptr, w.Y, w.out4, m, ad.hid, ad.n_out, false, false, st));
+    if (net_only) return 0;      // the head outputs stay in w.Y for pp_is_fused
     dim3 grid(cdiv(n, 256)), block(256);
     // kernel class 4 of the in-stream timing: draw + log q per particle (writes value and log q: 8 algorithmic bytes each)
     prof_begin(4, st);
@@ -676,6 +677,181 @@ __global__ __launch_bounds__(256) void logweight_multi_kernel(const LwTerms term
     lw[i] = acc;
 }
 
+// ---- one pass per posterior statement -------------------------------------------------------------------------------
+// Draw from the (shared) proposal, log q, the prior term and every queued likelihood term, the new log-weight and the
+// importance statistics in ONE grid-stride kernel: a particle costs a Philox block, the draw, K fused multiply-adds + exps
+// and a handful of log-probs; memory sees 8 bytes per particle (value and log-weight, written once). The per-component
+// constants of the proposal are computed once per workgroup. The statistics use the scheme of is_stats_partial_kernel
+// (per-workgroup maximum, fp64 sums relative to it, rescaled by is_stats_combine_kernel).
+//   term parameters flagged "value" read the particle's freshly drawn value (e.g. the mean of the likelihood Normal(mu, s)
+//   of observe statements that follow `mu = sample(...)`), so the program's statements up to the next sample are one pass.
+constexpr int FUSED_PT = 8;          // particles per thread per tile
+constexpr int FUSED_MAX_TERMS = 8;
+struct FusedTerm {
+    int kind, s0, s1, sx, flags;     // flags: 1 p0 = value, 2 p1 = value, 4 x = value
+    const float *p0, *p1, *x;
+    float scale;
+};
+struct FusedTerms {
+    FusedTerm t[FUSED_MAX_TERMS];
+    int count;
+};
+
+template <int KIND>      // -1: no draw (values are read), 0 / 1 / 2: mixture head kinds as is_mixture_shared_kernel
+__global__ __launch_bounds__(256) void is_fused_kernel(const float* __restrict__ y, const float* __restrict__ prior, int n, int K,
+                                                       const FusedTerms terms, float* __restrict__ value,
+                                                       float* __restrict__ lw, int overwrite, uint64_t seed, uint64_t offset,
+                                                       double* __restrict__ scratch) {
+    __shared__ float s_mu[MAXK], s_sd[MAXK], s_inv[MAXK], s_c[MAXK], s_cum[MAXK], s_ca[MAXK], s_cb[MAXK];
+    __shared__ float shmax[4];
+    __shared__ double sh[4][5];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float pa = 0.0f, pb = 1.0f;
+    if (KIND >= 0) {
+        pa = prior[0]; pb = prior[1];
+        if (tid < MAXK) {      // the proposal's components: same arithmetic as is_mixture_shared_kernel
+            const int k = tid;
+            float zmax = -INFINITY;
+            for (int j = 0; j < K; ++j) zmax = fmaxf(zmax, y[2 * K + j]);
+            float zs = 0.0f;
+            for (int j = 0; j < K; ++j) zs += expf(y[2 * K + j] - zmax);
+            float ps = 0.0f, cum = 0.0f;
+            for (int j = 0; j < K; ++j) ps += expf(y[2 * K + j] - zmax) / zs;
+            for (int j = 0; j <= k && j < K; ++j) cum += (expf(y[2 * K + j] - zmax) / zs) / ps;
+            if (k < K) {
+                const float pk = (expf(y[2 * K + k] - zmax) / zs) / ps;
+                float mu, sd;
+                if (KIND == 0) {
+                    mu = pa + y[k] * pb;
+                    sd = expf(y[K + k]) * pb;
+                } else {
+                    const float rng = pb - pa;
+                    mu = pa + sigmoidf_(y[k]) * rng;
+                    sd = KIND == 2 ? expf(y[K + k]) : rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
+                }
+                const float lpk = logf(fminf(fmaxf(pk, kFp32Eps), 1.0f - kFp32Eps));
+                s_mu[k] = mu; s_sd[k] = sd; s_inv[k] = 1.0f / sd; s_cum[k] = cum;
+                if (KIND == 0) {
+                    s_c[k] = lpk - logf(sd) - kHalfLog2Pi;
+                    s_ca[k] = s_cb[k] = 0.0f;
+                } else {
+                    const float ca = std_cdf((pa - mu) / sd), cb = std_cdf((pb - mu) / sd);
+                    s_ca[k] = ca; s_cb[k] = cb;
+                    s_c[k] = lpk - kHalfLog2Pi - logf(sd * (cb - ca));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double M = -INFINITY;
+    double S[5] = {0, 0, 0, 0, 0};
+    const int tile = 256 * FUSED_PT;
+    for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile) {
+        float l[FUSED_PT], xv[FUSED_PT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < FUSED_PT; ++q) {
+            const int i = base + q * 256 + tid;
+            l[q] = -INFINITY; xv[q] = 0.0f;
+            if (i >= n) continue;
+            float v, acc = overwrite ? 0.0f : lw[i];
+            if (KIND < 0) {
+                v = value[i];
+            } else {
+                Philox rng(seed, offset + (uint64_t)i, 0x1C);
+                v = NAN;
+                for (int attempt = 0; attempt < 64; ++attempt) {
+                    uint32_t r[4];
+                    rng.next(r);
+                    const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
+                    int kk = K - 1;
+                    for (int k = K - 2; k >= 0; --k)
+                        if (u0 < s_cum[k]) kk = k;
+                    const float mk = s_mu[kk], sk = s_sd[kk];
+                    if (KIND == 0) {
+                        v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);
+                        break;
+                    } else {
+                        const float uu = s_ca[kk] + u1 * (s_cb[kk] - s_ca[kk]);
+                        v = mk + sk * kSqrt2 * erfinvf(2.0f * uu - 1.0f);
+                        if (isfinite(v) && v >= pa && v < pb) break;
+                        v = NAN;
+                    }
+                }
+                const bool inside = (KIND == 0) || (v >= pa && v <= pb);
+                float a[MAXK], amax = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k)
+                    if (k < K) {
+                        const float t = (v - s_mu[k]) * s_inv[k];
+                        a[k] = inside ? s_c[k] - 0.5f * t * t : -INFINITY;
+                        amax = fmaxf(amax, a[k]);
+                    }
+                float lq = amax;
+                if (amax > -INFINITY) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < MAXK; ++k)
+                        if (k < K) sum += expf(a[k] - amax);
+                    lq = amax + logf(sum);
+                }
+                acc -= lq;                 // - log q(v)   (state.py:212, 217)
+                value[i] = v;
+            }
+            for (int t = 0; t < terms.count; ++t) {
+                const FusedTerm& T = terms.t[t];
+                const float x = (T.flags & 4) ? v : T.x[(int64_t)i * T.sx];
+                float lp;
+                if (T.kind == 2) {
+                    lp = x;
+                } else if (T.kind == 0 || T.kind == 1) {      // two parameters, either may BE the drawn value
+                    const float pa_ = (T.flags & 1) ? v : T.p0[(int64_t)i * T.s0];
+                    const float pb_ = (T.flags & 2) ? v : T.p1[(int64_t)i * T.s1];
+                    if (T.kind == 0) {
+                        const float d = x - pa_;
+                        lp = -(d * d) / (2.0f * pb_ * pb_) - logf(pb_) - kHalfLog2Pi;
+                    } else {
+                        lp = (x >= pa_ && x < pb_) ? -logf(pb_ - pa_) : -INFINITY;
+                    }
+                } else {
+                    lp = term_log_prob(T.kind, T.p0, T.s0, T.p1, T.s1, x, i);
+                }
+                acc += T.scale * lp;
+            }
+            lw[i] = acc;
+            l[q] = acc; xv[q] = v;
+            if (isfinite(acc)) m = fmaxf(m, acc);
+        }
+        if (!scratch) continue;
+        m = wave_max(m);
+        if (lane == 0) shmax[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
+        __syncthreads();
+        if (m == -INFINITY) continue;
+        if ((double)m > M) {
+            const double r = M == -INFINITY ? 0.0 : exp(M - (double)m);
+            S[0] *= r; S[1] *= r * r; S[2] *= r; S[3] *= r;
+            M = (double)m;
+        }
+#pragma unroll
+        for (int q = 0; q < FUSED_PT; ++q) {
+            if (!isfinite(l[q])) continue;
+            const double e = exp((double)l[q] - M), xd = (double)xv[q];
+            S[0] += e; S[1] += e * e; S[2] += e * xd; S[3] += e * xd * xd; S[4] += 1.0;
+        }
+    }
+    if (!scratch) return;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double r = wave_sum(S[q]);
+        if (lane == 0) sh[wave][q] = r;
+    }
+    __syncthreads();
+    if (tid < 5) scratch[blockIdx.x * 6 + 1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    if (tid == 0) scratch[blockIdx.x * 6] = M;
+}
+
 // kinds 0, 1 read p1; 3, 4 ignore it; 5 carries the number of categories in p1_stride
 static inline bool lw_kind_ok(int kind, const float* p1, int p1_stride) {
     if (kind == 0 || kind == 1) return p1 != nullptr;
@@ -706,6 +882,78 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
     return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows,
                        value_in,
                        value_out, logq_out, seed, offset, workspace, workspace_bytes, pp::as_stream(stream));
+}
+
+int pp_is_step_net(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+                   const float* e_obs_vec, const float* prev_value, float* h, float* c, int32_t state_rows, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, nullptr, 0, h, c, state_rows, nullptr,
+                       nullptr, nullptr, 0, 0, workspace, workspace_bytes, pp::as_stream(stream), /*net_only=*/true);
+}
+
+int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prior, const pp_lw_term* terms,
+                const int32_t* term_flags, int32_t n_terms, float* value, float* lw, int32_t overwrite, uint64_t seed,
+                uint64_t offset, double* stats_out, double* stats_scratch, void* workspace, size_t workspace_bytes,
+                void* stream) {
+    if (!(value && lw) || n_terms < 0 || n_terms > pp::FUSED_MAX_TERMS || (n_terms && !terms) || (stats_out && !stats_scratch)) {
+        pp::set_error("pp_is_fused: bad argument (at most %d terms; statistics need scratch)", pp::FUSED_MAX_TERMS);
+        return PP_EINVAL;
+    }
+    if (n <= 0) return 0;
+    pp::FusedTerms t;
+    t.count = n_terms;
+    for (int q = 0; q < n_terms; ++q) {
+        const pp_lw_term& s = terms[q];
+        const int fl = term_flags ? term_flags[q] : 0;
+        const bool two = s.kind == 0 || s.kind == 1;
+        if ((!(fl & 4) && !s.x) || (s.kind != 2 && !((fl & 1) || s.p0)) || (two && !((fl & 2) || s.p1)) ||
+            ((fl & 3) && !two) || (s.kind == 5 && s.p1_stride < 1) || s.kind < 0 || s.kind > 5) {
+            pp::set_error("pp_is_fused: bad term %d", q);
+            return PP_EINVAL;
+        }
+        t.t[q] = pp::FusedTerm{s.kind, s.p0_stride, s.p1_stride, s.x_stride, fl, s.p0, s.p1, s.x, s.scale};
+    }
+    const int tile = 256 * pp::FUSED_PT;
+    const int blocks = std::min(pp::STAT_BLOCKS, pp::cdiv(n, tile));
+    hipStream_t st = pp::as_stream(stream);
+    double* scratch = stats_out ? stats_scratch : nullptr;
+    pp::prof_begin(4, st);
+    if (addr_id < 0) {
+        hipLaunchKernelGGL(pp::is_fused_kernel<-1>, dim3(blocks), dim3(256), 0, st, nullptr, nullptr, n, 0, t, value, lw, overwrite,
+                           seed, offset, scratch);
+    } else {
+        if (!(net && prior && workspace) || addr_id >= net->n_addr) {
+            pp::set_error("pp_is_fused: a draw needs the network, the prior parameters and the workspace of pp_is_step_net");
+            return PP_EINVAL;
+        }
+        const pp_addr& ad = net->addrs[addr_id];
+        if (!(ad.kind == PP_HEAD_NORMAL_MIXTURE || ad.kind == PP_HEAD_TRUNCNORMAL_MIXTURE || ad.kind == PP_HEAD_POISSON_TN_MIXTURE) ||
+            ad.n_out % 3 != 0 || ad.n_out / 3 > pp::MAXK) {
+            pp::set_error("pp_is_fused: mixture heads only");
+            return PP_EINVAL;
+        }
+        pp::IsWorkspace w;
+        pp::is_carve(net, 1, workspace, w);       // the shared row's head outputs, left there by pp_is_step_net
+        if (w.bytes > workspace_bytes) {
+            pp::set_error("pp_is_fused: workspace too small");
+            return PP_ENOSPACE;
+        }
+        const int K = ad.n_out / 3;
+        if (ad.kind == PP_HEAD_NORMAL_MIXTURE)
+            hipLaunchKernelGGL(pp::is_fused_kernel<0>, dim3(blocks), dim3(256), 0, st, w.Y, prior, n, K, t, value, lw, overwrite, seed,
+                               offset, scratch);
+        else if (ad.kind == PP_HEAD_TRUNCNORMAL_MIXTURE)
+            hipLaunchKernelGGL(pp::is_fused_kernel<1>, dim3(blocks), dim3(256), 0, st, w.Y, prior, n, K, t, value, lw, overwrite, seed,
+                               offset, scratch);
+        else
+            hipLaunchKernelGGL(pp::is_fused_kernel<2>, dim3(blocks), dim3(256), 0, st, w.Y, prior, n, K, t, value, lw, overwrite, seed,
+                               offset, scratch);
+    }
+    pp::prof_end(4, 8.0 * n, st);
+    if (stats_out)
+        hipLaunchKernelGGL(pp::is_stats_combine_kernel, dim3(1), dim3(256), 0, st, stats_scratch, blocks, stats_out);
+    PP_LAUNCH_CHECK("pp_is_fused");
+    return 0;
 }
 
 int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,

@@ -77,13 +77,19 @@ class Normal(Distribution):
     def _device(self):
         return self._loc.device
 
+    def _raw_params(self):
+        # per-particle parameters of a lock-step run (state.ParticleTensor) are handed out as they are: building the
+        # torch.distributions object would broadcast - i.e. READ - a value whose draw may still be deferred
+        return self._td is None and (self._loc.shape == self._scale.shape or type(self._loc).__name__ == 'ParticleTensor' or
+                                     type(self._scale).__name__ == 'ParticleTensor')
+
     @property
     def mean(self):
-        return self._loc if self._td is None and self._loc.shape == self._scale.shape else self._torch_dist.mean
+        return self._loc if self._raw_params() else self._torch_dist.mean
 
     @property
     def stddev(self):
-        return self._scale if self._td is None and self._loc.shape == self._scale.shape else self._torch_dist.stddev
+        return self._scale if self._raw_params() else self._torch_dist.stddev
 
     @property
     def variance(self):
@@ -191,6 +197,30 @@ class Empirical:
         self._log_weights = log_weights
         if values is not None and len(values) > 0:
             self.finalize()
+
+    @classmethod
+    def from_device(cls, values, log_weights, device_stats, name='Empirical'):
+        """The result of a lock-step run: ONE device tensor of values, one of log-weights and the importance statistics
+        the device reduced in float64 (pp_is_stats / pp_is_fused). mean / variance / effective_sample_size answer from
+        those; the host copies behind everything else (weights, sampling, slicing ...) are made on first use - a
+        posterior call of 10^6 particles does not pay a 4 MB read-back and a host-side exp per call."""
+        out = cls(name=name)
+        out._values, out._log_weights = values, log_weights
+        out.length = int(log_weights.numel())
+        out.device_stats = device_stats
+        out._finalized = True
+        for k in ('_lw', '_w', '_uniform', '_cum'):      # (set by finalize(); absent = not materialised yet)
+            out.__dict__.pop(k, None)
+        return out
+
+    def __getattr__(self, name):
+        if name in ('_lw', '_w', '_uniform', '_cum') and '_log_weights' in self.__dict__ and self.__dict__.get('_finalized'):
+            self.finalize()          # host-side weights of a device-backed Empirical, on first use
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def _host_weights_ready(self):
+        return '_w' in self.__dict__
 
     # ---- construction ------------------------------------------------------------------------------------
     def add(self, value, log_weight=None, weight=None):
@@ -374,12 +404,22 @@ class Empirical:
                 pass
         return float(np.sum(self._w * np.asarray([float(func(x)) for x in self.get_values()])))
 
+    def _device_moments(self):
+        st = self.__dict__.get('device_stats')
+        return st if (st is not None and not self._host_weights_ready() and torch.is_tensor(self._values)) else None
+
     @property
     def mean(self):
+        st = self._device_moments()
+        if st is not None:
+            return float(st['mean'])
         return float(np.sum(self._w * self.values_numpy()))
 
     @property
     def variance(self):
+        st = self._device_moments()
+        if st is not None:
+            return float(max(st['var'], 0.0))
         v = self.values_numpy()
         return float(np.sum(self._w * (v - self.mean) ** 2))
 
@@ -399,6 +439,9 @@ class Empirical:
 
     @property
     def effective_sample_size(self):
+        st = self._device_moments()
+        if st is not None:
+            return float(st['ess'])
         return float(1.0 / np.sum(self._w ** 2))
 
     @property

@@ -34,6 +34,8 @@ class ISRunner:
         """1-element device tensor holding v (cached: no allocation / H2D copy in the steady state)."""
         t = self._consts.get(v)
         if t is None:
+            if len(self._consts) > 4096:      # (observed values of many posterior calls: keep the cache bounded)
+                self._consts.clear()
             t = torch.tensor([v], dtype=torch.float32, device=self.dev)
             self._consts[v] = t
         return t
@@ -78,6 +80,27 @@ class ISRunner:
         self.last_value = value
         return value, logq
 
+    def step_net(self, addr_id, prev_addr_id):
+        """The network part of `step` only (LSTM step + proposal layer): the head outputs stay in the workspace and the
+        draw happens in `fused`, together with the log-weight terms of the statements that follow."""
+        ops.is_step_net(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
+                        -1 if prev_addr_id is None else int(prev_addr_id), self.n, self.e_obs, self.prev_value, self.h, self.c,
+                        self.state_rows)
+        self.state_rows = 1 if prev_addr_id is None else self.n
+
+    def fused(self, addr_id, prior, terms, value, lw, overwrite, seed=0, stats=False):
+        """ONE pass over the particles: [draw from the shared proposal of `addr_id` (None: values are given), - log q,]
+        lw (+)= sum of `terms`, [importance statistics]. terms = [((kind, p0, s0, p1, s1), x, scale, flags)], flags bit
+        0 / 1 / 2: p0 / p1 / x is the particle's value. Returns the statistics dict when asked for."""
+        kinds, p0s, s0s, p1s, s1s, xs, scales, flags = [], [], [], [], [], [], [], []
+        for (kind, p0, s0, p1, s1), x, scale, fl in terms:
+            kinds.append(int(kind)); p0s.append(p0); s0s.append(int(s0)); p1s.append(p1); s1s.append(int(s1))
+            xs.append(x); scales.append(float(scale)); flags.append(int(fl))
+        out = ops.is_fused(self.ws, self.eng.net_handle, -1 if addr_id is None else int(addr_id),
+                           None if prior is None else prior.reshape(-1), kinds, p0s, s0s, p1s, s1s, xs, scales, flags, value, lw,
+                           bool(overwrite), int(seed), self.offset, self._stats_scratch if stats else None)
+        return self._stats_dict(out) if stats else None
+
     def step_rows(self, rows, addr_id, prev_addr_id, prior, seed=0, prior_compact=False):
         """The same statement for a SUBSET of the particles (a diverged control-flow path): the rows' LSTM state and
         previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor; prior:
@@ -111,6 +134,8 @@ class ISRunner:
         dev = self.dev
 
         def t(v):
+            if isinstance(v, (int, float)) or (torch.is_tensor(v) and v.device.type == 'cpu' and v.numel() == 1):
+                return self._const(float(v))          # cached device scalar: no host-to-device copy per statement
             return torch.as_tensor(v, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(dev).contiguous()
 
         def s(v):
@@ -184,7 +209,11 @@ class ISRunner:
         """Importance statistics (Empirical.finalize / expectation / effective_sample_size,
         pyprob/distributions/empirical.py:298-309, 451-466, 758-766) reduced on the device in float64."""
         self._stats = ops.is_stats(lw, x, self._stats_scratch)
-        m, sw, sw2, swx, swx2, cnt = self._stats[:6].cpu().numpy().tolist()
+        return self._stats_dict(self._stats)
+
+    @staticmethod
+    def _stats_dict(stats):
+        m, sw, sw2, swx, swx2, cnt = stats[:6].cpu().numpy().tolist()
         mean = swx / sw if sw > 0 else float('nan')
         var = swx2 / sw - mean * mean if sw > 0 else float('nan')
         return dict(max_lw=m, sum_w=sw, sum_w2=sw2, sum_wx=swx, sum_wx2=swx2, count=cnt,

@@ -85,9 +85,13 @@ class Model:
                 n_paths += 1
                 if not torch.is_tensor(result):
                     raise RuntimeError('lock-step importance sampling: forward() must return a per-particle tensor')
+                last = not ls.pending           # no queued control-flow path: the statistics ride in this path's last pass
+                if last and ls.active is None and torch.is_tensor(result) and result.numel() == num_traces:
+                    ls.stats_values = result.as_subclass(torch.Tensor).reshape(-1)
+                ls.flush(final=last)            # the deferred draw / log-weight terms of this execution (one pass)
                 result = result.as_subclass(torch.Tensor).reshape(-1).to(runner.dev, torch.float32)
                 if ls.active is None:
-                    values = result.clone() if result.numel() == num_traces else result.expand(num_traces).clone()
+                    values = result if result.numel() == num_traces else result.expand(num_traces).clone()
                 else:
                     if values is None:
                         values = torch.zeros(num_traces, dtype=torch.float32, device=runner.dev)
@@ -98,11 +102,14 @@ class Model:
             state._lock_step = None
             state._current_trace = None
         all_values, all_lw = values, ls.lw
-        values, lw = _drop_non_finite(values, ls.lw)
-        emp = Empirical(values=values, log_weights=lw)
+        stats = ls.final_stats if (ls.final_stats is not None and values is getattr(ls, 'stats_values', None)) else \
+            runner.stats(all_lw, values)
+        lw = all_lw
+        if int(stats['count']) != num_traces:      # non-finite log-weights are discarded like Model._traces does (model.py:64-66)
+            values, lw = _drop_non_finite(values, all_lw)
+            stats = runner.stats(lw, values)
+        emp = Empirical.from_device(values, lw, stats)      # (host arrays are made on demand, not per call)
         emp._all_values, emp._all_log_weights = all_values, all_lw     # (full shard: the distributed gather needs fixed sizes)
-        emp.finalize()
-        emp.device_stats = runner.stats(lw, values)
         emp.num_paths = n_paths
         emp.statement_log = ls.log       # per statement index: {address: (values [n], address id)} - what each path drew
         return emp

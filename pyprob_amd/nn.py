@@ -255,8 +255,28 @@ class InferenceNetworkLSTM:
         self._infer_prev_addr_id = None
 
     def _prior_tensor(self, distribution, n=1):
+        """The prior's parameter pair as the proposal heads read it, [rows, 2] on the device (scalar pairs are cached: no
+        host-to-device copy per statement)."""
+        key = None
+        if distribution.name in ('Normal', 'Uniform'):
+            a, b = (distribution._loc, distribution._scale) if distribution.name == 'Normal' else (distribution._low, distribution._high)
+            if a.numel() == 1 and b.numel() == 1 and a.device.type == 'cpu' and b.device.type == 'cpu':
+                key = (distribution.name, float(a), float(b))
+                cache = self.__dict__.setdefault('_prior_cache', {})
+                hit = cache.get(key)
+                if hit is not None:
+                    return hit
+                if len(cache) > 1024:
+                    cache.clear()
+        p = self._prior_tensor_uncached(distribution)
+        if key is not None:
+            self._prior_cache[key] = p
+        return p
+
+    def _prior_tensor_uncached(self, distribution):
         if distribution.name == 'Normal':
-            p = torch.stack([distribution.mean.reshape(-1), distribution.stddev.reshape(-1)], 1)
+            m, sd = torch.broadcast_tensors(distribution.mean.reshape(-1), distribution.stddev.reshape(-1))
+            p = torch.stack([m, sd], 1)
         elif distribution.name == 'Uniform':
             p = torch.stack([distribution.low.reshape(-1), distribution.high.reshape(-1)], 1)
         elif distribution.name == 'Poisson':      # the head's fixed interval, not the rate
@@ -332,6 +352,23 @@ class InferenceNetworkLSTM:
         a = spec.address_id[address]
         prior = self._prior_tensor(distribution)
         seed = ls.seed + 7919 * j + 104729 * ls.path_id
+        ls.flush()        # an earlier deferred draw is this statement's previous value: it must exist now
+        info = spec.addresses[a]
+        prior_term = runner.dist_term(distribution)
+        if (ls.fused and ls.active is None and ls.prev_addr_id is None and prior_term is not None and prior is not None and
+                prior.numel() == 2 and
+                info.dist_name in ('Normal', 'Uniform', 'Poisson')):
+            # First statement of a trace, full width: every particle has the same proposal. Only the network runs now; the
+            # draw, - log q, + log p and the observe terms that follow become ONE pass over the particles at the next flush.
+            runner.step_net(a, None)
+            values = torch.empty(ls.n, dtype=torch.float32, device=runner.dev)
+            ls.draw = dict(addr=a, prior=prior, values=values, seed=seed, prior_term=prior_term)
+            while len(ls.log) <= j:
+                ls.log.append({})
+            ls.log[j][address] = (values, a)
+            runner.prev_value = runner.last_value = values
+            ls.prev_addr_id = a
+            return ParticleTensor.wrap(values)
         if ls.active is None:
             value, logq = runner.step(a, ls.prev_addr_id, prior, seed=seed)
             values = value

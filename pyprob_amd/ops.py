@@ -44,6 +44,11 @@ _lib.define('is_init(Tensor params, Tensor(a!) workspace, int net, Tensor obs) -
 _lib.define('is_step(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
             'Tensor? prev_value, Tensor? prior, Tensor(b!) h, Tensor(c!) c, int state_rows, Tensor? value_in, int seed, '
             'int offset) -> (Tensor, Tensor)')
+_lib.define('is_step_net(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
+            'Tensor? prev_value, Tensor(b!) h, Tensor(c!) c, int state_rows) -> ()')
+_lib.define('is_fused(Tensor(a!) workspace, int net, int addr_id, Tensor? prior, int[] kinds, Tensor?[] p0, int[] p0_strides, '
+            'Tensor?[] p1, int[] p1_strides, Tensor?[] x, float[] scales, int[] flags, Tensor(b!) value, Tensor(c!) lw, '
+            'bool overwrite, int seed, int offset, Tensor(d!)? stats_scratch) -> Tensor')
 _lib.define('log_prob(int kind, Tensor p0, int p0_stride, Tensor? p1, int p1_stride, Tensor x, int n) -> Tensor')
 _lib.define('logweight_terms(Tensor(a!) lw, int[] kinds, Tensor?[] p0, int[] p0_strides, Tensor?[] p1, int[] p1_strides, '
             'Tensor[] x, float[] scales, bool overwrite) -> ()')
@@ -265,6 +270,51 @@ def _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_v
     return value, logq
 
 
+def _is_step_net_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, h, c, state_rows):
+    lib = L.load()
+    netc = net_struct(net)
+    _same_device(params, workspace, e_obs, prev_value, h, c)
+    ws_bytes = _is_ws(lib, netc, workspace, n)
+    if not (0 <= addr_id < netc.n_addr) or prev_addr_id >= netc.n_addr:
+        raise RuntimeError('pyprob_hip::is_step_net: address id out of range')
+    with torch.cuda.device(params.device):
+        rc = lib.pp_is_step_net(C.byref(netc), params.data_ptr(), int(addr_id), int(prev_addr_id), int(n), e_obs.data_ptr(),
+                                L.ptr(prev_value), L.ptr(h), L.ptr(c), int(state_rows), workspace.data_ptr(), ws_bytes,
+                                _stream(params))
+    L.check(rc, 'pp_is_step_net')
+
+
+def _is_fused_hip(workspace, net, addr_id, prior, kinds, p0, p0_strides, p1, p1_strides, x, scales, flags, value, lw, overwrite,
+                  seed, offset, stats_scratch):
+    lib = L.load()
+    netc = net_struct(net)
+    count = len(kinds)
+    n = value.numel()
+    _same_device(value, lw, workspace, prior, stats_scratch)
+    if _f32(lw, 'lw').numel() != n or not value.is_contiguous() or not lw.is_contiguous():
+        raise RuntimeError('pyprob_hip::is_fused: value and lw must be contiguous float32 vectors of one length')
+    arr = (L.pp_lw_term * max(count, 1))()
+    fl = (C.c_int32 * max(count, 1))()
+    for q in range(count):
+        _same_device(value, p0[q], p1[q], x[q])
+        arr[q].kind = int(kinds[q])
+        arr[q].p0, arr[q].p1, arr[q].x = L.ptr(p0[q]), L.ptr(p1[q]), L.ptr(x[q])
+        arr[q].p0_stride, arr[q].p1_stride = int(p0_strides[q]), int(p1_strides[q])
+        arr[q].x_stride = 0 if (x[q] is None or x[q].numel() == 1) else 1
+        arr[q].scale = float(scales[q])
+        fl[q] = int(flags[q])
+    out = torch.zeros(8, dtype=torch.float64, device=value.device)
+    if stats_scratch is not None and (stats_scratch.dtype != torch.float64 or stats_scratch.numel() < L.PP_IS_STATS_SCRATCH):
+        raise RuntimeError('pyprob_hip::is_fused: scratch must hold PP_IS_STATS_SCRATCH doubles')
+    with torch.cuda.device(value.device):
+        rc = lib.pp_is_fused(C.byref(netc), int(addr_id), n, L.ptr(prior), arr, fl, count, value.data_ptr(), lw.data_ptr(),
+                             1 if overwrite else 0, int(seed), int(offset), out.data_ptr() if stats_scratch is not None else None,
+                             L.ptr(stats_scratch), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                             _stream(value))
+    L.check(rc, 'pp_is_fused')
+    return out
+
+
 def _log_prob_hip(kind, p0, p0_stride, p1, p1_stride, x, n):
     lib = L.load()
     _same_device(x, p0, p1)
@@ -311,6 +361,8 @@ _lib.impl('sgd_step', _sgd_step_hip, 'CUDA')
 _lib.impl('larc_scale', _larc_scale_hip, 'CUDA')
 _lib.impl('is_init', _is_init_hip, 'CUDA')
 _lib.impl('is_step', _is_step_hip, 'CUDA')
+_lib.impl('is_step_net', _is_step_net_hip, 'CUDA')
+_lib.impl('is_fused', _is_fused_hip, 'CUDA')
 _lib.impl('log_prob', _log_prob_hip, 'CUDA')
 _lib.impl('logweight_terms', _logweight_terms_hip, 'CUDA')
 _lib.impl('is_stats', _is_stats_hip, 'CUDA')

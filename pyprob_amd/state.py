@@ -150,6 +150,24 @@ class ParticleTensor(torch.Tensor):
     def wrap(t):
         return t if isinstance(t, ParticleTensor) else torch.as_tensor(t).as_subclass(ParticleTensor)
 
+    # While a draw of the lock-step executor is still DEFERRED (LockStepState.draw: the values' storage exists but is
+    # filled by the fused kernel at the next flush), only operations that do not read the data may run on a ParticleTensor
+    # without forcing that flush: attribute getters, views, passing it as a distribution parameter.
+    _NO_READ = frozenset(('__get__', 'as_subclass', 'reshape', 'view', 'expand', 'numel', 'size', 'dim', 'is_contiguous',
+                          'data_ptr', 'stride', 'storage_offset', 'detach', 'is_floating_point', 'is_complex', 'as_tensor',
+                          'unsqueeze', 'squeeze', 'flatten', 'element_size', 'nelement', '__len__', 'ndimension'))
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        ls = _lock_step
+        if ls is not None and getattr(ls, 'draw', None) is not None:
+            name = getattr(func, '__name__', '')
+            lazy_ok = name in cls._NO_READ or (name in ('float', 'contiguous') and len(args) == 1 and torch.is_tensor(args[0]) and
+                                               args[0].dtype == torch.float32 and args[0].is_contiguous())
+            if not lazy_ok:
+                ls.flush()
+        return super().__torch_function__(func, types, args, kwargs or {})
+
     def __bool__(self):
         plain = self.as_subclass(torch.Tensor)
         ls = _lock_step
@@ -247,11 +265,64 @@ class LockStepState(PathExecutor):
     mode = 'is'
 
     def __init__(self, runner, n, seed, offset):
+        import os
         self.runner = runner
         self.seed = seed
         self.offset = offset
-        self.lw = torch.zeros(n, dtype=torch.float32, device=runner.dev)
+        self._lw = torch.empty(n, dtype=torch.float32, device=runner.dev)
+        self._lw_valid = False        # nothing has been accumulated yet: the first fused pass overwrites instead of adding
+        # Deferred work of the current execution (full-width statements only): `draw` = the first statement's draw from the
+        # shared proposal (its network part has run, pp_is_step_net), `terms` = log-weight terms queued since. flush() runs
+        # them as ONE pass over the particles (pp_is_fused); PP_IS_FUSED=0 keeps one kernel per term (A/B, tests).
+        self.fused = os.environ.get('PP_IS_FUSED', '1') != '0'
+        self.draw = None
+        self.terms = []
+        self.final_stats = None
         super().__init__(n, runner.dev)
+
+    @property
+    def lw(self):
+        """The per-particle log-weight accumulator; eager accumulation paths see a zero-initialised vector."""
+        if not self._lw_valid:
+            self._lw.zero_()
+            self._lw_valid = True
+        return self._lw
+
+    def defer_term(self, term, x, scale):
+        """Queue lw += scale * log_prob(term; x) for the next fused pass."""
+        self.terms.append((term, x, float(scale)))
+        if len(self.terms) >= 7:
+            self.flush()
+
+    def flush(self, final=False):
+        """Run the deferred draw and the queued terms as one pass over the particles; with final=True the importance
+        statistics of (lw, values) come out of the same pass (returned, and kept in final_stats)."""
+        draw, terms = self.draw, self.terms
+        if draw is None and not terms and not final:
+            return None
+        self.draw, self.terms = None, []          # (cleared first: the calls below may touch ParticleTensors)
+        value = draw['values'] if draw is not None else None
+        vptr = None if value is None else value.data_ptr()
+        fterms = []
+        if draw is not None:      # + log p(v) of the program's own prior (state.py:211); - log q(v) is part of the draw
+            fterms.append((draw['prior_term'], value, 1.0, 4))
+
+        def is_value(t):
+            return vptr is not None and t is not None and t.numel() == self.n and t.data_ptr() == vptr
+        for (kind, p0, s0, p1, s1), x, scale in terms:
+            fl = (1 if is_value(p0) else 0) | (2 if is_value(p1) else 0) | (4 if is_value(x) else 0)
+            fterms.append(((kind, p0, s0, p1, s1), x, scale, fl))
+        stats_x = value if value is not None else getattr(self, 'stats_values', None)
+        want_stats = final and stats_x is not None
+        out = self.runner.fused(None if draw is None else draw['addr'], None if draw is None else draw['prior'], fterms,
+                                stats_x if stats_x is not None else self._lw, self._lw, overwrite=not self._lw_valid,
+                                seed=0 if draw is None else draw['seed'], stats=want_stats) \
+            if (draw is not None or fterms or want_stats) else None
+        if draw is not None or fterms:
+            self._lw_valid = True
+        if want_stats:
+            self.final_stats = out
+        return out
 
 
 def _inflate(distribution):
@@ -435,13 +506,20 @@ def _lock_step_likelihood(distribution, value):
     """lw += likelihood_importance * log p(value | .) for the active particles of a lock-step IS run (state.py:147-149;
     also the 'Variable is observed' branch of state.sample, :175-180). A replayed prefix has already been scored."""
     ls = _lock_step
-    v = torch.as_tensor(value, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(ls.runner.dev)
+    if not torch.is_tensor(value) or (value.device.type == 'cpu' and value.numel() == 1):
+        v = ls.runner._const(float(value))       # cached device scalar (no host-to-device copy per statement)
+    else:
+        v = torch.as_tensor(value, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(ls.runner.dev)
     ls.observes += 1
     if ls.observes <= ls.replay_observes:
         return
     term = ls.runner.dist_term(distribution)
     if term is None:
         raise RuntimeError('lock-step importance sampling has no device likelihood for {}'.format(distribution.name))
+    if ls.fused and ls.active is None:       # full width: joins the next fused pass (with the draw, if one is pending)
+        ls.defer_term(term, v, _likelihood_importance)
+        return
+    ls.flush()
     ls.runner.accumulate_masked(ls.lw, None, None, None, v, ls.active, scale=_likelihood_importance, term=term)
 
 

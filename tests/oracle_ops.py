@@ -303,6 +303,39 @@ def _is_stats_cpu(lw, x, scratch):
     return out
 
 
+_NET_STASH = {}      # workspace address -> arguments of the last is_step_net (the device keeps the head outputs there)
+
+
+def _is_step_net_cpu(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, h, c, state_rows):
+    _NET_STASH[workspace.data_ptr()] = (params, net, addr_id, prev_addr_id, n, e_obs, prev_value, h, c, state_rows)
+
+
+def _is_fused_cpu(workspace, net, addr_id, prior, kinds, p0, p0_strides, p1, p1_strides, x, scales, flags, value, lw, overwrite,
+                  seed, offset, stats_scratch):
+    n = value.numel()
+    acc = np.zeros(n, np.float32) if overwrite else lw.numpy().copy()
+    if addr_id >= 0:
+        params, net_, a, prev_a, n_, e_obs, prev_value, h, c, state_rows = _NET_STASH.pop(workspace.data_ptr())
+        assert a == addr_id and n_ == n and net_ == net
+        v, logq = _is_step_cpu(params, workspace, net, addr_id, prev_a, n, e_obs, prev_value, prior.reshape(1, 2), h, c,
+                               state_rows, None, seed, offset)
+        value.copy_(v)
+        acc = (acc - logq.numpy()).astype(np.float32)
+    for q in range(len(kinds)):
+        f = int(flags[q])
+        a0 = value if f & 1 else p0[q]
+        a1 = value if f & 2 else p1[q]
+        xx = value if f & 4 else x[q]
+        s0 = 1 if f & 1 else p0_strides[q]
+        s1 = 1 if f & 2 else p1_strides[q]
+        t = np.asarray(_term(kinds[q], a0, s0, a1, s1, xx, n), np.float32)
+        acc = (acc + np.float32(scales[q]) * t).astype(np.float32)
+    lw.copy_(torch.from_numpy(acc))
+    if stats_scratch is None:
+        return torch.zeros(8, dtype=torch.float64)
+    return _is_stats_cpu(lw, value, stats_scratch)
+
+
 _registered = False
 
 
@@ -312,7 +345,8 @@ def register():
         return
     for name, fn in (('ic_loss', _ic_loss_cpu), ('adam_step', _adam_step_cpu), ('sgd_step', _sgd_step_cpu),
                      ('larc_scale', _larc_scale_cpu), ('is_init', _is_init_cpu),
-                     ('is_step', _is_step_cpu), ('log_prob', _log_prob_cpu), ('logweight_terms', _logweight_terms_cpu),
+                     ('is_step', _is_step_cpu), ('is_step_net', _is_step_net_cpu), ('is_fused', _is_fused_cpu),
+                     ('log_prob', _log_prob_cpu), ('logweight_terms', _logweight_terms_cpu),
                      ('is_stats', _is_stats_cpu)):
         P._lib.impl(name, fn, 'CPU')
     _registered = True

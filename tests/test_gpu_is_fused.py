@@ -1,0 +1,97 @@
+"""The fused posterior pass (pp_is_step_net + pp_is_fused: draw, - log q, + log p, the observe terms that follow and the
+importance statistics in ONE pass over the particles, state.LockStepState.flush) against the one-kernel-per-term path
+(PP_IS_FUSED=0) through the drop-in API Model.posterior_results: same Philox stream -> bit-identical values, equal
+log-weights and statistics; host-side Empirical reductions equal the device statistics."""
+import numpy as np
+import pytest
+
+from models import GaussianWithUnknownMean, GaussianWithUnknownMeanMarsagliaLockStep
+from pyprob_amd.state import InferenceEngine, InferenceNetwork
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+IC = InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
+OBS = {'obs0': 8, 'obs1': 9}
+EMB = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
+
+
+@pytest.fixture(scope='module')
+def gum():
+    torch.manual_seed(3)
+    model = GaussianWithUnknownMean()
+    model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=20000, observe_embeddings=EMB, batch_size=128,
+                                  lstm_dim=64, seed=1)
+    return model
+
+
+@pytest.fixture(scope='module')
+def gumm():
+    torch.manual_seed(4)
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=20000, observe_embeddings=EMB, batch_size=128,
+                                  lstm_dim=64, seed=2)
+    return model
+
+
+def _both(model, n, monkeypatch, observe, seed):
+    monkeypatch.setenv('PP_IS_FUSED', '1')
+    fused = model.posterior_results(n, IC, observe=observe, lock_step=True, seed=seed)
+    monkeypatch.setenv('PP_IS_FUSED', '0')
+    eager = model.posterior_results(n, IC, observe=observe, lock_step=True, seed=seed)
+    return fused, eager
+
+
+@pytest.mark.parametrize('n', [1000, 65537, 1000000])
+def test_fused_pass_equals_the_per_term_kernels(gum, monkeypatch, n):
+    fused, eager = _both(gum, n, monkeypatch, OBS, seed=11)
+    vf, ve = fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy()
+    assert np.array_equal(vf, ve)                              # the same Philox stream, the same draw arithmetic
+    lf, le = fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy()
+    np.testing.assert_allclose(lf, le, rtol=2e-6, atol=2e-6)
+    for k in ('mean', 'var', 'ess', 'max_lw', 'count'):
+        assert abs(fused.device_stats[k] - eager.device_stats[k]) <= 1e-6 * max(1.0, abs(eager.device_stats[k])), k
+    assert fused.length == n and int(fused.device_stats['count']) == n
+    # the device statistics are what the reference's Empirical computes on the host in float64
+    mean_dev, ess_dev, std_dev = fused.mean, fused.effective_sample_size, fused.stddev
+    w = fused.weights_numpy()                                  # materialises the host-side weights
+    v = fused.values_numpy()
+    assert abs(float(np.sum(w * v)) - mean_dev) < 1e-6 * max(1.0, abs(mean_dev))
+    assert abs(1.0 / float(np.sum(w * w)) - ess_dev) < 1e-6 * ess_dev
+    assert abs(fused.mean - mean_dev) < 1e-9 and abs(fused.stddev - std_dev) < 1e-6
+    assert abs(fused.mean - 7.25) < 0.75
+
+
+def test_fused_pass_in_a_program_with_control_flow(gumm, monkeypatch):
+    """First statement deferred (Uniform prior -> TruncatedNormal mixture), flushed by the second statement; the diverging
+    paths take the per-term kernels; the observe terms of every path are queued and flushed once per path."""
+    obs = {'obs0': 4, 'obs1': 5}
+    fused, eager = _both(gumm, 20000, monkeypatch, obs, seed=5)
+    assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())
+    np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    assert fused.num_paths == eager.num_paths > 1
+    assert abs(fused.device_stats['ess'] - eager.device_stats['ess']) <= 1e-5 * eager.device_stats['ess']
+
+
+class GumShifted(GaussianWithUnknownMean):
+    """The same program, but it LOOKS at the sampled value (arithmetic on it) before the observes."""
+
+    def forward(self):
+        import pyprob_amd as pyprob
+        from pyprob_amd.distributions import Normal
+        mu = pyprob.sample(Normal(self.prior_mean, self.prior_stddev))
+        centre = mu * 1.0 + 0.0                                # reads the value: a deferred draw has to run here
+        likelihood = Normal(centre, self.likelihood_stddev)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+def test_reading_a_deferred_value_materialises_it(monkeypatch):
+    torch.manual_seed(5)
+    model = GumShifted()
+    model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=8000, observe_embeddings=EMB, batch_size=128,
+                                  lstm_dim=64, seed=3)
+    fused, eager = _both(model, 30000, monkeypatch, OBS, seed=9)
+    assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())
+    np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    assert np.all(np.isfinite(fused._all_log_weights.cpu().numpy()))
