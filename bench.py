@@ -209,6 +209,103 @@ def cpu_baseline_is(n=20000):
                        'reference)' % m)
 
 
+def api_models():
+    """The reference's two test programs (tests/test_inference.py:97-109, 252-275) written against the drop-in API
+    (pyprob_amd.sample / observe / Model); the Marsaglia rejection loop uses a tensor condition so that it runs in lock step."""
+    import math
+    import pyprob_amd as pyprob
+    from pyprob_amd import Model
+    from pyprob_amd.distributions import Normal, Uniform
+
+    class GaussianWithUnknownMean(Model):
+        def __init__(self):
+            self.prior_mean, self.prior_stddev, self.likelihood_stddev = 1, math.sqrt(5), math.sqrt(2)
+            super().__init__('Gaussian with unknown mean')
+
+        def forward(self):
+            mu = pyprob.sample(Normal(self.prior_mean, self.prior_stddev))
+            likelihood = Normal(mu, self.likelihood_stddev)
+            pyprob.observe(likelihood, name='obs0')
+            pyprob.observe(likelihood, name='obs1')
+            return mu
+
+    class GaussianWithUnknownMeanMarsaglia(Model):
+        def __init__(self):
+            self.prior_mean, self.prior_stddev, self.likelihood_stddev = 1, math.sqrt(5), math.sqrt(2)
+            super().__init__('Gaussian with unknown mean (Marsaglia)')
+
+        def marsaglia(self, mean, stddev):
+            uniform = Uniform(-1, 1)
+            s = 1
+            while s >= 1:
+                x = pyprob.sample(uniform)
+                y = pyprob.sample(uniform)
+                s = x * x + y * y
+            return mean + stddev * (x * torch.sqrt(-2 * torch.log(s) / s))
+
+        def forward(self):
+            mu = self.marsaglia(self.prior_mean, self.prior_stddev)
+            likelihood = Normal(mu, self.likelihood_stddev)
+            pyprob.observe(likelihood, name='obs0')
+            pyprob.observe(likelihood, name='obs1')
+            return mu
+    return GaussianWithUnknownMean, GaussianWithUnknownMeanMarsaglia
+
+
+def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='gum', seed0=7, offset=0, train_traces=None):
+    """BASELINE.json configs[3] through the drop-in API: Model.learn_inference_network (a short run: the network only has to
+    exist and be sane) then `calls` x Model.posterior_results(particles, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
+    observe={'obs0': 8, 'obs1': 9}) on the user's forward() in lock step - state.sample / state.observe / Trace.end and the
+    Empirical statistics are all on the timed path (pyprob/model.py:47-88, 180-181; state.py:118-155, 203-219).
+    Returns (record, seconds, units)."""
+    import contextlib
+    import io
+    from pyprob_amd.state import InferenceEngine, InferenceNetwork
+    GUM, GUMM = api_models()
+    model = (GUM if program == 'gum' else GUMM)()
+    torch.manual_seed(123)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.learn_inference_network(num_traces=train_traces or (64 * 1024 if program == 'gum' else 96 * 1024),
+                                      inference_network=InferenceNetwork.LSTM,
+                                      observe_embeddings={'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, batch_size=1024, lstm_dim=lstm_dim,
+                                      seed=1)
+    IC = InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
+    observe = {'obs0': 8, 'obs1': 9} if program == 'gum' else {'obs0': 4, 'obs1': 5}
+    for i in range(warm):
+        post = model.posterior_results(particles, IC, observe=observe, lock_step=True, seed=i, offset=offset)
+    lib.pp_prof_arm(4, calls * 4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(calls):
+        post = model.posterior_results(particles, IC, observe=observe, lock_step=True, seed=seed0 + i, offset=offset)
+        _ = post.effective_sample_size           # (the caller looks at the result: mean / ESS are read back every call)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = np.zeros(calls * 4, np.float32)
+    fl = np.zeros(calls * 4, np.float64)
+    cnt = C.c_int32(0)
+    lib.pp_prof_collect(ms.ctypes.data, calls * 4, C.byref(cnt), fl.ctypes.data)
+    lib.pp_prof_arm(4, 0)
+    rec = dict(particles_per_sec=round(particles * calls / dt, 1), ms_per_call=round(dt / calls * 1e3, 4), particles_per_call=particles,
+               calls=calls, program='GaussianUnknownMean' if program == 'gum' else 'GaussianUnknownMeanMarsaglia (tensor-condition loop)',
+               api='Model.posterior_results(N, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe=..., lock_step=True) on the '
+                   "user's forward()", posterior_mean=round(float(post.mean), 4), posterior_stddev=round(float(post.stddev), 4),
+               ess=round(float(post.effective_sample_size), 1), control_flow_paths=int(getattr(post, 'num_paths', 1)),
+               network_params=model._inference_network._engine.spec.num_parameters())
+    if cnt.value > 0:
+        per_call_us = float(ms[:cnt.value].sum()) * 1e3 / calls
+        nbytes = float(fl[:cnt.value].sum()) / calls
+        rec['particle_kernels'] = dict(
+            bound='hbm', achieved=round(nbytes / (per_call_us * 1e-6) / 1e9, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+            frac=round(nbytes / (per_call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), us_per_call=round(per_call_us, 3),
+            launches_per_call=round(cnt.value / calls, 2), bytes_per_call=nbytes,
+            kernel='is_fused_kernel (draw from the shared proposal + log q + prior / likelihood terms + float64 statistics '
+                   'partials in one pass: 8 B per particle written) [+ per-row draw kernels of later statements]; HIP event '
+                   'pairs around the launches; compute-bound on Philox + logsumexp over K components, not on HBM',
+            wall_over_kernel=round(dt / calls * 1e6 / per_call_us, 2))
+    return rec, dt, particles * calls
+
+
 def _claim_stdout():
     """stdout must carry exactly ONE line, rank 0's JSON. Everything else this process writes to file descriptor 1 - RCCL
     prints a five-line version banner at its first communicator, libraries warn now and then - is sent to stderr: returns a
@@ -255,6 +352,7 @@ def main():
     ap.add_argument('--dataset', type=int, default=1000000, help='offline traces resident in HBM (per job)')
     ap.add_argument('--particles', type=int, default=1000000, help='IS particles per job')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-is', action='store_true', help='skip the posterior_results sub-record of the default line')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a captured HIP graph (1) or launch eagerly (0)')
     ap.add_argument('--prewarm-s', type=float, default=0.35, help='untimed steady-state pre-warm before the --warmup steps')
     args = ap.parse_args()
@@ -524,6 +622,10 @@ def main():
                       loop_probe_us_per_step={k: round(v * 1e6, 2) for k, v in probe.items()},
                       allreduce_bytes_per_step=(4 * (eng.grads_full.numel() - sum(c for _, c in eng.dp_skip)) if use_dist else 0),
                       dp_exchange=dp_exchange)
+        if world == 1 and not args.no_is:
+            # the other half of BASELINE.json's metric in the same line: particles/s of posterior_results through the API
+            # (configs[3] on one GPU; `--workload is` is the full record incl. the control-flow program)
+            out['is'] = api_posterior_bench(lib, device, args.lstm_dim, 1000000, 20, 3, 'gum')[0]
     elif args.workload == 'train_gumm':
         # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
         # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded
@@ -580,47 +682,21 @@ def main():
                 flops_per_launch=flops, kernel='grouped weight-gradient launch holding dW_ih / dW_hh of the backward pass '
                                                '(the head products of the %d addresses ride in the same grouped launches)' % len(addresses))
     else:
-        from pyprob_amd.is_engine import ISRunner, gum_posterior
+        # BASELINE.json configs[3]: posterior_results through the drop-in API, particles sharded over the ranks (no collective on
+        # the data path: distinct Philox counter ranges per rank)
         n = args.particles // world
-        run = ISRunner(eng)
-        for i in range(W):
-            gum_posterior(eng, n, seed=rank, offset=rank * n, runner=run)
-        lib.pp_prof_arm(4, K)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(K):
-            st = gum_posterior(eng, n, seed=7 + i, offset=rank * n, runner=run)
-        barrier()
-        dt = time.perf_counter() - t0
-        ms = np.zeros(K, np.float32)
-        fl = np.zeros(K, np.float64)
-        cnt = C.c_int32(0)
-        lib.pp_prof_collect(ms.ctypes.data, K, C.byref(cnt), fl.ctypes.data)
-        lib.pp_prof_arm(4, 0)
-        units = n * K
+        del eng
+        rec, dt, units = api_posterior_bench(lib, device, args.lstm_dim, n, K, max(W, 3), 'gum', offset=rank * n)
         metric, unit = 'is_posterior_particles_per_sec', 'particles/s'
-        # HBM roofline of the per-particle chain (the network itself runs once for one shared row): algorithmic bytes per
-        # particle = sample kernel writes value + log q (8) ; fused log-weight pass reads them and writes lw (12) ; the two
-        # statistics passes read lw twice and the value once (12) = 32 B
-        bytes_per_particle = 32.0
-        ach = units * bytes_per_particle / dt / 1e9
-        out['roofline'] = dict(bound='hbm', achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s',
-                               frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                               kernel='is_mixture_shared_kernel<0> + logweight_multi_kernel + is_stats_partial_kernel (whole '
-                                      'posterior call incl. the batch-1 network evaluation, wall-clock; the sampling kernel '
-                                      'is transcendental-bound, see profiles/)')
-        if cnt.value > 0:
-            avg_ms, nbytes = float(ms[:cnt.value].mean()), float(fl[0])
-            k_ach = nbytes / (avg_ms * 1e-3) / 1e9
-            out['roofline']['dominant_kernel'] = dict(
-                bound='hbm', achieved=round(k_ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(k_ach / HBM_PEAK_GBS, 5),
-                avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=int(cnt.value), bytes_per_launch=nbytes,
-                kernel='is_mixture_shared_kernel<0> (Philox draw of the mixture component and the value + log q per particle; '
-                       'transcendental-bound: logsumexp over K components, inverse CDF)')
-        config = dict(workload='GaussianUnknownMean posterior_results IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, '
-                               'LSTM hidden=%d, %d particles per posterior call per GPU' % (args.lstm_dim, n),
-                      particles_per_call=n * world, parallelism='particles sharded x%d' % world,
-                      ess=round(st['ess'], 1), posterior_mean=round(st['mean'], 4))
+        pk = rec.pop('particle_kernels', None)
+        out['roofline'] = pk if pk else dict(bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=None)
+        out['roofline'].setdefault('traffic', None)
+        config = dict(workload='GaussianUnknownMean posterior_results IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK through '
+                               'Model.posterior_results on the user program, LSTM hidden=%d, %d particles per call per GPU'
+                               % (args.lstm_dim, n), parallelism='particles sharded x%d' % world, **rec)
+        if world == 1:      # the N-row network step: a program with stochastic control flow in lock step
+            g, _, _ = api_posterior_bench(lib, device, args.lstm_dim, 200000, max(3, K // 10), 2, 'gumm')
+            out['gumm_lockstep'] = g
 
     # max over ranks
     if use_dist:

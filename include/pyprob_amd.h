@@ -424,7 +424,7 @@ int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream);
  * 451-466, 758-766): out (dev, double[6]) = { max lw, sum w, sum w^2, sum w*x, sum w*x^2, count finite } with
  * w = exp(lw - max lw) evaluated in fp64. ESS = (sum w)^2 / sum w^2. One pass over the particles (per-workgroup maxima, rescaled by a
  * one-workgroup combine); `scratch` dev >= PP_IS_STATS_SCRATCH doubles. */
-#define PP_IS_STATS_SCRATCH 1536
+#define PP_IS_STATS_SCRATCH 6144
 int pp_is_stats(const float* lw, const float* x, int32_t n, double* out, double* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

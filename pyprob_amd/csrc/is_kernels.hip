@@ -621,7 +621,8 @@ __global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __r
     __shared__ double shm[4];
     __shared__ double sh[4][5];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const double m = tid < nblocks ? scratch[tid * 6] : -INFINITY;
+    double m = -INFINITY;       // maximum over this thread's partials b = tid, tid + 256, ...
+    for (int b = tid; b < nblocks; b += 256) m = fmax(m, scratch[b * 6]);
     double gm = m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o, 64));
@@ -629,13 +630,15 @@ __global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __r
     __syncthreads();
     gm = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
     double S[5] = {0, 0, 0, 0, 0};
-    if (tid < nblocks && m > -INFINITY) {
-        const double r = exp(m - gm);
-        S[0] = scratch[tid * 6 + 1] * r;
-        S[1] = scratch[tid * 6 + 2] * r * r;
-        S[2] = scratch[tid * 6 + 3] * r;
-        S[3] = scratch[tid * 6 + 4] * r;
-        S[4] = scratch[tid * 6 + 5];
+    for (int b = tid; b < nblocks; b += 256) {
+        const double mb = scratch[b * 6];
+        if (!(mb > -INFINITY)) continue;
+        const double r = exp(mb - gm);
+        S[0] += scratch[b * 6 + 1] * r;
+        S[1] += scratch[b * 6 + 2] * r * r;
+        S[2] += scratch[b * 6 + 3] * r;
+        S[3] += scratch[b * 6 + 4] * r;
+        S[4] += scratch[b * 6 + 5];
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
@@ -685,7 +688,8 @@ __global__ __launch_bounds__(256) void logweight_multi_kernel(const LwTerms term
 // (per-workgroup maximum, fp64 sums relative to it, rescaled by is_stats_combine_kernel).
 //   term parameters flagged "value" read the particle's freshly drawn value (e.g. the mean of the likelihood Normal(mu, s)
 //   of observe statements that follow `mu = sample(...)`), so the program's statements up to the next sample are one pass.
-constexpr int FUSED_PT = 8;          // particles per thread per tile
+constexpr int FUSED_PT = 4;          // particles per thread at 1M particles (grid sizing)
+constexpr int FUSED_BLOCKS = 1024;   // workgroups at most (4 per CU: the per-particle chain is long and latency-bound)
 constexpr int FUSED_MAX_TERMS = 8;
 struct FusedTerm {
     int kind, s0, s1, sx, flags;     // flags: 1 p0 = value, 2 p1 = value, 4 x = value
@@ -698,7 +702,7 @@ struct FusedTerms {
 };
 
 template <int KIND>      // -1: no draw (values are read), 0 / 1 / 2: mixture head kinds as is_mixture_shared_kernel
-__global__ __launch_bounds__(256) void is_fused_kernel(const float* __restrict__ y, const float* __restrict__ prior, int n, int K,
+__global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restrict__ y, const float* __restrict__ prior, int n, int K,
                                                        const FusedTerms terms, float* __restrict__ value,
                                                        float* __restrict__ lw, int overwrite, uint64_t seed, uint64_t offset,
                                                        double* __restrict__ scratch) {
@@ -743,105 +747,119 @@ __global__ __launch_bounds__(256) void is_fused_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    double M = -INFINITY;
+    // Normal terms whose scale is one number for all particles: their constants once per workgroup (LDS). The term loop is
+    // NOT unrolled: eight unrolled copies kept ~100 scalar term fields live and spilled them into vector registers
+    // (189 VGPRs, two waves per SIMD for a latency-bound kernel).
+    __shared__ float s_tc0[FUSED_MAX_TERMS], s_tc1[FUSED_MAX_TERMS];
+    __shared__ int s_tcok[FUSED_MAX_TERMS];
+    if (tid < FUSED_MAX_TERMS) {
+        const int t = tid;
+        s_tcok[t] = 0; s_tc0[t] = 0.0f; s_tc1[t] = 0.0f;
+        if (t < terms.count && terms.t[t].kind == 0 && !(terms.t[t].flags & 2) && terms.t[t].s1 == 0) {
+            const float b = terms.t[t].p1[0];
+            s_tcok[t] = 1;
+            s_tc0[t] = -logf(b) - kHalfLog2Pi;
+            s_tc1[t] = 1.0f / (2.0f * b * b);
+        }
+    }
+    __syncthreads();
+    // statistics: every thread keeps (m, sums relative to m) of ITS particles - a new maximum rescales the thread's sums
+    // (rare after its first particles) - and the workgroup's threads meet once at the end; no per-tile barrier, no per-
+    // particle arrays: the loop body is one particle, 8 waves per SIMD hide its latency chain
+    float m_t = -INFINITY;
     double S[5] = {0, 0, 0, 0, 0};
-    const int tile = 256 * FUSED_PT;
-    for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile) {
-        float l[FUSED_PT], xv[FUSED_PT];
-        float m = -INFINITY;
-#pragma unroll
-        for (int q = 0; q < FUSED_PT; ++q) {
-            const int i = base + q * 256 + tid;
-            l[q] = -INFINITY; xv[q] = 0.0f;
-            if (i >= n) continue;
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
             float v, acc = overwrite ? 0.0f : lw[i];
-            if (KIND < 0) {
-                v = value[i];
-            } else {
-                Philox rng(seed, offset + (uint64_t)i, 0x1C);
-                v = NAN;
-                for (int attempt = 0; attempt < 64; ++attempt) {
-                    uint32_t r[4];
-                    rng.next(r);
-                    const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
-                    int kk = K - 1;
-                    for (int k = K - 2; k >= 0; --k)
-                        if (u0 < s_cum[k]) kk = k;
-                    const float mk = s_mu[kk], sk = s_sd[kk];
-                    if (KIND == 0) {
-                        v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);
-                        break;
-                    } else {
-                        const float uu = s_ca[kk] + u1 * (s_cb[kk] - s_ca[kk]);
-                        v = mk + sk * kSqrt2 * erfinvf(2.0f * uu - 1.0f);
-                        if (isfinite(v) && v >= pa && v < pb) break;
-                        v = NAN;
-                    }
+        if (KIND < 0) {
+            v = value[i];
+        } else {
+            Philox rng(seed, offset + (uint64_t)i, 0x1C);
+            v = NAN;
+            for (int attempt = 0; attempt < 64; ++attempt) {
+                uint32_t r[4];
+                rng.next(r);
+                const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
+                int kk = K - 1;
+                for (int k = K - 2; k >= 0; --k)
+                    if (u0 < s_cum[k]) kk = k;
+                const float mk = s_mu[kk], sk = s_sd[kk];
+                if (KIND == 0) {
+                    v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);
+                    break;
+                } else {
+                    const float uu = s_ca[kk] + u1 * (s_cb[kk] - s_ca[kk]);
+                    v = mk + sk * kSqrt2 * erfinvf(2.0f * uu - 1.0f);
+                    if (isfinite(v) && v >= pa && v < pb) break;
+                    v = NAN;
                 }
-                const bool inside = (KIND == 0) || (v >= pa && v <= pb);
-                float a[MAXK], amax = -INFINITY;
+            }
+            const bool inside = (KIND == 0) || (v >= pa && v <= pb);
+            float a[MAXK], amax = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (k < K) {
+                    const float t = (v - s_mu[k]) * s_inv[k];
+                    a[k] = inside ? s_c[k] - 0.5f * t * t : -INFINITY;
+                    amax = fmaxf(amax, a[k]);
+                }
+            float lq = amax;
+            if (amax > -INFINITY) {      // (hardware exp2 / log2: ~1e-6 absolute on log q, the 1e-4 bar is on log-weights)
+                float sum = 0.0f;
 #pragma unroll
                 for (int k = 0; k < MAXK; ++k)
-                    if (k < K) {
-                        const float t = (v - s_mu[k]) * s_inv[k];
-                        a[k] = inside ? s_c[k] - 0.5f * t * t : -INFINITY;
-                        amax = fmaxf(amax, a[k]);
-                    }
-                float lq = amax;
-                if (amax > -INFINITY) {
-                    float sum = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < MAXK; ++k)
-                        if (k < K) sum += expf(a[k] - amax);
-                    lq = amax + logf(sum);
-                }
-                acc -= lq;                 // - log q(v)   (state.py:212, 217)
-                value[i] = v;
+                    if (k < K) sum += __expf(a[k] - amax);
+                lq = amax + __logf(sum);
             }
-            for (int t = 0; t < terms.count; ++t) {
-                const FusedTerm& T = terms.t[t];
-                const float x = (T.flags & 4) ? v : T.x[(int64_t)i * T.sx];
-                float lp;
-                if (T.kind == 2) {
-                    lp = x;
-                } else if (T.kind == 0 || T.kind == 1) {      // two parameters, either may BE the drawn value
-                    const float pa_ = (T.flags & 1) ? v : T.p0[(int64_t)i * T.s0];
-                    const float pb_ = (T.flags & 2) ? v : T.p1[(int64_t)i * T.s1];
-                    if (T.kind == 0) {
-                        const float d = x - pa_;
-                        lp = -(d * d) / (2.0f * pb_ * pb_) - logf(pb_) - kHalfLog2Pi;
+            acc -= lq;                 // - log q(v)   (state.py:212, 217)
+            value[i] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < FUSED_MAX_TERMS; ++t) {
+            if (t >= terms.count) break;
+            const FusedTerm& T = terms.t[t];
+            const float x = (T.flags & 4) ? v : T.x[(int64_t)i * T.sx];
+            float lp;
+            if (T.kind == 2) {
+                lp = x;
+            } else if (T.kind == 0 || T.kind == 1) {      // two parameters, either may BE the drawn value
+                const float pa_ = (T.flags & 1) ? v : T.p0[(int64_t)i * T.s0];
+                const float pb_ = (T.flags & 2) ? v : T.p1[(int64_t)i * T.s1];
+                if (T.kind == 0) {
+                    const float d = x - pa_;
+                    if (s_tcok[t]) {      // constant scale: - log b - log sqrt(2 pi) and 1 / (2 b^2) once per thread
+                        lp = s_tc0[t] - d * d * s_tc1[t];
                     } else {
-                        lp = (x >= pa_ && x < pb_) ? -logf(pb_ - pa_) : -INFINITY;
+                        lp = -(d * d) / (2.0f * pb_ * pb_) - logf(pb_) - kHalfLog2Pi;
                     }
                 } else {
-                    lp = term_log_prob(T.kind, T.p0, T.s0, T.p1, T.s1, x, i);
+                    lp = (x >= pa_ && x < pb_) ? -logf(pb_ - pa_) : -INFINITY;
                 }
-                acc += T.scale * lp;
+            } else {
+                lp = term_log_prob(T.kind, T.p0, T.s0, T.p1, T.s1, x, i);
             }
-            lw[i] = acc;
-            l[q] = acc; xv[q] = v;
-            if (isfinite(acc)) m = fmaxf(m, acc);
+            acc += T.scale * lp;
         }
-        if (!scratch) continue;
-        m = wave_max(m);
-        if (lane == 0) shmax[wave] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
-        __syncthreads();
-        if (m == -INFINITY) continue;
-        if ((double)m > M) {
-            const double r = M == -INFINITY ? 0.0 : exp(M - (double)m);
-            S[0] *= r; S[1] *= r * r; S[2] *= r; S[3] *= r;
-            M = (double)m;
-        }
-#pragma unroll
-        for (int q = 0; q < FUSED_PT; ++q) {
-            if (!isfinite(l[q])) continue;
-            const double e = exp((double)l[q] - M), xd = (double)xv[q];
+        lw[i] = acc;
+        if (scratch && isfinite(acc)) {      // Model._traces drops non-finite weights (model.py:65-68)
+            if (acc > m_t) {
+                const double r = m_t == -INFINITY ? 0.0 : (double)expf(m_t - acc);
+                S[0] *= r; S[1] *= r * r; S[2] *= r; S[3] *= r;
+                m_t = acc;
+            }
+            // fp32 exponent of an exact fp32 difference <= 0 (relative error 1e-7 per weight), float64 sums
+            const double e = (double)expf(acc - m_t), xd = (double)v;
             S[0] += e; S[1] += e * e; S[2] += e * xd; S[3] += e * xd * xd; S[4] += 1.0;
         }
     }
     if (!scratch) return;
+    float M = wave_max(m_t);
+    if (lane == 0) shmax[wave] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
+    {
+        const double r = (m_t == -INFINITY || M == -INFINITY) ? 0.0 : (double)expf(m_t - M);
+        S[0] *= r; S[1] *= r * r; S[2] *= r; S[3] *= r;
+    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         const double r = wave_sum(S[q]);
@@ -849,7 +867,7 @@ __global__ __launch_bounds__(256) void is_fused_kernel(const float* __restrict__
     }
     __syncthreads();
     if (tid < 5) scratch[blockIdx.x * 6 + 1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
-    if (tid == 0) scratch[blockIdx.x * 6] = M;
+    if (tid == 0) scratch[blockIdx.x * 6] = (double)M;
 }
 
 // kinds 0, 1 read p1; 3, 4 ignore it; 5 carries the number of categories in p1_stride
@@ -914,7 +932,7 @@ int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prio
         t.t[q] = pp::FusedTerm{s.kind, s.p0_stride, s.p1_stride, s.x_stride, fl, s.p0, s.p1, s.x, s.scale};
     }
     const int tile = 256 * pp::FUSED_PT;
-    const int blocks = std::min(pp::STAT_BLOCKS, pp::cdiv(n, tile));
+    const int blocks = std::min(pp::FUSED_BLOCKS, pp::cdiv(n, tile));
     hipStream_t st = pp::as_stream(stream);
     double* scratch = stats_out ? stats_scratch : nullptr;
     pp::prof_begin(4, st);

@@ -62,8 +62,9 @@ class Normal(Distribution):
 
     def __init__(self, loc, scale):
         loc, scale = _t(loc).float(), _t(scale).float()
-        if scale.device != loc.device:
-            scale = scale.to(loc.device)
+        if scale.device != loc.device and not (scale.numel() == 1 and scale.device.type == 'cpu'):
+            scale = scale.to(loc.device)      # (a host scalar next to device locations stays where it is: the device kernels take
+                                              #  it as a cached constant, and a posterior call pays no copy for it)
         if scale.numel() == 1 and scale.device.type == 'cpu' and not float(scale) > 0.0:   # (what torch's validation rejects)
             raise ValueError('Normal: the scale must be positive, got {}'.format(float(scale)))
         self._loc, self._scale = loc, scale
@@ -72,7 +73,8 @@ class Normal(Distribution):
     def _make_torch_dist(self):
         # per-particle parameters of a lock-step run may hold stale (even NaN) entries for particles that are not on the
         # current control-flow path: no argument validation for vectors
-        return torch.distributions.Normal(self._loc, self._scale, validate_args=None if self._loc.numel() == 1 else False)
+        scale = self._scale if self._scale.device == self._loc.device else self._scale.to(self._loc.device)
+        return torch.distributions.Normal(self._loc, scale, validate_args=None if self._loc.numel() == 1 else False)
 
     def _device(self):
         return self._loc.device

@@ -24,7 +24,7 @@ def larc_scratch_floats(n_params, n_tensors):
     return 2 * (int(n_params) // 1024) + int(n_tensors)
 
 
-PP_IS_STATS_SCRATCH = 1536   # doubles (include/pyprob_amd.h)
+PP_IS_STATS_SCRATCH = 6144   # doubles (include/pyprob_amd.h)
 
 i32, i64, f32p, i32p, vp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p
 

@@ -102,8 +102,10 @@ class Model:
             state._lock_step = None
             state._current_trace = None
         all_values, all_lw = values, ls.lw
-        stats = ls.final_stats if (ls.final_stats is not None and values is getattr(ls, 'stats_values', None)) else \
-            runner.stats(all_lw, values)
+        sv = getattr(ls, 'stats_values', None)
+        same = (ls.final_stats is not None and sv is not None and values is not None and sv.data_ptr() == values.data_ptr() and
+                sv.numel() == values.numel())
+        stats = ls.final_stats if same else runner.stats(all_lw, values)
         lw = all_lw
         if int(stats['count']) != num_traces:      # non-finite log-weights are discarded like Model._traces does (model.py:64-66)
             values, lw = _drop_non_finite(values, all_lw)

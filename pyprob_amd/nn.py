@@ -275,8 +275,10 @@ class InferenceNetworkLSTM:
 
     def _prior_tensor_uncached(self, distribution):
         if distribution.name == 'Normal':
-            m, sd = torch.broadcast_tensors(distribution.mean.reshape(-1), distribution.stddev.reshape(-1))
-            p = torch.stack([m, sd], 1)
+            m, sd = distribution.mean.reshape(-1), distribution.stddev.reshape(-1)
+            if sd.device != m.device:         # (a host scalar next to per-particle device means, distributions.Normal)
+                sd = sd.to(m.device)
+            p = torch.stack(torch.broadcast_tensors(m, sd), 1)
         elif distribution.name == 'Uniform':
             p = torch.stack([distribution.low.reshape(-1), distribution.high.reshape(-1)], 1)
         elif distribution.name == 'Poisson':      # the head's fixed interval, not the rate

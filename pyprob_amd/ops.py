@@ -303,7 +303,7 @@ def _is_fused_hip(workspace, net, addr_id, prior, kinds, p0, p0_strides, p1, p1_
         arr[q].x_stride = 0 if (x[q] is None or x[q].numel() == 1) else 1
         arr[q].scale = float(scales[q])
         fl[q] = int(flags[q])
-    out = torch.zeros(8, dtype=torch.float64, device=value.device)
+    out = torch.empty(8, dtype=torch.float64, device=value.device)      # (the combine kernel writes the six statistics)
     if stats_scratch is not None and (stats_scratch.dtype != torch.float64 or stats_scratch.numel() < L.PP_IS_STATS_SCRATCH):
         raise RuntimeError('pyprob_hip::is_fused: scratch must hold PP_IS_STATS_SCRATCH doubles')
     with torch.cuda.device(value.device):

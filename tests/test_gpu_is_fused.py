@@ -47,7 +47,7 @@ def test_fused_pass_equals_the_per_term_kernels(gum, monkeypatch, n):
     vf, ve = fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy()
     assert np.array_equal(vf, ve)                              # the same Philox stream, the same draw arithmetic
     lf, le = fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy()
-    np.testing.assert_allclose(lf, le, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(lf, le, rtol=1e-5, atol=1e-5)
     for k in ('mean', 'var', 'ess', 'max_lw', 'count'):
         assert abs(fused.device_stats[k] - eager.device_stats[k]) <= 1e-6 * max(1.0, abs(eager.device_stats[k])), k
     assert fused.length == n and int(fused.device_stats['count']) == n
@@ -57,7 +57,7 @@ def test_fused_pass_equals_the_per_term_kernels(gum, monkeypatch, n):
     v = fused.values_numpy()
     assert abs(float(np.sum(w * v)) - mean_dev) < 1e-6 * max(1.0, abs(mean_dev))
     assert abs(1.0 / float(np.sum(w * w)) - ess_dev) < 1e-6 * ess_dev
-    assert abs(fused.mean - mean_dev) < 1e-9 and abs(fused.stddev - std_dev) < 1e-6
+    assert abs(fused.mean - mean_dev) < 1e-6 and abs(fused.stddev - std_dev) < 1e-6
     assert abs(fused.mean - 7.25) < 0.75
 
 
@@ -67,7 +67,7 @@ def test_fused_pass_in_a_program_with_control_flow(gumm, monkeypatch):
     obs = {'obs0': 4, 'obs1': 5}
     fused, eager = _both(gumm, 20000, monkeypatch, obs, seed=5)
     assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())
-    np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert fused.num_paths == eager.num_paths > 1
     assert abs(fused.device_stats['ess'] - eager.device_stats['ess']) <= 1e-5 * eager.device_stats['ess']
 
@@ -93,5 +93,5 @@ def test_reading_a_deferred_value_materialises_it(monkeypatch):
                                   lstm_dim=64, seed=3)
     fused, eager = _both(model, 30000, monkeypatch, OBS, seed=9)
     assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())
-    np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert np.all(np.isfinite(fused._all_log_weights.cpu().numpy()))

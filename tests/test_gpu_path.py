@@ -346,7 +346,8 @@ def test_adam_clears_consumed_gradients_and_train_step_skips_the_memset():
     # float atomics make the last bits of a gradient run-dependent, and the first Adam steps move every weight by
     # ~lr * sign(g): a near-zero gradient whose sign flips costs 2 lr. Compare with the tolerance of one such flip
     # (bitwise equality of repeated runs is what PP_DETERMINISTIC=1 gives: tests/test_gpu_holes.py)
-    assert max(rel_err(sa[n].numpy(), sb[n].numpy()) for n in sa) < 1e-3
+    # (three steps of lr 1e-3: up to three flips of one element = 6e-3 absolute; 1e-3 relative was within reach of two)
+    assert max(rel_err(sa[n].numpy(), sb[n].numpy()) for n in sa) < 4e-3
     assert torch.equal(a.tensor_step, b.tensor_step)
     g = b.loss(pb_, backward=True)                 # flag consumed: this call must NOT see stale gradients
     ga = a.loss(pa, backward=True)

@@ -42,6 +42,6 @@ def sequence(db, out, marker='adam_kernel', which=-3):
 
 if __name__ == '__main__':
     if len(sys.argv) > 3 and sys.argv[3] == 'sequence':
-        sequence(sys.argv[1], sys.argv[2])
+        sequence(sys.argv[1], sys.argv[2], *(sys.argv[4:5]))
     else:
         main(sys.argv[1], sys.argv[2])
