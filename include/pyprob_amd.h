@@ -417,6 +417,12 @@ int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prio
                 uint64_t seed, uint64_t offset, double* stats_out /*dev [6] or NULL*/, double* stats_scratch, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* Prior draws of vectorised trace generation (the per-trace generator: pyprob/nn/dataset.py:50-62 with state.sample's
+ * prior branch pyprob/state.py:278-290): out[i] ~ Normal(p0, p1) (kind 0) | Uniform[p0, p1) (kind 1), parameters shared
+ * (stride 0) or per trace (stride 1); Philox4x32-10, counter offset + i, key seed, `stream_id` distinguishes statements. */
+int pp_prior_draw(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride, int32_t n, uint64_t seed,
+                  uint64_t offset, uint32_t stream_id, float* out /*dev [n]*/, void* stream);
+
 /* lw[i] += scale * term[i] (e.g. -log q). */
 int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream);
 

@@ -870,6 +870,29 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
     if (tid == 0) scratch[blockIdx.x * 6] = (double)M;
 }
 
+// ---- prior draws for vectorised trace generation (pyprob/nn/dataset.py:50-62, state.py:278-290 run n times) -----------
+// out[i] ~ Normal(p0, p1) (kind 0, Box-Muller) | Uniform[p0, p1) (kind 1), parameters shared (stride 0) or per trace;
+// Philox counter = offset + i, key = seed, one stream id per statement: the columns of a chunk of prior traces are
+// drawn where the training step reads them, not on a host thread.
+__global__ __launch_bounds__(256) void prior_draw_kernel(int kind, const float* __restrict__ p0, int s0,
+                                                         const float* __restrict__ p1, int s1, int n, uint64_t seed,
+                                                         uint64_t offset, uint32_t stream_id, float* __restrict__ out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        Philox rng(seed, offset + (uint64_t)i, stream_id);
+        uint32_t r[4];
+        rng.next(r);
+        const float a = p0[(int64_t)i * s0], b = p1[(int64_t)i * s1];
+        float v;
+        if (kind == 0) {
+            v = a + b * sqrtf(-2.0f * logf(u01(r[0]))) * cosf(kTwoPi * u01(r[1]));
+        } else {
+            v = a + (b - a) * (((float)(r[0] >> 8)) * (1.0f / 16777216.0f));      // [a, b): torch.distributions.Uniform's support
+            v = v < b ? v : a;
+        }
+        out[i] = v;
+    }
+}
+
 // kinds 0, 1 read p1; 3, 4 ignore it; 5 carries the number of categories in p1_stride
 static inline bool lw_kind_ok(int kind, const float* p1, int p1_stride) {
     if (kind == 0 || kind == 1) return p1 != nullptr;
@@ -900,6 +923,19 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
     return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows,
                        value_in,
                        value_out, logq_out, seed, offset, workspace, workspace_bytes, pp::as_stream(stream));
+}
+
+int pp_prior_draw(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride, int32_t n, uint64_t seed,
+                  uint64_t offset, uint32_t stream_id, float* out, void* stream) {
+    if (!(p0 && p1 && out) || (kind != 0 && kind != 1)) {
+        pp::set_error("pp_prior_draw: Normal (0) or Uniform (1) with two parameter vectors");
+        return PP_EINVAL;
+    }
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pp::prior_draw_kernel, dim3(std::min(2048, pp::cdiv(n, 256))), dim3(256), 0, pp::as_stream(stream), kind, p0,
+                       p0_stride, p1, p1_stride, n, seed, offset, stream_id, out);
+    PP_LAUNCH_CHECK("pp_prior_draw");
+    return 0;
 }
 
 int pp_is_step_net(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,

@@ -578,12 +578,34 @@ class VectorisedOnlineDataset:
         self._prior_inflation = PriorInflation.DISABLED if prior_inflation is None else prior_inflation
         self.generated = 0
         self._worker = self._prepared = None
+        self.resident = None          # device columns of the current chunk (single-statement programs on a device), else None
         self.refresh()
 
     def _generate(self):
-        cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device, return_types=True,
-                                               prior_inflation=self._prior_inflation)
-        return PackedTraceDataset.from_columns(self.obs_names, None, *cols)
+        """(host dataset of the chunk, device columns or None). On a device: a program whose first chunk came out as ONE
+        single-statement path keeps its later chunks on the device only (no host copy: the host dataset of the first chunk
+        stays as the carrier of the address / trace-type tables); a program with several paths generates on a side stream, so
+        that the branch decisions and the copies to the host do not queue behind the training steps in flight."""
+        on_device = str(self._device) != 'cpu'
+        have_ds, single = self.__dict__.get('_ds') is not None, self.__dict__.get('_single_path', False)   # (__getattr__ forwards to _ds)
+        keep = on_device and single and have_ds
+        side = None
+        if on_device and not single and have_ds:
+            import torch
+            side = self.__dict__.setdefault('_gen_stream', torch.cuda.Stream(device=self._device))
+        import contextlib
+        import torch
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            cols = self._model.prior_traces_packed(self._chunk, self.obs_names, device=self._device, return_types=True,
+                                                   prior_inflation=self._prior_inflation, resident_only=keep)
+            if side is not None:
+                side.synchronize()
+        resident = getattr(self._model, '_last_prior_resident', None) if on_device else None
+        self._model._last_prior_resident = None
+        if cols is None:
+            return self._ds, resident
+        self._single_path = resident is not None
+        return PackedTraceDataset.from_columns(self.obs_names, None, *cols), resident
 
     def refresh(self):
         """Serve the next chunk of fresh prior traces (the one `start_prefetch` prepared, if any)."""
@@ -591,13 +613,13 @@ class VectorisedOnlineDataset:
         if worker is not None or self._prepared is not None:
             if worker is not None:
                 worker.join()
-            ds, err = self._prepared
+            made, err = self._prepared
             self._prepared = None
             if err is not None:
                 raise err
         else:
-            ds = self._generate()
-        self._ds = ds
+            made = self._generate()
+        self._ds, self.resident = made
         self.generated += self._chunk
 
     def wait_prefetch(self):

@@ -181,7 +181,7 @@ class Model:
         return emp
 
     def prior_traces_packed(self, num_traces, obs_names, device='cpu', *args, return_types=False,
-                            prior_inflation=PriorInflation.DISABLED, **kwargs):
+                            prior_inflation=PriorInflation.DISABLED, resident_only=False, **kwargs):
         """num_traces traces of the program in PRIOR_FOR_INFERENCE_NETWORK mode, generated TOGETHER (one execution of
         forward() per distinct control-flow path, state.PriorLockStep) and returned as ragged columns
         (trace_len, address table, address ids, values, prior parameters, observations) - what a training minibatch is
@@ -200,6 +200,9 @@ class Model:
         finally:
             state._lock_step = None
             state._current_trace = None
+        self._last_prior_resident = ls.columns_device(obs_names)      # (device chunks of single-statement programs)
+        if resident_only and self._last_prior_resident is not None:
+            return None          # the caller trains from the device columns: no host copy of the chunk
         return ls.columns(obs_names, return_types)
 
     def _lock_step_safe(self, observe, *args, **kwargs):
@@ -328,9 +331,13 @@ class Model:
             from .dataset import VectorisedOnlineDataset
             try:
                 self.prior_traces_packed(8, list(observe_embeddings.keys()))
+                import os
+                # the chunk is drawn on the training device when there is one (pp_prior_draw; PP_PRIOR_DEVICE=0: host draws)
+                gen_dev = device if (str(device).startswith('cuda') and torch.cuda.is_available() and
+                                     os.environ.get('PP_PRIOR_DEVICE', '1') != '0') else 'cpu'
                 dataset = VectorisedOnlineDataset(self, list(observe_embeddings.keys()),
                                                   chunk_traces=prior_chunk_traces or max(64 * batch_size, 16384),
-                                                  prior_inflation=prior_inflation)
+                                                  prior_inflation=prior_inflation, device=gen_dev)
             except Exception as exc:   # noqa: BLE001 - any failure of the probe means "not lock-step safe"
                 if vectorised_prior:
                     raise

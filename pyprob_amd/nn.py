@@ -595,6 +595,58 @@ class InferenceNetworkLSTM:
                         break
                     continue
                 steps, metas, planned, epoch_end = [], [], trace, False
+                res = getattr(dataset, 'resident', None) if world == 1 else None
+                if res is not None:
+                    # The chunk of prior traces was drawn ON THE DEVICE (state.PriorLockStep + pp_prior_draw) and every trace
+                    # has the same single statement: its columns stay in HBM as minibatch blocks (packed.ColumnarDataset) and a
+                    # run of steps is one pp_train_resident call - no host copy of the chunk, no packing, no upload.
+                    a_new = [res['address']] if res['address'][0] not in self._engine.spec.address_id else []
+                    if a_new and not self._layers_pre_generated and self._polymorph(_PackedIds(dataset, [], a_new)):
+                        self._engine.reset_optimizer()                                    # :481-483
+                    a_id = self._engine.spec.address_id[res['address'][0]]
+                    n_addr = len(self._engine.spec.addresses)
+                    if res.get('pos') is None:
+                        # ONE persistent block buffer per dataset: a new chunk is copied into it (stream-ordered behind the run
+                        # in flight) and the PackedBatch objects of its blocks are built once, not per chunk (64 x ~15 us of
+                        # Python per chunk were 15 % of the step time)
+                        from .packed import ColumnarDataset
+                        slot = dataset.__dict__.get('_resident_slot')
+                        key = (batch_size, a_id, n_addr)
+                        if slot is None or slot['key'] != key or not slot['cd'].refill(res['obs'], res['values'], res['prior']):
+                            cd = ColumnarDataset(res['obs'], res['values'], res['prior'], batch_size)
+                            cache = {}
+                            slot = dict(key=key, cd=cd, batches=[cd.batch(i, a_id, n_addr, cache) for i in range(cd.n_batches)])
+                            dataset.__dict__['_resident_slot'] = slot
+                        res['slot'], res['pos'] = slot, 0
+                    cd = res['slot']['cd']
+                    batches = []
+                    while len(batches) < chunk_steps and planned < num_traces and res['pos'] < cd.n_batches:
+                        batches.append(res['slot']['batches'][res['pos']])
+                        res['pos'] += 1
+                        metas.append((batch_size, 1.0, 1))
+                        planned += batch_size
+                    if batches:
+                        seen = self._total_train_traces + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
+                        lrs = [self._learning_rate(t) for t in seen]
+                        losses_t, status_t = self._engine.train_resident(batches, lrs, weight_decay=self._weight_decay)
+                        self._engine.spec.addresses[a_id].total_train_iterations += len(batches)
+                        launched = (metas, self._engine.read_back(losses_t, status_t))
+                        trace = planned
+                        stop = trace >= num_traces
+                        if chunk_steps == 1:
+                            inflight, launched = launched, None
+                        if inflight is not None:
+                            (metas_p, wait), inflight = inflight, None
+                            if book(metas_p, *wait()):
+                                return
+                        inflight = launched
+                    if res['pos'] >= cd.n_batches and not stop:      # chunk used up: the next one (prefetched meanwhile)
+                        dataset.refresh()
+                        if hasattr(dataset, 'start_prefetch'):
+                            dataset.start_prefetch()
+                        sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
+                        sampler_iter = iter(sampler)
+                    continue
                 while len(steps) < chunk_steps and planned < num_traces:
                     if carry is not None:
                         ids, carry = carry, None

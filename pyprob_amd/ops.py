@@ -49,6 +49,7 @@ _lib.define('is_step_net(Tensor params, Tensor(a!) workspace, int net, int addr_
 _lib.define('is_fused(Tensor(a!) workspace, int net, int addr_id, Tensor? prior, int[] kinds, Tensor?[] p0, int[] p0_strides, '
             'Tensor?[] p1, int[] p1_strides, Tensor?[] x, float[] scales, int[] flags, Tensor(b!) value, Tensor(c!) lw, '
             'bool overwrite, int seed, int offset, Tensor(d!)? stats_scratch) -> Tensor')
+_lib.define('prior_draw(int kind, Tensor p0, Tensor p1, int n, int seed, int offset, int stream_id) -> Tensor')
 _lib.define('log_prob(int kind, Tensor p0, int p0_stride, Tensor? p1, int p1_stride, Tensor x, int n) -> Tensor')
 _lib.define('logweight_terms(Tensor(a!) lw, int[] kinds, Tensor?[] p0, int[] p0_strides, Tensor?[] p1, int[] p1_strides, '
             'Tensor[] x, float[] scales, bool overwrite) -> ()')
@@ -315,6 +316,20 @@ def _is_fused_hip(workspace, net, addr_id, prior, kinds, p0, p0_strides, p1, p1_
     return out
 
 
+def _prior_draw_hip(kind, p0, p1, n, seed, offset, stream_id):
+    lib = L.load()
+    _same_device(p0, p1)
+    out = torch.empty(n, dtype=torch.float32, device=p0.device)
+    for t, name in ((p0, 'p0'), (p1, 'p1')):
+        if _f32(t, name).numel() not in (1, n):
+            raise RuntimeError('pyprob_hip::prior_draw: %s must have 1 or n elements' % name)
+    with torch.cuda.device(p0.device):
+        rc = lib.pp_prior_draw(int(kind), p0.data_ptr(), 0 if p0.numel() == 1 else 1, p1.data_ptr(), 0 if p1.numel() == 1 else 1,
+                               int(n), int(seed), int(offset), int(stream_id) & 0xFFFFFFFF, out.data_ptr(), _stream(p0))
+    L.check(rc, 'pp_prior_draw')
+    return out
+
+
 def _log_prob_hip(kind, p0, p0_stride, p1, p1_stride, x, n):
     lib = L.load()
     _same_device(x, p0, p1)
@@ -363,6 +378,7 @@ _lib.impl('is_init', _is_init_hip, 'CUDA')
 _lib.impl('is_step', _is_step_hip, 'CUDA')
 _lib.impl('is_step_net', _is_step_net_hip, 'CUDA')
 _lib.impl('is_fused', _is_fused_hip, 'CUDA')
+_lib.impl('prior_draw', _prior_draw_hip, 'CUDA')
 _lib.impl('log_prob', _log_prob_hip, 'CUDA')
 _lib.impl('logweight_terms', _logweight_terms_hip, 'CUDA')
 _lib.impl('is_stats', _is_stats_hip, 'CUDA')

@@ -236,14 +236,25 @@ class ColumnarDataset:
     (zero-copy view for eager steps, one device copy into the captured buffers for HIP-graph replay)."""
 
     def __init__(self, obs, value, prior, batch_size):
-        import torch
-        n = (value.shape[0] // batch_size) * batch_size
         self.B, self.w = batch_size, obs.shape[1]
-        self.n_batches = n // batch_size
-        B, w = self.B, self.w
-        blk = torch.cat([obs[:n].reshape(self.n_batches, B * w), value[:n].reshape(self.n_batches, B),
-                         prior[:n].reshape(self.n_batches, B * 2)], dim=1).contiguous()
-        self.blocks = blk                    # [n_batches, B*(w+3)]
+        self.n_batches = value.shape[0] // batch_size
+        self.blocks = self.block_layout(obs, value, prior, batch_size)      # [n_batches, B*(w+3)]
+
+    @staticmethod
+    def block_layout(obs, value, prior, batch_size):
+        import torch
+        B, w = batch_size, obs.shape[1]
+        nb = value.shape[0] // B
+        n = nb * B
+        return torch.cat([obs[:n].reshape(nb, B * w), value[:n].reshape(nb, B), prior[:n].reshape(nb, B * 2)], dim=1).contiguous()
+
+    def refill(self, obs, value, prior):
+        """New traces into the SAME buffers (stream-ordered copy): the PackedBatch objects of every block stay valid."""
+        new = self.block_layout(obs, value, prior, self.B)
+        if new.shape != self.blocks.shape:
+            return False
+        self.blocks.copy_(new)
+        return True
 
     def columns(self, i, block=None):
         B, w = self.B, self.w

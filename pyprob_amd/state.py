@@ -374,7 +374,34 @@ class PriorLockStep(PathExecutor):
     def __init__(self, n, device='cpu'):
         self.obs_log = []             # per observe index: {name: values [n]}
         self.paths = []               # finished executions: (particle indices or None, [(j, address)], [(i, name)])
+        # device chunks: Normal / Uniform columns are drawn by pp_prior_draw (Philox, csrc/is_kernels.hip) where the training
+        # step reads them; the key comes from torch's generator, so pyprob.seed / torch.manual_seed reproduce a chunk
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._consts = {}
         super().__init__(n, torch.device(device))
+
+    def _param(self, v):
+        """A distribution parameter as a float32 device vector (scalars cached: no host-to-device copy per statement)."""
+        if not torch.is_tensor(v) or (v.device.type == 'cpu' and v.numel() == 1):
+            key = float(v)
+            t = self._consts.get(key)
+            if t is None:
+                t = self._consts[key] = torch.tensor([key], dtype=torch.float32, device=self.dev)
+            return t
+        return v.as_subclass(torch.Tensor).reshape(-1).to(self.dev, torch.float32).contiguous()
+
+    def _draw(self, distribution, stream_id):
+        """One value per particle of this execution from `distribution` (prior inflation applied by the caller)."""
+        if self.dev.type != 'cpu' and distribution.name in ('Normal', 'Uniform'):
+            from .ops import ops
+            if distribution.name == 'Normal':
+                kind, p0, p1 = 0, self._param(distribution.mean), self._param(distribution.stddev)
+            else:
+                kind, p0, p1 = 1, self._param(distribution.low), self._param(distribution.high)
+            if p0.numel() in (1, self.width) and p1.numel() in (1, self.width):
+                # counters: particle index inside this execution; the path id separates re-run paths of one chunk
+                return ops.prior_draw(kind, p0, p1, self.width, self.seed, self.path_id << 32, stream_id)
+        return _vector_draw(distribution, self.width).to(self.dev)
 
     def start_path(self, active, decisions, statements_done, observes_done):
         super().start_path(active, decisions, statements_done, observes_done)
@@ -422,8 +449,13 @@ class PriorLockStep(PathExecutor):
         while len(self.log) <= j:
             self.log.append({})
         old = self.log[j].get(address)
-        draw = _vector_draw(_inflate(distribution) or distribution, self.width).to(self.dev)
-        p0, p1 = _vector_params(distribution, self.width, self.dev)
+        draw = self._draw(_inflate(distribution) or distribution, j)
+        if self.dev.type != 'cpu' and distribution.name in ('Normal', 'Uniform'):
+            # cached device constants: a host-to-device copy here would wait for every training step in flight on the stream
+            pp = (distribution.mean, distribution.stddev) if distribution.name == 'Normal' else (distribution.low, distribution.high)
+            p0, p1 = (self._param(q).expand(self.width) if self._param(q).numel() == 1 else self._param(q) for q in pp)
+        else:
+            p0, p1 = _vector_params(distribution, self.width, self.dev)
         o = (None, None, None) if old is None else old
         ncat = distribution.num_categories if distribution.name == 'Categorical' else None
         self.log[j][address] = (self._store(o[0], draw), self._store(o[1], p0), self._store(o[2], p1), distribution.name, ncat)
@@ -438,7 +470,7 @@ class PriorLockStep(PathExecutor):
             while len(self.obs_log) <= i:
                 self.obs_log.append({})
             if value is None:
-                draw = _vector_draw(distribution, self.width).to(self.dev)
+                draw = self._draw(distribution, 0x4000 + i)
             else:
                 draw = torch.as_tensor(value, dtype=torch.float32).reshape(-1).to(self.dev).expand(self.width)
             self.obs_log[i][name] = self._store(self.obs_log[i].get(name), draw)
@@ -452,6 +484,34 @@ class PriorLockStep(PathExecutor):
     def finish_path(self):
         rows = self.active_rows() if self.active is not None else self.base
         self.paths.append((rows, list(self.seq), list(self.obs_seq)))
+
+    def columns_device(self, obs_names):
+        """The chunk as device columns when every trace took the same path with ONE controlled statement (e.g.
+        GaussianUnknownMean): dict(address=(address, distribution, n_categories), values [n], prior [n, 2], obs [n, W]) -
+        what packed.ColumnarDataset blocks into minibatches; None otherwise."""
+        if self.dev.type == 'cpu' or len(self.paths) != 1:
+            return None
+        rows, seq, obs_seq = self.paths[0]
+        if rows is not None or len(seq) != 1:
+            return None
+        j, address = seq[0]
+        e = self.log[j][address]
+        if e[3] not in ('Normal', 'Uniform'):
+            return None
+        by_name = dict((name, i) for i, name in obs_seq)
+        try:
+            cols = [self.obs_log[by_name[name]][name] for name in obs_names]
+        except KeyError:
+            return None
+        if any(c.dim() != 1 or c.numel() not in (1, self.n) for c in cols):
+            return None
+
+        def full(t):
+            t = t.as_subclass(torch.Tensor).reshape(-1).to(self.dev, torch.float32)
+            return t.expand(self.n) if t.numel() == 1 else t
+        return dict(address=(address, e[3], e[4]), values=full(e[0]).contiguous(),
+                    prior=torch.stack([full(e[1]), full(e[2])], 1).contiguous(),
+                    obs=torch.stack([full(c) for c in cols], 1).contiguous())
 
     def columns(self, obs_names, return_types=False):
         """(trace_len [n], address table [(address, distribution, n_categories)], address ids [R], values [R],

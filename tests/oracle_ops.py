@@ -303,6 +303,14 @@ def _is_stats_cpu(lw, x, scratch):
     return out
 
 
+def _prior_draw_cpu(kind, p0, p1, n, seed, offset, stream_id):
+    rng = np.random.default_rng([int(seed) & 0xFFFFFFFF, int(offset) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF, n])
+    a = np.broadcast_to(p0.numpy().astype(DT).reshape(-1), (n,))
+    b = np.broadcast_to(p1.numpy().astype(DT).reshape(-1), (n,))
+    v = a + b * rng.standard_normal(n) if kind == 0 else a + (b - a) * rng.random(n)
+    return torch.from_numpy(np.asarray(v, np.float32))
+
+
 _NET_STASH = {}      # workspace address -> arguments of the last is_step_net (the device keeps the head outputs there)
 
 
@@ -345,7 +353,7 @@ def register():
         return
     for name, fn in (('ic_loss', _ic_loss_cpu), ('adam_step', _adam_step_cpu), ('sgd_step', _sgd_step_cpu),
                      ('larc_scale', _larc_scale_cpu), ('is_init', _is_init_cpu),
-                     ('is_step', _is_step_cpu), ('is_step_net', _is_step_net_cpu), ('is_fused', _is_fused_cpu),
+                     ('is_step', _is_step_cpu), ('is_step_net', _is_step_net_cpu), ('prior_draw', _prior_draw_cpu), ('is_fused', _is_fused_cpu),
                      ('log_prob', _log_prob_cpu), ('logweight_terms', _logweight_terms_cpu),
                      ('is_stats', _is_stats_cpu)):
         P._lib.impl(name, fn, 'CPU')
