@@ -11,12 +11,13 @@ hidden 512, 1 643 583 parameters, fp32. For N > 1 the driver launches one proces
 (torch.distributed.run); per-GPU work is fixed (weak scaling), value = whole-job traces/s.
 
 The JSON line also carries
-  roofline     : the dominant kernel of the step - the grouped weight-gradient launch of the backward pass (fp32 MFMA) -
-                 timed live with HIP events on the stream it runs on inside the timed region, priced against the
-                 fp32-matrix peak (157.3 TFLOP/s); `second_kernel` = the forward input GEMM, `hbm_kernels` = the
-                 HBM-bound launches (observe embedding + LSTM input rows, i.e. the gather path; the Adam pass) in
-                 algorithmic GB/s against 8 TB/s, `whole_step` = SURVEY.md 8(d)'s algorithmic FLOPs of the whole step /
-                 wall-clock step time; `traffic` = HBM bytes per launch from the committed PMC passes (`traffic_source`)
+  roofline     : the dominant kernel of the step - the row-panel launch (csrc/panel.hip: the whole forward + backward data
+                 path of the minibatch, fp32 MFMA 4x4x1 with weights streamed from L2) - timed live with HIP events on the
+                 stream it runs on inside the timed region (every stride-th launch), priced against the fp32-matrix peak
+                 (157.3 TFLOP/s); `second_kernel` = the grouped weight-gradient launch, `hbm_kernels` = the memory-side
+                 launches (observe embedding + LSTM input rows; the Adam pass), `whole_step` = SURVEY.md 8(d)'s algorithmic
+                 FLOPs of the whole step / wall-clock step time; `traffic` = HBM bytes per launch from the committed PMC
+                 passes (`traffic_source`), `rocprof_avg_us` = the committed rocprofv3 --kernel-trace --stats average
   cpu_baseline : the numpy oracle port of the same step (forward + backward + Adam) timed on this host's cores on a
                  bounded sample (rank 0, N = 1 only); `cpu_baseline_torch` = the torch-CPU restatement of the reference's
                  step (nn.LSTM / nn.Linear / autograd / optim.Adam, oracle/torch_ref.py) timed the same way
@@ -474,8 +475,17 @@ def main():
             if use_dist:
                 break         # (ranks would disagree on the count; the probes above already ran > 0.1 s)
         run_steps(0, W, native_loop)
+        # the launch timed live inside the timed region: class 0 = the row-panel kernel (csrc/panel.hip: forward + backward data
+        # path of the step, the longest launch) where it runs, else class 1 = the grouped weight-gradient launch. An event
+        # pair costs the stream ~3 us: every `stride`-th launch carries one, so the timed region stays within ~1 % of an
+        # untimed one
+        panel_expected = os.environ.get('PP_PANEL', '1') != '0' and args.lstm_dim == 512 and \
+            os.environ.get('PP_DETERMINISTIC', '0') != '1'
+        live_class = 0 if panel_expected else 1
+        stride = max(4, K // 50)
         if not args.graph:
-            lib.pp_prof_arm(1, K)      # kernel class 1: the grouped weight-gradient launch, the longest kernel of the step
+            lib.pp_prof_stride(stride)
+            lib.pp_prof_arm(live_class, K // stride + 1)
         barrier()
         t0 = time.perf_counter()
         run_steps(W, K, native_loop)
@@ -500,7 +510,8 @@ def main():
             torch.cuda.synchronize()
             return collect(which, n)
 
-        dominant = eager_pass(1, min(K, 50)) if args.graph else collect(1, K)
+        live = eager_pass(live_class, min(K, 50)) if args.graph else collect(live_class, K)
+        lib.pp_prof_stride(1)
         # per-step times (event pairs between consecutive steps of one more untimed pass): the median next to the mean
         n_med = min(max(K, 20), 200)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_med + 1)]
@@ -511,13 +522,14 @@ def main():
         torch.cuda.synchronize()
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_med))
         out['ms_per_step_median'] = round(per_step[n_med // 2], 4)
-        second = eager_pass(0, min(K, 50))
+        other = eager_pass(1 - live_class, min(K, 50))
+        first, dominant = (live, other) if live_class == 0 else (other, live)      # class 0 / class 1 samples
         gather = eager_pass(2, min(K, 50))
         adam = eager_pass(3, min(K, 50))
         final_loss = float(eng.loss_buf[0].item())
         units = B * K
         metric, unit = 'ic_train_traces_per_sec', 'traces/s'
-        pmc, pmc_file = {}, os.path.join('profiles', 'r02_pmc_traffic.json')   # (re-collected for the compact-row step: tools/pmc_train.sh)
+        pmc, pmc_file = {}, os.path.join('profiles', 'r03_pmc_traffic.json')   # tools/profile_round.sh
         try:   # HBM bytes per launch from the committed PMC passes (rocprof cannot run inside bench.py)
             with open(os.path.join(REPO, pmc_file)) as f:
                 pmc = json.load(f)['kernels'] if (B == 1024 and args.lstm_dim == 512) else {}
@@ -552,7 +564,7 @@ def main():
             if algorithmic is not None and bound == 'mfma':
                 d['executed_flops_per_launch'] = executed
                 d['frac_executed'] = round(executed / (avg_ms * 1e-3) / 1e12 / peak, 4)
-            d['timing'] = 'HIP event pair around the launch on its stream (adds 4-12 us to a ~10 us kernel: frac is a lower bound)'
+            d['timing'] = 'HIP event pair around the launch in an untimed pass of the same step right after the timed region'
             ravg = rocprof_avgs.get(key)
             if ravg:
                 d['rocprof_avg_us'] = ravg
@@ -561,23 +573,46 @@ def main():
                 if d['traffic'] is not None else None
             return d
         H, I = args.lstm_dim, eng.spec.lstm_in
-        if dominant:
+        if dominant and first:
             hid_ = int((H + 30) / 2)
+            e_obs = eng.spec.e_obs
+            timing_live = ('HIP event pair around every %d-th launch INSIDE the timed region, on the stream the kernel runs on (an '
+                           'event pair adds ~2-3 us to the interval: frac is a lower bound; rocprof_avg_us / frac_rocprof = the '
+                           'committed rocprofv3 --kernel-trace --stats average of this command)' % stride)
+            timing_post = 'HIP event pair around the launch in an untimed pass of the same step right after the timed region'
             # reference algorithm, weight gradients of one step: dW_ih [4H, I], dW1 [hid, H], dW2 [30, hid], the observe
             # embedding's four weight matrices (64x64 twice, 32x16 twice); K = batch rows
             wgrad_alg = 2.0 * B * (4 * H * I + hid_ * H + 30 * hid_ + 2 * 64 * 64 + 2 * 32 * 16)
-            out['roofline'] = roof(dominant, 'wgrad_group',
-                                   'gemm_f32_async_grouped_aux_kernel (last launch of the backward pass: the weight-gradient '
-                                   'group dW_ih[:, :e_obs] %dx%dx%d + head and observe-embedding leaves as MFMA tiles with '
-                                   'split-K float atomics, and behind them the reduction jobs - column sums, table-column '
-                                   'gradients from the per-address sums of dG, LSTM bias gradients, loss; algorithmic FLOPs = the '
-                                   "reference's dW_ih %dx%dx%d + leaves, SURVEY.md 8(d))" % (4 * H, eng.spec.e_obs, B, 4 * H, I, B),
-                                   algorithmic=wgrad_alg)
-            if second:
-                out['roofline']['second_kernel'] = roof(second, 'input_gemm', 'gemm_f32_async_lstm_kernel (forward LSTM input '
+            wgrad = roof(dominant, 'wgrad_group',
+                         'gemm_f32_async_grouped_aux_kernel (last launch of the backward pass: the weight-gradient '
+                         'group dW_ih[:, :e_obs] %dx%dx%d + head and observe-embedding leaves as MFMA tiles with '
+                         'split-K float atomics, and behind them the reduction jobs - column sums, table-column '
+                         'gradients from the per-address sums of dG, LSTM bias gradients, loss; algorithmic FLOPs = the '
+                         "reference's dW_ih %dx%dx%d + leaves, SURVEY.md 8(d))" % (4 * H, e_obs, B, 4 * H, I, B),
+                         algorithmic=wgrad_alg)
+            panel_exec = 2.0 * B * (2.0 * 3.0 * H * e_obs + 2.0 * H * hid_ + 2.0 * hid_ * 30)
+            if abs(first[1] - panel_exec) < 1.0:
+                # the row-panel launch carries the whole data path of the step: forward X W_ih^T + cell + both head layers +
+                # mixture log-prob, backward dy, dz1, dh, cell, dX. Algorithmic FLOPs = the reference's products of those
+                # (full LSTM input width I, all four gates); executed = 64 observe-embedding columns, three gates (c_prev = 0)
+                panel_alg = 2.0 * B * (2.0 * 4 * H * I + 2.0 * H * hid_ + 2.0 * hid_ * 30)
+                out['roofline'] = roof(first, 'panel',
+                                       'panel_t1_kernel (csrc/panel.hip: one launch = forward input product + LSTM cell + proposal '
+                                       'head + mixture log-prob + loss and the backward data path dy, dz1, dh, cell, dX of all %d '
+                                       'traces, 8-row panels, two workgroups per panel, v_mfma_f32_4x4x1 with weights streamed '
+                                       "k-major from L2; algorithmic FLOPs = the reference's X W_ih^T %dx%dx%d and dG W_ih, head "
+                                       'layers forward and backward)' % (B, B, 4 * H, I), algorithmic=panel_alg)
+                out['roofline']['timing'] = timing_live if live_class == 0 else timing_post
+                wgrad['timing'] = timing_post if live_class == 0 else timing_live
+                out['roofline']['second_kernel'] = wgrad
+            else:
+                out['roofline'] = wgrad
+                out['roofline']['timing'] = timing_live if live_class == 1 else timing_post
+                out['roofline']['second_kernel'] = roof(first, 'input_gemm', 'gemm_f32_async_lstm_kernel (forward LSTM input '
                                                         'product [E | s_prev] W_ih[:, :c2]^T + per-address bias, LSTM cell in '
                                                         "the epilogue; algorithmic FLOPs = the reference's X W_ih^T %dx%dx%d)"
                                                         % (B, 4 * H, I), algorithmic=2.0 * B * I * 4 * H)
+                out['roofline']['second_kernel']['timing'] = timing_post if live_class == 1 else timing_live
             hbm = []
             if gather:
                 d = roof(gather, 'obs_embed_fwd', 'obs_embed_fwd_kernel (observe embedding + fused address-dispatch '

@@ -502,6 +502,9 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
  * pp_prof_collect returns the elapsed milliseconds and the work of every recorded launch (flops_out).
  * ---------------------------------------------------------------------------------------------------- */
 int pp_prof_arm(int32_t which, int32_t max_samples);          /* allocate event pairs; 0 disarms */
+int pp_prof_stride(int32_t stride);                           /* time every stride-th launch of the class (default 1):
+                                                                 an event pair costs the stream ~3 us, a stride keeps the
+                                                                 timed region of a benchmark within ~1 % of an untimed one */
 int pp_prof_collect(float* ms_out, int32_t cap, int32_t* n_out, double* flops_out); /* syncs the events */
 
 /* Diagnostic: one wave runs `iters` dependent FMAs; out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed

@@ -78,17 +78,22 @@ struct Prof {
     std::vector<hipEvent_t> ev0, ev1;
     std::vector<double> flops;
     int used = 0;
+    int stride = 1, seen = 0;      // an event pair around every stride-th launch of the class (pp_prof_stride)
+    bool cur = false;
 };
 static Prof g_prof;
 
 void prof_begin(int which, hipStream_t st) {
-    if (g_prof.which == which && g_prof.used < (int)g_prof.ev0.size()) (void)hipEventRecord(g_prof.ev0[g_prof.used], st);
+    if (g_prof.which != which) return;
+    g_prof.cur = (g_prof.seen++ % g_prof.stride) == 0 && g_prof.used < (int)g_prof.ev0.size();
+    if (g_prof.cur) (void)hipEventRecord(g_prof.ev0[g_prof.used], st);
 }
 void prof_end(int which, double flops, hipStream_t st) {
-    if (g_prof.which == which && g_prof.used < (int)g_prof.ev0.size()) {
+    if (g_prof.which == which && g_prof.cur) {
         (void)hipEventRecord(g_prof.ev1[g_prof.used], st);
         g_prof.flops[g_prof.used] = flops;
         g_prof.used++;
+        g_prof.cur = false;
     }
 }
 
@@ -1098,6 +1103,8 @@ int pp_prof_arm(int32_t which, int32_t max_samples) {
     pp::g_prof.ev1.clear();
     pp::g_prof.flops.clear();
     pp::g_prof.used = 0;
+    pp::g_prof.seen = 0;
+    pp::g_prof.cur = false;
     pp::g_prof.which = -1;
     if (max_samples <= 0) return 0;
     pp::g_prof.ev0.resize(max_samples);
@@ -1110,6 +1117,11 @@ int pp_prof_arm(int32_t which, int32_t max_samples) {
         }
     }
     pp::g_prof.which = which;
+    return 0;
+}
+
+int pp_prof_stride(int32_t stride) {
+    pp::g_prof.stride = stride > 0 ? stride : 1;
     return 0;
 }
 
