@@ -14,7 +14,7 @@ KEYS = (('panel_t1_kernel', 'panel'), ('gemm_f32_async_grouped_aux_kernel', 'wgr
 # algorithmic bytes per launch at B = 1024, H = 512, hid = 271, e = 64: what the launch must read and write once
 ALG = {
     'panel': ('X 0.26 MB + weights once (W_ih[:, :64] and its transpose 1.0 MB, W1 and its transpose 1.1 MB, W2 0.03 MB) read; '
-              'h 2.1 MB, dG 8.4 MB, a1 1.1 MB, dz1 1.1 MB, dy 0.1 MB, dX 0.26 MB written. Measured traffic above that: every XCD's L2 '
+              'h 2.1 MB, dG 8.4 MB, a1 1.1 MB, dz1 1.1 MB, dy 0.1 MB, dX 0.26 MB written. Measured traffic above that: every L2 (one per XCD) '
               'fetches the 2.2 MB of weights (8 x, served by the Infinity Cache), and the two workgroups of a panel exchange their '
               'partial head-layer sums through 4.5 MB of write-through {value, tag} granules', 15.5e6),
     'wgrad_group': ('dG 8.4 MB, h 2.1 MB, a1 1.1 MB, dz1 1.1 MB, dy 0.1 MB, X 0.26 MB, observe-embedding activations 0.5 MB read; '
