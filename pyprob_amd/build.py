@@ -49,7 +49,7 @@ def _check_registers(remarks):
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the C-ABI shared library. Returns the library path."""
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'gather.hpp'), os.path.join(CSRC, 'aux_jobs.hpp'), os.path.join(CSRC, 'panel.hpp'),
+    headers = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'gather.hpp'), os.path.join(CSRC, 'aux_jobs.hpp'), os.path.join(CSRC, 'panel.hpp'), os.path.join(CSRC, 'obs_embed.hpp'),
                os.path.join(os.path.dirname(HERE), 'include', 'pyprob_amd.h')]
     if not force and not _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + headers):
         return LIB      # the prebuilt in-tree library travels to the GPU box; nothing to do

@@ -63,8 +63,7 @@ int adam_step(float* params, float* grads, float* m, float* v, int64_t n_params,
 
 extern long long* g_timeline;   // kernels.hip
 
-// obs_embed.hip
-bool obs_fused_supported(const pp_net* net);
+// obs_embed.hip (obs_embed.hpp: obs_fused_supported, obs_fused_args)
 int obs_embed_dgrad_fused(const pp_net* net, const float* P, int n_traces, float* const* obs_h, const float* cat,
                           const float* f1, const float* dX, int64_t ldx, const int32_t* row_off_dev, int t_max,
                           const float* E, float* dE, float* dF1, float* dCat, float* dHo0, int64_t dh_stride,
@@ -446,7 +445,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     for (int o = 0; o < net->n_obs; ++o) gather_bytes += 4.0 * B * net->obs_hid[o];
     // Row-panel kernel (panel.hip): a single-statement batch with ONE address keeps input product + cell, head layer 1, the
     // head tail, dz1, dH + cell backward and dX in one launch (rows of the one address group are the batch rows in order)
-    bool panel = false;
+    bool panel = false, obs_tail = false;
     if (lean_cell && n_present == 1 && fused_obs && bt->grp_off[only_addr] == 0 && bt->grp_off[only_addr + 1] == R) {
         const pp_addr& ad = net->addrs[only_addr];
         panel = panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && panel_t1_split(R, H) == 2 &&
@@ -559,7 +558,15 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 pa.lp_out = (flags & PP_LOSS_KEEP_LP) ? lp_out : nullptr;
                 pa.loss_acc = w.loss_acc; pa.flag = w.flag; pa.grad_scale = -1.0f / (float)B;
                 pa.dbg = g_timeline;
-                PP_TRY(panel_t1(ad.kind, pa, st));
+                // training: the observe-embedding backward of the rows rides in the kernel's tail (one launch less)
+                PanelObs po{};
+                obs_tail = bwd && panel_obs_tail_ok(net, H, ad.hid, ad.n_out, net->e_obs) && obs_fused_args(net, w.obs_h, po.a);
+                if (obs_tail) {
+                    po.P = P; po.cat = w.cat; po.f1 = w.f1;
+                    po.dE = w.dE; po.dF1 = w.dF1; po.dCat = w.dCat; po.dHo0 = w.dObsH;
+                    po.dh_stride = (int64_t)B * w.maxohid4;
+                }
+                PP_TRY(panel_t1(ad.kind, pa, st, obs_tail ? &po : nullptr));
                 cell_done = true;
                 // executed data-path FLOPs of the launch: forward + backward products of the 8-row panels
                 prof_end(0, 2.0 * R * (2.0 * 3.0 * H * net->e_obs + 2.0 * (double)H * ad.hid + 2.0 * (double)ad.hid * ad.n_out), st);
@@ -932,8 +939,9 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         // in one fused launch; weight gradients join the grouped MFMA launch; bias gradients are column sums of the same
         // buffers
         const int64_t dhs = (int64_t)B * w.maxohid4;
-        PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, dXs, ldxs, bt->row_off_dev, T, w.E, w.dE, w.dF1, w.dCat,
-                                     w.dObsH, dhs, st, dx_splits, (int64_t)R * w.i4));
+        if (!obs_tail)      // (single-statement batches on the panel kernel: done in its tail)
+            PP_TRY(obs_embed_dgrad_fused(net, P, B, w.obs_h, w.cat, w.f1, dXs, ldxs, bt->row_off_dev, T, w.E, w.dE, w.dF1, w.dCat,
+                                         w.dObsH, dhs, st, dx_splits, (int64_t)R * w.i4));
         const int e = net->e_obs;
         queue_wgrad(wq, w.dE, w.e4, w.f1, w.e4, nullptr, grads + net->fin_w1, B, e, e);
         queue_wgrad(wq, w.dF1, w.e4, w.cat, w.e4, nullptr, grads + net->fin_w0, B, e, e);

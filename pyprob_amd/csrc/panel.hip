@@ -171,8 +171,8 @@ __device__ __forceinline__ float gget(const unsigned long long* p, int epoch) {
 // one CU's L1 at ~25 B/clk is what bounds the kernel, profiles/r03_panel_v3_pmc_*.csv), the K-split partial sums of head
 // layer 1 and of dX cross between the pair through memory (two hand-offs of 8.7 KB and 2 KB), the small tail phases run
 // redundantly on both, each writes 4 of the 8 rows of the shared outputs. 1 024 rows then fill all 256 CUs.
-template <int KIND, int SPLIT>
-__global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
+template <int KIND, int SPLIT, bool OBS>
+__global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain, const PanelObs oin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PanelArgs a = ain;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -602,6 +602,36 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
     }
     PANEL_STAMP(11);
     __syncthreads();     // the staging images are complete
+    // observe-embedding backward (tail): its weights and this wave's row inputs are fetched now, behind phase 6's streams
+    constexpr int ONB = 2;                       // observables of the fused tail (static loops, see obs_embed.hip)
+    ObsStage<8, 512> of1, of0;                   // e x e <= 64 x 64
+    ObsStage<4, 512> ol1[ONB];                   // out x hid <= 64 x 32
+    float t_f1 = 0.0f, t_cat = 0.0f, t_h = 0.0f;
+    int t_oh = -1, t_jh = 0;
+    int64_t t_hld = 0;
+    if (OBS) {
+        const ObsFusedArgs& oa = oin.a;
+        of1.load(oin.P + oa.f1.w_off, oa.f1.rows * oa.f1.cols, tid);
+        of0.load(oin.P + oa.f0.w_off, oa.f0.rows * oa.f0.cols, tid);
+#pragma unroll
+        for (int o = 0; o < ONB; ++o)
+            if (o < oa.n_obs) ol1[o].load(oin.P + oa.l1[o].w_off, oa.l1[o].rows * oa.l1[o].cols, tid);
+        const float* my_h = nullptr;
+#pragma unroll
+        for (int o = 0; o < ONB; ++o)
+            if (o < oa.n_obs && lane >= oa.hoff[o] && lane < oa.hoff[o] + oa.hid[o]) {
+                t_oh = o; t_jh = lane - oa.hoff[o];
+                my_h = oa.obs_h[o]; t_hld = oa.ohid_ld[o];
+            }
+        const int tb = m0 + half * 4 + wave;      // waves 0..3 walk rows 4 half + wave
+        if (wave < 4 && tb < a.B) {
+            if (lane < oa.e_obs) {
+                t_f1 = oin.f1[(int64_t)tb * oa.e_ld + lane];
+                t_cat = oin.cat[(int64_t)tb * oa.e_ld + lane];
+            }
+            if (t_oh >= 0) t_h = my_h[(int64_t)tb * t_hld + t_jh];
+        }
+    }
     // ---------------- phase 6: dX[:, :e] = dG W_ih[:, :e]; K = this tile's 3 x 64 gate rows, split owner / helper ----------------
     {
         f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
@@ -634,6 +664,17 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
         atomicAdd(a.gsum + 3 * H + u, gs_o);
     }
     __syncthreads();
+    float* const oimg = sH;                               // LDS image of the embedding weights: sH .. sW2 are dead now
+    float* const sDX = sH + 10240 + 8;                    // this workgroup's four dX rows [4][64]
+    if (OBS) {
+        const ObsFusedArgs& oa = oin.a;
+        const int dummy = oa.lds_total;
+        of1.store(oimg, oa.f1.lds_w, oa.f1.rows, oa.f1.cols, dummy, tid);
+        of0.store(oimg, oa.f0.lds_w, oa.f0.rows, oa.f0.cols, dummy, tid);
+#pragma unroll
+        for (int o = 0; o < ONB; ++o)
+            if (o < oa.n_obs) ol1[o].store(oimg, oa.l1[o].lds_w, oa.l1[o].rows, oa.l1[o].cols, dummy, tid);
+    }
     {   // dX rows: the eight waves' partial tiles + the partner's half of the K range
         unsigned long long* const xd_own = a.xd + (int64_t)(panel * 2 + half) * (PANEL_ROWS * 64);
         const unsigned long long* const xd_other = a.xd + (int64_t)(panel * 2 + (half ^ 1)) * (PANEL_ROWS * 64);
@@ -646,11 +687,44 @@ __global__ __launch_bounds__(512) void panel_t1_kernel(const PanelArgs ain) {
             gput(xd_own + i, sum, epoch);
             if (m0 + r < a.B && (r >> 2) == half) {      // (the other rows' sums are the partner's to write)
                 const float theirs = gget(xd_other + i, epoch);
-                a.dX[(int64_t)(m0 + r) * a.ldx + c] = half == 0 ? sum + theirs : theirs + sum;
+                const float dx = half == 0 ? sum + theirs : theirs + sum;
+                a.dX[(int64_t)(m0 + r) * a.ldx + c] = dx;
+                if (OBS) sDX[(r & 3) * 64 + c] = dx;
             }
         }
     }
     PANEL_STAMP(13);
+    if (OBS) {
+        // dz2 = dX * [E > 0]; dz1 = (Wf1^T dz2) * [f1 > 0]; dzc = (Wf0^T dz1) * [cat > 0]; dh_o = (W1_o^T dzc_o) * [h_o > 0]
+        // (inference_network.py:132-139 backward; one wave per row, lane = unit, obs_embed.hip's walk)
+        __syncthreads();
+        const ObsFusedArgs& oa = oin.a;
+        const int r = half * 4 + wave, tb = m0 + r;
+        if (wave < 4 && tb < a.B) {
+            const bool acte = lane < oa.e_obs;
+            float dz2 = 0.0f;
+            if (acte) dz2 = sE[r * PE + lane] > 0.0f ? sDX[wave * 64 + lane] : 0.0f;
+            if (acte) oin.dE[(int64_t)tb * oa.e_ld + lane] = dz2;
+            float dz1 = obs_dense_t(oimg, oa.f1, lane, acte, dz2, 0);
+            dz1 = t_f1 > 0.0f ? dz1 : 0.0f;
+            if (acte) oin.dF1[(int64_t)tb * oa.e_ld + lane] = dz1;
+            float dzc = obs_dense_t(oimg, oa.f0, lane, acte, dz1, 0);
+            dzc = t_cat > 0.0f ? dzc : 0.0f;
+            if (acte) oin.dCat[(int64_t)tb * oa.e_ld + lane] = dzc;
+            float dh = 0.0f;
+            int co = 0;
+#pragma unroll
+            for (int o = 0; o < ONB; ++o) {
+                if (o >= oa.n_obs) break;
+                const bool acth = (t_oh == o);
+                const float d = obs_dense_t(oimg, oa.l1[o], t_jh, acth, dzc, co);
+                if (acth) dh = d;
+                co += oa.out[o];
+            }
+            if (t_oh >= 0) oin.dHo0[(int64_t)t_oh * oin.dh_stride + (int64_t)tb * t_hld + t_jh] = t_h > 0.0f ? dh : 0.0f;
+        }
+        PANEL_STAMP(14);
+    }
 #undef PANEL_STAMP
 }
 
@@ -670,11 +744,11 @@ bool panel_t1_supported(int kind, int H, int hid, int n_out, int e) {
     return panel_lds_bytes(H, hid, n_out, e) <= 160 * 1024;
 }
 
-template <int KIND, int SPLIT>
-static int panel_launch(const PanelArgs& a, size_t lds, hipStream_t st) {
+template <int KIND, int SPLIT, bool OBS>
+static int panel_launch(const PanelArgs& a, const PanelObs& po, size_t lds, hipStream_t st) {
     static thread_local bool configured = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)panel_t1_kernel<KIND, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)panel_t1_kernel<KIND, SPLIT, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) {
             set_error("panel_t1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -684,23 +758,39 @@ static int panel_launch(const PanelArgs& a, size_t lds, hipStream_t st) {
     }
     const int panels = cdiv(a.B, PANEL_ROWS);
     const int grid = SPLIT == 2 ? 16 * cdiv(panels, 8) : panels;      // pairs are blocks (b, b + 8) of a 16-block window
-    hipLaunchKernelGGL((panel_t1_kernel<KIND, SPLIT>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((panel_t1_kernel<KIND, SPLIT, OBS>), dim3(grid), dim3(512), lds, st, a, po);
     return 0;
 }
 
 // The launch uses two workgroups per panel (pairs are blocks (b, b + 8) of a 16-block window); up to 256 panels.
 int panel_t1_split(int B, int H) { return (H == 512 && cdiv(B, PANEL_ROWS) <= 256) ? 2 : 0; }
 
-int panel_t1(int kind, const PanelArgs& a, hipStream_t st) {
+// The embedding-backward tail: the fused embedding kernels' shapes with at most two observables, and the dead LDS buffers
+// (sH .. sW2) must hold the weight image and four dX rows.
+bool panel_obs_tail_ok(const pp_net* net, int H, int hid, int n_out, int e) {
+    static const int env = getenv("PP_PANEL_OBS") ? atoi(getenv("PP_PANEL_OBS")) : 1;
+    if (!env || !obs_fused_supported(net) || net->n_obs > 2 || net->e_obs != e) return false;
+    const PanelLds L = panel_lds(H, hid, n_out, e);
+    return L.sP - L.sH >= PANEL_OBS_LDS;
+}
+
+int panel_t1(int kind, const PanelArgs& a, hipStream_t st, const PanelObs* obs) {
     PP_CHECK_ARG(panel_t1_supported(kind, a.H, a.hid, a.n_out, a.e), "panel_t1: unsupported shape");
     PP_CHECK_ARG(a.ldx % 4 == 0 && a.ldw % 4 == 0 && a.lda1 % 4 == 0 && a.lda1 >= a.hid && a.lda1 <= ((a.hid + 15) & ~15) &&
                      a.lddy <= 64 && a.lddy >= a.n_out && a.K * 3 == a.n_out && a.e * PANEL_ROWS <= 512 && PANEL_ROWS * a.lda1 <= 512 * 5,
                  "panel_t1: bad leading dimensions");
     const size_t lds = panel_lds_bytes(a.H, a.hid, a.n_out, a.e);
     PP_CHECK_ARG(panel_t1_split(a.B, a.H) == 2 && a.xz && a.xd && a.epoch, "panel_t1: too many rows, or no hand-off buffers");
-#define PP_PANEL_GO(KIND)                                                \
-    do {                                                                 \
-        PP_TRY((panel_launch<KIND, 2>(a, lds, st)));                     \
+    if (obs) {
+        const PanelLds L = panel_lds(a.H, a.hid, a.n_out, a.e);
+        PP_CHECK_ARG(obs->a.n_obs <= 2 && obs->a.e_obs == a.e && obs->a.lds_total + 1 <= 10240 + 8 && L.sP - L.sH >= PANEL_OBS_LDS,
+                     "panel_t1: the observe-embedding tail does not fit");
+    }
+    static const PanelObs none{};
+#define PP_PANEL_GO(KIND)                                                             \
+    do {                                                                              \
+        if (obs) PP_TRY((panel_launch<KIND, 2, true>(a, *obs, lds, st)));             \
+        else PP_TRY((panel_launch<KIND, 2, false>(a, none, lds, st)));                \
     } while (0)
     if (kind == PP_HEAD_NORMAL_MIXTURE) PP_PANEL_GO(0);
     else if (kind == PP_HEAD_TRUNCNORMAL_MIXTURE) PP_PANEL_GO(1);

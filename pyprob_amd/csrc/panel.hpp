@@ -1,6 +1,7 @@
 // Row-panel kernel for single-statement batches (panel.hip): arguments and host entry points used by engine.hip.
 #pragma once
 #include "common.hpp"
+#include "obs_embed.hpp"
 
 namespace pp {
 
@@ -22,6 +23,19 @@ struct PanelArgs {
     unsigned long long* xz; unsigned long long* xd; const int* epoch;
     long long* dbg;                      // debug: clock64() stamps [2 workgroups][2 waves][16] (pp_debug_timeline) or nullptr
 };
+
+// Backward of the observe embedding as the TAIL of the panel kernel (obs_embed.hip's dgrad kernel, one launch less): a
+// workgroup finishes dX for 4 of its panel's rows; four of its waves then walk one row each through the final stack and the
+// per-observable layers (weights in an LDS image over the kernel's dead buffers) and write dE, dF1, dCat, dH_o - the
+// operands of the embedding's weight gradients in the grouped launch that follows.
+struct PanelObs {
+    ObsFusedArgs a;
+    const float* P;                      // flat parameters
+    const float* cat; const float* f1;   // saved activations [B][e_ld]
+    float* dE; float* dF1; float* dCat; float* dHo0;
+    int64_t dh_stride;
+};
+constexpr int PANEL_OBS_LDS = 10240 + 8 + 4 * 64;      // the LDS image (+ its dummy word) and four dX rows, floats
 
 // ---- k-major copies of the two forward weight matrices --------------------------------------------------------------
 // The panel kernel reads every weight matrix with the summation index as the row (one coalesced dword per lane and k). The
@@ -76,7 +90,9 @@ __device__ __forceinline__ void panel_transpose_block(const PanelTranspose& tr, 
 bool panel_t1_supported(int kind, int H, int hid, int n_out, int e);
 size_t panel_lds_bytes(int H, int hid, int n_out, int e);
 // one launch: input product + cell, head layer 1, tail + loss + dy, dz1, dh + cell backward (dG, group sums), dX
-int panel_t1(int kind, const PanelArgs& a, hipStream_t st);
+// obs != nullptr: the observe-embedding backward of the rows rides in the tail (panel_obs_tail_ok must hold)
+int panel_t1(int kind, const PanelArgs& a, hipStream_t st, const PanelObs* obs = nullptr);
+bool panel_obs_tail_ok(const pp_net* net, int H, int hid, int n_out, int e);
 int panel_t1_split(int B, int H);                   // 2 when the (two-workgroups-per-panel) launch takes this many rows, else 0
 
 }  // namespace pp
