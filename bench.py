@@ -583,12 +583,15 @@ def main():
             # reference algorithm, weight gradients of one step: dW_ih [4H, I], dW1 [hid, H], dW2 [30, hid], the observe
             # embedding's four weight matrices (64x64 twice, 32x16 twice); K = batch rows
             wgrad_alg = 2.0 * B * (4 * H * I + hid_ * H + 30 * hid_ + 2 * 64 * 64 + 2 * 32 * 16)
+            t1 = panel_expected and os.environ.get('PP_WGRAD_T1', '1') != '0'
             wgrad = roof(dominant, 'wgrad_group',
-                         'gemm_f32_async_grouped_aux_kernel (last launch of the backward pass: the weight-gradient '
-                         'group dW_ih[:, :e_obs] %dx%dx%d + head and observe-embedding leaves as MFMA tiles with '
-                         'split-K float atomics, and behind them the reduction jobs - column sums, table-column '
-                         'gradients from the per-address sums of dG, LSTM bias gradients, loss; algorithmic FLOPs = the '
-                         "reference's dW_ih %dx%dx%d + leaves, SURVEY.md 8(d))" % (4 * H, e_obs, B, 4 * H, I, B),
+                         ('wgrad_t1_kernel (csrc/wgrad_t1.hip: ' if t1 else 'gemm_f32_async_grouped_aux_kernel (') +
+                         'last launch of the backward pass: the weight gradients dW_ih[:, :e_obs] %dx%dx%d, dW1, dW2 and the '
+                         'observe-embedding leaves as 64x64 MFMA tiles over row ranges of the minibatch%s, combined with float '
+                         'atomics, and behind them the reduction jobs - column sums, table-column gradients from the per-address '
+                         "sums of dG, LSTM bias gradients, loss; algorithmic FLOPs = the reference's dW_ih %dx%dx%d + leaves, "
+                         'SURVEY.md 8(d))' % (4 * H, e_obs, B, ' (operands streamed as MFMA fragments straight from memory, no LDS '
+                                              'staging)' if t1 else '', 4 * H, I, B),
                          algorithmic=wgrad_alg)
             panel_exec = 2.0 * B * (2.0 * 3.0 * H * e_obs + 2.0 * H * hid_ + 2.0 * hid_ * 30)
             if abs(first[1] - panel_exec) < 1.0:

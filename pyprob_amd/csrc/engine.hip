@@ -4,6 +4,7 @@
 #include "gather.hpp"
 #include "aux_jobs.hpp"
 #include "panel.hpp"
+#include "wgrad_t1.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -282,11 +283,16 @@ static int linear_fwd(const float* x, int64_t ldx, const int32_t* x_idx, const f
 // products of a backward pass are leaves of the dependency graph and run as one grouped launch (gemm_f32_grouped)
 // the weight-gradient leaves of the backward pass, one grouped launch (timed as kernel class 1 when armed)
 static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st, const std::vector<GemmHole>* holes = nullptr,
-                         bool timed = true, const AuxJobs* aux = nullptr) {
+                         bool timed = true, const AuxJobs* aux = nullptr, bool t1 = false) {
     if (wq.empty()) return aux ? aux_jobs_launch(*aux, st) : 0;
     double flops = 0.0;
     for (const auto& g : wq) flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
     if (timed) prof_begin(1, st);
+    WgradT1Args wa;
+    // single-statement batch behind the panel kernel: operands stream straight into MFMA fragments (wgrad_t1.hip)
+    if (t1 && wgrad_t1_build(wq.data(), holes && holes->size() == wq.size() ? holes->data() : nullptr, (int)wq.size(), wa))
+        PP_TRY(wgrad_t1(wa, aux, st));
+    else
     PP_TRY(gemm_f32_grouped(wq.data(), (int)wq.size(), st, holes ? holes->data() : nullptr, nullptr, aux));
     if (timed) prof_end(1, flops, st);
     return 0;
@@ -690,7 +696,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     std::vector<GemmHole> wholes;
     auto flush_wgrads = [&](hipStream_t stream, bool timed, const AuxJobs* aux = nullptr) -> int {
         wholes.resize(wq.size(), GemmHole{});
-        PP_TRY(launch_wgrads(wq, stream, &wholes, timed, aux));
+        PP_TRY(launch_wgrads(wq, stream, &wholes, timed, aux, panel));
         wq.clear();
         wholes.clear();
         return 0;
@@ -717,7 +723,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                                 det ? nullptr : grads + ad.b1));   // db1 = colsum(dZ1) fused into the epilogue
             if (det) cs.push_back(ColsumJob{dZ1, w.hid4, nullptr, n, ad.hid, grads + ad.b1, nullptr});
         }
-        queue_wgrad(wq, dZ1, w.hid4, heads_in, heads_ld, bt->grp_rows + g0, grads + ad.w1, n, H, ad.hid);
+        // (panel kernel: one group that covers all rows in order - no gather, the product can take the streaming kernel)
+        queue_wgrad(wq, dZ1, w.hid4, heads_in, heads_ld, panel ? nullptr : bt->grp_rows + g0, grads + ad.w1, n, H, ad.hid);
         {   // dH[rows of this address] = dZ1 W1: queued, every address group in one grouped launch
             pp_gemm_args g{};
             g.A = dZ1; g.lda = w.hid4;

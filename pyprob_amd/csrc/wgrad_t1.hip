@@ -1,0 +1,217 @@
+// Weight gradients of a single-statement batch in one launch (the step after the row-panel kernel, panel.hip):
+//   dW_ih[:, :e] = dG^T E,  dW1 = dz1^T h,  dW2 = dy^T a1,  the observe-embedding's dWf1 = dE^T f1, dWf0 = dF1^T cat, dW1_o = dCat_o^T h_o
+// (inference_network_lstm.py:186-220 backward: torch.autograd's weight gradients of nn.LSTM / nn.Linear), every product
+// with K = the rows of the minibatch and both operands stored row = k by the panel kernel.
+//
+// Why not the grouped tile kernels (gemm_f32.hip): those stage K slabs through an LDS ring, three slabs ahead - a workgroup
+// streams ~45 GB/s, so 1 024 rows cost ~13 us per tile however small the problem (measured: the four one-tile embedding
+// problems ALONE take the launch 13 us, profiles/r03g_wgrad_composition.txt). Here both operands are k-major, which is the
+// MFMA operand layout of v_mfma_f32_32x32x2_f32 as it lies in memory (lane l supplies A[k0 + l / 32][m0 + l % 32]): the
+// fragments are plain coalesced dword loads into registers, sixteen rows in flight per wave while the previous sixteen
+// multiply - no LDS, no barrier in the K loop. A workgroup (8 waves) owns a 64 x 64 output tile over one of S row ranges:
+// waves = 2 x 2 quadrants x 2 halves of the row range; the halves meet in LDS, the S ranges in float atomics on dW.
+// The bound is the fp32 matrix rate (0.59 GFLOP -> 3.8 us at peak) against ~40 MB of fragment loads through the L1s.
+//
+// The reduction jobs of the backward pass (aux_jobs.hpp: column sums, table-column gradients, bias gradients, the loss) ride
+// behind the tiles as before.
+#include "wgrad_t1.hpp"
+
+#include <stdlib.h>
+
+#include <algorithm>
+
+namespace pp {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_RING = 8;    // row pairs in the ring: nine in flight (36 loads per wave) while one multiplies. The operands
+                              // were written by the previous kernel on other XCDs - every load is a ~2 us trip to the
+                              // Infinity Cache - and a CU needs ~100 KB in flight to stream at its L1 fill rate
+
+// two rows (k + lane / 32) of the tile's 64 A columns and 64 B columns: the operands of four MFMAs
+struct Pair {
+    float a0, a1, b0, b1;
+};
+
+__global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, const AuxJobs aux) {
+    __shared__ float lds[8192];      // [8 waves][16][64] partial quadrants; the reduction jobs use 2 048 floats
+    const int bx = blockIdx.x;
+    if (bx >= g.n_blocks) {
+        aux_job_run(aux, bx - g.n_blocks, lds);
+        return;
+    }
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < WGRAD_T1_MAX; ++q)
+        if (q < g.n_prob && bx >= g.p[q].first) pi = q;
+    // (scalar loads with a run-time index: one trip to the kernel arguments)
+    const float* const A = g.p[pi].A;
+    const float* const B = g.p[pi].B;
+    float* const C = g.p[pi].C;
+    const int lda = g.p[pi].lda, ldb = g.p[pi].ldb, ldc = g.p[pi].ldc, M = g.p[pi].M, N = g.p[pi].N, nt = g.p[pi].nt;
+    const int local = bx - g.p[pi].first;
+    const int tiles = ((M + 63) >> 6) * nt;
+    const int s = local / tiles, t = local - s * tiles;
+    const int tm = t / nt, tn = t - tm * nt;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = tm * 64, n0 = tn * 64;
+    // Every wave multiplies the WHOLE 64 x 64 tile over its own eighth of the split's rows: each row of the operands enters
+    // the CU once (quadrant-per-wave layouts fetch every line twice, and the L1 fill rate is what bounds the stream), and
+    // the four accumulators are independent MFMA chains.
+    const int k0 = s * g.ks, k1 = min(g.K, k0 + g.ks);
+    const int per = ((k1 - k0 + 15) >> 4) * 2;
+    const int kb = k0 + wave * per, ke = min(k1, kb + per);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const bool hm = m0 + 32 < M, hn = n0 + 32 < N;      // second half of the tile's rows / columns exists (wave-uniform)
+    if (kb < ke) {
+        // columns beyond M / N are clamped: their products land in accumulator rows / columns the epilogue never stores.
+        // Rows beyond the range are clamped too and enter as a * 0 (a multiply, not a select: a select lets the compiler
+        // predicate the LOAD, one branch per load)
+        const float* pa0 = A + min(m0 + l31, M - 1);
+        const float* pa1 = A + min(m0 + 32 + l31, M - 1);
+        const float* pb0 = B + min(n0 + l31, N - 1);
+        const float* pb1 = B + min(n0 + 32 + l31, N - 1);
+        auto load = [&](int kk, Pair& p) {
+            const int k = kk + h;
+            const int kc = min(k, ke - 1);
+            const float keep = k < ke ? 1.0f : 0.0f;
+            p.a0 = pa0[(int64_t)kc * lda] * keep;
+            p.a1 = pa1[(int64_t)kc * lda] * keep;
+            p.b0 = pb0[(int64_t)kc * ldb];
+            p.b1 = pb1[(int64_t)kc * ldb];
+        };
+        auto mma = [&](const Pair& p) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a0, p.b0, acc[0][0], 0, 0, 0);
+            if (hn) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a0, p.b1, acc[0][1], 0, 0, 0);
+            if (hm) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a1, p.b0, acc[1][0], 0, 0, 0);
+            if (hm && hn) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a1, p.b1, acc[1][1], 0, 0, 0);
+        };
+        Pair f[WG_RING];
+        const int nfr = (ke - kb + 1) >> 1;      // row pairs of this wave
+        // (loads are unconditional so that the compiler counts them with s_waitcnt vmcnt(N) instead of draining the queue at
+        // a branch)
+#pragma unroll
+        for (int i = 0; i < WG_RING - 1; ++i) load(kb + 2 * i, f[i]);
+        int i0 = 0;
+        for (; i0 + WG_RING <= nfr; i0 += WG_RING) {
+#pragma unroll
+            for (int j = 0; j < WG_RING; ++j) {
+                load(kb + 2 * (i0 + j + WG_RING - 1), f[(j + WG_RING - 1) % WG_RING]);
+                mma(f[j]);
+            }
+        }
+        const int nrem = nfr - i0;      // < WG_RING: already in the ring
+#pragma unroll
+        for (int j = 0; j < WG_RING - 1; ++j)
+            if (j < nrem) mma(f[j]);
+    }
+    // the eight waves' partial tiles meet in LDS, one 32 x 32 quadrant at a time; the S row ranges meet in float atomics
+    // D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj) {
+            if ((qi && !hm) || (qj && !hn)) continue;      // (block-uniform)
+            if (qi + qj > 0) __syncthreads();
+            float* mine = lds + wave * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = acc[qi][qj][r];
+            __syncthreads();
+            // 512 threads: element (r, lane) with r = 2 (tid >> 6) + {0, 1}
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * wave + e;
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += lds[w * 1024 + r * 64 + lane];
+                const int gm = m0 + 32 * qi + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gn = n0 + 32 * qj + l31;
+                if (gm < M && gn < N) atomicAdd(C + (int64_t)gm * ldc + gn, v);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1Args& out) {
+    static const int env = getenv("PP_WGRAD_T1") ? atoi(getenv("PP_WGRAD_T1")) : 1;
+    static const int env_s = getenv("PP_WGRAD_T1_SPLITS") ? atoi(getenv("PP_WGRAD_T1_SPLITS")) : 0;
+    if (!env || deterministic_mode() || n <= 0) return false;
+    out = WgradT1Args{};
+    const int K = q[0].K;
+    int np = 0;
+    int64_t tiles = 0;
+    auto add = [&](const pp_gemm_args& a, int m_lo, int m_hi, int n_hi) -> bool {
+        if (m_hi <= m_lo || n_hi <= 0) return true;
+        if (np >= WGRAD_T1_MAX) return false;
+        WgradT1Prob& p = out.p[np++];
+        p.A = a.A + m_lo; p.B = a.B; p.C = a.C + (int64_t)m_lo * a.ldc;
+        p.lda = (int)a.lda; p.ldb = (int)a.ldb; p.ldc = (int)a.ldc;
+        p.M = m_hi - m_lo; p.N = n_hi; p.nt = cdiv(n_hi, 64);
+        tiles += (int64_t)cdiv(p.M, 64) * p.nt;
+        return true;
+    };
+    for (int i = 0; i < n; ++i) {
+        const pp_gemm_args& a = q[i];
+        if (!a.a_kmajor || !a.b_kmajor || a.a_idx || a.b_idx || a.c_idx || a.bias || a.bias2 || a.mask || a.relu || a.colsum ||
+            !a.accumulate || a.K != K || a.M <= 0 || a.N <= 0 || a.lda >= (1 << 30) || a.ldb >= (1 << 30) || a.ldc >= (1 << 30))
+            return false;
+        // zero blocks (GemmHole): a column range [n_hi, N) over all rows, and one row range over the remaining columns
+        int n_hi = a.N, cut0 = 0, cut1 = 0;
+        if (holes) {
+            bool used[2] = {false, false};
+            for (int b = 0; b < 2; ++b) {
+                const GemmBlock& z = holes[i].b[b];
+                if (z.m1 <= z.m0 || z.n1 <= z.n0 || z.k1 <= z.k0) { used[b] = true; continue; }
+                if (z.k0 > 0 || z.k1 < K) return false;
+                if (z.m0 <= 0 && z.m1 >= a.M && z.n1 >= a.N) { n_hi = std::min(n_hi, std::max(z.n0, 0)); used[b] = true; }
+            }
+            for (int b = 0; b < 2; ++b) {
+                if (used[b]) continue;
+                const GemmBlock& z = holes[i].b[b];
+                if (z.n0 <= 0 && z.n1 >= n_hi && cut1 == 0) { cut0 = std::max(z.m0, 0); cut1 = std::min(z.m1, (int)a.M); }
+                else return false;
+            }
+        }
+        if (cut1 > cut0) {
+            if ((cut0 & 63) || (cut1 & 63)) return false;
+            if (!add(a, 0, cut0, n_hi) || !add(a, cut1, a.M, n_hi)) return false;
+        } else if (!add(a, 0, a.M, n_hi)) {
+            return false;
+        }
+    }
+    if (np == 0 || tiles == 0) return false;
+    // row splits: one workgroup per CU; at least 64 rows per split
+    int S = env_s > 0 ? env_s : (int)std::max<int64_t>(1, 240 / tiles);
+    S = std::min(S, std::max(1, K / 64));
+    S = std::min(S, 16);
+    out.K = K; out.S = S; out.ks = ((cdiv(K, S) + 3) / 4) * 4;
+    out.n_prob = np;
+    int first = 0;
+    for (int i = 0; i < np; ++i) {
+        out.p[i].first = first;
+        first += cdiv(out.p[i].M, 64) * out.p[i].nt * S;
+    }
+    out.n_blocks = first;
+    return true;
+}
+
+int wgrad_t1(const WgradT1Args& a, const AuxJobs* aux, hipStream_t st) {
+    static const AuxJobs none{};
+    const AuxJobs& j = aux ? *aux : none;
+    hipLaunchKernelGGL(wgrad_t1_kernel, dim3(a.n_blocks + (aux ? j.n_blocks : 0)), dim3(512), 0, st, a, j);
+    PP_LAUNCH_CHECK("wgrad_t1");
+    return 0;
+}
+
+}  // namespace pp

@@ -1,0 +1,31 @@
+// Weight gradients of a single-statement batch (wgrad_t1.hip): arguments and the host entry point used by engine.hip.
+#pragma once
+#include "aux_jobs.hpp"
+#include "common.hpp"
+
+namespace pp {
+
+constexpr int WGRAD_T1_MAX = 12;
+
+// dW[m][n] += sum_k A[k][m] B[k][n], k = the rows of the minibatch: both operands are activations the way the row-panel
+// kernel wrote them (row = k), dW is a row-major weight-gradient tensor (ldc = its row length).
+struct WgradT1Prob {
+    const float* A; const float* B; float* C;
+    int lda, ldb, ldc;
+    int M, N;            // extent of this problem (a cut of the tensor: zero blocks are left out by the host)
+    int nt;              // 64-column tiles
+    int first;           // first workgroup of the problem in the launch
+};
+
+struct WgradT1Args {
+    WgradT1Prob p[WGRAD_T1_MAX];
+    int n_prob, n_blocks;     // problems; workgroups of all tiles (the reduction jobs follow)
+    int K, S, ks;             // rows, row splits, rows per split (multiple of 4)
+};
+
+// Takes the queued weight-gradient products (queue_wgrad: k-major operands, accumulate) when every one of them fits the
+// kernel (no gathers, zero blocks that cut whole row / column ranges, one K for all); false: use the grouped tile kernels.
+bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1Args& out);
+int wgrad_t1(const WgradT1Args& a, const AuxJobs* aux, hipStream_t st);
+
+}  // namespace pp
