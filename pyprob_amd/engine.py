@@ -61,7 +61,8 @@ class ICEngine:
         self.loss_buf = self.grads_full[n + spec.n_tensors:n + spec.n_tensors + 1]   # the loss kernel writes into the tail
         self.status_tail = self.grads_full[n + spec.n_tensors + 1:]                  # float copy of the non-finite flag
         self.dp_skip = []      # (offset, count) float ranges left out of the gradient all-reduce, see skip_recurrent_weights
-        self.native_dp = False   # set by the caller after pyprob_amd.parallel.init_native_comm() returned True on ALL ranks
+        # set by the caller after pyprob_amd.parallel.init_native_comm() returned True on ALL ranks (kept when the network grows)
+        self.native_dp = getattr(self, 'native_dp', False)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.tensor_step = torch.zeros(spec.n_tensors, dtype=torch.int32, device=self.device)

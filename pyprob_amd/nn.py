@@ -494,7 +494,11 @@ class InferenceNetworkLSTM:
         # objects. Anything else is indexed trace by trace like the reference's DataLoader does.
         # (stop_with_bad_loss does not force per-iteration syncs: a flagged minibatch never touches the parameters - Adam
         # skips it on the device - and training stops when its status is read back, at most two runs later)
-        sync_every = 1 if (log_file_name or world > 1) else 16
+        # data parallel: the C loop's all-reduce branch needs this library's communicator on every rank; the ranks plan the
+        # same runs (same sampler length, same cuts: chunk size, parameter broadcasts, epoch ends, num_traces - and the
+        # loss / non-finite flag they book are the all-reduced ones), tests/test_dp_gloo.py. PP_DP_NATIVE_LOOP=0: per-step loop
+        dp_native = world > 1 and bool(self._engine.native_dp) and os.environ.get('PP_DP_NATIVE_LOOP', '1') == '1'
+        sync_every = 1 if (log_file_name or (world > 1 and not dp_native)) else 16
         save_state = [time_start - (save_every_sec or 0)]       # (the reference saves at the first iteration, :461-462)
         if valid_every is None:
             valid_every = max(100, num_traces / 1000)                                     # :435-436
@@ -557,11 +561,12 @@ class InferenceNetworkLSTM:
         # - dataset._bernoulli_step_stats -: such programs keep the per-step loop)
         has_bernoulli = any(a.dist_name == 'Bernoulli' for a in self._engine.spec.addresses) or \
             (packed and any(a[1] == 'Bernoulli' for a in getattr(dataset, 'addresses', [])))
-        # (data parallel: the C loop has an all-reduce branch - tests/test_gpu_dp_native.py on a one-rank group - but
-        # ranks must then cut their runs at the same steps; until that has run on a multi-GPU node it is opt-in,
-        # PP_DP_NATIVE_LOOP=1, and the default is the per-step loop with the exchange issued from C)
-        native = packed and plain_adam and (world == 1 or (self._engine.native_dp and os.environ.get('PP_DP_NATIVE_LOOP', '0') == '1')) and \
+        # (data parallel: the C loop has an all-reduce branch - tests/test_gpu_dp_native.py on a one-rank group, the run
+        # planning below on two gloo ranks in tests/test_dp_gloo.py)
+        native = packed and plain_adam and (world == 1 or dp_native) and \
             not has_bernoulli and os.environ.get('PP_PYTHON_LOOP', '0') != '1'
+        traces0 = self._total_train_traces
+        planned_iters = 0
         chunk_steps = 1 if sync_every == 1 else 64
         carry = None
         type_key, type_known = None, None
@@ -626,7 +631,7 @@ class InferenceNetworkLSTM:
                         metas.append((batch_size, 1.0, 1))
                         planned += batch_size
                     if batches:
-                        seen = self._total_train_traces + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
+                        seen = traces0 + trace + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
                         lrs = [self._learning_rate(t) for t in seen]
                         losses_t, status_t = self._engine.train_resident(batches, lrs, weight_decay=self._weight_decay)
                         self._engine.spec.addresses[a_id].total_train_iterations += len(batches)
@@ -647,7 +652,12 @@ class InferenceNetworkLSTM:
                         sampler = dataset.sampler(batch_size, rank, world, distributed_num_buckets)
                         sampler_iter = iter(sampler)
                     continue
-                while len(steps) < chunk_steps and planned < num_traces:
+                limit = chunk_steps
+                if world > 1:      # _distributed_sync_parameters every N iterations (:473-474): a run ends where one is due
+                    if planned_iters % distributed_params_sync_every_iter == 0:
+                        self._engine.broadcast_params()
+                    limit = min(limit, distributed_params_sync_every_iter - planned_iters % distributed_params_sync_every_iter)
+                while len(steps) < limit and planned < num_traces:
                     if carry is not None:
                         ids, carry = carry, None
                     else:
@@ -679,9 +689,10 @@ class InferenceNetworkLSTM:
                         metas.append((len(ids), float(dataset.trace_len[ids].mean()), len(dataset.types_of(ids))))
                     else:
                         metas.append((len(ids), 0.0, 0))
-                    planned += len(ids)
+                    planned += len(ids) * world
                 if steps:
-                    seen = self._total_train_traces + np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
+                    planned_iters += len(steps)
+                    seen = traces0 + trace + world * np.concatenate([[0], np.cumsum([m[0] for m in metas])[:-1]])
                     lrs = [self._learning_rate(t) for t in seen]
                     losses_t, status_t = self._engine.train_run(dataset, steps, lrs, weight_decay=self._weight_decay)
                     launched = (metas, self._engine.read_back(losses_t, status_t))
@@ -752,11 +763,11 @@ class InferenceNetworkLSTM:
                 l_out.copy_(self._engine.loss_buf[:1])
                 # the non-finite flag was reduced with the gradients: every rank skips (and books) the same iterations
                 s_out.copy_(self._engine.status_tail[:1])
-                self._engine.optimizer_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True,
+                self._engine.optimizer_step(self._learning_rate(traces0 + trace), weight_decay=self._weight_decay, zero_grads=True,
                                             skip=self._engine.reduced_status())
             else:
                 self._engine.loss(pb, backward=True, loss_out=l_out, status_out=s_out)
-                self._engine.optimizer_step(self._learning_rate(), weight_decay=self._weight_decay, zero_grads=True, skip=s_out)
+                self._engine.optimizer_step(self._learning_rate(traces0 + trace), weight_decay=self._weight_decay, zero_grads=True, skip=s_out)
             pending.append((batch.size, batch.mean_length_controlled, len(batch.sub_batches)))
             trace += batch.size * world
             stop = trace >= num_traces

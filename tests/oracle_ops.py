@@ -38,6 +38,32 @@ class CpuBufferEngine(ICEngine):
         self.force_allreduce = False
         self.optimizer = dict(kind='adam', larc=False, momentum=0.9)
         self._resize(initialise=list(spec.tensors.keys()))
+        self.run_lengths = []      # steps of every train_run call (the cuts of the run planner, nn.optimize)
+
+    def train_run(self, dataset, id_lists, lrs, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """pp_train_steps (csrc/train_loop.hip) restated on the host, step by step through the operators: pack the step's
+        traces -> zero_grad, loss, backward -> [one all-reduce of gradients | presence | loss | flag] -> Adam, which skips a
+        flagged step. Returns the per-step (loss, status) the C loop leaves in its rings: under data parallelism the
+        all-reduced SUM of the losses and the reduced flag."""
+        self._adam_only('train_run')
+        if len(lrs) != len(id_lists):
+            raise ValueError('one learning rate per step')
+        dp = self.world_size != 1 or self.force_allreduce
+        losses, statuses = [], []
+        for ids, lr in zip(id_lists, lrs):
+            pb = dataset.device_batch(np.asarray(ids), self.spec, 'cpu')
+            for a, n in enumerate(pb.cur_counts):
+                if n > 0:
+                    self.spec.addresses[a].total_train_iterations += 1      # inference_network_lstm.py:198
+            self.train_step(pb, float(lr), weight_decay=weight_decay)
+            losses.append(self.loss_buf[:1].clone())
+            statuses.append((self.reduced_status() if dp else self.status_buf)[:1].clone())
+        self.run_lengths.append(len(id_lists))
+        return torch.cat(losses), torch.cat(statuses)
+
+    def read_back(self, losses, statuses):
+        lo, st = losses.numpy().copy(), statuses.numpy().copy()
+        return lambda: (lo, st)
 
 
 def _net_from_flat(params, spec, dtype=DT):

@@ -14,6 +14,13 @@ from conftest import REPO, load_golden
 from helpers import spec_from_golden
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # (a fixed port can collide with an ephemeral one)
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -57,7 +64,7 @@ def _worker(rank, world, port, out):
 
 
 def test_flat_allreduce_equals_global_batch_gradient(tmp_path):
-    world, port = 2, 29500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     out = str(tmp_path / 'dp.pt')
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     r = torch.load(out, weights_only=False)
@@ -137,7 +144,7 @@ def _gather_worker(rank, world, port, out):
 
 def test_particle_gather_concatenates_the_rank_shards(tmp_path):
     """IS shards: every rank ends up with all particles in shard order (ParallelModel's merge)."""
-    world, port = 2, 31500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     out = str(tmp_path / 'g.pt')
     mp.spawn(_gather_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
@@ -203,7 +210,7 @@ def test_engine_data_parallel_step_merges_presence_and_skips_together(tmp_path):
     [grads | presence | loss | non-finite flag]; ranks that touch different heads end with IDENTICAL parameters equal to
     Adam on the averaged gradient with the merged presence map (inference_network.py:296-333); a non-finite loss on one
     rank makes BOTH ranks skip that iteration (no parameter, no step count changes) and leaves no NaN behind."""
-    world, port = 2, 33500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     out = str(tmp_path / 'eng.pt')
     mp.spawn(_engine_worker, args=(world, port, out), nprocs=world, join=True)
     r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)
@@ -282,7 +289,7 @@ def _skip_worker(rank, world, port, out):
 def test_recurrent_weight_range_can_be_left_out_of_the_allreduce(tmp_path):
     """Single-statement datasets (GUM): dL/dW_hh = 0 on every rank; reducing the flat buffer WITHOUT that range gives
     bit-identical parameters and step counts."""
-    world, port = 2, 35500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     out = str(tmp_path / 'skip.pt')
     mp.spawn(_skip_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
@@ -322,7 +329,7 @@ def test_sgd_and_larc_under_data_parallelism(tmp_path):
     """Optimizer.SGD / SGD_LARC / ADAM_LARC with world_size 2: LARC's norms are those of the AVERAGED gradient (the
     reference divides by the world size before optimizer.step(), inference_network.py:324-325, 496), the ranks stay
     identical, and two steps equal the oracle's optimizers on the averaged gradients with the merged presence map."""
-    world, port = 2, 37500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     out = str(tmp_path / 'larc.pt')
     mp.spawn(_larc_worker, args=(world, port, out), nprocs=world, join=True)
     r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)
@@ -427,7 +434,7 @@ def test_training_loop_on_two_ranks_equals_steps_on_the_averaged_gradients(tmp_p
     all-reduce per iteration, lr * sqrt(world) (:448), loss read-back per iteration. The ranks see disjoint minibatches, end
     with identical parameters and counters, and the parameters equal a single-process replay of the SAME minibatch pairs:
     gradients of both minibatches summed, presence maps merged, Adam on the average."""
-    world, port = 2, 41500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     out = str(tmp_path / 'loop.pt')
     mp.spawn(_loop_worker, args=(world, port, out), nprocs=world, join=True)
     r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)
@@ -460,6 +467,92 @@ def test_training_loop_on_two_ranks_equals_steps_on_the_averaged_gradients(tmp_p
     assert d < 1e-6, d
 
 
+def _native_engine_factory(spec, device='cpu', seed=None):
+    eng = _cpu_engine_factory(spec, device, seed)
+    eng.native_dp = True        # (what nn.optimize sets after init_native_comm() succeeded on every rank)
+    return eng
+
+
+def _native_loop_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.pop('PP_DP_NATIVE_LOOP', None)
+    os.environ.pop('PP_PYTHON_LOOP', None)
+    import contextlib
+    import io
+    from models import GaussianWithUnknownMeanMarsaglia
+    from pyprob_amd import nn as N
+    from pyprob_amd.state import InferenceNetwork
+    N.InferenceNetworkLSTM._engine_factory = staticmethod(_native_engine_factory)
+    ds = _gumm_dataset()
+    used = []
+    device_batch = ds.device_batch
+
+    def logged(ids, spec, device):
+        used.append(np.asarray(ids).copy())
+        return device_batch(ids, spec, device)
+    ds.device_batch = logged
+    model = GaussianWithUnknownMeanMarsaglia()
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.learn_inference_network(num_traces=16 * 2 * 12, dataset=ds, inference_network=InferenceNetwork.LSTM,
+                                      observe_embeddings={'obs0': {'dim': 8}, 'obs1': {'dim': 8}}, lstm_dim=16, batch_size=16,
+                                      learning_rate_init=1e-3, learning_rate_end=1e-5, learning_rate_scheduler_type='POLY2',
+                                      num_traces_end=16 * 2 * 12, weight_decay=0.0, distributed_backend='gloo',
+                                      distributed_num_buckets=3, pre_generate_layers=True, device='cpu', seed=5,
+                                      distributed_params_sync_every_iter=5)
+    net = model._inference_network
+    torch.save(dict(params=net._engine.params.clone(), used=used, iters=net._total_train_iterations,
+                    traces=net._total_train_traces, hist=list(net._history_train_loss), runs=list(net._engine.run_lengths),
+                    steps=net._engine.tensor_step.clone(),
+                    per_address=[a.total_train_iterations for a in net._engine.spec.addresses]), out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_planner_under_data_parallelism_cuts_the_same_runs_on_every_rank(tmp_path):
+    """The loop that hands RUNS of steps to one C call (pp_train_steps; nn.optimize's `while native`) on two gloo ranks, the C
+    call restated on the host (oracle_ops.CpuBufferEngine.train_run: pack -> loss + backward -> one all-reduce -> Adam per
+    step): both ranks cut the same runs (16-step chunks, a cut where a parameter broadcast is due - every 5 iterations -,
+    the end), book the same all-reduced losses and counters, end with identical parameters - and everything equals a
+    single-process replay of the same minibatch pairs with the POLY2 learning rate of the reference's trace count
+    (inference_network.py:357-379, 448, 473-474, 486-531)."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / 'native.pt')
+    mp.spawn(_native_loop_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)
+    assert r0['runs'] == r1['runs'] == [5, 5, 2]
+    assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['steps'], r1['steps'])
+    assert r0['iters'] == r1['iters'] == 12 and r0['traces'] == r1['traces'] == 16 * 2 * 12
+    np.testing.assert_allclose(r0['hist'], r1['hist'], rtol=1e-6)
+    for a, b in zip(r0['used'], r1['used']):
+        assert len(a) == len(b) == 16 and not set(a.tolist()) & set(b.tolist())
+    import oracle_ops  # noqa: F401
+    from pyprob_amd.spec import NetSpec
+    ds = _gumm_dataset()
+    spec = NetSpec({'obs0': {'dim': 8, 'input_dim': 1}, 'obs1': {'dim': 8, 'input_dim': 1}}, lstm_dim=16)
+    eng = _cpu_engine_factory(spec, seed=5)
+    eng.add_addresses([a for a in ds.addresses])
+    eng.force_allreduce = True
+    hist, seen, end = [], 0, 16 * 2 * 12
+    lr0, lr1 = 1e-3 * np.sqrt(2.0), 1e-5
+    for a, b in zip(r0['used'], r1['used']):
+        eng.loss(ds.device_batch(a, eng.spec, 'cpu'), backward=True)
+        g = eng.grads_full.clone()
+        eng.loss(ds.device_batch(b, eng.spec, 'cpu'), backward=True)
+        g += eng.grads_full
+        eng.grads_full.copy_(g)
+        hist.append(float(eng.loss_buf[0]) / 2)
+        lr = (lr0 - lr1) * max(0.0, 1.0 - seen / end) ** 2 + lr1
+        eng.adam_step(lr, weight_decay=0.0, zero_grads=True, grad_scale=0.5)
+        seen += 32
+    np.testing.assert_allclose(r0['hist'], hist, rtol=1e-5)
+    d = (eng.params - r0['params']).abs().max().item()
+    assert d < 1e-6, d
+    # (per-address iteration counters count a rank's OWN minibatches, like the reference's proposal layers)
+    assert max(r0['per_address']) == max(r1['per_address']) == 12
+
+
 def _gum_model_on_host():
     import oracle_ops  # noqa: F401  (CPU kernels of the operators)
     from is_helpers import network_from_golden
@@ -489,7 +582,7 @@ def test_distributed_posterior_on_two_ranks_is_the_concatenation_of_the_shards(t
     """Model.posterior_results_distributed (ParallelModel's sharding, pyprob/model.py:339-406) on two gloo ranks with the golden
     GUM network on the host: shards of 51 + 50 particles with their own counter offsets, ONE all-gather; every rank holds
     all 101 particles in shard order, equal to the two shards computed in one process, with the same statistics."""
-    world, port = 2, 43500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     out = str(tmp_path / 'post.pt')
     mp.spawn(_posterior_worker, args=(world, port, out), nprocs=world, join=True)
     r0, r1 = torch.load(out + '.0', weights_only=False), torch.load(out + '.1', weights_only=False)

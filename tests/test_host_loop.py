@@ -159,3 +159,33 @@ def test_posterior_after_training_in_lock_step_and_in_coroutines():
     assert np.isfinite(lock.log_weights).all() and lock.effective_sample_size > 4 and abs(lock.mean - exact) < 1.0
     co = model.posterior_results(200, IC, observe=obs, lock_step=False, seed=16)
     assert np.isfinite(co.log_weights).all() and co.effective_sample_size > 3 and abs(co.mean - exact) < 1.2
+
+
+@pytest.mark.parametrize('grow', [False, True])
+def test_run_planner_equals_the_per_step_loop(tmp_path, monkeypatch, grow):
+    """nn.optimize's run planner (runs of up to 64 steps handed to ONE call of pp_train_steps; here the call restated on the
+    host, oracle_ops.CpuBufferEngine.train_run) against the per-step loop on the same offline dataset: same minibatches,
+    same POLY2 learning rates, same bookkeeping, bit-identical parameters - with layers pre-generated (one run per epoch
+    tail) and with the network growing while it trains (a run ends before the minibatch that brings a new address, and
+    Adam restarts there like inference_network.py:481-483)."""
+    d = str(tmp_path / 'train')
+    torch.manual_seed(5)
+    GaussianWithUnknownMeanMarsaglia().save_dataset(d, 320, 160)
+    out = {}
+    for loop in ('python', 'planner'):
+        monkeypatch.setenv('PP_PYTHON_LOOP', '1' if loop == 'python' else '0')
+        torch.manual_seed(7)
+        model = GaussianWithUnknownMeanMarsaglia()
+        model.learn_inference_network(num_traces=16 * 45, dataset_dir=d, learning_rate_init=1e-3, learning_rate_end=1e-5,
+                                      learning_rate_scheduler_type='POLY2', num_traces_end=2000, pre_generate_layers=not grow,
+                                      seed=6, **KW)
+        net = model._inference_network
+        out[loop] = (net._engine.params.clone(), list(net._history_train_loss), net._total_train_iterations,
+                     net._total_train_traces, [a.total_train_iterations for a in net._engine.spec.addresses],
+                     net._engine.tensor_step.clone(), list(getattr(net._engine, 'run_lengths', [])))
+    p, q = out['python'], out['planner']
+    assert q[6] and max(q[6]) > 1 and sum(q[6]) == 45 and not p[6]          # the planner really handed out runs
+    assert p[2] == q[2] == 45 and p[3] == q[3] == 16 * 45 and p[4] == q[4]
+    assert torch.equal(p[5], q[5])
+    np.testing.assert_allclose(p[1], q[1], rtol=1e-6)
+    assert torch.equal(p[0], q[0])
