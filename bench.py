@@ -357,7 +357,7 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a captured HIP graph (1) or launch eagerly (0)')
     ap.add_argument('--prewarm-s', type=float, default=0.35, help='untimed steady-state pre-warm before the --warmup steps')
     args = ap.parse_args()
-    if args.gpus > 1 and 'RANK' not in os.environ:
+    if (args.gpus > 1 or os.environ.get('PP_BENCH_SELF_LAUNCH') == '1') and 'RANK' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one process per GPU ourselves, the way the reference spawns
         # its own workers (pyprob/model.py:339-406); rank 0 of the children prints the line
         raise SystemExit(_self_launch(args.gpus))
