@@ -289,7 +289,7 @@ static int launch_wgrads(std::vector<pp_gemm_args>& wq, hipStream_t st, const st
     for (const auto& g : wq) flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
     if (timed) prof_begin(1, st);
     WgradT1Args wa;
-    // single-statement batch behind the panel kernel: operands stream straight into MFMA fragments (wgrad_t1.hip)
+    // k-major operands stream straight into MFMA fragments (wgrad_t1.hip) unless a product needs what only the tile kernels do
     if (t1 && wgrad_t1_build(wq.data(), holes && holes->size() == wq.size() ? holes->data() : nullptr, (int)wq.size(), wa))
         PP_TRY(wgrad_t1(wa, aux, st));
     else
@@ -696,7 +696,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     std::vector<GemmHole> wholes;
     auto flush_wgrads = [&](hipStream_t stream, bool timed, const AuxJobs* aux = nullptr) -> int {
         wholes.resize(wq.size(), GemmHole{});
-        PP_TRY(launch_wgrads(wq, stream, &wholes, timed, aux, panel));
+        PP_TRY(launch_wgrads(wq, stream, &wholes, timed, aux, true));
         wq.clear();
         wholes.clear();
         return 0;

@@ -16,6 +16,7 @@
 // behind the tiles as before.
 #include "wgrad_t1.hpp"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -50,7 +51,9 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
     const float* const A = g.p[pi].A;
     const float* const B = g.p[pi].B;
     float* const C = g.p[pi].C;
+    const int32_t* const bidx = g.p[pi].bidx;
     const int lda = g.p[pi].lda, ldb = g.p[pi].ldb, ldc = g.p[pi].ldc, M = g.p[pi].M, N = g.p[pi].N, nt = g.p[pi].nt;
+    const int K = g.p[pi].K, ks = g.p[pi].ks;
     const int local = bx - g.p[pi].first;
     const int tiles = ((M + 63) >> 6) * nt;
     const int s = local / tiles, t = local - s * tiles;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
     // Every wave multiplies the WHOLE 64 x 64 tile over its own eighth of the split's rows: each row of the operands enters
     // the CU once (quadrant-per-wave layouts fetch every line twice, and the L1 fill rate is what bounds the stream), and
     // the four accumulators are independent MFMA chains.
-    const int k0 = s * g.ks, k1 = min(g.K, k0 + g.ks);
+    const int k0 = s * ks, k1 = min(K, k0 + ks);
     const int per = ((k1 - k0 + 15) >> 4) * 2;
     const int kb = k0 + wave * per, ke = min(k1, kb + per);
     f32x16 acc[2][2];
@@ -86,8 +89,9 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
             const float keep = k < ke ? 1.0f : 0.0f;
             p.a0 = pa0[(int64_t)kc * lda] * keep;
             p.a1 = pa1[(int64_t)kc * lda] * keep;
-            p.b0 = pb0[(int64_t)kc * ldb];
-            p.b1 = pb1[(int64_t)kc * ldb];
+            const int kb2 = bidx ? bidx[kc] : kc;      // (32 consecutive indices share a cache line: an L1 hit)
+            p.b0 = pb0[(int64_t)kb2 * ldb];
+            p.b1 = pb1[(int64_t)kb2 * ldb];
         };
         auto mma = [&](const Pair& p) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a0, p.b0, acc[0][0], 0, 0, 0);
@@ -146,63 +150,100 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
 bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1Args& out) {
     static const int env = getenv("PP_WGRAD_T1") ? atoi(getenv("PP_WGRAD_T1")) : 1;
     static const int env_s = getenv("PP_WGRAD_T1_SPLITS") ? atoi(getenv("PP_WGRAD_T1_SPLITS")) : 0;
+    static const bool env_wgs_set = getenv("PP_WGRAD_T1_BLOCKS") != nullptr;
+    static const int env_wgs = env_wgs_set ? atoi(getenv("PP_WGRAD_T1_BLOCKS")) : 240;
     if (!env || deterministic_mode() || n <= 0) return false;
     out = WgradT1Args{};
-    const int K = q[0].K;
     int np = 0;
-    int64_t tiles = 0;
-    auto add = [&](const pp_gemm_args& a, int m_lo, int m_hi, int n_hi) -> bool {
-        if (m_hi <= m_lo || n_hi <= 0) return true;
+    // a cut [m_lo, m_hi) x [n_lo, n_hi) of problem a whose first k_lo rows contribute nothing
+    auto add = [&](const pp_gemm_args& a, int m_lo, int m_hi, int n_lo, int n_hi, int k_lo) -> bool {
+        if (m_hi <= m_lo || n_hi <= n_lo || k_lo >= a.K) return true;
         if (np >= WGRAD_T1_MAX) return false;
         WgradT1Prob& p = out.p[np++];
-        p.A = a.A + m_lo; p.B = a.B; p.C = a.C + (int64_t)m_lo * a.ldc;
+        p.A = a.A + (int64_t)k_lo * a.lda + m_lo;
+        p.bidx = a.b_idx ? a.b_idx + k_lo : nullptr;
+        p.B = a.B + (a.b_idx ? 0 : (int64_t)k_lo * a.ldb) + n_lo;
+        p.C = a.C + (int64_t)m_lo * a.ldc + n_lo;
         p.lda = (int)a.lda; p.ldb = (int)a.ldb; p.ldc = (int)a.ldc;
-        p.M = m_hi - m_lo; p.N = n_hi; p.nt = cdiv(n_hi, 64);
-        tiles += (int64_t)cdiv(p.M, 64) * p.nt;
+        p.M = m_hi - m_lo; p.N = n_hi - n_lo; p.nt = cdiv(p.N, 64);
+        p.K = a.K - k_lo;
         return true;
     };
     for (int i = 0; i < n; ++i) {
         const pp_gemm_args& a = q[i];
-        if (!a.a_kmajor || !a.b_kmajor || a.a_idx || a.b_idx || a.c_idx || a.bias || a.bias2 || a.mask || a.relu || a.colsum ||
-            !a.accumulate || a.K != K || a.M <= 0 || a.N <= 0 || a.lda >= (1 << 30) || a.ldb >= (1 << 30) || a.ldc >= (1 << 30))
+        if (!a.a_kmajor || !a.b_kmajor || a.a_idx || a.c_idx || a.bias || a.bias2 || a.mask || a.relu || a.colsum ||
+            !a.accumulate || a.K <= 0 || a.M <= 0 || a.N <= 0 || a.lda >= (1 << 30) || a.ldb >= (1 << 30) || a.ldc >= (1 << 30))
             return false;
-        // zero blocks (GemmHole): a column range [n_hi, N) over all rows, and one row range over the remaining columns
-        int n_hi = a.N, cut0 = 0, cut1 = 0;
+        // Zero blocks (GemmHole: the product is zero for m, n, k inside the block): only blocks that start at k = 0 are used
+        // (a trace's first time step has no previous variable and a zero cell state). The tensor is cut along the blocks'
+        // edges; a cell starts at the largest k1 of the blocks that cover it.
+        int mc[6] = {0, (int)a.M, 0, 0, 0, 0}, nc[6] = {0, (int)a.N, 0, 0, 0, 0};
+        int nm = 2, nn = 2;
+        GemmBlock z[2];
+        int nz = 0;
         if (holes) {
-            bool used[2] = {false, false};
             for (int b = 0; b < 2; ++b) {
-                const GemmBlock& z = holes[i].b[b];
-                if (z.m1 <= z.m0 || z.n1 <= z.n0 || z.k1 <= z.k0) { used[b] = true; continue; }
-                if (z.k0 > 0 || z.k1 < K) return false;
-                if (z.m0 <= 0 && z.m1 >= a.M && z.n1 >= a.N) { n_hi = std::min(n_hi, std::max(z.n0, 0)); used[b] = true; }
-            }
-            for (int b = 0; b < 2; ++b) {
-                if (used[b]) continue;
-                const GemmBlock& z = holes[i].b[b];
-                if (z.n0 <= 0 && z.n1 >= n_hi && cut1 == 0) { cut0 = std::max(z.m0, 0); cut1 = std::min(z.m1, (int)a.M); }
-                else return false;
+                GemmBlock h = holes[i].b[b];
+                h.m0 = std::max(h.m0, 0); h.n0 = std::max(h.n0, 0);
+                h.m1 = std::min(h.m1, (int)a.M); h.n1 = std::min(h.n1, (int)a.N); h.k1 = std::min(h.k1, (int)a.K);
+                if (h.m1 <= h.m0 || h.n1 <= h.n0 || h.k1 <= h.k0 || h.k0 > 0) continue;      // (k0 > 0: not used, still correct)
+                z[nz++] = h;
+                mc[nm++] = h.m0; mc[nm++] = h.m1;
+                nc[nn++] = h.n0; nc[nn++] = h.n1;
             }
         }
-        if (cut1 > cut0) {
-            if ((cut0 & 63) || (cut1 & 63)) return false;
-            if (!add(a, 0, cut0, n_hi) || !add(a, cut1, a.M, n_hi)) return false;
-        } else if (!add(a, 0, a.M, n_hi)) {
-            return false;
+        std::sort(mc, mc + nm);
+        std::sort(nc, nc + nn);
+        nm = (int)(std::unique(mc, mc + nm) - mc);
+        nn = (int)(std::unique(nc, nc + nn) - nc);
+        for (int jn = 0; jn + 1 < nn; ++jn) {
+            int run_lo = -1, run_hi = -1, run_k = 0;      // consecutive row intervals with the same first row merge
+            for (int jm = 0; jm + 1 < nm; ++jm) {
+                int k_lo = 0;
+                for (int b = 0; b < nz; ++b)
+                    if (z[b].m0 <= mc[jm] && z[b].m1 >= mc[jm + 1] && z[b].n0 <= nc[jn] && z[b].n1 >= nc[jn + 1])
+                        k_lo = std::max(k_lo, z[b].k1);
+                if (run_lo >= 0 && k_lo == run_k) {
+                    run_hi = mc[jm + 1];
+                } else {
+                    if (run_lo >= 0 && !add(a, run_lo, run_hi, nc[jn], nc[jn + 1], run_k)) return false;
+                    run_lo = mc[jm]; run_hi = mc[jm + 1]; run_k = k_lo;
+                }
+            }
+            if (run_lo >= 0 && !add(a, run_lo, run_hi, nc[jn], nc[jn + 1], run_k)) return false;
         }
     }
-    if (np == 0 || tiles == 0) return false;
-    // row splits: one workgroup per CU; at least 64 rows per split
-    int S = env_s > 0 ? env_s : (int)std::max<int64_t>(1, 240 / tiles);
-    S = std::min(S, std::max(1, K / 64));
-    S = std::min(S, 16);
-    out.K = K; out.S = S; out.ks = ((cdiv(K, S) + 3) / 4) * 4;
+    if (np == 0) return false;
+    // row splits: ~240 workgroups in the launch when the work is small (one per CU: fewer, longer row ranges mean fewer
+    // atomics), one workgroup per tile when there are more tiles than that; at least 64 rows per split
+    int64_t tile_rows = 0;
+    for (int i = 0; i < np; ++i) tile_rows += (int64_t)cdiv(out.p[i].M, 64) * out.p[i].nt * out.p[i].K;
+    // (large launches - ragged batches: 10^6 tile rows - want ~600 rows per workgroup: balance over 2 x 256 slots matters more
+    // than the atomics of the extra splits)
+    const int64_t blocks = env_wgs_set ? env_wgs : std::min<int64_t>(1536, std::max<int64_t>(env_wgs, tile_rows / 600));
+    const int target_rows = (int)std::max<int64_t>(64, cdiv(tile_rows, std::max<int64_t>(blocks, 1)));
     out.n_prob = np;
+    // the longest row ranges first: their workgroups start first and the short ones fill the tail
+    std::stable_sort(out.p, out.p + np, [](const WgradT1Prob& x, const WgradT1Prob& y) { return x.K > y.K; });
     int first = 0;
     for (int i = 0; i < np; ++i) {
-        out.p[i].first = first;
-        first += cdiv(out.p[i].M, 64) * out.p[i].nt * S;
+        WgradT1Prob& p = out.p[i];
+        int S = env_s > 0 ? env_s : (p.K + target_rows / 2) / target_rows;
+        S = std::max(1, std::min(S, std::min(16, std::max(1, p.K / 64))));
+        p.S = S;
+        p.ks = ((cdiv(p.K, S) + 3) / 4) * 4;
+        p.first = first;
+        first += cdiv(p.M, 64) * p.nt * S;
     }
     out.n_blocks = first;
+    static int dbg_print = getenv("PP_WGRAD_T1_PRINT") ? atoi(getenv("PP_WGRAD_T1_PRINT")) : 0;
+    if (dbg_print > 0) {
+        --dbg_print;
+        for (int i = 0; i < np; ++i)
+            fprintf(stderr, "wgrad_t1 problem %d: M=%d N=%d K=%d S=%d ks=%d gather=%d blocks=%d\n", i, out.p[i].M, out.p[i].N, out.p[i].K,
+                    out.p[i].S, out.p[i].ks, out.p[i].bidx ? 1 : 0, cdiv(out.p[i].M, 64) * out.p[i].nt * out.p[i].S);
+        fprintf(stderr, "wgrad_t1: %d workgroups, target rows %d\n", first, target_rows);
+    }
     return true;
 }
 

@@ -349,6 +349,7 @@ def test_adam_clears_consumed_gradients_and_train_step_skips_the_memset():
     # (three steps of lr 1e-3: up to three flips of one element = 6e-3 absolute; 1e-3 relative was within reach of two)
     assert max(rel_err(sa[n].numpy(), sb[n].numpy()) for n in sa) < 4e-3
     assert torch.equal(a.tensor_step, b.tensor_step)
+    b.params.copy_(a.params)                       # (what follows is about stale gradients, not about the flips above)
     g = b.loss(pb_, backward=True)                 # flag consumed: this call must NOT see stale gradients
     ga = a.loss(pa, backward=True)
     assert abs(float(g.item()) - float(ga.item())) < 1e-5 * abs(float(ga.item()))
