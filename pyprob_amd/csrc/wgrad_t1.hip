@@ -1,16 +1,20 @@
-// Weight gradients of a single-statement batch in one launch (the step after the row-panel kernel, panel.hip):
-//   dW_ih[:, :e] = dG^T E,  dW1 = dz1^T h,  dW2 = dy^T a1,  the observe-embedding's dWf1 = dE^T f1, dWf0 = dF1^T cat, dW1_o = dCat_o^T h_o
+// Weight gradients of the backward pass in one launch:
+//   dW_ih = dG^T X,  dW_hh = dG_t^T h_{t-1},  dW1 = dz1^T h,  dW2 = dy^T a1,  the observe-embedding's dWf1 = dE^T f1, dWf0 = dF1^T cat,
+//   dW1_o = dCat_o^T h_o
 // (inference_network_lstm.py:186-220 backward: torch.autograd's weight gradients of nn.LSTM / nn.Linear), every product
-// with K = the rows of the minibatch and both operands stored row = k by the panel kernel.
+// with K = rows of the minibatch and both operands stored row = k by the kernels before it (the second one optionally
+// through a row gather: h_{t-1} by prev_row, the rows of an address group).
 //
 // Why not the grouped tile kernels (gemm_f32.hip): those stage K slabs through an LDS ring, three slabs ahead - a workgroup
 // streams ~45 GB/s, so 1 024 rows cost ~13 us per tile however small the problem (measured: the four one-tile embedding
 // problems ALONE take the launch 13 us, profiles/r03g_wgrad_composition.txt). Here both operands are k-major, which is the
 // MFMA operand layout of v_mfma_f32_32x32x2_f32 as it lies in memory (lane l supplies A[k0 + l / 32][m0 + l % 32]): the
-// fragments are plain coalesced dword loads into registers, sixteen rows in flight per wave while the previous sixteen
-// multiply - no LDS, no barrier in the K loop. A workgroup (8 waves) owns a 64 x 64 output tile over one of S row ranges:
-// waves = 2 x 2 quadrants x 2 halves of the row range; the halves meet in LDS, the S ranges in float atomics on dW.
-// The bound is the fp32 matrix rate (0.59 GFLOP -> 3.8 us at peak) against ~40 MB of fragment loads through the L1s.
+// fragments are plain coalesced dword loads into a register ring, eight row pairs ahead of the MFMAs - no LDS, no barrier
+// in the K loop. A workgroup (8 waves) owns a 64 x 64 output tile over one of S row ranges; every wave multiplies the whole
+// tile over its own eighth of the rows; the waves meet in LDS, the S ranges in float atomics on dW.
+// Single-statement batches (behind the panel kernel): 23.2 -> 15.2 us. Ragged batches (K up to 2 600 rows, 33 problems):
+// 117 -> 122 us of kernel time for one launch instead of two (step 0.555 -> 0.539 ms): there the 64 x 64 tile's 16 FLOP per
+// byte of L1 fill is the limit, DESIGN.md 8.
 //
 // The reduction jobs of the backward pass (aux_jobs.hpp: column sums, table-column gradients, bias gradients, the loss) ride
 // behind the tiles as before.
