@@ -13,8 +13,7 @@
 // in the K loop. A workgroup (8 waves) owns a 64 x 64 output tile over one of S row ranges; every wave multiplies the whole
 // tile over its own eighth of the rows; the waves meet in LDS, the S ranges in float atomics on dW.
 // Single-statement batches (behind the panel kernel): 23.2 -> 15.2 us. Ragged batches (K up to 2 600 rows, 33 problems):
-// 117 -> 122 us of kernel time for one launch instead of two (step 0.555 -> 0.539 ms): there the 64 x 64 tile's 16 FLOP per
-// byte of L1 fill is the limit, DESIGN.md 8.
+// one launch instead of two, step 0.555 -> 0.525 ms; the launch is far from its bound there.
 //
 // The reduction jobs of the backward pass (aux_jobs.hpp: column sums, table-column gradients, bias gradients, the loss) ride
 // behind the tiles as before.
@@ -39,6 +38,74 @@ constexpr int WG_RING = 8;    // row pairs in the ring: nine in flight (36 loads
 struct Pair {
     float a0, a1, b0, b1;
 };
+
+// K loop of one wave: the whole 64 x 64 tile over rows [kb, ke).
+template <bool GATHER>
+__device__ __forceinline__ void wgrad_kloop(f32x16 (&acc)[2][2], const float* __restrict__ A, const float* __restrict__ B,
+                                            const int32_t* __restrict__ bidx, const int lda, const int ldb, const int M, const int N,
+                                            const int m0, const int n0, const int kb, const int ke, const int lane,
+                                            const bool hm, const bool hn) {
+    const int l31 = lane & 31, h = lane >> 5;
+    // columns beyond M / N are clamped: their products land in accumulator rows / columns the epilogue never stores.
+    // Rows beyond the range are clamped too and enter as a * 0 (a multiply, not a select: a select lets the compiler
+    // predicate the LOAD, one branch per load)
+    const float* pa0 = A + min(m0 + l31, M - 1);
+    const float* pa1 = A + min(m0 + 32 + l31, M - 1);
+    const float* pb0 = B + min(n0 + l31, N - 1);
+    const float* pb1 = B + min(n0 + 32 + l31, N - 1);
+    // Row gather on the second operand: an index loaded next to its row would have to be WAITED for, and loads return in
+    // order - s_waitcnt on the youngest load drains the whole ring, every pair (measured: the ragged step's launch ran its
+    // MFMAs a third of the time). So a lane keeps the indices of 64 rows (one coalesced load per 32 pairs, issued a block
+    // ahead: by the time it is read more than 63 younger loads have been issued) and a pair takes its two with v_readlane.
+    int idxA = 0, idxB = 0;
+    if (GATHER) idxA = bidx[min(kb + lane, ke - 1)];
+    auto load = [&](int pidx, Pair& p) {      // row pair pidx of this wave: rows kb + 2 pidx + h
+        const int k = kb + 2 * pidx + h;
+        const int kc = min(k, ke - 1);
+        const float keep = k < ke ? 1.0f : 0.0f;
+        p.a0 = pa0[(int64_t)kc * lda] * keep;
+        p.a1 = pa1[(int64_t)kc * lda] * keep;
+        int kb2 = kc;
+        if (GATHER) {
+            if ((pidx & 31) == 0) {      // first pair of a 64-row block (wave-uniform): fetch the NEXT block's indices
+                const int nb = (pidx >> 5) + 1;
+                const int v = bidx[min(kb + 64 * nb + lane, ke - 1)];
+                idxB = (nb & 1) ? v : idxB;
+                idxA = (nb & 1) ? idxA : v;
+            }
+            const int v = ((pidx >> 5) & 1) ? idxB : idxA;
+            const int sel = 2 * (pidx & 31);
+            const int r0 = __builtin_amdgcn_readlane(v, sel), r1 = __builtin_amdgcn_readlane(v, sel + 1);
+            kb2 = h ? r1 : r0;
+        }
+        p.b0 = pb0[(int64_t)kb2 * ldb];
+        p.b1 = pb1[(int64_t)kb2 * ldb];
+    };
+    auto mma = [&](const Pair& p) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a0, p.b0, acc[0][0], 0, 0, 0);
+        if (hn) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a0, p.b1, acc[0][1], 0, 0, 0);
+        if (hm) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a1, p.b0, acc[1][0], 0, 0, 0);
+        if (hm && hn) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a1, p.b1, acc[1][1], 0, 0, 0);
+    };
+    Pair f[WG_RING];
+    const int nfr = (ke - kb + 1) >> 1;      // row pairs of this wave
+    // (loads are unconditional so that the compiler counts them with s_waitcnt vmcnt(N) instead of draining the queue at
+    // a branch)
+#pragma unroll
+    for (int i = 0; i < WG_RING - 1; ++i) load(i, f[i]);
+    int i0 = 0;
+    for (; i0 + WG_RING <= nfr; i0 += WG_RING) {
+#pragma unroll
+        for (int j = 0; j < WG_RING; ++j) {
+            load(i0 + j + WG_RING - 1, f[(j + WG_RING - 1) % WG_RING]);
+            mma(f[j]);
+        }
+    }
+    const int nrem = nfr - i0;      // < WG_RING: already in the ring
+#pragma unroll
+    for (int j = 0; j < WG_RING - 1; ++j)
+        if (j < nrem) mma(f[j]);
+}
 
 __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, const AuxJobs aux) {
     __shared__ float lds[8192];      // [8 waves][16][64] partial quadrants; the reduction jobs use 2 048 floats
@@ -80,47 +147,8 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const bool hm = m0 + 32 < M, hn = n0 + 32 < N;      // second half of the tile's rows / columns exists (wave-uniform)
     if (kb < ke) {
-        // columns beyond M / N are clamped: their products land in accumulator rows / columns the epilogue never stores.
-        // Rows beyond the range are clamped too and enter as a * 0 (a multiply, not a select: a select lets the compiler
-        // predicate the LOAD, one branch per load)
-        const float* pa0 = A + min(m0 + l31, M - 1);
-        const float* pa1 = A + min(m0 + 32 + l31, M - 1);
-        const float* pb0 = B + min(n0 + l31, N - 1);
-        const float* pb1 = B + min(n0 + 32 + l31, N - 1);
-        auto load = [&](int kk, Pair& p) {
-            const int k = kk + h;
-            const int kc = min(k, ke - 1);
-            const float keep = k < ke ? 1.0f : 0.0f;
-            p.a0 = pa0[(int64_t)kc * lda] * keep;
-            p.a1 = pa1[(int64_t)kc * lda] * keep;
-            const int kb2 = bidx ? bidx[kc] : kc;      // (32 consecutive indices share a cache line: an L1 hit)
-            p.b0 = pb0[(int64_t)kb2 * ldb];
-            p.b1 = pb1[(int64_t)kb2 * ldb];
-        };
-        auto mma = [&](const Pair& p) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a0, p.b0, acc[0][0], 0, 0, 0);
-            if (hn) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a0, p.b1, acc[0][1], 0, 0, 0);
-            if (hm) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a1, p.b0, acc[1][0], 0, 0, 0);
-            if (hm && hn) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.a1, p.b1, acc[1][1], 0, 0, 0);
-        };
-        Pair f[WG_RING];
-        const int nfr = (ke - kb + 1) >> 1;      // row pairs of this wave
-        // (loads are unconditional so that the compiler counts them with s_waitcnt vmcnt(N) instead of draining the queue at
-        // a branch)
-#pragma unroll
-        for (int i = 0; i < WG_RING - 1; ++i) load(kb + 2 * i, f[i]);
-        int i0 = 0;
-        for (; i0 + WG_RING <= nfr; i0 += WG_RING) {
-#pragma unroll
-            for (int j = 0; j < WG_RING; ++j) {
-                load(kb + 2 * (i0 + j + WG_RING - 1), f[(j + WG_RING - 1) % WG_RING]);
-                mma(f[j]);
-            }
-        }
-        const int nrem = nfr - i0;      // < WG_RING: already in the ring
-#pragma unroll
-        for (int j = 0; j < WG_RING - 1; ++j)
-            if (j < nrem) mma(f[j]);
+        if (bidx) wgrad_kloop<true>(acc, A, B, bidx, lda, ldb, M, N, m0, n0, kb, ke, lane, hm, hn);
+        else wgrad_kloop<false>(acc, A, B, bidx, lda, ldb, M, N, m0, n0, kb, ke, lane, hm, hn);
     }
     // the eight waves' partial tiles meet in LDS, one 32 x 32 quadrant at a time; the S row ranges meet in float atomics
     // D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
