@@ -13,7 +13,7 @@
 // in the K loop. A workgroup (8 waves) owns a 64 x 64 output tile over one of S row ranges; every wave multiplies the whole
 // tile over its own eighth of the rows; the waves meet in LDS, the S ranges in float atomics on dW.
 // Single-statement batches (behind the panel kernel): 23.2 -> 15.2 us. Ragged batches (K up to 2 600 rows, 33 problems):
-// one launch instead of two, step 0.555 -> 0.525 ms; the launch is far from its bound there.
+// one launch instead of two, step 0.555 -> 0.519 ms; what bounds it there: DESIGN.md 8.2 (the float atomics).
 //
 // The reduction jobs of the backward pass (aux_jobs.hpp: column sums, table-column gradients, bias gradients, the loss) ride
 // behind the tiles as before.
@@ -25,6 +25,9 @@
 #include <algorithm>
 
 namespace pp {
+
+extern long long* g_wgtrace;   // gemm_f32.hip (pp_debug_wgtrace)
+extern int g_wgtrace_cap, g_wgtrace_mode;
 
 namespace {
 
@@ -109,9 +112,18 @@ __device__ __forceinline__ void wgrad_kloop(f32x16 (&acc)[2][2], const float* __
 
 __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, const AuxJobs aux) {
     __shared__ float lds[8192];      // [8 waves][16][64] partial quadrants; the reduction jobs use 2 048 floats
-    const int bx = blockIdx.x;
-    if (bx >= g.n_blocks) {
-        aux_job_run(aux, bx - g.n_blocks, lds);
+    const long long t_start = g.trace ? wall_clock64() : 0;
+    // The reduction jobs ride in front of the tiles when the tiles need more than one round of the chip's workgroup slots
+    // (ragged batches: they would otherwise start when the last tile has been dispatched and BE the tail of the launch,
+    // ~15 us, tools/wg_trace_wgrad.py), else behind them (one round: the tiles are the long workgroups and start at once).
+    const int aux_lo = g.aux_first ? 0 : g.n_blocks;
+    const int bx = (int)blockIdx.x - (g.aux_first ? aux.n_blocks : 0);
+    if ((int)blockIdx.x >= aux_lo && (int)blockIdx.x < aux_lo + aux.n_blocks) {
+        aux_job_run(aux, (int)blockIdx.x - aux_lo, lds);
+        if (g.trace && threadIdx.x == 0) {
+            long long* tr = g.trace + 8 * blockIdx.x;
+            tr[0] = t_start; tr[1] = wall_clock64(); tr[2] = 100; tr[3] = 0;
+        }
         return;
     }
     int pi = 0;
@@ -150,12 +162,17 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
         if (bidx) wgrad_kloop<true>(acc, A, B, bidx, lda, ldb, M, N, m0, n0, kb, ke, lane, hm, hn);
         else wgrad_kloop<false>(acc, A, B, bidx, lda, ldb, M, N, m0, n0, kb, ke, lane, hm, hn);
     }
+    if (g.trace && threadIdx.x == 0) g.trace[8 * blockIdx.x + 4] = wall_clock64();
     // the eight waves' partial tiles meet in LDS, one 32 x 32 quadrant at a time; the S row ranges meet in float atomics
     // D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // (the atomics are issued after the LAST round: a barrier waits for the workgroup's outstanding memory operations, and an
+    // atomic is a ~2 us trip to memory - issued per round they cost the workgroup 9-11 us of its 30, tools/wg_trace_wgrad.py)
+    float out[2][2][2];
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj) {
+            out[qi][qj][0] = out[qi][qj][1] = 0.0f;
             if ((qi && !hm) || (qj && !hn)) continue;      // (block-uniform)
             if (qi + qj > 0) __syncthreads();
             float* mine = lds + wave * 1024 + lane;
@@ -169,11 +186,26 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
                 float v = 0.0f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += lds[w * 1024 + r * 64 + lane];
-                const int gm = m0 + 32 * qi + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int gn = n0 + 32 * qj + l31;
-                if (gm < M && gn < N) atomicAdd(C + (int64_t)gm * ldc + gn, v);
+                out[qi][qj][e] = v;
             }
         }
+    }
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj) {
+            if ((qi && !hm) || (qj && !hn)) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * wave + e;
+                const int gm = m0 + 32 * qi + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gn = n0 + 32 * qj + l31;
+                if (gm < M && gn < N) atomicAdd(C + (int64_t)gm * ldc + gn, out[qi][qj][e]);
+            }
+        }
+    if (g.trace && threadIdx.x == 0) {
+        long long* tr = g.trace + 8 * blockIdx.x;
+        tr[0] = t_start; tr[1] = wall_clock64(); tr[2] = pi; tr[3] = s;
     }
 }
 
@@ -282,7 +314,11 @@ bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1
 int wgrad_t1(const WgradT1Args& a, const AuxJobs* aux, hipStream_t st) {
     static const AuxJobs none{};
     const AuxJobs& j = aux ? *aux : none;
-    hipLaunchKernelGGL(wgrad_t1_kernel, dim3(a.n_blocks + (aux ? j.n_blocks : 0)), dim3(512), 0, st, a, j);
+    const int blocks = a.n_blocks + (aux ? j.n_blocks : 0);
+    WgradT1Args t = a;
+    t.aux_first = (aux && a.n_blocks > 512) ? 1 : 0;      // 2 workgroups x 256 CUs = one round
+    if (g_wgtrace && g_wgtrace_mode == 1 && blocks <= g_wgtrace_cap) t.trace = g_wgtrace;
+    hipLaunchKernelGGL(wgrad_t1_kernel, dim3(blocks), dim3(512), 0, st, t, j);
     PP_LAUNCH_CHECK("wgrad_t1");
     return 0;
 }

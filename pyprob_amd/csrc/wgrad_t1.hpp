@@ -22,7 +22,9 @@ struct WgradT1Prob {
 
 struct WgradT1Args {
     WgradT1Prob p[WGRAD_T1_MAX];
-    int n_prob, n_blocks;     // problems; workgroups of all tiles (the reduction jobs follow)
+    int n_prob, n_blocks;     // problems; workgroups of all tiles
+    int aux_first;            // workgroups of the reduction jobs in front of the tiles (launches with more than one round of tiles) or behind
+    long long* trace;         // debug (pp_debug_wgtrace, mode 1): per workgroup {start, end, problem, split, K loop done} wall-clock ticks
 };
 
 // Takes the queued weight-gradient products (queue_wgrad: k-major operands, accumulate) when every one of them fits the
