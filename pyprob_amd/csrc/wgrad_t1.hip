@@ -165,8 +165,8 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
     if (g.trace && threadIdx.x == 0) g.trace[8 * blockIdx.x + 4] = wall_clock64();
     // the eight waves' partial tiles meet in LDS, one 32 x 32 quadrant at a time; the S row ranges meet in float atomics
     // D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    // (the atomics are issued after the LAST round: a barrier waits for the workgroup's outstanding memory operations, and an
-    // atomic is a ~2 us trip to memory - issued per round they cost the workgroup 9-11 us of its 30, tools/wg_trace_wgrad.py)
+    // (launches with several rounds of workgroups issue the atomics after the LAST LDS round: a barrier waits for the
+    // workgroup's outstanding memory operations and the memory side is saturated with atomics there, tools/wg_trace_wgrad.py)
     float out[2][2][2];
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
@@ -187,6 +187,11 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += lds[w * 1024 + r * 64 + lane];
                 out[qi][qj][e] = v;
+                if (!g.aux_first) {      // one round of workgroups: the atomics of a round overlap the next round's LDS traffic
+                    const int gm = m0 + 32 * qi + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int gn = n0 + 32 * qj + l31;
+                    if (gm < M && gn < N) atomicAdd(C + (int64_t)gm * ldc + gn, v);
+                }
             }
         }
     }
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
     for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj) {
-            if ((qi && !hm) || (qj && !hn)) continue;
+            if (!g.aux_first || (qi && !hm) || (qj && !hn)) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int r = 2 * wave + e;
