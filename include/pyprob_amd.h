@@ -501,6 +501,13 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
  *   4  the draw + log q kernel of pp_is_step                         work = algorithmic bytes
  * pp_prof_collect returns the elapsed milliseconds and the work of every recorded launch (flops_out).
  * ---------------------------------------------------------------------------------------------------- */
+/* Host-side plan of the streaming weight-gradient launch (csrc/wgrad_t1.hip) for `count` queued products dW += A^T B (both
+ * operands k-major: torch.autograd's weight gradients of nn.Linear / nn.LSTM, inference_network_lstm.py:186-220 backward) -
+ * no device work, for tests of the host logic. zero_blocks: [count][2][6] = {m0, m1, n0, n1, k0, k1} or NULL; out: [cap][10] =
+ * {M, N, K, S, ks, gather, first workgroup, C offset, A offset, B (or index) offset}. Returns the number of problems (0: the
+ * tile kernels take the flush). */
+int pp_debug_wgrad_plan(const pp_gemm_args* products, const int32_t* zero_blocks, int32_t count, int64_t* out, int32_t cap,
+                        int32_t* n_blocks);
 int pp_prof_arm(int32_t which, int32_t max_samples);          /* allocate event pairs; 0 disarms */
 int pp_prof_stride(int32_t stride);                           /* time every stride-th launch of the class (default 1):
                                                                  an event pair costs the stream ~3 us, a stride keeps the

@@ -329,3 +329,34 @@ int wgrad_t1(const WgradT1Args& a, const AuxJobs* aux, hipStream_t st) {
 }
 
 }  // namespace pp
+
+// Host-side plan of the weight-gradient launch for `count` queued products (no device work): which cuts of the tensors become
+// problems, their row ranges and splits. For tests of the host logic (tests/test_host.py). zero_blocks: [count][2][6] =
+// {m0, m1, n0, n1, k0, k1} per product or NULL; out: [cap][10] = {M, N, K, S, ks, gather, first, C offset, A offset, B offset}
+// (offsets in floats from the product's own pointers). Returns the number of problems, 0 if the tile kernels take the flush.
+extern "C" int pp_debug_wgrad_plan(const pp_gemm_args* q, const int32_t* zero_blocks, int32_t count, int64_t* out, int32_t cap,
+                                   int32_t* n_blocks) {
+    std::vector<pp::GemmHole> holes((size_t)std::max(count, 0));
+    for (int i = 0; i < count && zero_blocks; ++i)
+        for (int b = 0; b < 2; ++b) {
+            const int32_t* z = zero_blocks + ((int64_t)i * 2 + b) * 6;
+            holes[i].b[b] = pp::GemmBlock{z[0], z[1], z[2], z[3], z[4], z[5]};
+        }
+    pp::WgradT1Args a;
+    if (!pp::wgrad_t1_build(q, zero_blocks ? holes.data() : nullptr, count, a)) return 0;
+    if (n_blocks) *n_blocks = a.n_blocks;
+    for (int i = 0; i < a.n_prob && i < cap; ++i) {
+        const pp::WgradT1Prob& p = a.p[i];
+        // which product does the problem belong to: the one whose C range contains its C
+        int src = -1;
+        for (int k = 0; k < count; ++k)
+            if (p.C >= q[k].C && p.C < q[k].C + (int64_t)q[k].M * q[k].ldc) src = k;
+        int64_t* o = out + (int64_t)i * 10;
+        o[0] = p.M; o[1] = p.N; o[2] = p.K; o[3] = p.S; o[4] = p.ks; o[5] = p.bidx ? 1 : 0; o[6] = p.first;
+        o[7] = src >= 0 ? p.C - q[src].C : -1;
+        o[8] = src >= 0 ? p.A - q[src].A : -1;
+        o[9] = src >= 0 ? (p.bidx ? p.bidx - q[src].b_idx : (p.B - q[src].B)) : -1;
+    }
+    return a.n_prob;
+}
+

@@ -146,6 +146,7 @@ PROTOTYPES = {
     'pp_dp_reduce_grads': (C.c_int, [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
     'pp_debug_timeline': (C.c_int, [vp]),
     'pp_debug_wgtrace': (C.c_int, [vp, C.c_int32, C.c_int32]),
+    'pp_debug_wgrad_plan': (C.c_int, [vp, vp, i32, vp, i32, vp]),
     'pp_prof_arm': (C.c_int, [i32, i32]),
     'pp_prof_stride': (C.c_int, [i32]),
     'pp_prof_collect': (C.c_int, [vp, i32, vp, vp]),

@@ -222,3 +222,84 @@ def test_bench_stdout_carries_only_the_json_line():
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"ok": 1}\n'
     assert 'banner written by a C library' in r.stderr and 'python chatter' in r.stderr
+
+
+# ---- host logic of the streaming weight-gradient launch (csrc/wgrad_t1.hip), no device work -----------------------------
+def _wgrad_plan(products, zero_blocks=None):
+    """products: dicts M, N, K, lda, ldb, ldc [, gather] -> list of problems {M, N, K, S, ks, gather, first, c_off, a_off, b_off}."""
+    import ctypes as C
+    from pyprob_amd import lib as L
+    lib = L.load()
+    n = len(products)
+    arr = (L.pp_gemm_args * n)()
+    for i, p in enumerate(products):
+        base = 0x10000000 * (i + 1)                      # fake device addresses: never dereferenced by the planner
+        a = arr[i]
+        a.A, a.lda, a.B, a.ldb, a.C, a.ldc = base, p['lda'], base + 0x4000000, p['ldb'], base + 0x8000000, p['ldc']
+        a.b_idx = base + 0xC000000 if p.get('gather') else None
+        a.M, a.N, a.K, a.a_kmajor, a.b_kmajor, a.accumulate, a.split_k = p['M'], p['N'], p['K'], 1, 1, 1, 1
+        for k, v in p.get('extra', {}).items():
+            setattr(a, k, v)
+    zb = None
+    if zero_blocks is not None:
+        zb = np.ascontiguousarray(zero_blocks, np.int32).reshape(n, 2, 6)
+    out = np.zeros((64, 10), np.int64)
+    nb = C.c_int32(0)
+    k = lib.pp_debug_wgrad_plan(arr, zb.ctypes.data if zb is not None else None, n, out.ctypes.data, 64, C.byref(nb))
+    keys = ('M', 'N', 'K', 'S', 'ks', 'gather', 'first', 'c_off', 'a_off', 'b_off')
+    return [dict(zip(keys, map(int, out[i]))) for i in range(k)], nb.value
+
+
+def test_wgrad_plan_single_statement_step(monkeypatch):
+    """The products of a GUM step (B = 1024, H = 512): dW_ih 2048 x 68 with the forget-gate rows and the previous-variable
+    columns zero for ALL rows (left out), the head and observe-embedding leaves; ~240 workgroups -> three row ranges each."""
+    monkeypatch.delenv('PP_DETERMINISTIC', raising=False)
+    H, B, I = 512, 1024, 212
+    prods = [dict(M=4 * H, N=68, K=B, lda=4 * H, ldb=68, ldc=I), dict(M=30, N=271, K=B, lda=32, ldb=272, ldc=271),
+             dict(M=271, N=512, K=B, lda=272, ldb=512, ldc=512), dict(M=64, N=64, K=B, lda=64, ldb=64, ldc=64),
+             dict(M=32, N=16, K=B, lda=64, ldb=16, ldc=16)]
+    zb = np.zeros((5, 2, 6), np.int32)
+    zb[0, 0] = (0, 4 * H, 64, 68, 0, B)                  # columns [64, 68): no previous variable at t = 0
+    zb[0, 1] = (H, 2 * H, 0, 68, 0, B)                   # forget gate: c_{-1} = 0
+    plan, blocks = _wgrad_plan(prods, zb)
+    ih = [p for p in plan if p['N'] == 64 and p['M'] in (512, 1024)]
+    assert sorted((p['M'], p['c_off'], p['a_off']) for p in ih) == [(512, 0, 0), (1024, 2 * H * I, 2 * H)]
+    assert all(p['K'] == B and p['S'] == 3 and p['ks'] % 4 == 0 and p['ks'] * 3 >= B and not p['gather'] for p in plan)
+    assert len(plan) == 6
+    tiles = sum(-(-p['M'] // 64) * -(-p['N'] // 64) for p in plan)
+    assert tiles == 8 + 16 + 5 + 40 + 1 + 1 and blocks == 3 * tiles
+    firsts = sorted(p['first'] for p in plan)
+    assert firsts[0] == 0 and len(set(firsts)) == len(plan)          # the problems tile the launch without overlap
+
+
+def test_wgrad_plan_ragged_step_prefix_blocks_and_gather(monkeypatch):
+    """A ragged step: the zero blocks of dW_ih cover only the first B rows (first time steps) - those cells START at row B;
+    dW_hh gathers h_{t-1} by prev_row (the index pointer moves with the first row, the operand pointer does not)."""
+    monkeypatch.delenv('PP_DETERMINISTIC', raising=False)
+    H, B, R, I = 512, 1024, 2600, 212
+    prods = [dict(M=4 * H, N=68, K=R, lda=4 * H, ldb=68, ldc=I), dict(M=4 * H, N=H, K=R - B, lda=4 * H, ldb=H, ldc=H, gather=True)]
+    zb = np.zeros((2, 2, 6), np.int32)
+    zb[0, 0] = (0, 4 * H, 64, 200, 0, B)
+    zb[0, 1] = (H, 2 * H, 0, 68, 0, B)
+    plan, blocks = _wgrad_plan(prods, zb)
+    cells = {(p['c_off'], p['M'], p['N']): p for p in plan if not p['gather']}
+    assert set(cells) == {(0, 512, 64), (H * I, 512, 64), (2 * H * I, 1024, 64), (64, 2048, 4)}
+    assert cells[(0, 512, 64)]['K'] == R and cells[(0, 512, 64)]['a_off'] == 0
+    assert cells[(H * I, 512, 64)]['K'] == R - B and cells[(H * I, 512, 64)]['a_off'] == B * 4 * H + H      # rows from B on
+    assert cells[(H * I, 512, 64)]['b_off'] == B * 68
+    assert cells[(64, 2048, 4)]['K'] == R - B and cells[(64, 2048, 4)]['b_off'] == B * 68 + 64
+    hh = [p for p in plan if p['gather']]
+    assert len(hh) == 1 and hh[0]['M'] == 2048 and hh[0]['N'] == 512 and hh[0]['K'] == R - B and hh[0]['b_off'] == 0
+    assert plan[0]['K'] == max(p['K'] for p in plan)                  # longest row ranges first
+    assert all(p['S'] >= 1 and p['ks'] * p['S'] >= p['K'] and p['K'] // max(p['S'], 1) >= 64 for p in plan)
+    assert blocks == sum(-(-p['M'] // 64) * -(-p['N'] // 64) * p['S'] for p in plan)
+
+
+def test_wgrad_plan_refuses_what_only_the_tile_kernels_do(monkeypatch):
+    monkeypatch.delenv('PP_DETERMINISTIC', raising=False)
+    ok = dict(M=64, N=64, K=256, lda=64, ldb=64, ldc=64)
+    assert _wgrad_plan([ok])[0]
+    for extra in (dict(a_kmajor=0), dict(b_kmajor=0), dict(accumulate=0), dict(relu=1), dict(a_idx=0x1000), dict(c_idx=0x1000),
+                  dict(colsum=0x1000), dict(bias=0x1000)):
+        assert _wgrad_plan([dict(ok, extra=extra)])[0] == [], extra
+    assert _wgrad_plan([dict(ok)] * 41)[0] == []                       # more problems than one launch carries
