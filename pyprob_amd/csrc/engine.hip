@@ -434,7 +434,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     AddrBias abias{};
     int n_present = 0, only_addr = 0;   // addresses that occur in the batch
     if (compact) {
-        abias.AB = w.AB; abias.gsum = w.gsum;
+        abias.AB = w.AB; abias.gsum = w.gsum; abias.step_epoch = w.epoch;
         abias.W = P + net->w_ih; abias.b_ih = P + net->b_ih; abias.b_hh = P + net->b_hh;
         abias.params = P; abias.at = net->addr_table; abias.ldw = I;
         abias.N = 4 * H; abias.c2 = c2x; abias.c3 = c2x + net->dtype_dim; abias.c4 = c2x + ne_x;
@@ -495,7 +495,6 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             ptr.H = H; ptr.hid = ad.hid; ptr.e = net->e_obs;
             ptr.tiles_ih = 3 * H / 64;
             ptr.n_blocks = panel_transpose_blocks(H, ad.hid);
-            ptr.epoch = w.epoch;
         }
         PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb, compact ? &abias : nullptr,
                                    panel ? &ptr : nullptr));

@@ -82,6 +82,8 @@ struct AddrBias {
     int N, c2, c3, c4, c5, I, n_addr, first_block;
     uint32_t present[32];   // bit a: address a occurs in the batch (current or previous statement); n_addr <= 1024
     int all_present;
+    int* step_epoch;        // counts the calls of this workspace (the job rides in a call's FIRST launch): the tag of the
+                            // cross-workgroup hand-offs of the launches that follow (handoff.hpp); nullptr: not counted
 };
 
 __device__ __forceinline__ bool addr_present(const uint32_t (&mask)[32], int all, int a) {
@@ -98,6 +100,7 @@ static inline int addr_bias_blocks(const AddrBias& ab) { return ab.n_addr * ((ab
 // eight partial sums meet through DPP. Needs ldw, c2 and ne to be multiples of 4, 2 and 2 (engine.hip checks).
 __device__ __forceinline__ void addr_bias_block(const AddrBias& ab, int bb, float* lds) {
     const int tid = threadIdx.x;
+    if (bb == 0 && tid == 0 && ab.step_epoch) ab.step_epoch[0] += 1;
     const int nchunk = (ab.N + ADDR_BIAS_ROWS - 1) / ADDR_BIAS_ROWS;
     const int a = bb / nchunk, n0 = (bb % nchunk) * ADDR_BIAS_ROWS;
     if (a >= ab.n_addr || !addr_present(ab.present, ab.all_present, a)) return;   // workgroup-uniform

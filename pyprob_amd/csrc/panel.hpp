@@ -43,19 +43,18 @@ constexpr int PANEL_OBS_LDS = 10240 + 8 + 4 * 64;      // the LDS image (+ its d
 // (Adam just changed the weights) by extra workgroups of the step's FIRST launch (obs_embed_fwd_kernel):
 //   block b < tiles_ih : rows [n0, n0 + 64) of W_ih (gates i, g, o only), columns [0, e)  ->  WihT[k][n0 ..]
 //   the rest           : tile (ti, tj) of W1 [hid][H]  ->  W1T[64 tj ..][64 ti ..]; rows beyond hid are written as zeros
+// (the epoch of the pair hand-off is advanced by the bias job of the same launch, gather.hpp AddrBias::step_epoch)
 struct PanelTranspose {
     const float* Wih; int64_t ldw; float* WihT;   // WihT [e][4H + 64]
     const float* W1; float* W1T; int64_t ld1T;    // W1 [hid][H], W1T [H][ld1T], ld1T = 64 ceil(hid / 64)
     int H, hid, e;
     int tiles_ih, first_block, n_blocks;           // 3 H / 64 tiles of W_ih; first workgroup of the job in its launch
-    int* epoch;                                    // the job's first workgroup advances the step's hand-off epoch
 };
 static inline int panel_transpose_blocks(int H, int hid) { return 3 * H / 64 + ((hid + 63) / 64) * (H / 64); }
 
 __device__ __forceinline__ void panel_transpose_block(const PanelTranspose& tr, int b, float* lds /* >= 64 * 65 floats */) {
     const int tid = threadIdx.x;       // 256 threads
     const int tx = tid & 63, ty = tid >> 6;
-    if (b == 0 && tid == 0 && tr.epoch) tr.epoch[0] += 1;
     const bool ih = b < tr.tiles_ih;
     const float* src; int64_t ld_src; int r0, c0, rmax, cmax;
     float* dst; int64_t ld_dst; int dr0, dc0, out_rows;
