@@ -61,7 +61,12 @@ class Normal(Distribution):
     """pyprob/distributions/normal.py:7-31"""
 
     def __init__(self, loc, scale):
-        loc, scale = _t(loc).float(), _t(scale).float()
+        # (a float32 tensor is taken as it is: on a state.ParticleTensor every torch call is a trip through __torch_function__,
+        # ~5 us each, and a posterior call builds two of these per statement)
+        if not (torch.is_tensor(loc) and loc.dtype == torch.float32):
+            loc = _t(loc).float()
+        if not (torch.is_tensor(scale) and scale.dtype == torch.float32):
+            scale = _t(scale).float()
         if scale.device != loc.device and not (scale.numel() == 1 and scale.device.type == 'cpu'):
             scale = scale.to(loc.device)      # (a host scalar next to device locations stays where it is: the device kernels take
                                               #  it as a cached constant, and a posterior call pays no copy for it)

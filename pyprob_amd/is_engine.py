@@ -136,6 +136,8 @@ class ISRunner:
         def t(v):
             if isinstance(v, (int, float)) or (torch.is_tensor(v) and v.device.type == 'cpu' and v.numel() == 1):
                 return self._const(float(v))          # cached device scalar: no host-to-device copy per statement
+            if torch.is_tensor(v) and v.dtype == torch.float32 and v.device == dev and v.dim() == 1 and v.is_contiguous():
+                return v.as_subclass(torch.Tensor)    # (per-particle parameters of a lock-step run: one call, not five)
             return torch.as_tensor(v, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(dev).contiguous()
 
         def s(v):
