@@ -583,7 +583,7 @@ def main():
             # reference algorithm, weight gradients of one step: dW_ih [4H, I], dW1 [hid, H], dW2 [30, hid], the observe
             # embedding's four weight matrices (64x64 twice, 32x16 twice); K = batch rows
             wgrad_alg = 2.0 * B * (4 * H * I + hid_ * H + 30 * hid_ + 2 * 64 * 64 + 2 * 32 * 16)
-            t1 = panel_expected and os.environ.get('PP_WGRAD_T1', '1') != '0'
+            t1 = os.environ.get('PP_WGRAD_T1', '1') != '0' and os.environ.get('PP_DETERMINISTIC', '0') != '1'
             wgrad = roof(dominant, 'wgrad_group',
                          ('wgrad_t1_kernel (csrc/wgrad_t1.hip: ' if t1 else 'gemm_f32_async_grouped_aux_kernel (') +
                          'last launch of the backward pass: the weight gradients dW_ih[:, :e_obs] %dx%dx%d, dW1, dW2 and the '
