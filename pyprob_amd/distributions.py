@@ -61,17 +61,21 @@ class Normal(Distribution):
     """pyprob/distributions/normal.py:7-31"""
 
     def __init__(self, loc, scale):
-        # (a float32 tensor is taken as it is: on a state.ParticleTensor every torch call is a trip through __torch_function__,
-        # ~5 us each, and a posterior call builds two of these per statement)
-        if not (torch.is_tensor(loc) and loc.dtype == torch.float32):
-            loc = _t(loc).float()
-        if not (torch.is_tensor(scale) and scale.dtype == torch.float32):
-            scale = _t(scale).float()
-        if scale.device != loc.device and not (scale.numel() == 1 and scale.device.type == 'cpu'):
-            scale = scale.to(loc.device)      # (a host scalar next to device locations stays where it is: the device kernels take
-                                              #  it as a cached constant, and a posterior call pays no copy for it)
-        if scale.numel() == 1 and scale.device.type == 'cpu' and not float(scale) > 0.0:   # (what torch's validation rejects)
-            raise ValueError('Normal: the scale must be positive, got {}'.format(float(scale)))
+        # A state.ParticleTensor (per-particle value of a lock-step run) pays a Python __torch_function__ round trip for EVERY
+        # torch call and attribute read (~4 us each; a posterior call builds two of these objects per statement): the
+        # constructor only looks at metadata, so it runs with the subclass dispatch off, and a float32 tensor is taken as it is.
+        with torch._C.DisableTorchFunctionSubclass():
+            if not (torch.is_tensor(loc) and loc.dtype == torch.float32):
+                loc = _t(loc).float()
+            if not (torch.is_tensor(scale) and scale.dtype == torch.float32):
+                scale = _t(scale).float()
+            if scale.device != loc.device and not (scale.numel() == 1 and scale.device.type == 'cpu'):
+                scale = scale.to(loc.device)      # (a host scalar next to device locations stays where it is: the device kernels
+                                                  #  take it as a cached constant, and a posterior call pays no copy for it)
+            if scale.numel() == 1 and scale.device.type == 'cpu' and not float(scale) > 0.0:   # (what torch's validation rejects)
+                raise ValueError('Normal: the scale must be positive, got {}'.format(float(scale)))
+            # per-particle parameters are handed out as they are (see _raw_params)
+            self._raw = loc.shape == scale.shape or type(loc).__name__ == 'ParticleTensor' or type(scale).__name__ == 'ParticleTensor'
         self._loc, self._scale = loc, scale
         super().__init__('Normal', 'Normal')
 
@@ -87,8 +91,7 @@ class Normal(Distribution):
     def _raw_params(self):
         # per-particle parameters of a lock-step run (state.ParticleTensor) are handed out as they are: building the
         # torch.distributions object would broadcast - i.e. READ - a value whose draw may still be deferred
-        return self._td is None and (self._loc.shape == self._scale.shape or type(self._loc).__name__ == 'ParticleTensor' or
-                                     type(self._scale).__name__ == 'ParticleTensor')
+        return self._td is None and self._raw
 
     @property
     def mean(self):

@@ -131,6 +131,10 @@ class ISRunner:
         """(kind, p0, p0_stride, p1, p1_stride) of pp_logweight_accumulate for a prior / likelihood distribution object
         (duck-typed: .name and the parameter attributes of pyprob/distributions/*.py); None if the family has no device
         kernel. Parameters may be shared (one element) or per particle (n elements)."""
+        with torch._C.DisableTorchFunctionSubclass():     # (metadata only: no Python dispatch per attribute of a ParticleTensor)
+            return self._dist_term(distribution)
+
+    def _dist_term(self, distribution):
         dev = self.dev
 
         def t(v):
