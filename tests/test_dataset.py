@@ -380,3 +380,27 @@ def test_bernoulli_programs_pack_from_a_dataset(tmp_path):
     b = spec.address_id[[a.address for a in spec.addresses if a.dist_name == 'Bernoulli'][0]]
     rows = got.addr == b
     assert np.all(got.prior[rows, 0] == rows.sum()) and np.all(got.prior[rows, 1] == got.value[rows].sum())
+
+
+def test_columnar_dataset_blocks_and_refill():
+    """packed.ColumnarDataset: a minibatch is one contiguous block [obs | value | prior]; refill() writes a new chunk into the SAME
+    storage (the PackedBatch objects of the blocks - raw pointers - stay valid, nn.optimize's resident chunks) and refuses a chunk
+    of another shape."""
+    import torch
+    from pyprob_amd.packed import ColumnarDataset
+    g = torch.Generator().manual_seed(3)
+    n, B, w = 70, 16, 2
+    obs, val, pri = torch.randn(n, w, generator=g), torch.randn(n, generator=g), torch.randn(n, 2, generator=g)
+    cd = ColumnarDataset(obs, val, pri, B)
+    assert cd.n_batches == 4 and cd.blocks.shape == (4, B * (w + 3))
+    for i in range(4):
+        o, v, p = cd.columns(i)
+        assert torch.equal(o, obs[i * B:(i + 1) * B]) and torch.equal(v, val[i * B:(i + 1) * B]) and torch.equal(p, pri[i * B:(i + 1) * B])
+        assert o.data_ptr() == cd.blocks[i].data_ptr()                      # views, not copies
+    ptr = cd.blocks.data_ptr()
+    obs2, val2, pri2 = obs + 1, val * 2, pri - 1
+    assert cd.refill(obs2, val2, pri2) and cd.blocks.data_ptr() == ptr
+    o, v, p = cd.columns(2)
+    assert torch.equal(o, obs2[2 * B:3 * B]) and torch.equal(v, val2[2 * B:3 * B]) and torch.equal(p, pri2[2 * B:3 * B])
+    assert not cd.refill(obs2[:40], val2[:40], pri2[:40])                     # two blocks instead of four: a new dataset is needed
+    assert torch.equal(cd.columns(3)[1], val2[3 * B:4 * B])                   # ... and nothing was touched
