@@ -91,7 +91,7 @@ class Normal(Distribution):
     def _raw_params(self):
         # per-particle parameters of a lock-step run (state.ParticleTensor) are handed out as they are: building the
         # torch.distributions object would broadcast - i.e. READ - a value whose draw may still be deferred
-        return self._td is None and self._raw
+        return self._td is None and getattr(self, '_raw', False)
 
     @property
     def mean(self):
