@@ -19,7 +19,6 @@
 // behind the tiles as before.
 #include "wgrad_t1.hpp"
 
-#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -305,14 +304,6 @@ bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1
         first += cdiv(p.M, 64) * p.nt * S;
     }
     out.n_blocks = first;
-    static int dbg_print = getenv("PP_WGRAD_T1_PRINT") ? atoi(getenv("PP_WGRAD_T1_PRINT")) : 0;
-    if (dbg_print > 0) {
-        --dbg_print;
-        for (int i = 0; i < np; ++i)
-            fprintf(stderr, "wgrad_t1 problem %d: M=%d N=%d K=%d S=%d ks=%d gather=%d blocks=%d\n", i, out.p[i].M, out.p[i].N, out.p[i].K,
-                    out.p[i].S, out.p[i].ks, out.p[i].bidx ? 1 : 0, cdiv(out.p[i].M, 64) * out.p[i].nt * out.p[i].S);
-        fprintf(stderr, "wgrad_t1: %d workgroups, target rows %d\n", first, target_rows);
-    }
     return true;
 }
 

@@ -1,6 +1,6 @@
 """Per-workgroup timeline of wgrad_t1_kernel (+ the reduction jobs behind it) for one ragged training step (GPU box):
-   PP_WGRAD_T1_PRINT=1 python tools/wg_trace_wgrad.py      # prints the problem list (stderr) and, per problem, when its workgroups
-                                                            # start, how long the K loop and the epilogue take, when they end"""
+   python tools/wg_trace_wgrad.py      # per problem of the launch (pp_debug_wgrad_plan lists them): when its workgroups start, how
+                                       # long the K loop and the epilogue take, when they end; resident workgroups over time"""
 import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
