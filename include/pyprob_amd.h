@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 8
+#define PP_ABI_VERSION 9
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -375,6 +375,20 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
                float* h, float* c, int32_t state_rows, const float* value_in, float* value_out, float* logq_out,
                uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream);
 
+/* pp_is_step for the particles of a diverged control-flow path (pyprob/state.py:203-219 on a subset of the traces of
+ * pyprob/model.py:59): particle i of the call owns row rows[i] of (h, c) (dev int64 [n], distinct rows; NULL = row i) - the
+ * state is read and written in place through the list, every other per-particle array (prev_value, prior, value_in / out,
+ * logq_out) is compact [n]. Statements after the first one only (prev_addr_id >= 0), and only where the fused statement
+ * kernel exists (csrc/is_step_fused.hip: one-layer LSTM, H = 256 or 512, head at most 32 outputs wide):
+ * pp_is_step_fused_supported(net, addr_id) != 0; PP_EINVAL otherwise (the caller gathers / scatters the rows itself).
+ * With that kernel a statement is ONE launch (+ one preparation launch): gates, LSTM cell, both head layers, the draw and
+ * log q; the gate pre-activations never reach memory, (h, c) are read once and written once. */
+int pp_is_step_rows(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+                    const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride,
+                    float* h, float* c, int32_t state_rows, const int64_t* rows, const float* value_in, float* value_out,
+                    float* logq_out, uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream);
+int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id);
+
 /* log p(value) of prior and likelihood terms, accumulated into the per-particle log-weight:
  *     lw[i] += scale * log_prob(dist(params_i); x_i)
  * (state.py:211-217: +prior, -proposal; state.py:147-149: +likelihood_importance * likelihood), evaluated in fp32 like
@@ -499,6 +513,8 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
  *   2  observe embedding + LSTM input rows (the gather path)         work = algorithmic bytes
  *   3  pp_adam_step (optimizer pass over the flat buffers)           work = algorithmic bytes
  *   4  the draw + log q kernel of pp_is_step                         work = algorithmic bytes
+ *   5  the fused statement kernel of pp_is_step / pp_is_step_rows    work = FLOPs (input + recurrent
+ *                                                                    product and both head layers per particle)
  * pp_prof_collect returns the elapsed milliseconds and the work of every recorded launch (flops_out).
  * ---------------------------------------------------------------------------------------------------- */
 /* Host-side plan of the streaming weight-gradient launch (csrc/wgrad_t1.hip) for `count` queued products dW += A^T B (both

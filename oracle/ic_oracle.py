@@ -399,11 +399,15 @@ def bernoulli_log_prob(v, probs):
     return v * np.log(pc) + (1 - v) * np.log1p(-pc)
 
 
-def head_forward(net, address, dist_name, h, prior, v):
+def head_forward(net, address, dist_name, h, prior, v, y=None):
     """`_layers_proposal[address].forward(h, variables)` + `.log_prob(values)` (inference_network_lstm.py:197-202).
-    Returns lp, caches for backward, proposal params."""
+    Returns lp, caches for backward, proposal params. (y: the layer's outputs when the caller already has them - rows that
+    share one hidden state.)"""
     Ws, bs = net.ff('_layers_proposal.%s._ff' % address)
-    y, acts = ff_forward(h, Ws, bs, False)
+    if y is None:
+        y, acts = ff_forward(h, Ws, bs, False)
+    else:
+        acts = None
     if dist_name == 'Normal':
         lp, dy, params = head_normal_mixture(y, prior, v, net.K)
     elif dist_name == 'Uniform':
@@ -717,6 +721,95 @@ def is_rescore(net, observe, trace_len, addr_idx, values, prior, addresses, dist
             prop_params.append(params)
             lw[b] += prior_lp[r] - prop_lp[r]
     return prior_lp, prop_lp, prop_params, lw
+
+
+def is_rescore_lockstep(net, observe, steps, n, chunk=16384, return_state=False):
+    """The same re-scoring as `is_rescore`, vectorised over PARTICLES: n traces advance statement by statement (the way the
+    lock-step executor runs them), `_infer_step` (inference_network_lstm.py:82-134) is evaluated for all particles of a
+    statement at once in `net.dtype`. One-layer LSTM. steps: list of dicts
+        address, dist_name   the statement's address / distribution name
+        values  [m]          the value of every particle that executes the statement
+        prior   [m, P] or [1, P]
+        rows    None (all n particles, m = n) or the m particle indices that execute it (a diverged control-flow path);
+                every particle's statements must appear in its program order.
+    Per particle: LSTM state reset at its first statement (prev_variable is None, :84-91), the previous statement's value /
+    address / distribution feed the sample, address and type embeddings (:106-121). Returns per-step (prior_lp, prop_lp) and
+    lw [n] = sum of fp32-rounded (log p - log q) per particle (state.py:211-217, trace.py:123-125) [, (h, c)]."""
+    dt = net.dtype
+    P = net.P
+    assert net.depth == 1
+    E, _ = embed_observe(net, np.asarray(observe, dt).reshape(1, -1))
+    W_ih, W_hh, b_ih, b_hh = net.lstm_layer(0)
+    H = W_hh.shape[1]
+    h = np.zeros((n, H), dt)
+    c = np.zeros((n, H), dt)
+    prev_step = np.full(n, -1, np.int64)          # index of the particle's previous statement
+    prev_val = np.zeros(n, dt)
+    lw = np.zeros(n)
+    out = []
+    col = E.shape[1]
+    for j, st in enumerate(steps):
+        a_cur, d_cur = st['address'], st['dist_name']
+        rows = np.arange(n) if st.get('rows') is None else np.asarray(st['rows'], np.int64)
+        m = len(rows)
+        values = np.asarray(st['values'], dt).reshape(-1)
+        prior = np.asarray(st['prior'], dt).reshape(-1, np.asarray(st['prior']).shape[-1])
+        if prior.shape[0] == 1:
+            prior = np.broadcast_to(prior, (m, prior.shape[1]))
+        assert values.shape[0] == m and prior.shape[0] == m
+        ps = prev_step[rows]
+        assert (ps == ps[0]).all(), 'the particles of a statement share their previous statement'
+        Ed = P['_layers_distribution_type_embedding.' + d_cur].shape[0]
+        Ea = P['_layers_address_embedding.' + a_cur].shape[0]
+        S_emb = net.ff('_layers_sample_embedding.' + a_cur)[0][0].shape[0]
+        x_shared = np.zeros(W_ih.shape[1], dt)
+        x_shared[:col] = E[0]
+        first = ps[0] < 0
+        if not first:
+            a_prev, d_prev = steps[ps[0]]['address'], steps[ps[0]]['dist_name']
+            x_shared[col + S_emb:col + S_emb + Ed] = P['_layers_distribution_type_embedding.' + d_prev]
+            x_shared[col + S_emb + Ed:col + S_emb + Ed + Ea] = P['_layers_address_embedding.' + a_prev]
+        c2 = col + S_emb + Ed + Ea
+        x_shared[c2:c2 + Ed] = P['_layers_distribution_type_embedding.' + d_cur]
+        x_shared[c2 + Ed:c2 + Ed + Ea] = P['_layers_address_embedding.' + a_cur]
+        p_lp_all, q_lp_all = np.zeros(m), np.zeros(m)
+        for lo in range(0, m, chunk):
+            r = rows[lo:lo + chunk]
+            x = np.broadcast_to(x_shared, (len(r), x_shared.shape[0])).copy()
+            if not first:
+                s_emb, _ = sample_embedding(net, a_prev, d_prev, prev_val[r])
+                x[:, col:col + S_emb] = s_emb
+            y_rows = None
+            if first:
+                # every particle has the same input row and a zero state (:84-91): one row through the LSTM and the head
+                _, _, (h1, c1) = lstm_forward(x[None, :1], W_ih, W_hh, b_ih, b_hh, np.zeros((1, H), dt), np.zeros((1, H), dt))
+                hn, cn = np.broadcast_to(h1, (len(r), H)), np.broadcast_to(c1, (len(r), H))
+                Wp, bp = net.ff('_layers_proposal.%s._ff' % a_cur)
+                y_rows = np.broadcast_to(ff_forward(h1, Wp, bp, False)[0], (len(r), bp[-1].shape[0])).copy()
+            else:
+                _, _, (hn, cn) = lstm_forward(x[None], W_ih, W_hh, b_ih, b_hh, h[r], c[r])
+            h[r], c[r] = hn, cn
+            v = values[lo:lo + chunk]
+            pr = prior[lo:lo + chunk]
+            if d_cur == 'Bernoulli':
+                # batch-1 semantics of `_infer_step`: particle i's value against ITS proposal - the diagonal of the [n, n]
+                # matrix the training-time restatement (head_bernoulli) builds for a sub-batch
+                q_lp = np.concatenate([np.diag(head_forward(net, a_cur, d_cur, hn[i:i + 256], pr[i:i + 256], v[i:i + 256])[2][1])
+                                       for i in range(0, len(r), 256)])
+            else:
+                q_lp, _, _ = head_forward(net, a_cur, d_cur, hn, pr, v, y=y_rows)
+            if d_cur == 'Categorical':
+                C = net.ff('_layers_proposal.%s._ff' % a_cur)[0][-1].shape[0]
+                p_lp = np.array([categorical_log_prob(v[i:i + 1], pr[i, :C])[0] for i in range(len(r))])
+            else:
+                p_lp = prior_log_prob(d_cur, pr, v)
+            p_lp_all[lo:lo + chunk] = np.asarray(p_lp, np.float32).astype(np.float64)
+            q_lp_all[lo:lo + chunk] = np.asarray(q_lp, np.float32).astype(np.float64)
+        lw[rows] += p_lp_all - q_lp_all
+        prev_step[rows] = j
+        prev_val[rows] = values
+        out.append((p_lp_all, q_lp_all))
+    return (out, lw, (h, c)) if return_state else (out, lw)
 
 
 def effective_sample_size(log_weights):

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpyprob_amd.so')
-SOURCES = ['gemm_f32.hip', 'kernels.hip', 'engine.hip', 'panel.hip', 'wgrad_t1.hip', 'is_kernels.hip', 'obs_embed.hip', 'pack.hip', 'train_loop.hip', 'lstm_tail.hip', 'dp.hip', 'optim.hip']
+SOURCES = ['gemm_f32.hip', 'kernels.hip', 'engine.hip', 'panel.hip', 'wgrad_t1.hip', 'is_kernels.hip', 'is_step_fused.hip', 'obs_embed.hip', 'pack.hip', 'train_loop.hip', 'lstm_tail.hip', 'dp.hip', 'optim.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-inline-asm']
 
 
@@ -49,8 +49,8 @@ def _check_registers(remarks):
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the C-ABI shared library. Returns the library path."""
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'gather.hpp'), os.path.join(CSRC, 'aux_jobs.hpp'), os.path.join(CSRC, 'panel.hpp'), os.path.join(CSRC, 'obs_embed.hpp'), os.path.join(CSRC, 'wgrad_t1.hpp'),
-               os.path.join(os.path.dirname(HERE), 'include', 'pyprob_amd.h')]
+    import glob
+    headers = sorted(glob.glob(os.path.join(CSRC, '*.hpp'))) + [os.path.join(os.path.dirname(HERE), 'include', 'pyprob_amd.h')]
     if not force and not _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + headers):
         return LIB      # the prebuilt in-tree library travels to the GPU box; nothing to do
     objdir = os.path.join(HERE, 'build')

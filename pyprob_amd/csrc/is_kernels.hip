@@ -4,6 +4,8 @@
 // wavefront-reduced importance statistics (ESS, weighted mean / variance).
 #include "common.hpp"
 #include "gather.hpp"
+#include "is_draw.hpp"
+#include "is_step_fused.hpp"
 
 #include <math.h>
 #include <string.h>
@@ -16,38 +18,6 @@ int lstm_cell_fwd(float* G, const float* c_prev, float* c, float* h, int n, int 
 bool obs_fused_supported(const pp_net* net);
 
 static inline int64_t round4(int64_t x) { return (x + 3) & ~int64_t(3); }
-
-constexpr int MAXK = 16;
-constexpr float kFp32Eps = 1.1920928955078125e-07f;
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;
-constexpr float kInvSqrt2 = 0.70710678118654752440f;
-constexpr float kSqrt2 = 1.41421356237309504880f;
-constexpr float kTwoPi = 6.28318530717958647692f;
-
-__device__ __forceinline__ float std_cdf(float x) { return 0.5f * (1.0f + erff(x * kInvSqrt2)); }
-
-// ---- Philox4x32-10 (Salmon et al. 2011), counter = particle index, key = seed ----------------------------
-struct Philox {
-    uint32_t c[4], k[2];
-    __device__ __forceinline__ Philox(uint64_t seed, uint64_t ctr, uint32_t stream) {
-        c[0] = (uint32_t)ctr; c[1] = (uint32_t)(ctr >> 32); c[2] = stream; c[3] = 0;
-        k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
-    }
-    __device__ __forceinline__ void next(uint32_t out[4]) {
-        uint32_t x0 = c[0], x1 = c[1], x2 = c[2], x3 = c[3], k0 = k[0], k1 = k[1];
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
-            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
-            const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
-            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-        out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
-        c[3]++;  // next block of four for this particle
-    }
-};
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // First statement of a lock-step run: every particle has the same LSTM state and prior, hence the SAME proposal.
 // The per-component quantities are computed once per workgroup into LDS (thread k owns component k); a particle then
@@ -159,100 +129,8 @@ __global__ __launch_bounds__(256) void is_mixture_kernel(const float* __restrict
     if (i >= n) return;
     const float* y = Y + (y_shared ? 0 : (int64_t)i * ldy);
     const float pa = prior[(int64_t)i * 2 * prior_stride], pb = prior[(int64_t)i * 2 * prior_stride + 1];
-    float mu[MAXK], sd[MAXK], p[MAXK];
-    float zmax = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-        if (k < K) zmax = fmaxf(zmax, y[2 * K + k]);
-    float zs = 0.0f;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-        if (k < K) {
-            p[k] = expf(y[2 * K + k] - zmax);
-            zs += p[k];
-        }
-    float ps = 0.0f;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-        if (k < K) {
-            p[k] = p[k] / zs;
-            ps += p[k];
-        }
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-        if (k < K) {
-            p[k] = p[k] / ps;
-            if (KIND == 0) {
-                mu[k] = pa + y[k] * pb;
-                sd[k] = expf(y[K + k]) * pb;
-            } else {
-                const float rng = pb - pa;
-                mu[k] = pa + sigmoidf_(y[k]) * rng;
-                sd[k] = KIND == 2 ? expf(y[K + k]) : rng / 1000.0f + sigmoidf_(y[K + k]) * rng * 10.0f;
-            }
-        }
-    float v;
-    if (value_in) {
-        v = value_in[i];
-    } else {
-        Philox rng(seed, offset + (uint64_t)i, 0x1C);
-        v = NAN;
-        for (int attempt = 0; attempt < 64; ++attempt) {
-            uint32_t r[4];
-            rng.next(r);
-            const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
-            // component index ~ Categorical(p)   (Mixture.sample, distributions/mixture.py:47-63)
-            float cum = 0.0f, mk = mu[0], sk = sd[0];
-            bool found = false;
-#pragma unroll
-            for (int k = 0; k < MAXK; ++k)
-                if (k < K) {
-                    cum += p[k];
-                    if (!found) {
-                        mk = mu[k];
-                        sk = sd[k];
-                        if (u0 < cum) found = true;
-                    }
-                }
-            if (KIND == 0) {
-                v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);   // Box-Muller
-                break;
-            } else {
-                // inverse-CDF draw inside [low, high) with rejection (distributions/truncated_normal.py:94-112)
-                const float ca = std_cdf((pa - mk) / sk), cb = std_cdf((pb - mk) / sk);
-                const float uu = ca + u1 * (cb - ca);
-                v = mk + sk * kSqrt2 * erfinvf(2.0f * uu - 1.0f);
-                if (isfinite(v) && v >= pa && v < pb) break;
-                v = NAN;
-            }
-        }
-    }
-    // log q(v)   (Mixture.log_prob, distributions/mixture.py:42-44)
-    float a[MAXK], amax = -INFINITY;
-    const bool inside = (KIND == 0) || (v >= pa && v <= pb);
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-        if (k < K) {
-            const float lpk = logf(fminf(fmaxf(p[k], kFp32Eps), 1.0f - kFp32Eps));
-            const float t = (v - mu[k]) / sd[k];
-            float comp;
-            if (KIND == 0) {
-                comp = -0.5f * t * t - logf(sd[k]) - kHalfLog2Pi;
-            } else {
-                const float Z = std_cdf((pb - mu[k]) / sd[k]) - std_cdf((pa - mu[k]) / sd[k]);
-                comp = (inside ? 0.0f : -INFINITY) + (-0.5f * t * t - kHalfLog2Pi) - logf(sd[k] * Z);
-            }
-            a[k] = lpk + comp;
-            amax = fmaxf(amax, a[k]);
-        }
-    float lp = amax;
-    if (amax > -INFINITY) {
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k)
-            if (k < K) s += expf(a[k] - amax);
-        lp = amax + logf(s);
-    }
+    float v, lp;
+    mixture_particle<KIND>(y, pa, pb, K, value_in != nullptr, value_in ? value_in[i] : 0.0f, seed, offset + (uint64_t)i, v, lp);
     value_out[i] = v;
     logq_out[i] = lp;
 }
@@ -323,6 +201,7 @@ struct IsWorkspace {
     float *X, *G, *A1, *Y, *rec, *c0;
     float *obs_h, *cat, *f1;
     int64_t i4, hid4, out4, e4, maxohid4;
+    IsFusedBuffers fz;   // operand images of the fused statement kernel (is_step_fused.hip)
     size_t bytes;
 };
 
@@ -356,6 +235,11 @@ static void is_carve(const pp_net* net, int n, void* p, IsWorkspace& w) {
     w.obs_h = take(PP_MAX_OBS * w.maxohid4);
     w.cat = take(w.e4);
     w.f1 = take(w.e4);
+    is_fused_carve_sizes(net, w.fz);
+    w.fz.whh = take(w.fz.n_whh);
+    w.fz.w1 = take(w.fz.n_w1);
+    w.fz.w2 = take(w.fz.n_w2);
+    w.fz.bias = take(w.fz.n_bias);
     w.bytes = off + 256;
 }
 
@@ -413,7 +297,7 @@ int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, v
 int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
             const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
             const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset, void* ws,
-            size_t ws_bytes, hipStream_t st, bool net_only = false) {
+            size_t ws_bytes, hipStream_t st, bool net_only = false, const int64_t* rows = nullptr) {
     const bool ff = net && net->lstm_dim == 0;   // FeedForward network: the proposal layer reads the observe embedding
     PP_CHECK_ARG(net && P && e_obs_vec && (ff || (h && c)) && (net_only || (value_out && logq_out)) && ws, "pp_is_step: null pointer");
     PP_CHECK_ARG(addr_id >= 0 && addr_id < net->n_addr && prev_addr_id < net->n_addr, "pp_is_step: address id out of range");
@@ -437,6 +321,23 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
         set_error("pp_is_step: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
         return PP_ENOSPACE;
     }
+    // A statement after the first one on a one-layer LSTM of a supported width: ONE kernel (is_step_fused.hip) - gates,
+    // cell, both head layers and the draw; (h, c) are read and written once, in place, optionally through a row index list.
+    // (PP_IS_STEP_FUSED=0, read per call: the unfused chain below, the A/B of tests/test_gpu_is_step_fused.py)
+    const bool fused_on = !(getenv("PP_IS_STEP_FUSED") && atoi(getenv("PP_IS_STEP_FUSED")) == 0);
+    bool head_done = false;
+    if (!shared && fused_on && is_step_fused_supported(net, addr_id)) {
+        bool sampled = false;
+        PP_TRY(is_step_fused(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows, rows,
+                             value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st));
+        if (sampled) return 0;
+        head_done = true;     // the head outputs are in w.Y: the sampling kernels below (or pp_is_fused) take over
+    } else {
+        PP_CHECK_ARG(!rows, "pp_is_step_rows: a row index list needs the fused statement kernel (pp_is_step_fused_supported)");
+    }
+    if (head_done) {
+        if (net_only) return 0;
+    } else {
     if (!ff)
         PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
                                  w.i4, st));
@@ -475,6 +376,7 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     PP_TRY(lin(top, H, P + ad.w1, P + ad.b1, nullptr, w.A1, w.hid4, m, H, ad.hid, true, false, st));
     PP_TRY(lin(w.A1, w.hid4, P + ad.w2, P + ad.b2, nullptr, w.Y, w.out4, m, ad.hid, ad.n_out, false, false, st));
     if (net_only) return 0;      // the head outputs stay in w.Y for pp_is_fused
+    }
     dim3 grid(cdiv(n, 256)), block(256);
     // kernel class 4 of the in-stream timing: draw + log q per particle (writes value and log q: 8 algorithmic bytes each)
     prof_begin(4, st);
@@ -923,6 +825,24 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
     return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows,
                        value_in,
                        value_out, logq_out, seed, offset, workspace, workspace_bytes, pp::as_stream(stream));
+}
+
+int pp_is_step_rows(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+                    const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride, float* h,
+                    float* c, int32_t state_rows, const int64_t* rows, const float* value_in, float* value_out,
+                    float* logq_out, uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream) {
+    if (prev_addr_id < 0 && rows) {
+        pp::set_error("pp_is_step_rows: the first statement of a trace has one shared state row (no index list)");
+        return PP_EINVAL;
+    }
+    return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows,
+                       value_in, value_out, logq_out, seed, offset, workspace, workspace_bytes, pp::as_stream(stream), false,
+                       rows);
+}
+
+int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id) {
+    const bool on = !(getenv("PP_IS_STEP_FUSED") && atoi(getenv("PP_IS_STEP_FUSED")) == 0);
+    return (on && pp::is_step_fused_supported(net, addr_id)) ? 1 : 0;
 }
 
 int pp_prior_draw(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride, int32_t n, uint64_t seed,

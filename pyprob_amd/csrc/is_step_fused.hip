@@ -1,0 +1,477 @@
+// One importance-sampling statement of N particles with per-particle LSTM state as ONE kernel
+// (InferenceNetworkLSTM._infer_step pyprob/nn/inference_network_lstm.py:82-134 + state.sample's IC branch
+// pyprob/state.py:203-219 + Mixture.sample / Mixture.log_prob pyprob/distributions/mixture.py:38-63):
+//
+//     gates = [s_prev | h] [W_s | W_hh]^T + bias        bias = b_ih + b_hh + W_ih[:, shared columns] x_shared
+//     (c, h) <- LSTM cell                                in registers: the gate matrix never exists in memory
+//     a1 = relu(h W1^T + b1),  y = a1 W2^T + b2          from the workgroup's own fresh h tile (LDS)
+//     v ~ mixture(y, prior),  log q(v)                   Philox draw in the tail
+//
+// Every particle of a statement has the same observe embedding and the same (previous, current) address, so of the
+// LSTM input row [E | s_prev | d_prev | a_prev | d_cur | a_cur] (inference_network_lstm.py:116-121) only the sample
+// embedding s_prev (smp_dim = 4 columns) differs between particles: the other 208 columns are ONE row times W_ih, a
+// bias vector computed once per call (is_prep_kernel). K of the per-particle product is H + smp_dim instead of H + 212.
+//
+// Geometry: a workgroup of eight waves owns 32 particles and ALL 4H gate columns; wave w owns the four gates of the
+// hidden units [w H/8, (w+1) H/8): 4 UB blocks of v_mfma_f32_32x32x2_f32 accumulators (UB = H / 256; 128 registers at
+// H = 512), so the cell runs on the accumulators without any exchange. 32 x 4H fp32 accumulators are half of a CU's
+// register file: 32 rows is the largest panel that keeps the whole gate row on chip.
+// Operands: the weights are re-tiled ONCE per call (is_prep_kernel) into "fragment images": for k-slab s (8 k), wave w,
+// block b one contiguous KB holding, for lane l = (column c = l & 31, half hh = l >> 5), the four k values 8 s + 4 hh + j of
+// its column - exactly the B operand of four consecutive MFMAs. A wave streams ITS blocks with one coalesced 16-byte load
+// per lane and block straight into VGPRs (no LDS, no barrier in the K loop, a two-slab register ring); the A fragment
+// (four k of the lane's particle row) is one 16-byte load per slab from the particle's h row (an optional row index list
+// gathers the rows of a diverged control-flow path in place). h and c are updated in place: a barrier separates the last
+// read of the old h rows from the first store.
+#include "is_step_fused.hpp"
+
+#include "gather.hpp"
+#include "is_draw.hpp"
+
+#include <algorithm>
+
+namespace pp {
+
+namespace {
+
+constexpr int FR = 32;   // particles per workgroup
+constexpr int FW = 8;    // waves per workgroup
+
+// sigmoid / tanh on v_exp_f32 / v_rcp_f32 (~1 ulp each; absolute error of the results ~1e-7, asserted by
+// tests/test_gpu_is_step_fused.py against the float64 oracle)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+struct PrepArgs {
+    const float* P;
+    const int64_t* at;
+    int64_t w_ih, w_hh, b_ih, b_hh, w1, w2;
+    int H, I, ub, nsh;              // nsh = H / 8 slabs of W_hh (slab nsh = the sample-embedding columns of W_ih)
+    GatherDims d;
+    int addr_id, prev_addr;
+    const float* e_obs_vec;
+    const float* h0;                // shared state row (its recurrent product joins the bias) or nullptr
+    const float* c0;
+    int hid, n_out, nb1, ns2;
+    float* whh_img; float* w1_img; float* w2_img; float* bias; float* c0_copy;
+    int64_t q_whh, q_w1, q_w2;      // 16-byte pieces of the three images
+    int img_blocks;
+};
+
+// blocks [0, img_blocks): the fragment images (one 16-byte piece = four k of one column per thread);
+// blocks [img_blocks, ...): the bias row, one wave per gate column.
+__global__ __launch_bounds__(256) void is_prep_kernel(const PrepArgs a) {
+    __shared__ float sx[1024 + 512];
+    const int tid = threadIdx.x;
+    const int H = a.H;
+    if ((int)blockIdx.x < a.img_blocks) {
+        const int64_t total = a.q_whh + a.q_w1 + a.q_w2;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + tid; q < total; q += (int64_t)a.img_blocks * 256) {
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            float* dst;
+            if (q < a.q_whh) {
+                const int lane = (int)(q & 63);
+                const int64_t t = q >> 6;
+                const int nb = 4 * a.ub;
+                const int blk = (int)(t % nb), w = (int)((t / nb) % FW), s = (int)(t / (nb * FW));
+                const int g = blk / a.ub, ub = blk - g * a.ub;
+                const int col = g * H + (w * a.ub + ub) * 32 + (lane & 31);
+                const int k0 = 4 * (lane >> 5);
+                if (s < a.nsh) {
+                    v = *reinterpret_cast<const f32x4*>(a.P + a.w_hh + (int64_t)col * H + 8 * s + k0);
+                } else {
+                    const float* wi = a.P + a.w_ih + (int64_t)col * a.I + a.d.e_obs;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (k0 + j < a.d.smp) ? wi[k0 + j] : 0.0f;
+                }
+                dst = a.whh_img + q * 4;
+            } else if (q < a.q_whh + a.q_w1) {
+                const int64_t r = q - a.q_whh;
+                const int lane = (int)(r & 63);
+                const int64_t t = r >> 6;
+                const int cb = (int)(t % a.nb1), s = (int)(t / a.nb1);
+                const int col = cb * 32 + (lane & 31);
+                if (col < a.hid) v = *reinterpret_cast<const f32x4*>(a.P + a.w1 + (int64_t)col * H + 8 * s + 4 * (lane >> 5));
+                dst = a.w1_img + r * 4;
+            } else {
+                const int64_t r = q - a.q_whh - a.q_w1;
+                const int lane = (int)(r & 63);
+                const int s = (int)(r >> 6);
+                const int col = lane & 31, k0 = 8 * s + 4 * (lane >> 5);
+                if (col < a.n_out) {
+                    const float* wr = a.P + a.w2 + (int64_t)col * a.hid;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (k0 + j < a.hid) ? wr[k0 + j] : 0.0f;
+                }
+                dst = a.w2_img + r * 4;
+            }
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+        return;
+    }
+    // ---- bias row: b_ih + b_hh + W_ih x_shared (sample-embedding columns left out) [+ W_hh h0] ----
+    const int bb = blockIdx.x - a.img_blocks;
+    const int c1 = a.d.e_obs, c2 = c1 + a.d.smp;
+    for (int k = tid; k < a.I; k += 256) {
+        float x;
+        if (k < c1) x = a.e_obs_vec[k];
+        else if (k < c2) x = 0.0f;
+        else x = gather_embedding_elem(a.d, a.P, a.at, k, a.prev_addr, 0.0f, a.addr_id);
+        sx[k] = x;
+    }
+    if (a.h0)
+        for (int k = tid; k < H; k += 256) sx[1024 + k] = a.h0[k];
+    if (bb == 0 && a.c0)
+        for (int k = tid; k < H; k += 256) a.c0_copy[k] = a.c0[k];
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int n = bb * 4 + wave;
+    if (n >= 4 * H) return;
+    const float* wi = a.P + a.w_ih + (int64_t)n * a.I;
+    float acc = 0.0f;
+    for (int k = lane; k < a.I; k += 64) acc += wi[k] * sx[k];
+    if (a.h0) {
+        const float* wh = a.P + a.w_hh + (int64_t)n * H;
+        for (int k = lane; k < H; k += 64) acc += wh[k] * sx[1024 + k];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.bias[n] = acc + (a.P[a.b_ih + n] + a.P[a.b_hh + n]);
+}
+
+struct FusedArgs {
+    const float* whh_img;
+    const float* bias;
+    float* h;
+    float* c;
+    const float* c0;            // state_shared: the shared previous cell state row (a copy: row 0 of c is rewritten)
+    const int64_t* rows;        // particle -> state row, or nullptr (identity)
+    int state_shared;
+    const float* prev_value;    // [n]
+    const float* smp_w;         // sample embedding of the previous address: [smp_dim, smp_in], [smp_dim]
+    const float* smp_b;
+    int smp_in, smp;
+    const float* w1_img; const float* b1; int hid, nb1;
+    const float* w2_img; const float* b2; int n_out, ns2;
+    float* y_out; int64_t ldy;  // optional copy of the head outputs (heads that are sampled by their own kernel)
+    const float* prior; int prior_stride;
+    const float* value_in; float* value_out; float* logq_out;
+    uint64_t seed, offset;
+    int K, n;
+};
+
+extern __shared__ __attribute__((aligned(1024))) float fused_lds[];
+
+// KIND 0 / 1 / 2: mixture heads (is_draw.hpp), drawn in the tail; 3: head outputs only
+template <int UB, int KIND>
+__global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
+    constexpr int H = 256 * UB;
+    constexpr int NSH = H / 8;
+    constexpr int NB = 4 * UB;
+    constexpr int SLAB = FW * NB * 256;            // floats of one k-slab of the gate image
+    float* sH = fused_lds;                         // [NSH][64][4]: the fresh hidden tile as A fragments
+    float* sA1 = sH + NSH * 256;                   // [ns2][64][4]: head layer 1 activations as A fragments
+    float* sY = sA1 + a.ns2 * 256;                 // [32][33] head outputs
+    int* sRow = reinterpret_cast<int*>(sY + FR * 33);   // [32] state row of every particle of the panel
+    float* sPart = sH;                             // [8][32][32] K-split partials of head layer 2 (the tile is dead by then)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c31 = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * FR;
+    if (tid < FR) {
+        const int gr = min(m0 + tid, a.n - 1);
+        sRow[tid] = a.rows ? (int)a.rows[gr] : gr;
+    }
+    const int gr = min(m0 + c31, a.n - 1);              // this lane's particle (A operand row)
+    const int64_t ridx = a.rows ? a.rows[gr] : (int64_t)gr;
+    const float* arow = a.h + ridx * H + 4 * hh;
+    const float* bimg = a.whh_img + (size_t)wave * (NB * 256) + lane * 4;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const int g = blk / UB, ub = blk % UB;
+        const float b = a.bias[g * H + (wave * UB + ub) * 32 + c31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[blk][r] = b;
+    }
+    auto load_b = [&](int s, f32x4 (&b)[NB]) {
+        const float* p = bimg + (size_t)s * SLAB;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) b[blk] = *reinterpret_cast<const f32x4*>(p + blk * 256);
+    };
+    auto load_a = [&](int s) { return *reinterpret_cast<const f32x4*>(arow + 8 * s); };
+    auto mma = [&](const f32x4& av, const f32x4 (&b)[NB]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[blk][j], acc[blk], 0, 0, 0);
+    };
+    const int NS = a.state_shared ? 0 : NSH;   // shared state: h W_hh^T is one row for everybody, part of the bias
+    f32x4 b0[NB], b1[NB], a0, a1;
+    // the sample embedding of the previous value first: k = 4 hh + j < smp_dim (embedding_feedforward.py: one Linear + ReLU);
+    // its weights are slab NSH of the image
+    load_b(NSH, b1);
+    {
+        // (gather.hpp sample_embed_elem: a Linear(1, smp_dim) of the value, or a row of the one-hot Linear(C, smp_dim))
+        const float pv = a.prev_value[gr];
+        int cat = (int)pv;
+        cat = cat < 0 ? 0 : (cat >= a.smp_in ? a.smp_in - 1 : cat);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(4 * hh + j, a.smp - 1);
+            const float e = a.smp_in == 1 ? a.smp_w[k] * pv + a.smp_b[k] : a.smp_w[k * a.smp_in + cat] + a.smp_b[k];
+            a1[j] = (4 * hh + j < a.smp) ? relu_keep_nan(e) : 0.0f;
+        }
+    }
+    if (NS) {
+        load_b(0, b0);
+        a0 = load_a(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NS) {
+        // two-slab register ring: the loads of slab s + 1 are issued BEFORE the MFMAs of slab s (the scheduling barriers keep
+        // the compiler from sinking them behind the MFMAs to save registers, which would expose a full L2 round trip per slab)
+        for (int s = 0; s + 2 < NS; s += 2) {
+            load_b(s + 1, b1);
+            a1 = load_a(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s + 2, b0);
+            a0 = load_a(s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_b(NS - 1, b1);
+        a1 = load_a(NS - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // every wave has read the old h rows of the panel (and sRow is visible)
+
+    // ---- LSTM cell on the accumulators (torch.nn.LSTM gate order i, f, g, o) ----
+    // (all loads of the old cell state first: the stores below go through the same pointer and would pin every load behind
+    // the previous store)
+    const float* cprev = a.state_shared ? a.c0 : a.c;
+    float cp[UB][16];
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+        const int u = (wave * UB + ub) * 32 + c31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            cp[ub][r] = cprev[a.state_shared ? (int64_t)u : (int64_t)sRow[row] * H + u];
+        }
+    }
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+        const int u = (wave * UB + ub) * 32 + c31;
+        const int hslot = ((u >> 3) * 64 + ((u >> 2) & 1) * 32) * 4 + (u & 3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float gi = fast_sigmoid(acc[0 * UB + ub][r]);
+            const float gf = fast_sigmoid(acc[1 * UB + ub][r]);
+            const float gg = fast_tanh(acc[2 * UB + ub][r]);
+            const float go = fast_sigmoid(acc[3 * UB + ub][r]);
+            const float cn = gf * cp[ub][r] + gi * gg;
+            const float hn = go * fast_tanh(cn);
+            if (m0 + row < a.n) {
+                const int64_t ro = (int64_t)sRow[row] * H + u;
+                a.c[ro] = cn;
+                a.h[ro] = hn;
+            }
+            sH[hslot + row * 4] = hn;
+        }
+    }
+    __syncthreads();
+
+    // ---- head layer 1: a1 = relu(h W1^T + b1); wave w takes the 32-column blocks w, w + 8, ... ----
+    for (int cb = wave; cb < a.nb1; cb += FW) {
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+        const float* wimg = a.w1_img + (size_t)cb * 256 + lane * 4;
+        const size_t sstride = (size_t)a.nb1 * 256;
+        f32x4 bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bq[u] = *reinterpret_cast<const f32x4*>(wimg + u * sstride);
+        for (int s = 0; s < NSH; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(sH + (s + u) * 256 + lane * 4);
+                const f32x4 bv = bq[u];
+                if (s + u + 4 < NSH) bq[u] = *reinterpret_cast<const f32x4*>(wimg + (size_t)(s + u + 4) * sstride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc1, 0, 0, 0);
+            }
+        }
+        const int col = cb * 32 + c31;
+        const float bias1 = col < a.hid ? a.b1[col] : 0.0f;
+        if ((col >> 3) < a.ns2) {
+            const int slot = ((col >> 3) * 64 + ((col >> 2) & 1) * 32) * 4 + (col & 3);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                sA1[slot + row * 4] = col < a.hid ? relu_keep_nan(acc1[r] + bias1) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- head layer 2: y = a1 W2^T + b2, K split over the waves, partials summed in a fixed order ----
+    {
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+        for (int s = wave; s < a.ns2; s += FW) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(sA1 + s * 256 + lane * 4);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.w2_img + (size_t)s * 256 + lane * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            sPart[(wave * 32 + row) * 32 + c31] = acc2[r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < FR * 32; e += 512) {
+        const int row = e >> 5, col = e & 31;
+        float y = col < a.n_out ? a.b2[col] : 0.0f;
+#pragma unroll
+        for (int w = 0; w < FW; ++w) y += sPart[(w * 32 + row) * 32 + col];
+        sY[row * 33 + col] = y;
+        if (a.y_out && m0 + row < a.n && col < a.n_out) a.y_out[(int64_t)(m0 + row) * a.ldy + col] = y;
+    }
+    if (KIND == 3) return;
+    __syncthreads();
+
+    // ---- draw + log q (Mixture.sample / log_prob), one lane per particle ----
+    if (tid < FR && m0 + tid < a.n) {
+        const int64_t i = m0 + tid;
+        const float pa = a.prior[i * 2 * a.prior_stride], pb = a.prior[i * 2 * a.prior_stride + 1];
+        float v, lp;
+        mixture_particle<(KIND == 3 ? 0 : KIND)>(sY + tid * 33, pa, pb, a.K, a.value_in != nullptr,
+                                                 a.value_in ? a.value_in[i] : 0.0f, a.seed, a.offset + (uint64_t)i, v, lp);
+        a.value_out[i] = v;
+        a.logq_out[i] = lp;
+    }
+}
+
+template <int UB, int KIND>
+int launch_fused(const FusedArgs& a, size_t lds, hipStream_t st) {
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&is_step_fused_kernel<UB, KIND>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("pp_is_step: cannot raise the LDS limit of the fused statement kernel: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        raised = true;
+    }
+    hipLaunchKernelGGL((is_step_fused_kernel<UB, KIND>), dim3(cdiv(a.n, FR)), dim3(512), lds, st, a);
+    return 0;
+}
+
+static inline int64_t round256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+}  // namespace
+
+bool is_step_fused_supported(const pp_net* net, int addr_id) {
+    if (!net || net->lstm_dim == 0 || std::max(1, (int)net->lstm_depth) != 1) return false;
+    if (net->lstm_dim != 256 && net->lstm_dim != 512) return false;
+    if (net->smp_dim < 1 || net->smp_dim > 8 || net->lstm_in > 1024 || !net->addr_table) return false;
+    if (addr_id < 0 || addr_id >= net->n_addr) return false;
+    const pp_addr& ad = net->addrs[addr_id];
+    if (ad.n_out < 1 || ad.n_out > 32 || ad.hid < 1) return false;
+    const int ns2 = (ad.hid + 7) / 8;
+    const size_t lds = ((size_t)(net->lstm_dim / 8) * 256 + (size_t)ns2 * 256 + FR * 33 + FR) * sizeof(float);
+    return lds <= 150 * 1024;
+}
+
+void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {
+    f = IsFusedBuffers{};
+    if (!net || (net->lstm_dim != 256 && net->lstm_dim != 512)) return;
+    const int H = net->lstm_dim, ub = H / 256, nsh = H / 8;
+    int64_t hid = 1;
+    for (int a = 0; a < net->n_addr; ++a) hid = std::max<int64_t>(hid, net->addrs[a].hid);
+    f.n_whh = (int64_t)(nsh + 1) * FW * 4 * ub * 256;
+    f.n_w1 = (int64_t)nsh * ((hid + 31) / 32) * 256;
+    f.n_w2 = (int64_t)((hid + 7) / 8) * 256;
+    f.n_bias = 4 * H;
+}
+
+int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
+                  const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
+                  const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
+                  const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st) {
+    const pp_addr& ad = net->addrs[addr_id];
+    const int H = net->lstm_dim, ub = H / 256, nsh = H / 8;
+    const bool shared = state_rows == 1;
+    PrepArgs p{};
+    p.P = P; p.at = net->addr_table;
+    p.w_ih = net->w_ih; p.w_hh = net->w_hh; p.b_ih = net->b_ih; p.b_hh = net->b_hh; p.w1 = ad.w1; p.w2 = ad.w2;
+    p.H = H; p.I = net->lstm_in; p.ub = ub; p.nsh = nsh;
+    p.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+    p.addr_id = addr_id; p.prev_addr = prev_addr_id;
+    p.e_obs_vec = e_obs_vec;
+    p.h0 = shared ? h : nullptr;
+    p.c0 = shared ? c : nullptr;
+    p.hid = ad.hid; p.n_out = ad.n_out; p.nb1 = (ad.hid + 31) / 32; p.ns2 = (ad.hid + 7) / 8;
+    p.whh_img = f.whh; p.w1_img = f.w1; p.w2_img = f.w2; p.bias = f.bias; p.c0_copy = c0_copy;
+    p.q_whh = (int64_t)(nsh + 1) * FW * 4 * ub * 64;
+    p.q_w1 = (int64_t)nsh * p.nb1 * 64;
+    p.q_w2 = (int64_t)p.ns2 * 64;
+    p.img_blocks = (int)std::min<int64_t>(1024, (p.q_whh + p.q_w1 + p.q_w2 + 255) / 256);
+    hipLaunchKernelGGL(is_prep_kernel, dim3(p.img_blocks + H), dim3(256), 0, st, p);
+    PP_LAUNCH_CHECK("pp_is_step(prepare)");
+
+    FusedArgs a{};
+    a.whh_img = f.whh; a.bias = f.bias;
+    a.h = h; a.c = c; a.c0 = c0_copy; a.rows = rows; a.state_shared = shared ? 1 : 0;
+    const pp_addr& pad = net->addrs[prev_addr_id];
+    a.prev_value = prev_value; a.smp_w = P + pad.smp_w; a.smp_b = P + pad.smp_b; a.smp_in = pad.smp_in; a.smp = net->smp_dim;
+    a.w1_img = f.w1; a.b1 = P + ad.b1; a.hid = ad.hid; a.nb1 = p.nb1;
+    a.w2_img = f.w2; a.b2 = P + ad.b2; a.n_out = ad.n_out; a.ns2 = p.ns2;
+    a.prior = prior; a.prior_stride = prior_stride;
+    a.value_in = value_in; a.value_out = value_out; a.logq_out = logq_out;
+    a.seed = seed; a.offset = offset; a.K = ad.n_out / 3; a.n = n;
+    int kind = 3;
+    if (!net_only && ad.n_out % 3 == 0 && ad.n_out / 3 <= MAXK) {
+        if (ad.kind == PP_HEAD_NORMAL_MIXTURE) kind = 0;
+        else if (ad.kind == PP_HEAD_TRUNCNORMAL_MIXTURE) kind = 1;
+        else if (ad.kind == PP_HEAD_POISSON_TN_MIXTURE) kind = 2;
+    }
+    if (kind == 3) { a.y_out = y_out; a.ldy = ldy; }
+    const size_t lds = ((size_t)nsh * 256 + (size_t)p.ns2 * 256 + FR * 33 + FR) * sizeof(float);
+    // kernel class 5 of the in-stream timing: the fused statement (work = FLOPs of the reference's algorithm, SURVEY.md 8d:
+    // input + recurrent product, both head layers)
+    const double flops = (double)n * (2.0 * (net->lstm_in + (shared ? 0 : H)) * 4.0 * H + 2.0 * ((double)H * ad.hid + (double)ad.hid * ad.n_out));
+    prof_begin(5, st);
+    int rc = 0;
+#define PP_FUSED_CASE(U, KD) rc = launch_fused<U, KD>(a, lds, st)
+    if (ub == 1) {
+        if (kind == 0) PP_FUSED_CASE(1, 0); else if (kind == 1) PP_FUSED_CASE(1, 1); else if (kind == 2) PP_FUSED_CASE(1, 2); else PP_FUSED_CASE(1, 3);
+    } else {
+        if (kind == 0) PP_FUSED_CASE(2, 0); else if (kind == 1) PP_FUSED_CASE(2, 1); else if (kind == 2) PP_FUSED_CASE(2, 2); else PP_FUSED_CASE(2, 3);
+    }
+#undef PP_FUSED_CASE
+    prof_end(5, flops, st);
+    if (rc) return rc;
+    PP_LAUNCH_CHECK("pp_is_step(fused statement)");
+    *sampled = kind != 3;   // false: the head outputs are in y_out, the caller's sampling kernel follows
+    return 0;
+}
+
+}  // namespace pp

@@ -1,0 +1,26 @@
+// The fused importance-sampling statement (is_step_fused.hip): interface towards is_kernels.hip.
+#pragma once
+#include "common.hpp"
+
+namespace pp {
+
+// per-call operand images in the pp_is_step workspace (sizes in floats; 0 when the network's shape has no fused kernel)
+struct IsFusedBuffers {
+    float *whh = nullptr, *w1 = nullptr, *w2 = nullptr, *bias = nullptr;
+    int64_t n_whh = 0, n_w1 = 0, n_w2 = 0, n_bias = 0;
+};
+
+// one-layer LSTM with H in {256, 512}, head of `addr_id` at most 32 outputs wide
+bool is_step_fused_supported(const pp_net* net, int addr_id);
+void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f);
+
+// A statement AFTER the first one of a trace (prev_addr_id >= 0) for n particles. state_rows == 1: row 0 of (h, c) is
+// everybody's previous state. rows (or nullptr): state row of particle i (h, c are read and written at rows[i]; all other
+// per-particle arrays are compact). *sampled: values and log q are written; false when only the head outputs were produced
+// (y_out [n, ldy]: categorical / Bernoulli heads and net_only calls - the caller samples).
+int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
+                  const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
+                  const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
+                  const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st);
+
+}  // namespace pp

@@ -106,6 +106,19 @@ class ISRunner:
         previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor; prior:
         [1, 2], or one row per particle ([n, 2]; prior_compact: one row per entry of `rows`)."""
         m = int(rows.numel())
+        if (prev_addr_id is not None and self.dev.type == 'cuda' and self.eng.spec.lstm_depth == 1 and
+                self.lib.pp_is_step_fused_supported(C.byref(self.eng.net), int(addr_id))):
+            # the fused statement kernel reads and writes the rows' state in place through the index list
+            if self.state_rows == 1 and self.n > 1:
+                self.h[:, 1:] = self.h[:, :1]
+                self.c[:, 1:] = self.c[:, :1]
+                self.state_rows = self.n
+            prev = self.prev_value.index_select(0, rows)
+            if prior is not None and prior.shape[0] != 1 and not prior_compact:
+                prior = prior.index_select(0, rows).contiguous()
+            self._ensure_ws(m)
+            return ops.is_step_rows(self.eng.params, self.ws, self.eng.net_handle, int(addr_id), int(prev_addr_id), m, self.e_obs,
+                                    prev, prior, self.h, self.c, m, rows, None, int(seed), self.offset)
         if self.state_rows == 1 and self.n > 1 and prev_addr_id is not None:
             self.h[:, 1:] = self.h[:, :1]      # the shared first-statement state (row 0) becomes per-particle
             self.c[:, 1:] = self.c[:, :1]

@@ -13,6 +13,7 @@ kernels for these operators from tests/, to execute the host logic above them wi
     larc_scale   the LARC wrapper's gradient rescaling               pyprob/nn/optimizer_larc.py:72-107
     is_init      InferenceNetwork._infer_init                        pyprob/nn/inference_network.py:141-148
     is_step      _infer_step + proposal.sample() + log_prob          pyprob/nn/inference_network_lstm.py:82-134,
+    is_step_rows   (the same for the rows of a diverged path, state in place)
                                                                      pyprob/state.py:207-212
     log_prob     prior / likelihood log_prob terms of the log-weight pyprob/state.py:211, 147-149
 
@@ -43,6 +44,9 @@ _lib.define('larc_scale(Tensor params, Tensor(a!) grads, Tensor chunk_tensor, Te
 _lib.define('is_init(Tensor params, Tensor(a!) workspace, int net, Tensor obs) -> Tensor')
 _lib.define('is_step(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
             'Tensor? prev_value, Tensor? prior, Tensor(b!) h, Tensor(c!) c, int state_rows, Tensor? value_in, int seed, '
+            'int offset) -> (Tensor, Tensor)')
+_lib.define('is_step_rows(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
+            'Tensor prev_value, Tensor? prior, Tensor(b!) h, Tensor(c!) c, int state_rows, Tensor rows, Tensor? value_in, int seed, '
             'int offset) -> (Tensor, Tensor)')
 _lib.define('is_step_net(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
             'Tensor? prev_value, Tensor(b!) h, Tensor(c!) c, int state_rows) -> ()')
@@ -240,7 +244,7 @@ def _is_init_hip(params, workspace, net, obs):
 
 
 def _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, prior, h, c, state_rows, value_in, seed,
-                 offset):
+                 offset, rows=None):
     lib = L.load()
     netc = net_struct(net)
     _same_device(params, workspace, e_obs, prev_value, prior, h, c, value_in)
@@ -249,7 +253,12 @@ def _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_v
         raise RuntimeError('pyprob_hip::is_step: address id out of range')
     H = netc.lstm_dim
     depth = max(1, int(netc.lstm_depth))
-    if H > 0 and (h.numel() < depth * n * H or c.numel() < depth * n * H):
+    if rows is not None:
+        if rows.dtype != torch.int64 or not rows.is_contiguous() or rows.numel() < n or rows.device != params.device:
+            raise RuntimeError('pyprob_hip::is_step_rows: rows must be a contiguous int64 device tensor with n entries')
+        if not lib.pp_is_step_fused_supported(C.byref(netc), int(addr_id)) or prev_addr_id < 0:
+            raise RuntimeError('pyprob_hip::is_step_rows: no fused statement kernel for this network / statement')
+    elif H > 0 and (h.numel() < depth * n * H or c.numel() < depth * n * H):
         raise RuntimeError('pyprob_hip::is_step: LSTM state smaller than [depth, n, H]')
     stride = 0
     if prior is not None:
@@ -263,12 +272,24 @@ def _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_v
     value = torch.empty(n, dtype=torch.float32, device=params.device)
     logq = torch.empty(n, dtype=torch.float32, device=params.device)
     with torch.cuda.device(params.device):
-        rc = lib.pp_is_step(C.byref(netc), params.data_ptr(), int(addr_id), int(prev_addr_id), int(n), e_obs.data_ptr(),
-                            L.ptr(prev_value), L.ptr(prior), stride, L.ptr(h), L.ptr(c), int(state_rows), L.ptr(value_in),
-                            value.data_ptr(), logq.data_ptr(), int(seed), int(offset), workspace.data_ptr(), ws_bytes,
-                            _stream(params))
+        if rows is None:
+            rc = lib.pp_is_step(C.byref(netc), params.data_ptr(), int(addr_id), int(prev_addr_id), int(n), e_obs.data_ptr(),
+                                L.ptr(prev_value), L.ptr(prior), stride, L.ptr(h), L.ptr(c), int(state_rows), L.ptr(value_in),
+                                value.data_ptr(), logq.data_ptr(), int(seed), int(offset), workspace.data_ptr(), ws_bytes,
+                                _stream(params))
+        else:
+            rc = lib.pp_is_step_rows(C.byref(netc), params.data_ptr(), int(addr_id), int(prev_addr_id), int(n), e_obs.data_ptr(),
+                                     L.ptr(prev_value), L.ptr(prior), stride, L.ptr(h), L.ptr(c), int(state_rows),
+                                     rows.data_ptr(), L.ptr(value_in), value.data_ptr(), logq.data_ptr(), int(seed), int(offset),
+                                     workspace.data_ptr(), ws_bytes, _stream(params))
     L.check(rc, 'pp_is_step')
     return value, logq
+
+
+def _is_step_rows_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, prior, h, c, state_rows, rows, value_in,
+                      seed, offset):
+    return _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, prior, h, c, state_rows, value_in,
+                        seed, offset, rows=rows)
 
 
 def _is_step_net_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, h, c, state_rows):
@@ -376,6 +397,7 @@ _lib.impl('sgd_step', _sgd_step_hip, 'CUDA')
 _lib.impl('larc_scale', _larc_scale_hip, 'CUDA')
 _lib.impl('is_init', _is_init_hip, 'CUDA')
 _lib.impl('is_step', _is_step_hip, 'CUDA')
+_lib.impl('is_step_rows', _is_step_rows_hip, 'CUDA')
 _lib.impl('is_step_net', _is_step_net_hip, 'CUDA')
 _lib.impl('is_fused', _is_fused_hip, 'CUDA')
 _lib.impl('prior_draw', _prior_draw_hip, 'CUDA')

@@ -169,8 +169,10 @@ class ParticleTensor(torch.Tensor):
         return super().__torch_function__(func, types, args, kwargs or {})
 
     def __bool__(self):
-        plain = self.as_subclass(torch.Tensor)
         ls = _lock_step
+        if ls is not None and getattr(ls, 'draw', None) is not None:
+            ls.flush()        # `if sample(...):` reads the values: a deferred draw has to exist before the branch looks at them
+        plain = self.as_subclass(torch.Tensor)
         if ls is None or plain.numel() != ls.width:
             return bool(plain)
         return ls.branch(plain)
@@ -240,6 +242,8 @@ class PathExecutor:
         self.decisions_seen += 1
         if k < len(self.decisions):
             return self.decisions[k]             # replayed prefix: this path already knows its way
+        if getattr(self, 'draw', None) is not None:
+            self.flush()      # (any path that reaches a branch with a deferred draw pending: the condition may alias its storage)
         c = cond.reshape(-1).to(self.dev) != 0
         t = c if self.active is None else (c & self.active)
         n_true = int(t.sum().item())

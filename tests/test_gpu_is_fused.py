@@ -95,3 +95,43 @@ def test_reading_a_deferred_value_materialises_it(monkeypatch):
     assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())
     np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert np.all(np.isfinite(fused._all_log_weights.cpu().numpy()))
+
+
+class BranchOnFirstDraw(GaussianWithUnknownMean):
+    """`if k:` on the FIRST statement's value - ParticleTensor.__bool__ straight on a deferred draw: the draw has to
+    be flushed before the branch reads it, otherwise the particles split on uninitialised memory."""
+
+    def forward(self):
+        import pyprob_amd as pyprob
+        from pyprob_amd.distributions import Normal, Poisson
+        k = pyprob.sample(Poisson(1.2))
+        if k:
+            mu = pyprob.sample(Normal(2.0, 1.0))
+        else:
+            mu = pyprob.sample(Normal(-2.0, 1.0))
+        likelihood = Normal(mu, self.likelihood_stddev)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+def test_branching_on_a_deferred_first_draw(monkeypatch):
+    torch.manual_seed(6)
+    model = BranchOnFirstDraw()
+    model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=8000, observe_embeddings=EMB, batch_size=128,
+                                  lstm_dim=64, seed=4)
+    obs = {'obs0': 1.0, 'obs1': 1.5}
+    fused, eager = _both(model, 20000, monkeypatch, obs, seed=13)
+    assert fused.num_paths == eager.num_paths == 2
+    kf = fused.statement_log[0]
+    ke = eager.statement_log[0]
+    (af, (vf, _)), = kf.items()
+    (ae, (ve, _)), = ke.items()
+    assert af == ae and torch.equal(vf, ve)                         # the same Poisson draws ...
+    zero = (vf == 0).cpu().numpy()
+    assert 0.02 < zero.mean() < 0.9
+    assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())   # ... and the same split
+    np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # the particles that drew k = 0 went down the `else` branch: their value comes from the proposal of Normal(-2, 1)
+    mu = fused._all_values.cpu().numpy()
+    assert mu[zero].mean() < mu[~zero].mean()

@@ -1,0 +1,261 @@
+"""The fused importance-sampling statement (csrc/is_step_fused.hip: gates + LSTM cell + both head layers + draw + log q of N
+particles with per-particle state in ONE kernel; `_infer_step` pyprob/nn/inference_network_lstm.py:82-134 + state.sample's IC
+branch pyprob/state.py:203-219) against the float64 oracle, through the C ABI (pp_is_step / pp_is_step_rows via the
+`pyprob_hip` operators): new (h, c), log q of the drawn values, the in-place row-index path, the shared-state second
+statement, ragged panel tails, the categorical / Bernoulli heads that are sampled by their own kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ic_oracle as O
+from pyprob_amd import lib as L
+from pyprob_amd.spec import NetSpec
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+EMB = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
+ADDRS = [('a_normal', 'Normal', None), ('a_uniform', 'Uniform', None), ('a_cat', 'Categorical', 7), ('a_poisson', 'Poisson', None),
+         ('a_bern', 'Bernoulli', None)]
+
+
+def _engine(H, seed=0):
+    from pyprob_amd.engine import ICEngine
+    from pyprob_amd.is_engine import ISRunner
+    spec = NetSpec(EMB, lstm_dim=H)
+    eng = ICEngine(spec, device='cuda:0', seed=seed)
+    eng.add_addresses(ADDRS)
+    rng = np.random.default_rng(seed + 1)
+    # trained-looking weights: larger than the default initialisation so that gates and mixtures are not near-uniform
+    sd = {k: (v.numpy() * (3.0 if ('lstm' in k or 'proposal' in k) else 1.0)).astype(np.float32) for k, v in eng.state_dict().items()}
+    for k in sd:
+        if k.endswith('bias') or 'bias_' in k:
+            sd[k] = (sd[k] + 0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+    eng.load_state_dict(sd)
+    run = ISRunner(eng)
+    run.init([8.0, 9.0])
+    return eng, run, sd
+
+
+def _oracle_statement(sd, H, observe, prev, cur, prev_val, h0, c0, values, prior):
+    """One `_infer_step` for n particles in float64: returns (h, c, log q, head outputs y)."""
+    net = O.Net(sd, list(EMB), K=10)
+    a_prev, d_prev = prev
+    a_cur, d_cur = cur
+    n = len(prev_val)
+    E, _ = O.embed_observe(net, np.asarray(observe, np.float64).reshape(1, -1))
+    W_ih, W_hh, b_ih, b_hh = net.lstm_layer(0)
+    x = np.zeros((n, W_ih.shape[1]))
+    col = E.shape[1]
+    x[:, :col] = E[0]
+    cat = 7 if d_prev == 'Categorical' else None
+    s, _ = O.sample_embedding(net, a_prev, d_prev, prev_val, cat)
+    S, Ed, Ea = s.shape[1], 8, 64
+    x[:, col:col + S] = s
+    x[:, col + S:col + S + Ed] = net.P['_layers_distribution_type_embedding.' + d_prev]
+    x[:, col + S + Ed:col + S + Ed + Ea] = net.P['_layers_address_embedding.' + a_prev]
+    c2 = col + S + Ed + Ea
+    x[:, c2:c2 + Ed] = net.P['_layers_distribution_type_embedding.' + d_cur]
+    x[:, c2 + Ed:] = net.P['_layers_address_embedding.' + a_cur]
+    _, _, (h, c) = O.lstm_forward(x[None], W_ih, W_hh, b_ih, b_hh, h0.astype(np.float64), c0.astype(np.float64))
+    Ws, bs = net.ff('_layers_proposal.%s._ff' % a_cur)
+    y, _ = O.ff_forward(h, Ws, bs, False)
+    lq = None
+    if values is not None:
+        if d_cur == 'Bernoulli':
+            lq = np.concatenate([np.diag(O.head_forward(net, a_cur, d_cur, h[i:i + 128], prior[i:i + 128], values[i:i + 128])[2][1])
+                                 for i in range(0, n, 128)])
+        else:
+            lq, _, _ = O.head_forward(net, a_cur, d_cur, h, prior, values)
+    return h, c, lq, y
+
+
+def _prior_for(dist, n, rng):
+    if dist == 'Normal':
+        return np.stack([rng.normal(0, 1, n), rng.uniform(0.5, 2.0, n)], 1).astype(np.float32)
+    if dist == 'Uniform':
+        lo = rng.uniform(-2, 0, n)
+        return np.stack([lo, lo + rng.uniform(0.5, 3, n)], 1).astype(np.float32)
+    return np.zeros((n, 2), np.float32)
+
+
+def _prev_values(dist, n, rng):
+    if dist == 'Categorical':
+        return rng.integers(0, 7, n).astype(np.float32)
+    return rng.normal(0, 1.5, n).astype(np.float32)
+
+
+def _ids(eng, name):
+    return eng.spec.address_id[name]
+
+
+@pytest.mark.parametrize('H,n,prev,cur', [
+    (512, 1000, ('a_normal', 'Normal'), ('a_uniform', 'Uniform')),        # TruncatedNormal mixture, ragged last panel
+    (512, 32, ('a_uniform', 'Uniform'), ('a_normal', 'Normal')),          # exactly one panel
+    (512, 4133, ('a_cat', 'Categorical'), ('a_normal', 'Normal')),        # one-hot sample embedding of the previous value
+    (512, 257, ('a_normal', 'Normal'), ('a_poisson', 'Poisson')),         # Poisson head (TN mixture on [0, 40])
+    (512, 300, ('a_normal', 'Normal'), ('a_cat', 'Categorical')),         # head outputs -> the categorical kernel
+    (512, 300, ('a_uniform', 'Uniform'), ('a_bern', 'Bernoulli')),
+    (256, 777, ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform')),
+])
+def test_fused_statement_against_the_oracle(H, n, prev, cur):
+    from pyprob_amd.ops import ops
+    eng, run, sd = _engine(H)
+    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0])) == 1
+    rng = np.random.default_rng(5)
+    h0 = (0.5 * rng.standard_normal((n, H))).astype(np.float32).clip(-0.99, 0.99)
+    c0 = rng.standard_normal((n, H)).astype(np.float32)
+    pv = _prev_values(prev[1], n, rng)
+    prior = _prior_for(cur[1], n, rng)
+    dev = eng.device
+    h = torch.from_numpy(h0.copy()).to(dev).reshape(1, n, H).contiguous()
+    c = torch.from_numpy(c0.copy()).to(dev).reshape(1, n, H).contiguous()
+    run._ensure_ws(n)
+    pt = torch.from_numpy(prior).to(dev) if cur[1] in ('Normal', 'Uniform') else (
+        torch.zeros(1, 2, device=dev) if cur[1] == 'Poisson' else None)
+    if cur[1] == 'Poisson':
+        pt = torch.tensor([[0.0, 40.0]], device=dev)
+        prior = np.tile(np.array([[0.0, 40.0]], np.float32), (n, 1))
+    value, logq = ops.is_step(eng.params, run.ws, eng.net_handle, _ids(eng, cur[0]), _ids(eng, prev[0]), n, run.e_obs,
+                              torch.from_numpy(pv).to(dev), pt, h, c, n, None, 1234, 0)
+    torch.cuda.synchronize()
+    v = value.cpu().numpy()
+    assert np.all(np.isfinite(v))
+    if cur[1] == 'Uniform':
+        assert np.all((v >= prior[:, 0]) & (v < prior[:, 1]))
+    href, cref, lq_ref, _ = _oracle_statement(sd, H, [8.0, 9.0], prev, cur, pv, h0, c0, v.astype(np.float64), prior.astype(np.float64))
+    # the LSTM cell on v_exp_f32 / v_rcp_f32 sigmoid / tanh: absolute error of (h, c) asserted here
+    eh = np.abs(h.cpu().numpy()[0] - href).max()
+    ec = np.abs(c.cpu().numpy()[0] - cref).max()
+    assert eh < 4e-6 and ec < 2e-5, (eh, ec)
+    lq = logq.cpu().numpy()
+    ok = np.isfinite(lq_ref)
+    assert ok.mean() > 0.99
+    err = np.abs(lq[ok] - lq_ref[ok]) / np.maximum(1.0, np.abs(lq_ref[ok]))
+    assert err.max() < 1e-4, err.max()
+    # re-scoring the same values (value_in) reproduces log q bit for bit and leaves the values alone
+    h2 = torch.from_numpy(h0.copy()).to(dev).reshape(1, n, H).contiguous()
+    c2 = torch.from_numpy(c0.copy()).to(dev).reshape(1, n, H).contiguous()
+    v2, lq2 = ops.is_step(eng.params, run.ws, eng.net_handle, _ids(eng, cur[0]), _ids(eng, prev[0]), n, run.e_obs,
+                          torch.from_numpy(pv).to(dev), pt, h2, c2, n, value, 99, 0)
+    assert torch.equal(v2, value) and torch.equal(lq2, logq) and torch.equal(h2, h) and torch.equal(c2, c)
+
+
+def test_fused_statement_equals_the_unfused_chain(monkeypatch):
+    """A/B inside one process: PP_IS_STEP_FUSED=0 takes the gather -> GEMM -> GEMM -> cell -> head chain. Same Philox
+    counters, so the draws agree to the rounding of the proposal parameters; states agree to fp32 summation order."""
+    from pyprob_amd.ops import ops
+    H, n = 512, 2000
+    eng, run, sd = _engine(H, seed=3)
+    rng = np.random.default_rng(9)
+    h0 = (0.5 * rng.standard_normal((n, H))).astype(np.float32)
+    c0 = rng.standard_normal((n, H)).astype(np.float32)
+    pv = rng.normal(0, 1, n).astype(np.float32)
+    prior = _prior_for('Uniform', n, rng)
+    dev = eng.device
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PP_IS_STEP_FUSED', flag)
+        h = torch.from_numpy(h0.copy()).to(dev).reshape(1, n, H).contiguous()
+        c = torch.from_numpy(c0.copy()).to(dev).reshape(1, n, H).contiguous()
+        run._ensure_ws(n)
+        v, lq = ops.is_step(eng.params, run.ws, eng.net_handle, _ids(eng, 'a_uniform'), _ids(eng, 'a_normal'), n, run.e_obs,
+                            torch.from_numpy(pv).to(dev), torch.from_numpy(prior).to(dev), h, c, n, None, 7, 11)
+        outs.append((v.cpu().numpy(), lq.cpu().numpy(), h.cpu().numpy(), c.cpu().numpy()))
+    (v1, l1, h1, c1), (v0, l0, h0_, c0_) = outs
+    assert np.abs(h1 - h0_).max() < 5e-6 and np.abs(c1 - c0_).max() < 2e-5
+    rel = np.abs(v1 - v0) / np.maximum(1e-3, np.abs(v0))
+    assert np.median(rel) < 1e-5 and np.quantile(rel, 0.99) < 1e-3
+    close = rel < 1e-5
+    np.testing.assert_allclose(l1[close], l0[close], rtol=2e-4, atol=2e-4)
+
+
+def test_row_index_list_updates_the_state_in_place():
+    """pp_is_step_rows: the particles of a diverged path own scattered rows of (h, c); the rows are read and written in
+    place, every other row is untouched, and the result equals the compact call on the gathered rows."""
+    from pyprob_amd.ops import ops
+    H, total, m = 512, 5000, 1777
+    eng, run, sd = _engine(H, seed=4)
+    rng = np.random.default_rng(2)
+    h0 = (0.5 * rng.standard_normal((total, H))).astype(np.float32)
+    c0 = rng.standard_normal((total, H)).astype(np.float32)
+    rows = np.sort(rng.choice(total, m, replace=False)).astype(np.int64)
+    pv = rng.normal(0, 1, m).astype(np.float32)
+    prior = _prior_for('Normal', m, rng)
+    dev = eng.device
+    h = torch.from_numpy(h0.copy()).to(dev).reshape(1, total, H).contiguous()
+    c = torch.from_numpy(c0.copy()).to(dev).reshape(1, total, H).contiguous()
+    run._ensure_ws(m)
+    a, p = _ids(eng, 'a_normal'), _ids(eng, 'a_uniform')
+    v, lq = ops.is_step_rows(eng.params, run.ws, eng.net_handle, a, p, m, run.e_obs, torch.from_numpy(pv).to(dev),
+                             torch.from_numpy(prior).to(dev), h, c, m, torch.from_numpy(rows).to(dev), None, 5, 0)
+    hg = torch.from_numpy(h0[rows].copy()).to(dev).reshape(1, m, H).contiguous()
+    cg = torch.from_numpy(c0[rows].copy()).to(dev).reshape(1, m, H).contiguous()
+    v2, lq2 = ops.is_step(eng.params, run.ws, eng.net_handle, a, p, m, run.e_obs, torch.from_numpy(pv).to(dev),
+                          torch.from_numpy(prior).to(dev), hg, cg, m, None, 5, 0)
+    assert torch.equal(v, v2) and torch.equal(lq, lq2)
+    hn, cn = h.cpu().numpy()[0], c.cpu().numpy()[0]
+    assert np.array_equal(hn[rows], hg.cpu().numpy()[0]) and np.array_equal(cn[rows], cg.cpu().numpy()[0])
+    rest = np.setdiff1d(np.arange(total), rows)
+    assert np.array_equal(hn[rest], h0[rest]) and np.array_equal(cn[rest], c0[rest])
+    href, cref, lq_ref, _ = _oracle_statement(sd, H, [8.0, 9.0], ('a_uniform', 'Uniform'), ('a_normal', 'Normal'), pv, h0[rows],
+                                              c0[rows], v.cpu().numpy().astype(np.float64), prior.astype(np.float64))
+    assert np.abs(hn[rows] - href).max() < 4e-6
+    np.testing.assert_allclose(lq.cpu().numpy(), lq_ref, rtol=1e-4, atol=1e-4)
+
+
+def test_second_statement_with_the_shared_first_state():
+    """state_rows = 1: row 0 holds the state every particle left the first statement with; its recurrent product joins the
+    bias row, the cell reads the one shared previous cell state, all n rows are written."""
+    from pyprob_amd.ops import ops
+    H, n = 512, 3001
+    eng, run, sd = _engine(H, seed=6)
+    rng = np.random.default_rng(3)
+    h_row = (0.5 * rng.standard_normal((1, H))).astype(np.float32)
+    c_row = rng.standard_normal((1, H)).astype(np.float32)
+    pv = rng.uniform(-1, 1, n).astype(np.float32)
+    prior = np.tile(np.array([[-1.0, 1.0]], np.float32), (n, 1))
+    dev = eng.device
+    h = torch.zeros(1, n, H, device=dev)
+    c = torch.zeros(1, n, H, device=dev)
+    h[0, 0] = torch.from_numpy(h_row[0]).to(dev)
+    c[0, 0] = torch.from_numpy(c_row[0]).to(dev)
+    run._ensure_ws(n)
+    v, lq = ops.is_step(eng.params, run.ws, eng.net_handle, _ids(eng, 'a_uniform'), _ids(eng, 'a_uniform'), n, run.e_obs,
+                        torch.from_numpy(pv).to(dev), torch.tensor([[-1.0, 1.0]], device=dev), h, c, 1, None, 21, 0)
+    href, cref, lq_ref, _ = _oracle_statement(sd, H, [8.0, 9.0], ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform'), pv,
+                                              np.repeat(h_row, n, 0), np.repeat(c_row, n, 0), v.cpu().numpy().astype(np.float64),
+                                              prior.astype(np.float64))
+    assert np.abs(h.cpu().numpy()[0] - href).max() < 4e-6 and np.abs(c.cpu().numpy()[0] - cref).max() < 2e-5
+    np.testing.assert_allclose(lq.cpu().numpy(), lq_ref, rtol=1e-4, atol=1e-4)
+
+
+def test_fast_activations_against_libm():
+    """The cell's sigmoid / tanh run on v_exp_f32 / v_rcp_f32: with W_hh = 0 and a zero previous state the new cell state is
+    sigmoid(b_i) * tanh(b_g) of the bias row - swept over [-12, 12] and compared with float64."""
+    from pyprob_amd.ops import ops
+    H, n = 512, 64
+    eng, run, sd = _engine(H, seed=8)
+    sd = dict(sd)
+    sd['_layers_lstm.weight_hh_l0'] = np.zeros_like(sd['_layers_lstm.weight_hh_l0'])
+    sd['_layers_lstm.weight_ih_l0'] = np.zeros_like(sd['_layers_lstm.weight_ih_l0'])
+    sweep = np.linspace(-12, 12, H).astype(np.float32)
+    b = np.concatenate([sweep, sweep[::-1], 0.37 * sweep, -sweep]).astype(np.float32)
+    sd['_layers_lstm.bias_ih_l0'] = b
+    sd['_layers_lstm.bias_hh_l0'] = np.zeros_like(b)
+    eng.load_state_dict(sd)
+    run.init([8.0, 9.0])
+    dev = eng.device
+    c0 = np.tile(np.linspace(-2, 2, H).astype(np.float32), (n, 1))
+    h = torch.zeros(1, n, H, device=dev)
+    c = torch.from_numpy(c0.copy()).to(dev).reshape(1, n, H).contiguous()
+    run._ensure_ws(n)
+    ops.is_step(eng.params, run.ws, eng.net_handle, _ids(eng, 'a_normal'), _ids(eng, 'a_normal'), n, run.e_obs,
+                torch.zeros(n, device=dev), torch.tensor([[0.0, 1.0]], device=dev), h, c, n, None, 1, 0)
+    b64 = b.astype(np.float64)
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    cn = sig(b64[H:2 * H]) * c0[0] + sig(b64[:H]) * np.tanh(b64[2 * H:3 * H])
+    hn = sig(b64[3 * H:]) * np.tanh(cn)
+    assert np.abs(c.cpu().numpy()[0] - cn).max() < 1e-6
+    assert np.abs(h.cpu().numpy()[0] - hn).max() < 5e-7

@@ -1,0 +1,132 @@
+"""The BENCHMARKED posterior against the oracle: BASELINE.json configs[3] - a config-4 network (LSTM
+hidden 512), `Model.posterior_results(n, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe, lock_step=True)` with the
+default fused pass - every particle's value and log-weight downloaded and re-scored by the float64 oracle
+(`O.is_rescore_lockstep`, pinned on the reference's records in tests/test_oracle.py): the shared first statement
+(pp_is_step_net + pp_is_fused, `is_fused_kernel<0>`) for GUM at 65 537 and 10^6 particles, and the N-row statements
+(pp_is_step / pp_is_step_rows, csrc/is_step_fused.hip) of the Marsaglia program with stochastic control flow.
+Reference semantics: pyprob/state.py:203-219 (log p - log q per controlled sample), :118-155 (observe terms),
+pyprob/trace.py:119-125 (the trace's log-weight), pyprob/model.py:47-88."""
+import math
+import warnings
+
+import numpy as np
+import pytest
+
+from models import GaussianWithUnknownMean, GaussianWithUnknownMeanMarsagliaLockStep
+from oracle import ic_oracle as O
+from pyprob_amd.state import InferenceEngine, InferenceNetwork
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+IC = InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
+OBS = {'obs0': 8, 'obs1': 9}
+EMB = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
+SIGMA = math.sqrt(2)
+
+
+def _train(model, num_traces, seed):
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=num_traces, observe_embeddings=EMB,
+                                      batch_size=256, lstm_dim=512, seed=seed)
+    return model
+
+
+@pytest.fixture(scope='module')
+def gum_fresh():
+    return _train(GaussianWithUnknownMean(), 256, 1)         # one minibatch: practically the initial weights
+
+
+@pytest.fixture(scope='module')
+def gum_trained():
+    return _train(GaussianWithUnknownMean(), 30000, 2)
+
+
+@pytest.fixture(scope='module')
+def gumm_trained():
+    return _train(GaussianWithUnknownMeanMarsagliaLockStep(), 30000, 3)
+
+
+def _oracle_net(model):
+    eng = model._inference_network._engine
+    assert eng.spec.lstm_dim == 512
+    params = {k: v.numpy() for k, v in eng.state_dict().items()}
+    return O.Net(params, ['obs0', 'obs1'], K=eng.spec.K), [a.address for a in eng.spec.addresses]
+
+
+def _likelihood(values):
+    obs = [float(OBS['obs0']), float(OBS['obs1'])]
+    return sum(np.asarray(O.normal_log_prob(y, values, SIGMA), np.float32).astype(np.float64) for y in obs)
+
+
+@pytest.mark.parametrize('which,n', [('fresh', 65537), ('trained', 65537), ('trained', 1000000)])
+def test_gum_posterior_every_particle_rescored(gum_fresh, gum_trained, which, n):
+    model = gum_fresh if which == 'fresh' else gum_trained
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model.posterior_results(n, IC, observe=OBS, lock_step=True, seed=17)
+    v = post._all_values.cpu().numpy().astype(np.float64)
+    lw = post._all_log_weights.cpu().numpy().astype(np.float64)
+    assert v.shape == (n,) and np.all(np.isfinite(v))
+    net, addresses = _oracle_net(model)
+    steps = [dict(address=addresses[0], dist_name='Normal', values=v, prior=np.array([[1.0, math.sqrt(5)]]))]
+    _, lw_ref = O.is_rescore_lockstep(net, [8.0, 9.0], steps, n, chunk=1 << 18)
+    lw_ref = lw_ref + _likelihood(v)
+    ok = np.isfinite(lw_ref)
+    assert ok.all()
+    err = np.abs(lw - lw_ref) / np.maximum(1.0, np.abs(lw_ref))
+    assert err.max() < 1e-4, (err.max(), int(err.argmax()))
+    # and the statistics the Empirical reports are those of these weights (float64, util.py:398-399)
+    w = np.exp(lw_ref - lw_ref.max())
+    w /= w.sum()
+    assert abs(post.mean - float((w * v).sum())) < 1e-4 * max(1.0, abs(post.mean))
+    assert abs(post.effective_sample_size - 1.0 / float((w * w).sum())) < 2e-3 * post.effective_sample_size
+    if which == 'trained':
+        assert abs(post.mean - 7.25) < 0.5
+
+
+def _gumm_steps(post, addresses, n):
+    """Statement log of a lock-step Marsaglia run -> the statement list of the oracle: iteration k draws (x_k, y_k) for the
+    particles whose earlier pairs all had x^2 + y^2 >= 1."""
+    log = [{a: v.cpu().numpy() for a, (v, _) in entry.items()} for entry in post.statement_log]
+    alive = np.arange(n)
+    steps, results = [], np.zeros(n)
+    k = 0
+    while len(alive):
+        (ax, vx), = log[2 * k].items()
+        (ay, vy), = log[2 * k + 1].items()
+        x, y = vx[alive], vy[alive]
+        if ax in addresses:      # (iterations the network never saw in training are proposed from the prior: log p - log q = 0)
+            steps.append(dict(address=ax, dist_name='Uniform', values=x.astype(np.float64), prior=np.array([[-1.0, 1.0]]), rows=alive))
+            steps.append(dict(address=ay, dist_name='Uniform', values=y.astype(np.float64), prior=np.array([[-1.0, 1.0]]), rows=alive))
+        s = x * x + y * y                      # float32 like the program
+        done = s < 1
+        xd, sd = x[done].astype(np.float64), s[done].astype(np.float64)
+        results[alive[done]] = 1.0 + math.sqrt(5.0) * xd * np.sqrt(-2.0 * np.log(sd) / sd)
+        alive = alive[~done]
+        k += 1
+    return steps, results
+
+
+@pytest.mark.parametrize('n', [65537])
+def test_gumm_posterior_every_particle_rescored(gumm_trained, n):
+    """Stochastic control flow at H = 512: the second statement (shared first state), then N-row statements on the rows of
+    the diverged paths (in place through the row index list) - the fused statement kernel - re-scored per particle."""
+    model = gumm_trained
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model.posterior_results(n, IC, observe=OBS, lock_step=True, seed=23)
+    assert post.num_paths > 3
+    net, addresses = _oracle_net(model)
+    steps, results = _gumm_steps(post, addresses, n)
+    assert len(steps) >= 4
+    _, lw_ref = O.is_rescore_lockstep(net, [8.0, 9.0], steps, n)
+    lw_ref = lw_ref + _likelihood(results)
+    lw = post._all_log_weights.cpu().numpy().astype(np.float64)
+    v = post._all_values.cpu().numpy().astype(np.float64)
+    ok = np.isfinite(lw_ref)
+    assert ok.mean() > 0.999
+    np.testing.assert_allclose(v[ok], results[ok], rtol=1e-4, atol=1e-4)
+    err = np.abs(lw[ok] - lw_ref[ok]) / np.maximum(1.0, np.abs(lw_ref[ok]))
+    assert err.max() < 1e-4, (err.max(), int(err.argmax()))

@@ -227,3 +227,61 @@ def test_is_log_weights_of_ten_thousand_reference_particles(case):
     d = big['prior_lp'] - big['prop_lp']
     sums = np.add.reduceat(d, off[:-1])
     np.testing.assert_allclose(sums + big['obs_lw'], big['lw'], rtol=1e-5, atol=1e-4)
+
+
+def _lockstep_steps(trace_len, addr, value, prior, addresses, dist_names):
+    """Ragged trace-major records -> the statement list of O.is_rescore_lockstep: statement (t, address) for the traces whose
+    t-th controlled variable has that address. Returns (steps, row index of every step's entries in the ragged arrays)."""
+    off = np.concatenate([[0], np.cumsum(trace_len)]).astype(np.int64)
+    steps, where = [], []
+    for t in range(int(np.max(trace_len))):
+        live = np.nonzero(trace_len > t)[0]
+        r = off[live] + t
+        for a in np.unique(addr[r]):
+            sel = addr[r] == a
+            steps.append(dict(address=addresses[a], dist_name=dist_names[a], values=value[r[sel]], prior=prior[r[sel]],
+                              rows=live[sel]))
+            where.append(r[sel])
+    return steps, where
+
+
+@pytest.mark.parametrize('case', ['gum', 'gumm', 'cat', 'poi', 'ber'])
+def test_vectorised_rescoring_equals_the_reference_records(case):
+    """O.is_rescore_lockstep (particles in lock step, what the GPU parity tests of large posteriors use) pinned on the
+    reference's own per-particle records and on the per-trace restatement."""
+    from conftest import load_golden
+    meta, params, batch, loss, isr = load_golden(case)
+    net = O.Net(params, meta['obs_names'], K=meta['mixture_components'])
+    addr_to_dist = dict(zip(meta['addresses'], meta['dist_names']))
+    addresses = meta['is_addresses']
+    dist_names = [addr_to_dist[a] for a in addresses]
+    steps, where = _lockstep_steps(isr['trace_len'], isr['addr'], isr['value'], isr['prior'], addresses, dist_names)
+    per_step, lw = O.is_rescore_lockstep(net, isr['observe'], steps, len(isr['trace_len']), chunk=7)
+    p_lp, q_lp = np.zeros(len(isr['value'])), np.zeros(len(isr['value']))
+    for (p, q), r in zip(per_step, where):
+        p_lp[r], q_lp[r] = p, q
+    np.testing.assert_allclose(p_lp, isr['prior_lp'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(q_lp, isr['prop_lp'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lw + isr['obs_lw'], isr['lw'], rtol=1e-4, atol=1e-4)
+    p1, q1, _, lw1 = O.is_rescore(net, isr['observe'], isr['trace_len'], isr['addr'], isr['value'], isr['prior'], addresses,
+                                  dist_names)
+    np.testing.assert_allclose(q_lp, q1, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(lw, lw1, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', ['gum', 'gumm'])
+def test_vectorised_rescoring_of_all_ten_thousand_reference_particles(case):
+    import os
+    from conftest import GOLDEN, load_golden
+    meta, params, batch, loss, isr = load_golden(case)
+    big = np.load(os.path.join(GOLDEN, case + '_is10k.npz'))
+    net = O.Net(params, meta['obs_names'], K=meta['mixture_components'])
+    addresses = [str(a) for a in big['addresses']]
+    dist_names = ['Normal' if '__Normal__' in a else 'Uniform' for a in addresses]
+    steps, where = _lockstep_steps(big['trace_len'], big['addr'], big['value'], big['prior'], addresses, dist_names)
+    per_step, lw = O.is_rescore_lockstep(net, big['observe'], steps, len(big['trace_len']))
+    q_lp = np.zeros(len(big['value']))
+    for (p, q), r in zip(per_step, where):
+        q_lp[r] = q
+    np.testing.assert_allclose(q_lp, big['prop_lp'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lw + big['obs_lw'], big['lw'], rtol=1e-4, atol=1e-4)
