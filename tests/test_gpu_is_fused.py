@@ -116,22 +116,28 @@ class BranchOnFirstDraw(GaussianWithUnknownMean):
 
 
 def test_branching_on_a_deferred_first_draw(monkeypatch):
+    """The Poisson head proposes continuous positive values (a TruncatedNormal mixture on [0, 40]), so `if k:` is True for every
+    particle - provided the branch reads the DRAWN values. The deferred draw's storage comes from torch.empty: the caching
+    allocator is primed with zeros of that size, so an unflushed read sees k = 0 everywhere and takes the other branch."""
     torch.manual_seed(6)
     model = BranchOnFirstDraw()
     model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=8000, observe_embeddings=EMB, batch_size=128,
                                   lstm_dim=64, seed=4)
     obs = {'obs0': 1.0, 'obs1': 1.5}
-    fused, eager = _both(model, 20000, monkeypatch, obs, seed=13)
-    assert fused.num_paths == eager.num_paths == 2
-    kf = fused.statement_log[0]
-    ke = eager.statement_log[0]
-    (af, (vf, _)), = kf.items()
-    (ae, (ve, _)), = ke.items()
-    assert af == ae and torch.equal(vf, ve)                         # the same Poisson draws ...
-    zero = (vf == 0).cpu().numpy()
-    assert 0.02 < zero.mean() < 0.9
-    assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())   # ... and the same split
+    n = 20000
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PP_IS_FUSED', flag)
+        for _ in range(4):
+            z = [torch.zeros(n, device='cuda:0') for _ in range(8)]      # freed blocks of exactly the size torch.empty(n) asks for
+            del z
+        outs.append(model.posterior_results(n, IC, observe=obs, lock_step=True, seed=13))
+    fused, eager = outs
+    assert fused.num_paths == eager.num_paths == 1
+    (af, (vf, _)), = fused.statement_log[0].items()
+    (ae, (ve, _)), = eager.statement_log[0].items()
+    assert af == ae and torch.equal(vf, ve) and bool((vf > 0).all())
+    assert len(fused.statement_log[1]) == 1 and list(fused.statement_log[1]) == list(eager.statement_log[1])    # the `if` branch
+    assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())
     np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=1e-5, atol=1e-5)
-    # the particles that drew k = 0 went down the `else` branch: their value comes from the proposal of Normal(-2, 1)
-    mu = fused._all_values.cpu().numpy()
-    assert mu[zero].mean() < mu[~zero].mean()
+    assert fused._all_values.mean() > 0          # proposals of Normal(2, 1), not of Normal(-2, 1)
