@@ -253,7 +253,36 @@ def api_models():
     return GaussianWithUnknownMean, GaussianWithUnknownMeanMarsaglia
 
 
-def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='gum', seed0=7, offset=0, train_traces=None):
+def csrc_sha():
+    """sha256 over the kernel sources (csrc/*, include/*): profiles/r04_*.json carry the hash of the sources they were
+    measured on; a line quotes them only when it matches the tree that is running."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, 'pyprob_amd', 'csrc', '*')) + glob.glob(os.path.join(REPO, 'include', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(name):
+    """(document, note): profiles/<name> when its `csrc_sha` equals the running tree's, else (None, why)."""
+    path = os.path.join('profiles', name)
+    try:
+        with open(os.path.join(REPO, path)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, '%s not found' % path
+    have = csrc_sha()
+    if d.get('csrc_sha') != have:
+        return None, '%s was measured on kernel sources %s, this tree is %s: not quoted (re-run tools/profile_round.sh)' % (
+            path, d.get('csrc_sha'), have)
+    return d, path
+
+
+def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='gum', seed0=7, offset=0, train_traces=None,
+                        prof_class=4):
     """BASELINE.json configs[3] through the drop-in API: Model.learn_inference_network (a short run: the network only has to
     exist and be sane) then `calls` x Model.posterior_results(particles, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
     observe={'obs0': 8, 'obs1': 9}) on the user's forward() in lock step - state.sample / state.observe / Trace.end and the
@@ -274,7 +303,8 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
     observe = {'obs0': 8, 'obs1': 9} if program == 'gum' else {'obs0': 4, 'obs1': 5}
     for i in range(warm):
         post = model.posterior_results(particles, IC, observe=observe, lock_step=True, seed=i, offset=offset)
-    lib.pp_prof_arm(4, calls * 4)
+    cap = calls * (4 if prof_class == 4 else 64)
+    lib.pp_prof_arm(prof_class, cap)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(calls):
@@ -282,18 +312,39 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         _ = post.effective_sample_size           # (the caller looks at the result: mean / ESS are read back every call)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms = np.zeros(calls * 4, np.float32)
-    fl = np.zeros(calls * 4, np.float64)
+    ms = np.zeros(cap, np.float32)
+    fl = np.zeros(cap, np.float64)
     cnt = C.c_int32(0)
-    lib.pp_prof_collect(ms.ctypes.data, calls * 4, C.byref(cnt), fl.ctypes.data)
-    lib.pp_prof_arm(4, 0)
+    lib.pp_prof_collect(ms.ctypes.data, cap, C.byref(cnt), fl.ctypes.data)
+    lib.pp_prof_arm(prof_class, 0)
     rec = dict(particles_per_sec=round(particles * calls / dt, 1), ms_per_call=round(dt / calls * 1e3, 4), particles_per_call=particles,
                calls=calls, program='GaussianUnknownMean' if program == 'gum' else 'GaussianUnknownMeanMarsaglia (tensor-condition loop)',
                api='Model.posterior_results(N, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe=..., lock_step=True) on the '
                    "user's forward()", posterior_mean=round(float(post.mean), 4), posterior_stddev=round(float(post.stddev), 4),
                ess=round(float(post.effective_sample_size), 1), control_flow_paths=int(getattr(post, 'num_paths', 1)),
                network_params=model._inference_network._engine.spec.num_parameters())
-    if cnt.value > 0:
+    if cnt.value > 0 and prof_class == 5:
+        # the N-row statement kernel (csrc/is_step_fused.hip), every launch of the timed calls: MFMA bound, priced on the
+        # reference algorithm's FLOPs per particle-statement (2 (I + H) 4H + 2 (H hid + hid 3K); a statement on
+        # the shared first state has no per-particle recurrent product: 2 I 4H + head)
+        us = float(ms[:cnt.value].sum()) * 1e3 / calls
+        flops = float(fl[:cnt.value].sum()) / calls
+        prof, note = committed_profile('r04_is_pmc_traffic.json')
+        tr = (prof or {}).get('kernels', {}).get('is_step_fused', {})
+        rec['statement_kernel'] = dict(
+            bound='mfma', achieved=round(flops / (us * 1e-6) / 1e12, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+            frac=round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), us_per_call=round(us, 1),
+            launches_per_call=round(cnt.value / calls, 2), flops_per_call=flops,
+            traffic=tr.get('traffic_bytes_per_particle_statement'), algorithmic_bytes=tr.get('algorithmic_bytes_per_particle_statement'),
+            traffic_source=note,
+            kernel='is_step_fused_kernel (one launch per statement after the first: [s_prev | h] [W_s | W_hh]^T + bias on '
+                   'v_mfma_f32_32x32x2_f32, LSTM cell on the accumulators, both head layers from the fresh h tile, Philox draw + '
+                   'log q; (h, c) read and written once, in place, through the row index list of a diverged path)',
+            timing='HIP event pair around EVERY launch of the class inside the timed calls',
+            wall_over_statement_kernels=round(dt / calls * 1e6 / us, 2),
+            wall_note='host wall per call / time inside the N-row statement kernels only: the shared first statement, the '
+                      'per-term log-weight kernels and torch index operations of the path bookkeeping are outside the event pairs')
+    elif cnt.value > 0:
         per_call_us = float(ms[:cnt.value].sum()) * 1e3 / calls
         nbytes = float(fl[:cnt.value].sum()) / calls
         rec['particle_kernels'] = dict(
@@ -421,13 +472,21 @@ def main():
             eng.capture_train_step(stage, lr)
 
             def step(i):
-                ds.load_into_staging(i)      # one 20 KB device copy: the next minibatch into the captured buffers
+                ds.load_into_staging(i % ds.n_batches)      # one 20 KB device copy: the next minibatch into the captured buffers
                 eng.replay_train_step()
+            walk = 1
         else:
-            batches = [ds.batch(i, 0, 1, cache) for i in range(min(ds.n_batches, K + W))]
+            # every minibatch of the resident dataset; the steps walk them with a stride coprime to their number, so that the
+            # timed region samples the WHOLE 1 M-trace dataset (each step a region of HBM it has not read recently), not its
+            # first K + W minibatches
+            batches = [ds.batch(i, 0, 1, cache) for i in range(ds.n_batches)]
+            walk = next(q for q in range(max(1, ds.n_batches // max(K, 1)), ds.n_batches + 2) if np.gcd(q, ds.n_batches) == 1)
+
+            def pick(i):
+                return batches[(i * walk) % len(batches)]
 
             def step(i):
-                eng.train_step(batches[i % len(batches)], lr)
+                eng.train_step(pick(i), lr)
         # Two host loops over the same kernels: one Python iteration per step (two C calls) or the native loop
         # pp_train_resident (up to 256 steps per C call: ~4x less host time per step, the robust choice on a slow or busy
         # host). The untimed pre-warm measures both in the steady state and the timed region uses the faster one
@@ -442,7 +501,7 @@ def main():
                 return
             for c0 in range(0, n, 256):
                 m = min(256, n - c0)
-                eng.train_resident([batches[(i0 + c0 + j) % len(batches)] for j in range(m)], [lr] * m)
+                eng.train_resident([pick(i0 + c0 + j) for j in range(m)], [lr] * m)
 
         def wall(native, n):
             barrier()
@@ -529,19 +588,15 @@ def main():
         final_loss = float(eng.loss_buf[0].item())
         units = B * K
         metric, unit = 'ic_train_traces_per_sec', 'traces/s'
-        pmc, pmc_file = {}, os.path.join('profiles', 'r03_pmc_traffic.json')   # tools/profile_round.sh
-        try:   # HBM bytes per launch from the committed PMC passes (rocprof cannot run inside bench.py)
-            with open(os.path.join(REPO, pmc_file)) as f:
-                pmc = json.load(f)['kernels'] if (B == 1024 and args.lstm_dim == 512) else {}
-        except (OSError, KeyError, ValueError):
-            pass
-
-        rocprof_avgs = {}    # per-kernel averages of the committed `rocprofv3 --kernel-trace --stats` run of this command
-        try:
-            with open(os.path.join(REPO, 'profiles', 'r03_kernel_avgs.json')) as f:
-                rocprof_avgs = json.load(f) if (B == 1024 and args.lstm_dim == 512) else {}
-        except (OSError, ValueError):
-            pass
+        # HBM bytes per launch (PMC passes) and rocprofv3 --kernel-trace --stats averages of this command, committed by
+        # tools/profile_round.sh together with the hash of the kernel sources they were measured on: quoted only on a match
+        std_shape = B == 1024 and args.lstm_dim == 512
+        pmc_doc, pmc_file = committed_profile('r04_pmc_traffic.json') if std_shape else (None, 'not the profiled shape')
+        pmc = (pmc_doc or {}).get('kernels', {})
+        avg_doc, avg_file = committed_profile('r04_kernel_avgs.json') if std_shape else (None, 'not the profiled shape')
+        rocprof_avgs = avg_doc or {}
+        if std_shape and (pmc_doc is None or avg_doc is None):
+            out['profile_note'] = pmc_file if pmc_doc is None else avg_file
 
         def roof(sample, key, label, bound='mfma', algorithmic=None):
             """achieved = ALGORITHMIC work per launch (what the reference's algorithm does in this launch) /
@@ -569,8 +624,8 @@ def main():
             if ravg:
                 d['rocprof_avg_us'] = ravg
                 d['frac_rocprof'] = round(work / (ravg * 1e-6) / (1e12 if bound == 'mfma' else 1e9) / peak, 4)
-            d['traffic_source'] = (pmc_file + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)') \
-                if d['traffic'] is not None else None
+            d['traffic_source'] = (pmc_file + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, csrc_sha %s)'
+                                   % pmc_doc.get('csrc_sha')) if d['traffic'] is not None else pmc_file
             return d
         H, I = args.lstm_dim, eng.spec.lstm_in
         if dominant and first:
@@ -656,7 +711,9 @@ def main():
                       launch='hip_graph_replay' if args.graph else
                       ('native loop: up to 256 steps per C call (pp_train_resident), eager launches' if native_loop else
                        'one Python iteration per step (ICEngine.train_step), eager launches'),
-                      prewarm_steps=prewarm_steps, prewarm_s=args.prewarm_s,
+                      prewarm_steps=prewarm_steps, prewarm_s=args.prewarm_s, minibatches_resident=ds.n_batches,
+                      minibatch_walk='step i trains minibatch (i * %d) mod %d of the resident dataset' % (walk, ds.n_batches),
+                      csrc_sha=csrc_sha(),
                       loop_probe_us_per_step={k: round(v * 1e6, 2) for k, v in probe.items()},
                       allreduce_bytes_per_step=(4 * (eng.grads_full.numel() - sum(c for _, c in eng.dp_skip)) if use_dist else 0),
                       dp_exchange=dp_exchange)
@@ -664,6 +721,9 @@ def main():
             # the other half of BASELINE.json's metric in the same line: particles/s of posterior_results through the API
             # (configs[3] on one GPU; `--workload is` is the full record incl. the control-flow program)
             out['is'] = api_posterior_bench(lib, device, args.lstm_dim, 1000000, 20, 3, 'gum')[0]
+            # ... and a program with stochastic control flow in lock step (BASELINE.json configs[2]'s model): statements after
+            # the first one run per particle - the N-row statement kernel, with its own MFMA roofline
+            out['gumm_lockstep'] = api_posterior_bench(lib, device, args.lstm_dim, 200000, 5, 2, 'gumm', prof_class=5)[0]
     elif args.workload == 'train_gumm':
         # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
         # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded
@@ -733,7 +793,7 @@ def main():
                                'Model.posterior_results on the user program, LSTM hidden=%d, %d particles per call per GPU'
                                % (args.lstm_dim, n), parallelism='particles sharded x%d' % world, **rec)
         if world == 1:      # the N-row network step: a program with stochastic control flow in lock step
-            g, _, _ = api_posterior_bench(lib, device, args.lstm_dim, 200000, max(3, K // 10), 2, 'gumm')
+            g, _, _ = api_posterior_bench(lib, device, args.lstm_dim, 200000, max(3, K // 10), 2, 'gumm', prof_class=5)
             out['gumm_lockstep'] = g
 
     # max over ranks

@@ -715,6 +715,15 @@ bool panel_t1_supported(int kind, int H, int hid, int n_out, int e) {
     if (!env || deterministic_mode()) return false;
     if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE && kind != PP_HEAD_POISSON_TN_MIXTURE) return false;
     if (H != 512) return false;      // (H = 1024: the LDS images do not fit; the tile kernels take it)
+    // the pair hand-off spins on its partner workgroup (b, b + 8): both must become resident together. One 160 KB workgroup
+    // per CU and in-order dispatch give that on a device with more than 16 free CUs; a CU-masked or partitioned device with
+    // fewer takes the tile kernels instead of risking the bounded spin's trap
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+    }();
+    if (cus < 32) return false;
     if (n_out % 3 != 0 || n_out < 3 || n_out > 48) return false;
     if (hid < 16 || hid > 576) return false;
     if (e < 16 || e > 64 || e % 16 != 0) return false;

@@ -226,7 +226,8 @@ class Empirical:
     def __getattr__(self, name):
         if name in ('_lw', '_w', '_uniform', '_cum') and '_log_weights' in self.__dict__ and self.__dict__.get('_finalized'):
             self.finalize()          # host-side weights of a device-backed Empirical, on first use
-            return self.__dict__[name]
+            if name in self.__dict__:
+                return self.__dict__[name]
         raise AttributeError(name)
 
     def _host_weights_ready(self):
@@ -416,7 +417,10 @@ class Empirical:
 
     def _device_moments(self):
         st = self.__dict__.get('device_stats')
-        return st if (st is not None and not self._host_weights_ready() and torch.is_tensor(self._values)) else None
+        # ONE source of truth per object: while the values live on the device the float64 device statistics answer mean /
+        # variance / ESS - also after something (weights_numpy, sampling, slicing) materialised the host-side weights, so the
+        # same property returns the same number whatever was called before
+        return st if (st is not None and torch.is_tensor(self._values)) else None
 
     @property
     def mean(self):

@@ -102,9 +102,10 @@ class Model:
             state._lock_step = None
             state._current_trace = None
         all_values, all_lw = values, ls.lw
-        sv = getattr(ls, 'stats_values', None)
-        same = (ls.final_stats is not None and sv is not None and values is not None and sv.data_ptr() == values.data_ptr() and
-                sv.numel() == values.numel())
+        # the fused pass's statistics count only when they were reduced over the tensor that is returned (a draw still
+        # pending at the last flush reduces over ITS values: forward() may return something else)
+        same = (ls.final_stats is not None and values is not None and
+                getattr(ls, 'final_stats_of', None) == (values.data_ptr(), values.numel()))
         stats = ls.final_stats if same else runner.stats(all_lw, values)
         lw = all_lw
         if int(stats['count']) != num_traces:      # non-finite log-weights are discarded like Model._traces does (model.py:64-66)

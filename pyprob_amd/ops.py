@@ -319,6 +319,11 @@ def _is_fused_hip(workspace, net, addr_id, prior, kinds, p0, p0_strides, p1, p1_
     fl = (C.c_int32 * max(count, 1))()
     for q in range(count):
         _same_device(value, p0[q], p1[q], x[q])
+        for t, what in ((p0[q], 'p0'), (p1[q], 'p1'), (x[q], 'x')):
+            # a term tensor is one shared value or one value per particle (Categorical: one probability row or n rows); a
+            # k-element tensor with k != n (a vector-valued observation) would be read at the particle index
+            if t is not None and int(kinds[q]) != 5 and t.numel() not in (1, n):
+                raise RuntimeError('pyprob_hip::is_fused: term %d: %s has %d elements (1 or n = %d)' % (q, what, t.numel(), n))
         arr[q].kind = int(kinds[q])
         arr[q].p0, arr[q].p1, arr[q].x = L.ptr(p0[q]), L.ptr(p1[q]), L.ptr(x[q])
         arr[q].p0_stride, arr[q].p1_stride = int(p0_strides[q]), int(p1_strides[q])

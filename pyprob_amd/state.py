@@ -326,6 +326,7 @@ class LockStepState(PathExecutor):
             self._lw_valid = True
         if want_stats:
             self.final_stats = out
+            self.final_stats_of = (stats_x.data_ptr(), stats_x.numel())     # what the statistics were reduced over
         return out
 
 
@@ -574,6 +575,11 @@ def _lock_step_likelihood(distribution, value):
         v = ls.runner._const(float(value))       # cached device scalar (no host-to-device copy per statement)
     else:
         v = torch.as_tensor(value, dtype=torch.float32).as_subclass(torch.Tensor).reshape(-1).to(ls.runner.dev)
+    if v.numel() not in (1, ls.width):
+        # a vector-valued observation (k != n values): the device terms read one value per particle - refuse instead of
+        # scoring element i against particle i (the coroutine executor, lock_step=False, sums vector observes on the host)
+        raise RuntimeError('lock-step importance sampling scores one observed value per particle (or one shared value); '
+                           'got {} values for {} particles - run this program with lock_step=False'.format(v.numel(), ls.width))
     ls.observes += 1
     if ls.observes <= ls.replay_observes:
         return

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import rel_err
+from helpers import grad_check, rel_err
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
@@ -23,7 +23,8 @@ from pyprob_amd.engine import ICEngine
 from pyprob_amd.packed import PackedBatch
 from pyprob_amd.spec import NetSpec
 out = {}
-for name, B, dist in (('gum1024', 1024, 'Normal'), ('gum1003', 1003, 'Normal'), ('uni777', 777, 'Uniform'), ('nan64', 64, 'Normal')):
+for name, B, dist in (('gum1024', 1024, 'Normal'), ('gum1003', 1003, 'Normal'), ('uni777', 777, 'Uniform'), ('nan64', 64, 'Normal'),
+                      ('gum2048', 2048, 'Normal'), ('gum2041', 2041, 'Normal'), ('gum4096', 4096, 'Normal')):
     spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
     spec.add_address('mu', dist)
     arr = synthetic_gum_arrays(B, seed=3 + B)
@@ -73,6 +74,29 @@ for it in range(48):        # and a run of training steps (Adam amplifies last-b
     losses.append(l.clone())
 torch.cuda.synchronize()
 out['run_losses'] = torch.cat(losses).cpu().numpy()
+# the same step while ANOTHER stream keeps compute units busy (small and large kernels in a loop): the pair hand-off of the
+# panel launch relies on both workgroups of a pair becoming resident; results must not depend on the neighbour
+arr = synthetic_gum_arrays(2048, seed=901)
+pbq = PackedBatch.from_ragged(arr['trace_len'], arr['addr_idx'], arr['values'], arr['prior'], arr['obs'], 1).to(eng.device)
+quiet = eng.loss(pbq, backward=True).clone()
+gq = eng.grads.clone()
+torch.cuda.synchronize()
+side = torch.cuda.Stream()
+A = torch.randn(2048, 2048, device='cuda:0')
+v = torch.randn(1 << 20, device='cuda:0')
+busy_l, busy_g = [], []
+for rep in range(8):
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            A2 = A @ A
+            v = v * 1.0001 + 0.5
+    l = eng.loss(pbq, backward=True)
+    busy_l.append(l.clone()); busy_g.append((eng.grads - gq).abs().max().reshape(1))
+torch.cuda.synchronize()
+out['busy_quiet_loss'] = quiet.cpu().numpy()
+out['busy_losses'] = torch.cat(busy_l).cpu().numpy()
+out['busy_gdiff'] = torch.cat(busy_g).cpu().numpy()
+out['busy_gmax'] = gq.abs().max().reshape(1).cpu().numpy()
 np.savez(sys.argv[1], **out)
 '''
 
@@ -94,8 +118,12 @@ def test_panel_kernel_equals_the_tile_path(tmp_path):
     for k in range(6, 60):      # visit k of a minibatch against its first visit (it * 5 % 6 has period 6)
         assert abs(panel['rep_losses'][k] - panel['rep_losses'][k % 6]) <= 2e-6 * abs(panel['rep_losses'][k % 6]), k
         assert abs(panel['rep_gsums'][k] - panel['rep_gsums'][k % 6]) <= 2e-5 * abs(panel['rep_gsums'][k % 6]), k
+    # two generations of polling pairs (B = 2048: 512 workgroups on 256 CUs), and next to a busy stream
+    for run in (panel, tiles):
+        np.testing.assert_allclose(run['busy_losses'], np.repeat(run['busy_quiet_loss'], 8), rtol=2e-6)
+        assert (run['busy_gdiff'] <= 3e-5 * run['busy_gmax'][0]).all(), run['busy_gdiff']
     for k in sorted(panel):
-        if k.startswith('run_') or k.startswith('rep_'):
+        if k.startswith('run_') or k.startswith('rep_') or k.startswith('busy_'):
             continue
         a, b = panel[k], tiles[k]
         if k.startswith('nan64'):
@@ -139,5 +167,5 @@ def test_panel_kernel_against_the_oracle():
     assert abs(float(loss.item()) - ref['loss']) <= 2e-5 * abs(ref['loss'])
     g = eng.grad_dict()
     for n in spec.tensors:
-        err = np.abs(g[n] - ref['grads'][n]).max() / max(np.abs(ref['grads'][n]).max(), 1e-6)
-        assert err < 2e-3, (n, err)
+        if np.abs(ref['grads'][n]).max() > 1e-7:
+            grad_check('panel_h512_b250/%s' % n, g[n], ref['grads'][n], 1e-4)

@@ -6,11 +6,14 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from helpers import (engine_from_golden, packed_from_golden, rel_err, synthetic_gum_arrays,
+from helpers import (engine_from_golden, grad_check, packed_from_golden, rel_err, synthetic_gum_arrays,
                      synthetic_gumm_arrays)
 from oracle import ic_oracle as O
 
 pytestmark = pytest.mark.gpu
+# gradient bars against the float64 oracle: <= 10x the largest error measured on MI355X (profiles/r04_grad_errors.jsonl)
+GRAD_BAR = 1e-4
+GRAD_BAR_RAGGED = 1e-4
 torch = pytest.importorskip('torch')
 
 
@@ -93,7 +96,8 @@ def test_benchmark_size_gum_against_oracle(H):
     np.testing.assert_allclose(lp_tm, out['lp'][0], rtol=1e-4, atol=1e-4)
     g = eng.grad_dict()
     for n in eng.spec.tensors:
-        assert rel_err(g[n], out['grads'][n]) < 2e-3 or np.abs(out['grads'][n]).max() < 1e-7, n
+        if np.abs(out['grads'][n]).max() >= 1e-7:
+            grad_check('gum_h%d_b1024/%s' % (H, n), g[n], out['grads'][n], GRAD_BAR)
 
 
 @pytest.mark.parametrize('B', [300, 1024])
@@ -111,7 +115,8 @@ def test_hidden_1024_against_oracle(B):
     assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
     g = eng.grad_dict()
     for n in eng.spec.tensors:
-        assert rel_err(g[n], out['grads'][n]) < 2e-3 or np.abs(out['grads'][n]).max() < 1e-7, n
+        if np.abs(out['grads'][n]).max() >= 1e-7:
+            grad_check('gum_h1024_b%d/%s' % (B, n), g[n], out['grads'][n], GRAD_BAR)
 
 
 def test_benchmark_size_gumm_ragged_against_oracle():
@@ -125,12 +130,9 @@ def test_benchmark_size_gumm_ragged_against_oracle():
     out = _oracle_run(eng.spec, params, arrays, addresses, ['Uniform'] * len(addresses))
     assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
     g = eng.grad_dict()
-    bad = []
     for n in eng.spec.tensors:
-        scale = np.abs(out['grads'][n]).max()
-        if scale > 1e-7 and rel_err(g[n], out['grads'][n]) > 3e-3:
-            bad.append((n, rel_err(g[n], out['grads'][n])))
-    assert not bad, bad[:5]
+        if np.abs(out['grads'][n]).max() > 1e-7:
+            grad_check('gumm_ragged_h512_b1024/%s' % n, g[n], out['grads'][n], GRAD_BAR_RAGGED)
 
 
 def test_feedforward_network_benchmark_size_against_oracle():
@@ -155,12 +157,9 @@ def test_feedforward_network_benchmark_size_against_oracle():
     assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
     assert abs(float(fwd.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
     g = eng.grad_dict()
-    bad = []
     for n in eng.spec.tensors:
-        scale = np.abs(out['grads'][n]).max()
-        if scale > 1e-7 and rel_err(g[n], out['grads'][n]) > 3e-3:
-            bad.append((n, rel_err(g[n], out['grads'][n])))
-    assert not bad, bad[:5]
+        if np.abs(out['grads'][n]).max() > 1e-7:
+            grad_check('ff_ragged_b1024/%s' % n, g[n], out['grads'][n], GRAD_BAR_RAGGED)
     # a few Adam steps reduce the loss
     first = float(l.item())
     for _ in range(30):

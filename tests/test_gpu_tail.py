@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import rel_err
+from helpers import grad_check, rel_err
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
@@ -107,9 +107,6 @@ def test_tail_path_against_the_oracle():
     out = O.loss_and_grads(net, arrays, addresses, ['Uniform'] * len(addresses))
     assert abs(float(l.item()) - out['loss']) <= 2e-5 * abs(out['loss'])
     g = eng.grad_dict()
-    bad = []
     for n in spec.tensors:
-        scale = np.abs(out['grads'][n]).max()
-        if scale > 1e-7 and rel_err(g[n], out['grads'][n]) > 3e-3:
-            bad.append((n, rel_err(g[n], out['grads'][n])))
-    assert not bad, bad[:5]
+        if np.abs(out['grads'][n]).max() > 1e-7:
+            grad_check('tail_ragged/%s' % n, g[n], out['grads'][n], 1e-4)

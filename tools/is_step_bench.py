@@ -30,7 +30,7 @@ for n in ns:
     run._ensure_ws(n)
     flops_alg = n * (2.0 * (spec.lstm_in + H) * 4 * H + 2.0 * (H * ad.hid + ad.hid * ad.n_out))
     flops_exe = n * (2.0 * (8 + H) * 4 * H + 2.0 * (H * 288 + 272 * 32))                                 # what the fused kernel multiplies
-    for mode in ('fused', 'fused_rows', 'chain'):
+    for mode in os.environ.get('MODES', 'fused,fused_rows,chain').split(','):
         os.environ['PP_IS_STEP_FUSED'] = '0' if mode == 'chain' else '1'
         def call():
             if mode == 'fused_rows':

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/r03_kernel_avgs.json + profiles/r03_pmc_traffic.json (what bench.py quotes next to its live HIP-event timings) from
+"""profiles/r04_kernel_avgs.json + profiles/r04_pmc_traffic.json (each stamped with `csrc_sha`, the hash of the kernel sources they
+were measured on: bench.py quotes them only when it matches the running tree) (what bench.py quotes next to its live HIP-event timings) from
 the per-kernel summaries of one `rocprofv3 --kernel-trace --stats` run and the two PMC passes (FETCH_SIZE, WRITE_SIZE) of
 `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-is`:
     python tools/profile_json.py <tag> <kernel_stats.csv> <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv>
@@ -31,6 +32,9 @@ def key_of(name):
 
 def main(tag, stats_csv, fetch_csv, write_csv):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    from bench import csrc_sha
+    sha = csrc_sha()
     avgs, kern = {}, {}
     for r in csv.DictReader(open(stats_csv)):
         k = key_of(r['kernel'])
@@ -39,7 +43,8 @@ def main(tag, stats_csv, fetch_csv, write_csv):
             kern[k] = '%s grid (%s,%s,%s)' % (r['kernel'].replace('(anonymous namespace)::', '').split('(')[0].replace('void pp::', ''),
                                               r['workgroups_x'], r['workgroups_y'], r['workgroups_z'])
     avgs['source'] = '%s (rocprofv3 --kernel-trace --stats of python bench.py)' % os.path.basename(stats_csv)
-    json.dump(avgs, open(os.path.join(repo, 'profiles', 'r03_kernel_avgs.json'), 'w'), indent=1)
+    avgs['csrc_sha'] = sha
+    json.dump(avgs, open(os.path.join(repo, 'profiles', 'r04_kernel_avgs.json'), 'w'), indent=1)
     pm = {}
     for path, col in ((fetch_csv, 'FETCH_SIZE_KB_raw'), (write_csv, 'WRITE_SIZE_KB')):
         for r in csv.DictReader(open(path)):
@@ -56,12 +61,12 @@ def main(tag, stats_csv, fetch_csv, write_csv):
         if k in ALG:
             d['algorithmic_bytes'] = ALG[k][0]
         out[k] = d
-    doc = dict(source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh %s) of '
+    doc = dict(csrc_sha=sha, source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh %s) of '
                       '`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-is`; per-kernel averages in %s, %s'
                       % (tag, os.path.basename(fetch_csv), os.path.basename(write_csv)),
                gfx950_fetch_correction='FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section): '
                                        'doubled; counter unit KB = 1024 bytes', kernels=out)
-    json.dump(doc, open(os.path.join(repo, 'profiles', 'r03_pmc_traffic.json'), 'w'), indent=1)
+    json.dump(doc, open(os.path.join(repo, 'profiles', 'r04_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps(avgs), '\n', json.dumps({k: v['traffic_bytes_per_launch'] for k, v in out.items()}))
 
 

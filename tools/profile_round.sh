@@ -1,9 +1,9 @@
 # One GPU call's worth of evidence for the training step: bash tools/profile_round.sh <tag>
 #   gpurun_out/<tag>_train_kernel_stats.csv, _step_sequence.csv   rocprofv3 --kernel-trace --stats of bench.py
 #   gpurun_out/<tag>_train_pmc_{FETCH,WRITE}_SIZE.csv             separate --pmc passes
-#   gpurun_out/<tag>_r03_kernel_avgs.json, _r03_pmc_traffic.json  what bench.py quotes (copy to profiles/r03_*.json)
+#   gpurun_out/<tag>_r04_kernel_avgs.json, _r04_pmc_traffic.json  what bench.py quotes (written to profiles/r04_*.json, stamped with the hash of csrc/)
 #   gpurun_out/<tag>_bench_20_5.json, _bench_default.json         the driver's command and the default command
-TAG=${1:-r03x}
+TAG=${1:-r04x}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fp_ks
@@ -23,7 +23,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $REPO
 python tools/profile_json.py $TAG $OUT/${TAG}_train_kernel_stats.csv $OUT/${TAG}_train_pmc_FETCH_SIZE.csv $OUT/${TAG}_train_pmc_WRITE_SIZE.csv
-cp profiles/r03_kernel_avgs.json $OUT/${TAG}_r03_kernel_avgs.json; cp profiles/r03_pmc_traffic.json $OUT/${TAG}_r03_pmc_traffic.json
+cp profiles/r04_kernel_avgs.json $OUT/${TAG}_r04_kernel_avgs.json; cp profiles/r04_pmc_traffic.json $OUT/${TAG}_r04_pmc_traffic.json
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20_5.json 2> $OUT/${TAG}_bench_20_5.err
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 tail -c 600 $OUT/${TAG}_bench_20_5.json; echo; python -c "
