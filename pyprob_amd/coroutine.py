@@ -428,6 +428,7 @@ def _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args,
 def _worker_main(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs):
     """A worker forked for ONE posterior call."""
     import os
+    _child_hardening()
     try:
         torch.set_num_threads(1)
         _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs)
@@ -488,8 +489,18 @@ def _runtime_install(state, forward, snapshot):
 # description, arguments) and the worker goes back to waiting afterwards. The workers hold the PROGRAM as it was when the
 # pool was forked (the network lives in the parent): `close_worker_pools()` after changing the model object, PP_IS_POOL=0
 # to fork per call as before.
+def _child_hardening():
+    """First thing in a forked particle worker: no garbage collection in the child. The parent's heap holds device tensors
+    (also in garbage cycles waiting for a collection); a collection in the child would run their destructors - HIP calls
+    in a forked process, which the ROCm runtime does not survive (a worker that dies without a message: EOFError in the
+    parent). The worker's own garbage is bounded by its job."""
+    import gc
+    gc.disable()
+
+
 def _pool_worker_main(conn, worker, state, forward, inherited):
     import os
+    _child_hardening()
     try:
         for c in inherited:      # pipe ends of the workers forked before this one
             try:
@@ -525,13 +536,19 @@ class _WorkerPool:
         except TypeError:
             self.model_ref = None
         self.conns, self.procs = [], []
-        for w in range(workers):
-            parent, child = ctx.Pipe()
-            pr = ctx.Process(target=_pool_worker_main, args=(child, w, state, forward, list(self.conns)), daemon=True)
-            pr.start()
-            child.close()
-            self.conns.append(parent)
-            self.procs.append(pr)
+        import gc
+        gc.collect()          # device tensors in garbage cycles are freed HERE, by the process that owns the device ...
+        gc.freeze()           # ... and what is alive now is never examined by a collector in a child
+        try:
+            for w in range(workers):
+                parent, child = ctx.Pipe()
+                pr = ctx.Process(target=_pool_worker_main, args=(child, w, state, forward, list(self.conns)), daemon=True)
+                pr.start()
+                child.close()
+                self.conns.append(parent)
+                self.procs.append(pr)
+        finally:
+            gc.unfreeze()
 
     def healthy(self):
         return all(pr.is_alive() for pr in self.procs)
@@ -632,14 +649,20 @@ class ShardedCoroutineIS:
                 conns[w].send((lo, lo + cnt, self.spec, self.seed, blob))
                 bounds.append((lo, lo + cnt))
         else:
-            for w in range(self.workers):
-                lo, cnt = shard_range(self.n, w, self.workers)
-                parent, child = ctx.Pipe()
-                pr = ctx.Process(target=_worker_main, args=(child, w, lo, lo + cnt, self.state, self.forward, self.spec,
-                                                            self.map_func, self.seed, args, kwargs), daemon=True)
-                pr.start()
-                child.close()
-                conns.append(parent); procs.append(pr); bounds.append((lo, lo + cnt))
+            import gc
+            gc.collect()
+            gc.freeze()           # (see _WorkerPool.__init__)
+            try:
+                for w in range(self.workers):
+                    lo, cnt = shard_range(self.n, w, self.workers)
+                    parent, child = ctx.Pipe()
+                    pr = ctx.Process(target=_worker_main, args=(child, w, lo, lo + cnt, self.state, self.forward, self.spec,
+                                                                self.map_func, self.seed, args, kwargs), daemon=True)
+                    pr.start()
+                    child.close()
+                    conns.append(parent); procs.append(pr); bounds.append((lo, lo + cnt))
+            finally:
+                gc.unfreeze()
         live = set(range(self.workers))
         results = [None] * self.workers
         stats = [0, 0, 0]

@@ -65,20 +65,26 @@ def rel_err(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
 
 
-def grad_check(label, got, ref, bar):
-    """Gradient tensor against the float64 oracle: max |got - ref| / max |ref| < bar. The bars of the callers are <= 10x the
-    error MEASURED on MI355X (profiles/r04_grad_errors.jsonl, recorded with PP_TEST_RECORD_ERRORS=<file>: every check appends
-    its error there), not a generic tolerance: a dropped small contribution shows up."""
+def grad_check(label, got, ref, bar, abs_floor=0.0):
+    """Gradient tensor against the float64 oracle: max |got - ref| < bar * max |ref| + abs_floor. The bars of the callers are
+    <= 10x the error MEASURED on MI355X (profiles/r04_grad_errors.jsonl, recorded with PP_TEST_RECORD_ERRORS=<file>: every
+    check appends its error there), not a generic tolerance: a dropped small contribution shows up. abs_floor: the ragged
+    cases run on freshly initialised networks whose gradients are ~1e-6 - their fp32 summation error (measured 5e-9, the
+    same absolute size as in the cases with gradients of 1e-2) is not small RELATIVE to such a tensor."""
     import json
     import os
-    err = rel_err(got, ref)
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    abs_err = float(np.abs(got - ref).max())
+    ref_max = float(np.abs(ref).max())
     path = os.environ.get('PP_TEST_RECORD_ERRORS')
     if path:
         with open(path, 'a') as f:
-            f.write(json.dumps(dict(check=label, err=err, bar=bar, ref_max=float(np.abs(np.asarray(ref)).max()))) + '\n')
-        return err
-    assert err < bar, (label, err, bar)
-    return err
+            f.write(json.dumps(dict(check=label, err=abs_err / max(ref_max, 1e-30), abs_err=abs_err, bar=bar, abs_floor=abs_floor,
+                                    ref_max=ref_max)) + '\n')
+        return abs_err
+    assert abs_err < bar * ref_max + abs_floor, (label, abs_err, ref_max, bar, abs_floor)
+    return abs_err
 
 
 def synthetic_gum_arrays(n, seed=0):

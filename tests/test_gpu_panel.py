@@ -168,4 +168,4 @@ def test_panel_kernel_against_the_oracle():
     g = eng.grad_dict()
     for n in spec.tensors:
         if np.abs(ref['grads'][n]).max() > 1e-7:
-            grad_check('panel_h512_b250/%s' % n, g[n], ref['grads'][n], 1e-4)
+            grad_check('panel_h512_b250/%s' % n, g[n], ref['grads'][n], 5e-6)      # measured 4.6e-7

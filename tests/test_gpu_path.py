@@ -11,9 +11,10 @@ from helpers import (engine_from_golden, grad_check, packed_from_golden, rel_err
 from oracle import ic_oracle as O
 
 pytestmark = pytest.mark.gpu
-# gradient bars against the float64 oracle: <= 10x the largest error measured on MI355X (profiles/r04_grad_errors.jsonl)
-GRAD_BAR = 1e-4
-GRAD_BAR_RAGGED = 1e-4
+# gradient bars against the float64 oracle: <= 10x the largest error measured on MI355X (profiles/r04_grad_errors.jsonl:
+# 8.6e-7 relative on the single-statement shapes; 5.0e-9 ABSOLUTE on the ragged ones, whose gradients are ~1e-6)
+GRAD_BAR = 1e-5
+GRAD_ABS_RAGGED = 5e-8
 torch = pytest.importorskip('torch')
 
 
@@ -132,7 +133,7 @@ def test_benchmark_size_gumm_ragged_against_oracle():
     g = eng.grad_dict()
     for n in eng.spec.tensors:
         if np.abs(out['grads'][n]).max() > 1e-7:
-            grad_check('gumm_ragged_h512_b1024/%s' % n, g[n], out['grads'][n], GRAD_BAR_RAGGED)
+            grad_check('gumm_ragged_h512_b1024/%s' % n, g[n], out['grads'][n], GRAD_BAR, GRAD_ABS_RAGGED)
 
 
 def test_feedforward_network_benchmark_size_against_oracle():
@@ -159,7 +160,7 @@ def test_feedforward_network_benchmark_size_against_oracle():
     g = eng.grad_dict()
     for n in eng.spec.tensors:
         if np.abs(out['grads'][n]).max() > 1e-7:
-            grad_check('ff_ragged_b1024/%s' % n, g[n], out['grads'][n], GRAD_BAR_RAGGED)
+            grad_check('ff_ragged_b1024/%s' % n, g[n], out['grads'][n], GRAD_BAR, GRAD_ABS_RAGGED)
     # a few Adam steps reduce the loss
     first = float(l.item())
     for _ in range(30):

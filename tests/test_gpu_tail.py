@@ -109,4 +109,4 @@ def test_tail_path_against_the_oracle():
     g = eng.grad_dict()
     for n in spec.tensors:
         if np.abs(out['grads'][n]).max() > 1e-7:
-            grad_check('tail_ragged/%s' % n, g[n], out['grads'][n], 1e-4)
+            grad_check('tail_ragged/%s' % n, g[n], out['grads'][n], 1e-5, 5e-8)      # measured 5.0e-9 absolute
