@@ -452,10 +452,6 @@ def main():
                 dp_exchange = 'pp_dp_reduce_grads (ncclAllReduce from the C side, grouped pieces)'
 
         eng.broadcast_params()
-        if args.workload == 'train':
-            # every GaussianUnknownMean trace has ONE controlled variable: dL/dW_hh is zero on every rank, its range (2/3 to
-            # 3/4 of the flat gradient) stays out of the all-reduce (ICEngine.skip_recurrent_weights, bit-identical result)
-            eng.skip_recurrent_weights(os.environ.get('PP_DP_SKIP_WHH', '1') != '0')
     out = {}
     K, W = args.steps, args.warmup
 
@@ -480,6 +476,12 @@ def main():
             # timed region samples the WHOLE 1 M-trace dataset (each step a region of HBM it has not read recently), not its
             # first K + W minibatches
             batches = [ds.batch(i, 0, 1, cache) for i in range(ds.n_batches)]
+            if use_dist:
+                # dL/dW_hh is zero on a rank whose traces all have ONE controlled variable; when that holds on EVERY rank (each
+                # reads it off its own resident minibatches, a MIN-all-reduce of the flag decides) the range - 2/3 of the flat
+                # gradient at H = 512 - stays out of the all-reduce: bit-identical result (ICEngine.agree_skip_recurrent)
+                single = all(b.t_max == 1 for b in batches) and os.environ.get('PP_DP_SKIP_WHH', '1') != '0'
+                out['dp_skip_recurrent'] = eng.agree_skip_recurrent(single)
             walk = next(q for q in range(max(1, ds.n_batches // max(K, 1)), ds.n_batches + 2) if np.gcd(q, ds.n_batches) == 1)
 
             def pick(i):

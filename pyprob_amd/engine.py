@@ -487,6 +487,23 @@ class ICEngine:
             n = int(np.prod(shape))
             self.dp_skip = [(off, ((n + 1023) // 1024) * 1024)]
 
+    def agree_skip_recurrent(self, single_statement):
+        """COLLECTIVE (every rank calls it): leave W_hh out of the gradient all-reduce iff the data of EVERY rank has one
+        controlled variable per trace. `single_statement` is this rank's own finding, read from its data (the trace lengths
+        of its dataset shard / its resident minibatches) - not a caller's assertion about the other ranks; one MIN-all-reduce
+        of a flag settles it, so all ranks issue all-reduces of the same layout. A per-step decision on the device is not
+        possible without a host round trip per step: the piece list of an RCCL call is a host-side argument."""
+        flag = 1 if single_statement else 0
+        if self.world_size > 1:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                dev = self.device if dist.get_backend() == 'nccl' else 'cpu'
+                t = torch.tensor([flag], dtype=torch.int32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                flag = int(t.item())
+        self.skip_recurrent_weights(bool(flag))
+        return bool(flag)
+
     def broadcast_params(self):
         """_distributed_sync_parameters (inference_network.py:290-294) as one broadcast of the flat buffer."""
         import torch.distributed as dist

@@ -297,6 +297,41 @@ def test_recurrent_weight_range_can_be_left_out_of_the_allreduce(tmp_path):
         assert d['same_params'] and d['same_steps'] and d['segments'] == 1
 
 
+def _agree_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle_ops
+    from helpers import packed_from_golden
+    res = {}
+    # (a) both ranks hold single-statement traces (GUM): every rank finds t_max == 1 in ITS data -> the range is skipped;
+    # (b) rank 1 holds GUMM traces (several statements): its finding vetoes the skip on BOTH ranks
+    for tag, cases in (('both_single', ('gum', 'gum')), ('one_ragged', ('gum', 'gumm'))):
+        meta, params, batch, loss, isr = load_golden(cases[rank])
+        spec = spec_from_golden(meta, params)
+        eng = oracle_ops.CpuBufferEngine(spec)
+        eng.world_size = world
+        pb = packed_from_golden(meta, batch, spec).to('cpu')
+        res[tag] = (eng.agree_skip_recurrent(pb.t_max == 1), len(eng.dp_skip), int(pb.t_max))
+    torch.save(res, out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_recurrent_skip_from_their_own_data(tmp_path):
+    """ICEngine.agree_skip_recurrent: the W_hh range leaves the all-reduce only when EVERY rank found single-statement traces
+    in its own data (a MIN-all-reduce of the per-rank finding) - no caller assertion about the other ranks' data."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / 'agree.pt')
+    mp.spawn(_agree_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = (torch.load(out + '.%d' % r) for r in range(world))
+    assert r0['both_single'][:2] == r1['both_single'][:2] == (True, 1)
+    assert r0['one_ragged'][2] == 1 and r1['one_ragged'][2] > 1
+    assert r0['one_ragged'][:2] == r1['one_ragged'][:2] == (False, 0)
+
+
 def _larc_worker(rank, world, port, out):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
