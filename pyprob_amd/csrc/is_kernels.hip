@@ -243,6 +243,17 @@ static void is_carve(const pp_net* net, int n, void* p, IsWorkspace& w) {
     w.bytes = off + 256;
 }
 
+// PP_IS_STEP_FUSED: 0 never, 1 (default) where it is the faster path, 2 always where supported
+static int is_step_fused_mode() {
+    const char* e = getenv("PP_IS_STEP_FUSED");
+    return e ? atoi(e) : 1;
+}
+constexpr int FUSED_MIN_ROWS = 3072;
+static bool is_step_fused_preferred(const pp_net* net, int addr_id, int n) {
+    (void)net; (void)addr_id;
+    return is_step_fused_mode() == 2 || n >= FUSED_MIN_ROWS;
+}
+
 static int lin(const float* x, int64_t ldx, const float* W, const float* b, const float* b2, float* y, int64_t ldy, int n,
                int in, int out, bool relu, bool accumulate, hipStream_t st) {
     pp_gemm_args g;
@@ -323,10 +334,13 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     }
     // A statement after the first one on a one-layer LSTM of a supported width: ONE kernel (is_step_fused.hip) - gates,
     // cell, both head layers and the draw; (h, c) are read and written once, in place, optionally through a row index list.
-    // (PP_IS_STEP_FUSED=0, read per call: the unfused chain below, the A/B of tests/test_gpu_is_step_fused.py)
-    const bool fused_on = !(getenv("PP_IS_STEP_FUSED") && atoi(getenv("PP_IS_STEP_FUSED")) == 0);
+    // A launch of fewer than FUSED_MIN_ROWS particles is a single generation of latency-bound workgroups (each streams all
+    // 4.7 MB of weights behind a two-slab ring: 0.23 ms whatever n, profiles/r04d_is_step_small_n.jsonl) - there the chain of
+    // small GEMM launches below is faster (0.05 ms at 64 rows, 0.14 ms at 2 048) and takes the statement.
+    // (PP_IS_STEP_FUSED, read per call: 0 = always the chain, 2 = the fused kernel at any n - the A/B and the small-panel
+    // parity cases of tests/test_gpu_is_step_fused.py)
     bool head_done = false;
-    if (!shared && fused_on && is_step_fused_supported(net, addr_id)) {
+    if (!shared && (rows || is_step_fused_preferred(net, addr_id, n)) && is_step_fused_supported(net, addr_id) && is_step_fused_mode() != 0) {
         bool sampled = false;
         PP_TRY(is_step_fused(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows, rows,
                              value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st));
@@ -840,9 +854,8 @@ int pp_is_step_rows(const pp_net* net, const float* params, int32_t addr_id, int
                        rows);
 }
 
-int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id) {
-    const bool on = !(getenv("PP_IS_STEP_FUSED") && atoi(getenv("PP_IS_STEP_FUSED")) == 0);
-    return (on && pp::is_step_fused_supported(net, addr_id)) ? 1 : 0;
+int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id, int32_t n) {
+    return (pp::is_step_fused_mode() != 0 && pp::is_step_fused_supported(net, addr_id) && pp::is_step_fused_preferred(net, addr_id, n)) ? 1 : 0;
 }
 
 int pp_prior_draw(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride, int32_t n, uint64_t seed,

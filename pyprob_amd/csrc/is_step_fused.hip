@@ -32,6 +32,8 @@
 
 namespace pp {
 
+extern long long* g_timeline;   // kernels.hip (pp_debug_timeline)
+
 namespace {
 
 constexpr int FR = 32;   // particles per workgroup
@@ -157,6 +159,7 @@ struct FusedArgs {
     const float* value_in; float* value_out; float* logq_out;
     uint64_t seed, offset;
     int K, n;
+    long long* dbg;             // debug: s_memtime stamps [2 workgroups][2 waves][16] (pp_debug_timeline) or nullptr
 };
 
 extern __shared__ __attribute__((aligned(1024))) float fused_lds[];
@@ -178,6 +181,13 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c31 = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * FR;
+    const int dbg_slot = a.dbg ? (blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1)) : -1;
+#define FUSED_STAMP(k)                                                                          \
+    do {                                                                                        \
+        if (dbg_slot >= 0 && lane == 0 && (wave == 0 || wave == 5))                             \
+            a.dbg[(dbg_slot * 2 + (wave == 5 ? 1 : 0)) * 16 + (k)] = clock64();                 \
+    } while (0)
+    FUSED_STAMP(0);
     if (tid < FR) {
         const int gr = min(m0 + tid, a.n - 1);
         sRow[tid] = a.rows ? (int)a.rows[gr] : gr;
@@ -255,7 +265,9 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
     }
+    FUSED_STAMP(1);    // K loop done
     __syncthreads();   // every wave has read the old h rows of the panel (and sRow is visible)
+    FUSED_STAMP(2);
 
     // ---- LSTM cell on the accumulators (torch.nn.LSTM gate order i, f, g, o) ----
     // (all loads of the old cell state first: the stores below go through the same pointer and would pin every load behind
@@ -292,7 +304,9 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
             sH[hslot + row * 4] = hn;
         }
     }
+    FUSED_STAMP(3);    // cell done
     __syncthreads();
+    FUSED_STAMP(4);
 
     // ---- head layer 1: a1 = relu(h W1^T + b1); wave w takes the 32-column blocks w, w + 8, ... ----
     for (int cb = wave; cb < a.nb1; cb += FW) {
@@ -325,7 +339,9 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
             }
         }
     }
+    FUSED_STAMP(5);    // head layer 1 done (this wave)
     __syncthreads();
+    FUSED_STAMP(6);
 
     // ---- head layer 2: y = a1 W2^T + b2, K split over the waves, partials summed in a fixed order ----
     {
@@ -353,6 +369,7 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         sY[row * 33 + col] = y;
         if (a.y_out && m0 + row < a.n && col < a.n_out) a.y_out[(int64_t)(m0 + row) * a.ldy + col] = y;
     }
+    FUSED_STAMP(7);    // head layer 2 + combine
     if (KIND == 3) return;
     __syncthreads();
 
@@ -366,6 +383,8 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         a.value_out[i] = v;
         a.logq_out[i] = lp;
     }
+    FUSED_STAMP(8);    // draw + log q
+#undef FUSED_STAMP
 }
 
 template <int UB, int KIND>
@@ -447,6 +466,7 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     a.prior = prior; a.prior_stride = prior_stride;
     a.value_in = value_in; a.value_out = value_out; a.logq_out = logq_out;
     a.seed = seed; a.offset = offset; a.K = ad.n_out / 3; a.n = n;
+    a.dbg = g_timeline;
     int kind = 3;
     if (!net_only && ad.n_out % 3 == 0 && ad.n_out / 3 <= MAXK) {
         if (ad.kind == PP_HEAD_NORMAL_MIXTURE) kind = 0;

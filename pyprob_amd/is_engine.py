@@ -107,7 +107,7 @@ class ISRunner:
         [1, 2], or one row per particle ([n, 2]; prior_compact: one row per entry of `rows`)."""
         m = int(rows.numel())
         if (prev_addr_id is not None and self.dev.type == 'cuda' and self.eng.spec.lstm_depth == 1 and
-                self.lib.pp_is_step_fused_supported(C.byref(self.eng.net), int(addr_id))):
+                self.lib.pp_is_step_fused_supported(C.byref(self.eng.net), int(addr_id), m)):
             # the fused statement kernel reads and writes the rows' state in place through the index list
             if self.state_rows == 1 and self.n > 1:
                 self.h[:, 1:] = self.h[:, :1]

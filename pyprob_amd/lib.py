@@ -124,7 +124,7 @@ PROTOTYPES = {
                              C.c_uint64, vp, C.c_size_t, vp]),
     'pp_is_step_rows': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, C.c_uint64,
                                   C.c_uint64, vp, C.c_size_t, vp]),
-    'pp_is_step_fused_supported': (C.c_int, [C.POINTER(pp_net), i32]),
+    'pp_is_step_fused_supported': (C.c_int, [C.POINTER(pp_net), i32, i32]),
     'pp_prior_draw': (C.c_int, [i32, vp, i32, vp, i32, i32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp]),
     'pp_is_step_net': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, C.c_size_t, vp]),
     'pp_is_fused': (C.c_int, [C.POINTER(pp_net), i32, i32, vp, C.POINTER(pp_lw_term), C.POINTER(C.c_int32), i32, vp, vp, i32,

@@ -256,7 +256,7 @@ def _is_step_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_v
     if rows is not None:
         if rows.dtype != torch.int64 or not rows.is_contiguous() or rows.numel() < n or rows.device != params.device:
             raise RuntimeError('pyprob_hip::is_step_rows: rows must be a contiguous int64 device tensor with n entries')
-        if not lib.pp_is_step_fused_supported(C.byref(netc), int(addr_id)) or prev_addr_id < 0:
+        if not lib.pp_is_step_fused_supported(C.byref(netc), int(addr_id), 1 << 30) or prev_addr_id < 0:
             raise RuntimeError('pyprob_hip::is_step_rows: no fused statement kernel for this network / statement')
     elif H > 0 and (h.numel() < depth * n * H or c.numel() < depth * n * H):
         raise RuntimeError('pyprob_hip::is_step: LSTM state smaller than [depth, n, H]')

@@ -20,6 +20,13 @@ ADDRS = [('a_normal', 'Normal', None), ('a_uniform', 'Uniform', None), ('a_cat',
          ('a_bern', 'Bernoulli', None)]
 
 
+@pytest.fixture(autouse=True)
+def _force_fused(monkeypatch):
+    """pp_is_step takes the fused kernel from ~3 000 particles on (smaller launches go to the chain of small GEMMs, which is
+    faster there); the parity cases below use small panels counts on purpose: PP_IS_STEP_FUSED=2 = the fused kernel at any n."""
+    monkeypatch.setenv('PP_IS_STEP_FUSED', '2')
+
+
 def _engine(H, seed=0):
     from pyprob_amd.engine import ICEngine
     from pyprob_amd.is_engine import ISRunner
@@ -102,7 +109,7 @@ def _ids(eng, name):
 def test_fused_statement_against_the_oracle(H, n, prev, cur):
     from pyprob_amd.ops import ops
     eng, run, sd = _engine(H)
-    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0])) == 1
+    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == 1
     rng = np.random.default_rng(5)
     h0 = (0.5 * rng.standard_normal((n, H))).astype(np.float32).clip(-0.99, 0.99)
     c0 = rng.standard_normal((n, H)).astype(np.float32)
@@ -155,7 +162,7 @@ def test_fused_statement_equals_the_unfused_chain(monkeypatch):
     prior = _prior_for('Uniform', n, rng)
     dev = eng.device
     outs = []
-    for flag in ('1', '0'):
+    for flag in ('2', '0'):
         monkeypatch.setenv('PP_IS_STEP_FUSED', flag)
         h = torch.from_numpy(h0.copy()).to(dev).reshape(1, n, H).contiguous()
         c = torch.from_numpy(c0.copy()).to(dev).reshape(1, n, H).contiguous()
