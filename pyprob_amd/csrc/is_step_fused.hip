@@ -44,6 +44,37 @@ constexpr int FW = 8;    // waves per workgroup
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
+// reductions over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15): every lane ends with the result
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v));   // row_ror:8
+    v = fmaxf(v, dpp_mov<0x124>(v));   // row_ror:4
+    v = fmaxf(v, dpp_mov<0x122>(v));   // row_ror:2
+    v = fmaxf(v, dpp_mov<0x121>(v));   // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ int row16_min_int(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false));
+    return v;
+}
+// inclusive prefix sum over the 16 lanes of a row (row_shr:n; lanes without a source add zero)
+__device__ __forceinline__ float row16_prefix(float v) {
+    v += dpp_mov<0x111>(v);
+    v += dpp_mov<0x112>(v);
+    v += dpp_mov<0x114>(v);
+    v += dpp_mov<0x118>(v);
+    return v;
+}
+
 struct PrepArgs {
     const float* P;
     const int64_t* at;
@@ -54,7 +85,7 @@ struct PrepArgs {
     const float* e_obs_vec;
     const float* h0;                // shared state row (its recurrent product joins the bias) or nullptr
     const float* c0;
-    int hid, n_out, nb1, ns2;
+    int hid, n_out, nb16, ns2;
     float* whh_img; float* w1_img; float* w2_img; float* bias; float* c0_copy;
     int64_t q_whh, q_w1, q_w2;      // 16-byte pieces of the three images
     int img_blocks;
@@ -88,12 +119,14 @@ __global__ __launch_bounds__(256) void is_prep_kernel(const PrepArgs a) {
                 }
                 dst = a.whh_img + q * 4;
             } else if (q < a.q_whh + a.q_w1) {
+                // W1 as B fragments of v_mfma_f32_16x16x4_f32: 16-k slab s, 16-column block cb, lane (column l % 16, k group
+                // l / 16) holds k = 16 s + 4 (l / 16) + j, j = 0..3 (MFMA j of the slab takes one k of every group)
                 const int64_t r = q - a.q_whh;
                 const int lane = (int)(r & 63);
                 const int64_t t = r >> 6;
-                const int cb = (int)(t % a.nb1), s = (int)(t / a.nb1);
-                const int col = cb * 32 + (lane & 31);
-                if (col < a.hid) v = *reinterpret_cast<const f32x4*>(a.P + a.w1 + (int64_t)col * H + 8 * s + 4 * (lane >> 5));
+                const int cb = (int)(t % a.nb16), s = (int)(t / a.nb16);
+                const int col = cb * 16 + (lane & 15);
+                if (col < a.hid) v = *reinterpret_cast<const f32x4*>(a.P + a.w1 + (int64_t)col * H + 16 * s + 4 * (lane >> 4));
                 dst = a.w1_img + r * 4;
             } else {
                 const int64_t r = q - a.q_whh - a.q_w1;
@@ -152,7 +185,7 @@ struct FusedArgs {
     const float* smp_w;         // sample embedding of the previous address: [smp_dim, smp_in], [smp_dim]
     const float* smp_b;
     int smp_in, smp;
-    const float* w1_img; const float* b1; int hid, nb1;
+    const float* w1_img; const float* b1; int hid, nb16;
     const float* w2_img; const float* b2; int n_out, ns2;
     float* y_out; int64_t ldy;  // optional copy of the head outputs (heads that are sampled by their own kernel)
     const float* prior; int prior_stride;
@@ -171,7 +204,7 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     constexpr int NSH = H / 8;
     constexpr int NB = 4 * UB;
     constexpr int SLAB = FW * NB * 256;            // floats of one k-slab of the gate image
-    float* sH = fused_lds;                         // [NSH][64][4]: the fresh hidden tile as A fragments
+    float* sH = fused_lds;                         // [H / 16][2][64][4]: the fresh hidden tile as 16-row A fragments (H * 32 floats)
     float* sA1 = sH + NSH * 256;                   // [ns2][64][4]: head layer 1 activations as A fragments
     float* sY = sA1 + a.ns2 * 256;                 // [32][33] head outputs
     int* sRow = reinterpret_cast<int*>(sY + FR * 33);   // [32] state row of every particle of the panel
@@ -205,26 +238,27 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[blk][r] = b;
     }
-    auto load_b = [&](int s, f32x4 (&b)[NB]) {
-        const float* p = bimg + (size_t)s * SLAB;
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) b[blk] = *reinterpret_cast<const f32x4*>(p + blk * 256);
-    };
+    auto load_blk = [&](int s, int blk) { return *reinterpret_cast<const f32x4*>(bimg + (size_t)s * SLAB + blk * 256); };
     auto load_a = [&](int s) { return *reinterpret_cast<const f32x4*>(arow + 8 * s); };
-    auto mma = [&](const f32x4& av, const f32x4 (&b)[NB]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
-                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[blk][j], acc[blk], 0, 0, 0);
-    };
+    // One slab: block by block, the four MFMAs of a block (k pairs j = 0..3) and then - REFILL - the load of the SAME block of
+    // the slab two steps ahead into the registers those MFMAs just read. The loads are spread one per four MFMAs (a burst of
+    // nine loads per slab stalled the wave in the memory pipeline's issue queue while its MFMAs could have run) and every
+    // fragment has almost two slab times to arrive: the register ring is two slabs deep without holding more than two slabs.
+#define FUSED_SLAB(AV, BUF, REFILL, SN)                                                                         \
+    _Pragma("unroll") for (int blk = 0; blk < NB; ++blk) {                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
+            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[j], BUF[blk][j], acc[blk], 0, 0, 0);             \
+        if (REFILL) BUF[blk] = load_blk(SN, blk);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }
     const int NS = a.state_shared ? 0 : NSH;   // shared state: h W_hh^T is one row for everybody, part of the bias
-    f32x4 b0[NB], b1[NB], a0, a1;
-    // the sample embedding of the previous value first: k = 4 hh + j < smp_dim (embedding_feedforward.py: one Linear + ReLU);
-    // its weights are slab NSH of the image
-    load_b(NSH, b1);
+    f32x4 b0[NB], b1[NB], a0, a1, a2, a3;
+    // item 0 of the stream: the sample embedding of the previous value, k = 4 hh + j < smp_dim (embedding_feedforward.py: one
+    // Linear + ReLU; gather.hpp sample_embed_elem: a Linear(1, smp_dim) of the value, or a row of the one-hot
+    // Linear(C, smp_dim)); its weights are slab NSH of the image. Items 1 .. NS: the slabs 0 .. NS - 1 of h W_hh^T.
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) b0[blk] = load_blk(NSH, blk);
     {
-        // (gather.hpp sample_embed_elem: a Linear(1, smp_dim) of the value, or a row of the one-hot Linear(C, smp_dim))
         const float pv = a.prev_value[gr];
         int cat = (int)pv;
         cat = cat < 0 ? 0 : (cat >= a.smp_in ? a.smp_in - 1 : cat);
@@ -232,39 +266,35 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         for (int j = 0; j < 4; ++j) {
             const int k = min(4 * hh + j, a.smp - 1);
             const float e = a.smp_in == 1 ? a.smp_w[k] * pv + a.smp_b[k] : a.smp_w[k * a.smp_in + cat] + a.smp_b[k];
-            a1[j] = (4 * hh + j < a.smp) ? relu_keep_nan(e) : 0.0f;
+            a0[j] = (4 * hh + j < a.smp) ? relu_keep_nan(e) : 0.0f;
         }
     }
     if (NS) {
-        load_b(0, b0);
-        a0 = load_a(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (NS) {
-        // two-slab register ring: the loads of slab s + 1 are issued BEFORE the MFMAs of slab s (the scheduling barriers keep
-        // the compiler from sinking them behind the MFMAs to save registers, which would expose a full L2 round trip per slab)
-        for (int s = 0; s + 2 < NS; s += 2) {
-            load_b(s + 1, b1);
-            a1 = load_a(s + 1);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) b1[blk] = load_blk(0, blk);
+        a1 = load_a(0);
+        __builtin_amdgcn_sched_barrier(0);
+        int it = 0;      // item `it` sits in b0 / a0, item it + 1 in b1 / a1
+        for (; it + 3 <= NS; it += 2) {
+            a2 = load_a(it + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
+            FUSED_SLAB(a0, b0, true, it + 1)      // consumes item it, refills with item it + 2 = slab it + 1
+            a3 = load_a(it + 2);
             __builtin_amdgcn_sched_barrier(0);
-            load_b(s + 2, b0);
-            a0 = load_a(s + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+            FUSED_SLAB(a1, b1, true, it + 2)
+            a0 = a2;
+            a1 = a3;
         }
-        load_b(NS - 1, b1);
-        a1 = load_a(NS - 1);
+        a2 = load_a(NS - 1);                      // it == NS - 2: items NS - 2, NS - 1, NS remain
         __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
+        FUSED_SLAB(a0, b0, true, NS - 1)
+        FUSED_SLAB(a1, b1, false, 0)
+        FUSED_SLAB(a2, b0, false, 0)
+    } else {
         __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+        FUSED_SLAB(a0, b0, false, 0)
     }
+#undef FUSED_SLAB
     FUSED_STAMP(1);    // K loop done
     __syncthreads();   // every wave has read the old h rows of the panel (and sRow is visible)
     FUSED_STAMP(2);
@@ -286,7 +316,8 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
         const int u = (wave * UB + ub) * 32 + c31;
-        const int hslot = ((u >> 3) * 64 + ((u >> 2) & 1) * 32) * 4 + (u & 3);
+        // A fragments of v_mfma_f32_16x16x4_f32 for head layer 1: [16-k slab u / 16][row block][k group (u / 4) % 4][row % 16][u % 4]
+        const int hslot = ((u >> 4) * 128 + ((u >> 2) & 3) * 16) * 4 + (u & 3);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -301,41 +332,54 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
                 a.c[ro] = cn;
                 a.h[ro] = hn;
             }
-            sH[hslot + row * 4] = hn;
+            sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hn;
         }
     }
     FUSED_STAMP(3);    // cell done
     __syncthreads();
     FUSED_STAMP(4);
 
-    // ---- head layer 1: a1 = relu(h W1^T + b1); wave w takes the 32-column blocks w, w + 8, ... ----
-    for (int cb = wave; cb < a.nb1; cb += FW) {
-        f32x16 acc1;
+    // ---- head layer 1: a1 = relu(h W1^T + b1) on v_mfma_f32_16x16x4_f32: 2 x nb16 tiles of 16 rows x 16 columns, wave w
+    // takes the contiguous tile range [w T / 8, (w + 1) T / 8) (hid = 271: 34 tiles, 4 or 5 per wave; with 32-column blocks one
+    // wave had two of nine blocks and the other seven waited for it, profiles/r04e_is_step_timeline.txt). Two accumulators
+    // per tile (even / odd k groups) keep the dependent-accumulate latency out of the chain; the B fragments (one KB per
+    // 16-k slab and tile, W1's second image) run eight slabs ahead in registers.
+    {
+        const int T16 = 2 * a.nb16;
+        const int t0 = (wave * T16) / FW, t1 = ((wave + 1) * T16) / FW;
+        constexpr int NS16 = H / 16;
+        const int i16 = lane & 15, kq = lane >> 4;
+        for (int t = t0; t < t1; ++t) {
+            const int cb = t >> 1, rb = t & 1;
+            f32x4 e0 = {0.0f, 0.0f, 0.0f, 0.0f}, e1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float* wimg = a.w1_img + (size_t)cb * 256 + lane * 4;
+            const size_t sstride = (size_t)a.nb16 * 256;
+            const float* aimg = sH + rb * 256 + lane * 4;
+            f32x4 bq[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
-        const float* wimg = a.w1_img + (size_t)cb * 256 + lane * 4;
-        const size_t sstride = (size_t)a.nb1 * 256;
-        f32x4 bq[4];
+            for (int u = 0; u < 8; ++u) bq[u] = *reinterpret_cast<const f32x4*>(wimg + u * sstride);
+            for (int s16 = 0; s16 < NS16; s16 += 8) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bq[u] = *reinterpret_cast<const f32x4*>(wimg + u * sstride);
-        for (int s = 0; s < NSH; s += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(sH + (s + u) * 256 + lane * 4);
-                const f32x4 bv = bq[u];
-                if (s + u + 4 < NSH) bq[u] = *reinterpret_cast<const f32x4*>(wimg + (size_t)(s + u + 4) * sstride);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc1, 0, 0, 0);
+                for (int u = 0; u < 8; ++u) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(aimg + (s16 + u) * 512);
+                    const f32x4 bv = bq[u];
+                    if (s16 + u + 8 < NS16) bq[u] = *reinterpret_cast<const f32x4*>(wimg + (size_t)(s16 + u + 8) * sstride);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], e1, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], e1, 0, 0, 0);
+                }
             }
-        }
-        const int col = cb * 32 + c31;
-        const float bias1 = col < a.hid ? a.b1[col] : 0.0f;
-        if ((col >> 3) < a.ns2) {
-            const int slot = ((col >> 3) * 64 + ((col >> 2) & 1) * 32) * 4 + (col & 3);
+            // D of 16x16x4: lane (column i16, row group kq) holds rows 4 kq + r of the tile
+            const int col = cb * 16 + i16;
+            const float bias1 = col < a.hid ? a.b1[col] : 0.0f;
+            if ((col >> 3) < a.ns2) {
+                const int slot = ((col >> 3) * 64 + ((col >> 2) & 1) * 32) * 4 + (col & 3);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                sA1[slot + row * 4] = col < a.hid ? relu_keep_nan(acc1[r] + bias1) : 0.0f;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rb * 16 + 4 * kq + r;
+                    sA1[slot + row * 4] = col < a.hid ? relu_keep_nan(e0[r] + e1[r] + bias1) : 0.0f;
+                }
             }
         }
     }
@@ -373,15 +417,88 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     if (KIND == 3) return;
     __syncthreads();
 
-    // ---- draw + log q (Mixture.sample / log_prob), one lane per particle ----
-    if (tid < FR && m0 + tid < a.n) {
-        const int64_t i = m0 + tid;
-        const float pa = a.prior[i * 2 * a.prior_stride], pb = a.prior[i * 2 * a.prior_stride + 1];
-        float v, lp;
-        mixture_particle<(KIND == 3 ? 0 : KIND)>(sY + tid * 33, pa, pb, a.K, a.value_in != nullptr,
-                                                 a.value_in ? a.value_in[i] : 0.0f, a.seed, a.offset + (uint64_t)i, v, lp);
-        a.value_out[i] = v;
-        a.logq_out[i] = lp;
+    // ---- draw + log q (Mixture.sample / log_prob, is_draw.hpp mixture_particle re-arranged): sixteen lanes per particle,
+    // lane k owns component k; maxima, sums and the inclusive prefix of the component probabilities cross the sixteen lanes
+    // through DPP row operations. (One lane per particle ran ~2 500 instructions on half a wave while seven waves and the
+    // CU's LDS waited: 22 000 cycles per panel.) ----
+    {
+        const int row = tid >> 4, k = tid & 15;
+        const int64_t i = m0 + row;
+        const bool live = i < a.n;
+        const int64_t ic = live ? i : a.n - 1;
+        const int K = a.K;
+        const float* y = sY + row * 33;
+        const float pa = a.prior[ic * 2 * a.prior_stride], pb = a.prior[ic * 2 * a.prior_stride + 1];
+        const bool comp = k < K;
+        const float z = comp ? y[2 * K + k] : -INFINITY;
+        const float zmax = row16_max(z);
+        float p = comp ? expf(z - zmax) : 0.0f;
+        p = p / row16_sum(p);
+        p = p / row16_sum(p);
+        float mu, sd;
+        if (KIND == 0) {
+            mu = pa + (comp ? y[k] : 0.0f) * pb;
+            sd = expf(comp ? y[K + k] : 0.0f) * pb;
+        } else {
+            const float rng = pb - pa;
+            mu = pa + sigmoidf_(comp ? y[k] : 0.0f) * rng;
+            sd = KIND == 2 ? expf(comp ? y[K + k] : 0.0f) : rng / 1000.0f + sigmoidf_(comp ? y[K + k] : 0.0f) * rng * 10.0f;
+        }
+        float ca = 0.0f, cb = 1.0f;
+        if (KIND != 0) {
+            ca = std_cdf((pa - mu) / sd);
+            cb = std_cdf((pb - mu) / sd);
+        }
+        float v;
+        if (a.value_in) {
+            v = a.value_in[ic];
+        } else {
+            const float cum = row16_prefix(p);                       // inclusive prefix over the components
+            Philox rng(a.seed, a.offset + (uint64_t)ic, 0x1C);
+            v = NAN;
+            bool done = false;
+            for (int attempt = 0; attempt < 64; ++attempt) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+                uint32_t r[4];
+                rng.next(r);
+                const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
+                // component ~ Categorical(p): the first k with u0 < cum_k, else the last one (mixture.py:47-63)
+                const int kk = row16_min_int((comp && u0 < cum) ? k : K - 1);
+                const int src = (lane & ~15) + kk;
+                const float mk = __shfl(mu, src, 64), sk = __shfl(sd, src, 64);
+                float cand;
+                bool ok;
+                if (KIND == 0) {
+                    cand = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);   // Box-Muller
+                    ok = true;
+                } else {      // inverse-CDF draw inside [low, high) with rejection (truncated_normal.py:94-112)
+                    const float cak = __shfl(ca, src, 64), cbk = __shfl(cb, src, 64);
+                    const float uu = cak + u1 * (cbk - cak);
+                    cand = mk + sk * kSqrt2 * erfinvf(2.0f * uu - 1.0f);
+                    ok = isfinite(cand) && cand >= pa && cand < pb;
+                }
+                if (!done && ok) {
+                    v = cand;
+                    done = true;
+                }
+                if (KIND == 0) break;
+            }
+        }
+        // log q(v) = logsumexp_k (log p_k + log f_k(v))   (mixture.py:42-44)
+        const bool inside = (KIND == 0) || (v >= pa && v <= pb);
+        const float lpk = logf(fminf(fmaxf(p, kFp32Eps), 1.0f - kFp32Eps));
+        const float tt = (v - mu) / sd;
+        float term;
+        if (KIND == 0) term = -0.5f * tt * tt - logf(sd) - kHalfLog2Pi;
+        else term = (inside ? 0.0f : -INFINITY) + (-0.5f * tt * tt - kHalfLog2Pi) - logf(sd * (cb - ca));
+        const float ak = comp ? lpk + term : -INFINITY;
+        const float amax = row16_max(ak);
+        float lp = amax;
+        if (amax > -INFINITY) lp = amax + logf(row16_sum(comp ? expf(ak - amax) : 0.0f));
+        if (live && k == 0) {
+            a.value_out[i] = v;
+            a.logq_out[i] = lp;
+        }
     }
     FUSED_STAMP(8);    // draw + log q
 #undef FUSED_STAMP
@@ -426,7 +543,7 @@ void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {
     int64_t hid = 1;
     for (int a = 0; a < net->n_addr; ++a) hid = std::max<int64_t>(hid, net->addrs[a].hid);
     f.n_whh = (int64_t)(nsh + 1) * FW * 4 * ub * 256;
-    f.n_w1 = (int64_t)nsh * ((hid + 31) / 32) * 256;
+    f.n_w1 = (int64_t)(H / 16) * ((hid + 15) / 16) * 256;
     f.n_w2 = (int64_t)((hid + 7) / 8) * 256;
     f.n_bias = 4 * H;
 }
@@ -447,10 +564,10 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     p.e_obs_vec = e_obs_vec;
     p.h0 = shared ? h : nullptr;
     p.c0 = shared ? c : nullptr;
-    p.hid = ad.hid; p.n_out = ad.n_out; p.nb1 = (ad.hid + 31) / 32; p.ns2 = (ad.hid + 7) / 8;
+    p.hid = ad.hid; p.n_out = ad.n_out; p.nb16 = (ad.hid + 15) / 16; p.ns2 = (ad.hid + 7) / 8;
     p.whh_img = f.whh; p.w1_img = f.w1; p.w2_img = f.w2; p.bias = f.bias; p.c0_copy = c0_copy;
     p.q_whh = (int64_t)(nsh + 1) * FW * 4 * ub * 64;
-    p.q_w1 = (int64_t)nsh * p.nb1 * 64;
+    p.q_w1 = (int64_t)(H / 16) * p.nb16 * 64;
     p.q_w2 = (int64_t)p.ns2 * 64;
     p.img_blocks = (int)std::min<int64_t>(1024, (p.q_whh + p.q_w1 + p.q_w2 + 255) / 256);
     hipLaunchKernelGGL(is_prep_kernel, dim3(p.img_blocks + H), dim3(256), 0, st, p);
@@ -461,7 +578,7 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     a.h = h; a.c = c; a.c0 = c0_copy; a.rows = rows; a.state_shared = shared ? 1 : 0;
     const pp_addr& pad = net->addrs[prev_addr_id];
     a.prev_value = prev_value; a.smp_w = P + pad.smp_w; a.smp_b = P + pad.smp_b; a.smp_in = pad.smp_in; a.smp = net->smp_dim;
-    a.w1_img = f.w1; a.b1 = P + ad.b1; a.hid = ad.hid; a.nb1 = p.nb1;
+    a.w1_img = f.w1; a.b1 = P + ad.b1; a.hid = ad.hid; a.nb16 = p.nb16;
     a.w2_img = f.w2; a.b2 = P + ad.b2; a.n_out = ad.n_out; a.ns2 = p.ns2;
     a.prior = prior; a.prior_stride = prior_stride;
     a.value_in = value_in; a.value_out = value_out; a.logq_out = logq_out;
