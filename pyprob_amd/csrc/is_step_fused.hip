@@ -41,8 +41,8 @@ constexpr int FW = 8;    // waves per workgroup
 
 // sigmoid / tanh on v_exp_f32 / v_rcp_f32 (~1 ulp each; absolute error of the results ~1e-7, asserted by
 // tests/test_gpu_is_step_fused.py against the float64 oracle)
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // reductions over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15): every lane ends with the result
 __device__ __forceinline__ float row16_max(float v) {

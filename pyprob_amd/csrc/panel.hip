@@ -49,8 +49,8 @@ constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
 constexpr float kLogEps = -18.420680743952367f;
 
 // sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each; absolute error of the results ~1e-7)
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float std_cdf_(float x) { return 0.5f * (1.0f + erff(x * kInvSqrt2)); }
 __device__ __forceinline__ float std_pdf_(float x) { return kInvSqrt2Pi * expf(-0.5f * x * x); }
 

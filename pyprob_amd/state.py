@@ -282,6 +282,11 @@ class LockStepState(PathExecutor):
         self.draw = None
         self.terms = []
         self.final_stats = None
+        # what Model._traces_lockstep needs to recognise a program whose whole call is ONE draw + ONE fused pass (launch plan,
+        # model.py): the number of flushes, where every deferred term's value came from, anything that read a draw early
+        self.flushes = 0
+        self.plan_terms = []          # (term, source, scale): source = ('obs', name) | ('value',) | ('const', tensor)
+        self.plan_ok = True
         super().__init__(n, runner.dev)
 
     @property
@@ -292,9 +297,10 @@ class LockStepState(PathExecutor):
             self._lw_valid = True
         return self._lw
 
-    def defer_term(self, term, x, scale):
+    def defer_term(self, term, x, scale, source=None):
         """Queue lw += scale * log_prob(term; x) for the next fused pass."""
         self.terms.append((term, x, float(scale)))
+        self.plan_terms.append((term, source, float(scale)))
         if len(self.terms) >= 7:
             self.flush()
 
@@ -304,6 +310,9 @@ class LockStepState(PathExecutor):
         draw, terms = self.draw, self.terms
         if draw is None and not terms and not final:
             return None
+        self.flushes += 1
+        if final:
+            self.plan_final = dict(draw=draw, n_terms=len(terms))
         self.draw, self.terms = None, []          # (cleared first: the calls below may touch ParticleTensors)
         value = draw['values'] if draw is not None else None
         vptr = None if value is None else value.data_ptr()
@@ -567,7 +576,7 @@ class PriorLockStep(PathExecutor):
         return out + ((np.concatenate(type_of), seqs),) if return_types else out
 
 
-def _lock_step_likelihood(distribution, value):
+def _lock_step_likelihood(distribution, value, obs_name=None):
     """lw += likelihood_importance * log p(value | .) for the active particles of a lock-step IS run (state.py:147-149;
     also the 'Variable is observed' branch of state.sample, :175-180). A replayed prefix has already been scored."""
     ls = _lock_step
@@ -587,8 +596,9 @@ def _lock_step_likelihood(distribution, value):
     if term is None:
         raise RuntimeError('lock-step importance sampling has no device likelihood for {}'.format(distribution.name))
     if ls.fused and ls.active is None:       # full width: joins the next fused pass (with the draw, if one is pending)
-        ls.defer_term(term, v, _likelihood_importance)
+        ls.defer_term(term, v, _likelihood_importance, source=('obs', obs_name) if (obs_name is not None and v.numel() == 1) else None)
         return
+    ls.plan_ok = False
     ls.flush()
     ls.runner.accumulate_masked(ls.lw, None, None, None, v, ls.active, scale=_likelihood_importance, term=term)
 
@@ -616,7 +626,7 @@ def observe(distribution, value=None, name=None, address=None):
                                     log_prob=None, log_importance_weight=None, observed=True, name=name))
         return value
     if _lock_step is not None and value is not None:
-        _lock_step_likelihood(distribution, value)
+        _lock_step_likelihood(distribution, value, obs_name=name if name in _current_trace_observed_variables else None)
         variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
                             log_prob=None, log_importance_weight=None, observed=True, name=name)
         _current_trace.add(variable)

@@ -141,3 +141,76 @@ def test_branching_on_a_deferred_first_draw(monkeypatch):
     assert np.array_equal(fused._all_values.cpu().numpy(), eager._all_values.cpu().numpy())
     np.testing.assert_allclose(fused._all_log_weights.cpu().numpy(), eager._all_log_weights.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert fused._all_values.mean() > 0          # proposals of Normal(2, 1), not of Normal(-2, 1)
+
+
+# ---- launch plan of a static program (Model._traces_lockstep) --------------------------------------------------------------
+def _same(a, b):
+    return (torch.equal(a._all_values, b._all_values) and torch.equal(a._all_log_weights, b._all_log_weights) and
+            a.mean == b.mean and a.effective_sample_size == b.effective_sample_size)
+
+
+def test_launch_plan_replay_equals_running_the_program(gum, monkeypatch):
+    """A call that was one deferred draw + one fused pass is replayed without running forward(): bit-identical values,
+    log-weights and statistics; replayed for OTHER observation values only after a second recording showed that the
+    program's constants do not depend on them; a changed model attribute asks for a new recording."""
+    monkeypatch.setenv('PP_IS_FUSED', '1')
+    monkeypatch.setenv('PP_IS_PLAN', '1')
+    gum.__dict__.pop('_lockstep_plans', None)
+    n = 50000
+    a = gum.posterior_results(n, IC, observe=OBS, lock_step=True, seed=3)
+    assert not getattr(a, 'replayed_plan', False)
+    b = gum.posterior_results(n, IC, observe=OBS, lock_step=True, seed=3)               # same observation: replayed
+    assert getattr(b, 'replayed_plan', False) and _same(a, b)
+    other = {'obs0': 6.5, 'obs1': 7.25}
+    c = gum.posterior_results(n, IC, observe=other, lock_step=True, seed=4)             # unverified plan: the program runs
+    assert not getattr(c, 'replayed_plan', False)
+    third = {'obs0': 5.0, 'obs1': 5.5}
+    d = gum.posterior_results(n, IC, observe=third, lock_step=True, seed=9)             # verified now: replayed with new values
+    assert getattr(d, 'replayed_plan', False)
+    monkeypatch.setenv('PP_IS_PLAN', '0')
+    e = gum.posterior_results(n, IC, observe=third, lock_step=True, seed=9)
+    assert not getattr(e, 'replayed_plan', False) and _same(d, e)
+    assert abs(d.mean - 4.7) < 0.6                                                       # posterior of (5.0, 5.5): 4.72
+    monkeypatch.setenv('PP_IS_PLAN', '1')
+    old = gum.likelihood_stddev
+    try:
+        gum.likelihood_stddev = 1.0                                                      # the recorded constants are stale
+        f = gum.posterior_results(n, IC, observe=third, lock_step=True, seed=9)
+        assert not getattr(f, 'replayed_plan', False) and not torch.equal(f._all_log_weights, d._all_log_weights)
+    finally:
+        gum.likelihood_stddev = old
+
+
+class ScaleFromObservation(GaussianWithUnknownMean):
+    """The likelihood's scale is computed IN PYTHON from an observed value: a launch plan recorded for one observation holds
+    a constant that is wrong for another one."""
+
+    def forward(self):
+        import pyprob_amd as pyprob
+        from pyprob_amd.distributions import Normal
+        mu = pyprob.sample(Normal(self.prior_mean, self.prior_stddev))
+        y0 = pyprob.observe(Normal(mu, self.likelihood_stddev), name='obs0')
+        pyprob.observe(Normal(mu, 1.0 + 0.1 * abs(float(y0))), name='obs1')
+        return mu
+
+
+def test_launch_plan_is_not_replayed_when_constants_follow_the_observation(monkeypatch):
+    monkeypatch.setenv('PP_IS_FUSED', '1')
+    torch.manual_seed(8)
+    model = ScaleFromObservation()
+    model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=4000, observe_embeddings=EMB, batch_size=128,
+                                  lstm_dim=64, seed=6)
+    n = 20000
+    runs = []
+    for k, obs in enumerate(({'obs0': 8.0, 'obs1': 9.0}, {'obs0': 2.0, 'obs1': 3.0}, {'obs0': -4.0, 'obs1': -3.0}, {'obs0': 8.0, 'obs1': 9.0})):
+        monkeypatch.setenv('PP_IS_PLAN', '1')
+        with_plan = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=20 + k)
+        monkeypatch.setenv('PP_IS_PLAN', '0')
+        without = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=20 + k)
+        assert _same(with_plan, without), k
+        runs.append(bool(getattr(with_plan, 'replayed_plan', False)))
+    assert runs == [False, False, False, False]        # never verified: every new observation runs the program
+    again = model.posterior_results(n, IC, observe={'obs0': 8.0, 'obs1': 9.0}, lock_step=True, seed=99)
+    monkeypatch.setenv('PP_IS_PLAN', '1')
+    again = model.posterior_results(n, IC, observe={'obs0': 8.0, 'obs1': 9.0}, lock_step=True, seed=99)
+    assert getattr(again, 'replayed_plan', False)      # the SAME observation as the last recording: its constants are right
