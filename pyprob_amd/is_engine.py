@@ -101,6 +101,53 @@ class ISRunner:
                            bool(overwrite), int(seed), self.offset, self._stats_scratch if stats else None)
         return self._stats_dict(out) if stats else None
 
+    def run_plan(self, plan, obs_values, n, offset, seed):
+        """Replay of a recorded single-statement posterior call (Model._replay_lockstep_plan) straight through the C ABI: the
+        observation goes up through a pinned staging buffer (its elements are also the `x` of the observe terms), then
+        pp_is_init -> pp_is_step_net -> pp_is_fused - three calls, no operator dispatch, no per-call ctypes structures.
+        plan['c'] caches the term array. Returns (values, log-weights, statistics dict)."""
+        lib, net = self.lib, C.byref(self.eng.net)
+        if torch.cuda.current_device() != (self.dev.index or 0):
+            torch.cuda.set_device(self.dev)
+        k = len(obs_values)
+        if getattr(self, '_obs_pin', None) is None or self._obs_pin.numel() < k:
+            self._obs_pin = torch.zeros(max(k, 16), dtype=torch.float32).pin_memory()
+            self._obs_dev = torch.zeros(max(k, 16), dtype=torch.float32, device=self.dev)
+        pin = self._obs_pin
+        for i, v in enumerate(obs_values):
+            pin[i] = v
+        self._obs_dev.copy_(pin, non_blocking=True)
+        self.begin(n, offset)
+        st = L.stream_ptr()
+        params, ws = self.eng.params.data_ptr(), self.ws.data_ptr()
+        L.check(lib.pp_is_init(net, params, self._obs_dev.data_ptr(), self.e_obs.data_ptr(), ws, self.ws_bytes, st), 'pp_is_init')
+        L.check(lib.pp_is_step_net(net, params, plan['addr'], -1, n, self.e_obs.data_ptr(), None, self.h.data_ptr(),
+                                   self.c.data_ptr(), 1, ws, self.ws_bytes, st), 'pp_is_step_net')
+        self.state_rows = 1
+        values = torch.empty(n, dtype=torch.float32, device=self.dev)
+        lw = torch.empty(n, dtype=torch.float32, device=self.dev)
+        out = torch.empty(8, dtype=torch.float64, device=self.dev)
+        c = plan.get('c')
+        if c is None or c['obs_base'] != self._obs_dev.data_ptr():
+            terms = [(plan['prior_term'], None, 1.0, 4)] + [((kind, (a[1] if a[0] == 'const' else None), s0,
+                                                               (b[1] if b[0] == 'const' else None), s1), xsrc, scale,
+                                                              (1 if a[0] == 'value' else 0) | (2 if b[0] == 'value' else 0))
+                                                             for kind, a, s0, b, s1, xsrc, scale in plan['terms']]
+            arr = (L.pp_lw_term * len(terms))()
+            fl = (C.c_int32 * len(terms))()
+            for q, ((kind, p0, s0, p1, s1), xsrc, scale, flags) in enumerate(terms):
+                arr[q].kind, arr[q].p0_stride, arr[q].p1_stride, arr[q].x_stride = int(kind), int(s0), int(s1), 0
+                arr[q].p0, arr[q].p1 = L.ptr(p0), L.ptr(p1)
+                arr[q].x = None if xsrc is None else self._obs_dev.data_ptr() + 4 * plan['obs_index'][xsrc[1]]
+                arr[q].scale = float(scale)
+                fl[q] = int(flags)
+            c = plan['c'] = dict(arr=arr, fl=fl, count=len(terms), obs_base=self._obs_dev.data_ptr(), prior=plan['prior'].reshape(-1))
+        L.check(lib.pp_is_fused(net, plan['addr'], n, c['prior'].data_ptr(), c['arr'], c['fl'], c['count'], values.data_ptr(),
+                                lw.data_ptr(), 1, int(seed), int(self.offset), out.data_ptr(), self._stats_scratch.data_ptr(), ws,
+                                self.ws_bytes, st), 'pp_is_fused')
+        self.prev_value = self.last_value = values
+        return values, lw, self._stats_dict(out)
+
     def step_rows(self, rows, addr_id, prev_addr_id, prior, seed=0, prior_compact=False):
         """The same statement for a SUBSET of the particles (a diverged control-flow path): the rows' LSTM state and
         previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor; prior:

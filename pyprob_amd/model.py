@@ -192,8 +192,15 @@ class Model:
         sig = tuple((k, a[0], float(a[1]) if a[0] == 'const' else None, s0, b[0], float(b[1]) if b[0] == 'const' else None, s1,
                      x, sc) for k, a, s0, b, s1, x, sc in terms)
         (address, (_, addr_id)), = ls.log[0].items()
+        net = self._inference_network
+        obs_index = None
+        spec = net._engine.spec
+        if all(o[1] == 1 for o in spec.obs) and all(x[1] in net._obs_names for _, _, _, _, _, x, _ in terms) and \
+                draw['prior'].numel() == 2 and all((a[0] != 'const' or a[1].is_cuda) and (b[0] != 'const' or b[1].is_cuda)
+                                                   for _, a, _, b, _, _, _ in terms):
+            obs_index = {name: i for i, name in enumerate(net._obs_names)}       # position in the observation vector
         new = dict(addr=int(draw['addr']), address=address, prior=draw['prior'], prior_term=draw['prior_term'], terms=terms, sig=sig,
-                   observe=self._observe_values(observe), verified=False)
+                   observe=self._observe_values(observe), verified=False, obs_index=obs_index)
         old = plans.get(key)
         if old is not None and old['sig'] == sig and old['addr'] == new['addr'] and old['observe'] != new['observe']:
             new['verified'] = True       # same constants under different observations: they do not depend on the observed values
@@ -204,6 +211,25 @@ class Model:
     def _replay_lockstep_plan(self, plan, num_traces, observe, seed, offset):
         net = self._inference_network
         runner = net._is
+        if plan.get('obs_index') is not None:
+            # every observable is one number: the observation vector of _infer_init holds the x of every observe term
+            try:
+                vec = [float(observe[name]) for name in net._obs_names]
+            except (KeyError, TypeError, ValueError):
+                return None
+            net._infer_observe = observe
+            net._infer_prev_addr_id = None
+            all_values, all_lw, stats = runner.run_plan(plan, vec, num_traces, offset, seed)
+            values, lw = all_values, all_lw
+            if int(stats['count']) != num_traces:
+                values, lw = _drop_non_finite(values, all_lw)
+                stats = runner.stats(lw, values)
+            emp = Empirical.from_device(values, lw, stats)
+            emp._all_values, emp._all_log_weights = all_values, all_lw
+            emp.num_paths = 1
+            emp.statement_log = [{plan['address']: (all_values, plan['addr'])}]
+            emp.replayed_plan = True
+            return emp
         net._infer_init(observe)                        # InferenceNetwork._infer_init (inference_network.py:141-148)
         runner.begin(num_traces, offset=offset)
         runner.step_net(plan['addr'], None)             # first statement: one shared row through the LSTM and the head
