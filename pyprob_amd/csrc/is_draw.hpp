@@ -42,6 +42,16 @@ struct Philox {
 };
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
+// Standard normal deviate of the SHARED-proposal kernels (the first statement of a lock-step run: is_mixture_shared_kernel and
+// is_fused_kernel, one draw per particle, 10^6 particles per call): sqrt(-2 ln u1) cos(2 pi u2) on the hardware log2 / cos /
+// sqrt (v_log_f32, v_cos_f32 takes its argument in revolutions, v_sqrt_f32: ~1e-6 absolute on a deviate of unit scale, ~60
+// issue slots fewer than the library forms). It shapes only WHICH value is drawn; log q, log p and the likelihood terms are
+// evaluated at the value that was drawn, with the accurate forms. Both kernels share this function, so the same Philox block
+// gives bit-identical values on the fused and on the per-term path (tests/test_gpu_is_fused.py).
+__device__ __forceinline__ float box_muller_fast(float u1, float u2) {
+    return __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+}
+
 // One particle of a mixture head. KIND 0: Normal mixture around a Normal prior (pa, pb) = (mean, stddev); KIND 1:
 // TruncatedNormal mixture inside a Uniform prior (low, high); KIND 2: the Poisson head (TruncatedNormal mixture on [0, 40],
 // stddev = exp(y)). y = the 3K head outputs of the particle (means | scales | logits). Draws v (Philox counter `ctr`,

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void is_mixture_shared_kernel(const float* __r
                 if (u0 < s_cum[k]) kk = k;
             const float mk = s_mu[kk], sk = s_sd[kk];
             if (KIND == 0) {
-                v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);   // Box-Muller
+                v = mk + sk * box_muller_fast(u1, u2);
                 break;
             } else {
                 const float uu = s_ca[kk] + u1 * (s_cb[kk] - s_ca[kk]);
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
                     if (u0 < s_cum[k]) kk = k;
                 const float mk = s_mu[kk], sk = s_sd[kk];
                 if (KIND == 0) {
-                    v = mk + sk * sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);
+                    v = mk + sk * box_muller_fast(u1, u2);
                     break;
                 } else {
                     const float uu = s_ca[kk] + u1 * (s_cb[kk] - s_ca[kk]);
