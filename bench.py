@@ -451,8 +451,16 @@ def main():
                 eng.native_dp = True
                 dp_exchange = 'pp_dp_reduce_grads (ncclAllReduce from the C side, grouped pieces)'
 
+        # the collective really spans N ranks: what RCCL itself reports (this library's communicator when it is up, else
+        # torch.distributed's), checked against --gpus - a run that silently fell back to fewer ranks must not print a line
+        rccl_ranks = int(lib.pp_dp_world()) if eng.native_dp else int(dist.get_world_size())
+        if rccl_ranks != world:
+            raise SystemExit('bench.py: RCCL reports %d ranks, --gpus %d' % (rccl_ranks, world))
+        out_rccl = rccl_ranks
         eng.broadcast_params()
     out = {}
+    if use_dist:
+        out['rccl_ranks'] = out_rccl
     K, W = args.steps, args.warmup
 
     if args.workload == 'train':
