@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 9
+#define PP_ABI_VERSION 10
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -390,6 +390,18 @@ int pp_is_step_rows(const pp_net* net, const float* params, int32_t addr_id, int
                     float* h, float* c, int32_t state_rows, const int64_t* rows, const float* value_in, float* value_out,
                     float* logq_out, uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream);
 int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id, int32_t n);
+/* The WHOLE statement of state.sample's IC branch (pyprob/state.py:203-219) for the particles of one control-flow path in ONE
+ * launch of the fused statement kernel: particle i owns row r = rows[i] (NULL: r = i) of the state AND of the full-width
+ * per-particle vectors - its previous value is prev_value_full[r], the drawn value goes to value_full[r], and
+ * lw_full[r] += log p(v) - log q(v) with p the program's own prior (prior_kind 0: Normal(prior[0], prior[1]), 1: Uniform[prior[0],
+ * prior[1]); prior_stride as in pp_is_step, rows of `prior` are compact). Replaces gather of the previous values + pp_is_step_rows
+ * + scatter of the values + pp_logweight_accumulate + pp_axpy. Statements after the first one, mixture heads, where
+ * pp_is_step_fused_supported says so; PP_EINVAL otherwise. */
+int pp_is_statement_rows(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+                         const float* e_obs_vec, const float* prev_value_full, const float* prior, int32_t prior_stride,
+                         float* h, float* c, int32_t state_rows, const int64_t* rows, float* value_full, float* lw_full,
+                         int32_t prior_kind, uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* log p(value) of prior and likelihood terms, accumulated into the per-particle log-weight:
  *     lw[i] += scale * log_prob(dist(params_i); x_i)

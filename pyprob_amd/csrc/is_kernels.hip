@@ -308,9 +308,10 @@ int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, v
 int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
             const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
             const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset, void* ws,
-            size_t ws_bytes, hipStream_t st, bool net_only = false, const int64_t* rows = nullptr) {
+            size_t ws_bytes, hipStream_t st, bool net_only = false, const int64_t* rows = nullptr,
+            const IsStatementOut* whole = nullptr) {
     const bool ff = net && net->lstm_dim == 0;   // FeedForward network: the proposal layer reads the observe embedding
-    PP_CHECK_ARG(net && P && e_obs_vec && (ff || (h && c)) && (net_only || (value_out && logq_out)) && ws, "pp_is_step: null pointer");
+    PP_CHECK_ARG(net && P && e_obs_vec && (ff || (h && c)) && (net_only || whole || (value_out && logq_out)) && ws, "pp_is_step: null pointer");
     PP_CHECK_ARG(addr_id >= 0 && addr_id < net->n_addr && prev_addr_id < net->n_addr, "pp_is_step: address id out of range");
     PP_CHECK_ARG(ff || prev_addr_id < 0 || prev_value, "pp_is_step: prev_value is required after the first statement");
     PP_CHECK_ARG(ff || prev_addr_id < 0 || state_rows == 1 || state_rows == n, "pp_is_step: state_rows must be 1 or n");
@@ -340,14 +341,16 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     // (PP_IS_STEP_FUSED, read per call: 0 = always the chain, 2 = the fused kernel at any n - the A/B and the small-panel
     // parity cases of tests/test_gpu_is_step_fused.py)
     bool head_done = false;
-    if (!shared && (rows || is_step_fused_preferred(net, addr_id, n)) && is_step_fused_supported(net, addr_id) && is_step_fused_mode() != 0) {
+    if (!shared && (rows || whole || is_step_fused_preferred(net, addr_id, n)) && is_step_fused_supported(net, addr_id) &&
+        is_step_fused_mode() != 0) {
         bool sampled = false;
         PP_TRY(is_step_fused(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows, rows,
-                             value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st));
+                             value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st, whole));
         if (sampled) return 0;
+        PP_CHECK_ARG(!whole, "pp_is_statement_rows: mixture heads only");
         head_done = true;     // the head outputs are in w.Y: the sampling kernels below (or pp_is_fused) take over
     } else {
-        PP_CHECK_ARG(!rows, "pp_is_step_rows: a row index list needs the fused statement kernel (pp_is_step_fused_supported)");
+        PP_CHECK_ARG(!rows && !whole, "pp_is_step_rows / pp_is_statement_rows need the fused statement kernel (pp_is_step_fused_supported)");
     }
     if (head_done) {
         if (net_only) return 0;
@@ -852,6 +855,28 @@ int pp_is_step_rows(const pp_net* net, const float* params, int32_t addr_id, int
     return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows,
                        value_in, value_out, logq_out, seed, offset, workspace, workspace_bytes, pp::as_stream(stream), false,
                        rows);
+}
+
+int pp_is_statement_rows(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
+                         const float* e_obs_vec, const float* prev_value_full, const float* prior, int32_t prior_stride,
+                         float* h, float* c, int32_t state_rows, const int64_t* rows, float* value_full, float* lw_full,
+                         int32_t prior_kind, uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    if (prev_addr_id < 0 || !(value_full && lw_full && prev_value_full) || (prior_kind != 0 && prior_kind != 1) || !prior) {
+        pp::set_error("pp_is_statement_rows: a statement after the first one, Normal (0) or Uniform (1) prior, value / log-weight / "
+                      "previous-value vectors indexed by the particles' rows");
+        return PP_EINVAL;
+    }
+    if (net && addr_id >= 0 && addr_id < net->n_addr) {
+        const int kind = net->addrs[addr_id].kind;
+        if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE) {
+            pp::set_error("pp_is_statement_rows: Normal / Uniform statements (mixture heads) only");
+            return PP_EINVAL;
+        }
+    }
+    const pp::IsStatementOut whole{value_full, lw_full, prior_kind};
+    return pp::is_step(net, params, addr_id, prev_addr_id, n, e_obs_vec, prev_value_full, prior, prior_stride, h, c, state_rows,
+                       nullptr, nullptr, nullptr, seed, offset, workspace, workspace_bytes, pp::as_stream(stream), false, rows, &whole);
 }
 
 int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id, int32_t n) {

@@ -192,6 +192,13 @@ struct FusedArgs {
     const float* value_in; float* value_out; float* logq_out;
     uint64_t seed, offset;
     int K, n;
+    // whole-statement mode (pp_is_statement_rows): the previous values are read at the particle's row, the drawn value goes to
+    // value_full[row] and the log-weight takes + log p(v) - log q(v) there (state.py:211-217) - no gather / scatter / axpy
+    // launches around the statement. prior_kind: 0 Normal(pa, pb), 1 Uniform[pa, pb)
+    int prev_indexed;
+    float* value_full;
+    float* lw_full;
+    int prior_kind;
     long long* dbg;             // debug: s_memtime stamps [2 workgroups][2 waves][16] (pp_debug_timeline) or nullptr
 };
 
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) b0[blk] = load_blk(NSH, blk);
     {
-        const float pv = a.prev_value[gr];
+        const float pv = a.prev_value[a.prev_indexed ? ridx : (int64_t)gr];
         int cat = (int)pv;
         cat = cat < 0 ? 0 : (cat >= a.smp_in ? a.smp_in - 1 : cat);
 #pragma unroll
@@ -496,8 +503,25 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         float lp = amax;
         if (amax > -INFINITY) lp = amax + logf(row16_sum(comp ? expf(ak - amax) : 0.0f));
         if (live && k == 0) {
-            a.value_out[i] = v;
-            a.logq_out[i] = lp;
+            if (a.value_out) a.value_out[i] = v;
+            if (a.logq_out) a.logq_out[i] = lp;
+            if (a.value_full) {
+                const int64_t ri = sRow[row];
+                a.value_full[ri] = v;
+                // + log p(v) of the program's own prior, then - log q(v): two fp32 additions in the order of the separate
+                // log-weight kernels (pp_logweight_accumulate, pp_axpy)
+                float plp;
+                if (a.prior_kind == 0) {
+                    const float d = v - pa;
+                    plp = -(d * d) / (2.0f * pb * pb) - logf(pb) - kHalfLog2Pi;
+                } else {
+                    plp = (v >= pa && v < pb) ? -logf(pb - pa) : -INFINITY;
+                }
+                float l = a.lw_full[ri];
+                l += plp;
+                l += -1.0f * lp;
+                a.lw_full[ri] = l;
+            }
         }
     }
     FUSED_STAMP(8);    // draw + log q
@@ -551,7 +575,8 @@ void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {
 int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
                   const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
                   const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
-                  const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st) {
+                  const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
+                  const IsStatementOut* whole) {
     const pp_addr& ad = net->addrs[addr_id];
     const int H = net->lstm_dim, ub = H / 256, nsh = H / 8;
     const bool shared = state_rows == 1;
@@ -584,6 +609,12 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     a.value_in = value_in; a.value_out = value_out; a.logq_out = logq_out;
     a.seed = seed; a.offset = offset; a.K = ad.n_out / 3; a.n = n;
     a.dbg = g_timeline;
+    if (whole) {
+        a.prev_indexed = 1;
+        a.value_full = whole->value_full;
+        a.lw_full = whole->lw_full;
+        a.prior_kind = whole->prior_kind;
+    }
     int kind = 3;
     if (!net_only && ad.n_out % 3 == 0 && ad.n_out / 3 <= MAXK) {
         if (ad.kind == PP_HEAD_NORMAL_MIXTURE) kind = 0;

@@ -14,6 +14,13 @@ struct IsFusedBuffers {
 bool is_step_fused_supported(const pp_net* net, int addr_id);
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f);
 
+// whole-statement mode: previous values indexed by the particle's row, value and log-weight written at that row
+struct IsStatementOut {
+    float* value_full;
+    float* lw_full;
+    int prior_kind;      // 0 Normal, 1 Uniform
+};
+
 // A statement AFTER the first one of a trace (prev_addr_id >= 0) for n particles. state_rows == 1: row 0 of (h, c) is
 // everybody's previous state. rows (or nullptr): state row of particle i (h, c are read and written at rows[i]; all other
 // per-particle arrays are compact). *sampled: values and log q are written; false when only the head outputs were produced
@@ -21,6 +28,7 @@ void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f);
 int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
                   const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
                   const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
-                  const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st);
+                  const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
+                  const IsStatementOut* whole = nullptr);
 
 }  // namespace pp

@@ -148,6 +148,31 @@ class ISRunner:
         self.prev_value = self.last_value = values
         return values, lw, self._stats_dict(out)
 
+    PRIOR_KIND = {'Normal': 0, 'Uniform': 1}
+
+    def whole_statement_ok(self, addr_id, prev_addr_id, m, dist_name, prior):
+        """Can `statement_rows` take this statement (fused statement kernel, shared Normal / Uniform prior pair)?"""
+        return (prev_addr_id is not None and self.dev.type == 'cuda' and self.eng.spec.lstm_depth == 1 and
+                dist_name in self.PRIOR_KIND and prior is not None and prior.numel() == 2 and self.prev_value is not None and
+                self.prev_value.numel() == self.n and
+                bool(self.lib.pp_is_step_fused_supported(C.byref(self.eng.net), int(addr_id), int(m))))
+
+    def statement_rows(self, rows, addr_id, prev_addr_id, prior, values_full, lw_full, dist_name, seed=0):
+        """The whole statement for the particles `rows` (None: all) in one launch: previous values read at the rows, value
+        written to values_full[rows], lw_full[rows] += log p(v) - log q(v) (pp_is_statement_rows)."""
+        m = self.n if rows is None else int(rows.numel())
+        state_rows = self.state_rows
+        if rows is not None and state_rows == 1 and self.n > 1:
+            self.h[:, 1:] = self.h[:, :1]      # the shared first-statement state (row 0) becomes per-particle
+            self.c[:, 1:] = self.c[:, :1]
+            state_rows = self.n
+        self._ensure_ws(m)
+        ops.is_statement_rows(self.eng.params, self.ws, self.eng.net_handle, int(addr_id), int(prev_addr_id), m, self.e_obs,
+                              self.prev_value, prior, self.h, self.c, 1 if state_rows == 1 else m, rows, values_full, lw_full,
+                              self.PRIOR_KIND[dist_name], int(seed), self.offset)
+        self.state_rows = self.n
+        self.prev_value = self.last_value = values_full
+
     def step_rows(self, rows, addr_id, prev_addr_id, prior, seed=0, prior_compact=False):
         """The same statement for a SUBSET of the particles (a diverged control-flow path): the rows' LSTM state and
         previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor; prior:

@@ -384,6 +384,21 @@ class InferenceNetworkLSTM:
             runner.prev_value = runner.last_value = values
             ls.prev_addr_id = a
             return ParticleTensor.wrap(values)
+        m_active = ls.n if ls.active is None else ls.n_active
+        if distribution.name == info.dist_name and runner.whole_statement_ok(a, ls.prev_addr_id, m_active, info.dist_name, prior):
+            # the whole statement in ONE launch: previous values read at the particles' rows, the draw written to values[rows],
+            # lw[rows] += log p(v) - log q(v) (state.py:211-217) - no gather, scatter, prior or axpy launches around it
+            entry = ls.log[j].get(address) if j < len(ls.log) else None
+            values = entry[0] if (entry is not None and ls.active is not None) else (
+                torch.zeros(ls.n, dtype=torch.float32, device=runner.dev) if ls.active is not None else
+                torch.empty(ls.n, dtype=torch.float32, device=runner.dev))
+            runner.statement_rows(ls.rows if ls.active is not None else None, a, ls.prev_addr_id, prior, values, ls.lw,
+                                  info.dist_name, seed=seed)
+            while len(ls.log) <= j:
+                ls.log.append({})
+            ls.log[j][address] = (values, a)
+            ls.prev_addr_id = a
+            return ParticleTensor.wrap(values)
         if ls.active is None:
             value, logq = runner.step(a, ls.prev_addr_id, prior, seed=seed)
             values = value

@@ -48,6 +48,9 @@ _lib.define('is_step(Tensor params, Tensor(a!) workspace, int net, int addr_id, 
 _lib.define('is_step_rows(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
             'Tensor prev_value, Tensor? prior, Tensor(b!) h, Tensor(c!) c, int state_rows, Tensor rows, Tensor? value_in, int seed, '
             'int offset) -> (Tensor, Tensor)')
+_lib.define('is_statement_rows(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
+            'Tensor prev_value_full, Tensor prior, Tensor(b!) h, Tensor(c!) c, int state_rows, Tensor? rows, Tensor(d!) value_full, '
+            'Tensor(e!) lw_full, int prior_kind, int seed, int offset) -> ()')
 _lib.define('is_step_net(Tensor params, Tensor(a!) workspace, int net, int addr_id, int prev_addr_id, int n, Tensor e_obs, '
             'Tensor? prev_value, Tensor(b!) h, Tensor(c!) c, int state_rows) -> ()')
 _lib.define('is_fused(Tensor(a!) workspace, int net, int addr_id, Tensor? prior, int[] kinds, Tensor?[] p0, int[] p0_strides, '
@@ -292,6 +295,31 @@ def _is_step_rows_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, p
                         seed, offset, rows=rows)
 
 
+def _is_statement_rows_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value_full, prior, h, c, state_rows, rows,
+                           value_full, lw_full, prior_kind, seed, offset):
+    """pp_is_statement_rows: the whole statement (previous values by row, draw, value scatter, log-weight update) in one launch."""
+    lib = L.load()
+    netc = net_struct(net)
+    _same_device(params, workspace, e_obs, prev_value_full, prior, h, c, rows, value_full, lw_full)
+    ws_bytes = _is_ws(lib, netc, workspace, n)
+    if not (0 <= addr_id < netc.n_addr) or not (0 <= prev_addr_id < netc.n_addr):
+        raise RuntimeError('pyprob_hip::is_statement_rows: address id out of range')
+    if rows is not None and (rows.dtype != torch.int64 or not rows.is_contiguous() or rows.numel() < n):
+        raise RuntimeError('pyprob_hip::is_statement_rows: rows must be a contiguous int64 tensor with n entries')
+    for t, name in ((prev_value_full, 'prev_value_full'), (value_full, 'value_full'), (lw_full, 'lw_full')):
+        if _f32(t, name).numel() < n:
+            raise RuntimeError('pyprob_hip::is_statement_rows: %s shorter than n' % name)
+    stride = 0 if _f32(prior, 'prior').numel() == 2 else 1
+    if stride and prior.numel() < 2 * n:
+        raise RuntimeError('pyprob_hip::is_statement_rows: prior must be [1, 2] or [n, 2]')
+    with torch.cuda.device(params.device):
+        rc = lib.pp_is_statement_rows(C.byref(netc), params.data_ptr(), int(addr_id), int(prev_addr_id), int(n), e_obs.data_ptr(),
+                                      prev_value_full.data_ptr(), prior.data_ptr(), stride, h.data_ptr(), c.data_ptr(), int(state_rows),
+                                      L.ptr(rows), value_full.data_ptr(), lw_full.data_ptr(), int(prior_kind), int(seed), int(offset),
+                                      workspace.data_ptr(), ws_bytes, _stream(params))
+    L.check(rc, 'pp_is_statement_rows')
+
+
 def _is_step_net_hip(params, workspace, net, addr_id, prev_addr_id, n, e_obs, prev_value, h, c, state_rows):
     lib = L.load()
     netc = net_struct(net)
@@ -403,6 +431,7 @@ _lib.impl('larc_scale', _larc_scale_hip, 'CUDA')
 _lib.impl('is_init', _is_init_hip, 'CUDA')
 _lib.impl('is_step', _is_step_hip, 'CUDA')
 _lib.impl('is_step_rows', _is_step_rows_hip, 'CUDA')
+_lib.impl('is_statement_rows', _is_statement_rows_hip, 'CUDA')
 _lib.impl('is_step_net', _is_step_net_hip, 'CUDA')
 _lib.impl('is_fused', _is_fused_hip, 'CUDA')
 _lib.impl('prior_draw', _prior_draw_hip, 'CUDA')

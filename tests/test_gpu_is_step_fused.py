@@ -266,3 +266,53 @@ def test_fast_activations_against_libm():
     hn = sig(b64[3 * H:]) * np.tanh(cn)
     assert np.abs(c.cpu().numpy()[0] - cn).max() < 1e-6
     assert np.abs(h.cpu().numpy()[0] - hn).max() < 5e-7
+
+
+@pytest.mark.parametrize('dist,use_rows', [('Uniform', True), ('Normal', True), ('Uniform', False)])
+def test_whole_statement_in_one_launch(dist, use_rows):
+    """pp_is_statement_rows: previous values read at the particles' rows, the drawn value scattered to values[rows] and
+    lw[rows] += log p(v) - log q(v) inside the statement kernel = pp_is_step_rows + the gather / scatter / log-weight launches
+    around it (same Philox counters: identical values; the two fp32 additions in the same order: identical log-weights)."""
+    from pyprob_amd.ops import ops
+    H, total = 512, 6000
+    eng, run, sd = _engine(H, seed=12)
+    rng = np.random.default_rng(4)
+    m = 2500 if use_rows else total
+    rows = np.sort(rng.choice(total, m, replace=False)).astype(np.int64) if use_rows else np.arange(total)
+    h0 = (0.5 * rng.standard_normal((total, H))).astype(np.float32)
+    c0 = rng.standard_normal((total, H)).astype(np.float32)
+    prev_full = rng.normal(0, 1, total).astype(np.float32)
+    lw0 = rng.normal(-3, 1, total).astype(np.float32)
+    prior = np.array([[-1.5, 2.0]], np.float32) if dist == 'Uniform' else np.array([[0.3, 1.7]], np.float32)
+    cur = 'a_uniform' if dist == 'Uniform' else 'a_normal'
+    dev = eng.device
+    a, p = _ids(eng, cur), _ids(eng, 'a_normal')
+    pt = torch.from_numpy(prior).to(dev)
+    rt = torch.from_numpy(rows).to(dev)
+    # reference: compact call + the operations the executor used to issue around it
+    h = torch.from_numpy(h0.copy()).to(dev).reshape(1, total, H).contiguous()
+    c = torch.from_numpy(c0.copy()).to(dev).reshape(1, total, H).contiguous()
+    run._ensure_ws(m)
+    pf = torch.from_numpy(prev_full).to(dev)
+    v, lq = ops.is_step_rows(eng.params, run.ws, eng.net_handle, a, p, m, run.e_obs, pf.index_select(0, rt).contiguous(), pt, h, c, m, rt,
+                             None, 31, 0)
+    vals_ref = torch.zeros(total, device=dev)
+    vals_ref.index_copy_(0, rt, v)
+    lw_ref = torch.from_numpy(lw0.copy()).to(dev)
+    kind = 1 if dist == 'Uniform' else 0
+    plp = ops.log_prob(kind, pt[0, :1].contiguous(), 0, pt[0, 1:].contiguous(), 0, v, m)
+    lw_rows = lw_ref.index_select(0, rt)
+    lw_rows = lw_rows + plp
+    lw_rows = lw_rows + (-1.0) * lq
+    lw_ref.index_copy_(0, rt, lw_rows)
+    # the whole statement in one launch
+    h2 = torch.from_numpy(h0.copy()).to(dev).reshape(1, total, H).contiguous()
+    c2 = torch.from_numpy(c0.copy()).to(dev).reshape(1, total, H).contiguous()
+    vals = torch.zeros(total, device=dev)
+    lw = torch.from_numpy(lw0.copy()).to(dev)
+    ops.is_statement_rows(eng.params, run.ws, eng.net_handle, a, p, m, run.e_obs, pf, pt, h2, c2, m, rt if use_rows else None, vals, lw,
+                          kind, 31, 0)
+    assert torch.equal(vals, vals_ref) and torch.equal(h2, h) and torch.equal(c2, c)
+    np.testing.assert_allclose(lw.cpu().numpy(), lw_ref.cpu().numpy(), rtol=0, atol=2e-6)
+    rest = np.setdiff1d(np.arange(total), rows)
+    assert np.array_equal(lw.cpu().numpy()[rest], lw0[rest])
