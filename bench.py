@@ -734,6 +734,16 @@ def main():
             # ... and a program with stochastic control flow in lock step (BASELINE.json configs[2]'s model): statements after
             # the first one run per particle - the N-row statement kernel, with its own MFMA roofline
             out['gumm_lockstep'] = api_posterior_bench(lib, device, args.lstm_dim, 200000, 5, 2, 'gumm', prof_class=5)[0]
+            # the same program with 10^6 particles per call: a 200 000-particle call is bound by the interpreter re-running
+            # forward() once per control-flow path (~10 ms for ~9 paths, whatever the particle count); with five times the
+            # particles the device is what a call waits for
+            g1m = api_posterior_bench(lib, device, args.lstm_dim, 1000000, 3, 1, 'gumm', prof_class=5)[0]
+            out['gumm_lockstep_1m'] = {k: g1m[k] for k in ('particles_per_sec', 'ms_per_call', 'particles_per_call', 'calls',
+                                                           'control_flow_paths', 'ess', 'posterior_mean') if k in g1m}
+            if 'statement_kernel' in g1m:
+                out['gumm_lockstep_1m']['statement_kernel'] = {k: g1m['statement_kernel'][k] for k in
+                                                               ('achieved', 'frac', 'us_per_call', 'launches_per_call',
+                                                                'wall_over_statement_kernels')}
     elif args.workload == 'train_gumm':
         # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
         # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded
