@@ -341,7 +341,9 @@ int pp_train_steps(const pp_net* net, const pp_train_buffers* buffers, const pp_
  * (pyprob/state.py:203-219, pyprob/nn/inference_network_lstm.py:82-134, pyprob/trace.py:123-125)
  * ---------------------------------------------------------------------------------------------------- */
 
-/* Bytes of scratch for pp_is_step with n particles. */
+/* Bytes of scratch for pp_is_step with n particles. The workspace must be ZERO-FILLED once when it is allocated (it holds an
+ * arrival counter of the first-statement kernels, which every launch leaves at zero); everything else in it is scratch of a
+ * single call. */
 size_t pp_is_workspace_bytes(const pp_net* net, int32_t n);
 
 /*

@@ -197,11 +197,85 @@ __global__ __launch_bounds__(256) void is_bernoulli_kernel(const float* __restri
     logq_out[i] = p == p ? v * logf(pc) + (1.0f - v) * log1pf(-pc) : p;
 }
 
+// ---- the shared first statement of a trace as two launches ------------------------------------------------------------------
+// Every particle has the same LSTM input row and a zero state (inference_network_lstm.py:84-91, 106-121): the network runs for
+// ONE row. The generic chain spent five launches on it (input gather, W_ih product, cell, two head layers: ~30 us of
+// launch-bound work per posterior call); here
+//   first_row_lstm_kernel   builds the row x = [E | 0 | 0 | 0 | d_cur | a_cur] in LDS, takes the gate pre-activations of 4 hidden
+//                           units per wave (i, g, o: the forget gate multiplies c0 = 0) as wave-reduced dot products and runs the
+//                           cell: h, c of row 0;
+//   first_row_head_kernel   a1 = relu(W1 h + b1), one wave per hidden column; the LAST workgroup to arrive (device-scope ticket)
+//                           finishes y = W2 a1 + b2 from the coherent copies of a1.
+// One-layer LSTM; the FeedForward network and deeper LSTMs keep the chain.
+__global__ __launch_bounds__(256) void first_row_lstm_kernel(GatherDims d, const float* __restrict__ P,
+                                                             const int64_t* __restrict__ at, const float* __restrict__ E,
+                                                             int addr_id, int64_t w_ih, int64_t b_ih, int64_t b_hh, int H,
+                                                             float* __restrict__ h, float* __restrict__ c) {
+    __shared__ float sx[1024];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < d.I; k += 256) sx[k] = k < d.e_obs ? E[k] : gather_embedding_elem(d, P, at, k, -1, 0.0f, addr_id);
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int u = (blockIdx.x * 4 + wave) * 4 + q;
+        if (u >= H) return;      // wave-uniform
+        float g3[3];
+#pragma unroll
+        for (int gsel = 0; gsel < 3; ++gsel) {
+            const int n = (gsel == 0 ? 0 : gsel + 1) * H + u;      // gates i, g, o
+            const float* wr = P + w_ih + (int64_t)n * d.I;
+            float acc = 0.0f;
+            for (int k = lane; k < d.I; k += 64) acc += wr[k] * sx[k];
+            g3[gsel] = wave_sum(acc) + (P[b_ih + n] + P[b_hh + n]);
+        }
+        if (lane == 0) {
+            const float cn = sigmoidf_(g3[0]) * tanhf(g3[1]);
+            c[u] = cn;
+            h[u] = sigmoidf_(g3[2]) * tanhf(cn);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void first_row_head_kernel(const float* __restrict__ P, const float* __restrict__ top, int Hin,
+                                                             int64_t w1, int64_t b1, int hid, int64_t w2, int64_t b2, int n_out,
+                                                             float* __restrict__ A1, float* __restrict__ Y, unsigned int* ticket) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j < hid) {
+        const float* wr = P + w1 + (int64_t)j * Hin;
+        float acc = 0.0f;
+        for (int k = lane; k < Hin; k += 64) acc += wr[k] * top[k];
+        const float v = relu_keep_nan(wave_sum(acc) + P[b1 + j]);
+        if (lane == 0) __hip_atomic_store(A1 + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = atomicAdd(ticket, 1u);
+        s_last = t == gridDim.x - 1u;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int o = wave; o < n_out; o += 4) {
+        const float* wr = P + w2 + (int64_t)o * hid;
+        float acc = 0.0f;
+        for (int k = lane; k < hid; k += 64) acc += wr[k] * __hip_atomic_load(A1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v = wave_sum(acc) + P[b2 + o];
+        if (lane == 0) Y[o] = v;
+    }
+}
+
 struct IsWorkspace {
     float *X, *G, *A1, *Y, *rec, *c0;
     float *obs_h, *cat, *f1;
     int64_t i4, hid4, out4, e4, maxohid4;
     IsFusedBuffers fz;   // operand images of the fused statement kernel (is_step_fused.hip)
+    float* ticket;       // arrival counter of first_row_head_kernel (a 32-bit word: zero when the workspace is allocated, left at
+                         // zero by every launch)
     size_t bytes;
 };
 
@@ -214,6 +288,7 @@ static void is_carve(const pp_net* net, int n, void* p, IsWorkspace& w) {
         off += (size_t)std::max<int64_t>(count, 1) * sizeof(float);
         return q;
     };
+    w.ticket = take(64);   // FIRST: a fixed place whatever n is (the scratch of an n-row call must never run over it)
     const int H = net->lstm_dim;
     w.i4 = round4(net->lstm_in);
     w.e4 = round4(net->e_obs);
@@ -351,6 +426,19 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
         head_done = true;     // the head outputs are in w.Y: the sampling kernels below (or pp_is_fused) take over
     } else {
         PP_CHECK_ARG(!rows && !whole, "pp_is_step_rows / pp_is_statement_rows need the fused statement kernel (pp_is_step_fused_supported)");
+    }
+    // the shared first statement on a one-layer LSTM: two launches (first_row_lstm_kernel, first_row_head_kernel) instead of the
+    // chain's five
+    const bool first_row = shared && !ff && std::max(1, (int)net->lstm_depth) == 1 && net->lstm_in <= 1024 && net->addr_table &&
+                           !(getenv("PP_IS_FIRST_ROW") && atoi(getenv("PP_IS_FIRST_ROW")) == 0);
+    if (first_row) {
+        GatherDims gd{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+        hipLaunchKernelGGL(first_row_lstm_kernel, dim3(cdiv(H, 16)), dim3(256), 0, st, gd, P, net->addr_table, e_obs_vec, addr_id,
+                           net->w_ih, net->b_ih, net->b_hh, H, h, c);
+        hipLaunchKernelGGL(first_row_head_kernel, dim3(cdiv(ad.hid, 4)), dim3(256), 0, st, P, (const float*)h, H, ad.w1, ad.b1,
+                           ad.hid, ad.w2, ad.b2, ad.n_out, w.A1, w.Y, reinterpret_cast<unsigned int*>(w.ticket));
+        PP_LAUNCH_CHECK("pp_is_step(first statement)");
+        head_done = true;
     }
     if (head_done) {
         if (net_only) return 0;

@@ -43,7 +43,7 @@ class ISRunner:
     def _ensure_ws(self, n):
         need = self.lib.pp_is_workspace_bytes(C.byref(self.eng.net), n)
         if need > self.ws_bytes:
-            self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)      # (zero-filled: the header's contract)
             self.ws_bytes = need
 
     def init(self, observe):
