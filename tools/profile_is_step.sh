@@ -36,6 +36,7 @@ if len(vals) == 2:
                                            algorithmic_bytes='h and c read once and written once (4 x 2 KB), previous value, prior, value, log q (20 B); the 4.7 MB of weights once per launch',
                                            **vals)
 json.dump(doc, open('profiles/r04_is_pmc_traffic.json', 'w'), indent=1)
+json.dump(doc, open('$OUT/${TAG}_r04_is_pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(doc['kernels']))
 P
 cat $OUT/${TAG}_is_step_bench.jsonl

@@ -5,6 +5,9 @@
 #   gpurun_out/<tag>_bench_20_5.json, _bench_default.json         the driver's command and the default command
 TAG=${1:-r04x}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
+# the driver's command FIRST, in the fresh session (a bench line measured right after a profiled or test run of the same box
+# session shows every memory-latency-bound kernel ~1.6x slower); it quotes no rocprof / PMC figures yet
+python $REPO/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20_5_fresh.json 2> $OUT/${TAG}_bench_20_5_fresh.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fp_ks
 rocprofv3 --kernel-trace --stats -d $OUT/fp_ks -o p -- python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-is > $OUT/${TAG}_ks.log 2>&1
