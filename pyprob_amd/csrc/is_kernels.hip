@@ -213,26 +213,42 @@ __global__ __launch_bounds__(256) void first_row_lstm_kernel(GatherDims d, const
                                                              float* __restrict__ h, float* __restrict__ c) {
     __shared__ float sx[1024];
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    // this wave's 4 hidden units x gates i, g, o: all weight loads are issued before the input row is complete (they do not
+    // depend on it): one memory round trip for the 12 rows, one for the row's table lookups, overlapped
+    const int u0 = (blockIdx.x * 4 + wave) * 4;
+    constexpr int KI = 4;      // lstm_in <= 256 per 64 lanes x 4
+    float wv[4][3][KI];
+    float bsum[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int gsel = 0; gsel < 3; ++gsel) {
+            const int n = (gsel == 0 ? 0 : gsel + 1) * H + min(u0 + q, H - 1);      // gates i, g, o
+            const float* wr = P + w_ih + (int64_t)n * d.I;
+#pragma unroll
+            for (int kk = 0; kk < KI; ++kk) wv[q][gsel][kk] = (lane + 64 * kk) < d.I ? wr[lane + 64 * kk] : 0.0f;
+            bsum[q][gsel] = P[b_ih + n] + P[b_hh + n];
+        }
     for (int k = tid; k < d.I; k += 256) sx[k] = k < d.e_obs ? E[k] : gather_embedding_elem(d, P, at, k, -1, 0.0f, addr_id);
     __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
+    float xv[KI];
+#pragma unroll
+    for (int kk = 0; kk < KI; ++kk) xv[kk] = (lane + 64 * kk) < d.I ? sx[lane + 64 * kk] : 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int u = (blockIdx.x * 4 + wave) * 4 + q;
-        if (u >= H) return;      // wave-uniform
         float g3[3];
 #pragma unroll
         for (int gsel = 0; gsel < 3; ++gsel) {
-            const int n = (gsel == 0 ? 0 : gsel + 1) * H + u;      // gates i, g, o
-            const float* wr = P + w_ih + (int64_t)n * d.I;
             float acc = 0.0f;
-            for (int k = lane; k < d.I; k += 64) acc += wr[k] * sx[k];
-            g3[gsel] = wave_sum(acc) + (P[b_ih + n] + P[b_hh + n]);
+#pragma unroll
+            for (int kk = 0; kk < KI; ++kk) acc += wv[q][gsel][kk] * xv[kk];
+            g3[gsel] = wave_sum(acc) + bsum[q][gsel];
         }
-        if (lane == 0) {
+        if (lane == 0 && u0 + q < H) {
             const float cn = sigmoidf_(g3[0]) * tanhf(g3[1]);
-            c[u] = cn;
-            h[u] = sigmoidf_(g3[2]) * tanhf(cn);
+            c[u0 + q] = cn;
+            h[u0 + q] = sigmoidf_(g3[2]) * tanhf(cn);
         }
     }
 }
@@ -240,12 +256,17 @@ __global__ __launch_bounds__(256) void first_row_lstm_kernel(GatherDims d, const
 __global__ __launch_bounds__(256) void first_row_head_kernel(const float* __restrict__ P, const float* __restrict__ top, int Hin,
                                                              int64_t w1, int64_t b1, int hid, int64_t w2, int64_t b2, int n_out,
                                                              float* __restrict__ A1, float* __restrict__ Y, unsigned int* ticket) {
+    __shared__ float sa[1024];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = blockIdx.x * 4 + wave;
     if (j < hid) {
         const float* wr = P + w1 + (int64_t)j * Hin;
         float acc = 0.0f;
-        for (int k = lane; k < Hin; k += 64) acc += wr[k] * top[k];
+        for (int k = lane * 4; k + 3 < Hin; k += 256) {      // (Hin is a multiple of 4: LSTM widths, observe-embedding widths)
+            const f32x4 wq = *reinterpret_cast<const f32x4*>(wr + k);
+            const f32x4 tq = *reinterpret_cast<const f32x4*>(top + k);
+            acc += wq[0] * tq[0] + wq[1] * tq[1] + wq[2] * tq[2] + wq[3] * tq[3];
+        }
         const float v = relu_keep_nan(wave_sum(acc) + P[b1 + j]);
         if (lane == 0) __hip_atomic_store(A1 + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -260,12 +281,23 @@ __global__ __launch_bounds__(256) void first_row_head_kernel(const float* __rest
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    for (int o = wave; o < n_out; o += 4) {
-        const float* wr = P + w2 + (int64_t)o * hid;
-        float acc = 0.0f;
-        for (int k = lane; k < hid; k += 64) acc += wr[k] * __hip_atomic_load(A1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float v = wave_sum(acc) + P[b2 + o];
-        if (lane == 0) Y[o] = v;
+    // the last workgroup: a1 (coherent copies) -> LDS in one round trip, then W2 a1 + b2 with the rows' loads in flight together
+    for (int k = tid; k < hid; k += 256) sa[k] = __hip_atomic_load(A1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    constexpr int OW = 8;      // outputs per wave and pass
+    for (int o0 = wave * OW; o0 < n_out; o0 += 4 * OW) {
+        float acc[OW];
+#pragma unroll
+        for (int q = 0; q < OW; ++q) {
+            acc[q] = 0.0f;
+            const float* wr = P + w2 + (int64_t)min(o0 + q, n_out - 1) * hid;
+            for (int k = lane; k < hid; k += 64) acc[q] += wr[k] * sa[k];
+        }
+#pragma unroll
+        for (int q = 0; q < OW; ++q) {
+            const float v = wave_sum(acc[q]);
+            if (lane == 0 && o0 + q < n_out) Y[o0 + q] = v + P[b2 + o0 + q];
+        }
     }
 }
 
@@ -429,7 +461,8 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     }
     // the shared first statement on a one-layer LSTM: two launches (first_row_lstm_kernel, first_row_head_kernel) instead of the
     // chain's five
-    const bool first_row = shared && !ff && std::max(1, (int)net->lstm_depth) == 1 && net->lstm_in <= 1024 && net->addr_table &&
+    const bool first_row = shared && !ff && std::max(1, (int)net->lstm_depth) == 1 && net->lstm_in <= 256 && (H % 4) == 0 &&
+                           ad.hid <= 1024 && net->addr_table &&
                            !(getenv("PP_IS_FIRST_ROW") && atoi(getenv("PP_IS_FIRST_ROW")) == 0);
     if (first_row) {
         GatherDims gd{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
