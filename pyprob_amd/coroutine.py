@@ -395,14 +395,7 @@ def _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args,
             p.trace = state._end_trace(result)
             p.result = result
             p.done = True
-        import os
-        if worker == 0 and os.environ.get('PP_IS_WORKER_PROFILE'):      # where does a worker's time go? (stderr)
-            import cProfile, pstats, sys
-            pr = cProfile.Profile()
-            particles = pr.runcall(sched.run_particles, particle_main)
-            pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(22)
-        else:
-            particles = sched.run_particles(particle_main)
+        particles = sched.run_particles(particle_main)
         if map_func is None:
             try:
                 results = np.array([float(p.result) for p in particles], np.float32)

@@ -982,7 +982,7 @@ __device__ __forceinline__ bool group_decode(const GroupedParams& g, int b, int&
 
 // placement of a problem: share the panel of the LARGER operand if that direction has at least 8 tiles to spread
 static inline int pick_pmode(int M, int N, int gx, int gy) {
-    static const int mode = getenv("PP_XCD_PANEL") ? atoi(getenv("PP_XCD_PANEL")) : 1;
+    static const int mode = 1;
     if (!mode) return 0;
     if (M >= N) return gy >= 8 ? 1 : (gx >= 8 ? 2 : 0);
     return gx >= 8 ? 2 : (gy >= 8 ? 1 : 0);
@@ -1502,7 +1502,7 @@ static int launch_direct_grouped_aux(const GroupedParams& g, const AuxJobs& aux,
 
 // eight waves per tile when the launch cannot put four workgroups on every CU anyway
 static bool eight_waves(int64_t blocks) {
-    static const int mode = getenv("PP_GEMM_KW") ? atoi(getenv("PP_GEMM_KW")) : 0;
+    static const int mode = 0;
     if (mode == 1) return false;
     if (mode == 2) return true;
     return blocks <= 512;
@@ -1557,7 +1557,7 @@ static void fill_params(const pp_gemm_args* a, GemmParams& p) {
     p.bias = a->bias; p.bias2 = a->bias2; p.mask = a->mask; p.ldmask = a->ldmask;
     p.relu = a->relu; p.accumulate = a->accumulate;
     p.colsum = a->colsum;
-    static const int plain = getenv("PP_DBG_PLAIN_SPLIT") ? atoi(getenv("PP_DBG_PLAIN_SPLIT")) : 0;
+    static const int plain = 0;
     p.dbg_plain = plain;
     p.split_stride = 0;
     clear_holes(p);
@@ -1573,12 +1573,12 @@ static bool vec_ok(const pp_gemm_args* a) {
 
 // The async tile needs 16-byte pieces and cannot gather along k (the k-major row pointer would change every slab).
 static bool async_ok(const pp_gemm_args* a) {
-    static const int mode = getenv("PP_GEMM_ASYNC") ? atoi(getenv("PP_GEMM_ASYNC")) : 1;
+    static const int mode = 1;
     return mode && vec_ok(a) && a->K >= 1;
 }
 // a k-major operand that gathers along k stages its index list in LDS: the workgroup's K range must fit
 static bool async_split_ok(const pp_gemm_args* a, int splits) {
-    static const int allow = getenv("PP_ASYNC_KGATHER") ? atoi(getenv("PP_ASYNC_KGATHER")) : 1;
+    static const int allow = 1;
     const bool kgather = (a->a_kmajor && a->a_idx) || (a->b_kmajor && a->b_idx);
     if (kgather && !allow) return false;
     return !kgather || cdiv(cdiv(a->K, BK), splits) <= AS_KSLABS;
@@ -1592,11 +1592,11 @@ static bool async_split_ok(const pp_gemm_args* a, int splits) {
 // kernel could not put ~2 workgroups on every CU and the K range is short (`slabs` = sum over tiles of their K slabs).
 // PP_GEMM_DIRECT=0/1 forces one of them (A/B measurements).
 static bool use_direct(int64_t tiles64, int64_t slabs) {
-    static const int mode = getenv("PP_GEMM_DIRECT") ? atoi(getenv("PP_GEMM_DIRECT")) : -1;
+    static const int mode = -1;
     // (128: the per-address head weight gradients of a ragged 12-address step - 24 problems, ~300 tiles - run 25 us faster
     // on the async tiles than on 2500 direct workgroups; the single products that need the direct tile stay below)
-    static const int limit = getenv("PP_GEMM_DIRECT_TILES") ? atoi(getenv("PP_GEMM_DIRECT_TILES")) : 128;
-    static const int kmax = getenv("PP_GEMM_DIRECT_SLABS") ? atoi(getenv("PP_GEMM_DIRECT_SLABS")) : 16;
+    static const int limit = 128;
+    static const int kmax = 16;
     if (mode == 0) return false;
     if (mode == 1) return tiles64 < 4096;
     // long-K products would need cross-workgroup split-K to occupy the chip; their float atomics cost more than the
@@ -1649,7 +1649,7 @@ static int launch_grouped(const GroupedParams& g, bool akm, bool bkm, hipStream_
 
 // A split product as a one-problem group: the grouped kernels own the XCD-aware workgroup -> (tile, split) mapping.
 static int launch_split(const GemmParams& p, bool vec, bool akm, bool bkm, int tile, int splits, int kind, hipStream_t st) {
-    static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
+    static const int xcd = 1;
     GroupedParams g;
     g.ext = GemmExt{};
     g.trace = nullptr;
@@ -1711,15 +1711,15 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole, const 
         const int64_t tiles32 = (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT);
         const int nslab = cdiv(a->K, BK);
         int splits = 1;
-        static const int maxsplit = getenv("PP_DIRECT_MAXSPLIT") ? atoi(getenv("PP_DIRECT_MAXSPLIT")) : 16;
+        static const int maxsplit = 16;
         if (split_allowed(a)) splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv(1024, tiles32), nslab / 8), maxsplit));
         if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
         if (splits > 1) return launch_split(p, vec, a->a_kmajor, a->b_kmajor, DT, splits, 1, st);
         return vec ? launch_direct<4>(p, a->a_kmajor, a->b_kmajor, splits, st)
                    : launch_direct<1>(p, a->a_kmajor, a->b_kmajor, splits, st);
     }
-    static const int budget = getenv("PP_SPLIT_BUDGET") ? atoi(getenv("PP_SPLIT_BUDGET")) : 256;
-    static const int force = getenv("PP_FORCE_SPLITS") ? atoi(getenv("PP_FORCE_SPLITS")) : 0;
+    static const int budget = 256;
+    static const int force = 0;
     const int splits = big ? 1 : (force && split_allowed(a) ? force : pick_splits(a, budget));
     if (splits > 1 && !a->accumulate) PP_TRY(zero_for_split(a, st));
     const bool as = !big && async_ok(a) && async_split_ok(a, splits);
@@ -1771,30 +1771,30 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         g.ext = ext ? *ext : GemmExt{};
         g.trace = nullptr;
         g.warm = 1;
-        static const int xcd = getenv("PP_XCD_SPLIT") ? atoi(getenv("PP_XCD_SPLIT")) : 1;
+        static const int xcd = 1;
         g.xcd_aware = xcd;
         g.count = 0;
         g.first[0] = 0;
         const int akm = args[i].a_kmajor, bkm = args[i].b_kmajor;
         // slabs each workgroup walks so that the launch has ~target workgroups
-        static const int target_staged = getenv("PP_GROUP_BLOCKS") ? atoi(getenv("PP_GROUP_BLOCKS")) : 768;
+        static const int target_staged = 768;
         // (with the zero blocks left out of the work estimate: 128-256 active workgroups measured equal, 0.152 ms per GUM
         // step; 320+ costs 4 us in split-K atomics, one split per tile 3 us in idle CUs - profiles/r02_e/f_ab_*.json)
-        static const int target_async = getenv("PP_GROUP_BLOCKS_ASYNC") ? atoi(getenv("PP_GROUP_BLOCKS_ASYNC")) : 256;
-        static const int target_direct = getenv("PP_GROUP_BLOCKS_DIRECT") ? atoi(getenv("PP_GROUP_BLOCKS_DIRECT")) : 1536;
+        static const int target_async = 256;
+        static const int target_direct = 1536;
         int64_t work = 0, work32 = 0, tiles = 0;
         bool as = true;
         for (int k = i, c = 0; k < count && c < GROUP_MAX; ++k) {
             const pp_gemm_args* a = &args[k];
             if (a->a_kmajor != akm || a->b_kmajor != bkm) break;
             if (a->M <= 0 || a->N <= 0) continue;
-            static const int trace = getenv("PP_GEMM_TRACE") ? 1 : 0;
+            static const int trace = 0;
             if (trace && !async_ok(a))
                 fprintf(stderr, "[pp_gemm] group problem not async: M=%d N=%d K=%d lda=%lld ldb=%lld A%%16=%d B%%16=%d\n", a->M, a->N,
                         a->K, (long long)a->lda, (long long)a->ldb, (int)((uintptr_t)a->A & 15), (int)((uintptr_t)a->B & 15));
             as = as && async_ok(a);
             tiles += (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64);
-            static const int effw = getenv("PP_GROUP_EFFWORK") ? atoi(getenv("PP_GROUP_EFFWORK")) : 1;
+            static const int effw = 1;
             work += effw ? effective_work(a, holes ? &holes[k] : nullptr)
                          : (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) * cdiv(a->K, BK);
             work32 += (int64_t)cdiv(a->M, DT) * cdiv(a->N, DT) * cdiv(a->K, BK);
@@ -1807,7 +1807,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
         // direct tiles: a workgroup's four waves share its slabs, so it should own >= 8 of them
         // ... but no workgroup should walk more than ~24 slabs (~10 us of K loop): a ragged batch's dW_ih / dW_hh have
         // K = 1600-2600 rows, and 82 slabs per workgroup made the weight-gradient launches of the GUMM step 98 + 89 us
-        static const int spb_max = getenv("PP_GROUP_SLABS_MAX") ? atoi(getenv("PP_GROUP_SLABS_MAX")) : 24;
+        static const int spb_max = 24;
         const int spb = direct ? (int)std::max<int64_t>(8, (work32 + target_direct - 1) / target_direct)
                                : (int)std::min<int64_t>(spb_max, std::max<int64_t>(2, (work + target - 1) / target));
         const int tile = direct ? DT : 64;
@@ -1830,7 +1830,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
             // the weight-gradient launch to finish, tools/wg_trace.py. Giving them 3x / 6x the splits made the launch SLOWER,
             // 24.5 -> 26.7 / 29 us: the launch is bound by its total number of float atomics, not by its longest workgroup.
             // PP_GROUP_SMALL_DIV > 1 re-enables the experiment.)
-            static const int small_div = getenv("PP_GROUP_SMALL_DIV") ? atoi(getenv("PP_GROUP_SMALL_DIV")) : 1;
+            static const int small_div = 1;
             if (!direct && as && small_div > 1 && split_allowed(a) && (int64_t)cdiv(a->M, 64) * cdiv(a->N, 64) <= 2)
                 splits = std::max(splits, pick_splits_by_work(a, std::max(2, spb / small_div)));
             // a gathered k range must fit the LDS index list of the async tile
@@ -1845,7 +1845,7 @@ int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const 
                 active_blocks += (int64_t)act * splits;
             }
             g.pmode[q] = pick_pmode(a->M, a->N, g.gx[q], g.gy[q]);
-            static const int rotate = getenv("PP_XCD_ROTATE") ? atoi(getenv("PP_XCD_ROTATE")) : 1;
+            static const int rotate = 1;
             g.rot[q] = (g.pmode[q] == 0 && rotate) ? (xcd_cursor & 7) : 0;
             if (g.pmode[q] == 0) xcd_cursor += g.gx[q] * g.gy[q];
             g.first[q + 1] = g.first[q] + group_blocks(g.gx[q], g.gy[q], splits, g.pmode[q]);

@@ -462,8 +462,7 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     // the shared first statement on a one-layer LSTM: two launches (first_row_lstm_kernel, first_row_head_kernel) instead of the
     // chain's five
     const bool first_row = shared && !ff && std::max(1, (int)net->lstm_depth) == 1 && net->lstm_in <= 256 && (H % 4) == 0 &&
-                           ad.hid <= 1024 && net->addr_table &&
-                           !(getenv("PP_IS_FIRST_ROW") && atoi(getenv("PP_IS_FIRST_ROW")) == 0);
+                           ad.hid <= 1024 && net->addr_table;
     if (first_row) {
         GatherDims gd{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
         hipLaunchKernelGGL(first_row_lstm_kernel, dim3(cdiv(H, 16)), dim3(256), 0, st, gd, P, net->addr_table, e_obs_vec, addr_id,

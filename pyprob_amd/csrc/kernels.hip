@@ -1057,7 +1057,7 @@ static size_t head_tail_lds_floats(int hid, int n_out) {
 }
 
 bool head_tail_supported(int kind, int hid, int n_out) {
-    static const bool disabled = getenv("PP_NO_HEAD_TAIL") && atoi(getenv("PP_NO_HEAD_TAIL")) != 0;   // A/B knob
+    static const bool disabled = false;
     if (disabled) return false;
     if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE && kind != PP_HEAD_POISSON_TN_MIXTURE) return false;
     if (n_out % 3 != 0 || n_out / 3 > MAXK || n_out / 3 < 1) return false;

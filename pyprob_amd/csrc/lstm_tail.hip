@@ -436,7 +436,7 @@ void lstm_tail_exchange_bytes(int H, size_t* fwd, size_t* bwd) {
 // How a batch uses the tail kernels: teams (0 = not at all) and the first time step they take.
 // n_active: host [T]. PP_LSTM_TAIL=0 switches the path off; PP_LSTM_TAIL_MIN_STEPS (default 2) = fewest steps worth a launch.
 int lstm_tail_plan(const int32_t* n_active, int T, int H, int* t0_out, int* teams_out) {
-    static const int min_steps = getenv("PP_LSTM_TAIL_MIN_STEPS") ? atoi(getenv("PP_LSTM_TAIL_MIN_STEPS")) : 2;
+    static const int min_steps = 2;
     *t0_out = T;
     *teams_out = 0;
     const int teams = lstm_tail_teams(H);
@@ -464,7 +464,7 @@ static unsigned next_tag_base(void* xch_f, size_t f_bytes, void* xch_b, size_t b
 }
 
 static int tail_probe() {
-    static const int probe = getenv("PP_LSTM_TAIL_PROBE") ? atoi(getenv("PP_LSTM_TAIL_PROBE")) : 1;
+    static const int probe = 1;
     return probe;
 }
 

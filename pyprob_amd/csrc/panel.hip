@@ -754,7 +754,7 @@ int panel_t1_split(int B, int H) { return (H == 512 && cdiv(B, PANEL_ROWS) <= 25
 // The embedding-backward tail: the fused embedding kernels' shapes with at most two observables, and the dead LDS buffers
 // (sH .. sW2) must hold the weight image and four dX rows.
 bool panel_obs_tail_ok(const pp_net* net, int H, int hid, int n_out, int e) {
-    static const int env = getenv("PP_PANEL_OBS") ? atoi(getenv("PP_PANEL_OBS")) : 1;
+    static const int env = 1;
     if (!env || !obs_fused_supported(net) || net->n_obs > 2 || net->e_obs != e) return false;
     const PanelLds L = panel_lds(H, hid, n_out, e);
     return L.sP - L.sH >= PANEL_OBS_LDS;

@@ -217,9 +217,9 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
 
 bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1Args& out) {
     static const int env = getenv("PP_WGRAD_T1") ? atoi(getenv("PP_WGRAD_T1")) : 1;
-    static const int env_s = getenv("PP_WGRAD_T1_SPLITS") ? atoi(getenv("PP_WGRAD_T1_SPLITS")) : 0;
-    static const bool env_wgs_set = getenv("PP_WGRAD_T1_BLOCKS") != nullptr;
-    static const int env_wgs = env_wgs_set ? atoi(getenv("PP_WGRAD_T1_BLOCKS")) : 240;
+    static const int env_s = 0;
+    static const bool env_wgs_set = false;
+    static const int env_wgs = 240;
     if (!env || deterministic_mode() || n <= 0) return false;
     out = WgradT1Args{};
     int np = 0;
