@@ -170,6 +170,7 @@ class ISRunner:
         ops.is_statement_rows(self.eng.params, self.ws, self.eng.net_handle, int(addr_id), int(prev_addr_id), m, self.e_obs,
                               self.prev_value, prior, self.h, self.c, 1 if state_rows == 1 else m, rows, values_full, lw_full,
                               self.PRIOR_KIND[dist_name], int(seed), self.offset)
+        torch.autograd.graph.increment_version(values_full)      # written by the kernel: memoised results of it are stale
         self.state_rows = self.n
         self.prev_value = self.last_value = values_full
 

@@ -113,6 +113,7 @@ class Model:
         finally:
             state._lock_step = None
             state._current_trace = None
+            ls.memo = None          # (the call's intermediate results are released)
         all_values, all_lw = values, ls.lw
         # the fused pass's statistics count only when they were reduced over the tensor that is returned (a draw still
         # pending at the last flush reduces over ITS values: forward() may return something else)

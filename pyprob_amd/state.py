@@ -157,15 +157,50 @@ class ParticleTensor(torch.Tensor):
                           'data_ptr', 'stride', 'storage_offset', 'detach', 'is_floating_point', 'is_complex', 'as_tensor',
                           'unsqueeze', 'squeeze', 'flatten', 'element_size', 'nelement', '__len__', 'ndimension'))
 
+    # Pure elementwise operators whose results the lock-step executor may REUSE within one posterior call: every control-flow
+    # path re-runs forward() from the top, so a path at depth d recomputes the arithmetic of its d - 1 replayed iterations on
+    # full-width tensors (`x * x + y * y`, `s >= 1` ...: O(d^2) launches per call, each ~5 us of interpreter + dispatch). The
+    # result of such an operator is a function of its inputs' contents only; it is kept under (operator, identity + version of
+    # every tensor argument, scalar arguments) and handed out again while the result itself has not been modified
+    # (`Tensor._version` counts in-place writes of inputs and results alike).
+    _PURE = frozenset(('add', 'sub', 'mul', 'div', 'true_divide', 'neg', 'pow', 'sqrt', 'rsqrt', 'log', 'log1p', 'log2', 'exp', 'expm1',
+                       'abs', 'sin', 'cos', 'tan', 'tanh', 'sigmoid', 'ge', 'gt', 'le', 'lt', 'eq', 'ne', 'maximum', 'minimum', 'square',
+                       'reciprocal', '__add__', '__radd__', '__sub__', '__rsub__', '__mul__', '__rmul__', '__truediv__', '__rtruediv__',
+                       '__pow__', '__rpow__', '__neg__', '__ge__', '__gt__', '__le__', '__lt__', '__eq__', '__ne__'))
+
+    @staticmethod
+    def _memo_key(name, args):
+        key = [name]
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                key.append((id(a), a._version))
+            elif isinstance(a, (bool, int, float)):
+                key.append(('s', type(a).__name__, a))
+            else:
+                return None
+        return tuple(key)
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         ls = _lock_step
+        name = getattr(func, '__name__', '') if ls is not None else ''
         if ls is not None and getattr(ls, 'draw', None) is not None:
-            name = getattr(func, '__name__', '')
             lazy_ok = name in cls._NO_READ or (name in ('float', 'contiguous') and len(args) == 1 and torch.is_tensor(args[0]) and
                                                args[0].dtype == torch.float32 and args[0].is_contiguous())
             if not lazy_ok:
                 ls.flush()
+        if ls is not None and not kwargs and name in cls._PURE:
+            memo = getattr(ls, 'memo', None)
+            if memo is not None:
+                key = cls._memo_key(name, args)
+                if key is not None:
+                    hit = memo.get(key)
+                    if hit is not None and hit[0]._version == hit[1]:
+                        return hit[0]
+                    out = super().__torch_function__(func, types, args, {})
+                    if isinstance(out, torch.Tensor):
+                        memo[key] = (out, out._version, args)      # (the arguments stay alive: their ids are not reused)
+                    return out
         return super().__torch_function__(func, types, args, kwargs or {})
 
     def __bool__(self):
@@ -284,6 +319,7 @@ class LockStepState(PathExecutor):
         self.final_stats = None
         # what Model._traces_lockstep needs to recognise a program whose whole call is ONE draw + ONE fused pass (launch plan,
         # model.py): the number of flushes, where every deferred term's value came from, anything that read a draw early
+        self.memo = {} if os.environ.get('PP_IS_MEMO', '1') != '0' else None     # ParticleTensor._PURE results of this call
         self.flushes = 0
         self.plan_terms = []          # (term, source, scale): source = ('obs', name) | ('value',) | ('const', tensor)
         self.plan_ok = True

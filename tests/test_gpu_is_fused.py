@@ -214,3 +214,41 @@ def test_launch_plan_is_not_replayed_when_constants_follow_the_observation(monke
     monkeypatch.setenv('PP_IS_PLAN', '1')
     again = model.posterior_results(n, IC, observe={'obs0': 8.0, 'obs1': 9.0}, lock_step=True, seed=99)
     assert getattr(again, 'replayed_plan', False)      # the SAME observation as the last recording: its constants are right
+
+
+class MarsagliaInPlace(GaussianWithUnknownMeanMarsagliaLockStep):
+    """The rejection loop with IN-PLACE arithmetic on intermediate results (`s += y * y`): a reused (memoised) result that the
+    program then modifies must not be handed out again as the product it once was."""
+
+    def marsaglia(self, mean, stddev):
+        import pyprob_amd as pyprob
+        from pyprob_amd.distributions import Uniform
+        uniform = Uniform(-1, 1)
+        s = 1
+        while s >= 1:
+            x = pyprob.sample(uniform)
+            y = pyprob.sample(uniform)
+            s = x * x
+            s += y * y
+        return mean + stddev * (x * torch.sqrt(-2 * torch.log(s) / s))
+
+
+@pytest.mark.parametrize('program', ['plain', 'inplace'])
+def test_reusing_pure_results_across_control_flow_paths_changes_nothing(gumm, monkeypatch, program):
+    """ParticleTensor memoisation (state.py): every path re-runs forward(); the arithmetic of its replayed iterations is served
+    from the results of earlier paths. Values, log-weights, paths and statistics equal a run that recomputes everything."""
+    model = gumm
+    if program == 'inplace':
+        torch.manual_seed(4)
+        model = MarsagliaInPlace()
+        model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=20000, observe_embeddings=EMB, batch_size=128,
+                                      lstm_dim=64, seed=2)
+    obs = {'obs0': 4, 'obs1': 5}
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PP_IS_MEMO', flag)
+        outs.append(model.posterior_results(30000, IC, observe=obs, lock_step=True, seed=21))
+    a, b = outs
+    assert a.num_paths == b.num_paths > 3
+    assert torch.equal(a._all_values, b._all_values) and torch.equal(a._all_log_weights, b._all_log_weights)
+    assert a.mean == b.mean and a.effective_sample_size == b.effective_sample_size
