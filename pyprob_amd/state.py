@@ -160,7 +160,7 @@ class ParticleTensor(torch.Tensor):
     # Pure elementwise operators whose results the lock-step executor may REUSE within one posterior call: every control-flow
     # path re-runs forward() from the top, so a path at depth d recomputes the arithmetic of its d - 1 replayed iterations on
     # full-width tensors (`x * x + y * y`, `s >= 1` ...: O(d^2) launches per call, each ~5 us of interpreter + dispatch). The
-    # result of such an operator is a function of its inputs' contents only; it is kept under (operator, identity + version of
+    # result of such an operator is a function of its inputs' contents only; it is kept under (operator, storage address + version of
     # every tensor argument, scalar arguments) and handed out again while the result itself has not been modified
     # (`Tensor._version` counts in-place writes of inputs and results alike).
     _PURE = frozenset(('add', 'sub', 'mul', 'div', 'true_divide', 'neg', 'pow', 'sqrt', 'rsqrt', 'log', 'log1p', 'log2', 'exp', 'expm1',
@@ -173,7 +173,8 @@ class ParticleTensor(torch.Tensor):
         key = [name]
         for a in args:
             if isinstance(a, torch.Tensor):
-                key.append((id(a), a._version))
+                # storage identity, not object identity: a replayed statement hands out a NEW wrapper of the recorded values
+                key.append((a.data_ptr(), a.numel(), a.dtype, a._version))
             elif isinstance(a, (bool, int, float)):
                 key.append(('s', type(a).__name__, a))
             else:
