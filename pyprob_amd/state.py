@@ -170,6 +170,11 @@ class ParticleTensor(torch.Tensor):
 
     @staticmethod
     def _memo_key(name, args):
+        with torch._C.DisableTorchFunctionSubclass():      # (metadata reads: no Python dispatch per attribute of a ParticleTensor)
+            return ParticleTensor._memo_key_plain(name, args)
+
+    @staticmethod
+    def _memo_key_plain(name, args):
         key = [name]
         for a in args:
             if isinstance(a, torch.Tensor):
@@ -196,11 +201,15 @@ class ParticleTensor(torch.Tensor):
                 key = cls._memo_key(name, args)
                 if key is not None:
                     hit = memo.get(key)
-                    if hit is not None and hit[0]._version == hit[1]:
-                        return hit[0]
+                    if hit is not None:
+                        with torch._C.DisableTorchFunctionSubclass():
+                            fresh = hit[0]._version == hit[1]
+                        if fresh:
+                            return hit[0]
                     out = super().__torch_function__(func, types, args, {})
                     if isinstance(out, torch.Tensor):
-                        memo[key] = (out, out._version, args)      # (the arguments stay alive: their ids are not reused)
+                        with torch._C.DisableTorchFunctionSubclass():
+                            memo[key] = (out, out._version, args)      # (the arguments stay alive: their storage is not reused)
                     return out
         return super().__torch_function__(func, types, args, kwargs or {})
 
