@@ -44,6 +44,7 @@ def main():
         rows = [r for rs in ex.map(lambda s: remarks(s, tmp), B.SOURCES) for r in rs]
     names = demangle([r['name'] for r in rows])
     for r, n in zip(rows, names):
+        n = n.replace('(anonymous namespace)::', '')      # (a '(' inside the name would otherwise cut it off below)
         n = re.sub(r'\(.*$', '', n).replace('void ', '').replace('pp::', '')
         r['short'] = n
     rows.sort(key=lambda r: (r['file'], r['short']))
