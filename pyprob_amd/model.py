@@ -151,7 +151,20 @@ class Model:
         eng = getattr(net, '_engine', None)
         if eng is None or eng.device.type != 'cuda':
             return None
-        plain = tuple(sorted((k, v) for k, v in vars(self).items() if isinstance(v, (bool, int, float, str))))
+        # every public attribute of the model enters the key by VALUE (a program reads them: a changed prior mean must not meet
+        # a plan recorded with the old one); an attribute whose value cannot be fingerprinted cheaply rules the plan out
+        plain = []
+        for k, v in sorted(vars(self).items()):
+            if k.startswith('_') or v is None or callable(v):
+                continue
+            if isinstance(v, (bool, int, float, str)):
+                plain.append((k, v))
+            elif isinstance(v, (torch.Tensor, np.ndarray)) and int(np.prod(tuple(v.shape))) <= 16 and \
+                    (not isinstance(v, torch.Tensor) or v.device.type == 'cpu'):
+                plain.append((k, tuple(float(x) for x in np.asarray(v, dtype=np.float64).reshape(-1))))
+            else:
+                return None
+        plain = tuple(plain)
         fwd = getattr(self.forward, '__func__', self.forward)
         return (id(eng), len(eng.spec.addresses), int(num_traces), tuple(sorted(observe or {})), float(likelihood_importance), plain,
                 id(getattr(fwd, '__code__', fwd)))
