@@ -204,8 +204,11 @@ struct FusedArgs {
 
 extern __shared__ __attribute__((aligned(1024))) float fused_lds[];
 
-// KIND 0 / 1 / 2: mixture heads (is_draw.hpp), drawn in the tail; 3: head outputs only
-template <int UB, int KIND>
+// KIND 0 / 1 / 2: mixture heads (is_draw.hpp), drawn in the tail; 3: head outputs only. SHARED: every particle's previous state is
+// one shared row (no per-particle recurrent product) - a template parameter, not a runtime branch: with both K-loop variants in
+// one function the 128 accumulator registers met at a control-flow join in different physical registers and the compiler
+// shuffled all of them and spilled 32 (8 KB of scratch traffic per particle in the PMC passes of the first version)
+template <int UB, int KIND, bool SHARED>
 __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     constexpr int H = 256 * UB;
     constexpr int NSH = H / 8;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         if (REFILL) BUF[blk] = load_blk(SN, blk);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
-    const int NS = a.state_shared ? 0 : NSH;   // shared state: h W_hh^T is one row for everybody, part of the bias
+    constexpr int NS = SHARED ? 0 : NSH;   // shared state: h W_hh^T is one row for everybody, part of the bias
     f32x4 b0[NB], b1[NB], a0, a1, a2, a3;
     // item 0 of the stream: the sample embedding of the previous value, k = 4 hh + j < smp_dim (embedding_feedforward.py: one
     // Linear + ReLU; gather.hpp sample_embed_elem: a Linear(1, smp_dim) of the value, or a row of the one-hot
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
             a0[j] = (4 * hh + j < a.smp) ? relu_keep_nan(e) : 0.0f;
         }
     }
-    if (NS) {
+    if constexpr (NS != 0) {
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) b1[blk] = load_blk(0, blk);
         a1 = load_a(0);
@@ -302,44 +305,61 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         FUSED_SLAB(a0, b0, false, 0)
     }
 #undef FUSED_SLAB
+    // Gate activations in place on the accumulators, before the barrier (a wave that is early does them while it would wait):
+    // acc[i] <- sigmoid(i) tanh(g), acc[f] <- sigmoid(f), acc[o] <- sigmoid(o); the g accumulators are dead afterwards, which is
+    // what keeps the cell phase below the register budget
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float gi = fast_sigmoid(acc[0 * UB + ub][r]);
+            const float gg = fast_tanh(acc[2 * UB + ub][r]);
+            acc[0 * UB + ub][r] = gi * gg;
+            acc[1 * UB + ub][r] = fast_sigmoid(acc[1 * UB + ub][r]);
+            acc[3 * UB + ub][r] = fast_sigmoid(acc[3 * UB + ub][r]);
+        }
     FUSED_STAMP(1);    // K loop done
     __syncthreads();   // every wave has read the old h rows of the panel (and sRow is visible)
     FUSED_STAMP(2);
 
     // ---- LSTM cell on the accumulators (torch.nn.LSTM gate order i, f, g, o) ----
-    // (all loads of the old cell state first: the stores below go through the same pointer and would pin every load behind
-    // the previous store)
-    const float* cprev = a.state_shared ? a.c0 : a.c;
-    float cp[UB][16];
+    // Two passes over the accumulator rows (r < 8, r >= 8): a pass's loads of the old cell state are issued together and BEFORE
+    // its stores (which go through the same pointer and would pin every later load behind them); 32-bit element offsets keep
+    // the address registers at one per row (state buffers of up to 2^32 elements: 8 M particles at H = 512).
+    const float* cprev = SHARED ? a.c0 : a.c;
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub) {
-        const int u = (wave * UB + ub) * 32 + c31;
+    for (int half = 0; half < 2; ++half) {
+        uint32_t off[8];
+        float cp[UB][8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * half + q;
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            cp[ub][r] = cprev[a.state_shared ? (int64_t)u : (int64_t)sRow[row] * H + u];
+            off[q] = (uint32_t)sRow[row] * (uint32_t)H;
         }
-    }
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub) {
-        const int u = (wave * UB + ub) * 32 + c31;
-        // A fragments of v_mfma_f32_16x16x4_f32 for head layer 1: [16-k slab u / 16][row block][k group (u / 4) % 4][row % 16][u % 4]
-        const int hslot = ((u >> 4) * 128 + ((u >> 2) & 3) * 16) * 4 + (u & 3);
+        for (int ub = 0; ub < UB; ++ub) {
+            const uint32_t u = (uint32_t)((wave * UB + ub) * 32 + c31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float gi = fast_sigmoid(acc[0 * UB + ub][r]);
-            const float gf = fast_sigmoid(acc[1 * UB + ub][r]);
-            const float gg = fast_tanh(acc[2 * UB + ub][r]);
-            const float go = fast_sigmoid(acc[3 * UB + ub][r]);
-            const float cn = gf * cp[ub][r] + gi * gg;
-            const float hn = go * fast_tanh(cn);
-            if (m0 + row < a.n) {
-                const int64_t ro = (int64_t)sRow[row] * H + u;
-                a.c[ro] = cn;
-                a.h[ro] = hn;
+            for (int q = 0; q < 8; ++q) cp[ub][q] = cprev[SHARED ? u : off[q] + u];
+        }
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) {
+            const int u = (wave * UB + ub) * 32 + c31;
+            // A fragments of v_mfma_f32_16x16x4_f32 for head layer 1: [16-k slab u / 16][row block][k group (u / 4) % 4][row % 16][u % 4]
+            const int hslot = ((u >> 4) * 128 + ((u >> 2) & 3) * 16) * 4 + (u & 3);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * half + q;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float cn = acc[1 * UB + ub][r] * cp[ub][q] + acc[0 * UB + ub][r];
+                const float hn = acc[3 * UB + ub][r] * fast_tanh(cn);
+                if (m0 + row < a.n) {
+                    a.c[off[q] + (uint32_t)u] = cn;
+                    a.h[off[q] + (uint32_t)u] = hn;
+                }
+                sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hn;
             }
-            sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hn;
         }
     }
     FUSED_STAMP(3);    // cell done
@@ -528,11 +548,11 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
 #undef FUSED_STAMP
 }
 
-template <int UB, int KIND>
-int launch_fused(const FusedArgs& a, size_t lds, hipStream_t st) {
+template <int UB, int KIND, bool SHARED>
+int launch_fused_s(const FusedArgs& a, size_t lds, hipStream_t st) {
     static bool raised = false;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&is_step_fused_kernel<UB, KIND>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&is_step_fused_kernel<UB, KIND, SHARED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_error("pp_is_step: cannot raise the LDS limit of the fused statement kernel: %s", hipGetErrorString(e));
@@ -540,8 +560,12 @@ int launch_fused(const FusedArgs& a, size_t lds, hipStream_t st) {
         }
         raised = true;
     }
-    hipLaunchKernelGGL((is_step_fused_kernel<UB, KIND>), dim3(cdiv(a.n, FR)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((is_step_fused_kernel<UB, KIND, SHARED>), dim3(cdiv(a.n, FR)), dim3(512), lds, st, a);
     return 0;
+}
+template <int UB, int KIND>
+int launch_fused(const FusedArgs& a, size_t lds, hipStream_t st) {
+    return a.state_shared ? launch_fused_s<UB, KIND, true>(a, lds, st) : launch_fused_s<UB, KIND, false>(a, lds, st);
 }
 
 static inline int64_t round256(int64_t x) { return (x + 255) & ~int64_t(255); }
