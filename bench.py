@@ -329,12 +329,29 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         # the shared first state has no per-particle recurrent product: 2 I 4H + head)
         us = float(ms[:cnt.value].sum()) * 1e3 / calls
         flops = float(fl[:cnt.value].sum()) / calls
+        # what the kernel EXECUTES per particle-statement (it multiplies H + 8 of the H + 212 input columns: the rest is one shared
+        # row, folded into a bias; head layers on 16- / 8-padded widths): a launch on the shared first state is recognised by
+        # its work = particles per call x the shared-state figure
+        H_, I_ = lstm_dim, 64 + 4 + 2 * (64 + 8)
+        hid_, nout_ = int((H_ + 30) / 2), 30
+        head_alg = 2.0 * (H_ * hid_ + hid_ * nout_)
+        alg_ns, alg_sh = 2.0 * (I_ + H_) * 4 * H_ + head_alg, 2.0 * I_ * 4 * H_ + head_alg
+        head_exe = 2.0 * H_ * 16 * ((hid_ + 15) // 16) + 2.0 * 8 * ((hid_ + 7) // 8) * 32
+        exe_ns, exe_sh = 2.0 * (H_ + 8) * 4 * H_ + head_exe, 2.0 * 8 * 4 * H_ + head_exe
+        executed = 0.0
+        for w in fl[:cnt.value]:
+            shared_launch = abs(w - particles * alg_sh) < 0.5 * alg_sh
+            executed += (w / alg_sh) * exe_sh if shared_launch else (w / alg_ns) * exe_ns
+        executed /= calls
         prof, note = committed_profile('r04_is_pmc_traffic.json')
         tr = (prof or {}).get('kernels', {}).get('is_step_fused', {})
         rec['statement_kernel'] = dict(
             bound='mfma', achieved=round(flops / (us * 1e-6) / 1e12, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
             frac=round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), us_per_call=round(us, 1),
-            launches_per_call=round(cnt.value / calls, 2), flops_per_call=flops,
+            launches_per_call=round(cnt.value / calls, 2), flops_per_call=flops, executed_flops_per_call=executed,
+            frac_executed=round(executed / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+            frac_note='frac prices the reference algorithm\'s FLOPs (SURVEY.md 8d: all 212 input columns per particle) - the kernel '
+                      'multiplies 8 of them per particle, so this fraction can exceed 1; frac_executed prices what runs on the MFMA pipe',
             traffic=tr.get('traffic_bytes_per_particle_statement'), algorithmic_bytes=tr.get('algorithmic_bytes_per_particle_statement'),
             traffic_source=note,
             kernel='is_step_fused_kernel (one launch per statement after the first: [s_prev | h] [W_s | W_hh]^T + bias on '
@@ -742,8 +759,8 @@ def main():
                                                            'control_flow_paths', 'ess', 'posterior_mean') if k in g1m}
             if 'statement_kernel' in g1m:
                 out['gumm_lockstep_1m']['statement_kernel'] = {k: g1m['statement_kernel'][k] for k in
-                                                               ('achieved', 'frac', 'us_per_call', 'launches_per_call',
-                                                                'wall_over_statement_kernels')}
+                                                               ('achieved', 'frac', 'frac_executed', 'us_per_call',
+                                                                'launches_per_call', 'wall_over_statement_kernels')}
     elif args.workload == 'train_gumm':
         # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
         # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded
