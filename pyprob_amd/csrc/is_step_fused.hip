@@ -294,6 +294,11 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
             FUSED_SLAB(a1, b1, true, it + 2)
             a0 = a2;
             a1 = a3;
+            // Not for data (the K loop shares nothing): the barrier keeps the two waves of a SIMD in step. Left alone, the older
+            // wave wins every issue arbitration, finishes its K loop at 0.55 of the pair's time and the younger one runs the rest
+            // by itself with nothing to hide its load latency behind (K loop 312 k cycles; with the barrier both take 287 k of
+            // 266 k of MFMA time; one barrier per slab instead of per two: the same; s_setprio per slab: no effect)
+            __builtin_amdgcn_s_barrier();
         }
         a2 = load_a(NS - 1);                      // it == NS - 2: items NS - 2, NS - 1, NS remain
         __builtin_amdgcn_sched_barrier(0);
