@@ -486,6 +486,16 @@ class InferenceNetworkLSTM:
             # pp_train_steps gets its data-parallel branch (every rank agrees on the outcome; otherwise torch.distributed)
             from .parallel import init_native_comm
             self._engine.native_dp = bool(init_native_comm(self._engine.device))
+        if world > 1:
+            # dL/dW_hh is zero on a rank whose traces all have one controlled variable: when EVERY rank finds that in its own
+            # dataset (packed datasets know their trace lengths; an online generator does not) the range leaves the gradient
+            # all-reduce (ICEngine.agree_skip_recurrent: one MIN-all-reduce of the per-rank finding, bit-identical parameters)
+            lens = getattr(dataset, 'trace_len', None)
+            try:
+                single = lens is not None and len(lens) > 0 and int(np.max(lens)) == 1
+            except (TypeError, ValueError):
+                single = False
+            self._engine.agree_skip_recurrent(bool(single))
         if self._learning_rate_init is None:
             self._learning_rate_init = learning_rate_init * math.sqrt(world)            # :448
         if self._learning_rate_end is None:
