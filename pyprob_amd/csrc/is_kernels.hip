@@ -740,8 +740,13 @@ struct FusedTerms {
     int count;
 };
 
-template <int KIND>      // -1: no draw (values are read), 0 / 1 / 2: mixture head kinds as is_mixture_shared_kernel
-__global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restrict__ y, const float* __restrict__ prior, int n, int K,
+// LEAN: every term is a Normal with ONE scale for all particles (or the identity) - the terms of a program whose observes are
+// Normal(f(latent), sigma): the term loop is then a handful of instructions instead of eight unrolled copies of the general
+// log-prob switch (9 600 lines of ISA, 128 VGPRs and two spilled quads for the general kernel).
+// KC: the number of mixture components as a compile-time constant (10, pyprob's default - nn/proposal_*_mixture.py
+// mixture_components = 10), 0 = read K: with KC the component loops are straight-line code without the sixteen k < K guards.
+template <int KIND, bool LEAN, int KC = 0>      // KIND -1: no draw (values are read), 0 / 1 / 2: mixture head kinds as is_mixture_shared_kernel
+__global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restrict__ y, const float* __restrict__ prior, int n, int K_rt,
                                                        const FusedTerms terms, float* __restrict__ value,
                                                        float* __restrict__ lw, int overwrite, uint64_t seed, uint64_t offset,
                                                        double* __restrict__ scratch) {
@@ -749,20 +754,28 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
     __shared__ float shmax[4];
     __shared__ double sh[4][5];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int K = KC ? KC : K_rt;
     float pa = 0.0f, pb = 1.0f;
     if (KIND >= 0) {
         pa = prior[0]; pb = prior[1];
-        if (tid < MAXK) {      // the proposal's components: same arithmetic as is_mixture_shared_kernel
-            const int k = tid;
+        if (wave == 0) {       // the proposal's components: the arithmetic (and summation order) of is_mixture_shared_kernel, the
+            const int k = lane;   // softmax terms computed ONCE - lane j holds term j, the sums walk the lanes in order
+            const float z = k < K ? y[2 * K + k] : -INFINITY;
             float zmax = -INFINITY;
-            for (int j = 0; j < K; ++j) zmax = fmaxf(zmax, y[2 * K + j]);
+            for (int j = 0; j < K; ++j) zmax = fmaxf(zmax, __shfl(z, j, 64));
+            const float e = k < K ? expf(z - zmax) : 0.0f;
             float zs = 0.0f;
-            for (int j = 0; j < K; ++j) zs += expf(y[2 * K + j] - zmax);
-            float ps = 0.0f, cum = 0.0f;
-            for (int j = 0; j < K; ++j) ps += expf(y[2 * K + j] - zmax) / zs;
-            for (int j = 0; j <= k && j < K; ++j) cum += (expf(y[2 * K + j] - zmax) / zs) / ps;
+            for (int j = 0; j < K; ++j) zs += __shfl(e, j, 64);
+            const float q = e / zs;
+            float ps = 0.0f;
+            for (int j = 0; j < K; ++j) ps += __shfl(q, j, 64);
+            const float pk = q / ps;
+            float cum = 0.0f;
+            for (int j = 0; j < K; ++j) {
+                const float rj = __shfl(pk, j, 64);
+                if (j <= k) cum += rj;
+            }
             if (k < K) {
-                const float pk = (expf(y[2 * K + k] - zmax) / zs) / ps;
                 float mu, sd;
                 if (KIND == 0) {
                     mu = pa + y[k] * pb;
@@ -784,15 +797,13 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
                 }
             }
         }
-        __syncthreads();
     }
-    // Normal terms whose scale is one number for all particles: their constants once per workgroup (LDS). The term loop is
-    // NOT unrolled: eight unrolled copies kept ~100 scalar term fields live and spilled them into vector registers
-    // (189 VGPRs, two waves per SIMD for a latency-bound kernel).
+    // Normal terms whose scale is one number for all particles: their constants once per workgroup (LDS; by the second wave,
+    // next to the first wave's softmax - one barrier for both).
     __shared__ float s_tc0[FUSED_MAX_TERMS], s_tc1[FUSED_MAX_TERMS];
     __shared__ int s_tcok[FUSED_MAX_TERMS];
-    if (tid < FUSED_MAX_TERMS) {
-        const int t = tid;
+    if (tid >= 64 && tid < 64 + FUSED_MAX_TERMS) {
+        const int t = tid - 64;
         s_tcok[t] = 0; s_tc0[t] = 0.0f; s_tc1[t] = 0.0f;
         if (t < terms.count && terms.t[t].kind == 0 && !(terms.t[t].flags & 2) && terms.t[t].s1 == 0) {
             const float b = terms.t[t].p1[0];
@@ -819,8 +830,14 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
                 rng.next(r);
                 const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]);
                 int kk = K - 1;
-                for (int k = K - 2; k >= 0; --k)
-                    if (u0 < s_cum[k]) kk = k;
+                if (KC) {
+#pragma unroll
+                    for (int k = KC - 2; k >= 0; --k)
+                        if (u0 < s_cum[k]) kk = k;
+                } else {
+                    for (int k = K - 2; k >= 0; --k)
+                        if (u0 < s_cum[k]) kk = k;
+                }
                 const float mk = s_mu[kk], sk = s_sd[kk];
                 if (KIND == 0) {
                     v = mk + sk * box_muller_fast(u1, u2);
@@ -852,6 +869,18 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
             acc -= lq;                 // - log q(v)   (state.py:212, 217)
             value[i] = v;
         }
+        if (LEAN) {
+#pragma unroll 1
+            for (int t = 0; t < terms.count; ++t) {
+                const FusedTerm& T = terms.t[t];
+                float lp = (T.flags & 4) ? v : T.x[(int64_t)i * T.sx];
+                if (T.kind == 0) {
+                    const float d = lp - ((T.flags & 1) ? v : T.p0[(int64_t)i * T.s0]);
+                    lp = s_tc0[t] - d * d * s_tc1[t];
+                }
+                acc += T.scale * lp;
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < FUSED_MAX_TERMS; ++t) {
             if (t >= terms.count) break;
@@ -1034,6 +1063,7 @@ int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prio
     if (n <= 0) return 0;
     pp::FusedTerms t;
     t.count = n_terms;
+    bool lean = true;       // Normal terms with one scale for all particles (is_fused_kernel's LEAN term loop)
     for (int q = 0; q < n_terms; ++q) {
         const pp_lw_term& s = terms[q];
         const int fl = term_flags ? term_flags[q] : 0;
@@ -1044,15 +1074,27 @@ int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prio
             return PP_EINVAL;
         }
         t.t[q] = pp::FusedTerm{s.kind, s.p0_stride, s.p1_stride, s.x_stride, fl, s.p0, s.p1, s.x, s.scale};
+        lean = lean && (s.kind == 2 || (s.kind == 0 && !(fl & 2) && s.p1_stride == 0));
     }
     const int tile = 256 * pp::FUSED_PT;
     const int blocks = std::min(pp::FUSED_BLOCKS, pp::cdiv(n, tile));
     hipStream_t st = pp::as_stream(stream);
     double* scratch = stats_out ? stats_scratch : nullptr;
     pp::prof_begin(4, st);
+#define PP_FUSED_LAUNCH(KIND, Y, PRIOR, KK)                                                                                  \
+    do {                                                                                                                     \
+        if (lean && KK == 10 && (KIND == 0 || KIND == 1))                                                                    \
+            hipLaunchKernelGGL((pp::is_fused_kernel<KIND, true, (KIND == 0 || KIND == 1) ? 10 : 0>), dim3(blocks), dim3(256), 0, st, Y,  \
+                               PRIOR, n, KK, t, value, lw, overwrite, seed, offset, scratch);                               \
+        else if (lean)                                                                                                       \
+            hipLaunchKernelGGL((pp::is_fused_kernel<KIND, true>), dim3(blocks), dim3(256), 0, st, Y, PRIOR, n, KK, t, value, lw,  \
+                               overwrite, seed, offset, scratch);                                                            \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((pp::is_fused_kernel<KIND, false>), dim3(blocks), dim3(256), 0, st, Y, PRIOR, n, KK, t, value, lw, \
+                               overwrite, seed, offset, scratch);                                                            \
+    } while (0)
     if (addr_id < 0) {
-        hipLaunchKernelGGL(pp::is_fused_kernel<-1>, dim3(blocks), dim3(256), 0, st, nullptr, nullptr, n, 0, t, value, lw, overwrite,
-                           seed, offset, scratch);
+        PP_FUSED_LAUNCH(-1, nullptr, nullptr, 0);
     } else {
         if (!(net && prior && workspace) || addr_id >= net->n_addr) {
             pp::set_error("pp_is_fused: a draw needs the network, the prior parameters and the workspace of pp_is_step_net");
@@ -1072,15 +1114,13 @@ int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prio
         }
         const int K = ad.n_out / 3;
         if (ad.kind == PP_HEAD_NORMAL_MIXTURE)
-            hipLaunchKernelGGL(pp::is_fused_kernel<0>, dim3(blocks), dim3(256), 0, st, w.Y, prior, n, K, t, value, lw, overwrite, seed,
-                               offset, scratch);
+            PP_FUSED_LAUNCH(0, w.Y, prior, K);
         else if (ad.kind == PP_HEAD_TRUNCNORMAL_MIXTURE)
-            hipLaunchKernelGGL(pp::is_fused_kernel<1>, dim3(blocks), dim3(256), 0, st, w.Y, prior, n, K, t, value, lw, overwrite, seed,
-                               offset, scratch);
+            PP_FUSED_LAUNCH(1, w.Y, prior, K);
         else
-            hipLaunchKernelGGL(pp::is_fused_kernel<2>, dim3(blocks), dim3(256), 0, st, w.Y, prior, n, K, t, value, lw, overwrite, seed,
-                               offset, scratch);
+            PP_FUSED_LAUNCH(2, w.Y, prior, K);
     }
+#undef PP_FUSED_LAUNCH
     pp::prof_end(4, 8.0 * n, st);
     if (stats_out)
         hipLaunchKernelGGL(pp::is_stats_combine_kernel, dim3(1), dim3(256), 0, st, stats_scratch, blocks, stats_out);

@@ -19,7 +19,8 @@
 // Operands: the weights are re-tiled ONCE per call (is_prep_kernel) into "fragment images": for k-slab s (8 k), wave w,
 // block b one contiguous KB holding, for lane l = (column c = l & 31, half hh = l >> 5), the four k values 8 s + 4 hh + j of
 // its column - exactly the B operand of four consecutive MFMAs. A wave streams ITS blocks with one coalesced 16-byte load
-// per lane and block straight into VGPRs (no LDS, no barrier in the K loop, a two-slab register ring); the A fragment
+// per lane and block straight into VGPRs (no LDS for the weights, a two-slab register ring refilled behind the MFMAs;
+// the one s_barrier per two slabs of the K loop orders no data, it keeps the two waves of a SIMD in step); the A fragment
 // (four k of the lane's particle row) is one 16-byte load per slab from the particle's h row (an optional row index list
 // gathers the rows of a diverged control-flow path in place). h and c are updated in place: a barrier separates the last
 // read of the old h rows from the first store.
