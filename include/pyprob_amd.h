@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 10
+#define PP_ABI_VERSION 11
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -417,6 +417,28 @@ int pp_is_statement_rows(const pp_net* net, const float* params, int32_t addr_id
 int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,
                             const float* x, int32_t x_stride, float scale, float* lw /*dev [n]*/, float* lp_out,
                             int32_t n, void* stream);
+
+/* The same term for the particles of ONE control-flow path of a lock-step run (the reference scores one trace at a time,
+ * state.py:147-149, 211-217; a path is the set of particles that took the same branches):
+ *     lw[r] += scale * log_prob(dist(params_r); x_r)   for r = rows[j], j < m
+ * rows: dev int64 [m], ascending particle indices; strides as above (1 = indexed by the particle, not by j). */
+int pp_logweight_accumulate_rows(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,
+                                 const float* x, int32_t x_stride, float scale, float* lw /*dev [n]*/,
+                                 const int64_t* rows, int32_t m, void* stream);
+
+/* dst[r] = src[r * src_stride] for r = rows[j], j < m (src_stride 0: one shared value): what a path's execution of the program
+ * returned, into the call's per-particle result vector (model.py:66-74 collects one trace's result at a time). */
+int pp_copy_rows(const float* src, int32_t src_stride, float* dst /*dev [n]*/, const int64_t* rows, int32_t m, void* stream);
+
+/* A branch of the program taken per particle (`while s >= 1:` - the reference runs the Python condition per trace): stable
+ * partition of a path's rows by a condition byte per particle.
+ *   cond: dev uint8 [n] (torch.bool storage), indexed by the PARTICLE; rows: dev int64 [m] ascending, or NULL = particles 0..m-1
+ *   rows_true / rows_false: dev int64 [m] each; the first counts[0] / counts[1] entries are written, ascending
+ *   counts: dev int32 [2] = { rows whose condition is non-zero, the others };  scratch: dev int32 [PP_PARTITION_SCRATCH(m)]
+ * Two launches, no host synchronisation (the caller reads `counts` when it needs the decision). */
+#define PP_PARTITION_SCRATCH(m) (((m) + 1023) / 1024 + 1)
+int pp_partition_rows(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
+                      int32_t* counts, int32_t* scratch, void* stream);
 
 /* Up to four log-weight terms in ONE pass over the particles:
  *   lw[i] (+)= sum_t scale_t * term_t(i);  kind as in pp_logweight_accumulate, or 2: the value x itself (e.g. -log q)

@@ -595,6 +595,105 @@ __global__ __launch_bounds__(256) void logweight_kernel(int kind, const float* _
     if (lw) lw[i] += scale * lp;
 }
 
+// The same for the particles of a diverged control-flow path: lw[r] += scale * log_prob(dist(p0_r, p1_r); x_r), r = rows[j]
+// (one launch on m rows instead of log_prob over all n particles + zeros + where + add).
+__global__ __launch_bounds__(256) void logweight_rows_kernel(int kind, const float* __restrict__ p0, int s0,
+                                                             const float* __restrict__ p1, int s1,
+                                                             const float* __restrict__ x, int sx, float scale,
+                                                             float* __restrict__ lw, const int64_t* __restrict__ rows, int m) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int i = (int)rows[j];
+    lw[i] += scale * term_log_prob(kind, p0, s0, p1, s1, x[(int64_t)i * sx], i);
+}
+
+// dst[r] = src[r * stride], r = rows[j]: what a path returns (or a shared scalar, stride 0) into the call's result vector
+__global__ __launch_bounds__(256) void rows_copy_kernel(const float* __restrict__ src, int stride, float* __restrict__ dst,
+                                                        const int64_t* __restrict__ rows, int m) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int64_t i = rows[j];
+    dst[i] = src[i * stride];
+}
+
+// ---- a branch of the lock-step executor: the rows of a path split by a per-particle condition ------------------------------
+// (PathExecutor.branch: `while s >= 1:` on the particles of a path.) Stable partition of the path's rows - all particles when
+// `rows` is null - into those whose condition byte is non-zero and the others, both in ascending order, and the two counts:
+// two launches and ONE 8-byte read-back where torch spent a masked sum + .item(), and two nonzero() (four launches and a
+// synchronisation each). Tile = 1024 rows per workgroup; a thread owns 4 consecutive rows.
+constexpr int PART_TILE = 1024;
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void partition_count_kernel(const uint8_t* __restrict__ cond, const int64_t* __restrict__ rows, int m,
+                                                              int32_t* __restrict__ block_true) {
+    __shared__ int sh[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j0 = blockIdx.x * PART_TILE + tid * 4;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (j < m) c += cond[rows ? rows[j] : (int64_t)j] != 0;
+    }
+    c = wave_sum_int(c);
+    if (lane == 0) sh[wave] = c;
+    __syncthreads();
+    if (tid == 0) block_true[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void partition_scatter_kernel(const uint8_t* __restrict__ cond, const int64_t* __restrict__ rows, int m,
+                                                                const int32_t* __restrict__ block_true, int64_t* __restrict__ rows_true,
+                                                                int64_t* __restrict__ rows_false, int32_t* __restrict__ counts) {
+    __shared__ int sh[4], shw[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    // true rows in the tiles before this one (the last workgroup also sums its own: the totals)
+    int before = 0;
+    for (int q = tid; q < b; q += 256) before += block_true[q];
+    before = wave_sum_int(before);
+    if (lane == 0) sh[wave] = before;
+    __syncthreads();
+    before = sh[0] + sh[1] + sh[2] + sh[3];
+    const int j0 = b * PART_TILE + tid * 4;
+    int64_t r[4];
+    int f[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        r[q] = j < m ? (rows ? rows[j] : (int64_t)j) : 0;
+        f[q] = j < m ? (cond[r[q]] != 0) : 0;
+        mine += f[q];
+    }
+    // exclusive prefix of `mine` over the workgroup's threads: inside the wave by shifts, across the waves through LDS
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) shw[wave] = incl;
+    __syncthreads();
+    int wave_before = 0;
+    for (int w = 0; w < wave; ++w) wave_before += shw[w];
+    int t_pos = before + wave_before + incl - mine;             // true rows before this thread's first row
+    int f_pos = (j0 - t_pos);                                   // false rows before it (every earlier row is one or the other)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (j0 + q >= m) break;
+        if (f[q]) rows_true[t_pos++] = r[q];
+        else rows_false[f_pos++] = r[q];
+    }
+    if (b == gridDim.x - 1 && tid == 255) {      // the last thread of the last tile has seen every row
+        const int total_true = before + wave_before + incl;
+        counts[0] = total_true;
+        counts[1] = m - total_true;
+    }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float scale, const float* __restrict__ t, float* __restrict__ lw, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) lw[i] += scale * t[i];
@@ -1139,6 +1238,50 @@ int pp_logweight_accumulate(int32_t kind, const float* p0, int32_t p0_stride, co
     hipLaunchKernelGGL(pp::logweight_kernel, dim3(pp::cdiv(n, 256)), dim3(256), 0, pp::as_stream(stream), kind, p0,
                        p0_stride, p1, p1_stride, x, x_stride, scale, lw, lp_out, n);
     PP_LAUNCH_CHECK("pp_logweight_accumulate");
+    return 0;
+}
+
+int pp_logweight_accumulate_rows(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride,
+                                 const float* x, int32_t x_stride, float scale, float* lw, const int64_t* rows, int32_t m,
+                                 void* stream) {
+    if (!(p0 && x && lw && rows) || !pp::lw_kind_ok(kind, p1, p1_stride) || kind == 2) {
+        pp::set_error("pp_logweight_accumulate_rows: bad argument");
+        return PP_EINVAL;
+    }
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(pp::logweight_rows_kernel, dim3(pp::cdiv(m, 256)), dim3(256), 0, pp::as_stream(stream), kind, p0, p0_stride,
+                       p1, p1_stride, x, x_stride, scale, lw, rows, m);
+    PP_LAUNCH_CHECK("pp_logweight_accumulate_rows");
+    return 0;
+}
+
+int pp_copy_rows(const float* src, int32_t src_stride, float* dst, const int64_t* rows, int32_t m, void* stream) {
+    if (!(src && dst && rows) || (src_stride != 0 && src_stride != 1)) {
+        pp::set_error("pp_copy_rows: bad argument");
+        return PP_EINVAL;
+    }
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(pp::rows_copy_kernel, dim3(pp::cdiv(m, 256)), dim3(256), 0, pp::as_stream(stream), src, src_stride, dst, rows, m);
+    PP_LAUNCH_CHECK("pp_copy_rows");
+    return 0;
+}
+
+int pp_partition_rows(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
+                      int32_t* counts, int32_t* scratch, void* stream) {
+    if (!(cond && rows_true && rows_false && counts && scratch) || m < 0) {
+        pp::set_error("pp_partition_rows: bad argument (scratch of PP_PARTITION_SCRATCH(m) int32 is required)");
+        return PP_EINVAL;
+    }
+    hipStream_t st = pp::as_stream(stream);
+    if (m == 0) {
+        (void)hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
+        return 0;
+    }
+    const int blocks = pp::cdiv(m, pp::PART_TILE);
+    hipLaunchKernelGGL(pp::partition_count_kernel, dim3(blocks), dim3(256), 0, st, cond, rows, m, scratch);
+    hipLaunchKernelGGL(pp::partition_scatter_kernel, dim3(blocks), dim3(256), 0, st, cond, rows, m, scratch, rows_true, rows_false,
+                       counts);
+    PP_LAUNCH_CHECK("pp_partition_rows");
     return 0;
 }
 

@@ -271,6 +271,45 @@ class ISRunner:
         lp = self.log_prob(term, x, lw.numel())
         lw.add_(torch.where(active, lp, torch.zeros_like(lp)), alpha=float(scale))
 
+    # ---- the particles of a control-flow path as a row list (LockStepState.by_rows): direct C-ABI calls ------------------------
+    def partition(self, cond, rows, m):
+        """A branch: split the path's rows (None: particles 0..m-1) by the bool [n] condition. Returns (rows where it holds,
+        the other rows, their counts) - ascending int64 device vectors; one synchronisation (the 8-byte count read-back)."""
+        buf = torch.empty(2 * max(m, 1), dtype=torch.int64, device=self.dev)
+        need = (m + 1023) // 1024 + 1
+        scratch = getattr(self, '_part_scratch', None)
+        if scratch is None or scratch.numel() < need:
+            scratch = self._part_scratch = torch.empty(max(need, 1024), dtype=torch.int32, device=self.dev)
+            self._part_counts = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        L.check(self.lib.pp_partition_rows(cond.data_ptr(), L.ptr(rows), int(m), buf.data_ptr(), buf.data_ptr() + 8 * m,
+                                           self._part_counts.data_ptr(), scratch.data_ptr(), L.stream_ptr()), 'pp_partition_rows')
+        n_true, n_false = self._part_counts.tolist()
+        return buf[:n_true], buf[m:m + n_false], n_true, n_false
+
+    def accumulate_rows(self, lw, term, x, rows, scale):
+        """lw[rows] += scale * log_prob(term; x[rows]) - one launch on the path's rows (pp_logweight_accumulate_rows)."""
+        kind, p0, s0, p1, s1 = term
+        x = x.as_subclass(torch.Tensor) if type(x) is not torch.Tensor else x
+        if x.dtype != torch.float32 or x.device != self.dev or not x.is_contiguous():
+            x = x.to(self.dev, torch.float32).contiguous()
+        for t in (p0, p1, x):
+            if t is not None and t.numel() not in (1, lw.numel()):
+                raise RuntimeError('lock-step log-weight term: tensors of 1 or n elements')
+        L.check(self.lib.pp_logweight_accumulate_rows(int(kind), L.ptr(p0), int(s0), L.ptr(p1), int(s1), x.data_ptr(),
+                                                      0 if x.numel() == 1 else 1, float(scale), lw.data_ptr(), rows.data_ptr(),
+                                                      int(rows.numel()), L.stream_ptr()), 'pp_logweight_accumulate_rows')
+
+    def copy_rows(self, src, dst, rows):
+        """dst[rows] = src[rows] (src: n values or one shared value), in place (pp_copy_rows)."""
+        src = src.as_subclass(torch.Tensor) if type(src) is not torch.Tensor else src
+        if src.dtype != torch.float32 or src.device != self.dev or not src.is_contiguous():
+            src = src.to(self.dev, torch.float32).contiguous()
+        if src.numel() not in (1, dst.numel()):
+            raise RuntimeError('copy_rows: a source of 1 or n elements')
+        L.check(self.lib.pp_copy_rows(src.data_ptr(), 0 if src.numel() == 1 else 1, dst.data_ptr(), rows.data_ptr(), int(rows.numel()),
+                                      L.stream_ptr()), 'pp_copy_rows')
+        torch.autograd.graph.increment_version(dst)       # written by the kernel: memoised results of it are stale
+
     def accumulate(self, lw, kind, p0, p1, x, scale=1.0, term=None):
         """lw += scale * log_prob(dist(p0, p1); x); p0/p1/x are device tensors of 1 (broadcast) or n elements."""
         if term is None:

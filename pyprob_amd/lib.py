@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 10
+PP_ABI_VERSION = 11
 PP_MAX_OBS = 8
 PP_MAX_LSTM_DEPTH = 4
 PP_MAX_OBS_DEPTH = 4
@@ -132,6 +132,9 @@ PROTOTYPES = {
     'pp_is_fused': (C.c_int, [C.POINTER(pp_net), i32, i32, vp, C.POINTER(pp_lw_term), C.POINTER(C.c_int32), i32, vp, vp, i32,
                               C.c_uint64, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),
     'pp_logweight_accumulate': (C.c_int, [i32, vp, i32, vp, i32, vp, i32, C.c_float, vp, vp, i32, vp]),
+    'pp_logweight_accumulate_rows': (C.c_int, [i32, vp, i32, vp, i32, vp, i32, C.c_float, vp, vp, i32, vp]),
+    'pp_copy_rows': (C.c_int, [vp, i32, vp, vp, i32, vp]),
+    'pp_partition_rows': (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'pp_logweight_terms': (C.c_int, [C.POINTER(pp_lw_term), i32, vp, i32, i32, vp]),
     'pp_axpy': (C.c_int, [C.c_float, vp, vp, i32, vp]),
     'pp_is_stats': (C.c_int, [vp, vp, i32, vp, vp, vp]),

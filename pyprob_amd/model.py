@@ -98,16 +98,19 @@ class Model:
                 if not torch.is_tensor(result):
                     raise RuntimeError('lock-step importance sampling: forward() must return a per-particle tensor')
                 last = not ls.pending           # no queued control-flow path: the statistics ride in this path's last pass
-                if last and ls.active is None and torch.is_tensor(result) and result.numel() == num_traces:
+                if last and ls.rows is None and torch.is_tensor(result) and result.numel() == num_traces:
                     ls.stats_values = result.as_subclass(torch.Tensor).reshape(-1)
                 ls.flush(final=last)            # the deferred draw / log-weight terms of this execution (one pass)
                 result = result.as_subclass(torch.Tensor).reshape(-1).to(runner.dev, torch.float32)
-                if ls.active is None:
+                if ls.rows is None:
                     values = result if result.numel() == num_traces else result.expand(num_traces).clone()
                 else:
                     if values is None:
                         values = torch.zeros(num_traces, dtype=torch.float32, device=runner.dev)
-                    values = torch.where(ls.active, result.expand(num_traces) if result.numel() == 1 else result, values)
+                    if ls.by_rows and result.numel() in (1, num_traces):
+                        runner.copy_rows(result.contiguous(), values, ls.rows)
+                    else:
+                        values = torch.where(ls.active, result.expand(num_traces) if result.numel() == 1 else result, values)
                 if not ls.next_path():
                     break
         finally:

@@ -356,7 +356,12 @@ class InferenceNetworkLSTM:
                 if draw.numel() == 1:     # shared prior: one draw per particle
                     draw = distribution._torch_dist.sample((ls.n,)).reshape(-1).float()
                 draw = draw.to(runner.dev)
-            values = draw if ls.active is None else torch.where(ls.active, draw, values)
+            if ls.rows is None:
+                values = draw
+            elif getattr(ls, 'by_rows', False):
+                runner.copy_rows(draw, values, ls.rows)      # (in place: the other paths' recorded values stay where they are)
+            else:
+                values = torch.where(ls.active, draw, values)
             while len(ls.log) <= j:
                 ls.log.append({})
             ls.log[j][address] = (values, spec.address_id.get(address))
@@ -370,7 +375,7 @@ class InferenceNetworkLSTM:
         ls.flush()        # an earlier deferred draw is this statement's previous value: it must exist now
         info = spec.addresses[a]
         prior_term = runner.dist_term(distribution)
-        if (ls.fused and ls.active is None and ls.prev_addr_id is None and prior_term is not None and prior is not None and
+        if (ls.fused and ls.rows is None and ls.prev_addr_id is None and prior_term is not None and prior is not None and
                 prior.numel() == 2 and
                 info.dist_name in ('Normal', 'Uniform', 'Poisson')):
             # First statement of a trace, full width: every particle has the same proposal. Only the network runs now; the
@@ -384,22 +389,22 @@ class InferenceNetworkLSTM:
             runner.prev_value = runner.last_value = values
             ls.prev_addr_id = a
             return ParticleTensor.wrap(values)
-        m_active = ls.n if ls.active is None else ls.n_active
+        m_active = ls.n if ls.rows is None else ls.n_active
         if distribution.name == info.dist_name and runner.whole_statement_ok(a, ls.prev_addr_id, m_active, info.dist_name, prior):
             # the whole statement in ONE launch: previous values read at the particles' rows, the draw written to values[rows],
             # lw[rows] += log p(v) - log q(v) (state.py:211-217) - no gather, scatter, prior or axpy launches around it
             entry = ls.log[j].get(address) if j < len(ls.log) else None
-            values = entry[0] if (entry is not None and ls.active is not None) else (
-                torch.zeros(ls.n, dtype=torch.float32, device=runner.dev) if ls.active is not None else
+            values = entry[0] if (entry is not None and ls.rows is not None) else (
+                torch.zeros(ls.n, dtype=torch.float32, device=runner.dev) if ls.rows is not None else
                 torch.empty(ls.n, dtype=torch.float32, device=runner.dev))
-            runner.statement_rows(ls.rows if ls.active is not None else None, a, ls.prev_addr_id, prior, values, ls.lw,
+            runner.statement_rows(ls.rows if ls.rows is not None else None, a, ls.prev_addr_id, prior, values, ls.lw,
                                   info.dist_name, seed=seed)
             while len(ls.log) <= j:
                 ls.log.append({})
             ls.log[j][address] = (values, a)
             ls.prev_addr_id = a
             return ParticleTensor.wrap(values)
-        if ls.active is None:
+        if ls.rows is None:
             value, logq = runner.step(a, ls.prev_addr_id, prior, seed=seed)
             values = value
         else:
@@ -412,7 +417,7 @@ class InferenceNetworkLSTM:
         ls.log[j][address] = (values, a)
         runner.prev_value = runner.last_value = values     # previous-sample embedding input of the next statement (full size)
         self._accumulate_prior(ls, distribution, values)             # + log p(value)   state.py:211
-        if ls.active is None:
+        if ls.rows is None:
             runner.axpy(ls.lw, -1.0, logq)                           # - log q(value)   state.py:212,217
         else:
             ls.lw.index_add_(0, ls.rows, logq, alpha=-1.0)
@@ -424,11 +429,14 @@ class InferenceNetworkLSTM:
         term = ls.runner.dist_term(distribution)
         if term is None:   # a family without a device kernel: scored on the host
             lp = distribution.log_prob(value.cpu()).to(self._engine.device, torch.float32).contiguous()
-            if ls.active is not None:
+            if ls.rows is not None:
                 lp = torch.where(ls.active, lp, torch.zeros_like(lp))
             ls.runner.axpy(ls.lw, 1.0, lp)
             return
-        ls.runner.accumulate_masked(ls.lw, None, None, None, value, ls.active, term=term)
+        if getattr(ls, 'by_rows', False) and ls.rows is not None:
+            ls.runner.accumulate_rows(ls.lw, term, value, ls.rows, 1.0)
+        else:
+            ls.runner.accumulate_masked(ls.lw, None, None, None, value, ls.active, term=term)
 
     def _validation_loss(self, dataset_valid, batch_size):
         """Mean `_loss` over the minibatches of a packed validation dataset, forward only (inference_network.py:538-543);

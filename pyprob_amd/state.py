@@ -333,7 +333,62 @@ class LockStepState(PathExecutor):
         self.flushes = 0
         self.plan_terms = []          # (term, source, scale): source = ('obs', name) | ('value',) | ('const', tensor)
         self.plan_ok = True
+        # A path's particles are its ROW LIST (ascending int64 indices, None = every particle): branches split it with one
+        # partition call (pp_partition_rows: two launches + one 8-byte read-back; the boolean-mask bookkeeping of PathExecutor
+        # cost a masked sum + .item() and two nonzero() - ten launches and three synchronisations - per branch), statements,
+        # observes and the result copy work on the rows. The boolean mask exists only if somebody asks for it (`active`).
+        self.by_rows = runner.dev.type == 'cuda' and os.environ.get('PP_IS_ROWS', '1') != '0'
+        self._mask = None
         super().__init__(n, runner.dev)
+
+    def start_path(self, active, decisions, statements_done, observes_done):
+        if not self.by_rows:
+            return super().start_path(active, decisions, statements_done, observes_done)
+        super().start_path(None, decisions, statements_done, observes_done)
+        self.rows = active            # (queued by branch(): the row list of the False side)
+        self._mask = None
+        self.n_active = self.n if active is None else int(active.numel())
+
+    @property
+    def active(self):
+        """bool [n] of this execution's particles, None = all of them."""
+        if not self.by_rows:
+            return self._mask
+        if self.rows is None:
+            return None
+        if self._mask is None:
+            self._mask = torch.zeros(self.n, dtype=torch.bool, device=self.dev).index_fill_(0, self.rows, True)
+        return self._mask
+
+    @active.setter
+    def active(self, mask):
+        self._mask = mask
+
+    def branch(self, cond):
+        if not self.by_rows:
+            return super().branch(cond)
+        k = self.decisions_seen
+        self.decisions_seen += 1
+        if k < len(self.decisions):
+            return self.decisions[k]             # replayed prefix: this path already knows its way
+        if self.draw is not None:
+            self.flush()      # (the condition may alias a deferred draw's storage)
+        c = cond.reshape(-1)
+        if c.dtype != torch.bool or c.device != self.dev or not c.is_contiguous():
+            c = (c.to(self.dev) != 0).contiguous()
+        rows_true, rows_false, n_true, n_false = self.runner.partition(c, self.rows, self.n_active)
+        if n_false == 0:
+            decision = True
+        elif n_true == 0:
+            decision = False
+        else:   # diverge: the False side is queued with everything this execution has done so far as its replay prefix
+            self.pending.append((rows_false, self.decisions + [False], self.statement, self.observes))
+            self.rows = rows_true
+            self._mask = None
+            self.n_active = n_true
+            decision = True
+        self.decisions.append(decision)
+        return decision
 
     @property
     def lw(self):
@@ -641,12 +696,15 @@ def _lock_step_likelihood(distribution, value, obs_name=None):
     term = ls.runner.dist_term(distribution)
     if term is None:
         raise RuntimeError('lock-step importance sampling has no device likelihood for {}'.format(distribution.name))
-    if ls.fused and ls.active is None:       # full width: joins the next fused pass (with the draw, if one is pending)
+    if ls.fused and ls.rows is None:       # full width: joins the next fused pass (with the draw, if one is pending)
         ls.defer_term(term, v, _likelihood_importance, source=('obs', obs_name) if (obs_name is not None and v.numel() == 1) else None)
         return
     ls.plan_ok = False
     ls.flush()
-    ls.runner.accumulate_masked(ls.lw, None, None, None, v, ls.active, scale=_likelihood_importance, term=term)
+    if getattr(ls, 'by_rows', False) and ls.rows is not None:
+        ls.runner.accumulate_rows(ls.lw, term, v, ls.rows, _likelihood_importance)
+    else:
+        ls.runner.accumulate_masked(ls.lw, None, None, None, v, ls.active, scale=_likelihood_importance, term=term)
 
 
 def observe(distribution, value=None, name=None, address=None):

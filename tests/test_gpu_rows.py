@@ -1,0 +1,88 @@
+"""The row-list primitives of the lock-step executor (a control-flow path's particles as ascending int64 indices):
+pp_partition_rows (a branch), pp_logweight_accumulate_rows (an observe / prior term on a path), pp_copy_rows (a path's result)
+against their torch formulations, and the executor with PP_IS_ROWS=1 against the boolean-mask bookkeeping (PP_IS_ROWS=0).
+Reference semantics: one trace at a time takes its own branches (pyprob/model.py:59-68); state.py:147-149, 211-217."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def runner():
+    from pyprob_amd.engine import ICEngine
+    from pyprob_amd.is_engine import ISRunner
+    from pyprob_amd.spec import NetSpec
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=64)
+    spec.add_address('mu', 'Normal')
+    return ISRunner(ICEngine(spec, device='cuda:0', seed=3))
+
+
+@pytest.mark.parametrize('n,frac', [(1, 1.0), (7, 0.5), (1024, 0.3), (1025, 0.0), (4097, 1.0), (200003, 0.215), (1000001, 0.5)])
+def test_partition_rows_is_the_stable_split(runner, n, frac):
+    g = torch.Generator(device='cpu').manual_seed(n)
+    cond = (torch.rand(n, generator=g) < frac).cuda()
+    t, f, nt, nf = runner.partition(cond, None, n)
+    assert (nt, nf) == (int(cond.sum()), n - int(cond.sum()))
+    assert torch.equal(t, torch.nonzero(cond).reshape(-1)) and torch.equal(f, torch.nonzero(~cond).reshape(-1))
+    # a path's rows: every third particle, split again by the condition
+    rows = torch.arange(0, n, 3, device='cuda')
+    t, f, nt, nf = runner.partition(cond, rows, int(rows.numel()))
+    assert torch.equal(t, rows[cond[rows]]) and torch.equal(f, rows[~cond[rows]])
+    assert nt == int(t.numel()) and nf == int(f.numel()) and nt + nf == int(rows.numel())
+
+
+def test_accumulate_rows_and_copy_rows(runner):
+    n = 50001
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.randn(n, generator=g).cuda()
+    mean = torch.randn(n, generator=g).cuda()
+    sd = torch.tensor([1.7], device='cuda')
+    rows = torch.nonzero(torch.rand(n, generator=g) < 0.2).reshape(-1).cuda()
+    mask = torch.zeros(n, dtype=torch.bool, device='cuda').index_fill_(0, rows, True)
+    term = (0, mean, 1, sd, 0)
+    for xx in (x, torch.tensor([0.3], device='cuda')):
+        lw_a = torch.randn(n, generator=g).cuda()
+        lw_b = lw_a.clone()
+        runner.accumulate_rows(lw_a, term, xx, rows, 0.5)
+        runner.accumulate_masked(lw_b, None, None, None, xx, mask, scale=0.5, term=term)
+        assert torch.equal(lw_a[~mask], lw_b[~mask])
+        torch.testing.assert_close(lw_a, lw_b, rtol=1e-6, atol=1e-6)
+    dst = torch.zeros(n, device='cuda')
+    runner.copy_rows(x, dst, rows)
+    assert torch.equal(dst, torch.where(mask, x, torch.zeros_like(x)))
+    runner.copy_rows(torch.tensor([2.5], device='cuda'), dst, rows[:10])
+    assert torch.equal(dst[rows[:10]], torch.full((10,), 2.5, device='cuda')) and torch.equal(dst[rows[10:]], x[rows[10:]])
+
+
+def test_row_list_executor_equals_the_mask_executor(monkeypatch):
+    """The same network and seeds: identical paths, values and log-weights whichever way a path's particles are kept."""
+    import warnings
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from models import GaussianWithUnknownMeanMarsagliaLockStep
+    from pyprob_amd.state import InferenceEngine, InferenceNetwork
+    model = GaussianWithUnknownMeanMarsagliaLockStep()
+    torch.manual_seed(3)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=8192, batch_size=256, lstm_dim=512, seed=3,
+                                      observe_embeddings={'obs0': {'dim': 32}, 'obs1': {'dim': 32}})
+        for mode in ('1', '0'):
+            monkeypatch.setenv('PP_IS_ROWS', mode)
+            post = model.posterior_results(30011, InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
+                                           observe={'obs0': 8, 'obs1': 9}, lock_step=True, seed=23)
+            out[mode] = dict(v=post._all_values.cpu().numpy(), lw=post._all_log_weights.cpu().numpy(), paths=post.num_paths,
+                             mean=float(post.mean), ess=float(post.effective_sample_size))
+    a, b = out['1'], out['0']
+    assert a['paths'] == b['paths'] > 3
+    np.testing.assert_allclose(a['v'], b['v'], rtol=1e-6, atol=1e-6)
+    fin = np.isfinite(b['lw'])
+    assert np.array_equal(fin, np.isfinite(a['lw']))
+    np.testing.assert_allclose(a['lw'][fin], b['lw'][fin], rtol=1e-5, atol=1e-5)
+    assert abs(a['mean'] - b['mean']) < 1e-4 and abs(a['ess'] - b['ess']) < 1e-3 * b['ess']

@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol(lib):
     assert declared == set(L.PROTOTYPES.keys()), declared ^ set(L.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.pp_abi_version() == L.PP_ABI_VERSION == 10
+    assert lib.pp_abi_version() == L.PP_ABI_VERSION == 11
 
 
 def test_struct_sizes_match_header_layout():
