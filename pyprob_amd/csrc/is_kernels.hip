@@ -350,15 +350,20 @@ static void is_carve(const pp_net* net, int n, void* p, IsWorkspace& w) {
     w.bytes = off + 256;
 }
 
-// PP_IS_STEP_FUSED: 0 never, 1 (default) where it is the faster path, 2 always where supported
+// PP_IS_STEP_FUSED (read per call; A/B and the parity cases of tests/test_gpu_is_step_fused.py): 0 = the chain of GEMM launches,
+// 1 (default) = one kernel from SPLIT_MAX_ROWS + 1 particles on, the two-launch split statement below that, 2 = always the
+// one-kernel statement, 3 = always the split statement
 static int is_step_fused_mode() {
     const char* e = getenv("PP_IS_STEP_FUSED");
     return e ? atoi(e) : 1;
 }
-constexpr int FUSED_MIN_ROWS = 3072;
-static bool is_step_fused_preferred(const pp_net* net, int addr_id, int n) {
-    (void)net; (void)addr_id;
-    return is_step_fused_mode() == 2 || n >= FUSED_MIN_ROWS;
+// One workgroup of the one-kernel statement streams all 4.7 MB of weights for its 32 particles: up to 256 workgroups (8 192
+// particles) that is one generation of ~0.23 ms whatever n. The split statement's LSTM launch is MFMA-bound from ~2 000
+// particles on (0.11 ms at 8 192) and its head launch costs ~0.04 ms: below 4 096 particles it wins clearly.
+constexpr int SPLIT_MAX_ROWS = 4096;
+static bool is_step_split(int n) {
+    const int mode = is_step_fused_mode();
+    return mode == 3 || (mode == 1 && n <= SPLIT_MAX_ROWS);
 }
 
 static int lin(const float* x, int64_t ldx, const float* W, const float* b, const float* b2, float* y, int64_t ldy, int n,
@@ -442,17 +447,15 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     }
     // A statement after the first one on a one-layer LSTM of a supported width: ONE kernel (is_step_fused.hip) - gates,
     // cell, both head layers and the draw; (h, c) are read and written once, in place, optionally through a row index list.
-    // A launch of fewer than FUSED_MIN_ROWS particles is a single generation of latency-bound workgroups (each streams all
-    // 4.7 MB of weights behind a two-slab ring: 0.23 ms whatever n, profiles/r04d_is_step_small_n.jsonl) - there the chain of
-    // small GEMM launches below is faster (0.05 ms at 64 rows, 0.14 ms at 2 048) and takes the statement.
-    // (PP_IS_STEP_FUSED, read per call: 0 = always the chain, 2 = the fused kernel at any n - the A/B and the small-panel
-    // parity cases of tests/test_gpu_is_step_fused.py)
+    // Small launches take the same statement as two launches (the LSTM step split over the gate columns, then head + draw):
+    // is_step_split above. PP_IS_STEP_FUSED=0 keeps the chain of GEMM launches below (A/B, tests).
     bool head_done = false;
-    if (!shared && (rows || whole || is_step_fused_preferred(net, addr_id, n)) && is_step_fused_supported(net, addr_id) &&
-        is_step_fused_mode() != 0) {
+    if (!shared && is_step_fused_supported(net, addr_id) && is_step_fused_mode() != 0) {
         bool sampled = false;
+        // (the split statement's new hidden rows go through the chain's gate buffer w.G: [n][4 H] >= [n][H])
         PP_TRY(is_step_fused(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows, rows,
-                             value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st, whole));
+                             value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st, whole,
+                             (state_rows != 1 && is_step_split(n)) ? w.G : nullptr));
         if (sampled) return 0;
         PP_CHECK_ARG(!whole, "pp_is_statement_rows: mixture heads only");
         head_done = true;     // the head outputs are in w.Y: the sampling kernels below (or pp_is_fused) take over
@@ -1128,7 +1131,8 @@ int pp_is_statement_rows(const pp_net* net, const float* params, int32_t addr_id
 }
 
 int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id, int32_t n) {
-    return (pp::is_step_fused_mode() != 0 && pp::is_step_fused_supported(net, addr_id) && pp::is_step_fused_preferred(net, addr_id, n)) ? 1 : 0;
+    (void)n;      // (any n: small launches take the two-launch split statement)
+    return (pp::is_step_fused_mode() != 0 && pp::is_step_fused_supported(net, addr_id)) ? 1 : 0;
 }
 
 int pp_prior_draw(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride, int32_t n, uint64_t seed,

@@ -201,6 +201,9 @@ struct FusedArgs {
     float* lw_full;
     int prior_kind;
     long long* dbg;             // debug: s_memtime stamps [2 workgroups][2 waves][16] (pp_debug_timeline) or nullptr
+    // split statement (small launches): the new hidden rows [n][H] written by is_small_lstm_kernel - the HEADONLY instantiation
+    // starts from them instead of running the K loop and the cell
+    const float* hn;
 };
 
 extern __shared__ __attribute__((aligned(1024))) float fused_lds[];
@@ -209,7 +212,9 @@ extern __shared__ __attribute__((aligned(1024))) float fused_lds[];
 // one shared row (no per-particle recurrent product) - a template parameter, not a runtime branch: with both K-loop variants in
 // one function the 128 accumulator registers met at a control-flow join in different physical registers and the compiler
 // shuffled all of them and spilled 32 (8 KB of scratch traffic per particle in the PMC passes of the first version)
-template <int UB, int KIND, bool SHARED>
+// HEADONLY: the second launch of a SPLIT statement (see is_small_lstm_kernel below): the panel's new hidden rows come from a.hn,
+// are stored to the state rows and laid out in LDS; everything from head layer 1 on is the same code.
+template <int UB, int KIND, bool SHARED, bool HEADONLY = false>
 __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     constexpr int H = 256 * UB;
     constexpr int NSH = H / 8;
@@ -236,6 +241,17 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         const int gr = min(m0 + tid, a.n - 1);
         sRow[tid] = a.rows ? (int)a.rows[gr] : gr;
     }
+    if constexpr (HEADONLY) {
+        __syncthreads();   // sRow
+        for (int e = tid; e < FR * H; e += 512) {
+            const int row = e / H, u = e - row * H;
+            const bool live = m0 + row < a.n;
+            const float hv = a.hn[(int64_t)min(m0 + row, a.n - 1) * H + u];
+            if (live) a.h[(uint32_t)sRow[row] * (uint32_t)H + (uint32_t)u] = hv;
+            const int hslot = ((u >> 4) * 128 + ((u >> 2) & 3) * 16) * 4 + (u & 3);
+            sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hv;
+        }
+    } else {
     const int gr = min(m0 + c31, a.n - 1);              // this lane's particle (A operand row)
     const int64_t ridx = a.rows ? a.rows[gr] : (int64_t)gr;
     const float* arow = a.h + ridx * H + 4 * hh;
@@ -367,6 +383,7 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
                 sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hn;
             }
         }
+    }
     }
     FUSED_STAMP(3);    // cell done
     __syncthreads();
@@ -554,11 +571,113 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
 #undef FUSED_STAMP
 }
 
-template <int UB, int KIND, bool SHARED>
+// ---- split statement: the LSTM step of a SMALL launch, split over the gate columns ----------------------------------------------
+// A launch of a few thousand particles is one generation of workgroups of the kernel above, each streaming ALL 4.7 MB of weights
+// through one CU for its 32 particles: 0.23 ms however few they are (profiles/r04d_is_step_small_n.jsonl) - the late iterations of
+// a program with stochastic control flow run 2 000, 400, 100 ... particles per statement. Here a workgroup owns 32 particles x
+// ONE column group (the 4 x 64 gate columns the big kernel gives to one wave), its waves one 32-column block each: 8 x as many
+// workgroups, each streaming an eighth of the weights - the same fragment images, the same k order per accumulator (bit-identical
+// gate pre-activations). The gates meet in LDS for the cell; c is updated in place, the new h goes to a.hn ([n][H], compact):
+// other column groups still read the old h rows, so the state rows are written by the second launch (is_step_fused_kernel
+// <.., HEADONLY>: head layers, draw, log q, whole-statement tail - the code above from head layer 1 on).
+struct SmallLstmArgs {
+    const float* whh_img; const float* bias;
+    const float* h; float* c;
+    const int64_t* rows;
+    const float* prev_value; int prev_indexed;
+    const float* smp_w; const float* smp_b; int smp_in, smp;
+    float* hn;
+    int n;
+};
+
+template <int UB>
+__global__ __launch_bounds__(256 * UB) void is_small_lstm_kernel(const SmallLstmArgs a) {
+    constexpr int H = 256 * UB;
+    constexpr int NSH = H / 8;
+    constexpr int NB = 4 * UB;
+    constexpr int SLAB = FW * NB * 256;
+    constexpr int RING = 4;
+    __shared__ float sG[NB][32][33];
+    __shared__ int sRow[32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int blk = __builtin_amdgcn_readfirstlane(tid >> 6);      // this wave's block: gate blk / UB, unit block blk % UB
+    const int c31 = lane & 31, hh = lane >> 5;
+    const int cg = blockIdx.x & (FW - 1);                          // column group = the big kernel's wave index
+    const int m0 = (blockIdx.x / FW) * FR;
+    if (tid < FR) {
+        const int gr = min(m0 + tid, a.n - 1);
+        sRow[tid] = a.rows ? (int)a.rows[gr] : gr;
+    }
+    const int gr = min(m0 + c31, a.n - 1);
+    const int64_t ridx = a.rows ? a.rows[gr] : (int64_t)gr;
+    const float* arow = a.h + ridx * H + 4 * hh;
+    const float* bimg = a.whh_img + (size_t)cg * (NB * 256) + blk * 256 + lane * 4;
+    const int g = blk / UB, ub = blk % UB;
+    f32x16 acc;
+    {
+        const float b = a.bias[g * H + (cg * UB + ub) * 32 + c31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b;
+    }
+    auto load_b = [&](int s) { return *reinterpret_cast<const f32x4*>(bimg + (size_t)s * SLAB); };
+    auto load_a = [&](int s) { return *reinterpret_cast<const f32x4*>(arow + 8 * s); };
+    f32x4 ra[RING], rb[RING];
+    const f32x4 bs = load_b(NSH);
+#pragma unroll
+    for (int i = 0; i < RING; ++i) {
+        ra[i] = load_a(i);
+        rb[i] = load_b(i);
+    }
+    f32x4 as;      // item 0: the sample embedding of the previous value (the big kernel's a0)
+    {
+        const float pv = a.prev_value[a.prev_indexed ? ridx : (int64_t)gr];
+        int cat = (int)pv;
+        cat = cat < 0 ? 0 : (cat >= a.smp_in ? a.smp_in - 1 : cat);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(4 * hh + j, a.smp - 1);
+            const float e = a.smp_in == 1 ? a.smp_w[k] * pv + a.smp_b[k] : a.smp_w[k * a.smp_in + cat] + a.smp_b[k];
+            as[j] = (4 * hh + j < a.smp) ? relu_keep_nan(e) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], bs[j], acc, 0, 0, 0);
+    for (int s = 0; s < NSH; s += RING) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) {
+            const f32x4 av = ra[i], bv = rb[i];
+            const int sn = min(s + i + RING, NSH - 1);      // (unconditional loads: the last ones are repeats nobody uses)
+            ra[i] = load_a(sn);
+            rb[i] = load_b(sn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        sG[blk][row][c31] = g == 2 ? fast_tanh(acc[r]) : fast_sigmoid(acc[r]);
+    }
+    __syncthreads();
+    // cell (torch.nn.LSTM gate order i, f, g, o): 32 rows x 32 UB units of this column group
+    for (int e = tid; e < FR * 32 * UB; e += 256 * UB) {
+        const int row = e / (32 * UB), uu = e - row * (32 * UB);
+        const int ub2 = uu >> 5, cc = uu & 31;
+        if (m0 + row >= a.n) continue;
+        const int u = (cg * UB + ub2) * 32 + cc;
+        const uint32_t off = (uint32_t)sRow[row] * (uint32_t)H + (uint32_t)u;
+        const float ig = sG[0 * UB + ub2][row][cc] * sG[2 * UB + ub2][row][cc];
+        const float cn = sG[1 * UB + ub2][row][cc] * a.c[off] + ig;
+        a.c[off] = cn;
+        a.hn[(int64_t)(m0 + row) * H + u] = sG[3 * UB + ub2][row][cc] * fast_tanh(cn);
+    }
+}
+
+template <int UB, int KIND, bool SHARED, bool HEADONLY = false>
 int launch_fused_s(const FusedArgs& a, size_t lds, hipStream_t st) {
     static bool raised = false;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&is_step_fused_kernel<UB, KIND, SHARED>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&is_step_fused_kernel<UB, KIND, SHARED, HEADONLY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_error("pp_is_step: cannot raise the LDS limit of the fused statement kernel: %s", hipGetErrorString(e));
@@ -566,11 +685,12 @@ int launch_fused_s(const FusedArgs& a, size_t lds, hipStream_t st) {
         }
         raised = true;
     }
-    hipLaunchKernelGGL((is_step_fused_kernel<UB, KIND, SHARED>), dim3(cdiv(a.n, FR)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((is_step_fused_kernel<UB, KIND, SHARED, HEADONLY>), dim3(cdiv(a.n, FR)), dim3(512), lds, st, a);
     return 0;
 }
 template <int UB, int KIND>
 int launch_fused(const FusedArgs& a, size_t lds, hipStream_t st) {
+    if (a.hn) return launch_fused_s<UB, KIND, false, true>(a, lds, st);
     return a.state_shared ? launch_fused_s<UB, KIND, true>(a, lds, st) : launch_fused_s<UB, KIND, false>(a, lds, st);
 }
 
@@ -606,7 +726,7 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
                   const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
                   const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
                   const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
-                  const IsStatementOut* whole) {
+                  const IsStatementOut* whole, float* hn_split) {
     const pp_addr& ad = net->addrs[addr_id];
     const int H = net->lstm_dim, ub = H / 256, nsh = H / 8;
     const bool shared = state_rows == 1;
@@ -658,6 +778,17 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     const double flops = (double)n * (2.0 * (net->lstm_in + (shared ? 0 : H)) * 4.0 * H + 2.0 * ((double)H * ad.hid + (double)ad.hid * ad.n_out));
     prof_begin(5, st);
     int rc = 0;
+    if (hn_split && !shared) {      // split statement: the LSTM step over 8 x as many workgroups, then the head-only launch
+        SmallLstmArgs q{};
+        q.whh_img = f.whh; q.bias = f.bias; q.h = h; q.c = c; q.rows = rows;
+        q.prev_value = prev_value; q.prev_indexed = a.prev_indexed;
+        q.smp_w = a.smp_w; q.smp_b = a.smp_b; q.smp_in = a.smp_in; q.smp = a.smp;
+        q.hn = hn_split; q.n = n;
+        if (ub == 1) hipLaunchKernelGGL(is_small_lstm_kernel<1>, dim3(cdiv(n, FR) * FW), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(is_small_lstm_kernel<2>, dim3(cdiv(n, FR) * FW), dim3(512), 0, st, q);
+        PP_LAUNCH_CHECK("pp_is_step(split statement, LSTM)");
+        a.hn = hn_split;
+    }
 #define PP_FUSED_CASE(U, KD) rc = launch_fused<U, KD>(a, lds, st)
     if (ub == 1) {
         if (kind == 0) PP_FUSED_CASE(1, 0); else if (kind == 1) PP_FUSED_CASE(1, 1); else if (kind == 2) PP_FUSED_CASE(1, 2); else PP_FUSED_CASE(1, 3);

@@ -25,10 +25,12 @@ struct IsStatementOut {
 // everybody's previous state. rows (or nullptr): state row of particle i (h, c are read and written at rows[i]; all other
 // per-particle arrays are compact). *sampled: values and log q are written; false when only the head outputs were produced
 // (y_out [n, ldy]: categorical / Bernoulli heads and net_only calls - the caller samples).
+// hn_split: [n][H] scratch - the statement runs as TWO launches (LSTM step split over the gate columns, then head + draw): the
+// faster shape for launches of a few thousand particles and fewer (ignored for the shared-state second statement)
 int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
                   const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
                   const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
                   const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
-                  const IsStatementOut* whole = nullptr);
+                  const IsStatementOut* whole = nullptr, float* hn_split = nullptr);
 
 }  // namespace pp

@@ -20,11 +20,13 @@ ADDRS = [('a_normal', 'Normal', None), ('a_uniform', 'Uniform', None), ('a_cat',
          ('a_bern', 'Bernoulli', None)]
 
 
-@pytest.fixture(autouse=True)
-def _force_fused(monkeypatch):
-    """pp_is_step takes the fused kernel from ~3 000 particles on (smaller launches go to the chain of small GEMMs, which is
-    faster there); the parity cases below use small panels counts on purpose: PP_IS_STEP_FUSED=2 = the fused kernel at any n."""
-    monkeypatch.setenv('PP_IS_STEP_FUSED', '2')
+@pytest.fixture(autouse=True, params=['2', '3'], ids=['one_kernel', 'split'])
+def _force_fused(monkeypatch, request):
+    """Every case runs the statement both ways: PP_IS_STEP_FUSED=2 = the one-kernel statement at any n, 3 = the two-launch split
+    statement (is_small_lstm_kernel + the head-only instantiation) at any n. By default pp_is_step picks by the number of
+    particles (split up to 4 096); the parity cases below use small panel counts on purpose."""
+    monkeypatch.setenv('PP_IS_STEP_FUSED', request.param)
+    return request.param
 
 
 def _engine(H, seed=0):
@@ -149,7 +151,7 @@ def test_fused_statement_against_the_oracle(H, n, prev, cur):
     assert torch.equal(v2, value) and torch.equal(lq2, logq) and torch.equal(h2, h) and torch.equal(c2, c)
 
 
-def test_fused_statement_equals_the_unfused_chain(monkeypatch):
+def test_fused_statement_equals_the_unfused_chain(monkeypatch, _force_fused):
     """A/B inside one process: PP_IS_STEP_FUSED=0 takes the gather -> GEMM -> GEMM -> cell -> head chain. Same Philox
     counters, so the draws agree to the rounding of the proposal parameters; states agree to fp32 summation order."""
     from pyprob_amd.ops import ops
@@ -162,7 +164,7 @@ def test_fused_statement_equals_the_unfused_chain(monkeypatch):
     prior = _prior_for('Uniform', n, rng)
     dev = eng.device
     outs = []
-    for flag in ('2', '0'):
+    for flag in (_force_fused, '0'):
         monkeypatch.setenv('PP_IS_STEP_FUSED', flag)
         h = torch.from_numpy(h0.copy()).to(dev).reshape(1, n, H).contiguous()
         c = torch.from_numpy(c0.copy()).to(dev).reshape(1, n, H).contiguous()
