@@ -272,19 +272,28 @@ class ISRunner:
         lw.add_(torch.where(active, lp, torch.zeros_like(lp)), alpha=float(scale))
 
     # ---- the particles of a control-flow path as a row list (LockStepState.by_rows): direct C-ABI calls ------------------------
-    def partition(self, cond, rows, m):
-        """A branch: split the path's rows (None: particles 0..m-1) by the bool [n] condition. Returns (rows where it holds,
-        the other rows, their counts) - ascending int64 device vectors; one synchronisation (the 8-byte count read-back)."""
+    def partition_launch(self, cond, rows, m):
+        """A branch: split the path's rows (None: particles 0..m-1) by the bool [n] condition - the launches only; the counts
+        are read by partition_read (the one synchronisation of a branch)."""
         buf = torch.empty(2 * max(m, 1), dtype=torch.int64, device=self.dev)
+        counts = torch.empty(2, dtype=torch.int32, device=self.dev)
         need = (m + 1023) // 1024 + 1
         scratch = getattr(self, '_part_scratch', None)
         if scratch is None or scratch.numel() < need:
             scratch = self._part_scratch = torch.empty(max(need, 1024), dtype=torch.int32, device=self.dev)
-            self._part_counts = torch.zeros(2, dtype=torch.int32, device=self.dev)
         L.check(self.lib.pp_partition_rows(cond.data_ptr(), L.ptr(rows), int(m), buf.data_ptr(), buf.data_ptr() + 8 * m,
-                                           self._part_counts.data_ptr(), scratch.data_ptr(), L.stream_ptr()), 'pp_partition_rows')
-        n_true, n_false = self._part_counts.tolist()
+                                           counts.data_ptr(), scratch.data_ptr(), L.stream_ptr()), 'pp_partition_rows')
+        return buf, counts, m, cond, rows      # (cond / rows stay alive until the kernels have run)
+
+    @staticmethod
+    def partition_read(handle):
+        """(rows where the condition holds, the other rows, their counts) - ascending int64 device vectors."""
+        buf, counts, m = handle[:3]
+        n_true, n_false = counts.tolist()
         return buf[:n_true], buf[m:m + n_false], n_true, n_false
+
+    def partition(self, cond, rows, m):
+        return self.partition_read(self.partition_launch(cond, rows, m))
 
     def accumulate_rows(self, lw, term, x, rows, scale):
         """lw[rows] += scale * log_prob(term; x[rows]) - one launch on the path's rows (pp_logweight_accumulate_rows)."""

@@ -90,33 +90,45 @@ class Model:
         runner.begin(num_traces, offset=offset)
         values = None
         n_paths = 0
+
+        def run_path():
+            """The program for the executor's current path, to its end."""
+            nonlocal values, n_paths
+            state._begin_trace()
+            result = self.forward(*args, **kwargs)
+            n_paths += 1
+            if not torch.is_tensor(result):
+                raise RuntimeError('lock-step importance sampling: forward() must return a per-particle tensor')
+            # no queued control-flow path (and nobody waiting for this nested run): the statistics ride in this path's last pass
+            last = not ls.pending and ls._nest_depth == 0
+            if last and ls.rows is None and torch.is_tensor(result) and result.numel() == num_traces:
+                ls.stats_values = result.as_subclass(torch.Tensor).reshape(-1)
+            ls.flush(final=last)            # the deferred draw / log-weight terms of this execution (one pass)
+            result = result.as_subclass(torch.Tensor).reshape(-1).to(runner.dev, torch.float32)
+            if ls.rows is None:
+                values = result if result.numel() == num_traces else result.expand(num_traces).clone()
+            else:
+                if values is None:
+                    values = torch.zeros(num_traces, dtype=torch.float32, device=runner.dev)
+                if ls.by_rows and result.numel() in (1, num_traces):
+                    runner.copy_rows(result.contiguous(), values, ls.rows)
+                else:
+                    values = torch.where(ls.active, result.expand(num_traces) if result.numel() == 1 else result, values)
+
+        def nested():      # (LockStepState.branch, while the host would wait for the device)
+            if ls.next_path():
+                run_path()
+        ls.nest = nested
         try:
             while True:
-                state._begin_trace()
-                result = self.forward(*args, **kwargs)
-                n_paths += 1
-                if not torch.is_tensor(result):
-                    raise RuntimeError('lock-step importance sampling: forward() must return a per-particle tensor')
-                last = not ls.pending           # no queued control-flow path: the statistics ride in this path's last pass
-                if last and ls.rows is None and torch.is_tensor(result) and result.numel() == num_traces:
-                    ls.stats_values = result.as_subclass(torch.Tensor).reshape(-1)
-                ls.flush(final=last)            # the deferred draw / log-weight terms of this execution (one pass)
-                result = result.as_subclass(torch.Tensor).reshape(-1).to(runner.dev, torch.float32)
-                if ls.rows is None:
-                    values = result if result.numel() == num_traces else result.expand(num_traces).clone()
-                else:
-                    if values is None:
-                        values = torch.zeros(num_traces, dtype=torch.float32, device=runner.dev)
-                    if ls.by_rows and result.numel() in (1, num_traces):
-                        runner.copy_rows(result.contiguous(), values, ls.rows)
-                    else:
-                        values = torch.where(ls.active, result.expand(num_traces) if result.numel() == 1 else result, values)
+                run_path()
                 if not ls.next_path():
                     break
         finally:
             state._lock_step = None
             state._current_trace = None
             ls.memo = None          # (the call's intermediate results are released)
+            ls.nest = None
         all_values, all_lw = values, ls.lw
         # the fused pass's statistics count only when they were reduced over the tensor that is returned (a draw still
         # pending at the last flush reduces over ITS values: forward() may return something else)

@@ -275,7 +275,8 @@ class PathExecutor:
         if not self.pending:
             return False
         active, decisions, st_done, ob_done = self.pending.pop()
-        self.path_id += 1
+        self.path_count = getattr(self, 'path_count', 0) + 1      # (ids in starting order; a nested run returns to its caller's id)
+        self.path_id = self.path_count
         if self.path_id > 4096:
             raise RuntimeError('lock-step execution: more than 4096 control-flow paths')
         self.start_path(active, decisions, st_done, ob_done)
@@ -339,7 +340,32 @@ class LockStepState(PathExecutor):
         # observes and the result copy work on the rows. The boolean mask exists only if somebody asks for it (`active`).
         self.by_rows = runner.dev.type == 'cuda' and os.environ.get('PP_IS_ROWS', '1') != '0'
         self._mask = None
+        # A branch has to WAIT for the device (the condition is computed from values the queued statement kernels are still
+        # drawing). Instead of idling there, the host first runs a queued path (Model._traces_lockstep sets `nest`): its
+        # replay and its handful of small launches - queued behind the statement kernels - overlap the wait. One level deep.
+        self.nest = None
+        self._nest_depth = 0
+        self.nest_ok = os.environ.get('PP_IS_NEST', '1') != '0'
         super().__init__(n, runner.dev)
+
+    _PATH_FIELDS = ('rows', '_mask', 'n_active', 'decisions', 'decisions_seen', 'replay_statements', 'replay_observes', 'statement',
+                    'observes', 'prev_addr_id', 'prev_unknown', 'path_id')
+
+    def _run_nested(self):
+        """Run the most recently queued path to its end inside the current execution (which is waiting at a branch)."""
+        global _current_trace, _current_trace_previous_variable, _current_trace_execution_start
+        saved = {k: getattr(self, k) for k in self._PATH_FIELDS}
+        saved_runner = (self.runner.prev_value, self.runner.last_value)
+        saved_trace = (_current_trace, _current_trace_previous_variable, _current_trace_execution_start)
+        self._nest_depth += 1
+        try:
+            self.nest()
+        finally:
+            self._nest_depth -= 1
+            for k, v in saved.items():
+                setattr(self, k, v)
+            self.runner.prev_value, self.runner.last_value = saved_runner
+            _current_trace, _current_trace_previous_variable, _current_trace_execution_start = saved_trace
 
     def start_path(self, active, decisions, statements_done, observes_done):
         if not self.by_rows:
@@ -376,7 +402,10 @@ class LockStepState(PathExecutor):
         c = cond.reshape(-1)
         if c.dtype != torch.bool or c.device != self.dev or not c.is_contiguous():
             c = (c.to(self.dev) != 0).contiguous()
-        rows_true, rows_false, n_true, n_false = self.runner.partition(c, self.rows, self.n_active)
+        handle = self.runner.partition_launch(c, self.rows, self.n_active)
+        if self.pending and self.nest is not None and self.nest_ok and self._nest_depth == 0:
+            self._run_nested()
+        rows_true, rows_false, n_true, n_false = self.runner.partition_read(handle)
         if n_false == 0:
             decision = True
         elif n_true == 0:
