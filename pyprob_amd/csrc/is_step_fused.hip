@@ -405,19 +405,26 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
             const float* wimg = a.w1_img + (size_t)cb * 256 + lane * 4;
             const size_t sstride = (size_t)a.nb16 * 256;
             const float* aimg = sH + rb * 256 + lane * 4;
-            f32x4 bq[8];
+            // (the head-only launch of a split statement has the registers for a ring of 16: its tiles are a latency chain -
+            // one small workgroup per 32 particles, nothing else on the CU to hide it)
+            constexpr int HR = HEADONLY ? 16 : 8;
+            f32x4 bq[HR];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bq[u] = *reinterpret_cast<const f32x4*>(wimg + u * sstride);
-            for (int s16 = 0; s16 < NS16; s16 += 8) {
+            for (int u = 0; u < HR; ++u) bq[u] = *reinterpret_cast<const f32x4*>(wimg + u * sstride);
+            // (head-only: the scheduler otherwise sinks every load next to its use - fewer registers, the latency of all 32
+            // slabs in a row; the one-kernel statement is left as measured)
+            if constexpr (HEADONLY) __builtin_amdgcn_sched_barrier(0);
+            for (int s16 = 0; s16 < NS16; s16 += HR) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < HR; ++u) {
                     const f32x4 av = *reinterpret_cast<const f32x4*>(aimg + (s16 + u) * 512);
                     const f32x4 bv = bq[u];
-                    if (s16 + u + 8 < NS16) bq[u] = *reinterpret_cast<const f32x4*>(wimg + (size_t)(s16 + u + 8) * sstride);
+                    if (s16 + u + HR < NS16) bq[u] = *reinterpret_cast<const f32x4*>(wimg + (size_t)(s16 + u + HR) * sstride);
                     e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], e0, 0, 0, 0);
                     e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], e1, 0, 0, 0);
                     e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], e0, 0, 0, 0);
                     e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], e1, 0, 0, 0);
+                    if constexpr (HEADONLY) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // D of 16x16x4: lane (column i16, row group kq) holds rows 4 kq + r of the tile
@@ -442,6 +449,27 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+        if constexpr (HEADONLY) {      // this wave's (at most 8) slabs of W2 in flight together instead of one after the other
+            f32x4 bw[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bw[q] = *reinterpret_cast<const f32x4*>(a.w2_img + (size_t)min(wave + q * FW, a.ns2 - 1) * 256 + lane * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int s = wave + q * FW;
+                if (s < a.ns2) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(sA1 + s * 256 + lane * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bw[q][j], acc2, 0, 0, 0);
+                }
+            }
+            for (int s = wave + 8 * FW; s < a.ns2; s += FW) {      // (heads wider than 512 hidden units)
+                const f32x4 av = *reinterpret_cast<const f32x4*>(sA1 + s * 256 + lane * 4);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.w2_img + (size_t)s * 256 + lane * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc2, 0, 0, 0);
+            }
+        } else
         for (int s = wave; s < a.ns2; s += FW) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(sA1 + s * 256 + lane * 4);
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.w2_img + (size_t)s * 256 + lane * 4);
@@ -596,7 +624,7 @@ __global__ __launch_bounds__(256 * UB) void is_small_lstm_kernel(const SmallLstm
     constexpr int NSH = H / 8;
     constexpr int NB = 4 * UB;
     constexpr int SLAB = FW * NB * 256;
-    constexpr int RING = 4;
+    constexpr int RING = 16;     // items in flight per wave: 65 items of ~0.1 us of MFMAs behind ~2 us of load latency (ring 4: 28 us per launch)
     __shared__ float sG[NB][32][33];
     __shared__ int sRow[32];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -645,12 +673,14 @@ __global__ __launch_bounds__(256 * UB) void is_small_lstm_kernel(const SmallLstm
     for (int s = 0; s < NSH; s += RING) {
 #pragma unroll
         for (int i = 0; i < RING; ++i) {
-            const f32x4 av = ra[i], bv = rb[i];
-            const int sn = min(s + i + RING, NSH - 1);      // (unconditional loads: the last ones are repeats nobody uses)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][j], rb[i][j], acc, 0, 0, 0);
+            // REFILL into the registers those MFMAs just read (loading first needs a second register set and a copy per
+            // item); unconditional loads: the last ones are repeats nobody uses
+            const int sn = min(s + i + RING, NSH - 1);
             ra[i] = load_a(sn);
             rb[i] = load_b(sn);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
