@@ -28,6 +28,7 @@ class ISRunner:
         self.offset = 0
         self._consts = {}
         self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self._st = None        # stream of the current posterior call (begin); None = the default stream
         self._stats_scratch = torch.zeros(L.PP_IS_STATS_SCRATCH, dtype=torch.float64, device=self.dev)
 
     def _const(self, v):
@@ -67,6 +68,15 @@ class ISRunner:
         self.state_rows = 1
         self.offset = int(offset)
         self._ensure_ws(n)
+        # the stream of this posterior call, looked up once (torch.cuda.current_stream() costs ~6 us of device-index resolution
+        # per lookup: 59 lookups per call of the Marsaglia program, profiles/r05d_gumm_cprofile.txt) - the direct C-ABI calls
+        # below (partition, rows terms, whole statements) use it
+        if self.dev.type == 'cuda':
+            if torch.cuda.current_device() != (self.dev.index or 0):
+                torch.cuda.set_device(self.dev)
+            self._st = L.stream_ptr()
+        else:
+            self._st = None
 
     def step(self, addr_id, prev_addr_id, prior, value_in=None, seed=0):
         """One controlled sample statement for all particles. prior: device tensor [1,2] (shared) or [n,2].
@@ -167,9 +177,12 @@ class ISRunner:
             self.c[:, 1:] = self.c[:, :1]
             state_rows = self.n
         self._ensure_ws(m)
-        ops.is_statement_rows(self.eng.params, self.ws, self.eng.net_handle, int(addr_id), int(prev_addr_id), m, self.e_obs,
-                              self.prev_value, prior, self.h, self.c, 1 if state_rows == 1 else m, rows, values_full, lw_full,
-                              self.PRIOR_KIND[dist_name], int(seed), self.offset)
+        # (straight through the C ABI: whole_statement_ok has checked the shapes, the tensors are this executor's own)
+        L.check(self.lib.pp_is_statement_rows(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id), int(prev_addr_id), m,
+                                              self.e_obs.data_ptr(), self.prev_value.data_ptr(), prior.data_ptr(), 0,
+                                              self.h.data_ptr(), self.c.data_ptr(), 1 if state_rows == 1 else m, L.ptr(rows),
+                                              values_full.data_ptr(), lw_full.data_ptr(), self.PRIOR_KIND[dist_name], int(seed),
+                                              int(self.offset), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_statement_rows')
         torch.autograd.graph.increment_version(values_full)      # written by the kernel: memoised results of it are stale
         self.state_rows = self.n
         self.prev_value = self.last_value = values_full
@@ -282,7 +295,7 @@ class ISRunner:
         if scratch is None or scratch.numel() < need:
             scratch = self._part_scratch = torch.empty(max(need, 1024), dtype=torch.int32, device=self.dev)
         L.check(self.lib.pp_partition_rows(cond.data_ptr(), L.ptr(rows), int(m), buf.data_ptr(), buf.data_ptr() + 8 * m,
-                                           counts.data_ptr(), scratch.data_ptr(), L.stream_ptr()), 'pp_partition_rows')
+                                           counts.data_ptr(), scratch.data_ptr(), self._st), 'pp_partition_rows')
         return buf, counts, m, cond, rows      # (cond / rows stay alive until the kernels have run)
 
     @staticmethod
@@ -306,7 +319,7 @@ class ISRunner:
                 raise RuntimeError('lock-step log-weight term: tensors of 1 or n elements')
         L.check(self.lib.pp_logweight_accumulate_rows(int(kind), L.ptr(p0), int(s0), L.ptr(p1), int(s1), x.data_ptr(),
                                                       0 if x.numel() == 1 else 1, float(scale), lw.data_ptr(), rows.data_ptr(),
-                                                      int(rows.numel()), L.stream_ptr()), 'pp_logweight_accumulate_rows')
+                                                      int(rows.numel()), self._st), 'pp_logweight_accumulate_rows')
 
     def copy_rows(self, src, dst, rows):
         """dst[rows] = src[rows] (src: n values or one shared value), in place (pp_copy_rows)."""
@@ -316,7 +329,7 @@ class ISRunner:
         if src.numel() not in (1, dst.numel()):
             raise RuntimeError('copy_rows: a source of 1 or n elements')
         L.check(self.lib.pp_copy_rows(src.data_ptr(), 0 if src.numel() == 1 else 1, dst.data_ptr(), rows.data_ptr(), int(rows.numel()),
-                                      L.stream_ptr()), 'pp_copy_rows')
+                                      self._st), 'pp_copy_rows')
         torch.autograd.graph.increment_version(dst)       # written by the kernel: memoised results of it are stale
 
     def accumulate(self, lw, kind, p0, p1, x, scale=1.0, term=None):

@@ -45,6 +45,7 @@ pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(45)
 open(out + '_cprofile.txt', 'w').write(s.getvalue())
+pr.dump_stats(out + '_cprofile.pstats')
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     post = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=78)

@@ -31,7 +31,7 @@ for n in ns:
     flops_alg = n * (2.0 * (spec.lstm_in + H) * 4 * H + 2.0 * (H * ad.hid + ad.hid * ad.n_out))
     flops_exe = n * (2.0 * (8 + H) * 4 * H + 2.0 * (H * 288 + 272 * 32))                                 # what the fused kernel multiplies
     for mode in os.environ.get('MODES', 'fused,fused_rows,chain').split(','):
-        os.environ['PP_IS_STEP_FUSED'] = '0' if mode == 'chain' else '2'
+        os.environ['PP_IS_STEP_FUSED'] = {'chain': '0', 'split': '3'}.get(mode, '2')      # (split: the two-launch statement)
         def call():
             if mode == 'fused_rows':
                 return ops.is_step_rows(eng.params, run.ws, eng.net_handle, 1, 0, n, run.e_obs, pv, prior, h, c, n, rows, None, 3, 0)
