@@ -372,6 +372,23 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
                    'partials in one pass: 8 B per particle written) [+ per-row draw kernels of later statements]; HIP event '
                    'pairs around the launches; compute-bound on Philox + logsumexp over K components, not on HBM',
             wall_over_kernel=round(dt / calls * 1e6 / per_call_us, 2))
+        # every launch of the call, not only the pass over the particles: kernel class 6 brackets pp_is_init ... pp_is_fused (the
+        # observe embedding, the two one-row network kernels, the pass with its statistics) - a few extra calls, outside `dt`
+        k6 = 8
+        lib.pp_prof_arm(6, k6 * 2)
+        for i in range(k6):
+            post = model.posterior_results(particles, IC, observe=observe, lock_step=True, seed=seed0 + calls + i, offset=offset)
+            _ = post.effective_sample_size
+        torch.cuda.synchronize()
+        ms6 = np.zeros(k6 * 2, np.float32)
+        c6 = C.c_int32(0)
+        lib.pp_prof_collect(ms6.ctypes.data, k6 * 2, C.byref(c6), None)
+        lib.pp_prof_arm(6, 0)
+        if c6.value > 0:
+            chain_us = float(np.median(ms6[:c6.value])) * 1e3
+            rec['device_chain'] = dict(us_per_call=round(chain_us, 2), wall_over_device_chain=round(dt / calls * 1e6 / chain_us, 2),
+                                       launches='observe embedding -> first_row_lstm_kernel -> first_row_head_kernel -> is_fused_kernel '
+                                                '(statistics combined by its last workgroup): HIP event pair around the whole chain')
     return rec, dt, particles * calls
 
 

@@ -553,6 +553,8 @@ int pp_head_logprob(int32_t kind, const float* y, int64_t ldy, const int32_t* ro
  *   4  the draw + log q kernel of pp_is_step                         work = algorithmic bytes
  *   5  the fused statement kernel of pp_is_step / pp_is_step_rows    work = FLOPs (input + recurrent
  *                                                                    product and both head layers per particle)
+ *   6  the device chain of a posterior call's first statement: every launch from pp_is_init to the end of pp_is_fused
+ *      (observe embedding, the one-row network, the pass over the particles with its statistics)   work = 0
  * pp_prof_collect returns the elapsed milliseconds and the work of every recorded launch (flops_out).
  * ---------------------------------------------------------------------------------------------------- */
 /* Host-side plan of the streaming weight-gradient launch (csrc/wgrad_t1.hip) for `count` queued products dW += A^T B (both

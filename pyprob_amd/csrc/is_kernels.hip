@@ -259,6 +259,19 @@ __global__ __launch_bounds__(256) void first_row_head_kernel(const float* __rest
     __shared__ float sa[1024];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = blockIdx.x * 4 + wave;
+    // W2 for the layer-2 pass of the LAST workgroup, requested by EVERY workgroup before it knows whether it is the last one
+    // (n_out x hid floats, 32 KB: nothing against the 0.5 MB of W1) - the last one finds them in registers instead of starting
+    // five dependent round trips after the ticket. Heads of at most 32 outputs and 320 hidden units; wider ones load below.
+    constexpr int OW = 8, KW = 5;      // outputs per wave, k per lane
+    const bool w2_pre = n_out <= 4 * OW && hid <= 64 * KW;
+    float w2r[OW][KW];
+#pragma unroll
+    for (int q = 0; q < OW; ++q)
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            const int o = min(wave * OW + q, n_out - 1), k = min(lane + 64 * i, hid - 1);
+            w2r[q][i] = w2_pre ? P[w2 + (int64_t)o * hid + k] : 0.0f;
+        }
     if (j < hid) {
         const float* wr = P + w1 + (int64_t)j * Hin;
         float acc = 0.0f;
@@ -284,14 +297,19 @@ __global__ __launch_bounds__(256) void first_row_head_kernel(const float* __rest
     // the last workgroup: a1 (coherent copies) -> LDS in one round trip, then W2 a1 + b2 with the rows' loads in flight together
     for (int k = tid; k < hid; k += 256) sa[k] = __hip_atomic_load(A1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    constexpr int OW = 8;      // outputs per wave and pass
     for (int o0 = wave * OW; o0 < n_out; o0 += 4 * OW) {
         float acc[OW];
 #pragma unroll
         for (int q = 0; q < OW; ++q) {
             acc[q] = 0.0f;
-            const float* wr = P + w2 + (int64_t)min(o0 + q, n_out - 1) * hid;
-            for (int k = lane; k < hid; k += 64) acc[q] += wr[k] * sa[k];
+            if (w2_pre) {      // (one pass: o0 = wave * OW)
+#pragma unroll
+                for (int i = 0; i < KW; ++i)
+                    if (lane + 64 * i < hid) acc[q] += w2r[q][i] * sa[lane + 64 * i];
+            } else {
+                const float* wr = P + w2 + (int64_t)min(o0 + q, n_out - 1) * hid;
+                for (int k = lane; k < hid; k += 64) acc[q] += wr[k] * sa[k];
+            }
         }
 #pragma unroll
         for (int q = 0; q < OW; ++q) {
@@ -757,13 +775,13 @@ __global__ __launch_bounds__(256) void is_stats_partial_kernel(const float* __re
     if (tid == 0) scratch[blockIdx.x * 6] = M;
 }
 
-__global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __restrict__ scratch, int nblocks,
-                                                               double* __restrict__ out) {
-    __shared__ double shm[4];
-    __shared__ double sh[4][5];
+// The combine of the per-workgroup partials (one workgroup of 256 threads).
+__device__ __forceinline__ void stats_combine_body(const double* __restrict__ scratch, int nblocks, double* __restrict__ out,
+                                                   double (&shm)[4], double (&sh)[4][5]) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    auto ld = [&](int i) -> double { return scratch[i]; };
     double m = -INFINITY;       // maximum over this thread's partials b = tid, tid + 256, ...
-    for (int b = tid; b < nblocks; b += 256) m = fmax(m, scratch[b * 6]);
+    for (int b = tid; b < nblocks; b += 256) m = fmax(m, ld(b * 6));
     double gm = m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o, 64));
@@ -772,14 +790,14 @@ __global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __r
     gm = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
     double S[5] = {0, 0, 0, 0, 0};
     for (int b = tid; b < nblocks; b += 256) {
-        const double mb = scratch[b * 6];
+        const double mb = ld(b * 6);
         if (!(mb > -INFINITY)) continue;
         const double r = exp(mb - gm);
-        S[0] += scratch[b * 6 + 1] * r;
-        S[1] += scratch[b * 6 + 2] * r * r;
-        S[2] += scratch[b * 6 + 3] * r;
-        S[3] += scratch[b * 6 + 4] * r;
-        S[4] += scratch[b * 6 + 5];
+        S[0] += ld(b * 6 + 1) * r;
+        S[1] += ld(b * 6 + 2) * r * r;
+        S[2] += ld(b * 6 + 3) * r;
+        S[3] += ld(b * 6 + 4) * r;
+        S[4] += ld(b * 6 + 5);
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
@@ -789,6 +807,13 @@ __global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __r
     __syncthreads();
     if (tid < 5) out[1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
     if (tid == 0) out[0] = gm;
+}
+
+__global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __restrict__ scratch, int nblocks,
+                                                               double* __restrict__ out) {
+    __shared__ double shm[4];
+    __shared__ double sh[4][5];
+    stats_combine_body(scratch, nblocks, out, shm, sh);
 }
 
 // Several log-weight terms in one pass over the particles (state.py:211-217, 147-149):
@@ -1038,6 +1063,9 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
     __syncthreads();
     if (tid < 5) scratch[blockIdx.x * 6 + 1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
     if (tid == 0) scratch[blockIdx.x * 6] = (double)M;
+    // (Folding the combine into this launch - last workgroup to arrive behind a device-scope ticket - was tried: every workgroup's
+    // release fence has to write back the 8 MB of values and log-weights it shares the L2 with, 18 -> 80 us per launch;
+    // profiles/r04_experiments_not_kept.txt. The one-workgroup is_stats_combine_kernel follows.)
 }
 
 // ---- prior draws for vectorised trace generation (pyprob/nn/dataset.py:50-62, state.py:278-290 run n times) -----------
@@ -1083,6 +1111,9 @@ size_t pp_is_workspace_bytes(const pp_net* net, int32_t n) {
 
 int pp_is_init(const pp_net* net, const float* params, const float* obs, float* e_out, void* workspace,
                size_t workspace_bytes, void* stream) {
+    // kernel class 6 of the in-stream timing: the device chain of a posterior call's shared first statement, from the observe
+    // embedding (here) to the end of pp_is_fused (which closes the bracket) - what the call's wall time is compared with
+    pp::prof_begin(6, pp::as_stream(stream));
     return pp::is_init(net, params, obs, e_out, workspace, workspace_bytes, pp::as_stream(stream));
 }
 
@@ -1227,6 +1258,7 @@ int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prio
     pp::prof_end(4, 8.0 * n, st);
     if (stats_out)
         hipLaunchKernelGGL(pp::is_stats_combine_kernel, dim3(1), dim3(256), 0, st, stats_scratch, blocks, stats_out);
+    pp::prof_end(6, 0.0, st);
     PP_LAUNCH_CHECK("pp_is_fused");
     return 0;
 }
