@@ -387,8 +387,8 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         if c6.value > 0:
             chain_us = float(np.median(ms6[:c6.value])) * 1e3
             rec['device_chain'] = dict(us_per_call=round(chain_us, 2), wall_over_device_chain=round(dt / calls * 1e6 / chain_us, 2),
-                                       launches='observe embedding -> first_row_lstm_kernel -> first_row_head_kernel -> is_fused_kernel '
-                                                '(statistics combined by its last workgroup): HIP event pair around the whole chain')
+                                       launches='observe embedding -> first_row_lstm_kernel -> first_row_head_kernel -> is_fused_kernel -> '
+                                                'is_stats_combine_kernel: ONE HIP event pair around the whole chain')
     return rec, dt, particles * calls
 
 

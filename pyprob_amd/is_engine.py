@@ -134,9 +134,9 @@ class ISRunner:
         L.check(lib.pp_is_step_net(net, params, plan['addr'], -1, n, self.e_obs.data_ptr(), None, self.h.data_ptr(),
                                    self.c.data_ptr(), 1, ws, self.ws_bytes, st), 'pp_is_step_net')
         self.state_rows = 1
-        values = torch.empty(n, dtype=torch.float32, device=self.dev)
-        lw = torch.empty(n, dtype=torch.float32, device=self.dev)
-        out = torch.empty(8, dtype=torch.float64, device=self.dev)
+        buf = torch.empty(2 * n, dtype=torch.float32, device=self.dev)      # values | log-weights: one allocation per call
+        values, lw = buf[:n], buf[n:]
+        out = self._stats                                                    # (read back before this call returns)
         c = plan.get('c')
         if c is None or c['obs_base'] != self._obs_dev.data_ptr():
             terms = [(plan['prior_term'], None, 1.0, 4)] + [((kind, (a[1] if a[0] == 'const' else None), s0,
@@ -366,7 +366,7 @@ class ISRunner:
 
     @staticmethod
     def _stats_dict(stats):
-        m, sw, sw2, swx, swx2, cnt = stats[:6].cpu().numpy().tolist()
+        m, sw, sw2, swx, swx2, cnt = stats.tolist()[:6]
         mean = swx / sw if sw > 0 else float('nan')
         var = swx2 / sw - mean * mean if sw > 0 else float('nan')
         return dict(max_lw=m, sum_w=sw, sum_w2=sw2, sum_wx=swx, sum_wx2=swx2, count=cnt,
