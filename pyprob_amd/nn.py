@@ -329,7 +329,11 @@ class InferenceNetworkLSTM:
             if a is not None:
                 ls.prev_addr_id = a
                 runner.prev_value = runner.last_value = values
-            return ParticleTensor.wrap(values)
+            wrappers = ls.wrappers      # one ParticleTensor per recorded tensor: every replay hands out the same object
+            w = wrappers.get(id(values))
+            if w is None or w[0] is not values:
+                w = wrappers[id(values)] = (values, ParticleTensor.wrap(values))
+            return w[1]
         prev_unknown = getattr(ls, 'prev_unknown', False) and not spec.feedforward    # (FF: no previous-variable input)
         ls.prev_unknown = address not in spec.address_id
         if ls.prev_unknown or prev_unknown:
@@ -374,9 +378,8 @@ class InferenceNetworkLSTM:
         seed = ls.seed + 7919 * j + 104729 * ls.path_id
         ls.flush()        # an earlier deferred draw is this statement's previous value: it must exist now
         info = spec.addresses[a]
-        prior_term = runner.dist_term(distribution)
-        if (ls.fused and ls.rows is None and ls.prev_addr_id is None and prior_term is not None and prior is not None and
-                prior.numel() == 2 and
+        prior_term = runner.dist_term(distribution) if (ls.fused and ls.rows is None and ls.prev_addr_id is None) else None
+        if (prior_term is not None and prior is not None and prior.numel() == 2 and
                 info.dist_name in ('Normal', 'Uniform', 'Poisson')):
             # First statement of a trace, full width: every particle has the same proposal. Only the network runs now; the
             # draw, - log q, + log p and the observe terms that follow become ONE pass over the particles at the next flush.

@@ -198,14 +198,12 @@ class ParticleTensor(torch.Tensor):
         if ls is not None and not kwargs and name in cls._PURE:
             memo = getattr(ls, 'memo', None)
             if memo is not None:
-                key = cls._memo_key(name, args)
+                with torch._C.DisableTorchFunctionSubclass():      # (metadata reads: no Python dispatch per attribute)
+                    key = cls._memo_key_plain(name, args)
+                    hit = memo.get(key) if key is not None else None
+                    if hit is not None and hit[0]._version == hit[1]:
+                        return hit[0]
                 if key is not None:
-                    hit = memo.get(key)
-                    if hit is not None:
-                        with torch._C.DisableTorchFunctionSubclass():
-                            fresh = hit[0]._version == hit[1]
-                        if fresh:
-                            return hit[0]
                     out = super().__torch_function__(func, types, args, {})
                     if isinstance(out, torch.Tensor):
                         with torch._C.DisableTorchFunctionSubclass():
@@ -345,6 +343,7 @@ class LockStepState(PathExecutor):
         # replay and its handful of small launches - queued behind the statement kernels - overlap the wait. One level deep.
         self.nest = None
         self._nest_depth = 0
+        self.wrappers = {}            # id(recorded values) -> (values, its ParticleTensor): replays hand out one object per tensor
         self.nest_ok = os.environ.get('PP_IS_NEST', '1') != '0'
         super().__init__(n, runner.dev)
 
