@@ -272,7 +272,9 @@ class PathExecutor:
         """Switch to the next queued path; False when none is left."""
         if not self.pending:
             return False
-        active, decisions, st_done, ob_done = self.pending.pop()
+        entry = self.pending.pop()
+        active, decisions, st_done, ob_done = entry[:4]
+        self._next_prefix = entry[4] if len(entry) > 4 else None      # (LockStepState: the statements of the replay prefix, in order)
         self.path_count = getattr(self, 'path_count', 0) + 1      # (ids in starting order; a nested run returns to its caller's id)
         self.path_id = self.path_count
         if self.path_id > 4096:
@@ -348,7 +350,7 @@ class LockStepState(PathExecutor):
         super().__init__(n, runner.dev)
 
     _PATH_FIELDS = ('rows', '_mask', 'n_active', 'decisions', 'decisions_seen', 'replay_statements', 'replay_observes', 'statement',
-                    'observes', 'prev_addr_id', 'prev_unknown', 'path_id')
+                    'observes', 'prev_addr_id', 'prev_unknown', 'path_id', 'history', 'prefix')
 
     def _run_nested(self):
         """Run the most recently queued path to its end inside the current execution (which is waiting at a branch)."""
@@ -367,6 +369,12 @@ class LockStepState(PathExecutor):
             _current_trace, _current_trace_previous_variable, _current_trace_execution_start = saved_trace
 
     def start_path(self, active, decisions, statements_done, observes_done):
+        # `history`: the controlled statements of this execution in order, (Variable, recorded values, address id, ParticleTensor).
+        # A queued path carries its parent's history as `prefix`: state.sample() replays statement j of the prefix from
+        # prefix[j] without building the address from the call stack again (a path at depth d replays 2 d statements: the
+        # frame walk, the Variable and the log look-up were ~8 us each, ~0.4 ms per call of the Marsaglia program)
+        self.history = []
+        self.prefix = self.__dict__.pop('_next_prefix', None)
         if not self.by_rows:
             return super().start_path(active, decisions, statements_done, observes_done)
         super().start_path(None, decisions, statements_done, observes_done)
@@ -410,7 +418,7 @@ class LockStepState(PathExecutor):
         elif n_true == 0:
             decision = False
         else:   # diverge: the False side is queued with everything this execution has done so far as its replay prefix
-            self.pending.append((rows_false, self.decisions + [False], self.statement, self.observes))
+            self.pending.append((rows_false, self.decisions + [False], self.statement, self.observes, list(self.history)))
             self.rows = rows_true
             self._mask = None
             self.n_active = n_true
@@ -780,6 +788,19 @@ def sample(distribution, name=None, address=None, control=True):
     global _current_trace_previous_variable
     if _current_trace is None:
         return distribution.sample()
+    ls = _lock_step
+    if ls is not None and ls.mode == 'is' and ls.prefix is not None and ls.statement < ls.replay_statements and \
+            ls.statement < len(ls.prefix) and (name is None or name not in _current_trace_observed_variables):
+        # a statement of the replay prefix, by position: what the parent execution recorded (same decisions, same statements)
+        entry = ls.prefix[ls.statement]
+        ls.statement += 1
+        variable, values, a, wrapper = entry
+        _current_trace.add(variable)          # (instance counting of the statements after the prefix)
+        if a is not None:
+            ls.prev_addr_id = a
+            ls.runner.prev_value = ls.runner.last_value = values
+        ls.history.append(entry)
+        return wrapper
     base, addr, instance = _make_address(distribution, address)
     if name in _current_trace_observed_variables and _coroutine is not None and _trace_mode == TraceMode.POSTERIOR:
         value = torch.as_tensor(_current_trace_observed_variables[name], dtype=torch.float32)
@@ -818,6 +839,10 @@ def sample(distribution, name=None, address=None, control=True):
         variable = Variable(distribution=distribution, value=value, address_base=base, address=addr, instance=instance,
                             log_prob=None, control=True, name=name)
         _current_trace.add(variable)
+        hist = getattr(ls, 'history', None)
+        if hist is not None:
+            rec = ls.log[ls.statement - 1].get(addr) if ls.statement - 1 < len(ls.log) else None
+            hist.append((variable, rec[0] if rec is not None else value.as_subclass(torch.Tensor), rec[1] if rec is not None else None, value))
         return value
 
     log_importance_weight = None
