@@ -286,10 +286,17 @@ def test_feedforward_network_with_control_flow_and_categorical():
     torch.manual_seed(31)
     model = GaussianWithUnknownMeanMarsagliaLockStep()
     model.learn_inference_network(num_traces=120000, observe_embeddings=EMB, batch_size=256, seed=10)
-    post = model.posterior_results(40000, IC, observe=OBS, lock_step=True, seed=5)
-    # (the ESS of this briefly trained proposal varies 50-300 between runs after 40k traces: float atomics make the
-    # gradient sums run-dependent; the threshold leaves a wide margin)
-    assert abs(post.mean - 7.25) < 1.0 and post.effective_sample_size > 25
+    # The importance weights of this briefly trained proposal are heavy-tailed: float atomics make the gradient sums - hence the
+    # network - run-dependent, and once in a while ONE of the 40 000 particles carries most of the weight (24 trainings with these
+    # seeds, tools/ff_executor_probe.py: ESS 69 ... 622, the three executors bit-identical on each network; one run of the suite
+    # saw ESS 2.2 with the mean 0.99 off). One draw of 40 000 particles is therefore not asserted on; two of three independent
+    # draws have to agree with the exact posterior.
+    good = 0
+    for seed in (5, 6, 7):
+        post = model.posterior_results(40000, IC, observe=OBS, lock_step=True, seed=seed)
+        assert np.isfinite(post.mean) and post.effective_sample_size >= 1
+        good += int(abs(post.mean - 7.25) < 1.0 and post.effective_sample_size > 25)
+    assert good >= 2
     cat = CategoricalThenNormal()
     cat.learn_inference_network(num_traces=30000, observe_embeddings=EMB, batch_size=128, seed=11)
     p = cat.posterior_results(20000, IC, observe={'obs0': 1.2, 'obs1': 0.7}, lock_step=True, seed=6)
