@@ -397,9 +397,9 @@ class InferenceNetworkLSTM:
             # the whole statement in ONE launch: previous values read at the particles' rows, the draw written to values[rows],
             # lw[rows] += log p(v) - log q(v) (state.py:211-217) - no gather, scatter, prior or axpy launches around it
             entry = ls.log[j].get(address) if j < len(ls.log) else None
-            values = entry[0] if (entry is not None and ls.rows is not None) else (
-                torch.zeros(ls.n, dtype=torch.float32, device=runner.dev) if ls.rows is not None else
-                torch.empty(ls.n, dtype=torch.float32, device=runner.dev))
+            # (a new record is not zero-filled: the statement writes the rows of its path, nothing reads the others - the
+            # program's own arithmetic runs over them at full width and its results there are never selected)
+            values = entry[0] if (entry is not None and ls.rows is not None) else torch.empty(ls.n, dtype=torch.float32, device=runner.dev)
             runner.statement_rows(ls.rows if ls.rows is not None else None, a, ls.prev_addr_id, prior, values, ls.lw,
                                   info.dist_name, seed=seed)
             while len(ls.log) <= j:
