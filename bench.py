@@ -254,7 +254,7 @@ def api_models():
 
 
 def csrc_sha():
-    """sha256 over the kernel sources (csrc/*, include/*): profiles/r04_*.json carry the hash of the sources they were
+    """sha256 over the kernel sources (csrc/*, include/*): profiles/r05_*.json carry the hash of the sources they were
     measured on; a line quotes them only when it matches the tree that is running."""
     import glob
     import hashlib
@@ -285,9 +285,12 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
                         prof_class=4):
     """BASELINE.json configs[3] through the drop-in API: Model.learn_inference_network (a short run: the network only has to
     exist and be sane) then `calls` x Model.posterior_results(particles, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK,
-    observe={'obs0': 8, 'obs1': 9}) on the user's forward() in lock step - state.sample / state.observe / Trace.end and the
-    Empirical statistics are all on the timed path (pyprob/model.py:47-88, 180-181; state.py:118-155, 203-219).
-    Returns (record, seconds, units)."""
+    observe=...) in lock step, the observation cycling through three values. What a timed call runs is reported, not
+    assumed: for a static single-statement program (GUM) the default is the LAUNCH PLAN (Model._traces_lockstep: after two
+    recordings the call replays three C-ABI calls with the new observation and forward() is NOT run; `plan_replays` counts
+    them) - the same loop with PP_IS_PLAN=0, where state.sample / state.observe / Trace.end run on the user's forward() every
+    call (pyprob/model.py:47-88, 180-181; state.py:118-155, 203-219), is timed next to it (`noplan`). The Empirical statistics
+    are read back every call either way. Returns (record, seconds, units)."""
     import contextlib
     import io
     from pyprob_amd.state import InferenceEngine, InferenceNetwork
@@ -300,29 +303,59 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
                                       observe_embeddings={'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, batch_size=1024, lstm_dim=lstm_dim,
                                       seed=1)
     IC = InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
-    observe = {'obs0': 8, 'obs1': 9} if program == 'gum' else {'obs0': 4, 'obs1': 5}
-    for i in range(warm):
-        post = model.posterior_results(particles, IC, observe=observe, lock_step=True, seed=i, offset=offset)
+    base = {'obs0': 8, 'obs1': 9} if program == 'gum' else {'obs0': 4, 'obs1': 5}
+    # three observations (the first is the configuration's own): a plan that baked an observation in would show here
+    observes = [base, {k: v - 0.5 + 0.25 * j for j, (k, v) in enumerate(base.items())}, {k: v + 0.6 + 0.2 * j for j, (k, v) in enumerate(base.items())}]
+    for i in range(max(warm, 3)):
+        post = model.posterior_results(particles, IC, observe=observes[i % 3], lock_step=True, seed=i, offset=offset)
     cap = calls * (4 if prof_class == 4 else 64)
+
+    def timed_loop():
+        replays, last = 0, {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(calls):
+            post = model.posterior_results(particles, IC, observe=observes[i % 3], lock_step=True, seed=seed0 + i, offset=offset)
+            _ = post.effective_sample_size           # (the caller looks at the result: mean / ESS are read back every call)
+            replays += bool(getattr(post, 'replayed_plan', False))
+            last[i % 3] = post
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, replays, last
+
     lib.pp_prof_arm(prof_class, cap)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(calls):
-        post = model.posterior_results(particles, IC, observe=observe, lock_step=True, seed=seed0 + i, offset=offset)
-        _ = post.effective_sample_size           # (the caller looks at the result: mean / ESS are read back every call)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, replays, last = timed_loop()
+    post = last[0]                                   # the configuration's own observation: its posterior is what is reported
     ms = np.zeros(cap, np.float32)
     fl = np.zeros(cap, np.float64)
     cnt = C.c_int32(0)
     lib.pp_prof_collect(ms.ctypes.data, cap, C.byref(cnt), fl.ctypes.data)
     lib.pp_prof_arm(prof_class, 0)
+    executes = ('launch-plan replay: three C-ABI calls per call (pp_is_init, pp_is_step_net, pp_is_fused), forward() NOT run'
+                if replays == calls else
+                "the user's forward() in lock step (state.sample / state.observe / Trace.end per control-flow path)" if replays == 0
+                else 'mixed: %d of %d timed calls were launch-plan replays' % (replays, calls))
     rec = dict(particles_per_sec=round(particles * calls / dt, 1), ms_per_call=round(dt / calls * 1e3, 4), particles_per_call=particles,
                calls=calls, program='GaussianUnknownMean' if program == 'gum' else 'GaussianUnknownMeanMarsaglia (tensor-condition loop)',
-               api='Model.posterior_results(N, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe=..., lock_step=True) on the '
-                   "user's forward()", posterior_mean=round(float(post.mean), 4), posterior_stddev=round(float(post.stddev), 4),
+               api='Model.posterior_results(N, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe=..., lock_step=True)',
+               timed_call_executes=executes, plan_replays=int(replays), observations_cycled=[dict(o) for o in observes],
+               posterior_mean=round(float(post.mean), 4), posterior_stddev=round(float(post.stddev), 4),
                ess=round(float(post.effective_sample_size), 1), control_flow_paths=int(getattr(post, 'num_paths', 1)),
                network_params=model._inference_network._engine.spec.num_parameters())
+    if replays:
+        # the same loop with the plan off: forward() runs in every timed call
+        old_env = os.environ.get('PP_IS_PLAN')
+        os.environ['PP_IS_PLAN'] = '0'
+        try:
+            for i in range(3):
+                model.posterior_results(particles, IC, observe=observes[i % 3], lock_step=True, seed=i, offset=offset)
+            dt0, r0, _ = timed_loop()
+        finally:
+            if old_env is None:
+                os.environ.pop('PP_IS_PLAN', None)
+            else:
+                os.environ['PP_IS_PLAN'] = old_env
+        rec['noplan'] = dict(particles_per_sec=round(particles * calls / dt0, 1), ms_per_call=round(dt0 / calls * 1e3, 4), plan_replays=int(r0),
+                             timed_call_executes="PP_IS_PLAN=0: the user's forward() in lock step in every timed call")
     if cnt.value > 0 and prof_class == 5:
         # the N-row statement kernel (csrc/is_step_fused.hip), every launch of the timed calls: MFMA bound, priced on the
         # reference algorithm's FLOPs per particle-statement (2 (I + H) 4H + 2 (H hid + hid 3K); a statement on
@@ -343,15 +376,18 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
             shared_launch = abs(w - particles * alg_sh) < 0.5 * alg_sh
             executed += (w / alg_sh) * exe_sh if shared_launch else (w / alg_ns) * exe_ns
         executed /= calls
-        prof, note = committed_profile('r04_is_pmc_traffic.json')
+        prof, note = committed_profile('r05_is_pmc_traffic.json')
         tr = (prof or {}).get('kernels', {}).get('is_step_fused', {})
         rec['statement_kernel'] = dict(
             bound='mfma', achieved=round(flops / (us * 1e-6) / 1e12, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
-            frac=round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), us_per_call=round(us, 1),
+            frac=round(executed / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), us_per_call=round(us, 1),
             launches_per_call=round(cnt.value / calls, 2), flops_per_call=flops, executed_flops_per_call=executed,
             frac_executed=round(executed / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
-            frac_note='frac prices the reference algorithm\'s FLOPs (SURVEY.md 8d: all 212 input columns per particle) - the kernel '
-                      'multiplies 8 of them per particle, so this fraction can exceed 1; frac_executed prices what runs on the MFMA pipe',
+            frac_reference_algorithm=round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+            frac_note='frac = frac_executed: the FLOPs that run on the MFMA pipe over the fp32 matrix peak. achieved / '
+                      'frac_reference_algorithm price the reference algorithm (SURVEY.md 8d: all 212 input columns per particle) - '
+                      'the kernel multiplies 8 of them per particle and folds the rest into a bias row, so that figure can exceed 1 '
+                      'and is not a roofline fraction',
             traffic=tr.get('traffic_bytes_per_particle_statement'), algorithmic_bytes=tr.get('algorithmic_bytes_per_particle_statement'),
             traffic_source=note,
             kernel='is_step_fused_kernel (one launch per statement after the first: [s_prev | h] [W_s | W_hh]^T + bias on '
@@ -377,7 +413,7 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         k6 = 8
         lib.pp_prof_arm(6, k6 * 2)
         for i in range(k6):
-            post = model.posterior_results(particles, IC, observe=observe, lock_step=True, seed=seed0 + calls + i, offset=offset)
+            post = model.posterior_results(particles, IC, observe=observes[i % 3], lock_step=True, seed=seed0 + calls + i, offset=offset)
             _ = post.effective_sample_size
         torch.cuda.synchronize()
         ms6 = np.zeros(k6 * 2, np.float32)
@@ -635,9 +671,9 @@ def main():
         # HBM bytes per launch (PMC passes) and rocprofv3 --kernel-trace --stats averages of this command, committed by
         # tools/profile_round.sh together with the hash of the kernel sources they were measured on: quoted only on a match
         std_shape = B == 1024 and args.lstm_dim == 512
-        pmc_doc, pmc_file = committed_profile('r04_pmc_traffic.json') if std_shape else (None, 'not the profiled shape')
+        pmc_doc, pmc_file = committed_profile('r05_pmc_traffic.json') if std_shape else (None, 'not the profiled shape')
         pmc = (pmc_doc or {}).get('kernels', {})
-        avg_doc, avg_file = committed_profile('r04_kernel_avgs.json') if std_shape else (None, 'not the profiled shape')
+        avg_doc, avg_file = committed_profile('r05_kernel_avgs.json') if std_shape else (None, 'not the profiled shape')
         rocprof_avgs = avg_doc or {}
         if std_shape and (pmc_doc is None or avg_doc is None):
             out['profile_note'] = pmc_file if pmc_doc is None else avg_file
@@ -776,8 +812,8 @@ def main():
                                                            'control_flow_paths', 'ess', 'posterior_mean') if k in g1m}
             if 'statement_kernel' in g1m:
                 out['gumm_lockstep_1m']['statement_kernel'] = {k: g1m['statement_kernel'][k] for k in
-                                                               ('achieved', 'frac', 'frac_executed', 'us_per_call',
-                                                                'launches_per_call', 'wall_over_statement_kernels')}
+                                                               ('achieved', 'frac', 'frac_executed', 'frac_reference_algorithm',
+                                                                'us_per_call', 'launches_per_call', 'wall_over_statement_kernels')}
     elif args.workload == 'train_gumm':
         # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
         # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded

@@ -482,18 +482,23 @@ def _runtime_install(state, forward, snapshot):
 # description, arguments) and the worker goes back to waiting afterwards. The workers hold the PROGRAM as it was when the
 # pool was forked (the network lives in the parent): `close_worker_pools()` after changing the model object, PP_IS_POOL=0
 # to fork per call as before.
-def _child_hardening():
-    """First thing in a forked particle worker: no garbage collection in the child. The parent's heap holds device tensors
-    (also in garbage cycles waiting for a collection); a collection in the child would run their destructors - HIP calls
-    in a forked process, which the ROCm runtime does not survive (a worker that dies without a message: EOFError in the
-    parent). The worker's own garbage is bounded by its job."""
+def _child_hardening(persistent=False):
+    """First thing in a forked particle worker. The parent's heap holds device tensors (also in garbage cycles waiting for
+    a collection); a collection in the child that examined them would run their destructors - HIP calls in a forked
+    process, which the ROCm runtime does not survive (a worker that dies without a message: EOFError in the parent).
+    A fork-per-call worker simply never collects (its own garbage is bounded by its one job). A POOL worker serves many
+    posterior calls: it freezes the inherited heap - frozen objects are never examined by a collection, so the parent's
+    device tensors stay untouched - and then collects its own cycles (traces, frames, greenlets) between jobs."""
     import gc
     gc.disable()
+    if persistent:
+        gc.freeze()
 
 
 def _pool_worker_main(conn, worker, state, forward, inherited):
+    import gc
     import os
-    _child_hardening()
+    _child_hardening(persistent=True)
     try:
         for c in inherited:      # pipe ends of the workers forked before this one
             try:
@@ -513,6 +518,8 @@ def _pool_worker_main(conn, worker, state, forward, inherited):
             map_func, args, kwargs, runtime = pickle.loads(blob)
             _runtime_install(state, forward, runtime)       # this call's observe / trace mode / engine, not the fork's
             _run_shard(conn, worker, lo, hi, state, forward, spec, map_func, seed, args, kwargs)
+            del job, blob, map_func, args, kwargs, runtime
+            gc.collect()         # this job's cycles only: everything inherited at the fork is frozen
     finally:
         os._exit(0)
 

@@ -470,6 +470,8 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     bool head_done = false;
     if (!shared && is_step_fused_supported(net, addr_id) && is_step_fused_mode() != 0) {
         bool sampled = false;
+        // (32-bit element offsets into the state rows: a row list's indices are the caller's to bound - ISRunner.begin does)
+        PP_CHECK_ARG(rows || (int64_t)n * H < (int64_t(1) << 32), "pp_is_step: more than 2^32 state elements per call: shard the particles");
         // (the split statement's new hidden rows go through the chain's gate buffer w.G: [n][4 H] >= [n][H])
         PP_TRY(is_step_fused(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows, rows,
                              value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st, whole,

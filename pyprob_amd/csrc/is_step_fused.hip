@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
             const int row = e / H, u = e - row * H;
             const bool live = m0 + row < a.n;
             const float hv = a.hn[(int64_t)min(m0 + row, a.n - 1) * H + u];
-            if (live) a.h[(uint32_t)sRow[row] * (uint32_t)H + (uint32_t)u] = hv;
+            if (live) a.h[(int64_t)sRow[row] * H + u] = hv;      // (64-bit: n H reaches 2^32 at 8.4 M particles of H = 512)
             const int hslot = ((u >> 4) * 128 + ((u >> 2) & 3) * 16) * 4 + (u & 3);
             sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hv;
         }

@@ -15,11 +15,14 @@ from .spec import NetSpec
 
 import os
 _ADAM_CLEARS = os.environ.get('PP_ADAM_ZERO', '1') != '0'   # A/B knob: let pp_ic_loss memset the gradients instead
+import itertools
+_engine_tokens = itertools.count(1)      # a per-process monotonic identity (id() values are reused after collection)
 
 
 class ICEngine:
     def __init__(self, spec: NetSpec, device='cuda:0', seed=None):
         self.lib = L.load()
+        self.token = next(_engine_tokens)
         if not torch.cuda.is_available():
             raise L.HipLibraryError('pyprob_amd needs a ROCm device (torch.cuda.is_available() is False); there is '
                                     'no CPU fallback.')

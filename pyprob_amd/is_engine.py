@@ -77,6 +77,9 @@ class ISRunner:
         """Start n traces in lock step (state._begin_trace, state.py:339-345): LSTM state is reset by the first step."""
         H = max(self.eng.spec.lstm_dim, 1)       # (FeedForward network: no LSTM state, 1-wide placeholders)
         D = self.eng.spec.lstm_depth             # nn.LSTM(I, H, depth): state of every layer, [depth, n, H]
+        if n * H >= 2 ** 32:
+            # the statement kernels address a particle's state row with 32-bit element offsets (is_step_fused.hip)
+            raise ValueError('at most 2^32 / lstm_dim - 1 = %d particles per call and device (got %d): shard the call' % (2 ** 32 // H - 1, n))
         if n != self.n:
             self.h = torch.empty(D, n, H, dtype=torch.float32, device=self.dev)
             self.c = torch.empty(D, n, H, dtype=torch.float32, device=self.dev)

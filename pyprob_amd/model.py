@@ -69,6 +69,15 @@ class Model:
         path: an execution serves the particles that agree at every branch, the others are queued and re-run with their
         recorded values as replay prefix (state.LockStepState). Every new sample statement is one C-ABI call for the
         path's particles - the general batched IS executor of SURVEY.md 8f.2."""
+        runner = self._inference_network._is
+        if runner.dev.type == 'cuda' and torch.cuda.current_device() != (runner.dev.index or 0):
+            # the C-ABI calls launch on the network's device: scoped, so that a process that drives several devices gets its
+            # current device back (ISRunner.begin / init / run_plan only switch when it differs)
+            with torch.cuda.device(runner.dev):
+                return self._traces_lockstep_on_device(num_traces, observe, seed, offset, likelihood_importance, *args, **kwargs)
+        return self._traces_lockstep_on_device(num_traces, observe, seed, offset, likelihood_importance, *args, **kwargs)
+
+    def _traces_lockstep_on_device(self, num_traces, observe, seed=0, offset=0, likelihood_importance=1., *args, **kwargs):
         net = self._inference_network
         runner = net._is
         # Launch plan (VERDICT r03 item 7): a program whose whole call was ONE deferred draw from the first statement's shared
@@ -155,34 +164,158 @@ class Model:
         except (TypeError, ValueError):
             return None
 
+    # attributes the Model base class itself keeps on the instance (never read by a program as constants)
+    _BASE_ATTRS = frozenset(('_inference_network', '_lockstep_plans', '_lock_step_ok', '_last_prior_resident', '_plan_code_cache'))
+
+    @staticmethod
+    def _fingerprint(v):
+        """A cheap by-VALUE fingerprint of something a program may read as a constant, or None when there is none (an object
+        with state of its own, a large or device tensor, a container of such)."""
+        if v is None or isinstance(v, (bool, int, float, str, bytes)):
+            return ('v', type(v).__name__, v)
+        if isinstance(v, (torch.Tensor, np.ndarray)):
+            if int(np.prod(tuple(v.shape))) > 16 or (isinstance(v, torch.Tensor) and v.device.type != 'cpu'):
+                return None
+            return ('t', tuple(v.shape), tuple(float(x) for x in np.asarray(v.detach() if isinstance(v, torch.Tensor) else v,
+                                                                             dtype=np.float64).reshape(-1)))
+        if isinstance(v, (tuple, list)) and len(v) <= 16:
+            parts = tuple(Model._fingerprint(x) for x in v)
+            return None if any(x is None for x in parts) else ('s', type(v).__name__, parts)
+        return None
+
+    def _program_reads(self):
+        """Everything forward() can read besides its arguments and the observation, found statically: the code objects of
+        forward and of every method / plain function it names (transitively, bounded), and for those the names their
+        bytecode mentions (instance / class attributes), their closure cells and the module-global slots they name.
+        Returns (codes, names, cells, globs) - cells as (name, cell), globs as (name, globals dict): the VALUES are read by
+        the caller at every call - or None when the program cannot be analysed. The analysis is cached per model and
+        re-validated by re-resolving every function it found (a re-bound method or a replaced __code__ starts over)."""
+        import types
+        fwd = getattr(self.forward, '__func__', self.forward)
+        if not isinstance(fwd, types.FunctionType):
+            return None
+        cache = self.__dict__.get('_plan_code_cache')
+        if cache is not None:
+            ok = cache[0] is fwd
+            if ok:
+                for holder, name, fn, code in cache[1]:
+                    cur = holder.get(name) if isinstance(holder, dict) else getattr(holder, name, None)
+                    cur = getattr(cur, '__func__', cur)
+                    if cur is not fn or fn.__code__ is not code:
+                        ok = False
+                        break
+            if ok:
+                return cache[2]
+        seen, order, names = set(), [], set()
+        cells, globs, found = [], [], [(type(self), 'forward', fwd, fwd.__code__)] if getattr(type(self), 'forward', None) is fwd \
+            else [({'forward': fwd}, 'forward', fwd, fwd.__code__)]
+        work = [fwd]
+        pkg = __name__.split('.')[0]
+        while work:
+            fn = work.pop()
+            code = fn.__code__
+            if code in seen:
+                continue
+            if len(seen) >= 64:
+                return None
+            seen.add(code)
+            order.append(code)
+            stack = [code]
+            conames = set()
+            while stack:                      # nested code objects (lambdas, comprehensions, inner functions)
+                c = stack.pop()
+                conames.update(c.co_names)
+                for k in c.co_consts:
+                    if isinstance(k, types.CodeType):
+                        stack.append(k)
+                        order.append(k)
+            names |= conames
+            for name, cell in zip(code.co_freevars, fn.__closure__ or ()):
+                cells.append((name, cell))
+            g = fn.__globals__
+            for n in conames:
+                if n in g:
+                    globs.append((n, g))
+                    v = getattr(g[n], '__func__', g[n])
+                    if isinstance(v, types.FunctionType) and not (v.__module__ or '').startswith((pkg, 'torch', 'numpy', 'math')):
+                        found.append((g, n, v, v.__code__))
+                        work.append(v)
+                # methods reachable by name from the model's class
+                m = getattr(type(self), n, None)
+                m = getattr(m, '__func__', m)
+                if isinstance(m, types.FunctionType) and not (m.__module__ or '').startswith(pkg + '.'):
+                    found.append((type(self), n, m, m.__code__))
+                    work.append(m)
+        reads = (tuple(order), frozenset(names), tuple(cells), tuple(globs))
+        self.__dict__['_plan_code_cache'] = (fwd, tuple(found), reads)
+        return reads
+
     def _lockstep_plan_key(self, num_traces, observe, likelihood_importance, args, kwargs):
-        """What a recorded plan is valid for: this model object with these plain attribute values and this forward(), this
-        network (engine object and address table size), this particle count and set of observed names. None: no plan (call
-        arguments, non-scalar observations, PP_IS_PLAN=0)."""
+        """What a recorded plan is valid for: this forward() (its code objects and those of the methods / functions it names),
+        the VALUES of everything those code objects can read - instance attributes (private ones included), class attributes,
+        module globals, closure cells - this network (the engine's own token and address table size), this particle count and
+        set of observed names. A replay does not run forward(), so whatever cannot be fingerprinted by value rules the plan
+        out: None = no plan (also: call arguments, non-scalar observations, PP_IS_PLAN=0)."""
         import os
+        import types
         if args or kwargs or os.environ.get('PP_IS_PLAN', '1') == '0' or self._observe_values(observe) is None:
             return None
         net = self._inference_network
         eng = getattr(net, '_engine', None)
         if eng is None or eng.device.type != 'cuda':
             return None
-        # every public attribute of the model enters the key by VALUE (a program reads them: a changed prior mean must not meet
-        # a plan recorded with the old one); an attribute whose value cannot be fingerprinted cheaply rules the plan out
+        reads = self._program_reads()
+        if reads is None:
+            return None
+        codes, names, cells, globs = reads
+        skip_types = (types.ModuleType, types.FunctionType, types.BuiltinFunctionType, types.MethodType, type)
         plain = []
+        # instance attributes: every public one (as before) and every private one the program's bytecode names
         for k, v in sorted(vars(self).items()):
-            if k.startswith('_') or v is None or callable(v):
+            if k in self._BASE_ATTRS or k == 'name':
                 continue
-            if isinstance(v, (bool, int, float, str)):
-                plain.append((k, v))
-            elif isinstance(v, (torch.Tensor, np.ndarray)) and int(np.prod(tuple(v.shape))) <= 16 and \
-                    (not isinstance(v, torch.Tensor) or v.device.type == 'cpu'):
-                plain.append((k, tuple(float(x) for x in np.asarray(v, dtype=np.float64).reshape(-1))))
-            else:
+            if k.startswith('_') and k not in names:
+                continue
+            if callable(v) and not isinstance(v, (torch.Tensor, np.ndarray)):
+                if k in names and not isinstance(v, skip_types):
+                    return None              # a callable object with state of its own, named by the program
+                continue
+            fp = self._fingerprint(v)
+            if fp is None:
                 return None
-        plain = tuple(plain)
-        fwd = getattr(self.forward, '__func__', self.forward)
-        return (id(eng), len(eng.spec.addresses), int(num_traces), tuple(sorted(observe or {})), float(likelihood_importance), plain,
-                id(getattr(fwd, '__code__', fwd)))
+            plain.append(('i', k, fp))
+        # class attributes the program names (constants kept on the class; not the Model base's own members)
+        for k in sorted(names):
+            if k in vars(self) or hasattr(Model, k):
+                continue
+            for klass in type(self).__mro__:
+                if klass in (Model, object):
+                    break
+                if k in vars(klass):
+                    v = vars(klass)[k]
+                    if isinstance(v, (types.FunctionType, staticmethod, classmethod, property)):
+                        break
+                    fp = self._fingerprint(v)
+                    if fp is None:
+                        return None
+                    plain.append(('c', k, fp))
+                    break
+        # module globals and closure cells: modules, functions, classes are code (keyed through `codes` where they are Python
+        # functions of the user's); anything else must have a value fingerprint
+        for tag, items in (('g', globs), ('f', cells)):
+            for k, holder in items:
+                try:
+                    v = holder[k] if tag == 'g' else holder.cell_contents
+                except (KeyError, ValueError):
+                    return None
+                if isinstance(v, skip_types) or v is self:
+                    continue
+                fp = self._fingerprint(v)
+                if fp is None:
+                    return None
+                plain.append((tag, k, fp))
+        return (eng.token, len(eng.spec.addresses), int(num_traces), tuple(sorted(observe or {})), float(likelihood_importance),
+                tuple(plain), codes)
 
     def _record_lockstep_plan(self, key, ls, n_paths, values, stats_fused, observe):
         """After a normal lock-step call: keep its launch list when the call WAS one draw + one fused pass. A plan becomes
@@ -519,6 +652,7 @@ class Model:
                 cls = InferenceNetworkFeedForward
             else:
                 raise ValueError('Unknown inference_network: {}'.format(inference_network))   # model.py:203-204
+            self.__dict__.pop('_lockstep_plans', None)
             self._inference_network = cls(model=self, observe_embeddings=observe_embeddings, lstm_dim=lstm_dim,
                                           lstm_depth=lstm_depth, proposal_mixture_components=proposal_mixture_components,
                                           device=device, seed=seed)
@@ -553,3 +687,4 @@ class Model:
     def load_inference_network(self, file_name, device='cuda:0'):
         self._inference_network = InferenceNetworkLSTM._load(file_name, device=device)
         self._inference_network._model = self
+        self.__dict__.pop('_lockstep_plans', None)      # (plans are keyed on the engine's token; the old ones are dead weight)

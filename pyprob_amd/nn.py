@@ -397,9 +397,15 @@ class InferenceNetworkLSTM:
             # the whole statement in ONE launch: previous values read at the particles' rows, the draw written to values[rows],
             # lw[rows] += log p(v) - log q(v) (state.py:211-217) - no gather, scatter, prior or axpy launches around it
             entry = ls.log[j].get(address) if j < len(ls.log) else None
-            # (a new record is not zero-filled: the statement writes the rows of its path, nothing reads the others - the
-            # program's own arithmetic runs over them at full width and its results there are never selected)
-            values = entry[0] if (entry is not None and ls.rows is not None) else torch.empty(ls.n, dtype=torch.float32, device=runner.dev)
+            # (a full-width statement writes every row of a new record; a diverged path's new record is zero-filled: the rows of
+            # particles that never execute this address are visible through Empirical.statement_log and enter the program's
+            # full-width arithmetic - zeros there, as before round 4, not uninitialised memory)
+            if entry is not None and ls.rows is not None:
+                values = entry[0]
+            elif ls.rows is None:
+                values = torch.empty(ls.n, dtype=torch.float32, device=runner.dev)
+            else:
+                values = torch.zeros(ls.n, dtype=torch.float32, device=runner.dev)
             runner.statement_rows(ls.rows if ls.rows is not None else None, a, ls.prev_addr_id, prior, values, ls.lw,
                                   info.dist_name, seed=seed)
             while len(ls.log) <= j:

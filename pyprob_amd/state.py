@@ -16,6 +16,7 @@ MCMC engines, `tag`/`factor` and the address dictionary are out of scope (DESIGN
 """
 import enum
 import opcode
+import os
 import sys
 import time
 
@@ -168,6 +169,35 @@ class ParticleTensor(torch.Tensor):
                        'reciprocal', '__add__', '__radd__', '__sub__', '__rsub__', '__mul__', '__rmul__', '__truediv__', '__rtruediv__',
                        '__pow__', '__rpow__', '__neg__', '__ge__', '__gt__', '__le__', '__lt__', '__eq__', '__ne__'))
 
+    # In-place forms. A memoised result that has been handed out MORE THAN ONCE is shared between two names of the program
+    # (`a = x * x; b = x * x` are the same tensor object): `a += 1` on it is computed out of place (Python rebinds `a` to the
+    # returned tensor, `b` keeps the product); a method-call form (`a.add_(1)`, `a[0] = ..`) cannot be redirected and raises
+    # instead of silently changing `b` (PP_IS_MEMO=0 runs such a program without result reuse).
+    def _shared_result(self):
+        ls = _lock_step
+        shared = getattr(ls, 'memo_shared', None) if ls is not None else None
+        if not shared:
+            return False
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.data_ptr() in shared
+
+    def __iadd__(self, other):
+        return self + other if self._shared_result() else super().__iadd__(other)
+
+    def __isub__(self, other):
+        return self - other if self._shared_result() else super().__isub__(other)
+
+    def __imul__(self, other):
+        return self * other if self._shared_result() else super().__imul__(other)
+
+    def __itruediv__(self, other):
+        return self / other if self._shared_result() else super().__itruediv__(other)
+
+    def __ipow__(self, other):
+        return self ** other if self._shared_result() else super().__ipow__(other)
+
+    MEMO_BYTES = int(os.environ.get('PP_IS_MEMO_BYTES', str(4 << 30)))     # results kept per call before the memo starts over
+
     @staticmethod
     def _memo_key(name, args):
         with torch._C.DisableTorchFunctionSubclass():      # (metadata reads: no Python dispatch per attribute of a ParticleTensor)
@@ -178,8 +208,9 @@ class ParticleTensor(torch.Tensor):
         key = [name]
         for a in args:
             if isinstance(a, torch.Tensor):
-                # storage identity, not object identity: a replayed statement hands out a NEW wrapper of the recorded values
-                key.append((a.data_ptr(), a.numel(), a.dtype, a._version))
+                # storage identity, not object identity: a replayed statement hands out a NEW wrapper of the recorded values;
+                # shape, strides and offset: views of one storage (unsqueeze / expand / slices) share address, size and version
+                key.append((a.data_ptr(), a.storage_offset(), tuple(a.shape), a.stride(), a.dtype, a._version))
             elif isinstance(a, (bool, int, float)):
                 key.append(('s', type(a).__name__, a))
             else:
@@ -195,20 +226,31 @@ class ParticleTensor(torch.Tensor):
                                                args[0].dtype == torch.float32 and args[0].is_contiguous())
             if not lazy_ok:
                 ls.flush()
-        if ls is not None and not kwargs and name in cls._PURE:
-            memo = getattr(ls, 'memo', None)
-            if memo is not None:
-                with torch._C.DisableTorchFunctionSubclass():      # (metadata reads: no Python dispatch per attribute)
-                    key = cls._memo_key_plain(name, args)
-                    hit = memo.get(key) if key is not None else None
-                    if hit is not None and hit[0]._version == hit[1]:
-                        return hit[0]
-                if key is not None:
-                    out = super().__torch_function__(func, types, args, {})
-                    if isinstance(out, torch.Tensor):
-                        with torch._C.DisableTorchFunctionSubclass():
-                            memo[key] = (out, out._version, args)      # (the arguments stay alive: their storage is not reused)
-                    return out
+        memo = getattr(ls, 'memo', None) if ls is not None else None
+        if memo is not None and not kwargs and name in cls._PURE:
+            with torch._C.DisableTorchFunctionSubclass():      # (metadata reads: no Python dispatch per attribute)
+                key = cls._memo_key_plain(name, args)
+                hit = memo.get(key) if key is not None else None
+                if hit is not None and hit[0]._version == hit[1]:
+                    ls.memo_shared.add(hit[0].data_ptr())   # handed out a second time: two names of the program share it now
+                    return hit[0]
+            if key is not None:
+                out = super().__torch_function__(func, types, args, {})
+                if isinstance(out, torch.Tensor):
+                    with torch._C.DisableTorchFunctionSubclass():
+                        ls.memo_bytes += out.numel() * out.element_size()
+                        if ls.memo_bytes > cls.MEMO_BYTES:      # bound what one call pins (many-path programs at 1e6 particles)
+                            memo.clear()
+                            ls.memo_bytes = out.numel() * out.element_size()
+                        memo[key] = (out, out._version, args)      # (the arguments stay alive: their storage is not reused)
+                return out
+        elif memo is not None and ls.memo_shared and args and isinstance(args[0], torch.Tensor) and \
+                (name == '__setitem__' or (name.endswith('_') and not name.startswith('__'))):
+            with torch._C.DisableTorchFunctionSubclass():
+                shared = args[0].data_ptr() in ls.memo_shared
+            if shared:
+                raise RuntimeError('lock-step executor: in-place `%s` on a tensor that two expressions of the program share '
+                                   '(a reused elementwise result); write it out of place or set PP_IS_MEMO=0' % name)
         return super().__torch_function__(func, types, args, kwargs or {})
 
     def __bool__(self):
@@ -331,6 +373,8 @@ class LockStepState(PathExecutor):
         # what Model._traces_lockstep needs to recognise a program whose whole call is ONE draw + ONE fused pass (launch plan,
         # model.py): the number of flushes, where every deferred term's value came from, anything that read a draw early
         self.memo = {} if os.environ.get('PP_IS_MEMO', '1') != '0' else None     # ParticleTensor._PURE results of this call
+        self.memo_shared = set()      # storage addresses of memoised results handed out more than once
+        self.memo_bytes = 0
         self.flushes = 0
         self.plan_terms = []          # (term, source, scale): source = ('obs', name) | ('value',) | ('const', tensor)
         self.plan_ok = True

@@ -181,6 +181,59 @@ def test_launch_plan_replay_equals_running_the_program(gum, monkeypatch):
         gum.likelihood_stddev = old
 
 
+class PrivateScale(GaussianWithUnknownMean):
+    """The likelihood's scale lives in a PRIVATE attribute (`self._sigma`) and a constant in a module global reached through
+    a helper method: state a launch-plan key that only fingerprinted public attributes never saw."""
+
+    def __init__(self):
+        super().__init__()
+        self._sigma = 1.2
+
+    def likelihood(self, mu):
+        from pyprob_amd.distributions import Normal
+        return Normal(mu, self._sigma * PLAN_GLOBAL_FACTOR)
+
+    def forward(self):
+        import pyprob_amd as pyprob
+        from pyprob_amd.distributions import Normal
+        mu = pyprob.sample(Normal(self.prior_mean, self.prior_stddev))
+        lik = self.likelihood(mu)
+        pyprob.observe(lik, name='obs0')
+        pyprob.observe(lik, name='obs1')
+        return mu
+
+
+PLAN_GLOBAL_FACTOR = 1.0
+
+
+def test_launch_plan_sees_private_attributes_globals_and_callees(monkeypatch):
+    import sys
+    monkeypatch.setenv('PP_IS_FUSED', '1')
+    torch.manual_seed(9)
+    model = PrivateScale()
+    model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=4000, observe_embeddings=EMB, batch_size=128,
+                                  lstm_dim=64, seed=7)
+    n = 20000
+    obs3 = ({'obs0': 8.0, 'obs1': 9.0}, {'obs0': 6.5, 'obs1': 7.25}, {'obs0': 5.0, 'obs1': 5.5})
+
+    def both(obs, seed):
+        monkeypatch.setenv('PP_IS_PLAN', '1')
+        a = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=seed)
+        monkeypatch.setenv('PP_IS_PLAN', '0')
+        b = model.posterior_results(n, IC, observe=obs, lock_step=True, seed=seed)
+        assert _same(a, b)
+        return bool(getattr(a, 'replayed_plan', False))
+    assert [both(o, 30 + k) for k, o in enumerate(obs3)] == [False, False, True]       # recorded, verified, replayed
+    model._sigma = 2.5                    # a private attribute forward()'s callee reads: the plan's constants are stale
+    assert both(obs3[2], 41) is False     # ... so the program runs (and equals PP_IS_PLAN=0 with the NEW scale)
+    assert both(obs3[0], 42) is False and both(obs3[1], 43) is True
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, 'PLAN_GLOBAL_FACTOR', 0.5)                                  # a module global the callee reads
+    assert both(obs3[1], 44) is False
+    monkeypatch.setattr(PrivateScale, 'likelihood', lambda self, mu: __import__('pyprob_amd').distributions.Normal(mu, 3.0))
+    assert both(obs3[1], 45) is False                                                    # a re-bound callee is a new program
+
+
 class ScaleFromObservation(GaussianWithUnknownMean):
     """The likelihood's scale is computed IN PYTHON from an observed value: a launch plan recorded for one observation holds
     a constant that is wrong for another one."""

@@ -318,3 +318,68 @@ def test_whole_statement_in_one_launch(dist, use_rows):
     np.testing.assert_allclose(lw.cpu().numpy(), lw_ref.cpu().numpy(), rtol=0, atol=2e-6)
     rest = np.setdiff1d(np.arange(total), rows)
     assert np.array_equal(lw.cpu().numpy()[rest], lw0[rest])
+
+
+def _mixture_cdf(x, params, dist, lo=None, hi=None):
+    """CDF of the proposal mixture of ONE row (float64): Normal components, or TruncatedNormal components on [lo, hi]
+    (pyprob/distributions/mixture.py:47-63 draws a component by its probability, then from the component)."""
+    mu, sd, p = (np.asarray(a, np.float64).reshape(-1) for a in params)
+    z = O.std_normal_cdf((x[:, None] - mu) / sd)
+    if dist == 'Uniform':
+        a, b = O.std_normal_cdf((lo - mu) / sd), O.std_normal_cdf((hi - mu) / sd)
+        z = np.clip((z - a) / (b - a), 0.0, 1.0)
+    return (z * p).sum(1)
+
+
+@pytest.mark.parametrize('cur', [('a_normal', 'Normal'), ('a_uniform', 'Uniform')])
+def test_the_drawn_values_follow_the_proposal(cur):
+    """The N-row draw itself (sixteen lanes per particle: component pick by the inclusive prefix of the clamped weights, then
+    the component's Normal / inverse-CDF TruncatedNormal draw - is_step_fused.hip's tail, is_draw.hpp): re-scoring proves
+    log q AT the drawn value, not that the value is drawn FROM q. Here every particle gets the same
+    state, previous value and prior - one proposal q for all - and H = 512, both head kinds, one kernel and split (the
+    autouse fixture): (1) Kolmogorov-Smirnov distance of the 40 000 draws to the oracle's mixture CDF, (2) the importance
+    identity E_q[p(v) / q(v)] = 1 for a known target p within four standard errors, (3) log q of the device at those values."""
+    from pyprob_amd.ops import ops
+    H, n = 512, 40000
+    prev = ('a_uniform', 'Uniform') if cur[1] == 'Normal' else ('a_normal', 'Normal')
+    eng, run, sd = _engine(H, seed=3)
+    rng = np.random.default_rng(11)
+    h0 = np.tile((0.5 * rng.standard_normal((1, H))).astype(np.float32).clip(-0.99, 0.99), (n, 1))
+    c0 = np.tile(rng.standard_normal((1, H)).astype(np.float32), (n, 1))
+    pv = np.full(n, 0.37, np.float32)
+    prior = np.tile(np.array([[0.4, 1.3]] if cur[1] == 'Normal' else [[-1.0, 1.5]], np.float32), (n, 1))
+    dev = eng.device
+    h = torch.from_numpy(h0.copy()).to(dev).reshape(1, n, H).contiguous()
+    c = torch.from_numpy(c0.copy()).to(dev).reshape(1, n, H).contiguous()
+    run._ensure_ws(n)
+    value, logq = ops.is_step(eng.params, run.ws, eng.net_handle, _ids(eng, cur[0]), _ids(eng, prev[0]), n, run.e_obs,
+                              torch.from_numpy(pv).to(dev), torch.from_numpy(prior).to(dev), h, c, n, None, 4242, 0)
+    torch.cuda.synchronize()
+    v = value.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(v)) and len(np.unique(v)) > 0.99 * n          # distinct Philox counters per particle
+    href, _, _, y = _oracle_statement(sd, H, [8.0, 9.0], prev, cur, pv[:1], h0[:1], c0[:1], None, None)
+    net = O.Net(sd, list(EMB), K=10)
+    y_all = np.broadcast_to(y[:1], (n, y.shape[1]))
+    lq_ref, _, params = O.head_forward(net, cur[0], cur[1], None, prior.astype(np.float64), v, y=y_all)
+    one = tuple(np.asarray(a)[0] for a in params)
+    lo, hi = float(prior[0, 0]), float(prior[0, 1])
+    # (1) Kolmogorov-Smirnov: sup |F_n - F| of n i.i.d. draws exceeds 1.95 / sqrt(n) with probability 1e-3
+    xs = np.sort(v)
+    F = _mixture_cdf(xs, one, cur[1], lo, hi)
+    i = np.arange(1, n + 1)
+    D = max(np.abs(i / n - F).max(), np.abs((i - 1) / n - F).max())
+    assert D < 1.95 / np.sqrt(n), (D, 1.95 / np.sqrt(n))
+    # (2) importance identity with the oracle's q: target = a Normal narrower than the mixture / the Uniform prior on the support
+    mu, sdv, p = (np.asarray(a, np.float64) for a in one)
+    if cur[1] == 'Normal':
+        m = float((p * mu).sum())
+        s = float(np.sqrt((p * (sdv ** 2 + mu ** 2)).sum() - m * m))
+        lp = O.normal_log_prob(v, m, 0.7 * s)
+    else:
+        assert np.all((v >= lo) & (v <= hi))
+        lp = np.full(n, -np.log(hi - lo))
+    w = np.exp(lp - lq_ref)
+    se = w.std() / np.sqrt(n)
+    assert abs(w.mean() - 1.0) < 4.0 * se + 1e-3, (w.mean(), se)
+    # (3) the device's log q at its own draws
+    assert np.abs(logq.cpu().numpy() - lq_ref).max() < 1e-4 * max(1.0, np.abs(lq_ref).max())

@@ -109,10 +109,14 @@ def _gumm_steps(post, addresses, n):
     return steps, results
 
 
-@pytest.mark.parametrize('n', [65537])
-def test_gumm_posterior_every_particle_rescored(gumm_trained, n):
+@pytest.mark.parametrize('n', [65537, 200000, 1000000])
+def test_gumm_posterior_every_particle_rescored(gumm_trained, n, monkeypatch):
     """Stochastic control flow at H = 512: the second statement (shared first state), then N-row statements on the rows of
-    the diverged paths (in place through the row index list) - the fused statement kernel - re-scored per particle."""
+    the diverged paths (in place through the row index list) - the fused statement kernel - re-scored per particle.
+    200 000 and 10^6 are the particle counts of bench.py's `gumm_lockstep` / `gumm_lockstep_1m` records, with the executor's
+    defaults (nested paths, the one-kernel / split switch at 4 096 rows, row lists): VERDICT r04 weak 1c."""
+    for k in ('PP_IS_NEST', 'PP_IS_ROWS', 'PP_IS_STEP_FUSED', 'PP_IS_MEMO', 'PP_IS_PLAN', 'PP_IS_FUSED'):
+        monkeypatch.delenv(k, raising=False)          # the defaults the bench line runs with
     model = gumm_trained
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
@@ -121,7 +125,7 @@ def test_gumm_posterior_every_particle_rescored(gumm_trained, n):
     net, addresses = _oracle_net(model)
     steps, results = _gumm_steps(post, addresses, n)
     assert len(steps) >= 4
-    _, lw_ref = O.is_rescore_lockstep(net, [8.0, 9.0], steps, n)
+    _, lw_ref = O.is_rescore_lockstep(net, [8.0, 9.0], steps, n, chunk=1 << 17)
     lw_ref = lw_ref + _likelihood(results)
     lw = post._all_log_weights.cpu().numpy().astype(np.float64)
     v = post._all_values.cpu().numpy().astype(np.float64)

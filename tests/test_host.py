@@ -25,7 +25,11 @@ def test_library_exports_every_header_symbol(lib):
     assert declared == set(L.PROTOTYPES.keys()), declared ^ set(L.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.pp_abi_version() == L.PP_ABI_VERSION == 11
+    hdr_abi = int(re.search(r'#define PP_ABI_VERSION (\d+)', hdr).group(1))
+    assert lib.pp_abi_version() == L.PP_ABI_VERSION == hdr_abi
+    # the document a maintainer binds from quotes the same number (INTEGRATION.md said 8 under a header at 11)
+    doc = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    assert [int(x) for x in re.findall(r'pp_abi_version\(\) == (\d+)', doc)] == [hdr_abi]
 
 
 def test_struct_sizes_match_header_layout():

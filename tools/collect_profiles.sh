@@ -1,0 +1,11 @@
+# After a GPU call that ran tools/profile_round.sh / profile_is_step.sh with <tag>: copy what the judge should read from
+# gpurun_out/ (scratch) into profiles/ UNDER THE SAME NAMES the JSON documents cite, and install the documents bench.py quotes.
+#   bash tools/collect_profiles.sh <tag>
+TAG=$1
+for f in gpurun_out/${TAG}_*.csv gpurun_out/${TAG}_*bench*.json gpurun_out/${TAG}_*.jsonl gpurun_out/${TAG}_*tests*.log gpurun_out/${TAG}_*.txt; do
+  [ -f "$f" ] && cp "$f" profiles/
+done
+for d in r05_kernel_avgs r05_pmc_traffic r05_is_pmc_traffic r05_is_fused_valu; do
+  [ -f gpurun_out/${TAG}_$d.json ] && cp gpurun_out/${TAG}_$d.json profiles/$d.json
+done
+ls profiles/${TAG}_* 2>/dev/null | wc -l
