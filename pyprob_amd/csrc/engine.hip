@@ -4,6 +4,7 @@
 #include "gather.hpp"
 #include "aux_jobs.hpp"
 #include "panel.hpp"
+#include "panel16.hpp"
 #include "wgrad_t1.hpp"
 
 #include <stdlib.h>
@@ -150,6 +151,7 @@ struct Workspace {
     float* WihT;               // [e_obs][4H] k-major copy of W_ih[:, :e_obs] (panel.hpp), rewritten every step
     float* W1T;                // [H][64 ceil(maxhid / 64)] k-major copy of the present address's first head layer
     unsigned long long* xz; unsigned long long* xd; int32_t* epoch;   // pair hand-off of the panel launch (panel.hpp)
+    Panel16Images p16;         // fragment images of the 16-row panel kernel (panel16_images.hpp), rewritten every step
     bool compact;              // LSTM input rows are [E | s_prev] (i4 = round4(e_obs + smp_dim)), the table columns a bias
     int xc;                    // columns of an LSTM input row: e_obs + smp_dim (compact) or lstm_in
     int64_t e4, i4, hid4, out4, ohid4[PP_MAX_OBS], maxohid4;
@@ -245,9 +247,15 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     w.WihT = c.take<float>(panel_shape ? (int64_t)net->e_obs * (4 * H + 64) : 0);
     w.W1T = c.take<float>(panel_shape ? (int64_t)H * 64 * ((hid + 63) / 64) : 0);
     // pair hand-off of the split panel launch: partial sums [panels][2][8][hid4] and [panels][2][8][64], flags, epoch
+    // (sized for whichever panel kernel takes the batch: two workgroups per 8-row panel / four per 16-row panel)
     const int64_t n_pan = (B + 7) / 8;
-    w.xz = c.take<unsigned long long>(panel_shape ? n_pan * 2 * 8 * w.hid4 : 0);
-    w.xd = c.take<unsigned long long>(panel_shape ? n_pan * 2 * 8 * 64 : 0);
+    w.xz = c.take<unsigned long long>(panel_shape ? std::max<int64_t>(n_pan * 2 * 8 * w.hid4, panel16_xz_granules(B, (int)w.hid4)) : 0);
+    w.xd = c.take<unsigned long long>(panel_shape ? std::max<int64_t>(n_pan * 2 * 8 * 64, panel16_xd_granules(B)) : 0);
+    w.p16 = Panel16Images{};
+    if (panel_shape && H == 512 && net->e_obs == 64) {
+        panel16_image_sizes(H, hid, net->e_obs, w.p16.frags);
+        for (int i = 0; i < 6; ++i) w.p16.img[i] = c.take<float>(w.p16.frags[i] * 256);
+    }
     w.bytes = c.off + 256;
 }
 
@@ -452,11 +460,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     // Row-panel kernel (panel.hip): a single-statement batch with ONE address keeps input product + cell, head layer 1, the
     // head tail, dz1, dH + cell backward and dX in one launch (rows of the one address group are the batch rows in order)
     bool panel = false, obs_tail = false;
+    bool panel16_go = false;      // the 16-row kernel (panel16.hip) instead of the 8-row one (panel.hip)
     if (lean_cell && n_present == 1 && fused_obs && bt->grp_off[only_addr] == 0 && bt->grp_off[only_addr + 1] == R) {
         const pp_addr& ad = net->addrs[only_addr];
-        panel = panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && panel_t1_split(R, H) == 2 &&
-                head_tail_supported(ad.kind, ad.hid, ad.n_out) &&
-                w.hid4 <= ((ad.hid + 15) & ~15) && w.out4 <= 64 && (flags & PP_LOSS_KEEP_LP ? lp_out != nullptr : true);
+        const bool shape_ok = head_tail_supported(ad.kind, ad.hid, ad.n_out) &&
+                              w.hid4 <= ((ad.hid + 15) & ~15) && w.out4 <= 64 && (flags & PP_LOSS_KEEP_LP ? lp_out != nullptr : true);
+        panel16_go = shape_ok && w.p16.img[0] && panel16_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs, R) &&
+                     (!bwd || panel_obs_tail_ok(net, H, ad.hid, ad.n_out, net->e_obs));
+        panel = panel16_go || (shape_ok && panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && panel_t1_split(R, H) == 2);
     }
     prof_begin(2, st);
     if (ff) {
@@ -495,6 +506,19 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             ptr.H = H; ptr.hid = ad.hid; ptr.e = net->e_obs;
             ptr.tiles_ih = 3 * H / 64;
             ptr.n_blocks = panel_transpose_blocks(H, ad.hid);
+            if (panel16_go) {      // the job writes the six fragment images instead (one thread per fragment lane)
+                ptr.mode16 = 1;
+                ptr.p16.W2 = P + ad.w2; ptr.p16.n_out = ad.n_out;
+                ptr.p16.im = w.p16;
+                panel16_image_sizes(H, ad.hid, net->e_obs, ptr.p16.im.frags);      // (this address's head; the buffers hold the widest)
+                int nb = 0;
+                for (int i = 0; i < 6; ++i) {
+                    ptr.p16.blocks_before[i] = nb;
+                    nb += cdiv(ptr.p16.im.frags[i] * 64, 256);
+                }
+                ptr.p16.blocks_before[6] = nb;
+                ptr.n_blocks = nb;
+            }
         }
         PP_TRY(obs_embed_fwd_fused(net, P, bt->obs, B, w.obs_h, w.cat, w.f1, w.E, st, &rb, compact ? &abias : nullptr,
                                    panel ? &ptr : nullptr));
@@ -571,7 +595,14 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                     po.dE = w.dE; po.dF1 = w.dF1; po.dCat = w.dCat; po.dHo0 = w.dObsH;
                     po.dh_stride = (int64_t)B * w.maxohid4;
                 }
-                PP_TRY(panel_t1(ad.kind, pa, st, obs_tail ? &po : nullptr));
+                if (panel16_go) {
+                    Panel16Args p16{};
+                    p16.a = pa;
+                    for (int i = 0; i < 6; ++i) p16.img[i] = w.p16.img[i];
+                    PP_TRY(panel16(ad.kind, p16, st, obs_tail ? &po : nullptr));
+                } else {
+                    PP_TRY(panel_t1(ad.kind, pa, st, obs_tail ? &po : nullptr));
+                }
                 cell_done = true;
                 // executed data-path FLOPs of the launch: forward + backward products of the 8-row panels
                 prof_end(0, 2.0 * R * (2.0 * 3.0 * H * net->e_obs + 2.0 * (double)H * ad.hid + 2.0 * (double)ad.hid * ad.n_out), st);

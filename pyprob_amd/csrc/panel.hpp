@@ -2,6 +2,7 @@
 #pragma once
 #include "common.hpp"
 #include "obs_embed.hpp"
+#include "panel16_images.hpp"
 
 namespace pp {
 
@@ -49,10 +50,16 @@ struct PanelTranspose {
     const float* W1; float* W1T; int64_t ld1T;    // W1 [hid][H], W1T [H][ld1T], ld1T = 64 ceil(hid / 64)
     int H, hid, e;
     int tiles_ih, first_block, n_blocks;           // 3 H / 64 tiles of W_ih; first workgroup of the job in its launch
+    int mode16;                                    // 1: the job writes the 16-row kernel's fragment images (p16) instead
+    Panel16Prep p16;
 };
 static inline int panel_transpose_blocks(int H, int hid) { return 3 * H / 64 + ((hid + 63) / 64) * (H / 64); }
 
 __device__ __forceinline__ void panel_transpose_block(const PanelTranspose& tr, int b, float* lds /* >= 64 * 65 floats */) {
+    if (tr.mode16) {
+        panel16_image_block(tr.Wih, tr.ldw, tr.W1, tr.H, tr.hid, tr.e, tr.p16, b);
+        return;
+    }
     const int tid = threadIdx.x;       // 256 threads
     const int tx = tid & 63, ty = tid >> 6;
     const bool ih = b < tr.tiles_ih;

@@ -108,10 +108,18 @@ def _run(tmp_path, tag, **env):
     return dict(np.load(f))
 
 
-def test_panel_kernel_equals_the_tile_path(tmp_path):
-    """Two workgroups per 8-row panel, partial sums handed over through memory (csrc/panel.hip)."""
-    panel = _run(tmp_path, 'panel', PP_PANEL='1')
-    tiles = _run(tmp_path, 'tiles', PP_PANEL='0')
+@pytest.fixture(scope='module')
+def tile_run(tmp_path_factory):
+    return _run(tmp_path_factory.mktemp('tiles'), 'tiles', PP_PANEL='0')
+
+
+@pytest.mark.parametrize('mode', ['2', '1'], ids=['rows16', 'rows8'])
+def test_panel_kernel_equals_the_tile_path(tmp_path, tile_run, mode):
+    """PP_PANEL=2 (default): four workgroups per 16-row panel on v_mfma_f32_16x16x4_f32 with fragment-image weight streams
+    (csrc/panel16.hip; batches of more than 2 048 rows too); PP_PANEL=1: two workgroups per 8-row panel (csrc/panel.hip).
+    Partial sums cross between a panel's workgroups through memory in both."""
+    panel = _run(tmp_path, 'panel', PP_PANEL=mode)
+    tiles = tile_run
     # a run of 48 Adam steps: both paths accumulate with float atomics and the panel's cell runs on v_exp_f32 / v_rcp_f32, so
     # the trajectories separate slowly (Adam turns last-bit differences of near-zero gradients into steps of +-lr): the first
     # steps agree to 2e-4, the whole run to 2e-3 (observed: 2.5e-4 at step 17 in one of nine runs of the suite)
@@ -157,7 +165,7 @@ def test_panel_kernel_against_the_oracle():
     from pyprob_amd.engine import ICEngine
     from pyprob_amd.packed import PackedBatch
     from pyprob_amd.spec import NetSpec
-    assert os.environ.get('PP_PANEL', '1') != '0'
+    assert os.environ.get('PP_PANEL', '2') != '0'
     spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
     spec.add_address('mu', 'Normal')
     eng = ICEngine(spec, device='cuda:0', seed=11)

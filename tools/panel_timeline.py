@@ -10,8 +10,13 @@ import bench
 from pyprob_amd import lib as L
 from pyprob_amd.packed import ColumnarDataset
 
-NAMES = ['start', 'staged', 'p1 input+cell', 'barrier', 'p2 units+W2 store', 'p2 barrier', 'p2 fixup', 'p3 tail product',
-         'mixture', 'p4 dz1', 'barrier', 'p5 dh+cell bwd', 'p6 dX units', 'gsum+store']
+NAMES8 = ['start', 'staged', 'p1 input+cell', 'barrier', 'p2 units+W2 store', 'p2 barrier', 'p2 fixup', 'p3 tail product',
+          'mixture', 'p4 dz1', 'barrier', 'p5 dh+cell bwd', 'p6 dX units', 'gsum+store']
+# csrc/panel16.hip (PP_PANEL=2, the default): stamp k closes the interval named NAMES16[k]
+NAMES16 = ['start', 'staged', 'p1 input+cell', 'barrier', 'p2 mfma', 'publish+tile16', 'fetch partners', 'z1+barrier', 'p3+barrier',
+           'mixture+barrier', 'p4+barrier', 'p5 dh+cell bwd', 'p6 dX', 'reduce+exchange 2', 'embedding tail']
+P16 = os.environ.get('PP_PANEL', '2') not in ('0', '1')
+NAMES = NAMES16 if P16 else NAMES8
 lib = L.load()
 dev = torch.device('cuda:0')
 eng = bench.make_engine(512, dev, seed=123)
@@ -31,6 +36,9 @@ for rep in range(3):
     print('--- step %d (cycles since the stamping wave started; 2400 cycles = 1 us)' % rep)
     for row, tag in zip(t, ('wg 0 wave 0', 'wg 0 wave 5', 'wg 77 wave 0', 'wg 77 wave 5')):
         base = row[0]
-        print('%-13s ' % tag + '  '.join('%s %d' % (NAMES[k], row[k] - row[k - 1]) for k in range(1, 14)) + '   | total %d | fixup: reduce+publish %d, wait+finish %d' % (row[13] - base, row[14] - row[5], row[6] - row[14]))
+        if P16:
+            print('%-13s ' % tag + '  '.join('%s %d' % (NAMES[k], row[k] - row[k - 1]) for k in range(1, 15)) + '   | total %d' % (row[14] - base))
+        else:
+            print('%-13s ' % tag + '  '.join('%s %d' % (NAMES[k], row[k] - row[k - 1]) for k in range(1, 14)) + '   | total %d | fixup: reduce+publish %d, wait+finish %d' % (row[13] - base, row[14] - row[5], row[6] - row[14]))
 
 lib.pp_debug_timeline(None)
