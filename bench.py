@@ -734,12 +734,19 @@ def main():
                 # mixture log-prob, backward dy, dz1, dh, cell, dX. Algorithmic FLOPs = the reference's products of those
                 # (full LSTM input width I, all four gates); executed = 64 observe-embedding columns, three gates (c_prev = 0)
                 panel_alg = 2.0 * B * (2.0 * 4 * H * I + 2.0 * H * hid_ + 2.0 * hid_ * 30)
-                out['roofline'] = roof(first, 'panel',
-                                       'panel_t1_kernel (csrc/panel.hip: one launch = forward input product + LSTM cell + proposal '
-                                       'head + mixture log-prob + loss and the backward data path dy, dz1, dh, cell, dX of all %d '
-                                       'traces, 8-row panels, two workgroups per panel, v_mfma_f32_4x4x1 with weights streamed '
-                                       "k-major from L2; algorithmic FLOPs = the reference's X W_ih^T %dx%dx%d and dG W_ih, head "
-                                       'layers forward and backward)' % (B, B, 4 * H, I), algorithmic=panel_alg)
+                p16 = os.environ.get('PP_PANEL', '2') not in ('0', '1') and H == 512 and B % 1 == 0
+                what = ('forward input product + LSTM cell + proposal head + mixture log-prob + loss and the backward data path '
+                        'dy, dz1, dh, cell, dX of all %d traces' % B)
+                if p16:
+                    label = ('panel16_kernel (csrc/panel16.hip: one launch = %s; 16-row panels, four workgroups per panel (a '
+                             'quarter of the hidden units each), v_mfma_f32_16x16x4_f32 with the weights streamed as fragment '
+                             "images through a register ring; algorithmic FLOPs = the reference's X W_ih^T %dx%dx%d and dG W_ih, "
+                             'head layers forward and backward)' % (what, B, 4 * H, I))
+                else:
+                    label = ('panel_t1_kernel (csrc/panel.hip: one launch = %s, 8-row panels, two workgroups per panel, '
+                             "v_mfma_f32_4x4x1 with weights streamed k-major from L2; algorithmic FLOPs = the reference's "
+                             'X W_ih^T %dx%dx%d and dG W_ih, head layers forward and backward)' % (what, B, 4 * H, I))
+                out['roofline'] = roof(first, 'panel', label, algorithmic=panel_alg)
                 out['roofline']['timing'] = timing_live if live_class == 0 else timing_post
                 wgrad['timing'] = timing_post if live_class == 0 else timing_live
                 out['roofline']['second_kernel'] = wgrad

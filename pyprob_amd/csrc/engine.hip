@@ -465,8 +465,11 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         const pp_addr& ad = net->addrs[only_addr];
         const bool shape_ok = head_tail_supported(ad.kind, ad.hid, ad.n_out) &&
                               w.hid4 <= ((ad.hid + 15) & ~15) && w.out4 <= 64 && (flags & PP_LOSS_KEEP_LP ? lp_out != nullptr : true);
-        panel16_go = shape_ok && w.p16.img[0] && panel16_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs, R) &&
-                     (!bwd || panel_obs_tail_ok(net, H, ad.hid, ad.n_out, net->e_obs));
+        panel16_go = shape_ok && w.p16.img[0] && panel16_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs, R);
+        if (panel16_go && bwd) {
+            ObsFusedArgs oa;
+            panel16_go = panel_obs_tail_ok(net, H, ad.hid, ad.n_out, net->e_obs) && obs_fused_args(net, w.obs_h, oa) && panel16_obs_ok(oa);
+        }
         panel = panel16_go || (shape_ok && panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && panel_t1_split(R, H) == 2);
     }
     prof_begin(2, st);

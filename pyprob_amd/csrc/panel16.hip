@@ -69,7 +69,6 @@ constexpr int L_XP = L_Z;                           // [wave][16][PX] partial dX
 static_assert(L_XP + NWV * PR * PX <= L_DZ, "the partial dX tiles must not reach the live dz1 tile");
 constexpr int L_OIMG = L_DZ;                        // observe-embedding weight image of the tail: over sDZ + sDG
 static_assert(L_END - L_OIMG >= 10240 + 8, "the embedding image must fit the dead buffers");
-constexpr int L_DX = L_H;                           // four finished dX rows [4][64]
 
 constexpr float kFp32Eps = 1.1920928955078125e-07f;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
@@ -124,7 +123,7 @@ __device__ __forceinline__ f32x4 mma4(const f32x4& a, const f32x4& b, f32x4 c) {
 // ---- the fragment stream of a wave ------------------------------------------------------------------------------------
 constexpr int F1 = 3 * KE, F2 = 17, F3 = 5, F4 = 6, F5 = NT, F6 = 3 * KE;
 constexpr int B1 = 0, B2 = B1 + F1, B3 = B2 + F2, B4 = B3 + F3, B5 = B4 + F4, B6 = B5 + F5, FT = B6 + F6;
-constexpr int RING = 16;
+constexpr int RING = 24;
 
 struct FragPtrs {
     const f32x4 *p1, *p2, *p3, *p4, *p5, *p6;      // per-phase bases, this lane's float4 of fragment 0
@@ -196,6 +195,10 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     fp.p4 = reinterpret_cast<const f32x4*>(ain.img[3]) + wave * 64 + lane;
     fp.p5 = reinterpret_cast<const f32x4*>(ain.img[4]) + ut * 64 + lane;
     fp.p6 = reinterpret_cast<const f32x4*>(ain.img[5]) + (ut * 3 * KE) * 64 + lane;
+    // ---------------- staging: E rows (their loads go out first), then the head of the fragment stream ----------------
+    f32x4 ev = {0, 0, 0, 0};
+    if (tid < PR * (EE / 4))
+        ev = *reinterpret_cast<const f32x4*>(a.X + (int64_t)min(m0 + (tid >> 4), a.B - 1) * a.ldx + 4 * (tid & 15));
     f32x4 ring[RING];
 #define P16_ISSUE(G)                                                   \
     do {                                                               \
@@ -205,17 +208,21 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
         constexpr int g0 = decltype(GG)::value;
         P16_ISSUE(g0);
     });
-
-    // ---------------- staging: E rows; zero pads ----------------
-    if (tid < PR * (EE / 4)) {
-        const int r = tid >> 4, c4 = tid & 15;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + (int64_t)min(m0 + r, a.B - 1) * a.ldx + 4 * c4);
-        *reinterpret_cast<f32x4*>(sE + r * PE + 4 * c4) = v;
-    }
-    for (int i = tid; i < PR * PDY; i += 512) sDY[i] = 0.0f;
+    // small vectors of later phases, fetched now (a first touch from memory costs ~2 000 cycles where it is needed): the LSTM
+    // bias of this lane's unit, b1 of its three head columns, and - waves 0..3, row 4 wave + g - the row's value, prior and b2
     float bias[3];
 #pragma unroll
     for (int y = 0; y < 3; ++y) bias[y] = a.AB[(y == 0 ? 0 : y + 1) * HH + u];
+    float b1v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b1v[t] = a.b1[16 * (t == 0 ? wave : wave + 8) + c];
+    const float b16 = a.b1[min(256 + (tid & 15), hid - 1)];      // (threads < 256: column 256 + tid % 16 of tile 16)
+    const int mrow = min(m0 + 4 * (wave & 3) + g, a.B - 1);
+    const float m_v = a.value[mrow], m_pa = a.prior[2 * mrow], m_pb = a.prior[2 * mrow + 1];
+    const int mcol = min(c, K - 1);
+    const float m_b2mu = a.b2[mcol], m_b2sd = a.b2[K + mcol], m_b2z = a.b2[2 * K + mcol];
+    if (tid < PR * (EE / 4)) *reinterpret_cast<f32x4*>(sE + (tid >> 4) * PE + 4 * (tid & 15)) = ev;
+    for (int i = tid; i < PR * PDY; i += 512) sDY[i] = 0.0f;
     __syncthreads();
     P16_STAMP(1);
 
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     P16_STAMP(3);
 
     // ---------------- phase 2: partial z1 = h[:, own units] W1^T; tiles wave, wave + 8 (all K), tile 16 (own unit) ----------------
-    float zt[3][4];      // z1 of (row 4 g + i, column 16 tile + c): tiles wave, wave + 8, and (wave 0) 16
+    float zt[2][4];      // z1 of (row 4 g + i, column 16 tile + c): tiles wave, wave + 8 (tile 16: in sZ)
     {
         f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         static_for<0, 8>([&](auto KL) {
@@ -280,43 +287,44 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
             gput(xz_own + (4 * g + i) * ZK + 16 * (wave + 8) + c, acc[1][i], epoch);
         }
         __syncthreads();     // tile 16's eight partial tiles
-        if (wave == 0) {
+        // tile 16 (the K split over the waves): one element per thread of the first four waves - sum of the eight partial tiles,
+        // published like the others; its partner sums ride in the same batch of loads below
+        const int er = tid >> 4, ec = tid & 15;          // (tid < 256: row er, column 256 + ec)
+        float own16 = 0.0f;
+        if (tid < 256) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float s = 0.0f;
-#pragma unroll
-                for (int w = 0; w < NWV; ++w) s += sT[(w * PR + 4 * g + i) * 16 + c];
-                acc[2][i] = s;
-                gput(xz_own + (4 * g + i) * ZK + 16 * 16 + c, s, epoch);
-            }
+            for (int w = 0; w < NWV; ++w) own16 += sT[(w * PR + er) * 16 + ec];
+            gput(xz_own + er * ZK + 256 + ec, own16, epoch);
         }
         P16_STAMP(5);
         // the three partners' partial sums: every granule load of the wave is in flight together; a pass is repeated until all
         // of a lane's granules carry this step's tag
-        float xs[3][12];
+        float xs[3][9];
         {
             const unsigned tag = gtag(epoch);
             const unsigned long long* pb[3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) pb[s] = a.xz + (int64_t)(panel * SS + (s + (s >= q ? 1 : 0))) * (PR * ZK) + c;
-            const int t2 = wave == 0 ? 16 : wave;          // (other waves: a duplicate of tile `wave`, waited for anyway)
+            for (int s = 0; s < 3; ++s) pb[s] = a.xz + (int64_t)(panel * SS + (s + (s >= q ? 1 : 0))) * (PR * ZK);
+            // (waves 4..7 have no element of tile 16: a duplicate of their first granule, waited for anyway)
+            const int o16 = tid < 256 ? er * ZK + 256 + ec : (4 * g) * ZK + 16 * wave + c;
             int spins = 0;
             while (true) {
-                unsigned long long x[3][12];
+                unsigned long long x[3][9];
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < 3; ++s) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int ro = (4 * g + i) * ZK;
+                        const int ro = (4 * g + i) * ZK + c;
                         x[s][i] = __hip_atomic_load(pb[s] + ro + 16 * wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         x[s][4 + i] = __hip_atomic_load(pb[s] + ro + 16 * (wave + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        x[s][8 + i] = __hip_atomic_load(pb[s] + ro + 16 * t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
+                    x[s][8] = __hip_atomic_load(pb[s] + o16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 bool ok = true;
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
-                    for (int e = 0; e < 12; ++e) {
+                    for (int e = 0; e < 9; ++e) {
                         ok = ok && ((unsigned)(x[s][e] >> 32) == tag);
                         xs[s][e] = __uint_as_float((unsigned)x[s][e]);
                     }
@@ -327,27 +335,30 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
         }
         P16_STAMP(6);
         // z1 = relu(b1 + quarter 0 + quarter 1 + quarter 2 + quarter 3): the SAME order in all four workgroups
+        auto four = [&](float own, float x0, float x1, float x2) {
+            const float v0 = q == 0 ? own : x0;
+            const float v1 = q == 1 ? own : (q > 1 ? x1 : x0);
+            const float v2 = q == 2 ? own : (q > 2 ? x2 : x1);
+            const float v3 = q == 3 ? own : x2;
+            return ((v0 + v1) + v2) + v3;
+        };
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int tile = t == 0 ? wave : (t == 1 ? wave + 8 : 16);
-            const int j = 16 * tile + c;
-            const float b1v = a.b1[min(j, hid - 1)];
+        for (int t = 0; t < 2; ++t) {
+            const int j = 16 * (t == 0 ? wave : wave + 8) + c;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int e = 4 * t + i;
-                const float own = acc[t][i];
-                const float v0 = q == 0 ? own : xs[0][e];
-                const float v1 = q == 1 ? own : (q > 1 ? xs[1][e] : xs[0][e]);
-                const float v2 = q == 2 ? own : (q > 2 ? xs[2][e] : xs[1][e]);
-                const float v3 = q == 3 ? own : xs[2][e];
-                const float z = j < hid ? relu_keep_nan((((v0 + v1) + v2) + v3) + b1v) : 0.0f;
+                const int e = 4 * t + i, r = 4 * g + i;
+                const float z = relu_keep_nan(four(acc[t][i], xs[0][e], xs[1][e], xs[2][e]) + b1v[t]);      // (j < 256 < hid)
                 zt[t][i] = z;
-                if (t < 2 || wave == 0) {
-                    const int r = 4 * g + i;
-                    sZ[r * PZ + j] = z;
-                    if (g == q && m0 + r < a.B && j < a.lda1) a.A1[(int64_t)(m0 + r) * a.lda1 + j] = z;
-                }
+                sZ[r * PZ + j] = z;
+                if (g == q && m0 + r < a.B) a.A1[(int64_t)(m0 + r) * a.lda1 + j] = z;
             }
+        }
+        if (tid < 256) {
+            const int j = 256 + ec;
+            const float z = j < hid ? relu_keep_nan(four(own16, xs[0][8], xs[1][8], xs[2][8]) + b16) : 0.0f;
+            sZ[er * PZ + j] = z;
+            if ((er >> 2) == q && m0 + er < a.B && j < a.lda1) a.A1[(int64_t)(m0 + er) * a.lda1 + j] = z;
         }
     }
     __syncthreads();     // z1 [16][272] complete
@@ -386,11 +397,11 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
         };
         float ymu = 0.0f, ysd = 0.0f, yz = -INFINITY;
         if (comp) {
-            ymu = a.b2[c] + yof(c);
-            ysd = a.b2[K + c] + yof(K + c);
-            yz = a.b2[2 * K + c] + yof(2 * K + c);
+            ymu = m_b2mu + yof(c);
+            ysd = m_b2sd + yof(K + c);
+            yz = m_b2z + yof(2 * K + c);
         }
-        const float v = a.value[gr], pa = a.prior[2 * gr], pb = a.prior[2 * gr + 1];
+        const float v = m_v, pa = m_pa, pb = m_pb;
         const float zmax = row_max(yz);
         const float ex = comp ? expf(yz - zmax) : 0.0f;
         const float pi = ex / row_sum(ex);
@@ -485,7 +496,8 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * g + i;
-                const float d = (j < hid && zt[t][i] > 0.0f) ? acc[t][i] : 0.0f;
+                const float zv = t < 2 ? zt[t < 2 ? t : 0][i] : sZ[r * PZ + j];
+                const float d = (j < hid && zv > 0.0f) ? acc[t][i] : 0.0f;
                 sDZ[r * PZ + j] = d;
                 if (g == q && m0 + r < a.B && j < a.lda1) a.dZ1[(int64_t)(m0 + r) * a.lda1 + j] = d;
             }
@@ -497,13 +509,23 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     // ---------------- phase 5: dh = dz1 W1 for this wave's units, cell backward in registers ----------------
     {
         f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-        static_for<0, F5>([&](auto F) {
-            constexpr int f = decltype(F)::value;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * f + 4 * g);
-            if constexpr (f & 1) d1 = mma4(av, ring[(B5 + f) % RING], d1);
-            else d0 = mma4(av, ring[(B5 + f) % RING], d0);
-            P16_ISSUE(B5 + f + RING);
+        static_for<0, F5 / 2>([&](auto FP) {          // two fragments at a time: their MFMA chains interleave
+            constexpr int f = 2 * decltype(FP)::value;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * f + 4 * g);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * (f + 1) + 4 * g);
+            const f32x4 b0 = ring[(B5 + f) % RING], b1 = ring[(B5 + f + 1) % RING];
+            PP_MMA(0, a0, b0, d0); PP_MMA(0, a1, b1, d1);
+            PP_MMA(1, a0, b0, d0); PP_MMA(1, a1, b1, d1);
+            PP_MMA(2, a0, b0, d0); PP_MMA(2, a1, b1, d1);
+            PP_MMA(3, a0, b0, d0); PP_MMA(3, a1, b1, d1);
+            P16_ISSUE(B5 + f + RING); P16_ISSUE(B5 + f + 1 + RING);
         });
+        static_assert(F5 % 2 == 1, "one fragment left");
+        {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * (F5 - 1) + 4 * g);
+            d0 = mma4(av, ring[(B5 + F5 - 1) % RING], d0);
+            P16_ISSUE(B5 + F5 - 1 + RING);
+        }
         float gs_i = 0.f, gs_g = 0.f, gs_o = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -540,9 +562,9 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     constexpr int ONB = 2;
     ObsStage<8, 512> of1, of0;
     ObsStage<4, 512> ol1[ONB];
-    float t_f1 = 0.0f, t_cat = 0.0f, t_h = 0.0f;
-    int t_oh = -1, t_jh = 0;
-    int64_t t_hld = 0;
+    // masks of the tail's three layers for this lane's outputs: waves 0..3 = column tile `wave` of the two 64-wide layers, lanes
+    // 0..15 (row group 0 of the C layout) = the workgroup's four rows; waves o < n_obs: the hidden units of observable o
+    float m_f1[4] = {0, 0, 0, 0}, m_cat[4] = {0, 0, 0, 0}, m_h[4] = {0, 0, 0, 0};
     if (OBS) {
         const ObsFusedArgs& oa = oin.a;
         of1.load(oin.P + oa.f1.w_off, oa.f1.rows * oa.f1.cols, tid);
@@ -550,20 +572,19 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
 #pragma unroll
         for (int o = 0; o < ONB; ++o)
             if (o < oa.n_obs) ol1[o].load(oin.P + oa.l1[o].w_off, oa.l1[o].rows * oa.l1[o].cols, tid);
-        const float* my_h = nullptr;
+        if (wave < 4 && g == 0) {
 #pragma unroll
-        for (int o = 0; o < ONB; ++o)
-            if (o < oa.n_obs && lane >= oa.hoff[o] && lane < oa.hoff[o] + oa.hid[o]) {
-                t_oh = o; t_jh = lane - oa.hoff[o];
-                my_h = oa.obs_h[o]; t_hld = oa.ohid_ld[o];
+            for (int i = 0; i < 4; ++i) {
+                const int tb = min(m0 + 4 * q + i, a.B - 1);
+                m_f1[i] = oin.f1[(int64_t)tb * oa.e_ld + 16 * wave + c];
+                m_cat[i] = oin.cat[(int64_t)tb * oa.e_ld + 16 * wave + c];
             }
-        const int tb = m0 + q * 4 + wave;      // waves 0..3 walk rows 4 q + wave
-        if (wave < 4 && tb < a.B) {
-            if (lane < oa.e_obs) {
-                t_f1 = oin.f1[(int64_t)tb * oa.e_ld + lane];
-                t_cat = oin.cat[(int64_t)tb * oa.e_ld + lane];
-            }
-            if (t_oh >= 0) t_h = my_h[(int64_t)tb * t_hld + t_jh];
+#pragma unroll
+            for (int o = 0; o < ONB; ++o)
+                if (o == wave && o < oa.n_obs && c < oa.hid[o]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m_h[i] = oa.obs_h[o][(int64_t)min(m0 + 4 * q + i, a.B - 1) * oa.ohid_ld[o] + c];
+                }
         }
     }
     // ---------------- phase 6: partial dX[:, :e] = dG[:, own gate rows] W_ih[own gate rows, :e] ----------------
@@ -588,7 +609,9 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     P16_STAMP(12);
     __syncthreads();
     float* const oimg = smem + L_OIMG;            // sDZ and the dG tiles are dead now
-    float* const sDX = smem + L_DX;
+    float* const sT0 = smem + L_H;                // A operands of the tail's layers: [16][PX], rows 0..3 = this workgroup's rows
+    float* const sT1 = smem + L_Z;                // (over the partial dX tiles, behind a barrier)
+    float* const sT2 = smem + L_Z + PR * PX;
     if (OBS) {
         const ObsFusedArgs& oa = oin.a;
         const int dummy = oa.lds_total;
@@ -639,38 +662,72 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
             const float v3 = q == 3 ? mine : xs[2];
             const float dx = ((v0 + v1) + v2) + v3;
             if (m0 + myrow < a.B) a.dX[(int64_t)(m0 + myrow) * a.ldx + col] = dx;
-            if (OBS) sDX[(myrow & 3) * 64 + col] = dx;
+            if (OBS) {      // dz2 = dX * [E > 0] (inference_network.py:132-139 backward, the last ReLU of the final stack)
+                const float dz2 = sE[myrow * PE + col] > 0.0f ? dx : 0.0f;
+                sT0[(myrow & 3) * PX + col] = dz2;
+                if (m0 + myrow < a.B) oin.dE[(int64_t)(m0 + myrow) * oin.a.e_ld + col] = dz2;
+            }
         }
     }
     P16_STAMP(13);
     if (OBS) {
-        // dz2 = dX * [E > 0]; dz1 = (Wf1^T dz2) * [f1 > 0]; dzc = (Wf0^T dz1) * [cat > 0]; dh_o = (W1_o^T dzc_o) * [h_o > 0]
-        // (inference_network.py:132-139 backward; one wave per row, lane = unit, obs_embed.hip's walk)
-        __syncthreads();
+        // dz1 = (dz2 Wf1) * [f1 > 0]; dzc = (dz1 Wf0) * [cat > 0]; dh_o = (dzc_o W1_o) * [h_o > 0]: the workgroup's four rows as
+        // rows 0..3 of a 16-row MFMA tile (the other rows of the A operand are whatever the buffer holds: rows are independent),
+        // B fragments from the weights' LDS image (row = k, stride cols + 1); wave t < 4 owns column tile t of the 64-wide layers
         const ObsFusedArgs& oa = oin.a;
-        const int r = q * 4 + wave, tb = m0 + r;
-        if (wave < 4 && tb < a.B) {
-            const bool acte = lane < oa.e_obs;
-            float dz2 = 0.0f;
-            if (acte) dz2 = sE[r * PE + lane] > 0.0f ? sDX[wave * 64 + lane] : 0.0f;
-            if (acte) oin.dE[(int64_t)tb * oa.e_ld + lane] = dz2;
-            float dz1 = obs_dense_t(oimg, oa.f1, lane, acte, dz2, 0);
-            dz1 = t_f1 > 0.0f ? dz1 : 0.0f;
-            if (acte) oin.dF1[(int64_t)tb * oa.e_ld + lane] = dz1;
-            float dzc = obs_dense_t(oimg, oa.f0, lane, acte, dz1, 0);
-            dzc = t_cat > 0.0f ? dzc : 0.0f;
-            if (acte) oin.dCat[(int64_t)tb * oa.e_ld + lane] = dzc;
-            float dh = 0.0f;
-            int co = 0;
+        auto layer64 = [&](const float* T, const ObsLayer& Lw, const float (&mask)[4], float* dst, int64_t dld, float* Tn) {
+            f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+            const float* wb = oimg + Lw.lds_w + 16 * wave + c;
+            const int ld = Lw.cols + 1;
 #pragma unroll
-            for (int o = 0; o < ONB; ++o) {
-                if (o >= oa.n_obs) break;
-                const bool acth = (t_oh == o);
-                const float d = obs_dense_t(oimg, oa.l1[o], t_jh, acth, dzc, co);
-                if (acth) dh = d;
-                co += oa.out[o];
+            for (int un = 0; un < 4; un += 2) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + c * PX + 16 * un + 4 * g);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + c * PX + 16 * (un + 1) + 4 * g);
+                const float* w0 = wb + (16 * un + 4 * g) * ld;
+                const float* w1 = w0 + 16 * ld;
+                const f32x4 b0 = {w0[0], w0[ld], w0[2 * ld], w0[3 * ld]}, b1 = {w1[0], w1[ld], w1[2 * ld], w1[3 * ld]};
+                PP_MMA(0, a0, b0, c0); PP_MMA(0, a1, b1, c1);
+                PP_MMA(1, a0, b0, c0); PP_MMA(1, a1, b1, c1);
+                PP_MMA(2, a0, b0, c0); PP_MMA(2, a1, b1, c1);
+                PP_MMA(3, a0, b0, c0); PP_MMA(3, a1, b1, c1);
             }
-            if (t_oh >= 0) oin.dHo0[(int64_t)t_oh * oin.dh_stride + (int64_t)tb * t_hld + t_jh] = t_h > 0.0f ? dh : 0.0f;
+            if (g == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = mask[i] > 0.0f ? c0[i] + c1[i] : 0.0f;
+                    Tn[i * PX + 16 * wave + c] = d;
+                    if (m0 + 4 * q + i < a.B) dst[(int64_t)(m0 + 4 * q + i) * dld + 16 * wave + c] = d;
+                }
+            }
+        };
+        __syncthreads();     // dz2 rows; the weight image
+        if (wave < 4) layer64(sT0, oa.f1, m_f1, oin.dF1, oa.e_ld, sT1);
+        __syncthreads();
+        if (wave < 4) layer64(sT1, oa.f0, m_cat, oin.dCat, oa.e_ld, sT2);
+        __syncthreads();
+        // per observable o (wave o): dh_o = dzc[:, co .. co + out_o) W1_o, out_o = 16 units of K, one column tile of hidden units
+        int co = 0;
+#pragma unroll
+        for (int o = 0; o < ONB; ++o) {
+            if (o >= oa.n_obs) break;
+            if (wave == o) {
+                f32x4 c0 = {0, 0, 0, 0};
+                const int ld = oa.l1[o].cols + 1;
+                const float* wb = oimg + oa.l1[o].lds_w + min(c, oa.hid[o] - 1);
+                for (int un = 0; un < (oa.out[o] >> 4); ++un) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sT2 + c * PX + co + 16 * un + 4 * g);
+                    const float* w0 = wb + (16 * un + 4 * g) * ld;
+                    const f32x4 b0 = {w0[0], w0[ld], w0[2 * ld], w0[3 * ld]};
+                    c0 = mma4(a0, b0, c0);
+                }
+                if (g == 0 && c < oa.hid[o]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (m0 + 4 * q + i < a.B)
+                            oin.dHo0[(int64_t)o * oin.dh_stride + (int64_t)(m0 + 4 * q + i) * oa.ohid_ld[o] + c] = m_h[i] > 0.0f ? c0[i] : 0.0f;
+                }
+            }
+            co += oa.out[o];
         }
         P16_STAMP(14);
     }
@@ -727,15 +784,26 @@ bool panel16_supported(int kind, int H, int hid, int n_out, int e, int B) {
     return slots >= 2 * 8 * SS;
 }
 
+// the MFMA tail's shapes: two 64 x 64 layers of the final stack, per observable a 16 k-multiple of outputs and <= 16 hidden units
+bool panel16_obs_ok(const ObsFusedArgs& oa) {
+    if (oa.n_obs < 1 || oa.n_obs > 2 || oa.e_obs != EE || oa.lds_total + 1 > 10240 + 8) return false;
+    if (oa.f1.rows != EE || oa.f1.cols != EE || oa.f0.rows != EE || oa.f0.cols != EE) return false;
+    int tot = 0;
+    for (int o = 0; o < oa.n_obs; ++o) {
+        if (oa.out[o] % 16 != 0 || oa.out[o] < 16 || oa.hid[o] < 1 || oa.hid[o] > 16) return false;
+        if (oa.l1[o].rows != oa.out[o] || oa.l1[o].cols != oa.hid[o]) return false;
+        tot += oa.out[o];
+    }
+    return tot == EE;
+}
+
 int panel16(int kind, const Panel16Args& a, hipStream_t st, const PanelObs* obs) {
     const PanelArgs& p = a.a;
     PP_CHECK_ARG(panel16_supported(kind, p.H, p.hid, p.n_out, p.e, p.B), "panel16: unsupported shape");
     PP_CHECK_ARG(p.ldx % 4 == 0 && p.ldw % 4 == 0 && p.lda1 >= p.hid && p.lddy >= p.n_out && p.K * 3 == p.n_out && p.xz && p.xd &&
                      p.epoch && a.img[0] && a.img[5],
                  "panel16: bad leading dimensions or missing buffers");
-    if (obs)
-        PP_CHECK_ARG(obs->a.n_obs <= 2 && obs->a.e_obs == p.e && obs->a.lds_total + 1 <= 10240 + 8,
-                     "panel16: the observe-embedding tail does not fit");
+    if (obs) PP_CHECK_ARG(panel16_obs_ok(obs->a), "panel16: the observe-embedding tail does not fit");
     static const PanelObs none{};
 #define PP_P16_GO(KIND)                                                          \
     do {                                                                         \

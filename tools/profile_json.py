@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-KEYS = (('panel_t1_kernel', 'panel'), ('wgrad_t1_kernel', 'wgrad_group'), ('gemm_f32_async_grouped_aux_kernel', 'wgrad_group'), ('obs_embed_fwd_kernel', 'obs_embed_fwd'),
+KEYS = (('panel16_kernel', 'panel'), ('panel_t1_kernel', 'panel'), ('wgrad_t1_kernel', 'wgrad_group'), ('gemm_f32_async_grouped_aux_kernel', 'wgrad_group'), ('obs_embed_fwd_kernel', 'obs_embed_fwd'),
         ('obs_embed_dgrad_kernel', 'obs_dgrad'), ('adam_kernel', 'adam'), ('gemm_f32_async_lstm_kernel', 'input_gemm'))
 # algorithmic bytes per launch at B = 1024, H = 512, hid = 271, e = 64: what the launch must read and write once
 ALG = {
