@@ -2,7 +2,7 @@
 #   gpurun_out/<tag>_is_step_kernel_stats.csv           rocprofv3 --kernel-trace --stats of tools/is_step_bench.py (fused + chain)
 #   gpurun_out/<tag>_is_step_pmc_{FETCH,WRITE}_SIZE.csv separate --pmc passes (fused kernel only)
 #   profiles/r05_is_pmc_traffic.json                    HBM bytes per particle-statement, stamped with the hash of csrc/
-TAG=${1:-r05a}; N=${2:-200000}
+TAG=${1:-s5a}; N=${2:-200000}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fp_isks

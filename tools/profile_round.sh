@@ -3,7 +3,7 @@
 #   gpurun_out/<tag>_train_pmc_{FETCH,WRITE}_SIZE.csv             separate --pmc passes
 #   gpurun_out/<tag>_r05_kernel_avgs.json, _r05_pmc_traffic.json  what bench.py quotes (written to profiles/r05_*.json on the box; tools/collect_profiles.sh installs them here, stamped with the hash of csrc/)
 #   gpurun_out/<tag>_bench_20_5.json, _bench_default.json         the driver's command and the default command
-TAG=${1:-r05a}
+TAG=${1:-s5a}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 # the driver's command FIRST, in the fresh session (a bench line measured right after a profiled or test run of the same box
 # session shows every memory-latency-bound kernel ~1.6x slower); it quotes no rocprof / PMC figures yet
