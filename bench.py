@@ -143,9 +143,9 @@ def cpu_baseline_reference(lstm_dim, batch, workload='train'):
 
 
 def recorded_reference():
-    """The reference's figures recorded in the build container (profiles/r03_cpu_reference.json, made by
+    """The reference's figures recorded in the build container (profiles/r05_cpu_reference.json, re-measured every round by
     tools/cpu_reference_bench.py): carried in the line when the reference itself cannot run on this box."""
-    src = os.path.join('profiles', 'r03_cpu_reference.json')
+    src = os.path.join('profiles', 'r05_cpu_reference.json')
     try:
         with open(os.path.join(REPO, src)) as f:
             d = json.load(f)
