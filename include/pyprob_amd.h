@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 11
+#define PP_ABI_VERSION 12
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -464,6 +464,18 @@ int pp_logweight_terms(const pp_lw_term* terms, int32_t count, float* lw /*dev [
 int pp_is_step_net(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
                    const float* e_obs_vec, const float* prev_value, float* h, float* c, int32_t state_rows, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* (ABI 12) pp_is_init + pp_is_step_net(addr_id, prev_addr_id = -1) of a trace's FIRST statement as two launches: the observe
+ * embedding of the one shared row (InferenceNetwork._infer_init, pyprob/nn/inference_network.py:141-148) is computed inside the
+ * launch of the LSTM step (_infer_step with prev_variable None, pyprob/nn/inference_network_lstm.py:82-134), the proposal layer's
+ * outputs stay in the workspace for pp_is_fused. `obs` (the observation vector, as for pp_is_init) may be host-mapped (pinned)
+ * memory: the kernel reads it in place, a posterior call needs no copy launch. e_out: [round4(e_obs) + 8]: the embedding, then the
+ * first 8 observation values (device copies: the x of the call's observe terms). (h, c): row 0 is written (state_rows = 1).
+ * Bit-identical to the two calls it replaces. pp_is_first_statement_supported: one-layer LSTM, lstm_in <= 256, an embedding
+ * the fused embedding kernels take. A statistics buffer of pp_is_fused / pp_is_stats may likewise be host-mapped memory: its
+ * element [5] (the count) is stored last, behind a system-scope fence - a caller that set it negative may poll it. */
+int pp_is_first_statement_supported(const pp_net* net, int32_t addr_id);
+int pp_is_first_statement(const pp_net* net, const float* params, const float* obs, int32_t addr_id, float* e_out, float* h, float* c,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int pp_is_fused(const pp_net* net, int32_t addr_id, int32_t n, const float* prior /*dev [2]*/, const pp_lw_term* terms,
                 const int32_t* term_flags, int32_t n_terms, float* value /*dev [n]*/, float* lw /*dev [n]*/, int32_t overwrite,
                 uint64_t seed, uint64_t offset, double* stats_out /*dev [6] or NULL*/, double* stats_scratch, void* workspace,

@@ -6,6 +6,7 @@
 #include "gather.hpp"
 #include "is_draw.hpp"
 #include "is_step_fused.hpp"
+#include "obs_embed.hpp"
 
 #include <math.h>
 #include <string.h>
@@ -253,6 +254,73 @@ __global__ __launch_bounds__(256) void first_row_lstm_kernel(GatherDims d, const
     }
 }
 
+// ... and with the observe embedding of the one row in the SAME launch (pp_is_first_statement: _infer_init + the first
+// _infer_step of a trace, inference_network.py:141-148 + inference_network_lstm.py:82-134): every workgroup stages the embedding's
+// weights (38 KB, one round trip, behind its own W_ih rows' loads), wave 0 walks the row (obs_embed.hpp: the walk and summation
+// order of obs_embed_fwd_kernel - the same embedding bit for bit), the other lanes look the table columns of x up meanwhile.
+// `obs` may be host-mapped (pinned) memory: a posterior call hands its observation over without a copy launch; workgroup 0 leaves
+// the embedding in e_out[0 .. e_obs) and the raw observation (at most 8 numbers: the x of the call's observe terms) behind it.
+template <int NOBS>
+__global__ __launch_bounds__(256) void first_row_net_kernel(const ObsFusedArgs ain, GatherDims d, const float* __restrict__ P,
+                                                            const int64_t* __restrict__ at, const float* __restrict__ obs,
+                                                            int addr_id, int64_t w_ih, int64_t b_ih, int64_t b_hh, int H,
+                                                            float* __restrict__ e_out, int e4, float* __restrict__ h,
+                                                            float* __restrict__ c) {
+    __shared__ float lds[10240 + 1024];
+    float* const sx = lds + 10240;
+    const ObsFusedArgs a = ain;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int u0 = (blockIdx.x * 4 + wave) * 4;
+    constexpr int KI = 4;      // lstm_in <= 256 per 64 lanes x 4
+    float wv[4][3][KI];
+    float bsum[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int gsel = 0; gsel < 3; ++gsel) {
+            const int n = (gsel == 0 ? 0 : gsel + 1) * H + min(u0 + q, H - 1);      // gates i, g, o
+            const float* wr = P + w_ih + (int64_t)n * d.I;
+#pragma unroll
+            for (int kk = 0; kk < KI; ++kk) wv[q][gsel][kk] = (lane + 64 * kk) < d.I ? wr[lane + 64 * kk] : 0.0f;
+            bsum[q][gsel] = P[b_ih + n] + P[b_hh + n];
+        }
+    float ov = 0.0f;
+    if (wave == 0 && lane < a.width) ov = obs[lane];      // (a.width <= 64: inputs of at most 8 observables x 8)
+    obs_stage_all<NOBS>(a, P, lds, tid);
+    for (int k = d.e_obs + tid; k < d.I; k += 256) sx[k] = gather_embedding_elem(d, P, at, k, -1, 0.0f, addr_id);
+    if (wave == 0 && lane < a.width) sx[d.I + lane] = ov;      // the observation row (I + width <= 1024, checked on the host)
+    __syncthreads();
+    if (wave == 0) {
+        const float e = obs_forward_row<NOBS>(a, lds, sx + d.I, lane);
+        if (lane < a.e_obs) {
+            sx[lane] = e;
+            if (blockIdx.x == 0) e_out[lane] = e;
+        }
+        if (blockIdx.x == 0 && lane < min(a.width, 8)) e_out[e4 + lane] = ov;
+    }
+    __syncthreads();
+    float xv[KI];
+#pragma unroll
+    for (int kk = 0; kk < KI; ++kk) xv[kk] = (lane + 64 * kk) < d.I ? sx[lane + 64 * kk] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float g3[3];
+#pragma unroll
+        for (int gsel = 0; gsel < 3; ++gsel) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KI; ++kk) acc += wv[q][gsel][kk] * xv[kk];
+            g3[gsel] = wave_sum(acc) + bsum[q][gsel];
+        }
+        if (lane == 0 && u0 + q < H) {
+            const float cn = sigmoidf_(g3[0]) * tanhf(g3[1]);
+            c[u0 + q] = cn;
+            h[u0 + q] = sigmoidf_(g3[2]) * tanhf(cn);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void first_row_head_kernel(const float* __restrict__ P, const float* __restrict__ top, int Hin,
                                                              int64_t w1, int64_t b1, int hid, int64_t w2, int64_t b2, int n_out,
                                                              float* __restrict__ A1, float* __restrict__ Y, unsigned int* ticket) {
@@ -432,6 +500,48 @@ int is_init(const pp_net* net, const float* P, const float* obs, float* e_out, v
     }
     PP_TRY(lin(w.cat, w.e4, P + net->fin_w0, P + net->fin_b0, nullptr, w.f1, w.e4, 1, net->e_obs, net->e_obs, true, false, st));
     PP_TRY(lin(w.f1, w.e4, P + net->fin_w1, P + net->fin_b1, nullptr, e_out, w.e4, 1, net->e_obs, net->e_obs, true, false, st));
+    return 0;
+}
+
+// _infer_init + the network part of a trace's first _infer_step in two launches (first_row_net_kernel, first_row_head_kernel)
+bool is_first_statement_supported(const pp_net* net, int addr_id) {
+    const char* ev = getenv("PP_IS_FIRST");      // (read per call: the A/B tests flip it inside one process)
+    if ((ev && atoi(ev) == 0) || !net || net->lstm_dim == 0 || std::max(1, (int)net->lstm_depth) != 1 || !net->addr_table) return false;
+    if (addr_id < 0 || addr_id >= net->n_addr || net->lstm_in > 256 || (net->lstm_dim % 4) != 0 || net->addrs[addr_id].hid > 1024) return false;
+    if (!obs_fused_supported(net)) return false;
+    int width = 0;
+    for (int o = 0; o < net->n_obs; ++o) width += net->obs_in[o];
+    return width <= 64 && net->lstm_in + width <= 1024;
+}
+
+int is_first_statement(const pp_net* net, const float* P, const float* obs, int addr_id, float* e_out, float* h, float* c, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+    PP_CHECK_ARG(net && P && obs && e_out && h && c && ws, "pp_is_first_statement: null pointer");
+    PP_CHECK_ARG(is_first_statement_supported(net, addr_id), "pp_is_first_statement: unsupported network (pp_is_first_statement_supported)");
+    IsWorkspace w;
+    is_carve(net, 1, ws, w);
+    if (w.bytes > ws_bytes) {
+        set_error("pp_is_first_statement: workspace too small (%zu < %zu bytes)", ws_bytes, w.bytes);
+        return PP_ENOSPACE;
+    }
+    float* oh[PP_MAX_OBS];
+    for (int o = 0; o < PP_MAX_OBS; ++o) oh[o] = w.obs_h + (int64_t)o * w.maxohid4;
+    ObsFusedArgs a;
+    PP_CHECK_ARG(obs_fused_args(net, oh, a), "pp_is_first_statement: the embedding image does not fit");
+    const pp_addr& ad = net->addrs[addr_id];
+    const int H = net->lstm_dim;
+    GatherDims gd{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+#define PP_FIRST_NET(N)                                                                                                       \
+    hipLaunchKernelGGL(first_row_net_kernel<N>, dim3(cdiv(H, 16)), dim3(256), 0, st, a, gd, P, net->addr_table, obs, addr_id, \
+                       net->w_ih, net->b_ih, net->b_hh, H, e_out, (int)w.e4, h, c)
+    if (a.n_obs <= 1) PP_FIRST_NET(1);
+    else if (a.n_obs <= 2) PP_FIRST_NET(2);
+    else if (a.n_obs <= 4) PP_FIRST_NET(4);
+    else PP_FIRST_NET(8);
+#undef PP_FIRST_NET
+    hipLaunchKernelGGL(first_row_head_kernel, dim3(cdiv(ad.hid, 4)), dim3(256), 0, st, P, (const float*)h, H, ad.w1, ad.b1, ad.hid,
+                       ad.w2, ad.b2, ad.n_out, w.A1, w.Y, reinterpret_cast<unsigned int*>(w.ticket));
+    PP_LAUNCH_CHECK("pp_is_first_statement");
     return 0;
 }
 
@@ -807,8 +917,13 @@ __device__ __forceinline__ void stats_combine_body(const double* __restrict__ sc
         if (lane == 0) sh[wave][q] = r;
     }
     __syncthreads();
-    if (tid < 5) out[1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    // `out` may be host-mapped (pinned) memory that the caller polls instead of reading the statistics back with a copy: the
+    // count - negative while the caller waits - is stored LAST, behind a system-scope fence
+    if (tid < 4) out[1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
     if (tid == 0) out[0] = gm;
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(out + 5, sh[0][4] + sh[1][4] + sh[2][4] + sh[3][4], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void is_stats_combine_kernel(const double* __restrict__ scratch, int nblocks,
@@ -1065,9 +1180,11 @@ __global__ __launch_bounds__(256, 4) void is_fused_kernel(const float* __restric
     __syncthreads();
     if (tid < 5) scratch[blockIdx.x * 6 + 1 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
     if (tid == 0) scratch[blockIdx.x * 6] = (double)M;
-    // (Folding the combine into this launch - last workgroup to arrive behind a device-scope ticket - was tried: every workgroup's
-    // release fence has to write back the 8 MB of values and log-weights it shares the L2 with, 18 -> 80 us per launch;
-    // profiles/r04_experiments_not_kept.txt. The one-workgroup is_stats_combine_kernel follows.)
+    // (Folding the combine into this launch - the last workgroup to arrive behind a device-scope ticket - was tried twice: behind
+    // a release fence per workgroup (round 4: each fence writes back the 8 MB of values and log-weights it shares the L2 with,
+    // 18 -> 80 us per launch) and with write-through partials + agent-scope atomic loads, no fence (round 5: the posterior call
+    // 70.8 -> 77.7 us at 10^6 particles, unchanged at 1 000: the last workgroup's loads queue behind the write stream);
+    // profiles/r04_experiments_not_kept.txt, r05_experiments_not_kept.txt. The one-workgroup is_stats_combine_kernel follows.)
 }
 
 // ---- prior draws for vectorised trace generation (pyprob/nn/dataset.py:50-62, state.py:278-290 run n times) -----------
@@ -1117,6 +1234,14 @@ int pp_is_init(const pp_net* net, const float* params, const float* obs, float* 
     // embedding (here) to the end of pp_is_fused (which closes the bracket) - what the call's wall time is compared with
     pp::prof_begin(6, pp::as_stream(stream));
     return pp::is_init(net, params, obs, e_out, workspace, workspace_bytes, pp::as_stream(stream));
+}
+
+int pp_is_first_statement_supported(const pp_net* net, int32_t addr_id) { return pp::is_first_statement_supported(net, addr_id) ? 1 : 0; }
+
+int pp_is_first_statement(const pp_net* net, const float* params, const float* obs, int32_t addr_id, float* e_out, float* h, float* c,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    pp::prof_begin(6, pp::as_stream(stream));      // (the bracket pp_is_init opens: the device chain of a posterior call)
+    return pp::is_first_statement(net, params, obs, addr_id, e_out, h, c, workspace, workspace_bytes, pp::as_stream(stream));
 }
 
 int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,

@@ -31,6 +31,17 @@ class ISRunner:
         self._st = None        # stream of the current posterior call (begin); None = the default stream
         self._stats_scratch = torch.zeros(L.PP_IS_STATS_SCRATCH, dtype=torch.float64, device=self.dev)
 
+    def _pins(self, k):
+        """Pinned host staging of a posterior call: the observation vector (read in place by pp_is_first_statement, or copied
+        to its device twin) and the statistics record pp_is_fused writes (polled, not copied back)."""
+        if getattr(self, '_obs_np', None) is None or self._obs_pin.numel() < k:
+            self._obs_pin = torch.zeros(max(k, 16), dtype=torch.float32).pin_memory()
+            self._obs_np = self._obs_pin.numpy()
+            self._obs_dev = torch.zeros(max(k, 16), dtype=torch.float32, device=self.dev)
+        if getattr(self, '_stats_np', None) is None:
+            self._stats_pin = torch.zeros(8, dtype=torch.float64).pin_memory()
+            self._stats_np = self._stats_pin.numpy()
+
     def _const(self, v):
         """1-element device tensor holding v (cached: no allocation / H2D copy in the steady state)."""
         t = self._consts.get(v)
@@ -59,10 +70,8 @@ class ISRunner:
             if torch.cuda.current_device() != (self.dev.index or 0):
                 torch.cuda.set_device(self.dev)
             k = int(vals.size)
-            if getattr(self, '_obs_pin', None) is None or self._obs_pin.numel() < k:
-                self._obs_pin = torch.zeros(max(k, 16), dtype=torch.float32).pin_memory()
-                self._obs_dev = torch.zeros(max(k, 16), dtype=torch.float32, device=self.dev)
-            self._obs_pin[:k] = torch.from_numpy(vals)
+            self._pins(k)
+            self._obs_np[:k] = vals
             self._obs_dev.copy_(self._obs_pin, non_blocking=True)
             if self.e_obs.numel() != self.eng.spec.e_obs + 8 or self.e_obs.device != self.dev:
                 self.e_obs = torch.zeros(self.eng.spec.e_obs + 8, dtype=torch.float32, device=self.dev)
@@ -133,33 +142,40 @@ class ISRunner:
         return self._stats_dict(out) if stats else None
 
     def run_plan(self, plan, obs_values, n, offset, seed):
-        """Replay of a recorded single-statement posterior call (Model._replay_lockstep_plan) straight through the C ABI: the
-        observation goes up through a pinned staging buffer (its elements are also the `x` of the observe terms), then
-        pp_is_init -> pp_is_step_net -> pp_is_fused - three calls, no operator dispatch, no per-call ctypes structures.
-        plan['c'] caches the term array. Returns (values, log-weights, statistics dict)."""
+        """Replay of a recorded single-statement posterior call (Model._replay_lockstep_plan) straight through the C ABI, with no
+        copy in either direction: the observation is written into PINNED host memory that the first kernel reads in place
+        (pp_is_first_statement: observe embedding + the one-row LSTM step in one launch, the proposal layer in a second), then
+        pp_is_fused, whose statistics land in pinned host memory too - the count last, behind a system-scope fence - and are
+        polled there instead of being copied back. Networks pp_is_first_statement does not take (and PP_IS_FIRST=0) go through
+        a staged copy + pp_is_init + pp_is_step_net as before. plan['c'] caches the term array.
+        Returns (values, log-weights, statistics dict)."""
         lib, net = self.lib, C.byref(self.eng.net)
         if torch.cuda.current_device() != (self.dev.index or 0):
             torch.cuda.set_device(self.dev)
         k = len(obs_values)
-        if getattr(self, '_obs_pin', None) is None or self._obs_pin.numel() < k:
-            self._obs_pin = torch.zeros(max(k, 16), dtype=torch.float32).pin_memory()
-            self._obs_dev = torch.zeros(max(k, 16), dtype=torch.float32, device=self.dev)
-        pin = self._obs_pin
-        for i, v in enumerate(obs_values):
-            pin[i] = v
-        self._obs_dev.copy_(pin, non_blocking=True)
+        self._pins(k)
+        self._obs_np[:k] = obs_values
         self.begin(n, offset)
-        st = L.stream_ptr()
+        st = self._st
         params, ws = self.eng.params.data_ptr(), self.ws.data_ptr()
-        L.check(lib.pp_is_init(net, params, self._obs_dev.data_ptr(), self.e_obs.data_ptr(), ws, self.ws_bytes, st), 'pp_is_init')
-        L.check(lib.pp_is_step_net(net, params, plan['addr'], -1, n, self.e_obs.data_ptr(), None, self.h.data_ptr(),
-                                   self.c.data_ptr(), 1, ws, self.ws_bytes, st), 'pp_is_step_net')
+        first = plan.get('first')
+        if first is None:
+            first = plan['first'] = bool(k <= 8 and lib.pp_is_first_statement_supported(net, plan['addr']))
+        if first:
+            L.check(lib.pp_is_first_statement(net, params, self._obs_pin.data_ptr(), plan['addr'], self.e_obs.data_ptr(),
+                                              self.h.data_ptr(), self.c.data_ptr(), ws, self.ws_bytes, st), 'pp_is_first_statement')
+            obs_base = self.e_obs.data_ptr() + 4 * ((self.eng.spec.e_obs + 3) & ~3)      # the device copies behind the embedding
+        else:
+            self._obs_dev.copy_(self._obs_pin, non_blocking=True)
+            L.check(lib.pp_is_init(net, params, self._obs_dev.data_ptr(), self.e_obs.data_ptr(), ws, self.ws_bytes, st), 'pp_is_init')
+            L.check(lib.pp_is_step_net(net, params, plan['addr'], -1, n, self.e_obs.data_ptr(), None, self.h.data_ptr(),
+                                       self.c.data_ptr(), 1, ws, self.ws_bytes, st), 'pp_is_step_net')
+            obs_base = self._obs_dev.data_ptr()
         self.state_rows = 1
         buf = torch.empty(2 * n, dtype=torch.float32, device=self.dev)      # values | log-weights: one allocation per call
         values, lw = buf[:n], buf[n:]
-        out = self._stats                                                    # (read back before this call returns)
         c = plan.get('c')
-        if c is None or c['obs_base'] != self._obs_dev.data_ptr():
+        if c is None or c['obs_base'] != obs_base:
             terms = [(plan['prior_term'], None, 1.0, 4)] + [((kind, (a[1] if a[0] == 'const' else None), s0,
                                                                (b[1] if b[0] == 'const' else None), s1), xsrc, scale,
                                                               (1 if a[0] == 'value' else 0) | (2 if b[0] == 'value' else 0))
@@ -169,15 +185,24 @@ class ISRunner:
             for q, ((kind, p0, s0, p1, s1), xsrc, scale, flags) in enumerate(terms):
                 arr[q].kind, arr[q].p0_stride, arr[q].p1_stride, arr[q].x_stride = int(kind), int(s0), int(s1), 0
                 arr[q].p0, arr[q].p1 = L.ptr(p0), L.ptr(p1)
-                arr[q].x = None if xsrc is None else self._obs_dev.data_ptr() + 4 * plan['obs_index'][xsrc[1]]
+                arr[q].x = None if xsrc is None else obs_base + 4 * plan['obs_index'][xsrc[1]]
                 arr[q].scale = float(scale)
                 fl[q] = int(flags)
-            c = plan['c'] = dict(arr=arr, fl=fl, count=len(terms), obs_base=self._obs_dev.data_ptr(), prior=plan['prior'].reshape(-1))
+            c = plan['c'] = dict(arr=arr, fl=fl, count=len(terms), obs_base=obs_base, prior=plan['prior'].reshape(-1))
+        snp = self._stats_np
+        snp[5] = -1.0                                                        # (the kernel stores the count last)
         L.check(lib.pp_is_fused(net, plan['addr'], n, c['prior'].data_ptr(), c['arr'], c['fl'], c['count'], values.data_ptr(),
-                                lw.data_ptr(), 1, int(seed), int(self.offset), out.data_ptr(), self._stats_scratch.data_ptr(), ws,
-                                self.ws_bytes, st), 'pp_is_fused')
+                                lw.data_ptr(), 1, int(seed), int(self.offset), self._stats_pin.data_ptr(),
+                                self._stats_scratch.data_ptr(), ws, self.ws_bytes, st), 'pp_is_fused')
         self.prev_value = self.last_value = values
-        return values, lw, self._stats_dict(out)
+        spins = 0
+        while snp[5] < 0.0:
+            spins += 1
+            if spins > 2000000:      # (~1 s of polling: not a posterior call's time scale - let the runtime report what happened)
+                torch.cuda.synchronize(self.dev)
+                if snp[5] < 0.0:
+                    raise L.HipLibraryError('pp_is_fused: the statistics never arrived in host memory')
+        return values, lw, self._stats_dict(snp)
 
     PRIOR_KIND = {'Normal': 0, 'Uniform': 1}
 
@@ -387,7 +412,7 @@ class ISRunner:
 
     @staticmethod
     def _stats_dict(stats):
-        m, sw, sw2, swx, swx2, cnt = stats.tolist()[:6]
+        m, sw, sw2, swx, swx2, cnt = (float(v) for v in stats[:6]) if isinstance(stats, np.ndarray) else stats.tolist()[:6]
         mean = swx / sw if sw > 0 else float('nan')
         var = swx2 / sw - mean * mean if sw > 0 else float('nan')
         return dict(max_lw=m, sum_w=sw, sum_w2=sw2, sum_wx=swx, sum_wx2=swx2, count=cnt,

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 11
+PP_ABI_VERSION = 12
 PP_MAX_OBS = 8
 PP_MAX_LSTM_DEPTH = 4
 PP_MAX_OBS_DEPTH = 4
@@ -128,6 +128,8 @@ PROTOTYPES = {
     'pp_is_statement_rows': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32,
                                        C.c_uint64, C.c_uint64, vp, C.c_size_t, vp]),
     'pp_prior_draw': (C.c_int, [i32, vp, i32, vp, i32, i32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp]),
+    'pp_is_first_statement_supported': (C.c_int, [C.POINTER(pp_net), i32]),
+    'pp_is_first_statement': (C.c_int, [C.POINTER(pp_net), vp, vp, i32, vp, vp, vp, vp, C.c_size_t, vp]),
     'pp_is_step_net': (C.c_int, [C.POINTER(pp_net), vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, C.c_size_t, vp]),
     'pp_is_fused': (C.c_int, [C.POINTER(pp_net), i32, i32, vp, C.POINTER(pp_lw_term), C.POINTER(C.c_int32), i32, vp, vp, i32,
                               C.c_uint64, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),

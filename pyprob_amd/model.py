@@ -8,6 +8,9 @@ from . import state
 from .distributions import Empirical
 from .nn import InferenceNetworkFeedForward, InferenceNetworkLSTM, OnlineDataset
 from .state import InferenceEngine, InferenceNetwork, Optimizer, PriorInflation, TraceMode
+from operator import is_ as _is
+from os import environ as _environ
+import types
 
 
 def trace_result(trace):
@@ -165,7 +168,8 @@ class Model:
             return None
 
     # attributes the Model base class itself keeps on the instance (never read by a program as constants)
-    _BASE_ATTRS = frozenset(('_inference_network', '_lockstep_plans', '_lock_step_ok', '_last_prior_resident', '_plan_code_cache'))
+    _BASE_ATTRS = frozenset(('_inference_network', '_lockstep_plans', '_lock_step_ok', '_last_prior_resident', '_plan_code_cache',
+                             '_plan_key_cache'))
 
     @staticmethod
     def _fingerprint(v):
@@ -256,9 +260,7 @@ class Model:
         module globals, closure cells - this network (the engine's own token and address table size), this particle count and
         set of observed names. A replay does not run forward(), so whatever cannot be fingerprinted by value rules the plan
         out: None = no plan (also: call arguments, non-scalar observations, PP_IS_PLAN=0)."""
-        import os
-        import types
-        if args or kwargs or os.environ.get('PP_IS_PLAN', '1') == '0' or self._observe_values(observe) is None:
+        if args or kwargs or _environ.get('PP_IS_PLAN', '1') == '0' or self._observe_values(observe) is None:
             return None
         net = self._inference_network
         eng = getattr(net, '_engine', None)
@@ -267,6 +269,74 @@ class Model:
         reads = self._program_reads()
         if reads is None:
             return None
+        codes, names, cells, globs = reads
+        # Fast path of a repeated call: every object the key was built from is STILL THE SAME OBJECT (the cache holds the old
+        # objects, so an address cannot be reused) and each of them is immutable or a tensor whose in-place version is unchanged.
+        head = (eng.token, len(eng.spec.addresses), int(num_traces), tuple(sorted(observe or {})), float(likelihood_importance), reads)
+        watch = self._plan_watch(reads)
+        kc = self.__dict__.get('_plan_key_cache')
+        if kc is not None and kc[0] == head and watch is not None and len(kc[1]) == len(watch) and \
+                all(map(_is, kc[1], watch)) and all(watch[i]._version == ver for i, ver in kc[2]):
+            return kc[3]
+        key = self._lockstep_plan_key_slow(eng, num_traces, observe, likelihood_importance, reads)
+        stable = (type(None), bool, int, float, str, bytes, torch.Tensor, types.ModuleType, types.FunctionType,
+                  types.BuiltinFunctionType, types.MethodType, type)
+        if key is not None and watch is not None and all(isinstance(v, stable) or v is self for v in watch):
+            self.__dict__['_plan_key_cache'] = (head, watch, [(i, v._version) for i, v in enumerate(watch) if isinstance(v, torch.Tensor)], key)
+        else:
+            self.__dict__.pop('_plan_key_cache', None)
+        return key
+
+    def _plan_watch(self, reads):
+        """Every object `_lockstep_plan_key` looks at, in a fixed order: attribute names and values of the instance (the base
+        class's own bookkeeping aside), the class attributes, module globals and closure cells the program's bytecode names."""
+        codes, names, cells, globs = reads
+        out = []
+        base = self._BASE_ATTRS
+        d = vars(self)
+        for k, v in d.items():
+            if k not in base:
+                out.append(k)
+                out.append(v)
+        for k in self._plan_class_names(names):
+            if k in d:
+                continue
+            for klass in type(self).__mro__:
+                if klass is Model or klass is object:
+                    break
+                kv = vars(klass)
+                if k in kv:
+                    out.append(kv[k])
+                    break
+        try:
+            for k, g in globs:
+                out.append(g[k])
+            for k, cell in cells:
+                out.append(cell.cell_contents)
+        except (KeyError, ValueError):
+            return None
+        return out
+
+    def _plan_class_names(self, names):
+        """The names of the program's bytecode that can be class attributes of the model's own classes (not members of the
+        Model base): cached per (class, name set) - classes gain attributes rarely, and a new one that shadows nothing the
+        program read before cannot change a recorded call."""
+        cache = type(self).__dict__.get('_plan_class_names_cache')
+        if cache is None or cache[0] is not names:
+            own = set()
+            for klass in type(self).__mro__:
+                if klass is Model or klass is object:
+                    break
+                own.update(vars(klass))
+            cache = (names, tuple(sorted(k for k in names if k in own and not hasattr(Model, k))))
+            try:
+                type(self)._plan_class_names_cache = cache
+            except (AttributeError, TypeError):
+                pass
+        return cache[1]
+
+    def _lockstep_plan_key_slow(self, eng, num_traces, observe, likelihood_importance, reads):
+        import types
         codes, names, cells, globs = reads
         skip_types = (types.ModuleType, types.FunctionType, types.BuiltinFunctionType, types.MethodType, type)
         plain = []

@@ -181,6 +181,30 @@ def test_launch_plan_replay_equals_running_the_program(gum, monkeypatch):
         gum.likelihood_stddev = old
 
 
+def test_first_statement_in_two_launches_equals_the_separate_calls(gum, monkeypatch):
+    """pp_is_first_statement (observe embedding inside the one-row LSTM launch, observation read from pinned host memory,
+    statistics polled in pinned host memory) against pp_is_init + pp_is_step_net behind a staged copy (PP_IS_FIRST=0): the
+    same embedding, state and proposal bit for bit -> identical particles, log-weights and statistics; three observations."""
+    monkeypatch.setenv('PP_IS_FUSED', '1')
+    monkeypatch.setenv('PP_IS_PLAN', '1')
+    n = 100000
+    obs3 = ({'obs0': 8.0, 'obs1': 9.0}, {'obs0': 6.5, 'obs1': 7.25}, {'obs0': -1.0, 'obs1': 0.5})
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PP_IS_FIRST', flag)
+        gum.__dict__.pop('_lockstep_plans', None)
+        res = []
+        for rep in range(2):                      # first round records and verifies the plan, second round replays it
+            for k, o in enumerate(obs3):
+                res.append(gum.posterior_results(n, IC, observe=o, lock_step=True, seed=50 + k))
+        assert all(getattr(r, 'replayed_plan', False) for r in res[3:])
+        outs[flag] = res
+    for a, b in zip(outs['1'], outs['0']):
+        assert _same(a, b)
+    for r, o in zip(outs['1'][3:], obs3):          # and a replay equals the recorded run of the same observation and seed
+        assert abs(r.mean - (1.0 / 5 + (o['obs0'] + o['obs1']) / 2) / (1.0 / 5 + 1.0)) < 1.0      # posterior mean of the conjugate model
+
+
 class PrivateScale(GaussianWithUnknownMean):
     """The likelihood's scale lives in a PRIVATE attribute (`self._sigma`) and a constant in a module global reached through
     a helper method: state a launch-plan key that only fingerprinted public attributes never saw."""
