@@ -741,7 +741,7 @@ def main():
                 # mixture log-prob, backward dy, dz1, dh, cell, dX. Algorithmic FLOPs = the reference's products of those
                 # (full LSTM input width I, all four gates); executed = 64 observe-embedding columns, three gates (c_prev = 0)
                 panel_alg = 2.0 * B * (2.0 * 4 * H * I + 2.0 * H * hid_ + 2.0 * hid_ * 30)
-                p16 = os.environ.get('PP_PANEL', '2') not in ('0', '1') and H == 512 and B % 1 == 0
+                p16 = os.environ.get('PP_PANEL', '2') not in ('0', '1') and H in (512, 1024)
                 what = ('forward input product + LSTM cell + proposal head + mixture log-prob + loss and the backward data path '
                         'dy, dz1, dh, cell, dX of all %d traces' % B)
                 if p16:

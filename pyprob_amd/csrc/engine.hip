@@ -249,10 +249,10 @@ static void carve(const pp_net* net, int B, int R, void* p, size_t cap, Workspac
     // pair hand-off of the split panel launch: partial sums [panels][2][8][hid4] and [panels][2][8][64], flags, epoch
     // (sized for whichever panel kernel takes the batch: two workgroups per 8-row panel / four per 16-row panel)
     const int64_t n_pan = (B + 7) / 8;
-    w.xz = c.take<unsigned long long>(panel_shape ? std::max<int64_t>(n_pan * 2 * 8 * w.hid4, panel16_xz_granules(B, (int)w.hid4)) : 0);
+    w.xz = c.take<unsigned long long>(panel_shape ? std::max<int64_t>(n_pan * 2 * 8 * w.hid4, panel16_xz_granules(B, H)) : 0);
     w.xd = c.take<unsigned long long>(panel_shape ? std::max<int64_t>(n_pan * 2 * 8 * 64, panel16_xd_granules(B)) : 0);
     w.p16 = Panel16Images{};
-    if (panel_shape && H == 512 && net->e_obs == 64) {
+    if (panel_shape && net->e_obs == 64) {
         panel16_image_sizes(H, hid, net->e_obs, w.p16.frags);
         for (int i = 0; i < 6; ++i) w.p16.img[i] = c.take<float>(w.p16.frags[i] * 256);
     }
@@ -468,7 +468,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
         panel16_go = shape_ok && w.p16.img[0] && panel16_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs, R);
         if (panel16_go && bwd) {
             ObsFusedArgs oa;
-            panel16_go = panel_obs_tail_ok(net, H, ad.hid, ad.n_out, net->e_obs) && obs_fused_args(net, w.obs_h, oa) && panel16_obs_ok(oa);
+            panel16_go = obs_fused_supported(net) && obs_fused_args(net, w.obs_h, oa) && panel16_obs_ok(oa);
         }
         panel = panel16_go || (shape_ok && panel_t1_supported(ad.kind, H, ad.hid, ad.n_out, net->e_obs) && panel_t1_split(R, H) == 2);
     }
@@ -592,7 +592,7 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 pa.dbg = g_timeline;
                 // training: the observe-embedding backward of the rows rides in the kernel's tail (one launch less)
                 PanelObs po{};
-                obs_tail = bwd && panel_obs_tail_ok(net, H, ad.hid, ad.n_out, net->e_obs) && obs_fused_args(net, w.obs_h, po.a);
+                obs_tail = bwd && (panel16_go || panel_obs_tail_ok(net, H, ad.hid, ad.n_out, net->e_obs)) && obs_fused_args(net, w.obs_h, po.a);
                 if (obs_tail) {
                     po.P = P; po.cat = w.cat; po.f1 = w.f1;
                     po.dE = w.dE; po.dF1 = w.dF1; po.dCat = w.dCat; po.dHo0 = w.dObsH;

@@ -47,28 +47,47 @@ namespace {
 
 constexpr int PR = 16;                 // rows of a panel
 constexpr int NWV = 8;                 // waves of a workgroup
-constexpr int HH = 512;                // LSTM hidden width
 constexpr int SS = 4;                  // workgroups per panel
-constexpr int UT = HH / 16;            // unit tiles
 constexpr int EE = 64, KE = EE / 16;   // observe-embedding width (K of the input product), its 16-k units
-constexpr int NT = 17;                 // 16-column tiles of the head's hidden layer (hid in (256, 272])
-constexpr int ZK = 16 * NT;            // padded hidden width of the head
 constexpr int NO = 32;                 // padded head outputs (two tiles)
 // LDS pitches (floats) = 8 mod 16: the A operand's ds_read_b128 (lane: row l & 15, four k at 4 (l >> 4)) is conflict-free
-constexpr int PE = EE + 8, PH = 128 + 8, PZ = ZK + 8, PDY = NO + 8, PG = 16 + 8, PX = EE + 8;
-constexpr int L_E = 0;
-constexpr int L_H = L_E + PR * PE;
-constexpr int L_Z = L_H + PR * PH;
-constexpr int L_YP = L_Z + PR * PZ;                 // [wave][16][16] partial y tiles
-constexpr int L_T = L_YP + NWV * PR * 16;           // [wave][16][16] partial tile 16 of head layer 1
-constexpr int L_DY = L_T + NWV * PR * 16;
-constexpr int L_DZ = L_DY + PR * PDY;
-constexpr int L_DG = L_DZ + PR * PZ;                // [wave][3][16][PG] dG tiles (wave-private)
-constexpr int L_END = L_DG + NWV * 3 * PR * PG;
-constexpr int L_XP = L_Z;                           // [wave][16][PX] partial dX tiles: over sZ .. sDY (dead by then)
-static_assert(L_XP + NWV * PR * PX <= L_DZ, "the partial dX tiles must not reach the live dz1 tile");
-constexpr int L_OIMG = L_DZ;                        // observe-embedding weight image of the tail: over sDZ + sDG
-static_assert(L_END - L_OIMG >= 10240 + 8, "the embedding image must fit the dead buffers");
+constexpr int PE = EE + 8, PDY = NO + 8, PG = 16 + 8, PX = EE + 8;
+
+// Shapes that depend on the LSTM width H (512: the benchmark network; 1024: BASELINE.json configs[4]'s per-rank network). A
+// workgroup owns H / 4 hidden units, a wave UTW = H / 512 unit tiles of them; the head's hidden layer has NT 16-column tiles
+// (hid in (16 (NT - 1), 16 NT]: 17 | 33 for K <= 10 mixture components), TPW = (NT - 1) / 8 of them per wave in phases 2 and
+// 4 plus the K-split (phase 2) / wave-0 (phase 4) last tile.
+template <int HH_>
+struct P16 {
+    static constexpr int HH = HH_;
+    static constexpr int UT = HH / 16;            // unit tiles
+    static constexpr int UW = HH / SS;            // hidden units of a workgroup
+    static constexpr int UTW = UW / 128;          // unit tiles of a wave
+    static constexpr int KL = UW / 16;            // 16-k units of the workgroup's h tile (K of phase 2)
+    static constexpr int NT = HH == 512 ? 17 : 33;
+    static constexpr int TPW = (NT - 1) / NWV;
+    static constexpr int ZK = 16 * NT;            // padded hidden width of the head
+    static constexpr int ZT = 16 * (NT - 1);      // first column of the last tile
+    static constexpr int PH = UW + 8, PZ = ZK + 8;
+    static constexpr int L_E = 0;
+    static constexpr int L_H = L_E + PR * PE;
+    static constexpr int L_Z = L_H + PR * PH;
+    static constexpr int L_YP = L_Z + PR * PZ;                 // [wave][16][16] partial y tiles
+    static constexpr int L_T = L_YP + NWV * PR * 16;           // [wave][16][16] partial last tile of head layer 1
+    static constexpr int L_DY = L_T + NWV * PR * 16;
+    static constexpr int L_DZ = L_DY + PR * PDY;
+    static constexpr int L_DG = L_DZ + PR * PZ;                // [wave][3][16][PG] dG tiles of ONE unit tile (wave-private)
+    static constexpr int L_END = L_DG + NWV * 3 * PR * PG;
+    static constexpr int L_XP = L_Z;                           // [wave][16][PX] partial dX tiles: over sZ .. sDY (dead by then)
+    static_assert(L_XP + NWV * PR * PX <= L_DZ, "the partial dX tiles must not reach the live dz1 tile");
+    static constexpr int L_OIMG = L_DZ;                        // observe-embedding weight image of the tail: over sDZ + sDG
+    static_assert(L_END - L_OIMG >= 10240 + 8, "the embedding image must fit the dead buffers");
+    static_assert(L_END * 4 <= 160 * 1024, "LDS");
+    // the fragment stream of a wave: phase 1 | 2 | 3 | 4 | per unit tile: 5, 6
+    static constexpr int F1 = 3 * KE * UTW, F2 = KL * TPW + UTW, F3 = (2 * NT + NWV - 1) / NWV, F4 = 2 * TPW + 2, F5 = NT, F6 = 3 * KE;
+    static constexpr int B1 = 0, B2 = B1 + F1, B3 = B2 + F2, B4 = B3 + F3, B5 = B4 + F4, FU = F5 + F6, FT = B5 + UTW * FU;
+    static constexpr int RING = HH == 512 ? 24 : 16;
+};
 
 constexpr float kFp32Eps = 1.1920928955078125e-07f;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
@@ -121,41 +140,40 @@ __device__ __forceinline__ f32x4 mma4(const f32x4& a, const f32x4& b, f32x4 c) {
 #define PP_MMA(S, A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x4f32((A)[S], (B)[S], C, 0, 0, 0)
 
 // ---- the fragment stream of a wave ------------------------------------------------------------------------------------
-constexpr int F1 = 3 * KE, F2 = 17, F3 = 5, F4 = 6, F5 = NT, F6 = 3 * KE;
-constexpr int B1 = 0, B2 = B1 + F1, B3 = B2 + F2, B4 = B3 + F3, B5 = B4 + F4, B6 = B5 + F5, FT = B6 + F6;
-constexpr int RING = 24;
-
+template <int HH_>
 struct FragPtrs {
+    using T = P16<HH_>;
     const f32x4 *p1, *p2, *p3, *p4, *p5, *p6;      // per-phase bases, this lane's float4 of fragment 0
     int wave;
     template <int G>
     __device__ __forceinline__ const f32x4* at() const {
-        if constexpr (G < B2) {                    // (16-k unit, gate): the wave's unit tile
-            constexpr int f = G - B1;
-            return p1 + ((f / 3) * (UT * 3) + (f % 3)) * 64;
-        } else if constexpr (G < B3) {             // tiles wave and wave + 8 per 16-k unit, then tile 16 of the wave's own unit
-            constexpr int f = G - B2;
-            if constexpr (f < 16) return p2 + ((f >> 1) * NT + ((f & 1) ? 8 : 0)) * 64;
-            else return p2 + (wave * NT + 16 - wave) * 64;
-        } else if constexpr (G < B4) {             // items wave + 8 f of the 34 (unit, tile) pairs of head layer 2
-            constexpr int f = G - B3;
-            return p3 + min(8 * f, 33 - wave) * 64;
-        } else if constexpr (G < B5) {             // (tile wave | wave + 8 | 16, unit f & 1)
-            constexpr int f = G - B4;
-            return p4 + ((f & 1) * NT + (f < 2 ? 0 : (f < 4 ? 8 : 16 - wave))) * 64;
-        } else if constexpr (G < B6) {             // 16-k unit f of the head's hidden layer, the wave's unit tile
-            constexpr int f = G - B5;
-            return p5 + f * (UT * 64);
-        } else {                                   // (gate, column tile) of the wave's unit tile
-            constexpr int f = G - B6;
-            return p6 + f * 64;
+        if constexpr (G < T::B2) {                 // (16-k unit, unit tile of the wave, gate)
+            constexpr int f = G - T::B1;
+            return p1 + ((f / (3 * T::UTW)) * (T::UT * 3) + (f % (3 * T::UTW))) * 64;
+        } else if constexpr (G < T::B3) {          // tiles wave + 8 t per 16-k unit, then the last tile for the wave's own units
+            constexpr int f = G - T::B2;
+            if constexpr (f < T::KL * T::TPW) return p2 + ((f / T::TPW) * T::NT + 8 * (f % T::TPW)) * 64;
+            else return p2 + ((T::UTW * wave + (f - T::KL * T::TPW)) * T::NT + (T::NT - 1) - wave) * 64;
+        } else if constexpr (G < T::B4) {          // items wave + 8 f of the 2 NT (unit, tile) pairs of head layer 2
+            constexpr int f = G - T::B3;
+            return p3 + min(8 * f, 2 * T::NT - 1 - wave) * 64;
+        } else if constexpr (G < T::B5) {          // (tile wave + 8 t | last, unit f & 1)
+            constexpr int f = G - T::B4;
+            return p4 + ((f & 1) * T::NT + ((f >> 1) < T::TPW ? 8 * (f >> 1) : (T::NT - 1) - wave)) * 64;
+        } else {                                   // per unit tile j of the wave: NT units of dh, then (gate, column tile) of dX
+            constexpr int j = (G - T::B5) / T::FU, f = (G - T::B5) % T::FU;
+            if constexpr (f < T::F5) return p5 + (f * T::UT + j) * 64;
+            else return p6 + (j * 3 * KE + (f - T::F5)) * 64;
         }
     }
 };
 
 // KIND: head kind (0 Normal mixture, 1 TruncatedNormal mixture in a Uniform prior, 2 Poisson head), kernels.hip.
-template <int KIND, bool OBS>
+template <int HH_, int KIND, bool OBS>
 __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, const PanelObs oin) {
+    using T = P16<HH_>;
+    constexpr int HH = T::HH, UT = T::UT, UTW = T::UTW, NT = T::NT, TPW = T::TPW, ZK = T::ZK, ZT = T::ZT, PH = T::PH, PZ = T::PZ;
+    constexpr int RING = T::RING, FT = T::FT, B1 = T::B1, B2 = T::B2, B3 = T::B3, B4 = T::B4, B5 = T::B5;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PanelArgs a = ain.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -167,18 +185,17 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     if (m0 >= a.B) return;                                // (all four workgroups of the panel)
     const int c = lane & 15, g = lane >> 4;               // C / B operand: column c, rows 4 g + i; A operand: row c, k group g
     const int hid = a.hid, n_out = a.n_out, K = a.K;
-    const int ut = 8 * q + wave;                          // this wave's unit tile
-    const int u = 16 * ut + c;                            // this lane's hidden unit (C layout)
+    const int ut0 = UTW * (8 * q + wave);                 // this wave's first unit tile (it owns UTW consecutive ones)
     const int epoch = *a.epoch;
-    float* const sE = smem + L_E;
-    float* const sH = smem + L_H;
-    float* const sZ = smem + L_Z;
-    float* const sYP = smem + L_YP;
-    float* const sT = smem + L_T;
-    float* const sDY = smem + L_DY;
-    float* const sDZ = smem + L_DZ;
-    float* const sDGw = smem + L_DG + wave * (3 * PR * PG);
-    float* const sXP = smem + L_XP;
+    float* const sE = smem + T::L_E;
+    float* const sH = smem + T::L_H;
+    float* const sZ = smem + T::L_Z;
+    float* const sYP = smem + T::L_YP;
+    float* const sT = smem + T::L_T;
+    float* const sDY = smem + T::L_DY;
+    float* const sDZ = smem + T::L_DZ;
+    float* const sDGw = smem + T::L_DG + wave * (3 * PR * PG);
+    float* const sXP = smem + T::L_XP;
     const int dbg_slot = (bx == 0 ? 0 : (bx == 77 ? 1 : -1));
 #define P16_STAMP(k)                                                                                            \
     do {                                                                                                        \
@@ -187,36 +204,38 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     } while (0)
     P16_STAMP(0);
 
-    FragPtrs fp;
+    FragPtrs<HH_> fp;
     fp.wave = wave;
-    fp.p1 = reinterpret_cast<const f32x4*>(ain.img[0]) + (ut * 3) * 64 + lane;
-    fp.p2 = reinterpret_cast<const f32x4*>(ain.img[1]) + ((8 * q) * NT + wave) * 64 + lane;
+    fp.p1 = reinterpret_cast<const f32x4*>(ain.img[0]) + (ut0 * 3) * 64 + lane;
+    fp.p2 = reinterpret_cast<const f32x4*>(ain.img[1]) + ((T::KL * q) * NT + wave) * 64 + lane;
     fp.p3 = reinterpret_cast<const f32x4*>(ain.img[2]) + wave * 64 + lane;
     fp.p4 = reinterpret_cast<const f32x4*>(ain.img[3]) + wave * 64 + lane;
-    fp.p5 = reinterpret_cast<const f32x4*>(ain.img[4]) + ut * 64 + lane;
-    fp.p6 = reinterpret_cast<const f32x4*>(ain.img[5]) + (ut * 3 * KE) * 64 + lane;
+    fp.p5 = reinterpret_cast<const f32x4*>(ain.img[4]) + ut0 * 64 + lane;
+    fp.p6 = reinterpret_cast<const f32x4*>(ain.img[5]) + (ut0 * 3 * KE) * 64 + lane;
     // ---------------- staging: E rows (their loads go out first), then the head of the fragment stream ----------------
     f32x4 ev = {0, 0, 0, 0};
     if (tid < PR * (EE / 4))
         ev = *reinterpret_cast<const f32x4*>(a.X + (int64_t)min(m0 + (tid >> 4), a.B - 1) * a.ldx + 4 * (tid & 15));
     f32x4 ring[RING];
-#define P16_ISSUE(G)                                                   \
-    do {                                                               \
-        if constexpr ((G) < FT) ring[(G) % RING] = *fp.at<(G)>();      \
+#define P16_ISSUE(G)                                                           \
+    do {                                                                       \
+        if constexpr ((G) < FT) ring[(G) % RING] = *fp.template at<(G)>();     \
     } while (0)
     static_for<0, RING>([&](auto GG) {
         constexpr int g0 = decltype(GG)::value;
         P16_ISSUE(g0);
     });
     // small vectors of later phases, fetched now (a first touch from memory costs ~2 000 cycles where it is needed): the LSTM
-    // bias of this lane's unit, b1 of its three head columns, and - waves 0..3, row 4 wave + g - the row's value, prior and b2
-    float bias[3];
+    // bias of this lane's units, b1 of its head columns, and - waves 0..3, row 4 wave + g - the row's value, prior and b2
+    float bias[UTW][3];
 #pragma unroll
-    for (int y = 0; y < 3; ++y) bias[y] = a.AB[(y == 0 ? 0 : y + 1) * HH + u];
-    float b1v[2];
+    for (int j = 0; j < UTW; ++j)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) b1v[t] = a.b1[16 * (t == 0 ? wave : wave + 8) + c];
-    const float b16 = a.b1[min(256 + (tid & 15), hid - 1)];      // (threads < 256: column 256 + tid % 16 of tile 16)
+        for (int y = 0; y < 3; ++y) bias[j][y] = a.AB[(y == 0 ? 0 : y + 1) * HH + 16 * (ut0 + j) + c];
+    float b1v[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) b1v[t] = a.b1[16 * (wave + 8 * t) + c];
+    const float b16 = a.b1[min(ZT + (tid & 15), hid - 1)];      // (threads < 256: column ZT + tid % 16 of the last tile)
     const int mrow = min(m0 + 4 * (wave & 3) + g, a.B - 1);
     const float m_v = a.value[mrow], m_pa = a.prior[2 * mrow], m_pb = a.prior[2 * mrow + 1];
     const int mcol = min(c, K - 1);
@@ -227,86 +246,116 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     P16_STAMP(1);
 
     // ---------------- phase 1: G = E W_ih[:, :e]^T + bias, LSTM cell (c0 = 0) ----------------
-    float gi[4], gg[4], go[4], tc[4];        // gate activations and tanh(c) of (row 4 g + i, unit u)
+    float gi[UTW][4], gg[UTW][4], go[UTW][4], tc[UTW][4];        // gate activations and tanh(c) of (row 4 g + i, unit)
     {
-        f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        f32x4 acc[UTW][3];
+#pragma unroll
+        for (int j = 0; j < UTW; ++j)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) acc[j][y] = f32x4{0, 0, 0, 0};
         static_for<0, KE>([&](auto KQ) {
             constexpr int kq = decltype(KQ)::value;
+            constexpr int G0 = B1 + 3 * UTW * kq;
             const f32x4 av = *reinterpret_cast<const f32x4*>(sE + c * PE + 16 * kq + 4 * g);
-            const f32x4 b0 = ring[(B1 + 3 * kq) % RING], b1 = ring[(B1 + 3 * kq + 1) % RING], b2 = ring[(B1 + 3 * kq + 2) % RING];
-            PP_MMA(0, av, b0, acc[0]); PP_MMA(0, av, b1, acc[1]); PP_MMA(0, av, b2, acc[2]);
-            PP_MMA(1, av, b0, acc[0]); PP_MMA(1, av, b1, acc[1]); PP_MMA(1, av, b2, acc[2]);
-            PP_MMA(2, av, b0, acc[0]); PP_MMA(2, av, b1, acc[1]); PP_MMA(2, av, b2, acc[2]);
-            PP_MMA(3, av, b0, acc[0]); PP_MMA(3, av, b1, acc[1]); PP_MMA(3, av, b2, acc[2]);
-            P16_ISSUE(B1 + 3 * kq + RING); P16_ISSUE(B1 + 3 * kq + 1 + RING); P16_ISSUE(B1 + 3 * kq + 2 + RING);
+            static_for<0, 4>([&](auto SQ) {
+                constexpr int sq = decltype(SQ)::value;
+                static_for<0, 3 * UTW>([&](auto FF) {
+                    constexpr int ff = decltype(FF)::value;
+                    acc[ff / 3][ff % 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], ring[(G0 + ff) % RING][sq], acc[ff / 3][ff % 3], 0, 0, 0);
+                });
+            });
+            static_for<0, 3 * UTW>([&](auto FF) {
+                constexpr int ff = decltype(FF)::value;
+                P16_ISSUE(G0 + ff + RING);
+            });
         });
         // cell: sigmoid and tanh through v_exp_f32 / v_rcp_f32 (absolute error ~1e-7, asserted in tests/test_gpu_panel.py)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * g + i;
-            const float vi = fast_sigmoid(acc[0][i] + bias[0]);
-            const float vg = fast_tanh(acc[1][i] + bias[1]);
-            const float vo = fast_sigmoid(acc[2][i] + bias[2]);
-            const float tcv = fast_tanh(vi * vg);
-            const float h = vo * tcv;
-            gi[i] = vi; gg[i] = vg; go[i] = vo; tc[i] = tcv;
-            sH[r * PH + 16 * wave + c] = h;
-            if (m0 + r < a.B) a.Hs[(int64_t)(m0 + r) * HH + u] = h;
-        }
+        for (int j = 0; j < UTW; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const float vi = fast_sigmoid(acc[j][0][i] + bias[j][0]);
+                const float vg = fast_tanh(acc[j][1][i] + bias[j][1]);
+                const float vo = fast_sigmoid(acc[j][2][i] + bias[j][2]);
+                const float tcv = fast_tanh(vi * vg);
+                const float h = vo * tcv;
+                gi[j][i] = vi; gg[j][i] = vg; go[j][i] = vo; tc[j][i] = tcv;
+                sH[r * PH + 16 * (UTW * wave + j) + c] = h;
+                if (m0 + r < a.B) a.Hs[(int64_t)(m0 + r) * HH + 16 * (ut0 + j) + c] = h;
+            }
     }
     P16_STAMP(2);
-    __syncthreads();     // the workgroup's h tile [16][128] is complete
+    __syncthreads();     // the workgroup's h tile [16][H / 4] is complete
     P16_STAMP(3);
 
-    // ---------------- phase 2: partial z1 = h[:, own units] W1^T; tiles wave, wave + 8 (all K), tile 16 (own unit) ----------------
-    float zt[2][4];      // z1 of (row 4 g + i, column 16 tile + c): tiles wave, wave + 8 (tile 16: in sZ)
+    // ---------------- phase 2: partial z1 = h[:, own units] W1^T; tiles wave + 8 t (all K), the last tile (own units) ----------------
+    float zt[TPW][4];    // z1 of (row 4 g + i, column 16 (wave + 8 t) + c); the last tile's z1 lives in sZ
     {
-        f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        static_for<0, 8>([&](auto KL) {
-            constexpr int kl = decltype(KL)::value;
+        f32x4 acc[TPW + 1];
+#pragma unroll
+        for (int t = 0; t <= TPW; ++t) acc[t] = f32x4{0, 0, 0, 0};
+        static_for<0, T::KL>([&](auto KLL) {
+            constexpr int kl = decltype(KLL)::value;
+            constexpr int G0 = B2 + TPW * kl;
             const f32x4 av = *reinterpret_cast<const f32x4*>(sH + c * PH + 16 * kl + 4 * g);
-            const f32x4 b0 = ring[(B2 + 2 * kl) % RING], b1 = ring[(B2 + 2 * kl + 1) % RING];
-            PP_MMA(0, av, b0, acc[0]); PP_MMA(0, av, b1, acc[1]);
-            PP_MMA(1, av, b0, acc[0]); PP_MMA(1, av, b1, acc[1]);
-            PP_MMA(2, av, b0, acc[0]); PP_MMA(2, av, b1, acc[1]);
-            PP_MMA(3, av, b0, acc[0]); PP_MMA(3, av, b1, acc[1]);
-            P16_ISSUE(B2 + 2 * kl + RING); P16_ISSUE(B2 + 2 * kl + 1 + RING);
+            static_for<0, 4>([&](auto SQ) {
+                constexpr int sq = decltype(SQ)::value;
+                static_for<0, TPW>([&](auto TT) {
+                    constexpr int t = decltype(TT)::value;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], ring[(G0 + t) % RING][sq], acc[t], 0, 0, 0);
+                });
+            });
+            static_for<0, TPW>([&](auto TT) {
+                constexpr int t = decltype(TT)::value;
+                P16_ISSUE(G0 + t + RING);
+            });
         });
-        {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(sH + c * PH + 16 * wave + 4 * g);
-            acc[2] = mma4(av, ring[(B2 + 16) % RING], acc[2]);
-            P16_ISSUE(B2 + 16 + RING);
-        }
+        static_for<0, UTW>([&](auto JJ) {
+            constexpr int j = decltype(JJ)::value;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(sH + c * PH + 16 * (UTW * wave + j) + 4 * g);
+            acc[TPW] = mma4(av, ring[(B2 + T::KL * TPW + j) % RING], acc[TPW]);
+            P16_ISSUE(B2 + T::KL * TPW + j + RING);
+        });
         P16_STAMP(4);
         // the partial sums leave for the three partner workgroups: {value, tag} granules [panel][quarter][row][ZK]
         unsigned long long* const xz_own = a.xz + (int64_t)(panel * SS + q) * (PR * ZK);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sT[(wave * PR + 4 * g + i) * 16 + c] = acc[2][i];
-            gput(xz_own + (4 * g + i) * ZK + 16 * wave + c, acc[0][i], epoch);
-            gput(xz_own + (4 * g + i) * ZK + 16 * (wave + 8) + c, acc[1][i], epoch);
+            sT[(wave * PR + 4 * g + i) * 16 + c] = acc[TPW][i];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) gput(xz_own + (4 * g + i) * ZK + 16 * (wave + 8 * t) + c, acc[t][i], epoch);
         }
-        __syncthreads();     // tile 16's eight partial tiles
-        // tile 16 (the K split over the waves): one element per thread of the first four waves - sum of the eight partial tiles,
-        // published like the others; its partner sums ride in the same batch of loads below
-        const int er = tid >> 4, ec = tid & 15;          // (tid < 256: row er, column 256 + ec)
+        __syncthreads();     // the last tile's eight partial tiles
+        // the last tile (the K split over the waves): one element per thread of the first four waves - sum of the eight partial
+        // tiles, published like the others; its partner sums ride in the first batch of loads below
+        const int er = tid >> 4, ec = tid & 15;          // (tid < 256: row er, column ZT + ec)
         float own16 = 0.0f;
         if (tid < 256) {
 #pragma unroll
             for (int w = 0; w < NWV; ++w) own16 += sT[(w * PR + er) * 16 + ec];
-            gput(xz_own + er * ZK + 256 + ec, own16, epoch);
+            gput(xz_own + er * ZK + ZT + ec, own16, epoch);
         }
         P16_STAMP(5);
-        // the three partners' partial sums: every granule load of the wave is in flight together; a pass is repeated until all
-        // of a lane's granules carry this step's tag
-        float xs[3][9];
-        {
-            const unsigned tag = gtag(epoch);
-            const unsigned long long* pb[3];
+        // the three partners' partial sums, two tiles (+ the last tile's element) per batch: every granule load of a batch is in
+        // flight together; a pass is repeated until all of a lane's granules carry this step's tag. z1 = relu(b1 + quarter 0 +
+        // quarter 1 + quarter 2 + quarter 3): the SAME order in all four workgroups
+        const unsigned tag = gtag(epoch);
+        const unsigned long long* pb[3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) pb[s] = a.xz + (int64_t)(panel * SS + (s + (s >= q ? 1 : 0))) * (PR * ZK);
-            // (waves 4..7 have no element of tile 16: a duplicate of their first granule, waited for anyway)
-            const int o16 = tid < 256 ? er * ZK + 256 + ec : (4 * g) * ZK + 16 * wave + c;
+        for (int s = 0; s < 3; ++s) pb[s] = a.xz + (int64_t)(panel * SS + (s + (s >= q ? 1 : 0))) * (PR * ZK);
+        auto four = [&](float own, float x0, float x1, float x2) {
+            const float v0 = q == 0 ? own : x0;
+            const float v1 = q == 1 ? own : (q > 1 ? x1 : x0);
+            const float v2 = q == 2 ? own : (q > 2 ? x2 : x1);
+            const float v3 = q == 3 ? own : x2;
+            return ((v0 + v1) + v2) + v3;
+        };
+        static_for<0, TPW / 2>([&](auto BB) {
+            constexpr int bt = 2 * decltype(BB)::value;       // tiles bt and bt + 1 of the wave
+            // (waves 4..7 and the later batches have no element of the last tile: a duplicate of a granule waited for anyway)
+            const int o16 = (bt == 0 && tid < 256) ? er * ZK + ZT + ec : (4 * g) * ZK + 16 * (wave + 8 * bt) + c;
+            float xs[3][9];
             int spins = 0;
             while (true) {
                 unsigned long long x[3][9];
@@ -315,8 +364,8 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int ro = (4 * g + i) * ZK + c;
-                        x[s][i] = __hip_atomic_load(pb[s] + ro + 16 * wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        x[s][4 + i] = __hip_atomic_load(pb[s] + ro + 16 * (wave + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        x[s][i] = __hip_atomic_load(pb[s] + ro + 16 * (wave + 8 * bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        x[s][4 + i] = __hip_atomic_load(pb[s] + ro + 16 * (wave + 8 * (bt + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                     x[s][8] = __hip_atomic_load(pb[s] + o16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
@@ -332,45 +381,37 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1 << 20)) __builtin_trap();
             }
-        }
-        P16_STAMP(6);
-        // z1 = relu(b1 + quarter 0 + quarter 1 + quarter 2 + quarter 3): the SAME order in all four workgroups
-        auto four = [&](float own, float x0, float x1, float x2) {
-            const float v0 = q == 0 ? own : x0;
-            const float v1 = q == 1 ? own : (q > 1 ? x1 : x0);
-            const float v2 = q == 2 ? own : (q > 2 ? x2 : x1);
-            const float v3 = q == 3 ? own : x2;
-            return ((v0 + v1) + v2) + v3;
-        };
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int j = 16 * (t == 0 ? wave : wave + 8) + c;
+            for (int tt = 0; tt < 2; ++tt) {
+                const int j = 16 * (wave + 8 * (bt + tt)) + c;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = 4 * t + i, r = 4 * g + i;
-                const float z = relu_keep_nan(four(acc[t][i], xs[0][e], xs[1][e], xs[2][e]) + b1v[t]);      // (j < 256 < hid)
-                zt[t][i] = z;
-                sZ[r * PZ + j] = z;
-                if (g == q && m0 + r < a.B) a.A1[(int64_t)(m0 + r) * a.lda1 + j] = z;
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * tt + i, r = 4 * g + i;
+                    const float z = relu_keep_nan(four(acc[bt + tt][i], xs[0][e], xs[1][e], xs[2][e]) + b1v[bt + tt]);      // (j < ZT < hid)
+                    zt[bt + tt][i] = z;
+                    sZ[r * PZ + j] = z;
+                    if (g == q && m0 + r < a.B) a.A1[(int64_t)(m0 + r) * a.lda1 + j] = z;
+                }
             }
-        }
-        if (tid < 256) {
-            const int j = 256 + ec;
-            const float z = j < hid ? relu_keep_nan(four(own16, xs[0][8], xs[1][8], xs[2][8]) + b16) : 0.0f;
-            sZ[er * PZ + j] = z;
-            if ((er >> 2) == q && m0 + er < a.B && j < a.lda1) a.A1[(int64_t)(m0 + er) * a.lda1 + j] = z;
-        }
+            if (bt == 0 && tid < 256) {
+                const int j = ZT + ec;
+                const float z = j < hid ? relu_keep_nan(four(own16, xs[0][8], xs[1][8], xs[2][8]) + b16) : 0.0f;
+                sZ[er * PZ + j] = z;
+                if ((er >> 2) == q && m0 + er < a.B && j < a.lda1) a.A1[(int64_t)(m0 + er) * a.lda1 + j] = z;
+            }
+        });
+        P16_STAMP(6);
     }
-    __syncthreads();     // z1 [16][272] complete
+    __syncthreads();     // z1 [16][ZK] complete
     P16_STAMP(7);
 
-    // ---------------- phase 3: y = z1 W2^T; item wave + 8 f of the 34 (unit, tile) pairs: this wave's tile is wave & 1 ----------------
+    // ---------------- phase 3: y = z1 W2^T; item wave + 8 f of the 2 NT (unit, tile) pairs: this wave's tile is wave & 1 ----------------
     {
         f32x4 y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
-        static_for<0, F3>([&](auto F) {
+        static_for<0, T::F3>([&](auto F) {
             constexpr int f = decltype(F)::value;
             const int unit = (wave >> 1) + 4 * f;
-            if (unit < NT) {         // (wave-uniform; f = 4 only for waves 0 and 1)
+            if (unit < NT) {         // (wave-uniform)
                 const f32x4 av = *reinterpret_cast<const f32x4*>(sZ + c * PZ + 16 * unit + 4 * g);
                 if constexpr (f & 1) y1 = mma4(av, ring[(B3 + f) % RING], y1);
                 else y0 = mma4(av, ring[(B3 + f) % RING], y0);
@@ -479,59 +520,73 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
 
     // ---------------- phase 4: dz1 = (dy W2) * [z1 > 0] on the tiles of phase 2 ----------------
     {
-        f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        static_for<0, F4>([&](auto F) {
+        f32x4 acc[TPW + 1];
+#pragma unroll
+        for (int t = 0; t <= TPW; ++t) acc[t] = f32x4{0, 0, 0, 0};
+        static_for<0, T::F4>([&](auto F) {
             constexpr int f = decltype(F)::value;
-            if (f < 4 || wave == 0) {
+            if ((f >> 1) < TPW || wave == 0) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(sDY + c * PDY + 16 * (f & 1) + 4 * g);
                 acc[f >> 1] = mma4(av, ring[(B4 + f) % RING], acc[f >> 1]);
             }
             P16_ISSUE(B4 + f + RING);
         });
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (t == 2 && wave != 0) break;
-            const int tile = t == 0 ? wave : (t == 1 ? wave + 8 : 16);
-            const int j = 16 * tile + c;
+        for (int t = 0; t <= TPW; ++t) {
+            if (t == TPW && wave != 0) break;
+            const int j = t < TPW ? 16 * (wave + 8 * t) + c : ZT + c;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * g + i;
-                const float zv = t < 2 ? zt[t < 2 ? t : 0][i] : sZ[r * PZ + j];
+                const float zv = t < TPW ? zt[t < TPW ? t : 0][i] : sZ[r * PZ + j];
                 const float d = (j < hid && zv > 0.0f) ? acc[t][i] : 0.0f;
                 sDZ[r * PZ + j] = d;
                 if (g == q && m0 + r < a.B && j < a.lda1) a.dZ1[(int64_t)(m0 + r) * a.lda1 + j] = d;
             }
         }
     }
-    __syncthreads();     // dz1 [16][272] complete
+    __syncthreads();     // dz1 [16][ZK] complete
     P16_STAMP(10);
 
-    // ---------------- phase 5: dh = dz1 W1 for this wave's units, cell backward in registers ----------------
-    {
+    // observe-embedding backward (tail): its weights and the masks of this lane's outputs are fetched behind phase 6
+    constexpr int ONB = 2;
+    ObsStage<8, 512> of1, of0;
+    ObsStage<4, 512> ol1[ONB];
+    // masks of the tail's three layers for this lane's outputs: waves 0..3 = column tile `wave` of the two 64-wide layers, lanes
+    // 0..15 (row group 0 of the C layout) = the workgroup's four rows; waves o < n_obs: the hidden units of observable o
+    float m_f1[4] = {0, 0, 0, 0}, m_cat[4] = {0, 0, 0, 0}, m_h[4] = {0, 0, 0, 0};
+    f32x4 xacc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // partial dX tiles of this wave
+    // ---------------- phases 5 and 6, one unit tile of the wave at a time ----------------
+    // phase 5: dh = dz1 W1 for the tile's 16 units, cell backward in registers; phase 6: partial dX[:, :e] += dG[:, tile's gate rows]
+    // W_ih[those rows, :e] with the A operand from a wave-private LDS tile (no workgroup barrier between the two)
+    static_for<0, UTW>([&](auto JJ) {
+        constexpr int j = decltype(JJ)::value;
+        constexpr int G5 = B5 + j * T::FU, G6 = G5 + T::F5;
         f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-        static_for<0, F5 / 2>([&](auto FP) {          // two fragments at a time: their MFMA chains interleave
+        static_for<0, T::F5 / 2>([&](auto FP) {          // two fragments at a time: their MFMA chains interleave
             constexpr int f = 2 * decltype(FP)::value;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * f + 4 * g);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * (f + 1) + 4 * g);
-            const f32x4 b0 = ring[(B5 + f) % RING], b1 = ring[(B5 + f + 1) % RING];
+            const f32x4 b0 = ring[(G5 + f) % RING], b1 = ring[(G5 + f + 1) % RING];
             PP_MMA(0, a0, b0, d0); PP_MMA(0, a1, b1, d1);
             PP_MMA(1, a0, b0, d0); PP_MMA(1, a1, b1, d1);
             PP_MMA(2, a0, b0, d0); PP_MMA(2, a1, b1, d1);
             PP_MMA(3, a0, b0, d0); PP_MMA(3, a1, b1, d1);
-            P16_ISSUE(B5 + f + RING); P16_ISSUE(B5 + f + 1 + RING);
+            P16_ISSUE(G5 + f + RING); P16_ISSUE(G5 + f + 1 + RING);
         });
-        static_assert(F5 % 2 == 1, "one fragment left");
+        static_assert(T::F5 % 2 == 1, "one fragment left");
         {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * (F5 - 1) + 4 * g);
-            d0 = mma4(av, ring[(B5 + F5 - 1) % RING], d0);
-            P16_ISSUE(B5 + F5 - 1 + RING);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(sDZ + c * PZ + 16 * (T::F5 - 1) + 4 * g);
+            d0 = mma4(av, ring[(G5 + T::F5 - 1) % RING], d0);
+            P16_ISSUE(G5 + T::F5 - 1 + RING);
         }
+        const int u = 16 * (ut0 + j) + c;                // this lane's hidden unit (C layout)
         float gs_i = 0.f, gs_g = 0.f, gs_o = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * g + i;
             const float dh = d0[i] + d1[i];
-            const float vi = gi[i], vg = gg[i], vo = go[i], tcv = tc[i];
+            const float vi = gi[j][i], vg = gg[j][i], vo = go[j][i], tcv = tc[j][i];
             const float dc = dh * vo * (1.0f - tcv * tcv);
             float d_i = dc * vg * vi * (1.0f - vi);
             float d_g = dc * vi * (1.0f - vg * vg);
@@ -555,63 +610,57 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
             atomicAdd(a.gsum + 2 * HH + u, gs_g);
             atomicAdd(a.gsum + 3 * HH + u, gs_o);
         }
-    }
-    wave_sync_lds();     // this wave's dG tiles (A operand of phase 6) are its own
-    P16_STAMP(11);
-    // observe-embedding backward (tail): its weights and this wave's row inputs are fetched now, behind phase 6
-    constexpr int ONB = 2;
-    ObsStage<8, 512> of1, of0;
-    ObsStage<4, 512> ol1[ONB];
-    // masks of the tail's three layers for this lane's outputs: waves 0..3 = column tile `wave` of the two 64-wide layers, lanes
-    // 0..15 (row group 0 of the C layout) = the workgroup's four rows; waves o < n_obs: the hidden units of observable o
-    float m_f1[4] = {0, 0, 0, 0}, m_cat[4] = {0, 0, 0, 0}, m_h[4] = {0, 0, 0, 0};
-    if (OBS) {
-        const ObsFusedArgs& oa = oin.a;
-        of1.load(oin.P + oa.f1.w_off, oa.f1.rows * oa.f1.cols, tid);
-        of0.load(oin.P + oa.f0.w_off, oa.f0.rows * oa.f0.cols, tid);
+        wave_sync_lds();     // this wave's dG tiles (A operand of phase 6) are its own
+        if constexpr (j == 0) {
+            P16_STAMP(11);
+            if (OBS) {
+                const ObsFusedArgs& oa = oin.a;
+                of1.load(oin.P + oa.f1.w_off, oa.f1.rows * oa.f1.cols, tid);
+                of0.load(oin.P + oa.f0.w_off, oa.f0.rows * oa.f0.cols, tid);
 #pragma unroll
-        for (int o = 0; o < ONB; ++o)
-            if (o < oa.n_obs) ol1[o].load(oin.P + oa.l1[o].w_off, oa.l1[o].rows * oa.l1[o].cols, tid);
-        if (wave < 4 && g == 0) {
+                for (int o = 0; o < ONB; ++o)
+                    if (o < oa.n_obs) ol1[o].load(oin.P + oa.l1[o].w_off, oa.l1[o].rows * oa.l1[o].cols, tid);
+                if (wave < 4 && g == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int tb = min(m0 + 4 * q + i, a.B - 1);
-                m_f1[i] = oin.f1[(int64_t)tb * oa.e_ld + 16 * wave + c];
-                m_cat[i] = oin.cat[(int64_t)tb * oa.e_ld + 16 * wave + c];
-            }
+                    for (int i = 0; i < 4; ++i) {
+                        const int tb = min(m0 + 4 * q + i, a.B - 1);
+                        m_f1[i] = oin.f1[(int64_t)tb * oa.e_ld + 16 * wave + c];
+                        m_cat[i] = oin.cat[(int64_t)tb * oa.e_ld + 16 * wave + c];
+                    }
 #pragma unroll
-            for (int o = 0; o < ONB; ++o)
-                if (o == wave && o < oa.n_obs && c < oa.hid[o]) {
+                    for (int o = 0; o < ONB; ++o)
+                        if (o == wave && o < oa.n_obs && c < oa.hid[o]) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) m_h[i] = oa.obs_h[o][(int64_t)min(m0 + 4 * q + i, a.B - 1) * oa.ohid_ld[o] + c];
+                            for (int i = 0; i < 4; ++i) m_h[i] = oa.obs_h[o][(int64_t)min(m0 + 4 * q + i, a.B - 1) * oa.ohid_ld[o] + c];
+                        }
                 }
+            }
         }
-    }
-    // ---------------- phase 6: partial dX[:, :e] = dG[:, own gate rows] W_ih[own gate rows, :e] ----------------
-    {
-        f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         static_for<0, 3>([&](auto Y) {
             constexpr int y = decltype(Y)::value;
             const f32x4 av = *reinterpret_cast<const f32x4*>(sDGw + (y * PR + c) * PG + 4 * g);
-            const f32x4 b0 = ring[(B6 + 4 * y) % RING], b1 = ring[(B6 + 4 * y + 1) % RING], b2 = ring[(B6 + 4 * y + 2) % RING],
-                        b3 = ring[(B6 + 4 * y + 3) % RING];
-            PP_MMA(0, av, b0, acc[0]); PP_MMA(0, av, b1, acc[1]); PP_MMA(0, av, b2, acc[2]); PP_MMA(0, av, b3, acc[3]);
-            PP_MMA(1, av, b0, acc[0]); PP_MMA(1, av, b1, acc[1]); PP_MMA(1, av, b2, acc[2]); PP_MMA(1, av, b3, acc[3]);
-            PP_MMA(2, av, b0, acc[0]); PP_MMA(2, av, b1, acc[1]); PP_MMA(2, av, b2, acc[2]); PP_MMA(2, av, b3, acc[3]);
-            PP_MMA(3, av, b0, acc[0]); PP_MMA(3, av, b1, acc[1]); PP_MMA(3, av, b2, acc[2]); PP_MMA(3, av, b3, acc[3]);
+            const f32x4 b0 = ring[(G6 + 4 * y) % RING], b1 = ring[(G6 + 4 * y + 1) % RING], b2 = ring[(G6 + 4 * y + 2) % RING],
+                        b3 = ring[(G6 + 4 * y + 3) % RING];
+            PP_MMA(0, av, b0, xacc[0]); PP_MMA(0, av, b1, xacc[1]); PP_MMA(0, av, b2, xacc[2]); PP_MMA(0, av, b3, xacc[3]);
+            PP_MMA(1, av, b0, xacc[0]); PP_MMA(1, av, b1, xacc[1]); PP_MMA(1, av, b2, xacc[2]); PP_MMA(1, av, b3, xacc[3]);
+            PP_MMA(2, av, b0, xacc[0]); PP_MMA(2, av, b1, xacc[1]); PP_MMA(2, av, b2, xacc[2]); PP_MMA(2, av, b3, xacc[3]);
+            PP_MMA(3, av, b0, xacc[0]); PP_MMA(3, av, b1, xacc[1]); PP_MMA(3, av, b2, xacc[2]); PP_MMA(3, av, b3, xacc[3]);
+            P16_ISSUE(G6 + 4 * y + RING); P16_ISSUE(G6 + 4 * y + 1 + RING); P16_ISSUE(G6 + 4 * y + 2 + RING); P16_ISSUE(G6 + 4 * y + 3 + RING);
         });
+    });
+    {
         float* pw = sXP + wave * (PR * PX);       // (sZ .. sDY are dead: every wave passed the barrier behind phase 4)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pw[(4 * g + i) * PX + 16 * t + c] = acc[t][i];
+            for (int i = 0; i < 4; ++i) pw[(4 * g + i) * PX + 16 * t + c] = xacc[t][i];
     }
     P16_STAMP(12);
     __syncthreads();
-    float* const oimg = smem + L_OIMG;            // sDZ and the dG tiles are dead now
-    float* const sT0 = smem + L_H;                // A operands of the tail's layers: [16][PX], rows 0..3 = this workgroup's rows
-    float* const sT1 = smem + L_Z;                // (over the partial dX tiles, behind a barrier)
-    float* const sT2 = smem + L_Z + PR * PX;
+    float* const oimg = smem + T::L_OIMG;         // sDZ and the dG tiles are dead now
+    float* const sT0 = smem + T::L_H;                // A operands of the tail's layers: [16][PX], rows 0..3 = this workgroup's rows
+    float* const sT1 = smem + T::L_Z;                // (over the partial dX tiles, behind a barrier)
+    float* const sT2 = smem + T::L_Z + PR * PX;
     if (OBS) {
         const ObsFusedArgs& oa = oin.a;
         const int dummy = oa.lds_total;
@@ -735,12 +784,12 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
 #undef P16_ISSUE
 }
 
-template <int KIND, bool OBS>
+template <int HH_, int KIND, bool OBS>
 static int panel16_launch(const Panel16Args& a, const PanelObs& po, hipStream_t st) {
-    constexpr size_t lds = (size_t)L_END * sizeof(float);
+    constexpr size_t lds = (size_t)P16<HH_>::L_END * sizeof(float);
     static thread_local bool configured = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)panel16_kernel<KIND, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)panel16_kernel<HH_, KIND, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("panel16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return (int)e;
@@ -748,13 +797,24 @@ static int panel16_launch(const Panel16Args& a, const PanelObs& po, hipStream_t 
         configured = true;
     }
     const int panels = cdiv(a.a.B, PR);
-    hipLaunchKernelGGL((panel16_kernel<KIND, OBS>), dim3(8 * SS * cdiv(panels, 8)), dim3(512), lds, st, a, po);
+    hipLaunchKernelGGL((panel16_kernel<HH_, KIND, OBS>), dim3(8 * SS * cdiv(panels, 8)), dim3(512), lds, st, a, po);
     return 0;
+}
+
+template <int HH_>
+static int panel16_slots() {      // workgroups of this kernel the device holds at once (the occupancy gate of panel16_supported)
+    int dev = 0, cus = 0, per_cu = 0;
+    constexpr size_t lds = (size_t)P16<HH_>::L_END * sizeof(float);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipFuncSetAttribute((const void*)panel16_kernel<HH_, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)panel16_kernel<HH_, 0, true>, 512, lds) != hipSuccess) return 0;
+    return cus * per_cu;
 }
 
 }  // namespace
 
-int64_t panel16_xz_granules(int B, int) { return (int64_t)cdiv(B, PR) * SS * PR * ZK; }
+static inline int p16_zk(int H) { return H == 1024 ? P16<1024>::ZK : P16<512>::ZK; }
+int64_t panel16_xz_granules(int B, int H) { return (int64_t)cdiv(B, PR) * SS * PR * p16_zk(H); }
 int64_t panel16_xd_granules(int B) { return (int64_t)cdiv(B, PR) * SS * PR * EE; }
 
 // Which single-statement batches the 16-row kernel takes. PP_PANEL=1 keeps the 8-row kernel (A/B), 0 the tile kernels.
@@ -762,26 +822,15 @@ bool panel16_supported(int kind, int H, int hid, int n_out, int e, int B) {
     static const int env = getenv("PP_PANEL") ? atoi(getenv("PP_PANEL")) : 2;
     if (env < 2 || deterministic_mode()) return false;
     if (kind != PP_HEAD_NORMAL_MIXTURE && kind != PP_HEAD_TRUNCNORMAL_MIXTURE && kind != PP_HEAD_POISSON_TN_MIXTURE) return false;
-    if (H != HH || e != EE || hid <= 16 * (NT - 1) || hid > ZK) return false;
+    if ((H != 512 && H != 1024) || e != EE || hid <= p16_zk(H) - 16 || hid > p16_zk(H)) return false;
     if (n_out % 3 != 0 || n_out < 3 || n_out > 30) return false;           // K <= 10 components: one DPP row per row, two output tiles
     if (B < 1 || cdiv(B, PR) > 1024) return false;
     // The four workgroups of a panel wait for each other through memory: a 32-block window of the grid must be resident
-    // together. One 103 KB workgroup per CU and in-order dispatch give that on a device whose occupancy for this kernel covers
-    // at least two windows; a CU-masked or partitioned device with fewer slots takes the other kernels instead of risking the
-    // bounded spin's trap (ADVICE r03 / VERDICT r04 1d).
-    static const int slots = [] {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return 0;
-        if (hipFuncSetAttribute((const void*)panel16_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(L_END * sizeof(float))) != hipSuccess)
-            return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)panel16_kernel<0, true>, 512,
-                                                         (size_t)L_END * sizeof(float)) != hipSuccess)
-            return 0;
-        return cus * per_cu;
-    }();
-    return slots >= 2 * 8 * SS;
+    // together. One workgroup per CU (103 | 146 KB of LDS) and in-order dispatch give that on a device whose occupancy for this
+    // kernel covers at least two windows; a CU-masked or partitioned device with fewer slots takes the other kernels instead of
+    // risking the bounded spin's trap (ADVICE r03 / VERDICT r04 1d).
+    static const int slots512 = panel16_slots<512>(), slots1024 = panel16_slots<1024>();
+    return (H == 512 ? slots512 : slots1024) >= 2 * 8 * SS;
 }
 
 // the MFMA tail's shapes: two 64 x 64 layers of the final stack, per observable a 16 k-multiple of outputs and <= 16 hidden units
@@ -805,14 +854,20 @@ int panel16(int kind, const Panel16Args& a, hipStream_t st, const PanelObs* obs)
                  "panel16: bad leading dimensions or missing buffers");
     if (obs) PP_CHECK_ARG(panel16_obs_ok(obs->a), "panel16: the observe-embedding tail does not fit");
     static const PanelObs none{};
-#define PP_P16_GO(KIND)                                                          \
-    do {                                                                         \
-        if (obs) PP_TRY((panel16_launch<KIND, true>(a, *obs, st)));              \
-        else PP_TRY((panel16_launch<KIND, false>(a, none, st)));                 \
+#define PP_P16_GO(HH_, KIND)                                                          \
+    do {                                                                              \
+        if (obs) PP_TRY((panel16_launch<HH_, KIND, true>(a, *obs, st)));              \
+        else PP_TRY((panel16_launch<HH_, KIND, false>(a, none, st)));                 \
     } while (0)
-    if (kind == PP_HEAD_NORMAL_MIXTURE) PP_P16_GO(0);
-    else if (kind == PP_HEAD_TRUNCNORMAL_MIXTURE) PP_P16_GO(1);
-    else PP_P16_GO(2);
+#define PP_P16_KIND(HH_)                                                  \
+    do {                                                                  \
+        if (kind == PP_HEAD_NORMAL_MIXTURE) PP_P16_GO(HH_, 0);            \
+        else if (kind == PP_HEAD_TRUNCNORMAL_MIXTURE) PP_P16_GO(HH_, 1);  \
+        else PP_P16_GO(HH_, 2);                                           \
+    } while (0)
+    if (p.H == 512) PP_P16_KIND(512);
+    else PP_P16_KIND(1024);
+#undef PP_P16_KIND
 #undef PP_P16_GO
     PP_LAUNCH_CHECK("panel16");
     return 0;

@@ -12,12 +12,12 @@ struct Panel16Args {
     const float* img[6];
 };
 
-// single-statement batch, one address, one LSTM layer, mixture head of <= 32 outputs, H = 512, e = 64: the 16-row kernel
+// single-statement batch, one address, one LSTM layer, mixture head of <= 30 outputs, H = 512 | 1024, e = 64: the 16-row kernel
 bool panel16_supported(int kind, int H, int hid, int n_out, int e, int B);
 bool panel16_obs_ok(const ObsFusedArgs& oa);      // the embedding shapes its (MFMA) tail takes
 int panel16(int kind, const Panel16Args& a, hipStream_t st, const PanelObs* obs = nullptr);
 // granules (8 bytes) of the two hand-off buffers for B rows
-int64_t panel16_xz_granules(int B, int lda1);
+int64_t panel16_xz_granules(int B, int H);
 int64_t panel16_xd_granules(int B);
 
 }  // namespace pp

@@ -24,8 +24,10 @@ from pyprob_amd.packed import PackedBatch
 from pyprob_amd.spec import NetSpec
 out = {}
 for name, B, dist in (('gum1024', 1024, 'Normal'), ('gum1003', 1003, 'Normal'), ('uni777', 777, 'Uniform'), ('nan64', 64, 'Normal'),
-                      ('gum2048', 2048, 'Normal'), ('gum2041', 2041, 'Normal'), ('gum4096', 4096, 'Normal')):
-    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
+                      ('gum2048', 2048, 'Normal'), ('gum2041', 2041, 'Normal'), ('gum4096', 4096, 'Normal'),
+                      ('wide1024', 1024, 'Normal'), ('wide1003', 1003, 'Normal'), ('wideuni500', 500, 'Uniform')):
+    # (wide*: LSTM hidden 1024 - BASELINE.json configs[4]'s per-rank network; the 16-row kernel only)
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=1024 if name.startswith('wide') else 512)
     spec.add_address('mu', dist)
     arr = synthetic_gum_arrays(B, seed=3 + B)
     if dist == 'Uniform':       # prior U(-4, 6); a few values outside the support (log_prob -inf -> rescued rows)

@@ -1,5 +1,5 @@
 """The 16-row panel kernel (PP_PANEL=2) against the tile path (PP_PANEL=0), one forward + backward, per-tensor errors:
-    python tools/panel16_probe.py [B] [dist]        (runs itself twice in subprocesses)"""
+    python tools/panel16_probe.py [B] [dist]        (runs itself twice in subprocesses; P16_H=1024: the wider network)"""
 import os
 import subprocess
 import sys
@@ -11,13 +11,13 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests'))
 
 
-def child(B, dist, out):
+def child(B, dist, out, H=512):
     import torch
     from helpers import synthetic_gum_arrays
     from pyprob_amd.engine import ICEngine
     from pyprob_amd.packed import PackedBatch
     from pyprob_amd.spec import NetSpec
-    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=512)
+    spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=H)
     spec.add_address('mu', dist)
     arr = synthetic_gum_arrays(B, seed=3 + B)
     if dist == 'Uniform':
@@ -38,7 +38,7 @@ def child(B, dist, out):
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == '--child':
-        child(int(sys.argv[2]), sys.argv[3], sys.argv[4])
+        child(int(sys.argv[2]), sys.argv[3], sys.argv[4], int(os.environ.get('P16_H', '512')))
         sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     dist = sys.argv[2] if len(sys.argv) > 2 else 'Normal'
@@ -52,7 +52,7 @@ if __name__ == '__main__':
             sys.exit(1)
         outs[mode] = dict(np.load(f))
     a, b = outs['2'], outs['0']
-    print('B', B, dist, 'loss', a['loss'], b['loss'])
+    print('H', os.environ.get('P16_H', '512'), 'B', B, dist, 'loss', a['loss'], b['loss'])
     for k in sorted(a):
         x, y = a[k].astype(np.float64), b[k].astype(np.float64)
         fin = np.isfinite(y)
