@@ -157,7 +157,11 @@ def test_panel_kernel_equals_the_tile_path(tmp_path, tile_run, mode):
             pa, pb = a.reshape(-1, 1024), b.reshape(-1, 1024)      # per 1024-float chunk: a wrong region shows up here
             den = np.maximum(np.abs(pb).max(axis=1), 1e-6 * np.abs(b).max())
             worst = (np.abs(pa - pb).max(axis=1) / den).max()
-            assert worst < 2e-3, (k, worst)
+            # (the wide network under a Uniform prior: gradients of ~1e-6 and 540 000 hidden pre-activations of the head per
+            # minibatch - one of them within rounding of the ReLU kink flips its mask between two fp32 summation orders and moves a
+            # chunk of dW1 by ~5e-3 of its own size: tools/panel16_sweep.sh shows the tile path doing the same against the float64
+            # oracle at B = 1024. A wrong REGION is a deviation of order 1.)
+            assert worst < (2e-2 if k.startswith('wideuni') else 2e-3), (k, worst)
 
 
 def test_panel_kernel_against_the_oracle():

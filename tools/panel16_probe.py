@@ -23,6 +23,7 @@ def child(B, dist, out, H=512):
     if dist == 'Uniform':
         arr['prior'] = np.tile(np.array([[-4.0, 6.0]], np.float32), (B, 1))
         arr['values'] = np.clip(arr['values'], -3.9, 5.9).astype(np.float32)
+        arr['values'][::97] = 7.5
     eng = ICEngine(spec, device='cuda:0', seed=5)
     pb = PackedBatch.from_ragged(arr['trace_len'], arr['addr_idx'], arr['values'], arr['prior'], arr['obs'], 1).to(eng.device)
     res = {}
@@ -52,9 +53,38 @@ if __name__ == '__main__':
             sys.exit(1)
         outs[mode] = dict(np.load(f))
     a, b = outs['2'], outs['0']
+    if os.environ.get('P16_ORACLE'):      # both against the float64 oracle (which of the two moved?)
+        from helpers import synthetic_gum_arrays
+        from oracle import ic_oracle as O
+        from pyprob_amd.spec import NetSpec
+        import torch
+        from pyprob_amd.engine import ICEngine
+        H = int(os.environ.get('P16_H', '512'))
+        arr = synthetic_gum_arrays(B, seed=3 + B)
+        if dist == 'Uniform':
+            arr['prior'] = np.tile(np.array([[-4.0, 6.0]], np.float32), (B, 1))
+            arr['values'] = np.clip(arr['values'], -3.9, 5.9).astype(np.float32)
+            arr['values'][::97] = 7.5
+        spec = NetSpec({'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, lstm_dim=H)
+        spec.add_address('mu', dist)
+        eng = ICEngine(spec, device='cuda:0', seed=5)
+        P = {k: v.numpy().astype(np.float64) for k, v in eng.state_dict().items()}
+        ref = O.loss_and_grads(O.Net(P, ['obs0', 'obs1'], K=10), arr, ['mu'], [dist])
+        print('oracle loss', ref['loss'], 'panel16', a['loss'], 'tiles', b['loss'])
+        for n in sorted(ref['grads']):
+            r = ref['grads'][n]
+            m = max(np.abs(r).max(), 1e-30)
+            print('%-62s max|ref| %.2e  panel16 err %.2e  tiles err %.2e' % (n, m, np.abs(a['g/' + n] - r).max() / m, np.abs(b['g/' + n] - r).max() / m))
+        sys.exit(0)
     print('H', os.environ.get('P16_H', '512'), 'B', B, dist, 'loss', a['loss'], b['loss'])
     for k in sorted(a):
         x, y = a[k].astype(np.float64), b[k].astype(np.float64)
         fin = np.isfinite(y)
         err = np.abs(x[fin] - y[fin]).max() / max(np.abs(y[fin]).max(), 1e-30)
-        print('%-70s max|ref| %.3e  rel err %.2e %s' % (k, np.abs(y[fin]).max(), err, '' if err < 3e-5 else '  <-----'))
+        worst = 0.0
+        if x.size >= 1024 and fin.all():      # per 1024-element chunk, relative to the chunk's own magnitude (tests/test_gpu_panel.py)
+            n = (x.size // 1024) * 1024
+            xa, ya = x.reshape(-1)[:n].reshape(-1, 1024), y.reshape(-1)[:n].reshape(-1, 1024)
+            den = np.maximum(np.abs(ya).max(axis=1), 1e-6 * np.abs(y).max())
+            worst = float((np.abs(xa - ya).max(axis=1) / den).max())
+        print('%-70s max|ref| %.3e  rel err %.2e  worst chunk %.2e %s' % (k, np.abs(y[fin]).max(), err, worst, '' if err < 3e-5 and worst < 2e-3 else '  <-----'))
