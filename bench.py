@@ -408,13 +408,21 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
     elif cnt.value > 0:
         per_call_us = float(ms[:cnt.value].sum()) * 1e3 / calls
         nbytes = float(fl[:cnt.value].sum()) / calls
+        # The pass is VALU-bound (a Philox block, the draw, K exps and a logsumexp per particle; 8 B per particle reach memory): it
+        # is priced on the VALU pipe with SQ counters from a committed PMC run of the same sources (tools/pmc_is_fused.sh), not on
+        # HBM - the memory figure rides along for the record
+        vprof, vnote = committed_profile('r05_is_fused_valu.json')
         rec['particle_kernels'] = dict(
-            bound='hbm', achieved=round(nbytes / (per_call_us * 1e-6) / 1e9, 2), peak=HBM_PEAK_GBS, unit='GB/s',
-            frac=round(nbytes / (per_call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), us_per_call=round(per_call_us, 3),
-            launches_per_call=round(cnt.value / calls, 2), bytes_per_call=nbytes,
+            bound='valu', unit='VALU issue fraction', peak=1.0,
+            achieved=(vprof or {}).get('valu_issue_fraction'), frac=(vprof or {}).get('valu_issue_fraction'),
+            valu_active_over_wave_cycles=(vprof or {}).get('valu_active_over_wave_cycles'),
+            counters=(vprof or {}).get('counters'), counters_source=vnote,
+            frac_note=(vprof or {}).get('valu_issue_fraction_note'),
+            hbm_gbs=round(nbytes / (per_call_us * 1e-6) / 1e9, 2), hbm_frac=round(nbytes / (per_call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+            us_per_call=round(per_call_us, 3), launches_per_call=round(cnt.value / calls, 2), bytes_per_call=nbytes,
             kernel='is_fused_kernel (draw from the shared proposal + log q + prior / likelihood terms + float64 statistics '
                    'partials in one pass: 8 B per particle written) [+ per-row draw kernels of later statements]; HIP event '
-                   'pairs around the launches; compute-bound on Philox + logsumexp over K components, not on HBM',
+                   'pairs around the launches of a second, instrumented loop',
             wall_over_kernel=round(dt / calls * 1e6 / per_call_us, 2))
         # every launch of the call, not only the pass over the particles: kernel class 6 brackets pp_is_init ... pp_is_fused (the
         # observe embedding, the two one-row network kernels, the pass with its statistics) - a few extra calls, outside `dt`

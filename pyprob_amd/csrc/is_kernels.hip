@@ -387,6 +387,161 @@ __global__ __launch_bounds__(256) void first_row_head_kernel(const float* __rest
     }
 }
 
+// ... and head layer 1 in the SAME launch as the one-row LSTM step (pp_is_first_statement's default): blocks [0, nl) are the
+// LSTM workgroups of first_row_net_kernel - their h values leave as agent-scope atomic stores and each workgroup counts itself
+// in `ready` once its waves' stores are acknowledged -, blocks [nl, nl + cdiv(hid, 4)) are first_row_head_kernel's: they fetch
+// their rows of W1 (and W2 for the last arriver) FIRST - the loads do not depend on h -, then wait for ready == nl and read h
+// with agent-scope atomic loads. The head's cold weight loads (~2 us) and one kernel boundary disappear from the call's chain.
+// Progress: the LSTM blocks have the lower block ids (dispatched first), 100 workgroups fit any device this library runs on.
+template <int NOBS>
+__global__ __launch_bounds__(256) void first_row_all_kernel(const ObsFusedArgs ain, GatherDims d, const float* __restrict__ P,
+                                                            const int64_t* __restrict__ at, const float* __restrict__ obs,
+                                                            int addr_id, int64_t w_ih, int64_t b_ih, int64_t b_hh, int H,
+                                                            float* __restrict__ e_out, int e4, float* __restrict__ h,
+                                                            float* __restrict__ c, int nl, int64_t w1, int64_t b1, int hid,
+                                                            int64_t w2, int64_t b2, int n_out, float* __restrict__ A1,
+                                                            float* __restrict__ Y, unsigned int* ticket, unsigned int* ready) {
+    __shared__ float lds[10240 + 1024];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    if ((int)blockIdx.x < nl) {
+        // ---- the LSTM workgroups (first_row_net_kernel) ----
+        float* const sx = lds + 10240;
+        const ObsFusedArgs a = ain;
+        const int u0 = (blockIdx.x * 4 + wave) * 4;
+        constexpr int KI = 4;
+        float wv[4][3][KI];
+        float bsum[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int gsel = 0; gsel < 3; ++gsel) {
+                const int n = (gsel == 0 ? 0 : gsel + 1) * H + min(u0 + q, H - 1);
+                const float* wr = P + w_ih + (int64_t)n * d.I;
+#pragma unroll
+                for (int kk = 0; kk < KI; ++kk) wv[q][gsel][kk] = (lane + 64 * kk) < d.I ? wr[lane + 64 * kk] : 0.0f;
+                bsum[q][gsel] = P[b_ih + n] + P[b_hh + n];
+            }
+        float ov = 0.0f;
+        if (wave == 0 && lane < a.width) ov = obs[lane];
+        obs_stage_all<NOBS>(a, P, lds, tid);
+        for (int k = d.e_obs + tid; k < d.I; k += 256) sx[k] = gather_embedding_elem(d, P, at, k, -1, 0.0f, addr_id);
+        if (wave == 0 && lane < a.width) sx[d.I + lane] = ov;
+        __syncthreads();
+        if (wave == 0) {
+            const float e = obs_forward_row<NOBS>(a, lds, sx + d.I, lane);
+            if (lane < a.e_obs) {
+                sx[lane] = e;
+                if (blockIdx.x == 0) e_out[lane] = e;
+            }
+            if (blockIdx.x == 0 && lane < min(a.width, 8)) e_out[e4 + lane] = ov;
+        }
+        __syncthreads();
+        float xv[KI];
+#pragma unroll
+        for (int kk = 0; kk < KI; ++kk) xv[kk] = (lane + 64 * kk) < d.I ? sx[lane + 64 * kk] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float g3[3];
+#pragma unroll
+            for (int gsel = 0; gsel < 3; ++gsel) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < KI; ++kk) acc += wv[q][gsel][kk] * xv[kk];
+                g3[gsel] = wave_sum(acc) + bsum[q][gsel];
+            }
+            if (lane == 0 && u0 + q < H) {
+                const float cn = sigmoidf_(g3[0]) * tanhf(g3[1]);
+                c[u0 + q] = cn;
+                __hip_atomic_store(h + u0 + q, sigmoidf_(g3[2]) * tanhf(cn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's h stores are acknowledged
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // ---- head layer 1 (first_row_head_kernel), the last arriver finishes layer 2 ----
+    float* const sa = lds;
+    const int j = ((int)blockIdx.x - nl) * 4 + wave;
+    const int nh = (int)gridDim.x - nl;
+    constexpr int OW = 8, KW = 5;
+    const bool w2_pre = n_out <= 4 * OW && hid <= 64 * KW;
+    float w2r[OW][KW];
+#pragma unroll
+    for (int q = 0; q < OW; ++q)
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            const int o = min(wave * OW + q, n_out - 1), k = min(lane + 64 * i, hid - 1);
+            w2r[q][i] = w2_pre ? P[w2 + (int64_t)o * hid + k] : 0.0f;
+        }
+    // this wave's row of W1, all of it, before h exists (H <= 1024: four float4 per lane)
+    constexpr int WQ = 4;
+    f32x4 wq[WQ];
+    const float* wr = P + w1 + (int64_t)min(j, hid - 1) * H;
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) wq[i] = (lane * 4 + 256 * i + 3 < H) ? *reinterpret_cast<const f32x4*>(wr + lane * 4 + 256 * i) : f32x4{0, 0, 0, 0};
+    const float b1v = P[b1 + min(j, hid - 1)];
+    {
+        int spins = 0;
+        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nl) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 22)) __builtin_trap();
+        }
+    }
+    if (j < hid) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+            const int k = lane * 4 + 256 * i;
+            if (k + 3 < H) {      // (first_row_head_kernel's expression: the same rounding, bit-identical outputs)
+                const float t0 = __hip_atomic_load(h + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float t1 = __hip_atomic_load(h + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float t2 = __hip_atomic_load(h + k + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float t3 = __hip_atomic_load(h + k + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc += wq[i][0] * t0 + wq[i][1] * t1 + wq[i][2] * t2 + wq[i][3] * t3;
+            }
+        }
+        const float v = relu_keep_nan(wave_sum(acc) + b1v);
+        if (lane == 0) __hip_atomic_store(A1 + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (unsigned)nh - 1u;
+        if (s_last) {      // every head workgroup has passed its wait: both words are ready for the next launch
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int k = tid; k < hid; k += 256) sa[k] = __hip_atomic_load(A1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int o0 = wave * OW; o0 < n_out; o0 += 4 * OW) {
+        float acc[OW];
+#pragma unroll
+        for (int q = 0; q < OW; ++q) {
+            acc[q] = 0.0f;
+            if (w2_pre) {
+#pragma unroll
+                for (int i = 0; i < KW; ++i)
+                    if (lane + 64 * i < hid) acc[q] += w2r[q][i] * sa[lane + 64 * i];
+            } else {
+                const float* wr2 = P + w2 + (int64_t)min(o0 + q, n_out - 1) * hid;
+                for (int k = lane; k < hid; k += 64) acc[q] += wr2[k] * sa[k];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < OW; ++q) {
+            const float v = wave_sum(acc[q]);
+            if (lane == 0 && o0 + q < n_out) Y[o0 + q] = v + P[b2 + o0 + q];
+        }
+    }
+}
+
 struct IsWorkspace {
     float *X, *G, *A1, *Y, *rec, *c0;
     float *obs_h, *cat, *f1;
@@ -531,16 +686,31 @@ int is_first_statement(const pp_net* net, const float* P, const float* obs, int 
     const pp_addr& ad = net->addrs[addr_id];
     const int H = net->lstm_dim;
     GatherDims gd{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+    const char* ev = getenv("PP_IS_FIRST");      // 1 (default): one launch; 2: the LSTM and the head launches separately (A/B)
+    const bool one = !(ev && atoi(ev) == 2) && H <= 1024 && cdiv(H, 16) + cdiv(ad.hid, 4) <= 200;
+    unsigned int* tk = reinterpret_cast<unsigned int*>(w.ticket);
+    if (one) {
+#define PP_FIRST_ALL(N)                                                                                                          \
+    hipLaunchKernelGGL(first_row_all_kernel<N>, dim3(cdiv(H, 16) + cdiv(ad.hid, 4)), dim3(256), 0, st, a, gd, P, net->addr_table, \
+                       obs, addr_id, net->w_ih, net->b_ih, net->b_hh, H, e_out, (int)w.e4, h, c, cdiv(H, 16), ad.w1, ad.b1,       \
+                       ad.hid, ad.w2, ad.b2, ad.n_out, w.A1, w.Y, tk, tk + 1)
+        if (a.n_obs <= 1) PP_FIRST_ALL(1);
+        else if (a.n_obs <= 2) PP_FIRST_ALL(2);
+        else if (a.n_obs <= 4) PP_FIRST_ALL(4);
+        else PP_FIRST_ALL(8);
+#undef PP_FIRST_ALL
+    } else {
 #define PP_FIRST_NET(N)                                                                                                       \
     hipLaunchKernelGGL(first_row_net_kernel<N>, dim3(cdiv(H, 16)), dim3(256), 0, st, a, gd, P, net->addr_table, obs, addr_id, \
                        net->w_ih, net->b_ih, net->b_hh, H, e_out, (int)w.e4, h, c)
-    if (a.n_obs <= 1) PP_FIRST_NET(1);
-    else if (a.n_obs <= 2) PP_FIRST_NET(2);
-    else if (a.n_obs <= 4) PP_FIRST_NET(4);
-    else PP_FIRST_NET(8);
+        if (a.n_obs <= 1) PP_FIRST_NET(1);
+        else if (a.n_obs <= 2) PP_FIRST_NET(2);
+        else if (a.n_obs <= 4) PP_FIRST_NET(4);
+        else PP_FIRST_NET(8);
 #undef PP_FIRST_NET
-    hipLaunchKernelGGL(first_row_head_kernel, dim3(cdiv(ad.hid, 4)), dim3(256), 0, st, P, (const float*)h, H, ad.w1, ad.b1, ad.hid,
-                       ad.w2, ad.b2, ad.n_out, w.A1, w.Y, reinterpret_cast<unsigned int*>(w.ticket));
+        hipLaunchKernelGGL(first_row_head_kernel, dim3(cdiv(ad.hid, 4)), dim3(256), 0, st, P, (const float*)h, H, ad.w1, ad.b1, ad.hid,
+                           ad.w2, ad.b2, ad.n_out, w.A1, w.Y, tk);
+    }
     PP_LAUNCH_CHECK("pp_is_first_statement");
     return 0;
 }

@@ -206,6 +206,16 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream_ptr():
+_raw_stream = None
+
+
+def stream_ptr(device_index=None):
+    """hipStream_t of torch's current stream on the current (or given) device. torch._C._cuda_getCurrentRawStream is the raw
+    handle without building a torch.cuda.Stream object (~0.3 us instead of ~6 us: a replayed posterior call is ~70 us)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
     return torch.cuda.current_stream().cuda_stream
