@@ -37,5 +37,6 @@ if 'SQ_INSTS_VALU' in vals and 'GRBM_GUI_ACTIVE' in vals and vals['GRBM_GUI_ACTI
 if 'SQ_ACTIVE_INST_VALU' in vals and vals.get('SQ_WAVE_CYCLES'):
     doc['valu_active_over_wave_cycles'] = round(vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_WAVE_CYCLES'], 4)
 json.dump(doc, open('$OUT/${TAG}_r05_is_fused_valu.json', 'w'), indent=1)
+json.dump(doc, open('profiles/r05_is_fused_valu.json', 'w'), indent=1)
 print(json.dumps(doc))
 P
