@@ -413,11 +413,13 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         # HBM - the memory figure rides along for the record
         vprof, vnote = committed_profile('r05_is_fused_valu.json')
         rec['particle_kernels'] = dict(
-            bound='valu', unit='VALU issue fraction', peak=1.0,
-            achieved=(vprof or {}).get('valu_issue_fraction'), frac=(vprof or {}).get('valu_issue_fraction'),
+            bound='valu', unit='share of the VALU pipes\' time busy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles of the launch at 2.4 GHz)', peak=1.0,
+            achieved=(vprof or {}).get('valu_busy_fraction'), frac=(vprof or {}).get('valu_busy_fraction'),
+            valu_issue_fraction=(vprof or {}).get('valu_issue_fraction'),
             valu_active_over_wave_cycles=(vprof or {}).get('valu_active_over_wave_cycles'),
+            wait_any_over_wave_cycles=(vprof or {}).get('wait_any_over_wave_cycles'),
             counters=(vprof or {}).get('counters'), counters_source=vnote,
-            frac_note=(vprof or {}).get('valu_issue_fraction_note'),
+            frac_note=(vprof or {}).get('valu_busy_fraction_note'),
             hbm_gbs=round(nbytes / (per_call_us * 1e-6) / 1e9, 2), hbm_frac=round(nbytes / (per_call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
             us_per_call=round(per_call_us, 3), launches_per_call=round(cnt.value / calls, 2), bytes_per_call=nbytes,
             kernel='is_fused_kernel (draw from the shared proposal + log q + prior / likelihood terms + float64 statistics '
@@ -822,7 +824,7 @@ def main():
         if world == 1 and not args.no_is:
             # the other half of BASELINE.json's metric in the same line: particles/s of posterior_results through the API
             # (configs[3] on one GPU; `--workload is` is the full record incl. the control-flow program)
-            out['is'] = api_posterior_bench(lib, device, args.lstm_dim, 1000000, 20, 3, 'gum')[0]
+            out['is'] = api_posterior_bench(lib, device, args.lstm_dim, 1000000, 100, 6, 'gum')[0]      # (100 calls: ~7 ms timed)
             # ... and a program with stochastic control flow in lock step (BASELINE.json configs[2]'s model): statements after
             # the first one run per particle - the N-row statement kernel, with its own MFMA roofline
             out['gumm_lockstep'] = api_posterior_bench(lib, device, args.lstm_dim, 200000, 5, 2, 'gumm', prof_class=5)[0]

@@ -132,6 +132,9 @@ class ISRunner:
         """ONE pass over the particles: [draw from the shared proposal of `addr_id` (None: values are given), - log q,]
         lw (+)= sum of `terms`, [importance statistics]. terms = [((kind, p0, s0, p1, s1), x, scale, flags)], flags bit
         0 / 1 / 2: p0 / p1 / x is the particle's value. Returns the statistics dict when asked for."""
+        if stats and self.dev.type == 'cuda' and value.is_contiguous() and lw.is_contiguous() and value.dtype == torch.float32 \
+                and lw.dtype == torch.float32 and lw.numel() == value.numel():
+            return self._fused_stats_direct(addr_id, prior, terms, value, lw, overwrite, seed)
         kinds, p0s, s0s, p1s, s1s, xs, scales, flags = [], [], [], [], [], [], [], []
         for (kind, p0, s0, p1, s1), x, scale, fl in terms:
             kinds.append(int(kind)); p0s.append(p0); s0s.append(int(s0)); p1s.append(p1); s1s.append(int(s1))
@@ -140,6 +143,45 @@ class ISRunner:
                            None if prior is None else prior.reshape(-1), kinds, p0s, s0s, p1s, s1s, xs, scales, flags, value, lw,
                            bool(overwrite), int(seed), self.offset, self._stats_scratch if stats else None)
         return self._stats_dict(out) if stats else None
+
+    def _fused_stats_direct(self, addr_id, prior, terms, value, lw, overwrite, seed):
+        """`fused(..., stats=True)` straight through the C ABI with the statistics record in PINNED host memory (the count is
+        stored last behind a system-scope fence and polled here): no operator dispatch, no device-to-host copy with its
+        synchronisation - the last flush of every lock-step posterior call ends in this."""
+        n = value.numel()
+        count = len(terms)
+        arr = (L.pp_lw_term * max(count, 1))()
+        fl = (C.c_int32 * max(count, 1))()
+        for q, ((kind, p0, s0, p1, s1), x, scale, flags) in enumerate(terms):
+            for t, what in ((p0, 'p0'), (p1, 'p1'), (x, 'x')):
+                # (a term tensor is one shared value or one value per particle; Categorical: one probability row or n rows)
+                if t is not None and int(kind) != 5 and t.numel() not in (1, n):
+                    raise RuntimeError('is_fused: term %d: %s has %d elements (1 or n = %d)' % (q, what, t.numel(), n))
+                if t is not None and (t.device != value.device or t.dtype != torch.float32):
+                    raise RuntimeError('is_fused: term %d: %s must be a float32 tensor on %s' % (q, what, value.device))
+            arr[q].kind = int(kind)
+            arr[q].p0, arr[q].p1, arr[q].x = L.ptr(p0), L.ptr(p1), L.ptr(x)
+            arr[q].p0_stride, arr[q].p1_stride = int(s0), int(s1)
+            arr[q].x_stride = 0 if (x is None or x.numel() == 1) else 1
+            arr[q].scale = float(scale)
+            fl[q] = int(flags)
+        self._pins(1)
+        snp = self._stats_np
+        snp[5] = -1.0
+        pr = None if prior is None else prior.reshape(-1)
+        st = self._st if self._st is not None else L.stream_ptr()
+        L.check(self.lib.pp_is_fused(C.byref(self.eng.net), -1 if addr_id is None else int(addr_id), n, L.ptr(pr), arr, fl, count,
+                                     value.data_ptr(), lw.data_ptr(), 1 if overwrite else 0, int(seed), int(self.offset),
+                                     self._stats_pin.data_ptr(), self._stats_scratch.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                     st), 'pp_is_fused')
+        spins = 0
+        while snp[5] < 0.0:
+            spins += 1
+            if spins > 2000000:
+                torch.cuda.synchronize(self.dev)
+                if snp[5] < 0.0:
+                    raise L.HipLibraryError('pp_is_fused: the statistics never arrived in host memory')
+        return self._stats_dict(snp)
 
     def run_plan(self, plan, obs_values, n, offset, seed):
         """Replay of a recorded single-statement posterior call (Model._replay_lockstep_plan) straight through the C ABI, with no

@@ -27,15 +27,24 @@ for n in (1, 2):
 doc = dict(csrc_sha=csrc_sha(), particles=1000000, avg_duration_us_profiled=None if dur is None else round(dur / 1e3, 2), counters=vals,
            source='rocprofv3 --kernel-trace --pmc (two passes, tools/pmc_is_fused.sh $TAG) of python tools/is_call_profile.py 1000000 40; '
                   'per-kernel averages in ${TAG}_is_fused_pmc_1.csv, ${TAG}_is_fused_pmc_2.csv')
-if 'SQ_INSTS_VALU' in vals and 'GRBM_GUI_ACTIVE' in vals and vals['GRBM_GUI_ACTIVE'] > 0:
-    # VALU issue slots: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (transcendentals 8); 256 CUs x 4 SIMDs
-    cyc = vals['GRBM_GUI_ACTIVE']
-    doc['valu_issue_fraction'] = round(vals['SQ_INSTS_VALU'] * 2.0 / (cyc * 1024.0), 4)
-    doc['valu_issue_fraction_note'] = ('SQ_INSTS_VALU x 2 issue cycles / (GRBM_GUI_ACTIVE cycles x 1024 SIMDs): a LOWER bound of the VALU '
-                                       'pipe occupancy (transcendental and fp64 instructions take 4x / longer); SQ_ACTIVE_INST_VALU / '
-                                       'SQ_WAVE_CYCLES = the share of wave time with a VALU instruction in flight')
+# SIMD cycles of the launch: its average duration x the 2.4 GHz maximum clock x 256 CUs x 4 SIMDs - the clock under the
+# profiler is lower (MI355X guide: 1.9-2.0 GHz), so both fractions are LOWER bounds. (GRBM_GUI_ACTIVE is collected but not used: it
+# reads ~12x the launch's own cycles here - summed over XCDs / shader engines.)
+if dur and 'SQ_INSTS_VALU' in vals:
+    simd_cycles = dur * 1e-9 * 2.4e9 * 1024.0
+    doc['simd_cycles_at_max_clock'] = round(simd_cycles)
+    doc['valu_issue_fraction'] = round(vals['SQ_INSTS_VALU'] * 2.0 / simd_cycles, 4)
+    doc['valu_issue_fraction_note'] = ('SQ_INSTS_VALU x 2 issue cycles (a wave64 instruction on a SIMD-32; transcendentals take 8) / SIMD '
+                                       'cycles of the launch at the 2.4 GHz maximum clock: a lower bound')
+    if 'SQ_ACTIVE_INST_VALU' in vals:
+        doc['valu_busy_fraction'] = round(vals['SQ_ACTIVE_INST_VALU'] * 4.0 / simd_cycles, 4)
+        doc['valu_busy_fraction_note'] = ('SQ_ACTIVE_INST_VALU (quad-cycles a VALU instruction is executing, summed over the waves) x 4 / '
+                                          'SIMD cycles of the launch: the share of the VALU pipes\' time that is busy - the roofline '
+                                          'fraction of this VALU-bound kernel')
 if 'SQ_ACTIVE_INST_VALU' in vals and vals.get('SQ_WAVE_CYCLES'):
     doc['valu_active_over_wave_cycles'] = round(vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_WAVE_CYCLES'], 4)
+if vals.get('SQ_WAIT_ANY') and vals.get('SQ_WAVE_CYCLES'):
+    doc['wait_any_over_wave_cycles'] = round(vals['SQ_WAIT_ANY'] / vals['SQ_WAVE_CYCLES'], 4)
 json.dump(doc, open('$OUT/${TAG}_r05_is_fused_valu.json', 'w'), indent=1)
 json.dump(doc, open('profiles/r05_is_fused_valu.json', 'w'), indent=1)
 print(json.dumps(doc))
