@@ -778,12 +778,24 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     if (head_done) {
         if (net_only) return 0;
     } else {
-    if (!ff)
+    // H = 1024, one layer: the LSTM step as ONE launch (is_step_fused.hip is_lstm_wide: gates on the accumulators, cell in place;
+    // no gathered input rows, no gate matrix in memory), then the head GEMMs below. Launches of a few thousand particles keep the
+    // GEMM chain (a workgroup of the wide launch streams 8.4 MB of weights for its 32 particles whatever n).
+    const int fmode = is_step_fused_mode();
+    const bool wide = !ff && !shared && is_lstm_wide_supported(net) && (fmode >= 2 || (fmode == 1 && n > SPLIT_MAX_ROWS)) &&
+                      (int64_t)n * H < (int64_t(1) << 32);
+    if (!ff && !wide)
         PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
                                  w.i4, st));
     const float* top = h;    // hidden rows the proposal layer reads
     if (ff) {
         top = e_obs_vec;
+    } else if (wide) {
+        // the new hidden rows pass through the chain's gate buffer (other workgroups still read the old rows); with the shared
+        // state of the second statement nobody does
+        float* hn = state_rows == 1 ? h : w.G;
+        PP_TRY(is_lstm_wide(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, h, c, state_rows, w.fz, w.c0, hn, st));
+        if (hn != h) (void)hipMemcpyAsync(h, hn, (size_t)n * H * sizeof(float), hipMemcpyDeviceToDevice, st);
     } else {
         // nn.LSTM(I, H, depth): layer k reads the new hidden rows of layer k - 1; (h, c) hold [depth, n, H]
         const int L = std::max(1, (int)net->lstm_depth);

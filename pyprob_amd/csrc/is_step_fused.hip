@@ -81,6 +81,7 @@ struct PrepArgs {
     const int64_t* at;
     int64_t w_ih, w_hh, b_ih, b_hh, w1, w2;
     int H, I, ub, nsh;              // nsh = H / 8 slabs of W_hh (slab nsh = the sample-embedding columns of W_ih)
+    int hu, halves;                 // hidden units per gate image (H; the wide LSTM launch: H / halves, one image per part)
     GatherDims d;
     int addr_id, prev_addr;
     const float* e_obs_vec;
@@ -95,7 +96,7 @@ struct PrepArgs {
 // blocks [0, img_blocks): the fragment images (one 16-byte piece = four k of one column per thread);
 // blocks [img_blocks, ...): the bias row, one wave per gate column.
 __global__ __launch_bounds__(256) void is_prep_kernel(const PrepArgs a) {
-    __shared__ float sx[1024 + 512];
+    __shared__ float sx[1024 + 1024];
     const int tid = threadIdx.x;
     const int H = a.H;
     if ((int)blockIdx.x < a.img_blocks) {
@@ -107,9 +108,10 @@ __global__ __launch_bounds__(256) void is_prep_kernel(const PrepArgs a) {
                 const int lane = (int)(q & 63);
                 const int64_t t = q >> 6;
                 const int nb = 4 * a.ub;
-                const int blk = (int)(t % nb), w = (int)((t / nb) % FW), s = (int)(t / (nb * FW));
+                const int blk = (int)(t % nb), w = (int)((t / nb) % FW);
+                const int sp = (int)(t / (nb * FW)), part = sp / (a.nsh + 1), s = sp - part * (a.nsh + 1);
                 const int g = blk / a.ub, ub = blk - g * a.ub;
-                const int col = g * H + (w * a.ub + ub) * 32 + (lane & 31);
+                const int col = g * H + part * a.hu + (w * a.ub + ub) * 32 + (lane & 31);
                 const int k0 = 4 * (lane >> 5);
                 if (s < a.nsh) {
                     v = *reinterpret_cast<const f32x4*>(a.P + a.w_hh + (int64_t)col * H + 8 * s + k0);
@@ -204,6 +206,9 @@ struct FusedArgs {
     // split statement (small launches): the new hidden rows [n][H] written by is_small_lstm_kernel - the HEADONLY instantiation
     // starts from them instead of running the K loop and the cell
     const float* hn;
+    // wide LSTM launch (KM > 1): the new hidden rows go to hout [n][H K-extent] (compact); panels = workgroups per part
+    float* hout;
+    int panels;
 };
 
 extern __shared__ __attribute__((aligned(1024))) float fused_lds[];
@@ -214,22 +219,32 @@ extern __shared__ __attribute__((aligned(1024))) float fused_lds[];
 // shuffled all of them and spilled 32 (8 KB of scratch traffic per particle in the PMC passes of the first version)
 // HEADONLY: the second launch of a SPLIT statement (see is_small_lstm_kernel below): the panel's new hidden rows come from a.hn,
 // are stored to the state rows and laid out in LDS; everything from head layer 1 on is the same code.
-template <int UB, int KIND, bool SHARED, bool HEADONLY = false>
+// KM > 1: the WIDE LSTM launch (LSTM of 256 UB KM hidden units: H = 1024 as UB = 2, KM = 2). The gate row of 32 particles no
+// longer fits a CU's accumulators, so a workgroup owns 32 particles x ONE PART of the hidden units (256 UB of them, all four
+// gates): the same K loop over the whole previous state (K extent HK = 256 UB KM), one gate image per part, the cell on the
+// accumulators; workgroups [part * panels, (part + 1) * panels) take part `part`. c is updated in place (a part reads and writes
+// only its own units); the new h goes to a.hout ([n][HK], compact) because the other parts still read the old rows; the kernel
+// ends after the cell (the head layers and the draw run as the chain's launches, is_kernels.hip is_step).
+template <int UB, int KIND, bool SHARED, bool HEADONLY = false, int KM = 1>
 __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
-    constexpr int H = 256 * UB;
+    constexpr int H = 256 * UB;                    // hidden units of this workgroup
+    constexpr int HK = H * KM;                     // hidden units of the LSTM: K extent of the recurrent product, state row pitch
     constexpr int NSH = H / 8;
+    constexpr int NSK = HK / 8;                    // k-slabs of W_hh (slab NSK of an image: the sample-embedding columns of W_ih)
     constexpr int NB = 4 * UB;
     constexpr int SLAB = FW * NB * 256;            // floats of one k-slab of the gate image
     float* sH = fused_lds;                         // [H / 16][2][64][4]: the fresh hidden tile as 16-row A fragments (H * 32 floats)
     float* sA1 = sH + NSH * 256;                   // [ns2][64][4]: head layer 1 activations as A fragments
     float* sY = sA1 + a.ns2 * 256;                 // [32][33] head outputs
-    int* sRow = reinterpret_cast<int*>(sY + FR * 33);   // [32] state row of every particle of the panel
+    int* sRow = reinterpret_cast<int*>(KM > 1 ? fused_lds : sY + FR * 33);   // [32] state row of every particle of the panel
     float* sPart = sH;                             // [8][32][32] K-split partials of head layer 2 (the tile is dead by then)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c31 = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * FR;
+    const int part = KM > 1 ? (int)blockIdx.x / a.panels : 0;
+    const int u0 = part * H;                       // first hidden unit of this workgroup
+    const int m0 = ((int)blockIdx.x - part * (KM > 1 ? a.panels : 0)) * FR;
     const int dbg_slot = a.dbg ? (blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1)) : -1;
 #define FUSED_STAMP(k)                                                                          \
     do {                                                                                        \
@@ -254,14 +269,14 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     } else {
     const int gr = min(m0 + c31, a.n - 1);              // this lane's particle (A operand row)
     const int64_t ridx = a.rows ? a.rows[gr] : (int64_t)gr;
-    const float* arow = a.h + ridx * H + 4 * hh;
-    const float* bimg = a.whh_img + (size_t)wave * (NB * 256) + lane * 4;
+    const float* arow = a.h + ridx * HK + 4 * hh;
+    const float* bimg = a.whh_img + (size_t)part * ((size_t)(NSK + 1) * SLAB) + (size_t)wave * (NB * 256) + lane * 4;
 
     f32x16 acc[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
         const int g = blk / UB, ub = blk % UB;
-        const float b = a.bias[g * H + (wave * UB + ub) * 32 + c31];
+        const float b = a.bias[g * HK + u0 + (wave * UB + ub) * 32 + c31];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[blk][r] = b;
     }
@@ -278,13 +293,13 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         if (REFILL) BUF[blk] = load_blk(SN, blk);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
-    constexpr int NS = SHARED ? 0 : NSH;   // shared state: h W_hh^T is one row for everybody, part of the bias
+    constexpr int NS = SHARED ? 0 : NSK;   // shared state: h W_hh^T is one row for everybody, part of the bias
     f32x4 b0[NB], b1[NB], a0, a1, a2, a3;
     // item 0 of the stream: the sample embedding of the previous value, k = 4 hh + j < smp_dim (embedding_feedforward.py: one
     // Linear + ReLU; gather.hpp sample_embed_elem: a Linear(1, smp_dim) of the value, or a row of the one-hot
     // Linear(C, smp_dim)); its weights are slab NSH of the image. Items 1 .. NS: the slabs 0 .. NS - 1 of h W_hh^T.
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk) b0[blk] = load_blk(NSH, blk);
+    for (int blk = 0; blk < NB; ++blk) b0[blk] = load_blk(NSK, blk);
     {
         const float pv = a.prev_value[a.prev_indexed ? ridx : (int64_t)gr];
         int cat = (int)pv;
@@ -357,17 +372,17 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
         for (int q = 0; q < 8; ++q) {
             const int r = 8 * half + q;
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            off[q] = (uint32_t)sRow[row] * (uint32_t)H;
+            off[q] = (uint32_t)sRow[row] * (uint32_t)HK;
         }
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) {
-            const uint32_t u = (uint32_t)((wave * UB + ub) * 32 + c31);
+            const uint32_t u = (uint32_t)(u0 + (wave * UB + ub) * 32 + c31);
 #pragma unroll
             for (int q = 0; q < 8; ++q) cp[ub][q] = cprev[SHARED ? u : off[q] + u];
         }
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) {
-            const int u = (wave * UB + ub) * 32 + c31;
+            const int u = u0 + (wave * UB + ub) * 32 + c31;
             // A fragments of v_mfma_f32_16x16x4_f32 for head layer 1: [16-k slab u / 16][row block][k group (u / 4) % 4][row % 16][u % 4]
             const int hslot = ((u >> 4) * 128 + ((u >> 2) & 3) * 16) * 4 + (u & 3);
 #pragma unroll
@@ -376,16 +391,24 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 const float cn = acc[1 * UB + ub][r] * cp[ub][q] + acc[0 * UB + ub][r];
                 const float hn = acc[3 * UB + ub][r] * fast_tanh(cn);
-                if (m0 + row < a.n) {
-                    a.c[off[q] + (uint32_t)u] = cn;
-                    a.h[off[q] + (uint32_t)u] = hn;
+                if constexpr (KM > 1) {
+                    if (m0 + row < a.n) {
+                        a.c[off[q] + (uint32_t)u] = cn;
+                        a.hout[(uint32_t)(m0 + row) * (uint32_t)HK + (uint32_t)u] = hn;
+                    }
+                } else {
+                    if (m0 + row < a.n) {
+                        a.c[off[q] + (uint32_t)u] = cn;
+                        a.h[off[q] + (uint32_t)u] = hn;
+                    }
+                    sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hn;
                 }
-                sH[hslot + (row >> 4) * 256 + (row & 15) * 4] = hn;
             }
         }
     }
     }
     FUSED_STAMP(3);    // cell done
+    if constexpr (KM > 1) return;
     __syncthreads();
     FUSED_STAMP(4);
 
@@ -740,8 +763,19 @@ bool is_step_fused_supported(const pp_net* net, int addr_id) {
     return lds <= 150 * 1024;
 }
 
+bool is_lstm_wide_supported(const pp_net* net) {
+    if (!net || net->lstm_dim != 1024 || std::max(1, (int)net->lstm_depth) != 1) return false;
+    return net->smp_dim >= 1 && net->smp_dim <= 8 && net->lstm_in <= 1024 && net->addr_table;
+}
+
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {
     f = IsFusedBuffers{};
+    if (is_lstm_wide_supported(net)) {      // two gate images of 512 hidden units each, K extent 1024; no head images
+        const int H = net->lstm_dim;
+        f.n_whh = (int64_t)2 * (H / 8 + 1) * FW * 8 * 256;
+        f.n_bias = 4 * H;
+        return;
+    }
     if (!net || (net->lstm_dim != 256 && net->lstm_dim != 512)) return;
     const int H = net->lstm_dim, ub = H / 256, nsh = H / 8;
     int64_t hid = 1;
@@ -763,7 +797,7 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     PrepArgs p{};
     p.P = P; p.at = net->addr_table;
     p.w_ih = net->w_ih; p.w_hh = net->w_hh; p.b_ih = net->b_ih; p.b_hh = net->b_hh; p.w1 = ad.w1; p.w2 = ad.w2;
-    p.H = H; p.I = net->lstm_in; p.ub = ub; p.nsh = nsh;
+    p.H = H; p.I = net->lstm_in; p.ub = ub; p.nsh = nsh; p.hu = H; p.halves = 1;
     p.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
     p.addr_id = addr_id; p.prev_addr = prev_addr_id;
     p.e_obs_vec = e_obs_vec;
@@ -830,6 +864,46 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     if (rc) return rc;
     PP_LAUNCH_CHECK("pp_is_step(fused statement)");
     *sampled = kind != 3;   // false: the head outputs are in y_out, the caller's sampling kernel follows
+    return 0;
+}
+
+// The LSTM step of a statement on the H = 1024 network (one layer): is_step_fused_kernel<2, 3, SHARED, false, 2>, 2 cdiv(n, 32)
+// workgroups. c in place, the new hidden rows to hn [n][H] (state_rows == 1: hn may be h itself - the old state is one row, read by
+// the prepare launch only).
+int is_lstm_wide(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
+                 const float* prev_value, float* h, float* c, int state_rows, const IsFusedBuffers& f, float* c0_copy, float* hn,
+                 hipStream_t st) {
+    const int H = net->lstm_dim, hu = 512, ub = hu / 256, nsh = H / 8;
+    const bool shared = state_rows == 1;
+    PrepArgs p{};
+    p.P = P; p.at = net->addr_table;
+    p.w_ih = net->w_ih; p.w_hh = net->w_hh; p.b_ih = net->b_ih; p.b_hh = net->b_hh;
+    p.H = H; p.I = net->lstm_in; p.ub = ub; p.nsh = nsh; p.hu = hu; p.halves = H / hu;
+    p.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
+    p.addr_id = addr_id; p.prev_addr = prev_addr_id;
+    p.e_obs_vec = e_obs_vec;
+    p.h0 = shared ? h : nullptr;
+    p.c0 = shared ? c : nullptr;
+    p.whh_img = f.whh; p.bias = f.bias; p.c0_copy = c0_copy;
+    p.q_whh = (int64_t)p.halves * (nsh + 1) * FW * 4 * ub * 64;
+    p.img_blocks = (int)std::min<int64_t>(2048, (p.q_whh + 255) / 256);
+    hipLaunchKernelGGL(is_prep_kernel, dim3(p.img_blocks + H), dim3(256), 0, st, p);
+    PP_LAUNCH_CHECK("pp_is_step(prepare, wide LSTM)");
+
+    FusedArgs a{};
+    a.whh_img = f.whh; a.bias = f.bias;
+    a.h = h; a.c = c; a.c0 = c0_copy; a.state_shared = shared ? 1 : 0;
+    const pp_addr& pad = net->addrs[prev_addr_id];
+    a.prev_value = prev_value; a.smp_w = P + pad.smp_w; a.smp_b = P + pad.smp_b; a.smp_in = pad.smp_in; a.smp = net->smp_dim;
+    a.n = n; a.hout = hn; a.panels = cdiv(n, FR);
+    a.dbg = g_timeline;
+    // kernel class 5 of the in-stream timing (work = FLOPs of the reference's algorithm, SURVEY.md 8d: input + recurrent product)
+    const double flops = (double)n * 2.0 * (net->lstm_in + (shared ? 0 : H)) * 4.0 * H;
+    prof_begin(5, st);
+    if (shared) hipLaunchKernelGGL((is_step_fused_kernel<2, 3, true, false, 2>), dim3(2 * a.panels), dim3(512), 256, st, a);
+    else hipLaunchKernelGGL((is_step_fused_kernel<2, 3, false, false, 2>), dim3(2 * a.panels), dim3(512), 256, st, a);
+    prof_end(5, flops, st);
+    PP_LAUNCH_CHECK("pp_is_step(wide LSTM)");
     return 0;
 }
 

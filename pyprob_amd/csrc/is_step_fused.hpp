@@ -33,4 +33,11 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
                   const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
                   const IsStatementOut* whole = nullptr, float* hn_split = nullptr);
 
+// H = 1024 (one layer): the LSTM step of a statement as ONE launch (two workgroups per 32 particles, half of the hidden units
+// each); the head layers and the draw stay with the caller's launches. c is updated in place, the new hidden rows go to hn [n][H]
+bool is_lstm_wide_supported(const pp_net* net);
+int is_lstm_wide(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
+                 const float* prev_value, float* h, float* c, int state_rows, const IsFusedBuffers& f, float* c0_copy, float* hn,
+                 hipStream_t st);
+
 }  // namespace pp

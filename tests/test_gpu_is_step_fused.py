@@ -107,11 +107,17 @@ def _ids(eng, name):
     (512, 300, ('a_normal', 'Normal'), ('a_cat', 'Categorical')),         # head outputs -> the categorical kernel
     (512, 300, ('a_uniform', 'Uniform'), ('a_bern', 'Bernoulli')),
     (256, 777, ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform')),
+    # H = 1024: the LSTM step is the wide launch (two workgroups per 32 particles, half of the hidden units each), the head layers
+    # and the draw are the chain's launches (is_kernels.hip is_step)
+    (1024, 1000, ('a_normal', 'Normal'), ('a_uniform', 'Uniform')),
+    (1024, 33, ('a_uniform', 'Uniform'), ('a_normal', 'Normal')),
+    (1024, 300, ('a_cat', 'Categorical'), ('a_cat', 'Categorical')),
 ])
 def test_fused_statement_against_the_oracle(H, n, prev, cur):
     from pyprob_amd.ops import ops
     eng, run, sd = _engine(H)
-    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == 1
+    # (pp_is_step_fused_supported answers for the row-list / whole-statement entry points: not at H = 1024)
+    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == (1 if H <= 512 else 0)
     rng = np.random.default_rng(5)
     h0 = (0.5 * rng.standard_normal((n, H))).astype(np.float32).clip(-0.99, 0.99)
     c0 = rng.standard_normal((n, H)).astype(np.float32)
@@ -137,7 +143,8 @@ def test_fused_statement_against_the_oracle(H, n, prev, cur):
     # the LSTM cell on v_exp_f32 / v_rcp_f32 sigmoid / tanh: absolute error of (h, c) asserted here
     eh = np.abs(h.cpu().numpy()[0] - href).max()
     ec = np.abs(c.cpu().numpy()[0] - cref).max()
-    assert eh < 4e-6 and ec < 2e-5, (eh, ec)
+    tol = 1.0 if H <= 512 else 2.0      # (K = 1028 terms per gate at H = 1024)
+    assert eh < 4e-6 * tol and ec < 2e-5 * tol, (eh, ec)
     lq = logq.cpu().numpy()
     ok = np.isfinite(lq_ref)
     assert ok.mean() > 0.99
@@ -151,11 +158,12 @@ def test_fused_statement_against_the_oracle(H, n, prev, cur):
     assert torch.equal(v2, value) and torch.equal(lq2, logq) and torch.equal(h2, h) and torch.equal(c2, c)
 
 
-def test_fused_statement_equals_the_unfused_chain(monkeypatch, _force_fused):
+@pytest.mark.parametrize('H', [512, 1024])
+def test_fused_statement_equals_the_unfused_chain(monkeypatch, _force_fused, H):
     """A/B inside one process: PP_IS_STEP_FUSED=0 takes the gather -> GEMM -> GEMM -> cell -> head chain. Same Philox
     counters, so the draws agree to the rounding of the proposal parameters; states agree to fp32 summation order."""
     from pyprob_amd.ops import ops
-    H, n = 512, 2000
+    n = 2000
     eng, run, sd = _engine(H, seed=3)
     rng = np.random.default_rng(9)
     h0 = (0.5 * rng.standard_normal((n, H))).astype(np.float32)
@@ -173,7 +181,8 @@ def test_fused_statement_equals_the_unfused_chain(monkeypatch, _force_fused):
                             torch.from_numpy(pv).to(dev), torch.from_numpy(prior).to(dev), h, c, n, None, 7, 11)
         outs.append((v.cpu().numpy(), lq.cpu().numpy(), h.cpu().numpy(), c.cpu().numpy()))
     (v1, l1, h1, c1), (v0, l0, h0_, c0_) = outs
-    assert np.abs(h1 - h0_).max() < 5e-6 and np.abs(c1 - c0_).max() < 2e-5
+    tol = 1.0 if H <= 512 else 2.0
+    assert np.abs(h1 - h0_).max() < 5e-6 * tol and np.abs(c1 - c0_).max() < 2e-5 * tol
     rel = np.abs(v1 - v0) / np.maximum(1e-3, np.abs(v0))
     assert np.median(rel) < 1e-5 and np.quantile(rel, 0.99) < 1e-3
     close = rel < 1e-5
@@ -214,11 +223,12 @@ def test_row_index_list_updates_the_state_in_place():
     np.testing.assert_allclose(lq.cpu().numpy(), lq_ref, rtol=1e-4, atol=1e-4)
 
 
-def test_second_statement_with_the_shared_first_state():
+@pytest.mark.parametrize('H', [512, 1024])
+def test_second_statement_with_the_shared_first_state(H):
     """state_rows = 1: row 0 holds the state every particle left the first statement with; its recurrent product joins the
     bias row, the cell reads the one shared previous cell state, all n rows are written."""
     from pyprob_amd.ops import ops
-    H, n = 512, 3001
+    n = 3001
     eng, run, sd = _engine(H, seed=6)
     rng = np.random.default_rng(3)
     h_row = (0.5 * rng.standard_normal((1, H))).astype(np.float32)
@@ -236,7 +246,8 @@ def test_second_statement_with_the_shared_first_state():
     href, cref, lq_ref, _ = _oracle_statement(sd, H, [8.0, 9.0], ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform'), pv,
                                               np.repeat(h_row, n, 0), np.repeat(c_row, n, 0), v.cpu().numpy().astype(np.float64),
                                               prior.astype(np.float64))
-    assert np.abs(h.cpu().numpy()[0] - href).max() < 4e-6 and np.abs(c.cpu().numpy()[0] - cref).max() < 2e-5
+    tol = 1.0 if H <= 512 else 2.0
+    assert np.abs(h.cpu().numpy()[0] - href).max() < 4e-6 * tol and np.abs(c.cpu().numpy()[0] - cref).max() < 2e-5 * tol
     np.testing.assert_allclose(lq.cpu().numpy(), lq_ref, rtol=1e-4, atol=1e-4)
 
 
