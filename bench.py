@@ -789,7 +789,7 @@ def main():
                 # 32 B x all padded parameters.) 46 MB of flat buffers sit inside the 256 MB Infinity Cache: this is a
                 # cache-resident rate, not an HBM one.
                 seen = eng.arrived.view(-1, L.PP_ADAM_SCRATCH)[:, L.PP_ADAM_SEEN].cpu().numpy() != 0
-                act = eng.active.cpu().numpy() > 0
+                act = eng.presence().cpu().numpy() > 0
                 ct = eng.spec.chunk_tensor_map()
                 per_tensor = np.bincount(ct, minlength=eng.spec.n_tensors).astype(np.float64) * 1024
                 adam_bytes = float((per_tensor * (act & seen)).sum() * 32 + (per_tensor * (act & ~seen)).sum() * 4)

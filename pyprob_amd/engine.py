@@ -165,8 +165,20 @@ class ICEngine:
         if act is None:
             act = torch.from_numpy(self.spec.active_mask(batch.cur_counts, batch.prev_counts)).to(self.device)
             self._active_cache[key] = act
-        self.active.copy_(act)
+        if self.world_size == 1 and not self.force_allreduce:
+            # the optimizer reads the cached map where it lies: no copy launch between the backward pass and the optimizer (a
+            # ragged minibatch changes the map almost every step: 4 us of copy + 12 us of idle gaps around it)
+            self._presence = act
+        else:
+            self.active.copy_(act)      # data parallel: the map travels in the tail of the reduced buffer
+            self._presence = self.active
         self._active_key = key
+
+    def presence(self):
+        """The presence map the optimizer reads ([n_tensors] floats, > 0: the tensor had a gradient this step): the cached map of
+        the last `loss(backward=True)`, or the tail of the gradient buffer when somebody else wrote it (`_active_key` None: the
+        binding's optimizers, data parallel)."""
+        return self._presence if self._active_key is not None else self.active
 
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, zero_grads=False, skip=None, grad_scale=None):
         """optimizer.step() for optim.Adam (inference_network.py:348,496); grads are divided by world_size first
@@ -176,13 +188,13 @@ class ICEngine:
         gs = 1.0 / self.world_size if grad_scale is None else grad_scale
         if getattr(self, '_use_ops', False):
             from .ops import ops
-            ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.chunk_tensor, self.active,
+            ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.chunk_tensor, self.presence(),
                           self.tensor_step, self.arrived, lr, beta1, beta2, eps, weight_decay, gs,
                           L.PP_ADAM_ZERO_GRADS if zero_grads else 0, skip)
         else:
             rc = self.lib.pp_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.spec.n_params, self.chunk_tensor.data_ptr(),
-                                       self.active.data_ptr(), self.tensor_step.data_ptr(), self.arrived.data_ptr(),
+                                       self.presence().data_ptr(), self.tensor_step.data_ptr(), self.arrived.data_ptr(),
                                        self.spec.n_tensors, lr, beta1, beta2, eps, weight_decay, gs,
                                        L.PP_ADAM_ZERO_GRADS if zero_grads else 0, L.ptr(skip), L.stream_ptr())
             L.check(rc, 'pp_adam_step')
@@ -205,11 +217,11 @@ class ICEngine:
         flags = L.PP_ADAM_ZERO_GRADS if zero_grads else 0
         if getattr(self, '_use_ops', False):
             from .ops import ops
-            ops.sgd_step(self.params, self.grads, self.exp_avg, self.chunk_tensor, self.active, float(lr), float(momentum),
+            ops.sgd_step(self.params, self.grads, self.exp_avg, self.chunk_tensor, self.presence(), float(lr), float(momentum),
                          bool(nesterov), float(weight_decay), float(gs), flags, skip)
         else:
             rc = self.lib.pp_sgd_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.spec.n_params,
-                                      self.chunk_tensor.data_ptr(), self.active.data_ptr(), self.spec.n_tensors, lr, momentum,
+                                      self.chunk_tensor.data_ptr(), self.presence().data_ptr(), self.spec.n_tensors, lr, momentum,
                                       int(bool(nesterov)), weight_decay, gs, flags, L.ptr(skip), L.stream_ptr())
             L.check(rc, 'pp_sgd_step')
         self._grads_clean = bool(zero_grads)
@@ -223,12 +235,12 @@ class ICEngine:
             self._larc_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
         if getattr(self, '_use_ops', False):
             from .ops import ops
-            ops.larc_scale(self.params, self.grads, self.chunk_tensor, self.active, float(lr), float(weight_decay),
+            ops.larc_scale(self.params, self.grads, self.chunk_tensor, self.presence(), float(lr), float(weight_decay),
                            1.0 / self.world_size, float(trust_coefficient), float(eps), float(epsilon), bool(clip),
                            self._larc_scratch, skip)
         else:
             rc = self.lib.pp_larc_scale(self.params.data_ptr(), self.grads.data_ptr(), self.spec.n_params,
-                                        self.chunk_tensor.data_ptr(), self.active.data_ptr(), self.spec.n_tensors, lr, weight_decay,
+                                        self.chunk_tensor.data_ptr(), self.presence().data_ptr(), self.spec.n_tensors, lr, weight_decay,
                                         1.0 / self.world_size, trust_coefficient, eps, epsilon, int(bool(clip)),
                                         self._larc_scratch.data_ptr(), L.ptr(skip), L.stream_ptr())
             L.check(rc, 'pp_larc_scale')

@@ -55,7 +55,7 @@ def test_golden_loss_logprob_and_gradients(golden):
             assert np.all(g[n] == 0), n
     assert worst[1] < 1e-3, worst
     # presence map = which tensors had grad != None in the reference
-    act = eng.active.cpu().numpy()
+    act = eng.presence().cpu().numpy()
     names = list(eng.spec.tensors.keys())
     ref_has = dict(zip(meta['param_names'], meta['has_grad']))
     assert [bool(a) for a in act] == [bool(ref_has[n]) for n in names]

@@ -24,12 +24,12 @@ EMB = {'obs0': {'dim': 32}, 'obs1': {'dim': 32}}
 SIGMA = math.sqrt(2)
 
 
-def _train(model, num_traces, seed):
+def _train(model, num_traces, seed, lstm_dim=512):
     torch.manual_seed(seed)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model.learn_inference_network(inference_network=InferenceNetwork.LSTM, num_traces=num_traces, observe_embeddings=EMB,
-                                      batch_size=256, lstm_dim=512, seed=seed)
+                                      batch_size=256, lstm_dim=lstm_dim, seed=seed)
     return model
 
 
@@ -48,9 +48,14 @@ def gumm_trained():
     return _train(GaussianWithUnknownMeanMarsagliaLockStep(), 30000, 3)
 
 
-def _oracle_net(model):
+@pytest.fixture(scope='module')
+def gumm_trained_h1024():
+    return _train(GaussianWithUnknownMeanMarsagliaLockStep(), 30000, 4, lstm_dim=1024)
+
+
+def _oracle_net(model, lstm_dim=512):
     eng = model._inference_network._engine
-    assert eng.spec.lstm_dim == 512
+    assert eng.spec.lstm_dim == lstm_dim
     params = {k: v.numpy() for k, v in eng.state_dict().items()}
     return O.Net(params, ['obs0', 'obs1'], K=eng.spec.K), [a.address for a in eng.spec.addresses]
 
@@ -126,6 +131,32 @@ def test_gumm_posterior_every_particle_rescored(gumm_trained, n, monkeypatch):
     steps, results = _gumm_steps(post, addresses, n)
     assert len(steps) >= 4
     _, lw_ref = O.is_rescore_lockstep(net, [8.0, 9.0], steps, n, chunk=1 << 17)
+    lw_ref = lw_ref + _likelihood(results)
+    lw = post._all_log_weights.cpu().numpy().astype(np.float64)
+    v = post._all_values.cpu().numpy().astype(np.float64)
+    ok = np.isfinite(lw_ref)
+    assert ok.mean() > 0.999
+    np.testing.assert_allclose(v[ok], results[ok], rtol=1e-4, atol=1e-4)
+    err = np.abs(lw[ok] - lw_ref[ok]) / np.maximum(1.0, np.abs(lw_ref[ok]))
+    assert err.max() < 1e-4, (err.max(), int(err.argmax()))
+
+
+def test_gumm_posterior_h1024_every_particle_rescored(gumm_trained_h1024, monkeypatch):
+    """The same program on the H = 1024 network (BASELINE.json configs[4]'s per-rank network): the N-row statements of more than
+    4 096 particles run the wide LSTM launch (csrc/is_step_fused.hip is_lstm_wide: two workgroups per 32 particles, half of the
+    hidden units each) + the head GEMMs, the smaller ones the GEMM chain; diverged paths gather / scatter their state rows
+    (ISRunner.step_rows). Every particle re-scored by the float64 oracle."""
+    for k in ('PP_IS_NEST', 'PP_IS_ROWS', 'PP_IS_STEP_FUSED', 'PP_IS_MEMO', 'PP_IS_PLAN', 'PP_IS_FUSED'):
+        monkeypatch.delenv(k, raising=False)
+    model, n = gumm_trained_h1024, 65537
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model.posterior_results(n, IC, observe=OBS, lock_step=True, seed=29)
+    assert post.num_paths > 3
+    net, addresses = _oracle_net(model, 1024)
+    steps, results = _gumm_steps(post, addresses, n)
+    assert len(steps) >= 4
+    _, lw_ref = O.is_rescore_lockstep(net, [8.0, 9.0], steps, n, chunk=1 << 15)
     lw_ref = lw_ref + _likelihood(results)
     lw = post._all_log_weights.cpu().numpy().astype(np.float64)
     v = post._all_values.cpu().numpy().astype(np.float64)
