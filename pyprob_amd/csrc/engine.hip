@@ -945,28 +945,10 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
             }
         }
         if (!compact) {
-            if (ff) {   // (LSTM: the first cell launch of the backward pass finalises the loss)
+            if (ff)   // (LSTM: the first cell launch of the backward pass finalises the loss)
                 PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st, fin_acc, w.flag, B, loss_out, status_out));
-                return flush_wgrads(st, true);
-            }
-            // Ragged LSTM batch: the column sums (bias gradients of every address's layers, of the embeddings) read what the
-            // weight-gradient leaves read and write other tensors - up to AUX_MAX_COLSUM of them ride behind the tiles of the
-            // grouped launch (their own launch was 13 us of the step), the rest keep a launch of their own
-            static const int lstm_ride = env_flag("PP_AUX_COLSUM", 1);
-            if (lstm_ride && !det && !wq.empty()) {
-                AuxJobs aux{};
-                std::vector<ColsumJob> rest;
-                for (const auto& j : cs) {
-                    if (j.n_rows <= 0 || j.n_cols <= 0) continue;
-                    if (aux.n_colsum < AUX_MAX_COLSUM) aux.cs[aux.n_colsum++] = j;
-                    else rest.push_back(j);
-                }
-                if (!rest.empty()) PP_TRY(colsum_multi(rest.data(), (int)rest.size(), st));
-                if (aux.n_colsum == 0) return flush_wgrads(st, true);
-                aux_layout(aux, false);
-                return flush_wgrads(st, true, &aux);
-            }
-            PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
+            else
+                PP_TRY(colsum_multi(cs.data(), (int)cs.size(), st));
             return flush_wgrads(st, true);
         }
         AuxJobs aux{};
