@@ -779,10 +779,13 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
         if (net_only) return 0;
     } else {
     // H = 1024, one layer: the LSTM step as ONE launch (is_step_fused.hip is_lstm_wide: gates on the accumulators, cell in place;
-    // no gathered input rows, no gate matrix in memory), then the head GEMMs below. Launches of a few thousand particles keep the
-    // GEMM chain (a workgroup of the wide launch streams 8.4 MB of weights for its 32 particles whatever n).
+    // no gathered input rows, no gate matrix in memory), then the head GEMMs below. Launches of up to 2 048 particles keep the
+    // GEMM chain: a workgroup of the wide launch streams 8.4 MB of weights for its 32 particles whatever n - 0.33 ms per statement
+    // up to 4 096 particles, the chain 0.14 / 0.20 / 0.33 / 0.69 ms at 512 / 1 024 / 2 048 / 4 096
+    // (profiles/s5w_h1024_statement_sweep.jsonl).
+    constexpr int WIDE_MIN_ROWS = 2048;
     const int fmode = is_step_fused_mode();
-    const bool wide = !ff && !shared && is_lstm_wide_supported(net) && (fmode >= 2 || (fmode == 1 && n > SPLIT_MAX_ROWS)) &&
+    const bool wide = !ff && !shared && is_lstm_wide_supported(net) && (fmode >= 2 || (fmode == 1 && n > WIDE_MIN_ROWS)) &&
                       (int64_t)n * H < (int64_t(1) << 32);
     if (!ff && !wide)
         PP_TRY(lstm_input_gather(net, P, e_obs_vec, 0, nullptr, prev_value, nullptr, nullptr, addr_id, prev_addr_id, m, w.X,
