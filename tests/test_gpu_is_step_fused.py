@@ -112,12 +112,15 @@ def _ids(eng, name):
     (1024, 1000, ('a_normal', 'Normal'), ('a_uniform', 'Uniform')),
     (1024, 33, ('a_uniform', 'Uniform'), ('a_normal', 'Normal')),
     (1024, 300, ('a_cat', 'Categorical'), ('a_cat', 'Categorical')),
+    # widths without a fused kernel (BASELINE.json configs[0]'s plumbing network is H = 64): the chain of GEMM launches, same oracle
+    (64, 500, ('a_normal', 'Normal'), ('a_uniform', 'Uniform')),
+    (128, 200, ('a_uniform', 'Uniform'), ('a_normal', 'Normal')),
 ])
 def test_fused_statement_against_the_oracle(H, n, prev, cur):
     from pyprob_amd.ops import ops
     eng, run, sd = _engine(H)
     # (pp_is_step_fused_supported answers for the row-list / whole-statement entry points: not at H = 1024)
-    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == (1 if H <= 512 else 0)
+    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == (1 if H in (256, 512) else 0)
     rng = np.random.default_rng(5)
     h0 = (0.5 * rng.standard_normal((n, H))).astype(np.float32).clip(-0.99, 0.99)
     c0 = rng.standard_normal((n, H)).astype(np.float32)
