@@ -386,7 +386,10 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
  * the faster path for n particles (below ~3 000 rows a launch is one generation of latency-bound workgroups and pp_is_step's
  * chain of small launches wins; pp_is_step makes the same choice).
  * With that kernel a statement is ONE launch (+ one preparation launch): gates, LSTM cell, both head layers, the draw and
- * log q; the gate pre-activations never reach memory, (h, c) are read once and written once. */
+ * log q; the gate pre-activations never reach memory, (h, c) are read once and written once.
+ * H = 1024 (one layer): pp_is_step runs the LSTM step of more than 2 048 particles as one wide launch (two workgroups per 32
+ * particles, half of the hidden units each; gates on the accumulators, c in place) followed by the head GEMMs and the draw;
+ * pp_is_step_rows / pp_is_statement_rows are not available at that width (pp_is_step_fused_supported = 0). */
 int pp_is_step_rows(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
                     const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride,
                     float* h, float* c, int32_t state_rows, const int64_t* rows, const float* value_in, float* value_out,
@@ -464,10 +467,11 @@ int pp_logweight_terms(const pp_lw_term* terms, int32_t count, float* lw /*dev [
 int pp_is_step_net(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
                    const float* e_obs_vec, const float* prev_value, float* h, float* c, int32_t state_rows, void* workspace,
                    size_t workspace_bytes, void* stream);
-/* (ABI 12) pp_is_init + pp_is_step_net(addr_id, prev_addr_id = -1) of a trace's FIRST statement as two launches: the observe
+/* (ABI 12) pp_is_init + pp_is_step_net(addr_id, prev_addr_id = -1) of a trace's FIRST statement as ONE launch: the observe
  * embedding of the one shared row (InferenceNetwork._infer_init, pyprob/nn/inference_network.py:141-148) is computed inside the
  * launch of the LSTM step (_infer_step with prev_variable None, pyprob/nn/inference_network_lstm.py:82-134), the proposal layer's
- * outputs stay in the workspace for pp_is_fused. `obs` (the observation vector, as for pp_is_init) may be host-mapped (pinned)
+ * workgroups ride behind the LSTM's in the same launch (environment PP_IS_FIRST=2: as a second launch), its outputs stay in the
+ * workspace for pp_is_fused. `obs` (the observation vector, as for pp_is_init) may be host-mapped (pinned)
  * memory: the kernel reads it in place, a posterior call needs no copy launch. e_out: [round4(e_obs) + 8]: the embedding, then the
  * first 8 observation values (device copies: the x of the call's observe terms). (h, c): row 0 is written (state_rows = 1).
  * Bit-identical to the two calls it replaces. pp_is_first_statement_supported: one-layer LSTM, lstm_in <= 256, an embedding
