@@ -100,6 +100,10 @@ int gemm_f32(const pp_gemm_args* a, hipStream_t st, const GemmHole* hole = nullp
 int gemm_f32_grouped(const pp_gemm_args* args, int count, hipStream_t st, const GemmHole* holes = nullptr,
                      const GemmExt* ext = nullptr, const AuxJobs* aux = nullptr);
 int aux_jobs_launch(const AuxJobs& jobs, hipStream_t st);   // kernels.hip: the same jobs as their own launch
+// lstm_input.hip: the LSTM input product of a minibatch (K = e_obs + smp_dim) with its row biases and the first time step's cell as
+// one short launch, where the shape allows it (else the async tile kernel of gemm_f32.hip takes the same arguments)
+bool lstm_input_fast_ok(const pp_gemm_args& g, const GemmExt& x);
+int lstm_input_fast(const pp_gemm_args& g, const GemmExt& x, hipStream_t st);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

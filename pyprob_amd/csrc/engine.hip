@@ -610,7 +610,8 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
                 // executed data-path FLOPs of the launch: forward + backward products of the 8-row panels
                 prof_end(0, 2.0 * R * (2.0 * 3.0 * H * net->e_obs + 2.0 * (double)H * ad.hid + 2.0 * (double)ad.hid * ad.n_out), st);
             } else {
-            PP_TRY(gemm_f32(&g, st, &zc, &x));
+            if (lstm_input_fast_ok(g, x)) PP_TRY(lstm_input_fast(g, x, st));      // (lstm_input.hip; the zero block is zeros in X)
+            else PP_TRY(gemm_f32(&g, st, &zc, &x));
             prof_end(0, 2.0 * R * (double)nx * 4.0 * H, st);
             }
         } else {
