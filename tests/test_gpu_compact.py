@@ -135,6 +135,7 @@ def test_compact_rows_match_the_full_width_path(tmp_path, legacy):
     {'PP_FUSE_CELL_REC': '0'},
     {'PP_DH_PARTIALS': '0'},                                 # dh_{t-1} += dG_t W_hh with float atomics instead of stored partials                               # recurrent products accumulate into G, stand-alone cell kernels                                   # forget-gate columns and cell state written although unused
     {'PP_FUSE_CELL': '0', 'PP_FUSE_CELL_BWD': '0', 'PP_AUX_FUSED': '0'},
+    {'PP_LSTM_INPUT_FAST': '0'},                             # the LSTM input product on the async tile kernel instead of csrc/lstm_input.hip
 ])
 def test_each_fusion_switch_is_result_neutral(tmp_path, legacy, env):
     _compare(_run(tmp_path, 'sw', **env), legacy, str(env))
