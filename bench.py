@@ -24,6 +24,7 @@ The JSON line also carries
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -609,6 +610,12 @@ def main():
 
         # ---- untimed pre-warm: code objects, clocks, host caches; then a probe of both loops (the
         # driver's 20-step region after 5 warm-up steps used to start a few launches after process start)
+        # (the timed region is ~1.3 ms at the driver's K = 20: a generational collection of the interpreter inside it would be a
+        # visible fraction - collected HERE, before the pre-warm, and held off until the timed region is over. Not right before the
+        # timed region: a collection idles the device for tens of ms and the first steps after an idle period run at ramping
+        # clocks - 0.077 instead of 0.067 ms/step over 20 steps, profiles/r05_experiments_not_kept.txt)
+        gc.collect()
+        gc.disable()
         t_pre = time.perf_counter()
         run_steps(0, 30, False)
         prewarm_steps = 30
@@ -647,6 +654,7 @@ def main():
         run_steps(W, K, native_loop)
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
 
         def collect(which, n):
             ms = np.zeros(n, np.float32)
