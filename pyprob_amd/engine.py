@@ -158,7 +158,7 @@ class ICEngine:
         return (self.loss_buf[:1], lp) if keep_lp else self.loss_buf[:1]
 
     def _set_active(self, batch):
-        key = (tuple(batch.cur_counts > 0), tuple(batch.prev_counts > 0))
+        key = batch.presence_key
         if key == self._active_key and self.world_size == 1 and not self.force_allreduce:
             return          # presence map already in place (it is only overwritten by the DP all-reduce)
         act = self._active_cache.get(key)
@@ -367,7 +367,7 @@ class ICEngine:
         for b in batches:
             if b.c is None:
                 b.to(self.device)
-            key = (tuple(b.cur_counts > 0), tuple(b.prev_counts > 0))
+            key = b.presence_key
             act = self._active_cache.get(key)
             if act is None:
                 act = torch.from_numpy(self.spec.active_mask(b.cur_counts, b.prev_counts)).to(self.device)

@@ -34,6 +34,17 @@ class PackedBatch:
         self.dev = None
         self.c = None
 
+    @property
+    def presence_key(self):
+        """Which addresses appear as the current / the previous variable of a row (hashable; decides the presence map of the
+        optimizer step, NetSpec.active_mask). Computed once: a packed batch does not change, and a resident minibatch is
+        trained on again and again (4 us of numpy per step otherwise)."""
+        k = self.__dict__.get('_presence_key')
+        if k is None:
+            k = self._presence_key = (tuple((np.asarray(self.cur_counts) > 0).tolist()),
+                                      tuple((np.asarray(self.prev_counts) > 0).tolist()))
+        return k
+
     # ---------------------------------------------------------------------------------------------------
     @staticmethod
     def from_ragged(trace_len, addr_ids, values, prior, obs, n_addr):
