@@ -133,6 +133,10 @@ def test_active_mask_matches_reference_has_grad(golden):
     ref = dict(zip(meta['param_names'], meta['has_grad']))
     for i, n in enumerate(names):
         assert bool(act[i]) == bool(ref[n]), n
+    # the key the engine caches presence maps under: which addresses appear as current / previous variable; computed once per batch
+    key = pb.presence_key
+    assert key == (tuple(bool(v) for v in pb.cur_counts > 0), tuple(bool(v) for v in pb.prev_counts > 0))
+    assert pb.presence_key is key and hash(key) == hash((tuple(pb.cur_counts > 0), tuple(pb.prev_counts > 0)))
 
 
 def test_ragged_synthetic_generator_lengths():
