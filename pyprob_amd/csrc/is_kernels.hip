@@ -602,6 +602,13 @@ static int is_step_fused_mode() {
 // particles) that is one generation of ~0.23 ms whatever n. The split statement's LSTM launch is MFMA-bound from ~2 000
 // particles on (0.11 ms at 8 192) and its head launch costs ~0.04 ms: below 4 096 particles it wins clearly.
 constexpr int SPLIT_MAX_ROWS = 4096;
+// H = 1024: a workgroup of the wide LSTM launch streams 8.4 MB of weights for its 32 particles whatever n - 0.33 ms per statement up
+// to 4 096 particles; the GEMM chain takes 0.14 / 0.20 / 0.33 / 0.69 ms at 512 / 1 024 / 2 048 / 4 096
+// (profiles/s5w_h1024_statement_sweep.jsonl): from 2 049 particles on the fused statement
+constexpr int WIDE_MIN_ROWS = 2048;
+static bool is_step_fused_pays(const pp_net* net, int n) {      // mode 1: is the fused statement the faster path for n particles?
+    return !(net->lstm_dim == 1024 && is_step_fused_mode() == 1 && n <= WIDE_MIN_ROWS);
+}
 static bool is_step_split(int n) {
     const int mode = is_step_fused_mode();
     return mode == 3 || (mode == 1 && n <= SPLIT_MAX_ROWS);
@@ -748,14 +755,15 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     // Small launches take the same statement as two launches (the LSTM step split over the gate columns, then head + draw):
     // is_step_split above. PP_IS_STEP_FUSED=0 keeps the chain of GEMM launches below (A/B, tests).
     bool head_done = false;
-    if (!shared && is_step_fused_supported(net, addr_id) && is_step_fused_mode() != 0) {
+    // (H = 1024 below WIDE_MIN_ROWS particles: the chain, unless the caller needs the row list / the whole-statement tail)
+    if (!shared && is_step_fused_supported(net, addr_id) && is_step_fused_mode() != 0 && (rows || whole || is_step_fused_pays(net, n))) {
         bool sampled = false;
         // (32-bit element offsets into the state rows: a row list's indices are the caller's to bound - ISRunner.begin does)
         PP_CHECK_ARG(rows || (int64_t)n * H < (int64_t(1) << 32), "pp_is_step: more than 2^32 state elements per call: shard the particles");
         // (the split statement's new hidden rows go through the chain's gate buffer w.G: [n][4 H] >= [n][H])
         PP_TRY(is_step_fused(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows, rows,
                              value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st, whole,
-                             (state_rows != 1 && is_step_split(n)) ? w.G : nullptr));
+                             (H == 1024 || (state_rows != 1 && is_step_split(n))) ? w.G : nullptr));
         if (sampled) return 0;
         PP_CHECK_ARG(!whole, "pp_is_statement_rows: mixture heads only");
         head_done = true;     // the head outputs are in w.Y: the sampling kernels below (or pp_is_fused) take over
@@ -782,8 +790,8 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     // no gathered input rows, no gate matrix in memory), then the head GEMMs below. Launches of up to 2 048 particles keep the
     // GEMM chain: a workgroup of the wide launch streams 8.4 MB of weights for its 32 particles whatever n - 0.33 ms per statement
     // up to 4 096 particles, the chain 0.14 / 0.20 / 0.33 / 0.69 ms at 512 / 1 024 / 2 048 / 4 096
-    // (profiles/s5w_h1024_statement_sweep.jsonl).
-    constexpr int WIDE_MIN_ROWS = 2048;
+    // (profiles/s5w_h1024_statement_sweep.jsonl). (Heads the fused statement's head-only launch does not take: wider than 32 outputs
+    // or 576 hidden units; else pp_is_step took the fused statement above.)
     const int fmode = is_step_fused_mode();
     const bool wide = !ff && !shared && is_lstm_wide_supported(net) && (fmode >= 2 || (fmode == 1 && n > WIDE_MIN_ROWS)) &&
                       (int64_t)n * H < (int64_t(1) << 32);
@@ -1474,8 +1482,8 @@ int pp_is_statement_rows(const pp_net* net, const float* params, int32_t addr_id
 }
 
 int pp_is_step_fused_supported(const pp_net* net, int32_t addr_id, int32_t n) {
-    (void)n;      // (any n: small launches take the two-launch split statement)
-    return (pp::is_step_fused_mode() != 0 && pp::is_step_fused_supported(net, addr_id)) ? 1 : 0;
+    // (H = 256 / 512: any n - small launches take the two-launch split statement; H = 1024: from WIDE_MIN_ROWS + 1 particles on)
+    return (pp::is_step_fused_mode() != 0 && pp::is_step_fused_supported(net, addr_id) && pp::is_step_fused_pays(net, n)) ? 1 : 0;
 }
 
 int pp_prior_draw(int32_t kind, const float* p0, int32_t p0_stride, const float* p1, int32_t p1_stride, int32_t n, uint64_t seed,

@@ -234,8 +234,10 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     constexpr int NB = 4 * UB;
     constexpr int SLAB = FW * NB * 256;            // floats of one k-slab of the gate image
     float* sH = fused_lds;                         // [H / 16][2][64][4]: the fresh hidden tile as 16-row A fragments (H * 32 floats)
-    float* sA1 = sH + NSH * 256;                   // [ns2][64][4]: head layer 1 activations as A fragments
-    float* sY = sA1 + a.ns2 * 256;                 // [32][33] head outputs
+    // (UB = 4, the head-only launch of the H = 1024 statement: the tile alone is 128 KB - the activations of head layer 1 go OVER it,
+    // behind the K-split partials' 32 KB, once every wave has finished reading it)
+    float* sA1 = UB == 4 ? sH + 8192 : sH + NSH * 256;   // [ns2][64][4]: head layer 1 activations as A fragments
+    float* sY = UB == 4 ? sH + NSH * 256 : sA1 + a.ns2 * 256;   // [32][33] head outputs
     int* sRow = reinterpret_cast<int*>(KM > 1 ? fused_lds : sY + FR * 33);   // [32] state row of every particle of the panel
     float* sPart = sH;                             // [8][32][32] K-split partials of head layer 2 (the tile is dead by then)
 
@@ -417,6 +419,66 @@ __global__ __launch_bounds__(512) void is_step_fused_kernel(const FusedArgs a) {
     // wave had two of nine blocks and the other seven waited for it, profiles/r04e_is_step_timeline.txt). Two accumulators
     // per tile (even / odd k groups) keep the dependent-accumulate latency out of the chain; the B fragments (one KB per
     // 16-k slab and tile, W1's second image) run eight slabs ahead in registers.
+    if constexpr (UB == 4) {
+        // (H = 1024: the tiles' results wait in registers for a barrier - see sA1 above; up to MAXT tiles per wave: hid <= 576;
+        // pyprob's proposal layer is (H + 3 K) / 2 = 527 wide at H = 1024, K = 10)
+        constexpr int MAXT = 9;
+        const int T16 = 2 * a.nb16;
+        const int t0 = (wave * T16) / FW, t1 = ((wave + 1) * T16) / FW;
+        constexpr int NS16 = H / 16;
+        constexpr int HR = 16;
+        const int i16 = lane & 15, kq = lane >> 4;
+        f32x4 res[MAXT];
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti) {
+            res[ti] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const int t = t0 + ti;
+            if (t < t1) {      // (wave-uniform)
+                const int cb = t >> 1, rb = t & 1;
+                f32x4 e0 = {0.0f, 0.0f, 0.0f, 0.0f}, e1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float* wimg = a.w1_img + (size_t)cb * 256 + lane * 4;
+                const size_t sstride = (size_t)a.nb16 * 256;
+                const float* aimg = sH + rb * 256 + lane * 4;
+                f32x4 bq[HR];
+#pragma unroll
+                for (int u = 0; u < HR; ++u) bq[u] = *reinterpret_cast<const f32x4*>(wimg + u * sstride);
+                __builtin_amdgcn_sched_barrier(0);
+                for (int s16 = 0; s16 < NS16; s16 += HR) {
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(aimg + (s16 + u) * 512);
+                        const f32x4 bv = bq[u];
+                        if (s16 + u + HR < NS16) bq[u] = *reinterpret_cast<const f32x4*>(wimg + (size_t)(s16 + u + HR) * sstride);
+                        e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], e0, 0, 0, 0);
+                        e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], e1, 0, 0, 0);
+                        e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], e0, 0, 0, 0);
+                        e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], e1, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res[ti][r] = e0[r] + e1[r];
+            }
+        }
+        __syncthreads();      // every wave has read the hidden tile: the activations go over it
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti) {
+            const int t = t0 + ti;
+            if (t < t1) {
+                const int cb = t >> 1, rb = t & 1;
+                const int col = cb * 16 + i16;
+                const float bias1 = col < a.hid ? a.b1[col] : 0.0f;
+                if ((col >> 3) < a.ns2) {
+                    const int slot = ((col >> 3) * 64 + ((col >> 2) & 1) * 32) * 4 + (col & 3);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rb * 16 + 4 * kq + r;
+                        sA1[slot + row * 4] = col < a.hid ? relu_keep_nan(res[ti][r] + bias1) : 0.0f;
+                    }
+                }
+            }
+        }
+    } else
     {
         const int T16 = 2 * a.nb16;
         const int t0 = (wave * T16) / FW, t1 = ((wave + 1) * T16) / FW;
@@ -753,11 +815,14 @@ static inline int64_t round256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 bool is_step_fused_supported(const pp_net* net, int addr_id) {
     if (!net || net->lstm_dim == 0 || std::max(1, (int)net->lstm_depth) != 1) return false;
-    if (net->lstm_dim != 256 && net->lstm_dim != 512) return false;
+    if (net->lstm_dim != 256 && net->lstm_dim != 512 && net->lstm_dim != 1024) return false;
     if (net->smp_dim < 1 || net->smp_dim > 8 || net->lstm_in > 1024 || !net->addr_table) return false;
     if (addr_id < 0 || addr_id >= net->n_addr) return false;
     const pp_addr& ad = net->addrs[addr_id];
     if (ad.n_out < 1 || ad.n_out > 32 || ad.hid < 1) return false;
+    // H = 1024: the wide LSTM launch + the head-only launch (its layer-1 tiles wait in registers: at most 9 per wave, and the
+    // activations go over the hidden tile behind the 32 KB of K-split partials)
+    if (net->lstm_dim == 1024) return ad.hid <= 576;
     const int ns2 = (ad.hid + 7) / 8;
     const size_t lds = ((size_t)(net->lstm_dim / 8) * 256 + (size_t)ns2 * 256 + FR * 33 + FR) * sizeof(float);
     return lds <= 150 * 1024;
@@ -770,9 +835,13 @@ bool is_lstm_wide_supported(const pp_net* net) {
 
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {
     f = IsFusedBuffers{};
-    if (is_lstm_wide_supported(net)) {      // two gate images of 512 hidden units each, K extent 1024; no head images
+    if (is_lstm_wide_supported(net)) {      // two gate images of 512 hidden units each, K extent 1024; the head images
         const int H = net->lstm_dim;
+        int64_t hid = 1;
+        for (int a = 0; a < net->n_addr; ++a) hid = std::max<int64_t>(hid, net->addrs[a].hid);
         f.n_whh = (int64_t)2 * (H / 8 + 1) * FW * 8 * 256;
+        f.n_w1 = (int64_t)(H / 16) * ((hid + 15) / 16) * 256;
+        f.n_w2 = (int64_t)((hid + 7) / 8) * 256;
         f.n_bias = 4 * H;
         return;
     }
@@ -792,12 +861,17 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
                   const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
                   const IsStatementOut* whole, float* hn_split) {
     const pp_addr& ad = net->addrs[addr_id];
-    const int H = net->lstm_dim, ub = H / 256, nsh = H / 8;
+    const bool wide = net->lstm_dim == 1024;      // the LSTM step as the wide launch, then the head-only launch (hn_split required)
+    const int H = net->lstm_dim, ub = wide ? 2 : H / 256, nsh = H / 8;
     const bool shared = state_rows == 1;
+    if (wide && !hn_split) {
+        set_error("pp_is_step: the H = 1024 statement needs the scratch rows of its two launches");
+        return PP_EINVAL;
+    }
     PrepArgs p{};
     p.P = P; p.at = net->addr_table;
     p.w_ih = net->w_ih; p.w_hh = net->w_hh; p.b_ih = net->b_ih; p.b_hh = net->b_hh; p.w1 = ad.w1; p.w2 = ad.w2;
-    p.H = H; p.I = net->lstm_in; p.ub = ub; p.nsh = nsh; p.hu = H; p.halves = 1;
+    p.H = H; p.I = net->lstm_in; p.ub = ub; p.nsh = nsh; p.hu = wide ? 512 : H; p.halves = wide ? 2 : 1;
     p.d = GatherDims{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
     p.addr_id = addr_id; p.prev_addr = prev_addr_id;
     p.e_obs_vec = e_obs_vec;
@@ -805,10 +879,10 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
     p.c0 = shared ? c : nullptr;
     p.hid = ad.hid; p.n_out = ad.n_out; p.nb16 = (ad.hid + 15) / 16; p.ns2 = (ad.hid + 7) / 8;
     p.whh_img = f.whh; p.w1_img = f.w1; p.w2_img = f.w2; p.bias = f.bias; p.c0_copy = c0_copy;
-    p.q_whh = (int64_t)(nsh + 1) * FW * 4 * ub * 64;
+    p.q_whh = (int64_t)p.halves * (nsh + 1) * FW * 4 * ub * 64;
     p.q_w1 = (int64_t)(H / 16) * p.nb16 * 64;
     p.q_w2 = (int64_t)p.ns2 * 64;
-    p.img_blocks = (int)std::min<int64_t>(1024, (p.q_whh + p.q_w1 + p.q_w2 + 255) / 256);
+    p.img_blocks = (int)std::min<int64_t>(wide ? 2048 : 1024, (p.q_whh + p.q_w1 + p.q_w2 + 255) / 256);
     hipLaunchKernelGGL(is_prep_kernel, dim3(p.img_blocks + H), dim3(256), 0, st, p);
     PP_LAUNCH_CHECK("pp_is_step(prepare)");
 
@@ -836,12 +910,31 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
         else if (ad.kind == PP_HEAD_POISSON_TN_MIXTURE) kind = 2;
     }
     if (kind == 3) { a.y_out = y_out; a.ldy = ldy; }
-    const size_t lds = ((size_t)nsh * 256 + (size_t)p.ns2 * 256 + FR * 33 + FR) * sizeof(float);
+    const size_t lds = wide ? ((size_t)nsh * 256 + FR * 33 + FR) * sizeof(float)      // (the activations lie over the hidden tile)
+                            : ((size_t)nsh * 256 + (size_t)p.ns2 * 256 + FR * 33 + FR) * sizeof(float);
     // kernel class 5 of the in-stream timing: the fused statement (work = FLOPs of the reference's algorithm, SURVEY.md 8d:
     // input + recurrent product, both head layers)
     const double flops = (double)n * (2.0 * (net->lstm_in + (shared ? 0 : H)) * 4.0 * H + 2.0 * ((double)H * ad.hid + (double)ad.hid * ad.n_out));
     prof_begin(5, st);
     int rc = 0;
+    if (wide) {      // H = 1024: the LSTM step as the wide launch (KM = 2; shared state: no recurrent product), then the head-only launch
+        FusedArgs q = a;
+        q.hout = hn_split; q.panels = cdiv(n, FR);
+        if (shared) hipLaunchKernelGGL((is_step_fused_kernel<2, 3, true, false, 2>), dim3(2 * q.panels), dim3(512), 256, st, q);
+        else hipLaunchKernelGGL((is_step_fused_kernel<2, 3, false, false, 2>), dim3(2 * q.panels), dim3(512), 256, st, q);
+        PP_LAUNCH_CHECK("pp_is_step(wide LSTM)");
+        a.hn = hn_split;
+        a.state_shared = 0;      // (the head-only launch writes every particle's new row)
+        if (kind == 0) rc = launch_fused_s<4, 0, false, true>(a, lds, st);
+        else if (kind == 1) rc = launch_fused_s<4, 1, false, true>(a, lds, st);
+        else if (kind == 2) rc = launch_fused_s<4, 2, false, true>(a, lds, st);
+        else rc = launch_fused_s<4, 3, false, true>(a, lds, st);
+        prof_end(5, flops, st);
+        if (rc) return rc;
+        PP_LAUNCH_CHECK("pp_is_step(fused statement, H = 1024)");
+        *sampled = kind != 3;
+        return 0;
+    }
     if (hn_split && !shared) {      // split statement: the LSTM step over 8 x as many workgroups, then the head-only launch
         SmallLstmArgs q{};
         q.whh_img = f.whh; q.bias = f.bias; q.h = h; q.c = c; q.rows = rows;

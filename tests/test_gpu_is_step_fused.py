@@ -107,8 +107,8 @@ def _ids(eng, name):
     (512, 300, ('a_normal', 'Normal'), ('a_cat', 'Categorical')),         # head outputs -> the categorical kernel
     (512, 300, ('a_uniform', 'Uniform'), ('a_bern', 'Bernoulli')),
     (256, 777, ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform')),
-    # H = 1024: the LSTM step is the wide launch (two workgroups per 32 particles, half of the hidden units each), the head layers
-    # and the draw are the chain's launches (is_kernels.hip is_step)
+    # H = 1024: the LSTM step is the wide launch (two workgroups per 32 particles, half of the hidden units each), head layers and
+    # draw the head-only launch (UB = 4: the activations of layer 1 go over the hidden tile in LDS)
     (1024, 1000, ('a_normal', 'Normal'), ('a_uniform', 'Uniform')),
     (1024, 33, ('a_uniform', 'Uniform'), ('a_normal', 'Normal')),
     (1024, 300, ('a_cat', 'Categorical'), ('a_cat', 'Categorical')),
@@ -119,8 +119,8 @@ def _ids(eng, name):
 def test_fused_statement_against_the_oracle(H, n, prev, cur):
     from pyprob_amd.ops import ops
     eng, run, sd = _engine(H)
-    # (pp_is_step_fused_supported answers for the row-list / whole-statement entry points: not at H = 1024)
-    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == (1 if H in (256, 512) else 0)
+    # (the fixture forces the fused statement at any n; by default H = 1024 takes it from 2 049 particles on)
+    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == (1 if H in (256, 512, 1024) else 0)
     rng = np.random.default_rng(5)
     h0 = (0.5 * rng.standard_normal((n, H))).astype(np.float32).clip(-0.99, 0.99)
     c0 = rng.standard_normal((n, H)).astype(np.float32)
@@ -192,11 +192,12 @@ def test_fused_statement_equals_the_unfused_chain(monkeypatch, _force_fused, H):
     np.testing.assert_allclose(l1[close], l0[close], rtol=2e-4, atol=2e-4)
 
 
-def test_row_index_list_updates_the_state_in_place():
+@pytest.mark.parametrize('H', [512, 1024])
+def test_row_index_list_updates_the_state_in_place(H):
     """pp_is_step_rows: the particles of a diverged path own scattered rows of (h, c); the rows are read and written in
     place, every other row is untouched, and the result equals the compact call on the gathered rows."""
     from pyprob_amd.ops import ops
-    H, total, m = 512, 5000, 1777
+    total, m = 5000, 1777
     eng, run, sd = _engine(H, seed=4)
     rng = np.random.default_rng(2)
     h0 = (0.5 * rng.standard_normal((total, H))).astype(np.float32)
@@ -222,7 +223,7 @@ def test_row_index_list_updates_the_state_in_place():
     assert np.array_equal(hn[rest], h0[rest]) and np.array_equal(cn[rest], c0[rest])
     href, cref, lq_ref, _ = _oracle_statement(sd, H, [8.0, 9.0], ('a_uniform', 'Uniform'), ('a_normal', 'Normal'), pv, h0[rows],
                                               c0[rows], v.cpu().numpy().astype(np.float64), prior.astype(np.float64))
-    assert np.abs(hn[rows] - href).max() < 4e-6
+    assert np.abs(hn[rows] - href).max() < (4e-6 if H <= 512 else 8e-6)
     np.testing.assert_allclose(lq.cpu().numpy(), lq_ref, rtol=1e-4, atol=1e-4)
 
 
@@ -284,13 +285,14 @@ def test_fast_activations_against_libm():
     assert np.abs(h.cpu().numpy()[0] - hn).max() < 5e-7
 
 
-@pytest.mark.parametrize('dist,use_rows', [('Uniform', True), ('Normal', True), ('Uniform', False)])
-def test_whole_statement_in_one_launch(dist, use_rows):
+@pytest.mark.parametrize('dist,use_rows,H', [('Uniform', True, 512), ('Normal', True, 512), ('Uniform', False, 512),
+                                             ('Uniform', True, 1024), ('Normal', False, 1024)])
+def test_whole_statement_in_one_launch(dist, use_rows, H):
     """pp_is_statement_rows: previous values read at the particles' rows, the drawn value scattered to values[rows] and
     lw[rows] += log p(v) - log q(v) inside the statement kernel = pp_is_step_rows + the gather / scatter / log-weight launches
     around it (same Philox counters: identical values; the two fp32 additions in the same order: identical log-weights)."""
     from pyprob_amd.ops import ops
-    H, total = 512, 6000
+    total = 6000
     eng, run, sd = _engine(H, seed=12)
     rng = np.random.default_rng(4)
     m = 2500 if use_rows else total
@@ -345,8 +347,8 @@ def _mixture_cdf(x, params, dist, lo=None, hi=None):
     return (z * p).sum(1)
 
 
-@pytest.mark.parametrize('cur', [('a_normal', 'Normal'), ('a_uniform', 'Uniform')])
-def test_the_drawn_values_follow_the_proposal(cur):
+@pytest.mark.parametrize('cur,H', [(('a_normal', 'Normal'), 512), (('a_uniform', 'Uniform'), 512), (('a_uniform', 'Uniform'), 1024)])
+def test_the_drawn_values_follow_the_proposal(cur, H):
     """The N-row draw itself (sixteen lanes per particle: component pick by the inclusive prefix of the clamped weights, then
     the component's Normal / inverse-CDF TruncatedNormal draw - is_step_fused.hip's tail, is_draw.hpp): re-scoring proves
     log q AT the drawn value, not that the value is drawn FROM q. Here every particle gets the same
@@ -354,7 +356,7 @@ def test_the_drawn_values_follow_the_proposal(cur):
     autouse fixture): (1) Kolmogorov-Smirnov distance of the 40 000 draws to the oracle's mixture CDF, (2) the importance
     identity E_q[p(v) / q(v)] = 1 for a known target p within four standard errors, (3) log q of the device at those values."""
     from pyprob_amd.ops import ops
-    H, n = 512, 40000
+    n = 40000
     prev = ('a_uniform', 'Uniform') if cur[1] == 'Normal' else ('a_normal', 'Normal')
     eng, run, sd = _engine(H, seed=3)
     rng = np.random.default_rng(11)
