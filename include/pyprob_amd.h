@@ -381,15 +381,16 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
  * pyprob/model.py:59): particle i of the call owns row rows[i] of (h, c) (dev int64 [n], distinct rows; NULL = row i) - the
  * state is read and written in place through the list, every other per-particle array (prev_value, prior, value_in / out,
  * logq_out) is compact [n]. Statements after the first one only (prev_addr_id >= 0), and only where the fused statement
- * kernel exists (csrc/is_step_fused.hip: one-layer LSTM, H = 256 or 512, head at most 32 outputs wide); PP_EINVAL otherwise
+ * kernel exists (csrc/is_step_fused.hip: one-layer LSTM, H = 256, 512 or 1024, head at most 32 outputs wide); PP_EINVAL otherwise
  * (the caller gathers / scatters the rows itself). pp_is_step_fused_supported(net, addr_id, n) != 0: the kernel exists AND is
  * the faster path for n particles (below ~3 000 rows a launch is one generation of latency-bound workgroups and pp_is_step's
  * chain of small launches wins; pp_is_step makes the same choice).
  * With that kernel a statement is ONE launch (+ one preparation launch): gates, LSTM cell, both head layers, the draw and
  * log q; the gate pre-activations never reach memory, (h, c) are read once and written once.
- * H = 1024 (one layer): pp_is_step runs the LSTM step of more than 2 048 particles as one wide launch (two workgroups per 32
- * particles, half of the hidden units each; gates on the accumulators, c in place) followed by the head GEMMs and the draw;
- * pp_is_step_rows / pp_is_statement_rows are not available at that width (pp_is_step_fused_supported = 0). */
+ * H = 1024 (one layer): the statement is TWO launches - the LSTM step as one wide launch (two workgroups per 32 particles, half of
+ * the hidden units each; gates on the accumulators, c in place, the new hidden rows through a scratch) and the head-only launch
+ * (state rows, both head layers, draw, log q, whole-statement tail) - from 2 049 particles on (pp_is_step_fused_supported says so
+ * per n); below that pp_is_step takes the chain of GEMM launches, pp_is_step_rows / pp_is_statement_rows still the two launches. */
 int pp_is_step_rows(const pp_net* net, const float* params, int32_t addr_id, int32_t prev_addr_id, int32_t n,
                     const float* e_obs_vec, const float* prev_value, const float* prior, int32_t prior_stride,
                     float* h, float* c, int32_t state_rows, const int64_t* rows, const float* value_in, float* value_out,

@@ -10,7 +10,7 @@ struct IsFusedBuffers {
     int64_t n_whh = 0, n_w1 = 0, n_w2 = 0, n_bias = 0;
 };
 
-// one-layer LSTM with H in {256, 512}, head of `addr_id` at most 32 outputs wide
+// one-layer LSTM with H in {256, 512, 1024} (1024: two launches, head at most 576 hidden units), head of `addr_id` at most 32 outputs wide
 bool is_step_fused_supported(const pp_net* net, int addr_id);
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f);
 

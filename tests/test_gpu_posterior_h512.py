@@ -143,9 +143,9 @@ def test_gumm_posterior_every_particle_rescored(gumm_trained, n, monkeypatch):
 
 def test_gumm_posterior_h1024_every_particle_rescored(gumm_trained_h1024, monkeypatch):
     """The same program on the H = 1024 network (BASELINE.json configs[4]'s per-rank network): the N-row statements of more than
-    4 096 particles run the wide LSTM launch (csrc/is_step_fused.hip is_lstm_wide: two workgroups per 32 particles, half of the
-    hidden units each) + the head GEMMs, the smaller ones the GEMM chain; diverged paths gather / scatter their state rows
-    (ISRunner.step_rows). Every particle re-scored by the float64 oracle."""
+    2 048 particles run as two launches (csrc/is_step_fused.hip: the wide LSTM launch - two workgroups per 32 particles, half of the
+    hidden units each - and the head-only launch; row lists in place, whole-statement mode), the smaller ones the GEMM chain with
+    their state rows gathered / scattered (ISRunner.step_rows). Every particle re-scored by the float64 oracle."""
     for k in ('PP_IS_NEST', 'PP_IS_ROWS', 'PP_IS_STEP_FUSED', 'PP_IS_MEMO', 'PP_IS_PLAN', 'PP_IS_FUSED'):
         monkeypatch.delenv(k, raising=False)
     model, n = gumm_trained_h1024, 65537
