@@ -210,7 +210,7 @@ class ParticleTensor(torch.Tensor):
             if isinstance(a, torch.Tensor):
                 # storage identity, not object identity: a replayed statement hands out a NEW wrapper of the recorded values;
                 # shape, strides and offset: views of one storage (unsqueeze / expand / slices) share address, size and version
-                key.append((a.data_ptr(), a.storage_offset(), tuple(a.shape), a.stride(), a.dtype, a._version))
+                key.append((a.data_ptr(), a.storage_offset(), a.shape, a.stride(), a.dtype, a._version))
             elif isinstance(a, (bool, int, float)):
                 key.append(('s', type(a).__name__, a))
             else:
@@ -227,23 +227,28 @@ class ParticleTensor(torch.Tensor):
             if not lazy_ok:
                 ls.flush()
         memo = getattr(ls, 'memo', None) if ls is not None else None
-        if memo is not None and not kwargs and name in cls._PURE:
-            with torch._C.DisableTorchFunctionSubclass():      # (metadata reads: no Python dispatch per attribute)
+        if memo is not None and not kwargs and name in cls._PURE and len(types) == 1:
+            # One stretch with the subclass dispatch off: the key (metadata reads), the lookup, and on a miss the operator itself on
+            # the plain tensors + ONE as_subclass of its result - torch's default __torch_function__ (re-dispatch + _convert of the
+            # result) costs ~6 us per operator, a third of what a deep level of a control-flow program spends per statement
+            with torch._C.DisableTorchFunctionSubclass():
                 key = cls._memo_key_plain(name, args)
-                hit = memo.get(key) if key is not None else None
-                if hit is not None and hit[0]._version == hit[1]:
-                    ls.memo_shared.add(hit[0].data_ptr())   # handed out a second time: two names of the program share it now
-                    return hit[0]
-            if key is not None:
-                out = super().__torch_function__(func, types, args, {})
-                if isinstance(out, torch.Tensor):
-                    with torch._C.DisableTorchFunctionSubclass():
-                        ls.memo_bytes += out.numel() * out.element_size()
+                if key is not None:
+                    hit = memo.get(key)
+                    if hit is not None and hit[0]._version == hit[1]:
+                        ls.memo_shared.add(hit[0].data_ptr())   # handed out a second time: two names of the program share it now
+                        return hit[0]
+                    out = func(*args)
+                    if isinstance(out, torch.Tensor):
+                        if type(out) is not cls:
+                            out = out.as_subclass(cls)
+                        nbytes = out.numel() * out.element_size()
+                        ls.memo_bytes += nbytes
                         if ls.memo_bytes > cls.MEMO_BYTES:      # bound what one call pins (many-path programs at 1e6 particles)
                             memo.clear()
-                            ls.memo_bytes = out.numel() * out.element_size()
+                            ls.memo_bytes = nbytes
                         memo[key] = (out, out._version, args)      # (the arguments stay alive: their storage is not reused)
-                return out
+                    return out
         elif memo is not None and ls.memo_shared and args and isinstance(args[0], torch.Tensor) and \
                 (name == '__setitem__' or (name.endswith('_') and not name.startswith('__'))):
             with torch._C.DisableTorchFunctionSubclass():
