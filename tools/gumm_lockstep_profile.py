@@ -44,6 +44,7 @@ torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(45)
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(60)
 open(out + '_cprofile.txt', 'w').write(s.getvalue())
 pr.dump_stats(out + '_cprofile.pstats')
 from torch.profiler import profile, ProfilerActivity
