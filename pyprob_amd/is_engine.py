@@ -186,7 +186,7 @@ class ISRunner:
     def run_plan(self, plan, obs_values, n, offset, seed):
         """Replay of a recorded single-statement posterior call (Model._replay_lockstep_plan) straight through the C ABI, with no
         copy in either direction: the observation is written into PINNED host memory that the first kernel reads in place
-        (pp_is_first_statement: observe embedding + the one-row LSTM step in one launch, the proposal layer in a second), then
+        (pp_is_first_statement: observe embedding, the one-row LSTM step and the proposal layer in one launch), then
         pp_is_fused, whose statistics land in pinned host memory too - the count last, behind a system-scope fence - and are
         polled there instead of being copied back. Networks pp_is_first_statement does not take (and PP_IS_FIRST=0) go through
         a staged copy + pp_is_init + pp_is_step_net as before. plan['c'] caches the term array.
