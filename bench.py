@@ -338,7 +338,11 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
     cnt = C.c_int32(0)
     lib.pp_prof_collect(ms.ctypes.data, cap, C.byref(cnt), fl.ctypes.data)
     lib.pp_prof_arm(prof_class, 0)
-    executes = ('launch-plan replay: three C-ABI calls per call (pp_is_init, pp_is_step_net, pp_is_fused), forward() NOT run'
+    plans = getattr(model, '_lockstep_plans', None) or {}
+    first_kernel = any(p.get('first') for p in plans.values() if isinstance(p, dict))
+    executes = (('launch-plan replay: two C-ABI calls per call (pp_is_first_statement, pp_is_fused), forward() NOT run'
+                 if first_kernel else
+                 'launch-plan replay: three C-ABI calls per call (pp_is_init, pp_is_step_net, pp_is_fused), forward() NOT run')
                 if replays == calls else
                 "the user's forward() in lock step (state.sample / state.observe / Trace.end per control-flow path)" if replays == 0
                 else 'mixed: %d of %d timed calls were launch-plan replays' % (replays, calls))
@@ -389,14 +393,14 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         tr = (prof or {}).get('kernels', {}).get('is_step_fused', {})
         rec['statement_kernel'] = dict(
             bound='mfma', achieved=round(flops / (us * 1e-6) / 1e12, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
-            frac=round(executed / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), us_per_call=round(us, 1),
+            frac=round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), us_per_call=round(us, 1),
             launches_per_call=round(cnt.value / calls, 2), flops_per_call=flops, executed_flops_per_call=executed,
             frac_executed=round(executed / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
-            frac_reference_algorithm=round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
-            frac_note='frac = frac_executed: the FLOPs that run on the MFMA pipe over the fp32 matrix peak. achieved / '
-                      'frac_reference_algorithm price the reference algorithm (SURVEY.md 8d: all 212 input columns per particle) - '
-                      'the kernel multiplies 8 of them per particle and folds the rest into a bias row, so that figure can exceed 1 '
-                      'and is not a roofline fraction',
+            frac_note='ONE meaning of `frac` in every record of this file: achieved / peak with achieved = the REFERENCE '
+                      "algorithm's FLOPs (SURVEY.md 8d) over the measured time; `frac_executed` beside it = the FLOPs that run on "
+                      'the MFMA pipe. Here 8d prices all 212 input columns per particle-statement while the kernel multiplies 8 of '
+                      'them per particle and folds the rest into a bias row: `frac` can exceed 1 for this kernel, `frac_executed` '
+                      'is the pipe utilisation',
             traffic=tr.get('traffic_bytes_per_particle_statement'), algorithmic_bytes=tr.get('algorithmic_bytes_per_particle_statement'),
             traffic_source=note,
             kernel='is_step_fused_kernel (one launch per statement after the first: [s_prev | h] [W_s | W_hh]^T + bias on '
@@ -844,8 +848,38 @@ def main():
                                                            'control_flow_paths', 'ess', 'posterior_mean') if k in g1m}
             if 'statement_kernel' in g1m:
                 out['gumm_lockstep_1m']['statement_kernel'] = {k: g1m['statement_kernel'][k] for k in
-                                                               ('achieved', 'frac', 'frac_executed', 'frac_reference_algorithm',
+                                                               ('achieved', 'frac', 'frac_executed',
                                                                 'us_per_call', 'launches_per_call', 'wall_over_statement_kernels')}
+        # the driver's record keeps the flat scalars of `config` / `roofline` and only the NAMES of nested objects: every
+        # number README.md quotes is repeated here as a flat key
+        config['ms_per_step_median'] = out.get('ms_per_step_median')
+        for key, flat in (('is', 'is_particles_per_sec'), ('gumm_lockstep', 'gumm_lockstep_particles_per_sec'),
+                          ('gumm_lockstep_1m', 'gumm_lockstep_1m_particles_per_sec')):
+            if key in out:
+                config[flat] = out[key].get('particles_per_sec')
+        if 'is' in out:
+            config['is_ms_per_call'] = out['is'].get('ms_per_call')
+            config['is_noplan_particles_per_sec'] = out['is'].get('noplan', {}).get('particles_per_sec')
+            config['is_host'] = 'pyprob_amd.Model (the stand-alone mirror host; pyprob itself is not on the GPU box)'
+        if 'gumm_lockstep' in out:
+            sk = out['gumm_lockstep'].get('statement_kernel', {})
+            config['gumm_lockstep_ms_per_call'] = out['gumm_lockstep'].get('ms_per_call')
+            config['gumm_statement_frac'] = sk.get('frac')
+            config['gumm_statement_frac_executed'] = sk.get('frac_executed')
+            config['gumm_wall_over_statement_kernels'] = sk.get('wall_over_statement_kernels')
+        rl = out.get('roofline', {})
+        if 'whole_step' in rl:
+            rl['whole_step_frac'] = rl['whole_step']['frac']
+        if 'second_kernel' in rl:
+            rl['wgrad_frac'] = rl['second_kernel'].get('frac')
+            rl['wgrad_frac_executed'] = rl['second_kernel'].get('frac_executed')
+            rl['wgrad_us'] = rl['second_kernel'].get('avg_launch_us')
+            t2, a2 = rl['second_kernel'].get('traffic'), rl['second_kernel'].get('algorithmic_bytes')
+            rl['wgrad_traffic_ratio'] = round(t2 / a2, 3) if t2 and a2 else None
+        if rl.get('traffic') and rl.get('algorithmic_bytes'):
+            rl['traffic_ratio'] = round(rl['traffic'] / rl['algorithmic_bytes'], 3)
+        for d in rl.get('hbm_kernels', []):
+            rl[d['kernel'].split(' ')[0].replace('_kernel', '') + '_us'] = d.get('avg_launch_us')
     elif args.workload == 'train_gumm':
         # BASELINE.json configs[2]: GaussianUnknownMeanMarsaglia (stochastic control flow -> variable-length traces, one
         # proposal head per address), batch 1024, hidden 512. Ragged minibatches are packed on the host and uploaded

@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void first_row_all_kernel(const ObsFusedArgs a
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's h stores are acknowledged
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release / acquire on `ready`: the count publishes the workgroup's h and c stores at agent scope
+        if (tid == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // ---- head layer 1 (first_row_head_kernel), the last arriver finishes layer 2 ----
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(256) void first_row_all_kernel(const ObsFusedArgs a
             __builtin_amdgcn_s_sleep(4);
             if (++spins > (1 << 22)) __builtin_trap();
         }
+        (void)__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (j < hid) {
         float acc = 0.0f;
@@ -694,7 +696,25 @@ int is_first_statement(const pp_net* net, const float* P, const float* obs, int 
     const int H = net->lstm_dim;
     GatherDims gd{net->e_obs, net->smp_dim, net->dtype_dim, net->addr_dim, net->lstm_in};
     const char* ev = getenv("PP_IS_FIRST");      // 1 (default): one launch; 2: the LSTM and the head launches separately (A/B)
-    const bool one = !(ev && atoi(ev) == 2) && H <= 1024 && cdiv(H, 16) + cdiv(ad.hid, 4) <= 200;
+    // The head workgroups of the one-launch variant WAIT for the LSTM workgroups of the same launch: every workgroup of the
+    // grid must be resident at once (gated on an occupancy query like panel16_supported, not on a block count
+    // alone) - otherwise the two-launch path
+    const int grid_one = cdiv(H, 16) + cdiv(ad.hid, 4);
+    bool one = !(ev && atoi(ev) == 2) && H <= 1024 && grid_one <= 200;
+    if (one) {
+        static int resident[4] = {-1, -1, -1, -1};
+        const int vi = a.n_obs <= 1 ? 0 : a.n_obs <= 2 ? 1 : a.n_obs <= 4 ? 2 : 3;
+        if (resident[vi] < 0) {
+            int per_cu = 0, dev = 0, cus = 0;
+            const void* fn = vi == 0 ? (const void*)first_row_all_kernel<1> : vi == 1 ? (const void*)first_row_all_kernel<2>
+                           : vi == 2 ? (const void*)first_row_all_kernel<4> : (const void*)first_row_all_kernel<8>;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess)
+                per_cu = cus = 0;
+            resident[vi] = per_cu * cus;
+        }
+        one = resident[vi] >= grid_one;
+    }
     unsigned int* tk = reinterpret_cast<unsigned int*>(w.ticket);
     if (one) {
 #define PP_FIRST_ALL(N)                                                                                                          \

@@ -8,6 +8,7 @@ fused prior/likelihood log-prob kernels that accumulate the per-particle log-wei
 (log w = sum_t [log p(v_t) - log q(v_t)] + sum_j log p(y_j | .), pyprob/trace.py:123-125).
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -21,7 +22,7 @@ class ISRunner:
         self.eng = engine
         self.lib = engine.lib
         self.dev = engine.device
-        self.e_obs = torch.zeros(engine.spec.e_obs + 8, dtype=torch.float32, device=self.dev)
+        self.e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
         self.ws = None
         self.ws_bytes = 0
         self.n = 0
@@ -30,6 +31,11 @@ class ISRunner:
         self._stats = torch.zeros(8, dtype=torch.float64, device=self.dev)
         self._st = None        # stream of the current posterior call (begin); None = the default stream
         self._stats_scratch = torch.zeros(L.PP_IS_STATS_SCRATCH, dtype=torch.float64, device=self.dev)
+
+    def e_obs_floats(self):
+        """Size of the embedding row buffer: pp_is_first_statement writes the (at most 8) observation copies at
+        `e_out[round4(e_obs) + lane]` (include/pyprob_amd.h) - round4(e_obs) + 8 floats, not e_obs + 8."""
+        return ((self.eng.spec.e_obs + 3) & ~3) + 8
 
     def _pins(self, k):
         """Pinned host staging of a posterior call: the observation vector (read in place by pp_is_first_statement, or copied
@@ -73,8 +79,8 @@ class ISRunner:
             self._pins(k)
             self._obs_np[:k] = vals
             self._obs_dev.copy_(self._obs_pin, non_blocking=True)
-            if self.e_obs.numel() != self.eng.spec.e_obs + 8 or self.e_obs.device != self.dev:
-                self.e_obs = torch.zeros(self.eng.spec.e_obs + 8, dtype=torch.float32, device=self.dev)
+            if self.e_obs.numel() != self.e_obs_floats() or self.e_obs.device != self.dev:
+                self.e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
             self._st = L.stream_ptr()
             L.check(self.lib.pp_is_init(C.byref(self.eng.net), self.eng.params.data_ptr(), self._obs_dev.data_ptr(),
                                         self.e_obs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_init')
@@ -200,9 +206,11 @@ class ISRunner:
         self.begin(n, offset)
         st = self._st
         params, ws = self.eng.params.data_ptr(), self.ws.data_ptr()
-        first = plan.get('first')
-        if first is None:
-            first = plan['first'] = bool(k <= 8 and lib.pp_is_first_statement_supported(net, plan['addr']))
+        # (asked per call, not cached in the plan: the C side re-reads PP_IS_FIRST on every call, a plan recorded under another
+        # setting must take the staged path instead of failing with PP_EINVAL - ADVICE r05)
+        first = plan['first'] = bool(k <= 8 and lib.pp_is_first_statement_supported(net, plan['addr']))
+        if self.e_obs.numel() != self.e_obs_floats():
+            self.e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
         if first:
             L.check(lib.pp_is_first_statement(net, params, self._obs_pin.data_ptr(), plan['addr'], self.e_obs.data_ptr(),
                                               self.h.data_ptr(), self.c.data_ptr(), ws, self.ws_bytes, st), 'pp_is_first_statement')
@@ -237,13 +245,20 @@ class ISRunner:
                                 lw.data_ptr(), 1, int(seed), int(self.offset), self._stats_pin.data_ptr(),
                                 self._stats_scratch.data_ptr(), ws, self.ws_bytes, st), 'pp_is_fused')
         self.prev_value = self.last_value = values
-        spins = 0
+        # a short busy poll (the record arrives ~40 us after the launch), then yield the GIL between polls, bounded by TIME: after
+        # one second let the runtime report what happened (also the path of non-coherent host allocations, HIP_HOST_COHERENT=0)
+        spins, deadline = 0, None
         while snp[5] < 0.0:
             spins += 1
-            if spins > 2000000:      # (~1 s of polling: not a posterior call's time scale - let the runtime report what happened)
-                torch.cuda.synchronize(self.dev)
-                if snp[5] < 0.0:
-                    raise L.HipLibraryError('pp_is_fused: the statistics never arrived in host memory')
+            if spins > 4000:
+                now = time.perf_counter()
+                if deadline is None:
+                    deadline = now + 1.0
+                elif now > deadline:
+                    torch.cuda.synchronize(self.dev)
+                    if snp[5] < 0.0:
+                        raise L.HipLibraryError('pp_is_fused: the statistics never arrived in host memory')
+                time.sleep(0)
         return values, lw, self._stats_dict(snp)
 
     PRIOR_KIND = {'Normal': 0, 'Uniform': 1}

@@ -315,6 +315,66 @@ class Model:
                 out.append(cell.cell_contents)
         except (KeyError, ValueError):
             return None
+        ind = self._plan_indirect(reads)
+        if ind is None:
+            return None
+        for _, _, v in ind:
+            out.append(v)
+        return out
+
+    _PLAN_CODE_MODULES = ('math', 'torch', 'numpy', 'builtins', 'operator', 'functools', 'itertools')
+
+    def _plan_indirect(self, reads):
+        """What the program can read THROUGH an object it names: for every module or class reached from a module
+        global, a closure cell or an instance attribute - `settings.PRIOR_MEAN`, `Config.MU` - the attributes of it that the
+        program's bytecode names (co_names holds the name after the LOAD_GLOBAL / LOAD_ATTR); for every plain function kept
+        as an instance attribute and named by the program (`self.helper = other_fn`) its code object, defaults and closure
+        contents. Returns [(label, name, value)] in a fixed order, or None when something cannot be enumerated. Modules that
+        are code only (math, torch, numpy, this package) are not walked."""
+        import types
+        codes, names, cells, globs = reads
+        pkg = __name__.split('.')[0]
+        holders = []
+        try:
+            for k, g in globs:
+                holders.append(('g:' + k, g[k]))
+            for k, cell in cells:
+                holders.append(('f:' + k, cell.cell_contents))
+        except (KeyError, ValueError):
+            return None
+        for k, v in sorted(vars(self).items()):
+            if k not in self._BASE_ATTRS and k in names:
+                holders.append(('i:' + k, v))
+        out = []
+        sorted_names = sorted(names)
+        for label, h in holders:
+            if isinstance(h, types.ModuleType):
+                root = (getattr(h, '__name__', '') or '').split('.')[0]
+                if root in self._PLAN_CODE_MODULES or root == pkg:
+                    continue
+                d = vars(h)
+                for n in sorted_names:
+                    if n in d:
+                        out.append((label, n, d[n]))
+            elif isinstance(h, type):
+                if h is type(self) or (getattr(h, '__module__', '') or '').split('.')[0] in self._PLAN_CODE_MODULES + (pkg,):
+                    continue
+                for n in sorted_names:
+                    for klass in h.__mro__:
+                        if klass is object:
+                            break
+                        if n in vars(klass):
+                            out.append((label, n, vars(klass)[n]))
+                            break
+            elif isinstance(h, types.FunctionType) and label.startswith('i:'):
+                out.append((label, '__code__', h.__code__))
+                out.append((label, '__defaults__', h.__defaults__))
+                out.append((label, '__kwdefaults__', h.__kwdefaults__))
+                try:
+                    for cn, cell in zip(h.__code__.co_freevars, h.__closure__ or ()):
+                        out.append((label, 'cell:' + cn, cell.cell_contents))
+                except ValueError:
+                    return None
         return out
 
     def _plan_class_names(self, names):
@@ -384,6 +444,25 @@ class Model:
                 if fp is None:
                     return None
                 plain.append((tag, k, fp))
+        # values read through a module / class / instance-attribute function the program names: by value, or no plan
+        ind = self._plan_indirect(reads)
+        if ind is None:
+            return None
+        extra_codes = []
+        for label, n, v in ind:
+            if isinstance(v, types.CodeType):
+                extra_codes.append(v)
+                continue
+            if isinstance(v, (types.ModuleType, types.BuiltinFunctionType)):
+                continue
+            if isinstance(v, (types.FunctionType, types.MethodType, type, staticmethod, classmethod, property)) or callable(v) \
+                    and not isinstance(v, (torch.Tensor, np.ndarray)):
+                return None          # code (or an object with state) reached indirectly: its reads are not analysed - no plan
+            fp = self._fingerprint(v)
+            if fp is None:
+                return None
+            plain.append(('x', label, n, fp))
+        codes = codes + tuple(extra_codes)
         return (eng.token, len(eng.spec.addresses), int(num_traces), tuple(sorted(observe or {})), float(likelihood_importance),
                 tuple(plain), codes)
 

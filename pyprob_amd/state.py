@@ -179,7 +179,7 @@ class ParticleTensor(torch.Tensor):
         if not shared:
             return False
         with torch._C.DisableTorchFunctionSubclass():
-            return self.data_ptr() in shared
+            return self.untyped_storage()._cdata in shared
 
     def __iadd__(self, other):
         return self + other if self._shared_result() else super().__iadd__(other)
@@ -236,7 +236,11 @@ class ParticleTensor(torch.Tensor):
                 if key is not None:
                     hit = memo.get(key)
                     if hit is not None and hit[0]._version == hit[1]:
-                        ls.memo_shared.add(hit[0].data_ptr())   # handed out a second time: two names of the program share it now
+                        # handed out a second time: two names of the program share it now. Keyed by STORAGE identity (views
+                        # of the result are covered) and the tensor is held for the rest of the call, so that neither
+                        # memo.clear() nor the program dropping both names can hand its address to an unrelated tensor
+                        with torch._C.DisableTorchFunctionSubclass():
+                            ls.memo_shared[hit[0].untyped_storage()._cdata] = hit[0]
                         return hit[0]
                     out = func(*args)
                     if isinstance(out, torch.Tensor):
@@ -252,7 +256,7 @@ class ParticleTensor(torch.Tensor):
         elif memo is not None and ls.memo_shared and args and isinstance(args[0], torch.Tensor) and \
                 (name == '__setitem__' or (name.endswith('_') and not name.startswith('__'))):
             with torch._C.DisableTorchFunctionSubclass():
-                shared = args[0].data_ptr() in ls.memo_shared
+                shared = args[0].untyped_storage()._cdata in ls.memo_shared
             if shared:
                 raise RuntimeError('lock-step executor: in-place `%s` on a tensor that two expressions of the program share '
                                    '(a reused elementwise result); write it out of place or set PP_IS_MEMO=0' % name)
@@ -378,7 +382,7 @@ class LockStepState(PathExecutor):
         # what Model._traces_lockstep needs to recognise a program whose whole call is ONE draw + ONE fused pass (launch plan,
         # model.py): the number of flushes, where every deferred term's value came from, anything that read a draw early
         self.memo = {} if os.environ.get('PP_IS_MEMO', '1') != '0' else None     # ParticleTensor._PURE results of this call
-        self.memo_shared = set()      # storage addresses of memoised results handed out more than once
+        self.memo_shared = {}         # storage identity -> memoised result handed out more than once (kept alive for the call)
         self.memo_bytes = 0
         self.flushes = 0
         self.plan_terms = []          # (term, source, scale): source = ('obs', name) | ('value',) | ('const', tensor)

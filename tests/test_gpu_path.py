@@ -44,16 +44,15 @@ def test_golden_loss_logprob_and_gradients(golden):
             ref = ref.reshape(len(rows), len(rows)).sum(1)
         np.testing.assert_allclose(lp_tm[rows], ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
     # every parameter gradient against loss.backward() of the reference
+    # (the reference's gradients are fp32 themselves: the bar is 1e-4 of a tensor's largest element + the absolute fp32
+    # summation floor of helpers.grad_check - measured against these goldens on MI355X: profiles/r06_grad_errors.jsonl)
     g = eng.grad_dict()
-    worst = ('', 0.0)
     for i, n in enumerate(meta['param_names']):
         ref = loss['g%d' % i]
-        err = np.abs(g[n] - ref).max() / max(np.abs(ref).max(), 1e-6)
-        if err > worst[1]:
-            worst = (n, err)
         if not meta['has_grad'][i]:
             assert np.all(g[n] == 0), n
-    assert worst[1] < 1e-3, worst
+            continue
+        grad_check('golden_%s/%s' % (case, n), g[n], ref, 1e-4, 1e-7)
     # presence map = which tensors had grad != None in the reference
     act = eng.presence().cpu().numpy()
     names = list(eng.spec.tensors.keys())
@@ -188,8 +187,14 @@ def test_resident_loop_matches_the_per_step_calls():
     assert not status.cpu().numpy().any() and not status2.cpu().numpy().any()
     np.testing.assert_allclose(got, ref, rtol=2e-5)
     # (Adam normalises the gradient: an element whose gradient is at round-off level may move by +-lr in either run)
+    # per element: Adam normalises the gradient, so an element whose gradient is at round-off level may move by +-lr in either
+    # run and step (a sign flip of m / sqrt(v)): no element may differ by more than the sum of the learning rates both ways, and
+    # all but a handful of such elements must agree to fp32 round-off of the seven updates
     pa, pb_ = a.params.cpu().numpy().astype(np.float64), b.params.cpu().numpy().astype(np.float64)
-    assert np.linalg.norm(pa - pb_) < 5e-3 * np.linalg.norm(pa), np.linalg.norm(pa - pb_) / np.linalg.norm(pa)
+    diff = np.abs(pa - pb_)
+    assert diff.max() <= 2.0 * sum(lrs) * 1.001, diff.max()
+    loose = diff > 2e-6 + 2e-5 * np.abs(pa)
+    assert loose.mean() < 2e-3, (loose.mean(), diff.max())
     assert torch.equal(b.tensor_step.cpu(), a.tensor_step.cpu())
 
 

@@ -12,7 +12,7 @@ from pyprob_amd.state import ParticleTensor
 
 @pytest.fixture
 def ls():
-    fake = types.SimpleNamespace(memo={}, memo_shared=set(), memo_bytes=0, draw=None, width=-1)
+    fake = types.SimpleNamespace(memo={}, memo_shared={}, memo_bytes=0, draw=None, width=-1)
     old = state._lock_step
     state._lock_step = fake
     try:
@@ -52,6 +52,26 @@ def test_identical_expressions_are_served_once_and_stay_independent(ls):
         b.add_(1.0)                                # a method-call form can not be redirected: loud, not silent
     with pytest.raises(RuntimeError, match='in-place'):
         b[0] = 5.0
+    with pytest.raises(RuntimeError, match='in-place'):
+        b[1:].add_(1.0)                            # a partial VIEW of the shared result has another data_ptr: same storage
+
+
+def test_a_shared_result_outlives_the_memo(ls, monkeypatch):
+    """ADVICE r05 (state.py:248): the shared set is keyed by storage identity and keeps the tensor, so a cleared memo cannot
+    hand the address of a shared result to an unrelated tensor (spurious error / silent redirect of its +=)."""
+    monkeypatch.setattr(ParticleTensor, 'MEMO_BYTES', 2 * 4 * 64)
+    x = P(torch.arange(64.0))
+    a = x * x
+    b = x * x
+    key = b.as_subclass(torch.Tensor).untyped_storage()._cdata
+    assert key in ls.memo_shared
+    for k in range(8):                             # the memo overflows and is cleared
+        _ = x * float(k + 2)
+    del a, b
+    assert key in ls.memo_shared and ls.memo_shared[key] is not None      # still alive: its address cannot be reused
+    fresh = x + 100.0
+    fresh += 1.0                                   # an unrelated tensor: in place, no error
+    assert torch.equal(fresh.as_subclass(torch.Tensor), torch.arange(64.0) + 101.0)
 
 
 def test_unshared_results_may_be_modified_in_place(ls):

@@ -170,3 +170,89 @@ def test_engine_identity_is_a_token_not_an_address():
     m._inference_network = net
     assert m._lockstep_plan_key(100, {'obs0': 1.0}, 1.0, (), {}) != k0
     assert m._lockstep_plan_key(100, {'obs0': 1.0}, 1.0, (1,), {}) is None        # call arguments: no plan
+
+
+# ---- values read THROUGH a module, a class or an instance-attribute function (model.py:381) -------------------
+settings = types.ModuleType('user_settings')
+settings.PRIOR_MEAN = 1.0
+settings.helper = lambda x: x
+
+
+class Config:
+    MU = 1.5
+    SIGMA = 2.0
+
+
+def _scaled(x, k=2.0):
+    return k * x
+
+
+class ThroughModule(Model):
+    def forward(self):
+        mu = pyprob.sample(Normal(settings.PRIOR_MEAN, 1.0))
+        pyprob.observe(Normal(mu, Config.SIGMA), name='obs0')
+        return mu
+
+
+def test_constants_read_through_a_module_or_a_class_are_in_the_key():
+    m = ThroughModule()
+    k0 = _key(m)
+    assert k0 is not None
+    settings.PRIOR_MEAN = 4.0
+    try:
+        k1 = _key(m)
+        assert k1 is not None and k1 != k0          # (the identity fast path notices too: the float is a new object)
+    finally:
+        settings.PRIOR_MEAN = 1.0
+    assert _key(m) == k0
+    Config.SIGMA = 3.0
+    try:
+        k2 = _key(m)
+        assert k2 is not None and k2 != k0
+        Config.SIGMA = object()                      # no value fingerprint: no plan
+        assert _key(m) is None
+    finally:
+        Config.SIGMA = 2.0
+    assert _key(m) == k0
+
+
+class ThroughModuleFunction(Model):
+    def forward(self):
+        mu = pyprob.sample(Normal(settings.helper(1.0), 1.0))
+        pyprob.observe(Normal(mu, 1.0), name='obs0')
+        return mu
+
+
+def test_code_reached_through_a_module_rules_the_plan_out():
+    assert _key(ThroughModuleFunction()) is None     # settings.helper's reads are not analysed: forward() runs every call
+
+
+class InstanceFunction(Model):
+    def __init__(self, fn):
+        super().__init__()
+        self.helper = fn
+
+    def forward(self):
+        mu = pyprob.sample(Normal(self.helper(1.0), 1.0))
+        pyprob.observe(Normal(mu, 1.0), name='obs0')
+        return mu
+
+
+def test_function_kept_on_the_instance_is_keyed_by_code_defaults_and_closure():
+    m = InstanceFunction(_scaled)
+    k0 = _key(m)
+    assert k0 is not None
+    old = _scaled.__defaults__
+    _scaled.__defaults__ = (3.0,)
+    try:
+        k1 = _key(m)
+        assert k1 is not None and k1 != k0
+    finally:
+        _scaled.__defaults__ = old
+    assert _key(m) == k0
+    m.helper = lambda x: 2.0 * x                      # another function: another key
+    assert _key(m) not in (None, k0)
+    scale = [2.0]
+    state = object()
+    m.helper = lambda x: x if state else scale[0]    # a closure over an object without a value: no plan
+    assert _key(m) is None
