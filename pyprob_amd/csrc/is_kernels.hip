@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void first_row_all_kernel(const ObsFusedArgs a
                                                             float* __restrict__ e_out, int e4, float* __restrict__ h,
                                                             float* __restrict__ c, int nl, int64_t w1, int64_t b1, int hid,
                                                             int64_t w2, int64_t b2, int n_out, float* __restrict__ A1,
-                                                            float* __restrict__ Y, unsigned int* ticket, unsigned int* ready) {
+                                                            float* __restrict__ Y, unsigned int* ticket, unsigned int* ready, const int acqrel) {
     __shared__ float lds[10240 + 1024];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -459,7 +459,12 @@ __global__ __launch_bounds__(256) void first_row_all_kernel(const ObsFusedArgs a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's h stores are acknowledged
         __syncthreads();
         // release / acquire on `ready`: the count publishes the workgroup's h and c stores at agent scope
-        if (tid == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (PP_IS_FIRST_SYNC=0: relaxed count behind the waves' own s_waitcnt - the stores above are agent-scope atomics that
+        // bypass the non-coherent caches; A/B of the fence's cost)
+        if (tid == 0) {
+            if (acqrel) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     // ---- head layer 1 (first_row_head_kernel), the last arriver finishes layer 2 ----
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256) void first_row_all_kernel(const ObsFusedArgs a
             __builtin_amdgcn_s_sleep(4);
             if (++spins > (1 << 22)) __builtin_trap();
         }
-        (void)__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (acqrel) (void)__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (j < hid) {
         float acc = 0.0f;
@@ -716,11 +721,18 @@ int is_first_statement(const pp_net* net, const float* P, const float* obs, int 
         one = resident[vi] >= grid_one;
     }
     unsigned int* tk = reinterpret_cast<unsigned int*>(w.ticket);
+    // `ready` with release / acquire semantics (PP_IS_FIRST_SYNC=1) or relaxed behind the producers' own s_waitcnt vmcnt(0) +
+    // barrier (default). Measured (profiles/r06c_ab.txt): the agent-scope release costs every LSTM workgroup an L2 write-back and
+    // the call 3.5 us of ~70 (0.0735 vs 0.0700 ms at 10^6 particles). The relaxed protocol is the hand-off protocol of
+    // handoff.hpp: h and the count are agent-scope atomics (they bypass the per-XCD caches), a wave's stores are acknowledged
+    // before its workgroup's count goes up, a consumer wave issues its h loads after its count load has returned.
+    const char* es = getenv("PP_IS_FIRST_SYNC");
+    const int acqrel = es ? atoi(es) : 0;
     if (one) {
 #define PP_FIRST_ALL(N)                                                                                                          \
     hipLaunchKernelGGL(first_row_all_kernel<N>, dim3(cdiv(H, 16) + cdiv(ad.hid, 4)), dim3(256), 0, st, a, gd, P, net->addr_table, \
                        obs, addr_id, net->w_ih, net->b_ih, net->b_hh, H, e_out, (int)w.e4, h, c, cdiv(H, 16), ad.w1, ad.b1,       \
-                       ad.hid, ad.w2, ad.b2, ad.n_out, w.A1, w.Y, tk, tk + 1)
+                       ad.hid, ad.w2, ad.b2, ad.n_out, w.A1, w.Y, tk, tk + 1, acqrel)
         if (a.n_obs <= 1) PP_FIRST_ALL(1);
         else if (a.n_obs <= 2) PP_FIRST_ALL(2);
         else if (a.n_obs <= 4) PP_FIRST_ALL(4);

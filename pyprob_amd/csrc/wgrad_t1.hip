@@ -137,9 +137,27 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
     const int lda = g.p[pi].lda, ldb = g.p[pi].ldb, ldc = g.p[pi].ldc, M = g.p[pi].M, N = g.p[pi].N, nt = g.p[pi].nt;
     const int K = g.p[pi].K, ks = g.p[pi].ks;
     const int local = bx - g.p[pi].first;
-    const int tiles = ((M + 63) >> 6) * nt;
-    const int s = local / tiles, t = local - s * tiles;
-    const int tm = t / nt, tn = t - tm * nt;
+    const int mtg = g.p[pi].mtg;
+    int s, tm, tn;
+    if (mtg > 0) {
+        // XCD-aware order (workgroups go to the 8 XCDs round-robin by block index, each XCD has its own L2): block r (mod 8)
+        // of the problem owns the row tiles tm = r (mod 8) - all their column tiles and row splits. An XCD then fetches ITS
+        // M / 8 columns of A once and all of B; with the column tile fastest (below) every XCD owned one column tile of B and
+        // streamed ALL of A - the larger operand (dG: 4H columns) - from the Infinity Cache: 8 x |A| + |B| instead of
+        // |A| + 8 x |B| per launch. Row tiles past the end of a ragged last group are empty workgroups.
+        const int r = local & 7, u = local >> 3;
+        const int tmg = u % mtg, v = u / mtg;
+        tn = v % nt;
+        s = v / nt;
+        tm = tmg * 8 + r;
+        if (tm * 64 >= M) return;
+    } else {
+        const int tiles = ((M + 63) >> 6) * nt;
+        s = local / tiles;
+        const int t = local - s * tiles;
+        tm = t / nt;
+        tn = t - tm * nt;
+    }
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = tm * 64, n0 = tn * 64;
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_t1_kernel(const WgradT1Args g, c
 bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1Args& out) {
     static const int env = getenv("PP_WGRAD_T1") ? atoi(getenv("PP_WGRAD_T1")) : 1;
     static const int env_s = 0;
+    static const int env_xmap = getenv("PP_WGRAD_XMAP") ? atoi(getenv("PP_WGRAD_XMAP")) : 1;      // A/B: 0 = column tiles fastest
     static const bool env_wgs_set = false;
     static const int env_wgs = 240;
     if (!env || deterministic_mode() || n <= 0) return false;
@@ -301,7 +320,9 @@ bool wgrad_t1_build(const pp_gemm_args* q, const GemmHole* holes, int n, WgradT1
         p.S = S;
         p.ks = ((cdiv(p.K, S) + 3) / 4) * 4;
         p.first = first;
-        first += cdiv(p.M, 64) * p.nt * S;
+        const int mt = cdiv(p.M, 64);
+        p.mtg = (env_xmap && mt >= 8) ? cdiv(mt, 8) : 0;
+        first += (p.mtg ? p.mtg * 8 : mt) * p.nt * S;
     }
     out.n_blocks = first;
     return true;

@@ -18,6 +18,7 @@ struct WgradT1Prob {
     int nt;              // 64-column tiles
     int K, S, ks;        // rows, row splits, rows per split (multiple of 4)
     int first;           // first workgroup of the problem in the launch
+    int mtg;             // > 0: XCD-aware tile order (groups of 8 row tiles, see wgrad_t1_kernel); 0: column tiles fastest
 };
 
 struct WgradT1Args {

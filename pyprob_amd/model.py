@@ -169,7 +169,7 @@ class Model:
 
     # attributes the Model base class itself keeps on the instance (never read by a program as constants)
     _BASE_ATTRS = frozenset(('_inference_network', '_lockstep_plans', '_lock_step_ok', '_last_prior_resident', '_plan_code_cache',
-                             '_plan_key_cache'))
+                             '_plan_key_cache', '_plan_indirect_cache'))
 
     @staticmethod
     def _fingerprint(v):
@@ -334,31 +334,27 @@ class Model:
         import types
         codes, names, cells, globs = reads
         pkg = __name__.split('.')[0]
-        holders = []
-        try:
-            for k, g in globs:
-                holders.append(('g:' + k, g[k]))
-            for k, cell in cells:
-                holders.append(('f:' + k, cell.cell_contents))
-        except (KeyError, ValueError):
-            return None
-        for k, v in sorted(vars(self).items()):
-            if k not in self._BASE_ATTRS and k in names:
-                holders.append(('i:' + k, v))
+        cache = self.__dict__.get('_plan_indirect_cache')
+        if cache is None or cache[0] is not reads:
+            cache = self.__dict__['_plan_indirect_cache'] = (reads, tuple(sorted(names)))
+        sorted_names = cache[1]
         out = []
-        sorted_names = sorted(names)
-        for label, h in holders:
+        code_modules = self._PLAN_CODE_MODULES
+
+        def walk(label, h, instance_attr):
+            # (called per posterior call from the key's fast path: the common holder - a code-only module, a class of this
+            # package, a plain value - costs two type checks)
             if isinstance(h, types.ModuleType):
                 root = (getattr(h, '__name__', '') or '').split('.')[0]
-                if root in self._PLAN_CODE_MODULES or root == pkg:
-                    continue
+                if root in code_modules or root == pkg:
+                    return True
                 d = vars(h)
                 for n in sorted_names:
                     if n in d:
                         out.append((label, n, d[n]))
             elif isinstance(h, type):
-                if h is type(self) or (getattr(h, '__module__', '') or '').split('.')[0] in self._PLAN_CODE_MODULES + (pkg,):
-                    continue
+                if h is type(self) or (getattr(h, '__module__', '') or '').split('.')[0] in code_modules + (pkg,):
+                    return True
                 for n in sorted_names:
                     for klass in h.__mro__:
                         if klass is object:
@@ -366,7 +362,7 @@ class Model:
                         if n in vars(klass):
                             out.append((label, n, vars(klass)[n]))
                             break
-            elif isinstance(h, types.FunctionType) and label.startswith('i:'):
+            elif instance_attr and isinstance(h, types.FunctionType):
                 out.append((label, '__code__', h.__code__))
                 out.append((label, '__defaults__', h.__defaults__))
                 out.append((label, '__kwdefaults__', h.__kwdefaults__))
@@ -374,7 +370,21 @@ class Model:
                     for cn, cell in zip(h.__code__.co_freevars, h.__closure__ or ()):
                         out.append((label, 'cell:' + cn, cell.cell_contents))
                 except ValueError:
+                    return False
+            return True
+        try:
+            for k, g in globs:
+                if not walk('g:' + k, g[k], False):
                     return None
+            for k, cell in cells:
+                if not walk('f:' + k, cell.cell_contents, False):
+                    return None
+        except (KeyError, ValueError):
+            return None
+        base = self._BASE_ATTRS
+        for k, v in vars(self).items():      # (insertion order: stable for one instance)
+            if k in names and k not in base and not walk('i:' + k, v, True):
+                return None
         return out
 
     def _plan_class_names(self, names):

@@ -102,6 +102,9 @@ class RecordedInferenceNetworkLSTM(nn.Module):
         self._total_train_iterations = 0
         self._history_num_params = []
         self._history_num_params_trace = []
+        self._distributed_train_loss = torch.tensor(0.)
+        self._distributed_history_train_loss = []
+        self._distributed_history_train_loss_trace = []
         self._on_cuda = False
         self._device = torch.device('cpu')
         self._layers_proposal = nn.ModuleDict()
