@@ -46,14 +46,53 @@ from .hip_network import _PROPOSAL_DIST, _HipNetworkMixin  # noqa: F401
 from .nn import ProposalSample
 
 
-class InferenceNetworkLSTMHip(_HipNetworkMixin, _RefLSTM):
+class _FastOptimize:
+    """`optimize` (inference_network.py:381-599) of the HIP-backed classes: online training with Adam goes through the batched
+    data path of pyprob_amd/pyprob_host.py (prior traces generated in lock step, runs of minibatches inside one C call) when
+    the program allows it; everything else - offline datasets, validation, schedulers, SGD / LARC, a log file, a process group,
+    `PYPROB_HIP_FAST_TRAIN=0` - is the reference's own loop over `_loss` / `HipAdam`, unchanged."""
+
+    def optimize(self, num_traces, dataset, dataset_valid=None, num_traces_end=1e9, batch_size=64, valid_every=None,
+                 optimizer_type=None, learning_rate_init=0.0001, learning_rate_end=1e-6, learning_rate_scheduler_type=None,
+                 momentum=0.9, weight_decay=1e-5, save_file_name_prefix=None, save_every_sec=600, distributed_backend=None,
+                 distributed_params_sync_every_iter=10000, distributed_num_buckets=10, dataloader_offline_num_workers=0,
+                 stop_with_bad_loss=False, log_file_name=None):
+        from pyprob import LearningRateScheduler, Optimizer
+        from pyprob.nn import OnlineDataset
+        optimizer_type = Optimizer.ADAM if optimizer_type is None else optimizer_type
+        learning_rate_scheduler_type = LearningRateScheduler.NONE if learning_rate_scheduler_type is None else learning_rate_scheduler_type
+        fast = (type(dataset) is OnlineDataset and dataset_valid is None and distributed_backend is None and log_file_name is None
+                and (self._optimizer_type or optimizer_type) == Optimizer.ADAM
+                and (self._learning_rate_scheduler_type or learning_rate_scheduler_type) == LearningRateScheduler.NONE
+                and not self._layers_pre_generated and os.environ.get('PYPROB_HIP_FAST_TRAIN', '1') != '0')
+        if fast:
+            from . import pyprob_host
+            if pyprob_host.optimize_online(self, dataset, num_traces, batch_size, learning_rate_init, learning_rate_end, weight_decay,
+                                           num_traces_end, save_file_name_prefix, save_every_sec, stop_with_bad_loss,
+                                           optimizer_type, momentum):
+                self._hip_last_optimize = 'batched (pyprob_host.optimize_online)'
+                return
+        self._hip_last_optimize = "pyprob's loop"
+        return super().optimize(num_traces=num_traces, dataset=dataset, dataset_valid=dataset_valid, num_traces_end=num_traces_end,
+                                batch_size=batch_size, valid_every=valid_every, optimizer_type=optimizer_type,
+                                learning_rate_init=learning_rate_init, learning_rate_end=learning_rate_end,
+                                learning_rate_scheduler_type=learning_rate_scheduler_type, momentum=momentum,
+                                weight_decay=weight_decay, save_file_name_prefix=save_file_name_prefix,
+                                save_every_sec=save_every_sec, distributed_backend=distributed_backend,
+                                distributed_params_sync_every_iter=distributed_params_sync_every_iter,
+                                distributed_num_buckets=distributed_num_buckets,
+                                dataloader_offline_num_workers=dataloader_offline_num_workers,
+                                stop_with_bad_loss=stop_with_bad_loss, log_file_name=log_file_name)
+
+
+class InferenceNetworkLSTMHip(_FastOptimize, _HipNetworkMixin, _RefLSTM):
     _hip_kind = 'lstm'
 
     def _init_layers(self):
         super()._init_layers()          # nn.LSTM with the reference's initialisation; bound at the first _polymorph
 
 
-class InferenceNetworkFeedForwardHip(_HipNetworkMixin, _RefFeedForward):
+class InferenceNetworkFeedForwardHip(_FastOptimize, _HipNetworkMixin, _RefFeedForward):
     _hip_kind = 'feedforward'
 
 
@@ -84,6 +123,7 @@ _original_traces = None
 def _traces_with_coroutines(self, num_traces=10, trace_mode=None, prior_inflation=None, inference_engine=None,
                             inference_network=None, map_func=None, silent=False, observe=None, file_name=None,
                             likelihood_importance=1., *args, **kwargs):
+    import pyprob.model as M
     from pyprob import InferenceEngine, PriorInflation, TraceMode, state
     from pyprob.distributions import Empirical
     trace_mode = TraceMode.PRIOR if trace_mode is None else trace_mode
@@ -92,6 +132,17 @@ def _traces_with_coroutines(self, num_traces=10, trace_mode=None, prior_inflatio
     fast = (inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
             and isinstance(inference_network, _HipNetworkMixin) and num_traces > 1 and _have_greenlet()
             and os.environ.get('PYPROB_HIP_COROUTINES', '1') != '0')
+    batched = (inference_engine == InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
+               and isinstance(inference_network, _HipNetworkMixin) and num_traces > 1 and file_name is None
+               and trace_mode == TraceMode.POSTERIOR and prior_inflation == PriorInflation.DISABLED
+               and map_func is getattr(M, 'trace_result', None))
+    if batched:
+        # posterior_results: only forward()'s return value of every particle is asked for - all particles in lock step when the
+        # program allows it (pyprob_host.traces_lockstep; None = it does not)
+        from . import pyprob_host
+        emp = pyprob_host.traces_lockstep(self, inference_network, num_traces, observe, likelihood_importance, args, kwargs)
+        if emp is not None:
+            return emp
     if not fast:
         return _original_traces(self, num_traces=num_traces, trace_mode=trace_mode, prior_inflation=prior_inflation,
                                 inference_engine=inference_engine, inference_network=inference_network, map_func=map_func,

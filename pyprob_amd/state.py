@@ -74,6 +74,9 @@ _lock_step = None      # LockStepState when N particles advance together
 _coroutine = None      # coroutine.CoroutineIS while particle coroutines run an unmodified program (one greenlet per particle)
 
 
+_address_frame_skip = 0
+
+
 def _make_address(distribution, address):
     if address is None:
         base = _extract_address_from_caller() + '__' + distribution._address_suffix
@@ -126,8 +129,9 @@ def _assignment_target(frame):
 def _extract_address_from_caller():
     """'<instruction offset>__<root function>__..__<calling function>__<assignment target>' exactly as the reference
     builds it (pyprob/state.py:29-47), so that networks and datasets interchange."""
-    # one extra frame because of _make_address
-    frame = sys._getframe(3)
+    # one extra frame because of _make_address; `_address_frame_skip` more when sample / observe were entered through a
+    # wrapper (pyprob_amd/pyprob_host.py: pyprob's own entry points forwarding to this runtime)
+    frame = sys._getframe(3 + _address_frame_skip)
     ip = frame.f_lasti
     names = [_assignment_target(frame)]
     while frame is not None:

@@ -33,8 +33,22 @@ import oracle_ops  # noqa: E402  (CPU kernels of the operators)
 import pyprob_amd.binding as hip  # noqa: E402
 from oracle import ic_oracle as O  # noqa: E402
 
+
+
+def _cpu_engine(spec, device):
+    eng = oracle_ops.CpuBufferEngine(spec)
+    eng._use_ops = True                    # (ICEngine's compute methods go through the operators: oracle-backed here)
+    return eng
+
+
 hip._HipNetworkMixin._hip_device = 'cpu'
-hip._HipNetworkMixin._hip_engine_factory = staticmethod(lambda spec, device: oracle_ops.CpuBufferEngine(spec))
+hip._HipNetworkMixin._hip_engine_factory = staticmethod(_cpu_engine)
+os.environ['PP_PYTHON_LOOP'] = '1'         # the runs of minibatches inside one C call (pp_train_steps) need the device
+# The tests that compare a bound run with a stock run SEED BY SEED need both to consume torch's generator identically: they pin
+# pyprob's own per-trace loop (PYPROB_HIP_FAST_TRAIN=0 / PYPROB_HIP_LOCKSTEP=0). The batched paths that install() selects by
+# default (pyprob_amd/pyprob_host.py) have their own tests at the end of this file.
+os.environ['PYPROB_HIP_FAST_TRAIN'] = '0'
+os.environ['PYPROB_HIP_LOCKSTEP'] = '0'
 
 IC = InferenceEngine.IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK
 EMB = {'obs0': {'dim': 16}, 'obs1': {'dim': 16}}
@@ -796,3 +810,180 @@ def test_parameter_layout_equals_the_reference_modules(network):
         assert mine == ref, (set(mine) ^ set(ref), [(k, mine[k], ref[k]) for k in mine if k in ref and mine[k] != ref[k]])
         assert spec.num_parameters() == sum(p.numel() for p in net.parameters())
     check()
+
+
+# ---- the batched paths install() selects by default (pyprob_amd/pyprob_host.py) ------------------------------------------------
+@pytest.fixture
+def batched(monkeypatch):
+    monkeypatch.setenv('PYPROB_HIP_FAST_TRAIN', '1')
+    monkeypatch.setenv('PYPROB_HIP_LOCKSTEP', '1')
+    hip.install()
+    yield
+    hip.uninstall()
+
+
+class GaussianWithUnknownMeanMarsagliaTensorLoop(Model):
+    """The rejection-sampling program with a TENSOR condition (`while s >= 1:` - legal pyprob, same semantics one trace at a
+    time): the form the lock-step executors can run for all particles together."""
+
+    def __init__(self):
+        super().__init__('Gaussian with unknown mean (Marsaglia, tensor loop)')
+
+    def marsaglia(self, mean, stddev):
+        uniform = Uniform(-1, 1)
+        s = torch.ones(())
+        while s >= 1:
+            x = pyprob.sample(uniform)
+            y = pyprob.sample(uniform)
+            s = x * x + y * y
+        return mean + stddev * (x * torch.sqrt(-2 * torch.log(s) / s))
+
+    def forward(self):
+        mu = self.marsaglia(1, math.sqrt(5))
+        likelihood = Normal(mu, math.sqrt(2))
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
+def _quiet_learn(model, **kw):
+    import contextlib
+    import io
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter('ignore')
+        model.learn_inference_network(observe_embeddings=EMB, inference_network=InferenceNetwork.LSTM, lstm_dim=24,
+                                      learning_rate_init=1e-3, **kw)
+    return model._inference_network
+
+
+def test_online_training_of_a_pyprob_model_takes_the_batched_data_path(batched, tmp_path, monkeypatch):
+    """pyprob's OWN Model.learn_inference_network with install(): the OnlineDataset + per-minibatch loop of optimize()
+    (nn/dataset.py:50-62, inference_network.py:461-499) are replaced by lock-step prior generation and runs of minibatches;
+    the module tree, address strings, layer creation, bookkeeping, optimizer object and checkpoints stay pyprob's."""
+    monkeypatch.setattr(torch, 'load', functools.partial(torch.load, weights_only=False))
+    pyprob.seed(4)
+    model = GaussianWithUnknownMean()
+    net = _quiet_learn(model, num_traces=32 * 40, batch_size=32)
+    assert net._hip_last_optimize.startswith('batched')
+    assert type(net).__name__ == 'InferenceNetworkLSTMHip' and isinstance(net, torch.nn.Module)
+    assert net._total_train_iterations == 40 and net._total_train_traces == 32 * 40 and len(net._history_train_loss) == 40
+    assert net._history_train_loss_trace == [32 * (i + 1) for i in range(40)]
+    hist = np.asarray(net._history_train_loss)
+    assert np.isfinite(hist).all() and net._loss_init == hist[0] and net._loss_min == hist.min() and net._loss_previous == hist[-1]
+    # the address the batched run created layers for is the one pyprob's own runtime extracts from the program
+    pyprob.seed(1)
+    stock_trace = next(model._trace_generator(trace_mode=pyprob.TraceMode.PRIOR_FOR_INFERENCE_NETWORK))
+    address = stock_trace.variables_controlled[0].address
+    assert list(net._layers_proposal.keys()) == [address] and net._layers_proposal[address]._total_train_iterations == 40
+    # same parameter set as a stock network of this program (names and shapes): checkpoints interchange
+    hip.uninstall()
+    stock = _train(GaussianWithUnknownMean, False, 64)._inference_network
+    hip.install()
+    assert [(n, tuple(p.shape)) for n, p in net.named_parameters()] == [(n, tuple(p.shape)) for n, p in stock.named_parameters()]
+    assert net._history_num_params == stock._history_num_params
+    assert isinstance(net._optimizer, hip.HipAdam) and int(net._hip_engine.tensor_step.max()) == 40
+    # it learns: the loss of the stock network after the same number of traces is the yardstick (different random streams)
+    assert abs(hist[-10:].mean() - np.mean(stock._history_train_loss)) < 0.6 and hist[-10:].mean() < hist[:5].mean() + 0.1
+    # _save / _load (pyprob's tarball + pickle) and training continues on either loop from the saved optimizer state
+    f = str(tmp_path / 'batched.network')
+    model.save_inference_network(f)
+    clone = GaussianWithUnknownMean()
+    clone.load_inference_network(f)
+    cn = clone._inference_network
+    assert cn._total_train_traces == 32 * 40 and cn._history_train_loss == net._history_train_loss
+    for (n0, p0), (n1, p1) in zip(net.named_parameters(), cn.named_parameters()):
+        assert n0 == n1 and torch.equal(p0.detach().cpu(), p1.detach().cpu())
+    _quiet_learn(clone, num_traces=64, batch_size=32)                          # batched again
+    assert cn._total_train_iterations == 42 and cn._hip_last_optimize.startswith('batched')
+    assert int(cn._hip_engine.tensor_step.max()) == 42                         # Adam's step count carried through the checkpoint
+    monkeypatch.setenv('PYPROB_HIP_FAST_TRAIN', '0')
+    _quiet_learn(clone, num_traces=64, batch_size=32)                          # pyprob's own loop on the same network
+    assert cn._total_train_iterations == 44 and cn._hip_last_optimize == "pyprob's loop"
+
+
+def test_a_program_that_reads_sampled_values_keeps_pyprobs_loop(batched):
+    """`while float(s) >= 1` (the reference's own Marsaglia program) cannot run with N-wide values: the probe says so, training
+    takes pyprob's per-trace loop and importance sampling the particle coroutines - same results as before."""
+    pyprob.seed(2)
+    model = GaussianWithUnknownMeanMarsaglia()
+    net = _quiet_learn(model, num_traces=96, batch_size=32)
+    assert net._hip_last_optimize == "pyprob's loop" and net._total_train_iterations == 3
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model.posterior_results(24, IC, observe={'obs0': 4, 'obs1': 5})
+    assert type(post).__name__ == 'Empirical' and post.length == 24
+    assert pyprob.sample is pyprob.state.sample and pyprob.util._device == torch.device('cpu')      # everything restored
+
+
+@pytest.mark.parametrize('program', [GaussianWithUnknownMean, GaussianWithUnknownMeanMarsagliaTensorLoop], ids=['gum', 'gumm_tensor_loop'])
+def test_posterior_results_of_a_pyprob_model_in_lock_step(batched, program):
+    """pyprob's OWN Model.posterior_results with install(): forward() runs once per control-flow path with all particles
+    (pyprob.sample / observe forwarded for the call, priors and likelihoods read off pyprob's Distribution objects), and what
+    comes back is a pyprob Empirical. Every particle's log-weight is re-scored by the oracle from the values the run drew
+    (state.py:203-219, trace.py:123-125; 1e-4)."""
+    pyprob.seed(6)
+    model = program()
+    net = _quiet_learn(model, num_traces=32 * 12, batch_size=32)
+    assert net._hip_last_optimize.startswith('batched')
+    observe = {'obs0': 8.0, 'obs1': 9.0} if program is GaussianWithUnknownMean else {'obs0': 4.0, 'obs1': 5.0}
+    n = 300
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model.posterior_results(n, IC, observe=observe)
+    from pyprob.distributions import Empirical
+    assert isinstance(post, Empirical) and type(post).__name__ == 'HipEmpirical' and post._hip_executor['executor'] == 'lock step'
+    assert post.length == n and len(post) == n and post.name.startswith('Posterior, IC, traces: {:,}'.format(n))
+    assert pyprob.sample is pyprob.state.sample and pyprob.observe is pyprob.state.observe and pyprob.util._device == torch.device('cpu')
+    values, lw = (t.detach().cpu().double().numpy() for t in post.values_device())
+    # the base class's view of the same particles (lists made on first use) and its statistics
+    assert len(post.values) == n and abs(float(post.values[3]) - values[3]) < 1e-6
+    w = np.exp(lw - lw.max())
+    w /= w.sum()
+    assert abs(float(post.mean) - float((w * values).sum())) < 1e-5 * max(1.0, abs(float(post.mean)))
+    assert abs(float(post.effective_sample_size) - 1.0 / float((w ** 2).sum())) < 1e-3 * float(post.effective_sample_size)
+    assert abs(float(post.expectation(lambda x: x)) - float(post.mean)) < 1e-4
+    # oracle re-scoring of every particle from what it drew at each statement
+    params = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    onet = O.Net(params, ['obs0', 'obs1'], K=10)
+    obs = np.array([observe['obs0'], observe['obs1']], np.float64)
+    log = post._hip.statement_log
+    addresses = list(net._layers_proposal.keys())
+    dist_name = 'Normal' if program is GaussianWithUnknownMean else 'Uniform'
+    prior_pair = [1.0, math.sqrt(5.0)] if program is GaussianWithUnknownMean else [-1.0, 1.0]
+    trace_len, addr_idx, vals, prior = [], [], [], []
+    if program is GaussianWithUnknownMean:
+        assert post._hip_executor['control_flow_paths'] == 1
+        for b in range(n):
+            trace_len.append(1), addr_idx.append(0), vals.append(values[b]), prior.append(prior_pair)
+        mu = values
+    else:
+        assert post._hip_executor['control_flow_paths'] > 1
+        stmts = [{a: v[0].detach().cpu().double().numpy() for a, v in entry.items()} for entry in log]
+        # (a particle that loops deeper than any trace of the short training run meets addresses without proposal layers:
+        # the executor draws those from the prior like inference_network_lstm.py:132-134 - left out of the re-scoring)
+        keep = []
+        for b in range(n):
+            k, known, mine = 0, True, []
+            while True:
+                (ax, xs), (ay, ys) = list(stmts[2 * k].items())[0], list(stmts[2 * k + 1].items())[0]
+                known = known and ax in addresses and ay in addresses
+                if known:
+                    mine.extend([(addresses.index(ax), xs[b]), (addresses.index(ay), ys[b])])
+                s_ = float(np.float32(np.float32(xs[b]) * np.float32(xs[b]) + np.float32(ys[b]) * np.float32(ys[b])))
+                k += 1
+                if s_ < 1.0:
+                    break
+            if known:
+                keep.append(b)
+                trace_len.append(2 * k)
+                addr_idx.extend(a for a, _ in mine)
+                vals.extend(v for _, v in mine)
+                prior.extend([prior_pair] * len(mine))
+        assert len(keep) > 0.8 * n
+        keep = np.asarray(keep)
+        mu, lw = values[keep], lw[keep]
+    _, _, _, want = O.is_rescore(onet, obs, np.asarray(trace_len), np.asarray(addr_idx), np.asarray(vals, np.float64),
+                                 np.asarray(prior, np.float64), addresses, [dist_name] * len(addresses))
+    for b in range(len(want)):
+        want[b] += sum(float(O.normal_log_prob(y, mu[b], math.sqrt(2.0))) for y in obs)
+    np.testing.assert_allclose(lw, want, rtol=1e-4, atol=1e-4)
