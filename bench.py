@@ -115,8 +115,8 @@ def cpu_baseline_torch(lstm_dim, batch, budget_s=10.0):
 def cpu_baseline_reference(lstm_dim, batch, workload='train'):
     """The UNMODIFIED reference timed live on this host (tools/cpu_reference_bench.py) - only where a pyprob checkout is
     importable (the build container; the GPU box has none). Returns None otherwise."""
-    ref = os.environ.get('PYPROB_REFERENCE', '/root/reference')
-    if not os.path.isdir(os.path.join(ref, 'pyprob')):
+    ref = os.environ.get('PYPROB_REFERENCE')      # (only when asked for: bench.py never looks for /root/reference by itself)
+    if not ref or not os.path.isdir(os.path.join(ref, 'pyprob')):
         return None
     try:
         sys.path.insert(0, os.path.join(REPO, 'tools'))
@@ -144,9 +144,9 @@ def cpu_baseline_reference(lstm_dim, batch, workload='train'):
 
 
 def recorded_reference():
-    """The reference's figures recorded in the build container (profiles/r05_cpu_reference.json, re-measured every round by
+    """The reference's figures recorded in the build container (profiles/r06_cpu_reference.json, re-measured every round by
     tools/cpu_reference_bench.py): carried in the line when the reference itself cannot run on this box."""
-    src = os.path.join('profiles', 'r05_cpu_reference.json')
+    src = os.path.join('profiles', 'r06_cpu_reference.json')
     try:
         with open(os.path.join(REPO, src)) as f:
             d = json.load(f)
@@ -450,6 +450,36 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
     return rec, dt, particles * calls
 
 
+def online_training_bench(device, lstm_dim, batch, traces, program='gum'):
+    """End to end through the host API, trace generation INCLUDED: Model.learn_inference_network(num_traces) on the program itself
+    (no dataset handed in) - prior traces generated in lock step (on the device for a single-path program, pp_prior_draw), layers
+    created at the first minibatch, runs of minibatches inside one C call. This is the loop pyprob_amd/pyprob_host.py routes a
+    real pyprob.Model's learn_inference_network through (InferenceNetwork.optimize on an OnlineDataset, pyprob/nn/dataset.py:50-62,
+    inference_network.py:381-599) and the counterpart of the reference's end-to-end figure (`_total_train_traces /
+    _total_train_seconds`, inference_network.py:529-534). Host: pyprob_amd.Model (pyprob itself is not on the GPU box)."""
+    import contextlib
+    import io
+    from pyprob_amd.state import InferenceNetwork
+    GUM, GUMM = api_models()
+    model = (GUM if program == 'gum' else GUMM)()
+    kw = dict(inference_network=InferenceNetwork.LSTM, observe_embeddings={'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, batch_size=batch,
+              lstm_dim=lstm_dim, seed=1)
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.learn_inference_network(num_traces=128 * batch, **kw)          # layers, code objects, first chunk
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.learn_inference_network(num_traces=traces, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    net = model._inference_network
+    return dict(traces_per_sec=round(traces / dt, 1), traces=traces, seconds=round(dt, 4), program=program,
+                bookkept_traces_per_sec=round(net._total_train_traces / max(net._total_train_seconds, 1e-9), 1),
+                final_loss=round(float(net._history_train_loss[-1]), 4), host='pyprob_amd.Model',
+                api='Model.learn_inference_network(num_traces, LSTM, observe_embeddings, batch_size=%d, lstm_dim=%d): online, prior '
+                    'generation + layer creation + training' % (batch, lstm_dim))
+
+
 def _claim_stdout():
     """stdout must carry exactly ONE line, rank 0's JSON. Everything else this process writes to file descriptor 1 - RCCL
     prints a five-line version banner at its first communicator, libraries warn now and then - is sent to stderr: returns a
@@ -490,7 +520,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='train', choices=['train', 'train_gumm', 'is'])
+    ap.add_argument('--workload', default='train', choices=['train', 'train_gumm', 'is', 'dropin'])
     ap.add_argument('--lstm-dim', type=int, default=512)
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--dataset', type=int, default=1000000, help='offline traces resident in HBM (per job)')
@@ -850,6 +880,9 @@ def main():
                 out['gumm_lockstep_1m']['statement_kernel'] = {k: g1m['statement_kernel'][k] for k in
                                                                ('achieved', 'frac', 'frac_executed',
                                                                 'us_per_call', 'launches_per_call', 'wall_over_statement_kernels')}
+        if world == 1 and not args.no_is:
+            out['online_e2e'] = online_training_bench(device, args.lstm_dim, B, 2 * 1024 * 1024)
+            config['online_e2e_traces_per_sec'] = out['online_e2e']['traces_per_sec']
         # the driver's record keeps the flat scalars of `config` / `roofline` and only the NAMES of nested objects: every
         # number README.md quotes is repeated here as a flat key
         config['ms_per_step_median'] = out.get('ms_per_step_median')
@@ -935,6 +968,37 @@ def main():
                 frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), avg_launch_us=round(avg_ms * 1e3, 3), launches_timed=int(cnt.value),
                 flops_per_launch=flops, kernel='grouped weight-gradient launch holding dW_ih / dW_hh of the backward pass '
                                                '(the head products of the %d addresses ride in the same grouped launches)' % len(addresses))
+    elif args.workload == 'dropin':
+        # What a pyprob user gets after binding.install(): the executors pyprob_amd/pyprob_host.py routes pyprob.Model through,
+        # end to end (trace generation, layer creation, bookkeeping included) - measured here through pyprob_amd.Model, the host
+        # that exists on the GPU box; under pyprob itself every sample / observe statement additionally constructs one pyprob
+        # Distribution object and forward() runs in every posterior call (no launch plan: `is_noplan`).
+        del eng
+        B = args.batch
+        rec = online_training_bench(device, args.lstm_dim, B, max(K, 1) * 64 * B, 'gum')
+        dt, units = rec['seconds'], rec['traces']
+        K = units // B
+        metric, unit = 'ic_train_traces_per_sec', 'traces/s'
+        old_env = os.environ.get('PP_IS_PLAN')
+        os.environ['PP_IS_PLAN'] = '0'
+        try:
+            isr = api_posterior_bench(lib, device, args.lstm_dim, args.particles, 20, 3, 'gum')[0]
+            gm = api_posterior_bench(lib, device, args.lstm_dim, 200000, 5, 2, 'gumm', prof_class=5)[0]
+        finally:
+            if old_env is None:
+                os.environ.pop('PP_IS_PLAN', None)
+            else:
+                os.environ['PP_IS_PLAN'] = old_env
+        gmm = online_training_bench(device, args.lstm_dim, B, 256 * B, 'gumm')
+        config = dict(workload='drop-in paths end to end (pyprob_host executors through pyprob_amd.Model): GaussianUnknownMean online '
+                               'IC training incl. prior generation, LSTM hidden=%d, batch=%d' % (args.lstm_dim, B),
+                      parallelism='dp1', online_e2e_traces_per_sec=rec['traces_per_sec'],
+                      online_e2e_bookkept_traces_per_sec=rec['bookkept_traces_per_sec'], online_final_loss=rec['final_loss'],
+                      gumm_online_e2e_traces_per_sec=gmm['traces_per_sec'],
+                      is_noplan_particles_per_sec=isr['particles_per_sec'], is_noplan_ms_per_call=isr['ms_per_call'],
+                      gumm_lockstep_particles_per_sec=gm['particles_per_sec'], api=rec['api'])
+        out['roofline'] = dict(bound='host', achieved=None, peak=None, unit='traces/s', frac=None, traffic=None,
+                               note='an end-to-end rate through the host API: see the default workload for the kernels\' rooflines')
     else:
         # BASELINE.json configs[3]: posterior_results through the drop-in API, particles sharded over the ranks (no collective on
         # the data path: distinct Philox counter ranges per rank)
@@ -969,9 +1033,10 @@ def main():
             live = cpu_baseline_reference(args.lstm_dim, args.batch, args.workload)
             if live is not None:
                 line['cpu_baseline'] = live
-            elif args.workload == 'train':
+            elif args.workload in ('train', 'dropin'):
                 line['cpu_baseline'] = cpu_baseline_torch(args.lstm_dim, args.batch)
-                line['cpu_baseline_numpy'] = cpu_baseline_train(args.lstm_dim, args.batch, budget_s=6.0)
+                if args.workload == 'train':
+                    line['cpu_baseline_numpy'] = cpu_baseline_train(args.lstm_dim, args.batch, budget_s=6.0)
             elif args.workload == 'train_gumm':
                 line['cpu_baseline'] = cpu_baseline_gumm(args.lstm_dim, args.batch)
             else:
