@@ -389,7 +389,7 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
             shared_launch = abs(w - particles * alg_sh) < 0.5 * alg_sh
             executed += (w / alg_sh) * exe_sh if shared_launch else (w / alg_ns) * exe_ns
         executed /= calls
-        prof, note = committed_profile('r05_is_pmc_traffic.json')
+        prof, note = committed_profile('r06_is_pmc_traffic.json')
         tr = (prof or {}).get('kernels', {}).get('is_step_fused', {})
         rec['statement_kernel'] = dict(
             bound='mfma', achieved=round(flops / (us * 1e-6) / 1e12, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
@@ -416,7 +416,7 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         # The pass is VALU-bound (a Philox block, the draw, K exps and a logsumexp per particle; 8 B per particle reach memory): it
         # is priced on the VALU pipe with SQ counters from a committed PMC run of the same sources (tools/pmc_is_fused.sh), not on
         # HBM - the memory figure rides along for the record
-        vprof, vnote = committed_profile('r05_is_fused_valu.json')
+        vprof, vnote = committed_profile('r06_is_fused_valu.json')
         rec['particle_kernels'] = dict(
             bound='valu', unit='share of the VALU pipes\' time busy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles of the launch at 2.4 GHz)', peak=1.0,
             achieved=(vprof or {}).get('valu_busy_fraction'), frac=(vprof or {}).get('valu_busy_fraction'),
@@ -730,9 +730,9 @@ def main():
         # HBM bytes per launch (PMC passes) and rocprofv3 --kernel-trace --stats averages of this command, committed by
         # tools/profile_round.sh together with the hash of the kernel sources they were measured on: quoted only on a match
         std_shape = B == 1024 and args.lstm_dim == 512
-        pmc_doc, pmc_file = committed_profile('r05_pmc_traffic.json') if std_shape else (None, 'not the profiled shape')
+        pmc_doc, pmc_file = committed_profile('r06_pmc_traffic.json') if std_shape else (None, 'not the profiled shape')
         pmc = (pmc_doc or {}).get('kernels', {})
-        avg_doc, avg_file = committed_profile('r05_kernel_avgs.json') if std_shape else (None, 'not the profiled shape')
+        avg_doc, avg_file = committed_profile('r06_kernel_avgs.json') if std_shape else (None, 'not the profiled shape')
         rocprof_avgs = avg_doc or {}
         if std_shape and (pmc_doc is None or avg_doc is None):
             out['profile_note'] = pmc_file if pmc_doc is None else avg_file
@@ -932,7 +932,10 @@ def main():
         lr = 1e-3 * (world ** 0.5)
         for i in range(W):
             eng.train_step(batches[i % nb], lr)
-        lib.pp_prof_arm(1, K)
+        # the weight-gradient launch timed live: an event pair costs the stream ~5 us (two boundaries around the launch, visible
+        # as gaps in profiles/s5v_ragged_step_sequence.csv) - every 4-th launch carries one, as in the default workload
+        lib.pp_prof_stride(4)
+        lib.pp_prof_arm(1, K // 4 + 1)
         barrier()
         t0 = time.perf_counter()
         for i in range(K):
@@ -944,6 +947,7 @@ def main():
         cnt = C.c_int32(0)
         lib.pp_prof_collect(ms.ctypes.data, K, C.byref(cnt), fl.ctypes.data)
         lib.pp_prof_arm(1, 0)
+        lib.pp_prof_stride(1)
         units = B * K
         metric, unit = 'ic_train_traces_per_sec', 'traces/s'
         mean_len = float(np.mean([b.mean_length_controlled for b in batches]))
@@ -960,6 +964,22 @@ def main():
                                unit='TFLOP/s', frac=round(flops_step * K / dt / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
                                kernel='whole step (all GEMM + elementwise kernels), algorithmic FLOPs of SURVEY.md 8(d) x3 for '
                                       'training / wall-clock step time')
+        # HBM bytes of the WHOLE step (all launches) from the committed PMC passes of this command (tools/profile_round6.sh), quoted
+        # on a source-hash match; algorithmic bytes per step: every parameter read in the forward and the backward
+        # pass, its gradient written, Adam's read of (w, g, m, v) and write of (w, m, v) = 44 B per parameter, + the materialised
+        # LSTM input rows (written, read by the weight gradients) and the per-row gate / hidden / cell rows written forward and
+        # read backward
+        P_ = eng.spec.num_parameters()
+        rows_ = float(np.mean([b.n_rows for b in batches]))
+        H_ = args.lstm_dim
+        alg_bytes = 44.0 * P_ + rows_ * 4.0 * (2 * 68 + 2 * (4 * H_ + 2 * H_) + 2 * (int((H_ + 30) / 2) + 30))
+        gdoc, gnote = committed_profile('r06_gumm_traffic.json') if (B == 1024 and H_ == 512) else (None, 'not the profiled shape')
+        out['roofline']['traffic'] = (gdoc or {}).get('traffic_bytes_per_step')
+        out['roofline']['algorithmic_bytes'] = round(alg_bytes)
+        out['roofline']['traffic_source'] = gnote if gdoc is None else '%s (csrc_sha %s)' % (gnote, gdoc.get('csrc_sha'))
+        if out['roofline']['traffic']:
+            out['roofline']['traffic_ratio'] = round(out['roofline']['traffic'] / alg_bytes, 3)
+        out['roofline']['launches_per_step'] = (gdoc or {}).get('launches_per_step')
         if cnt.value > 0:
             avg_ms, flops = float(ms[:cnt.value].mean()), float(fl[:cnt.value].mean())
             ach = flops / (avg_ms * 1e-3) / 1e12

@@ -1,5 +1,5 @@
 # SQ counters of is_fused_kernel (the pass over the particles of a GUM posterior call): bash tools/pmc_is_fused.sh <tag>
-#   gpurun_out/<tag>_is_fused_pmc_{1,2}.csv, gpurun_out/<tag>_r05_is_fused_valu.json (-> profiles/r05_is_fused_valu.json, stamped with
+#   gpurun_out/<tag>_is_fused_pmc_{1,2}.csv, gpurun_out/<tag>_r06_is_fused_valu.json (-> profiles/r06_is_fused_valu.json, stamped with
 #   the hash of csrc/: bench.py quotes it as `is.particle_kernels` when it matches the running tree)
 TAG=${1:-s5a}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
@@ -45,7 +45,7 @@ if 'SQ_ACTIVE_INST_VALU' in vals and vals.get('SQ_WAVE_CYCLES'):
     doc['valu_active_over_wave_cycles'] = round(vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_WAVE_CYCLES'], 4)
 if vals.get('SQ_WAIT_ANY') and vals.get('SQ_WAVE_CYCLES'):
     doc['wait_any_over_wave_cycles'] = round(vals['SQ_WAIT_ANY'] / vals['SQ_WAVE_CYCLES'], 4)
-json.dump(doc, open('$OUT/${TAG}_r05_is_fused_valu.json', 'w'), indent=1)
-json.dump(doc, open('profiles/r05_is_fused_valu.json', 'w'), indent=1)
+json.dump(doc, open('$OUT/${TAG}_r06_is_fused_valu.json', 'w'), indent=1)
+json.dump(doc, open('profiles/r06_is_fused_valu.json', 'w'), indent=1)
 print(json.dumps(doc))
 P

@@ -1,7 +1,7 @@
 # The N-row importance-sampling statement under rocprofv3: bash tools/profile_is_step.sh <tag> [n]
 #   gpurun_out/<tag>_is_step_kernel_stats.csv           rocprofv3 --kernel-trace --stats of tools/is_step_bench.py (fused + chain)
 #   gpurun_out/<tag>_is_step_pmc_{FETCH,WRITE}_SIZE.csv separate --pmc passes (fused kernel only)
-#   profiles/r05_is_pmc_traffic.json                    HBM bytes per particle-statement, stamped with the hash of csrc/
+#   profiles/r06_is_pmc_traffic.json                    HBM bytes per particle-statement, stamped with the hash of csrc/
 TAG=${1:-s5a}; N=${2:-200000}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -35,8 +35,8 @@ if len(vals) == 2:
                                            algorithmic_bytes_per_particle_statement=16 * 512 + 20,
                                            algorithmic_bytes='h and c read once and written once (4 x 2 KB), previous value, prior, value, log q (20 B); the 4.7 MB of weights once per launch',
                                            **vals)
-json.dump(doc, open('profiles/r05_is_pmc_traffic.json', 'w'), indent=1)
-json.dump(doc, open('$OUT/${TAG}_r05_is_pmc_traffic.json', 'w'), indent=1)
+json.dump(doc, open('profiles/r06_is_pmc_traffic.json', 'w'), indent=1)
+json.dump(doc, open('$OUT/${TAG}_r06_is_pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(doc['kernels']))
 P
 cat $OUT/${TAG}_is_step_bench.jsonl

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_kernel_avgs.json + profiles/r05_pmc_traffic.json (each stamped with `csrc_sha`, the hash of the kernel sources they
+"""profiles/r06_kernel_avgs.json + profiles/r06_pmc_traffic.json (each stamped with `csrc_sha`, the hash of the kernel sources they
 were measured on: bench.py quotes them only when it matches the running tree) (what bench.py quotes next to its live HIP-event timings) from
 the per-kernel summaries of one `rocprofv3 --kernel-trace --stats` run and the two PMC passes (FETCH_SIZE, WRITE_SIZE) of
 `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-is`:
@@ -44,7 +44,7 @@ def main(tag, stats_csv, fetch_csv, write_csv):
                                               r['workgroups_x'], r['workgroups_y'], r['workgroups_z'])
     avgs['source'] = '%s (rocprofv3 --kernel-trace --stats of python bench.py)' % os.path.basename(stats_csv)
     avgs['csrc_sha'] = sha
-    json.dump(avgs, open(os.path.join(repo, 'profiles', 'r05_kernel_avgs.json'), 'w'), indent=1)
+    json.dump(avgs, open(os.path.join(repo, 'profiles', 'r06_kernel_avgs.json'), 'w'), indent=1)
     pm = {}
     for path, col in ((fetch_csv, 'FETCH_SIZE_KB_raw'), (write_csv, 'WRITE_SIZE_KB')):
         for r in csv.DictReader(open(path)):
@@ -66,7 +66,7 @@ def main(tag, stats_csv, fetch_csv, write_csv):
                       % (tag, os.path.basename(fetch_csv), os.path.basename(write_csv)),
                gfx950_fetch_correction='FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section): '
                                        'doubled; counter unit KB = 1024 bytes', kernels=out)
-    json.dump(doc, open(os.path.join(repo, 'profiles', 'r05_pmc_traffic.json'), 'w'), indent=1)
+    json.dump(doc, open(os.path.join(repo, 'profiles', 'r06_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps(avgs), '\n', json.dumps({k: v['traffic_bytes_per_launch'] for k, v in out.items()}))
 
 

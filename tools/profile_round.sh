@@ -1,7 +1,7 @@
 # One GPU call's worth of evidence for the training step: bash tools/profile_round.sh <tag>
 #   gpurun_out/<tag>_train_kernel_stats.csv, _step_sequence.csv   rocprofv3 --kernel-trace --stats of bench.py
 #   gpurun_out/<tag>_train_pmc_{FETCH,WRITE}_SIZE.csv             separate --pmc passes
-#   gpurun_out/<tag>_r05_kernel_avgs.json, _r05_pmc_traffic.json  what bench.py quotes (written to profiles/r05_*.json on the box; tools/collect_profiles.sh installs them here, stamped with the hash of csrc/)
+#   gpurun_out/<tag>_r06_kernel_avgs.json, _r06_pmc_traffic.json  what bench.py quotes (written to profiles/r05_*.json on the box; tools/collect_profiles.sh installs them here, stamped with the hash of csrc/)
 #   gpurun_out/<tag>_bench_20_5.json, _bench_default.json         the driver's command and the default command
 TAG=${1:-s5a}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
@@ -26,7 +26,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $REPO
 python tools/profile_json.py $TAG $OUT/${TAG}_train_kernel_stats.csv $OUT/${TAG}_train_pmc_FETCH_SIZE.csv $OUT/${TAG}_train_pmc_WRITE_SIZE.csv
-cp profiles/r05_kernel_avgs.json $OUT/${TAG}_r05_kernel_avgs.json; cp profiles/r05_pmc_traffic.json $OUT/${TAG}_r05_pmc_traffic.json
+cp profiles/r06_kernel_avgs.json $OUT/${TAG}_r06_kernel_avgs.json; cp profiles/r06_pmc_traffic.json $OUT/${TAG}_r06_pmc_traffic.json
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20_5.json 2> $OUT/${TAG}_bench_20_5.err
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 tail -c 600 $OUT/${TAG}_bench_20_5.json; echo; python -c "

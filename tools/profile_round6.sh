@@ -1,0 +1,34 @@
+# Round 6: one GPU call's worth of evidence: bash tools/profile_round6.sh <tag>
+#   the default command's profile (tools/profile_round.sh <tag>: kernel stats, step sequence, PMC FETCH / WRITE, the documents
+#   bench.py quotes) + the same for the ragged step (--workload train_gumm: its own traffic document) + the dropin workload
+TAG=${1:-r06p}
+REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
+bash tools/profile_round.sh $TAG > $OUT/${TAG}_round.log 2>&1
+tail -3 $OUT/${TAG}_round.log
+cd /tmp && export TMPDIR=/tmp
+rm -rf $OUT/fg_ks
+rocprofv3 --kernel-trace --stats -d $OUT/fg_ks -o p -- python $REPO/bench.py --workload train_gumm --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_gumm_ks.log 2>&1
+python $REPO/tools/rocprof_summary.py $OUT/fg_ks/p_results.db $OUT/${TAG}_train_gumm_kernel_stats.csv > /dev/null
+python - <<P
+import sys; sys.path.insert(0, '$REPO/tools')
+import rocprof_summary as R
+R.sequence('$OUT/fg_ks/p_results.db', '$OUT/${TAG}_ragged_step_sequence.csv')
+P
+rm -rf $OUT/fg_ks
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/fg_pmc_$c
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/fg_pmc_$c -o p -- python $REPO/bench.py --workload train_gumm --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_gumm_pmc_$c.log 2>&1
+  python $REPO/tools/pmc_summary.py $OUT/fg_pmc_$c/p_results.db $OUT/${TAG}_train_gumm_pmc_$c.csv 0
+  rm -rf $OUT/fg_pmc_$c
+done
+# kernel stats of the 25-step command for the launch count (same command as the PMC passes)
+rm -rf $OUT/fg_ks2
+rocprofv3 --kernel-trace --stats -d $OUT/fg_ks2 -o p -- python $REPO/bench.py --workload train_gumm --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python $REPO/tools/rocprof_summary.py $OUT/fg_ks2/p_results.db $OUT/${TAG}_train_gumm_kernel_stats_25.csv > /dev/null
+rm -rf $OUT/fg_ks2
+cd $REPO
+python tools/profile_gumm_json.py $TAG $OUT/${TAG}_train_gumm_pmc_FETCH_SIZE.csv $OUT/${TAG}_train_gumm_pmc_WRITE_SIZE.csv $OUT/${TAG}_train_gumm_kernel_stats_25.csv 25 $OUT/${TAG}_ragged_step_sequence.csv
+cp profiles/r06_gumm_traffic.json $OUT/${TAG}_r06_gumm_traffic.json
+python bench.py --workload train_gumm --steps 60 --warmup 10 > $OUT/${TAG}_gumm_bench_line.json 2> $OUT/${TAG}_gumm_bench.err
+python bench.py --workload dropin --steps 50 > $OUT/${TAG}_dropin_bench_line.json 2> $OUT/${TAG}_dropin_bench.err
+tail -c 400 $OUT/${TAG}_gumm_bench_line.json; echo
