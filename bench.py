@@ -1036,6 +1036,39 @@ def main():
             g, _, _ = api_posterior_bench(lib, device, args.lstm_dim, 200000, max(3, K // 10), 2, 'gumm', prof_class=5)
             out['gumm_lockstep'] = g
 
+    if use_dist and args.workload == 'train' and eng.native_dp and not args.graph:
+        # the exchange of a step, by HIP event pairs (a short pass of its own: a record costs the stream ~1.5 us): the early
+        # ranges' all-reduce on the side stream, the rest's on the step's stream, and what the step then still waited for the side
+        # stream. exposed = rest + wait (what sits between the backward pass and Adam); PP_DP_OVERLAP=0: one collective, all of it
+        # exposed
+        us = (C.c_float * 3)()
+        samples = []
+        if eng.dp_overlap:
+            lib.pp_dp_overlap_stats(1, None)
+            for i in range(12):
+                step(K + W + i)
+                if lib.pp_dp_overlap_stats(1, us) == 1:
+                    samples.append([float(v) for v in us])
+            lib.pp_dp_overlap_stats(0, None)
+        if samples:
+            med = np.median(np.asarray(samples[2:] or samples), axis=0)
+            config['allreduce_us'] = round(float(med[0] + med[1]), 2)
+            config['exposed_allreduce_us'] = round(float(med[1] + med[2]), 2)
+            config['early_bucket_allreduce_us'] = round(float(med[0]), 2)
+            config['early_bucket_bytes'] = int(4 * sum(c for _, c in eng.dp_overlap))
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            vals = []
+            for i in range(12):
+                eng.loss(pick(K + W + i), backward=True)
+                e0.record()
+                eng.allreduce_grads()
+                e1.record()
+                eng.optimizer_step(lr, zero_grads=True, skip=eng.reduced_status())
+                torch.cuda.synchronize()
+                vals.append(e0.elapsed_time(e1) * 1e3)
+            config['allreduce_us'] = config['exposed_allreduce_us'] = round(float(np.median(vals[2:])), 2)
+        config['dp_overlap_ranges'] = [[int(o), int(c)] for o, c in eng.dp_overlap]
     # max over ranks
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)

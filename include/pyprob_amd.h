@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 12
+#define PP_ABI_VERSION 13
 #define PP_MAX_OBS 8
 #define PP_MAX_LSTM_DEPTH 4
 #define PP_MAX_OBS_DEPTH 4
@@ -609,6 +609,20 @@ int pp_dp_allreduce(float* base /*dev*/, const int64_t* off /*host*/, const int6
 int pp_dp_reduce_grads(float* grads_full, int64_t n_params, int32_t n_tensors, const float* presence, const int32_t* status,
                        const int64_t* skip_off /*host*/, const int64_t* skip_cnt /*host*/, int32_t n_skip, float* loss_out,
                        int32_t* status_out, void* stream);
+
+/* (ABI 13) Bucket 0 under the rest of the backward pass - what `distributed_num_buckets` is for in the reference
+ * (pyprob/nn/inference_network.py:300-325: gradients reduced bucket by bucket). off / cnt (host, n <= 2 ascending ranges of the
+ * flat gradient buffer, in floats; n = 0: off) name gradient tensors that the backward pass completes EARLY: pp_ic_loss then
+ * issues its weight-gradient launch in two parts - the products (and reduction jobs) that write into the hull of the ranges
+ * first, the remaining ones after - and starts the ranges' all-reduce on a side stream between the two; pp_dp_reduce_grads
+ * leaves the ranges out of its own collective and makes its stream wait for the side stream before it returns the step to
+ * Adam. Host-side state: every rank must set the same ranges (pyprob_amd.engine.ICEngine.enable_dp_overlap: the first LSTM
+ * layer's weight and bias gradients, minus a skipped W_hh). Bit-identical to the unsplit exchange. */
+int pp_dp_overlap(const int64_t* off /*host*/, const int64_t* cnt /*host*/, int32_t n);
+/* arm = 1 / 0: HIP event pairs around the collectives of the following overlapped steps on / off. us_out (host [3] or NULL):
+ * the LAST overlapped step's {ranges' all-reduce on the side stream, the rest's all-reduce, what the step's stream then still
+ * waited for the side stream} in microseconds (synchronises on those events). Returns 1 when us_out was filled, else 0. */
+int pp_dp_overlap_stats(int32_t arm, float* us_out);
 
 int pp_debug_timeline(long long* buf /*dev [16] or NULL*/);
 /* debug: per-workgroup {start, end, problem, split, operands ready, loads issued, first slab landed, K loop done} stamps (10 ns ticks) of the grouped async GEMM launches

@@ -28,6 +28,8 @@ int sample_embed_bwd(const pp_net* net, const float* params, const float* value,
                      const int32_t* prev_row, int row_begin, int n_rows, const float* dX, int64_t ldx, float* grads,
                      hipStream_t st);
 // lstm_tail.hip: the late time steps of a ragged batch in one launch per direction
+bool dp_overlap_hull(int64_t* lo, int64_t* hi);          // dp.hip
+int dp_bucket0_issue(float* grads_full, hipStream_t st);
 int lstm_tail_plan(const int32_t* n_active, int T, int H, int* t0_out, int* teams_out);
 void lstm_tail_exchange_bytes(int H, size_t* fwd, size_t* bwd);
 int lstm_tail_fwd(float* G, float* C, float* Hs, const float* Whh, const int32_t* row_off_dev, int t0, int T, int H, int teams,
@@ -730,6 +732,27 @@ int ic_loss(const pp_net* net, const pp_batch* bt, const float* P, float* grads,
     std::vector<GemmHole> wholes;
     auto flush_wgrads = [&](hipStream_t stream, bool timed, const AuxJobs* aux = nullptr) -> int {
         wholes.resize(wq.size(), GemmHole{});
+        // data parallel with an overlap range (dp.hip): the products that complete the range - the LSTM layer's weight
+        // gradients - and the reduction jobs go first; the range's all-reduce starts on the side stream behind them and the
+        // remaining products (proposal layers, observe embedding) run under it
+        int64_t lo = 0, hi = 0;
+        if (dp_overlap_hull(&lo, &hi) && wq.size() > 1) {
+            std::vector<pp_gemm_args> qa, qb;
+            std::vector<GemmHole> ha, hb;
+            for (size_t i = 0; i < wq.size(); ++i) {
+                const bool in = wq[i].C >= grads + lo && wq[i].C < grads + hi;
+                (in ? qa : qb).push_back(wq[i]);
+                (in ? ha : hb).push_back(wholes[i]);
+            }
+            if (!qa.empty() && !qb.empty()) {
+                PP_TRY(launch_wgrads(qa, stream, &ha, timed, aux, true));
+                PP_TRY(dp_bucket0_issue(grads, stream));
+                PP_TRY(launch_wgrads(qb, stream, &hb, false, nullptr, true));
+                wq.clear();
+                wholes.clear();
+                return 0;
+            }
+        }
         PP_TRY(launch_wgrads(wq, stream, &wholes, timed, aux, true));
         wq.clear();
         wholes.clear();

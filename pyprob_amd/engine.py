@@ -64,6 +64,7 @@ class ICEngine:
         self.loss_buf = self.grads_full[n + spec.n_tensors:n + spec.n_tensors + 1]   # the loss kernel writes into the tail
         self.status_tail = self.grads_full[n + spec.n_tensors + 1:]                  # float copy of the non-finite flag
         self.dp_skip = []      # (offset, count) float ranges left out of the gradient all-reduce, see skip_recurrent_weights
+        self.dp_overlap = getattr(self, 'dp_overlap', [])     # (offset, count) ranges reduced EARLY, see enable_dp_overlap
         # set by the caller after pyprob_amd.parallel.init_native_comm() returned True on ALL ranks (kept when the network grows)
         self.native_dp = getattr(self, 'native_dp', False)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -470,6 +471,22 @@ class ICEngine:
             return
         from .parallel import allreduce_flat_
         self.status_tail.copy_(self.status_buf[:1])          # int32 flag -> float, into the reduced tail
+        if self.dp_overlap:
+            # the bucketed order of enable_dp_overlap on torch.distributed: the early ranges go out first as asynchronous
+            # collectives, the rest follows, the early ones are waited for last (same pieces, same order on every rank)
+            import torch.distributed as dist
+            from .parallel import allreduce_pieces_
+            early = [dist.all_reduce(self.grads_full[o:o + c], async_op=True) for o, c in self.dp_overlap]
+            pieces, pos = [], 0
+            for off, cnt in sorted(list(self.dp_skip) + list(self.dp_overlap)):
+                if off > pos:
+                    pieces.append((pos, off))
+                pos = off + cnt
+            pieces.append((pos, self.grads_full.numel()))
+            allreduce_pieces_([self.grads_full[a:b] for a, b in pieces if b > a])
+            for work in early:
+                work.wait()
+            return
         if not self.dp_skip:
             allreduce_flat_(self.grads_full)
             return
@@ -502,6 +519,33 @@ class ICEngine:
             n = int(np.prod(shape))
             self.dp_skip = [(off, ((n + 1023) // 1024) * 1024)]
 
+    def enable_dp_overlap(self, enable=True):
+        """Data parallel: reduce the first LSTM layer's gradients (W_ih, W_hh unless it is skipped, both bias vectors - 0.4 to
+        0.7 of what a step exchanges) EARLY - the backward pass issues its weight-gradient launch in two parts and the ranges'
+        all-reduce runs on a side stream under the second part (pp_dp_overlap, csrc/dp.hip; the reference's bucketed
+        `_distributed_sync_grad`, inference_network.py:300-325). Every rank must make the same call (it follows
+        `agree_skip_recurrent`, which all ranks settle together). Returns the ranges."""
+        self.dp_overlap = []
+        if enable and not self.spec.feedforward and os.environ.get('PP_DP_OVERLAP', '1') != '0':
+            names = ['_layers_lstm.weight_ih_l0', '_layers_lstm.weight_hh_l0', '_layers_lstm.bias_ih_l0', '_layers_lstm.bias_hh_l0']
+            pieces = []
+            for n in names:
+                off, shape = self.spec.tensors[n]
+                cnt = ((int(np.prod(shape)) + 1023) // 1024) * 1024
+                if any(o <= off and off + cnt <= o + c for o, c in self.dp_skip):
+                    continue                                   # (zero on every rank: it leaves the exchange altogether)
+                if pieces and pieces[-1][0] + pieces[-1][1] == off:
+                    pieces[-1] = (pieces[-1][0], pieces[-1][1] + cnt)
+                else:
+                    pieces.append((off, cnt))
+            self.dp_overlap = pieces[:2] if len(pieces) <= 2 else []
+        if self.native_dp and not self.grads_full.is_cpu and self.lib.pp_dp_world() >= 1:
+            k = len(self.dp_overlap)
+            off = (C.c_int64 * max(k, 1))(*[o for o, _ in self.dp_overlap])
+            cnt = (C.c_int64 * max(k, 1))(*[c for _, c in self.dp_overlap])
+            L.check(self.lib.pp_dp_overlap(off, cnt, k), 'pp_dp_overlap')
+        return list(self.dp_overlap)
+
     def agree_skip_recurrent(self, single_statement):
         """COLLECTIVE (every rank calls it): leave W_hh out of the gradient all-reduce iff the data of EVERY rank has one
         controlled variable per trace. `single_statement` is this rank's own finding, read from its data (the trace lengths
@@ -517,6 +561,8 @@ class ICEngine:
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 flag = int(t.item())
         self.skip_recurrent_weights(bool(flag))
+        if self.world_size > 1 or self.force_allreduce:
+            self.enable_dp_overlap(True)       # (after the skip is settled: a skipped W_hh is not part of the early ranges)
         return bool(flag)
 
     def broadcast_params(self):

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 12
+PP_ABI_VERSION = 13
 PP_MAX_OBS = 8
 PP_MAX_LSTM_DEPTH = 4
 PP_MAX_OBS_DEPTH = 4
@@ -154,6 +154,8 @@ PROTOTYPES = {
     'pp_dp_destroy': (C.c_int, []),
     'pp_dp_allreduce': (C.c_int, [vp, vp, vp, i32, vp]),
     'pp_dp_reduce_grads': (C.c_int, [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
+    'pp_dp_overlap': (C.c_int, [vp, vp, i32]),
+    'pp_dp_overlap_stats': (C.c_int, [i32, vp]),
     'pp_debug_timeline': (C.c_int, [vp]),
     'pp_debug_wgtrace': (C.c_int, [vp, C.c_int32, C.c_int32]),
     'pp_debug_wgrad_plan': (C.c_int, [vp, vp, i32, vp, i32, vp]),

@@ -636,3 +636,59 @@ def test_distributed_posterior_on_two_ranks_is_the_concatenation_of_the_shards(t
     np.testing.assert_allclose(torch.cat(lws).cpu().numpy(), r0['lw'].numpy(), rtol=0, atol=0)
     assert abs(r0['stats']['ess'] - r0['ess']) < 1e-6 * r0['ess'] and r0['stats']['count'] == 101
     assert abs(r0['mean'] - 7.25) < 1.5        # (the golden network is only briefly trained)
+
+
+# ---- the early-bucket order of the gradient exchange (ICEngine.enable_dp_overlap; csrc/dp.hip on the device) --------------------
+def _overlap_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle_ops
+    from pyprob_amd.packed import PackedBatch
+    meta, params, batch, loss, isr = load_golden('gumm')
+    spec = spec_from_golden(meta, params)
+    local = _local_batches(meta, batch, rank)
+    ids = np.array([spec.address_id[meta['addresses'][i]] for i in local['addr_idx']])
+    pb = PackedBatch.from_ragged(local['trace_len'], ids, local['values'], local['prior'], local['obs'], len(spec.addresses)).to('cpu')
+    rec = {}
+    for mode in ('plain', 'overlap', 'skip', 'overlap_skip'):
+        eng = oracle_ops.CpuBufferEngine(spec)
+        eng._use_ops = True
+        eng.load_state_dict(params)
+        eng.world_size = world
+        if mode.endswith('skip'):
+            eng.skip_recurrent_weights(True)      # (only the RANGES are under test: W_hh's gradient is not zero on this data -
+            #                                        the yardstick is the same skip without the early ranges)
+        rec[mode + '_ranges'] = eng.enable_dp_overlap(mode.startswith('overlap'))
+        for k in range(3):
+            eng.train_step(pb, lr=1e-3)
+        rec[mode] = eng.params.clone()
+        rec[mode + '_steps'] = eng.tensor_step.clone()
+        rec[mode + '_loss'] = float(eng.loss_buf[0]) / world
+    rec['whh'] = spec.tensors['_layers_lstm.weight_hh_l0']
+    torch.save(rec, out + '.%d' % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_bucket_order_changes_no_bit_of_the_exchange(tmp_path):
+    """The bucketed order (the first LSTM layer's gradient ranges as asynchronous collectives first, the rest after, the early
+    ones waited for last - what csrc/dp.hip does with a side stream) on two gloo ranks: the same parameters, bit for bit, as
+    the single all-reduce; with W_hh skipped the early ranges are the two pieces around it."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / 'ov')
+    mp.spawn(_overlap_worker, args=(world, port, out), nprocs=world, join=True)
+    r = [torch.load(out + '.%d' % k, weights_only=False) for k in range(world)]
+    for k in range(world):
+        assert r[k]['plain_ranges'] == []
+        (o0, c0), = r[k]['overlap_ranges']                        # W_ih | W_hh | b_ih | b_hh are adjacent: one range
+        off, shape = r[k]['whh']
+        assert o0 < off and off + int(np.prod(shape)) <= o0 + c0
+        assert len(r[k]['overlap_skip_ranges']) == 2 and r[k]['overlap_skip_ranges'][0][0] == o0
+        assert r[k]['overlap_skip_ranges'][0][0] + r[k]['overlap_skip_ranges'][0][1] == off      # ... ends where W_hh begins
+        assert torch.equal(r[k]['overlap'], r[k]['plain']) and torch.equal(r[k]['overlap_steps'], r[k]['plain_steps'])
+        assert r[k]['overlap_loss'] == r[k]['plain_loss']
+        assert torch.equal(r[k]['overlap'], r[0]['overlap'])       # the ranks hold identical parameters
+        assert r[k]['skip_ranges'] == [] and torch.equal(r[k]['overlap_skip'], r[k]['skip'])

@@ -131,3 +131,62 @@ def test_grouped_pieces(one_rank_group):
     L.check(lib.pp_dp_allreduce(x.data_ptr(), off, cnt, 3, L.stream_ptr()), 'pp_dp_allreduce')
     torch.cuda.synchronize()
     assert torch.equal(x, ref)          # one rank: the sum over the ranks is the buffer itself
+
+
+@pytest.mark.parametrize('shape', ['single_statement_panel', 'ragged'])
+def test_early_bucket_on_the_side_stream_changes_no_bit(one_rank_group, shape):
+    """pp_dp_overlap (ABI 13): the backward pass issues its weight-gradient launch in two parts, the LSTM layer's gradient
+    ranges are reduced on a SIDE stream under the second part, pp_dp_reduce_grads reduces the rest and joins the streams
+    before Adam - per-step calls, the resident loop and the packing loop, on the one-rank communicator. Same launches' results
+    bit for bit as the single exchange (the split changes WHEN products run, not what they compute), and the event-pair
+    statistics arrive."""
+    lib = one_rank_group
+    import ctypes as C
+    from pyprob_amd.packed import PackedBatch
+    if shape == 'single_statement_panel':
+        H, addresses, dist_name = 512, ['mu'], 'Normal'
+        arrs = [synthetic_gum_arrays(1024, seed=70 + k) for k in range(3)]
+        ids = [np.zeros(1024, np.int64)] * 3
+    else:
+        H, dist_name = 64, 'Uniform'
+        arrs = []
+        for k in range(3):
+            arr, addresses = synthetic_gumm_arrays(300, seed=80 + k, max_iter=4)
+            arrs.append(arr)
+        ids = None
+    runs = {}
+    for mode in ('single', 'early'):
+        eng = _engine(H, addresses, dist_name, seed=11)
+        eng.force_allreduce = True
+        eng.native_dp = True
+        single = shape == 'single_statement_panel'
+        eng.skip_recurrent_weights(single)
+        ranges = eng.enable_dp_overlap(mode == 'early')
+        assert (len(ranges) == (2 if single else 1)) if mode == 'early' else ranges == []
+        batches = []
+        for k, arr in enumerate(arrs):
+            a_ids = ids[k] if ids is not None else np.array([eng.spec.address_id[addresses[j]] for j in arr['addr_idx']])
+            batches.append(PackedBatch.from_ragged(arr['trace_len'], a_ids, arr['values'], arr['prior'], arr['obs'],
+                                                   len(eng.spec.addresses)).to(eng.device))
+        losses = [float(eng.train_step(pb, 1e-3).item()) for pb in batches]                  # per-step C calls
+        l2, st = eng.train_resident(batches, [1e-3] * 3)                                      # the resident loop
+        if mode == 'early':
+            assert lib.pp_dp_overlap_stats(1, None) == 0
+            eng.train_step(batches[0], 1e-3)
+            us = (C.c_float * 3)()
+            assert lib.pp_dp_overlap_stats(0, us) == 1 and all(0.0 <= v < 1e5 for v in us) and us[0] > 0.0
+        else:
+            eng.train_step(batches[0], 1e-3)
+        torch.cuda.synchronize()
+        runs[mode] = (losses, l2.cpu().numpy().copy(), eng.params.cpu().numpy().copy(), eng.tensor_step.cpu().numpy().copy())
+        eng.enable_dp_overlap(False)
+    if shape == 'ragged':
+        # (float atomics order the splits of a weight-gradient tile differently from launch to launch: 1e-6, not bitwise)
+        np.testing.assert_allclose(runs['early'][0], runs['single'][0], rtol=2e-6)
+        np.testing.assert_allclose(runs['early'][1], runs['single'][1], rtol=2e-5)
+        assert np.linalg.norm(runs['early'][2] - runs['single'][2]) < 1e-3 * np.linalg.norm(runs['single'][2])
+    else:
+        assert runs['early'][0] == runs['single'][0]
+        np.testing.assert_allclose(runs['early'][1], runs['single'][1], rtol=2e-5)
+        assert np.linalg.norm(runs['early'][2] - runs['single'][2]) < 1e-3 * np.linalg.norm(runs['single'][2])
+    assert (runs['early'][3] == runs['single'][3]).all()
