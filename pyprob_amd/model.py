@@ -169,7 +169,7 @@ class Model:
 
     # attributes the Model base class itself keeps on the instance (never read by a program as constants)
     _BASE_ATTRS = frozenset(('_inference_network', '_lockstep_plans', '_lock_step_ok', '_last_prior_resident', '_plan_code_cache',
-                             '_plan_key_cache', '_plan_indirect_cache'))
+                             '_plan_key_cache', '_plan_indirect_cache', '_plan_indirect_pairs'))
 
     @staticmethod
     def _fingerprint(v):
@@ -315,9 +315,21 @@ class Model:
                 out.append(cell.cell_contents)
         except (KeyError, ValueError):
             return None
+        # values read THROUGH the objects above (modules, classes, functions kept on the instance): whether there are any
+        # depends only on the identity of those holders - the common "none" case is remembered and costs an identity compare
+        ic = self.__dict__.get('_plan_indirect_pairs')
+        if ic is not None and ic[0] is reads and len(ic[1]) == len(out) and all(map(_is, ic[1], out)):
+            return out
         ind = self._plan_indirect(reads)
         if ind is None:
+            self.__dict__.pop('_plan_indirect_pairs', None)
             return None
+        stable = (type(None), bool, int, float, str, bytes, torch.Tensor, types.ModuleType, types.FunctionType,
+                  types.BuiltinFunctionType, types.MethodType, type)
+        if not ind and all(isinstance(v, stable) or v is self for v in out):
+            self.__dict__['_plan_indirect_pairs'] = (reads, list(out))
+        else:
+            self.__dict__.pop('_plan_indirect_pairs', None)
         for _, _, v in ind:
             out.append(v)
         return out
