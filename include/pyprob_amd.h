@@ -617,7 +617,8 @@ int pp_dp_reduce_grads(float* grads_full, int64_t n_params, int32_t n_tensors, c
  * first, the remaining ones after - and starts the ranges' all-reduce on a side stream between the two; pp_dp_reduce_grads
  * leaves the ranges out of its own collective and makes its stream wait for the side stream before it returns the step to
  * Adam. Host-side state: every rank must set the same ranges (pyprob_amd.engine.ICEngine.enable_dp_overlap: the first LSTM
- * layer's weight and bias gradients, minus a skipped W_hh). Bit-identical to the unsplit exchange. */
+ * layer's weight and bias gradients, minus a skipped W_hh; PP_DP_OVERLAP=1 - measured on a one-rank group the two-part launch and
+ * its two cross-stream waits cost a 67 us step ~26 us, so it is not the default). Same result as the unsplit exchange. */
 int pp_dp_overlap(const int64_t* off /*host*/, const int64_t* cnt /*host*/, int32_t n);
 /* arm = 1 / 0: HIP event pairs around the collectives of the following overlapped steps on / off. us_out (host [3] or NULL):
  * the LAST overlapped step's {ranges' all-reduce on the side stream, the rest's all-reduce, what the step's stream then still

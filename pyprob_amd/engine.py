@@ -525,8 +525,11 @@ class ICEngine:
         all-reduce runs on a side stream under the second part (pp_dp_overlap, csrc/dp.hip; the reference's bucketed
         `_distributed_sync_grad`, inference_network.py:300-325). Every rank must make the same call (it follows
         `agree_skip_recurrent`, which all ranks settle together). Returns the ranges."""
+        # NOT the default: on a one-rank RCCL group the two-part launch + the two cross-stream event waits cost the 67 us step
+        # ~26 us (profiles/r06e_dp_overlap_one_rank.txt) - more than the <= 8-10 us of an 8-rank exchange the second part can
+        # cover. PP_DP_OVERLAP=1 selects it (larger networks / slower links, where the early ranges' collective is long)
         self.dp_overlap = []
-        if enable and not self.spec.feedforward and os.environ.get('PP_DP_OVERLAP', '1') != '0':
+        if enable and not self.spec.feedforward and os.environ.get('PP_DP_OVERLAP', '0') == '1':
             names = ['_layers_lstm.weight_ih_l0', '_layers_lstm.weight_hh_l0', '_layers_lstm.bias_ih_l0', '_layers_lstm.bias_hh_l0']
             pieces = []
             for n in names:

@@ -640,6 +640,7 @@ def test_distributed_posterior_on_two_ranks_is_the_concatenation_of_the_shards(t
 
 # ---- the early-bucket order of the gradient exchange (ICEngine.enable_dp_overlap; csrc/dp.hip on the device) --------------------
 def _overlap_worker(rank, world, port, out):
+    os.environ['PP_DP_OVERLAP'] = '1'          # (off by default, pyprob_amd/engine.py enable_dp_overlap)
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
