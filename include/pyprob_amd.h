@@ -443,6 +443,13 @@ int pp_copy_rows(const float* src, int32_t src_stride, float* dst /*dev [n]*/, c
 #define PP_PARTITION_SCRATCH(m) (((m) + 1023) / 1024 + 1)
 int pp_partition_rows(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
                       int32_t* counts, int32_t* scratch, void* stream);
+/* (ABI 13) The same partition with the decision POLLED instead of copied back: counts = int32 [3] in host-mapped (pinned)
+ * memory; the kernel stores counts[0], counts[1] and then, behind a system-scope fence, counts[2] = seq (non-zero; the caller
+ * cleared the word before the call and spins on it). A branch of a lock-step run costs the host a poll of ~10 us instead of a
+ * blocking 8-byte device-to-host copy of ~45 us (profiles/r04x_gumm_call_timeline_after.csv: the gap behind every
+ * __amd_rocclr_copyBuffer). m must be > 0. */
+int pp_partition_rows_polled(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
+                             int32_t* counts /*host-mapped [3]*/, int32_t seq, int32_t* scratch, void* stream);
 
 /* Up to four log-weight terms in ONE pass over the particles:
  *   lw[i] (+)= sum_t scale_t * term_t(i);  kind as in pp_logweight_accumulate, or 2: the value x itself (e.g. -log q)

@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(256) void partition_count_kernel(const uint8_t* __r
 
 __global__ __launch_bounds__(256) void partition_scatter_kernel(const uint8_t* __restrict__ cond, const int64_t* __restrict__ rows, int m,
                                                                 const int32_t* __restrict__ block_true, int64_t* __restrict__ rows_true,
-                                                                int64_t* __restrict__ rows_false, int32_t* __restrict__ counts) {
+                                                                int64_t* __restrict__ rows_false, int32_t* __restrict__ counts,
+                                                                const int seq) {
     __shared__ int sh[4], shw[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
@@ -1049,6 +1050,10 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(const uint8_t* _
         const int total_true = before + wave_before + incl;
         counts[0] = total_true;
         counts[1] = m - total_true;
+        if (seq != 0) {      // polled by the host in mapped (pinned) memory: the sequence word goes last, behind a system-scope fence
+            __threadfence_system();
+            __hip_atomic_store(counts + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1654,23 +1659,41 @@ int pp_copy_rows(const float* src, int32_t src_stride, float* dst, const int64_t
     return 0;
 }
 
-int pp_partition_rows(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
-                      int32_t* counts, int32_t* scratch, void* stream) {
+static int partition_rows(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
+                          int32_t* counts, int32_t* scratch, int seq, void* stream) {
     if (!(cond && rows_true && rows_false && counts && scratch) || m < 0) {
         pp::set_error("pp_partition_rows: bad argument (scratch of PP_PARTITION_SCRATCH(m) int32 is required)");
         return PP_EINVAL;
     }
     hipStream_t st = pp::as_stream(stream);
     if (m == 0) {
+        if (seq != 0) {
+            pp::set_error("pp_partition_rows_polled: m = 0 needs no launch (the caller knows the counts)");
+            return PP_EINVAL;
+        }
         (void)hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
         return 0;
     }
     const int blocks = pp::cdiv(m, pp::PART_TILE);
     hipLaunchKernelGGL(pp::partition_count_kernel, dim3(blocks), dim3(256), 0, st, cond, rows, m, scratch);
     hipLaunchKernelGGL(pp::partition_scatter_kernel, dim3(blocks), dim3(256), 0, st, cond, rows, m, scratch, rows_true, rows_false,
-                       counts);
+                       counts, seq);
     PP_LAUNCH_CHECK("pp_partition_rows");
     return 0;
+}
+
+int pp_partition_rows(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
+                      int32_t* counts, int32_t* scratch, void* stream) {
+    return partition_rows(cond, rows, m, rows_true, rows_false, counts, scratch, 0, stream);
+}
+
+int pp_partition_rows_polled(const uint8_t* cond, const int64_t* rows, int32_t m, int64_t* rows_true, int64_t* rows_false,
+                             int32_t* counts, int32_t seq, int32_t* scratch, void* stream) {
+    if (seq == 0) {
+        pp::set_error("pp_partition_rows_polled: seq must be non-zero");
+        return PP_EINVAL;
+    }
+    return partition_rows(cond, rows, m, rows_true, rows_false, counts, scratch, seq, stream);
 }
 
 int pp_axpy(float scale, const float* term, float* lw, int32_t n, void* stream) {

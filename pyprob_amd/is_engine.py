@@ -8,6 +8,7 @@ fused prior/likelihood log-prob kernels that accumulate the per-particle log-wei
 (log w = sum_t [log p(v_t) - log q(v_t)] + sum_j log p(y_j | .), pyprob/trace.py:123-125).
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -392,20 +393,50 @@ class ISRunner:
         """A branch: split the path's rows (None: particles 0..m-1) by the bool [n] condition - the launches only; the counts
         are read by partition_read (the one synchronisation of a branch)."""
         buf = torch.empty(2 * max(m, 1), dtype=torch.int64, device=self.dev)
-        counts = torch.empty(2, dtype=torch.int32, device=self.dev)
         need = (m + 1023) // 1024 + 1
         scratch = getattr(self, '_part_scratch', None)
         if scratch is None or scratch.numel() < need:
             scratch = self._part_scratch = torch.empty(max(need, 1024), dtype=torch.int32, device=self.dev)
+        if m > 0 and self.dev.type == 'cuda' and os.environ.get('PP_IS_PART_POLL', '1') != '0':
+            # the decision comes back through PINNED host memory the kernel writes in place (counts, then a sequence word behind a
+            # system-scope fence) and the host polls: no 8-byte device-to-host copy, whose blocking call cost every branch ~45 us
+            ring = getattr(self, '_part_ring', None)
+            if ring is None:
+                self._part_pin = torch.zeros(64 * 4, dtype=torch.int32).pin_memory()
+                ring = self._part_ring = self._part_pin.numpy().reshape(64, 4)
+                self._part_seq = 0
+            self._part_seq = self._part_seq % 0x3fffffff + 1
+            slot = self._part_seq & 63          # (nested paths keep a few partitions in flight: one slot each)
+            ring[slot, 2] = 0
+            L.check(self.lib.pp_partition_rows_polled(cond.data_ptr(), L.ptr(rows), int(m), buf.data_ptr(), buf.data_ptr() + 8 * m,
+                                                      self._part_pin.data_ptr() + 16 * slot, self._part_seq, scratch.data_ptr(),
+                                                      self._st), 'pp_partition_rows_polled')
+            return buf, (ring[slot], self._part_seq), m, cond, rows
+        counts = torch.empty(2, dtype=torch.int32, device=self.dev)
         L.check(self.lib.pp_partition_rows(cond.data_ptr(), L.ptr(rows), int(m), buf.data_ptr(), buf.data_ptr() + 8 * m,
                                            counts.data_ptr(), scratch.data_ptr(), self._st), 'pp_partition_rows')
         return buf, counts, m, cond, rows      # (cond / rows stay alive until the kernels have run)
 
-    @staticmethod
-    def partition_read(handle):
+    def partition_read(self, handle):
         """(rows where the condition holds, the other rows, their counts) - ascending int64 device vectors."""
         buf, counts, m = handle[:3]
-        n_true, n_false = counts.tolist()
+        if isinstance(counts, tuple):
+            slot, seq = counts
+            spins, deadline = 0, None
+            while slot[2] != seq:
+                spins += 1
+                if spins > 4000:                 # a long statement kernel is still running: yield between polls, bounded by time
+                    now = time.perf_counter()
+                    if deadline is None:
+                        deadline = now + 30.0
+                    elif now > deadline:
+                        torch.cuda.synchronize(self.dev)
+                        if slot[2] != seq:
+                            raise L.HipLibraryError('pp_partition_rows_polled: the counts never arrived in host memory')
+                    time.sleep(0)
+            n_true, n_false = int(slot[0]), int(slot[1])
+        else:
+            n_true, n_false = counts.tolist()
         return buf[:n_true], buf[m:m + n_false], n_true, n_false
 
     def partition(self, cond, rows, m):

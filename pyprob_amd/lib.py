@@ -137,6 +137,7 @@ PROTOTYPES = {
     'pp_logweight_accumulate_rows': (C.c_int, [i32, vp, i32, vp, i32, vp, i32, C.c_float, vp, vp, i32, vp]),
     'pp_copy_rows': (C.c_int, [vp, i32, vp, vp, i32, vp]),
     'pp_partition_rows': (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp]),
+    'pp_partition_rows_polled': (C.c_int, [vp, vp, i32, vp, vp, vp, i32, vp, vp]),
     'pp_logweight_terms': (C.c_int, [C.POINTER(pp_lw_term), i32, vp, i32, i32, vp]),
     'pp_axpy': (C.c_int, [C.c_float, vp, vp, i32, vp]),
     'pp_is_stats': (C.c_int, [vp, vp, i32, vp, vp, vp]),

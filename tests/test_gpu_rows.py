@@ -23,8 +23,12 @@ def runner():
     return ISRunner(ICEngine(spec, device='cuda:0', seed=3))
 
 
+@pytest.mark.parametrize('poll', ['1', '0'], ids=['polled', 'copied'])
 @pytest.mark.parametrize('n,frac', [(1, 1.0), (7, 0.5), (1024, 0.3), (1025, 0.0), (4097, 1.0), (200003, 0.215), (1000001, 0.5)])
-def test_partition_rows_is_the_stable_split(runner, n, frac):
+def test_partition_rows_is_the_stable_split(runner, n, frac, poll, monkeypatch):
+    # poll: the counts come back through pinned host memory the kernel writes in place (pp_partition_rows_polled, the default)
+    # or through an 8-byte device-to-host copy (pp_partition_rows)
+    monkeypatch.setenv('PP_IS_PART_POLL', poll)
     g = torch.Generator(device='cpu').manual_seed(n)
     cond = (torch.rand(n, generator=g) < frac).cuda()
     t, f, nt, nf = runner.partition(cond, None, n)
@@ -35,6 +39,10 @@ def test_partition_rows_is_the_stable_split(runner, n, frac):
     t, f, nt, nf = runner.partition(cond, rows, int(rows.numel()))
     assert torch.equal(t, rows[cond[rows]]) and torch.equal(f, rows[~cond[rows]])
     assert nt == int(t.numel()) and nf == int(f.numel()) and nt + nf == int(rows.numel())
+    # several partitions in flight before the first is read (nested paths of the executor): one slot each
+    handles = [runner.partition_launch(cond, None, n) for _ in range(5)]
+    for h in reversed(handles):
+        assert runner.partition_read(h)[2:] == (int(cond.sum()), n - int(cond.sum()))
 
 
 def test_accumulate_rows_and_copy_rows(runner):
