@@ -323,15 +323,12 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
         torch.cuda.synchronize()
         return time.perf_counter() - t0, replays, last
 
-    if prof_class == 4:
-        # a call of this program is ~70 us: the event pairs of the in-stream kernel timing (two hipEventRecord per launch) cost
-        # it ~20 us - the wall time is taken from an UN-instrumented loop, the kernel times from a second, instrumented one
-        dt, replays, last = timed_loop()
-        lib.pp_prof_arm(prof_class, cap)
-        timed_loop()
-    else:
-        lib.pp_prof_arm(prof_class, cap)
-        dt, replays, last = timed_loop()
+    # the event pairs of the in-stream kernel timing (two hipEventRecord per launch) cost a ~70 us GUM call ~20 us and a Marsaglia
+    # call (~25 statement launches) ~0.5 ms: the wall time is taken from an UN-instrumented loop, the kernel times from a second,
+    # instrumented one
+    dt, replays, last = timed_loop()
+    lib.pp_prof_arm(prof_class, cap)
+    timed_loop()
     post = last[0]                                   # the configuration's own observation: its posterior is what is reported
     ms = np.zeros(cap, np.float32)
     fl = np.zeros(cap, np.float64)
@@ -350,7 +347,7 @@ def api_posterior_bench(lib, device, lstm_dim, particles, calls, warm, program='
                calls=calls, program='GaussianUnknownMean' if program == 'gum' else 'GaussianUnknownMeanMarsaglia (tensor-condition loop)',
                api='Model.posterior_results(N, IMPORTANCE_SAMPLING_WITH_INFERENCE_NETWORK, observe=..., lock_step=True)',
                timed_call_executes=executes, plan_replays=int(replays),
-               timing='wall time of `calls` un-instrumented calls (statistics read back every call); kernel figures from a second, instrumented loop' if prof_class == 4 else 'wall time of `calls` calls with the statement kernel\'s event pairs armed', observations_cycled=[dict(o) for o in observes],
+               timing='wall time of `calls` un-instrumented calls (statistics read back every call); kernel figures from a second, instrumented loop', observations_cycled=[dict(o) for o in observes],
                posterior_mean=round(float(post.mean), 4), posterior_stddev=round(float(post.stddev), 4),
                ess=round(float(post.effective_sample_size), 1), control_flow_paths=int(getattr(post, 'num_paths', 1)),
                network_params=model._inference_network._engine.spec.num_parameters())
