@@ -987,3 +987,45 @@ def test_posterior_results_of_a_pyprob_model_in_lock_step(batched, program):
     for b in range(len(want)):
         want[b] += sum(float(O.normal_log_prob(y, mu[b], math.sqrt(2.0))) for y in obs)
     np.testing.assert_allclose(lw, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('program,first', [(_CategoricalThenNormal, 'Categorical'), (_PoissonThenNormal, 'Poisson')], ids=['cat', 'poi'])
+def test_other_proposal_layers_in_lock_step_through_pyprob_model(batched, program, first):
+    """A Categorical / Poisson first statement followed by a Normal whose mean depends on it, through pyprob's OWN
+    learn_inference_network (batched online path: the one-hot / Poisson layers are created by pyprob's `_polymorph`) and
+    posterior_results (lock step): addresses in pyprob's format, every particle re-scored by the oracle."""
+    pyprob.seed(8)
+    model = program()
+    net = _quiet_learn(model, num_traces=32 * 10, batch_size=32)
+    assert net._hip_last_optimize.startswith('batched')
+    addresses = list(net._layers_proposal.keys())
+    assert len(addresses) == 2 and first in addresses[0] and 'Normal' in addresses[1]
+    observe = {'obs0': 1.0, 'obs1': 1.5}
+    n = 200
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model.posterior_results(n, IC, observe=observe)
+    assert type(post).__name__ == 'HipEmpirical' and post._hip_executor == dict(executor='lock step', control_flow_paths=1)
+    values, lw = (t.detach().cpu().double().numpy() for t in post.values_device())
+    log = post._hip.statement_log
+    v0 = list(log[0].values())[0][0].detach().cpu().double().numpy()
+    v1 = list(log[1].values())[0][0].detach().cpu().double().numpy()
+    np.testing.assert_allclose(v1, values)                                   # forward() returns the second draw
+    prior = np.zeros((2 * n, 3))
+    if first == 'Categorical':
+        prior[0::2] = [0.2, 0.3, 0.5]
+        prior[1::2, 0], prior[1::2, 1] = v0 * 2.0 - 1.0, 1.5
+        sigma = 0.8
+    else:
+        prior[0::2, 0] = 4.0
+        prior[1::2, 0], prior[1::2, 1] = v0 * 0.5, 1.0
+        sigma = 0.8
+    vals = np.empty(2 * n)
+    vals[0::2], vals[1::2] = v0, v1
+    params = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    onet = O.Net(params, ['obs0', 'obs1'], K=10)
+    obs = np.array([observe['obs0'], observe['obs1']], np.float64)
+    _, _, _, want = O.is_rescore(onet, obs, np.full(n, 2), np.tile([0, 1], n), vals, prior, addresses, [first, 'Normal'])
+    for b in range(n):
+        want[b] += sum(float(O.normal_log_prob(y, v1[b], sigma)) for y in obs)
+    np.testing.assert_allclose(lw, want, rtol=1e-4, atol=2e-4)
