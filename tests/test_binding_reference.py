@@ -851,8 +851,8 @@ def _quiet_learn(model, **kw):
     import io
     with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
         warnings.simplefilter('ignore')
-        model.learn_inference_network(observe_embeddings=EMB, inference_network=InferenceNetwork.LSTM, lstm_dim=24,
-                                      learning_rate_init=1e-3, **kw)
+        kw.setdefault('inference_network', InferenceNetwork.LSTM)
+        model.learn_inference_network(observe_embeddings=EMB, lstm_dim=24, learning_rate_init=1e-3, **kw)
     return model._inference_network
 
 
@@ -989,15 +989,17 @@ def test_posterior_results_of_a_pyprob_model_in_lock_step(batched, program):
     np.testing.assert_allclose(lw, want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('network', [InferenceNetwork.LSTM, InferenceNetwork.FEEDFORWARD], ids=['lstm', 'feedforward'])
 @pytest.mark.parametrize('program,first', [(_CategoricalThenNormal, 'Categorical'), (_PoissonThenNormal, 'Poisson')], ids=['cat', 'poi'])
-def test_other_proposal_layers_in_lock_step_through_pyprob_model(batched, program, first):
+def test_other_proposal_layers_in_lock_step_through_pyprob_model(batched, program, first, network):
     """A Categorical / Poisson first statement followed by a Normal whose mean depends on it, through pyprob's OWN
     learn_inference_network (batched online path: the one-hot / Poisson layers are created by pyprob's `_polymorph`) and
     posterior_results (lock step): addresses in pyprob's format, every particle re-scored by the oracle."""
     pyprob.seed(8)
     model = program()
-    net = _quiet_learn(model, num_traces=32 * 10, batch_size=32)
+    net = _quiet_learn(model, num_traces=32 * 10, batch_size=32, inference_network=network)
     assert net._hip_last_optimize.startswith('batched')
+    assert type(net).__name__ == ('InferenceNetworkLSTMHip' if network == InferenceNetwork.LSTM else 'InferenceNetworkFeedForwardHip')
     addresses = list(net._layers_proposal.keys())
     assert len(addresses) == 2 and first in addresses[0] and 'Normal' in addresses[1]
     observe = {'obs0': 1.0, 'obs1': 1.5}
@@ -1025,7 +1027,8 @@ def test_other_proposal_layers_in_lock_step_through_pyprob_model(batched, progra
     params = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
     onet = O.Net(params, ['obs0', 'obs1'], K=10)
     obs = np.array([observe['obs0'], observe['obs1']], np.float64)
-    _, _, _, want = O.is_rescore(onet, obs, np.full(n, 2), np.tile([0, 1], n), vals, prior, addresses, [first, 'Normal'])
+    rescore_fn = O.is_rescore if network == InferenceNetwork.LSTM else O.is_rescore_feedforward
+    _, _, _, want = rescore_fn(onet, obs, np.full(n, 2), np.tile([0, 1], n), vals, prior, addresses, [first, 'Normal'])
     for b in range(n):
         want[b] += sum(float(O.normal_log_prob(y, v1[b], sigma)) for y in obs)
     np.testing.assert_allclose(lw, want, rtol=1e-4, atol=2e-4)
