@@ -22,6 +22,7 @@ Nothing here computes: the arithmetic is the engine's. Importing this module nee
 import contextlib
 import os
 import warnings
+import weakref
 
 import torch
 
@@ -115,10 +116,13 @@ class ProgramAdapter(_MirrorModel):
 
     def __init__(self, pp_model):
         super().__init__(getattr(pp_model, 'name', 'pyprob model'))
-        self._pp = pp_model
+        try:
+            self._pp_ref = weakref.ref(pp_model)          # (the adapter is cached per model: no cycle that keeps the model alive)
+        except TypeError:
+            self._pp_ref = lambda: pp_model
 
     def forward(self, *args, **kwargs):
-        return self._pp.forward(*args, **kwargs)
+        return self._pp_ref().forward(*args, **kwargs)
 
     def _lockstep_plan_key(self, *args, **kwargs):
         # a launch-plan replay does not run forward(): its key would have to fingerprint everything the USER's forward() reads
@@ -142,11 +146,17 @@ def network_view(net):
     return view
 
 
+_ADAPTERS = weakref.WeakKeyDictionary()      # pyprob model -> ProgramAdapter (not an attribute of the model: it must stay picklable)
+
+
 def adapter_for(pp_model, net):
     """One adapter per pyprob model (the lock-step probe's verdict is cached on it); the network view follows the engine."""
-    ad = pp_model.__dict__.get('_hip_adapter')
-    if ad is None:
-        ad = pp_model.__dict__['_hip_adapter'] = ProgramAdapter(pp_model)
+    try:
+        ad = _ADAPTERS.get(pp_model)
+        if ad is None:
+            ad = _ADAPTERS[pp_model] = ProgramAdapter(pp_model)
+    except TypeError:                        # (a model class with __slots__ and no weak references: no caching)
+        ad = ProgramAdapter(pp_model)
     view = ad.__dict__.get('_inference_network')
     if view is None or view._engine is not net._hip_engine or view._is is not net._hip_is:
         ad._inference_network = network_view(net)
