@@ -78,15 +78,29 @@ def _refuse(*args, **kwargs):
     raise NotImplementedError('pyprob.tag / pyprob.factor have no batched executor')
 
 
+def _to_tensor_in_place(value, dtype=torch.float32):
+    """`pyprob.util.to_tensor` (util.py:133-143) for the duration of a batched call: a tensor STAYS WHERE IT IS (the reference moves
+    everything to `util._device`: an N-wide per-particle value would be pulled to the host by `Normal(mu, s)` of the user's
+    program), a Python number becomes a HOST scalar (no host-to-device copy per distribution object; the kernels take shared
+    parameters as cached constants)."""
+    if value is None:
+        return None
+    if torch.is_tensor(value):
+        return value if value.dtype == dtype else value.to(dtype=dtype)
+    import numpy as np
+    if isinstance(value, (np.integer, np.floating)):
+        value = float(value)
+    return torch.tensor(value, dtype=dtype)
+
+
 @contextlib.contextmanager
 def forwarded(device):
     """`pyprob.sample` / `pyprob.observe` (and the `state` module's names) forward to this package's trace runtime; pyprob's
-    tensors are created on the engine's device (`util.to_tensor`, so that `Normal(mu, s)` of the user's program does not pull
-    an N-wide value to the host); torch.distributions' argument validation - a device synchronisation per object, and a READ
-    of values whose draw may still be deferred - is off. Everything is restored on exit. A program that imported the names
+    `util.to_tensor` leaves tensors on their device (`_to_tensor_in_place`); torch.distributions' argument validation - a device
+    synchronisation per object, and a READ of values whose draw may still be deferred - is off. Everything is restored on exit. A program that imported the names
     (`from pyprob import sample`) keeps pyprob's own functions: it then fails the probe and takes the other executors."""
     saved = dict(sample=pyprob.sample, observe=pyprob.observe, tag=getattr(pyprob, 'tag', None), factor=getattr(pyprob, 'factor', None),
-                 s_sample=_pp_state.sample, s_observe=_pp_state.observe, device=_pp_util._device, cuda=getattr(_pp_util, '_cuda_enabled', False),
+                 s_sample=_pp_state.sample, s_observe=_pp_state.observe, to_tensor=_pp_util.to_tensor,
                  skip=S._address_frame_skip, validate=torch.distributions.Distribution._validate_args)
     pyprob.sample, pyprob.observe = _hip_sample, _hip_observe
     _pp_state.sample, _pp_state.observe = _hip_sample, _hip_observe
@@ -94,7 +108,7 @@ def forwarded(device):
         pyprob.tag = _refuse
     if saved['factor'] is not None:
         pyprob.factor = _refuse
-    _pp_util._device = torch.device(device)
+    _pp_util.to_tensor = _to_tensor_in_place
     S._address_frame_skip = 1
     torch.distributions.Distribution.set_default_validate_args(False)
     try:
@@ -106,7 +120,7 @@ def forwarded(device):
             pyprob.tag = saved['tag']
         if saved['factor'] is not None:
             pyprob.factor = saved['factor']
-        _pp_util._device = saved['device']
+        _pp_util.to_tensor = saved['to_tensor']
         S._address_frame_skip = saved['skip']
         torch.distributions.Distribution.set_default_validate_args(saved['validate'])
 

@@ -912,7 +912,7 @@ def test_a_program_that_reads_sampled_values_keeps_pyprobs_loop(batched):
         warnings.simplefilter('ignore')
         post = model.posterior_results(24, IC, observe={'obs0': 4, 'obs1': 5})
     assert type(post).__name__ == 'Empirical' and post.length == 24
-    assert pyprob.sample is pyprob.state.sample and pyprob.util._device == torch.device('cpu')      # everything restored
+    assert pyprob.sample is pyprob.state.sample and pyprob.util.to_tensor.__module__ == 'pyprob.util'      # everything restored
 
 
 @pytest.mark.parametrize('program', [GaussianWithUnknownMean, GaussianWithUnknownMeanMarsagliaTensorLoop], ids=['gum', 'gumm_tensor_loop'])
@@ -933,7 +933,7 @@ def test_posterior_results_of_a_pyprob_model_in_lock_step(batched, program):
     from pyprob.distributions import Empirical
     assert isinstance(post, Empirical) and type(post).__name__ == 'HipEmpirical' and post._hip_executor['executor'] == 'lock step'
     assert post.length == n and len(post) == n and post.name.startswith('Posterior, IC, traces: {:,}'.format(n))
-    assert pyprob.sample is pyprob.state.sample and pyprob.observe is pyprob.state.observe and pyprob.util._device == torch.device('cpu')
+    assert pyprob.sample is pyprob.state.sample and pyprob.observe is pyprob.state.observe and pyprob.util.to_tensor.__module__ == 'pyprob.util'
     values, lw = (t.detach().cpu().double().numpy() for t in post.values_device())
     # the base class's view of the same particles (lists made on first use) and its statistics
     assert len(post.values) == n and abs(float(post.values[3]) - values[3]) < 1e-6
