@@ -10,8 +10,11 @@ def __getattr__(name):
     if name in ('sample', 'observe', 'TraceMode', 'InferenceEngine', 'PriorInflation', 'InferenceNetwork', 'LearningRateScheduler',
                 'Optimizer'):
         from . import state
-        return getattr(state, name)
+        value = getattr(state, name)
+        globals()[name] = value          # (resolved once: `pyprob.sample(...)` in a program runs per statement and per path)
+        return value
     if name == 'Model':
         from .model import Model
+        globals()[name] = Model
         return Model
     raise AttributeError(name)
