@@ -140,7 +140,6 @@ class Model:
             state._lock_step = None
             state._current_trace = None
             ls.memo = None          # (the call's intermediate results are released)
-            ls.memo_fast = None
             ls.nest = None
         all_values, all_lw = values, ls.lw
         # the fused pass's statistics count only when they were reduced over the tensor that is returned (a draw still

@@ -221,35 +221,9 @@ class ParticleTensor(torch.Tensor):
                 return None
         return tuple(key)
 
-    _PURE_FUNCS = {}      # func object -> is it a _PURE operator (decided once per operator by its name)
-
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         ls = _lock_step
-        if ls is not None and not kwargs and len(args) <= 2 and len(types) == 1:
-            # IDENTITY fast path of the memo (round 6): a replayed prefix hands out the SAME wrapper objects for the recorded
-            # values and memoised results are objects themselves, so at depth d the d - 1 replayed iterations ask for
-            # (operator, the same argument objects) again. One dict lookup on (func, id of the arguments) + the version checks
-            # replace the storage-metadata key of the general path (6.6 -> ~3 us per hit; ~200 hits per call of the Marsaglia
-            # program). An entry holds its argument tensors, so an id cannot be reused while the entry lives.
-            fast = getattr(ls, 'memo_fast', None)
-            if fast is not None and getattr(ls, 'draw', None) is None:
-                a = args[0]
-                b = args[1] if len(args) == 2 else None
-                tb = type(b)
-                if tb is cls or tb is torch.Tensor:
-                    hit = fast.get((func, id(a), id(b)))
-                elif tb is float or tb is int or tb is bool or b is None:
-                    hit = fast.get((func, id(a), (tb, b)))
-                else:
-                    hit = None
-                if hit is not None:
-                    with torch._C.DisableTorchFunctionSubclass():
-                        if hit[0]._version == hit[1] and hit[2]._version == hit[3] and (hit[4] is None or hit[4]._version == hit[5]):
-                            if not hit[6]:
-                                hit[6] = True
-                                ls.memo_shared[hit[0].untyped_storage()._cdata] = hit[0]
-                            return hit[0]
         name = getattr(func, '__name__', '') if ls is not None else ''
         if ls is not None and getattr(ls, 'draw', None) is not None:
             lazy_ok = name in cls._NO_READ or (name in ('float', 'contiguous') and len(args) == 1 and torch.is_tensor(args[0]) and
@@ -271,7 +245,6 @@ class ParticleTensor(torch.Tensor):
                         # memo.clear() nor the program dropping both names can hand its address to an unrelated tensor
                         with torch._C.DisableTorchFunctionSubclass():
                             ls.memo_shared[hit[0].untyped_storage()._cdata] = hit[0]
-                        cls._memo_fast_put(ls, func, args, hit[0], True)
                         return hit[0]
                     out = func(*args)
                     if isinstance(out, torch.Tensor):
@@ -281,11 +254,8 @@ class ParticleTensor(torch.Tensor):
                         ls.memo_bytes += nbytes
                         if ls.memo_bytes > cls.MEMO_BYTES:      # bound what one call pins (many-path programs at 1e6 particles)
                             memo.clear()
-                            if getattr(ls, 'memo_fast', None) is not None:
-                                ls.memo_fast.clear()
                             ls.memo_bytes = nbytes
                         memo[key] = (out, out._version, args)      # (the arguments stay alive: their storage is not reused)
-                        cls._memo_fast_put(ls, func, args, out, False)
                     return out
         elif memo is not None and ls.memo_shared and args and isinstance(args[0], torch.Tensor) and \
                 (name == '__setitem__' or (name.endswith('_') and not name.startswith('__'))):
@@ -295,24 +265,6 @@ class ParticleTensor(torch.Tensor):
                 raise RuntimeError('lock-step executor: in-place `%s` on a tensor that two expressions of the program share '
                                    '(a reused elementwise result); write it out of place or set PP_IS_MEMO=0' % name)
         return super().__torch_function__(func, types, args, kwargs or {})
-
-    @classmethod
-    def _memo_fast_put(cls, ls, func, args, out, shared):
-        """Identity-keyed twin of a memo entry (see __torch_function__): [result, its version, first argument, its version, second
-        tensor argument or None, its version, already registered as shared]. Called with the subclass dispatch off."""
-        fast = getattr(ls, 'memo_fast', None)
-        if fast is None or not 1 <= len(args) <= 2 or not isinstance(args[0], torch.Tensor):
-            return
-        a = args[0]
-        b = args[1] if len(args) == 2 else None
-        tb = type(b)
-        if tb is cls or tb is torch.Tensor:
-            kb, vb = id(b), b._version
-        elif b is None or isinstance(b, (bool, int, float)):
-            kb, vb, b = (tb, b), 0, None
-        else:
-            return
-        fast[(func, id(a), kb)] = [out, out._version, a, a._version, b, vb, shared]
 
     def __bool__(self):
         ls = _lock_step
@@ -435,7 +387,6 @@ class LockStepState(PathExecutor):
         # model.py): the number of flushes, where every deferred term's value came from, anything that read a draw early
         self.memo = {} if os.environ.get('PP_IS_MEMO', '1') != '0' else None     # ParticleTensor._PURE results of this call
         self.memo_shared = {}         # storage identity -> memoised result handed out more than once (kept alive for the call)
-        self.memo_fast = {} if self.memo is not None and os.environ.get('PP_IS_MEMO_FAST', '1') != '0' else None
         self.memo_bytes = 0
         self.flushes = 0
         self.plan_terms = []          # (term, source, scale): source = ('obs', name) | ('value',) | ('const', tensor)

@@ -10,9 +10,9 @@ from pyprob_amd import state
 from pyprob_amd.state import ParticleTensor
 
 
-@pytest.fixture(params=[True, False], ids=['identity_fast_path', 'storage_keys_only'])
-def ls(request):
-    fake = types.SimpleNamespace(memo={}, memo_shared={}, memo_fast={} if request.param else None, memo_bytes=0, draw=None, width=-1)
+@pytest.fixture
+def ls():
+    fake = types.SimpleNamespace(memo={}, memo_shared={}, memo_bytes=0, draw=None, width=-1)
     old = state._lock_step
     state._lock_step = fake
     try:
@@ -89,23 +89,3 @@ def test_the_memo_is_bounded(ls, monkeypatch):
     for k in range(10):
         _ = x * float(k)
     assert len(ls.memo) <= 3 and ls.memo_bytes <= 3 * 4 * 100
-
-
-def test_identity_fast_path_respects_versions_and_types(ls):
-    """The identity-keyed twin of the memo (round 6): the same argument OBJECTS get the memoised result back; an in-place write
-    to an argument, or a scalar of another type with an equal value (1 / 1.0 / True hash alike), does not."""
-    x, y = P(torch.arange(4.0)), P(torch.ones(4))
-    a = x + y
-    assert (x + y) is a
-    assert (x + y) is a                               # (second hit: already registered as shared)
-    y.as_subclass(torch.Tensor).add_(1.0)             # the argument changed in place: version bump -> recomputed
-    b = x + y
-    assert b is not a and torch.equal(b.as_subclass(torch.Tensor), torch.arange(4.0) + 2.0)
-    c = x * 2
-    d = x * 2.0
-    assert (x * 2) is c and (x * 2.0) is d and c is not d       # int 2 and float 2.0 are different keys
-    e = torch.sqrt(x)
-    assert torch.sqrt(x) is e                         # one-argument operators
-    z = x + [1.0, 2.0, 3.0, 4.0] if False else None   # (an unhashable second argument never reaches the key)
-    with pytest.raises(RuntimeError, match='in-place'):
-        a.add_(1.0)                                   # a was handed out more than once
