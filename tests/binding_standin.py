@@ -69,7 +69,12 @@ class ProposalUniformTruncatedNormalMixture(_Proposal):
     pass
 
 
-_PROPOSAL_CLASS = {'Normal': ProposalNormalNormalMixture, 'Uniform': ProposalUniformTruncatedNormalMixture}
+class ProposalCategoricalCategorical(_Proposal):
+    pass
+
+
+_PROPOSAL_CLASS = {'Normal': ProposalNormalNormalMixture, 'Uniform': ProposalUniformTruncatedNormalMixture,
+                   'Categorical': ProposalCategoricalCategorical}
 
 
 def _linears(init, prefix):
@@ -158,14 +163,74 @@ class RecordedInferenceNetworkLSTM(nn.Module):
         return layers_changed
 
 
+class RecordedInferenceNetworkFeedForward(nn.Module):
+    """`InferenceNetwork.__init__` + `InferenceNetworkFeedForward.__init__` (inference_network_feedforward.py:11-19): observe
+    embeddings and one proposal layer per address, nothing else."""
+
+    def __init__(self, session, proposal_mixture_components=10, **unused):
+        super().__init__()
+        self._session_meta, self._session_init = session
+        self._layers_observe_embedding = nn.ModuleDict()
+        self._layers_observe_embedding_final = None
+        self._layers_pre_generated = False
+        self._layers_initialized = False
+        self._observe_embedding_dim = None
+        self._optimizer = None
+        self._optimizer_type = None
+        self._momentum = None
+        self._weight_decay = None
+        self._learning_rate_init = None
+        self._total_train_traces = 0
+        self._total_train_iterations = 0
+        self._history_num_params = []
+        self._history_num_params_trace = []
+        self._distributed_train_loss = torch.tensor(0.)
+        self._distributed_history_train_loss = []
+        self._distributed_history_train_loss_trace = []
+        self._on_cuda = False
+        self._device = torch.device('cpu')
+        self._layers_proposal = nn.ModuleDict()
+        self._proposal_mixture_components = proposal_mixture_components
+
+    _init_layers_observe_embedding = RecordedInferenceNetworkLSTM._init_layers_observe_embedding
+
+    def _init_layers(self):
+        pass
+
+    def _polymorph(self, batch):                                                            # inference_network_feedforward.py:21-50
+        init = self._session_init
+        layers_changed = False
+        for sub_batch in batch.sub_batches:
+            for variable in sub_batch[0].variables_controlled:
+                address, dname = variable.address, variable.distribution.name
+                if address not in self._layers_proposal:
+                    self._layers_proposal[address] = _PROPOSAL_CLASS[dname](_linears(init, '_layers_proposal.%s._ff.' % address))
+                    layers_changed = True
+        if layers_changed:
+            self._history_num_params.append(sum(p.numel() for p in self.parameters()))
+            self._history_num_params_trace.append(self._total_train_traces)
+        return layers_changed
+
+
 class RecordedLSTMHip(_HipNetworkMixin, RecordedInferenceNetworkLSTM):
     """= `binding.InferenceNetworkLSTMHip` with the recorded module tree in the place of `pyprob.nn.InferenceNetworkLSTM`."""
     _hip_kind = 'lstm'
 
 
+class RecordedFeedForwardHip(_HipNetworkMixin, RecordedInferenceNetworkFeedForward):
+    """= `binding.InferenceNetworkFeedForwardHip` over the recorded module tree."""
+    _hip_kind = 'feedforward'
+
+
 # ---- recorded minibatches ------------------------------------------------------------------------------------------------
 def _distribution(name, p):
-    return D.Normal(float(p[0]), float(p[1])) if name == 'Normal' else D.Uniform(float(p[0]), float(p[1]))
+    if name == 'Normal':
+        return D.Normal(float(p[0]), float(p[1]))
+    if name == 'Uniform':
+        return D.Uniform(float(p[0]), float(p[1]))
+    if name == 'Categorical':
+        return D.Categorical([float(x) for x in p])
+    raise ValueError(name)
 
 
 def traces_from_arrays(meta, trace_len, addr_idx, values, prior, obs):
@@ -192,10 +257,11 @@ def session_batch(meta, arrays, i):
 
 def new_network(case, device, engine_factory=None):
     meta, arrays, init, final = load_session(case)
-    cls = RecordedLSTMHip
+    base = RecordedLSTMHip if meta.get('network', 'lstm') == 'lstm' else RecordedFeedForwardHip
+    cls = base
     if engine_factory is not None or device != cls._hip_device:
-        name = 'RecordedLSTMHip_' + str(device).replace(':', '_')
-        cls = type(name, (RecordedLSTMHip,), dict(_hip_device=device, __module__=__name__))
+        name = base.__name__ + '_' + str(device).replace(':', '_')
+        cls = type(name, (base,), dict(_hip_device=device, __module__=__name__))
         if engine_factory is not None:
             cls._hip_engine_factory = staticmethod(engine_factory)
         globals()[name] = cls               # (importable by name: torch.save pickles the class by reference)

@@ -34,13 +34,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import pyprob  # noqa: E402
 from pyprob import InferenceEngine, InferenceNetwork, Model  # noqa: E402
-from pyprob.distributions import Normal, Uniform  # noqa: E402
-from pyprob.nn import InferenceNetworkLSTM  # noqa: E402
+from pyprob.distributions import Categorical, Normal, Uniform  # noqa: E402
+from pyprob.nn import InferenceNetworkFeedForward, InferenceNetworkLSTM  # noqa: E402
 
 torch.set_num_threads(2)
 LSTM_DIM, BATCH, ITERATIONS, PARTICLES = 32, 32, 12, 48
 EMB = {'obs0': {'dim': 16}, 'obs1': {'dim': 16}}
-OBSERVE = {'gum': {'obs0': 8.0, 'obs1': 9.0}, 'gumm': {'obs0': 4.0, 'obs1': 5.0}}
+OBSERVE = {'gum': {'obs0': 8.0, 'obs1': 9.0}, 'gumm': {'obs0': 4.0, 'obs1': 5.0}, 'ffcat': {'obs0': 1.0, 'obs1': 1.5}}
 
 
 class GaussianWithUnknownMean(Model):
@@ -76,15 +76,30 @@ class GaussianWithUnknownMeanMarsaglia(Model):
         return mu
 
 
+class CategoricalThenNormal(Model):      # the program of the `cat` golden case
+    def __init__(self):
+        super().__init__('categorical then normal')
+
+    def forward(self):
+        c = pyprob.sample(Categorical([0.2, 0.3, 0.5]))
+        mu = pyprob.sample(Normal(c.float() * 2.0 - 1.0, 1.5))
+        likelihood = Normal(mu, 0.8)
+        pyprob.observe(likelihood, name='obs0')
+        pyprob.observe(likelihood, name='obs1')
+        return mu
+
+
 def dist_params(d):
     if d.name == 'Normal':
-        return [float(d.mean), float(d.stddev)]
+        return [float(d.mean), float(d.stddev), 0.0]
     if d.name == 'Uniform':
-        return [float(d.low), float(d.high)]
+        return [float(d.low), float(d.high), 0.0]
+    if d.name == 'Categorical':
+        return [float(p) for p in d._probs.reshape(-1)]          # (three categories in the recorded program)
     raise ValueError(d.name)
 
 
-def record(case, program, seed):
+def record(case, program, seed, network='lstm'):
     rec = dict(created={}, batches=[], losses=[], addresses=[], dist_names=[])
     arrays = {}
     state = dict(iteration=-1, known=[])
@@ -101,7 +116,9 @@ def record(case, program, seed):
                 rec['created'][key].append(n)
                 state['known'].append(n)
 
-    class Recording(InferenceNetworkLSTM):
+    base = InferenceNetworkLSTM if network == 'lstm' else InferenceNetworkFeedForward
+
+    class Recording(base):
         def _init_layers(self):
             super()._init_layers()
             note_created(self)
@@ -136,24 +153,26 @@ def record(case, program, seed):
             return ok, loss
 
     import pyprob.model as M
-    stock = M.InferenceNetworkLSTM
-    M.InferenceNetworkLSTM = Recording
+    slot = 'InferenceNetworkLSTM' if network == 'lstm' else 'InferenceNetworkFeedForward'
+    stock = getattr(M, slot)
+    setattr(M, slot, Recording)
     try:
         pyprob.seed(seed)
         model = program()
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             model.learn_inference_network(num_traces=ITERATIONS * BATCH, batch_size=BATCH, observe_embeddings=EMB,
-                                          inference_network=InferenceNetwork.LSTM, lstm_dim=LSTM_DIM, learning_rate_init=1e-3)
+                                          inference_network=InferenceNetwork.LSTM if network == 'lstm' else InferenceNetwork.FEEDFORWARD,
+                                          lstm_dim=LSTM_DIM, learning_rate_init=1e-3)
     finally:
-        M.InferenceNetworkLSTM = stock
+        setattr(M, slot, stock)
     net = model._inference_network
     assert len(rec['losses']) == ITERATIONS and np.allclose(rec['losses'], net._history_train_loss)
     names = [n for n, _ in net.named_parameters()]
     for k, (n, p) in enumerate(net.named_parameters()):
         arrays['final_%d' % k] = p.detach().cpu().numpy().copy()
     ost = net._optimizer.state
-    watch = [names.index('_layers_lstm.weight_ih_l0'), len(names) - 1]
+    watch = [names.index('_layers_lstm.weight_ih_l0') if network == 'lstm' else 0, len(names) - 1]
     for k in watch:
         p = dict(net.named_parameters())[names[k]]
         arrays['exp_avg_%d' % k] = ost[p]['exp_avg'].cpu().numpy().copy()
@@ -180,7 +199,7 @@ def record(case, program, seed):
     arrays.update(is_trace_len=np.asarray(is_len, np.int32), is_addr_idx=np.asarray(is_addr, np.int32),
                   is_values=np.asarray(is_val, np.float64), is_prior=np.asarray(is_prior, np.float64),
                   is_logq=np.asarray(is_logq, np.float64), is_lw=np.asarray(is_lw, np.float64), is_result=np.asarray(is_result, np.float64))
-    meta = dict(case=case, lstm_dim=LSTM_DIM, mixture_components=10, batch_size=BATCH, iterations=ITERATIONS,
+    meta = dict(case=case, network=network, lstm_dim=LSTM_DIM, mixture_components=10, batch_size=BATCH, iterations=ITERATIONS,
                 observe_embeddings=EMB, obs_names=list(EMB), observe=observe, learning_rate=1e-3, weight_decay=0.0, optimizer='ADAM',
                 created=rec['created'], losses=rec['losses'], addresses=rec['addresses'], dist_names=rec['dist_names'],
                 param_order=names, exp_avg_watch=watch, history_num_params=net._history_num_params,
@@ -194,5 +213,8 @@ def record(case, program, seed):
 
 
 if __name__ == '__main__':
-    record('gum', GaussianWithUnknownMean, 5)
-    record('gumm', GaussianWithUnknownMeanMarsaglia, 7)
+    only = sys.argv[1:]
+    for case, program, seed, network in (('gum', GaussianWithUnknownMean, 5, 'lstm'), ('gumm', GaussianWithUnknownMeanMarsaglia, 7, 'lstm'),
+                                         ('ffcat', CategoricalThenNormal, 9, 'feedforward')):
+        if not only or case in only:
+            record(case, program, seed, network)

@@ -102,7 +102,7 @@ def check_infer_steps(net, meta, arrays, final, logq_rtol=1e-4):
     the reference drew with these final weights (so the chain device -> oracle -> stock reference is closed on this network)."""
     onet = O.Net({n: np.asarray(v, np.float64) for n, v in final.items()}, meta['obs_names'], K=meta['mixture_components'])
     obs = np.array([float(meta['observe'][n]) for n in meta['obs_names']])
-    _, logq_ref, _, _ = O.is_rescore(onet, obs, arrays['is_trace_len'], arrays['is_addr_idx'], arrays['is_values'], arrays['is_prior'],
+    _, logq_ref, _, _ = (O.is_rescore if meta.get('network', 'lstm') == 'lstm' else O.is_rescore_feedforward)(onet, obs, arrays['is_trace_len'], arrays['is_addr_idx'], arrays['is_values'], arrays['is_prior'],
                                      meta['addresses'], meta['dist_names'])
     np.testing.assert_allclose(np.asarray(logq_ref).reshape(-1), arrays['is_logq'], rtol=2e-4, atol=2e-4)
     # the device weights of `net` are the replayed ones (within the trajectory tolerance of the stock's): score against THEM
@@ -113,32 +113,40 @@ def check_infer_steps(net, meta, arrays, final, logq_rtol=1e-4):
     torch.manual_seed(4)
     net._infer_init({n: torch.tensor(float(v)) for n, v in meta['observe'].items()})
     trace_len, addr_idx, values, prior, logq = [], [], [], [], []
-    gumm = len(meta['addresses']) > 1
+    case = meta['case']
+
+    def statement(address, pr, prev):
+        """state.sample's IC branch for one variable (state.py:203-219): proposal, draw, log q."""
+        a = meta['addresses'].index(address)
+        var = Variable(distribution=_distribution(meta['dist_names'][a], pr), address=address, address_base=address, control=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')                                 # "Using prior" would be a failure here
+            proposal = net._infer_step(var, prev_variable=prev)
+        value = proposal.sample()
+        lq = proposal.log_prob(value, sum=True)
+        var.value = torch.as_tensor(value, dtype=torch.float32).reshape(())
+        addr_idx.append(a), values.append(float(var.value)), prior.append(list(pr) + [0.0] * (3 - len(pr))), logq.append(float(lq))
+        return var
+
     for particle in range(24):
         prev, n_vars = None, 0
-        while True:
-            stmts = meta['addresses'][2 * (n_vars // 2):2 * (n_vars // 2) + 2] if gumm else meta['addresses'][:1]
-            if len(stmts) < (2 if gumm else 1):
-                break                                                      # deeper than any address training saw
-            drawn = []
-            for address in stmts:
-                a = meta['addresses'].index(address)
-                pr = (-1.0, 1.0) if gumm else (1.0, math.sqrt(5.0))
-                var = Variable(distribution=_distribution(meta['dist_names'][a], pr), address=address, address_base=address, control=True)
-                with warnings.catch_warnings():
-                    warnings.simplefilter('error')                         # "Using prior" would be a failure here
-                    proposal = net._infer_step(var, prev_variable=prev)
-                value = proposal.sample()
-                lq = proposal.log_prob(value, sum=True)
-                var.value = torch.as_tensor(value, dtype=torch.float32).reshape(())
-                addr_idx.append(a), values.append(float(var.value)), prior.append(pr), logq.append(float(lq))
-                drawn.append(float(var.value))
-                prev = var
-                n_vars += 1
-            if not gumm or drawn[0] ** 2 + drawn[1] ** 2 < 1.0:           # the Marsaglia loop of the program
-                break
+        if case == 'ffcat':                                                # c ~ Categorical; mu ~ Normal(2 c - 1, 1.5)
+            c = statement(meta['addresses'][0], (0.2, 0.3, 0.5), None)
+            statement(meta['addresses'][1], (float(c.value) * 2.0 - 1.0, 1.5), c)
+            n_vars = 2
+        elif case == 'gum':
+            statement(meta['addresses'][0], (1.0, math.sqrt(5.0)), None)
+            n_vars = 1
+        else:                                                              # the Marsaglia loop of the program
+            while 2 * (n_vars // 2) + 2 <= len(meta['addresses']):         # (not deeper than any address training saw)
+                x = statement(meta['addresses'][n_vars], (-1.0, 1.0), prev)
+                prev = statement(meta['addresses'][n_vars + 1], (-1.0, 1.0), x)
+                n_vars += 2
+                if float(x.value) ** 2 + float(prev.value) ** 2 < 1.0:
+                    break
         trace_len.append(n_vars)
-    _, want, _, _ = O.is_rescore(dnet, obs, np.asarray(trace_len), np.asarray(addr_idx), np.asarray(values, np.float64),
+    rescore = O.is_rescore if meta.get('network', 'lstm') == 'lstm' else O.is_rescore_feedforward
+    _, want, _, _ = rescore(dnet, obs, np.asarray(trace_len), np.asarray(addr_idx), np.asarray(values, np.float64),
                                  np.asarray(prior, np.float64), meta['addresses'], meta['dist_names'])
     np.testing.assert_allclose(logq, np.asarray(want).reshape(-1), rtol=logq_rtol, atol=logq_rtol)
     return len(logq)
