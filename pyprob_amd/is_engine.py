@@ -79,15 +79,30 @@ class ISRunner:
             k = int(vals.size)
             self._pins(k)
             self._obs_np[:k] = vals
-            self._obs_dev.copy_(self._obs_pin, non_blocking=True)
             if self.e_obs.numel() != self.e_obs_floats() or self.e_obs.device != self.dev:
                 self.e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
             self._st = L.stream_ptr()
-            L.check(self.lib.pp_is_init(C.byref(self.eng.net), self.eng.params.data_ptr(), self._obs_dev.data_ptr(),
-                                        self.e_obs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_init')
+            # The embedding launch is DEFERRED to the first statement (round 6): a trace's first statement on a network
+            # pp_is_first_statement takes runs embedding + LSTM row + proposal layer as ONE launch that reads the observation
+            # from the pinned staging in place (what a launch-plan replay does) - also when forward() runs in every call
+            # (PP_IS_PLAN=0, a program without a plan, pyprob as the host). Anything else that needs the embedding first
+            # (`_ensure_init`) launches pp_is_init as before.
+            self._init_pending = k
+            if os.environ.get('PP_IS_LAZY_INIT', '1') == '0':
+                self._ensure_init()
             return
         obs = torch.as_tensor(vals).to(self.dev)
         self.e_obs = ops.is_init(self.eng.params, self.ws, self.eng.net_handle, obs)
+
+    _init_pending = 0
+
+    def _ensure_init(self):
+        """The observe embedding of the call's observation exists on the device after this (see `init`)."""
+        k, self._init_pending = self._init_pending, 0
+        if k:
+            self._obs_dev.copy_(self._obs_pin, non_blocking=True)
+            L.check(self.lib.pp_is_init(C.byref(self.eng.net), self.eng.params.data_ptr(), self._obs_dev.data_ptr(),
+                                        self.e_obs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_init')
 
     def begin(self, n, offset=0):
         """Start n traces in lock step (state._begin_trace, state.py:339-345): LSTM state is reset by the first step."""
@@ -119,6 +134,7 @@ class ISRunner:
         """One controlled sample statement for all particles. prior: device tensor [1,2] (shared) or [n,2].
         Returns (values [n], log q [n]) as device tensors."""
         n = self.n
+        self._ensure_init()
         value, logq = ops.is_step(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
                                   -1 if prev_addr_id is None else int(prev_addr_id), n, self.e_obs, self.prev_value, prior,
                                   self.h, self.c, self.state_rows, value_in, int(seed), self.offset)
@@ -130,6 +146,17 @@ class ISRunner:
     def step_net(self, addr_id, prev_addr_id):
         """The network part of `step` only (LSTM step + proposal layer): the head outputs stay in the workspace and the
         draw happens in `fused`, together with the log-weight terms of the statements that follow."""
+        k = self._init_pending
+        if k and prev_addr_id is None and k <= 8 and self.dev.type == 'cuda' and \
+                self.lib.pp_is_first_statement_supported(C.byref(self.eng.net), int(addr_id)):
+            # embedding + one-row LSTM step + proposal layer in ONE launch, the observation read from pinned memory in place
+            self._init_pending = 0
+            L.check(self.lib.pp_is_first_statement(C.byref(self.eng.net), self.eng.params.data_ptr(), self._obs_pin.data_ptr(),
+                                                   int(addr_id), self.e_obs.data_ptr(), self.h.data_ptr(), self.c.data_ptr(),
+                                                   self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_first_statement')
+            self.state_rows = 1
+            return
+        self._ensure_init()
         ops.is_step_net(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
                         -1 if prev_addr_id is None else int(prev_addr_id), self.n, self.e_obs, self.prev_value, self.h, self.c,
                         self.state_rows)
@@ -204,6 +231,7 @@ class ISRunner:
         k = len(obs_values)
         self._pins(k)
         self._obs_np[:k] = obs_values
+        self._init_pending = 0          # (this call issues its own first statement)
         self.begin(n, offset)
         st = self._st
         params, ws = self.eng.params.data_ptr(), self.ws.data_ptr()
@@ -275,6 +303,7 @@ class ISRunner:
         """The whole statement for the particles `rows` (None: all) in one launch: previous values read at the rows, value
         written to values_full[rows], lw_full[rows] += log p(v) - log q(v) (pp_is_statement_rows)."""
         m = self.n if rows is None else int(rows.numel())
+        self._ensure_init()
         state_rows = self.state_rows
         if rows is not None and state_rows == 1 and self.n > 1:
             self.h[:, 1:] = self.h[:, :1]      # the shared first-statement state (row 0) becomes per-particle
@@ -296,6 +325,7 @@ class ISRunner:
         previous values are gathered into a compact batch, stepped, and scattered back. rows: int64 device tensor; prior:
         [1, 2], or one row per particle ([n, 2]; prior_compact: one row per entry of `rows`)."""
         m = int(rows.numel())
+        self._ensure_init()
         if (prev_addr_id is not None and self.dev.type == 'cuda' and self.eng.spec.lstm_depth == 1 and
                 self.lib.pp_is_step_fused_supported(C.byref(self.eng.net), int(addr_id), m)):
             # the fused statement kernel reads and writes the rows' state in place through the index list
