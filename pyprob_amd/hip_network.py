@@ -214,7 +214,8 @@ class _HipNetworkMixin:
         for name in self._hip_obs_names:
             vals.extend(torch.as_tensor(observe[name], dtype=torch.float32).reshape(-1).tolist())
         self._hip_is.init(vals)
-        self._infer_observe_embedding = self._hip_is.e_obs[:self._hip_engine.spec.e_obs].reshape(1, -1)
+        # (a VIEW of the runner's embedding row: the launch that fills it is deferred into the first statement, ISRunner.init)
+        self._infer_observe_embedding = self._hip_is._e_obs[:self._hip_engine.spec.e_obs].reshape(1, -1)
         self._hip_prev_address = None
 
     def _infer_step(self, variable, prev_variable=None, proposal_min_train_iterations=None):

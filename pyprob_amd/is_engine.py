@@ -23,7 +23,7 @@ class ISRunner:
         self.eng = engine
         self.lib = engine.lib
         self.dev = engine.device
-        self.e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
+        self._e_obs = torch.zeros(self._e_obs_floats(), dtype=torch.float32, device=self.dev)
         self.ws = None
         self.ws_bytes = 0
         self.n = 0
@@ -79,8 +79,8 @@ class ISRunner:
             k = int(vals.size)
             self._pins(k)
             self._obs_np[:k] = vals
-            if self.e_obs.numel() != self.e_obs_floats() or self.e_obs.device != self.dev:
-                self.e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
+            if self._e_obs.numel() != self._e_obs_floats() or self._e_obs.device != self.dev:
+                self._e_obs = torch.zeros(self._e_obs_floats(), dtype=torch.float32, device=self.dev)
             self._st = L.stream_ptr()
             # The embedding launch is DEFERRED to the first statement (round 6): a trace's first statement on a network
             # pp_is_first_statement takes runs embedding + LSTM row + proposal layer as ONE launch that reads the observation
@@ -92,9 +92,19 @@ class ISRunner:
                 self._ensure_init()
             return
         obs = torch.as_tensor(vals).to(self.dev)
-        self.e_obs = ops.is_init(self.eng.params, self.ws, self.eng.net_handle, obs)
+        self._e_obs = ops.is_init(self.eng.params, self.ws, self.eng.net_handle, obs)
 
     _init_pending = 0
+
+    @property
+    def e_obs(self):
+        """The observe embedding row (+ the device copies of the observation behind it) - computed by now if it was deferred."""
+        self._ensure_init()
+        return self._e_obs
+
+    @e_obs.setter
+    def e_obs(self, value):
+        self._e_obs = value
 
     def _ensure_init(self):
         """The observe embedding of the call's observation exists on the device after this (see `init`)."""
@@ -102,7 +112,7 @@ class ISRunner:
         if k:
             self._obs_dev.copy_(self._obs_pin, non_blocking=True)
             L.check(self.lib.pp_is_init(C.byref(self.eng.net), self.eng.params.data_ptr(), self._obs_dev.data_ptr(),
-                                        self.e_obs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_init')
+                                        self._e_obs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_init')
 
     def begin(self, n, offset=0):
         """Start n traces in lock step (state._begin_trace, state.py:339-345): LSTM state is reset by the first step."""
@@ -136,7 +146,7 @@ class ISRunner:
         n = self.n
         self._ensure_init()
         value, logq = ops.is_step(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
-                                  -1 if prev_addr_id is None else int(prev_addr_id), n, self.e_obs, self.prev_value, prior,
+                                  -1 if prev_addr_id is None else int(prev_addr_id), n, self._e_obs, self.prev_value, prior,
                                   self.h, self.c, self.state_rows, value_in, int(seed), self.offset)
         self.state_rows = 1 if prev_addr_id is None else n   # see include/pyprob_amd.h
         self.prev_value = value
@@ -152,13 +162,13 @@ class ISRunner:
             # embedding + one-row LSTM step + proposal layer in ONE launch, the observation read from pinned memory in place
             self._init_pending = 0
             L.check(self.lib.pp_is_first_statement(C.byref(self.eng.net), self.eng.params.data_ptr(), self._obs_pin.data_ptr(),
-                                                   int(addr_id), self.e_obs.data_ptr(), self.h.data_ptr(), self.c.data_ptr(),
+                                                   int(addr_id), self._e_obs.data_ptr(), self.h.data_ptr(), self.c.data_ptr(),
                                                    self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_first_statement')
             self.state_rows = 1
             return
         self._ensure_init()
         ops.is_step_net(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
-                        -1 if prev_addr_id is None else int(prev_addr_id), self.n, self.e_obs, self.prev_value, self.h, self.c,
+                        -1 if prev_addr_id is None else int(prev_addr_id), self.n, self._e_obs, self.prev_value, self.h, self.c,
                         self.state_rows)
         self.state_rows = 1 if prev_addr_id is None else self.n
 
@@ -238,16 +248,16 @@ class ISRunner:
         # (asked per call, not cached in the plan: the C side re-reads PP_IS_FIRST on every call, a plan recorded under another
         # setting must take the staged path instead of failing with PP_EINVAL - ADVICE r05)
         first = plan['first'] = bool(k <= 8 and lib.pp_is_first_statement_supported(net, plan['addr']))
-        if self.e_obs.numel() != self.e_obs_floats():
-            self.e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
+        if self._e_obs.numel() != self._e_obs_floats():
+            self._e_obs = torch.zeros(self._e_obs_floats(), dtype=torch.float32, device=self.dev)
         if first:
-            L.check(lib.pp_is_first_statement(net, params, self._obs_pin.data_ptr(), plan['addr'], self.e_obs.data_ptr(),
+            L.check(lib.pp_is_first_statement(net, params, self._obs_pin.data_ptr(), plan['addr'], self._e_obs.data_ptr(),
                                               self.h.data_ptr(), self.c.data_ptr(), ws, self.ws_bytes, st), 'pp_is_first_statement')
-            obs_base = self.e_obs.data_ptr() + 4 * ((self.eng.spec.e_obs + 3) & ~3)      # the device copies behind the embedding
+            obs_base = self._e_obs.data_ptr() + 4 * ((self.eng.spec.e_obs + 3) & ~3)      # the device copies behind the embedding
         else:
             self._obs_dev.copy_(self._obs_pin, non_blocking=True)
-            L.check(lib.pp_is_init(net, params, self._obs_dev.data_ptr(), self.e_obs.data_ptr(), ws, self.ws_bytes, st), 'pp_is_init')
-            L.check(lib.pp_is_step_net(net, params, plan['addr'], -1, n, self.e_obs.data_ptr(), None, self.h.data_ptr(),
+            L.check(lib.pp_is_init(net, params, self._obs_dev.data_ptr(), self._e_obs.data_ptr(), ws, self.ws_bytes, st), 'pp_is_init')
+            L.check(lib.pp_is_step_net(net, params, plan['addr'], -1, n, self._e_obs.data_ptr(), None, self.h.data_ptr(),
                                        self.c.data_ptr(), 1, ws, self.ws_bytes, st), 'pp_is_step_net')
             obs_base = self._obs_dev.data_ptr()
         self.state_rows = 1
@@ -312,7 +322,7 @@ class ISRunner:
         self._ensure_ws(m)
         # (straight through the C ABI: whole_statement_ok has checked the shapes, the tensors are this executor's own)
         L.check(self.lib.pp_is_statement_rows(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id), int(prev_addr_id), m,
-                                              self.e_obs.data_ptr(), self.prev_value.data_ptr(), prior.data_ptr(), 0,
+                                              self._e_obs.data_ptr(), self.prev_value.data_ptr(), prior.data_ptr(), 0,
                                               self.h.data_ptr(), self.c.data_ptr(), 1 if state_rows == 1 else m, L.ptr(rows),
                                               values_full.data_ptr(), lw_full.data_ptr(), self.PRIOR_KIND[dist_name], int(seed),
                                               int(self.offset), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_statement_rows')
@@ -337,7 +347,7 @@ class ISRunner:
             if prior is not None and prior.shape[0] != 1 and not prior_compact:
                 prior = prior.index_select(0, rows).contiguous()
             self._ensure_ws(m)
-            return ops.is_step_rows(self.eng.params, self.ws, self.eng.net_handle, int(addr_id), int(prev_addr_id), m, self.e_obs,
+            return ops.is_step_rows(self.eng.params, self.ws, self.eng.net_handle, int(addr_id), int(prev_addr_id), m, self._e_obs,
                                     prev, prior, self.h, self.c, m, rows, None, int(seed), self.offset)
         if self.state_rows == 1 and self.n > 1 and prev_addr_id is not None:
             self.h[:, 1:] = self.h[:, :1]      # the shared first-statement state (row 0) becomes per-particle
@@ -350,7 +360,7 @@ class ISRunner:
             prior = prior.index_select(0, rows).contiguous()
         self._ensure_ws(m)
         value, logq = ops.is_step(self.eng.params, self.ws, self.eng.net_handle, int(addr_id),
-                                  -1 if prev_addr_id is None else int(prev_addr_id), m, self.e_obs, prev, prior, h, c,
+                                  -1 if prev_addr_id is None else int(prev_addr_id), m, self._e_obs, prev, prior, h, c,
                                   1 if prev_addr_id is None else m, None, int(seed), self.offset)
         if prev_addr_id is None:     # the call left the (shared) new state in row 0 of every layer
             h = h[:, :1].expand(-1, m, -1)
