@@ -23,7 +23,7 @@ class ISRunner:
         self.eng = engine
         self.lib = engine.lib
         self.dev = engine.device
-        self._e_obs = torch.zeros(self._e_obs_floats(), dtype=torch.float32, device=self.dev)
+        self._e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
         self.ws = None
         self.ws_bytes = 0
         self.n = 0
@@ -79,8 +79,8 @@ class ISRunner:
             k = int(vals.size)
             self._pins(k)
             self._obs_np[:k] = vals
-            if self._e_obs.numel() != self._e_obs_floats() or self._e_obs.device != self.dev:
-                self._e_obs = torch.zeros(self._e_obs_floats(), dtype=torch.float32, device=self.dev)
+            if self._e_obs.numel() != self.e_obs_floats() or self._e_obs.device != self.dev:
+                self._e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
             self._st = L.stream_ptr()
             # The embedding launch is DEFERRED to the first statement (round 6): a trace's first statement on a network
             # pp_is_first_statement takes runs embedding + LSTM row + proposal layer as ONE launch that reads the observation
@@ -248,8 +248,8 @@ class ISRunner:
         # (asked per call, not cached in the plan: the C side re-reads PP_IS_FIRST on every call, a plan recorded under another
         # setting must take the staged path instead of failing with PP_EINVAL - ADVICE r05)
         first = plan['first'] = bool(k <= 8 and lib.pp_is_first_statement_supported(net, plan['addr']))
-        if self._e_obs.numel() != self._e_obs_floats():
-            self._e_obs = torch.zeros(self._e_obs_floats(), dtype=torch.float32, device=self.dev)
+        if self._e_obs.numel() != self.e_obs_floats():
+            self._e_obs = torch.zeros(self.e_obs_floats(), dtype=torch.float32, device=self.dev)
         if first:
             L.check(lib.pp_is_first_statement(net, params, self._obs_pin.data_ptr(), plan['addr'], self._e_obs.data_ptr(),
                                               self.h.data_ptr(), self.c.data_ptr(), ws, self.ws_bytes, st), 'pp_is_first_statement')
