@@ -898,6 +898,14 @@ def main():
             config['gumm_statement_frac_executed'] = sk.get('frac_executed')
             config['gumm_wall_over_statement_kernels'] = sk.get('wall_over_statement_kernels')
         rl = out.get('roofline', {})
+        # MFMA utilisation by COUNTER (SQ_VALU_MFMA_BUSY_CYCLES over the launch's SIMD cycles, tools/pmc_kernel.sh; quoted on a
+        # source-hash match): what `frac_executed` estimates from the FLOP count
+        mdoc, mnote = committed_profile('r06_mfma_busy.json') if (args.batch == 1024 and args.lstm_dim == 512) else (None, 'not the profiled shape')
+        if mdoc is not None and 'kernel' in rl:
+            key = 'panel' if 'panel16' in rl['kernel'] else 'wgrad_group'
+            rl['mfma_busy_frac'] = mdoc['kernels'].get(key, {}).get('mfma_busy_frac')
+            rl['wgrad_mfma_busy_frac'] = mdoc['kernels'].get('wgrad_group', {}).get('mfma_busy_frac')
+            rl['mfma_busy_source'] = mnote
         if 'whole_step' in rl:
             rl['whole_step_frac'] = rl['whole_step']['frac']
         if 'second_kernel' in rl:
