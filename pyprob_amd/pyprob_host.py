@@ -93,6 +93,17 @@ def _to_tensor_in_place(value, dtype=torch.float32):
     return torch.tensor(value, dtype=dtype)
 
 
+class _NoDirectCalls:
+    """`pyprob.state._current_trace` for the duration of a batched call: pyprob's ORIGINAL `sample` / `observe` - reached by a program
+    that captured them (`from pyprob import sample`) - would find no current trace and quietly hand out ONE prior draw with no
+    weight (state.py:162-163); with this object in place they fail, the probe rejects the program, and it takes the executors
+    that run pyprob's own trace runtime."""
+
+    def __getattr__(self, name):
+        raise NotImplementedError('pyprob.state.sample / observe were called directly during a batched run (the program captured the '
+                                  'functions instead of calling pyprob.sample / pyprob.observe)')
+
+
 @contextlib.contextmanager
 def forwarded(device):
     """`pyprob.sample` / `pyprob.observe` (and the `state` module's names) forward to this package's trace runtime; pyprob's
@@ -109,6 +120,8 @@ def forwarded(device):
     if saved['factor'] is not None:
         pyprob.factor = _refuse
     _pp_util.to_tensor = _to_tensor_in_place
+    saved['trace'] = _pp_state._current_trace
+    _pp_state._current_trace = _NoDirectCalls()
     S._address_frame_skip = 1
     torch.distributions.Distribution.set_default_validate_args(False)
     try:
@@ -121,6 +134,7 @@ def forwarded(device):
         if saved['factor'] is not None:
             pyprob.factor = saved['factor']
         _pp_util.to_tensor = saved['to_tensor']
+        _pp_state._current_trace = saved['trace']
         S._address_frame_skip = saved['skip']
         torch.distributions.Distribution.set_default_validate_args(saved['validate'])
 

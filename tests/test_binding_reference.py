@@ -1032,3 +1032,37 @@ def test_other_proposal_layers_in_lock_step_through_pyprob_model(batched, progra
     for b in range(n):
         want[b] += sum(float(O.normal_log_prob(y, v1[b], sigma)) for y in obs)
     np.testing.assert_allclose(lw, want, rtol=1e-4, atol=2e-4)
+
+
+from pyprob import observe as _captured_observe, sample as _captured_sample  # noqa: E402  (what a program may have done)
+
+
+class _CapturedNames(Model):
+    """A program that holds pyprob's functions by name: the forwarding of `pyprob.sample` / `pyprob.observe` cannot reach it."""
+
+    def __init__(self):
+        super().__init__('captured names')
+
+    def forward(self):
+        mu = _captured_sample(Normal(1, math.sqrt(5)))
+        likelihood = Normal(mu, math.sqrt(2))
+        _captured_observe(likelihood, name='obs0')
+        _captured_observe(likelihood, name='obs1')
+        return mu
+
+
+def test_a_program_that_captured_pyprobs_functions_is_not_batched(batched):
+    """pyprob's original `sample` without a current trace returns one bare prior draw (state.py:162-163): a batched run of such a
+    program would be silently wrong. The forwarding context makes the original functions fail, the probes reject the program,
+    and training / inference take pyprob's own loops (and are right)."""
+    pyprob.seed(3)
+    model = _CapturedNames()
+    net = _quiet_learn(model, num_traces=32 * 6, batch_size=32)
+    assert net._hip_last_optimize == "pyprob's loop" and net._total_train_iterations == 6
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        post = model.posterior_results(40, IC, observe={'obs0': 8.0, 'obs1': 9.0})
+    assert type(post).__name__ == 'Empirical' and post.length == 40           # coroutines / pyprob's loop, not the lock-step executor
+    values = np.array([float(v) for v in post.values])
+    assert len(set(np.round(values, 5))) > 30                                  # distinct particles (not one bare prior draw)
+    assert pyprob.state._current_trace is None or type(pyprob.state._current_trace).__name__ != '_NoDirectCalls'
