@@ -72,6 +72,21 @@ class _FastOptimize:
                                            optimizer_type, momentum):
                 self._hip_last_optimize = 'batched (pyprob_host.optimize_online)'
                 return
+        from .dataset import PackedTraceDataset
+        if isinstance(dataset, PackedTraceDataset):
+            # an offline dataset of packed shards (install() makes learn_inference_network(dataset_dir=...) open them): the
+            # reference's DataLoader + Batch route cannot read it - single process, Adam; anything else is an error, not a fallback
+            if distributed_backend is not None or (self._optimizer_type or optimizer_type) != Optimizer.ADAM or \
+                    not (dataset_valid is None or isinstance(dataset_valid, PackedTraceDataset)):
+                raise NotImplementedError('packed offline datasets train in one process with Optimizer.ADAM (and a packed validation '
+                                          'set); use pyprob.nn.OfflineDataset files (PYPROB_HIP_PACKED_DATASET=0) for the other paths')
+            from . import pyprob_host
+            pyprob_host.optimize_packed(self, dataset, dataset_valid, num_traces, batch_size, valid_every, learning_rate_init,
+                                        learning_rate_end, learning_rate_scheduler_type, weight_decay, num_traces_end,
+                                        save_file_name_prefix, save_every_sec, stop_with_bad_loss, optimizer_type, momentum,
+                                        log_file_name, distributed_num_buckets)
+            self._hip_last_optimize = 'batched (pyprob_host.optimize_packed)'
+            return
         self._hip_last_optimize = "pyprob's loop"
         return super().optimize(num_traces=num_traces, dataset=dataset, dataset_valid=dataset_valid, num_traces_end=num_traces_end,
                                 batch_size=batch_size, valid_every=valid_every, optimizer_type=optimizer_type,
@@ -83,6 +98,14 @@ class _FastOptimize:
                                 distributed_num_buckets=distributed_num_buckets,
                                 dataloader_offline_num_workers=dataloader_offline_num_workers,
                                 stop_with_bad_loss=stop_with_bad_loss, log_file_name=log_file_name)
+
+
+    def _pre_generate_layers(self, dataset, batch_size=64, save_file_name_prefix=None):
+        from .dataset import PackedTraceDataset
+        if isinstance(dataset, PackedTraceDataset):       # inference_network.py:269-288 from the dataset's address table
+            from . import pyprob_host
+            return pyprob_host.pre_generate_layers_packed(self, dataset, save_file_name_prefix)
+        return super()._pre_generate_layers(dataset, batch_size=batch_size, save_file_name_prefix=save_file_name_prefix)
 
 
 class InferenceNetworkLSTMHip(_FastOptimize, _HipNetworkMixin, _RefLSTM):
@@ -180,6 +203,31 @@ def _traces_with_coroutines(self, num_traces=10, trace_mode=None, prior_inflatio
     return traces
 
 
+_original_offline = None
+_original_save_dataset = None
+
+
+def _open_offline_dataset(dataset_dir):
+    from . import pyprob_host
+    return pyprob_host.open_offline_dataset(dataset_dir)
+
+
+def _save_dataset(self, dataset_dir, num_traces, num_traces_per_file, prior_inflation=None, *args, **kwargs):
+    from pyprob import PriorInflation
+    prior_inflation = PriorInflation.DISABLED if prior_inflation is None else prior_inflation
+    if os.environ.get('PYPROB_HIP_PACKED_DATASET', '1') == '0':
+        return _original_save_dataset(self, dataset_dir, num_traces, num_traces_per_file, prior_inflation, *args, **kwargs)
+    from . import pyprob_host
+    return pyprob_host.save_dataset_packed(self, dataset_dir, num_traces, num_traces_per_file, prior_inflation, args, kwargs)
+
+
+def convert_dataset(shelve_dir, packed_dir, num_traces_per_file=100000, obs_names=None):
+    """An existing pyprob dataset directory (shelve files) -> packed shards `learn_inference_network(dataset_dir=packed_dir)` trains
+    from at full speed (pyprob_host.convert_dataset)."""
+    from . import pyprob_host
+    return pyprob_host.convert_dataset(shelve_dir, packed_dir, num_traces_per_file, obs_names)
+
+
 def _have_greenlet():
     try:
         import greenlet  # noqa: F401
@@ -192,20 +240,29 @@ def install():
     """Make pyprob build HIP-backed inference networks and serve importance sampling in batches: replaces the two
     classes `Model.learn_inference_network` instantiates (pyprob/model.py:199-204) and wraps `Model._traces`. Networks
     saved afterwards unpickle as the HIP classes (they must be importable: `import pyprob_amd.binding`)."""
-    global _original_traces
+    global _original_traces, _original_save_dataset, _original_offline
     import pyprob.model as M
     M.InferenceNetworkLSTM = InferenceNetworkLSTMHip
     M.InferenceNetworkFeedForward = InferenceNetworkFeedForwardHip
     if _original_traces is None:
         _original_traces = M.Model._traces
         M.Model._traces = _traces_with_coroutines
+    if _original_offline is None:
+        # offline datasets (pyprob/model.py:186-195, 227-232): `save_dataset` writes packed shards and `dataset_dir` opens them
+        # (pyprob's shelve files are still opened by pyprob's own OfflineDataset; PYPROB_HIP_PACKED_DATASET=0 writes them too)
+        _original_offline, _original_save_dataset = M.OfflineDataset, M.Model.save_dataset
+        M.OfflineDataset = _open_offline_dataset
+        M.Model.save_dataset = _save_dataset
 
 
 def uninstall():
-    global _original_traces
+    global _original_traces, _original_save_dataset, _original_offline
     import pyprob.model as M
     M.InferenceNetworkLSTM = _RefLSTM
     M.InferenceNetworkFeedForward = _RefFeedForward
     if _original_traces is not None:
         M.Model._traces = _original_traces
         _original_traces = None
+    if _original_offline is not None:
+        M.OfflineDataset, M.Model.save_dataset = _original_offline, _original_save_dataset
+        _original_offline = _original_save_dataset = None

@@ -381,46 +381,144 @@ def optimize_online(net, dataset, num_traces, batch_size, learning_rate_init, le
                 ad.prior_traces_packed(8, obs_names, prior_inflation=inflation)             # the probe
         except Exception:   # noqa: BLE001 - any failure of the probe means "not lock-step safe"
             return False
-        # the optimizer settings the reference fixes at the first call (inference_network.py:438-452)
-        if net._optimizer_type is None:
-            net._optimizer_type = optimizer_type
-        if net._momentum is None:
-            net._momentum = momentum
-        if net._weight_decay is None:
-            net._weight_decay = weight_decay
-        if net._learning_rate_scheduler_type is None:
-            net._learning_rate_scheduler_type = pyprob.LearningRateScheduler.NONE
-        if net._learning_rate_init is None:
-            net._learning_rate_init = learning_rate_init
-        if net._learning_rate_end is None:
-            net._learning_rate_end = learning_rate_end
-        if net._total_train_traces_end is None:
-            net._total_train_traces_end = num_traces_end
-        net.train()
-        if net._hip_engine is None:
-            net._hip_bind()                          # the layers that exist so far (observe embedding, LSTM) into the flat buffer
-        if net._optimizer is None:
-            net._create_optimizer()
-            net._create_lr_scheduler()
-        cls = _OptimizeViewFF if net._hip_kind == 'feedforward' else _OptimizeView
-        base = network_view(net)
-        view = cls.__new__(cls)
-        view.__dict__.update(base.__dict__)
-        view._hip_owner = net
-        for k in _BOOKKEEPING:
-            setattr(view, k, getattr(net, k))
-        view._optimizer_type = 'ADAM'
-        view._learning_rate_scheduler_type = None
         gen_dev = net._hip_device if str(net._hip_device).startswith('cuda') and os.environ.get('PP_PRIOR_DEVICE', '1') != '0' else 'cpu'
         vds = VectorisedOnlineDataset(ad, obs_names, chunk_traces=max(64 * batch_size, 16384), prior_inflation=inflation,
                                       device=gen_dev)
-        try:
-            view.optimize(num_traces, vds, batch_size=batch_size, learning_rate_init=net._learning_rate_init,
-                          learning_rate_end=net._learning_rate_end, weight_decay=net._weight_decay,
-                          num_traces_end=net._total_train_traces_end, stop_with_bad_loss=stop_with_bad_loss,
-                          save_file_name_prefix=save_file_name_prefix, save_every_sec=save_every_sec, verbose=False,
-                          optimizer_type='ADAM')
-        finally:
-            view._sync_back()
+        _run_view_optimize(net, vds, None, num_traces, batch_size, learning_rate_init, learning_rate_end, weight_decay, num_traces_end,
+                           save_file_name_prefix, save_every_sec, stop_with_bad_loss, optimizer_type, momentum,
+                           pyprob.LearningRateScheduler.NONE, None, None, None)
+    return True
+
+
+def _run_view_optimize(net, dataset, dataset_valid, num_traces, batch_size, learning_rate_init, learning_rate_end, weight_decay,
+                       num_traces_end, save_file_name_prefix, save_every_sec, stop_with_bad_loss, optimizer_type, momentum,
+                       learning_rate_scheduler_type, valid_every, log_file_name, distributed_num_buckets):
+    """The settings the reference fixes at the first call (inference_network.py:438-452), the optimizer / scheduler objects, then
+    `pyprob_amd.nn.InferenceNetworkLSTM.optimize` over the binding's engine (`_OptimizeView`), and the bookkeeping back."""
+    if net._optimizer_type is None:
+        net._optimizer_type = optimizer_type
+    if net._momentum is None:
+        net._momentum = momentum
+    if net._weight_decay is None:
+        net._weight_decay = weight_decay
+    if net._learning_rate_scheduler_type is None:
+        net._learning_rate_scheduler_type = learning_rate_scheduler_type
+    if net._learning_rate_init is None:
+        net._learning_rate_init = learning_rate_init
+    if net._learning_rate_end is None:
+        net._learning_rate_end = learning_rate_end
+    if net._total_train_traces_end is None:
+        net._total_train_traces_end = num_traces_end
+    net.train()
+    if net._hip_engine is None:
+        net._hip_bind()                          # the layers that exist so far (observe embedding, LSTM) into the flat buffer
+    if net._optimizer is None:
+        net._create_optimizer()
+        net._create_lr_scheduler()
+    cls = _OptimizeViewFF if net._hip_kind == 'feedforward' else _OptimizeView
+    base = network_view(net)
+    view = cls.__new__(cls)
+    view.__dict__.update(base.__dict__)
+    view._hip_owner = net
+    for k in _BOOKKEEPING:
+        setattr(view, k, getattr(net, k))
+    view._optimizer_type = 'ADAM'
+    sched = str(net._learning_rate_scheduler_type).split('.')[-1].upper()
+    view._learning_rate_scheduler_type = None if sched == 'NONE' else sched
+    try:
+        view.optimize(num_traces, dataset, batch_size=batch_size, learning_rate_init=net._learning_rate_init,
+                      learning_rate_end=net._learning_rate_end, weight_decay=net._weight_decay,
+                      num_traces_end=net._total_train_traces_end, stop_with_bad_loss=stop_with_bad_loss,
+                      save_file_name_prefix=save_file_name_prefix, save_every_sec=save_every_sec, verbose=False,
+                      optimizer_type='ADAM', learning_rate_scheduler_type=view._learning_rate_scheduler_type,
+                      dataset_valid=dataset_valid, valid_every=valid_every, log_file_name=log_file_name,
+                      distributed_num_buckets=distributed_num_buckets)
+    finally:
+        view._sync_back()
+        if net._learning_rate_scheduler is not None:
+            # the reference steps its LambdaLR with the TRACE COUNT every iteration (inference_network.py:567-568): one step to
+            # where training stands leaves the scheduler object (and the optimizer's lr) where pyprob's own loop would have
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                net._learning_rate_scheduler.step(net._total_train_traces)
     net._hip_grads_clean = False
+
+
+# ---- offline datasets (pyprob/nn/dataset.py:121-263, pyprob/model.py:186-232) -------------------------------------------------
+def open_offline_dataset(dataset_dir):
+    """What `Model.learn_inference_network(dataset_dir=...)` opens: packed shards (pyprob_amd/dataset.py: columnar `.npy` files +
+    `meta.json`, written by `save_dataset_packed` / `convert_dataset`) as a `PackedTraceDataset`, anything else - pyprob's shelve
+    files - as pyprob's own `OfflineDataset`."""
+    from pyprob.nn import OfflineDataset
+    from .dataset import PackedTraceDataset
+    packed = os.path.isdir(dataset_dir) and any(os.path.exists(os.path.join(dataset_dir, d, 'meta.json')) for d in os.listdir(dataset_dir))
+    if packed and os.environ.get('PYPROB_HIP_PACKED_DATASET', '1') != '0':
+        return PackedTraceDataset(dataset_dir)
+    return OfflineDataset(dataset_dir=dataset_dir)
+
+
+def save_dataset_packed(pp_model, dataset_dir, num_traces, num_traces_per_file, prior_inflation, args, kwargs):
+    """`Model.save_dataset` (pyprob/model.py:227-232) writing packed shards: prior traces generated in lock step when the program
+    allows it, else one `forward()` per trace through this package's trace runtime (same address strings either way)."""
+    from pyprob import PriorInflation
+    from .dataset import save_dataset
+    inflation = S.PriorInflation.ENABLED if prior_inflation == PriorInflation.ENABLED else S.PriorInflation.DISABLED
+    with forwarded('cpu'):
+        return save_dataset(ProgramAdapter(pp_model), dataset_dir, int(num_traces), int(num_traces_per_file), None, *args,
+                            prior_inflation=inflation, **kwargs)
+
+
+def convert_dataset(shelve_dir, packed_dir, num_traces_per_file=100000, obs_names=None):
+    """An existing pyprob dataset (shelve files, read with pyprob's own `OfflineDataset`: the slow per-trace decode, once) into
+    packed shards. obs_names: the observables to keep, in the order of the network's `observe_embeddings` (default: every named
+    variable of the pruned traces, `nn/dataset.py:64-119`, in their order). Returns the number of traces."""
+    from pyprob.nn import OfflineDataset
+    from .dataset import PackedTraceWriter
+    src = OfflineDataset(dataset_dir=shelve_dir)
+    os.makedirs(packed_dir, exist_ok=True)
+    n, shard, writer, names = len(src), 0, None, (None if obs_names is None else list(obs_names))
+    for i in range(n):
+        trace = src[i]
+        if names is None:
+            names = list(trace.named_variables.keys())
+        if writer is None:
+            m = min(num_traces_per_file, n - i)
+            writer = PackedTraceWriter(os.path.join(packed_dir, 'pyprob_traces_packed_{:06d}_{}'.format(shard, m)), names)
+            left = m
+        writer.add_trace(trace)
+        left -= 1
+        if left == 0:
+            writer.close()
+            writer, shard = None, shard + 1
+    if writer is not None:
+        writer.close()
+    return n
+
+
+def pre_generate_layers_packed(net, dataset, save_file_name_prefix=None):
+    """`InferenceNetwork._pre_generate_layers` (inference_network.py:269-288) for a packed dataset: its address table names every
+    layer there is to create - no pass over the traces."""
+    if not net._layers_initialized:
+        net._init_layers_observe_embedding(net._observe_embeddings, example_trace=dataset[0])
+        net._init_layers()
+        net._layers_initialized = True
+    net._layers_pre_generated = True
+    new = [a for a in dataset.addresses if a[0] not in net._layers_proposal]
+    if new and net._polymorph(_example_batch(new)) and save_file_name_prefix is not None:
+        net._save('{}_00000000_pre_generated.network'.format(save_file_name_prefix))
+
+
+def optimize_packed(net, dataset, dataset_valid, num_traces, batch_size, valid_every, learning_rate_init, learning_rate_end,
+                    learning_rate_scheduler_type, weight_decay, num_traces_end, save_file_name_prefix, save_every_sec,
+                    stop_with_bad_loss, optimizer_type, momentum, log_file_name, distributed_num_buckets):
+    """`InferenceNetwork.optimize` on a packed offline dataset (single process, Adam): the reference's sampler over the sorted
+    index, minibatches packed from memory-mapped columns, runs of steps inside one C call; validation loss, POLY1 / POLY2
+    schedule, log file and checkpoints as in inference_network.py:381-599."""
+    if not net._layers_initialized:
+        net._init_layers_observe_embedding(net._observe_embeddings, example_trace=dataset[0])
+        net._init_layers()
+        net._layers_initialized = True
+    _run_view_optimize(net, dataset, dataset_valid, num_traces, batch_size, learning_rate_init, learning_rate_end, weight_decay,
+                       num_traces_end, save_file_name_prefix, save_every_sec, stop_with_bad_loss, optimizer_type, momentum,
+                       learning_rate_scheduler_type, valid_every, log_file_name, distributed_num_buckets)
     return True

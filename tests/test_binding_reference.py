@@ -1066,3 +1066,58 @@ def test_a_program_that_captured_pyprobs_functions_is_not_batched(batched):
     values = np.array([float(v) for v in post.values])
     assert len(set(np.round(values, 5))) > 30                                  # distinct particles (not one bare prior draw)
     assert pyprob.state._current_trace is None or type(pyprob.state._current_trace).__name__ != '_NoDirectCalls'
+
+
+def test_offline_training_of_a_pyprob_model_from_packed_shards(batched, tmp_path, monkeypatch):
+    """pyprob's OWN Model.save_dataset / learn_inference_network(dataset_dir=, dataset_valid_dir=, pre_generate_layers=True,
+    POLY2 schedule, log file, checkpoints) with install(): the dataset is packed shards (no shelve / pickle / zlib decode per
+    trace, pyprob/nn/dataset.py:121-205), layers are pre-generated from its address table, minibatches come from the reference's
+    sampler over the sorted index and runs of them train inside one C call; module tree, bookkeeping, scheduler object and
+    checkpoints stay pyprob's. A shelve dataset written by stock pyprob converts once (hip.convert_dataset) and trains the same way."""
+    import glob
+    monkeypatch.setattr(torch, 'load', functools.partial(torch.load, weights_only=False))
+    pyprob.seed(12)
+    model = GaussianWithUnknownMeanMarsaglia()             # (`while float(s) >= 1`: traces generated one forward() at a time)
+    d, dv = str(tmp_path / 'train'), str(tmp_path / 'valid')
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.save_dataset(d, 256, 128)
+        model.save_dataset(dv, 64, 64)
+    assert sorted(os.listdir(d)) == ['pyprob_traces_packed_000000_128', 'pyprob_traces_packed_000001_128']
+    from pyprob_amd.dataset import PackedTraceDataset
+    ds = PackedTraceDataset(d)
+    stock_trace = next(model._trace_generator(trace_mode=pyprob.TraceMode.PRIOR_FOR_INFERENCE_NETWORK))
+    assert len(ds) == 256 and ds.addresses[0][0] == stock_trace.variables_controlled[0].address      # pyprob's address strings
+    log, prefix = str(tmp_path / 'log.csv'), str(tmp_path / 'ckpt')
+    net = _quiet_learn(model, num_traces=32 * 8, batch_size=32, dataset_dir=d, dataset_valid_dir=dv, valid_every=64,
+                       pre_generate_layers=True, learning_rate_end=1e-5, num_traces_end=1000,
+                       learning_rate_scheduler_type=pyprob.LearningRateScheduler.POLY2, log_file_name=log,
+                       save_file_name_prefix=prefix, save_every_sec=0)
+    assert net._hip_last_optimize == 'batched (pyprob_host.optimize_packed)' and net._layers_pre_generated
+    assert set(net._layers_proposal.keys()) == {a for a, _, _ in ds.addresses}            # every address of the dataset, up front
+    assert net._total_train_iterations == 8 and net._total_train_traces == 256 and len(net._history_train_loss) == 8
+    assert np.isfinite(net._history_train_loss).all() and len(net._history_valid_loss) >= 1
+    want_lr = (1e-3 - 1e-5) * (1 - 256 / 1000) ** 2 + 1e-5                                # inference_network.py:357-379 at 256 traces
+    assert abs(net._optimizer.param_groups[0]['lr'] - want_lr) < 1e-9 and net._learning_rate_scheduler.last_epoch == 256
+    assert len(open(log).read().strip().splitlines()) == 1 + 8
+    assert glob.glob(prefix + '_*_pre_generated.network') and len(glob.glob(prefix + '_*_traces_*.network')) >= 2
+    # a dataset written by STOCK pyprob (shelve files) is opened by pyprob's own OfflineDataset, and converts once
+    hip.uninstall()
+    ds_stock = str(tmp_path / 'shelve')
+    os.makedirs(ds_stock)
+    with contextlib.redirect_stdout(io.StringIO()):
+        GaussianWithUnknownMeanMarsaglia().save_dataset(ds_stock, 96, 48)
+    hip.install()
+    from pyprob.nn import OfflineDataset
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert isinstance(hip._open_offline_dataset(ds_stock), OfflineDataset)
+        packed = str(tmp_path / 'converted')
+        assert hip.convert_dataset(ds_stock, packed, num_traces_per_file=64) == 96
+    conv = PackedTraceDataset(packed)
+    assert len(conv) == 96 and conv.obs_names == ['obs0', 'obs1']
+    src = OfflineDataset(ds_stock) if False else None
+    model2 = GaussianWithUnknownMeanMarsaglia()
+    net2 = _quiet_learn(model2, num_traces=64, batch_size=32, dataset_dir=packed)
+    assert net2._hip_last_optimize == 'batched (pyprob_host.optimize_packed)' and net2._total_train_iterations == 2
+    assert np.isfinite(net2._history_train_loss).all()
