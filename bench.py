@@ -477,6 +477,43 @@ def online_training_bench(device, lstm_dim, batch, traces, program='gum'):
                     'generation + layer creation + training' % (batch, lstm_dim))
 
 
+def offline_training_bench(device, lstm_dim, batch, traces):
+    """BASELINE.json configs[1] as the reference states it - 1 M OFFLINE traces: Model.save_dataset(dir, N, N / 4) writes packed shards
+    (pyprob_amd/dataset.py), Model.learn_inference_network(dataset_dir=dir) opens them, pre-sorted index, the reference's sampler,
+    minibatches packed from memory-mapped columns, runs of steps inside pp_train_steps. The route pyprob_host.optimize_packed gives a
+    real pyprob.Model (the reference: shelve + pickle + zlib decode per trace, ~1.1-1.4 k traces/s). One epoch."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from pyprob_amd.state import InferenceNetwork
+    GUM, _ = api_models()
+    model = GUM()
+    root = tempfile.mkdtemp(prefix='pp_bench_ds_')
+    kw = dict(inference_network=InferenceNetwork.LSTM, observe_embeddings={'obs0': {'dim': 32}, 'obs1': {'dim': 32}}, batch_size=batch,
+              lstm_dim=lstm_dim, seed=1)
+    try:
+        torch.manual_seed(2)
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            model.save_dataset(root, traces, max(traces // 4, batch))
+            t_write = time.perf_counter() - t0
+            model.learn_inference_network(num_traces=64 * batch, dataset_dir=root, **kw)      # layers, code objects, page cache
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.learn_inference_network(num_traces=traces, dataset_dir=root, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    net = model._inference_network
+    return dict(traces_per_sec=round(traces / dt, 1), traces=traces, seconds=round(dt, 4), save_dataset_traces_per_sec=round(traces / t_write, 1),
+                bytes_per_trace_on_disk=round(size / traces, 1), final_loss=round(float(net._history_train_loss[-1]), 4), host='pyprob_amd.Model',
+                api='Model.save_dataset(dir, %d, %d) + Model.learn_inference_network(num_traces=%d, dataset_dir=dir, batch_size=%d, '
+                    'lstm_dim=%d)' % (traces, max(traces // 4, batch), traces, batch, lstm_dim))
+
+
 def _claim_stdout():
     """stdout must carry exactly ONE line, rank 0's JSON. Everything else this process writes to file descriptor 1 - RCCL
     prints a five-line version banner at its first communicator, libraries warn now and then - is sent to stderr: returns a
@@ -1015,11 +1052,15 @@ def main():
             else:
                 os.environ['PP_IS_PLAN'] = old_env
         gmm = online_training_bench(device, args.lstm_dim, B, 256 * B, 'gumm')
+        off = offline_training_bench(device, args.lstm_dim, B, args.dataset)
+        out['offline_e2e'] = off
         config = dict(workload='drop-in paths end to end (pyprob_host executors through pyprob_amd.Model): GaussianUnknownMean online '
                                'IC training incl. prior generation, LSTM hidden=%d, batch=%d' % (args.lstm_dim, B),
                       parallelism='dp1', online_e2e_traces_per_sec=rec['traces_per_sec'],
                       online_e2e_bookkept_traces_per_sec=rec['bookkept_traces_per_sec'], online_final_loss=rec['final_loss'],
                       gumm_online_e2e_traces_per_sec=gmm['traces_per_sec'],
+                      offline_e2e_traces_per_sec=off['traces_per_sec'], offline_traces_on_disk=off['traces'],
+                      save_dataset_traces_per_sec=off['save_dataset_traces_per_sec'],
                       is_noplan_particles_per_sec=isr['particles_per_sec'], is_noplan_ms_per_call=isr['ms_per_call'],
                       gumm_lockstep_particles_per_sec=gm['particles_per_sec'], api=rec['api'])
         out['roofline'] = dict(bound='host', achieved=None, peak=None, unit='traces/s', frac=None, traffic=None,
