@@ -917,6 +917,12 @@ def main():
         if world == 1 and not args.no_is:
             out['online_e2e'] = online_training_bench(device, args.lstm_dim, B, 2 * 1024 * 1024)
             config['online_e2e_traces_per_sec'] = out['online_e2e']['traces_per_sec']
+            try:      # (needs a writable temporary directory for the 40 MB of packed shards)
+                out['offline_e2e'] = offline_training_bench(device, args.lstm_dim, B, 1000000)
+                config['offline_e2e_traces_per_sec'] = out['offline_e2e']['traces_per_sec']
+            except OSError as exc:
+                config['offline_e2e_traces_per_sec'] = None
+                out['offline_e2e'] = dict(error=repr(exc))
         # the driver's record keeps the flat scalars of `config` / `roofline` and only the NAMES of nested objects: every
         # number README.md quotes is repeated here as a flat key
         config['ms_per_step_median'] = out.get('ms_per_step_median')
