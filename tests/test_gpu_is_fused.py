@@ -205,6 +205,25 @@ def test_first_statement_in_two_launches_equals_the_separate_calls(gum, monkeypa
         assert abs(r.mean - (1.0 / 5 + (o['obs0'] + o['obs1']) / 2) / (1.0 / 5 + 1.0)) < 1.0      # posterior mean of the conjugate model
 
 
+@pytest.mark.parametrize('program', ['gum', 'gumm'])
+def test_embedding_inside_the_first_statement_without_a_plan(gum, gumm, monkeypatch, program):
+    """forward() in every call (PP_IS_PLAN=0 - what runs with pyprob as the host): `ISRunner.init` only stages the observation and
+    the first statement issues pp_is_first_statement (embedding + LSTM row + proposal layer in one launch) - against the
+    separate pp_is_init launch (PP_IS_LAZY_INIT=0): identical particles, log-weights and statistics, also for a program with
+    control flow (whose later statements read the embedding the fused launch left on the device)."""
+    monkeypatch.setenv('PP_IS_FUSED', '1')
+    monkeypatch.setenv('PP_IS_PLAN', '0')
+    model = gum if program == 'gum' else gumm
+    obs3 = ({'obs0': 8.0, 'obs1': 9.0}, {'obs0': 6.5, 'obs1': 7.25}, {'obs0': 4.0, 'obs1': 5.0})
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PP_IS_LAZY_INIT', flag)
+        outs[flag] = [model.posterior_results(30000, IC, observe=o, lock_step=True, seed=70 + k) for k, o in enumerate(obs3)]
+        assert not any(getattr(r, 'replayed_plan', False) for r in outs[flag])
+    for a, b in zip(outs['1'], outs['0']):
+        assert _same(a, b)
+
+
 class PrivateScale(GaussianWithUnknownMean):
     """The likelihood's scale lives in a PRIVATE attribute (`self._sigma`) and a constant in a module global reached through
     a helper method: state a launch-plan key that only fingerprinted public attributes never saw."""
