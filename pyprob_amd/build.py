@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpyprob_amd.so')
-SOURCES = ['gemm_f32.hip', 'kernels.hip', 'engine.hip', 'panel.hip', 'panel16.hip', 'lstm_input.hip', 'wgrad_t1.hip', 'is_kernels.hip', 'is_step_fused.hip', 'obs_embed.hip', 'pack.hip', 'train_loop.hip', 'lstm_tail.hip', 'dp.hip', 'optim.hip']
+SOURCES = ['gemm_f32.hip', 'kernels.hip', 'engine.hip', 'panel.hip', 'panel16.hip', 'lstm_input.hip', 'wgrad_t1.hip', 'is_kernels.hip', 'is_step_fused.hip', 'is_step_small.hip', 'obs_embed.hip', 'pack.hip', 'train_loop.hip', 'lstm_tail.hip', 'dp.hip', 'optim.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-inline-asm']
 
 

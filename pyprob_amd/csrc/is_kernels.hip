@@ -763,7 +763,11 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
     PP_CHECK_ARG(net && P && e_obs_vec && (ff || (h && c)) && (net_only || whole || (value_out && logq_out)) && ws, "pp_is_step: null pointer");
     PP_CHECK_ARG(addr_id >= 0 && addr_id < net->n_addr && prev_addr_id < net->n_addr, "pp_is_step: address id out of range");
     PP_CHECK_ARG(ff || prev_addr_id < 0 || prev_value, "pp_is_step: prev_value is required after the first statement");
-    PP_CHECK_ARG(ff || prev_addr_id < 0 || state_rows == 1 || state_rows == n, "pp_is_step: state_rows must be 1 or n");
+    // (with a row index list state_rows is 1 or the row count of one layer of the state buffer: the rows point anywhere into it)
+    PP_CHECK_ARG(ff || prev_addr_id < 0 || state_rows == 1 || (rows ? state_rows >= 1 : state_rows == n),
+                 "pp_is_step: state_rows must be 1 or n (with a row list: 1 or the rows of a layer of the state buffer)");
+    PP_CHECK_ARG(ff || !rows || state_rows != 1 || std::max(1, (int)net->lstm_depth) == 1,
+                 "pp_is_step_rows: a shared first state with a row list on an LSTM of depth > 1: expand the state rows first");
     if (n <= 0) return 0;
     const pp_addr& ad = net->addrs[addr_id];
     PP_CHECK_ARG(net_only || ad.kind == PP_HEAD_CATEGORICAL || ad.kind == PP_HEAD_BERNOULLI || prior,
@@ -795,7 +799,8 @@ int is_step(const pp_net* net, const float* P, int addr_id, int prev_addr_id, in
         // (the split statement's new hidden rows go through the chain's gate buffer w.G: [n][4 H] >= [n][H])
         PP_TRY(is_step_fused(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows, rows,
                              value_in, value_out, logq_out, seed, offset, w.fz, w.c0, w.Y, w.out4, net_only, &sampled, st, whole,
-                             (H == 1024 || (state_rows != 1 && is_step_split(n))) ? w.G : nullptr));
+                             (H == 1024 || (state_rows != 1 && is_step_split(n))) ? w.G : nullptr,
+                             rows && state_rows != 1 ? state_rows : n));
         if (sampled) return 0;
         PP_CHECK_ARG(!whole, "pp_is_statement_rows: mixture heads only");
         head_done = true;     // the head outputs are in w.Y: the sampling kernels below (or pp_is_fused) take over

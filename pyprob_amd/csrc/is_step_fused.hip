@@ -814,6 +814,7 @@ static inline int64_t round256(int64_t x) { return (x + 255) & ~int64_t(255); }
 }  // namespace
 
 bool is_step_fused_supported(const pp_net* net, int addr_id) {
+    if (is_step_small_supported(net, addr_id)) return true;
     if (!net || net->lstm_dim == 0 || std::max(1, (int)net->lstm_depth) != 1) return false;
     if (net->lstm_dim != 256 && net->lstm_dim != 512 && net->lstm_dim != 1024) return false;
     if (net->smp_dim < 1 || net->smp_dim > 8 || net->lstm_in > 1024 || !net->addr_table) return false;
@@ -835,6 +836,10 @@ bool is_lstm_wide_supported(const pp_net* net) {
 
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {
     f = IsFusedBuffers{};
+    if (net && (net->lstm_dim == 32 || net->lstm_dim == 64 || net->lstm_dim == 128) && net->lstm_depth <= PP_MAX_LSTM_DEPTH) {
+        is_small_carve_sizes(net, f);
+        return;
+    }
     if (is_lstm_wide_supported(net)) {      // two gate images of 512 hidden units each, K extent 1024; the head images
         const int H = net->lstm_dim;
         int64_t hid = 1;
@@ -859,7 +864,11 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
                   const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
                   const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
                   const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
-                  const IsStatementOut* whole, float* hn_split) {
+                  const IsStatementOut* whole, float* hn_split, int64_t layer_rows) {
+    if (is_step_small_supported(net, addr_id))
+        return is_step_small(net, P, addr_id, prev_addr_id, n, e_obs_vec, prev_value, prior, prior_stride, h, c, state_rows,
+                             layer_rows > 0 ? layer_rows : n, rows, value_in, value_out, logq_out, seed, offset, f, y_out, ldy, net_only,
+                             sampled, st, whole);
     const pp_addr& ad = net->addrs[addr_id];
     const bool wide = net->lstm_dim == 1024;      // the LSTM step as the wide launch, then the head-only launch (hn_split required)
     const int H = net->lstm_dim, ub = wide ? 2 : H / 256, nsh = H / 8;

@@ -10,7 +10,8 @@ struct IsFusedBuffers {
     int64_t n_whh = 0, n_w1 = 0, n_w2 = 0, n_bias = 0;
 };
 
-// one-layer LSTM with H in {256, 512, 1024} (1024: two launches, head at most 576 hidden units), head of `addr_id` at most 32 outputs wide
+// one-layer LSTM with H in {256, 512, 1024} (1024: two launches, head at most 576 hidden units) or an LSTM of up to four layers with
+// H in {32, 64, 128} (is_step_small.hip); head of `addr_id` at most 32 outputs wide
 bool is_step_fused_supported(const pp_net* net, int addr_id);
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f);
 
@@ -31,7 +32,17 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
                   const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
                   const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed, uint64_t offset,
                   const IsFusedBuffers& f, float* c0_copy, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
-                  const IsStatementOut* whole = nullptr, float* hn_split = nullptr);
+                  const IsStatementOut* whole = nullptr, float* hn_split = nullptr, int64_t layer_rows = 0);
+// (layer_rows: rows of one layer of (h, c) - the state of an LSTM of depth > 1 is [depth, layer_rows, H]; 0 = n)
+
+// is_step_small.hip: the same statement for H = 32 / 64 / 128 and 1 .. PP_MAX_LSTM_DEPTH layers (one kernel, every mode above)
+bool is_step_small_supported(const pp_net* net, int addr_id);
+void is_small_carve_sizes(const pp_net* net, IsFusedBuffers& f);
+int is_step_small(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,
+                  const float* prev_value, const float* prior, int prior_stride, float* h, float* c, int state_rows,
+                  int64_t layer_rows, const int64_t* rows, const float* value_in, float* value_out, float* logq_out, uint64_t seed,
+                  uint64_t offset, const IsFusedBuffers& f, float* y_out, int64_t ldy, bool net_only, bool* sampled, hipStream_t st,
+                  const IsStatementOut* whole);
 
 // H = 1024 (one layer): the LSTM step of a statement as ONE launch (two workgroups per 32 particles, half of the hidden units
 // each); the head layers and the draw stay with the caller's launches. c is updated in place, the new hidden rows go to hn [n][H]

@@ -304,7 +304,7 @@ class ISRunner:
 
     def whole_statement_ok(self, addr_id, prev_addr_id, m, dist_name, prior):
         """Can `statement_rows` take this statement (fused statement kernel, shared Normal / Uniform prior pair)?"""
-        return (prev_addr_id is not None and self.dev.type == 'cuda' and self.eng.spec.lstm_depth == 1 and
+        return (prev_addr_id is not None and self.dev.type == 'cuda' and
                 dist_name in self.PRIOR_KIND and prior is not None and prior.numel() == 2 and self.prev_value is not None and
                 self.prev_value.numel() == self.n and
                 bool(self.lib.pp_is_step_fused_supported(C.byref(self.eng.net), int(addr_id), int(m))))
@@ -320,10 +320,12 @@ class ISRunner:
             self.c[:, 1:] = self.c[:, :1]
             state_rows = self.n
         self._ensure_ws(m)
-        # (straight through the C ABI: whole_statement_ok has checked the shapes, the tensors are this executor's own)
+        # (straight through the C ABI: whole_statement_ok has checked the shapes, the tensors are this executor's own; state_rows =
+        # the rows of one layer of the state buffer: a path of ONE particle is not the shared first state, include/pyprob_amd.h)
         L.check(self.lib.pp_is_statement_rows(C.byref(self.eng.net), self.eng.params.data_ptr(), int(addr_id), int(prev_addr_id), m,
                                               self._e_obs.data_ptr(), self.prev_value.data_ptr(), prior.data_ptr(), 0,
-                                              self.h.data_ptr(), self.c.data_ptr(), 1 if state_rows == 1 else m, L.ptr(rows),
+                                              self.h.data_ptr(), self.c.data_ptr(), 1 if state_rows == 1 else self.n,
+                                              L.ptr(rows if self.n > 1 else None),
                                               values_full.data_ptr(), lw_full.data_ptr(), self.PRIOR_KIND[dist_name], int(seed),
                                               int(self.offset), self.ws.data_ptr(), self.ws_bytes, self._st), 'pp_is_statement_rows')
         torch.autograd.graph.increment_version(values_full)      # written by the kernel: memoised results of it are stale
@@ -336,7 +338,7 @@ class ISRunner:
         [1, 2], or one row per particle ([n, 2]; prior_compact: one row per entry of `rows`)."""
         m = int(rows.numel())
         self._ensure_init()
-        if (prev_addr_id is not None and self.dev.type == 'cuda' and self.eng.spec.lstm_depth == 1 and
+        if (prev_addr_id is not None and self.dev.type == 'cuda' and self.n > 1 and
                 self.lib.pp_is_step_fused_supported(C.byref(self.eng.net), int(addr_id), m)):
             # the fused statement kernel reads and writes the rows' state in place through the index list
             if self.state_rows == 1 and self.n > 1:
@@ -348,7 +350,7 @@ class ISRunner:
                 prior = prior.index_select(0, rows).contiguous()
             self._ensure_ws(m)
             return ops.is_step_rows(self.eng.params, self.ws, self.eng.net_handle, int(addr_id), int(prev_addr_id), m, self._e_obs,
-                                    prev, prior, self.h, self.c, m, rows, None, int(seed), self.offset)
+                                    prev, prior, self.h, self.c, self.n, rows, None, int(seed), self.offset)
         if self.state_rows == 1 and self.n > 1 and prev_addr_id is not None:
             self.h[:, 1:] = self.h[:, :1]      # the shared first-statement state (row 0) becomes per-particle
             self.c[:, 1:] = self.c[:, :1]

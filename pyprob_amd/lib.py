@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libpyprob_amd.so')
 
-PP_ABI_VERSION = 13
+PP_ABI_VERSION = 14
 PP_MAX_OBS = 8
 PP_MAX_LSTM_DEPTH = 4
 PP_MAX_OBS_DEPTH = 4
