@@ -15,7 +15,9 @@
 //   * layer 0's input is what it is in the big kernel: only the sample embedding of the previous value differs between the
 //     particles of a statement - one 8-k slab; everything else of [E | s | d | a | d | a] W_ih^T is a bias row per call;
 //   * the draw is is_draw.hpp's mixture_particle, one lane per particle (the chain's own tail: same Philox counters, same
-//     arithmetic) on the first wave of the workgroup - 64 particles fill it.
+//     arithmetic) on ONE wave of the workgroup - 64 particles fill it -, a different one from workgroup to workgroup;
+//   * LDS: the tile, and the staged old rows with the head activations / outputs over them once the last layer has read them
+//     (H = 64, one layer: 39 KB - four workgroups per CU).
 #include "is_step_fused.hpp"
 
 #include "gather.hpp"
@@ -25,10 +27,14 @@
 
 namespace pp {
 
+extern long long* g_timeline;   // kernels.hip (pp_debug_timeline)
+
 namespace {
 
-constexpr int SR = 64;      // particles per workgroup
-constexpr int RING = 4;     // k-slabs of gate fragments in flight per wave
+constexpr int RING = 3;     // k-slabs of gate fragments in flight per wave
+// particles per workgroup: 32 RB - two row blocks (the drawing wave is full), one at H = 128 (four waves per workgroup: three
+// workgroups per CU overlap their phases, where one workgroup of eight waves ran them one after the other)
+constexpr int rows_per_block(int ubk) { return ubk == 4 ? 32 : 64; }
 
 __device__ __forceinline__ float fast_sigmoid_s(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh_s(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
@@ -160,25 +166,30 @@ struct SmallArgs {
     int K, n, L;
     int prev_indexed;
     float* value_full; float* lw_full; int prior_kind;
+    long long* dbg;             // debug: clock64 stamps [2 workgroups][2 waves][16] (pp_debug_timeline, tools/is_small_timeline.py)
 };
 
 extern __shared__ __attribute__((aligned(16))) float small_lds[];
 
 // UBK = H / 32 unit blocks; KIND 0 / 1 / 2: mixture heads drawn in the tail, 3: head outputs only; SHARED: one previous state row
 // for every particle (its recurrent products are in the bias rows).
+// Registers: four accumulators (64) + the ring (48) + the previous cell values (16) fit 168 = three waves per SIMD; the compiler
+// left alone takes ~180 (two waves per SIMD), and every phase of a workgroup outside the K loop (staging, cell, head layers, the
+// ~20 000-cycle draw of one wave) leaves the MFMA pipe to the OTHER workgroups of the CU.
 template <int UBK, int KIND, bool SHARED>
-__global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArgs a) {
+__global__ __launch_bounds__(2 * rows_per_block(UBK) * UBK) __attribute__((amdgpu_waves_per_eu(3, 3))) void is_step_small_kernel(const SmallArgs a) {
+    constexpr int SR = rows_per_block(UBK);
     constexpr int H = 32 * UBK;
     constexpr int HP = H + 4;                       // row pitch of the hidden tiles (16-byte aligned rows, rows 4 banks apart)
     constexpr int NSH = H / 8;
-    constexpr int NT = 128 * UBK;
+    constexpr int NT = 2 * SR * UBK;
     constexpr int ITEMF = UBK * 4 * 256;            // floats of one item of the gate image
     const int AP = a.ns2 * 8 + 4;                   // row pitch of the head activations
     float* sH = small_lds;                          // [64][HP] fresh hidden rows of the layer below (first: the sample embedding)
-    float* sA1 = sH + SR * HP;                      // [64][AP]
-    float* sY = sA1 + SR * AP;                      // [64][33]
-    int* sRow = reinterpret_cast<int*>(sY + SR * 33);   // [64]
-    float* sHold = reinterpret_cast<float*>(sRow + SR); // [L][64][HP] old hidden rows of every layer (not SHARED)
+    int* sRow = reinterpret_cast<int*>(sH + SR * HP);   // [64]
+    float* sHold = reinterpret_cast<float*>(sRow + SR); // [L][64][HP] old hidden rows of every layer (not SHARED); dead after the
+    float* sA1 = sHold;                             // last layer's K loop: [64][AP] head activations and
+    float* sY = sA1 + SR * AP;                      // [64][33] head outputs lie over them
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,6 +197,15 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
     const int c31 = lane & 31, hh = lane >> 5;
     const int m0 = (int)blockIdx.x * SR;
     const int u = ub * 32 + c31;                    // this lane's hidden unit
+    const int dbg_slot = a.dbg ? (blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1)) : -1;
+    int dbg_k = 0;
+#define SMALL_STAMP()                                                                              \
+    do {                                                                                           \
+        if (dbg_slot >= 0 && lane == 0 && (wave == 0 || wave == NT / 64 - 1) && dbg_k < 16)          \
+            a.dbg[(dbg_slot * 2 + (wave == 0 ? 0 : 1)) * 16 + dbg_k] = clock64();                  \
+        ++dbg_k;                                                                                   \
+    } while (0)
+    SMALL_STAMP();      // 0 start
     if (tid < SR) {
         const int gr = min(m0 + tid, a.n - 1);
         const int64_t ri = a.rows ? a.rows[gr] : (int64_t)gr;
@@ -202,9 +222,11 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
             sH[tid * HP + k] = k < a.smp ? relu_keep_nan(e) : 0.0f;
         }
     }
-    __syncthreads();
+    SMALL_STAMP();      // 1 rows + sample embedding (this wave's share)
     if constexpr (!SHARED) {
-        // the old hidden rows of every layer -> LDS, 16 bytes per thread and load, four loads in flight
+        // the old hidden rows of every layer -> LDS, 16 bytes per thread and load, four loads in flight. Every thread looks its
+        // rows up itself (the list is read again from L1 / L2): no barrier between the row list and these loads - the two
+        // dependent round trips of the sample embedding (row -> previous value) and of the staging (row -> hidden row) overlap
         const int per_layer = SR * (H / 4);
         const int total = a.L * per_layer;
         for (int e0 = tid; e0 < total; e0 += 4 * NT) {
@@ -215,7 +237,9 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
                 if (e < total) {
                     const int l = e / per_layer, r = e - l * per_layer;
                     const int row = r / (H / 4), p = r - row * (H / 4);
-                    v[q] = *reinterpret_cast<const f32x4*>(a.h + l * a.layer_stride + (int64_t)sRow[row] * H + 4 * p);
+                    const int gr = min(m0 + row, a.n - 1);
+                    const int64_t ri = a.rows ? a.rows[gr] : (int64_t)gr;
+                    v[q] = *reinterpret_cast<const f32x4*>(a.h + l * a.layer_stride + ri * H + 4 * p);
                 }
             }
 #pragma unroll
@@ -228,8 +252,9 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
                 }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
+    SMALL_STAMP();      // 2 old rows staged
 
     const int arow = (rb * 32 + c31) * HP + 4 * hh;   // this lane's A row (+ its k half) inside a tile
     const float* gim = a.gimg + (size_t)ub * (4 * 256) + lane * 4;
@@ -287,7 +312,9 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
             acc[1][r] = fast_sigmoid_s(acc[1][r]);
             acc[3][r] = fast_sigmoid_s(acc[3][r]);
         }
+        SMALL_STAMP();      // 3 + 4 l: K loop + gates
         __syncthreads();
+        SMALL_STAMP();      // 4 + 4 l: barrier
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -300,7 +327,9 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
             }
             sH[row * HP + u] = hn;
         }
+        SMALL_STAMP();      // 5 + 4 l: cell
         __syncthreads();
+        SMALL_STAMP();      // 6 + 4 l: barrier
     }
 
     // ---- head layer 1: a1 = relu(h W1^T + b1): wave (rb, ub) takes the 32-column blocks ub, ub + UBK, ... of its row block ----
@@ -329,7 +358,9 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
             }
         }
     }
+    SMALL_STAMP();          // head layer 1
     __syncthreads();
+    SMALL_STAMP();          // barrier
 
     // ---- head layer 2: y = a1 W2^T + b2 (at most 32 columns): the first unit-block wave of each row block ----
     if (ub == 0) {
@@ -337,11 +368,18 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) e[r] = 0.0f;
         const float* arow1 = sA1 + (rb * 32 + c31) * AP + 4 * hh;
-        for (int s = 0; s < a.ns2; ++s) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow1 + 8 * s);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.w2_img + (size_t)s * 256 + lane * 4);
+        for (int s0 = 0; s0 < a.ns2; s0 += 8) {      // eight slabs of W2 in flight together (loaded one by one inside the loop,
+            f32x4 bw[8];                              // each MFMA group waited a full L2 round trip: 9 000 of the phase's 11 000 cycles)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], e, 0, 0, 0);
+            for (int q = 0; q < 8; ++q)
+                bw[q] = *reinterpret_cast<const f32x4*>(a.w2_img + (size_t)min(s0 + q, a.ns2 - 1) * 256 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (s0 + q < a.ns2) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(arow1 + 8 * (s0 + q));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bw[q][j], e, 0, 0, 0);
+                }
         }
         const float bias2 = c31 < a.n_out ? a.b2[c31] : 0.0f;
 #pragma unroll
@@ -352,13 +390,17 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
             if (a.y_out && m0 + row < a.n && c31 < a.n_out) a.y_out[(int64_t)(m0 + row) * a.ldy + c31] = y;
         }
     }
+    SMALL_STAMP();          // head layer 2
     if (KIND == 3) return;
     __syncthreads();
+    SMALL_STAMP();          // barrier
 
     // ---- draw + log q: one lane per particle (is_draw.hpp mixture_particle - the tail of the chain's own launches) ----
-    if (wave == 0) {
+    // (the drawing wave rotates with the workgroup: the ~2 500 instructions of a draw are as long as a wave's whole MFMA phase, and
+    // the first wave of every workgroup lands on the same SIMD)
+    if (wave == (int)(blockIdx.x % (NT / 64))) {
         const int64_t i = m0 + lane;
-        if (i < a.n) {
+        if (lane < SR && i < a.n) {
             const float pa = a.prior[i * 2 * a.prior_stride], pb = a.prior[i * 2 * a.prior_stride + 1];
             float v, lp;
             mixture_particle<KIND == 3 ? 0 : KIND>(sY + lane * 33, pa, pb, a.K, a.value_in != nullptr, a.value_in ? a.value_in[i] : 0.0f,
@@ -384,11 +426,14 @@ __global__ __launch_bounds__(128 * UBK) void is_step_small_kernel(const SmallArg
             }
         }
     }
+    SMALL_STAMP();          // draw (the drawing wave: workgroup 0 -> wave 0, the middle workgroup -> wave (grid / 2) % waves)
+#undef SMALL_STAMP
 }
 
 size_t small_lds_bytes(int H, int L, int ns2, bool shared) {
-    const int HP = H + 4, AP = ns2 * 8 + 4;
-    return ((size_t)SR * HP + (size_t)SR * AP + SR * 33 + SR + (shared ? 0 : (size_t)L * SR * HP)) * sizeof(float);
+    const int HP = H + 4, AP = ns2 * 8 + 4, SR = rows_per_block(H / 32);
+    const size_t head = (size_t)SR * AP + SR * 33, old = shared ? 0 : (size_t)L * SR * HP;
+    return ((size_t)SR * HP + SR + std::max(head, old)) * sizeof(float);
 }
 
 template <int UBK, int KIND, bool SHARED>
@@ -403,7 +448,8 @@ int launch_small(const SmallArgs& a, size_t lds, hipStream_t st) {
         }
         raised = true;
     }
-    hipLaunchKernelGGL((is_step_small_kernel<UBK, KIND, SHARED>), dim3(cdiv(a.n, SR)), dim3(128 * UBK), lds, st, a);
+    constexpr int SR = rows_per_block(UBK);
+    hipLaunchKernelGGL((is_step_small_kernel<UBK, KIND, SHARED>), dim3(cdiv(a.n, SR)), dim3(2 * SR * UBK), lds, st, a);
     return 0;
 }
 template <int UBK>
@@ -486,6 +532,7 @@ int is_step_small(const pp_net* net, const float* P, int addr_id, int prev_addr_
     a.prior = prior; a.prior_stride = prior_stride;
     a.value_in = value_in; a.value_out = value_out; a.logq_out = logq_out;
     a.seed = seed; a.offset = offset; a.K = ad.n_out / 3; a.n = n; a.L = L;
+    a.dbg = g_timeline;
     if (whole) {
         a.prev_indexed = 1;
         a.value_full = whole->value_full;

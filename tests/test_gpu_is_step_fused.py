@@ -134,7 +134,7 @@ def _ids(eng, name):
     (128, 777, ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform'), 2),
     (128, 300, ('a_uniform', 'Uniform'), ('a_bern', 'Bernoulli'), 2),
     (64, 300, ('a_uniform', 'Uniform'), ('a_bern', 'Bernoulli'), 3),
-    (128, 300, ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform'), 3),       # (the chain)
+    (128, 300, ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform'), 4),
     (64, 1, ('a_uniform', 'Uniform'), ('a_normal', 'Normal'), 4),
     # shapes without a fused kernel: the chain of GEMM launches, same oracle
     (96, 200, ('a_uniform', 'Uniform'), ('a_normal', 'Normal'), 1),
@@ -144,8 +144,7 @@ def test_fused_statement_against_the_oracle(H, n, prev, cur, depth):
     from pyprob_amd.ops import ops
     eng, run, sd = _engine(H, depth=depth)
     # (the fixture forces the fused statement at any n; by default H = 1024 takes it from 2 049 particles on)
-    # (H = 128 with three layers and more: the staged old rows of every layer do not fit the LDS - the chain)
-    fused = (H in (256, 512, 1024) and depth == 1) or H in (32, 64) or (H == 128 and depth <= 2)
+    fused = (H in (256, 512, 1024) and depth == 1) or H in (32, 64, 128)
     assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == (1 if fused else 0)
     rng = np.random.default_rng(5)
     h0 = (0.5 * rng.standard_normal((depth, n, H))).astype(np.float32).clip(-0.99, 0.99)
