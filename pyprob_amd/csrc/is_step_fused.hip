@@ -836,7 +836,7 @@ bool is_lstm_wide_supported(const pp_net* net) {
 
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {
     f = IsFusedBuffers{};
-    if (net && (net->lstm_dim == 32 || net->lstm_dim == 64 || net->lstm_dim == 128) && net->lstm_depth <= PP_MAX_LSTM_DEPTH) {
+    if (is_small_network(net)) {
         is_small_carve_sizes(net, f);
         return;
     }

@@ -11,7 +11,7 @@ struct IsFusedBuffers {
 };
 
 // one-layer LSTM with H in {256, 512, 1024} (1024: two launches, head at most 576 hidden units) or an LSTM of up to four layers with
-// H in {32, 64, 128} (is_step_small.hip); head of `addr_id` at most 32 outputs wide
+// H a multiple of 32 up to 256 (is_step_small.hip); head of `addr_id` at most 32 outputs wide
 bool is_step_fused_supported(const pp_net* net, int addr_id);
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f);
 
@@ -35,7 +35,9 @@ int is_step_fused(const pp_net* net, const float* P, int addr_id, int prev_addr_
                   const IsStatementOut* whole = nullptr, float* hn_split = nullptr, int64_t layer_rows = 0);
 // (layer_rows: rows of one layer of (h, c) - the state of an LSTM of depth > 1 is [depth, layer_rows, H]; 0 = n)
 
-// is_step_small.hip: the same statement for H = 32 / 64 / 128 and 1 .. PP_MAX_LSTM_DEPTH layers (one kernel, every mode above)
+// is_step_small.hip: the same statement for H = 32, 64 .. 256 (multiples of 32; H = 256 from two layers on) and 1 .. PP_MAX_LSTM_DEPTH
+// layers (one kernel, every mode above)
+bool is_small_network(const pp_net* net);
 bool is_step_small_supported(const pp_net* net, int addr_id);
 void is_small_carve_sizes(const pp_net* net, IsFusedBuffers& f);
 int is_step_small(const pp_net* net, const float* P, int addr_id, int prev_addr_id, int n, const float* e_obs_vec,

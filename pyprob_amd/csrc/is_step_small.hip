@@ -1,4 +1,5 @@
-// The fused importance-sampling statement for SMALL LSTMs: H = 32, 64 or 128 hidden units, 1 .. PP_MAX_LSTM_DEPTH layers
+// The fused importance-sampling statement for SMALL LSTMs: H = 32, 64 .. 256 hidden units (multiples of 32; tuned instantiations for
+// 32, 64 and 128, one with run-time indices for the rest), 1 .. PP_MAX_LSTM_DEPTH layers
 // (InferenceNetworkLSTM._infer_step pyprob/nn/inference_network_lstm.py:82-134 with nn.LSTM(I, H, depth) :31, state.sample's IC
 // branch pyprob/state.py:203-219, Mixture.sample / log_prob pyprob/distributions/mixture.py:38-63) - the networks of the
 // reference's own tests (lstm_dim 32 / 64, tests/test_inference.py) and BASELINE.json configs[0]. Same entry points and the same
@@ -34,7 +35,7 @@ namespace {
 constexpr int RING = 3;     // k-slabs of gate fragments in flight per wave
 // particles per workgroup: 32 RB - two row blocks (the drawing wave is full), one at H = 128 (four waves per workgroup: three
 // workgroups per CU overlap their phases, where one workgroup of eight waves ran them one after the other)
-constexpr int rows_per_block(int ubk) { return ubk == 4 ? 32 : 64; }
+constexpr int rows_per_block(int ubk) { return (ubk == 1 || ubk == 2) ? 64 : 32; }
 
 __device__ __forceinline__ float fast_sigmoid_s(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh_s(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
@@ -63,7 +64,7 @@ struct SmallPrepArgs {
 //   layer l >= 1: items 0 .. H / 8 - 1 = W_ih_l ([4H, H]: the input is the hidden row of layer l - 1), then H / 8 items of W_hh_l.
 // blocks [0, img_blocks): images; then L * H blocks of four waves: one gate column's bias each.
 __global__ __launch_bounds__(256) void is_small_prep_kernel(const SmallPrepArgs a) {
-    __shared__ float sx[1024 + 128];
+    __shared__ float sx[1024 + 256];
     const int tid = threadIdx.x;
     const int H = a.H, nsh = a.nsh;
     if ((int)blockIdx.x < a.img_blocks) {
@@ -163,7 +164,7 @@ struct SmallArgs {
     const float* prior; int prior_stride;
     const float* value_in; float* value_out; float* logq_out;
     uint64_t seed, offset;
-    int K, n, L;
+    int K, n, L, ubk;
     int prev_indexed;
     float* value_full; float* lw_full; int prior_kind;
     long long* dbg;             // debug: clock64 stamps [2 workgroups][2 waves][16] (pp_debug_timeline, tools/is_small_timeline.py)
@@ -176,14 +177,17 @@ extern __shared__ __attribute__((aligned(16))) float small_lds[];
 // Registers: four accumulators (64) + the ring (48) + the previous cell values (16) fit 168 = three waves per SIMD; the compiler
 // left alone takes ~180 (two waves per SIMD), and every phase of a workgroup outside the K loop (staging, cell, head layers, the
 // ~20 000-cycle draw of one wave) leaves the MFMA pipe to the OTHER workgroups of the CU.
+// UBK = 0: the unit-block count is a.ubk (H = 96, 160 .. 256: every index below is a run-time value; 32 particles per workgroup)
 template <int UBK, int KIND, bool SHARED>
-__global__ __launch_bounds__(2 * rows_per_block(UBK) * UBK) __attribute__((amdgpu_waves_per_eu(3, 3))) void is_step_small_kernel(const SmallArgs a) {
+__global__ __launch_bounds__(UBK ? 2 * rows_per_block(UBK) * UBK : 512) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void is_step_small_kernel(const SmallArgs a) {
+    const int ubk = UBK ? UBK : a.ubk;
     constexpr int SR = rows_per_block(UBK);
-    constexpr int H = 32 * UBK;
-    constexpr int HP = H + 4;                       // row pitch of the hidden tiles (16-byte aligned rows, rows 4 banks apart)
-    constexpr int NSH = H / 8;
-    constexpr int NT = 2 * SR * UBK;
-    constexpr int ITEMF = UBK * 4 * 256;            // floats of one item of the gate image
+    const int H = 32 * ubk;
+    const int HP = H + 4;                           // row pitch of the hidden tiles (16-byte aligned rows, rows 4 banks apart)
+    const int NSH = H / 8;
+    const int NT = 2 * SR * ubk;
+    const int ITEMF = ubk * 4 * 256;                // floats of one item of the gate image
     const int AP = a.ns2 * 8 + 4;                   // row pitch of the head activations
     float* sH = small_lds;                          // [64][HP] fresh hidden rows of the layer below (first: the sample embedding)
     int* sRow = reinterpret_cast<int*>(sH + SR * HP);   // [64]
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(2 * rows_per_block(UBK) * UBK) __attribute__((amdgp
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ub = wave % UBK, rb = wave / UBK;
+    const int ub = wave % ubk, rb = wave / ubk;
     const int c31 = lane & 31, hh = lane >> 5;
     const int m0 = (int)blockIdx.x * SR;
     const int u = ub * 32 + c31;                    // this lane's hidden unit
@@ -333,20 +337,23 @@ __global__ __launch_bounds__(2 * rows_per_block(UBK) * UBK) __attribute__((amdgp
     }
 
     // ---- head layer 1: a1 = relu(h W1^T + b1): wave (rb, ub) takes the 32-column blocks ub, ub + UBK, ... of its row block ----
-    for (int cb = ub; cb < a.nb1; cb += UBK) {
+    for (int cb = ub; cb < a.nb1; cb += ubk) {
         f32x16 e;
 #pragma unroll
         for (int r = 0; r < 16; ++r) e[r] = 0.0f;
         const float* wimg = a.w1_img + (size_t)cb * 256 + lane * 4;
         const size_t sstride = (size_t)a.nb1 * 256;
-        f32x4 bq[NSH];
+        for (int s0 = 0; s0 < NSH; s0 += 8) {      // eight slabs of W1 in flight together
+            f32x4 bq[8];
 #pragma unroll
-        for (int s = 0; s < NSH; ++s) bq[s] = *reinterpret_cast<const f32x4*>(wimg + s * sstride);
+            for (int q = 0; q < 8; ++q) bq[q] = *reinterpret_cast<const f32x4*>(wimg + (size_t)min(s0 + q, NSH - 1) * sstride);
 #pragma unroll
-        for (int s = 0; s < NSH; ++s) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(sH + arow + 8 * s);
+            for (int q = 0; q < 8; ++q)
+                if (s0 + q < NSH) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(sH + arow + 8 * (s0 + q));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[s][j], e, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) e = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[q][j], e, 0, 0, 0);
+                }
         }
         const int col = cb * 32 + c31;
         if (col < a.ns2 * 8) {
@@ -449,7 +456,7 @@ int launch_small(const SmallArgs& a, size_t lds, hipStream_t st) {
         raised = true;
     }
     constexpr int SR = rows_per_block(UBK);
-    hipLaunchKernelGGL((is_step_small_kernel<UBK, KIND, SHARED>), dim3(cdiv(a.n, SR)), dim3(2 * SR * UBK), lds, st, a);
+    hipLaunchKernelGGL((is_step_small_kernel<UBK, KIND, SHARED>), dim3(cdiv(a.n, SR)), dim3(2 * SR * a.ubk), lds, st, a);
     return 0;
 }
 template <int UBK>
@@ -466,10 +473,16 @@ int launch_small_kind(const SmallArgs& a, int kind, bool shared, size_t lds, hip
 
 }  // namespace
 
-bool is_step_small_supported(const pp_net* net, int addr_id) {
+// every multiple of 32 up to 256 (H = 256 with one layer is the big kernel's: is_step_fused.hip)
+bool is_small_network(const pp_net* net) {
     if (!net) return false;
     const int H = net->lstm_dim, L = std::max(1, (int)net->lstm_depth);
-    if ((H != 32 && H != 64 && H != 128) || L > PP_MAX_LSTM_DEPTH) return false;
+    return H >= 32 && H <= 256 && (H % 32) == 0 && !(H == 256 && L == 1) && L <= PP_MAX_LSTM_DEPTH;
+}
+
+bool is_step_small_supported(const pp_net* net, int addr_id) {
+    if (!is_small_network(net)) return false;
+    const int H = net->lstm_dim, L = std::max(1, (int)net->lstm_depth);
     if (net->smp_dim < 1 || net->smp_dim > 8 || net->lstm_in > 1024 || !net->addr_table) return false;
     if (addr_id < 0 || addr_id >= net->n_addr) return false;
     const pp_addr& ad = net->addrs[addr_id];
@@ -523,6 +536,7 @@ int is_step_small(const pp_net* net, const float* P, int addr_id, int prev_addr_
     PP_LAUNCH_CHECK("pp_is_step(prepare, small network)");
 
     SmallArgs a{};
+    a.ubk = ubk;
     a.gimg = f.whh; a.bias = f.bias;
     a.h = h; a.c = c; a.layer_stride = p.layer_stride; a.c0 = c0_copy; a.rows = rows;
     const pp_addr& pad = net->addrs[prev_addr_id];
@@ -555,7 +569,8 @@ int is_step_small(const pp_net* net, const float* P, int addr_id, int prev_addr_
     int rc;
     if (ubk == 1) rc = launch_small_kind<1>(a, kind, shared, lds, st);
     else if (ubk == 2) rc = launch_small_kind<2>(a, kind, shared, lds, st);
-    else rc = launch_small_kind<4>(a, kind, shared, lds, st);
+    else if (ubk == 4) rc = launch_small_kind<4>(a, kind, shared, lds, st);
+    else rc = launch_small_kind<0>(a, kind, shared, lds, st);
     prof_end(5, flops * n, st);
     if (rc) return rc;
     PP_LAUNCH_CHECK("pp_is_step(fused statement, small network)");

@@ -136,15 +136,20 @@ def _ids(eng, name):
     (64, 300, ('a_uniform', 'Uniform'), ('a_bern', 'Bernoulli'), 3),
     (128, 300, ('a_uniform', 'Uniform'), ('a_uniform', 'Uniform'), 4),
     (64, 1, ('a_uniform', 'Uniform'), ('a_normal', 'Normal'), 4),
-    # shapes without a fused kernel: the chain of GEMM launches, same oracle
+    # the other multiples of 32 up to 256 (and H = 256 from two layers on): the same kernel with run-time indices
     (96, 200, ('a_uniform', 'Uniform'), ('a_normal', 'Normal'), 1),
+    (160, 333, ('a_cat', 'Categorical'), ('a_uniform', 'Uniform'), 2),
+    (224, 100, ('a_normal', 'Normal'), ('a_poisson', 'Poisson'), 1),
     (256, 300, ('a_normal', 'Normal'), ('a_uniform', 'Uniform'), 2),
+    # shapes without a fused kernel: the chain of GEMM launches, same oracle
+    (48, 200, ('a_uniform', 'Uniform'), ('a_normal', 'Normal'), 1),
+    (512, 150, ('a_normal', 'Normal'), ('a_uniform', 'Uniform'), 2),
 ])
 def test_fused_statement_against_the_oracle(H, n, prev, cur, depth):
     from pyprob_amd.ops import ops
     eng, run, sd = _engine(H, depth=depth)
     # (the fixture forces the fused statement at any n; by default H = 1024 takes it from 2 049 particles on)
-    fused = (H in (256, 512, 1024) and depth == 1) or H in (32, 64, 128)
+    fused = (H in (512, 1024) and depth == 1) or (H % 32 == 0 and H <= 256)
     assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == (1 if fused else 0)
     rng = np.random.default_rng(5)
     h0 = (0.5 * rng.standard_normal((depth, n, H))).astype(np.float32).clip(-0.99, 0.99)
@@ -188,7 +193,7 @@ def test_fused_statement_against_the_oracle(H, n, prev, cur, depth):
     assert torch.equal(v2, value) and torch.equal(lq2, logq) and torch.equal(h2, h) and torch.equal(c2, c)
 
 
-@pytest.mark.parametrize('H,depth', [(512, 1), (1024, 1), (32, 2), (64, 1), (128, 2)])
+@pytest.mark.parametrize('H,depth', [(512, 1), (1024, 1), (32, 2), (64, 1), (128, 2), (192, 2)])
 def test_fused_statement_equals_the_unfused_chain(monkeypatch, _force_fused, H, depth):
     """A/B inside one process: PP_IS_STEP_FUSED=0 takes the gather -> GEMM -> GEMM -> cell -> head chain. Same Philox
     counters, so the draws agree to the rounding of the proposal parameters; states agree to fp32 summation order."""
@@ -219,7 +224,7 @@ def test_fused_statement_equals_the_unfused_chain(monkeypatch, _force_fused, H, 
     np.testing.assert_allclose(l1[close], l0[close], rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize('H,depth,m', [(512, 1, 1777), (1024, 1, 1777), (64, 1, 1777), (32, 2, 1777), (128, 2, 900), (512, 1, 1), (64, 2, 1)])
+@pytest.mark.parametrize('H,depth,m', [(512, 1, 1777), (1024, 1, 1777), (64, 1, 1777), (32, 2, 1777), (128, 2, 900), (512, 1, 1), (64, 2, 1), (96, 1, 700), (256, 2, 700)])
 def test_row_index_list_updates_the_state_in_place(H, depth, m):
     """pp_is_step_rows: the particles of a diverged path own scattered rows of (h, c) - [depth, total, H], state_rows = total -;
     the rows are read and written in place, every other row is untouched, and the result equals the compact call on the
@@ -263,7 +268,7 @@ def test_row_index_list_updates_the_state_in_place(H, depth, m):
     np.testing.assert_allclose(lq.cpu().numpy(), lq_ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('H,depth', [(512, 1), (1024, 1), (32, 2), (64, 3), (128, 2)])
+@pytest.mark.parametrize('H,depth', [(512, 1), (1024, 1), (32, 2), (64, 3), (128, 2), (160, 2)])
 def test_second_statement_with_the_shared_first_state(H, depth):
     """state_rows = 1: row 0 (of every layer) holds the state every particle left the first statement with; its recurrent
     product joins the bias row, the cell reads the one shared previous cell state, all n rows are written."""

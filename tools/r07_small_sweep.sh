@@ -1,12 +1,13 @@
 #!/bin/bash
 # The small-network statement kernel (csrc/is_step_small.hip) against the chain of GEMM launches: H = 32 / 64 / 128, one and two layers
-# usage: tools/r07_small_sweep.sh [out_dir] [modes] [n ...]
+# usage: [SHAPES='96 1,192 2'] tools/r07_small_sweep.sh [out_dir] [modes] [n ...]
 cd /root/repo
 dir=${1:-gpurun_out/r07b}; modes=${2:-fused,fused_rows,chain}; shift 2 2>/dev/null
 ns=${@:-64 2000 45000 200000 1000000}
 mkdir -p $dir
 out=$dir/small_statement_sweep.jsonl; : > $out
-for hd in "32 1" "32 2" "64 1" "64 2" "128 1" "128 2"; do
+IFS=',' read -ra shapes <<< "${SHAPES:-32 1,32 2,64 1,64 2,128 1,128 2}"
+for hd in "${shapes[@]}"; do
   set -- $hd
   H=$1 DEPTH=$2 MODES=$modes timeout 600 python tools/is_step_bench.py $ns >> $out 2>$dir/err_$1_$2.log
 done
