@@ -381,7 +381,7 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
  * pyprob/model.py:59): particle i of the call owns row rows[i] of (h, c) (dev int64 [n], distinct rows; NULL = row i) - the
  * state is read and written in place through the list, every other per-particle array (prev_value, prior, value_in / out,
  * logq_out) is compact [n]. Statements after the first one only (prev_addr_id >= 0), and only where the fused statement
- * kernel exists (csrc/is_step_fused.hip: one-layer LSTM, H = 256, 512 or 1024; csrc/is_step_small.hip: H = 32, 64 or 128 with 1 ..
+ * kernel exists (csrc/is_step_fused.hip: one-layer LSTM, H = 256, 512 or 1024; csrc/is_step_small.hip: H a multiple of 32 up to 256 with 1 ..
  * PP_MAX_LSTM_DEPTH layers; head at most 32 outputs wide); PP_EINVAL otherwise (the caller gathers / scatters the rows itself).
  * (ABI 14) state_rows with a row list: 1 = row 0 is everybody's previous state (one-layer LSTMs only), otherwise the ROW COUNT OF
  * ONE LAYER of the state buffer - (h, c) are [depth, state_rows, H], layer k at offset k * state_rows * H, and rows[i] < state_rows.
@@ -390,7 +390,7 @@ int pp_is_step(const pp_net* net, const float* params, int32_t addr_id, int32_t 
  * chain of small launches wins; pp_is_step makes the same choice).
  * With that kernel a statement is ONE launch (+ one preparation launch): gates, LSTM cell, both head layers, the draw and
  * log q; the gate pre-activations never reach memory, (h, c) are read once and written once.
- * H = 32 / 64 / 128 (csrc/is_step_small.hip, one kernel at every n): a workgroup owns 64 particles, wave (row block, unit block)
+ * H = 32, 64 .. 256 (csrc/is_step_small.hip, one kernel at every n; H = 256 from two layers on): a workgroup owns 64 particles, wave (row block, unit block)
  * the four gates of 32 hidden units; the old hidden rows of every layer are staged in LDS once, layer l reads the fresh rows of
  * layer l - 1 from an LDS tile; the draw is the chain's own one-lane-per-particle tail.
  * H = 1024 (one layer): the statement is TWO launches - the LSTM step as one wide launch (two workgroups per 32 particles, half of
