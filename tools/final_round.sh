@@ -9,7 +9,7 @@ tail -1 $OUT/${TAG}_is_fused.log | cut -c1-400
 bash tools/profile_is_step.sh $TAG > $OUT/${TAG}_is_step.log 2>&1      # statement kernel: rocprof + PMC traffic -> r06_is_pmc_traffic.json
 tail -2 $OUT/${TAG}_is_step.log | cut -c1-300
 bash tools/quick_is_seq.sh $TAG > /dev/null 2>&1                        # kernels of one replayed posterior call
-cp profiles/r06_is_fused_valu.json profiles/r06_is_pmc_traffic.json $OUT/ 2>/dev/null
+for d in r06_is_fused_valu r06_is_pmc_traffic; do cp profiles/$d.json $OUT/${TAG}_$d.json 2>/dev/null; done
 H=1024 MODES=fused,fused_rows,chain python tools/is_step_bench.py 45000 200000 2> /dev/null | grep '^{' > $OUT/${TAG}_h1024_statement_bench.jsonl
 python bench.py --steps 20 --warmup 5 --no-is --no-cpu-baseline --lstm-dim 1024 > $OUT/${TAG}_train_h1024_bench_line.json 2> /dev/null
 python bench.py --workload train_gumm --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_gumm_bench_line.json 2> /dev/null
