@@ -265,7 +265,8 @@ def new_network(case, device, engine_factory=None):
         if engine_factory is not None:
             cls._hip_engine_factory = staticmethod(engine_factory)
         globals()[name] = cls               # (importable by name: torch.save pickles the class by reference)
-    net = cls((meta, init), lstm_dim=meta['lstm_dim'], proposal_mixture_components=meta['mixture_components'])
+    net = cls((meta, init), lstm_dim=meta['lstm_dim'], lstm_depth=meta.get('lstm_depth', 1),
+              proposal_mixture_components=meta['mixture_components'])
     net._init_layers_observe_embedding(meta['observe_embeddings'])
     net._init_layers()
     net._layers_initialized = True

@@ -40,7 +40,8 @@ from pyprob.nn import InferenceNetworkFeedForward, InferenceNetworkLSTM  # noqa:
 torch.set_num_threads(2)
 LSTM_DIM, BATCH, ITERATIONS, PARTICLES = 32, 32, 12, 48
 EMB = {'obs0': {'dim': 16}, 'obs1': {'dim': 16}}
-OBSERVE = {'gum': {'obs0': 8.0, 'obs1': 9.0}, 'gumm': {'obs0': 4.0, 'obs1': 5.0}, 'ffcat': {'obs0': 1.0, 'obs1': 1.5}}
+OBSERVE = {'gum': {'obs0': 8.0, 'obs1': 9.0}, 'gumm': {'obs0': 4.0, 'obs1': 5.0}, 'ffcat': {'obs0': 1.0, 'obs1': 1.5},
+           'gumm2': {'obs0': 6.0, 'obs1': 7.0}}
 
 
 class GaussianWithUnknownMean(Model):
@@ -99,7 +100,7 @@ def dist_params(d):
     raise ValueError(d.name)
 
 
-def record(case, program, seed, network='lstm'):
+def record(case, program, seed, network='lstm', lstm_depth=1):
     rec = dict(created={}, batches=[], losses=[], addresses=[], dist_names=[])
     arrays = {}
     state = dict(iteration=-1, known=[])
@@ -163,7 +164,7 @@ def record(case, program, seed, network='lstm'):
             warnings.simplefilter('ignore')
             model.learn_inference_network(num_traces=ITERATIONS * BATCH, batch_size=BATCH, observe_embeddings=EMB,
                                           inference_network=InferenceNetwork.LSTM if network == 'lstm' else InferenceNetwork.FEEDFORWARD,
-                                          lstm_dim=LSTM_DIM, learning_rate_init=1e-3)
+                                          lstm_dim=LSTM_DIM, lstm_depth=lstm_depth, learning_rate_init=1e-3)
     finally:
         setattr(M, slot, stock)
     net = model._inference_network
@@ -199,7 +200,7 @@ def record(case, program, seed, network='lstm'):
     arrays.update(is_trace_len=np.asarray(is_len, np.int32), is_addr_idx=np.asarray(is_addr, np.int32),
                   is_values=np.asarray(is_val, np.float64), is_prior=np.asarray(is_prior, np.float64),
                   is_logq=np.asarray(is_logq, np.float64), is_lw=np.asarray(is_lw, np.float64), is_result=np.asarray(is_result, np.float64))
-    meta = dict(case=case, network=network, lstm_dim=LSTM_DIM, mixture_components=10, batch_size=BATCH, iterations=ITERATIONS,
+    meta = dict(case=case, network=network, lstm_dim=LSTM_DIM, lstm_depth=lstm_depth, mixture_components=10, batch_size=BATCH, iterations=ITERATIONS,
                 observe_embeddings=EMB, obs_names=list(EMB), observe=observe, learning_rate=1e-3, weight_decay=0.0, optimizer='ADAM',
                 created=rec['created'], losses=rec['losses'], addresses=rec['addresses'], dist_names=rec['dist_names'],
                 param_order=names, exp_avg_watch=watch, history_num_params=net._history_num_params,
@@ -214,7 +215,8 @@ def record(case, program, seed, network='lstm'):
 
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for case, program, seed, network in (('gum', GaussianWithUnknownMean, 5, 'lstm'), ('gumm', GaussianWithUnknownMeanMarsaglia, 7, 'lstm'),
-                                         ('ffcat', CategoricalThenNormal, 9, 'feedforward')):
+    for case, program, seed, network, depth in (('gum', GaussianWithUnknownMean, 5, 'lstm', 1), ('gumm', GaussianWithUnknownMeanMarsaglia, 7, 'lstm', 1),
+                                                ('ffcat', CategoricalThenNormal, 9, 'feedforward', 1),
+                                                ('gumm2', GaussianWithUnknownMeanMarsaglia, 11, 'lstm', 2)):      # nn.LSTM(I, 32, 2)
         if not only or case in only:
-            record(case, program, seed, network)
+            record(case, program, seed, network, depth)

@@ -12,7 +12,7 @@ def _factory(spec, device):
     return oracle_ops.CpuBufferEngine(spec)
 
 
-@pytest.mark.parametrize('case', ['gum', 'gumm', 'ffcat'])
+@pytest.mark.parametrize('case', ['gum', 'gumm', 'ffcat', 'gumm2'])
 def test_recorded_training_session_through_the_mixin(case):
     net, meta, arrays = check_training_session(case, 'cpu', _factory)
     clone = check_pickle_roundtrip(net, meta, arrays)

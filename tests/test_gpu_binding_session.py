@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 
-@pytest.mark.parametrize('case', ['gum', 'gumm', 'ffcat'])
+@pytest.mark.parametrize('case', ['gum', 'gumm', 'ffcat', 'gumm2'])
 def test_recorded_training_session_through_the_mixin_on_the_device(case):
     net, meta, arrays = check_training_session(case, 'cuda:0')
     assert net._hip_engine.params.is_cuda and all(p.is_cuda for p in net.parameters())
