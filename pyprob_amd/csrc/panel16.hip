@@ -169,7 +169,13 @@ struct FragPtrs {
 };
 
 // KIND: head kind (0 Normal mixture, 1 TruncatedNormal mixture in a Uniform prior, 2 Poisson head), kernels.hip.
-template <int HH_, int KIND, bool OBS>
+// FLAGS (PP_PANEL_HANDOFF=flag, A/B of the hand-off protocol INSIDE this kernel; default: the {value, tag} granules of handoff.hpp):
+// the partial sums cross as 4-byte payloads - the first half of a workgroup's slot of a.xz / a.xd - behind ONE flag word per producer
+// wave (s_waitcnt vmcnt(0), then a relaxed system-scope store of the step's tag; the flag words lie in the second half of the
+// workgroup's xz slot: [0, 8) the tile sums of phase 2, [8, 12) the last tile's elements, [16, 24) the dX sums). A consumer wave
+// polls the flags of the partner waves of ITS index (they wrote what it needs), then loads the payloads: half the bytes, two
+// dependent round trips instead of one (tools/micro/handoff_probe.hip: +0.2 us median per exchange in isolation).
+template <int HH_, int KIND, bool OBS, bool FLAGS = false>
 __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, const PanelObs oin) {
     using T = P16<HH_>;
     constexpr int HH = T::HH, UT = T::UT, UTW = T::UTW, NT = T::NT, TPW = T::TPW, ZK = T::ZK, ZT = T::ZT, PH = T::PH, PZ = T::PZ;
@@ -187,6 +193,28 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
     const int hid = a.hid, n_out = a.n_out, K = a.K;
     const int ut0 = UTW * (8 * q + wave);                 // this wave's first unit tile (it owns UTW consecutive ones)
     const int epoch = *a.epoch;
+    auto put32 = [](float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto get32 = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto flag_set = [&](unsigned* f) {      // (the whole wave: its payload stores are acknowledged before the flag leaves)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(f, gtag(epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    auto flags_wait = [&](const unsigned* f0, const unsigned* f1, const unsigned* f2) {
+        const unsigned tag = gtag(epoch);
+        int spins = 0;
+        while (true) {
+            const unsigned x0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned x1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned x2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (x0 == tag && x1 == tag && x2 == tag) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 20)) __builtin_trap();
+        }
+    };
+    // (flag words of workgroup (panel, quarter): behind the PR * ZK payload floats of its xz slot)
+    auto flags_of = [&](int quarter) {
+        return reinterpret_cast<unsigned*>(reinterpret_cast<float*>(a.xz + (int64_t)(panel * SS + quarter) * (PR * ZK)) + PR * ZK);
+    };
     float* const sE = smem + T::L_E;
     float* const sH = smem + T::L_H;
     float* const sZ = smem + T::L_Z;
@@ -320,12 +348,17 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
         P16_STAMP(4);
         // the partial sums leave for the three partner workgroups: {value, tag} granules [panel][quarter][row][ZK]
         unsigned long long* const xz_own = a.xz + (int64_t)(panel * SS + q) * (PR * ZK);
+        float* const xzf_own = reinterpret_cast<float*>(xz_own);      // FLAGS: [row][ZK] payloads
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             sT[(wave * PR + 4 * g + i) * 16 + c] = acc[TPW][i];
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) gput(xz_own + (4 * g + i) * ZK + 16 * (wave + 8 * t) + c, acc[t][i], epoch);
+            for (int t = 0; t < TPW; ++t) {
+                if constexpr (FLAGS) put32(xzf_own + (4 * g + i) * ZK + 16 * (wave + 8 * t) + c, acc[t][i]);
+                else gput(xz_own + (4 * g + i) * ZK + 16 * (wave + 8 * t) + c, acc[t][i], epoch);
+            }
         }
+        if constexpr (FLAGS) flag_set(flags_of(q) + wave);
         __syncthreads();     // the last tile's eight partial tiles
         // the last tile (the K split over the waves): one element per thread of the first four waves - sum of the eight partial
         // tiles, published like the others; its partner sums ride in the first batch of loads below
@@ -334,7 +367,11 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
         if (tid < 256) {
 #pragma unroll
             for (int w = 0; w < NWV; ++w) own16 += sT[(w * PR + er) * 16 + ec];
-            gput(xz_own + er * ZK + ZT + ec, own16, epoch);
+            if constexpr (FLAGS) put32(xzf_own + er * ZK + ZT + ec, own16);
+            else gput(xz_own + er * ZK + ZT + ec, own16, epoch);
+        }
+        if constexpr (FLAGS) {
+            if (wave < 4) flag_set(flags_of(q) + 8 + wave);      // (tid < 256: the first four waves)
         }
         P16_STAMP(5);
         // the three partners' partial sums, two tiles (+ the last tile's element) per batch: every granule load of a batch is in
@@ -351,12 +388,30 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
             const float v3 = q == 3 ? own : x2;
             return ((v0 + v1) + v2) + v3;
         };
+        if constexpr (FLAGS) {      // the partner waves of this wave's index have published everything the batches below load
+            const int q0 = q == 0 ? 1 : 0, q1 = q <= 1 ? 2 : 1, q2 = q <= 2 ? 3 : 2;
+            flags_wait(flags_of(q0) + wave, flags_of(q1) + wave, flags_of(q2) + wave);
+            if (wave < 4) flags_wait(flags_of(q0) + 8 + wave, flags_of(q1) + 8 + wave, flags_of(q2) + 8 + wave);
+        }
         static_for<0, TPW / 2>([&](auto BB) {
             constexpr int bt = 2 * decltype(BB)::value;       // tiles bt and bt + 1 of the wave
             // (waves 4..7 and the later batches have no element of the last tile: a duplicate of a granule waited for anyway)
             const int o16 = (bt == 0 && tid < 256) ? er * ZK + ZT + ec : (4 * g) * ZK + 16 * (wave + 8 * bt) + c;
             float xs[3][9];
             int spins = 0;
+            if constexpr (FLAGS) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const float* pf = reinterpret_cast<const float*>(pb[s]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ro = (4 * g + i) * ZK + c;
+                        xs[s][i] = get32(pf + ro + 16 * (wave + 8 * bt));
+                        xs[s][4 + i] = get32(pf + ro + 16 * (wave + 8 * (bt + 1)));
+                    }
+                    xs[s][8] = get32(pf + o16);
+                }
+            } else
             while (true) {
                 unsigned long long x[3][9];
 #pragma unroll
@@ -682,13 +737,23 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
             float sum = 0.0f;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) sum += pr[w * (PR * PX)];
-            gput(xd_own + r * EE + col, sum, epoch);
+            if constexpr (FLAGS) put32(reinterpret_cast<float*>(xd_own) + r * EE + col, sum);
+            else gput(xd_own + r * EE + col, sum, epoch);
             if ((r >> 2) == q) { mine = sum; myrow = r; }
         }
-        if (myrow >= 0) {
+        if constexpr (FLAGS) flag_set(flags_of(q) + 16 + wave);
+        if (myrow >= 0) {      // (wave-uniform: the four waves whose row r = wave (+ 8) lies in this workgroup's quarter)
             const unsigned tag = gtag(epoch);
             float xs[3];
             int spins = 0;
+            if constexpr (FLAGS) {      // element (myrow, col) of a partner was written by ITS wave of this index
+                const int q0 = q == 0 ? 1 : 0, q1 = q <= 1 ? 2 : 1, q2 = q <= 2 ? 3 : 2;
+                flags_wait(flags_of(q0) + 16 + wave, flags_of(q1) + 16 + wave, flags_of(q2) + 16 + wave);
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    xs[s] = get32(reinterpret_cast<const float*>(a.xd + (int64_t)(panel * SS + (s + (s >= q ? 1 : 0))) * (PR * EE)) + myrow * EE + col);
+                (void)tag; (void)spins;
+            } else
             while (true) {
                 unsigned long long x[3];
 #pragma unroll
@@ -784,12 +849,12 @@ __global__ __launch_bounds__(512) void panel16_kernel(const Panel16Args ain, con
 #undef P16_ISSUE
 }
 
-template <int HH_, int KIND, bool OBS>
+template <int HH_, int KIND, bool OBS, bool FLAGS = false>
 static int panel16_launch(const Panel16Args& a, const PanelObs& po, hipStream_t st) {
     constexpr size_t lds = (size_t)P16<HH_>::L_END * sizeof(float);
     static thread_local bool configured = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)panel16_kernel<HH_, KIND, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)panel16_kernel<HH_, KIND, OBS, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("panel16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return (int)e;
@@ -797,7 +862,7 @@ static int panel16_launch(const Panel16Args& a, const PanelObs& po, hipStream_t 
         configured = true;
     }
     const int panels = cdiv(a.a.B, PR);
-    hipLaunchKernelGGL((panel16_kernel<HH_, KIND, OBS>), dim3(8 * SS * cdiv(panels, 8)), dim3(512), lds, st, a, po);
+    hipLaunchKernelGGL((panel16_kernel<HH_, KIND, OBS, FLAGS>), dim3(8 * SS * cdiv(panels, 8)), dim3(512), lds, st, a, po);
     return 0;
 }
 
@@ -854,10 +919,15 @@ int panel16(int kind, const Panel16Args& a, hipStream_t st, const PanelObs* obs)
                  "panel16: bad leading dimensions or missing buffers");
     if (obs) PP_CHECK_ARG(panel16_obs_ok(obs->a), "panel16: the observe-embedding tail does not fit");
     static const PanelObs none{};
-#define PP_P16_GO(HH_, KIND)                                                          \
-    do {                                                                              \
-        if (obs) PP_TRY((panel16_launch<HH_, KIND, true>(a, *obs, st)));              \
-        else PP_TRY((panel16_launch<HH_, KIND, false>(a, none, st)));                 \
+    // PP_PANEL_HANDOFF=flag (read per call: the A/B tests flip it inside one process): 4-byte payloads behind one flag per producer
+    // wave instead of {value, tag} granules - the kernel with the observe-embedding tail, H = 512 only (the benchmarked instantiations)
+    const char* hv = getenv("PP_PANEL_HANDOFF");
+    const bool flags = hv && hv[0] == 'f' && obs && p.H == 512;
+#define PP_P16_GO(HH_, KIND)                                                                       \
+    do {                                                                                           \
+        if (obs && flags && HH_ == 512) PP_TRY((panel16_launch<512, KIND, true, true>(a, *obs, st)));  \
+        else if (obs) PP_TRY((panel16_launch<HH_, KIND, true>(a, *obs, st)));                      \
+        else PP_TRY((panel16_launch<HH_, KIND, false>(a, none, st)));                              \
     } while (0)
 #define PP_P16_KIND(HH_)                                                  \
     do {                                                                  \

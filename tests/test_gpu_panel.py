@@ -115,12 +115,14 @@ def tile_run(tmp_path_factory):
     return _run(tmp_path_factory.mktemp('tiles'), 'tiles', PP_PANEL='0')
 
 
-@pytest.mark.parametrize('mode', ['2', '1'], ids=['rows16', 'rows8'])
+@pytest.mark.parametrize('mode', ['2', '1', '2flag'], ids=['rows16', 'rows8', 'rows16_flag_handoff'])
 def test_panel_kernel_equals_the_tile_path(tmp_path, tile_run, mode):
     """PP_PANEL=2 (default): four workgroups per 16-row panel on v_mfma_f32_16x16x4_f32 with fragment-image weight streams
     (csrc/panel16.hip; batches of more than 2 048 rows too); PP_PANEL=1: two workgroups per 8-row panel (csrc/panel.hip).
     Partial sums cross between a panel's workgroups through memory in both."""
-    panel = _run(tmp_path, 'panel', PP_PANEL=mode)
+    # (2flag: PP_PANEL_HANDOFF=flag - the 16-row kernel's partial sums as 4-byte payloads behind one flag word per producer wave
+    # instead of {value, tag} granules, csrc/panel16.hip FLAGS: the same sums in the same order)
+    panel = _run(tmp_path, 'panel', PP_PANEL=mode[0], **({'PP_PANEL_HANDOFF': 'flag'} if mode.endswith('flag') else {}))
     tiles = tile_run
     # a run of 48 Adam steps: both paths accumulate with float atomics and the panel's cell runs on v_exp_f32 / v_rcp_f32, so
     # the trajectories separate slowly (Adam turns last-bit differences of near-zero gradients into steps of +-lr): the first

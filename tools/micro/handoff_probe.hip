@@ -24,7 +24,7 @@ __device__ __forceinline__ unsigned gtag(int epoch) { return 0x7FC00001u + ((uns
 
 template <int SCHEME>
 __global__ __launch_bounds__(NT) void exchange_kernel(unsigned long long* gran /*[WGS][NV][NT]*/, float* pay /*[WGS][NV][NT]*/,
-                                                      unsigned* flags /*[WGS][8]*/, int epoch0, float* sink, long long* cyc /*[WGS][EXCH]*/) {
+                                                      unsigned* flags /*[WGS][8]*/, int epoch0, float* sink, long long* cyc /*[WGS][EXCH]*/, float* check /*[WGS][NT]*/) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const int q = (b >> 3) & 3, panel = (b & 7) + 8 * (b >> 5);
@@ -102,21 +102,22 @@ __global__ __launch_bounds__(NT) void exchange_kernel(unsigned long long* gran /
         for (int i = 0; i < NV; ++i) total += v[i];
     }
     if (total == 123.456f) sink[0] = total;
+    check[(size_t)b * NT + tid] = total;      // (both schemes run the same arithmetic in the same order: bit-identical sums)
 }
 
 template <int SCHEME>
-static void run(const char* name, unsigned long long* gran, float* pay, unsigned* flags, float* sink, long long* cyc, int& epoch) {
+static double run(const char* name, unsigned long long* gran, float* pay, unsigned* flags, float* sink, long long* cyc, int& epoch, float* check) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int w = 0; w < 3; ++w) {
-        hipLaunchKernelGGL(exchange_kernel<SCHEME>, dim3(WGS), dim3(NT), 0, 0, gran, pay, flags, epoch, sink, cyc);
+        hipLaunchKernelGGL(exchange_kernel<SCHEME>, dim3(WGS), dim3(NT), 0, 0, gran, pay, flags, epoch, sink, cyc, check);
         epoch += EXCH;
     }
     hipDeviceSynchronize();
     const int reps = 20;
     hipEventRecord(e0, 0);
     for (int r = 0; r < reps; ++r) {
-        hipLaunchKernelGGL(exchange_kernel<SCHEME>, dim3(WGS), dim3(NT), 0, 0, gran, pay, flags, epoch, sink, cyc);
+        hipLaunchKernelGGL(exchange_kernel<SCHEME>, dim3(WGS), dim3(NT), 0, 0, gran, pay, flags, epoch, sink, cyc, check);
         epoch += EXCH;
     }
     hipEventRecord(e1, 0);
@@ -134,6 +135,11 @@ static void run(const char* name, unsigned long long* gran, float* pay, unsigned
            "exchange (incl. the ~1 us delay) | %.2f MB written per exchange\n",
            name, s[s.size() / 2], s[s.size() * 9 / 10], s[s.size() * 99 / 100], ms * 1e3 / (reps * EXCH), bytes / 1e6);
     hipEventDestroy(e0); hipEventDestroy(e1);
+    std::vector<float> hc((size_t)WGS * NT);
+    hipMemcpy(hc.data(), check, hc.size() * sizeof(float), hipMemcpyDeviceToHost);
+    double sum = 0.0;
+    for (float x : hc) sum += (double)x;
+    return sum;
 }
 
 int main() {
@@ -146,10 +152,13 @@ int main() {
     hipMemset(gran, 0, (size_t)2 * WGS * NV * NT * 8);
     hipMemset(pay, 0, (size_t)2 * WGS * NV * NT * 4);
     hipMemset(flags, 0, 2 * WGS * 8 * 4);
+    float* check;
+    hipMalloc(&check, (size_t)WGS * NT * 4);
     int epoch = 1;
     for (int round = 0; round < 2; ++round) {
-        run<0>("A {value, tag} granules", gran, pay, flags, sink, cyc, epoch);
-        run<1>("B payload + flag per wave", gran, pay, flags, sink, cyc, epoch);
+        const double ca = run<0>("A {value, tag} granules", gran, pay, flags, sink, cyc, epoch, check);
+        const double cb = run<1>("B payload + flag per wave", gran, pay, flags, sink, cyc, epoch, check);
+        printf("checksum of the last launch's values: A %.9e  B %.9e  %s\n", ca, cb, ca == cb ? "(identical)" : "(DIFFERENT)");
     }
     return 0;
 }
