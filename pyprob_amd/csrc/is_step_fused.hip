@@ -148,26 +148,35 @@ __global__ __launch_bounds__(256) void is_prep_kernel(const PrepArgs a) {
         return;
     }
     // ---- bias row: b_ih + b_hh + W_ih x_shared (sample-embedding columns left out) [+ W_hh h0] ----
+    // (the input row passes through LDS in chunks of 1 024 columns: any lstm_in - pyprob's default observe embedding is 256 wide
+    // per observable; one chunk, i.e. the same order of additions as before, up to 1 024)
     const int bb = blockIdx.x - a.img_blocks;
     const int c1 = a.d.e_obs, c2 = c1 + a.d.smp;
-    for (int k = tid; k < a.I; k += 256) {
-        float x;
-        if (k < c1) x = a.e_obs_vec[k];
-        else if (k < c2) x = 0.0f;
-        else x = gather_embedding_elem(a.d, a.P, a.at, k, a.prev_addr, 0.0f, a.addr_id);
-        sx[k] = x;
-    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int n = bb * 4 + wave;
+    const bool own = n < 4 * H;
+    const float* wi = a.P + a.w_ih + (int64_t)(own ? n : 0) * a.I;
+    float acc = 0.0f;
     if (a.h0)
         for (int k = tid; k < H; k += 256) sx[1024 + k] = a.h0[k];
     if (bb == 0 && a.c0)
         for (int k = tid; k < H; k += 256) a.c0_copy[k] = a.c0[k];
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    const int n = bb * 4 + wave;
-    if (n >= 4 * H) return;
-    const float* wi = a.P + a.w_ih + (int64_t)n * a.I;
-    float acc = 0.0f;
-    for (int k = lane; k < a.I; k += 64) acc += wi[k] * sx[k];
+    for (int base = 0; base < a.I; base += 1024) {
+        const int cnt = min(1024, a.I - base);
+        if (base) __syncthreads();      // the previous chunk has been consumed
+        for (int kk = tid; kk < cnt; kk += 256) {
+            const int k = base + kk;
+            float x;
+            if (k < c1) x = a.e_obs_vec[k];
+            else if (k < c2) x = 0.0f;
+            else x = gather_embedding_elem(a.d, a.P, a.at, k, a.prev_addr, 0.0f, a.addr_id);
+            sx[kk] = x;
+        }
+        __syncthreads();
+        if (own)
+            for (int kk = lane; kk < cnt; kk += 64) acc += wi[base + kk] * sx[kk];
+    }
+    if (!own) return;
     if (a.h0) {
         const float* wh = a.P + a.w_hh + (int64_t)n * H;
         for (int k = lane; k < H; k += 64) acc += wh[k] * sx[1024 + k];
@@ -817,7 +826,7 @@ bool is_step_fused_supported(const pp_net* net, int addr_id) {
     if (is_step_small_supported(net, addr_id)) return true;
     if (!net || net->lstm_dim == 0 || std::max(1, (int)net->lstm_depth) != 1) return false;
     if (net->lstm_dim != 256 && net->lstm_dim != 512 && net->lstm_dim != 1024) return false;
-    if (net->smp_dim < 1 || net->smp_dim > 8 || net->lstm_in > 1024 || !net->addr_table) return false;
+    if (net->smp_dim < 1 || net->smp_dim > 8 || !net->addr_table) return false;
     if (addr_id < 0 || addr_id >= net->n_addr) return false;
     const pp_addr& ad = net->addrs[addr_id];
     if (ad.n_out < 1 || ad.n_out > 32 || ad.hid < 1) return false;
@@ -831,7 +840,7 @@ bool is_step_fused_supported(const pp_net* net, int addr_id) {
 
 bool is_lstm_wide_supported(const pp_net* net) {
     if (!net || net->lstm_dim != 1024 || std::max(1, (int)net->lstm_depth) != 1) return false;
-    return net->smp_dim >= 1 && net->smp_dim <= 8 && net->lstm_in <= 1024 && net->addr_table;
+    return net->smp_dim >= 1 && net->smp_dim <= 8 && net->addr_table;
 }
 
 void is_fused_carve_sizes(const pp_net* net, IsFusedBuffers& f) {

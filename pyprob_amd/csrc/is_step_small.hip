@@ -118,27 +118,32 @@ __global__ __launch_bounds__(256) void is_small_prep_kernel(const SmallPrepArgs 
     //      shared previous state: + W_hh_l h0_l (every particle's recurrent product is this one row) ----
     const int bb = blockIdx.x - a.img_blocks;
     const int l = bb / H, nb = bb - l * H;      // H blocks of four gate columns per layer
-    if (l == 0) {
-        const int c1 = a.d.e_obs, c2 = c1 + a.d.smp;
-        for (int k = tid; k < a.I; k += 256) {
-            float x;
-            if (k < c1) x = a.e_obs_vec[k];
-            else if (k < c2) x = 0.0f;
-            else x = gather_embedding_elem(a.d, a.P, a.at, k, a.prev_addr, 0.0f, a.addr_id);
-            sx[k] = x;
-        }
-    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int n = nb * 4 + wave;
+    float acc = 0.0f;
     if (a.h0)
         for (int k = tid; k < H; k += 256) sx[1024 + k] = a.h0[l * a.layer_stride + k];
     if (nb == 0 && a.c0)
         for (int k = tid; k < H; k += 256) a.c0_copy[l * H + k] = a.c0[l * a.layer_stride + k];
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    const int n = nb * 4 + wave;
-    float acc = 0.0f;
-    if (l == 0) {
+    if (l == 0) {      // (the input row in chunks of 1 024 columns: any lstm_in)
+        const int c1 = a.d.e_obs, c2 = c1 + a.d.smp;
         const float* wi = a.P + a.w_ih[0] + (int64_t)n * a.I;
-        for (int k = lane; k < a.I; k += 64) acc += wi[k] * sx[k];
+        for (int base = 0; base < a.I; base += 1024) {
+            const int cnt = min(1024, a.I - base);
+            if (base) __syncthreads();
+            for (int kk = tid; kk < cnt; kk += 256) {
+                const int k = base + kk;
+                float x;
+                if (k < c1) x = a.e_obs_vec[k];
+                else if (k < c2) x = 0.0f;
+                else x = gather_embedding_elem(a.d, a.P, a.at, k, a.prev_addr, 0.0f, a.addr_id);
+                sx[kk] = x;
+            }
+            __syncthreads();
+            for (int kk = lane; kk < cnt; kk += 64) acc += wi[base + kk] * sx[kk];
+        }
+    } else {
+        __syncthreads();
     }
     if (a.h0) {
         const float* wh = a.P + a.w_hh[l] + (int64_t)n * H;
@@ -483,7 +488,7 @@ bool is_small_network(const pp_net* net) {
 bool is_step_small_supported(const pp_net* net, int addr_id) {
     if (!is_small_network(net)) return false;
     const int H = net->lstm_dim, L = std::max(1, (int)net->lstm_depth);
-    if (net->smp_dim < 1 || net->smp_dim > 8 || net->lstm_in > 1024 || !net->addr_table) return false;
+    if (net->smp_dim < 1 || net->smp_dim > 8 || !net->addr_table) return false;
     if (addr_id < 0 || addr_id >= net->n_addr) return false;
     const pp_addr& ad = net->addrs[addr_id];
     if (ad.n_out < 1 || ad.n_out > 32 || ad.hid < 1 || ad.hid > 512) return false;

@@ -29,10 +29,10 @@ def _force_fused(monkeypatch, request):
     return request.param
 
 
-def _engine(H, seed=0, depth=1):
+def _engine(H, seed=0, depth=1, emb=None):
     from pyprob_amd.engine import ICEngine
     from pyprob_amd.is_engine import ISRunner
-    spec = NetSpec(EMB, lstm_dim=H, lstm_depth=depth)
+    spec = NetSpec(emb or EMB, lstm_dim=H, lstm_depth=depth)
     eng = ICEngine(spec, device='cuda:0', seed=seed)
     eng.add_addresses(ADDRS)
     rng = np.random.default_rng(seed + 1)
@@ -47,10 +47,10 @@ def _engine(H, seed=0, depth=1):
     return eng, run, sd
 
 
-def _oracle_statement(sd, H, observe, prev, cur, prev_val, h0, c0, values, prior, depth=1):
+def _oracle_statement(sd, H, observe, prev, cur, prev_val, h0, c0, values, prior, depth=1, emb=None):
     """One `_infer_step` for n particles in float64: returns (h, c, log q, head outputs y); depth > 1: (h0, c0) and the returned
     states are [depth, n, H] (nn.LSTM(I, H, depth): layer k reads the new hidden rows of layer k - 1)."""
-    net = O.Net(sd, list(EMB), K=10)
+    net = O.Net(sd, list(emb or EMB), K=10)
     a_prev, d_prev = prev
     a_cur, d_cur = cur
     n = len(prev_val)
@@ -458,3 +458,40 @@ def test_the_golden_networks_of_the_reference_take_the_fused_statement():
         assert len(eng.spec.addresses) >= 1
         for a in range(len(eng.spec.addresses)):
             assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), a, 1000) == 1, (case, a)
+
+
+WIDE_EMB = {'obs0': {'dim': 700}, 'obs1': {'dim': 500}}      # lstm_in = 1 200 + 4 + 2 (8 + 64) = 1 348
+
+
+@pytest.mark.parametrize('H,depth', [(512, 1), (64, 2)])
+def test_fused_statement_with_a_wide_observe_embedding(H, depth):
+    """LSTM inputs wider than 1 024 columns (pyprob's default observe embedding is 256 wide per observable): the per-call bias row
+    W_ih x_shared is accumulated through LDS in chunks of 1 024 columns - the fused statement kernels take any lstm_in."""
+    from pyprob_amd.ops import ops
+    n = 700
+    eng, run, sd = _engine(H, seed=2, depth=depth, emb=WIDE_EMB)
+    assert eng.spec.lstm_in > 1024
+    prev, cur = ('a_normal', 'Normal'), ('a_uniform', 'Uniform')
+    assert eng.lib.pp_is_step_fused_supported(C.byref(eng.net), _ids(eng, cur[0]), n) == 1
+    rng = np.random.default_rng(5)
+    h0 = (0.5 * rng.standard_normal((depth, n, H))).astype(np.float32).clip(-0.99, 0.99)
+    c0 = rng.standard_normal((depth, n, H)).astype(np.float32)
+    pv = _prev_values(prev[1], n, rng)
+    prior = _prior_for(cur[1], n, rng)
+    dev = eng.device
+    h = torch.from_numpy(h0.copy()).to(dev).contiguous()
+    c = torch.from_numpy(c0.copy()).to(dev).contiguous()
+    run._ensure_ws(n)
+    value, logq = ops.is_step(eng.params, run.ws, eng.net_handle, _ids(eng, cur[0]), _ids(eng, prev[0]), n, run.e_obs,
+                              torch.from_numpy(pv).to(dev), torch.from_numpy(prior).to(dev), h, c, n, None, 1234, 0)
+    torch.cuda.synchronize()
+    v = value.cpu().numpy()
+    o_h0, o_c0 = (h0[0], c0[0]) if depth == 1 else (h0, c0)
+    href, cref, lq_ref, _ = _oracle_statement(sd, H, [8.0, 9.0], prev, cur, pv, o_h0, o_c0, v.astype(np.float64), prior.astype(np.float64),
+                                              depth=depth, emb=WIDE_EMB)
+    # (1 348 input terms per gate pre-activation: twice the bars of the 212-wide input)
+    assert np.abs(h.cpu().numpy().reshape(np.shape(href)) - href).max() < 8e-6 * depth
+    assert np.abs(c.cpu().numpy().reshape(np.shape(cref)) - cref).max() < 4e-5 * depth
+    ok = np.isfinite(lq_ref)
+    err = np.abs(logq.cpu().numpy()[ok] - lq_ref[ok]) / np.maximum(1.0, np.abs(lq_ref[ok]))
+    assert ok.mean() > 0.99 and err.max() < 1e-4, err.max()
