@@ -1,7 +1,7 @@
 # Second GPU call of a round's measurement set (the first: tools/final_round.sh <tag>): bash tools/final_round_b.sh <tag>
 #   the ragged step (--workload train_gumm): kernel stats, launch sequence, PMC FETCH / WRITE -> profiles/r06_gumm_traffic.json, its
 #   bench line, the dropin workload's line; then the SQ counter passes of the training step -> profiles/r06_mfma_busy.json
-TAG=${1:-r07z}
+TAG=${1:-r07A}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fg_ks
